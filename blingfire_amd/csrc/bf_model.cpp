@@ -1,0 +1,687 @@
+// bf_model.cpp -- see bf_model.h.  Host only (no HIP): parse the .bin, decode the automata,
+// build the displacement-packed tables and code-point maps the kernels consume.
+#include "bf_model.h"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <functional>
+#include <map>
+#include <unordered_map>
+
+namespace bfa {
+
+namespace {
+
+struct Reader {
+    const uint8_t *p; size_t n;
+    bool ok(size_t off, size_t len) const { return off <= n && len <= n - off; }
+    int32_t i32(size_t off) const { int32_t v = 0; if (ok(off, 4)) memcpy(&v, p + off, 4); return v; }
+    uint32_t u32(size_t off) const { uint32_t v = 0; if (ok(off, 4)) memcpy(&v, p + off, 4); return v; }
+    uint32_t le(size_t off, int size) const {  // little-endian unsigned of 1/2/4 bytes
+        uint32_t v = 0; if (ok(off, (size_t)size)) memcpy(&v, p + off, (size_t)size); return v;
+    }
+    int32_t sle(size_t off, int size) const {  // signed little-endian of 1/2/4 bytes
+        if (!ok(off, (size_t)size)) return 0;
+        if (size == 1) return (int8_t)p[off];
+        if (size == 2) { int16_t v; memcpy(&v, p + off, 2); return v; }
+        int32_t v; memcpy(&v, p + off, 4); return v;
+    }
+    uint32_t be(size_t off, int size) const {  // big-endian unsigned of 1..4 bytes
+        uint32_t v = 0; if (!ok(off, (size_t)size)) return 0;
+        for (int i = 0; i < size; ++i) v = (v << 8) | p[off + i];
+        return v;
+    }
+};
+
+// Length-prefixed int arrays (format: reference FAChains_pack_triv.h:81-163): header {SizeOfValue, MaxCount}
+struct Chains {
+    Reader r; int sov = 4;
+    void set(const Reader &rr) { r = rr; sov = r.i32(0); }
+    bool valid() const { return sov == 1 || sov == 2 || sov == 4; }
+    int count(size_t off) const { return r.sle(off, sov); }
+    int value(size_t off, int idx) const { return r.sle(off + (size_t)sov * (1 + (size_t)idx), sov); }
+};
+
+// key -> int[] map (format: reference FAMultiMap_pack.cpp:22-53)
+struct TrivMap {
+    Reader r; uint32_t max_key = 0; int soo = 0; size_t offs = 8; Chains vals; bool set_ = false;
+    bool set(const Reader &rr) {
+        r = rr; max_key = r.u32(0); soo = (int)r.u32(4);
+        if (soo < 1 || soo > 4) return false;
+        size_t off = 8 + (size_t)soo * (1 + (size_t)max_key);
+        if (off % 4) off += 4 - off % 4;
+        if (!r.ok(off, 8)) return false;
+        vals.set(Reader{r.p + off, r.n - off});
+        set_ = vals.valid();
+        return set_;
+    }
+    bool get(int key, std::vector<int> &out) const {
+        out.clear();
+        if (!set_ || key < 0 || (uint32_t)key > max_key) return false;
+        uint32_t vo = r.be(offs + (size_t)soo * (size_t)key, soo);
+        if (vo == 0) return false;
+        int c = vals.count(vo - 1);
+        if (c < 0 || c > 4096) return false;
+        for (int i = 0; i < c; ++i) out.push_back(vals.value(vo - 1, i));
+        return true;
+    }
+};
+
+// fixed-stride key -> int[] map (format: reference FAMultiMap_pack_fixed.cpp:25-58)
+struct FixedMap {
+    Reader r; int sov = 0, max_count = 0, min_key = 0, max_key = -1; uint32_t stride = 0; bool set_ = false;
+    bool set(const Reader &rr) {
+        r = rr; sov = (int)r.u32(0); max_count = r.i32(4); min_key = r.i32(8); max_key = r.i32(12);
+        if (!(sov == 1 || sov == 2 || sov == 4) || max_count <= 0 || min_key < 0 || max_key < min_key) return false;
+        stride = (uint32_t)(max_count + 1) * (uint32_t)sov;
+        if (!r.ok(16, (size_t)stride * (size_t)(max_key - min_key + 1))) return false;
+        set_ = true; return true;
+    }
+    // returns the reference Get(Key,pValues,MaxCount=cap) count: -1 = no entry; values filled only if 0 <= count <= cap
+    int get(int key, int *out, int cap) const {
+        if (!set_ || key < min_key || key > max_key) return -1;
+        size_t off = 16 + (size_t)((uint32_t)stride * (uint32_t)(key - min_key));
+        int c = r.sle(off, sov);
+        if (c > max_count) return -1;
+        if (c >= 0 && c <= cap) for (int i = 0; i < c; ++i) out[i] = r.sle(off + (size_t)sov * (1 + (size_t)i), sov);
+        return c;
+    }
+};
+
+uint32_t crc32_update(const uint8_t *p, size_t n, uint32_t crc)
+{
+    static uint32_t table[256]; static bool init = false;
+    if (!init) {
+        for (uint32_t k = 0; k < 256; ++k) { uint32_t c = k; for (int j = 0; j < 8; ++j) c = (c & 1) ? 0xEDB88320u ^ (c >> 1) : c >> 1; table[k] = c; }
+        init = true;
+    }
+    crc = ~crc;
+    for (size_t i = 0; i < n; ++i) crc = table[(crc ^ p[i]) & 0xff] ^ (crc >> 8);
+    return ~crc;
+}
+
+bool is_boolean_param(int p)
+{   // reference FALDB.cpp:119-132
+    return p == 10 || p == PARAM_NO_TR || p == PARAM_IGNORE_CASE || p == 31 || p == 35 || p == 37 || p == 40 || p == 46 ||
+           p == PARAM_VERIFY_LDB_BIN;
+}
+
+// ---- automaton decoding (format spec: reference blingfirecompile.library/inc/FADfaPack_triv.h:27-96)
+struct DfaHeader { int dst_size = 3; int ows_offset = 0; bool remap = false; size_t initial = 0; };
+
+bool decode_dfa(const Reader &r, bool mealy, RawDfa &out, std::string &err)
+{
+    DfaHeader h;
+    size_t off = 0;
+    h.dst_size = r.i32(0); if (h.dst_size < 1 || h.dst_size > 4) h.dst_size = 3;
+    h.ows_offset = r.i32(4);
+    uint32_t iwc = r.u32(8); off = 12;
+    h.remap = (iwc & 0x80000000u) != 0;
+    iwc &= 0x7fffffffu;
+    if (iwc == 0 || (iwc & 1) || !r.ok(off, 4 * (size_t)iwc)) { err = "bad DFA alphabet header"; return false; }
+    off += 4 * (size_t)iwc;
+    out.remap = h.remap;
+    if (h.remap) {
+        if (mealy) { err = "Mealy DFA with remapped Iws is not a legal model"; return false; }
+        int sz = r.i32(off); off += 4;
+        // Iw map image (format: reference FAIwMap_pack.cpp:44-61)
+        Reader m{r.p + off, r.n - off};
+        int son = m.i32(0), ic = m.i32(4);
+        if (son < 1 || son > 4 || ic < 0 || !m.ok(8, 12 * (size_t)ic)) { err = "bad Iw map"; return false; }
+        size_t from_off = 8, to_off = 8 + 4 * (size_t)ic, data_off = 8 + 12 * (size_t)ic;
+        for (int i = 0; i < ic; ++i) {
+            int from = m.i32(from_off + 4 * (size_t)i), to = m.i32(to_off + 8 * (size_t)i), ioff = m.i32(to_off + 8 * (size_t)i + 4);
+            if (to < from || ioff < 0 || (long)to - from > 0x200000) { err = "bad Iw map interval"; return false; }
+            out.iw_from.push_back(from); out.iw_to.push_back(to);
+            std::vector<int> cls((size_t)(to - from + 1));
+            for (int k = 0; k <= to - from; ++k) {
+                uint32_t v = m.be(data_off + (size_t)ioff + (size_t)son * (size_t)k, son);
+                cls[(size_t)k] = v ? (int)v - 1 : -1;
+            }
+            out.iw_cls.push_back(std::move(cls));
+        }
+        off += (size_t)sz;
+    }
+    h.initial = off;
+
+    Chains ows;
+    if (mealy) {
+        if (h.ows_offset == 0 || !r.ok((size_t)h.ows_offset, 8)) { err = "Mealy DFA without Ows section"; return false; }
+        ows.set(Reader{r.p + h.ows_offset, r.n - (size_t)h.ows_offset});
+        if (!ows.valid()) { err = "bad Ows section"; return false; }
+    }
+
+    // BFS over states identified by byte offset
+    std::unordered_map<int, int> idx_of;
+    std::vector<int> queue;
+    auto intern = [&](int soff) -> int {
+        auto it = idx_of.find(soff);
+        if (it != idx_of.end()) return it->second;
+        int id = (int)out.state_off.size();
+        idx_of.emplace(soff, id); out.state_off.push_back(soff); queue.push_back(soff);
+        return id;
+    };
+    intern((int)h.initial);
+    out.initial = 0;
+    struct Tr { int sym, dst, ow; };
+    std::vector<std::vector<Tr>> trs;
+    const int ds = h.dst_size;
+    const uint32_t dead_mark = ds == 4 ? 0xffffffffu : ((1u << (8 * ds)) - 1);
+    size_t total_tr = 0;
+    for (size_t qi = 0; qi < queue.size(); ++qi) {
+        const int s = queue[qi];
+        if (s <= 0 || !r.ok((size_t)s, 1)) { err = "state offset out of range"; return false; }
+        const uint32_t info = r.p[s];
+        const int iw_size = (int)((info & 0x18) >> 3) + 1; // 1,2,3(unused),4
+        const int tr = (int)(info & 7), ow_code = (int)((info & 0x60) >> 5);
+        const int ow_size = ow_code == 3 ? 4 : ow_code;
+        if (iw_size == 3) { err = "unsupported IwSize 3"; return false; }
+        std::vector<Tr> list;
+        size_t p = (size_t)s + 1, ow_pos = 0;
+        auto dst_of = [&](size_t base, size_t idx) -> int {
+            uint32_t v = r.be(base + (size_t)ds * idx, ds);
+            return v == dead_mark ? DFA_DEAD_STATE : (int)v;
+        };
+        if (tr == TRS_PARA) {
+            size_t cnt = 1 + (size_t)r.le(p, iw_size); p += (size_t)iw_size;
+            size_t iws = p, dsts = p + cnt * (size_t)iw_size;
+            if (!r.ok(dsts, cnt * (size_t)ds)) { err = "truncated PARA state"; return false; }
+            for (size_t i = 0; i < cnt; ++i) list.push_back({(int)r.le(iws + i * (size_t)iw_size, iw_size), dst_of(dsts, i), (int)i});
+            ow_pos = dsts + cnt * (size_t)ds;
+        } else if (tr == TRS_IWIA) {
+            if (mealy) { err = "IWIA state in a Mealy DFA"; return false; }
+            uint32_t base = r.le(p, iw_size); p += (size_t)iw_size;
+            uint32_t mx = r.le(p, iw_size); p += (size_t)iw_size;
+            if (mx < base || mx - base > 0x200000 || !r.ok(p, (size_t)(mx - base + 1) * (size_t)ds)) { err = "bad IWIA state"; return false; }
+            for (uint32_t k = 0; k <= mx - base; ++k) {
+                int d = dst_of(p, k);
+                if (d != 0) list.push_back({(int)(base + k), d, 0});
+            }
+            ow_pos = p + (size_t)(mx - base + 1) * (size_t)ds;
+        } else if (tr == TRS_RANGE) {
+            if (mealy) { err = "RANGE state in a Mealy DFA"; return false; }
+            size_t cnt = 1 + (size_t)r.le(p, iw_size); p += (size_t)iw_size;
+            size_t froms = p, tos = p + cnt * (size_t)iw_size, dsts = tos + cnt * (size_t)iw_size;
+            if (!r.ok(dsts, cnt * (size_t)ds)) { err = "truncated RANGE state"; return false; }
+            for (size_t i = 0; i < cnt; ++i) {
+                uint32_t f = r.le(froms + i * (size_t)iw_size, iw_size), t = r.le(tos + i * (size_t)iw_size, iw_size);
+                // the reference picks the LAST range whose From <= Iw and then requires Iw <= To
+                uint32_t next_from = i + 1 < cnt ? r.le(froms + (i + 1) * (size_t)iw_size, iw_size) : 0xffffffffu;
+                if (t >= next_from) t = next_from - 1;
+                if (t < f) continue;
+                if ((uint64_t)t - f > 0x20000 || total_tr + list.size() > 8000000) { err = "RANGE state too wide to expand (unsupported packing)"; return false; }
+                int d = dst_of(dsts, i);
+                for (uint32_t k = f; k <= t; ++k) list.push_back({(int)k, d, 0});
+            }
+            ow_pos = dsts + cnt * (size_t)ds;
+        } else if (tr == TRS_IMPL) {
+            int iw = (int)r.le(p, iw_size);
+            list.push_back({iw, s + 1 + iw_size + ow_size, 0});
+            ow_pos = p + (size_t)iw_size;
+        } else if (tr == TRS_NONE) {
+            ow_pos = p;
+        } else { err = "unknown transition type"; return false; }
+
+        int state_ow = -1;
+        if (ow_code != 0) state_ow = r.sle(ow_pos, ow_size);
+        if (mealy) {
+            for (auto &t : list) {
+                if (ow_code == 0) { err = "Mealy transition without output weight"; return false; }
+                if (state_ow < 0 || !ows.r.ok((size_t)state_ow, (size_t)ows.sov)) { err = "bad Ows offset"; return false; }
+                int c = ows.count((size_t)state_ow);
+                if (t.ow >= c) { err = "Ows record shorter than the transition list"; return false; }
+                t.ow = ows.value((size_t)state_ow, t.ow);
+                if (t.ow < 0) { err = "negative Mealy output weight"; return false; }
+            }
+        }
+        for (auto &t : list) if (t.dst != DFA_DEAD_STATE) t.dst = intern(t.dst);
+        std::sort(list.begin(), list.end(), [](const Tr &a, const Tr &b) { return a.sym < b.sym; });
+        for (size_t i = 1; i < list.size(); ++i) if (list[i].sym == list[i - 1].sym) { err = "duplicate symbol in a state"; return false; }
+        total_tr += list.size();
+        trs.push_back(std::move(list));
+        out.is_final.push_back((info & 0x80) ? 1 : 0);
+        out.ow.push_back(mealy ? -1 : state_ow);
+        if (trs.size() > 4000000) { err = "automaton too large"; return false; }
+    }
+    out.tr_begin.assign(1, 0);
+    for (auto &l : trs) {
+        for (auto &t : l) { out.tr_sym.push_back(t.sym); out.tr_dst.push_back(t.dst); if (mealy) out.tr_ow.push_back(t.ow); }
+        out.tr_begin.push_back((uint32_t)out.tr_sym.size());
+    }
+    out.off_index.clear();
+    for (size_t i = 0; i < out.state_off.size(); ++i) out.off_index.push_back({out.state_off[i], (int)i});
+    std::sort(out.off_index.begin(), out.off_index.end());
+    return true;
+}
+
+// ---- displacement packing: first-fit, unique base per state
+bool pack_dfa(const RawDfa &raw, bool wide, const std::vector<int> &extra_syms, PackedDfa &out, std::string &err)
+{
+    const size_t ns = raw.state_off.size();
+    // class space
+    std::vector<int> cls_of_tr(raw.tr_sym.size());
+    if (raw.remap) {
+        int mx = -1;
+        for (auto &v : raw.iw_cls) for (int c : v) mx = std::max(mx, c);
+        for (size_t i = 0; i < raw.tr_sym.size(); ++i) { cls_of_tr[i] = raw.tr_sym[i]; mx = std::max(mx, raw.tr_sym[i]); }
+        out.nclasses = mx + 1;
+    } else {
+        std::vector<int> syms(raw.tr_sym);
+        syms.insert(syms.end(), extra_syms.begin(), extra_syms.end());
+        std::sort(syms.begin(), syms.end());
+        syms.erase(std::unique(syms.begin(), syms.end()), syms.end());
+        out.sym_of_class = syms;
+        out.nclasses = (int)syms.size();
+        for (size_t i = 0; i < raw.tr_sym.size(); ++i)
+            cls_of_tr[i] = (int)(std::lower_bound(syms.begin(), syms.end(), raw.tr_sym[i]) - syms.begin());
+    }
+    for (int c : cls_of_tr) if (c < 0) { err = "negative symbol in automaton"; return false; }
+    const uint32_t cls_limit = wide ? (uint32_t)T64_CLS_MASK : T32_CLS_MASK;
+    if ((uint32_t)out.nclasses >= cls_limit) { err = "too many symbol classes for the table entry format"; return false; }
+    out.wide = wide;
+
+    const size_t ntr = raw.tr_sym.size();
+    size_t cap = ntr + ntr / 4 + ns + (size_t)out.nclasses + 4096;
+    std::vector<int32_t> slot_state(cap, -1);   // owner state index per slot
+    std::vector<uint8_t> base_used(cap, 0);
+    std::vector<uint32_t> base(ns + 1, 0xffffffffu);
+    auto grow = [&](size_t need) {
+        if (need <= cap) return;
+        size_t nc = std::max(need + need / 8 + 1024, cap * 2);
+        slot_state.resize(nc, -1); base_used.resize(nc, 0); cap = nc;
+    };
+    std::vector<uint32_t> order(ns);
+    for (size_t i = 0; i < ns; ++i) order[i] = (uint32_t)i;
+    auto fan = [&](uint32_t s) { return raw.tr_begin[s + 1] - raw.tr_begin[s]; };
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return fan(a) > fan(b); });
+    // next_free[i]: smallest free slot >= i (union-find with path halving), so the first-fit search
+    // only ever visits free slots
+    std::vector<uint32_t> next_free(cap + 1);
+    for (size_t i = 0; i <= cap; ++i) next_free[i] = (uint32_t)i;
+    auto grow_nf = [&]() {
+        const size_t old = next_free.size();
+        if (old >= cap + 1) return;
+        next_free.resize(cap + 1);
+        for (size_t i = old; i <= cap; ++i) next_free[i] = (uint32_t)i;
+    };
+    auto find_free = [&](size_t i) -> size_t {
+        while (next_free[i] != i) { next_free[i] = next_free[next_free[i]]; i = next_free[i]; }
+        return i;
+    };
+    size_t max_slot = 0;
+    for (uint32_t s : order) {
+        const uint32_t b0 = raw.tr_begin[s], b1 = raw.tr_begin[s + 1];
+        if (b0 == b1) break;  // leaves are last
+        const size_t c0 = (size_t)cls_of_tr[b0], clast = (size_t)cls_of_tr[b1 - 1];
+        size_t f = find_free(c0);          // candidate slot for the first symbol (base >= 0)
+        size_t b;
+        for (;;) {
+            if (f + (clast - c0) + 2 >= cap) { grow(f + (clast - c0) + 2); grow_nf(); }
+            b = f - c0;
+            bool ok = !base_used[b];
+            for (uint32_t t = b0 + 1; ok && t < b1; ++t) if (slot_state[b + (size_t)cls_of_tr[t]] != -1) ok = false;
+            if (ok) break;
+            f = find_free(f + 1);
+        }
+        base[s] = (uint32_t)b; base_used[b] = 1;
+        for (uint32_t t = b0; t < b1; ++t) {
+            const size_t sl = b + (size_t)cls_of_tr[t];
+            slot_state[sl] = (int32_t)s; next_free[sl] = (uint32_t)(sl + 1);
+        }
+        max_slot = std::max(max_slot, b + clast);
+    }
+    // leaves + the synthetic dead state take unused base values (they own no slot)
+    size_t bcur = 0;
+    auto next_free_base = [&]() -> uint32_t {
+        for (;; ++bcur) { grow(bcur + 1); if (!base_used[bcur]) { base_used[bcur] = 1; return (uint32_t)bcur++; } }
+    };
+    for (uint32_t s : order) if (fan(s) == 0) base[s] = next_free_base();
+    base[ns] = next_free_base();
+    uint32_t max_base = 0;
+    for (uint32_t v : base) max_base = std::max(max_base, v);
+    const size_t table_len = std::max(max_slot + 1, (size_t)max_base + 1) + (size_t)out.nclasses + 1; // any base + any class stays in range
+    const uint64_t next_limit = wide ? (T64_NEXT_MASK + 1) : (1ull << (32 - T32_NEXT_SHIFT));
+    if (table_len >= next_limit) { err = "automaton too large for the table entry format"; return false; }
+
+    out.state_base.assign(base.begin(), base.begin() + (long)ns);
+    out.dead_base = base[ns];
+    out.initial_base = base[(size_t)raw.initial];
+    if (wide) out.t64.assign(table_len, T64_CLS_MASK); else out.t32.assign(table_len, T32_CLS_MASK);
+    for (size_t s = 0; s < ns; ++s) {
+        for (uint32_t t = raw.tr_begin[s]; t < raw.tr_begin[s + 1]; ++t) {
+            const int d = raw.tr_dst[t];
+            const uint32_t db = d == DFA_DEAD_STATE ? out.dead_base : base[(size_t)d];
+            const bool fin = d != DFA_DEAD_STATE && raw.is_final[(size_t)d];
+            const size_t slot = (size_t)base[s] + (size_t)cls_of_tr[t];
+            if (wide) {
+                uint64_t ow = raw.tr_ow.empty() ? 0 : (uint64_t)raw.tr_ow[t];
+                if (ow >= (1ull << (64 - T64_OW_SHIFT))) { err = "output weight too large for the table entry format"; return false; }
+                out.t64[slot] = (uint64_t)cls_of_tr[t] | (fin ? T64_FINAL_BIT : 0) | ((uint64_t)db << T64_NEXT_SHIFT) | (ow << T64_OW_SHIFT);
+            } else {
+                out.t32[slot] = (uint32_t)cls_of_tr[t] | (fin ? T32_FINAL_BIT : 0) | (db << T32_NEXT_SHIFT);
+            }
+        }
+    }
+    return true;
+}
+
+} // namespace
+
+int RawDfa::class_of(int iw) const
+{
+    if (!remap) return iw;
+    // last interval with from <= iw (reference FAIwMap_pack.h:72-110)
+    auto it = std::upper_bound(iw_from.begin(), iw_from.end(), iw);
+    if (it == iw_from.begin()) return -1;
+    size_t i = (size_t)(it - iw_from.begin()) - 1;
+    if (iw > iw_to[i]) return -1;
+    return iw_cls[i][(size_t)(iw - iw_from[i])];
+}
+
+int RawDfa::find_state(int off) const
+{
+    auto it = std::lower_bound(off_index.begin(), off_index.end(), std::make_pair(off, -1));
+    return (it != off_index.end() && it->first == off) ? it->second : -1;
+}
+
+void TwoLevelMap::init(uint32_t default_value)
+{
+    def = default_value;
+    l1.assign(0x1100, 0);
+    pages.assign(256, default_value);
+}
+
+void TwoLevelMap::set(int cp, uint32_t v)
+{
+    if (cp < 0 || cp > 0x10FFFF) return;
+    uint16_t &pg = l1[(size_t)(cp >> 8)];
+    if (pg == 0) {
+        if (v == def) return;
+        pg = (uint16_t)(pages.size() / 256);
+        pages.resize(pages.size() + 256, def);
+    }
+    pages[(size_t)pg * 256 + (size_t)(cp & 255)] = v;
+}
+
+long PackedDfa::step(uint32_t base, uint32_t cls, int *final_out, int *ow_out) const
+{
+    if (wide) {
+        if (cls >= T64_CLS_MASK) return -1;
+        uint64_t e = t64[(size_t)base + cls];
+        if ((e & T64_CLS_MASK) != cls) return -1;
+        if (final_out) *final_out = (e & T64_FINAL_BIT) != 0;
+        if (ow_out) *ow_out = (int)(e >> T64_OW_SHIFT);
+        return (long)((e >> T64_NEXT_SHIFT) & T64_NEXT_MASK);
+    }
+    if (cls >= T32_CLS_MASK) return -1;
+    uint32_t e = t32[(size_t)base + cls];
+    if ((e & T32_CLS_MASK) != cls) return -1;
+    if (final_out) *final_out = (e & T32_FINAL_BIT) != 0;
+    if (ow_out) *ow_out = 0;
+    return (long)(e >> T32_NEXT_SHIFT);
+}
+
+bool load_file(const char *path, std::vector<uint8_t> &out)
+{
+    FILE *f = path ? fopen(path, "rb") : nullptr;
+    if (!f) return false;
+    fseek(f, 0, SEEK_END); long sz = ftell(f); fseek(f, 0, SEEK_SET);
+    if (sz <= 0) { fclose(f); return false; }
+    out.resize((size_t)sz);
+    bool ok = fread(out.data(), 1, (size_t)sz, f) == (size_t)sz;
+    fclose(f);
+    return ok;
+}
+
+static bool fail(Model &m, const std::string &e) { m.error = e; return false; }
+
+bool build_model(Model &m, const uint8_t *img, size_t size)
+{
+    if (!img || size < 8) return fail(m, "empty model image");
+    m.image.assign(img, img + size);
+    m.image.resize(size + 16, 0);   // slack so that bounded unaligned reads at the tail are defined
+    Reader R{m.image.data(), size};
+
+    // ---- LDB container (format: reference FALDB.cpp:24-64)
+    const int count = R.i32(0);
+    if (count <= 0 || count > 3 * 64 || !R.ok(4, 4 * (size_t)count)) return fail(m, "bad LDB dump count");
+    for (int i = 0; i < count; ++i) {
+        int off = R.i32(4 + 4 * (size_t)i);
+        if (off < 0 || (size_t)off >= size) return fail(m, "bad LDB dump offset");
+        m.dump_off.push_back((size_t)off);
+    }
+    auto dump = [&](int i) -> Reader {
+        if (i < 0 || i >= count) return Reader{m.image.data(), 0};
+        size_t b = m.dump_off[(size_t)i];
+        return Reader{m.image.data() + b, size - b};
+    };
+    TrivMap conf;
+    if (!conf.set(dump(0))) return fail(m, "bad LDB configuration dump");
+    std::vector<int> vals;
+
+    // optional CRC32 verification (reference FALDB.cpp:67-116)
+    if (conf.get(FUNC_GLOBAL, vals)) {
+        for (size_t i = 0; i < vals.size(); ++i) {
+            if (vals[i] == PARAM_VERIFY_LDB_BIN) {
+                if (count < 2) return fail(m, "verify-ldb-bin without a validation dump");
+                Reader v = dump(count - 1);
+                if (v.u32(0) == 0) {
+                    uint32_t dsize = 0, crc = 0;
+                    for (int k = 0; k < count - 1; ++k) {
+                        if (m.dump_off[(size_t)k + 1] < m.dump_off[(size_t)k]) return fail(m, "Invalid LDB binary file detected.");
+                        size_t sz = m.dump_off[(size_t)k + 1] - m.dump_off[(size_t)k];
+                        dsize += (uint32_t)sz; crc = crc32_update(m.image.data() + m.dump_off[(size_t)k], sz, crc);
+                    }
+                    if (dsize != v.u32(4) || crc != v.u32(8)) return fail(m, "Invalid LDB binary file detected.");
+                }
+            } else if (!is_boolean_param(vals[i])) ++i;
+        }
+    }
+
+    // ---- [wbd] section (semantics: reference FAWbdConfKeeper.cpp:56-232)
+    if (conf.get(FUNC_WBD, vals)) {
+        m.has_wbd = true;
+        int fsm_dump = -1, acts_dump = -1, charmap_dump = -1, fsm_type = TYPE_MOORE_DFA;
+        for (size_t i = 0; i < vals.size(); ++i) {
+            const int p = vals[i];
+            if (p == PARAM_IGNORE_CASE) { m.ignore_case = true; continue; }
+            if (i + 1 >= vals.size()) return fail(m, "truncated [wbd] parameters");
+            const int v = vals[++i];
+            switch (p) {
+            case PARAM_MAP_MODE: if (v != MODE_PACK_TRIV) return fail(m, "[wbd] map mode must be triv"); break;
+            case PARAM_DEPTH: m.max_depth = v; break;
+            case PARAM_MAX_LENGTH: m.max_token_length = v; break;
+            case PARAM_FSM_TYPE: fsm_type = v; break;
+            case PARAM_FSM: fsm_dump = v; break;
+            case PARAM_MULTI_MAP: acts_dump = v; break;
+            case PARAM_CHARMAP: charmap_dump = v; break;
+            default: break;   // tag ids (word/xword/seg/ignore/punkt/eos/eop/max-tag) and act-data: unused on this path
+            }
+        }
+        if (fsm_dump >= 0) {
+            if (fsm_type != TYPE_MOORE_DFA) return fail(m, "moore-multi-dfa lexers are not on the TextToIds path (unsupported)");
+            if (m.ignore_case) return fail(m, "ignore-case lexers are not supported");
+            if (acts_dump < 0) return fail(m, "[wbd] without an action map");
+            if (m.max_depth < 0 || m.max_token_length < 0) return fail(m, "bad [wbd] limits");
+            if (!decode_dfa(dump(fsm_dump), false, m.wbd_raw, m.error)) return false;
+            if (!pack_dfa(m.wbd_raw, false, {IW_ANY, IW_L_ANCHOR, IW_R_ANCHOR, IW_EPSILON}, m.wbd, m.error)) return false;
+            auto cls_sym = [&](int iw) -> uint32_t {   // symbol -> class of the packed table
+                int c = m.wbd_raw.class_of(iw);
+                if (c < 0) return CLS_NONE;
+                if (!m.wbd_raw.remap) {
+                    auto &S = m.wbd.sym_of_class;
+                    auto it = std::lower_bound(S.begin(), S.end(), c);
+                    if (it == S.end() || *it != c) return CLS_NONE;
+                    c = (int)(it - S.begin());
+                }
+                return (uint32_t)c;
+            };
+            m.cls_any = cls_sym(IW_ANY); m.cls_l = cls_sym(IW_L_ANCHOR); m.cls_r = cls_sym(IW_R_ANCHOR);
+
+            // actions (format: reference FAMultiMap_pack.cpp; semantics FALexTools_t.h:158-202, FAWbdConfKeeper.cpp:246-314)
+            TrivMap acts;
+            if (!acts.set(dump(acts_dump))) return fail(m, "bad action map");
+            std::vector<std::vector<int>> actions;
+            std::vector<int> a;
+            int max_fn = -1;
+            for (int id = 0; acts.get(id, a); ++id) {
+                if (a.size() < 3) return fail(m, "invalid lexer action");
+                actions.push_back(a);
+                size_t i = 2;
+                for (; i < a.size(); ++i) if (a[i] == 0 && i + 1 < a.size()) { ++i; break; }
+                for (; i < a.size(); ++i) { if (a[i] < 0) return fail(m, "bad function id"); max_fn = std::max(max_fn, a[i]); }
+            }
+            // Fn2Ini[f] = GetDest(GetDest(Initial, IW_R_ANCHOR), f)
+            std::vector<long> fn2ini((size_t)std::max(max_fn + 1, 1), -1);
+            fn2ini[0] = m.wbd.initial_base;
+            if (max_fn >= 1) {
+                long sr = m.cls_r == CLS_NONE ? -1 : m.wbd.step(m.wbd.initial_base, m.cls_r, nullptr, nullptr);
+                for (int f = 1; f <= max_fn; ++f) {
+                    uint32_t c = cls_sym(f);
+                    fn2ini[(size_t)f] = (sr < 0 || c == CLS_NONE) ? -1 : m.wbd.step((uint32_t)sr, c, nullptr, nullptr);
+                }
+            }
+            std::vector<uint32_t> act_info(actions.size());
+            for (size_t id = 0; id < actions.size(); ++id) {
+                const auto &v = actions[id];
+                const int left = v[0], right = v[1], tag = v[2];
+                if (left < -65535 || left > 65535 || right < -65535 || right > 65535) return fail(m, "invalid lexer action context");
+                size_t fi = v.size();
+                if (v.size() == 3 && tag != 0) fi = 3;
+                else if (v.size() > 3 && tag == 0) fi = 3;
+                else if (v.size() > 4 && v[3] == 0) fi = 4;
+                else return fail(m, "invalid lexer action");
+                const size_t nfn = v.size() - fi;
+                if (nfn == 0 && left == 0 && right == 0 && tag > 0) { act_info[id] = INFO_SIMPLE_BIT | (uint32_t)tag; continue; }
+                act_info[id] = (uint32_t)m.acts_pool.size();
+                m.acts_pool.push_back(left); m.acts_pool.push_back(right); m.acts_pool.push_back(tag); m.acts_pool.push_back((int)nfn);
+                for (size_t k = fi; k < v.size(); ++k) {
+                    const int fn = v[k];
+                    if (fn < 0 || fn > max_fn || fn2ini[(size_t)fn] < 0) return fail(m, "lexer action calls an unknown function");
+                    m.acts_pool.push_back(fn); m.acts_pool.push_back((int)fn2ini[(size_t)fn]);
+                }
+            }
+            m.wbd_info.assign(m.wbd.table_len(), 0);
+            for (size_t s = 0; s < m.wbd_raw.state_off.size(); ++s) {
+                if (!m.wbd_raw.is_final[s]) continue;
+                const int ow = m.wbd_raw.ow[s];
+                if (ow < 0 || (size_t)ow >= actions.size()) return fail(m, "final state without a valid action");
+                m.wbd_info[m.wbd.state_base[s]] = act_info[(size_t)ow];
+            }
+
+            // fused code point -> class map (charmap semantics: reference FAUtils_cl.h:311-369 + FAMultiMap_pack_fixed.cpp:67-137)
+            FixedMap cm;
+            if (charmap_dump >= 0) { if (!cm.set(dump(charmap_dump))) return fail(m, "bad charmap"); m.wbd_has_charmap = true; }
+            m.wbd_cpmap.init(CLS_NONE);
+            for (int cp = 0; cp <= 0x10FFFF; ++cp) {
+                int norm[10]; int c = cm.set_ ? cm.get(cp, norm, 10) : -1;
+                auto cls_text = [&](int o) -> uint32_t { return cls_sym(o < IW_EPSILON ? IW_EPSILON : o); };
+                if (c == -1) { uint32_t k = cls_text(cp); if (k != CLS_NONE) m.wbd_cpmap.set(cp, k); }
+                else if (c == 1) { uint32_t k = cls_text(norm[0]); if (k != CLS_NONE) m.wbd_cpmap.set(cp, k); }
+                else {
+                    if (c < 0 || c > 10) c = 0;    // silently dropped by FANormalize
+                    m.wbd_charmap_multi = true;
+                    if (m.wbd_multi_pool.size() > 0x7fff0000u) return fail(m, "charmap too large");
+                    m.wbd_cpmap.set(cp, FUSED_MULTI | (uint32_t)m.wbd_multi_pool.size());
+                    m.wbd_multi_pool.push_back((uint16_t)c);
+                    for (int k = 0; k < c; ++k) m.wbd_multi_pool.push_back((uint16_t)cls_text(norm[k]));
+                }
+            }
+        }
+    }
+
+    // ---- [pos-dict] section (semantics: reference FADictConfKeeper.cpp:57-228)
+    if (conf.get(FUNC_POS_DICT, vals)) {
+        m.has_seg = true;
+        int fsm_dump = -1, i2info_dump = -1, charmap_dump = -1, k2i_dump = -1, fsm_type = TYPE_MOORE_DFA, mode = MODE_PACK_TRIV;
+        for (size_t i = 0; i < vals.size(); ++i) {
+            const int p = vals[i];
+            if (p == PARAM_NO_TR) continue;
+            if (p == PARAM_IGNORE_CASE) { m.ignore_case = true; continue; }
+            if (p == PARAM_USE_BYTE_ENCODING) { m.use_bytes = true; continue; }
+            if (p == PARAM_NO_DUMMY_PREFIX) { m.no_dummy_prefix = true; continue; }
+            if (i + 1 >= vals.size()) return fail(m, "truncated [pos-dict] parameters");
+            const int v = vals[++i];
+            switch (p) {
+            case PARAM_DIRECTION: break;
+            case PARAM_TOKENIZATION_TYPE: m.tok_algo = v; break;
+            case PARAM_ID_OFFSET: m.id_offset = v; break;
+            case PARAM_FSM_TYPE: fsm_type = v; break;
+            case PARAM_MAP_MODE: mode = v; break;
+            case PARAM_FSM: if (fsm_type != TYPE_MEALY_DFA) return fail(m, "[pos-dict] fsm must be a Mealy DFA (fsm-type must precede fsm)"); fsm_dump = v; break;
+            case PARAM_ARRAY: k2i_dump = v; break;
+            case PARAM_CHARMAP: charmap_dump = v; break;
+            case PARAM_MULTI_MAP: if (mode != MODE_PACK_FIXED) return fail(m, "[pos-dict] multi-map must be fixed-dump"); i2info_dump = v; break;
+            default: return fail(m, "unknown [pos-dict] parameter");
+            }
+        }
+        if (fsm_dump < 0 || i2info_dump < 0 || k2i_dump < 0) return fail(m, "[pos-dict] is missing fsm / array / multi-map");
+        if (dump(k2i_dump).i32(12) <= 0) return fail(m, "[pos-dict] K2I array is empty");   // reference 1best_t.h:113
+        m.kind = m.tok_algo == TOKENIZE_BPE ? KIND_BPE : m.tok_algo == TOKENIZE_BPE_OPT ? KIND_BPE_OPT :
+                 m.tok_algo == TOKENIZE_BPE_OPT_WITH_MERGES ? KIND_BPE_MERGES : KIND_UNIGRAM;
+        if (!decode_dfa(dump(fsm_dump), true, m.dict_raw, m.error)) return false;
+        if (!pack_dfa(m.dict_raw, true, {}, m.dict, m.error)) return false;
+        m.dict_clsmap.init(CLS_NONE_W);
+        for (size_t c = 0; c < m.dict.sym_of_class.size(); ++c) m.dict_clsmap.set(m.dict.sym_of_class[c], (uint32_t)c);
+        for (int s : m.dict.sym_of_class) if (s < 0 || s > 0x10FFFF) return fail(m, "dictionary symbol outside the code point range");
+
+        FixedMap info;
+        if (!info.set(dump(i2info_dump)) || info.sov != 4) return fail(m, "bad I2Info map");
+        const size_t rows = (size_t)(info.max_key - info.min_key + 1);
+        m.i2info_min_key = info.min_key;
+        m.i2info_id.assign(rows, 0); m.i2info_score.assign(rows, 0); m.i2info_valid.assign(rows, 0);
+        for (size_t k = 0; k < rows; ++k) {
+            int v[2] = {0, 0}; int c = info.get(info.min_key + (int)k, v, 2);
+            if (c < 1 || c > 2) continue;
+            m.i2info_id[k] = v[0]; m.i2info_score[k] = (uint32_t)v[1]; m.i2info_valid[k] = (uint8_t)c;
+        }
+        // every reachable final state's MPH index must have a usable row (else the reference LogAsserts at run time)
+        {
+            const auto &rw = m.dict_raw; const size_t ns = rw.state_off.size();
+            // longest path + reachable ow sums are bounded by construction; verify keys lazily on the GPU would be silent,
+            // so verify all finals here by DFS with accumulated ow
+            std::vector<int> depth(ns, -1); std::vector<uint8_t> onstack(ns, 0);
+            bool cyclic = false;
+            std::function<int(int)> dfs = [&](int s) -> int {
+                if (depth[(size_t)s] >= 0) return depth[(size_t)s];
+                if (onstack[(size_t)s]) { cyclic = true; return 0; }
+                onstack[(size_t)s] = 1; int d = 0;
+                for (uint32_t t = rw.tr_begin[(size_t)s]; t < rw.tr_begin[(size_t)s + 1]; ++t)
+                    if (rw.tr_dst[t] >= 0) d = std::max(d, 1 + dfs(rw.tr_dst[t]));
+                onstack[(size_t)s] = 0; depth[(size_t)s] = d; return d;
+            };
+            // iterative-safe: tries are shallow (<= 128), recursion depth == path length
+            m.trie_max_depth = dfs(rw.initial);
+            if (cyclic) m.trie_max_depth = 0x7fffffff;
+        }
+        const int need = m.kind == KIND_UNIGRAM || m.kind == KIND_BPE_MERGES ? 2 : 1;
+        size_t nvalid = 0; for (uint8_t v : m.i2info_valid) if (v >= need) ++nvalid;
+        if (nvalid == 0) return fail(m, "I2Info has no usable rows");
+
+        if (charmap_dump >= 0) {
+            FixedMap cm;
+            if (!cm.set(dump(charmap_dump))) return fail(m, "bad charmap");
+            m.dict_has_charmap = true;
+            m.dict_charmap.init(NORM_NONE);
+            for (int cp = cm.min_key; cp <= cm.max_key && cp <= 0x10FFFF; ++cp) {
+                int norm[10]; int c = cm.get(cp, norm, 10);
+                if (c == -1) continue;
+                if (c < 0 || c > 10) c = 0;
+                if (c == 1 && norm[0] >= 0 && norm[0] < (1 << 24)) { m.dict_charmap.set(cp, (1u << 24) | (uint32_t)norm[0]); continue; }
+                if (m.dict_norm_pool.size() >= (1u << 24)) return fail(m, "charmap too large");
+                m.dict_charmap.set(cp, ((uint32_t)c << 24) | (uint32_t)m.dict_norm_pool.size());
+                if (c == 1) { m.dict_charmap.set(cp, (11u << 24) | (uint32_t)m.dict_norm_pool.size()); }
+                for (int k = 0; k < c; ++k) m.dict_norm_pool.push_back(norm[k]);
+            }
+            if (cm.max_key > 0x10FFFF) return fail(m, "charmap keys beyond the code point range");
+        }
+    }
+    if (!m.has_seg) {
+        m.kind = KIND_WP;
+        if (!m.has_wbd || m.wbd.table_len() == 0) return fail(m, "model has neither a [wbd] lexer nor a [pos-dict] dictionary");
+    }
+    return true;
+}
+
+} // namespace bfa

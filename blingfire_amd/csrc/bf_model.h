@@ -1,0 +1,132 @@
+// bf_model.h -- host-side model loader: BlingFire .bin image -> GPU table layout.
+//
+// The .bin format is consumed unchanged (format spec read from the reference:
+// blingfirecompile.library/inc/FADfaPack_triv.h:27-96, blingfireclient.library/src/FALDB.cpp:24-64).
+// Nothing here walks the packed bytes at tokenisation time: LoadModel decodes every
+// automaton ONCE into an abstract (state, symbol) -> (dst, final, ow) relation and
+// re-lays it out as a displacement-packed ("comb") transition table, so that one DFA
+// step on the GPU is ONE gather:   e = T[state + class];  hit <=> e.cls == class.
+// State ids are the displacement bases, which are unique per state.
+#pragma once
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+namespace bfa {
+
+// ---- enum values baked into .bin files (reference blingfireclient.library/inc/FAFsmConst.h:67-80,152-273,364-371,402-415)
+enum : int {
+    IW_ANY = 0, IW_L_ANCHOR = 1, IW_R_ANCHOR = 2, IW_EPSILON = 3,
+    DFA_DEAD_STATE = -2,
+    TRS_NONE = 0, TRS_RANGE = 1, TRS_IMPL = 2, TRS_PARA = 4, TRS_IWIA = 6,
+    FUNC_POS_DICT = 12, FUNC_WBD = 19, FUNC_GLOBAL = 20,
+    PARAM_DIRECTION = 11, PARAM_FSM = 2, PARAM_MAP_MODE = 16, PARAM_NO_TR = 18, PARAM_IGNORE_CASE = 22,
+    PARAM_ARRAY = 24, PARAM_MULTI_MAP = 25, PARAM_FSM_TYPE = 26, PARAM_DEPTH = 38, PARAM_CHARMAP = 47,
+    PARAM_MAX_LENGTH = 69, PARAM_VERIFY_LDB_BIN = 70, PARAM_TOKENIZATION_TYPE = 71, PARAM_ID_OFFSET = 72,
+    PARAM_USE_BYTE_ENCODING = 73, PARAM_NO_DUMMY_PREFIX = 74,
+    MODE_PACK_TRIV = 1, MODE_PACK_FIXED = 3, TYPE_MOORE_DFA = 3, TYPE_MEALY_DFA = 7,
+    TOKENIZE_BPE = 3, TOKENIZE_BPE_OPT = 4, TOKENIZE_BPE_OPT_WITH_MERGES = 5,
+};
+
+// kinds of TextToIds algorithm a model selects (reference tokdll:959-974, 1619-1646)
+enum ModelKind : int { KIND_WP = 0, KIND_UNIGRAM = 1, KIND_BPE = 2, KIND_BPE_OPT = 3, KIND_BPE_MERGES = 4 };
+
+// Abstract automaton decoded from a packed dump (test hooks compare it with the oracle's readers).
+struct RawDfa {
+    int initial = -1;                  // state index
+    bool remap = false;                // symbols are equivalence classes of the dump's own Iw map
+    std::vector<int> state_off;        // state index -> byte offset in the dump (the reference's state id)
+    std::vector<uint8_t> is_final;
+    std::vector<int> ow;               // Moore output weight (action id) or -1
+    std::vector<uint32_t> tr_begin;    // CSR over transitions, size = nstates + 1
+    std::vector<int> tr_sym;           // symbol (class if remap, raw Iw otherwise), ascending per state
+    std::vector<int> tr_dst;           // destination state index, or DFA_DEAD_STATE
+    std::vector<int> tr_ow;            // Mealy output weight per transition (empty for Moore)
+    // Iw map of the dump (remap only): intervals [from,to] -> class+1 values
+    std::vector<int> iw_from, iw_to; std::vector<std::vector<int>> iw_cls;   // class or -1 per code point
+    int class_of(int iw) const;        // -1 = not in alphabet
+    int find_state(int off) const;     // byte offset -> index or -1
+    std::vector<std::pair<int,int>> off_index; // sorted (off, idx)
+};
+
+// Two-level code-point map: l1[cp >> 8] -> page; pages[page*256 + (cp & 255)] -> value.
+// Page 0 is the all-default page.  Covers 0 .. 0x10FFFF (4352 l1 entries).
+struct TwoLevelMap {
+    std::vector<uint16_t> l1;
+    std::vector<uint32_t> pages;
+    uint32_t def = 0;
+    void init(uint32_t default_value);
+    void set(int cp, uint32_t v);
+    uint32_t get(int cp) const { return (cp < 0 || cp > 0x10FFFF) ? def : pages[(size_t)l1[cp >> 8] * 256 + (cp & 255)]; }
+};
+
+constexpr uint32_t CLS_NONE = 0xFFFFu;        // "code point not in the alphabet" in class streams
+
+// Displacement-packed transition table.
+//  T32 entry (lexer / Moore):  [12:0] class, [13] dst-is-final, [31:14] dst base
+//  T64 entry (dictionary / Mealy): [19:0] class, [20] dst-is-final, [41:21] dst base, [63:42] output weight
+struct PackedDfa {
+    bool wide = false;                 // false: t32, true: t64
+    std::vector<uint32_t> t32;
+    std::vector<uint64_t> t64;
+    std::vector<uint32_t> state_base;  // state index -> base (unique)
+    uint32_t dead_base = 0;            // base of the synthetic dead state
+    uint32_t initial_base = 0;
+    int nclasses = 0;                  // classes are 0 .. nclasses-1
+    std::vector<int> sym_of_class;     // non-remap: class -> raw symbol
+    uint32_t table_len() const { return (uint32_t)(wide ? t64.size() : t32.size()); }
+    // host-side lookup identical to the device step (for equivalence tests): returns dst base or -1 (miss)
+    long step(uint32_t base, uint32_t cls, int *final_out, int *ow_out) const;
+};
+
+constexpr uint32_t T32_CLS_MASK = 0x1FFFu, T32_FINAL_BIT = 1u << 13;
+constexpr int T32_NEXT_SHIFT = 14;
+constexpr uint64_t T64_CLS_MASK = 0xFFFFFull, T64_FINAL_BIT = 1ull << 20;
+constexpr int T64_NEXT_SHIFT = 21, T64_OW_SHIFT = 42;
+constexpr uint64_t T64_NEXT_MASK = 0x1FFFFFull;
+
+// lexer action record in acts_pool: [left, right, tag, nfn, (fn_id, fn_initial_base) * nfn]
+constexpr uint32_t INFO_SIMPLE_BIT = 0x80000000u; // info[base] = SIMPLE | tag   (left=right=0, no functions, tag != 0)
+
+struct Model {
+    std::vector<uint8_t> image;        // private copy of the .bin
+    std::vector<size_t> dump_off;
+    int kind = KIND_WP;
+    std::string error;                 // why load failed
+
+    // ---- [wbd] lexer (reference FAWbdConfKeeper.cpp:56-232, FALexTools_t.h:129-202)
+    bool has_wbd = false;
+    int max_depth = 2, max_token_length = 300; bool ignore_case = false;
+    RawDfa wbd_raw; PackedDfa wbd;
+    std::vector<uint32_t> wbd_info;    // indexed by base: action info for final states
+    std::vector<int32_t> acts_pool;
+    uint32_t cls_any = CLS_NONE, cls_l = CLS_NONE, cls_r = CLS_NONE;
+    // fused "code point -> charmap -> (cp<3 ? 3 : cp) -> class" map:
+    //   value = CLS_NONE | class (count 1 implicit) or FUSED_MULTI | pool offset for 0 or 2..10 outputs
+    TwoLevelMap wbd_cpmap;
+    std::vector<uint16_t> wbd_multi_pool;   // [count, cls0, cls1 ...] records for 1:n / deleted chars
+    bool wbd_has_charmap = false, wbd_charmap_multi = false;
+
+    // ---- [pos-dict] segmenters (reference FADictConfKeeper.cpp:57-228)
+    bool has_seg = false;
+    int tok_algo = 0, id_offset = 0; bool use_bytes = false, no_dummy_prefix = false;
+    RawDfa dict_raw; PackedDfa dict;
+    std::vector<int32_t> i2info_id; std::vector<uint32_t> i2info_score;  // I2Info rows (key = MPH index)
+    std::vector<uint8_t> i2info_valid;
+    int i2info_min_key = 0;
+    // "code point -> charmap" map for the _sp prologue: value = NORM_NONE (copy), or count<<24 | (value | pool offset)
+    TwoLevelMap dict_charmap; std::vector<int32_t> dict_norm_pool; bool dict_has_charmap = false;
+    TwoLevelMap dict_clsmap;           // code point (or byte) -> class of the dictionary alphabet, CLS_NONE_W if absent
+    int trie_max_depth = 0;            // longest path from the initial state (bounds every arc length)
+};
+
+constexpr uint32_t FUSED_MULTI = 0x80000000u;
+constexpr uint32_t NORM_NONE = 0xFFFFFFFFu;
+constexpr uint32_t CLS_NONE_W = 0xFFFFFu;     // T64 class "none"
+
+// Parses and re-lays-out a model image.  Returns false and sets m.error on failure.
+bool build_model(Model &m, const uint8_t *img, size_t size);
+bool load_file(const char *path, std::vector<uint8_t> &out);
+
+} // namespace bfa

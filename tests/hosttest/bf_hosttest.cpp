@@ -1,0 +1,194 @@
+// bf_hosttest.cpp -- TEST-ONLY library (never linked into the product).
+//
+//  * bft_verify_tables: exhaustive (state x symbol) equivalence of the GPU table layout built
+//    by bf_model.cpp against the oracle's packed-image readers -- the idea of the reference's
+//    `fa_fsm2fsm_pack --auto-test` (blingfirecompile.library/inc/FATestCmpDfa.h:29-54).
+//  * bft_emu_*: runs the per-lane device programs of bf_lex.h / bf_seg.h on the host, fed by a
+//    scalar restatement of the prep kernels, so that the lane logic can be fuzzed against the
+//    oracle on millions of documents without a GPU.
+#include "../../blingfire_amd/csrc/bf_model.h"
+#include "../../blingfire_amd/csrc/bf_lex.h"
+#include "../../blingfire_amd/csrc/bf_seg.h"
+#include "../../oracle/bf_oracle.h"
+
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace bfa;
+
+struct Handle { Model m; std::string path; };
+
+extern "C" {
+
+void *bft_load(const char *path)
+{
+    Handle *h = new Handle();
+    h->path = path ? path : "";
+    std::vector<uint8_t> img;
+    if (!load_file(path, img)) { h->m.error = "cannot read file"; return h; }
+    build_model(h->m, img.data(), img.size());
+    return h;
+}
+const char *bft_error(void *hv) { return ((Handle *)hv)->m.error.c_str(); }
+void bft_free(void *hv) { delete (Handle *)hv; }
+int bft_kind(void *hv) { return ((Handle *)hv)->m.kind; }
+
+// sizes for reports: out[0]=wbd states, [1]=wbd transitions, [2]=wbd table entries, [3]=wbd classes,
+// [4..7] same for dict, [8]=trie depth
+void bft_stats(void *hv, long *out)
+{
+    Model &m = ((Handle *)hv)->m;
+    out[0] = (long)m.wbd_raw.state_off.size(); out[1] = (long)m.wbd_raw.tr_sym.size(); out[2] = m.wbd.table_len(); out[3] = m.wbd.nclasses;
+    out[4] = (long)m.dict_raw.state_off.size(); out[5] = (long)m.dict_raw.tr_sym.size(); out[6] = m.dict.table_len(); out[7] = m.dict.nclasses;
+    out[8] = m.trie_max_depth;
+}
+
+static long verify_dfa(const Model &m, const bfo_model *o, int which, int verbose)
+{
+    const RawDfa &raw = which ? m.dict_raw : m.wbd_raw;
+    const PackedDfa &pk = which ? m.dict : m.wbd;
+    long bad = 0;
+    auto report = [&](const char *what, int s, int sym, long a, long b) {
+        if (++bad <= 10 && verbose) fprintf(stderr, "  [%s] state@%d sym %d: oracle %ld, table %ld\n", what, s, sym, a, b);
+    };
+    if (raw.state_off[(size_t)raw.initial] != bfo_dfa_initial(o, which)) report("initial", 0, 0, bfo_dfa_initial(o, which), raw.state_off[(size_t)raw.initial]);
+    // representative raw symbol per class
+    std::vector<int> rep((size_t)pk.nclasses, -1);
+    if (raw.remap) {
+        for (size_t i = 0; i < raw.iw_from.size(); ++i)
+            for (int k = 0; k <= raw.iw_to[i] - raw.iw_from[i]; ++k) {
+                int c = raw.iw_cls[i][(size_t)k];
+                if (c >= 0 && c < pk.nclasses && rep[(size_t)c] < 0) rep[(size_t)c] = raw.iw_from[i] + k;
+            }
+    } else {
+        for (int c = 0; c < pk.nclasses; ++c) rep[(size_t)c] = pk.sym_of_class[(size_t)c];
+    }
+    // base -> expected oracle state offset
+    std::vector<int> off_of_base(pk.table_len(), -9);
+    for (size_t s = 0; s < raw.state_off.size(); ++s) off_of_base[pk.state_base[s]] = raw.state_off[s];
+    off_of_base[pk.dead_base] = DFA_DEAD_STATE;
+    for (size_t s = 0; s < raw.state_off.size(); ++s) {
+        const int soff = raw.state_off[s];
+        for (int c = 0; c < pk.nclasses; ++c) {
+            if (rep[(size_t)c] < 0) continue;
+            int fin = 0, ow = 0;
+            long nb = pk.step(pk.state_base[s], (uint32_t)c, &fin, &ow);
+            long got = nb < 0 ? -1 : off_of_base[(size_t)nb];
+            long want; int want_ow = 0;
+            if (which) want = bfo_mealy_dest_ow(o, soff, rep[(size_t)c], &want_ow);
+            else want = bfo_dfa_dest(o, which, soff, rep[(size_t)c]);
+            if (got != want) { report("dest", soff, rep[(size_t)c], want, got); continue; }
+            if (want >= 0) {
+                if ((int)bfo_dfa_is_final(o, which, (int)want) != fin) report("final", soff, rep[(size_t)c], bfo_dfa_is_final(o, which, (int)want), fin);
+                if (which && want_ow != ow) report("ow", soff, rep[(size_t)c], want_ow, ow);
+            }
+        }
+    }
+    return bad;
+}
+
+// returns the number of mismatches (0 = equivalent)
+long bft_verify_tables(void *hv, int verbose)
+{
+    Handle *h = (Handle *)hv;
+    Model &m = h->m;
+    bfo_model *o = bfo_load_model(h->path.c_str());
+    if (!o) return -1;
+    long bad = 0;
+    if (m.has_wbd && bfo_has_dfa(o, 0)) {
+        bad += verify_dfa(m, o, 0, verbose);
+        // fused code point map == charmap o class map, for every code point
+        for (int cp = 0; cp <= 0x10FFFF; ++cp) {
+            int norm[10]; int c = bfo_charmap_get(o, 0, cp, norm, 10);
+            std::vector<uint32_t> want;
+            auto cls = [&](int x) { int k = bfo_wbd_iw_class(o, x < 3 ? 3 : x); if (k >= 0 && !m.wbd_raw.remap) { auto &S = m.wbd.sym_of_class; auto it = std::lower_bound(S.begin(), S.end(), k); k = (it != S.end() && *it == k) ? (int)(it - S.begin()) : -1; } return k < 0 ? CLS_NONE : (uint32_t)k; };
+            if (c == -1) want.push_back(cls(cp));
+            else if (c >= 1 && c <= 10) for (int k = 0; k < c; ++k) want.push_back(cls(norm[k]));
+            uint32_t v = m.wbd_cpmap.get(cp);
+            std::vector<uint32_t> got;
+            if (v & FUSED_MULTI) { size_t off = v & 0x7fffffffu; int n = m.wbd_multi_pool[off]; for (int k = 0; k < n; ++k) got.push_back(m.wbd_multi_pool[off + 1 + (size_t)k]); }
+            else got.push_back(v);
+            if (got != want) { if (++bad <= 10 && verbose) fprintf(stderr, "  [cpmap] U+%04X differs\n", cp); }
+        }
+        // actions of every final state
+        for (size_t s = 0; s < m.wbd_raw.state_off.size(); ++s) {
+            if (!m.wbd_raw.is_final[s]) continue;
+            int act[64]; int n = bfo_wbd_action(o, bfo_state2ow(o, m.wbd_raw.state_off[s]), act, 64);
+            uint32_t inf = m.wbd_info[m.wbd.state_base[s]];
+            bool ok = n >= 3;
+            if (ok) {
+                if (inf & INFO_SIMPLE_BIT) ok = n == 3 && act[0] == 0 && act[1] == 0 && act[2] == (int)(inf & 0x7fffffffu);
+                else {
+                    const int32_t *a = m.acts_pool.data() + inf;
+                    int fi = act[2] != 0 ? (n > 3 ? 4 : 3) : 3;
+                    ok = a[0] == act[0] && a[1] == act[1] && a[2] == act[2] && a[3] == n - fi;
+                    for (int k = 0; ok && k < a[3]; ++k) ok = a[4 + 2 * k] == act[fi + k];
+                }
+            }
+            if (!ok && ++bad <= 10 && verbose) fprintf(stderr, "  [action] state@%d differs\n", m.wbd_raw.state_off[s]);
+        }
+    }
+    if (m.has_seg && bfo_has_dfa(o, 1)) {
+        bad += verify_dfa(m, o, 1, verbose);
+        for (size_t k = 0; k < m.i2info_id.size(); ++k) {
+            int id = 0; uint32_t bits = 0; int c = bfo_i2info_get(o, m.i2info_min_key + (int)k, &id, &bits);
+            if (c < 1) { if (m.i2info_valid[k] && ++bad <= 10 && verbose) fprintf(stderr, "  [i2info] key %zu validity\n", k); continue; }
+            if ((c > 2 ? 0 : c) != m.i2info_valid[k] || (m.i2info_valid[k] && (id != m.i2info_id[k] || (c >= 2 && bits != m.i2info_score[k]))))
+                if (++bad <= 10 && verbose) fprintf(stderr, "  [i2info] key %zu differs\n", k);
+        }
+        if (m.dict_has_charmap) {
+            for (int cp = 0; cp <= 0x10FFFF; ++cp) {
+                int norm[10]; int c = bfo_charmap_get(o, 1, cp, norm, 10);
+                uint32_t v = m.dict_charmap.get(cp);
+                bool ok;
+                if (c == -1) ok = v == NORM_NONE;
+                else {
+                    if (c < 0 || c > 10) c = 0;
+                    uint32_t cnt = v >> 24, pay = v & 0xffffffu;
+                    if (cnt == 11) { ok = c == 1 && m.dict_norm_pool[pay] == norm[0]; }
+                    else if (cnt == 1) ok = c == 1 && (int)pay == norm[0];
+                    else { ok = (int)cnt == c && v != NORM_NONE; for (int k = 0; ok && k < c; ++k) ok = m.dict_norm_pool[pay + (size_t)k] == norm[k]; }
+                }
+                if (!ok && ++bad <= 10 && verbose) fprintf(stderr, "  [charmap] U+%04X differs\n", cp);
+            }
+        }
+    }
+    bfo_free_model(o);
+    return bad;
+}
+
+// ---- host emulation of the GPU pipeline (scalar prep + the device lane programs)
+static int emu_wp(const Model &m, const char *s, int n, int32_t *ids, int max_ids, int unk)
+{
+    if (n <= 0 || !s) return 0;
+    std::vector<int> cps((size_t)n);
+    int len = bfo_utf8_to_utf32(s, n, cps.data(), n);   // the prep KERNEL has its own parallel decoder; GPU tests cover it
+    if (len <= 0) return 0;
+    std::vector<uint16_t> cls;
+    for (int i = 0; i < len; ++i) {
+        uint32_t v = m.wbd_cpmap.get(cps[(size_t)i]);
+        if (v & FUSED_MULTI) { size_t off = v & 0x7fffffffu; int c = m.wbd_multi_pool[off]; for (int k = 0; k < c; ++k) cls.push_back(m.wbd_multi_pool[off + 1 + (size_t)k]); }
+        else cls.push_back((uint16_t)v);
+    }
+    if (cls.empty() || (int)cls.size() > n) return 0;
+    LexTables L;
+    L.T = m.wbd.t32.data(); L.info = m.wbd_info.data(); L.acts = m.acts_pool.data();
+    L.initial = m.wbd.initial_base; L.cls_any = m.cls_any; L.cls_l = m.cls_l; L.cls_r = m.cls_r;
+    L.max_depth = m.max_depth; L.max_token_length = m.max_token_length;
+    const uint16_t *cp = cls.data();
+    return lex_doc(L, [cp](int i) -> uint32_t { return cp[i]; }, (int)cls.size(), ids, max_ids, unk);
+}
+
+static int emu_sp(const Model &, const char *, int, int32_t *, int, int) { return -1; }
+
+int bft_emu_text_to_ids(void *hv, const char *s, int n, int32_t *ids, int max_ids, int unk)
+{
+    Model &m = ((Handle *)hv)->m;
+    if (!m.error.empty()) return -1;
+    if (m.kind == KIND_WP) return emu_wp(m, s, n, ids, max_ids, unk);
+    return emu_sp(m, s, n, ids, max_ids, unk);
+}
+
+} // extern "C"
