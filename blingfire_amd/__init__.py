@@ -1,0 +1,152 @@
+"""blingfire_amd -- Python mirror of the reference wrapper for the TextToIds path.
+
+Same function names, argument meaning and return conventions as the reference
+``dist-pypi/blingfire/__init__.py`` (load_model :229-234, free_model :237-240, text_to_ids :243-253,
+change_settings_dummy_prefix :287-288), bound to the MI355X-native ``libblingfiretokdll.so`` built
+in-tree by ``blingfire_amd/build.py``.  Additive: ``text_to_ids_batch`` (host buffers) and
+``text_to_ids_batch_device`` (torch tensors already resident in HBM).
+
+There is no CPU fallback: if the shared library is missing or no HIP device is visible the calls
+raise / return the reference's error value, loudly.
+"""
+import ctypes
+import os
+from ctypes import POINTER, byref, c_char_p, c_float, c_int, c_int32, c_int64, c_void_p
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libblingfiretokdll.so")
+
+_lib = None
+
+
+def lib():
+    """The loaded C-ABI library (built by blingfire_amd/build.py)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError("%s is missing: run `python -m blingfire_amd.build` (hipcc, gfx950) first; "
+                               "there is no CPU fallback" % LIB_PATH)
+        L = ctypes.CDLL(LIB_PATH)
+        L.LoadModel.restype = c_void_p
+        L.LoadModel.argtypes = [c_char_p]
+        L.SetModel.restype = c_void_p
+        L.SetModel.argtypes = [c_char_p, c_int]
+        L.FreeModel.restype = c_int
+        L.FreeModel.argtypes = [c_void_p]
+        for name in ("TextToIds", "TextToIds_wp", "TextToIds_sp"):
+            f = getattr(L, name)
+            f.restype = c_int
+            f.argtypes = [c_void_p, c_char_p, c_int, c_void_p, c_int, c_int]
+        L.SetNoDummyPrefix.restype = c_int
+        L.SetNoDummyPrefix.argtypes = [c_void_p, c_int]
+        L.GetBlingFireTokVersion.restype = c_int
+        L.TextToIdsBatch.restype = c_int64
+        L.TextToIdsBatch.argtypes = [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int, c_int]
+        L.TextToIdsBatchDevice.restype = c_int
+        L.TextToIdsBatchDevice.argtypes = [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_void_p,
+                                           c_int, c_int, c_void_p]
+        L.BfLastKernelMs.restype = c_int
+        L.BfLastKernelMs.argtypes = [c_void_p, POINTER(c_float), c_int]
+        L.BfLastStatus.restype = c_int
+        L.BfLastStatus.argtypes = [c_void_p]
+        L.BfLastError.restype = c_char_p
+        L.BfModelKind.restype = c_int
+        L.BfModelKind.argtypes = [c_void_p]
+        L.BfSetVariant.restype = c_int
+        L.BfSetVariant.argtypes = [c_void_p, c_int]
+        _lib = L
+    return _lib
+
+
+def get_blingfiretok_version():
+    return lib().GetBlingFireTokVersion()
+
+
+def load_model(file_name):
+    """reference __init__.py:229-234; raises instead of returning a NULL handle."""
+    h = lib().LoadModel(file_name.encode("utf-8"))
+    if not h:
+        raise RuntimeError("LoadModel(%r) failed: %s" % (file_name, lib().BfLastError().decode("utf-8", "replace")))
+    return h
+
+
+def free_model(h):
+    lib().FreeModel(c_void_p(h))
+
+
+def text_to_ids(h, s, max_len, unk=0, no_padding=False):
+    """reference __init__.py:243-253: zero-padded uint32 array of max_len (or the exact count with no_padding)."""
+    s_bytes = s.encode("utf-8") if isinstance(s, str) else bytes(s)
+    o = (c_int32 * max_len)()
+    t = lib().TextToIds(c_void_p(h), s_bytes, len(s_bytes), byref(o), max_len, unk)
+    n = min(max_len, t) if no_padding else max_len
+    return np.frombuffer(o, dtype=np.uint32, count=n)
+
+
+def change_settings_dummy_prefix(h, add_prefix):
+    lib().SetNoDummyPrefix(c_void_p(h), int(not add_prefix))
+
+
+# ---------------------------------------------------------------------------------------------
+# additive batch API
+# ---------------------------------------------------------------------------------------------
+
+def pack_docs(docs):
+    """list of str/bytes -> (uint8 array, int64 offsets[ndocs+1])"""
+    bs = [d.encode("utf-8") if isinstance(d, str) else bytes(d) for d in docs]
+    off = np.zeros(len(bs) + 1, dtype=np.int64)
+    if bs:
+        np.cumsum([len(b) for b in bs], out=off[1:])
+    text = np.frombuffer(b"".join(bs), dtype=np.uint8) if bs else np.zeros(0, dtype=np.uint8)
+    return text, off
+
+
+def text_to_ids_batch(h, docs, max_len, unk=0):
+    """For every document exactly what TextToIds(h, doc, len, buf, max_len, unk) writes, concatenated.
+
+    docs: list of str/bytes, or a (uint8 ndarray, int64 offsets) pair.  Returns (ids int32[total], offsets int64[ndocs+1]).
+    """
+    text, off = docs if isinstance(docs, tuple) else pack_docs(docs)
+    text = np.ascontiguousarray(text, dtype=np.uint8)
+    off = np.ascontiguousarray(off, dtype=np.int64)
+    ndocs = len(off) - 1
+    total = int(off[-1] - off[0]) if ndocs > 0 else 0
+    cap = min(total, ndocs * max(max_len, 0)) + 1
+    ids = np.empty(cap, dtype=np.int32)
+    id_off = np.zeros(ndocs + 1, dtype=np.int64)
+    r = lib().TextToIdsBatch(c_void_p(h), text.ctypes.data, off.ctypes.data, ndocs, ids.ctypes.data, cap, id_off.ctypes.data,
+                             max_len, unk)
+    if r < 0:
+        raise RuntimeError("TextToIdsBatch failed (%d): %s" % (r, lib().BfLastError().decode("utf-8", "replace")))
+    return ids[:r], id_off
+
+
+def text_to_ids_batch_device(h, d_text, d_doc_off, max_len, unk=0, out_ids=None, out_off=None, stream=None):
+    """Device-resident batch: torch uint8 text tensor + int64 offsets tensor (both on the model's GPU).
+
+    Enqueues on torch's current stream (or `stream`) and returns (ids int32[cap], id_offsets int64[ndocs+1]) tensors
+    without synchronising; the valid id count is id_offsets[-1].
+    """
+    import torch
+    ndocs = d_doc_off.numel() - 1
+    total = d_text.numel()
+    cap = max(1, min(total, ndocs * max(max_len, 0)))
+    if out_ids is None:
+        out_ids = torch.empty(cap, dtype=torch.int32, device=d_text.device)
+    if out_off is None:
+        out_off = torch.empty(ndocs + 1, dtype=torch.int64, device=d_text.device)
+    s = stream if stream is not None else torch.cuda.current_stream(d_text.device).cuda_stream
+    r = lib().TextToIdsBatchDevice(c_void_p(h), d_text.data_ptr(), d_doc_off.data_ptr(), ndocs, total, out_ids.data_ptr(),
+                                   out_ids.numel(), out_off.data_ptr(), max_len, unk, c_void_p(s))
+    if r != 0:
+        raise RuntimeError("TextToIdsBatchDevice failed (%d): %s" % (r, lib().BfLastError().decode("utf-8", "replace")))
+    return out_ids, out_off
+
+
+def last_kernel_ms(h):
+    """[prep, tokenise, scan, compact, total] GPU milliseconds of the last batch call (HIP events on its stream)."""
+    buf = (c_float * 5)()
+    n = lib().BfLastKernelMs(c_void_p(h), buf, 5)
+    return [buf[i] for i in range(max(n, 0))]

@@ -1,0 +1,80 @@
+"""Build recipe for the native pieces (explicit hipcc / gcc invocations, in-tree outputs).
+
+  blingfire_amd/libblingfiretokdll.so   the product: HIP kernels (gfx950) + C-ABI
+  oracle/liboracle.so                   TEST INFRA: plain-C restatement of the reference path
+  oracle/libcpubaseline.so              TEST INFRA: multi-threaded driver that times a TextToIds .so on host cores
+  tools/libcorpusgen.so                 TEST INFRA: deterministic synthetic corpus generator
+  tests/hosttest/libbf_hosttest.so      TEST INFRA: table-equivalence + host emulation of the lane programs
+  oracle/_ref/libblingfiretokdll_ref.so TEST INFRA: the unmodified reference, only when /root/reference exists
+"""
+import os
+import shutil
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "blingfire_amd", "csrc")
+PRODUCT = os.path.join(ROOT, "blingfire_amd", "libblingfiretokdll.so")
+REF_DIR = os.environ.get("BF_REFERENCE", "/root/reference")
+
+
+def _run(cmd, cwd=None):
+    print("+", " ".join(cmd), flush=True)
+    subprocess.check_call(cmd, cwd=cwd)
+
+
+def _newer(target, sources):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(s) > t for s in sources)
+
+
+def hipcc():
+    for c in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if c and os.path.exists(c):
+            return c
+    raise RuntimeError("hipcc not found")
+
+
+def build_product(force=False):
+    srcs = [os.path.join(CSRC, f) for f in ("bf_kernels.hip", "bf_capi.cpp", "bf_model.cpp")]
+    deps = srcs + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + [
+        os.path.join(ROOT, "include", "blingfiretokdll_amd.h")]
+    if force or _newer(PRODUCT, deps):
+        _run([hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
+              "-Wall", "-Wno-unused-result", "-x", "hip"] + srcs + ["-o", PRODUCT])
+    return PRODUCT
+
+
+def build_test_infra(force=False):
+    odir = os.path.join(ROOT, "oracle")
+    lib = os.path.join(odir, "liboracle.so")
+    if force or _newer(lib, [os.path.join(odir, "bf_oracle.c"), os.path.join(odir, "bf_oracle.h")]):
+        _run(["gcc", "-O2", "-Wall", "-Wextra", "-std=c99", "-fPIC", "-shared", "bf_oracle.c", "-o", "liboracle.so"], cwd=odir)
+    drv = os.path.join(odir, "libcpubaseline.so")
+    if force or _newer(drv, [os.path.join(odir, "cpu_baseline.c")]):
+        _run(["gcc", "-O2", "-Wall", "-std=gnu99", "-fPIC", "-shared", "cpu_baseline.c", "-o", "libcpubaseline.so", "-ldl", "-lpthread"], cwd=odir)
+    cg = os.path.join(ROOT, "tools", "libcorpusgen.so")
+    if force or _newer(cg, [os.path.join(ROOT, "tools", "corpusgen.c")]):
+        _run(["gcc", "-O2", "-Wall", "-std=gnu99", "-fPIC", "-shared", "corpusgen.c", "-o", "libcorpusgen.so", "-lm", "-lpthread"],
+             cwd=os.path.join(ROOT, "tools"))
+    ht = os.path.join(ROOT, "tests", "hosttest", "libbf_hosttest.so")
+    ht_src = [os.path.join(ROOT, "tests", "hosttest", "bf_hosttest.cpp"), os.path.join(CSRC, "bf_model.cpp")]
+    ht_dep = ht_src + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + [os.path.join(odir, "bf_oracle.c")]
+    if force or _newer(ht, ht_dep):
+        obj = os.path.join(ROOT, "tests", "hosttest", "bf_oracle.o")
+        _run(["gcc", "-O2", "-std=c99", "-fPIC", "-c", os.path.join(odir, "bf_oracle.c"), "-o", obj])
+        _run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-o", ht] + ht_src + [obj])
+    ref = os.path.join(odir, "_ref", "libblingfiretokdll_ref.so")
+    if os.path.isdir(os.path.join(REF_DIR, "blingfireclient.library")) and (force or not os.path.exists(ref)):
+        _run(["make", "-C", odir, "ref", "REF=" + REF_DIR])
+
+
+def build_all(force=False):
+    build_product(force)
+    build_test_infra(force)
+
+
+if __name__ == "__main__":
+    build_all("--force" in sys.argv)

@@ -1,0 +1,324 @@
+// bf_capi.cpp -- extern "C" surface of libblingfiretokdll.so (see include/blingfiretokdll_amd.h)
+// and the host runtime around the kernels: device-resident tables, grow-only workspaces,
+// stream/event plumbing.  No CPU tokenisation path exists here: every entry point that
+// produces ids launches the HIP kernels, and fails loudly if there is no device.
+#include "../../include/blingfiretokdll_amd.h"
+#include "bf_kernels.h"
+#include "bf_model.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+using namespace bfa;
+
+namespace {
+
+thread_local std::string g_last_error;
+
+bool hip_ok(hipError_t e, const char *what)
+{
+    if (e == hipSuccess) return true;
+    g_last_error = std::string(what) + ": " + hipGetErrorString(e);
+    fprintf(stderr, "[blingfire_amd] HIP error in %s: %s\n", what, hipGetErrorString(e));
+    return false;
+}
+
+struct DevBuf {
+    void *p = nullptr; size_t cap = 0;
+    bool reserve(size_t bytes)
+    {
+        if (bytes <= cap) return true;
+        if (p) (void)hipFree(p);
+        p = nullptr; cap = 0;
+        size_t want = bytes + bytes / 8 + 256;
+        if (!hip_ok(hipMalloc(&p, want), "hipMalloc(workspace)")) return false;
+        cap = want; return true;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    template <class T> T *as() const { return (T *)p; }
+};
+
+template <class T> bool upload(DevBuf &b, const std::vector<T> &v, size_t pad_elems = 0)
+{
+    const size_t bytes = (v.size() + pad_elems) * sizeof(T);
+    if (!b.reserve(bytes ? bytes : 16)) return false;
+    if (pad_elems && !hip_ok(hipMemset(b.p, 0, b.cap), "hipMemset")) return false;
+    if (!v.empty() && !hip_ok(hipMemcpy(b.p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice), "hipMemcpy(table)")) return false;
+    return true;
+}
+
+enum { EV_BEGIN = 0, EV_PREP, EV_TOK, EV_SCAN, EV_COMPACT, EV_COUNT };
+
+struct Handle {
+    uint32_t magic = 0xB1F14E01u;
+    Model m;
+    int device = 0;
+    int variant = 0;
+    std::mutex mu;
+    // device tables
+    DevBuf t_wbd, t_info, t_acts, t_cp_l1, t_cp_pages, t_multi;
+    // workspaces
+    DevBuf w_cls, w_nchars, w_tmp, w_counts, w_bsums, w_misc;   // w_misc: [0] next_doc (u64), [2] status (int)
+    DevBuf w_text, w_docoff, w_ids, w_idoff;                    // host-API staging
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[EV_COUNT] = {};
+    bool ev_valid = false;
+    ~Handle()
+    {
+        for (DevBuf *b : {&t_wbd, &t_info, &t_acts, &t_cp_l1, &t_cp_pages, &t_multi, &w_cls, &w_nchars, &w_tmp, &w_counts,
+                          &w_bsums, &w_misc, &w_text, &w_docoff, &w_ids, &w_idoff}) b->release();
+        for (auto &e : ev) if (e) (void)hipEventDestroy(e);
+        if (stream) (void)hipStreamDestroy(stream);
+        magic = 0;
+    }
+};
+
+Handle *as_handle(void *p)
+{
+    Handle *h = (Handle *)p;
+    return (h && h->magic == 0xB1F14E01u) ? h : nullptr;
+}
+
+Handle *make_handle(const uint8_t *img, size_t size)
+{
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        g_last_error = "no HIP device available: this library has no CPU path";
+        fprintf(stderr, "[blingfire_amd] %s\n", g_last_error.c_str());
+        return nullptr;
+    }
+    Handle *h = new Handle();
+    if (!build_model(h->m, img, size)) {
+        g_last_error = "cannot load model: " + h->m.error;
+        fprintf(stderr, "[blingfire_amd] %s\n", g_last_error.c_str());
+        delete h; return nullptr;
+    }
+    if (hipGetDevice(&h->device) != hipSuccess) h->device = 0;
+    Model &m = h->m;
+    bool ok = true;
+    if (m.kind == KIND_WP) {
+        if (m.max_depth > LEX_MAX_DEPTH) { g_last_error = "lexer max-depth exceeds the supported 4"; fprintf(stderr, "[blingfire_amd] %s\n", g_last_error.c_str()); delete h; return nullptr; }
+        ok = ok && upload(h->t_wbd, m.wbd.t32, 16) && upload(h->t_info, m.wbd_info, 16) && upload(h->t_acts, m.acts_pool, 16) &&
+             upload(h->t_cp_l1, m.wbd_cpmap.l1) && upload(h->t_cp_pages, m.wbd_cpmap.pages) && upload(h->t_multi, m.wbd_multi_pool, 16);
+    } else {
+        g_last_error = "segmenter models are not wired yet";
+        ok = false;
+    }
+    ok = ok && hip_ok(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking), "hipStreamCreate");
+    for (auto &e : h->ev) ok = ok && hip_ok(hipEventCreate(&e), "hipEventCreate");
+    ok = ok && h->w_misc.reserve(64) && hip_ok(hipMemset(h->w_misc.p, 0, 64), "hipMemset");
+    if (!ok) { fprintf(stderr, "[blingfire_amd] %s\n", g_last_error.c_str()); delete h; return nullptr; }
+    return h;
+}
+
+// Enqueue the whole pipeline for a batch resident on the device.
+int run_device(Handle *h, const char *d_text, const int64_t *d_doc_off, int64_t ndocs, int64_t total_bytes,
+               int32_t *d_ids_out, int64_t ids_cap, int64_t *d_id_off, int max_ids, int unk, hipStream_t s)
+{
+    if (ndocs < 0 || total_bytes < 0 || !d_doc_off || !d_id_off || (ids_cap > 0 && !d_ids_out) || (total_bytes > 0 && !d_text)) return BF_E_ARG;
+    if (max_ids < 0) max_ids = 0;
+    Model &m = h->m;
+    const int nblocks = scan_nblocks(ndocs);
+    if (!h->w_nchars.reserve((size_t)(ndocs + 1) * 4) || !h->w_counts.reserve((size_t)(ndocs + 1) * 4) ||
+        !h->w_bsums.reserve((size_t)(nblocks + 1) * 8) || !h->w_tmp.reserve((size_t)(total_bytes + 16) * 4)) return BF_E_DEVICE;
+    Batch b{(const uint8_t *)d_text, d_doc_off, ndocs};
+    unsigned long long *next_doc = h->w_misc.as<unsigned long long>();
+    int *status = (int *)(h->w_misc.as<char>() + 16);
+    if (!hip_ok(hipMemsetAsync(h->w_misc.p, 0, 64, s), "hipMemsetAsync")) return BF_E_DEVICE;
+    (void)hipEventRecord(h->ev[EV_BEGIN], s);
+    if (m.kind == KIND_WP) {
+        if (!h->w_cls.reserve((size_t)(total_bytes + 64) * 2)) return BF_E_DEVICE;
+        WpPrepParams pp{b, DevCpMap{h->t_cp_l1.as<uint16_t>(), h->t_cp_pages.as<uint32_t>()}, h->t_multi.as<uint16_t>(),
+                        m.wbd_charmap_multi ? 1 : 0, h->w_cls.as<uint16_t>(), h->w_nchars.as<int32_t>()};
+        if (ndocs > 0) launch_prep_wp(pp, s);
+        (void)hipEventRecord(h->ev[EV_PREP], s);
+        WpLexParams lp;
+        lp.L.T = h->t_wbd.as<uint32_t>(); lp.L.info = h->t_info.as<uint32_t>(); lp.L.acts = h->t_acts.as<int32_t>();
+        lp.L.initial = m.wbd.initial_base; lp.L.cls_any = m.cls_any; lp.L.cls_l = m.cls_l; lp.L.cls_r = m.cls_r;
+        lp.L.max_depth = m.max_depth; lp.L.max_token_length = m.max_token_length;
+        lp.b = b; lp.cls = h->w_cls.as<uint16_t>(); lp.nchars = h->w_nchars.as<int32_t>();
+        lp.ids_tmp = h->w_tmp.as<int32_t>(); lp.counts = h->w_counts.as<int32_t>();
+        lp.max_ids = max_ids; lp.unk = unk; lp.next_doc = next_doc; lp.status = status;
+        if (ndocs > 0) launch_lex_wp(lp, h->variant, s);
+        (void)hipEventRecord(h->ev[EV_TOK], s);
+    } else {
+        return BF_E_UNSUPPORTED;
+    }
+    ScanParams sp{h->w_counts.as<int32_t>(), ndocs, d_id_off, h->w_bsums.as<int64_t>(), nblocks};
+    launch_scan(sp, s);
+    (void)hipEventRecord(h->ev[EV_SCAN], s);
+    CompactParams cp{b, h->w_tmp.as<int32_t>(), h->w_counts.as<int32_t>(), d_id_off, d_ids_out, ids_cap, status};
+    if (ndocs > 0) launch_compact(cp, s);
+    (void)hipEventRecord(h->ev[EV_COMPACT], s);
+    h->ev_valid = true;
+    if (!hip_ok(hipGetLastError(), "kernel launch")) return BF_E_DEVICE;
+    return 0;
+}
+
+int64_t run_host(Handle *h, const char *text, const int64_t *doc_off, int64_t ndocs, int32_t *ids_out, int64_t ids_cap,
+                 int64_t *id_off_out, int max_ids, int unk)
+{
+    if (ndocs < 0 || !doc_off || (ndocs > 0 && !text && doc_off[ndocs] > doc_off[0])) return BF_E_ARG;
+    const int64_t base = doc_off[0];
+    const int64_t total = ndocs > 0 ? doc_off[ndocs] - base : 0;
+    if (total < 0) return BF_E_ARG;
+    std::lock_guard<std::mutex> lock(h->mu);
+    if (!hip_ok(hipSetDevice(h->device), "hipSetDevice")) return BF_E_DEVICE;
+    hipStream_t s = h->stream;
+    // worst-case id count (every id covers >= 1 byte)
+    int64_t worst = total;
+    if (max_ids >= 0 && ndocs * (int64_t)max_ids < worst) worst = ndocs * (int64_t)(max_ids < 0 ? 0 : max_ids);
+    if (!h->w_text.reserve((size_t)total + 16) || !h->w_docoff.reserve((size_t)(ndocs + 1) * 8) ||
+        !h->w_idoff.reserve((size_t)(ndocs + 1) * 8) || !h->w_ids.reserve((size_t)(worst + 1) * 4)) return BF_E_DEVICE;
+    std::vector<int64_t> rel;
+    const int64_t *src_off = doc_off;
+    if (base != 0) { rel.resize((size_t)ndocs + 1); for (int64_t i = 0; i <= ndocs; ++i) rel[(size_t)i] = doc_off[i] - base; src_off = rel.data(); }
+    if (total > 0 && !hip_ok(hipMemcpyAsync(h->w_text.p, text + base, (size_t)total, hipMemcpyHostToDevice, s), "H2D text")) return BF_E_DEVICE;
+    if (!hip_ok(hipMemcpyAsync(h->w_docoff.p, src_off, (size_t)(ndocs + 1) * 8, hipMemcpyHostToDevice, s), "H2D offsets")) return BF_E_DEVICE;
+    int rc = run_device(h, h->w_text.as<char>(), h->w_docoff.as<int64_t>(), ndocs, total, h->w_ids.as<int32_t>(), worst,
+                        h->w_idoff.as<int64_t>(), max_ids, unk, s);
+    if (rc != 0) return rc;
+    std::vector<int64_t> tmp_off;
+    int64_t *dst_off = id_off_out;
+    if (!dst_off) { tmp_off.resize((size_t)ndocs + 1); dst_off = tmp_off.data(); }
+    if (!hip_ok(hipMemcpyAsync(dst_off, h->w_idoff.p, (size_t)(ndocs + 1) * 8, hipMemcpyDeviceToHost, s), "D2H offsets")) return BF_E_DEVICE;
+    int status = 0;
+    if (!hip_ok(hipMemcpyAsync(&status, h->w_misc.as<char>() + 16, 4, hipMemcpyDeviceToHost, s), "D2H status")) return BF_E_DEVICE;
+    if (!hip_ok(hipStreamSynchronize(s), "hipStreamSynchronize")) return BF_E_DEVICE;
+    if (status & 2) return BF_E_INTERNAL;
+    const int64_t nids = dst_off[ndocs];
+    if (nids > ids_cap) return BF_E_CAPACITY;
+    if (nids > 0) {
+        if (!ids_out) return BF_E_ARG;
+        if (!hip_ok(hipMemcpy(ids_out, h->w_ids.p, (size_t)nids * 4, hipMemcpyDeviceToHost), "D2H ids")) return BF_E_DEVICE;
+    }
+    return nids;
+}
+
+int text_to_ids_one(void *hp, const char *s, int n, int32_t *ids, int max_ids, int unk, int want_kind /* -1 any, 0 wp, 1 sp */)
+{
+    Handle *h = as_handle(hp);
+    if (!h) return 0;                                         // tokdll:1629-1631
+    if (n <= 0 || n > 1000000000 || !s) return 0;             // tokdll:1121-1123
+    if (want_kind == 0 && h->m.kind != KIND_WP) return 0;
+    if (want_kind == 1 && h->m.kind == KIND_WP) return 0;
+    if (max_ids <= 0 || !ids) return 0;
+    const int64_t off[2] = {0, n};
+    int64_t r = run_host(h, s, off, 1, ids, max_ids, nullptr, max_ids, unk);
+    if (r < 0) { fprintf(stderr, "[blingfire_amd] TextToIds failed (%lld): %s\n", (long long)r, g_last_error.c_str()); return 0; }
+    return (int)r;
+}
+
+} // namespace
+
+extern "C" {
+
+int GetBlingFireTokVersion(void) { return 18000; }
+
+void *LoadModel(const char *path)
+{
+    g_last_error.clear();
+    std::vector<uint8_t> img;
+    if (!load_file(path, img)) {
+        g_last_error = std::string("cannot read model file: ") + (path ? path : "(null)");
+        fprintf(stderr, "[blingfire_amd] %s\n", g_last_error.c_str());
+        return nullptr;
+    }
+    return make_handle(img.data(), img.size());
+}
+
+void *SetModel(const unsigned char *img, int size)
+{
+    g_last_error.clear();
+    if (!img || size <= 0) return nullptr;
+    return make_handle(img, (size_t)size);
+}
+
+int FreeModel(void *p)
+{
+    Handle *h = as_handle(p);
+    if (!h) return 0;
+    (void)hipSetDevice(h->device);
+    (void)hipDeviceSynchronize();
+    delete h;
+    return 1;
+}
+
+int TextToIds(void *h, const char *s, int n, int32_t *ids, const int max_ids, const int unk) { return text_to_ids_one(h, s, n, ids, max_ids, unk, -1); }
+int TextToIds_wp(void *h, const char *s, int n, int32_t *ids, const int max_ids, const int unk) { return text_to_ids_one(h, s, n, ids, max_ids, unk, 0); }
+int TextToIds_sp(void *h, const char *s, int n, int32_t *ids, const int max_ids, const int unk) { return text_to_ids_one(h, s, n, ids, max_ids, unk, 1); }
+
+int SetNoDummyPrefix(void *p, int flag)
+{
+    Handle *h = as_handle(p);
+    if (!h) return 0;
+    std::lock_guard<std::mutex> lock(h->mu);
+    h->m.no_dummy_prefix = flag != 0;
+    return 1;
+}
+
+int64_t TextToIdsBatch(void *p, const char *text, const int64_t *doc_offsets, int64_t ndocs, int32_t *ids_out, int64_t ids_cap,
+                       int64_t *id_offsets_out, int max_ids_per_doc, int unk)
+{
+    Handle *h = as_handle(p);
+    if (!h) return BF_E_ARG;
+    return run_host(h, text, doc_offsets, ndocs, ids_out, ids_cap, id_offsets_out, max_ids_per_doc, unk);
+}
+
+int TextToIdsBatchDevice(void *p, const char *d_text, const int64_t *d_doc_offsets, int64_t ndocs, int64_t total_bytes,
+                         int32_t *d_ids_out, int64_t ids_cap, int64_t *d_id_offsets_out, int max_ids_per_doc, int unk, void *stream)
+{
+    Handle *h = as_handle(p);
+    if (!h) return BF_E_ARG;
+    std::lock_guard<std::mutex> lock(h->mu);
+    if (!hip_ok(hipSetDevice(h->device), "hipSetDevice")) return BF_E_DEVICE;
+    return run_device(h, d_text, d_doc_offsets, ndocs, total_bytes, d_ids_out, ids_cap, d_id_offsets_out, max_ids_per_doc, unk, (hipStream_t)stream);
+}
+
+int BfLastKernelMs(void *p, float *ms, int n)
+{
+    Handle *h = as_handle(p);
+    if (!h || !ms || n <= 0) return BF_E_ARG;
+    std::lock_guard<std::mutex> lock(h->mu);
+    if (!h->ev_valid) return 0;
+    if (!hip_ok(hipEventSynchronize(h->ev[EV_COMPACT]), "hipEventSynchronize")) return BF_E_DEVICE;
+    float v[5] = {0, 0, 0, 0, 0};
+    (void)hipEventElapsedTime(&v[0], h->ev[EV_BEGIN], h->ev[EV_PREP]);
+    (void)hipEventElapsedTime(&v[1], h->ev[EV_PREP], h->ev[EV_TOK]);
+    (void)hipEventElapsedTime(&v[2], h->ev[EV_TOK], h->ev[EV_SCAN]);
+    (void)hipEventElapsedTime(&v[3], h->ev[EV_SCAN], h->ev[EV_COMPACT]);
+    (void)hipEventElapsedTime(&v[4], h->ev[EV_BEGIN], h->ev[EV_COMPACT]);
+    int k = n < 5 ? n : 5;
+    for (int i = 0; i < k; ++i) ms[i] = v[i];
+    return k;
+}
+
+int BfLastStatus(void *p)
+{
+    Handle *h = as_handle(p);
+    if (!h) return BF_E_ARG;
+    std::lock_guard<std::mutex> lock(h->mu);
+    if (h->ev_valid) (void)hipEventSynchronize(h->ev[EV_COMPACT]);
+    int status = 0;
+    if (!hip_ok(hipMemcpy(&status, h->w_misc.as<char>() + 16, 4, hipMemcpyDeviceToHost), "D2H status")) return BF_E_DEVICE;
+    return status;
+}
+
+const char *BfLastError(void) { return g_last_error.c_str(); }
+
+int BfModelKind(void *p) { Handle *h = as_handle(p); return h ? h->m.kind : BF_E_ARG; }
+
+int BfSetVariant(void *p, int variant)
+{
+    Handle *h = as_handle(p);
+    if (!h) return BF_E_ARG;
+    std::lock_guard<std::mutex> lock(h->mu);
+    int old = h->variant; h->variant = variant; return old;
+}
+
+} // extern "C"

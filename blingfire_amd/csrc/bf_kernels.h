@@ -1,0 +1,53 @@
+// bf_kernels.h -- device-side parameter blocks + launch wrappers (implemented in bf_kernels.hip).
+#pragma once
+#include <stdint.h>
+#include <hip/hip_runtime_api.h>
+#include "bf_lex.h"
+
+namespace bfa {
+
+// Inputs shared by the prep kernels: the batch (concatenated documents) and where results go.
+struct Batch {
+    const uint8_t *text;        // concatenated UTF-8 documents
+    const int64_t *doc_off;     // [ndocs+1] byte offsets
+    int64_t ndocs;
+};
+
+// code point map (TwoLevelMap on the device)
+struct DevCpMap { const uint16_t *l1; const uint32_t *pages; };
+
+struct WpPrepParams {
+    Batch b;
+    DevCpMap cpmap;             // fused charmap+class map (bf_model.h Model::wbd_cpmap)
+    const uint16_t *multi_pool; // records for 0 / 2..10 output chars
+    int has_multi;
+    uint16_t *cls;              // [total_bytes] class stream: document d occupies cls[doc_off[d] ..)
+    int32_t *nchars;            // [ndocs] normalised length, 0 = "TextToIds returns 0"
+};
+
+struct WpLexParams {
+    LexTables L;
+    Batch b;
+    const uint16_t *cls;
+    const int32_t *nchars;
+    int32_t *ids_tmp;           // [total_bytes] staging: document d writes ids_tmp[doc_off[d] ..)
+    int32_t *counts;            // [ndocs]
+    int max_ids, unk;
+    unsigned long long *next_doc; // work counter (persistent variants)
+    int *status;
+};
+
+struct ScanParams { const int32_t *counts; int64_t ndocs; int64_t *id_off; int64_t *block_sums; int nblocks; };
+
+struct CompactParams {
+    Batch b; const int32_t *ids_tmp; const int32_t *counts; const int64_t *id_off;
+    int32_t *ids_out; int64_t ids_cap; int *status;
+};
+
+void launch_prep_wp(const WpPrepParams &p, hipStream_t s);
+void launch_lex_wp(const WpLexParams &p, int variant, hipStream_t s);
+void launch_scan(const ScanParams &p, hipStream_t s);
+void launch_compact(const CompactParams &p, hipStream_t s);
+int scan_nblocks(int64_t ndocs);
+
+} // namespace bfa

@@ -1,0 +1,104 @@
+/*
+ * blingfiretokdll_amd.h -- C-ABI of the MI355X-native drop-in for BlingFire's
+ * libblingfiretokdll (TextToIds hot path).
+ *
+ * The library is built as blingfire_amd/libblingfiretokdll.so and exports the SAME
+ * unmangled extern "C" symbols the reference's wrappers bind by name
+ * (reference: blingfiretools/blingfiretokdll/blingfiretokdll.h:23-104,
+ *  blingfiretools/blingfiretokdll/blingfiretokdll.def:3-26,
+ *  dist-pypi/blingfire/__init__.py:16-22,243-253, nuget/lib/BlingFireUtils.cs:23-35,195-215).
+ *
+ * All compute happens on the GPU (HIP, gfx950).  There is no CPU fallback: without a HIP
+ * device LoadModel/SetModel print a diagnostic to stderr and return NULL.
+ *
+ * Plain pointers and sizes only; no C++/torch types.  Batch entry points (additive, not in
+ * the reference) take either host buffers or device buffers + a hipStream_t passed as void*.
+ */
+#ifndef BLINGFIRETOKDLL_AMD_H
+#define BLINGFIRETOKDLL_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- reference entry points (same names, argument meaning and error behaviour) ---- */
+
+/* reference tokdll:107-111: returns 18000 for v0.1.8-compatible behaviour */
+int GetBlingFireTokVersion(void);
+
+/* reference tokdll:1077-1094.  Returns an opaque handle or NULL.  (The reference throws a C++
+ * exception through the C boundary for a nonexistent file; this returns NULL instead.) */
+void *LoadModel(const char *pszLdbFileName);
+
+/* reference tokdll:1056-1070.  The image is copied (the reference borrows it). */
+void *SetModel(const unsigned char *pImgBytes, int ModelByteCount);
+
+/* reference tokdll:1650-1662.  Returns 1, or 0 for a NULL handle. */
+int FreeModel(void *ModelPtr);
+
+/* reference tokdll:1619-1646.  Writes at most MaxIdsArrLength ids, leaves the rest of pIdsArr
+ * untouched, returns the number written; 0 on any error (NULL model/text, n <= 0, n > 1e9,
+ * invalid UTF-8 for non-byte models). */
+int TextToIds(void *ModelPtr, const char *pInUtf8Str, int InUtf8StrByteCount,
+              int32_t *pIdsArr, const int MaxIdsArrLength, const int UnkId);
+
+/* reference tokdll:1320-1331 and 1541-1552: the two algorithm-specific spellings */
+int TextToIds_wp(void *ModelPtr, const char *pInUtf8Str, int InUtf8StrByteCount,
+                 int32_t *pIdsArr, const int MaxIdsArrLength, const int UnkId);
+int TextToIds_sp(void *ModelPtr, const char *pInUtf8Str, int InUtf8StrByteCount,
+                 int32_t *pIdsArr, const int MaxIdsArrLength, const int UnkId);
+
+/* reference tokdll:1669-1679 */
+int SetNoDummyPrefix(void *ModelPtr, int fNoDummyPrefix);
+
+/* ---- additive batch entry points (a GPU wants batches; semantics = "for every document,
+ *      exactly what TextToIds(h, doc, len, buf, max_ids_per_doc, unk) would have written",
+ *      concatenated in document order) ---- */
+
+/* Host buffers.  text = concatenated documents; doc_offsets[ndocs+1] = byte offsets.
+ * ids_out[ids_cap] receives the concatenated ids, id_offsets_out[ndocs+1] their boundaries.
+ * Returns the total number of ids, or a negative error code (BF_E_*). */
+int64_t TextToIdsBatch(void *ModelPtr, const char *text, const int64_t *doc_offsets, int64_t ndocs,
+                       int32_t *ids_out, int64_t ids_cap, int64_t *id_offsets_out,
+                       int max_ids_per_doc, int unk);
+
+/* Device buffers (all five pointers are device memory of the model's GPU).  Work is enqueued on
+ * `stream` (a hipStream_t; NULL = the default stream) and the call returns without synchronising:
+ * 0 = enqueued, negative = error.  The total id count is d_id_offsets_out[ndocs].  ids_cap must be
+ * >= min(total_bytes, ndocs * max_ids_per_doc) to be safe for any input; ids beyond ids_cap are dropped
+ * and reported by BfLastStatus.  d_text needs no padding. */
+int TextToIdsBatchDevice(void *ModelPtr, const char *d_text, const int64_t *d_doc_offsets, int64_t ndocs,
+                         int64_t total_bytes, int32_t *d_ids_out, int64_t ids_cap, int64_t *d_id_offsets_out,
+                         int max_ids_per_doc, int unk, void *stream);
+
+/* Per-kernel GPU time of the last batch call on this handle, measured with HIP events recorded on the
+ * call's own stream.  Synchronises with those events.  Fills up to n floats (milliseconds):
+ * [0] prep (decode+normalise+classify)  [1] tokenise (lexer / segmenter)  [2] scan  [3] compact  [4] total.
+ * Returns the number of values written, or a negative error. */
+int BfLastKernelMs(void *ModelPtr, float *ms, int n);
+
+/* Status word of the last batch call (synchronises): 0 = ok; bit 0 = ids_cap overflow; bit 1 = an internal
+ * per-document capacity was exceeded (results are not trustworthy; never expected for shipped models). */
+int BfLastStatus(void *ModelPtr);
+
+/* Last load error message of the calling thread ("" if none). */
+const char *BfLastError(void);
+
+/* Model facts: 0 = WordPiece lexer, 1 = Unigram-LM, 2 = BPE, 3 = BPE-opt, 4 = BPE with merge ranks */
+int BfModelKind(void *ModelPtr);
+
+/* tuning knob for experiments: selects a kernel variant (0 = default). Returns the previous value. */
+int BfSetVariant(void *ModelPtr, int variant);
+
+#define BF_E_ARG      (-1)   /* bad argument */
+#define BF_E_DEVICE   (-2)   /* HIP error */
+#define BF_E_CAPACITY (-3)   /* ids_cap too small */
+#define BF_E_INTERNAL (-4)   /* internal capacity exceeded */
+#define BF_E_UNSUPPORTED (-5)
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,84 @@
+/*
+ * cpu_baseline.c -- TEST / BENCH INFRASTRUCTURE: times a CPU TextToIds implementation on host cores.
+ *
+ * dlopen()s a library that exports the reference C-ABI (LoadModel / TextToIds / FreeModel) -- normally
+ * oracle/_ref/libblingfiretokdll_ref.so, the unmodified reference compiled by oracle/Makefile -- and calls
+ * TextToIds once per document from T threads sharing one model handle (the usage the reference recommends:
+ * README.md:105,215), static interleaved document assignment, per-thread id buffer.
+ * Used only by bench.py's cpu_baseline leg and by tests; never by the product.
+ */
+#define _GNU_SOURCE
+#include <dlfcn.h>
+#include <pthread.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+typedef void *(*load_fn)(const char *);
+typedef int (*free_fn)(void *);
+typedef int (*t2i_fn)(void *, const char *, int, int32_t *, int, int);
+
+typedef struct {
+    t2i_fn t2i; void *model; const char *text; const int64_t *off; int64_t ndocs; int max_ids, unk;
+    int tid, nthreads; int64_t ids; uint64_t checksum; int32_t *out_ids; int64_t *out_counts; int64_t stride;
+} job_t;
+
+static void *worker(void *arg)
+{
+    job_t *j = (job_t *)arg;
+    int32_t *buf = (int32_t *)malloc(sizeof(int32_t) * (size_t)(j->max_ids > 0 ? j->max_ids : 1));
+    for (int64_t d = j->tid; d < j->ndocs; d += j->nthreads) {
+        int32_t *dst = j->out_ids ? j->out_ids + d * j->stride : buf;
+        int n = j->t2i(j->model, j->text + j->off[d], (int)(j->off[d + 1] - j->off[d]), dst, j->max_ids, j->unk);
+        j->ids += n;
+        for (int k = 0; k < n; ++k) j->checksum = j->checksum * 1099511628211ull + (uint64_t)(uint32_t)dst[k] + (uint64_t)d;
+        if (j->out_counts) j->out_counts[d] = n;
+    }
+    free(buf);
+    return NULL;
+}
+
+/* Returns seconds of wall time for one pass (negative on error).  If out_ids != NULL it receives the ids of
+ * document d at out_ids[d*max_ids ..] and out_counts[d] the count (golden-file generation). */
+double bfc_time_text_to_ids(const char *lib_path, const char *model_path, const char *text, const int64_t *doc_off,
+                            int64_t ndocs, int max_ids, int unk, int nthreads, int passes, int64_t *total_ids,
+                            int32_t *out_ids, int64_t *out_counts)
+{
+    void *lib = dlopen(lib_path, RTLD_NOW | RTLD_LOCAL);
+    if (!lib) { fprintf(stderr, "cpu_baseline: dlopen(%s): %s\n", lib_path, dlerror()); return -1.0; }
+    load_fn load = (load_fn)dlsym(lib, "LoadModel");
+    free_fn fre = (free_fn)dlsym(lib, "FreeModel");
+    t2i_fn t2i = (t2i_fn)dlsym(lib, "TextToIds");
+    if (!load) {   /* the plain-C restatement (oracle/liboracle.so) spells the same three calls bfo_* */
+        load = (load_fn)dlsym(lib, "bfo_load_model"); fre = (free_fn)dlsym(lib, "bfo_free_model"); t2i = (t2i_fn)dlsym(lib, "bfo_text_to_ids");
+    }
+    if (!load || !fre || !t2i) { fprintf(stderr, "cpu_baseline: missing symbols in %s\n", lib_path); return -2.0; }
+    void *model = load(model_path);
+    if (!model) { fprintf(stderr, "cpu_baseline: LoadModel(%s) failed\n", model_path); return -3.0; }
+    if (nthreads < 1) nthreads = 1;
+    if (nthreads > 256) nthreads = 256;
+    if (passes < 1) passes = 1;
+    double best = 1e30; int64_t ids = 0;
+    for (int p = 0; p < passes; ++p) {
+        pthread_t th[256]; job_t jobs[256];
+        struct timespec t0, t1;
+        clock_gettime(CLOCK_MONOTONIC, &t0);
+        for (int t = 0; t < nthreads; ++t) {
+            memset(&jobs[t], 0, sizeof(job_t));
+            jobs[t].t2i = t2i; jobs[t].model = model; jobs[t].text = text; jobs[t].off = doc_off; jobs[t].ndocs = ndocs;
+            jobs[t].max_ids = max_ids; jobs[t].unk = unk; jobs[t].tid = t; jobs[t].nthreads = nthreads;
+            jobs[t].out_ids = out_ids; jobs[t].out_counts = out_counts; jobs[t].stride = max_ids;
+            pthread_create(&th[t], NULL, worker, &jobs[t]);
+        }
+        ids = 0;
+        for (int t = 0; t < nthreads; ++t) { pthread_join(th[t], NULL); ids += jobs[t].ids; }
+        clock_gettime(CLOCK_MONOTONIC, &t1);
+        double s = (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+        if (s < best) best = s;
+    }
+    if (total_ids) *total_ids = ids;
+    fre(model);
+    return best;
+}

@@ -1,0 +1,227 @@
+"""Shared TEST / BENCH helpers (not part of the product): synthetic corpora, the oracle and the
+compiled reference as checkers, the CPU-baseline timer.  Only tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg use this module; the product (blingfire_amd/) never imports it."""
+import ctypes
+import os
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+MODELS = os.path.join(ROOT, "models")
+ORACLE_LIB = os.path.join(ROOT, "oracle", "liboracle.so")
+REF_LIB = os.path.join(ROOT, "oracle", "_ref", "libblingfiretokdll_ref.so")
+CPUBASE_LIB = os.path.join(ROOT, "oracle", "libcpubaseline.so")
+CORPUSGEN_LIB = os.path.join(ROOT, "tools", "libcorpusgen.so")
+HOSTTEST_LIB = os.path.join(ROOT, "tests", "hosttest", "libbf_hosttest.so")
+WORDS_EN = os.path.join(ROOT, "tests", "data", "words_en.txt")
+
+
+def model_path(name):
+    return os.path.join(MODELS, name)
+
+
+def have_model(name):
+    return os.path.exists(model_path(name))
+
+
+def bert_model_name():
+    """headline model: bert_base_tok.bin when the rebuilt file is present, else the checked-in cased sibling
+    (same engine and format, SURVEY.md §7 'Minimum slice')."""
+    return "bert_base_tok.bin" if have_model("bert_base_tok.bin") else "bert_base_cased_tok.bin"
+
+
+# ------------------------------------------------------------------------------------------------
+# oracle (plain-C restatement) and compiled reference
+# ------------------------------------------------------------------------------------------------
+class _T2I:
+    """TextToIds-style checker around a C library."""
+
+    def __init__(self, lib_path, load_name, t2i_name, free_name):
+        self.lib = ctypes.CDLL(lib_path)
+        self._load = getattr(self.lib, load_name)
+        self._load.restype = ctypes.c_void_p
+        self._load.argtypes = [ctypes.c_char_p]
+        self._t2i = getattr(self.lib, t2i_name)
+        self._t2i.restype = ctypes.c_int
+        self._t2i.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+        self._free = getattr(self.lib, free_name)
+        self._free.argtypes = [ctypes.c_void_p]
+
+    def load(self, path):
+        h = self._load(path.encode())
+        if not h:
+            raise RuntimeError("checker could not load %s" % path)
+        return h
+
+    def free(self, h):
+        self._free(ctypes.c_void_p(h))
+
+    def text_to_ids(self, h, b, max_ids, unk, sentinel=-7):
+        """returns (count, full buffer as list) with the buffer pre-filled with `sentinel`"""
+        n = max(max_ids, 1)
+        arr = (ctypes.c_int32 * n)(*([sentinel] * n))
+        c = self._t2i(ctypes.c_void_p(h), b, len(b), arr, max_ids, unk)
+        return c, list(arr)
+
+    def batch(self, h, text, off, max_ids, unk):
+        """per-document loop -> (ids int32[total], id_offsets int64[ndocs+1]) -- the golden form of TextToIdsBatch"""
+        ndocs = len(off) - 1
+        buf = (ctypes.c_int32 * max(max_ids, 1))()
+        out = []
+        id_off = np.zeros(ndocs + 1, dtype=np.int64)
+        raw = text.tobytes() if isinstance(text, np.ndarray) else bytes(text)
+        for d in range(ndocs):
+            b = raw[off[d]:off[d + 1]]
+            c = self._t2i(ctypes.c_void_p(h), b, len(b), buf, max_ids, unk)
+            out.append(np.frombuffer(buf, dtype=np.int32, count=c).copy())
+            id_off[d + 1] = id_off[d] + c
+        ids = np.concatenate(out) if out else np.zeros(0, dtype=np.int32)
+        return ids, id_off
+
+
+def oracle():
+    return _T2I(ORACLE_LIB, "bfo_load_model", "bfo_text_to_ids", "bfo_free_model")
+
+
+def have_ref():
+    return os.path.exists(REF_LIB)
+
+
+def reference():
+    return _T2I(REF_LIB, "LoadModel", "TextToIds", "FreeModel")
+
+
+def checker_lib_path():
+    """the CPU TextToIds used as golden/CPU baseline: the compiled reference when present, else the oracle port"""
+    return (REF_LIB, "reference") if have_ref() else (ORACLE_LIB, "port")
+
+
+def cpu_text_to_ids_batch(lib_path, model, text, off, max_ids, unk, nthreads=None, passes=1, want_ids=True):
+    """Runs TextToIds per document on host threads through oracle/libcpubaseline.so.
+    Returns (seconds, total_ids, ids int32[total] or None, id_offsets or None)."""
+    L = ctypes.CDLL(CPUBASE_LIB)
+    f = L.bfc_time_text_to_ids
+    f.restype = ctypes.c_double
+    f.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_int,
+                  ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+    text = np.ascontiguousarray(text, dtype=np.uint8)
+    off = np.ascontiguousarray(off, dtype=np.int64)
+    ndocs = len(off) - 1
+    if nthreads is None:
+        nthreads = os.cpu_count() or 1
+    total = ctypes.c_int64(0)
+    out_ids = out_counts = None
+    if want_ids:
+        out_ids = np.empty((ndocs, max(max_ids, 1)), dtype=np.int32)
+        out_counts = np.zeros(ndocs, dtype=np.int64)
+    # oracle library exports bfo_* names; the driver wants the reference names -> use a tiny shim for the port
+    path = lib_path
+    secs = f(path.encode(), model.encode(), text.ctypes.data, off.ctypes.data, ndocs, max_ids, unk, nthreads, passes,
+             ctypes.byref(total), out_ids.ctypes.data if want_ids else None, out_counts.ctypes.data if want_ids else None)
+    if secs < 0:
+        raise RuntimeError("cpu baseline driver failed (%s)" % secs)
+    if not want_ids:
+        return secs, total.value, None, None
+    id_off = np.zeros(ndocs + 1, dtype=np.int64)
+    np.cumsum(out_counts, out=id_off[1:])
+    mask = np.arange(out_ids.shape[1])[None, :] < out_counts[:, None]
+    return secs, total.value, out_ids[mask], id_off
+
+
+# ------------------------------------------------------------------------------------------------
+# synthetic corpora (tools/corpusgen.c)
+# ------------------------------------------------------------------------------------------------
+_words_cache = None
+
+
+def _words():
+    global _words_cache
+    if _words_cache is None:
+        ws = [w.encode() for w in open(WORDS_EN).read().split()]
+        blob = np.frombuffer(b"".join(ws), dtype=np.uint8).copy()
+        woff = np.zeros(len(ws) + 1, dtype=np.int32)
+        np.cumsum([len(w) for w in ws], out=woff[1:])
+        ranks = np.arange(1, len(ws) + 1, dtype=np.float64)
+        p = ranks ** -1.07
+        cdf = np.cumsum(p / p.sum())
+        cdf[-1] = 1.0
+        _words_cache = (blob, woff, cdf)
+    return _words_cache
+
+
+def gen_corpus(ndocs, seed=20240202, mean=128, sd=16, minlen=32, maxlen=256, loguniform=False, multibyte=False,
+               first_doc=0, nthreads=None):
+    """Deterministic synthetic corpus.  Returns (text uint8[total], doc_off int64[ndocs+1])."""
+    L = ctypes.CDLL(CORPUSGEN_LIB)
+    f = L.bfc_gen
+    f.restype = ctypes.c_int64
+    f.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int64, ctypes.c_int64,
+                  ctypes.c_int, ctypes.c_double, ctypes.c_double, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
+                  ctypes.c_void_p, ctypes.c_int]
+    blob, woff, cdf = _words()
+    off = np.zeros(ndocs + 1, dtype=np.int64)
+    args = [blob.ctypes.data, woff.ctypes.data, len(woff) - 1, cdf.ctypes.data, seed, first_doc, ndocs,
+            1 if loguniform else 0, float(mean), float(sd), minlen, maxlen, 1 if multibyte else 0]
+    total = f(*args, None, off.ctypes.data, 1)
+    text = np.empty(total, dtype=np.uint8)
+    f(*args, text.ctypes.data, off.ctypes.data, nthreads or min(os.cpu_count() or 1, 16))
+    return text, off
+
+
+WORKLOADS = {
+    # name: generator kwargs + tokenizer call parameters
+    "headline512": dict(model=None, gen=dict(seed=20240201, mean=512, sd=64, minlen=128, maxlen=1024), max_ids=512, unk=100),
+    "config2": dict(model=None, gen=dict(seed=20240202, mean=128, sd=16, minlen=32, maxlen=256), max_ids=512, unk=100),
+    "config3": dict(model="gpt2.bin", gen=dict(seed=3, minlen=32, maxlen=2048, loguniform=True, multibyte=True), max_ids=2048, unk=0),
+}
+
+
+ADVERSARIAL = [
+    b"a", b" ", b"   ", b"\xef\xbb\xbf", b"\xef\xbb\xbfhello", b"hello", b"   hello  ", b"Hello, world! This is a test.",
+    b"Hello, world! This is a test of unaffable.", b"Hello unaffable qzxjkvw [UNK] world", b"Hello unaffable world again",
+    b"ab\xff cd", b"ab\xff\xfecd", b"ab\x00cd", b"ab\x01\x02cd", "café naïve".encode(), b"a" * 400, "́".encode(),
+    "Эpple pie.".encode(), "Sergei Alonichau I saw a girl with a \ttelescope.".encode(), "好好好 ok".encode(),
+    "à la".encode(), b"a la", b"\xc0\xaf", b"\xe0\x80\xaf", b"\xed\xa0\x80", b"\xf4\x90\x80\x80", b"\xf8\x88\x80\x80\x80",
+    b"\xe2\x82", b"abc\xe2\x82", b"\x80abc", b"abc\x80", b"abc\xc3", "\U0001F600 smile \U00010000".encode(),
+    "a b c‏d e f⁠g␠h␤i　j﻿k".encode(), "ª ﬁ ㍿".encode(),
+    "▁▁ a ▁ b  ▁".encode(), b"[UNK] [CLS] [SEP] [MASK] [PAD]", b"don't U.S.A. e-mail 3,000.50", b"x" * 299 + b" " + b"y" * 301,
+    ("word " * 200).encode(), b"\t\n\r\x0b\x0c", b"\x7f\x1f", "İstanbul ǅ ß".encode(), b"A" * 1025,
+]
+
+
+def fuzz_docs(n, seed=1, maxwords=60):
+    """mixed adversarial documents: real words, control chars, astral code points, random bytes, broken UTF-8"""
+    import random
+    rnd = random.Random(seed)
+    words = ("the of and to in a is that for it as was with be by on not he I this are or his from at which but have an had "
+             "they you were their one all we can her has there been if more when will would who so no Hello unaffable qzxjkvw "
+             "[UNK] [CLS] world café naïve 好好 好 привет мир Sergei Alonichau telescope . , ! ? ; : ' \" ( ) - 123 4.5 \t ▁ ﬁ ª ㍿ "
+             "́ é Ünïcödé ß Straße İstanbul ǅ 𝒳 😀 don't U.S.A. e-mail 3,000.50 http://a.b/c?d=e&f x@y.com ##ing á "
+             "​   ١٢٣ עברית").split(" ")
+    alpha = "abcdefghijklmnopqrstuvwxyzABCDEFGHIJKLMNOPQRSTUVWXYZ0123456789"
+    docs = []
+    while len(docs) < n:
+        r = rnd.random()
+        if r < 0.05:
+            b = bytes(rnd.randrange(256) for _ in range(rnd.randint(1, 40)))
+        elif r < 0.1:
+            b = "".join(rnd.choice(alpha) for _ in range(rnd.randint(250, 700))).encode()
+        else:
+            parts = []
+            for _ in range(rnd.randint(0, maxwords)):
+                q = rnd.random()
+                if q < 0.08:
+                    parts.append("".join(rnd.choice(alpha) for _ in range(rnd.randint(1, 20))))
+                elif q < 0.11:
+                    parts.append(chr(rnd.choice([0, 1, 2, 3, 0x7f, 0x85, 0x2028, 0xfeff, 0x10000, 0x10ffff, 0xe000, 0xd7ff])))
+                else:
+                    parts.append(rnd.choice(words))
+            b = rnd.choice([" ", " ", "  ", "\n", ""]).join(parts).encode("utf-8")
+            if rnd.random() < 0.05 and len(b) > 2:
+                i = rnd.randrange(len(b))
+                b = b[:i] + bytes([rnd.randrange(256)]) + b[i + 1:]
+            if rnd.random() < 0.03:
+                b = b"\xef\xbb\xbf" + b
+        if b:
+            docs.append(b)
+    return docs

@@ -1,0 +1,101 @@
+"""GPU parity, WordPiece path: the HIP pipeline (through the C-ABI) vs the CPU checker on the same inputs.
+Bar: bit-exact ids and counts (integer work)."""
+import numpy as np
+import pytest
+
+import bfutil
+import blingfire_amd as bf
+
+pytestmark = pytest.mark.gpu
+
+WP_MODELS = [m for m in ("bert_base_tok.bin", "bert_base_cased_tok.bin", "bert_chinese.bin", "wbd.bin", "sbd.bin") if bfutil.have_model(m)]
+
+
+@pytest.fixture(scope="module")
+def checker():
+    return bfutil.reference() if bfutil.have_ref() else bfutil.oracle()
+
+
+def _compare(h, ck, hck, docs, max_ids, unk):
+    text, off = bf.pack_docs(docs)
+    ids, id_off = bf.text_to_ids_batch(h, (text, off), max_ids, unk)
+    gids, goff = ck.batch(hck, text, off, max_ids, unk)
+    if not np.array_equal(id_off, goff) or not np.array_equal(ids, gids):
+        for d in range(len(docs)):
+            a = ids[id_off[d]:id_off[d + 1]]
+            b = gids[goff[d]:goff[d + 1]]
+            if not np.array_equal(a, b):
+                raise AssertionError("doc %d %r (max %d unk %d): gpu %s != ref %s" % (d, docs[d][:80], max_ids, unk, a[:40], b[:40]))
+        raise AssertionError("offset arrays differ")
+
+
+@pytest.mark.parametrize("model", WP_MODELS)
+def test_adversarial_and_fuzz(model, checker):
+    h = bf.load_model(bfutil.model_path(model))
+    hck = checker.load(bfutil.model_path(model))
+    try:
+        docs = list(bfutil.ADVERSARIAL) + bfutil.fuzz_docs(3000, seed=11)
+        for max_ids, unk in ((512, 100), (3, 100), (1, 0), (64, 7)):
+            _compare(h, checker, hck, docs, max_ids, unk)
+    finally:
+        bf.free_model(h)
+        checker.free(hck)
+
+
+def test_single_doc_api_untouched_tail(checker):
+    """TextToIds writes only `count` ids: the rest of the caller's array is untouched (tokdll:1098-1101)."""
+    model = bfutil.bert_model_name()
+    h = bf.load_model(bfutil.model_path(model))
+    hck = checker.load(bfutil.model_path(model))
+    try:
+        import ctypes
+        for b in bfutil.ADVERSARIAL:
+            for max_ids in (0, 3, 64):
+                n = max(max_ids, 1)
+                arr = (ctypes.c_int32 * n)(*([-7] * n))
+                c = bf.lib().TextToIds(ctypes.c_void_p(h), b, len(b), arr, max_ids, 100)
+                gc, gbuf = checker.text_to_ids(hck, b, max_ids, 100)
+                assert (c, list(arr)) == (gc, gbuf), (b, max_ids)
+        assert bf.lib().TextToIds(None, b"abc", 3, None, 4, 0) == 0
+        assert bf.text_to_ids(h, "", 8).tolist() == [0] * 8
+    finally:
+        bf.free_model(h)
+        checker.free(hck)
+
+
+def test_config2_corpus_bit_exact(checker):
+    """BASELINE.json configs[1] at a size the CPU checker finishes in seconds; golden from the compiled reference."""
+    model = bfutil.bert_model_name()
+    text, off = bfutil.gen_corpus(20000, **bfutil.WORKLOADS["config2"]["gen"])
+    lib_path, _ = bfutil.checker_lib_path()
+    _, _, gids, goff = bfutil.cpu_text_to_ids_batch(lib_path, bfutil.model_path(model), text, off, 512, 100)
+    h = bf.load_model(bfutil.model_path(model))
+    try:
+        ids, id_off = bf.text_to_ids_batch(h, (text, off), 512, 100)
+        assert np.array_equal(id_off, goff)
+        assert np.array_equal(ids, gids)
+    finally:
+        bf.free_model(h)
+
+
+def test_headline_corpus_properties():
+    """Full-size-independent properties on the 512-byte north-star documents: determinism, shard invariance
+    (tokenising any contiguous shard == the slice of the whole), truncation prefix property."""
+    model = bfutil.bert_model_name()
+    text, off = bfutil.gen_corpus(30000, **bfutil.WORKLOADS["headline512"]["gen"])
+    h = bf.load_model(bfutil.model_path(model))
+    try:
+        ids, id_off = bf.text_to_ids_batch(h, (text, off), 512, 100)
+        ids2, id_off2 = bf.text_to_ids_batch(h, (text, off), 512, 100)
+        assert np.array_equal(ids, ids2) and np.array_equal(id_off, id_off2)
+        lo, hi = 7000, 19000
+        sids, soff = bf.text_to_ids_batch(h, (text, off[lo:hi + 1]), 512, 100)
+        assert np.array_equal(sids, ids[id_off[lo]:id_off[hi]])
+        assert np.array_equal(soff, id_off[lo:hi + 1] - id_off[lo])
+        tids, toff = bf.text_to_ids_batch(h, (text, off), 16, 100)
+        cnt = np.minimum(np.diff(id_off), 16)
+        assert np.array_equal(np.diff(toff), cnt)
+        for d in range(0, 30000, 997):
+            assert np.array_equal(tids[toff[d]:toff[d + 1]], ids[id_off[d]:id_off[d] + cnt[d]])
+    finally:
+        bf.free_model(h)
