@@ -1,0 +1,60 @@
+"""CPU: (1) the GPU table layout built by the product's loader realises the same automaton as the packed image
+(exhaustive state x symbol comparison against the oracle's readers -- the reference's `--auto-test` idea,
+blingfirecompile.library/inc/FATestCmpDfa.h:29-54); (2) the per-lane device programs, compiled for the host by
+tests/hosttest (test-only), produce the oracle's ids on adversarial + fuzz input."""
+import ctypes
+
+import pytest
+
+import bfutil
+
+ALL_MODELS = ["wbd.bin", "wbd_chuni.bin", "sbd.bin", "bert_base_tok.bin", "bert_base_cased_tok.bin", "bert_chinese.bin", "gpt2.bin", "roberta.bin",
+              "xlnet.bin", "xlnet_nonorm.bin", "bpe_example.bin", "laser100k.bin", "xlm_roberta_base.bin", "laser500k.bin"]
+
+
+@pytest.fixture(scope="module")
+def ht():
+    L = ctypes.CDLL(bfutil.HOSTTEST_LIB)
+    L.bft_load.restype = ctypes.c_void_p
+    L.bft_load.argtypes = [ctypes.c_char_p]
+    L.bft_error.restype = ctypes.c_char_p
+    L.bft_error.argtypes = [ctypes.c_void_p]
+    L.bft_free.argtypes = [ctypes.c_void_p]
+    L.bft_verify_tables.restype = ctypes.c_long
+    L.bft_verify_tables.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    L.bft_emu_text_to_ids.restype = ctypes.c_int
+    L.bft_emu_text_to_ids.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+    return L
+
+
+@pytest.mark.parametrize("model", ALL_MODELS)
+def test_gpu_tables_equal_packed_image(ht, model):
+    if not bfutil.have_model(model):
+        pytest.skip("%s not present" % model)
+    h = ht.bft_load(bfutil.model_path(model).encode())
+    assert ht.bft_error(h) == b"", ht.bft_error(h)
+    assert ht.bft_verify_tables(h, 1) == 0
+    ht.bft_free(h)
+
+
+@pytest.mark.parametrize("model", ALL_MODELS)
+def test_lane_programs_on_host_match_oracle(ht, model):
+    if not bfutil.have_model(model):
+        pytest.skip("%s not present" % model)
+    ora = bfutil.oracle()
+    h = ht.bft_load(bfutil.model_path(model).encode())
+    assert ht.bft_error(h) == b""
+    ho = ora.load(bfutil.model_path(model))
+    docs = list(bfutil.ADVERSARIAL) + bfutil.fuzz_docs(4000, seed=31)
+    for k, b in enumerate(docs):
+        mx = (512, 3, 64, 1, 2048, 0)[k % 6]
+        unk = (100, 0, 3, 257)[k % 4]
+        n = max(mx, 1)
+        arr = (ctypes.c_int32 * n)()
+        c = ht.bft_emu_text_to_ids(h, b, len(b), arr, mx, unk)
+        if c == -1:
+            pytest.skip("lane program for this model kind is not implemented yet")
+        gc, gbuf = ora.text_to_ids(ho, b, mx, unk)
+        assert c == gc and list(arr)[:c] == gbuf[:gc], (model, b[:60], mx, unk)
+    ora.free(ho)
+    ht.bft_free(h)
