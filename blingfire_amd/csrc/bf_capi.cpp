@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -58,7 +59,7 @@ struct Handle {
     uint32_t magic = 0xB1F14E01u;
     Model m;
     int device = 0;
-    int variant = 0;
+    int variant = 3;
     std::mutex mu;
     // device tables
     DevBuf t_wbd, t_info, t_acts, t_cp_l1, t_cp_pages, t_multi;
@@ -99,11 +100,12 @@ Handle *make_handle(const uint8_t *img, size_t size)
         delete h; return nullptr;
     }
     if (hipGetDevice(&h->device) != hipSuccess) h->device = 0;
+    if (const char *v = getenv("BF_LEX_VARIANT")) h->variant = atoi(v);      // experiments only
     Model &m = h->m;
     bool ok = true;
     if (m.kind == KIND_WP) {
         if (m.max_depth > LEX_MAX_DEPTH) { g_last_error = "lexer max-depth exceeds the supported 4"; fprintf(stderr, "[blingfire_amd] %s\n", g_last_error.c_str()); delete h; return nullptr; }
-        ok = ok && upload(h->t_wbd, m.wbd.t32, 16) && upload(h->t_info, m.wbd_info, 16) && upload(h->t_acts, m.acts_pool, 16) &&
+        ok = ok && upload(h->t_wbd, m.wbd_t2, 16) && upload(h->t_acts, m.acts_pool, 16) &&
              upload(h->t_cp_l1, m.wbd_cpmap.l1) && upload(h->t_cp_pages, m.wbd_cpmap.pages) && upload(h->t_multi, m.wbd_multi_pool, 16);
     } else {
         g_last_error = "segmenter models are not wired yet";
@@ -125,7 +127,7 @@ int run_device(Handle *h, const char *d_text, const int64_t *d_doc_off, int64_t 
     Model &m = h->m;
     const int nblocks = scan_nblocks(ndocs);
     if (!h->w_nchars.reserve((size_t)(ndocs + 1) * 4) || !h->w_counts.reserve((size_t)(ndocs + 1) * 4) ||
-        !h->w_bsums.reserve((size_t)(nblocks + 1) * 8) || !h->w_tmp.reserve((size_t)(total_bytes + 16) * 4)) return BF_E_DEVICE;
+        !h->w_bsums.reserve((size_t)(nblocks + 1) * 8) || !h->w_tmp.reserve((size_t)(total_bytes + 8 * ndocs + 64) * 4)) return BF_E_DEVICE;
     Batch b{(const uint8_t *)d_text, d_doc_off, ndocs};
     unsigned long long *next_doc = h->w_misc.as<unsigned long long>();
     int *status = (int *)(h->w_misc.as<char>() + 16);
@@ -138,12 +140,12 @@ int run_device(Handle *h, const char *d_text, const int64_t *d_doc_off, int64_t 
         if (ndocs > 0) launch_prep_wp(pp, s);
         (void)hipEventRecord(h->ev[EV_PREP], s);
         WpLexParams lp;
-        lp.L.T = h->t_wbd.as<uint32_t>(); lp.L.info = h->t_info.as<uint32_t>(); lp.L.acts = h->t_acts.as<int32_t>();
+        lp.L.T = h->t_wbd.as<uint64_t>(); lp.L.acts = h->t_acts.as<int32_t>();
         lp.L.initial = m.wbd.initial_base; lp.L.cls_any = m.cls_any; lp.L.cls_l = m.cls_l; lp.L.cls_r = m.cls_r;
-        lp.L.max_depth = m.max_depth; lp.L.max_token_length = m.max_token_length;
+        lp.L.max_depth = m.max_depth; lp.L.max_token_length = m.max_token_length; lp.L.max_frames = m.lex_frames;
         lp.b = b; lp.cls = h->w_cls.as<uint16_t>(); lp.nchars = h->w_nchars.as<int32_t>();
         lp.ids_tmp = h->w_tmp.as<int32_t>(); lp.counts = h->w_counts.as<int32_t>();
-        lp.max_ids = max_ids; lp.unk = unk; lp.next_doc = next_doc; lp.status = status;
+        lp.max_ids = max_ids; lp.unk = unk; lp.next_doc = next_doc; lp.status = status; lp.ev_thresh = 0; lp.fetch_thresh = 0; lp.acts_n = (int)m.acts_pool.size();
         if (ndocs > 0) launch_lex_wp(lp, h->variant, s);
         (void)hipEventRecord(h->ev[EV_TOK], s);
     } else {

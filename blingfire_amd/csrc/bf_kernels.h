@@ -35,6 +35,8 @@ struct WpLexParams {
     int max_ids, unk;
     unsigned long long *next_doc; // work counter (persistent variants)
     int *status;
+    int ev_thresh, fetch_thresh;  // vote thresholds of the divergence-aware driver
+    int acts_n;                   // ints in L.acts (staged in LDS when small)
 };
 
 struct ScanParams { const int32_t *counts; int64_t ndocs; int64_t *id_off; int64_t *block_sums; int nblocks; };

@@ -152,29 +152,200 @@ void launch_prep_wp(const WpPrepParams &p, hipStream_t s)
 }
 
 // ------------------------------------------------------------------------------------------
-// k_lex_wp variant 0: one document per lane, static assignment, the sequential program of
-// bf_lex.h executed as-is (the compiler's reconvergence gives "walk until every lane's walk
-// ends, then handle matches").
+// k_lex_wp: one document per lane (bf_lex.h).  Staging slot of document d in ids_tmp (32-byte aligned so that
+// 8-id chunks are whole 32-byte sectors): base = align8(doc_off[d]) + 8*d.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_lex_wp_v0(WpLexParams p)
+__host__ __device__ __forceinline__ int64_t ids_slot(int64_t doc_off_d, int64_t d) { return ((doc_off_d + 7) & ~(int64_t)7) + 8 * d; }
+
+// 16-byte register window over the lane's class stream: one dwordx4 load per 8 characters
+struct ClsWin {
+    const uint4 *base; int shift; uint4 w; int tag;
+    __device__ __forceinline__ void init(const uint16_t *cls)
+    {
+        const uintptr_t a = (uintptr_t)cls;
+        base = (const uint4 *)(a & ~(uintptr_t)15); shift = (int)((a & 15) >> 1); tag = -1; w = make_uint4(0, 0, 0, 0);
+    }
+    __device__ __forceinline__ uint32_t operator()(int i)
+    {
+        const int a = i + shift, t = a >> 3;
+        if (t != tag) { w = base[t]; tag = t; }
+        const uint32_t lo = (a & 2) ? w.y : w.x, hi = (a & 2) ? w.w : w.z;
+        const uint32_t dw = (a & 4) ? hi : lo;
+        return (a & 1) ? (dw >> 16) : (dw & 0xFFFFu);
+    }
+};
+
+// saved frames in LDS, structure-of-arrays (bank = lane): word (d, field) of lane t at [(d*12 + field) * nthreads + t]
+struct FramesLds {
+    int32_t *lds; int nthreads;
+    __device__ __forceinline__ void save(int d, const LexFrame &f)
+    {
+        int32_t *q = lds + (size_t)d * LEX_FRAME_WORDS * nthreads + threadIdx.x;
+        q[0] = (int32_t)f.ini; q[1 * nthreads] = f.off; q[2 * nthreads] = f.n; q[3 * nthreads] = f.from; q[4 * nthreads] = f.once;
+        q[5 * nthreads] = f.a_idx; q[6 * nthreads] = f.a_end; q[7 * nthreads] = f.to2; q[8 * nthreads] = f.fn_once;
+        q[9 * nthreads] = f.fp_r; q[10 * nthreads] = f.fn_from; q[11 * nthreads] = f.emit_mark;
+    }
+    __device__ __forceinline__ void load(int d, LexFrame &f) const
+    {
+        const int32_t *q = lds + (size_t)d * LEX_FRAME_WORDS * nthreads + threadIdx.x;
+        f.ini = (uint32_t)q[0]; f.off = q[1 * nthreads]; f.n = q[2 * nthreads]; f.from = q[3 * nthreads]; f.once = q[4 * nthreads];
+        f.a_idx = q[5 * nthreads]; f.a_end = q[6 * nthreads]; f.to2 = q[7 * nthreads]; f.fn_once = q[8 * nthreads];
+        f.fp_r = q[9 * nthreads]; f.fn_from = q[10 * nthreads]; f.emit_mark = q[11 * nthreads];
+    }
+};
+
+// id chunk buffer in LDS (8 ids per lane, structure-of-arrays): ids leave the lane as whole 32-byte sectors
+struct IdOutLds {
+    int32_t *slot; int32_t *buf; int nthreads; int cb;     // buf = &lds_idbuf[threadIdx.x]; word i at buf[i * nthreads]
+    __device__ __forceinline__ void init(int32_t *s) { slot = s; cb = -1; }
+    __device__ __forceinline__ void flush()
+    {
+        int4 *q = (int4 *)(slot + (int64_t)cb * 8);
+        q[0] = make_int4(buf[0], buf[nthreads], buf[2 * nthreads], buf[3 * nthreads]);
+        q[1] = make_int4(buf[4 * nthreads], buf[5 * nthreads], buf[6 * nthreads], buf[7 * nthreads]);
+    }
+    __device__ __forceinline__ void put(int k, int32_t v)
+    {
+        const int c = k >> 3;
+        if (c != cb) {
+            if (c > cb) { if (cb >= 0) flush(); }
+            else {   // rewind into an earlier chunk (UNK after a long run of tentative sub-tokens): reload it
+                const int4 *q = (const int4 *)(slot + (int64_t)c * 8);
+                const int4 a = q[0], b = q[1];
+                buf[0] = a.x; buf[nthreads] = a.y; buf[2 * nthreads] = a.z; buf[3 * nthreads] = a.w;
+                buf[4 * nthreads] = b.x; buf[5 * nthreads] = b.y; buf[6 * nthreads] = b.z; buf[7 * nthreads] = b.w;
+            }
+            cb = c;
+        }
+        buf[(k & 7) * nthreads] = v;
+    }
+    __device__ __forceinline__ void finish(int count) { if (cb >= 0 && cb * 8 < count) flush(); }
+};
+
+// variant 1: sequential driver (bf_lex.h lex_doc), static document-per-thread assignment.  The compiler's
+// reconvergence makes every wave walk until ALL its lanes' walks end, then handle matches.
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void k_lex_wp_seq(WpLexParams p)
 {
-    const int64_t d = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    extern __shared__ int32_t lex_lds[];
+    const int64_t d = (int64_t)blockIdx.x * THREADS + threadIdx.x;
     if (d >= p.b.ndocs) return;
     const int64_t b = p.b.doc_off[d];
     const int64_t nbytes = p.b.doc_off[d + 1] - b;
     const int n = p.nchars[d];
-    const uint16_t *cls = p.cls + b;
     int cap = p.max_ids; if ((int64_t)cap > nbytes) cap = (int)nbytes;
     if (cap < 0) cap = 0;
-    const int c = lex_doc(p.L, [cls](int i) -> uint32_t { return cls[i]; }, n, p.ids_tmp + b, cap, p.unk);
-    p.counts[d] = c;
+    ClsWin cls_at; cls_at.init(p.cls + b);
+    IdOutLds out; out.buf = lex_lds + (size_t)p.L.max_frames * LEX_FRAME_WORDS * THREADS + threadIdx.x; out.nthreads = THREADS;
+    out.init(p.ids_tmp + ids_slot(b, d));
+    FramesLds frames{lex_lds, THREADS};
+    p.counts[d] = lex_doc(p.L, cls_at, n, out, cap, p.unk, frames);
 }
+
+// variant 3 (default): divergence-aware driver.  Lanes are persistent and pull documents from a global
+// counter; every loop iteration a lane in WALK mode makes exactly one DFA transition, while the heavier
+// "event" code (match handling, calls/returns, next start position) and the document fetch run only when
+// enough lanes of the wave are waiting for them (ballot vote), so that they execute with most lanes active.
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void k_lex_wp_flat(WpLexParams p)
+{
+    extern __shared__ int32_t lex_lds[];
+    enum { M_NEED = 0, M_WALK = 1, M_EVENT = 2, M_EXIT = 3 };
+    ClsWin cls_at; cls_at.init(p.cls);
+    IdOutLds out; out.buf = lex_lds + (size_t)p.L.max_frames * LEX_FRAME_WORDS * THREADS + threadIdx.x; out.nthreads = THREADS;
+    out.init(p.ids_tmp);
+    FramesLds frames{lex_lds, THREADS};
+    // the (tiny) action pool is staged in LDS so that match handling touches no global memory
+    LexTables L = p.L;
+    if (p.acts_n > 0) {
+        int32_t *acts_lds = lex_lds + ((size_t)p.L.max_frames * LEX_FRAME_WORDS + 8) * THREADS;
+        for (int i = threadIdx.x; i < p.acts_n; i += THREADS) acts_lds[i] = p.L.acts[i];
+        __syncthreads();
+        L.acts = acts_lds;
+    }
+    LexLane<ClsWin, IdOutLds, FramesLds> lane(L, cls_at, out, frames);
+    lane.init(0, 0, 0);
+    int mode = M_NEED;
+    int64_t doc = -1;
+    const int ev_thresh = p.ev_thresh, fetch_thresh = p.fetch_thresh;
+    for (;;) {
+        // ---- walk: every lane in WALK mode makes one DFA transition per trip, until enough lanes have a
+        //      finished walk (or nobody walks any more)
+        unsigned long long m_event;
+        for (;;) {
+            if (mode == M_WALK) { if (!lane.step()) mode = M_EVENT; }
+            const unsigned long long m_walk = __ballot(mode == M_WALK);
+            m_event = __ballot(mode == M_EVENT);
+            if (m_walk == 0 || __popcll(m_event) >= ev_thresh) break;
+        }
+        // ---- events: match handling, calls / returns, next start position
+        if (mode == M_EVENT) {
+            lane.after_walk();
+            if (lane.prepare()) mode = M_WALK;
+            else { p.counts[doc] = lane.finish(); mode = M_NEED; }
+        }
+        // ---- fetch documents for idle lanes
+        const unsigned long long m_need = __ballot(mode == M_NEED);
+        if (m_need) {
+            const unsigned long long m_busy = __ballot(mode == M_WALK || mode == M_EVENT);
+            if (__popcll(m_need) >= fetch_thresh || m_busy == 0) {
+                if (mode == M_NEED) {
+                    const int cnt = __popcll(m_need);
+                    const int leader = __ffsll((long long)m_need) - 1;
+                    unsigned long long base = 0;
+                    if (lane_id() == leader) base = atomicAdd(p.next_doc, (unsigned long long)cnt);
+                    base = __shfl(base, leader, 64);
+                    doc = (int64_t)base + __popcll(m_need & lanemask_lt());
+                    if (doc >= p.b.ndocs) mode = M_EXIT;
+                    else {
+                        const int64_t b = p.b.doc_off[doc];
+                        const int64_t nbytes = p.b.doc_off[doc + 1] - b;
+                        const int n = p.nchars[doc];
+                        int cap = p.max_ids; if ((int64_t)cap > nbytes) cap = (int)nbytes;
+                        if (cap < 0) cap = 0;
+                        cls_at.init(p.cls + b);
+                        out.init(p.ids_tmp + ids_slot(b, doc));
+                        lane.init(n, cap, p.unk);
+                        if (lane.prepare()) mode = M_WALK;
+                        else p.counts[doc] = lane.finish();          // empty / invalid document: 0 ids, stay idle
+                    }
+                }
+                if (__ballot(mode != M_EXIT) == 0) break;
+            }
+        }
+    }
+}
+
+static size_t lex_lds_bytes(const WpLexParams &p, int threads) { return (((size_t)p.L.max_frames * LEX_FRAME_WORDS + 8) * threads + (size_t)p.acts_n) * 4; }
 
 void launch_lex_wp(const WpLexParams &p, int variant, hipStream_t s)
 {
-    (void)variant;
-    const int64_t blocks = (p.b.ndocs + 255) / 256;
-    hipLaunchKernelGGL(k_lex_wp_v0, dim3((unsigned)blocks), dim3(256), 0, s, p);
+    const int kind = variant & 0xff;
+    if (kind == 1) {
+        const int64_t blocks = (p.b.ndocs + 63) / 64;
+        WpLexParams q = p; q.acts_n = 0;
+        hipLaunchKernelGGL(k_lex_wp_seq<64>, dim3((unsigned)blocks), dim3(64), lex_lds_bytes(q, 64), s, q);
+    } else {
+        WpLexParams q = p;
+        q.ev_thresh = (variant >> 8) & 0xff; if (q.ev_thresh == 0) q.ev_thresh = 32;
+        q.fetch_thresh = (variant >> 16) & 0xff; if (q.fetch_thresh == 0) q.fetch_thresh = 8;
+        q.acts_n = p.acts_n <= 2048 ? p.acts_n : 0;
+        int waves_per_cu = (variant >> 24) & 0x3f;
+        if (waves_per_cu == 0) {                                      // persistent: exactly the resident waves
+            int per_cu = 0, ncu = 256;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_lex_wp_flat<64>, 64, lex_lds_bytes(q, 64)) != hipSuccess || per_cu <= 0) per_cu = 16;
+            hipDeviceProp_t prop; int dev = 0;
+            if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ncu = prop.multiProcessorCount;
+            static_cast<void>(ncu);
+            waves_per_cu = per_cu;
+            (void)hipGetLastError();
+        }
+        int64_t blocks = 256 * (int64_t)waves_per_cu;
+        const int64_t need = (p.b.ndocs + 63) / 64;
+        if (blocks > need) blocks = need;
+        if (blocks < 1) blocks = 1;
+        hipLaunchKernelGGL(k_lex_wp_flat<64>, dim3((unsigned)blocks), dim3(64), lex_lds_bytes(q, 64), s, q);
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -256,7 +427,7 @@ __global__ __launch_bounds__(256) void k_compact(CompactParams p)
     const int64_t nwaves = (int64_t)gridDim.x * 4;
     for (int64_t d = wave0; d < p.b.ndocs; d += nwaves) {
         const int c = p.counts[d];
-        const int32_t *src = p.ids_tmp + p.b.doc_off[d];
+        const int32_t *src = p.ids_tmp + ids_slot(p.b.doc_off[d], d);
         const int64_t o = p.id_off[d];
         for (int i = lane; i < c; i += 64) {
             if (o + i < p.ids_cap) p.ids_out[o + i] = src[i];

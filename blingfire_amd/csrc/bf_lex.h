@@ -3,12 +3,18 @@
 // Reproduces, on the re-laid-out tables of bf_model.h, the reference
 //   FALexTools_t<int>::Process_int          (blingfireclient.library/inc/FALexTools_t.h:205-400)
 //   + the TextToIdsWithOffsets_wp post-pass (blingfiretools/blingfiretokdll/blingfiretokdll.cpp:1207-1313)
-// fused: <tag,from,to> triples are consumed by the post-pass as they are produced,
-// so no triple buffer exists.  Recursion (_call functions) is an explicit frame stack.
+// fused: <tag,from,to> triples are consumed by the post-pass as they are produced, so no triple
+// buffer exists.  Recursion (_call functions) is an explicit frame stack.
 //
-// The code is written once as BF_HD functions: the HIP kernel (bf_kernels.hip) runs it per
-// lane; tests/hosttest compiles the same header for the host to fuzz it against the oracle
-// without a GPU (test-only: the product library never executes it on the CPU).
+// The program is a resumable state machine (LexLane): prepare() runs everything between two DFA
+// walks (calls/returns, start-position advance), step() is exactly one DFA transition, after_walk()
+// consumes the result of a walk.  A sequential driver (lex_doc) and the divergence-aware GPU driver
+// (bf_kernels.hip: lanes vote on when to run the "event" code) call the same methods, so the order of
+// operations per document is always the reference's.
+//
+// Written once as BF_HD code: the HIP kernels run it per lane; tests/hosttest compiles the same
+// header for the host to fuzz it against the oracle without a GPU (test-only: the product library
+// never executes it on the CPU).
 #pragma once
 #include <stdint.h>
 
@@ -25,157 +31,229 @@ constexpr uint32_t LX_CLS_NONE = 0xFFFFu; // class-stream value: code point not 
 constexpr uint32_t LX_T_CLS_MASK = 0x1FFFu, LX_T_FINAL = 1u << 13;
 constexpr int LX_T_NEXT_SHIFT = 14;
 constexpr uint32_t LX_INFO_SIMPLE = 0x80000000u;
+constexpr uint32_t LX_MISS = 0xFFFFFFFFu;
 constexpr int WBD_WORD_TAG = 1, WBD_IGNORE_TAG = 4;   // reference tokdll:39-40
 
 struct LexTables {
-    const uint32_t *T;        // displacement-packed transitions (bf_model.h T32 entry)
-    const uint32_t *info;     // action info of final states, indexed by state base
+    const uint64_t *T;        // displacement-packed transitions: low word = bf_model.h T32 entry, high word = action
+                              // info of the destination state when it is final (so a match needs no second gather)
     const int32_t *acts;      // general action records [left,right,tag,nfn,(fn,ini)*]
     uint32_t initial;
     uint32_t cls_any, cls_l, cls_r;   // LX_CLS_NONE when the symbol is not in the alphabet
     int max_depth, max_token_length;
+    int max_frames;           // saved frames the call graph can need (= call depth - 1, computed at load; <= LEX_MAX_DEPTH - 1)
 };
 
-// one DFA transition: returns the table entry or ~0u on a miss
-BF_HD uint32_t lx_lookup(const LexTables &L, uint32_t state, uint32_t cls)
+// one DFA transition: returns the table entry (low word LX_MISS on a miss)
+BF_HD uint64_t lx_lookup(const LexTables &L, uint32_t state, uint32_t cls)
 {
-    if (cls >= LX_T_CLS_MASK) return 0xFFFFFFFFu;
-    const uint32_t e = L.T[state + cls];
-    return (e & LX_T_CLS_MASK) == cls ? e : 0xFFFFFFFFu;
+    if (cls >= LX_T_CLS_MASK) return LX_MISS;
+    const uint64_t e = L.T[state + cls];
+#ifdef BF_LEX_PROFILE_HOOK
+    BF_LEX_PROFILE_HOOK(state + cls);
+#endif
+    return ((uint32_t)e & LX_T_CLS_MASK) == cls ? e : (uint64_t)LX_MISS;
 }
 // GetDest(State, Iw) with the IW_ANY retry of FALexTools_t.h:265-270
-BF_HD uint32_t lx_dest(const LexTables &L, uint32_t state, uint32_t cls)
+BF_HD uint64_t lx_dest(const LexTables &L, uint32_t state, uint32_t cls)
 {
-    uint32_t e = lx_lookup(L, state, cls);
-    if (e == 0xFFFFFFFFu && L.cls_any != LX_CLS_NONE) e = lx_lookup(L, state, L.cls_any);
+    uint64_t e = lx_lookup(L, state, cls);
+    if ((uint32_t)e == LX_MISS && L.cls_any != LX_CLS_NONE) e = lx_lookup(L, state, L.cls_any);
     return e;
 }
 
-// streaming form of the _wp post-pass (tokdll:1210-1311)
-struct WpSink {
-    int32_t *ids; int max_ids; int unk;
-    int out_count; int scanning; int tok_to, expected, nsub, word_out;
-    BF_HD void init(int32_t *ids_, int max_ids_, int unk_)
-    { ids = ids_; max_ids = max_ids_; unk = unk_; out_count = 0; scanning = 0; tok_to = expected = nsub = word_out = 0; }
-    BF_HD void finalize_word()
-    {
-        if (nsub > 0 && expected - 1 == tok_to) {       // sub-tokens tile the word exactly
-            const int c = word_out + nsub;
-            out_count = c < max_ids ? c : max_ids;
-        } else if (word_out < max_ids) {                 // otherwise one UNK (tokdll:1282-1301)
-            ids[word_out] = unk; out_count = word_out + 1;
-        }
-        scanning = 0;
-    }
-    // returns false once the id array is full (tokdll:1308-1310): nothing can change afterwards
-    BF_HD bool push(int tag, int from, int to)
-    {
-        if (scanning) {
-            if (tag > WBD_IGNORE_TAG && expected == from) {   // tokdll:1239
-                const int k = word_out + nsub;
-                if (k < max_ids) ids[k] = tag;
-                nsub++; expected = to + 1;
-                return true;
-            }
-            finalize_word();
-            if (out_count >= max_ids) return false;
-        }
-        if (tag == WBD_WORD_TAG) { scanning = 1; tok_to = to; expected = from; nsub = 0; word_out = out_count; }
-        return out_count < max_ids || scanning;   // a pending word at out_count == max_ids cannot happen (checked above)
-    }
-    BF_HD int finish() { if (scanning) finalize_word(); return out_count; }
+// direct id output (host emulation): ids[k] = v
+struct IdOutDirect {
+    int32_t *ids;
+    BF_HD void put(int k, int32_t v) { ids[k] = v; }
+    BF_HD void finish(int) {}
 };
 
 struct LexFrame {      // caller state saved across a _call (FALexTools_t.h:350-382)
     uint32_t ini; int off, n, from, once, a_idx, a_end, to2, fn_once, fp_r, fn_from, emit_mark;
 };
+constexpr int LEX_FRAME_WORDS = 12;
 
-// Runs the lexer + post-pass over one document's class stream cls_at(0..n-1).
-// Returns the number of ids written (<= max_ids); ids beyond it are untouched.
-template <class ClsAt>
-BF_HD int lex_doc(const LexTables &L, ClsAt cls_at, int n, int32_t *ids, int max_ids, int unk)
-{
-    WpSink sink; sink.init(ids, max_ids, unk);
-    if (n <= 0 || L.max_depth < 1) return 0;
-    const int max_triples = 2 * n;            // WbdRes holds 6*BuffSize ints = 2*BuffSize triples (tokdll:1194)
-    int emitted = 0, last_to = 0;
+struct FramesArray {   // host emulation only (a dynamically indexed private struct array mis-executed on the device)
     LexFrame st[LEX_MAX_DEPTH - 1];
-    int d = 0;                                // RecDepth - 1
-    // current frame
-    uint32_t ini = L.initial; int off = 0, fn_ = n, from = -1, once = 0;
-    // continuation of the action being executed in the current frame
-    int a_idx = 0, a_end = 0, to2 = 0, fn_once = 0, fp_r = 0, fn_from = 0;
-    for (;;) {
-        if (from >= fn_) {
-            // ---- Process_int returns (FALexTools_t.h:399); resume the caller's function loop
-            if (d == 0) break;
-            --d;
-            const LexFrame &f = st[d];
-            ini = f.ini; off = f.off; fn_ = f.n; from = f.from; once = f.once;
-            a_idx = f.a_idx + 2; a_end = f.a_end; to2 = f.to2; fn_once = f.fn_once; fp_r = f.fp_r; fn_from = f.fn_from;
-            if (emitted > f.emit_mark) {                      // FnOutSize > 0 (FALexTools_t.h:372-381)
-                fn_from = last_to + 1 - off;
-                if (fn_from > to2) a_idx = a_end;
-            }
-        } else {
-            // ---- one start position (FALexTools_t.h:229-290)
-            uint32_t state = ini, fs = 0; int fp = -1;
-            int j = from;
-            int bound = from + L.max_token_length; if (fn_ < bound) bound = fn_;
-            if (j == -1) {
-                const uint32_t e = lx_dest(L, ini, L.cls_l);
-                if (e == 0xFFFFFFFFu) { ++from; continue; }
-                state = e >> LX_T_NEXT_SHIFT; j = 0;
-            }
-            for (; j < bound; ++j) {
-                const uint32_t e = lx_dest(L, state, cls_at(off + j));
-                if (e == 0xFFFFFFFFu) break;
-                state = e >> LX_T_NEXT_SHIFT;
-                if (e & LX_T_FINAL) { fs = state; fp = j; }
-            }
-            if (j == fn_) {
-                const uint32_t e = lx_dest(L, state, L.cls_r);
-                if (e != 0xFFFFFFFFu && (e & LX_T_FINAL)) { fs = e >> LX_T_NEXT_SHIFT; fp = j; }
-            }
-            if (fp == -1) { ++from; continue; }
-            // ---- a match (FALexTools_t.h:293-342)
-            const uint32_t inf = L.info[fs];
-            int left = 0, right = 0, tag;
-            if (inf & LX_INFO_SIMPLE) { tag = (int)(inf & 0x7FFFFFFFu); a_idx = a_end = 0; fn_once = 0; }
-            else {
-                const int32_t *a = L.acts + inf;
-                left = a[0]; right = a[1]; tag = a[2];
-                a_idx = (int)inf + 4; a_end = a_idx + 2 * a[3]; fn_once = a[3] > 1;
-            }
-            int from2 = from + left; if (from2 < 0) from2 = 0; else if (fn_ <= from2) from2 = fn_ - 1;
-            to2 = fp - right; if (to2 < 0) to2 = 0; else if (fn_ <= to2) to2 = fn_ - 1;
-            fp_r = fp - right;
-            if (tag != 0) {
-                if (emitted >= max_triples) break;            // output buffer full (FALexTools_t.h:337-340): nothing more can be added
-                ++emitted; last_to = to2 + off;
-                if (!sink.push(tag, from2 + off, to2 + off)) break;   // id array full (tokdll:1308-1310)
-            }
-            fn_from = from2;                                  // FALexTools_t.h:347
+    BF_HD void save(int d, const LexFrame &f) { st[d] = f; }
+    BF_HD void load(int d, LexFrame &f) const { f = st[d]; }
+};
+
+template <class ClsAt, class IdOut, class Frames>
+struct LexLane {
+    const LexTables &L; ClsAt &cls_at; IdOut &ids; Frames &frames;
+    // ---- streaming _wp post-pass (tokdll:1210-1311)
+    int max_ids, unk;
+    int out_count, scanning, tok_to, expected, nsub, word_out;
+    // ---- lexer
+    int max_triples, emitted, last_to, d;
+    uint32_t ini; int off, fn_, from, once;                       // current frame
+    int a_idx, a_end, to2, fn_once, fp_r, fn_from;                // action being executed in it
+    uint32_t state, finfo; int j, bound, fp;                      // current walk (finfo: action info of the deepest final state)
+    bool stop;                                                    // nothing can change any more
+
+    BF_HD LexLane(const LexTables &L_, ClsAt &c, IdOut &o, Frames &f) : L(L_), cls_at(c), ids(o), frames(f) {}
+
+    BF_HD void sink_finalize_word()
+    {
+        if (nsub > 0 && expected - 1 == tok_to) {       // sub-tokens tile the word exactly (tokdll:1252)
+            const int c = word_out + nsub;
+            out_count = c < max_ids ? c : max_ids;
+        } else if (word_out < max_ids) {                 // otherwise one UNK (tokdll:1282-1301)
+            ids.put(word_out, unk); out_count = word_out + 1;
         }
-        // ---- (rest of) the action's function list (FALexTools_t.h:350-382)
+        scanning = 0;
+    }
+    // returns false once the id array is full (tokdll:1308-1310): nothing can change afterwards
+    BF_HD bool sink_push(int tag, int from_, int to_)
+    {
+        if (scanning) {
+            if (tag > WBD_IGNORE_TAG && expected == from_) {   // tokdll:1239
+                const int k = word_out + nsub;
+                if (k < max_ids) ids.put(k, tag);
+                nsub++; expected = to_ + 1;
+                return true;
+            }
+            sink_finalize_word();
+            if (out_count >= max_ids) return false;
+        }
+        if (tag == WBD_WORD_TAG) { scanning = 1; tok_to = to_; expected = from_; nsub = 0; word_out = out_count; }
+        return out_count < max_ids || scanning;
+    }
+
+    // Start a document of n normalised characters.  Follow with prepare().
+    BF_HD void init(int n, int max_ids_, int unk_)
+    {
+        max_ids = max_ids_; unk = unk_;
+        out_count = 0; scanning = 0; tok_to = expected = nsub = word_out = 0;
+        max_triples = 2 * n;               // WbdRes holds 6*BuffSize ints = 2*BuffSize triples (tokdll:1194)
+        emitted = 0; last_to = 0; d = 0;
+        ini = L.initial; off = 0; fn_ = n; from = -1; once = 0;
+        a_idx = a_end = 0; to2 = 0; fn_once = 0; fp_r = 0; fn_from = 0;
+        state = finfo = 0; j = 0; bound = 0; fp = -1;
+        stop = (n <= 0 || L.max_depth < 1);
+    }
+
+    // Everything between two walks.  Returns true when a walk is set up (call step() until it returns
+    // false, then after_walk()), false when the document is finished (call finish()).
+    BF_HD bool prepare()
+    {
+        if (stop) return false;
+        for (;;) {
+            if (from >= fn_) {
+                // ---- Process_int returns (FALexTools_t.h:399); resume the caller's function loop
+                if (d == 0) return false;
+                --d;
+                LexFrame f; frames.load(d, f);
+                ini = f.ini; off = f.off; fn_ = f.n; from = f.from; once = f.once;
+                a_idx = f.a_idx + 2; a_end = f.a_end; to2 = f.to2; fn_once = f.fn_once; fp_r = f.fp_r; fn_from = f.fn_from;
+                if (emitted > f.emit_mark) {                      // FnOutSize > 0 (FALexTools_t.h:372-381)
+                    fn_from = last_to + 1 - off;
+                    if (fn_from > to2) a_idx = a_end;
+                }
+                after_action();
+                continue;
+            }
+            // ---- set up one start position (FALexTools_t.h:229-252)
+            state = ini; fp = -1; finfo = 0; j = from;
+            bound = from + L.max_token_length; if (fn_ < bound) bound = fn_;
+            if (j >= 0 && !(j < bound)) { ++from; continue; }     // MaxTokenLength == 0: no letters, j != InSize
+            return true;
+        }
+    }
+
+    // Exactly one DFA transition (anchors included).  Returns true while the walk continues.
+    // Written with selects instead of branches: on the GPU this is the hot loop body and every
+    // divergent branch costs scalar instructions for the whole wave.
+    BF_HD bool step()
+    {
+        const bool la = j < 0, ra = j >= fn_;          // feeding the left / right anchor (FALexTools_t.h:244-252, 280-290)
+        int jj = j < 0 ? 0 : j; if (ra) jj = fn_ > 0 ? fn_ - 1 : 0;
+        uint32_t c = LX_CLS_NONE;
+        if (fn_ > 0) c = cls_at(off + jj);             // a letter (FALexTools_t.h:255-277); unused under an anchor
+        c = la ? L.cls_l : (ra ? L.cls_r : c);
+        const uint64_t e64 = lx_dest(L, state, c);
+        const uint32_t e = (uint32_t)e64;
+        const bool hit = e != LX_MISS;
+        const bool fin = hit && !la && (e & LX_T_FINAL);   // no finality check after the left anchor
+        fp = fin ? j : fp;
+        finfo = fin ? (uint32_t)(e64 >> 32) : finfo;
+        const bool adv = hit && !ra;
+        state = adv ? (e >> LX_T_NEXT_SHIFT) : state;
+        const int jn = la ? 0 : j + 1;
+        j = adv ? jn : j;
+        // the walk goes on while letters remain below the length bound; the right anchor is fed only
+        // when the input was exhausted (j == InSize)
+        return adv && (jn < bound || jn == fn_);
+    }
+
+    // Consume the result (fp, finfo) of the walk that just ended.  Follow with prepare().
+    BF_HD void after_walk()
+    {
+        if (fp == -1) { ++from; return; }
+        // ---- a match (FALexTools_t.h:293-342)
+        const uint32_t inf = finfo;
+        int left = 0, right = 0, tag;
+        if (inf & LX_INFO_SIMPLE) { tag = (int)(inf & 0x7FFFFFFFu); a_idx = a_end = 0; fn_once = 0; }
+        else {
+            const int32_t *a = L.acts + inf;
+            left = a[0]; right = a[1]; tag = a[2];
+            a_idx = (int)inf + 4; a_end = a_idx + 2 * a[3]; fn_once = a[3] > 1;
+        }
+        int from2 = from + left; if (from2 < 0) from2 = 0; else if (fn_ <= from2) from2 = fn_ - 1;
+        to2 = fp - right; if (to2 < 0) to2 = 0; else if (fn_ <= to2) to2 = fn_ - 1;
+        fp_r = fp - right;
+        if (tag != 0) {
+            if (emitted >= max_triples) { stop = true; return; }      // output buffer full (FALexTools_t.h:337-340)
+            ++emitted; last_to = to2 + off;
+            if (!sink_push(tag, from2 + off, to2 + off)) { stop = true; return; }   // id array full (tokdll:1308-1310)
+        }
+        fn_from = from2;                                              // FALexTools_t.h:347
+        after_action();
+    }
+
+    // (Rest of) the action's function list, then the start-position update (FALexTools_t.h:350-393).
+    BF_HD void after_action()
+    {
         if (a_idx < a_end) {
-            if (L.max_depth < d + 2) a_idx = a_end;           // callee returns 0 at once (FALexTools_t.h:222-224)
+            if (L.max_depth < d + 2 || d + 1 > L.max_frames) a_idx = a_end;   // callee returns 0 at once (FALexTools_t.h:222-224)
             else {
-                LexFrame &f = st[d];
+                LexFrame f;
                 f.ini = ini; f.off = off; f.n = fn_; f.from = from; f.once = once;
                 f.a_idx = a_idx; f.a_end = a_end; f.to2 = to2; f.fn_once = fn_once; f.fp_r = fp_r; f.fn_from = fn_from; f.emit_mark = emitted;
+                frames.save(d, f);
                 const int fn = L.acts[a_idx];
                 ini = (uint32_t)L.acts[a_idx + 1];
                 off = fn_from + off; fn_ = to2 - fn_from + 1; from = -1; once = (fn == 0) ? 0 : fn_once;
                 ++d;
-                continue;
+                return;
             }
         }
-        if (once) { from = fn_; continue; }                   // "called once": return (FALexTools_t.h:385-387)
-        if (fp_r > from) from = fp_r;                         // FALexTools_t.h:390-393
+        if (once) { from = fn_; return; }                             // "called once": return (FALexTools_t.h:385-387)
+        if (fp_r > from) from = fp_r;                                 // FALexTools_t.h:390-393
         ++from;
     }
-    return sink.finish();
+
+    BF_HD int finish()
+    {
+        if (scanning) sink_finalize_word();
+        ids.finish(out_count);
+        return out_count;
+    }
+};
+
+// Sequential driver (host emulation).  Returns the number of ids written (<= max_ids).
+template <class ClsAt, class IdOut, class Frames>
+BF_HD int lex_doc(const LexTables &L, ClsAt &cls_at, int n, IdOut &out, int max_ids, int unk, Frames &frames)
+{
+    LexLane<ClsAt, IdOut, Frames> lane(L, cls_at, out, frames);
+    lane.init(n, max_ids, unk);
+    while (lane.prepare()) {
+        while (lane.step()) {}
+        lane.after_walk();
+    }
+    return lane.finish();
 }
 
 } // namespace bfa

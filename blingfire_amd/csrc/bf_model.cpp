@@ -562,12 +562,65 @@ bool build_model(Model &m, const uint8_t *img, size_t size)
                     m.acts_pool.push_back(fn); m.acts_pool.push_back((int)fn2ini[(size_t)fn]);
                 }
             }
+            // static call depth: which functions can a function's rules call?  (bounds the frame stack of the lane program)
+            {
+                const RawDfa &rw = m.wbd_raw;
+                const int r_sym = rw.remap ? rw.class_of(IW_R_ANCHOR) : IW_R_ANCHOR;
+                std::vector<std::vector<int>> callees((size_t)max_fn + 1);
+                std::vector<int> base2idx(m.wbd.table_len(), -1);
+                for (size_t s = 0; s < rw.state_off.size(); ++s) base2idx[m.wbd.state_base[s]] = (int)s;
+                for (int f = 0; f <= max_fn; ++f) {
+                    if (fn2ini[(size_t)f] < 0) continue;
+                    std::vector<uint8_t> seen(rw.state_off.size(), 0);
+                    std::vector<int> stack{base2idx[(size_t)fn2ini[(size_t)f]]};
+                    std::vector<uint8_t> called((size_t)max_fn + 1, 0);
+                    auto note_final = [&](int st) {
+                        if (!rw.is_final[(size_t)st]) return;
+                        const int ow = rw.ow[(size_t)st];
+                        if (ow < 0 || (size_t)ow >= actions.size()) return;
+                        const auto &v = actions[(size_t)ow];
+                        size_t fi = (v.size() > 3 && v[2] == 0) ? 3 : (v.size() > 4 && v[3] == 0) ? 4 : v.size();
+                        for (size_t k = fi; k < v.size(); ++k) if (v[k] >= 0 && v[k] <= max_fn) called[(size_t)v[k]] = 1;
+                    };
+                    if (stack[0] < 0) continue;
+                    seen[(size_t)stack[0]] = 1;
+                    while (!stack.empty()) {
+                        const int st = stack.back(); stack.pop_back();
+                        note_final(st);
+                        for (uint32_t t = rw.tr_begin[(size_t)st]; t < rw.tr_begin[(size_t)st + 1]; ++t) {
+                            const int dst = rw.tr_dst[t];
+                            if (dst < 0) continue;
+                            if (rw.tr_sym[t] == r_sym) { note_final(dst); continue; }   // the right anchor is always the last symbol fed
+                            if (!seen[(size_t)dst]) { seen[(size_t)dst] = 1; stack.push_back(dst); }
+                        }
+                    }
+                    for (int g = 0; g <= max_fn; ++g) if (called[(size_t)g]) callees[(size_t)f].push_back(g);
+                }
+                std::vector<int> depth((size_t)max_fn + 1, -1); std::vector<uint8_t> on((size_t)max_fn + 1, 0);
+                std::function<int(int)> dep = [&](int f) -> int {
+                    if (on[(size_t)f]) return 1 << 20;                 // recursion: bounded only by max-depth
+                    if (depth[(size_t)f] >= 0) return depth[(size_t)f];
+                    on[(size_t)f] = 1; int dmax = 1;
+                    for (int g : callees[(size_t)f]) dmax = std::max(dmax, std::min(1 << 20, 1 + dep(g)));
+                    on[(size_t)f] = 0; depth[(size_t)f] = dmax; return dmax;
+                };
+                const int call_depth = max_fn >= 0 ? dep(0) : 1;
+                m.lex_frames = std::max(0, std::min(m.max_depth, call_depth) - 1);
+            }
             m.wbd_info.assign(m.wbd.table_len(), 0);
             for (size_t s = 0; s < m.wbd_raw.state_off.size(); ++s) {
                 if (!m.wbd_raw.is_final[s]) continue;
                 const int ow = m.wbd_raw.ow[s];
                 if (ow < 0 || (size_t)ow >= actions.size()) return fail(m, "final state without a valid action");
                 m.wbd_info[m.wbd.state_base[s]] = act_info[(size_t)ow];
+            }
+
+            m.wbd_t2.resize(m.wbd.t32.size());
+            for (size_t i = 0; i < m.wbd.t32.size(); ++i) {
+                const uint32_t e = m.wbd.t32[i];
+                uint64_t hi = 0;
+                if ((e & T32_CLS_MASK) != T32_CLS_MASK && (e & T32_FINAL_BIT)) hi = m.wbd_info[e >> T32_NEXT_SHIFT];
+                m.wbd_t2[i] = (uint64_t)e | (hi << 32);
             }
 
             // fused code point -> class map (charmap semantics: reference FAUtils_cl.h:311-369 + FAMultiMap_pack_fixed.cpp:67-137)

@@ -98,8 +98,10 @@ struct Model {
     // ---- [wbd] lexer (reference FAWbdConfKeeper.cpp:56-232, FALexTools_t.h:129-202)
     bool has_wbd = false;
     int max_depth = 2, max_token_length = 300; bool ignore_case = false;
+    int lex_frames = 0;                // saved frames the call graph can need: min(max_depth, call depth) - 1
     RawDfa wbd_raw; PackedDfa wbd;
     std::vector<uint32_t> wbd_info;    // indexed by base: action info for final states
+    std::vector<uint64_t> wbd_t2;      // device form: low = T32 entry, high = wbd_info[destination] when the destination is final
     std::vector<int32_t> acts_pool;
     uint32_t cls_any = CLS_NONE, cls_l = CLS_NONE, cls_r = CLS_NONE;
     // fused "code point -> charmap -> (cp<3 ? 3 : cp) -> class" map:

@@ -42,7 +42,7 @@ void bft_stats(void *hv, long *out)
     Model &m = ((Handle *)hv)->m;
     out[0] = (long)m.wbd_raw.state_off.size(); out[1] = (long)m.wbd_raw.tr_sym.size(); out[2] = m.wbd.table_len(); out[3] = m.wbd.nclasses;
     out[4] = (long)m.dict_raw.state_off.size(); out[5] = (long)m.dict_raw.tr_sym.size(); out[6] = m.dict.table_len(); out[7] = m.dict.nclasses;
-    out[8] = m.trie_max_depth;
+    out[8] = m.trie_max_depth; out[9] = m.lex_frames;
 }
 
 static long verify_dfa(const Model &m, const bfo_model *o, int which, int verbose)
@@ -174,11 +174,14 @@ static int emu_wp(const Model &m, const char *s, int n, int32_t *ids, int max_id
     }
     if (cls.empty() || (int)cls.size() > n) return 0;
     LexTables L;
-    L.T = m.wbd.t32.data(); L.info = m.wbd_info.data(); L.acts = m.acts_pool.data();
+    L.T = m.wbd_t2.data(); L.acts = m.acts_pool.data();
     L.initial = m.wbd.initial_base; L.cls_any = m.cls_any; L.cls_l = m.cls_l; L.cls_r = m.cls_r;
-    L.max_depth = m.max_depth; L.max_token_length = m.max_token_length;
+    L.max_depth = m.max_depth; L.max_token_length = m.max_token_length; L.max_frames = m.lex_frames;
     const uint16_t *cp = cls.data();
-    return lex_doc(L, [cp](int i) -> uint32_t { return cp[i]; }, (int)cls.size(), ids, max_ids, unk);
+    auto cls_at = [cp](int i) -> uint32_t { return cp[i]; };
+    IdOutDirect out{ids};
+    FramesArray frames;
+    return lex_doc(L, cls_at, (int)cls.size(), out, max_ids, unk, frames);
 }
 
 static int emu_sp(const Model &, const char *, int, int32_t *, int, int) { return -1; }

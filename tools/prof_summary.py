@@ -38,7 +38,7 @@ def main():
         db = sqlite3.connect(dbs[0])
         out.append("")
         out.append("== rocprofv3 --pmc pass %s (per-dispatch averages over the bfa:: kernels) ==" % os.path.basename(d))
-        _, rs = rows(db, "select kernel_name, counter_name, count(*), avg(value), avg(duration) from counters_collection where kernel_name like 'bfa::%' group by kernel_name, counter_name order by kernel_name, counter_name")
+        _, rs = rows(db, "select kernel_name, counter_name, count(*), avg(value), avg(duration) from counters_collection where kernel_name like '%bfa::%' group by kernel_name, counter_name order by kernel_name, counter_name")
         out.append("%-44s %-22s %5s %18s %12s" % ("kernel", "counter", "n", "avg_value", "avg_ns"))
         for r in rs:
             out.append("%-44s %-22s %5d %18.1f %12.0f" % (r[0][:44], r[1], r[2], r[3], r[4]))
