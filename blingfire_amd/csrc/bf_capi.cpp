@@ -104,6 +104,7 @@ Handle *make_handle(const uint8_t *img, size_t size)
     Model &m = h->m;
     bool ok = true;
     if (m.kind == KIND_WP) {
+        if (m.acts_pool.size() > 4096) { g_last_error = "lexer action pool exceeds the LDS staging limit (4096 ints)"; fprintf(stderr, "[blingfire_amd] %s\n", g_last_error.c_str()); delete h; return nullptr; }
         if (m.max_depth > LEX_MAX_DEPTH) { g_last_error = "lexer max-depth exceeds the supported 4"; fprintf(stderr, "[blingfire_amd] %s\n", g_last_error.c_str()); delete h; return nullptr; }
         ok = ok && upload(h->t_wbd, m.wbd_t2, 16) && upload(h->t_acts, m.acts_pool, 16) &&
              upload(h->t_cp_l1, m.wbd_cpmap.l1) && upload(h->t_cp_pages, m.wbd_cpmap.pages) && upload(h->t_multi, m.wbd_multi_pool, 16);

@@ -157,18 +157,19 @@ void launch_prep_wp(const WpPrepParams &p, hipStream_t s)
 // ------------------------------------------------------------------------------------------
 __host__ __device__ __forceinline__ int64_t ids_slot(int64_t doc_off_d, int64_t d) { return ((doc_off_d + 7) & ~(int64_t)7) + 8 * d; }
 
-// 16-byte register window over the lane's class stream: one dwordx4 load per 8 characters
+// 16-byte register window over the lane's class stream: one dwordx4 load per 8 characters.  The stream of
+// document d starts at element doc_off[d] of the (256-byte aligned) cls buffer; block t of the lane is the
+// aligned 16-byte block ((doc_off[d] >> 3) + t) -- kept as base pointer + index so the loads stay global_load.
 struct ClsWin {
-    const uint4 *base; int shift; uint4 w; int tag;
-    __device__ __forceinline__ void init(const uint16_t *cls)
+    const uint4 *cls16; int64_t blk0; int shift; uint4 w; int tag;
+    __device__ __forceinline__ void init(const uint16_t *cls_buf, int64_t elem_off)
     {
-        const uintptr_t a = (uintptr_t)cls;
-        base = (const uint4 *)(a & ~(uintptr_t)15); shift = (int)((a & 15) >> 1); tag = -1; w = make_uint4(0, 0, 0, 0);
+        cls16 = (const uint4 *)cls_buf; blk0 = elem_off >> 3; shift = (int)(elem_off & 7); tag = -1; w = make_uint4(0, 0, 0, 0);
     }
     __device__ __forceinline__ uint32_t operator()(int i)
     {
         const int a = i + shift, t = a >> 3;
-        if (t != tag) { w = base[t]; tag = t; }
+        if (t != tag) { w = cls16[blk0 + t]; tag = t; }
         const uint32_t lo = (a & 2) ? w.y : w.x, hi = (a & 2) ? w.w : w.z;
         const uint32_t dw = (a & 4) ? hi : lo;
         return (a & 1) ? (dw >> 16) : (dw & 0xFFFFu);
@@ -235,7 +236,7 @@ __global__ __launch_bounds__(THREADS) void k_lex_wp_seq(WpLexParams p)
     const int n = p.nchars[d];
     int cap = p.max_ids; if ((int64_t)cap > nbytes) cap = (int)nbytes;
     if (cap < 0) cap = 0;
-    ClsWin cls_at; cls_at.init(p.cls + b);
+    ClsWin cls_at; cls_at.init(p.cls, b);
     IdOutLds out; out.buf = lex_lds + (size_t)p.L.max_frames * LEX_FRAME_WORDS * THREADS + threadIdx.x; out.nthreads = THREADS;
     out.init(p.ids_tmp + ids_slot(b, d));
     FramesLds frames{lex_lds, THREADS};
@@ -251,17 +252,17 @@ __global__ __launch_bounds__(THREADS) void k_lex_wp_flat(WpLexParams p)
 {
     extern __shared__ int32_t lex_lds[];
     enum { M_NEED = 0, M_WALK = 1, M_EVENT = 2, M_EXIT = 3 };
-    ClsWin cls_at; cls_at.init(p.cls);
+    ClsWin cls_at; cls_at.init(p.cls, 0);
     IdOutLds out; out.buf = lex_lds + (size_t)p.L.max_frames * LEX_FRAME_WORDS * THREADS + threadIdx.x; out.nthreads = THREADS;
     out.init(p.ids_tmp);
     FramesLds frames{lex_lds, THREADS};
     // the (tiny) action pool is staged in LDS so that match handling touches no global memory
     LexTables L = p.L;
-    if (p.acts_n > 0) {
+    {
         int32_t *acts_lds = lex_lds + ((size_t)p.L.max_frames * LEX_FRAME_WORDS + 8) * THREADS;
         for (int i = threadIdx.x; i < p.acts_n; i += THREADS) acts_lds[i] = p.L.acts[i];
         __syncthreads();
-        L.acts = acts_lds;
+        L.acts = acts_lds;          // unconditionally LDS: the loads compile to ds_read, not flat_load
     }
     LexLane<ClsWin, IdOutLds, FramesLds> lane(L, cls_at, out, frames);
     lane.init(0, 0, 0);
@@ -303,7 +304,7 @@ __global__ __launch_bounds__(THREADS) void k_lex_wp_flat(WpLexParams p)
                         const int n = p.nchars[doc];
                         int cap = p.max_ids; if ((int64_t)cap > nbytes) cap = (int)nbytes;
                         if (cap < 0) cap = 0;
-                        cls_at.init(p.cls + b);
+                        cls_at.init(p.cls, b);
                         out.init(p.ids_tmp + ids_slot(b, doc));
                         lane.init(n, cap, p.unk);
                         if (lane.prepare()) mode = M_WALK;
@@ -329,7 +330,7 @@ void launch_lex_wp(const WpLexParams &p, int variant, hipStream_t s)
         WpLexParams q = p;
         q.ev_thresh = (variant >> 8) & 0xff; if (q.ev_thresh == 0) q.ev_thresh = 32;
         q.fetch_thresh = (variant >> 16) & 0xff; if (q.fetch_thresh == 0) q.fetch_thresh = 8;
-        q.acts_n = p.acts_n <= 2048 ? p.acts_n : 0;
+        q.acts_n = p.acts_n;                                          // <= 4096 ints, checked at LoadModel
         int waves_per_cu = (variant >> 24) & 0x3f;
         if (waves_per_cu == 0) {                                      // persistent: exactly the resident waves
             int per_cu = 0, ncu = 256;
