@@ -113,7 +113,7 @@ def text_to_ids_batch(h, docs, max_len, unk=0):
     off = np.ascontiguousarray(off, dtype=np.int64)
     ndocs = len(off) - 1
     total = int(off[-1] - off[0]) if ndocs > 0 else 0
-    cap = min(total, ndocs * max(max_len, 0)) + 1
+    cap = min(2 * (total + ndocs), ndocs * max(max_len, 0)) + 1      # every id covers >= 1 element of <= 2*(n+1) per document
     ids = np.empty(cap, dtype=np.int32)
     id_off = np.zeros(ndocs + 1, dtype=np.int64)
     r = lib().TextToIdsBatch(c_void_p(h), text.ctypes.data, off.ctypes.data, ndocs, ids.ctypes.data, cap, id_off.ctypes.data,
@@ -132,7 +132,7 @@ def text_to_ids_batch_device(h, d_text, d_doc_off, max_len, unk=0, out_ids=None,
     import torch
     ndocs = d_doc_off.numel() - 1
     total = d_text.numel()
-    cap = max(1, min(total, ndocs * max(max_len, 0)))
+    cap = max(1, min(2 * (total + ndocs), ndocs * max(max_len, 0)))
     if out_ids is None:
         out_ids = torch.empty(cap, dtype=torch.int32, device=d_text.device)
     if out_off is None:

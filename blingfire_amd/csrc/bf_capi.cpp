@@ -63,6 +63,8 @@ struct Handle {
     std::mutex mu;
     // device tables
     DevBuf t_wbd, t_info, t_acts, t_cp_l1, t_cp_pages, t_multi;
+    DevBuf t_dict, t_seginfo;                                    // _sp: Mealy table, I2Info rows (code-point maps reuse t_cp_*/t_multi)
+    DevBuf w_s1, w_s2, w_s3, w_s4;                               // _sp scratch
     // workspaces
     DevBuf w_cls, w_nchars, w_tmp, w_counts, w_bsums, w_misc;   // w_misc: [0] next_doc (u64), [2] status (int)
     DevBuf w_text, w_docoff, w_ids, w_idoff;                    // host-API staging
@@ -71,7 +73,7 @@ struct Handle {
     bool ev_valid = false;
     ~Handle()
     {
-        for (DevBuf *b : {&t_wbd, &t_info, &t_acts, &t_cp_l1, &t_cp_pages, &t_multi, &w_cls, &w_nchars, &w_tmp, &w_counts,
+        for (DevBuf *b : {&t_wbd, &t_info, &t_acts, &t_cp_l1, &t_cp_pages, &t_multi, &t_dict, &t_seginfo, &w_s1, &w_s2, &w_s3, &w_s4, &w_cls, &w_nchars, &w_tmp, &w_counts,
                           &w_bsums, &w_misc, &w_text, &w_docoff, &w_ids, &w_idoff}) b->release();
         for (auto &e : ev) if (e) (void)hipEventDestroy(e);
         if (stream) (void)hipStreamDestroy(stream);
@@ -109,8 +111,8 @@ Handle *make_handle(const uint8_t *img, size_t size)
         ok = ok && upload(h->t_wbd, m.wbd_t2, 16) && upload(h->t_acts, m.acts_pool, 16) &&
              upload(h->t_cp_l1, m.wbd_cpmap.l1) && upload(h->t_cp_pages, m.wbd_cpmap.pages) && upload(h->t_multi, m.wbd_multi_pool, 16);
     } else {
-        g_last_error = "segmenter models are not wired yet";
-        ok = false;
+        ok = ok && upload(h->t_dict, m.dict.t64, 16) && upload(h->t_seginfo, m.seg_info, 16) &&
+             upload(h->t_cp_l1, m.sp_cpmap.l1) && upload(h->t_cp_pages, m.sp_cpmap.pages) && upload(h->t_multi, m.sp_multi_pool, 16);
     }
     ok = ok && hip_ok(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking), "hipStreamCreate");
     for (auto &e : h->ev) ok = ok && hip_ok(hipEventCreate(&e), "hipEventCreate");
@@ -130,6 +132,7 @@ int run_device(Handle *h, const char *d_text, const int64_t *d_doc_off, int64_t 
     if (!h->w_nchars.reserve((size_t)(ndocs + 1) * 4) || !h->w_counts.reserve((size_t)(ndocs + 1) * 4) ||
         !h->w_bsums.reserve((size_t)(nblocks + 1) * 8) || !h->w_tmp.reserve((size_t)(total_bytes + 8 * ndocs + 64) * 4)) return BF_E_DEVICE;
     Batch b{(const uint8_t *)d_text, d_doc_off, ndocs};
+    int slot_mul = 0;
     unsigned long long *next_doc = h->w_misc.as<unsigned long long>();
     int *status = (int *)(h->w_misc.as<char>() + 16);
     if (!hip_ok(hipMemsetAsync(h->w_misc.p, 0, 64, s), "hipMemsetAsync")) return BF_E_DEVICE;
@@ -150,12 +153,40 @@ int run_device(Handle *h, const char *d_text, const int64_t *d_doc_off, int64_t 
         if (ndocs > 0) launch_lex_wp(lp, h->variant, s);
         (void)hipEventRecord(h->ev[EV_TOK], s);
     } else {
-        return BF_E_UNSUPPORTED;
+        const int mul = m.dict_has_charmap ? 2 : 1;
+        slot_mul = mul;
+        const size_t cap = (size_t)mul * (size_t)(total_bytes + ndocs) + 64;      // elements over all documents
+        if (!h->w_cls.reserve(cap * 2) || !h->w_tmp.reserve(cap * 4)) return BF_E_DEVICE;
+        SpPrepParams pp;
+        pp.b = b; pp.cpmap = DevCpMap{h->t_cp_l1.as<uint16_t>(), h->t_cp_pages.as<uint32_t>()}; pp.multi_pool = h->t_multi.as<uint16_t>();
+        pp.has_multi = m.sp_has_multi ? 1 : 0; pp.use_bytes = m.use_bytes ? 1 : 0; pp.has_charmap = m.dict_has_charmap ? 1 : 0;
+        pp.delim_code = m.sp_delim_code;
+        pp.prefix_n = m.no_dummy_prefix ? 0 : (int)m.sp_prefix.size();
+        for (int k = 0; k < 10; ++k) pp.prefix[k] = k < pp.prefix_n ? m.sp_prefix[(size_t)k] : 0;
+        pp.slot_mul = mul; pp.stream = h->w_cls.as<uint16_t>(); pp.lens = h->w_nchars.as<int32_t>();
+        if (ndocs > 0) launch_prep_sp(pp, s);
+        (void)hipEventRecord(h->ev[EV_PREP], s);
+        SpSegParams sg;
+        sg.S.T = h->t_dict.as<uint64_t>(); sg.S.info = h->t_seginfo.as<SegInfo>(); sg.S.initial = m.dict.initial_base;
+        sg.S.cls_delim = m.sp_delim_code; sg.S.kind = m.kind; sg.S.id_offset = m.id_offset;
+        sg.b = b; sg.stream = h->w_cls.as<uint16_t>(); sg.lens = h->w_nchars.as<int32_t>(); sg.slot_mul = mul;
+        sg.ids_tmp = h->w_tmp.as<int32_t>(); sg.counts = h->w_counts.as<int32_t>(); sg.max_ids = max_ids; sg.unk = unk; sg.status = status;
+        sg.sc = nullptr; sg.bi = nullptr; sg.arcs = nullptr; sg.tos = nullptr; sg.idsv = nullptr; sg.inter = nullptr;
+        if (m.kind == KIND_UNIGRAM) {
+            if (!h->w_s1.reserve(cap * 8) || !h->w_s2.reserve(cap * 8)) return BF_E_DEVICE;
+            sg.sc = h->w_s1.as<double>(); sg.bi = h->w_s2.as<SegBest>();
+        } else {
+            if (!h->w_s1.reserve((6 * cap + 32 * (size_t)ndocs + 64) * 16) || !h->w_s2.reserve(cap * 4) || !h->w_s3.reserve(cap * 4) ||
+                !h->w_s4.reserve(cap)) return BF_E_DEVICE;
+            sg.arcs = h->w_s1.as<SegArc>(); sg.tos = h->w_s2.as<int32_t>(); sg.idsv = h->w_s3.as<int32_t>(); sg.inter = h->w_s4.as<uint8_t>();
+        }
+        if (ndocs > 0) launch_seg_sp(sg, s);
+        (void)hipEventRecord(h->ev[EV_TOK], s);
     }
     ScanParams sp{h->w_counts.as<int32_t>(), ndocs, d_id_off, h->w_bsums.as<int64_t>(), nblocks};
     launch_scan(sp, s);
     (void)hipEventRecord(h->ev[EV_SCAN], s);
-    CompactParams cp{b, h->w_tmp.as<int32_t>(), h->w_counts.as<int32_t>(), d_id_off, d_ids_out, ids_cap, status};
+    CompactParams cp{b, h->w_tmp.as<int32_t>(), h->w_counts.as<int32_t>(), d_id_off, d_ids_out, ids_cap, status, slot_mul};
     if (ndocs > 0) launch_compact(cp, s);
     (void)hipEventRecord(h->ev[EV_COMPACT], s);
     h->ev_valid = true;
@@ -174,7 +205,8 @@ int64_t run_host(Handle *h, const char *text, const int64_t *doc_off, int64_t nd
     if (!hip_ok(hipSetDevice(h->device), "hipSetDevice")) return BF_E_DEVICE;
     hipStream_t s = h->stream;
     // worst-case id count (every id covers >= 1 byte)
-    int64_t worst = total;
+    // worst-case id count: _wp ids cover >= 1 byte each; _sp tokens cover >= 1 element of <= mul*(n+1) elements
+    int64_t worst = h->m.kind == KIND_WP ? total : (int64_t)(h->m.dict_has_charmap ? 2 : 1) * (total + ndocs);
     if (max_ids >= 0 && ndocs * (int64_t)max_ids < worst) worst = ndocs * (int64_t)(max_ids < 0 ? 0 : max_ids);
     if (!h->w_text.reserve((size_t)total + 16) || !h->w_docoff.reserve((size_t)(ndocs + 1) * 8) ||
         !h->w_idoff.reserve((size_t)(ndocs + 1) * 8) || !h->w_ids.reserve((size_t)(worst + 1) * 4)) return BF_E_DEVICE;

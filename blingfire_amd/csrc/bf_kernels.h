@@ -3,6 +3,7 @@
 #include <stdint.h>
 #include <hip/hip_runtime_api.h>
 #include "bf_lex.h"
+#include "bf_seg.h"
 
 namespace bfa {
 
@@ -39,15 +40,45 @@ struct WpLexParams {
     int acts_n;                   // ints in L.acts (staged in LDS when small)
 };
 
+// _sp branch: element slot of document d (stream, DP arrays and the id staging slot share it):
+//   first element = slot_mul * (doc_off[d] + d), capacity slot_mul * (nbytes + 1)
+struct SpPrepParams {
+    Batch b;
+    DevCpMap cpmap;             // fused charmap + element-code map (bf_model.h Model::sp_cpmap)
+    const uint16_t *multi_pool;
+    int has_multi, use_bytes, has_charmap;
+    uint16_t delim_code;
+    int prefix_n; uint16_t prefix[10];
+    int slot_mul;
+    uint16_t *stream;           // element codes after prefix / charmap / whitespace collapse
+    int32_t *lens;              // [ndocs] stream length, 0 = "TextToIds returns 0"
+};
+
+struct SpSegParams {
+    SegTables S;
+    Batch b;
+    const uint16_t *stream; const int32_t *lens;
+    int slot_mul;
+    int32_t *ids_tmp; int32_t *counts;
+    int max_ids, unk;
+    // scratch (indexed by element slot): unigram sc/bi; bpe arcs (6 per element + 32 per document), tos/idsv/inter
+    double *sc; SegBest *bi;
+    SegArc *arcs; int32_t *tos; int32_t *idsv; uint8_t *inter;
+    int *status;
+};
+
 struct ScanParams { const int32_t *counts; int64_t ndocs; int64_t *id_off; int64_t *block_sums; int nblocks; };
 
 struct CompactParams {
     Batch b; const int32_t *ids_tmp; const int32_t *counts; const int64_t *id_off;
     int32_t *ids_out; int64_t ids_cap; int *status;
+    int slot_mul;               // 0: _wp slots (align8(doc_off)+8d); >0: _sp slots (slot_mul*(doc_off+d))
 };
 
 void launch_prep_wp(const WpPrepParams &p, hipStream_t s);
 void launch_lex_wp(const WpLexParams &p, int variant, hipStream_t s);
+void launch_prep_sp(const SpPrepParams &p, hipStream_t s);
+void launch_seg_sp(const SpSegParams &p, hipStream_t s);
 void launch_scan(const ScanParams &p, hipStream_t s);
 void launch_compact(const CompactParams &p, hipStream_t s);
 int scan_nblocks(int64_t ndocs);

@@ -350,6 +350,172 @@ void launch_lex_wp(const WpLexParams &p, int variant, hipStream_t s)
 }
 
 // ------------------------------------------------------------------------------------------
+// k_prep_sp: wave per document.  bytes / strict UTF-8 -> fused charmap+element-code map -> dummy prefix ->
+// whitespace collapse (local keep-predicate) -> trailing trim  (tokdll:1367-1496).
+// ------------------------------------------------------------------------------------------
+__host__ __device__ __forceinline__ int64_t sp_slot(int64_t doc_off_d, int64_t d, int mul) { return (int64_t)mul * (doc_off_d + d); }
+
+__device__ __forceinline__ bool sp_delimish(uint32_t code, uint32_t delim) { return code == 0xFFFDu || code == delim; }
+
+__global__ __launch_bounds__(256) void k_prep_sp(SpPrepParams p)
+{
+    const int lane = lane_id();
+    const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * 4;
+    const uint32_t D = p.delim_code;
+    for (int64_t d = wave0; d < p.b.ndocs; d += nwaves) {
+        const int64_t b = p.b.doc_off[d];
+        const int64_t n64 = p.b.doc_off[d + 1] - b;
+        if (n64 <= 0 || n64 > 1000000000) { if (lane == 0) p.lens[d] = 0; continue; }     // tokdll:1361-1363
+        const int n = (int)n64;
+        const uint8_t *s = p.b.text + b;
+        uint16_t *out = p.stream + sp_slot(b, d, p.slot_mul);
+        const int cap = p.slot_mul * (n + 1);
+        int pos = 0;
+        if (n >= 3 && s[0] == 0xEF && s[1] == 0xBB && s[2] == 0xBF) pos = 3;             // BOM, also in bytes mode (FAUtf8Utils.cpp:330-335)
+        const int bom = pos;
+        // ---- state after the (normalised) dummy prefix: uniform across the wave
+        int outc = 0, normc = 0, decoded = 0;
+        uint32_t prev = 0; bool have_prev = false;
+        for (int k = 0; k < p.prefix_n; ++k) {
+            const uint32_t e = p.prefix[k];
+            const bool ws = e == 0xFFFDu;
+            const bool keep = !ws || !have_prev || !sp_delimish(prev, D);
+            if (keep) { if (lane == 0 && outc < cap) out[outc] = (uint16_t)(ws ? D : e); ++outc; }
+            prev = e; have_prev = true; ++normc;
+        }
+        bool bad = false;
+        while (pos < n) {
+            const int q = pos + lane;
+            const bool in = q < n;
+            uint32_t b0 = 0, b1 = 0, b2 = 0, b3 = 0;
+            if (in) b0 = s[q];
+            bool start = in; bool err = false; int cp = (int)b0;
+            if (!p.use_bytes) {
+                if (q + 1 < n) b1 = s[q + 1];
+                if (q + 2 < n) b2 = s[q + 2];
+                if (q + 3 < n) b3 = s[q + 3];
+                const bool cont = (b0 & 0xC0) == 0x80;
+                start = in && !cont;
+                if (in && cont) {
+                    uint32_t p1 = (q - 1 >= bom) ? s[q - 1] : 0x80u, p2 = (q - 2 >= bom) ? s[q - 2] : 0x80u, p3 = (q - 3 >= bom) ? s[q - 3] : 0x80u;
+                    bool ok;
+                    if ((p1 & 0xC0) != 0x80) ok = (q - 1 >= bom) && p1 >= 0xC0;
+                    else if ((p2 & 0xC0) != 0x80) ok = (q - 2 >= bom) && p2 >= 0xE0;
+                    else if ((p3 & 0xC0) != 0x80) ok = (q - 3 >= bom) && p3 >= 0xF0;
+                    else ok = false;
+                    err = !ok;
+                } else if (start && b0 >= 0x80) {
+                    int len;
+                    if ((b0 & 0xE0) == 0xC0) { len = 2; cp = (int)(b0 & 0x1F); }
+                    else if ((b0 & 0xF0) == 0xE0) { len = 3; cp = (int)(b0 & 0x0F); }
+                    else if ((b0 & 0xF8) == 0xF0) { len = 4; cp = (int)(b0 & 0x07); }
+                    else { len = 1; err = true; }
+                    if (q + len > n) err = true;
+                    if (len >= 2) { if ((b1 & 0xC0) != 0x80) err = true; cp = (cp << 6) | (int)(b1 & 0x3F); }
+                    if (len >= 3) { if ((b2 & 0xC0) != 0x80) err = true; cp = (cp << 6) | (int)(b2 & 0x3F); }
+                    if (len >= 4) { if ((b3 & 0xC0) != 0x80) err = true; cp = (cp << 6) | (int)(b3 & 0x3F); }
+                    const int need = cp <= 0x7F ? 1 : cp <= 0x7FF ? 2 : cp <= 0xFFFF ? 3 : cp <= 0x10FFFF ? 4 : 0;
+                    if (need != len) err = true;
+                    if ((cp & 0xFFFFF800) == 0xD800) err = true;
+                    if (err) cp = 0;
+                }
+                if (__any(err)) bad = true;
+            }
+            // ---- elements of this character
+            uint32_t v = 0xFFFFu; int c = 0;
+            if (start && !err) {
+                v = cpmap_get(p.cpmap, cp);
+                c = (v & 0x80000000u) ? (int)p.multi_pool[v & 0x7FFFFFFFu] : 1;
+            }
+            const uint16_t *rec = p.multi_pool + (v & 0x7FFFFFFFu) + 1;
+            const bool multi = (v & 0x80000000u) != 0;
+            const uint32_t first = c > 0 ? (multi ? (uint32_t)rec[0] : v) : 0u;
+            const uint32_t last = c > 0 ? (multi ? (uint32_t)rec[c - 1] : v) : 0u;
+            // previous element = last element of the nearest earlier lane that produced any, else the carry
+            const unsigned long long m_has = __ballot(c > 0);
+            const unsigned long long below = m_has & lanemask_lt();
+            const int pl = below ? 63 - __clzll((long long)below) : 0;
+            const uint32_t pl_last = __shfl(last, pl, 64);
+            uint32_t pe = below ? pl_last : prev;
+            bool hp = below ? true : have_prev;
+            // keep flags
+            int kept = 0;
+            {
+                uint32_t e = first;
+                for (int k = 0; k < c; ++k) {
+                    if (k > 0) e = rec[k];
+                    const bool ws = e == 0xFFFDu;
+                    if (!ws || !hp || !sp_delimish(pe, D)) ++kept;
+                    pe = e; hp = true;
+                }
+            }
+            const int inc = wave_incl_scan(kept);
+            int idx = outc + inc - kept;
+            {
+                uint32_t pe2 = below ? pl_last : prev; bool hp2 = below ? true : have_prev;
+                uint32_t e = first;
+                for (int k = 0; k < c; ++k) {
+                    if (k > 0) e = rec[k];
+                    const bool ws = e == 0xFFFDu;
+                    if (!ws || !hp2 || !sp_delimish(pe2, D)) { if (idx < cap) out[idx] = (uint16_t)(ws ? D : e); ++idx; }
+                    pe2 = e; hp2 = true;
+                }
+            }
+            outc += __shfl(inc, 63, 64);
+            normc += __shfl(wave_incl_scan(c), 63, 64);
+            decoded += __popcll(__ballot(start && !err));
+            if (m_has) { const int hl = 63 - __clzll((long long)m_has); prev = __shfl(last, hl, 64); have_prev = true; }
+            pos += 64;
+        }
+        int len = outc;
+        if (len > 1 && have_prev && sp_delimish(prev, D)) --len;                          // tokdll:1491-1493
+        if (bad || decoded <= 0) len = 0;                                                   // tokdll:1409-1411
+        if (p.has_charmap && (normc <= 0 || normc > 2 * (n + 1))) len = 0;                // tokdll:1440-1444
+        if (len > cap) len = 0;
+        if (lane == 0) p.lens[d] = len;
+    }
+}
+
+void launch_prep_sp(const SpPrepParams &p, hipStream_t s)
+{
+    int64_t blocks = (p.b.ndocs + 3) / 4;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(k_prep_sp, dim3((unsigned)blocks), dim3(256), 0, s, p);
+}
+
+// ------------------------------------------------------------------------------------------
+// k_seg_sp: one document per lane, the sequential programs of bf_seg.h with lane-private global scratch.
+// (First correct version: static assignment, compiler-managed divergence.)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_seg_sp(SpSegParams p)
+{
+    const int64_t d = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    if (d >= p.b.ndocs) return;
+    const int64_t b = p.b.doc_off[d];
+    const int64_t slot = sp_slot(b, d, p.slot_mul);
+    const int L = p.lens[d];
+    ClsWin cls_at; cls_at.init(p.stream, slot);
+    IdOutDirect out{p.ids_tmp + slot};
+    int r;
+    if (p.S.kind == SG_KIND_UNIGRAM) r = seg_unigram_doc(p.S, cls_at, L, p.sc + slot, p.bi + slot, out, p.max_ids, p.unk);
+    else {
+        const int64_t nbytes = p.b.doc_off[d + 1] - b;
+        const int arc_cap = 6 * (int)(p.slot_mul * (nbytes + 1)) + 32;
+        r = seg_bpe_doc(p.S, cls_at, L, p.arcs + 6 * slot + 32 * d, arc_cap, p.tos + slot, p.idsv + slot, p.inter + slot, out, p.max_ids, p.unk);
+        if (r < 0) { atomicOr(p.status, 2); r = 0; }
+    }
+    p.counts[d] = r;
+}
+
+void launch_seg_sp(const SpSegParams &p, hipStream_t s)
+{
+    const int64_t blocks = (p.b.ndocs + 63) / 64;
+    hipLaunchKernelGGL(k_seg_sp, dim3((unsigned)blocks), dim3(64), 0, s, p);
+}
+
+// ------------------------------------------------------------------------------------------
 // scan: counts[ndocs] (int32) -> id_off[ndocs+1] (int64), three small kernels
 // ------------------------------------------------------------------------------------------
 constexpr int SCAN_ITEMS = 4, SCAN_THREADS = 256, SCAN_TILE = SCAN_ITEMS * SCAN_THREADS;
@@ -428,7 +594,7 @@ __global__ __launch_bounds__(256) void k_compact(CompactParams p)
     const int64_t nwaves = (int64_t)gridDim.x * 4;
     for (int64_t d = wave0; d < p.b.ndocs; d += nwaves) {
         const int c = p.counts[d];
-        const int32_t *src = p.ids_tmp + ids_slot(p.b.doc_off[d], d);
+        const int32_t *src = p.ids_tmp + (p.slot_mul > 0 ? sp_slot(p.b.doc_off[d], d, p.slot_mul) : ids_slot(p.b.doc_off[d], d));
         const int64_t o = p.id_off[d];
         for (int i = lane; i < c; i += 64) {
             if (o + i < p.ids_cap) p.ids_out[o + i] = src[i];

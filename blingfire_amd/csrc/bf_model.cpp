@@ -730,6 +730,58 @@ bool build_model(Model &m, const uint8_t *img, size_t size)
             if (cm.max_key > 0x10FFFF) return fail(m, "charmap keys beyond the code point range");
         }
     }
+    if (m.has_seg) {
+        // ---- device forms of the dictionary side
+        if (m.dict.nclasses >= 0xFFF0) return fail(m, "dictionary alphabet too large for the 16-bit class stream");
+        if (m.i2info_min_key != 0) return fail(m, "I2Info keys must start at 0");
+        {   // the MPH index of every accepted string must have a usable I2Info row (the reference LogAsserts otherwise)
+            const auto &rw = m.dict_raw; const size_t ns = rw.state_off.size();
+            std::vector<double> paths(ns, -1.0);
+            std::function<double(int)> cnt = [&](int s) -> double {
+                if (paths[(size_t)s] >= 0) return paths[(size_t)s];
+                double c = rw.is_final[(size_t)s] ? 1.0 : 0.0;
+                paths[(size_t)s] = 0;   // cycle guard
+                for (uint32_t t = rw.tr_begin[(size_t)s]; t < rw.tr_begin[(size_t)s + 1]; ++t) if (rw.tr_dst[t] >= 0) c += cnt(rw.tr_dst[t]);
+                paths[(size_t)s] = c; return c;
+            };
+            const double nstrings = m.trie_max_depth == 0x7fffffff ? 1e18 : cnt(rw.initial);
+            const int need = (m.kind == KIND_UNIGRAM || m.kind == KIND_BPE_MERGES) ? 2 : 1;
+            if (nstrings > (double)m.i2info_id.size()) return fail(m, "dictionary accepts more strings than I2Info has rows");
+            for (size_t k = 0; k < (size_t)nstrings; ++k) if (m.i2info_valid[k] < need) return fail(m, "I2Info row without id/score");
+        }
+        m.seg_info.resize(m.i2info_id.size());
+        for (size_t k = 0; k < m.i2info_id.size(); ++k) m.seg_info[k] = (uint64_t)(uint32_t)m.i2info_id[k] | ((uint64_t)m.i2info_score[k] << 32);
+        auto is_ws = [](int c) { return c <= 0x20 || c == 0xa0 || (c >= 0x2000 && c <= 0x200f) || c == 0x202f || c == 0x205f || c == 0x2060 ||
+                                        c == 0x2420 || c == 0x2424 || c == 0x3000 || c == 0xfeff; };   // blingfiretokdll.h:17-21
+        auto code_of = [&](int c) -> uint16_t {
+            if (is_ws(c)) return SP_WS;
+            uint32_t k = m.dict_clsmap.get(c);
+            if (k != CLS_NONE_W) return (uint16_t)k;
+            return c == 0x2581 ? SP_DELIM_ABSENT : SP_NONE;
+        };
+        m.sp_delim_code = code_of(0x2581);
+        m.sp_cpmap.init(SP_NONE);
+        const int cp_max = m.use_bytes ? 255 : 0x10FFFF;
+        auto fused = [&](int cp, std::vector<uint16_t> &codes) {
+            codes.clear();
+            uint32_t v = m.dict_has_charmap ? m.dict_charmap.get(cp) : NORM_NONE;
+            if (v == NORM_NONE) { codes.push_back(code_of(cp)); return; }
+            const uint32_t cntv = v >> 24, pay = v & 0xffffffu;
+            if (cntv == 1) codes.push_back(code_of((int)pay));
+            else if (cntv == 11) codes.push_back(code_of(m.dict_norm_pool[pay]));
+            else for (uint32_t k = 0; k < cntv; ++k) codes.push_back(code_of(m.dict_norm_pool[pay + k]));
+        };
+        std::vector<uint16_t> codes;
+        for (int cp = 0; cp <= cp_max; ++cp) {
+            fused(cp, codes);
+            if (codes.size() == 1) { if (codes[0] != SP_NONE) m.sp_cpmap.set(cp, codes[0]); continue; }
+            m.sp_has_multi = true;
+            m.sp_cpmap.set(cp, FUSED_MULTI | (uint32_t)m.sp_multi_pool.size());
+            m.sp_multi_pool.push_back((uint16_t)codes.size());
+            for (uint16_t c : codes) m.sp_multi_pool.push_back(c);
+        }
+        fused(0x2581, m.sp_prefix);
+    }
     if (!m.has_seg) {
         m.kind = KIND_WP;
         if (!m.has_wbd || m.wbd.table_len() == 0) return fail(m, "model has neither a [wbd] lexer nor a [pos-dict] dictionary");

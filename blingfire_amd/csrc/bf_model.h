@@ -121,11 +121,21 @@ struct Model {
     TwoLevelMap dict_charmap; std::vector<int32_t> dict_norm_pool; bool dict_has_charmap = false;
     TwoLevelMap dict_clsmap;           // code point (or byte) -> class of the dictionary alphabet, CLS_NONE_W if absent
     int trie_max_depth = 0;            // longest path from the initial state (bounds every arc length)
+    // device forms
+    std::vector<uint64_t> seg_info;    // I2Info rows as (id | score_bits << 32), key = MPH index
+    // fused "code point (or byte) -> charmap -> element code" map of the _sp prologue.  Element codes (u16):
+    //   class of the dictionary alphabet | SP_NONE (not in alphabet) | SP_WS (whitespace, tokdll.h:17-21) |
+    //   SP_DELIM_ABSENT (U+2581 when the alphabet lacks it).  Value = code, or FUSED_MULTI | pool offset
+    //   ([count, codes...]) for 0 or 2..10 outputs.
+    TwoLevelMap sp_cpmap; std::vector<uint16_t> sp_multi_pool; bool sp_has_multi = false;
+    uint16_t sp_delim_code = 0xFFFE;   // element code of U+2581
+    std::vector<uint16_t> sp_prefix;   // element codes of the normalised dummy prefix (tokdll:1372)
 };
 
 constexpr uint32_t FUSED_MULTI = 0x80000000u;
 constexpr uint32_t NORM_NONE = 0xFFFFFFFFu;
 constexpr uint32_t CLS_NONE_W = 0xFFFFFu;     // T64 class "none"
+constexpr uint16_t SP_NONE = 0xFFFF, SP_DELIM_ABSENT = 0xFFFE, SP_WS = 0xFFFD;
 
 // Parses and re-lays-out a model image.  Returns false and sets m.error on failure.
 bool build_model(Model &m, const uint8_t *img, size_t size);

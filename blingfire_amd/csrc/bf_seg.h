@@ -1,3 +1,211 @@
-// bf_seg.h -- per-document segmenter programs (Unigram-LM / BPE); filled in below.
+// bf_seg.h -- per-document segmenter programs for the SentencePiece-style branch (one document per lane).
+//
+// Reproduce, on the re-laid-out dictionary tables of bf_model.h (64-bit displacement-packed Mealy entries
+// + I2Info rows), the reference
+//   FATokenSegmentationTools_1best_t<int>::Process               (Unigram-LM Viterbi 1-best)
+//       blingfireclient.library/inc/FATokenSegmentationTools_1best_t.h:175-279 (AddArc 118-142, AddUnknownArc 145-171)
+//   FATokenSegmentationTools_1best_bpe_t<int>::Process            (BPE, rank == id, optional bpe-opt shortcut)
+//       blingfireclient.library/inc/FATokenSegmentationTools_1best_bpe_t.h:126-316
+//   FATokenSegmentationTools_1best_bpe_with_merges_t<int>::Process (BPE with a separate float merge rank)
+//       blingfireclient.library/inc/FATokenSegmentationTools_1best_bpe_with_merges_t.h:129-323
+// and the id loop of TextToIdsWithOffsets_sp (blingfiretools/blingfiretokdll/blingfiretokdll.cpp:1509-1532).
+// Input = the class stream the prep stage produced (dummy prefix, charmap, whitespace collapse already done,
+// tokdll:1367-1496).
+//
+// Floating point: scores are float32 bit patterns widened to double and accumulated exactly as the reference
+// does (same operations, same order, strict '<'); compiled with -ffp-contract=off.
+//
+// BF_HD code: the HIP kernels run it per lane; tests/hosttest compiles it for the host (test-only).
 #pragma once
 #include "bf_lex.h"
+
+namespace bfa {
+
+constexpr uint64_t SG_CLS_MASK = 0xFFFFFull, SG_FINAL = 1ull << 20, SG_NEXT_MASK = 0x1FFFFFull;
+constexpr int SG_NEXT_SHIFT = 21, SG_OW_SHIFT = 42;
+constexpr uint64_t SG_MISS = ~0ull;
+constexpr uint32_t SG_CLS_NONE = 0xFFFFu;          // class stream: symbol not in the dictionary alphabet
+constexpr uint32_t SG_CLS_DELIM_ABSENT = 0xFFFEu;  // class stream: U+2581 when the alphabet does not contain it
+constexpr int SG_KIND_UNIGRAM = 1, SG_KIND_BPE = 2, SG_KIND_BPE_OPT = 3, SG_KIND_BPE_MERGES = 4;
+
+struct SegInfo { int32_t id; uint32_t score_bits; };   // one I2Info row (FAMultiMap_pack_fixed.cpp:140-160): [id, float score]
+
+struct SegTables {
+    const uint64_t *T;          // displacement-packed Mealy transitions (bf_model.h T64 entry)
+    const SegInfo *info;        // I2Info rows, key = MPH index (sum of output weights along the path)
+    uint32_t initial;
+    uint32_t cls_delim;         // class-stream value of U+2581
+    int kind, id_offset;
+};
+
+struct SegArc { int32_t start, end, id; uint32_t rank_bits; };   // BPE arc (…_bpe_t.h:66-88, …_with_merges_t.h)
+
+// FAMealyDfa_pack_triv::GetDestOw (cl/src/FAMealyDfa_pack_triv.cpp:69-244) on the packed table
+BF_HD uint64_t sg_lookup(const SegTables &S, uint32_t state, uint32_t cls)
+{
+    if (cls >= SG_CLS_DELIM_ABSENT) return SG_MISS;
+    const uint64_t e = S.T[state + cls];
+    return (e & SG_CLS_MASK) == cls ? e : SG_MISS;
+}
+BF_HD float sg_bits_to_float(uint32_t b) { union { uint32_t u; float f; } x; x.u = b; return x.f; }
+
+// ---------------------------------------------------------------------------------------------------
+// Unigram-LM.  sc[] / bi[] are the End2BestArc array (…_1best_t.h:61-77,193), one entry per position.
+// ---------------------------------------------------------------------------------------------------
+struct SegBest { int32_t begin, id; };
+
+template <class ClsAt, class IdOut>
+BF_HD int seg_unigram_doc(const SegTables &S, ClsAt &cls_at, int L, double *sc, SegBest *bi, IdOut &out, int max_ids, int unk)
+{
+    if (L <= 0) return 0;                                              // …_1best_t.h:186-188
+    const double neg_flt_max = -3.40282346638528859811704183484516925e+38;   // (double)-FLT_MAX
+    for (int i = 0; i < L; ++i) { sc[i] = neg_flt_max; bi[i].begin = -1; bi[i].id = -1; }
+    for (int start = 0; start < L; ++start) {
+        uint32_t state = S.initial; int sum = 0; bool unknown = true;
+        for (int i = start; i < L; ++i) {
+            const uint64_t e = sg_lookup(S, state, cls_at(i));
+            if (e == SG_MISS) break;
+            state = (uint32_t)((e >> SG_NEXT_SHIFT) & SG_NEXT_MASK);
+            sum += (int)(e >> SG_OW_SHIFT);
+            if (e & SG_FINAL) {                                        // AddArc (…_1best_t.h:118-142)
+                const SegInfo r = S.info[sum];
+                const float score = sg_bits_to_float(r.score_bits);
+                const double prev = 0 < start ? sc[start - 1] : 0;
+                const double cand = score + prev;
+                if (sc[i] < cand) { bi[i].begin = start; bi[i].id = r.id; sc[i] = cand; }
+                unknown = false;
+            }
+        }
+        if (unknown) {                                                 // AddUnknownArc (…_1best_t.h:145-171)
+            const float unk_score = -100000.0f;
+            const double prev = 0 < start ? sc[start - 1] : 0;
+            const double cand = unk_score + prev;
+            if (sc[start] < cand) {
+                int b = start;
+                if (0 < start && -1 == bi[start - 1].id) b = bi[start - 1].begin;
+                bi[start].begin = b; bi[start].id = -1; sc[start] = cand;
+            }
+        }
+    }
+    // follow the best path backwards (…_1best_t.h:237-265); the reference reverses the triple array afterwards,
+    // here the token count is taken first so that each id goes straight to its forward position
+    int cnt = 0;
+    for (int end = L - 1; 0 <= end; end = bi[end].begin - 1) ++cnt;
+    int k = cnt - 1;
+    for (int end = L - 1; 0 <= end; end = bi[end].begin - 1, --k) {
+        const int id = bi[end].id != -1 ? bi[end].id : unk;
+        if (k < max_ids) out.put(k, id + S.id_offset);                 // tokdll:1512-1516
+    }
+    const int n = cnt < max_ids ? cnt : max_ids;
+    out.finish(n);
+    return n;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// BPE (both flavours).  arcs[] has room for arc_cap entries; tos/idsv/inter are the three work arrays of
+// …_bpe_t.h:258-296.  Returns -1 if arc_cap is exceeded (the host turns that into a loud error).
+// ---------------------------------------------------------------------------------------------------
+BF_HD bool sg_arc_less(const SegArc &a, const SegArc &b, bool merges)
+{
+    if (merges) {                                                      // …_with_merges_t.h:242-262: bigger ranks first
+        const float ra = sg_bits_to_float(a.rank_bits), rb = sg_bits_to_float(b.rank_bits);
+        if (ra > rb) return true;
+        if (!(ra == rb)) return false;
+    }
+    if (a.id < b.id) return true;                                      // …_bpe_t.h:238-255: smaller ids first
+    if (a.id != b.id) return false;
+    return a.start < b.start;                                          // then left-most first
+}
+
+// in-place heap sort (the order is total on the arcs that can occur, so any correct sort equals std::qsort)
+BF_HD void sg_sort_arcs(SegArc *a, int n, bool merges)
+{
+    for (int root0 = n / 2 - 1; root0 >= 0; --root0) {
+        int root = root0; const SegArc v = a[root];
+        for (;;) {
+            int child = 2 * root + 1;
+            if (child >= n) break;
+            if (child + 1 < n && sg_arc_less(a[child], a[child + 1], merges)) ++child;
+            if (!sg_arc_less(v, a[child], merges)) break;
+            a[root] = a[child]; root = child;
+        }
+        a[root] = v;
+    }
+    for (int end = n - 1; end > 0; --end) {
+        const SegArc v = a[end]; a[end] = a[0];
+        int root = 0;
+        for (;;) {
+            int child = 2 * root + 1;
+            if (child >= end) break;
+            if (child + 1 < end && sg_arc_less(a[child], a[child + 1], merges)) ++child;
+            if (!sg_arc_less(v, a[child], merges)) break;
+            a[root] = a[child]; root = child;
+        }
+        a[root] = v;
+    }
+}
+
+template <class ClsAt, class IdOut>
+BF_HD int seg_bpe_doc(const SegTables &S, ClsAt &cls_at, int L, SegArc *arcs, int arc_cap, int32_t *tos, int32_t *idsv,
+                      uint8_t *inter, IdOut &out, int max_ids, int unk)
+{
+    if (L <= 0) return 0;
+    const bool merges = S.kind == SG_KIND_BPE_MERGES;
+    const bool fast = S.kind == SG_KIND_BPE_OPT || merges;             // m_fFastBpe (…_bpe_t.h:110, …_with_merges_t.h:113)
+    int narcs = 0;
+    for (int start = 0; start < L; ++start) {
+        uint32_t state = S.initial; int sum = 0; bool unknown = true;
+        const bool token_start = cls_at(start) == S.cls_delim;
+        const int count_at_start = narcs;
+        int ff = start;
+        for (int i = start; i < L; ++i) {
+            const uint64_t e = sg_lookup(S, state, cls_at(i));
+            if (e == SG_MISS) break;
+            state = (uint32_t)((e >> SG_NEXT_SHIFT) & SG_NEXT_MASK);
+            sum += (int)(e >> SG_OW_SHIFT);
+            if (e & SG_FINAL) {
+                const SegInfo r = S.info[sum];
+                const bool apply = fast && token_start && ((i < L - 1) ? cls_at(i + 1) == S.cls_delim : true) && count_at_start < narcs;
+                SegArc a; a.start = start; a.end = i; a.id = r.id; a.rank_bits = r.score_bits;
+                if (!apply) {
+                    if (narcs >= arc_cap) return -1;
+                    arcs[narcs++] = a;
+                } else {                                               // whole-token arc replaces the pieces (…_bpe_t.h:189-206)
+                    arcs[count_at_start] = a; narcs = count_at_start + 1; ff = i;
+                }
+                unknown = false;
+            }
+        }
+        if (unknown) {                                                 // …_bpe_t.h:212-225
+            if (0 < narcs && unk == arcs[narcs - 1].id) arcs[narcs - 1].end = start;
+            else {
+                if (narcs >= arc_cap) return -1;
+                SegArc a; a.start = start; a.end = start; a.id = unk; a.rank_bits = 0;   // rank 0.0f
+                arcs[narcs++] = a;
+            }
+        }
+        if (fast) start = ff;                                          // …_bpe_t.h:228-230
+    }
+    sg_sort_arcs(arcs, narcs, merges);
+    for (int i = 0; i < L; ++i) { tos[i] = 0; idsv[i] = unk; inter[i] = 0; }
+    for (int k = 0; k < narcs; ++k) {                                  // …_bpe_t.h:274-296
+        const int s = arcs[k].start, e = arcs[k].end;
+        if (0 == inter[s] && (e + 1 == L || 0 == inter[e + 1])) {
+            tos[s] = e; idsv[s] = arcs[k].id;
+            for (int q = s + 1; q <= e; ++q) inter[q] = 1;
+        }
+    }
+    int cnt = 0;
+    for (int start = 0; start < L; ++start) {                          // …_bpe_t.h:299-313 + tokdll:1512-1516
+        const int e = tos[start];
+        if (e < start) return -2;   // a token start without an applied arc: the reference would loop forever here; fail loudly
+        if (cnt < max_ids) out.put(cnt, idsv[start] + S.id_offset);
+        ++cnt;
+        start = e;
+    }
+    const int n = cnt < max_ids ? cnt : max_ids;
+    out.finish(n);
+    return n;
+}
+
+} // namespace bfa

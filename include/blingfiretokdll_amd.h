@@ -67,7 +67,8 @@ int64_t TextToIdsBatch(void *ModelPtr, const char *text, const int64_t *doc_offs
 /* Device buffers (all five pointers are device memory of the model's GPU).  Work is enqueued on
  * `stream` (a hipStream_t; NULL = the default stream) and the call returns without synchronising:
  * 0 = enqueued, negative = error.  The total id count is d_id_offsets_out[ndocs].  ids_cap must be
- * >= min(total_bytes, ndocs * max_ids_per_doc) to be safe for any input; ids beyond ids_cap are dropped
+ * >= min(2 * (total_bytes + ndocs), ndocs * max_ids_per_doc) to be safe for any input (WordPiece models never
+ * need more than total_bytes); ids beyond ids_cap are dropped
  * and reported by BfLastStatus.  d_text needs no padding. */
 int TextToIdsBatchDevice(void *ModelPtr, const char *d_text, const int64_t *d_doc_offsets, int64_t ndocs,
                          int64_t total_bytes, int32_t *d_ids_out, int64_t ids_cap, int64_t *d_id_offsets_out,

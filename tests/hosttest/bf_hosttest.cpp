@@ -184,7 +184,50 @@ static int emu_wp(const Model &m, const char *s, int n, int32_t *ids, int max_id
     return lex_doc(L, cls_at, (int)cls.size(), out, max_ids, unk, frames);
 }
 
-static int emu_sp(const Model &, const char *, int, int32_t *, int, int) { return -1; }
+// scalar restatement of the _sp prologue on the fused element-code map (the prep KERNEL is wave-parallel; GPU tests cover it)
+static int emu_sp(const Model &m, const char *s, int n, int32_t *ids, int max_ids, int unk)
+{
+    if (n <= 0 || !s) return 0;
+    std::vector<int> cps((size_t)n);
+    int len;
+    if (m.use_bytes) {
+        const unsigned char *p = (const unsigned char *)s; int k = 0;
+        if (n >= 3 && p[0] == 0xEF && p[1] == 0xBB && p[2] == 0xBF) k = 3;
+        len = 0; for (; k < n; ++k) cps[(size_t)len++] = p[k];
+    } else len = bfo_utf8_to_utf32(s, n, cps.data(), n);
+    if (len <= 0) return 0;
+    std::vector<uint16_t> el;
+    if (!m.no_dummy_prefix) el = m.sp_prefix;
+    for (int i = 0; i < len; ++i) {
+        uint32_t v = m.sp_cpmap.get(cps[(size_t)i]);
+        if (v & FUSED_MULTI) { size_t off = v & 0x7fffffffu; int c = m.sp_multi_pool[off]; for (int k = 0; k < c; ++k) el.push_back(m.sp_multi_pool[off + 1 + (size_t)k]); }
+        else el.push_back((uint16_t)v);
+    }
+    if (m.dict_has_charmap && (el.empty() || (long)el.size() > 2L * (n + 1))) return 0;
+    std::vector<uint16_t> st;
+    const uint16_t D = m.sp_delim_code;
+    for (size_t i = 0; i < el.size(); ++i) {
+        const uint16_t e = el[i];
+        if (e != SP_WS) st.push_back(e);
+        else if (i == 0 || !(el[i - 1] == SP_WS || el[i - 1] == D)) st.push_back(D);
+    }
+    if (st.size() > 1 && st.back() == D) st.pop_back();
+    const int L = (int)st.size();
+    SegTables S;
+    S.T = m.dict.t64.data(); S.info = (const SegInfo *)m.seg_info.data(); S.initial = m.dict.initial_base; S.cls_delim = D;
+    S.kind = m.kind; S.id_offset = m.id_offset;
+    const uint16_t *cp = st.data();
+    auto cls_at = [cp](int i) -> uint32_t { return cp[i]; };
+    IdOutDirect out{ids};
+    if (m.kind == KIND_UNIGRAM) {
+        std::vector<double> sc((size_t)L + 1); std::vector<SegBest> bi((size_t)L + 1);
+        return seg_unigram_doc(S, cls_at, L, sc.data(), bi.data(), out, max_ids, unk);
+    }
+    const int cap = 6 * L + 32;
+    std::vector<SegArc> arcs((size_t)cap); std::vector<int32_t> tos((size_t)L + 1), idsv((size_t)L + 1); std::vector<uint8_t> inter((size_t)L + 1);
+    int r = seg_bpe_doc(S, cls_at, L, arcs.data(), cap, tos.data(), idsv.data(), inter.data(), out, max_ids, unk);
+    return r < 0 ? -2 : r;
+}
 
 int bft_emu_text_to_ids(void *hv, const char *s, int n, int32_t *ids, int max_ids, int unk)
 {

@@ -1,0 +1,81 @@
+"""GPU parity, SentencePiece-style branch (Unigram-LM / BPE / BPE with merge ranks): the HIP pipeline through the
+C-ABI vs the CPU checker.  Bar: bit-exact ids and counts (the Unigram scores are float32 bit patterns accumulated
+in float64 in the reference's exact order, so even the floating-point path must agree exactly)."""
+import numpy as np
+import pytest
+
+import bfutil
+import blingfire_amd as bf
+
+pytestmark = pytest.mark.gpu
+
+SP_MODELS = [m for m in ("gpt2.bin", "roberta.bin", "bpe_example.bin", "xlnet.bin", "xlnet_nonorm.bin", "laser100k.bin",
+                         "xlm_roberta_base.bin", "laser500k.bin") if bfutil.have_model(m)]
+
+
+@pytest.fixture(scope="module")
+def checker():
+    return bfutil.reference() if bfutil.have_ref() else bfutil.oracle()
+
+
+def _compare(h, ck, hck, docs, max_ids, unk):
+    text, off = bf.pack_docs(docs)
+    ids, id_off = bf.text_to_ids_batch(h, (text, off), max_ids, unk)
+    gids, goff = ck.batch(hck, text, off, max_ids, unk)
+    if not np.array_equal(id_off, goff) or not np.array_equal(ids, gids):
+        for d in range(len(docs)):
+            a = ids[id_off[d]:id_off[d + 1]]
+            b = gids[goff[d]:goff[d + 1]]
+            if not np.array_equal(a, b):
+                raise AssertionError("doc %d %r (max %d unk %d): gpu %s != ref %s" % (d, docs[d][:80], max_ids, unk, a[:40], b[:40]))
+        raise AssertionError("offset arrays differ")
+
+
+@pytest.mark.parametrize("model", SP_MODELS)
+def test_adversarial_and_fuzz(model, checker):
+    h = bf.load_model(bfutil.model_path(model))
+    hck = checker.load(bfutil.model_path(model))
+    try:
+        docs = list(bfutil.ADVERSARIAL) + bfutil.fuzz_docs(2500, seed=13)
+        for max_ids, unk in ((2048, 0), (3, 0), (64, 3), (1, 1)):
+            _compare(h, checker, hck, docs, max_ids, unk)
+    finally:
+        bf.free_model(h)
+        checker.free(hck)
+
+
+@pytest.mark.parametrize("model,workload", [("gpt2.bin", "config3"), ("xlm_roberta_base.bin", "headline512"), ("laser500k.bin", "headline512")])
+def test_corpus_bit_exact(model, workload, checker):
+    if not bfutil.have_model(model):
+        pytest.skip("%s not present" % model)
+    wl = bfutil.WORKLOADS[workload]
+    text, off = bfutil.gen_corpus(6000, **wl["gen"])
+    max_ids, unk = (2048, 0) if workload == "config3" else (1024, 3)
+    lib_path, _ = bfutil.checker_lib_path()
+    _, _, gids, goff = bfutil.cpu_text_to_ids_batch(lib_path, bfutil.model_path(model), text, off, max_ids, unk)
+    h = bf.load_model(bfutil.model_path(model))
+    try:
+        ids, id_off = bf.text_to_ids_batch(h, (text, off), max_ids, unk)
+        assert np.array_equal(id_off, goff)
+        assert np.array_equal(ids, gids)
+    finally:
+        bf.free_model(h)
+
+
+def test_no_dummy_prefix_switch(checker):
+    """SetNoDummyPrefix (tokdll:1669-1679) changes the prologue at run time"""
+    import ctypes
+    model = "xlnet.bin"
+    h = bf.load_model(bfutil.model_path(model))
+    hck = checker.load(bfutil.model_path(model))
+    try:
+        setter = getattr(checker.lib, "SetNoDummyPrefix", None) or getattr(checker.lib, "bfo_set_no_dummy_prefix")
+        setter.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        docs = list(bfutil.ADVERSARIAL) + bfutil.fuzz_docs(300, seed=17)
+        for flag in (1, 0):
+            bf.change_settings_dummy_prefix(h, not flag)
+            setter(ctypes.c_void_p(hck), flag)
+            _compare(h, checker, hck, docs, 256, 0)
+    finally:
+        bf.free_model(h)
+        checker.free(hck)
