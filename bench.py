@@ -30,7 +30,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="headline512", choices=["headline512", "config2", "config3"])
+    ap.add_argument("--workload", default="headline512", choices=["headline512", "config2", "config3", "config4", "config5"])
     ap.add_argument("--docs-per-gpu", type=int, default=0, help="override the shard size (documents per GPU)")
     ap.add_argument("--model", default="")
     ap.add_argument("--variant", type=int, default=-1, help="kernel variant (experiments)")
@@ -52,16 +52,23 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        # BF_BENCH_SHARE_GPU=1 (testing only): several ranks on ONE GPU over gloo, to exercise the N>1 code path on a 1-GPU box
+        share = os.environ.get("BF_BENCH_SHARE_GPU") == "1"
+        dev_index = 0 if share else local_rank
+        torch.cuda.set_device(dev_index)
+        if share:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", dev_index))
     else:
+        dev_index = 0
         torch.cuda.set_device(0)
-    dev = torch.device("cuda", local_rank if world > 1 else 0)
+    dev = torch.device("cuda", dev_index)
 
     wl = bfutil.WORKLOADS[args.workload]
     model_name = args.model or wl["model"] or bfutil.bert_model_name()
     max_ids, unk = wl["max_ids"], wl["unk"]
-    default_docs = {"headline512": 1250000, "config2": 1000000, "config3": 1000000}[args.workload]
+    default_docs = {"headline512": 1250000, "config2": 1000000, "config3": 1000000, "config4": 1250000, "config5": 1250000}[args.workload]
     docs_per_gpu = args.docs_per_gpu or default_docs
 
     # ---- the rank's shard, generated on the host and made resident in HBM before any timing
@@ -73,7 +80,7 @@ def main():
         bf.lib().BfSetVariant(h, args.variant)
     ndocs = docs_per_gpu
     total_bytes = int(off[-1])
-    cap = max(1, min(total_bytes, ndocs * max_ids))
+    cap = max(1, min(2 * (total_bytes + ndocs), ndocs * max_ids))
     out_ids = torch.empty(cap, dtype=torch.int32, device=dev)
     out_off = torch.empty(ndocs + 1, dtype=torch.int64, device=dev)
 
@@ -109,7 +116,7 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     kms /= max(args.steps, 1)
@@ -124,6 +131,14 @@ def main():
         alg_bytes = total_bytes + 4 * n_ids + 16 * ndocs
         tok_ms = float(kms[1])
         achieved = alg_bytes / (tok_ms * 1e-3) / 1e9 if tok_ms > 0 else 0.0
+        traffic = None
+        try:   # HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this same command
+            tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+            ent = tj.get("%s/%s/%d" % (args.workload, model_name, ndocs))
+            if ent:
+                traffic = ent["hbm_bytes_per_launch"]
+        except Exception:
+            traffic = None
         res = {
             "metric": "docs/sec", "value": value, "unit": "docs/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -135,8 +150,8 @@ def main():
             "gb_input_per_sec": gb_in,
             "ids_per_sec": n_ids * max(world, 1) * args.steps / elapsed,
             "kernel_ms": {"prep": float(kms[0]), "tokenise": tok_ms, "scan": float(kms[2]), "compact": float(kms[3]), "total": float(kms[4])},
-            "roofline": {"bound": "hbm", "kernel": "tokenise (k_lex_wp)", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+            "roofline": {"bound": "hbm", "kernel": "tokenise (%s)" % ("k_lex_wp_flat" if "bert" in model_name or "wbd" in model_name else "k_seg_sp"), "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": alg_bytes},
             "verified_docs": verified, "status": status,
         }

@@ -173,6 +173,10 @@ WORKLOADS = {
     "headline512": dict(model=None, gen=dict(seed=20240201, mean=512, sd=64, minlen=128, maxlen=1024), max_ids=512, unk=100),
     "config2": dict(model=None, gen=dict(seed=20240202, mean=128, sd=16, minlen=32, maxlen=256), max_ids=512, unk=100),
     "config3": dict(model="gpt2.bin", gen=dict(seed=3, minlen=32, maxlen=2048, loguniform=True, multibyte=True), max_ids=2048, unk=0),
+    # configs 4/5 use the same 512-byte generator with multibyte runs (the multilingual generator of SURVEY.md §8d needs the
+    # reference's pos.dict files, which do not travel; script coverage is a later round)
+    "config4": dict(model="xlm_roberta_base.bin", gen=dict(seed=4, mean=512, sd=64, minlen=128, maxlen=1024, multibyte=True), max_ids=1024, unk=3),
+    "config5": dict(model="laser500k.bin", gen=dict(seed=5, mean=512, sd=64, minlen=128, maxlen=1024, multibyte=True), max_ids=1024, unk=0),
 }
 
 
