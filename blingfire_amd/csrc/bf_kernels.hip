@@ -176,6 +176,26 @@ struct ClsWin {
     }
 };
 
+// 32-byte variant of the window (16 characters per refill)
+struct ClsWin32 {
+    const uint4 *cls16; int64_t blk0; int shift; uint4 w0, w1; int tag;
+    __device__ __forceinline__ void init(const uint16_t *cls_buf, int64_t elem_off)
+    {
+        cls16 = (const uint4 *)cls_buf; blk0 = (elem_off >> 4) * 2; shift = (int)(elem_off & 15); tag = -1;
+        w0 = make_uint4(0, 0, 0, 0); w1 = w0;
+    }
+    __device__ __forceinline__ uint32_t operator()(int i)
+    {
+        const int a = i + shift, t = a >> 4;
+        if (t != tag) { const uint4 *q = cls16 + blk0 + 2 * (int64_t)t; w0 = q[0]; w1 = q[1]; tag = t; }
+        const uint32_t l0 = (a & 2) ? w0.y : w0.x, h0 = (a & 2) ? w0.w : w0.z;
+        const uint32_t l1 = (a & 2) ? w1.y : w1.x, h1 = (a & 2) ? w1.w : w1.z;
+        const uint32_t d0 = (a & 4) ? h0 : l0, d1 = (a & 4) ? h1 : l1;
+        const uint32_t dw = (a & 8) ? d1 : d0;
+        return (a & 1) ? (dw >> 16) : (dw & 0xFFFFu);
+    }
+};
+
 // saved frames in LDS, structure-of-arrays (bank = lane): word (d, field) of lane t at [(d*12 + field) * nthreads + t]
 struct FramesLds {
     int32_t *lds; int nthreads;
@@ -247,12 +267,12 @@ __global__ __launch_bounds__(THREADS) void k_lex_wp_seq(WpLexParams p)
 // counter; every loop iteration a lane in WALK mode makes exactly one DFA transition, while the heavier
 // "event" code (match handling, calls/returns, next start position) and the document fetch run only when
 // enough lanes of the wave are waiting for them (ballot vote), so that they execute with most lanes active.
-template <int THREADS>
+template <int THREADS, class WIN, bool HAS_ANY, int UNROLL>
 __global__ __launch_bounds__(THREADS) void k_lex_wp_flat(WpLexParams p)
 {
     extern __shared__ int32_t lex_lds[];
     enum { M_NEED = 0, M_WALK = 1, M_EVENT = 2, M_EXIT = 3 };
-    ClsWin cls_at; cls_at.init(p.cls, 0);
+    WIN cls_at; cls_at.init(p.cls, 0);
     IdOutLds out; out.buf = lex_lds + (size_t)p.L.max_frames * LEX_FRAME_WORDS * THREADS + threadIdx.x; out.nthreads = THREADS;
     out.init(p.ids_tmp);
     FramesLds frames{lex_lds, THREADS};
@@ -264,7 +284,7 @@ __global__ __launch_bounds__(THREADS) void k_lex_wp_flat(WpLexParams p)
         __syncthreads();
         L.acts = acts_lds;          // unconditionally LDS: the loads compile to ds_read, not flat_load
     }
-    LexLane<ClsWin, IdOutLds, FramesLds> lane(L, cls_at, out, frames);
+    LexLane<WIN, IdOutLds, FramesLds, HAS_ANY> lane(L, cls_at, out, frames);
     lane.init(0, 0, 0);
     int mode = M_NEED;
     int64_t doc = -1;
@@ -274,7 +294,8 @@ __global__ __launch_bounds__(THREADS) void k_lex_wp_flat(WpLexParams p)
         //      finished walk (or nobody walks any more)
         unsigned long long m_event;
         for (;;) {
-            if (mode == M_WALK) { if (!lane.step()) mode = M_EVENT; }
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) { if (mode == M_WALK) { if (!lane.step()) mode = M_EVENT; } }
             const unsigned long long m_walk = __ballot(mode == M_WALK);
             m_event = __ballot(mode == M_EVENT);
             if (m_walk == 0 || __popcll(m_event) >= ev_thresh) break;
@@ -334,7 +355,7 @@ void launch_lex_wp(const WpLexParams &p, int variant, hipStream_t s)
         int waves_per_cu = (variant >> 24) & 0x3f;
         if (waves_per_cu == 0) {                                      // persistent: exactly the resident waves
             int per_cu = 0, ncu = 256;
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_lex_wp_flat<64>, 64, lex_lds_bytes(q, 64)) != hipSuccess || per_cu <= 0) per_cu = 16;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_lex_wp_flat<64, ClsWin, false, 1>, 64, lex_lds_bytes(q, 64)) != hipSuccess || per_cu <= 0) per_cu = 16;
             hipDeviceProp_t prop; int dev = 0;
             if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ncu = prop.multiProcessorCount;
             static_cast<void>(ncu);
@@ -345,7 +366,12 @@ void launch_lex_wp(const WpLexParams &p, int variant, hipStream_t s)
         const int64_t need = (p.b.ndocs + 63) / 64;
         if (blocks > need) blocks = need;
         if (blocks < 1) blocks = 1;
-        hipLaunchKernelGGL(k_lex_wp_flat<64>, dim3((unsigned)blocks), dim3(64), lex_lds_bytes(q, 64), s, q);
+        const bool has_any = p.L.cls_any != LX_CLS_NONE;
+        const int unroll = (variant >> 30) & 1 ? 1 : 2;      // two DFA transitions per vote by default
+        const dim3 g((unsigned)blocks), t(64); const size_t lds = lex_lds_bytes(q, 64);
+        if (has_any) hipLaunchKernelGGL((k_lex_wp_flat<64, ClsWin, true, 1>), g, t, lds, s, q);
+        else if (unroll == 2) hipLaunchKernelGGL((k_lex_wp_flat<64, ClsWin, false, 2>), g, t, lds, s, q);
+        else hipLaunchKernelGGL((k_lex_wp_flat<64, ClsWin, false, 1>), g, t, lds, s, q);
     }
 }
 

@@ -44,21 +44,25 @@ struct LexTables {
     int max_frames;           // saved frames the call graph can need (= call depth - 1, computed at load; <= LEX_MAX_DEPTH - 1)
 };
 
-// one DFA transition: returns the table entry (low word LX_MISS on a miss)
+// one DFA transition: returns the table entry (low word LX_MISS on a miss).  Branch-free: a class outside the
+// alphabet (LX_CLS_NONE) probes slot state + 0x1FFF, whose stored class can never equal it (the table is padded
+// by 0x2000 entries past the largest base, bf_model.cpp).
 BF_HD uint64_t lx_lookup(const LexTables &L, uint32_t state, uint32_t cls)
 {
-    if (cls >= LX_T_CLS_MASK) return LX_MISS;
-    const uint64_t e = L.T[state + cls];
+    const uint32_t idx = state + (cls < LX_T_CLS_MASK ? cls : LX_T_CLS_MASK);
+    const uint64_t e = L.T[idx];
 #ifdef BF_LEX_PROFILE_HOOK
-    BF_LEX_PROFILE_HOOK(state + cls);
+    BF_LEX_PROFILE_HOOK(idx);
 #endif
     return ((uint32_t)e & LX_T_CLS_MASK) == cls ? e : (uint64_t)LX_MISS;
 }
-// GetDest(State, Iw) with the IW_ANY retry of FALexTools_t.h:265-270
+// GetDest(State, Iw) with the IW_ANY retry of FALexTools_t.h:265-270.  HAS_ANY is a compile-time fact of the
+// model (IW_ANY is in the alphabet or not) so that models without it pay nothing for the retry.
+template <bool HAS_ANY>
 BF_HD uint64_t lx_dest(const LexTables &L, uint32_t state, uint32_t cls)
 {
     uint64_t e = lx_lookup(L, state, cls);
-    if ((uint32_t)e == LX_MISS && L.cls_any != LX_CLS_NONE) e = lx_lookup(L, state, L.cls_any);
+    if (HAS_ANY) { if ((uint32_t)e == LX_MISS) e = lx_lookup(L, state, L.cls_any); }
     return e;
 }
 
@@ -73,6 +77,9 @@ struct LexFrame {      // caller state saved across a _call (FALexTools_t.h:350-
     uint32_t ini; int off, n, from, once, a_idx, a_end, to2, fn_once, fp_r, fn_from, emit_mark;
 };
 constexpr int LEX_FRAME_WORDS = 12;
+#ifndef LEX_SKIP_DEAD_STARTS
+#define LEX_SKIP_DEAD_STARTS 0
+#endif
 
 struct FramesArray {   // host emulation only (a dynamically indexed private struct array mis-executed on the device)
     LexFrame st[LEX_MAX_DEPTH - 1];
@@ -80,7 +87,7 @@ struct FramesArray {   // host emulation only (a dynamically indexed private str
     BF_HD void load(int d, LexFrame &f) const { f = st[d]; }
 };
 
-template <class ClsAt, class IdOut, class Frames>
+template <class ClsAt, class IdOut, class Frames, bool HAS_ANY>
 struct LexLane {
     const LexTables &L; ClsAt &cls_at; IdOut &ids; Frames &frames;
     // ---- streaming _wp post-pass (tokdll:1210-1311)
@@ -156,6 +163,28 @@ struct LexLane {
                 continue;
             }
             // ---- set up one start position (FALexTools_t.h:229-252)
+            if (LEX_SKIP_DEAD_STARTS && from >= 0 && L.max_token_length > 0) {
+                // A start whose first letter has no transition from the frame's initial state matches nothing
+                // (the walk breaks at j == from < InSize, so no right anchor either): skip such starts here instead
+                // of spending a walk + an event on each (whitespace in the BERT models).  The first transition is
+                // taken here and the walk resumes at the second letter.
+                uint64_t e64 = LX_MISS;
+                while (from < fn_) {
+                    e64 = lx_dest<HAS_ANY>(L, ini, cls_at(off + from));
+                    if ((uint32_t)e64 != LX_MISS) break;
+                    ++from;
+                }
+                if (from >= fn_) continue;
+                const uint32_t e = (uint32_t)e64;
+                state = e >> LX_T_NEXT_SHIFT; fp = -1; finfo = 0;
+                if (e & LX_T_FINAL) { finfo = (uint32_t)(e64 >> 32); fp = from; }
+                j = from + 1;
+                bound = from + L.max_token_length; if (fn_ < bound) bound = fn_;
+                if (j < bound || j == fn_) return true;               // more letters, or the right anchor
+                after_walk();                                         // the walk already ended (token length bound 1)
+                if (stop) return false;
+                continue;
+            }
             state = ini; fp = -1; finfo = 0; j = from;
             bound = from + L.max_token_length; if (fn_ < bound) bound = fn_;
             if (j >= 0 && !(j < bound)) { ++from; continue; }     // MaxTokenLength == 0: no letters, j != InSize
@@ -170,10 +199,9 @@ struct LexLane {
     {
         const bool la = j < 0, ra = j >= fn_;          // feeding the left / right anchor (FALexTools_t.h:244-252, 280-290)
         int jj = j < 0 ? 0 : j; if (ra) jj = fn_ > 0 ? fn_ - 1 : 0;
-        uint32_t c = LX_CLS_NONE;
-        if (fn_ > 0) c = cls_at(off + jj);             // a letter (FALexTools_t.h:255-277); unused under an anchor
+        uint32_t c = cls_at(off + jj);                 // a letter (FALexTools_t.h:255-277); read but unused under an anchor
         c = la ? L.cls_l : (ra ? L.cls_r : c);
-        const uint64_t e64 = lx_dest(L, state, c);
+        const uint64_t e64 = lx_dest<HAS_ANY>(L, state, c);
         const uint32_t e = (uint32_t)e64;
         const bool hit = e != LX_MISS;
         const bool fin = hit && !la && (e & LX_T_FINAL);   // no finality check after the left anchor
@@ -244,16 +272,23 @@ struct LexLane {
 };
 
 // Sequential driver (host emulation).  Returns the number of ids written (<= max_ids).
-template <class ClsAt, class IdOut, class Frames>
-BF_HD int lex_doc(const LexTables &L, ClsAt &cls_at, int n, IdOut &out, int max_ids, int unk, Frames &frames)
+template <bool HAS_ANY, class ClsAt, class IdOut, class Frames>
+BF_HD int lex_doc_t(const LexTables &L, ClsAt &cls_at, int n, IdOut &out, int max_ids, int unk, Frames &frames)
 {
-    LexLane<ClsAt, IdOut, Frames> lane(L, cls_at, out, frames);
+    LexLane<ClsAt, IdOut, Frames, HAS_ANY> lane(L, cls_at, out, frames);
     lane.init(n, max_ids, unk);
     while (lane.prepare()) {
         while (lane.step()) {}
         lane.after_walk();
     }
     return lane.finish();
+}
+
+template <class ClsAt, class IdOut, class Frames>
+BF_HD int lex_doc(const LexTables &L, ClsAt &cls_at, int n, IdOut &out, int max_ids, int unk, Frames &frames)
+{
+    return L.cls_any != LX_CLS_NONE ? lex_doc_t<true>(L, cls_at, n, out, max_ids, unk, frames)
+                                    : lex_doc_t<false>(L, cls_at, n, out, max_ids, unk, frames);
 }
 
 } // namespace bfa

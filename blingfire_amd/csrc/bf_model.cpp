@@ -340,7 +340,7 @@ bool pack_dfa(const RawDfa &raw, bool wide, const std::vector<int> &extra_syms, 
     base[ns] = next_free_base();
     uint32_t max_base = 0;
     for (uint32_t v : base) max_base = std::max(max_base, v);
-    const size_t table_len = std::max(max_slot + 1, (size_t)max_base + 1) + (size_t)out.nclasses + 1; // any base + any class stays in range
+    const size_t table_len = std::max(max_slot + 1, (size_t)max_base + 1) + (wide ? (size_t)out.nclasses + 1 : (size_t)T32_CLS_MASK + 1); // any base + any class (or the lexer's "none" probe at +0x1FFF) stays in range
     const uint64_t next_limit = wide ? (T64_NEXT_MASK + 1) : (1ull << (32 - T32_NEXT_SHIFT));
     if (table_len >= next_limit) { err = "automaton too large for the table entry format"; return false; }
 
