@@ -64,7 +64,7 @@ struct Handle {
     // device tables
     DevBuf t_wbd, t_info, t_acts, t_cp_l1, t_cp_pages, t_multi;
     DevBuf t_dict, t_seginfo;                                    // _sp: Mealy table, I2Info rows (code-point maps reuse t_cp_*/t_multi)
-    DevBuf w_s1, w_s2, w_s3, w_s4;                               // _sp scratch
+    DevBuf w_s1, w_s2, w_s3, w_s4, w_perm, w_hist, w_narcs;      // _sp scratch
     // workspaces
     DevBuf w_cls, w_nchars, w_tmp, w_counts, w_bsums, w_misc;   // w_misc: [0] next_doc (u64), [2] status (int)
     DevBuf w_text, w_docoff, w_ids, w_idoff;                    // host-API staging
@@ -73,7 +73,7 @@ struct Handle {
     bool ev_valid = false;
     ~Handle()
     {
-        for (DevBuf *b : {&t_wbd, &t_info, &t_acts, &t_cp_l1, &t_cp_pages, &t_multi, &t_dict, &t_seginfo, &w_s1, &w_s2, &w_s3, &w_s4, &w_cls, &w_nchars, &w_tmp, &w_counts,
+        for (DevBuf *b : {&t_wbd, &t_info, &t_acts, &t_cp_l1, &t_cp_pages, &t_multi, &t_dict, &t_seginfo, &w_s1, &w_s2, &w_s3, &w_s4, &w_perm, &w_hist, &w_narcs, &w_cls, &w_nchars, &w_tmp, &w_counts,
                           &w_bsums, &w_misc, &w_text, &w_docoff, &w_ids, &w_idoff}) b->release();
         for (auto &e : ev) if (e) (void)hipEventDestroy(e);
         if (stream) (void)hipStreamDestroy(stream);
@@ -180,6 +180,9 @@ int run_device(Handle *h, const char *d_text, const int64_t *d_doc_off, int64_t 
                 !h->w_s4.reserve(cap)) return BF_E_DEVICE;
             sg.arcs = h->w_s1.as<SegArc>(); sg.tos = h->w_s2.as<int32_t>(); sg.idsv = h->w_s3.as<int32_t>(); sg.inter = h->w_s4.as<uint8_t>();
         }
+        if (!h->w_perm.reserve((size_t)(ndocs + 1) * 4) || !h->w_hist.reserve(2048 * 4) || !h->w_narcs.reserve((size_t)(ndocs + 1) * 4)) return BF_E_DEVICE;
+        sg.narcs = h->w_narcs.as<int32_t>(); sg.next_doc = next_doc;
+        sg.perm = h->w_perm.as<int32_t>(); sg.hist = h->w_hist.as<unsigned int>();
         if (ndocs > 0) launch_seg_sp(sg, s);
         (void)hipEventRecord(h->ev[EV_TOK], s);
     }

@@ -65,6 +65,11 @@ struct SpSegParams {
     double *sc; SegBest *bi;
     SegArc *arcs; int32_t *tos; int32_t *idsv; uint8_t *inter;
     int *status;
+    // documents are handed to lanes in order of stream length (counting sort), so the 64 documents of a wave
+    // are of similar size: perm[i] = document processed by thread i; hist = 1024 bucket counters / cursors
+    int32_t *perm; unsigned int *hist;
+    int32_t *narcs;             // [ndocs] BPE arc count per document (-1 = capacity exceeded)
+    unsigned long long *next_doc;
 };
 
 struct ScanParams { const int32_t *counts; int64_t ndocs; int64_t *id_off; int64_t *block_sums; int nblocks; };

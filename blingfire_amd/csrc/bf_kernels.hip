@@ -515,21 +515,123 @@ void launch_prep_sp(const SpPrepParams &p, hipStream_t s)
 // k_seg_sp: one document per lane, the sequential programs of bf_seg.h with lane-private global scratch.
 // (First correct version: static assignment, compiler-managed divergence.)
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_seg_sp(SpSegParams p)
+// length bucketing: key = min(len / 4, 1023)
+__device__ __forceinline__ int sp_len_bucket(int len) { int k = len >> 2; return k > 1023 ? 1023 : k; }
+
+__global__ __launch_bounds__(256) void k_sp_hist(SpSegParams p)
 {
-    const int64_t d = (int64_t)blockIdx.x * 64 + threadIdx.x;
-    if (d >= p.b.ndocs) return;
+    const int64_t d = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (d < p.b.ndocs) atomicAdd(&p.hist[sp_len_bucket(p.lens[d])], 1u);
+}
+__global__ __launch_bounds__(1024) void k_sp_hist_scan(SpSegParams p)
+{
+    // exclusive scan of the 1024 bucket counts, longest documents first (they start first: better tail)
+    __shared__ unsigned int sh[1024];
+    const int t = threadIdx.x;
+    sh[t] = p.hist[1023 - t];
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) { unsigned int v = t >= o ? sh[t - o] : 0; __syncthreads(); sh[t] += v; __syncthreads(); }
+    p.hist[1024 + (1023 - t)] = t ? sh[t - 1] : 0;      // cursor of bucket (1023 - t)
+}
+__global__ __launch_bounds__(256) void k_sp_scatter(SpSegParams p)
+{
+    const int64_t d = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (d < p.b.ndocs) { const unsigned int pos = atomicAdd(&p.hist[1024 + sp_len_bucket(p.lens[d])], 1u); p.perm[pos] = (int32_t)d; }
+}
+
+// Unigram-LM: the sequential program per lane (documents in length order)
+__global__ __launch_bounds__(64) void k_seg_unigram(SpSegParams p)
+{
+    const int64_t i = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    if (i >= p.b.ndocs) return;
+    const int64_t d = p.perm[i];
+    const int64_t slot = sp_slot(p.b.doc_off[d], d, p.slot_mul);
+    ClsWin cls_at; cls_at.init(p.stream, slot);
+    IdOutDirect out{p.ids_tmp + slot};
+    p.counts[d] = seg_unigram_doc(p.S, cls_at, p.lens[d], p.sc + slot, p.bi + slot, out, p.max_ids, p.unk);
+}
+
+// BPE phase A: collect arcs, one document per lane
+__global__ __launch_bounds__(64) void k_bpe_collect(SpSegParams p)
+{
+    const int64_t i = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    if (i >= p.b.ndocs) return;
+    const int64_t d = p.perm[i];
     const int64_t b = p.b.doc_off[d];
     const int64_t slot = sp_slot(b, d, p.slot_mul);
     const int L = p.lens[d];
+    const int64_t nbytes = p.b.doc_off[d + 1] - b;
+    const int arc_cap = 6 * (int)(p.slot_mul * (nbytes + 1)) + 32;
     ClsWin cls_at; cls_at.init(p.stream, slot);
+    p.narcs[d] = L > 0 ? seg_bpe_collect(p.S, cls_at, L, p.arcs + 6 * slot + 32 * d, arc_cap, p.unk) : 0;
+}
+
+// BPE phase B1: sort the arcs of one document per 256-thread block (bitonic sort in LDS on the integer keys of
+// bf_seg.h; the order is total, so the result equals the reference's qsort).  Documents with more arcs than the
+// LDS holds are sorted by one thread with the in-place heap sort (slow path, loud in the docs).
+constexpr int BPE_NMAX = 4096;
+__global__ __launch_bounds__(256) void k_bpe_sort(SpSegParams p)
+{
+    __shared__ uint32_t k_hi[BPE_NMAX];
+    __shared__ uint64_t k_lo[BPE_NMAX];
+    __shared__ uint32_t k_val[BPE_NMAX];
+    __shared__ unsigned long long s_doc;
+    const bool merges = p.S.kind == SG_KIND_BPE_MERGES;
+    for (;;) {
+        __syncthreads();
+        if (threadIdx.x == 0) s_doc = atomicAdd(p.next_doc, 1ull);
+        __syncthreads();
+        const unsigned long long i = s_doc;
+        if (i >= (unsigned long long)p.b.ndocs) break;
+        const int64_t d = p.perm[i];
+        const int n = p.narcs[d];
+        if (n <= 1) continue;
+        SegArc *arcs = p.arcs + 6 * sp_slot(p.b.doc_off[d], d, p.slot_mul) + 32 * d;
+        if (n > BPE_NMAX) { if (threadIdx.x == 0) sg_sort_arcs(arcs, n, merges); continue; }
+        int n2 = 256; while (n2 < n) n2 <<= 1;
+        for (int k = threadIdx.x; k < n2; k += 256) {
+            if (k < n) { const SegArc a = arcs[k]; k_hi[k] = sg_key_hi(a, merges); k_lo[k] = sg_key_lo(a); k_val[k] = (uint32_t)a.end; }
+            else { k_hi[k] = 0xFFFFFFFFu; k_lo[k] = ~0ull; k_val[k] = 0; }
+        }
+        __syncthreads();
+        for (int k2 = 2; k2 <= n2; k2 <<= 1) {
+            for (int j2 = k2 >> 1; j2 > 0; j2 >>= 1) {
+                for (int t = threadIdx.x; t < (n2 >> 1); t += 256) {
+                    const int lo_i = ((t / j2) * (j2 << 1)) + (t % j2), hi_i = lo_i + j2;
+                    const bool up = (lo_i & k2) == 0;
+                    const uint32_t ah = k_hi[lo_i], bh = k_hi[hi_i];
+                    const uint64_t al = k_lo[lo_i], bl = k_lo[hi_i];
+                    const bool a_gt_b = ah > bh || (ah == bh && al > bl);
+                    if (a_gt_b == up) {
+                        k_hi[lo_i] = bh; k_hi[hi_i] = ah; k_lo[lo_i] = bl; k_lo[hi_i] = al;
+                        const uint32_t av = k_val[lo_i]; k_val[lo_i] = k_val[hi_i]; k_val[hi_i] = av;
+                    }
+                }
+                __syncthreads();
+            }
+        }
+        for (int k = threadIdx.x; k < n; k += 256) {
+            SegArc a; a.start = (int32_t)(uint32_t)k_lo[k]; a.end = (int32_t)k_val[k];
+            a.id = (int32_t)((uint32_t)(k_lo[k] >> 32) ^ 0x80000000u); a.rank_bits = 0;
+            arcs[k] = a;
+        }
+    }
+}
+
+// BPE phase B2: apply the sorted arcs and emit ids, one document per lane
+__global__ __launch_bounds__(64) void k_bpe_apply(SpSegParams p)
+{
+    const int64_t i = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    if (i >= p.b.ndocs) return;
+    const int64_t d = p.perm[i];
+    const int64_t slot = sp_slot(p.b.doc_off[d], d, p.slot_mul);
+    const int L = p.lens[d];
+    const int n = p.narcs[d];
     IdOutDirect out{p.ids_tmp + slot};
-    int r;
-    if (p.S.kind == SG_KIND_UNIGRAM) r = seg_unigram_doc(p.S, cls_at, L, p.sc + slot, p.bi + slot, out, p.max_ids, p.unk);
-    else {
-        const int64_t nbytes = p.b.doc_off[d + 1] - b;
-        const int arc_cap = 6 * (int)(p.slot_mul * (nbytes + 1)) + 32;
-        r = seg_bpe_doc(p.S, cls_at, L, p.arcs + 6 * slot + 32 * d, arc_cap, p.tos + slot, p.idsv + slot, p.inter + slot, out, p.max_ids, p.unk);
+    int r = 0;
+    if (n < 0) { atomicOr(p.status, 2); }
+    else if (L > 0) {
+        r = seg_bpe_finish(p.S, L, p.arcs + 6 * slot + 32 * d, n, p.tos + slot, p.idsv + slot, p.inter + slot, out, p.max_ids, p.unk, true);
         if (r < 0) { atomicOr(p.status, 2); r = 0; }
     }
     p.counts[d] = r;
@@ -537,8 +639,21 @@ __global__ __launch_bounds__(64) void k_seg_sp(SpSegParams p)
 
 void launch_seg_sp(const SpSegParams &p, hipStream_t s)
 {
-    const int64_t blocks = (p.b.ndocs + 63) / 64;
-    hipLaunchKernelGGL(k_seg_sp, dim3((unsigned)blocks), dim3(64), 0, s, p);
+    const unsigned b256 = (unsigned)((p.b.ndocs + 255) / 256);
+    const unsigned b64 = (unsigned)((p.b.ndocs + 63) / 64);
+    (void)hipMemsetAsync(p.hist, 0, 2048 * sizeof(unsigned int), s);
+    hipLaunchKernelGGL(k_sp_hist, dim3(b256), dim3(256), 0, s, p);
+    hipLaunchKernelGGL(k_sp_hist_scan, dim3(1), dim3(1024), 0, s, p);
+    hipLaunchKernelGGL(k_sp_scatter, dim3(b256), dim3(256), 0, s, p);
+    if (p.S.kind == SG_KIND_UNIGRAM) {
+        hipLaunchKernelGGL(k_seg_unigram, dim3(b64), dim3(64), 0, s, p);
+    } else {
+        hipLaunchKernelGGL(k_bpe_collect, dim3(b64), dim3(64), 0, s, p);
+        unsigned sort_blocks = 256 * 2;
+        if ((int64_t)sort_blocks > p.b.ndocs) sort_blocks = (unsigned)p.b.ndocs;
+        hipLaunchKernelGGL(k_bpe_sort, dim3(sort_blocks), dim3(256), 0, s, p);
+        hipLaunchKernelGGL(k_bpe_apply, dim3(b64), dim3(64), 0, s, p);
+    }
 }
 
 // ------------------------------------------------------------------------------------------

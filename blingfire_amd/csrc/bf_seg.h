@@ -145,11 +145,10 @@ BF_HD void sg_sort_arcs(SegArc *a, int n, bool merges)
     }
 }
 
-template <class ClsAt, class IdOut>
-BF_HD int seg_bpe_doc(const SegTables &S, ClsAt &cls_at, int L, SegArc *arcs, int arc_cap, int32_t *tos, int32_t *idsv,
-                      uint8_t *inter, IdOut &out, int max_ids, int unk)
+// Phase A: collect the arcs of one document (…_bpe_t.h:151-232).  Returns the arc count, or -1 if arc_cap is exceeded.
+template <class ClsAt>
+BF_HD int seg_bpe_collect(const SegTables &S, ClsAt &cls_at, int L, SegArc *arcs, int arc_cap, int unk)
 {
-    if (L <= 0) return 0;
     const bool merges = S.kind == SG_KIND_BPE_MERGES;
     const bool fast = S.kind == SG_KIND_BPE_OPT || merges;             // m_fFastBpe (…_bpe_t.h:110, …_with_merges_t.h:113)
     int narcs = 0;
@@ -186,7 +185,17 @@ BF_HD int seg_bpe_doc(const SegTables &S, ClsAt &cls_at, int L, SegArc *arcs, in
         }
         if (fast) start = ff;                                          // …_bpe_t.h:228-230
     }
-    sg_sort_arcs(arcs, narcs, merges);
+    return narcs;
+}
+
+// Phase B, sequential form: sort, apply the merges in order, emit (…_bpe_t.h:234-313 + tokdll:1512-1516).
+// Returns the id count, or -2 when a token start has no applied arc (the reference would loop forever there).
+template <class IdOut>
+BF_HD int seg_bpe_finish(const SegTables &S, int L, SegArc *arcs, int narcs, int32_t *tos, int32_t *idsv, uint8_t *inter,
+                         IdOut &out, int max_ids, int unk, bool presorted = false)
+{
+    const bool merges = S.kind == SG_KIND_BPE_MERGES;
+    if (!presorted) sg_sort_arcs(arcs, narcs, merges);
     for (int i = 0; i < L; ++i) { tos[i] = 0; idsv[i] = unk; inter[i] = 0; }
     for (int k = 0; k < narcs; ++k) {                                  // …_bpe_t.h:274-296
         const int s = arcs[k].start, e = arcs[k].end;
@@ -196,9 +205,9 @@ BF_HD int seg_bpe_doc(const SegTables &S, ClsAt &cls_at, int L, SegArc *arcs, in
         }
     }
     int cnt = 0;
-    for (int start = 0; start < L; ++start) {                          // …_bpe_t.h:299-313 + tokdll:1512-1516
+    for (int start = 0; start < L; ++start) {                          // …_bpe_t.h:299-313
         const int e = tos[start];
-        if (e < start) return -2;   // a token start without an applied arc: the reference would loop forever here; fail loudly
+        if (e < start) return -2;
         if (cnt < max_ids) out.put(cnt, idsv[start] + S.id_offset);
         ++cnt;
         start = e;
@@ -207,5 +216,27 @@ BF_HD int seg_bpe_doc(const SegTables &S, ClsAt &cls_at, int L, SegArc *arcs, in
     out.finish(n);
     return n;
 }
+
+template <class ClsAt, class IdOut>
+BF_HD int seg_bpe_doc(const SegTables &S, ClsAt &cls_at, int L, SegArc *arcs, int arc_cap, int32_t *tos, int32_t *idsv,
+                      uint8_t *inter, IdOut &out, int max_ids, int unk)
+{
+    if (L <= 0) return 0;
+    const int narcs = seg_bpe_collect(S, cls_at, L, arcs, arc_cap, unk);
+    if (narcs < 0) return -1;
+    return seg_bpe_finish(S, L, arcs, narcs, tos, idsv, inter, out, max_ids, unk);
+}
+
+// Sort key of an arc as unsigned integers, ascending == the reference's comparator order:
+//   hi = merge rank, descending (0 for plain BPE);  lo = (id ascending) << 32 | start ascending
+BF_HD uint32_t sg_key_hi(const SegArc &a, bool merges)
+{
+    if (!merges) return 0;
+    uint32_t b = a.rank_bits;
+    if ((b << 1) == 0) b = 0;                                          // -0.0f == 0.0f
+    const uint32_t asc = (b & 0x80000000u) ? ~b : (b | 0x80000000u);   // monotone in the float value
+    return ~asc;                                                       // bigger ranks first
+}
+BF_HD uint64_t sg_key_lo(const SegArc &a) { return ((uint64_t)((uint32_t)a.id ^ 0x80000000u) << 32) | (uint32_t)a.start; }
 
 } // namespace bfa
