@@ -171,10 +171,10 @@ int run_device(Handle *h, const char *d_text, const int64_t *d_doc_off, int64_t 
         sg.S.cls_delim = m.sp_delim_code; sg.S.kind = m.kind; sg.S.id_offset = m.id_offset;
         sg.b = b; sg.stream = h->w_cls.as<uint16_t>(); sg.lens = h->w_nchars.as<int32_t>(); sg.slot_mul = mul;
         sg.ids_tmp = h->w_tmp.as<int32_t>(); sg.counts = h->w_counts.as<int32_t>(); sg.max_ids = max_ids; sg.unk = unk; sg.status = status;
-        sg.sc = nullptr; sg.bi = nullptr; sg.arcs = nullptr; sg.tos = nullptr; sg.idsv = nullptr; sg.inter = nullptr;
+        sg.best = nullptr; sg.arcs = nullptr; sg.tos = nullptr; sg.idsv = nullptr; sg.inter = nullptr;
         if (m.kind == KIND_UNIGRAM) {
-            if (!h->w_s1.reserve(cap * 8) || !h->w_s2.reserve(cap * 8)) return BF_E_DEVICE;
-            sg.sc = h->w_s1.as<double>(); sg.bi = h->w_s2.as<SegBest>();
+            if (!h->w_s1.reserve(cap * 16)) return BF_E_DEVICE;
+            sg.best = h->w_s1.as<SegBest>();
         } else {
             if (!h->w_s1.reserve((6 * cap + 32 * (size_t)ndocs + 64) * 16) || !h->w_s2.reserve(cap * 4) || !h->w_s3.reserve(cap * 4) ||
                 !h->w_s4.reserve(cap)) return BF_E_DEVICE;

@@ -62,7 +62,7 @@ struct SpSegParams {
     int32_t *ids_tmp; int32_t *counts;
     int max_ids, unk;
     // scratch (indexed by element slot): unigram sc/bi; bpe arcs (6 per element + 32 per document), tos/idsv/inter
-    double *sc; SegBest *bi;
+    SegBest *best;
     SegArc *arcs; int32_t *tos; int32_t *idsv; uint8_t *inter;
     int *status;
     // documents are handed to lanes in order of stream length (counting sort), so the 64 documents of a wave

@@ -548,7 +548,7 @@ __global__ __launch_bounds__(64) void k_seg_unigram(SpSegParams p)
     const int64_t slot = sp_slot(p.b.doc_off[d], d, p.slot_mul);
     ClsWin cls_at; cls_at.init(p.stream, slot);
     IdOutDirect out{p.ids_tmp + slot};
-    p.counts[d] = seg_unigram_doc(p.S, cls_at, p.lens[d], p.sc + slot, p.bi + slot, out, p.max_ids, p.unk);
+    p.counts[d] = seg_unigram_doc(p.S, cls_at, p.lens[d], p.best + slot, out, p.max_ids, p.unk);
 }
 
 // BPE phase A: collect arcs, one document per lane

@@ -52,16 +52,19 @@ BF_HD float sg_bits_to_float(uint32_t b) { union { uint32_t u; float f; } x; x.u
 // ---------------------------------------------------------------------------------------------------
 // Unigram-LM.  sc[] / bi[] are the End2BestArc array (…_1best_t.h:61-77,193), one entry per position.
 // ---------------------------------------------------------------------------------------------------
-struct SegBest { int32_t begin, id; };
+struct SegBest { double score; int32_t begin, id; };   // one End2BestArc entry (…_1best_t.h:61-77), 16 bytes
 
 template <class ClsAt, class IdOut>
-BF_HD int seg_unigram_doc(const SegTables &S, ClsAt &cls_at, int L, double *sc, SegBest *bi, IdOut &out, int max_ids, int unk)
+BF_HD int seg_unigram_doc(const SegTables &S, ClsAt &cls_at, int L, SegBest *best, IdOut &out, int max_ids, int unk)
 {
     if (L <= 0) return 0;                                              // …_1best_t.h:186-188
     const double neg_flt_max = -3.40282346638528859811704183484516925e+38;   // (double)-FLT_MAX
-    for (int i = 0; i < L; ++i) { sc[i] = neg_flt_max; bi[i].begin = -1; bi[i].id = -1; }
+    { SegBest z; z.score = neg_flt_max; z.begin = -1; z.id = -1; for (int i = 0; i < L; ++i) best[i] = z; }
     for (int start = 0; start < L; ++start) {
         uint32_t state = S.initial; int sum = 0; bool unknown = true;
+        SegBest pb; pb.score = 0; pb.begin = -1; pb.id = 0;
+        if (0 < start) pb = best[start - 1];                           // final by now: every arc ending there started earlier
+        const double prev = 0 < start ? pb.score : 0;
         for (int i = start; i < L; ++i) {
             const uint64_t e = sg_lookup(S, state, cls_at(i));
             if (e == SG_MISS) break;
@@ -70,31 +73,33 @@ BF_HD int seg_unigram_doc(const SegTables &S, ClsAt &cls_at, int L, double *sc, 
             if (e & SG_FINAL) {                                        // AddArc (…_1best_t.h:118-142)
                 const SegInfo r = S.info[sum];
                 const float score = sg_bits_to_float(r.score_bits);
-                const double prev = 0 < start ? sc[start - 1] : 0;
                 const double cand = score + prev;
-                if (sc[i] < cand) { bi[i].begin = start; bi[i].id = r.id; sc[i] = cand; }
+                SegBest b = best[i];
+                if (b.score < cand) { b.begin = start; b.id = r.id; b.score = cand; best[i] = b; }
                 unknown = false;
             }
         }
         if (unknown) {                                                 // AddUnknownArc (…_1best_t.h:145-171)
             const float unk_score = -100000.0f;
-            const double prev = 0 < start ? sc[start - 1] : 0;
             const double cand = unk_score + prev;
-            if (sc[start] < cand) {
-                int b = start;
-                if (0 < start && -1 == bi[start - 1].id) b = bi[start - 1].begin;
-                bi[start].begin = b; bi[start].id = -1; sc[start] = cand;
+            SegBest b = best[start];
+            if (b.score < cand) {
+                b.begin = start;
+                if (0 < start && -1 == pb.id) b.begin = pb.begin;
+                b.id = -1; b.score = cand; best[start] = b;
             }
         }
     }
     // follow the best path backwards (…_1best_t.h:237-265); the reference reverses the triple array afterwards,
     // here the token count is taken first so that each id goes straight to its forward position
     int cnt = 0;
-    for (int end = L - 1; 0 <= end; end = bi[end].begin - 1) ++cnt;
+    for (int end = L - 1; 0 <= end; end = best[end].begin - 1) ++cnt;
     int k = cnt - 1;
-    for (int end = L - 1; 0 <= end; end = bi[end].begin - 1, --k) {
-        const int id = bi[end].id != -1 ? bi[end].id : unk;
+    for (int end = L - 1; 0 <= end; --k) {
+        const SegBest b = best[end];
+        const int id = b.id != -1 ? b.id : unk;
         if (k < max_ids) out.put(k, id + S.id_offset);                 // tokdll:1512-1516
+        end = b.begin - 1;
     }
     const int n = cnt < max_ids ? cnt : max_ids;
     out.finish(n);

@@ -220,8 +220,8 @@ static int emu_sp(const Model &m, const char *s, int n, int32_t *ids, int max_id
     auto cls_at = [cp](int i) -> uint32_t { return cp[i]; };
     IdOutDirect out{ids};
     if (m.kind == KIND_UNIGRAM) {
-        std::vector<double> sc((size_t)L + 1); std::vector<SegBest> bi((size_t)L + 1);
-        return seg_unigram_doc(S, cls_at, L, sc.data(), bi.data(), out, max_ids, unk);
+        std::vector<SegBest> best((size_t)L + 1);
+        return seg_unigram_doc(S, cls_at, L, best.data(), out, max_ids, unk);
     }
     const int cap = 6 * L + 32;
     std::vector<SegArc> arcs((size_t)cap); std::vector<int32_t> tos((size_t)L + 1), idsv((size_t)L + 1); std::vector<uint8_t> inter((size_t)L + 1);
