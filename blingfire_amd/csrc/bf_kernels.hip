@@ -295,7 +295,7 @@ __global__ __launch_bounds__(THREADS) void k_lex_wp_flat(WpLexParams p)
         unsigned long long m_event;
         for (;;) {
 #pragma unroll
-            for (int u = 0; u < UNROLL; ++u) { if (mode == M_WALK) { if (!lane.step()) mode = M_EVENT; } }
+            for (int u = 0; u < UNROLL; ++u) { if (mode == M_WALK) { if (!lane.step_r()) mode = M_EVENT; } }
             const unsigned long long m_walk = __ballot(mode == M_WALK);
             m_event = __ballot(mode == M_EVENT);
             if (m_walk == 0 || __popcll(m_event) >= ev_thresh) break;
@@ -367,10 +367,12 @@ void launch_lex_wp(const WpLexParams &p, int variant, hipStream_t s)
         if (blocks > need) blocks = need;
         if (blocks < 1) blocks = 1;
         const bool has_any = p.L.cls_any != LX_CLS_NONE;
-        const int unroll = (variant >> 30) & 1 ? 1 : 2;      // two DFA transitions per vote by default
+        const int usel = (variant >> 30) & 3;                // 0: two DFA transitions per vote (default), 1: one, 2: three, 3: four
         const dim3 g((unsigned)blocks), t(64); const size_t lds = lex_lds_bytes(q, 64);
         if (has_any) hipLaunchKernelGGL((k_lex_wp_flat<64, ClsWin, true, 1>), g, t, lds, s, q);
-        else if (unroll == 2) hipLaunchKernelGGL((k_lex_wp_flat<64, ClsWin, false, 2>), g, t, lds, s, q);
+        else if (usel == 0) hipLaunchKernelGGL((k_lex_wp_flat<64, ClsWin, false, 2>), g, t, lds, s, q);
+        else if (usel == 2) hipLaunchKernelGGL((k_lex_wp_flat<64, ClsWin, false, 3>), g, t, lds, s, q);
+        else if (usel == 3) hipLaunchKernelGGL((k_lex_wp_flat<64, ClsWin, false, 4>), g, t, lds, s, q);
         else hipLaunchKernelGGL((k_lex_wp_flat<64, ClsWin, false, 1>), g, t, lds, s, q);
     }
 }

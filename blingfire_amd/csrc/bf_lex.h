@@ -216,6 +216,21 @@ struct LexLane {
         return adv && (jn < bound || jn == fn_);
     }
 
+    // step() that also absorbs the cheapest event: a walk that ended WITHOUT a match simply restarts at the next
+    // start position (what after_walk() + prepare() would do: FALexTools_t.h:229, 293), as long as the frame has
+    // input left.  Lanes then stay in the walk loop instead of waiting for the next event vote.
+    BF_HD bool step_r()
+    {
+        bool cont = step();
+        const int nf = from + 1;
+        if (!cont && fp == -1 && nf < fn_ && L.max_token_length > 0) {
+            from = nf; state = ini; finfo = 0; j = nf;
+            bound = nf + L.max_token_length; if (fn_ < bound) bound = fn_;
+            cont = true;
+        }
+        return cont;
+    }
+
     // Consume the result (fp, finfo) of the walk that just ended.  Follow with prepare().
     BF_HD void after_walk()
     {
@@ -278,7 +293,7 @@ BF_HD int lex_doc_t(const LexTables &L, ClsAt &cls_at, int n, IdOut &out, int ma
     LexLane<ClsAt, IdOut, Frames, HAS_ANY> lane(L, cls_at, out, frames);
     lane.init(n, max_ids, unk);
     while (lane.prepare()) {
-        while (lane.step()) {}
+        while (lane.step_r()) {}
         lane.after_walk();
     }
     return lane.finish();
