@@ -132,7 +132,7 @@ int run_device(Handle *h, const char *d_text, const int64_t *d_doc_off, int64_t 
     if (!h->w_nchars.reserve((size_t)(ndocs + 1) * 4) || !h->w_counts.reserve((size_t)(ndocs + 1) * 4) ||
         !h->w_bsums.reserve((size_t)(nblocks + 1) * 8) || !h->w_tmp.reserve((size_t)(total_bytes + 8 * ndocs + 64) * 4)) return BF_E_DEVICE;
     Batch b{(const uint8_t *)d_text, d_doc_off, ndocs};
-    int slot_mul = 0;
+    int slot_mul = 0; const int32_t *first = nullptr;
     unsigned long long *next_doc = h->w_misc.as<unsigned long long>();
     int *status = (int *)(h->w_misc.as<char>() + 16);
     if (!hip_ok(hipMemsetAsync(h->w_misc.p, 0, 64, s), "hipMemsetAsync")) return BF_E_DEVICE;
@@ -181,7 +181,8 @@ int run_device(Handle *h, const char *d_text, const int64_t *d_doc_off, int64_t 
             sg.arcs = h->w_s1.as<SegArc>(); sg.tos = h->w_s2.as<int32_t>(); sg.idsv = h->w_s3.as<int32_t>(); sg.inter = h->w_s4.as<uint8_t>();
         }
         if (!h->w_perm.reserve((size_t)(ndocs + 1) * 4) || !h->w_hist.reserve(2048 * 4) || !h->w_narcs.reserve((size_t)(ndocs + 1) * 4)) return BF_E_DEVICE;
-        sg.narcs = h->w_narcs.as<int32_t>(); sg.next_doc = next_doc;
+        sg.narcs = h->w_narcs.as<int32_t>(); sg.next_doc = next_doc; sg.trie_depth = m.trie_max_depth; sg.variant = h->variant & 0xff;
+        if (m.kind == KIND_UNIGRAM && sg.variant != 1 && m.trie_max_depth > 0 && m.trie_max_depth <= 4096) first = h->w_narcs.as<int32_t>();
         sg.perm = h->w_perm.as<int32_t>(); sg.hist = h->w_hist.as<unsigned int>();
         if (ndocs > 0) launch_seg_sp(sg, s);
         (void)hipEventRecord(h->ev[EV_TOK], s);
@@ -189,7 +190,7 @@ int run_device(Handle *h, const char *d_text, const int64_t *d_doc_off, int64_t 
     ScanParams sp{h->w_counts.as<int32_t>(), ndocs, d_id_off, h->w_bsums.as<int64_t>(), nblocks};
     launch_scan(sp, s);
     (void)hipEventRecord(h->ev[EV_SCAN], s);
-    CompactParams cp{b, h->w_tmp.as<int32_t>(), h->w_counts.as<int32_t>(), d_id_off, d_ids_out, ids_cap, status, slot_mul};
+    CompactParams cp{b, h->w_tmp.as<int32_t>(), h->w_counts.as<int32_t>(), d_id_off, d_ids_out, ids_cap, status, slot_mul, first};
     if (ndocs > 0) launch_compact(cp, s);
     (void)hipEventRecord(h->ev[EV_COMPACT], s);
     h->ev_valid = true;

@@ -68,7 +68,9 @@ struct SpSegParams {
     // documents are handed to lanes in order of stream length (counting sort), so the 64 documents of a wave
     // are of similar size: perm[i] = document processed by thread i; hist = 1024 bucket counters / cursors
     int32_t *perm; unsigned int *hist;
-    int32_t *narcs;             // [ndocs] BPE arc count per document (-1 = capacity exceeded)
+    int32_t *narcs;             // [ndocs] BPE arc count per document (-1 = capacity exceeded); Unigram: first id index within the slot
+    int trie_depth;             // longest dictionary entry (bounds every arc length)
+    int variant;
     unsigned long long *next_doc;
 };
 
@@ -78,6 +80,7 @@ struct CompactParams {
     Batch b; const int32_t *ids_tmp; const int32_t *counts; const int64_t *id_off;
     int32_t *ids_out; int64_t ids_cap; int *status;
     int slot_mul;               // 0: _wp slots (align8(doc_off)+8d); >0: _sp slots (slot_mul*(doc_off+d))
+    const int32_t *first;       // optional: index of the first id inside the slot (Unigram flat kernel writes ids right-aligned)
 };
 
 void launch_prep_wp(const WpPrepParams &p, hipStream_t s);

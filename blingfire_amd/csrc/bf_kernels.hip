@@ -553,6 +553,107 @@ __global__ __launch_bounds__(64) void k_seg_unigram(SpSegParams p)
     p.counts[d] = seg_unigram_doc(p.S, cls_at, p.lens[d], p.best + slot, out, p.max_ids, p.unk);
 }
 
+// Unigram-LM, divergence-aware form (default): persistent lanes pull documents (longest first) from a counter;
+// every loop trip a lane makes ONE micro-step -- a trie transition with its AddArc / AddUnknownArc, or one hop of
+// the backward pass -- so walks of different lengths and documents of different sizes do not idle the wave.
+// Per-document order of operations is exactly seg_unigram_doc's.  Best-arc entries are initialised lazily,
+// `depth` positions ahead of the current start (an arc from `start` ends before start + depth); ids are written
+// right-aligned in the document's slot during the single backward pass (first[d] = index of the first one).
+__global__ __launch_bounds__(64) void k_seg_unigram_flat(SpSegParams p)
+{
+    enum { M_NEED = 0, M_WALK = 1, M_BACK = 2, M_EXIT = 3 };
+    const double neg_flt_max = -3.40282346638528859811704183484516925e+38;
+    const int depth = p.trie_depth;
+    int mode = M_NEED;
+    int64_t doc = 0; SegBest *best = nullptr; int32_t *ids = nullptr;
+    ClsWin cls_at; cls_at.init(p.stream, 0);
+    int L = 0, cap = 0, start = 0, i = 0, sum = 0, cnt = 0, end = 0, pb_begin = -1, pb_id = 0;
+    uint32_t state = 0; bool unknown = true; double prev = 0;
+    for (unsigned long long trip = 0; trip < (1ull << 34); ++trip) {
+        const unsigned long long m_need = __ballot(mode == M_NEED);
+        if (m_need) {
+            const unsigned long long m_busy = __ballot(mode == M_WALK || mode == M_BACK);
+            if (__popcll(m_need) >= 8 || m_busy == 0) {
+                if (mode == M_NEED) {
+                    const int c = __popcll(m_need);
+                    const int leader = __ffsll((long long)m_need) - 1;
+                    unsigned long long base = 0;
+                    if (lane_id() == leader) base = atomicAdd(p.next_doc, (unsigned long long)c);
+                    base = __shfl(base, leader, 64);
+                    const int64_t idx = (int64_t)base + __popcll(m_need & lanemask_lt());
+                    if (idx >= p.b.ndocs) mode = M_EXIT;
+                    else {
+                        doc = p.perm[idx];
+                        const int64_t b = p.b.doc_off[doc];
+                        const int64_t slot = sp_slot(b, doc, p.slot_mul);
+                        cap = p.slot_mul * (int)(p.b.doc_off[doc + 1] - b + 1);
+                        L = p.lens[doc];
+                        best = p.best + slot; ids = p.ids_tmp + slot; cls_at.init(p.stream, slot);
+                        if (L <= 0) { p.counts[doc] = 0; p.narcs[doc] = 0; }
+                        else {
+                            SegBest z; z.score = neg_flt_max; z.begin = -1; z.id = -1;
+                            const int n0 = depth < L ? depth : L;
+                            for (int k = 0; k < n0; ++k) best[k] = z;
+                            start = 0; i = 0; state = p.S.initial; sum = 0; unknown = true; prev = 0; pb_begin = -1; pb_id = 0;
+                            mode = M_WALK;
+                        }
+                    }
+                }
+                if (__ballot(mode != M_EXIT) == 0) break;
+            }
+        }
+        if (mode == M_WALK) {
+            const uint64_t e = sg_lookup(p.S, state, cls_at(i));
+            bool walk_ends = e == SG_MISS;
+            if (!walk_ends) {
+                state = (uint32_t)((e >> SG_NEXT_SHIFT) & SG_NEXT_MASK);
+                sum += (int)(e >> SG_OW_SHIFT);
+                if (e & SG_FINAL) {                                     // AddArc
+                    const SegInfo r = p.S.info[sum];
+                    const double cand = sg_bits_to_float(r.score_bits) + prev;
+                    SegBest bb = best[i];
+                    if (bb.score < cand) { bb.begin = start; bb.id = r.id; bb.score = cand; best[i] = bb; }
+                    unknown = false;
+                }
+                ++i;
+                walk_ends = i >= L;
+            }
+            if (walk_ends) {
+                if (unknown) {                                          // AddUnknownArc
+                    const float unk_score = -100000.0f;
+                    const double cand = unk_score + prev;
+                    SegBest bb = best[start];
+                    if (bb.score < cand) {
+                        bb.begin = start;
+                        if (0 < start && -1 == pb_id) bb.begin = pb_begin;
+                        bb.id = -1; bb.score = cand; best[start] = bb;
+                    }
+                }
+                ++start;
+                if (start < L) {
+                    const SegBest pb = best[start - 1];
+                    prev = pb.score; pb_begin = pb.begin; pb_id = pb.id;
+                    const int fresh = start + depth - 1;                 // enters the reach of this start
+                    if (fresh < L) { SegBest z; z.score = neg_flt_max; z.begin = -1; z.id = -1; best[fresh] = z; }
+                    i = start; state = p.S.initial; sum = 0; unknown = true;
+                } else { mode = M_BACK; end = L - 1; cnt = 0; }
+            }
+        } else if (mode == M_BACK) {
+            const SegBest bb = best[end];
+            const int id = bb.id != -1 ? bb.id : p.unk;
+            ids[cap - 1 - cnt] = id + p.S.id_offset;
+            ++cnt;
+            end = bb.begin - 1;
+            if (end < 0) {
+                p.counts[doc] = cnt < p.max_ids ? cnt : p.max_ids;
+                p.narcs[doc] = cap - cnt;
+                mode = M_NEED;
+            }
+        }
+    }
+    if (mode != M_EXIT) atomicOr(p.status, 2);      // trip limit hit: never expected
+}
+
 // BPE phase A: collect arcs, one document per lane
 __global__ __launch_bounds__(64) void k_bpe_collect(SpSegParams p)
 {
@@ -648,7 +749,15 @@ void launch_seg_sp(const SpSegParams &p, hipStream_t s)
     hipLaunchKernelGGL(k_sp_hist_scan, dim3(1), dim3(1024), 0, s, p);
     hipLaunchKernelGGL(k_sp_scatter, dim3(b256), dim3(256), 0, s, p);
     if (p.S.kind == SG_KIND_UNIGRAM) {
-        hipLaunchKernelGGL(k_seg_unigram, dim3(b64), dim3(64), 0, s, p);
+        if (p.variant == 1 || p.trie_depth <= 0 || p.trie_depth > 4096) hipLaunchKernelGGL(k_seg_unigram, dim3(b64), dim3(64), 0, s, p);
+        else {
+            int per_cu = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_seg_unigram_flat, 64, 0) != hipSuccess || per_cu <= 0) per_cu = 16;
+            (void)hipGetLastError();
+            unsigned blocks = 256u * (unsigned)per_cu;
+            if ((int64_t)blocks > (int64_t)b64) blocks = b64;
+            hipLaunchKernelGGL(k_seg_unigram_flat, dim3(blocks), dim3(64), 0, s, p);
+        }
     } else {
         hipLaunchKernelGGL(k_bpe_collect, dim3(b64), dim3(64), 0, s, p);
         unsigned sort_blocks = 256 * 2;
@@ -737,7 +846,7 @@ __global__ __launch_bounds__(256) void k_compact(CompactParams p)
     const int64_t nwaves = (int64_t)gridDim.x * 4;
     for (int64_t d = wave0; d < p.b.ndocs; d += nwaves) {
         const int c = p.counts[d];
-        const int32_t *src = p.ids_tmp + (p.slot_mul > 0 ? sp_slot(p.b.doc_off[d], d, p.slot_mul) : ids_slot(p.b.doc_off[d], d));
+        const int32_t *src = p.ids_tmp + (p.slot_mul > 0 ? sp_slot(p.b.doc_off[d], d, p.slot_mul) : ids_slot(p.b.doc_off[d], d)) + (p.first ? p.first[d] : 0);
         const int64_t o = p.id_off[d];
         for (int i = lane; i < c; i += 64) {
             if (o + i < p.ids_cap) p.ids_out[o + i] = src[i];
