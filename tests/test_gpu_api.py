@@ -1,0 +1,105 @@
+"""GPU: C-ABI behaviour around the hot path -- empty batches, empty documents inside a batch, SetModel from memory,
+concurrent calls from several host threads (on one handle and on two handles), error codes."""
+import ctypes
+import threading
+
+import numpy as np
+import pytest
+
+import bfutil
+import blingfire_amd as bf
+
+pytestmark = pytest.mark.gpu
+
+
+def test_empty_batch_and_empty_documents():
+    h = bf.load_model(bfutil.model_path(bfutil.bert_model_name()))
+    try:
+        ids, off = bf.text_to_ids_batch(h, [], 16, 100)
+        assert len(ids) == 0 and off.tolist() == [0]
+        docs = [b"", b"hello world", b"", b"", b"a", b""]
+        ids, off = bf.text_to_ids_batch(h, docs, 16, 100)
+        ora = bfutil.oracle()
+        ho = ora.load(bfutil.model_path(bfutil.bert_model_name()))
+        text, doff = bf.pack_docs(docs)
+        gids, goff = ora.batch(ho, text, doff, 16, 100)
+        ora.free(ho)
+        assert np.array_equal(ids, gids) and np.array_equal(off, goff)
+        assert off[1] == 0 and off[3] == off[2]
+    finally:
+        bf.free_model(h)
+
+
+def test_set_model_from_memory_and_capacity_error():
+    img = open(bfutil.model_path("gpt2.bin"), "rb").read()
+    L = bf.lib()
+    h = L.SetModel(img, len(img))
+    assert h
+    try:
+        assert L.BfModelKind(ctypes.c_void_p(h)) == 3          # BPE-opt
+        docs = [b"Hello, world! This is a test."] * 50
+        ids, off = bf.text_to_ids_batch(h, docs, 64, 0)
+        assert ids[:9].tolist() == [18435, 11, 995, 0, 770, 318, 257, 1332, 13]
+        assert np.array_equal(np.diff(off), np.full(50, 9))
+        # ids_cap too small -> BF_E_CAPACITY, never a silent truncation
+        text, doff = bf.pack_docs(docs)
+        small = np.zeros(10, dtype=np.int32)
+        id_off = np.zeros(51, dtype=np.int64)
+        r = L.TextToIdsBatch(ctypes.c_void_p(h), text.ctypes.data, doff.ctypes.data, 50, small.ctypes.data, 10, id_off.ctypes.data, 64, 0)
+        assert r == -3
+    finally:
+        L.FreeModel(ctypes.c_void_p(h))
+    assert L.SetModel(b"garbage-not-a-model", 19) is None or L.SetModel(b"garbage-not-a-model", 19) == 0
+    assert L.LoadModel(b"/nonexistent/model.bin") in (None, 0)
+
+
+def test_concurrent_callers():
+    """The reference is re-entrant on a loaded handle (README.md:105,215); calls on one handle serialise here,
+    different handles run independently -- results must be the same as a serial run."""
+    name = bfutil.bert_model_name()
+    h1 = bf.load_model(bfutil.model_path(name))
+    h2 = bf.load_model(bfutil.model_path(name))
+    docs = bfutil.fuzz_docs(400, seed=23)
+    want = bf.text_to_ids_batch(h1, docs, 64, 100)
+    errs = []
+
+    def work(h, k):
+        try:
+            for _ in range(5):
+                ids, off = bf.text_to_ids_batch(h, docs, 64, 100)
+                if not (np.array_equal(ids, want[0]) and np.array_equal(off, want[1])):
+                    errs.append("thread %d: mismatch" % k)
+                s = docs[k]
+                assert bf.text_to_ids(h, s, 32, 100, no_padding=True).tolist() == want[0][want[1][k]:want[1][k + 1]][:32].tolist()
+        except Exception as e:   # noqa: BLE001
+            errs.append(repr(e))
+
+    ts = [threading.Thread(target=work, args=(h1 if k % 2 == 0 else h2, k)) for k in range(6)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    bf.free_model(h1)
+    bf.free_model(h2)
+    assert not errs, errs
+
+
+def test_device_api_on_torch_tensors():
+    import torch
+    name = "xlnet.bin"
+    h = bf.load_model(bfutil.model_path(name))
+    try:
+        docs = bfutil.fuzz_docs(500, seed=29)
+        text, off = bf.pack_docs(docs)
+        d_text = torch.from_numpy(text.copy()).cuda()
+        d_off = torch.from_numpy(off).cuda()
+        ids, id_off = bf.text_to_ids_batch_device(h, d_text, d_off, 128, 0)
+        torch.cuda.synchronize()
+        n = int(id_off[-1].item())
+        want = bf.text_to_ids_batch(h, (text, off), 128, 0)
+        assert np.array_equal(ids[:n].cpu().numpy(), want[0]) and np.array_equal(id_off.cpu().numpy(), want[1])
+        assert bf.lib().BfLastStatus(h) == 0
+        ms = bf.last_kernel_ms(h)
+        assert len(ms) == 5 and ms[4] > 0
+    finally:
+        bf.free_model(h)
