@@ -116,7 +116,7 @@ Handle *make_handle(const uint8_t *img, size_t size)
     }
     ok = ok && hip_ok(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking), "hipStreamCreate");
     for (auto &e : h->ev) ok = ok && hip_ok(hipEventCreate(&e), "hipEventCreate");
-    ok = ok && h->w_misc.reserve(64) && hip_ok(hipMemset(h->w_misc.p, 0, 64), "hipMemset");
+    ok = ok && h->w_misc.reserve(256) && hip_ok(hipMemset(h->w_misc.p, 0, 256), "hipMemset");
     if (!ok) { fprintf(stderr, "[blingfire_amd] %s\n", g_last_error.c_str()); delete h; return nullptr; }
     return h;
 }
@@ -150,6 +150,7 @@ int run_device(Handle *h, const char *d_text, const int64_t *d_doc_off, int64_t 
         lp.b = b; lp.cls = h->w_cls.as<uint16_t>(); lp.nchars = h->w_nchars.as<int32_t>();
         lp.ids_tmp = h->w_tmp.as<int32_t>(); lp.counts = h->w_counts.as<int32_t>();
         lp.max_ids = max_ids; lp.unk = unk; lp.next_doc = next_doc; lp.status = status; lp.ev_thresh = 0; lp.fetch_thresh = 0; lp.acts_n = (int)m.acts_pool.size();
+        lp.stats = getenv("BF_LEX_STATS") ? (unsigned long long *)(h->w_misc.as<char>() + 64) : nullptr;
         if (ndocs > 0) launch_lex_wp(lp, h->variant, s);
         (void)hipEventRecord(h->ev[EV_TOK], s);
     } else {
@@ -349,6 +350,18 @@ int BfLastStatus(void *p)
 }
 
 const char *BfLastError(void) { return g_last_error.c_str(); }
+
+/* experiments: instrumentation counters of the lexer kernel (BF_LEX_STATS=1), accumulated since LoadModel */
+int BfLexStats(void *p, unsigned long long *out, int n)
+{
+    Handle *h = as_handle(p);
+    if (!h || !out || n <= 0) return BF_E_ARG;
+    std::lock_guard<std::mutex> lock(h->mu);
+    (void)hipDeviceSynchronize();
+    if (n > 16) n = 16;
+    if (!hip_ok(hipMemcpy(out, h->w_misc.as<char>() + 64, (size_t)n * 8, hipMemcpyDeviceToHost), "D2H stats")) return BF_E_DEVICE;
+    return n;
+}
 
 int BfModelKind(void *p) { Handle *h = as_handle(p); return h ? h->m.kind : BF_E_ARG; }
 

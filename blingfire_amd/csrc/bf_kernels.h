@@ -38,6 +38,7 @@ struct WpLexParams {
     int *status;
     int ev_thresh, fetch_thresh;  // vote thresholds of the divergence-aware driver
     int acts_n;                   // ints in L.acts (staged in LDS when small)
+    unsigned long long *stats;    // optional instrumentation counters (experiments), else nullptr
 };
 
 // _sp branch: element slot of document d (stream, DP arrays and the id staging slot share it):

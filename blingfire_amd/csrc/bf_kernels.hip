@@ -267,7 +267,7 @@ __global__ __launch_bounds__(THREADS) void k_lex_wp_seq(WpLexParams p)
 // counter; every loop iteration a lane in WALK mode makes exactly one DFA transition, while the heavier
 // "event" code (match handling, calls/returns, next start position) and the document fetch run only when
 // enough lanes of the wave are waiting for them (ballot vote), so that they execute with most lanes active.
-template <int THREADS, class WIN, bool HAS_ANY, int UNROLL>
+template <int THREADS, class WIN, bool HAS_ANY, int UNROLL, bool STATS>
 __global__ __launch_bounds__(THREADS) void k_lex_wp_flat(WpLexParams p)
 {
     extern __shared__ int32_t lex_lds[];
@@ -289,28 +289,36 @@ __global__ __launch_bounds__(THREADS) void k_lex_wp_flat(WpLexParams p)
     int mode = M_NEED;
     int64_t doc = -1;
     const int ev_thresh = p.ev_thresh, fetch_thresh = p.fetch_thresh;
+    // instrumentation (STATS builds only: BF_LEX_STATS=1): trips, useful lane-steps, event / fetch rounds, cycles per phase
+    unsigned long long st_trips = 0, st_walk_lanes = 0, st_ev_rounds = 0, st_ev_lanes = 0, st_fetch_rounds = 0, st_need_lanes = 0;
+    unsigned long long tk_walk = 0, tk_event = 0, tk_fetch = 0, tk0 = 0;
     for (;;) {
+        if (STATS) tk0 = __builtin_readcyclecounter();
         // ---- walk: every lane in WALK mode makes one DFA transition per trip, until enough lanes have a
         //      finished walk (or nobody walks any more)
         unsigned long long m_event;
         for (;;) {
+            if (STATS) { st_trips += UNROLL; st_walk_lanes += UNROLL * __popcll(__ballot(mode == M_WALK)); st_need_lanes += UNROLL * __popcll(__ballot(mode == M_NEED)); }
 #pragma unroll
             for (int u = 0; u < UNROLL; ++u) { if (mode == M_WALK) { if (!lane.step_r()) mode = M_EVENT; } }
             const unsigned long long m_walk = __ballot(mode == M_WALK);
             m_event = __ballot(mode == M_EVENT);
             if (m_walk == 0 || __popcll(m_event) >= ev_thresh) break;
         }
+        if (STATS) { st_ev_rounds += 1; st_ev_lanes += __popcll(m_event); const unsigned long long t1 = __builtin_readcyclecounter(); tk_walk += t1 - tk0; tk0 = t1; }
         // ---- events: match handling, calls / returns, next start position
         if (mode == M_EVENT) {
             lane.after_walk();
             if (lane.prepare()) mode = M_WALK;
             else { p.counts[doc] = lane.finish(); mode = M_NEED; }
         }
+        if (STATS) { const unsigned long long t1 = __builtin_readcyclecounter(); tk_event += t1 - tk0; tk0 = t1; }
         // ---- fetch documents for idle lanes
         const unsigned long long m_need = __ballot(mode == M_NEED);
         if (m_need) {
             const unsigned long long m_busy = __ballot(mode == M_WALK || mode == M_EVENT);
             if (__popcll(m_need) >= fetch_thresh || m_busy == 0) {
+                if (STATS) st_fetch_rounds += 1;
                 if (mode == M_NEED) {
                     const int cnt = __popcll(m_need);
                     const int leader = __ffsll((long long)m_need) - 1;
@@ -335,6 +343,12 @@ __global__ __launch_bounds__(THREADS) void k_lex_wp_flat(WpLexParams p)
                 if (__ballot(mode != M_EXIT) == 0) break;
             }
         }
+        if (STATS) { const unsigned long long t1 = __builtin_readcyclecounter(); tk_fetch += t1 - tk0; }
+    }
+    if (STATS && lane_id() == 0) {
+        atomicAdd(&p.stats[0], st_trips); atomicAdd(&p.stats[1], st_walk_lanes); atomicAdd(&p.stats[2], st_ev_rounds);
+        atomicAdd(&p.stats[3], st_ev_lanes); atomicAdd(&p.stats[4], st_fetch_rounds); atomicAdd(&p.stats[5], st_need_lanes);
+        atomicAdd(&p.stats[6], tk_walk); atomicAdd(&p.stats[7], tk_event); atomicAdd(&p.stats[8], tk_fetch);
     }
 }
 
@@ -355,7 +369,7 @@ void launch_lex_wp(const WpLexParams &p, int variant, hipStream_t s)
         int waves_per_cu = (variant >> 24) & 0x3f;
         if (waves_per_cu == 0) {                                      // persistent: exactly the resident waves
             int per_cu = 0, ncu = 256;
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_lex_wp_flat<64, ClsWin, false, 1>, 64, lex_lds_bytes(q, 64)) != hipSuccess || per_cu <= 0) per_cu = 16;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_lex_wp_flat<64, ClsWin, false, 1, false>, 64, lex_lds_bytes(q, 64)) != hipSuccess || per_cu <= 0) per_cu = 16;
             hipDeviceProp_t prop; int dev = 0;
             if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ncu = prop.multiProcessorCount;
             static_cast<void>(ncu);
@@ -369,11 +383,11 @@ void launch_lex_wp(const WpLexParams &p, int variant, hipStream_t s)
         const bool has_any = p.L.cls_any != LX_CLS_NONE;
         const int usel = (variant >> 30) & 3;                // 0: two DFA transitions per vote (default), 1: one, 2: three, 3: four
         const dim3 g((unsigned)blocks), t(64); const size_t lds = lex_lds_bytes(q, 64);
-        if (has_any) hipLaunchKernelGGL((k_lex_wp_flat<64, ClsWin, true, 1>), g, t, lds, s, q);
-        else if (usel == 0) hipLaunchKernelGGL((k_lex_wp_flat<64, ClsWin, false, 2>), g, t, lds, s, q);
-        else if (usel == 2) hipLaunchKernelGGL((k_lex_wp_flat<64, ClsWin, false, 3>), g, t, lds, s, q);
-        else if (usel == 3) hipLaunchKernelGGL((k_lex_wp_flat<64, ClsWin, false, 4>), g, t, lds, s, q);
-        else hipLaunchKernelGGL((k_lex_wp_flat<64, ClsWin, false, 1>), g, t, lds, s, q);
+        if (has_any) hipLaunchKernelGGL((k_lex_wp_flat<64, ClsWin, true, 1, false>), g, t, lds, s, q);
+        else if (p.stats) hipLaunchKernelGGL((k_lex_wp_flat<64, ClsWin, false, 2, true>), g, t, lds, s, q);
+        else if (usel == 0) hipLaunchKernelGGL((k_lex_wp_flat<64, ClsWin, false, 2, false>), g, t, lds, s, q);
+        else if (usel == 2) hipLaunchKernelGGL((k_lex_wp_flat<64, ClsWin, false, 3, false>), g, t, lds, s, q);
+        else hipLaunchKernelGGL((k_lex_wp_flat<64, ClsWin, false, 1, false>), g, t, lds, s, q);
     }
 }
 

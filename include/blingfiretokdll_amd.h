@@ -90,6 +90,9 @@ const char *BfLastError(void);
 /* Model facts: 0 = WordPiece lexer, 1 = Unigram-LM, 2 = BPE, 3 = BPE-opt, 4 = BPE with merge ranks */
 int BfModelKind(void *ModelPtr);
 
+/* experiments: instrumentation counters of the lexer kernel when BF_LEX_STATS=1 is set in the environment */
+int BfLexStats(void *ModelPtr, unsigned long long *out, int n);
+
 /* tuning knob for experiments: selects a kernel variant (0 = default). Returns the previous value. */
 int BfSetVariant(void *ModelPtr, int variant);
 
