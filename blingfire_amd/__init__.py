@@ -39,6 +39,15 @@ def lib():
             f = getattr(L, name)
             f.restype = c_int
             f.argtypes = [c_void_p, c_char_p, c_int, c_void_p, c_int, c_int]
+        for name in ("TextToIdsWithOffsets", "TextToIdsWithOffsets_wp", "TextToIdsWithOffsets_sp"):
+            f = getattr(L, name)
+            f.restype = c_int
+            f.argtypes = [c_void_p, c_char_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int]
+        L.TextToIdsWithOffsetsBatch.restype = c_int64
+        L.TextToIdsWithOffsetsBatch.argtypes = [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int, c_int]
+        L.TextToIdsWithOffsetsBatchDevice.restype = c_int
+        L.TextToIdsWithOffsetsBatchDevice.argtypes = [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_int64,
+                                                      c_void_p, c_int, c_int, c_void_p]
         L.SetNoDummyPrefix.restype = c_int
         L.SetNoDummyPrefix.argtypes = [c_void_p, c_int]
         L.GetBlingFireTokVersion.restype = c_int
@@ -85,6 +94,17 @@ def text_to_ids(h, s, max_len, unk=0, no_padding=False):
     return np.frombuffer(o, dtype=np.uint32, count=n)
 
 
+def utf8text_to_ids_with_offsets(h, s_bytes, max_len, unk=0, no_padding=False):
+    """reference __init__.py:272-284: (ids uint32, start offsets int32, end offsets int32), zero padded to max_len."""
+    o = (c_int32 * max_len)()
+    o_s = (c_int32 * max_len)()
+    o_e = (c_int32 * max_len)()
+    t = lib().TextToIdsWithOffsets(c_void_p(h), s_bytes, len(s_bytes), byref(o), byref(o_s), byref(o_e), max_len, unk)
+    n = min(max_len, t) if no_padding else max_len
+    return (np.frombuffer(o, dtype=np.uint32, count=n), np.frombuffer(o_s, dtype=np.int32, count=n),
+            np.frombuffer(o_e, dtype=np.int32, count=n))
+
+
 def change_settings_dummy_prefix(h, add_prefix):
     lib().SetNoDummyPrefix(c_void_p(h), int(not add_prefix))
 
@@ -121,6 +141,25 @@ def text_to_ids_batch(h, docs, max_len, unk=0):
     if r < 0:
         raise RuntimeError("TextToIdsBatch failed (%d): %s" % (r, lib().BfLastError().decode("utf-8", "replace")))
     return ids[:r], id_off
+
+
+def text_to_ids_with_offsets_batch(h, docs, max_len, unk=0):
+    """Batch form of TextToIdsWithOffsets: (ids, starts, ends, id_offsets); starts/ends are byte offsets inside each document."""
+    text, off = docs if isinstance(docs, tuple) else pack_docs(docs)
+    text = np.ascontiguousarray(text, dtype=np.uint8)
+    off = np.ascontiguousarray(off, dtype=np.int64)
+    ndocs = len(off) - 1
+    total = int(off[-1] - off[0]) if ndocs > 0 else 0
+    cap = min(2 * (total + ndocs), ndocs * max(max_len, 0)) + 1
+    ids = np.empty(cap, dtype=np.int32)
+    starts = np.empty(cap, dtype=np.int32)
+    ends = np.empty(cap, dtype=np.int32)
+    id_off = np.zeros(ndocs + 1, dtype=np.int64)
+    r = lib().TextToIdsWithOffsetsBatch(c_void_p(h), text.ctypes.data, off.ctypes.data, ndocs, ids.ctypes.data, starts.ctypes.data,
+                                        ends.ctypes.data, cap, id_off.ctypes.data, max_len, unk)
+    if r < 0:
+        raise RuntimeError("TextToIdsWithOffsetsBatch failed (%d): %s" % (r, lib().BfLastError().decode("utf-8", "replace")))
+    return ids[:r], starts[:r], ends[:r], id_off
 
 
 def text_to_ids_batch_device(h, d_text, d_doc_off, max_len, unk=0, out_ids=None, out_off=None, stream=None):

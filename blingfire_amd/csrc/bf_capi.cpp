@@ -67,14 +67,15 @@ struct Handle {
     DevBuf w_s1, w_s2, w_s3, w_s4, w_perm, w_hist, w_narcs;      // _sp scratch
     // workspaces
     DevBuf w_cls, w_nchars, w_tmp, w_counts, w_bsums, w_misc;   // w_misc: [0] next_doc (u64), [2] status (int)
-    DevBuf w_text, w_docoff, w_ids, w_idoff;                    // host-API staging
+    DevBuf w_text, w_docoff, w_ids, w_idoff, w_starts, w_ends;  // host-API staging
+    DevBuf w_srcoff, w_span;                                    // offsets API: source-offset stream, staged id spans
     hipStream_t stream = nullptr;
     hipEvent_t ev[EV_COUNT] = {};
     bool ev_valid = false;
     ~Handle()
     {
         for (DevBuf *b : {&t_wbd, &t_info, &t_acts, &t_cp_l1, &t_cp_pages, &t_multi, &t_dict, &t_seginfo, &w_s1, &w_s2, &w_s3, &w_s4, &w_perm, &w_hist, &w_narcs, &w_cls, &w_nchars, &w_tmp, &w_counts,
-                          &w_bsums, &w_misc, &w_text, &w_docoff, &w_ids, &w_idoff}) b->release();
+                          &w_bsums, &w_misc, &w_text, &w_docoff, &w_ids, &w_idoff, &w_starts, &w_ends, &w_srcoff, &w_span}) b->release();
         for (auto &e : ev) if (e) (void)hipEventDestroy(e);
         if (stream) (void)hipStreamDestroy(stream);
         magic = 0;
@@ -123,8 +124,10 @@ Handle *make_handle(const uint8_t *img, size_t size)
 
 // Enqueue the whole pipeline for a batch resident on the device.
 int run_device(Handle *h, const char *d_text, const int64_t *d_doc_off, int64_t ndocs, int64_t total_bytes,
-               int32_t *d_ids_out, int64_t ids_cap, int64_t *d_id_off, int max_ids, int unk, hipStream_t s)
+               int32_t *d_ids_out, int64_t ids_cap, int64_t *d_id_off, int max_ids, int unk, hipStream_t s,
+               int32_t *d_starts = nullptr, int32_t *d_ends = nullptr)
 {
+    const bool want_off = d_starts && d_ends;                                  // fNeedOffsets (tokdll:1137,1381)
     if (ndocs < 0 || total_bytes < 0 || !d_doc_off || !d_id_off || (ids_cap > 0 && !d_ids_out) || (total_bytes > 0 && !d_text)) return BF_E_ARG;
     if (max_ids < 0) max_ids = 0;
     Model &m = h->m;
@@ -139,8 +142,9 @@ int run_device(Handle *h, const char *d_text, const int64_t *d_doc_off, int64_t 
     (void)hipEventRecord(h->ev[EV_BEGIN], s);
     if (m.kind == KIND_WP) {
         if (!h->w_cls.reserve((size_t)(total_bytes + 64) * 2)) return BF_E_DEVICE;
+        if (want_off && (!h->w_srcoff.reserve((size_t)(total_bytes + 64) * 4) || !h->w_span.reserve((size_t)(total_bytes + 8 * ndocs + 64) * 8))) return BF_E_DEVICE;
         WpPrepParams pp{b, DevCpMap{h->t_cp_l1.as<uint16_t>(), h->t_cp_pages.as<uint32_t>()}, h->t_multi.as<uint16_t>(),
-                        m.wbd_charmap_multi ? 1 : 0, h->w_cls.as<uint16_t>(), h->w_nchars.as<int32_t>()};
+                        m.wbd_charmap_multi ? 1 : 0, h->w_cls.as<uint16_t>(), want_off ? h->w_srcoff.as<int32_t>() : nullptr, h->w_nchars.as<int32_t>()};
         if (ndocs > 0) launch_prep_wp(pp, s);
         (void)hipEventRecord(h->ev[EV_PREP], s);
         WpLexParams lp;
@@ -148,7 +152,7 @@ int run_device(Handle *h, const char *d_text, const int64_t *d_doc_off, int64_t 
         lp.L.initial = m.wbd.initial_base; lp.L.cls_any = m.cls_any; lp.L.cls_l = m.cls_l; lp.L.cls_r = m.cls_r;
         lp.L.max_depth = m.max_depth; lp.L.max_token_length = m.max_token_length; lp.L.max_frames = m.lex_frames;
         lp.b = b; lp.cls = h->w_cls.as<uint16_t>(); lp.nchars = h->w_nchars.as<int32_t>();
-        lp.ids_tmp = h->w_tmp.as<int32_t>(); lp.counts = h->w_counts.as<int32_t>();
+        lp.ids_tmp = h->w_tmp.as<int32_t>(); lp.counts = h->w_counts.as<int32_t>(); lp.span_tmp = want_off ? h->w_span.as<int32_t>() : nullptr;
         lp.max_ids = max_ids; lp.unk = unk; lp.next_doc = next_doc; lp.status = status; lp.ev_thresh = 0; lp.fetch_thresh = 0; lp.acts_n = (int)m.acts_pool.size();
         lp.stats = getenv("BF_LEX_STATS") ? (unsigned long long *)(h->w_misc.as<char>() + 64) : nullptr;
         if (ndocs > 0) launch_lex_wp(lp, h->variant, s);
@@ -158,20 +162,21 @@ int run_device(Handle *h, const char *d_text, const int64_t *d_doc_off, int64_t 
         slot_mul = mul;
         const size_t cap = (size_t)mul * (size_t)(total_bytes + ndocs) + 64;      // elements over all documents
         if (!h->w_cls.reserve(cap * 2) || !h->w_tmp.reserve(cap * 4)) return BF_E_DEVICE;
+        if (want_off && (!h->w_srcoff.reserve(cap * 4) || !h->w_span.reserve(cap * 8))) return BF_E_DEVICE;
         SpPrepParams pp;
         pp.b = b; pp.cpmap = DevCpMap{h->t_cp_l1.as<uint16_t>(), h->t_cp_pages.as<uint32_t>()}; pp.multi_pool = h->t_multi.as<uint16_t>();
         pp.has_multi = m.sp_has_multi ? 1 : 0; pp.use_bytes = m.use_bytes ? 1 : 0; pp.has_charmap = m.dict_has_charmap ? 1 : 0;
         pp.delim_code = m.sp_delim_code;
         pp.prefix_n = m.no_dummy_prefix ? 0 : (int)m.sp_prefix.size();
         for (int k = 0; k < 10; ++k) pp.prefix[k] = k < pp.prefix_n ? m.sp_prefix[(size_t)k] : 0;
-        pp.slot_mul = mul; pp.stream = h->w_cls.as<uint16_t>(); pp.lens = h->w_nchars.as<int32_t>();
+        pp.slot_mul = mul; pp.stream = h->w_cls.as<uint16_t>(); pp.lens = h->w_nchars.as<int32_t>(); pp.src_off = want_off ? h->w_srcoff.as<int32_t>() : nullptr;
         if (ndocs > 0) launch_prep_sp(pp, s);
         (void)hipEventRecord(h->ev[EV_PREP], s);
         SpSegParams sg;
         sg.S.T = h->t_dict.as<uint64_t>(); sg.S.info = h->t_seginfo.as<SegInfo>(); sg.S.initial = m.dict.initial_base;
         sg.S.cls_delim = m.sp_delim_code; sg.S.kind = m.kind; sg.S.id_offset = m.id_offset;
         sg.b = b; sg.stream = h->w_cls.as<uint16_t>(); sg.lens = h->w_nchars.as<int32_t>(); sg.slot_mul = mul;
-        sg.ids_tmp = h->w_tmp.as<int32_t>(); sg.counts = h->w_counts.as<int32_t>(); sg.max_ids = max_ids; sg.unk = unk; sg.status = status;
+        sg.ids_tmp = h->w_tmp.as<int32_t>(); sg.counts = h->w_counts.as<int32_t>(); sg.span_tmp = want_off ? h->w_span.as<int32_t>() : nullptr; sg.max_ids = max_ids; sg.unk = unk; sg.status = status;
         sg.best = nullptr; sg.arcs = nullptr; sg.tos = nullptr; sg.idsv = nullptr; sg.inter = nullptr;
         if (m.kind == KIND_UNIGRAM) {
             if (!h->w_s1.reserve(cap * 16)) return BF_E_DEVICE;
@@ -191,7 +196,8 @@ int run_device(Handle *h, const char *d_text, const int64_t *d_doc_off, int64_t 
     ScanParams sp{h->w_counts.as<int32_t>(), ndocs, d_id_off, h->w_bsums.as<int64_t>(), nblocks};
     launch_scan(sp, s);
     (void)hipEventRecord(h->ev[EV_SCAN], s);
-    CompactParams cp{b, h->w_tmp.as<int32_t>(), h->w_counts.as<int32_t>(), d_id_off, d_ids_out, ids_cap, status, slot_mul, first};
+    CompactParams cp{b, h->w_tmp.as<int32_t>(), h->w_counts.as<int32_t>(), d_id_off, d_ids_out, ids_cap, status, slot_mul, first,
+                     want_off ? h->w_span.as<int32_t>() : nullptr, want_off ? h->w_srcoff.as<int32_t>() : nullptr, want_off ? d_starts : nullptr, want_off ? d_ends : nullptr};
     if (ndocs > 0) launch_compact(cp, s);
     (void)hipEventRecord(h->ev[EV_COMPACT], s);
     h->ev_valid = true;
@@ -200,8 +206,9 @@ int run_device(Handle *h, const char *d_text, const int64_t *d_doc_off, int64_t 
 }
 
 int64_t run_host(Handle *h, const char *text, const int64_t *doc_off, int64_t ndocs, int32_t *ids_out, int64_t ids_cap,
-                 int64_t *id_off_out, int max_ids, int unk)
+                 int64_t *id_off_out, int max_ids, int unk, int32_t *starts_out = nullptr, int32_t *ends_out = nullptr)
 {
+    const bool want_off = starts_out && ends_out;
     if (ndocs < 0 || !doc_off || (ndocs > 0 && !text && doc_off[ndocs] > doc_off[0])) return BF_E_ARG;
     const int64_t base = doc_off[0];
     const int64_t total = ndocs > 0 ? doc_off[ndocs] - base : 0;
@@ -215,13 +222,15 @@ int64_t run_host(Handle *h, const char *text, const int64_t *doc_off, int64_t nd
     if (max_ids >= 0 && ndocs * (int64_t)max_ids < worst) worst = ndocs * (int64_t)(max_ids < 0 ? 0 : max_ids);
     if (!h->w_text.reserve((size_t)total + 16) || !h->w_docoff.reserve((size_t)(ndocs + 1) * 8) ||
         !h->w_idoff.reserve((size_t)(ndocs + 1) * 8) || !h->w_ids.reserve((size_t)(worst + 1) * 4)) return BF_E_DEVICE;
+    if (want_off && (!h->w_starts.reserve((size_t)(worst + 1) * 4) || !h->w_ends.reserve((size_t)(worst + 1) * 4))) return BF_E_DEVICE;
     std::vector<int64_t> rel;
     const int64_t *src_off = doc_off;
     if (base != 0) { rel.resize((size_t)ndocs + 1); for (int64_t i = 0; i <= ndocs; ++i) rel[(size_t)i] = doc_off[i] - base; src_off = rel.data(); }
     if (total > 0 && !hip_ok(hipMemcpyAsync(h->w_text.p, text + base, (size_t)total, hipMemcpyHostToDevice, s), "H2D text")) return BF_E_DEVICE;
     if (!hip_ok(hipMemcpyAsync(h->w_docoff.p, src_off, (size_t)(ndocs + 1) * 8, hipMemcpyHostToDevice, s), "H2D offsets")) return BF_E_DEVICE;
     int rc = run_device(h, h->w_text.as<char>(), h->w_docoff.as<int64_t>(), ndocs, total, h->w_ids.as<int32_t>(), worst,
-                        h->w_idoff.as<int64_t>(), max_ids, unk, s);
+                        h->w_idoff.as<int64_t>(), max_ids, unk, s, want_off ? h->w_starts.as<int32_t>() : nullptr,
+                        want_off ? h->w_ends.as<int32_t>() : nullptr);
     if (rc != 0) return rc;
     std::vector<int64_t> tmp_off;
     int64_t *dst_off = id_off_out;
@@ -236,11 +245,14 @@ int64_t run_host(Handle *h, const char *text, const int64_t *doc_off, int64_t nd
     if (nids > 0) {
         if (!ids_out) return BF_E_ARG;
         if (!hip_ok(hipMemcpy(ids_out, h->w_ids.p, (size_t)nids * 4, hipMemcpyDeviceToHost), "D2H ids")) return BF_E_DEVICE;
+        if (want_off && (!hip_ok(hipMemcpy(starts_out, h->w_starts.p, (size_t)nids * 4, hipMemcpyDeviceToHost), "D2H starts") ||
+                         !hip_ok(hipMemcpy(ends_out, h->w_ends.p, (size_t)nids * 4, hipMemcpyDeviceToHost), "D2H ends"))) return BF_E_DEVICE;
     }
     return nids;
 }
 
-int text_to_ids_one(void *hp, const char *s, int n, int32_t *ids, int max_ids, int unk, int want_kind /* -1 any, 0 wp, 1 sp */)
+int text_to_ids_one(void *hp, const char *s, int n, int32_t *ids, int max_ids, int unk, int want_kind /* -1 any, 0 wp, 1 sp */,
+                    int32_t *starts = nullptr, int32_t *ends = nullptr)
 {
     Handle *h = as_handle(hp);
     if (!h) return 0;                                         // tokdll:1629-1631
@@ -249,7 +261,7 @@ int text_to_ids_one(void *hp, const char *s, int n, int32_t *ids, int max_ids, i
     if (want_kind == 1 && h->m.kind == KIND_WP) return 0;
     if (max_ids <= 0 || !ids) return 0;
     const int64_t off[2] = {0, n};
-    int64_t r = run_host(h, s, off, 1, ids, max_ids, nullptr, max_ids, unk);
+    int64_t r = run_host(h, s, off, 1, ids, max_ids, nullptr, max_ids, unk, starts, ends);
     if (r < 0) { fprintf(stderr, "[blingfire_amd] TextToIds failed (%lld): %s\n", (long long)r, g_last_error.c_str()); return 0; }
     return (int)r;
 }
@@ -293,6 +305,14 @@ int TextToIds(void *h, const char *s, int n, int32_t *ids, const int max_ids, co
 int TextToIds_wp(void *h, const char *s, int n, int32_t *ids, const int max_ids, const int unk) { return text_to_ids_one(h, s, n, ids, max_ids, unk, 0); }
 int TextToIds_sp(void *h, const char *s, int n, int32_t *ids, const int max_ids, const int unk) { return text_to_ids_one(h, s, n, ids, max_ids, unk, 1); }
 
+/* reference tokdll:1562-1609, 1108-1118, 1349-1359: ids plus inclusive byte offsets; NULL starts/ends = ids only */
+int TextToIdsWithOffsets(void *h, const char *s, int n, int32_t *ids, int *starts, int *ends, const int max_ids, const int unk)
+{ return text_to_ids_one(h, s, n, ids, max_ids, unk, -1, starts, ends); }
+int TextToIdsWithOffsets_wp(void *h, const char *s, int n, int32_t *ids, int *starts, int *ends, const int max_ids, const int unk)
+{ return text_to_ids_one(h, s, n, ids, max_ids, unk, 0, starts, ends); }
+int TextToIdsWithOffsets_sp(void *h, const char *s, int n, int32_t *ids, int *starts, int *ends, const int max_ids, const int unk)
+{ return text_to_ids_one(h, s, n, ids, max_ids, unk, 1, starts, ends); }
+
 int SetNoDummyPrefix(void *p, int flag)
 {
     Handle *h = as_handle(p);
@@ -308,6 +328,26 @@ int64_t TextToIdsBatch(void *p, const char *text, const int64_t *doc_offsets, in
     Handle *h = as_handle(p);
     if (!h) return BF_E_ARG;
     return run_host(h, text, doc_offsets, ndocs, ids_out, ids_cap, id_offsets_out, max_ids_per_doc, unk);
+}
+
+int64_t TextToIdsWithOffsetsBatch(void *p, const char *text, const int64_t *doc_offsets, int64_t ndocs, int32_t *ids_out, int32_t *starts_out,
+                                  int32_t *ends_out, int64_t cap, int64_t *id_offsets_out, int max_ids_per_doc, int unk)
+{
+    Handle *h = as_handle(p);
+    if (!h) return BF_E_ARG;
+    return run_host(h, text, doc_offsets, ndocs, ids_out, cap, id_offsets_out, max_ids_per_doc, unk, starts_out, ends_out);
+}
+
+int TextToIdsWithOffsetsBatchDevice(void *p, const char *d_text, const int64_t *d_doc_offsets, int64_t ndocs, int64_t total_bytes,
+                                    int32_t *d_ids_out, int32_t *d_starts_out, int32_t *d_ends_out, int64_t cap, int64_t *d_id_offsets_out,
+                                    int max_ids_per_doc, int unk, void *stream)
+{
+    Handle *h = as_handle(p);
+    if (!h) return BF_E_ARG;
+    std::lock_guard<std::mutex> lock(h->mu);
+    if (!hip_ok(hipSetDevice(h->device), "hipSetDevice")) return BF_E_DEVICE;
+    return run_device(h, d_text, d_doc_offsets, ndocs, total_bytes, d_ids_out, cap, d_id_offsets_out, max_ids_per_doc, unk, (hipStream_t)stream,
+                      d_starts_out, d_ends_out);
 }
 
 int TextToIdsBatchDevice(void *p, const char *d_text, const int64_t *d_doc_offsets, int64_t ndocs, int64_t total_bytes,

@@ -23,6 +23,7 @@ struct WpPrepParams {
     const uint16_t *multi_pool; // records for 0 / 2..10 output chars
     int has_multi;
     uint16_t *cls;              // [total_bytes] class stream: document d occupies cls[doc_off[d] ..)
+    int32_t *src_off;           // optional (offsets API): byte offset in the document of the source character of every stream element
     int32_t *nchars;            // [ndocs] normalised length, 0 = "TextToIds returns 0"
 };
 
@@ -32,6 +33,7 @@ struct WpLexParams {
     const uint16_t *cls;
     const int32_t *nchars;
     int32_t *ids_tmp;           // [total_bytes] staging: document d writes ids_tmp[doc_off[d] ..)
+    int32_t *span_tmp;          // optional (offsets API): [2k],[2k+1] = first / last stream position of staged id k
     int32_t *counts;            // [ndocs]
     int max_ids, unk;
     unsigned long long *next_doc; // work counter (persistent variants)
@@ -52,6 +54,7 @@ struct SpPrepParams {
     int prefix_n; uint16_t prefix[10];
     int slot_mul;
     uint16_t *stream;           // element codes after prefix / charmap / whitespace collapse
+    int32_t *src_off;           // optional (offsets API): byte offset of the source character of every kept element (-1: dummy prefix)
     int32_t *lens;              // [ndocs] stream length, 0 = "TextToIds returns 0"
 };
 
@@ -61,6 +64,7 @@ struct SpSegParams {
     const uint16_t *stream; const int32_t *lens;
     int slot_mul;
     int32_t *ids_tmp; int32_t *counts;
+    int32_t *span_tmp;          // optional (offsets API)
     int max_ids, unk;
     // scratch (indexed by element slot): unigram sc/bi; bpe arcs (6 per element + 32 per document), tos/idsv/inter
     SegBest *best;
@@ -82,6 +86,8 @@ struct CompactParams {
     int32_t *ids_out; int64_t ids_cap; int *status;
     int slot_mul;               // 0: _wp slots (align8(doc_off)+8d); >0: _sp slots (slot_mul*(doc_off+d))
     const int32_t *first;       // optional: index of the first id inside the slot (Unigram flat kernel writes ids right-aligned)
+    // offsets API (all optional): stream positions of the staged ids -> byte offsets in the original text (tokdll:1263-1273,1519-1529)
+    const int32_t *span_tmp; const int32_t *src_off; int32_t *starts_out; int32_t *ends_out;
 };
 
 void launch_prep_wp(const WpPrepParams &p, hipStream_t s);

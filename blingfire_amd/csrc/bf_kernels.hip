@@ -73,6 +73,7 @@ __global__ __launch_bounds__(256) void k_prep_wp(WpPrepParams p)
                     uint16_t *o = out + outc + lane * 4;
                     if (nb == 4) { const uint64_t pk = (uint64_t)c0 | ((uint64_t)c1 << 16) | ((uint64_t)c2 << 32) | ((uint64_t)c3 << 48); __builtin_memcpy(o, &pk, 8); }
                     else { if (nb > 0) o[0] = c0; if (nb > 1) o[1] = c1; if (nb > 2) o[2] = c2; }
+                    if (p.src_off) { int32_t *so = p.src_off + b + outc + lane * 4; for (int k = 0; k < nb; ++k) so[k] = q + k; }
                     const int adv = (n - pos) < 256 ? (n - pos) : 256;
                     outc += adv; pos += adv;
                     continue;
@@ -131,10 +132,10 @@ __global__ __launch_bounds__(256) void k_prep_wp(WpPrepParams p)
                 idx = outc + inc - w;
                 total = __shfl(inc, 63, 64);
             }
-            if (w == 1 && !(v & 0x80000000u)) { if (idx < n) out[idx] = (uint16_t)v; }
+            if (w == 1 && !(v & 0x80000000u)) { if (idx < n) { out[idx] = (uint16_t)v; if (p.src_off) p.src_off[b + idx] = q; } }
             else if (w > 0) {
                 const uint16_t *rec = p.multi_pool + (v & 0x7FFFFFFFu) + 1;
-                for (int k = 0; k < w; ++k) if (idx + k < n) out[idx + k] = rec[k];
+                for (int k = 0; k < w; ++k) if (idx + k < n) { out[idx + k] = rec[k]; if (p.src_off) p.src_off[b + idx + k] = q; }
             }
             outc += total;
             pos += 64;
@@ -218,7 +219,9 @@ struct FramesLds {
 // id chunk buffer in LDS (8 ids per lane, structure-of-arrays): ids leave the lane as whole 32-byte sectors
 struct IdOutLds {
     int32_t *slot; int32_t *buf; int nthreads; int cb;     // buf = &lds_idbuf[threadIdx.x]; word i at buf[i * nthreads]
-    __device__ __forceinline__ void init(int32_t *s) { slot = s; cb = -1; }
+    int32_t *spans;                                        // optional (offsets API): global, same indexing as the slot, 2 ints per id
+    __device__ __forceinline__ void init(int32_t *s, int32_t *sp = nullptr) { slot = s; cb = -1; spans = sp; }
+    __device__ __forceinline__ void span(int k, int from, int to) { if (spans) { spans[2 * k] = from; spans[2 * k + 1] = to; } }
     __device__ __forceinline__ void flush()
     {
         int4 *q = (int4 *)(slot + (int64_t)cb * 8);
@@ -258,7 +261,7 @@ __global__ __launch_bounds__(THREADS) void k_lex_wp_seq(WpLexParams p)
     if (cap < 0) cap = 0;
     ClsWin cls_at; cls_at.init(p.cls, b);
     IdOutLds out; out.buf = lex_lds + (size_t)p.L.max_frames * LEX_FRAME_WORDS * THREADS + threadIdx.x; out.nthreads = THREADS;
-    out.init(p.ids_tmp + ids_slot(b, d));
+    out.init(p.ids_tmp + ids_slot(b, d), p.span_tmp ? p.span_tmp + 2 * ids_slot(b, d) : nullptr);
     FramesLds frames{lex_lds, THREADS};
     p.counts[d] = lex_doc(p.L, cls_at, n, out, cap, p.unk, frames);
 }
@@ -334,7 +337,7 @@ __global__ __launch_bounds__(THREADS) void k_lex_wp_flat(WpLexParams p)
                         int cap = p.max_ids; if ((int64_t)cap > nbytes) cap = (int)nbytes;
                         if (cap < 0) cap = 0;
                         cls_at.init(p.cls, b);
-                        out.init(p.ids_tmp + ids_slot(b, doc));
+                        out.init(p.ids_tmp + ids_slot(b, doc), p.span_tmp ? p.span_tmp + 2 * ids_slot(b, doc) : nullptr);
                         lane.init(n, cap, p.unk);
                         if (lane.prepare()) mode = M_WALK;
                         else p.counts[doc] = lane.finish();          // empty / invalid document: 0 ids, stay idle
@@ -423,7 +426,7 @@ __global__ __launch_bounds__(256) void k_prep_sp(SpPrepParams p)
             const uint32_t e = p.prefix[k];
             const bool ws = e == 0xFFFDu;
             const bool keep = !ws || !have_prev || !sp_delimish(prev, D);
-            if (keep) { if (lane == 0 && outc < cap) out[outc] = (uint16_t)(ws ? D : e); ++outc; }
+            if (keep) { if (lane == 0 && outc < cap) { out[outc] = (uint16_t)(ws ? D : e); if (p.src_off) p.src_off[sp_slot(b, d, p.slot_mul) + outc] = -1; } ++outc; }
             prev = e; have_prev = true; ++normc;
         }
         bool bad = false;
@@ -500,7 +503,7 @@ __global__ __launch_bounds__(256) void k_prep_sp(SpPrepParams p)
                 for (int k = 0; k < c; ++k) {
                     if (k > 0) e = rec[k];
                     const bool ws = e == 0xFFFDu;
-                    if (!ws || !hp2 || !sp_delimish(pe2, D)) { if (idx < cap) out[idx] = (uint16_t)(ws ? D : e); ++idx; }
+                    if (!ws || !hp2 || !sp_delimish(pe2, D)) { if (idx < cap) { out[idx] = (uint16_t)(ws ? D : e); if (p.src_off) p.src_off[sp_slot(b, d, p.slot_mul) + idx] = q; } ++idx; }
                     pe2 = e; hp2 = true;
                 }
             }
@@ -563,7 +566,7 @@ __global__ __launch_bounds__(64) void k_seg_unigram(SpSegParams p)
     const int64_t d = p.perm[i];
     const int64_t slot = sp_slot(p.b.doc_off[d], d, p.slot_mul);
     ClsWin cls_at; cls_at.init(p.stream, slot);
-    IdOutDirect out{p.ids_tmp + slot};
+    IdOutDirect out{p.ids_tmp + slot, p.span_tmp ? p.span_tmp + 2 * slot : nullptr};
     p.counts[d] = seg_unigram_doc(p.S, cls_at, p.lens[d], p.best + slot, out, p.max_ids, p.unk);
 }
 
@@ -579,7 +582,7 @@ __global__ __launch_bounds__(64) void k_seg_unigram_flat(SpSegParams p)
     const double neg_flt_max = -3.40282346638528859811704183484516925e+38;
     const int depth = p.trie_depth;
     int mode = M_NEED;
-    int64_t doc = 0; SegBest *best = nullptr; int32_t *ids = nullptr;
+    int64_t doc = 0; SegBest *best = nullptr; int32_t *ids = nullptr; int32_t *spans = nullptr;
     ClsWin cls_at; cls_at.init(p.stream, 0);
     int L = 0, cap = 0, start = 0, i = 0, sum = 0, cnt = 0, end = 0, pb_begin = -1, pb_id = 0;
     uint32_t state = 0; bool unknown = true; double prev = 0;
@@ -602,7 +605,7 @@ __global__ __launch_bounds__(64) void k_seg_unigram_flat(SpSegParams p)
                         const int64_t slot = sp_slot(b, doc, p.slot_mul);
                         cap = p.slot_mul * (int)(p.b.doc_off[doc + 1] - b + 1);
                         L = p.lens[doc];
-                        best = p.best + slot; ids = p.ids_tmp + slot; cls_at.init(p.stream, slot);
+                        best = p.best + slot; ids = p.ids_tmp + slot; spans = p.span_tmp ? p.span_tmp + 2 * slot : nullptr; cls_at.init(p.stream, slot);
                         if (L <= 0) { p.counts[doc] = 0; p.narcs[doc] = 0; }
                         else {
                             SegBest z; z.score = neg_flt_max; z.begin = -1; z.id = -1;
@@ -656,6 +659,7 @@ __global__ __launch_bounds__(64) void k_seg_unigram_flat(SpSegParams p)
             const SegBest bb = best[end];
             const int id = bb.id != -1 ? bb.id : p.unk;
             ids[cap - 1 - cnt] = id + p.S.id_offset;
+            if (spans) { spans[2 * (cap - 1 - cnt)] = bb.begin; spans[2 * (cap - 1 - cnt) + 1] = end; }
             ++cnt;
             end = bb.begin - 1;
             if (end < 0) {
@@ -744,7 +748,7 @@ __global__ __launch_bounds__(64) void k_bpe_apply(SpSegParams p)
     const int64_t slot = sp_slot(p.b.doc_off[d], d, p.slot_mul);
     const int L = p.lens[d];
     const int n = p.narcs[d];
-    IdOutDirect out{p.ids_tmp + slot};
+    IdOutDirect out{p.ids_tmp + slot, p.span_tmp ? p.span_tmp + 2 * slot : nullptr};
     int r = 0;
     if (n < 0) { atomicOr(p.status, 2); }
     else if (L > 0) {
@@ -860,11 +864,25 @@ __global__ __launch_bounds__(256) void k_compact(CompactParams p)
     const int64_t nwaves = (int64_t)gridDim.x * 4;
     for (int64_t d = wave0; d < p.b.ndocs; d += nwaves) {
         const int c = p.counts[d];
-        const int32_t *src = p.ids_tmp + (p.slot_mul > 0 ? sp_slot(p.b.doc_off[d], d, p.slot_mul) : ids_slot(p.b.doc_off[d], d)) + (p.first ? p.first[d] : 0);
+        const int64_t b = p.b.doc_off[d];
+        const int64_t stream_slot = p.slot_mul > 0 ? sp_slot(b, d, p.slot_mul) : b;
+        const int64_t id_slot = (p.slot_mul > 0 ? stream_slot : ids_slot(b, d)) + (p.first ? p.first[d] : 0);
+        const int32_t *src = p.ids_tmp + id_slot;
         const int64_t o = p.id_off[d];
         for (int i = lane; i < c; i += 64) {
-            if (o + i < p.ids_cap) p.ids_out[o + i] = src[i];
-            else if (i == lane) atomicOr(p.status, 1);
+            if (o + i < p.ids_cap) {
+                p.ids_out[o + i] = src[i];
+                if (p.starts_out) {
+                    // stream positions -> byte offsets of the source characters; the end offset is inclusive and
+                    // covers the whole last character (FAUtf8Size of its first byte; tokdll:1270-1272,1527-1528)
+                    const int from = p.span_tmp[2 * (id_slot + i)], to = p.span_tmp[2 * (id_slot + i) + 1];
+                    const int so = from >= 0 ? p.src_off[stream_slot + from] : -1;
+                    const int eo = to >= 0 ? p.src_off[stream_slot + to] : -1;
+                    int sz = 0;
+                    if (eo >= 0) { const uint32_t ch = p.b.text[b + eo]; sz = (ch & 0x80) == 0 ? 1 : (ch & 0xE0) == 0xC0 ? 2 : (ch & 0xF0) == 0xE0 ? 3 : (ch & 0xF8) == 0xF0 ? 4 : 0; }
+                    p.starts_out[o + i] = so; p.ends_out[o + i] = eo + (sz > 0 ? sz - 1 : 0);
+                }
+            } else if (i == lane) atomicOr(p.status, 1);
         }
     }
 }

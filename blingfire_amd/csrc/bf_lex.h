@@ -69,7 +69,9 @@ BF_HD uint64_t lx_dest(const LexTables &L, uint32_t state, uint32_t cls)
 // direct id output (host emulation): ids[k] = v
 struct IdOutDirect {
     int32_t *ids;
+    int32_t *spans;    // optional [2*k], [2*k+1]: first / last stream position of id k (TextToIdsWithOffsets)
     BF_HD void put(int k, int32_t v) { ids[k] = v; }
+    BF_HD void span(int k, int from, int to) { if (spans) { spans[2 * k] = from; spans[2 * k + 1] = to; } }
     BF_HD void finish(int) {}
 };
 
@@ -92,7 +94,7 @@ struct LexLane {
     const LexTables &L; ClsAt &cls_at; IdOut &ids; Frames &frames;
     // ---- streaming _wp post-pass (tokdll:1210-1311)
     int max_ids, unk;
-    int out_count, scanning, tok_to, expected, nsub, word_out;
+    int out_count, scanning, tok_from, tok_to, expected, nsub, word_out;
     // ---- lexer
     int max_triples, emitted, last_to, d;
     uint32_t ini; int off, fn_, from, once;                       // current frame
@@ -108,7 +110,8 @@ struct LexLane {
             const int c = word_out + nsub;
             out_count = c < max_ids ? c : max_ids;
         } else if (word_out < max_ids) {                 // otherwise one UNK (tokdll:1282-1301)
-            ids.put(word_out, unk); out_count = word_out + 1;
+            ids.put(word_out, unk); ids.span(word_out, tok_from, tok_to);      // offsets of the whole word (tokdll:1289-1297)
+            out_count = word_out + 1;
         }
         scanning = 0;
     }
@@ -118,14 +121,14 @@ struct LexLane {
         if (scanning) {
             if (tag > WBD_IGNORE_TAG && expected == from_) {   // tokdll:1239
                 const int k = word_out + nsub;
-                if (k < max_ids) ids.put(k, tag);
+                if (k < max_ids) { ids.put(k, tag); ids.span(k, from_, to_); }
                 nsub++; expected = to_ + 1;
                 return true;
             }
             sink_finalize_word();
             if (out_count >= max_ids) return false;
         }
-        if (tag == WBD_WORD_TAG) { scanning = 1; tok_to = to_; expected = from_; nsub = 0; word_out = out_count; }
+        if (tag == WBD_WORD_TAG) { scanning = 1; tok_from = from_; tok_to = to_; expected = from_; nsub = 0; word_out = out_count; }
         return out_count < max_ids || scanning;
     }
 
@@ -133,7 +136,7 @@ struct LexLane {
     BF_HD void init(int n, int max_ids_, int unk_)
     {
         max_ids = max_ids_; unk = unk_;
-        out_count = 0; scanning = 0; tok_to = expected = nsub = word_out = 0;
+        out_count = 0; scanning = 0; tok_from = tok_to = expected = nsub = word_out = 0;
         max_triples = 2 * n;               // WbdRes holds 6*BuffSize ints = 2*BuffSize triples (tokdll:1194)
         emitted = 0; last_to = 0; d = 0;
         ini = L.initial; off = 0; fn_ = n; from = -1; once = 0;

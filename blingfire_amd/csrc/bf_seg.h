@@ -98,7 +98,7 @@ BF_HD int seg_unigram_doc(const SegTables &S, ClsAt &cls_at, int L, SegBest *bes
     for (int end = L - 1; 0 <= end; --k) {
         const SegBest b = best[end];
         const int id = b.id != -1 ? b.id : unk;
-        if (k < max_ids) out.put(k, id + S.id_offset);                 // tokdll:1512-1516
+        if (k < max_ids) { out.put(k, id + S.id_offset); out.span(k, b.begin, end); }   // tokdll:1512-1529
         end = b.begin - 1;
     }
     const int n = cnt < max_ids ? cnt : max_ids;
@@ -213,7 +213,7 @@ BF_HD int seg_bpe_finish(const SegTables &S, int L, SegArc *arcs, int narcs, int
     for (int start = 0; start < L; ++start) {                          // …_bpe_t.h:299-313
         const int e = tos[start];
         if (e < start) return -2;
-        if (cnt < max_ids) out.put(cnt, idsv[start] + S.id_offset);
+        if (cnt < max_ids) { out.put(cnt, idsv[start] + S.id_offset); out.span(cnt, start, e); }
         ++cnt;
         start = e;
     }

@@ -50,6 +50,18 @@ int TextToIds_wp(void *ModelPtr, const char *pInUtf8Str, int InUtf8StrByteCount,
 int TextToIds_sp(void *ModelPtr, const char *pInUtf8Str, int InUtf8StrByteCount,
                  int32_t *pIdsArr, const int MaxIdsArrLength, const int UnkId);
 
+/* reference tokdll:1562-1609 (dispatch), 1108-1314 (_wp), 1349-1535 (_sp): ids plus, for every id, the byte offset of its first
+ * character and the INCLUSIVE byte offset of the last byte of its last character in the caller's string (a BOM counts; the
+ * dummy prefix has offset -1).  NULL pStartOffsets / pEndOffsets = ids only, exactly like the reference.  One deviation: for a
+ * token made of the dummy prefix alone the reference adds the UTF-8 size of the byte BEFORE the caller's buffer (undefined);
+ * this library reports end = -1. */
+int TextToIdsWithOffsets(void *ModelPtr, const char *pInUtf8Str, int InUtf8StrByteCount, int32_t *pIdsArr,
+                         int *pStartOffsets, int *pEndOffsets, const int MaxIdsArrLength, const int UnkId);
+int TextToIdsWithOffsets_wp(void *ModelPtr, const char *pInUtf8Str, int InUtf8StrByteCount, int32_t *pIdsArr,
+                            int *pStartOffsets, int *pEndOffsets, const int MaxIdsArrLength, const int UnkId);
+int TextToIdsWithOffsets_sp(void *ModelPtr, const char *pInUtf8Str, int InUtf8StrByteCount, int32_t *pIdsArr,
+                            int *pStartOffsets, int *pEndOffsets, const int MaxIdsArrLength, const int UnkId);
+
 /* reference tokdll:1669-1679 */
 int SetNoDummyPrefix(void *ModelPtr, int fNoDummyPrefix);
 
@@ -73,6 +85,14 @@ int64_t TextToIdsBatch(void *ModelPtr, const char *text, const int64_t *doc_offs
 int TextToIdsBatchDevice(void *ModelPtr, const char *d_text, const int64_t *d_doc_offsets, int64_t ndocs,
                          int64_t total_bytes, int32_t *d_ids_out, int64_t ids_cap, int64_t *d_id_offsets_out,
                          int max_ids_per_doc, int unk, void *stream);
+
+/* Batch forms of TextToIdsWithOffsets: starts_out / ends_out are parallel to ids_out (same offsets array). */
+int64_t TextToIdsWithOffsetsBatch(void *ModelPtr, const char *text, const int64_t *doc_offsets, int64_t ndocs,
+                                  int32_t *ids_out, int32_t *starts_out, int32_t *ends_out, int64_t cap,
+                                  int64_t *id_offsets_out, int max_ids_per_doc, int unk);
+int TextToIdsWithOffsetsBatchDevice(void *ModelPtr, const char *d_text, const int64_t *d_doc_offsets, int64_t ndocs,
+                                    int64_t total_bytes, int32_t *d_ids_out, int32_t *d_starts_out, int32_t *d_ends_out,
+                                    int64_t cap, int64_t *d_id_offsets_out, int max_ids_per_doc, int unk, void *stream);
 
 /* Per-kernel GPU time of the last batch call on this handle, measured with HIP events recorded on the
  * call's own stream.  Synchronises with those events.  Fills up to n floats (milliseconds):

@@ -607,28 +607,54 @@ int bfo_utf8_to_utf32(const char *s, int len, int *out, int max_out)
     return i;
 }
 
-/* FAStrUtf8AsBytesToArray :316-345 */
-static int utf8_as_bytes(const char *s, int len, int *out, int max_out)
+/* FAStrUtf8ToArray with offsets :273-313 (offsets are relative to the ORIGINAL start: a BOM counts) */
+static int utf8_to_utf32_off(const char *s, int len, int *out, int *offs, int max_out)
 {
-    const uint8_t *p = (const uint8_t *)s, *end = p + len;
+    const uint8_t *begin = (const uint8_t *)s, *p = begin, *end = p + len;
     int i = 0;
     if (len >= 3 && p[0] == 0xEF && p[1] == 0xBB && p[2] == 0xBF) p += 3;
-    while (p < end && i < max_out) out[i++] = *p++;
+    while (p < end && i < max_out) {
+        int n = utf8_to_int(p, end, out + i);
+        if (!n) return -1;
+        offs[i] = (int)(p - begin);
+        p += n; i++;
+    }
     return i;
 }
 
-/* cl/inc/FAUtils_cl.h:311-369 FANormalize */
-static int normalize(const int *in, int n, int *out, int max_out, const mmapf_t *map)
+/* FAStrUtf8AsBytesToArray :316-345 (+ offsets variant :348-381) */
+static int utf8_as_bytes(const char *s, int len, int *out, int *offs, int max_out)
+{
+    const uint8_t *begin = (const uint8_t *)s, *p = begin, *end = p + len;
+    int i = 0;
+    if (len >= 3 && p[0] == 0xEF && p[1] == 0xBB && p[2] == 0xBF) p += 3;
+    while (p < end && i < max_out) { if (offs) offs[i] = (int)(p - begin); out[i++] = *p++; }
+    return i;
+}
+
+/* FAUtf8Size(const char*) cl/src/FAUtf8Utils.cpp:23-42 */
+static int utf8_size_at(const char *p)
+{
+    int ch = *(const unsigned char *)p;
+    if ((ch & 0x80) == 0x00) return 1;
+    if ((ch & 0xE0) == 0xC0) return 2;
+    if ((ch & 0xF0) == 0xE0) return 3;
+    if ((ch & 0xF8) == 0xF0) return 4;
+    return 0;
+}
+
+/* cl/inc/FAUtils_cl.h:311-369 FANormalize (offs != NULL: the offsets form :374-436) */
+static int normalize(const int *in, int n, int *out, int *offs, int max_out, const mmapf_t *map)
 {
     int norm[10], o = 0, i, j;
     for (i = 0; i < n; ++i) {
         int c = mmapf_get(map, in[i], norm, 10);
-        if (c == -1) { if (o < max_out) out[o] = in[i]; o++; }
-        else if (c == 1) { if (o < max_out) out[o] = norm[0]; o++; }
+        if (c == -1) { if (o < max_out) { out[o] = in[i]; if (offs) offs[o] = i; } o++; }
+        else if (c == 1) { if (o < max_out) { out[o] = norm[0]; if (offs) offs[o] = i; } o++; }
         else if (c > 1 && c <= 10) {
             int copy = max_out - o;
             if (c < copy) copy = c;
-            for (j = 0; j < copy; ++j) out[o + j] = norm[j];
+            for (j = 0; j < copy; ++j) { out[o + j] = norm[j]; if (offs) offs[o + j] = i; }
             o += c;
         }
     }
@@ -709,26 +735,31 @@ int bfo_lex_process(const bfo_model *m, const int *in, int n, int *out, int max_
     return lex_process_int(m, m->wbd_dfa.initial, 0, in, n, out, max_out, 1, 0);
 }
 
-/* tokdll:1108-1314 TextToIdsWithOffsets_wp (ids only) */
-static int text_to_ids_wp(const bfo_model *m, const char *s, int n, int32_t *ids, int max_ids, int unk)
+/* tokdll:1108-1314 TextToIdsWithOffsets_wp (starts/ends may be NULL: ids only) */
+static int text_to_ids_wp(const bfo_model *m, const char *s, int n, int32_t *ids, int *starts, int *ends, int max_ids, int unk)
 {
     int *buf, *norm = NULL, *res, len, res_max, res_size, out = 0, i;
+    int *offs = NULL, *noffs = NULL;
+    const int need_off = starts && ends;
     const int *in;
     if (n <= 0 || n > MAX_ARR_SIZE || !s || !m) return 0;
     buf = (int *)malloc(sizeof(int) * (size_t)n);
-    len = bfo_utf8_to_utf32(s, n, buf, n);
-    if (len <= 0 || len > n) { free(buf); return 0; }
+    if (need_off) { offs = (int *)malloc(sizeof(int) * (size_t)n); len = utf8_to_utf32_off(s, n, buf, offs, n); }
+    else len = bfo_utf8_to_utf32(s, n, buf, n);
+    if (len <= 0 || len > n) { free(buf); free(offs); return 0; }
     in = buf;
     if (m->wbd_charmap.set) {
         norm = (int *)malloc(sizeof(int) * (size_t)n);
-        len = normalize(buf, len, norm, n, &m->wbd_charmap);
-        if (len <= 0 || len > n) { free(buf); free(norm); return 0; }
+        if (need_off) noffs = (int *)malloc(sizeof(int) * (size_t)n);
+        len = normalize(buf, len, norm, noffs, n, &m->wbd_charmap);
+        if (len <= 0 || len > n) { free(buf); free(norm); free(offs); free(noffs); return 0; }
         in = norm;
     }
+#define BFO_OFF(k) (offs[m->wbd_charmap.set ? noffs[(k)] : (k)])
     res_max = len * 6;
     res = (int *)calloc((size_t)res_max + 8, sizeof(int)); /* std::vector<int>(n) zero-fills, tokdll:1195 */
     res_size = bfo_lex_process(m, in, len, res, res_max);
-    if (res_size > res_max || res_size % 3 != 0 || res_size < 0) { free(buf); free(norm); free(res); return 0; }
+    if (res_size > res_max || res_size % 3 != 0 || res_size < 0) { free(buf); free(norm); free(res); free(offs); free(noffs); return 0; }
     for (i = 0; i < res_size; i += 3) {
         int tag = res[i];
         if (tag == WBD_IGNORE_TAG) continue;
@@ -743,16 +774,36 @@ static int text_to_ids_wp(const bfo_model *m, const char *s, int n, int32_t *ids
                     if (j < res_size) { st = res[j]; sf = res[j + 1]; sto = res[j + 2]; }
                 }
                 if (nsub > 0 && expected - 1 == tok_to) {
-                    for (k = 0; k < nsub && out < max_ids; ++k) ids[out++] = res[(k + 1) * 3 + i];
+                    for (k = 0; k < nsub && out < max_ids; ++k) {
+                        int ti = (k + 1) * 3 + i;
+                        ids[out] = res[ti];
+                        if (need_off) {                                        /* tokdll:1263-1273 */
+                            int to_off = BFO_OFF(res[ti + 2]), sz;
+                            starts[out] = BFO_OFF(res[ti + 1]);
+                            sz = utf8_size_at(s + to_off);
+                            ends[out] = to_off + (0 < sz ? sz - 1 : 0);
+                        }
+                        out++;
+                    }
                     covered = 1;
                 }
             }
-            if (!covered && out < max_ids) ids[out++] = unk;
+            if (!covered && out < max_ids) {
+                ids[out] = unk;
+                if (need_off) {                                                /* tokdll:1289-1297 */
+                    int to_off = BFO_OFF(tok_to), sz;
+                    starts[out] = BFO_OFF(tok_from);
+                    sz = utf8_size_at(s + to_off);
+                    ends[out] = to_off + (0 < sz ? sz - 1 : 0);
+                }
+                out++;
+            }
             i = j - 3;
         }
         if (out >= max_ids) break;
     }
-    free(buf); free(norm); free(res);
+#undef BFO_OFF
+    free(buf); free(norm); free(res); free(offs); free(noffs);
     return out;
 }
 
@@ -912,29 +963,35 @@ static int seg_bpe(const bfo_model *m, const int *in, int n, int *out, int max_o
     return actual;
 }
 
-/* tokdll:1349-1535 TextToIdsWithOffsets_sp (ids only) */
-static int text_to_ids_sp(const bfo_model *m, const char *s, int n, int32_t *ids, int max_ids, int unk)
+/* tokdll:1349-1535 TextToIdsWithOffsets_sp (starts/ends may be NULL: ids only) */
+static int text_to_ids_sp(const bfo_model *m, const char *s, int n, int32_t *ids, int *starts, int *ends, int max_ids, int unk)
 {
     int *buf, *norm = NULL, *in, *res, len, off, i, j, res_max, res_size, out = 0;
+    int *offs = NULL, *noffs = NULL, *adj = NULL;
+    const int need_off = starts && ends;
     if (n <= 0 || n > MAX_ARR_SIZE || !s || !m) return 0;
     buf = (int *)malloc(sizeof(int) * ((size_t)n + 1));
     buf[0] = SP_DELIM;
+    if (need_off) { offs = (int *)malloc(sizeof(int) * ((size_t)n + 1)); offs[0] = -1; }   /* tokdll:1387 */
     off = m->no_dummy_prefix ? 0 : 1;
-    len = m->use_bytes ? utf8_as_bytes(s, n, buf + off, n) : bfo_utf8_to_utf32(s, n, buf + off, n);
-    if (len <= 0 || len > n) { free(buf); return 0; }
+    if (m->use_bytes) len = utf8_as_bytes(s, n, buf + off, need_off ? offs + off : NULL, n);
+    else len = need_off ? utf8_to_utf32_off(s, n, buf + off, offs + off, n) : bfo_utf8_to_utf32(s, n, buf + off, n);
+    if (len <= 0 || len > n) { free(buf); free(offs); return 0; }
     len += off;
     in = buf;
     if (m->dict_charmap.set) {
         int max_norm = (n + 1) * 2, actual;
         norm = (int *)malloc(sizeof(int) * (size_t)max_norm);
-        actual = normalize(buf, len, norm, max_norm, &m->dict_charmap);
-        if (actual <= 0 || actual > max_norm) { free(buf); free(norm); return 0; }
+        if (need_off) noffs = (int *)malloc(sizeof(int) * (size_t)max_norm);
+        actual = normalize(buf, len, norm, noffs, max_norm, &m->dict_charmap);
+        if (actual <= 0 || actual > max_norm) { free(buf); free(norm); free(offs); free(noffs); return 0; }
         len = actual; in = norm;
     }
+    adj = need_off ? (m->dict_charmap.set ? noffs : offs) : NULL;                          /* tokdll:1460 */
     for (i = 0, j = 0; i < len; ++i) {            /* tokdll:1462-1488 */
         int c = in[i];
-        if (!is_ws(c)) in[j++] = c;
-        else if (0 == j || SP_DELIM != in[j - 1]) in[j++] = SP_DELIM;
+        if (!is_ws(c)) { in[j] = c; if (adj) adj[j] = adj[i]; j++; }
+        else if (0 == j || SP_DELIM != in[j - 1]) { in[j] = SP_DELIM; if (adj) adj[j] = adj[i]; j++; }
     }
     if (1 < j && in[j - 1] == SP_DELIM) j--;      /* tokdll:1491-1493 */
     len = j;
@@ -943,17 +1000,35 @@ static int text_to_ids_sp(const bfo_model *m, const char *s, int n, int32_t *ids
     if (m->tok_algo == TOKENIZE_BPE || m->tok_algo == TOKENIZE_BPE_OPT) res_size = seg_bpe(m, in, len, res, res_max, unk, 0);
     else if (m->tok_algo == TOKENIZE_BPE_OPT_WITH_MERGES) res_size = seg_bpe(m, in, len, res, res_max, unk, 1);
     else res_size = seg_unigram(m, in, len, res, res_max, unk);
-    if (res_size > res_max || res_size % 3 != 0 || res_size < 0) { free(buf); free(norm); free(res); return 0; }
-    for (i = 0; i < res_size && out < max_ids; i += 3) ids[out++] = res[i] + m->id_offset;
-    free(buf); free(norm); free(res);
+    if (res_size > res_max || res_size % 3 != 0 || res_size < 0) { free(buf); free(norm); free(res); free(offs); free(noffs); return 0; }
+    for (i = 0; i < res_size && out < max_ids; i += 3) {
+        ids[out] = res[i] + m->id_offset;
+        if (need_off) {                                                        /* tokdll:1519-1529 */
+            int from_off = offs[m->dict_charmap.set ? noffs[res[i + 1]] : res[i + 1]];
+            int to_off = offs[m->dict_charmap.set ? noffs[res[i + 2]] : res[i + 2]];
+            /* a token made of the dummy prefix alone has offset -1: the reference then reads the byte BEFORE the
+             * caller's string (undefined); the restatement treats its size as 0 */
+            int sz = to_off >= 0 ? utf8_size_at(s + to_off) : 0;
+            starts[out] = from_off;
+            ends[out] = to_off + (0 < sz ? sz - 1 : 0);
+        }
+        out++;
+    }
+    free(buf); free(norm); free(res); free(offs); free(noffs);
     return out;
 }
 
 int bfo_text_to_ids(const bfo_model *m, const char *utf8, int n, int32_t *ids, int max_ids, int unk)
 {
+    return bfo_text_to_ids_with_offsets(m, utf8, n, ids, NULL, NULL, max_ids, unk);
+}
+
+/* tokdll:1562-1609 TextToIdsWithOffsets */
+int bfo_text_to_ids_with_offsets(const bfo_model *m, const char *utf8, int n, int32_t *ids, int *starts, int *ends, int max_ids, int unk)
+{
     if (!m) return 0;
-    if (!m->has_seg) return m->has_wbd ? text_to_ids_wp(m, utf8, n, ids, max_ids, unk) : 0;
-    return text_to_ids_sp(m, utf8, n, ids, max_ids, unk);
+    if (!m->has_seg) return m->has_wbd ? text_to_ids_wp(m, utf8, n, ids, starts, ends, max_ids, unk) : 0;
+    return text_to_ids_sp(m, utf8, n, ids, starts, ends, max_ids, unk);
 }
 
 /* ---------------- exported building blocks ---------------- */

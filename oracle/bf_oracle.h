@@ -40,6 +40,10 @@ int bfo_free_model(bfo_model *m);
 int bfo_text_to_ids(const bfo_model *m, const char *utf8, int n,
                     int32_t *ids, int max_ids, int unk);
 
+/* tokdll:1562-1609 TextToIdsWithOffsets: byte offsets (inclusive ends) of every id in the original string */
+int bfo_text_to_ids_with_offsets(const bfo_model *m, const char *utf8, int n,
+                                 int32_t *ids, int *starts, int *ends, int max_ids, int unk);
+
 /* tokdll:1669-1679 SetNoDummyPrefix */
 int bfo_set_no_dummy_prefix(bfo_model *m, int flag);
 

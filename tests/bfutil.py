@@ -63,6 +63,22 @@ class _T2I:
         c = self._t2i(ctypes.c_void_p(h), b, len(b), arr, max_ids, unk)
         return c, list(arr)
 
+    def with_offsets(self, h, b, max_ids, unk, name):
+        """TextToIdsWithOffsets through `name` (reference: TextToIdsWithOffsets, oracle: bfo_text_to_ids_with_offsets).
+        The text is passed at buffer+1 behind a fixed ASCII byte: the reference reads the byte BEFORE the string for a
+        token made of the dummy prefix alone (tokdll:1527 with ToOffset == -1)."""
+        f = getattr(self.lib, name)
+        f.restype = ctypes.c_int
+        f.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+        n = max(max_ids, 1)
+        i = (ctypes.c_int32 * n)()
+        s = (ctypes.c_int32 * n)()
+        e = (ctypes.c_int32 * n)()
+        buf = ctypes.create_string_buffer(b"A" + b, len(b) + 1)
+        c = f(ctypes.c_void_p(h), ctypes.addressof(buf) + 1, len(b), i, s, e, max_ids, unk)
+        c = max(c, 0)
+        return c, list(i)[:c], list(s)[:c], list(e)[:c]
+
     def batch(self, h, text, off, max_ids, unk):
         """per-document loop -> (ids int32[total], id_offsets int64[ndocs+1]) -- the golden form of TextToIdsBatch"""
         ndocs = len(off) - 1

@@ -160,17 +160,20 @@ long bft_verify_tables(void *hv, int verbose)
 }
 
 // ---- host emulation of the GPU pipeline (scalar prep + the device lane programs)
-static int emu_wp(const Model &m, const char *s, int n, int32_t *ids, int max_ids, int unk)
+static int emu_wp(const Model &m, const char *s, int n, int32_t *ids, int32_t *spans, std::vector<int> *src_off, int max_ids, int unk)
 {
     if (n <= 0 || !s) return 0;
     std::vector<int> cps((size_t)n);
     int len = bfo_utf8_to_utf32(s, n, cps.data(), n);   // the prep KERNEL has its own parallel decoder; GPU tests cover it
     if (len <= 0) return 0;
     std::vector<uint16_t> cls;
+    // byte offset of every decoded character (BOM included, like FAStrUtf8ToArray's offsets form)
+    std::vector<int> boff; { int p = (n >= 3 && (unsigned char)s[0] == 0xEF && (unsigned char)s[1] == 0xBB && (unsigned char)s[2] == 0xBF) ? 3 : 0;
+        for (int i = 0; i < len; ++i) { boff.push_back(p); int c = cps[(size_t)i]; p += c < 0x80 ? 1 : c < 0x800 ? 2 : c < 0x10000 ? 3 : 4; } }
     for (int i = 0; i < len; ++i) {
         uint32_t v = m.wbd_cpmap.get(cps[(size_t)i]);
-        if (v & FUSED_MULTI) { size_t off = v & 0x7fffffffu; int c = m.wbd_multi_pool[off]; for (int k = 0; k < c; ++k) cls.push_back(m.wbd_multi_pool[off + 1 + (size_t)k]); }
-        else cls.push_back((uint16_t)v);
+        if (v & FUSED_MULTI) { size_t off = v & 0x7fffffffu; int c = m.wbd_multi_pool[off]; for (int k = 0; k < c; ++k) { cls.push_back(m.wbd_multi_pool[off + 1 + (size_t)k]); if (src_off) src_off->push_back(boff[(size_t)i]); } }
+        else { cls.push_back((uint16_t)v); if (src_off) src_off->push_back(boff[(size_t)i]); }
     }
     if (cls.empty() || (int)cls.size() > n) return 0;
     LexTables L;
@@ -179,13 +182,13 @@ static int emu_wp(const Model &m, const char *s, int n, int32_t *ids, int max_id
     L.max_depth = m.max_depth; L.max_token_length = m.max_token_length; L.max_frames = m.lex_frames;
     const uint16_t *cp = cls.data();
     auto cls_at = [cp](int i) -> uint32_t { return cp[i]; };
-    IdOutDirect out{ids};
+    IdOutDirect out{ids, spans};
     FramesArray frames;
     return lex_doc(L, cls_at, (int)cls.size(), out, max_ids, unk, frames);
 }
 
 // scalar restatement of the _sp prologue on the fused element-code map (the prep KERNEL is wave-parallel; GPU tests cover it)
-static int emu_sp(const Model &m, const char *s, int n, int32_t *ids, int max_ids, int unk)
+static int emu_sp(const Model &m, const char *s, int n, int32_t *ids, int32_t *spans, std::vector<int> *src_off, int max_ids, int unk)
 {
     if (n <= 0 || !s) return 0;
     std::vector<int> cps((size_t)n);
@@ -196,20 +199,25 @@ static int emu_sp(const Model &m, const char *s, int n, int32_t *ids, int max_id
         len = 0; for (; k < n; ++k) cps[(size_t)len++] = p[k];
     } else len = bfo_utf8_to_utf32(s, n, cps.data(), n);
     if (len <= 0) return 0;
-    std::vector<uint16_t> el;
-    if (!m.no_dummy_prefix) el = m.sp_prefix;
-    for (int i = 0; i < len; ++i) {
-        uint32_t v = m.sp_cpmap.get(cps[(size_t)i]);
-        if (v & FUSED_MULTI) { size_t off = v & 0x7fffffffu; int c = m.sp_multi_pool[off]; for (int k = 0; k < c; ++k) el.push_back(m.sp_multi_pool[off + 1 + (size_t)k]); }
-        else el.push_back((uint16_t)v);
+    std::vector<uint16_t> el; std::vector<int> eoff;
+    if (!m.no_dummy_prefix) { el = m.sp_prefix; eoff.assign(el.size(), -1); }
+    {
+        int p = (n >= 3 && (unsigned char)s[0] == 0xEF && (unsigned char)s[1] == 0xBB && (unsigned char)s[2] == 0xBF) ? 3 : 0;
+        for (int i = 0; i < len; ++i) {
+            const int c0 = cps[(size_t)i];
+            uint32_t v = m.sp_cpmap.get(c0);
+            if (v & FUSED_MULTI) { size_t off = v & 0x7fffffffu; int c = m.sp_multi_pool[off]; for (int k = 0; k < c; ++k) { el.push_back(m.sp_multi_pool[off + 1 + (size_t)k]); eoff.push_back(p); } }
+            else { el.push_back((uint16_t)v); eoff.push_back(p); }
+            p += m.use_bytes ? 1 : (c0 < 0x80 ? 1 : c0 < 0x800 ? 2 : c0 < 0x10000 ? 3 : 4);
+        }
     }
     if (m.dict_has_charmap && (el.empty() || (long)el.size() > 2L * (n + 1))) return 0;
     std::vector<uint16_t> st;
     const uint16_t D = m.sp_delim_code;
     for (size_t i = 0; i < el.size(); ++i) {
         const uint16_t e = el[i];
-        if (e != SP_WS) st.push_back(e);
-        else if (i == 0 || !(el[i - 1] == SP_WS || el[i - 1] == D)) st.push_back(D);
+        if (e != SP_WS) { st.push_back(e); if (src_off) src_off->push_back(eoff[i]); }
+        else if (i == 0 || !(el[i - 1] == SP_WS || el[i - 1] == D)) { st.push_back(D); if (src_off) src_off->push_back(eoff[i]); }
     }
     if (st.size() > 1 && st.back() == D) st.pop_back();
     const int L = (int)st.size();
@@ -218,7 +226,7 @@ static int emu_sp(const Model &m, const char *s, int n, int32_t *ids, int max_id
     S.kind = m.kind; S.id_offset = m.id_offset;
     const uint16_t *cp = st.data();
     auto cls_at = [cp](int i) -> uint32_t { return cp[i]; };
-    IdOutDirect out{ids};
+    IdOutDirect out{ids, spans};
     if (m.kind == KIND_UNIGRAM) {
         std::vector<SegBest> best((size_t)L + 1);
         return seg_unigram_doc(S, cls_at, L, best.data(), out, max_ids, unk);
@@ -233,8 +241,27 @@ int bft_emu_text_to_ids(void *hv, const char *s, int n, int32_t *ids, int max_id
 {
     Model &m = ((Handle *)hv)->m;
     if (!m.error.empty()) return -1;
-    if (m.kind == KIND_WP) return emu_wp(m, s, n, ids, max_ids, unk);
-    return emu_sp(m, s, n, ids, max_ids, unk);
+    if (m.kind == KIND_WP) return emu_wp(m, s, n, ids, nullptr, nullptr, max_ids, unk);
+    return emu_sp(m, s, n, ids, nullptr, nullptr, max_ids, unk);
+}
+
+// offsets form: the lane programs report stream positions, the source-offset stream maps them to bytes and the end
+// offset adds the UTF-8 size of the last character (tokdll:1263-1273,1519-1529) -- what k_compact does on the GPU
+int bft_emu_text_to_ids_with_offsets(void *hv, const char *s, int n, int32_t *ids, int32_t *starts, int32_t *ends, int max_ids, int unk)
+{
+    Model &m = ((Handle *)hv)->m;
+    if (!m.error.empty()) return -1;
+    std::vector<int32_t> spans(2 * (size_t)(max_ids > 0 ? max_ids : 1) + 2, 0);
+    std::vector<int> src;
+    int c = m.kind == KIND_WP ? emu_wp(m, s, n, ids, spans.data(), &src, max_ids, unk) : emu_sp(m, s, n, ids, spans.data(), &src, max_ids, unk);
+    for (int k = 0; k < c; ++k) {
+        const int f = spans[2 * (size_t)k], t = spans[2 * (size_t)k + 1];
+        const int so = src[(size_t)f], eo = src[(size_t)t];
+        int sz = 0;
+        if (eo >= 0) { const unsigned char b = (unsigned char)s[eo]; sz = (b & 0x80) == 0 ? 1 : (b & 0xE0) == 0xC0 ? 2 : (b & 0xF0) == 0xE0 ? 3 : (b & 0xF8) == 0xF0 ? 4 : 0; }
+        starts[k] = so; ends[k] = eo + (sz > 0 ? sz - 1 : 0);
+    }
+    return c;
 }
 
 } // extern "C"
