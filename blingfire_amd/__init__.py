@@ -2,7 +2,7 @@
 
 Same function names, argument meaning and return conventions as the reference
 ``dist-pypi/blingfire/__init__.py`` (load_model :229-234, free_model :237-240, text_to_ids :243-253,
-change_settings_dummy_prefix :287-288), bound to the MI355X-native ``libblingfiretokdll.so`` built
+change_settings_dummy_prefix :287-288, text_to_words :85-102, text_to_words_with_model :105-122), bound to the MI355X-native ``libblingfiretokdll.so`` built
 in-tree by ``blingfire_amd/build.py``.  Additive: ``text_to_ids_batch`` (host buffers) and
 ``text_to_ids_batch_device`` (torch tensors already resident in HBM).
 
@@ -56,6 +56,14 @@ def lib():
         L.TextToIdsBatchDevice.restype = c_int
         L.TextToIdsBatchDevice.argtypes = [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_void_p,
                                            c_int, c_int, c_void_p]
+        L.TextToWords.restype = c_int
+        L.TextToWords.argtypes = [c_char_p, c_int, c_void_p, c_int]
+        L.TextToWordsWithModel.restype = c_int
+        L.TextToWordsWithModel.argtypes = [c_char_p, c_int, c_void_p, c_int, c_void_p]
+        L.TextToWordsWithOffsets.restype = c_int
+        L.TextToWordsWithOffsets.argtypes = [c_char_p, c_int, c_void_p, c_void_p, c_void_p, c_int]
+        L.TextToWordsWithOffsetsWithModel.restype = c_int
+        L.TextToWordsWithOffsetsWithModel.argtypes = [c_char_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p]
         L.BfLastKernelMs.restype = c_int
         L.BfLastKernelMs.argtypes = [c_void_p, POINTER(c_float), c_int]
         L.BfLastStatus.restype = c_int
@@ -103,6 +111,39 @@ def utf8text_to_ids_with_offsets(h, s_bytes, max_len, unk=0, no_padding=False):
     n = min(max_len, t) if no_padding else max_len
     return (np.frombuffer(o, dtype=np.uint32, count=n), np.frombuffer(o_s, dtype=np.int32, count=n),
             np.frombuffer(o_e, dtype=np.int32, count=n))
+
+
+def text_to_words(s):
+    """reference __init__.py:85-102: space-joined words by the built-in wbd.bin; '' on error."""
+    s_bytes = s.encode("utf-8")
+    o = ctypes.create_string_buffer(len(s_bytes) * 3)
+    n = lib().TextToWords(s_bytes, len(s_bytes), o, len(o))
+    return "" if n == -1 or n > len(o) else o.value.decode("utf-8")
+
+
+def text_to_words_with_model(h, s):
+    """reference __init__.py:105-122"""
+    s_bytes = s.encode("utf-8")
+    o = ctypes.create_string_buffer(len(s_bytes) * 3)
+    n = lib().TextToWordsWithModel(s_bytes, len(s_bytes), o, len(o), c_void_p(h))
+    return "" if n == -1 or n > len(o) else o.value.decode("utf-8")
+
+
+def text_to_words_with_offsets(s, h=None):
+    """reference __init__.py:161-223: (string, [(begin, end) per word]) as character offsets into `s`, end exclusive."""
+    s_bytes = s.encode("utf-8")
+    cap = len(s_bytes) * 3
+    o = ctypes.create_string_buffer(max(cap, 1))
+    st = (c_int32 * max(cap, 1))()
+    en = (c_int32 * max(cap, 1))()
+    n = lib().TextToWordsWithOffsetsWithModel(s_bytes, len(s_bytes), o, byref(st), byref(en), cap, c_void_p(h) if h else None)
+    if n == -1 or n > cap:
+        return "", []
+    words = o.value.decode("utf-8")
+    k = len(words.split(" ")) if words else 0
+    lead = np.frombuffer(s_bytes, dtype=np.uint8) & 0xC0 != 0x80
+    char_at = np.concatenate([[0], np.cumsum(lead)])          # byte offset -> number of characters that start before it
+    return words, [(int(char_at[st[i]]), int(char_at[en[i] + 1])) for i in range(k)]
 
 
 def change_settings_dummy_prefix(h, add_prefix):

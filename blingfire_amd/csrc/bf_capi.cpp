@@ -63,6 +63,7 @@ struct Handle {
     std::mutex mu;
     // device tables
     DevBuf t_wbd, t_info, t_acts, t_cp_l1, t_cp_pages, t_multi;
+    DevBuf t_wcp_l1, t_wcp_pages;                                // TextToWords: code point -> class without the charmap
     DevBuf t_dict, t_seginfo;                                    // _sp: Mealy table, I2Info rows (code-point maps reuse t_cp_*/t_multi)
     DevBuf w_s1, w_s2, w_s3, w_s4, w_perm, w_hist, w_narcs;      // _sp scratch
     // workspaces
@@ -72,15 +73,34 @@ struct Handle {
     hipStream_t stream = nullptr;
     hipEvent_t ev[EV_COUNT] = {};
     bool ev_valid = false;
+    bool last_nonempty = false;                                 // TextToWords: the (single) document decoded to >= 1 character
     ~Handle()
     {
-        for (DevBuf *b : {&t_wbd, &t_info, &t_acts, &t_cp_l1, &t_cp_pages, &t_multi, &t_dict, &t_seginfo, &w_s1, &w_s2, &w_s3, &w_s4, &w_perm, &w_hist, &w_narcs, &w_cls, &w_nchars, &w_tmp, &w_counts,
+        for (DevBuf *b : {&t_wbd, &t_info, &t_acts, &t_cp_l1, &t_cp_pages, &t_multi, &t_wcp_l1, &t_wcp_pages, &t_dict, &t_seginfo, &w_s1, &w_s2, &w_s3, &w_s4, &w_perm, &w_hist, &w_narcs, &w_cls, &w_nchars, &w_tmp, &w_counts,
                           &w_bsums, &w_misc, &w_text, &w_docoff, &w_ids, &w_idoff, &w_starts, &w_ends, &w_srcoff, &w_span}) b->release();
         for (auto &e : ev) if (e) (void)hipEventDestroy(e);
         if (stream) (void)hipStreamDestroy(stream);
         magic = 0;
     }
 };
+
+Handle *make_handle(const uint8_t *img, size_t size);
+
+// The reference's built-in word-breaking model (tokdll:175-183,426-434: g_DefaultWbd = the bytes of ldbsrc/ldb/wbd.bin compiled
+// into the library).  Here the same file (models/wbd.bin, unchanged data) is embedded with .incbin at build time.
+#if !defined(__HIP_DEVICE_COMPILE__)
+__asm__(".section .rodata\n.balign 16\n.global bf_default_wbd_begin\nbf_default_wbd_begin:\n.incbin \"" BF_DEFAULT_WBD_PATH "\"\n"
+        ".global bf_default_wbd_end\nbf_default_wbd_end:\n.byte 0\n.previous\n");
+#endif
+extern "C" const unsigned char bf_default_wbd_begin[], bf_default_wbd_end[];
+
+Handle *default_wbd()
+{
+    static std::mutex mu; static Handle *h = nullptr; static bool tried = false;
+    std::lock_guard<std::mutex> lock(mu);
+    if (!tried) { tried = true; h = make_handle(bf_default_wbd_begin, (size_t)(bf_default_wbd_end - bf_default_wbd_begin)); }
+    return h;
+}
 
 Handle *as_handle(void *p)
 {
@@ -110,7 +130,8 @@ Handle *make_handle(const uint8_t *img, size_t size)
         if (m.acts_pool.size() > 4096) { g_last_error = "lexer action pool exceeds the LDS staging limit (4096 ints)"; fprintf(stderr, "[blingfire_amd] %s\n", g_last_error.c_str()); delete h; return nullptr; }
         if (m.max_depth > LEX_MAX_DEPTH) { g_last_error = "lexer max-depth exceeds the supported 4"; fprintf(stderr, "[blingfire_amd] %s\n", g_last_error.c_str()); delete h; return nullptr; }
         ok = ok && upload(h->t_wbd, m.wbd_t2, 16) && upload(h->t_acts, m.acts_pool, 16) &&
-             upload(h->t_cp_l1, m.wbd_cpmap.l1) && upload(h->t_cp_pages, m.wbd_cpmap.pages) && upload(h->t_multi, m.wbd_multi_pool, 16);
+             upload(h->t_cp_l1, m.wbd_cpmap.l1) && upload(h->t_cp_pages, m.wbd_cpmap.pages) && upload(h->t_multi, m.wbd_multi_pool, 16) &&
+             upload(h->t_wcp_l1, m.words_cpmap.l1) && upload(h->t_wcp_pages, m.words_cpmap.pages);
     } else {
         ok = ok && upload(h->t_dict, m.dict.t64, 16) && upload(h->t_seginfo, m.seg_info, 16) &&
              upload(h->t_cp_l1, m.sp_cpmap.l1) && upload(h->t_cp_pages, m.sp_cpmap.pages) && upload(h->t_multi, m.sp_multi_pool, 16);
@@ -125,9 +146,10 @@ Handle *make_handle(const uint8_t *img, size_t size)
 // Enqueue the whole pipeline for a batch resident on the device.
 int run_device(Handle *h, const char *d_text, const int64_t *d_doc_off, int64_t ndocs, int64_t total_bytes,
                int32_t *d_ids_out, int64_t ids_cap, int64_t *d_id_off, int max_ids, int unk, hipStream_t s,
-               int32_t *d_starts = nullptr, int32_t *d_ends = nullptr)
+               int32_t *d_starts = nullptr, int32_t *d_ends = nullptr, bool words = false)
 {
     const bool want_off = d_starts && d_ends;                                  // fNeedOffsets (tokdll:1137,1381)
+    if (words && (h->m.kind != KIND_WP || !want_off)) return BF_E_ARG;
     if (ndocs < 0 || total_bytes < 0 || !d_doc_off || !d_id_off || (ids_cap > 0 && !d_ids_out) || (total_bytes > 0 && !d_text)) return BF_E_ARG;
     if (max_ids < 0) max_ids = 0;
     Model &m = h->m;
@@ -145,6 +167,7 @@ int run_device(Handle *h, const char *d_text, const int64_t *d_doc_off, int64_t 
         if (want_off && (!h->w_srcoff.reserve((size_t)(total_bytes + 64) * 4) || !h->w_span.reserve((size_t)(total_bytes + 8 * ndocs + 64) * 8))) return BF_E_DEVICE;
         WpPrepParams pp{b, DevCpMap{h->t_cp_l1.as<uint16_t>(), h->t_cp_pages.as<uint32_t>()}, h->t_multi.as<uint16_t>(),
                         m.wbd_charmap_multi ? 1 : 0, h->w_cls.as<uint16_t>(), want_off ? h->w_srcoff.as<int32_t>() : nullptr, h->w_nchars.as<int32_t>()};
+        if (words) { pp.cpmap = DevCpMap{h->t_wcp_l1.as<uint16_t>(), h->t_wcp_pages.as<uint32_t>()}; pp.has_multi = 0; }   // no charmap (tokdll:476-499)
         if (ndocs > 0) launch_prep_wp(pp, s);
         (void)hipEventRecord(h->ev[EV_PREP], s);
         WpLexParams lp;
@@ -153,7 +176,7 @@ int run_device(Handle *h, const char *d_text, const int64_t *d_doc_off, int64_t 
         lp.L.max_depth = m.max_depth; lp.L.max_token_length = m.max_token_length; lp.L.max_frames = m.lex_frames;
         lp.b = b; lp.cls = h->w_cls.as<uint16_t>(); lp.nchars = h->w_nchars.as<int32_t>();
         lp.ids_tmp = h->w_tmp.as<int32_t>(); lp.counts = h->w_counts.as<int32_t>(); lp.span_tmp = want_off ? h->w_span.as<int32_t>() : nullptr;
-        lp.max_ids = max_ids; lp.unk = unk; lp.next_doc = next_doc; lp.status = status; lp.ev_thresh = 0; lp.fetch_thresh = 0; lp.acts_n = (int)m.acts_pool.size();
+        lp.max_ids = max_ids; lp.unk = unk; lp.next_doc = next_doc; lp.status = status; lp.ev_thresh = 0; lp.fetch_thresh = 0; lp.acts_n = (int)m.acts_pool.size(); lp.words = words ? 1 : 0;
         lp.stats = getenv("BF_LEX_STATS") ? (unsigned long long *)(h->w_misc.as<char>() + 64) : nullptr;
         if (ndocs > 0) launch_lex_wp(lp, h->variant, s);
         (void)hipEventRecord(h->ev[EV_TOK], s);
@@ -206,7 +229,7 @@ int run_device(Handle *h, const char *d_text, const int64_t *d_doc_off, int64_t 
 }
 
 int64_t run_host(Handle *h, const char *text, const int64_t *doc_off, int64_t ndocs, int32_t *ids_out, int64_t ids_cap,
-                 int64_t *id_off_out, int max_ids, int unk, int32_t *starts_out = nullptr, int32_t *ends_out = nullptr)
+                 int64_t *id_off_out, int max_ids, int unk, int32_t *starts_out = nullptr, int32_t *ends_out = nullptr, bool words = false)
 {
     const bool want_off = starts_out && ends_out;
     if (ndocs < 0 || !doc_off || (ndocs > 0 && !text && doc_off[ndocs] > doc_off[0])) return BF_E_ARG;
@@ -230,7 +253,7 @@ int64_t run_host(Handle *h, const char *text, const int64_t *doc_off, int64_t nd
     if (!hip_ok(hipMemcpyAsync(h->w_docoff.p, src_off, (size_t)(ndocs + 1) * 8, hipMemcpyHostToDevice, s), "H2D offsets")) return BF_E_DEVICE;
     int rc = run_device(h, h->w_text.as<char>(), h->w_docoff.as<int64_t>(), ndocs, total, h->w_ids.as<int32_t>(), worst,
                         h->w_idoff.as<int64_t>(), max_ids, unk, s, want_off ? h->w_starts.as<int32_t>() : nullptr,
-                        want_off ? h->w_ends.as<int32_t>() : nullptr);
+                        want_off ? h->w_ends.as<int32_t>() : nullptr, words);
     if (rc != 0) return rc;
     std::vector<int64_t> tmp_off;
     int64_t *dst_off = id_off_out;
@@ -238,7 +261,10 @@ int64_t run_host(Handle *h, const char *text, const int64_t *doc_off, int64_t nd
     if (!hip_ok(hipMemcpyAsync(dst_off, h->w_idoff.p, (size_t)(ndocs + 1) * 8, hipMemcpyDeviceToHost, s), "D2H offsets")) return BF_E_DEVICE;
     int status = 0;
     if (!hip_ok(hipMemcpyAsync(&status, h->w_misc.as<char>() + 16, 4, hipMemcpyDeviceToHost, s), "D2H status")) return BF_E_DEVICE;
+    int32_t nch0 = 0;
+    if (words && ndocs == 1 && !hip_ok(hipMemcpyAsync(&nch0, h->w_nchars.p, 4, hipMemcpyDeviceToHost, s), "D2H nchars")) return BF_E_DEVICE;
     if (!hip_ok(hipStreamSynchronize(s), "hipStreamSynchronize")) return BF_E_DEVICE;
+    h->last_nonempty = nch0 > 0;
     if (status & 2) return BF_E_INTERNAL;
     const int64_t nids = dst_off[ndocs];
     if (nids > ids_cap) return BF_E_CAPACITY;
@@ -312,6 +338,43 @@ int TextToIdsWithOffsets_wp(void *h, const char *s, int n, int32_t *ids, int *st
 { return text_to_ids_one(h, s, n, ids, max_ids, unk, 0, starts, ends); }
 int TextToIdsWithOffsets_sp(void *h, const char *s, int n, int32_t *ids, int *starts, int *ends, const int max_ids, const int unk)
 { return text_to_ids_one(h, s, n, ids, max_ids, unk, 1, starts, ends); }
+
+/* ---- TextToWords family (reference tokdll:415-614).  The lexer runs on the GPU in "words" mode (raw tokens, no charmap,
+ *      U+0000 fed as U+0020); what remains on the host is the output formatting the reference does with an ostringstream:
+ *      copy each word's bytes out of the caller's string (' ' and NUL inside a word -> '_'), join with ' ', terminate with 0. */
+int TextToWordsWithOffsetsWithModel(const char *s, int n, char *out, int *starts, int *ends, const int max_out, void *hModel)
+{
+    Handle *h = hModel ? as_handle(hModel) : default_wbd();
+    if (!h || h->m.kind != KIND_WP) return -1;
+    if (n == 0) return 0;                                                      // tokdll:447-449
+    if (n < 0 || n > 1000000000 || !s) return -1;                              // tokdll:450-455
+    if (starts && max_out > 0) memset(starts, 0, sizeof(int) * (size_t)max_out);   // tokdll:469-474
+    if (ends && max_out > 0) memset(ends, 0, sizeof(int) * (size_t)max_out);
+    std::vector<int32_t> tags((size_t)n + 1), ws((size_t)n + 1), we((size_t)n + 1);
+    const int64_t off[2] = {0, n};
+    int64_t id_off[2] = {0, 0};
+    const int64_t w = run_host(h, s, off, 1, tags.data(), n + 1, id_off, 0x7fffffff, 0, ws.data(), we.data(), true);
+    if (w < 0) { fprintf(stderr, "[blingfire_amd] TextToWords failed (%lld): %s\n", (long long)w, g_last_error.c_str()); return -1; }
+    if (w == 0 && !h->last_nonempty) return -1;                                // invalid UTF-8 / nothing decoded (tokdll:477-480)
+    std::string os;
+    os.reserve((size_t)n + (size_t)w + 1);
+    for (int64_t k = 0; k < w; ++k) {
+        if (k) os.push_back(' ');
+        for (int q = ws[(size_t)k]; q <= we[(size_t)k]; ++q) { const char c = s[q]; os.push_back((c == ' ' || c == 0) ? '_' : c); }
+        if (starts && k < max_out) starts[k] = ws[(size_t)k];
+        if (ends && k < max_out) ends[k] = we[(size_t)k];
+    }
+    os.push_back((char)0);                                                     // tokdll:555
+    const int len = (int)os.size();
+    if (len <= max_out && out) memcpy(out, os.data(), (size_t)len);
+    return len;
+}
+int TextToWordsWithOffsets(const char *s, int n, char *out, int *starts, int *ends, const int max_out)
+{ return TextToWordsWithOffsetsWithModel(s, n, out, starts, ends, max_out, nullptr); }
+int TextToWordsWithModel(const char *s, int n, char *out, const int max_out, void *hModel)
+{ return TextToWordsWithOffsetsWithModel(s, n, out, nullptr, nullptr, max_out, hModel); }
+int TextToWords(const char *s, int n, char *out, const int max_out)
+{ return TextToWordsWithOffsetsWithModel(s, n, out, nullptr, nullptr, max_out, nullptr); }
 
 int SetNoDummyPrefix(void *p, int flag)
 {

@@ -40,6 +40,7 @@ struct WpLexParams {
     int *status;
     int ev_thresh, fetch_thresh;  // vote thresholds of the divergence-aware driver
     int acts_n;                   // ints in L.acts (staged in LDS when small)
+    int words;                    // TextToWords mode (bf_lex.h LexLane::words)
     unsigned long long *stats;    // optional instrumentation counters (experiments), else nullptr
 };
 

@@ -101,6 +101,7 @@ struct LexLane {
     int a_idx, a_end, to2, fn_once, fp_r, fn_from;                // action being executed in it
     uint32_t state, finfo; int j, bound, fp;                      // current walk (finfo: action info of the deepest final state)
     bool stop;                                                    // nothing can change any more
+    bool words;                                                   // TextToWords mode: raw <tag,from,to> tokens instead of the _wp post-pass
 
     BF_HD LexLane(const LexTables &L_, ClsAt &c, IdOut &o, Frames &f) : L(L_), cls_at(c), ids(o), frames(f) {}
 
@@ -133,11 +134,12 @@ struct LexLane {
     }
 
     // Start a document of n normalised characters.  Follow with prepare().
-    BF_HD void init(int n, int max_ids_, int unk_)
+    BF_HD void init(int n, int max_ids_, int unk_, bool words_ = false)
     {
-        max_ids = max_ids_; unk = unk_;
+        max_ids = max_ids_; unk = unk_; words = words_;
         out_count = 0; scanning = 0; tok_from = tok_to = expected = nsub = word_out = 0;
-        max_triples = 2 * n;               // WbdRes holds 6*BuffSize ints = 2*BuffSize triples (tokdll:1194)
+        // WbdRes holds 6*BuffSize ints = 2*BuffSize triples for TextToIds (tokdll:1194), 3*BuffSize ints for TextToWords (tokdll:494-499)
+        max_triples = words_ ? n : 2 * n;
         emitted = 0; last_to = 0; d = 0;
         ini = L.initial; off = 0; fn_ = n; from = -1; once = 0;
         a_idx = a_end = 0; to2 = 0; fn_once = 0; fp_r = 0; fn_from = 0;
@@ -253,7 +255,9 @@ struct LexLane {
         if (tag != 0) {
             if (emitted >= max_triples) { stop = true; return; }      // output buffer full (FALexTools_t.h:337-340)
             ++emitted; last_to = to2 + off;
-            if (!sink_push(tag, from2 + off, to2 + off)) { stop = true; return; }   // id array full (tokdll:1308-1310)
+            if (words) {                                              // every non-IGNORE token is a word (tokdll:511-517)
+                if (tag != WBD_IGNORE_TAG && out_count < max_ids) { ids.put(out_count, tag); ids.span(out_count, from2 + off, to2 + off); ++out_count; }
+            } else if (!sink_push(tag, from2 + off, to2 + off)) { stop = true; return; }   // id array full (tokdll:1308-1310)
         }
         fn_from = from2;                                              // FALexTools_t.h:347
         after_action();
@@ -283,7 +287,7 @@ struct LexLane {
 
     BF_HD int finish()
     {
-        if (scanning) sink_finalize_word();
+        if (scanning && !words) sink_finalize_word();
         ids.finish(out_count);
         return out_count;
     }
@@ -291,10 +295,10 @@ struct LexLane {
 
 // Sequential driver (host emulation).  Returns the number of ids written (<= max_ids).
 template <bool HAS_ANY, class ClsAt, class IdOut, class Frames>
-BF_HD int lex_doc_t(const LexTables &L, ClsAt &cls_at, int n, IdOut &out, int max_ids, int unk, Frames &frames)
+BF_HD int lex_doc_t(const LexTables &L, ClsAt &cls_at, int n, IdOut &out, int max_ids, int unk, Frames &frames, bool words = false)
 {
     LexLane<ClsAt, IdOut, Frames, HAS_ANY> lane(L, cls_at, out, frames);
-    lane.init(n, max_ids, unk);
+    lane.init(n, max_ids, unk, words);
     while (lane.prepare()) {
         while (lane.step_r()) {}
         lane.after_walk();
@@ -303,10 +307,10 @@ BF_HD int lex_doc_t(const LexTables &L, ClsAt &cls_at, int n, IdOut &out, int ma
 }
 
 template <class ClsAt, class IdOut, class Frames>
-BF_HD int lex_doc(const LexTables &L, ClsAt &cls_at, int n, IdOut &out, int max_ids, int unk, Frames &frames)
+BF_HD int lex_doc(const LexTables &L, ClsAt &cls_at, int n, IdOut &out, int max_ids, int unk, Frames &frames, bool words = false)
 {
-    return L.cls_any != LX_CLS_NONE ? lex_doc_t<true>(L, cls_at, n, out, max_ids, unk, frames)
-                                    : lex_doc_t<false>(L, cls_at, n, out, max_ids, unk, frames);
+    return L.cls_any != LX_CLS_NONE ? lex_doc_t<true>(L, cls_at, n, out, max_ids, unk, frames, words)
+                                    : lex_doc_t<false>(L, cls_at, n, out, max_ids, unk, frames, words);
 }
 
 } // namespace bfa

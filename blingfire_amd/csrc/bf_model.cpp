@@ -627,7 +627,10 @@ bool build_model(Model &m, const uint8_t *img, size_t size)
             FixedMap cm;
             if (charmap_dump >= 0) { if (!cm.set(dump(charmap_dump))) return fail(m, "bad charmap"); m.wbd_has_charmap = true; }
             m.wbd_cpmap.init(CLS_NONE);
+            m.words_cpmap.init(CLS_NONE);
             for (int cp = 0; cp <= 0x10FFFF; ++cp) {
+                { const int wcp = cp == 0 ? 0x20 : cp;                          // tokdll:482, then FALexTools_t.h:258-261
+                  const uint32_t k = cls_sym(wcp < IW_EPSILON ? IW_EPSILON : wcp); if (k != CLS_NONE) m.words_cpmap.set(cp, k); }
                 int norm[10]; int c = cm.set_ ? cm.get(cp, norm, 10) : -1;
                 auto cls_text = [&](int o) -> uint32_t { return cls_sym(o < IW_EPSILON ? IW_EPSILON : o); };
                 if (c == -1) { uint32_t k = cls_text(cp); if (k != CLS_NONE) m.wbd_cpmap.set(cp, k); }

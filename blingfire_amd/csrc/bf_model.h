@@ -109,6 +109,8 @@ struct Model {
     TwoLevelMap wbd_cpmap;
     std::vector<uint16_t> wbd_multi_pool;   // [count, cls0, cls1 ...] records for 1:n / deleted chars
     bool wbd_has_charmap = false, wbd_charmap_multi = false;
+    // TextToWords view of the same lexer (tokdll:415-566): NO charmap, U+0000 is fed as U+0020 -> plain code point -> class map
+    TwoLevelMap words_cpmap;
 
     // ---- [pos-dict] segmenters (reference FADictConfKeeper.cpp:57-228)
     bool has_seg = false;

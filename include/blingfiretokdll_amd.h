@@ -62,6 +62,18 @@ int TextToIdsWithOffsets_wp(void *ModelPtr, const char *pInUtf8Str, int InUtf8St
 int TextToIdsWithOffsets_sp(void *ModelPtr, const char *pInUtf8Str, int InUtf8StrByteCount, int32_t *pIdsArr,
                             int *pStartOffsets, int *pEndOffsets, const int MaxIdsArrLength, const int UnkId);
 
+/* reference tokdll:610-614, 585-591, 569-575, 415-566: splits text into words with a lexer model (hModel == NULL: the built-in
+ * wbd.bin, embedded like the reference embeds it).  Output = words joined by ' ' (inner spaces -> '_') + terminating 0; returns
+ * the byte count needed (terminator included; copied only if it fits), 0 for empty input, -1 on error (invalid UTF-8, ...).
+ * pStartOffsets / pEndOffsets (MaxOutUtf8StrByteCount entries each, may be NULL) receive the byte span of every word.
+ * The tokenisation runs on the GPU; only the output string is assembled on the host. */
+int TextToWords(const char *pInUtf8Str, int InUtf8StrByteCount, char *pOutUtf8Str, const int MaxOutUtf8StrByteCount);
+int TextToWordsWithModel(const char *pInUtf8Str, int InUtf8StrByteCount, char *pOutUtf8Str, const int MaxOutUtf8StrByteCount, void *hModel);
+int TextToWordsWithOffsets(const char *pInUtf8Str, int InUtf8StrByteCount, char *pOutUtf8Str, int *pStartOffsets, int *pEndOffsets,
+                           const int MaxOutUtf8StrByteCount);
+int TextToWordsWithOffsetsWithModel(const char *pInUtf8Str, int InUtf8StrByteCount, char *pOutUtf8Str, int *pStartOffsets,
+                                    int *pEndOffsets, const int MaxOutUtf8StrByteCount, void *hModel);
+
 /* reference tokdll:1669-1679 */
 int SetNoDummyPrefix(void *ModelPtr, int fNoDummyPrefix);
 

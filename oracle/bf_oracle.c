@@ -1031,6 +1031,54 @@ int bfo_text_to_ids_with_offsets(const bfo_model *m, const char *utf8, int n, in
     return text_to_ids_sp(m, utf8, n, ids, starts, ends, max_ids, unk);
 }
 
+/* tokdll:415-566 TextToWordsWithOffsetsWithModel: the lexer of the model (NO charmap, U+0000 -> U+0020), every
+ * non-IGNORE token re-encoded as UTF-8 with inner ' ' -> '_', joined by ' ', terminated by 0.  Returns the byte
+ * count needed (terminator included), -1 on error, 0 for empty input; copies only if it fits. */
+int bfo_text_to_words_with_offsets(const bfo_model *m, const char *s, int n, char *out, int *starts, int *ends, int max_out)
+{
+    int *buf, *offs, *res, len, res_size, i, words = 0, added = 0, pos = 0;
+    char *tmp;
+    if (!m || !m->has_wbd) return -1;
+    if (n == 0) return 0;
+    if (n < 0 || n > MAX_ARR_SIZE || !s) return -1;
+    buf = (int *)malloc(sizeof(int) * (size_t)n);
+    offs = (int *)malloc(sizeof(int) * (size_t)n);
+    if (starts) memset(starts, 0, sizeof(int) * (size_t)(max_out > 0 ? max_out : 0));   /* tokdll:469-474 */
+    if (ends) memset(ends, 0, sizeof(int) * (size_t)(max_out > 0 ? max_out : 0));
+    len = utf8_to_utf32_off(s, n, buf, offs, n);
+    if (len <= 0 || len > n) { free(buf); free(offs); return -1; }
+    for (i = 0; i < len; ++i) if (buf[i] == 0) buf[i] = 0x20;                           /* tokdll:482 */
+    res = (int *)calloc((size_t)len * 3 + 8, sizeof(int));
+    res_size = bfo_lex_process(m, buf, len, res, len * 3);
+    if (res_size > len * 3 || res_size % 3 != 0 || res_size < 0) { free(buf); free(offs); free(res); return -1; }
+    {   /* tokens may overlap (a token and the sub-tokens a _call produced from it): size the buffer from the triples */
+        size_t need = 2;
+        for (i = 0; i < res_size; i += 3) if (res[i] != WBD_IGNORE_TAG && res[i + 2] >= res[i + 1]) need += 4 * (size_t)(res[i + 2] - res[i + 1] + 1) + 1;
+        tmp = (char *)malloc(need);
+    }
+    for (i = 0; i < res_size; i += 3) {
+        int from, to, k;
+        if (res[i] == WBD_IGNORE_TAG) continue;
+        from = res[i + 1]; to = res[i + 2];
+        if (starts && words < max_out) starts[words] = offs[from];
+        if (ends && words < max_out) { int sz = utf8_size_at(s + offs[to]); ends[words] = offs[to] + (0 < sz ? sz - 1 : 0); }
+        words++;
+        if (added) tmp[pos++] = ' ';
+        for (k = from; k <= to; ++k) {                                                  /* FAArrayToStrUtf8 cl/src/FAUtf8Utils.cpp:530-557 */
+            unsigned c = (unsigned)buf[k];
+            if (c < 0x80) tmp[pos++] = (char)(c == ' ' ? '_' : c);                      /* tokdll:543 */
+            else if (c < 0x800) { tmp[pos++] = (char)(0xC0 | (c >> 6)); tmp[pos++] = (char)(0x80 | (c & 0x3F)); }
+            else if (c < 0x10000) { tmp[pos++] = (char)(0xE0 | (c >> 12)); tmp[pos++] = (char)(0x80 | ((c >> 6) & 0x3F)); tmp[pos++] = (char)(0x80 | (c & 0x3F)); }
+            else { tmp[pos++] = (char)(0xF0 | (c >> 18)); tmp[pos++] = (char)(0x80 | ((c >> 12) & 0x3F)); tmp[pos++] = (char)(0x80 | ((c >> 6) & 0x3F)); tmp[pos++] = (char)(0x80 | (c & 0x3F)); }
+        }
+        added = 1;
+    }
+    tmp[pos++] = 0;
+    if (pos <= max_out && out) memcpy(out, tmp, (size_t)pos);
+    free(buf); free(offs); free(res); free(tmp);
+    return pos;
+}
+
 /* ---------------- exported building blocks ---------------- */
 
 static const dfa_t *pick(const bfo_model *m, int which) { return which ? &m->dict_dfa : &m->wbd_dfa; }

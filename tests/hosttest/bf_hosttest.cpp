@@ -245,6 +245,47 @@ int bft_emu_text_to_ids(void *hv, const char *s, int n, int32_t *ids, int max_id
     return emu_sp(m, s, n, ids, nullptr, nullptr, max_ids, unk);
 }
 
+// TextToWords on the host: words-mode lane program on the unfused class map + the output formatting of the product
+int bft_emu_text_to_words(void *hv, const char *s, int n, char *out, int32_t *starts, int32_t *ends, int max_out)
+{
+    Model &m = ((Handle *)hv)->m;
+    if (!m.error.empty() || m.kind != KIND_WP) return -1;
+    if (n == 0) return 0;
+    if (n < 0 || !s) return -1;
+    if (starts && max_out > 0) memset(starts, 0, sizeof(int32_t) * (size_t)max_out);
+    if (ends && max_out > 0) memset(ends, 0, sizeof(int32_t) * (size_t)max_out);
+    std::vector<int> cps((size_t)n);
+    const int len = bfo_utf8_to_utf32(s, n, cps.data(), n);
+    if (len <= 0) return -1;
+    std::vector<uint16_t> cls; std::vector<int> boff;
+    { int p = (n >= 3 && (unsigned char)s[0] == 0xEF && (unsigned char)s[1] == 0xBB && (unsigned char)s[2] == 0xBF) ? 3 : 0;
+      for (int i = 0; i < len; ++i) { boff.push_back(p); int c = cps[(size_t)i]; p += c < 0x80 ? 1 : c < 0x800 ? 2 : c < 0x10000 ? 3 : 4; cls.push_back((uint16_t)m.words_cpmap.get(c)); } }
+    LexTables L;
+    L.T = m.wbd_t2.data(); L.acts = m.acts_pool.data(); L.initial = m.wbd.initial_base; L.cls_any = m.cls_any; L.cls_l = m.cls_l; L.cls_r = m.cls_r;
+    L.max_depth = m.max_depth; L.max_token_length = m.max_token_length; L.max_frames = m.lex_frames;
+    struct HostCls { const uint16_t *cp; uint32_t operator()(int i) const { return cp[i]; } void prefetch(int) const {} };
+    HostCls cls_at{cls.data()};
+    std::vector<int32_t> tags((size_t)len + 1), spans(2 * (size_t)len + 2);
+    IdOutDirect o{tags.data(), spans.data()};
+    FramesArray frames;
+    const int w = lex_doc(L, cls_at, len, o, len, 0, frames, true);
+    std::string os;
+    for (int k = 0; k < w; ++k) {
+        const int f = spans[2 * (size_t)k], t = spans[2 * (size_t)k + 1];
+        const int so = boff[(size_t)f], eo0 = boff[(size_t)t];
+        const unsigned char b = (unsigned char)s[eo0];
+        const int sz = (b & 0x80) == 0 ? 1 : (b & 0xE0) == 0xC0 ? 2 : (b & 0xF0) == 0xE0 ? 3 : (b & 0xF8) == 0xF0 ? 4 : 0;
+        const int eo = eo0 + (sz > 0 ? sz - 1 : 0);
+        if (k) os.push_back(' ');
+        for (int q = so; q <= eo; ++q) os.push_back((s[q] == ' ' || s[q] == 0) ? '_' : s[q]);
+        if (starts && k < max_out) starts[k] = so;
+        if (ends && k < max_out) ends[k] = eo;
+    }
+    os.push_back((char)0);
+    if ((int)os.size() <= max_out && out) memcpy(out, os.data(), os.size());
+    return (int)os.size();
+}
+
 // offsets form: the lane programs report stream positions, the source-offset stream maps them to bytes and the end
 // offset adds the UTF-8 size of the last character (tokdll:1263-1273,1519-1529) -- what k_compact does on the GPU
 int bft_emu_text_to_ids_with_offsets(void *hv, const char *s, int n, int32_t *ids, int32_t *starts, int32_t *ends, int max_ids, int unk)

@@ -1,0 +1,139 @@
+"""TextToWords family (reference tokdll:415-614; BASELINE.json configs[0] is its CPU-only case).  CPU tests pin the oracle's
+restatement to the compiled reference and run the words-mode lane program on the host; the GPU test calls the product's
+TextToWords* exports (lexer on the GPU, built-in wbd.bin embedded like the reference's)."""
+import ctypes
+
+import pytest
+
+import bfutil
+
+WORD_MODELS = ["wbd.bin", "wbd_chuni.bin", "bert_base_cased_tok.bin", "bert_chinese.bin"]
+
+
+def _docs(n, seed):
+    return list(bfutil.ADVERSARIAL) + bfutil.fuzz_docs(n, seed=seed) + [b"Hello world . This is a test ."]
+
+
+def _call(fn, args_before, b, mx, args_after=()):
+    o = ctypes.create_string_buffer(b"\x7f" * (max(mx, 1) + 4))
+    s = (ctypes.c_int32 * max(mx, 1))(*([-7] * max(mx, 1)))
+    e = (ctypes.c_int32 * max(mx, 1))(*([-7] * max(mx, 1)))
+    r = fn(*args_before, b, len(b), o, s, e, mx, *args_after)
+    return r, o.raw, list(s), list(e)
+
+
+def _oracle_fn():
+    ora = bfutil.oracle()
+    f = ora.lib.bfo_text_to_words_with_offsets
+    f.restype = ctypes.c_int
+    f.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+    return ora, f
+
+
+def test_readme_known_answer():
+    """reference README.md:64-75: text_to_words on the built-in model"""
+    ora, f = _oracle_fn()
+    h = ora.load(bfutil.model_path("wbd.bin"))
+    s = "After reading this post, you will know: What \"natural language\" is and how it is different from other types of data.".encode()
+    r, out, _, _ = _call(f, (ctypes.c_void_p(h),), s, 4 * len(s))
+    assert out[:r - 1].decode() == ("After reading this post , you will know : What \" natural language \" is and how it is different from other "
+                                    "types of data .")
+    ora.free(h)
+
+
+@pytest.mark.skipif(not bfutil.have_ref(), reason="oracle/_ref not built (needs /root/reference)")
+@pytest.mark.parametrize("model", WORD_MODELS + [None])
+def test_oracle_words_vs_live_reference(model):
+    ora, f = _oracle_fn()
+    ref = bfutil.reference()
+    g = ref.lib.TextToWordsWithOffsetsWithModel
+    g.restype = ctypes.c_int
+    g.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+    ho = ora.load(bfutil.model_path(model or "wbd.bin"))
+    hr = ref.load(bfutil.model_path(model)) if model else None      # None = the reference's built-in model
+    for k, b in enumerate(_docs(1500, 61)):
+        mx = (4 * len(b) + 8, 5, 0)[k % 3]
+        assert _call(f, (ctypes.c_void_p(ho),), b, mx) == _call(g, (), b, mx, (ctypes.c_void_p(hr) if hr else None,)), (model, b[:60], mx)
+    ora.free(ho)
+
+
+@pytest.mark.parametrize("model", WORD_MODELS)
+def test_words_lane_program_on_host_matches_oracle(model):
+    ora, f = _oracle_fn()
+    L = ctypes.CDLL(bfutil.HOSTTEST_LIB)
+    L.bft_load.restype = ctypes.c_void_p
+    L.bft_load.argtypes = [ctypes.c_char_p]
+    g = L.bft_emu_text_to_words
+    g.restype = ctypes.c_int
+    g.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+    h = L.bft_load(bfutil.model_path(model).encode())
+    ho = ora.load(bfutil.model_path(model))
+    for k, b in enumerate(_docs(3000, 67)):
+        mx = (4 * len(b) + 8, 5, 0)[k % 3]
+        assert _call(g, (ctypes.c_void_p(h),), b, mx) == _call(f, (ctypes.c_void_p(ho),), b, mx), (model, b[:60], mx)
+    ora.free(ho)
+
+
+def test_config1_reference_cpu_case():
+    """BASELINE.json configs[0]: default pattern tokenizer on 10k short English lines, CPU reference path only -- the oracle
+    (and the compiled reference when present) agree on a deterministic 10k-line corpus (~43 bytes per line)."""
+    ora, f = _oracle_fn()
+    ho = ora.load(bfutil.model_path("wbd.bin"))
+    text, off = bfutil.gen_corpus(10000, seed=1, mean=43, sd=12, minlen=8, maxlen=120)
+    raw = text.tobytes()
+    ref = bfutil.reference() if bfutil.have_ref() else None
+    if ref:
+        g = ref.lib.TextToWordsWithOffsetsWithModel
+        g.restype = ctypes.c_int
+        g.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+    nwords = 0
+    for d in range(10000):
+        b = raw[off[d]:off[d + 1]]
+        a = _call(f, (ctypes.c_void_p(ho),), b, 4 * len(b) + 8)
+        nwords += a[1][:a[0]].count(b" ") + 1
+        if ref:
+            assert a == _call(g, (), b, 4 * len(b) + 8, (None,))
+    assert nwords > 50000
+    ora.free(ho)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("model", WORD_MODELS + [None])
+def test_gpu_text_to_words(model):
+    import blingfire_amd as bf
+    L = bf.lib()
+    g = L.TextToWordsWithOffsetsWithModel
+    g.restype = ctypes.c_int
+    g.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+    ora, f = _oracle_fn()
+    ho = ora.load(bfutil.model_path(model or "wbd.bin"))
+    h = bf.load_model(bfutil.model_path(model)) if model else None
+    try:
+        for k, b in enumerate(_docs(400, 71)):
+            mx = (4 * len(b) + 8, 5, 0)[k % 3]
+            assert _call(g, (), b, mx, (ctypes.c_void_p(h) if h else None,)) == _call(f, (ctypes.c_void_p(ho),), b, mx), (model, b[:60], mx)
+        if model is None:
+            L.TextToWords.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int]
+            o = ctypes.create_string_buffer(256)
+            s = b"Hello, world! It's 3.14."
+            r = L.TextToWords(s, len(s), o, 256)
+            assert o.raw[:r - 1] == b"Hello , world ! It 's 3.14 ."
+    finally:
+        if h:
+            bf.free_model(h)
+        ora.free(ho)
+
+
+@pytest.mark.gpu
+def test_gpu_python_mirror_words():
+    """reference README.md:64-75 and dist-pypi/blingfire/__init__.py:222 semantics through the Python mirror"""
+    import blingfire_amd as bf
+    s = "Hello, wörld! It's 3.14."
+    assert bf.text_to_words(s) == "Hello , wörld ! It 's 3.14 ."
+    words, spans = bf.text_to_words_with_offsets(s)
+    assert [s[b:e] for b, e in spans] == words.split(" ")
+    h = bf.load_model(bfutil.model_path("bert_base_cased_tok.bin"))
+    try:
+        assert bf.text_to_words_with_model(h, "unaffable!") == "unaffable un af fa ble ! !"   # word and sub-word tokens both reported
+    finally:
+        bf.free_model(h)
