@@ -117,7 +117,7 @@ __global__ __launch_bounds__(256) void k_prep_wp(WpPrepParams p)
                 if (err) cp = 0;
             }
             if (__any(err)) bad = true;
-            uint32_t v = 0xFFFFu; int w = 0;
+            uint32_t v = LX_CLS_NONE; int w = 0;
             if (start && !err) {
                 v = cpmap_get(p.cpmap, cp);
                 w = (v & 0x80000000u) ? (int)p.multi_pool[v & 0x7FFFFFFFu] : 1;
@@ -171,9 +171,37 @@ struct ClsWin {
     {
         const int a = i + shift, t = a >> 3;
         if (t != tag) { w = cls16[blk0 + t]; tag = t; }
-        const uint32_t lo = (a & 2) ? w.y : w.x, hi = (a & 2) ? w.w : w.z;
-        const uint32_t dw = (a & 4) ? hi : lo;
-        return (a & 1) ? (dw >> 16) : (dw & 0xFFFFu);
+        // element a & 7 of the window: pick the 8-byte half, then one v_perm_b32 extracts the 16-bit class
+        // (selector bytes 2k, 2k+1 of the pair; 0x0c = constant zero)
+        const bool up = (a & 4) != 0;
+        const uint32_t d0 = up ? w.z : w.x, d1 = up ? w.w : w.y;
+        return __builtin_amdgcn_perm(d1, d0, 0x0c0c0100u + 0x0202u * (uint32_t)(a & 3));
+    }
+    // refill for position i if it lies outside the window (issued early by LexLane::step(); not waited for here)
+    __device__ __forceinline__ void prefetch(int i)
+    {
+        const int t = (i + shift) >> 3;
+        if (t != tag) { w = cls16[blk0 + t]; tag = t; }
+    }
+};
+
+// 8-byte window (4 characters per refill): cheaper extraction, twice the refills
+struct ClsWin8 {
+    const uint2 *cls8; int64_t blk0; int shift; uint2 w; int tag;
+    __device__ __forceinline__ void init(const uint16_t *cls_buf, int64_t elem_off)
+    {
+        cls8 = (const uint2 *)cls_buf; blk0 = elem_off >> 2; shift = (int)(elem_off & 3); tag = -1; w = make_uint2(0, 0);
+    }
+    __device__ __forceinline__ uint32_t operator()(int i)
+    {
+        const int a = i + shift, t = a >> 2;
+        if (t != tag) { w = cls8[blk0 + t]; tag = t; }
+        return __builtin_amdgcn_perm(w.y, w.x, 0x0c0c0100u + 0x0202u * (uint32_t)(a & 3));
+    }
+    __device__ __forceinline__ void prefetch(int i)
+    {
+        const int t = (i + shift) >> 2;
+        if (t != tag) { w = cls8[blk0 + t]; tag = t; }
     }
 };
 
@@ -195,6 +223,7 @@ struct ClsWin32 {
         const uint32_t dw = (a & 8) ? d1 : d0;
         return (a & 1) ? (dw >> 16) : (dw & 0xFFFFu);
     }
+    __device__ __forceinline__ void prefetch(int) {}
 };
 
 // saved frames in LDS, structure-of-arrays (bank = lane): word (d, field) of lane t at [(d*12 + field) * nthreads + t]
@@ -297,17 +326,19 @@ __global__ __launch_bounds__(THREADS) void k_lex_wp_flat(WpLexParams p)
     unsigned long long tk_walk = 0, tk_event = 0, tk_fetch = 0, tk0 = 0;
     for (;;) {
         if (STATS) tk0 = __builtin_readcyclecounter();
-        // ---- walk: every lane in WALK mode makes one DFA transition per trip, until enough lanes have a
-        //      finished walk (or nobody walks any more)
-        unsigned long long m_event;
-        for (;;) {
-            if (STATS) { st_trips += UNROLL; st_walk_lanes += UNROLL * __popcll(__ballot(mode == M_WALK)); st_need_lanes += UNROLL * __popcll(__ballot(mode == M_NEED)); }
+        // ---- walk: every walking lane makes UNROLL DFA transitions per trip, until enough lanes have a finished
+        //      walk (or nobody walks any more).  `walk` lives in a scalar lane mask: the loop control costs no VALU.
+        bool walk = mode == M_WALK;
+        const unsigned long long m_entry = __ballot(walk);
+        unsigned long long m_walk = m_entry;
+        while (m_walk != 0 && __popcll(m_entry & ~m_walk) < ev_thresh) {
+            if (STATS) { st_trips += UNROLL; st_walk_lanes += UNROLL * __popcll(m_walk); st_need_lanes += UNROLL * __popcll(__ballot(mode == M_NEED)); }
 #pragma unroll
-            for (int u = 0; u < UNROLL; ++u) { if (mode == M_WALK) { if (!lane.step_r()) mode = M_EVENT; } }
-            const unsigned long long m_walk = __ballot(mode == M_WALK);
-            m_event = __ballot(mode == M_EVENT);
-            if (m_walk == 0 || __popcll(m_event) >= ev_thresh) break;
+            for (int u = 0; u < UNROLL; ++u) { if (walk) walk = lane.step_r(); }
+            m_walk = __ballot(walk);
         }
+        if (mode == M_WALK && !walk) mode = M_EVENT;
+        const unsigned long long m_event = m_entry & ~m_walk;
         if (STATS) { st_ev_rounds += 1; st_ev_lanes += __popcll(m_event); const unsigned long long t1 = __builtin_readcyclecounter(); tk_walk += t1 - tk0; tk0 = t1; }
         // ---- events: match handling, calls / returns, next start position
         if (mode == M_EVENT) {

@@ -17,6 +17,7 @@
 // never executes it on the CPU).
 #pragma once
 #include <stdint.h>
+#include "bf_layout.h"
 
 #if defined(__HIPCC__)
 #define BF_HD __host__ __device__ __forceinline__
@@ -27,16 +28,13 @@
 namespace bfa {
 
 constexpr int LEX_MAX_DEPTH = 4;          // frames; LoadModel refuses lexers with a deeper max-depth
-constexpr uint32_t LX_CLS_NONE = 0xFFFFu; // class-stream value: code point not in the alphabet
-constexpr uint32_t LX_T_CLS_MASK = 0x1FFFu, LX_T_FINAL = 1u << 13;
-constexpr int LX_T_NEXT_SHIFT = 14;
 constexpr uint32_t LX_INFO_SIMPLE = 0x80000000u;
-constexpr uint32_t LX_MISS = 0xFFFFFFFFu;
 constexpr int WBD_WORD_TAG = 1, WBD_IGNORE_TAG = 4;   // reference tokdll:39-40
 
 struct LexTables {
-    const uint64_t *T;        // displacement-packed transitions: low word = bf_model.h T32 entry, high word = action
-                              // info of the destination state when it is final (so a match needs no second gather)
+    const uint64_t *T;        // displacement-packed transitions: low word = bf_layout.h entry, high word = action info of
+                              // the destination state when it is final (so a match needs no second gather; a 4-byte
+                              // table + an info gather per match measured 5 % slower on MI355X)
     const int32_t *acts;      // general action records [left,right,tag,nfn,(fn,ini)*]
     uint32_t initial;
     uint32_t cls_any, cls_l, cls_r;   // LX_CLS_NONE when the symbol is not in the alphabet
@@ -44,25 +42,36 @@ struct LexTables {
     int max_frames;           // saved frames the call graph can need (= call depth - 1, computed at load; <= LEX_MAX_DEPTH - 1)
 };
 
-// one DFA transition: returns the table entry (low word LX_MISS on a miss).  Branch-free: a class outside the
-// alphabet (LX_CLS_NONE) probes slot state + 0x1FFF, whose stored class can never equal it (the table is padded
-// by 0x2000 entries past the largest base, bf_model.cpp).
-BF_HD uint64_t lx_lookup(const LexTables &L, uint32_t state, uint32_t cls)
-{
-    const uint32_t idx = state + (cls < LX_T_CLS_MASK ? cls : LX_T_CLS_MASK);
-    const uint64_t e = L.T[idx];
+// where table entries come from: a policy, so that the host build can count lookups per table index
+// (tools/lookup_profile.py).  An LDS-resident table prefix behind this policy was measured on MI355X (89 % of the
+// lookups served from LDS, one 1024-thread block per CU) and was slower: see DESIGN.md section 5.
+struct TabDirect {
+    const uint64_t *T;
+    BF_HD uint64_t operator()(uint32_t idx) const
+    {
 #ifdef BF_LEX_PROFILE_HOOK
-    BF_LEX_PROFILE_HOOK(idx);
+        BF_LEX_PROFILE_HOOK(idx);                  // host-only instrumentation (tools/lookup_profile.py)
 #endif
-    return ((uint32_t)e & LX_T_CLS_MASK) == cls ? e : (uint64_t)LX_MISS;
+        return T[idx];
+    }
+};
+
+// one DFA transition: the table entry + whether it is a hit.  Branch-free and unclamped: the table is padded by
+// 0x2000 entries past the largest base (bf_model.cpp) and cls <= LX_CLS_NONE.
+template <class Tab>
+BF_HD uint64_t lx_lookup(const Tab &tab, uint32_t state, uint32_t cls, bool &hit)
+{
+    const uint64_t e = tab(state + cls);
+    hit = ((uint32_t)e & LX_T_CLS_MASK) == cls;
+    return e;
 }
 // GetDest(State, Iw) with the IW_ANY retry of FALexTools_t.h:265-270.  HAS_ANY is a compile-time fact of the
 // model (IW_ANY is in the alphabet or not) so that models without it pay nothing for the retry.
-template <bool HAS_ANY>
-BF_HD uint64_t lx_dest(const LexTables &L, uint32_t state, uint32_t cls)
+template <bool HAS_ANY, class Tab>
+BF_HD uint64_t lx_dest(const Tab &tab, uint32_t cls_any, uint32_t state, uint32_t cls, bool &hit)
 {
-    uint64_t e = lx_lookup(L, state, cls);
-    if (HAS_ANY) { if ((uint32_t)e == LX_MISS) e = lx_lookup(L, state, L.cls_any); }
+    uint64_t e = lx_lookup(tab, state, cls, hit);
+    if (HAS_ANY) { if (!hit) e = lx_lookup(tab, state, cls_any, hit); }
     return e;
 }
 
@@ -79,9 +88,6 @@ struct LexFrame {      // caller state saved across a _call (FALexTools_t.h:350-
     uint32_t ini; int off, n, from, once, a_idx, a_end, to2, fn_once, fp_r, fn_from, emit_mark;
 };
 constexpr int LEX_FRAME_WORDS = 12;
-#ifndef LEX_SKIP_DEAD_STARTS
-#define LEX_SKIP_DEAD_STARTS 0
-#endif
 
 struct FramesArray {   // host emulation only (a dynamically indexed private struct array mis-executed on the device)
     LexFrame st[LEX_MAX_DEPTH - 1];
@@ -89,9 +95,9 @@ struct FramesArray {   // host emulation only (a dynamically indexed private str
     BF_HD void load(int d, LexFrame &f) const { f = st[d]; }
 };
 
-template <class ClsAt, class IdOut, class Frames, bool HAS_ANY>
+template <class ClsAt, class IdOut, class Frames, bool HAS_ANY, class Tab = TabDirect>
 struct LexLane {
-    const LexTables &L; ClsAt &cls_at; IdOut &ids; Frames &frames;
+    const LexTables &L; ClsAt &cls_at; IdOut &ids; Frames &frames; Tab tab;
     // ---- streaming _wp post-pass (tokdll:1210-1311)
     int max_ids, unk;
     int out_count, scanning, tok_from, tok_to, expected, nsub, word_out;
@@ -99,11 +105,13 @@ struct LexLane {
     int max_triples, emitted, last_to, d;
     uint32_t ini; int off, fn_, from, once;                       // current frame
     int a_idx, a_end, to2, fn_once, fp_r, fn_from;                // action being executed in it
-    uint32_t state, finfo; int j, bound, fp;                      // current walk (finfo: action info of the deepest final state)
+    uint32_t state, finfo; int j, lim, fp;                        // current walk (finfo: action info of the deepest final state;
+                                                                  // lim: the walk goes on while the next position is < lim)
     bool stop;                                                    // nothing can change any more
     bool words;                                                   // TextToWords mode: raw <tag,from,to> tokens instead of the _wp post-pass
 
-    BF_HD LexLane(const LexTables &L_, ClsAt &c, IdOut &o, Frames &f) : L(L_), cls_at(c), ids(o), frames(f) {}
+    BF_HD LexLane(const LexTables &L_, ClsAt &c, IdOut &o, Frames &f) : L(L_), cls_at(c), ids(o), frames(f), tab{L_.T} {}
+    BF_HD LexLane(const LexTables &L_, ClsAt &c, IdOut &o, Frames &f, const Tab &t) : L(L_), cls_at(c), ids(o), frames(f), tab(t) {}
 
     BF_HD void sink_finalize_word()
     {
@@ -143,7 +151,7 @@ struct LexLane {
         emitted = 0; last_to = 0; d = 0;
         ini = L.initial; off = 0; fn_ = n; from = -1; once = 0;
         a_idx = a_end = 0; to2 = 0; fn_once = 0; fp_r = 0; fn_from = 0;
-        state = finfo = 0; j = 0; bound = 0; fp = -1;
+        state = finfo = 0; j = 0; lim = 0; fp = -1;
         stop = (n <= 0 || L.max_depth < 1);
     }
 
@@ -168,57 +176,52 @@ struct LexLane {
                 continue;
             }
             // ---- set up one start position (FALexTools_t.h:229-252)
-            if (LEX_SKIP_DEAD_STARTS && from >= 0 && L.max_token_length > 0) {
-                // A start whose first letter has no transition from the frame's initial state matches nothing
-                // (the walk breaks at j == from < InSize, so no right anchor either): skip such starts here instead
-                // of spending a walk + an event on each (whitespace in the BERT models).  The first transition is
-                // taken here and the walk resumes at the second letter.
-                uint64_t e64 = LX_MISS;
-                while (from < fn_) {
-                    e64 = lx_dest<HAS_ANY>(L, ini, cls_at(off + from));
-                    if ((uint32_t)e64 != LX_MISS) break;
-                    ++from;
-                }
-                if (from >= fn_) continue;
-                const uint32_t e = (uint32_t)e64;
-                state = e >> LX_T_NEXT_SHIFT; fp = -1; finfo = 0;
-                if (e & LX_T_FINAL) { finfo = (uint32_t)(e64 >> 32); fp = from; }
-                j = from + 1;
-                bound = from + L.max_token_length; if (fn_ < bound) bound = fn_;
-                if (j < bound || j == fn_) return true;               // more letters, or the right anchor
-                after_walk();                                         // the walk already ended (token length bound 1)
-                if (stop) return false;
-                continue;
-            }
             state = ini; fp = -1; finfo = 0; j = from;
-            bound = from + L.max_token_length; if (fn_ < bound) bound = fn_;
-            if (j >= 0 && !(j < bound)) { ++from; continue; }     // MaxTokenLength == 0: no letters, j != InSize
+            set_lim(from);
+            if (j < 0) {
+                // the left anchor (from == -1, FALexTools_t.h:244-252) is fed here, so that step() only ever sees
+                // letters and the right anchor; no finality check after it
+                bool hit; const uint32_t e = (uint32_t)lx_dest<HAS_ANY>(tab, L.cls_any, ini, L.cls_l, hit);
+                if (!hit || !(0 < lim)) { ++from; continue; }         // the walk ended without a match
+                state = (e >> LX_T_NEXT_SHIFT) & LX_T_NEXT_MASK; j = 0;
+                return true;
+            }
+            if (!(j < lim)) { ++from; continue; }                 // MaxTokenLength == 0: no letters, j != InSize
             return true;
         }
     }
 
-    // Exactly one DFA transition (anchors included).  Returns true while the walk continues.
-    // Written with selects instead of branches: on the GPU this is the hot loop body and every
-    // divergent branch costs scalar instructions for the whole wave.
+    // The walk started at `f` reads letters while position < min(InSize, f + MaxTokenLength) and feeds the right
+    // anchor only when the input was exhausted (position == InSize): one bound `lim` for "next position < lim".
+    BF_HD void set_lim(int f)
+    {
+        const int b = f + L.max_token_length;
+        lim = b < fn_ ? b : fn_ + 1;
+    }
+
+    // Exactly one DFA transition on a letter or on the right anchor.  Returns true while the walk continues.
+    // Written with selects instead of branches: on the GPU this is the hot loop body (VALU-issue bound) and every
+    // divergent branch costs scalar instructions for the whole wave.  Reads position off + InSize under the right
+    // anchor (value unused): class streams carry at least one element of padding.
     BF_HD bool step()
     {
-        const bool la = j < 0, ra = j >= fn_;          // feeding the left / right anchor (FALexTools_t.h:244-252, 280-290)
-        int jj = j < 0 ? 0 : j; if (ra) jj = fn_ > 0 ? fn_ - 1 : 0;
-        uint32_t c = cls_at(off + jj);                 // a letter (FALexTools_t.h:255-277); read but unused under an anchor
-        c = la ? L.cls_l : (ra ? L.cls_r : c);
-        const uint64_t e64 = lx_dest<HAS_ANY>(L, state, c);
+        const bool ra = j >= fn_;                      // feeding the right anchor (FALexTools_t.h:280-290)
+        uint32_t c = cls_at(off + j);                  // a letter (FALexTools_t.h:255-277)
+        c = ra ? L.cls_r : c;
+        uint64_t e64 = tab(state + c);                 // the gather is issued ...
+        cls_at.prefetch(off + j + 1);                  // ... and the refill of the class window for the next letter (when it
+                                                       // crosses a block) travels with it instead of in front of the next gather
+        bool hit = ((uint32_t)e64 & LX_T_CLS_MASK) == c;
+        if (HAS_ANY) { if (!hit) e64 = lx_lookup(tab, state, L.cls_any, hit); }       // IW_ANY retry (FALexTools_t.h:265-270)
         const uint32_t e = (uint32_t)e64;
-        const bool hit = e != LX_MISS;
-        const bool fin = hit && !la && (e & LX_T_FINAL);   // no finality check after the left anchor
+        const bool fin = hit && (int32_t)e < 0;
         fp = fin ? j : fp;
         finfo = fin ? (uint32_t)(e64 >> 32) : finfo;
         const bool adv = hit && !ra;
-        state = adv ? (e >> LX_T_NEXT_SHIFT) : state;
-        const int jn = la ? 0 : j + 1;
+        state = adv ? ((e >> LX_T_NEXT_SHIFT) & LX_T_NEXT_MASK) : state;
+        const int jn = j + 1;
         j = adv ? jn : j;
-        // the walk goes on while letters remain below the length bound; the right anchor is fed only
-        // when the input was exhausted (j == InSize)
-        return adv && (jn < bound || jn == fn_);
+        return adv && jn < lim;
     }
 
     // step() that also absorbs the cheapest event: a walk that ended WITHOUT a match simply restarts at the next
@@ -230,7 +233,7 @@ struct LexLane {
         const int nf = from + 1;
         if (!cont && fp == -1 && nf < fn_ && L.max_token_length > 0) {
             from = nf; state = ini; finfo = 0; j = nf;
-            bound = nf + L.max_token_length; if (fn_ < bound) bound = fn_;
+            set_lim(nf);
             cont = true;
         }
         return cont;

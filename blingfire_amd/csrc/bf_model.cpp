@@ -1,6 +1,7 @@
 // bf_model.cpp -- see bf_model.h.  Host only (no HIP): parse the .bin, decode the automata,
 // build the displacement-packed tables and code-point maps the kernels consume.
 #include "bf_model.h"
+#include "bf_layout.h"
 
 #include <algorithm>
 #include <cstdio>
@@ -615,12 +616,16 @@ bool build_model(Model &m, const uint8_t *img, size_t size)
                 m.wbd_info[m.wbd.state_base[s]] = act_info[(size_t)ow];
             }
 
+            // device entries (bf_layout.h): low word [final:1 | next:18 | cls:13], high word = action info of a final destination
+            if (m.wbd.nclasses >= (int)LX_CLS_NONE) return fail(m, "too many symbol classes for the lexer table entry format");
             m.wbd_t2.resize(m.wbd.t32.size());
             for (size_t i = 0; i < m.wbd.t32.size(); ++i) {
                 const uint32_t e = m.wbd.t32[i];
-                uint64_t hi = 0;
-                if ((e & T32_CLS_MASK) != T32_CLS_MASK && (e & T32_FINAL_BIT)) hi = m.wbd_info[e >> T32_NEXT_SHIFT];
-                m.wbd_t2[i] = (uint64_t)e | (hi << 32);
+                if ((e & T32_CLS_MASK) == T32_CLS_MASK) { m.wbd_t2[i] = LX_T_CLS_MASK; continue; }     // empty slot
+                const uint32_t next = e >> T32_NEXT_SHIFT;
+                const bool fin = (e & T32_FINAL_BIT) != 0;
+                const uint32_t lo = (e & T32_CLS_MASK) | (next << LX_T_NEXT_SHIFT) | (fin ? LX_T_FINAL : 0u);
+                m.wbd_t2[i] = (uint64_t)lo | ((uint64_t)(fin ? m.wbd_info[next] : 0u) << 32);
             }
 
             // fused code point -> class map (charmap semantics: reference FAUtils_cl.h:311-369 + FAMultiMap_pack_fixed.cpp:67-137)

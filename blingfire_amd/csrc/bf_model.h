@@ -61,7 +61,7 @@ struct TwoLevelMap {
     uint32_t get(int cp) const { return (cp < 0 || cp > 0x10FFFF) ? def : pages[(size_t)l1[cp >> 8] * 256 + (cp & 255)]; }
 };
 
-constexpr uint32_t CLS_NONE = 0xFFFFu;        // "code point not in the alphabet" in class streams
+constexpr uint32_t CLS_NONE = 0x1FFEu;        // "code point not in the alphabet" in lexer class streams (= bf_lex.h LX_CLS_NONE)
 
 // Displacement-packed transition table.
 //  T32 entry (lexer / Moore):  [12:0] class, [13] dst-is-final, [31:14] dst base
@@ -101,7 +101,7 @@ struct Model {
     int lex_frames = 0;                // saved frames the call graph can need: min(max_depth, call depth) - 1
     RawDfa wbd_raw; PackedDfa wbd;
     std::vector<uint32_t> wbd_info;    // indexed by base: action info for final states
-    std::vector<uint64_t> wbd_t2;      // device form: low = T32 entry, high = wbd_info[destination] when the destination is final
+    std::vector<uint64_t> wbd_t2;      // device form: low = bf_layout.h entry, high = wbd_info[destination] when the destination is final
     std::vector<int32_t> acts_pool;
     uint32_t cls_any = CLS_NONE, cls_l = CLS_NONE, cls_r = CLS_NONE;
     // fused "code point -> charmap -> (cp<3 ? 3 : cp) -> class" map:

@@ -6,6 +6,10 @@
 //  * bft_emu_*: runs the per-lane device programs of bf_lex.h / bf_seg.h on the host, fed by a
 //    scalar restatement of the prep kernels, so that the lane logic can be fuzzed against the
 //    oracle on millions of documents without a GPU.
+#include <stdint.h>
+// lookup-index histogram of the lexer table (design evidence for the LDS-resident prefix, tools/lookup_profile.py)
+static unsigned long long g_lookup_hist[4096];
+#define BF_LEX_PROFILE_HOOK(idx) (g_lookup_hist[((idx) >> 8) & 4095]++)
 #include "../../blingfire_amd/csrc/bf_model.h"
 #include "../../blingfire_amd/csrc/bf_lex.h"
 #include "../../blingfire_amd/csrc/bf_seg.h"
@@ -33,6 +37,8 @@ void *bft_load(const char *path)
 }
 const char *bft_error(void *hv) { return ((Handle *)hv)->m.error.c_str(); }
 void bft_free(void *hv) { delete (Handle *)hv; }
+void bft_lookup_hist(unsigned long long *out, int n, int reset) { for (int i = 0; i < n && i < 4096; ++i) out[i] = g_lookup_hist[i]; if (reset) memset(g_lookup_hist, 0, sizeof(g_lookup_hist)); }
+long bft_table_len(void *hv) { return (long)((Handle *)hv)->m.wbd_t2.size(); }
 int bft_kind(void *hv) { return ((Handle *)hv)->m.kind; }
 
 // sizes for reports: out[0]=wbd states, [1]=wbd transitions, [2]=wbd table entries, [3]=wbd classes,
@@ -180,11 +186,13 @@ static int emu_wp(const Model &m, const char *s, int n, int32_t *ids, int32_t *s
     L.T = m.wbd_t2.data(); L.acts = m.acts_pool.data();
     L.initial = m.wbd.initial_base; L.cls_any = m.cls_any; L.cls_l = m.cls_l; L.cls_r = m.cls_r;
     L.max_depth = m.max_depth; L.max_token_length = m.max_token_length; L.max_frames = m.lex_frames;
-    const uint16_t *cp = cls.data();
-    auto cls_at = [cp](int i) -> uint32_t { return cp[i]; };
+    const int nch = (int)cls.size();
+    cls.push_back((uint16_t)CLS_NONE);        // one element of padding: step() reads (and ignores) position InSize under the right anchor
+    struct HostCls { const uint16_t *cp; uint32_t operator()(int i) const { return cp[i]; } void prefetch(int) const {} };
+    HostCls cls_at{cls.data()};
     IdOutDirect out{ids, spans};
     FramesArray frames;
-    return lex_doc(L, cls_at, (int)cls.size(), out, max_ids, unk, frames);
+    return lex_doc(L, cls_at, nch, out, max_ids, unk, frames);
 }
 
 // scalar restatement of the _sp prologue on the fused element-code map (the prep KERNEL is wave-parallel; GPU tests cover it)
@@ -264,6 +272,7 @@ int bft_emu_text_to_words(void *hv, const char *s, int n, char *out, int32_t *st
     L.T = m.wbd_t2.data(); L.acts = m.acts_pool.data(); L.initial = m.wbd.initial_base; L.cls_any = m.cls_any; L.cls_l = m.cls_l; L.cls_r = m.cls_r;
     L.max_depth = m.max_depth; L.max_token_length = m.max_token_length; L.max_frames = m.lex_frames;
     struct HostCls { const uint16_t *cp; uint32_t operator()(int i) const { return cp[i]; } void prefetch(int) const {} };
+    cls.push_back((uint16_t)CLS_NONE);        // padding (see emu_wp)
     HostCls cls_at{cls.data()};
     std::vector<int32_t> tags((size_t)len + 1), spans(2 * (size_t)len + 2);
     IdOutDirect o{tags.data(), spans.data()};
