@@ -172,7 +172,7 @@ int run_device(Handle *h, const char *d_text, const int64_t *d_doc_off, int64_t 
         (void)hipEventRecord(h->ev[EV_PREP], s);
         WpLexParams lp;
         lp.L.T = h->t_wbd.as<uint64_t>(); lp.L.acts = h->t_acts.as<int32_t>();
-        lp.L.initial = m.wbd.initial_base; lp.L.cls_any = m.cls_any; lp.L.cls_l = m.cls_l; lp.L.cls_r = m.cls_r;
+        lp.L.initial = m.wbd.initial_base; lp.L.initial_l = m.initial_l; lp.L.cls_any = m.cls_any; lp.L.cls_l = m.cls_l; lp.L.cls_r = m.cls_r;
         lp.L.max_depth = m.max_depth; lp.L.max_token_length = m.max_token_length; lp.L.max_frames = m.lex_frames;
         lp.b = b; lp.cls = h->w_cls.as<uint16_t>(); lp.nchars = h->w_nchars.as<int32_t>();
         lp.ids_tmp = h->w_tmp.as<int32_t>(); lp.counts = h->w_counts.as<int32_t>(); lp.span_tmp = want_off ? h->w_span.as<int32_t>() : nullptr;

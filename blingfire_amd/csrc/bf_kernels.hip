@@ -415,12 +415,13 @@ void launch_lex_wp(const WpLexParams &p, int variant, hipStream_t s)
         if (blocks > need) blocks = need;
         if (blocks < 1) blocks = 1;
         const bool has_any = p.L.cls_any != LX_CLS_NONE;
-        const int usel = (variant >> 30) & 3;                // 0: two DFA transitions per vote (default), 1: one, 2: three, 3: four
+        const int usel = (variant >> 30) & 3;                // DFA transitions per vote: 0 = three (default; swept on MI355X), 1 = one, 2 = two, 3 = four
         const dim3 g((unsigned)blocks), t(64); const size_t lds = lex_lds_bytes(q, 64);
         if (has_any) hipLaunchKernelGGL((k_lex_wp_flat<64, ClsWin, true, 1, false>), g, t, lds, s, q);
-        else if (p.stats) hipLaunchKernelGGL((k_lex_wp_flat<64, ClsWin, false, 2, true>), g, t, lds, s, q);
-        else if (usel == 0) hipLaunchKernelGGL((k_lex_wp_flat<64, ClsWin, false, 2, false>), g, t, lds, s, q);
-        else if (usel == 2) hipLaunchKernelGGL((k_lex_wp_flat<64, ClsWin, false, 3, false>), g, t, lds, s, q);
+        else if (p.stats) hipLaunchKernelGGL((k_lex_wp_flat<64, ClsWin, false, 3, true>), g, t, lds, s, q);
+        else if (usel == 0) hipLaunchKernelGGL((k_lex_wp_flat<64, ClsWin, false, 3, false>), g, t, lds, s, q);
+        else if (usel == 2) hipLaunchKernelGGL((k_lex_wp_flat<64, ClsWin, false, 2, false>), g, t, lds, s, q);
+        else if (usel == 3) hipLaunchKernelGGL((k_lex_wp_flat<64, ClsWin, false, 4, false>), g, t, lds, s, q);
         else hipLaunchKernelGGL((k_lex_wp_flat<64, ClsWin, false, 1, false>), g, t, lds, s, q);
     }
 }

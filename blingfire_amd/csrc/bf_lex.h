@@ -29,14 +29,18 @@ namespace bfa {
 
 constexpr int LEX_MAX_DEPTH = 4;          // frames; LoadModel refuses lexers with a deeper max-depth
 constexpr uint32_t LX_INFO_SIMPLE = 0x80000000u;
+constexpr uint32_t LX_NO_STATE = 0xFFFFFFFFu;
+constexpr int LX_ACT_FN_STRIDE = 3;
 constexpr int WBD_WORD_TAG = 1, WBD_IGNORE_TAG = 4;   // reference tokdll:39-40
 
 struct LexTables {
     const uint64_t *T;        // displacement-packed transitions: low word = bf_layout.h entry, high word = action info of
                               // the destination state when it is final (so a match needs no second gather; a 4-byte
                               // table + an info gather per match measured 5 % slower on MI355X)
-    const int32_t *acts;      // general action records [left,right,tag,nfn,(fn,ini)*]
+    const int32_t *acts;      // general action records [left,right,tag,nfn,(fn,ini,ini_l)*]
     uint32_t initial;
+    uint32_t initial_l;       // state after feeding the left anchor to `initial` (LX_NO_STATE: no such transition); the same
+                              // is precomputed per callable function (ini_l above), so the anchor costs no gather
     uint32_t cls_any, cls_l, cls_r;   // LX_CLS_NONE when the symbol is not in the alphabet
     int max_depth, max_token_length;
     int max_frames;           // saved frames the call graph can need (= call depth - 1, computed at load; <= LEX_MAX_DEPTH - 1)
@@ -103,7 +107,7 @@ struct LexLane {
     int out_count, scanning, tok_from, tok_to, expected, nsub, word_out;
     // ---- lexer
     int max_triples, emitted, last_to, d;
-    uint32_t ini; int off, fn_, from, once;                       // current frame
+    uint32_t ini, ini_l; int off, fn_, from, once;                // current frame (ini_l is only needed by its first walk)
     int a_idx, a_end, to2, fn_once, fp_r, fn_from;                // action being executed in it
     uint32_t state, finfo; int j, lim, fp;                        // current walk (finfo: action info of the deepest final state;
                                                                   // lim: the walk goes on while the next position is < lim)
@@ -149,7 +153,7 @@ struct LexLane {
         // WbdRes holds 6*BuffSize ints = 2*BuffSize triples for TextToIds (tokdll:1194), 3*BuffSize ints for TextToWords (tokdll:494-499)
         max_triples = words_ ? n : 2 * n;
         emitted = 0; last_to = 0; d = 0;
-        ini = L.initial; off = 0; fn_ = n; from = -1; once = 0;
+        ini = L.initial; ini_l = L.initial_l; off = 0; fn_ = n; from = -1; once = 0;
         a_idx = a_end = 0; to2 = 0; fn_once = 0; fp_r = 0; fn_from = 0;
         state = finfo = 0; j = 0; lim = 0; fp = -1;
         stop = (n <= 0 || L.max_depth < 1);
@@ -167,7 +171,7 @@ struct LexLane {
                 --d;
                 LexFrame f; frames.load(d, f);
                 ini = f.ini; off = f.off; fn_ = f.n; from = f.from; once = f.once;
-                a_idx = f.a_idx + 2; a_end = f.a_end; to2 = f.to2; fn_once = f.fn_once; fp_r = f.fp_r; fn_from = f.fn_from;
+                a_idx = f.a_idx + LX_ACT_FN_STRIDE; a_end = f.a_end; to2 = f.to2; fn_once = f.fn_once; fp_r = f.fp_r; fn_from = f.fn_from;
                 if (emitted > f.emit_mark) {                      // FnOutSize > 0 (FALexTools_t.h:372-381)
                     fn_from = last_to + 1 - off;
                     if (fn_from > to2) a_idx = a_end;
@@ -179,14 +183,16 @@ struct LexLane {
             state = ini; fp = -1; finfo = 0; j = from;
             set_lim(from);
             if (j < 0) {
-                // the left anchor (from == -1, FALexTools_t.h:244-252) is fed here, so that step() only ever sees
-                // letters and the right anchor; no finality check after it
-                bool hit; const uint32_t e = (uint32_t)lx_dest<HAS_ANY>(tab, L.cls_any, ini, L.cls_l, hit);
-                if (!hit || !(0 < lim)) { ++from; continue; }         // the walk ended without a match
-                state = (e >> LX_T_NEXT_SHIFT) & LX_T_NEXT_MASK; j = 0;
+                // the left anchor (from == -1: the first walk of a frame, FALexTools_t.h:244-252) is taken here, so that
+                // step() only ever sees letters and the right anchor; its destination is a fact of the frame's initial
+                // state, resolved at LoadModel (IW_ANY retry included); no finality check after it
+                if (ini_l == LX_NO_STATE || !(0 < lim)) { ++from; continue; }         // the walk ended without a match
+                state = ini_l; j = 0;
+                cls_at.prefetch(off);                                 // start the class-window refill for the first letter now
                 return true;
             }
             if (!(j < lim)) { ++from; continue; }                 // MaxTokenLength == 0: no letters, j != InSize
+            cls_at.prefetch(off + j);
             return true;
         }
     }
@@ -250,7 +256,7 @@ struct LexLane {
         else {
             const int32_t *a = L.acts + inf;
             left = a[0]; right = a[1]; tag = a[2];
-            a_idx = (int)inf + 4; a_end = a_idx + 2 * a[3]; fn_once = a[3] > 1;
+            a_idx = (int)inf + 4; a_end = a_idx + LX_ACT_FN_STRIDE * a[3]; fn_once = a[3] > 1;
         }
         int from2 = from + left; if (from2 < 0) from2 = 0; else if (fn_ <= from2) from2 = fn_ - 1;
         to2 = fp - right; if (to2 < 0) to2 = 0; else if (fn_ <= to2) to2 = fn_ - 1;
@@ -277,7 +283,7 @@ struct LexLane {
                 f.a_idx = a_idx; f.a_end = a_end; f.to2 = to2; f.fn_once = fn_once; f.fp_r = fp_r; f.fn_from = fn_from; f.emit_mark = emitted;
                 frames.save(d, f);
                 const int fn = L.acts[a_idx];
-                ini = (uint32_t)L.acts[a_idx + 1];
+                ini = (uint32_t)L.acts[a_idx + 1]; ini_l = (uint32_t)L.acts[a_idx + 2];
                 off = fn_from + off; fn_ = to2 - fn_from + 1; from = -1; once = (fn == 0) ? 0 : fn_once;
                 ++d;
                 return;

@@ -543,6 +543,13 @@ bool build_model(Model &m, const uint8_t *img, size_t size)
                     fn2ini[(size_t)f] = (sr < 0 || c == CLS_NONE) ? -1 : m.wbd.step((uint32_t)sr, c, nullptr, nullptr);
                 }
             }
+            // destination of the left anchor from a frame's initial state, IW_ANY retry included (FALexTools_t.h:244-252, 265-270)
+            auto after_l = [&](uint32_t ini) -> uint32_t {
+                long d = m.cls_l == CLS_NONE ? -1 : m.wbd.step(ini, m.cls_l, nullptr, nullptr);
+                if (d < 0 && m.cls_any != CLS_NONE) d = m.wbd.step(ini, m.cls_any, nullptr, nullptr);
+                return d < 0 ? 0xFFFFFFFFu : (uint32_t)d;
+            };
+            m.initial_l = after_l(m.wbd.initial_base);
             std::vector<uint32_t> act_info(actions.size());
             for (size_t id = 0; id < actions.size(); ++id) {
                 const auto &v = actions[id];
@@ -561,6 +568,7 @@ bool build_model(Model &m, const uint8_t *img, size_t size)
                     const int fn = v[k];
                     if (fn < 0 || fn > max_fn || fn2ini[(size_t)fn] < 0) return fail(m, "lexer action calls an unknown function");
                     m.acts_pool.push_back(fn); m.acts_pool.push_back((int)fn2ini[(size_t)fn]);
+                    m.acts_pool.push_back((int)after_l((uint32_t)fn2ini[(size_t)fn]));
                 }
             }
             // static call depth: which functions can a function's rules call?  (bounds the frame stack of the lane program)

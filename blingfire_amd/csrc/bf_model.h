@@ -86,7 +86,7 @@ constexpr uint64_t T64_CLS_MASK = 0xFFFFFull, T64_FINAL_BIT = 1ull << 20;
 constexpr int T64_NEXT_SHIFT = 21, T64_OW_SHIFT = 42;
 constexpr uint64_t T64_NEXT_MASK = 0x1FFFFFull;
 
-// lexer action record in acts_pool: [left, right, tag, nfn, (fn_id, fn_initial_base) * nfn]
+// lexer action record in acts_pool: [left, right, tag, nfn, (fn_id, fn_initial_base, base after the left anchor) * nfn]
 constexpr uint32_t INFO_SIMPLE_BIT = 0x80000000u; // info[base] = SIMPLE | tag   (left=right=0, no functions, tag != 0)
 
 struct Model {
@@ -104,6 +104,7 @@ struct Model {
     std::vector<uint64_t> wbd_t2;      // device form: low = bf_layout.h entry, high = wbd_info[destination] when the destination is final
     std::vector<int32_t> acts_pool;
     uint32_t cls_any = CLS_NONE, cls_l = CLS_NONE, cls_r = CLS_NONE;
+    uint32_t initial_l = 0xFFFFFFFFu;  // state after the left anchor from the initial state (0xFFFFFFFF: none)
     // fused "code point -> charmap -> (cp<3 ? 3 : cp) -> class" map:
     //   value = CLS_NONE | class (count 1 implicit) or FUSED_MULTI | pool offset for 0 or 2..10 outputs
     TwoLevelMap wbd_cpmap;

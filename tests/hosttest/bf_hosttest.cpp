@@ -130,7 +130,7 @@ long bft_verify_tables(void *hv, int verbose)
                     const int32_t *a = m.acts_pool.data() + inf;
                     int fi = act[2] != 0 ? (n > 3 ? 4 : 3) : 3;
                     ok = a[0] == act[0] && a[1] == act[1] && a[2] == act[2] && a[3] == n - fi;
-                    for (int k = 0; ok && k < a[3]; ++k) ok = a[4 + 2 * k] == act[fi + k];
+                    for (int k = 0; ok && k < a[3]; ++k) ok = a[4 + LX_ACT_FN_STRIDE * k] == act[fi + k];
                 }
             }
             if (!ok && ++bad <= 10 && verbose) fprintf(stderr, "  [action] state@%d differs\n", m.wbd_raw.state_off[s]);
@@ -184,7 +184,7 @@ static int emu_wp(const Model &m, const char *s, int n, int32_t *ids, int32_t *s
     if (cls.empty() || (int)cls.size() > n) return 0;
     LexTables L;
     L.T = m.wbd_t2.data(); L.acts = m.acts_pool.data();
-    L.initial = m.wbd.initial_base; L.cls_any = m.cls_any; L.cls_l = m.cls_l; L.cls_r = m.cls_r;
+    L.initial = m.wbd.initial_base; L.initial_l = m.initial_l; L.cls_any = m.cls_any; L.cls_l = m.cls_l; L.cls_r = m.cls_r;
     L.max_depth = m.max_depth; L.max_token_length = m.max_token_length; L.max_frames = m.lex_frames;
     const int nch = (int)cls.size();
     cls.push_back((uint16_t)CLS_NONE);        // one element of padding: step() reads (and ignores) position InSize under the right anchor
@@ -269,7 +269,7 @@ int bft_emu_text_to_words(void *hv, const char *s, int n, char *out, int32_t *st
     { int p = (n >= 3 && (unsigned char)s[0] == 0xEF && (unsigned char)s[1] == 0xBB && (unsigned char)s[2] == 0xBF) ? 3 : 0;
       for (int i = 0; i < len; ++i) { boff.push_back(p); int c = cps[(size_t)i]; p += c < 0x80 ? 1 : c < 0x800 ? 2 : c < 0x10000 ? 3 : 4; cls.push_back((uint16_t)m.words_cpmap.get(c)); } }
     LexTables L;
-    L.T = m.wbd_t2.data(); L.acts = m.acts_pool.data(); L.initial = m.wbd.initial_base; L.cls_any = m.cls_any; L.cls_l = m.cls_l; L.cls_r = m.cls_r;
+    L.T = m.wbd_t2.data(); L.acts = m.acts_pool.data(); L.initial = m.wbd.initial_base; L.initial_l = m.initial_l; L.cls_any = m.cls_any; L.cls_l = m.cls_l; L.cls_r = m.cls_r;
     L.max_depth = m.max_depth; L.max_token_length = m.max_token_length; L.max_frames = m.lex_frames;
     struct HostCls { const uint16_t *cp; uint32_t operator()(int i) const { return cp[i]; } void prefetch(int) const {} };
     cls.push_back((uint16_t)CLS_NONE);        // padding (see emu_wp)
