@@ -67,7 +67,7 @@ struct Handle {
     DevBuf t_dict, t_seginfo;                                    // _sp: Mealy table, I2Info rows (code-point maps reuse t_cp_*/t_multi)
     DevBuf w_s1, w_s2, w_s3, w_s4, w_perm, w_hist, w_narcs;      // _sp scratch
     // workspaces
-    DevBuf w_cls, w_nchars, w_tmp, w_counts, w_bsums, w_misc;   // w_misc: [0] next_doc (u64), [2] status (int)
+    DevBuf w_cls, w_nchars, w_tmp, w_counts, w_bsums, w_misc, w_flags;   // w_misc: [0] next_doc (u64), [2] status (int)
     DevBuf w_text, w_docoff, w_ids, w_idoff, w_starts, w_ends;  // host-API staging
     DevBuf w_srcoff, w_span;                                    // offsets API: source-offset stream, staged id spans
     hipStream_t stream = nullptr;
@@ -76,7 +76,7 @@ struct Handle {
     bool last_nonempty = false;                                 // TextToWords: the (single) document decoded to >= 1 character
     ~Handle()
     {
-        for (DevBuf *b : {&t_wbd, &t_info, &t_acts, &t_cp_l1, &t_cp_pages, &t_multi, &t_wcp_l1, &t_wcp_pages, &t_dict, &t_seginfo, &w_s1, &w_s2, &w_s3, &w_s4, &w_perm, &w_hist, &w_narcs, &w_cls, &w_nchars, &w_tmp, &w_counts,
+        for (DevBuf *b : {&t_wbd, &t_info, &t_acts, &t_cp_l1, &t_cp_pages, &t_multi, &t_wcp_l1, &t_wcp_pages, &t_dict, &t_seginfo, &w_s1, &w_s2, &w_s3, &w_s4, &w_perm, &w_hist, &w_narcs, &w_cls, &w_nchars, &w_tmp, &w_counts, &w_flags,
                           &w_bsums, &w_misc, &w_text, &w_docoff, &w_ids, &w_idoff, &w_starts, &w_ends, &w_srcoff, &w_span}) b->release();
         for (auto &e : ev) if (e) (void)hipEventDestroy(e);
         if (stream) (void)hipStreamDestroy(stream);
@@ -168,7 +168,8 @@ int run_device(Handle *h, const char *d_text, const int64_t *d_doc_off, int64_t 
         WpPrepParams pp{b, DevCpMap{h->t_cp_l1.as<uint16_t>(), h->t_cp_pages.as<uint32_t>()}, h->t_multi.as<uint16_t>(),
                         m.wbd_charmap_multi ? 1 : 0, h->w_cls.as<uint16_t>(), want_off ? h->w_srcoff.as<int32_t>() : nullptr, h->w_nchars.as<int32_t>()};
         if (words) { pp.cpmap = DevCpMap{h->t_wcp_l1.as<uint16_t>(), h->t_wcp_pages.as<uint32_t>()}; pp.has_multi = 0; }   // no charmap (tokdll:476-499)
-        if (ndocs > 0) launch_prep_wp(pp, s);
+        if (!h->w_flags.reserve((size_t)((total_bytes >> 10) + 2) * 8)) return BF_E_DEVICE;
+        if (ndocs > 0) launch_prep_wp(pp, total_bytes, h->w_flags.as<unsigned long long>(), s);
         (void)hipEventRecord(h->ev[EV_PREP], s);
         WpLexParams lp;
         lp.L.T = h->t_wbd.as<uint64_t>(); lp.L.acts = h->t_acts.as<int32_t>();

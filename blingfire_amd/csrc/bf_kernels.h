@@ -91,7 +91,8 @@ struct CompactParams {
     const int32_t *span_tmp; const int32_t *src_off; int32_t *starts_out; int32_t *ends_out;
 };
 
-void launch_prep_wp(const WpPrepParams &p, hipStream_t s);
+// flags: one bit per 16-byte chunk of the text (u64 per KiB, + 1), or nullptr for the one-pass wave-per-document form
+void launch_prep_wp(const WpPrepParams &p, int64_t total_bytes, unsigned long long *flags, hipStream_t s);
 void launch_lex_wp(const WpLexParams &p, int variant, hipStream_t s);
 void launch_prep_sp(const SpPrepParams &p, hipStream_t s);
 void launch_seg_sp(const SpSegParams &p, hipStream_t s);

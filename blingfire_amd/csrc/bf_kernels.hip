@@ -36,116 +36,212 @@ __device__ __forceinline__ int wave_incl_scan(int v)
 // ------------------------------------------------------------------------------------------
 // k_prep_wp
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_prep_wp(WpPrepParams p)
+__device__ __forceinline__ void prep_ascii_table(const WpPrepParams &p, uint16_t *ascii_cls)
 {
-    __shared__ uint16_t ascii_cls[128];      // fused map of U+0000..U+007F; 0xFFFE = needs the general path
     if (threadIdx.x < 128) {
         const uint32_t v = cpmap_get(p.cpmap, (int)threadIdx.x);
         ascii_cls[threadIdx.x] = (v & 0x80000000u) ? (uint16_t)0xFFFE : (uint16_t)v;
     }
     __syncthreads();
+}
+
+// One document, the whole wave, 512 bytes per iteration: every lane owns 8 consecutive bytes (one 8-byte load) and sees
+// the 3 bytes on either side through shuffles, so a strict UTF-8 decode of each byte position needs no further loads.
+// Per byte position q (same rules as the sequential decoder, FAUtf8Utils.cpp:121-196,233-270):
+//   continuation byte  -> no character; it must be covered by a lead at q-1 / q-2 / q-3 (else the decoder would meet
+//                         it at a character start and reject it, :152-165)
+//   lead byte          -> length from the lead, continuation bytes checked, truncated tail (:167-171), overlong and
+//                         > U+10FFFF (:185-188), surrogates (:190-193)
+// then the fused charmap+class map gives 0 / 1 / 2..10 stream elements per character, compacted with a wave scan.
+__device__ __forceinline__ void prep_wp_doc(const WpPrepParams &p, int64_t d, int64_t b, int64_t n64, int lane, const uint16_t *ascii_cls)
+{
+    if (n64 <= 0 || n64 > 1000000000) { if (lane == 0) p.nchars[d] = 0; return; }   // tokdll:1121
+    const int n = (int)n64;
+    const uint8_t *s = p.b.text + b;
+    uint16_t *out = p.cls + b;
+    int outc = 0, bom = 0; bool err_any = false;
+    uint32_t carry = 0;
+    for (int pos = 0; pos < n; pos += 512) {
+        const int q0 = pos + lane * 8;
+        uint64_t own = 0;
+        int nb = n - q0; nb = nb < 0 ? 0 : (nb > 8 ? 8 : nb);
+        if (nb == 8) __builtin_memcpy(&own, s + q0, 8);
+        else for (int k = 0; k < nb; ++k) own |= (uint64_t)s[q0 + k] << (8 * k);
+        uint32_t nxt = __shfl_down((uint32_t)own, 1, 64);
+        if (lane == 63) { nxt = 0; for (int k = 0; k < 3; ++k) if (q0 + 8 + k < n) nxt |= (uint32_t)s[q0 + 8 + k] << (8 * k); }
+        const uint32_t tail3 = (uint32_t)(own >> 40);                     // own bytes 5, 6, 7
+        uint32_t prv = __shfl_up(tail3, 1, 64);
+        if (lane == 0) prv = carry;
+        carry = __shfl(tail3, 63, 64);
+        if (pos == 0) {                                                   // FAUtf8Utils.cpp:247-252
+            const int has_bom = (n >= 3 && ((uint32_t)own & 0xFFFFFFu) == 0xBFBBEFu) ? 3 : 0;
+            bom = __shfl(has_bom, 0, 64);
+        }
+        // X[i] = byte at q0 - 3 + i, i = 0..13
+        uint32_t X[14];
+        X[0] = prv & 0xFF; X[1] = (prv >> 8) & 0xFF; X[2] = (prv >> 16) & 0xFF;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) X[3 + k] = (uint32_t)(own >> (8 * k)) & 0xFF;
+        X[11] = nxt & 0xFF; X[12] = (nxt >> 8) & 0xFF; X[13] = (nxt >> 16) & 0xFF;
+        uint32_t v[8]; int w[8]; int cnt = 0; bool err = false;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int q = q0 + k;
+            const bool in = q >= bom && q < n;
+            const uint32_t b0 = X[3 + k], b1 = X[4 + k], b2 = X[5 + k], b3 = X[6 + k];
+            const bool cont = (b0 & 0xC0) == 0x80;
+            const bool start = in && !cont;
+            uint32_t vv = LX_CLS_NONE; int ww = 0;
+            if (in && cont) {
+                const uint32_t p1 = X[2 + k], p2 = X[1 + k], p3 = X[k];
+                bool ok;
+                if ((p1 & 0xC0) != 0x80 || q - 1 < bom) ok = (q - 1 >= bom) && p1 >= 0xC0;                 // any multi-byte lead covers +1
+                else if ((p2 & 0xC0) != 0x80 || q - 2 < bom) ok = (q - 2 >= bom) && p2 >= 0xE0;            // 3- or 4-byte lead covers +2
+                else if ((p3 & 0xC0) != 0x80 || q - 3 < bom) ok = (q - 3 >= bom) && p3 >= 0xF0;            // 4-byte lead covers +3
+                else ok = false;
+                err |= !ok;                       // invalid leads (F8..FF) are rejected at their own position
+            } else if (start) {
+                if (b0 < 0x80) {
+                    vv = ascii_cls[b0];
+                    if (vv == 0xFFFEu) vv = cpmap_get(p.cpmap, (int)b0);
+                } else {
+                    int len, cp; bool e = false;
+                    if ((b0 & 0xE0) == 0xC0) { len = 2; cp = (int)(b0 & 0x1F); }
+                    else if ((b0 & 0xF0) == 0xE0) { len = 3; cp = (int)(b0 & 0x0F); }
+                    else if ((b0 & 0xF8) == 0xF0) { len = 4; cp = (int)(b0 & 0x07); }
+                    else { len = 1; cp = 0; e = true; }
+                    if (q + len > n) e = true;                                                 // truncated tail (:167-171)
+                    if (len >= 2) { if ((b1 & 0xC0) != 0x80) e = true; cp = (cp << 6) | (int)(b1 & 0x3F); }
+                    if (len >= 3) { if ((b2 & 0xC0) != 0x80) e = true; cp = (cp << 6) | (int)(b2 & 0x3F); }
+                    if (len >= 4) { if ((b3 & 0xC0) != 0x80) e = true; cp = (cp << 6) | (int)(b3 & 0x3F); }
+                    const int need = cp <= 0x7F ? 1 : cp <= 0x7FF ? 2 : cp <= 0xFFFF ? 3 : cp <= 0x10FFFF ? 4 : 0;
+                    if (need != len) e = true;                                                 // overlong / > U+10FFFF (:185-188)
+                    if ((cp & 0xFFFFF800) == 0xD800) e = true;                                 // surrogate (:190-193)
+                    err |= e;
+                    if (!e) vv = cpmap_get(p.cpmap, cp);
+                    else ww = -1;
+                }
+                if (ww == 0) ww = (vv & 0x80000000u) ? (int)p.multi_pool[vv & 0x7FFFFFFFu] : 1;
+                else ww = 0;
+            }
+            v[k] = vv; w[k] = ww; cnt += ww;
+        }
+        err_any |= err;
+        const int inc = wave_incl_scan(cnt);
+        int idx = outc + inc - cnt;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            if (w[k] == 1 && !(v[k] & 0x80000000u)) { if (idx < n) { out[idx] = (uint16_t)v[k]; if (p.src_off) p.src_off[b + idx] = q0 + k; } }
+            else if (w[k] > 0) {
+                const uint16_t *rec = p.multi_pool + (v[k] & 0x7FFFFFFFu) + 1;
+                for (int t = 0; t < w[k]; ++t) if (idx + t < n) { out[idx + t] = rec[t]; if (p.src_off) p.src_off[b + idx + t] = q0 + k; }
+            }
+            idx += w[k];
+        }
+        outc += __shfl(inc, 63, 64);
+    }
+    const bool bad = __any(err_any);
+    if (lane == 0) p.nchars[d] = (bad || outc > n) ? 0 : outc;     // tokdll:1151-1153,1185-1187
+}
+
+// wave per document, every document through prep_wp_doc (used when the source offsets are wanted or the text is unaligned)
+__global__ __launch_bounds__(256) void k_prep_wp(WpPrepParams p)
+{
+    __shared__ uint16_t ascii_cls[128];      // fused map of U+0000..U+007F; 0xFFFE = needs the general path
+    prep_ascii_table(p, ascii_cls);
     const int lane = lane_id();
     const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int64_t nwaves = (int64_t)gridDim.x * 4;
-    for (int64_t d = wave0; d < p.b.ndocs; d += nwaves) {
-        const int64_t b = p.b.doc_off[d];
-        const int64_t n64 = p.b.doc_off[d + 1] - b;
-        if (n64 <= 0 || n64 > 1000000000) { if (lane == 0) p.nchars[d] = 0; continue; }   // tokdll:1121
-        const int n = (int)n64;
-        const uint8_t *s = p.b.text + b;
-        uint16_t *out = p.cls + b;
-        int pos = 0;
-        if (n >= 3 && s[0] == 0xEF && s[1] == 0xBB && s[2] == 0xBF) pos = 3;            // FAUtf8Utils.cpp:247-252
-        const int bom = pos;
-        int outc = 0; bool bad = false;
-        while (pos < n) {
-            // ---- fast path: up to 256 bytes, all ASCII, all 1:1
-            {
-                const int q = pos + lane * 4;
-                int nb = n - q; nb = nb < 0 ? 0 : (nb > 4 ? 4 : nb);
-                uint32_t w = 0;
-                if (nb == 4) __builtin_memcpy(&w, s + q, 4);
-                else for (int k = 0; k < nb; ++k) w |= (uint32_t)s[q + k] << (8 * k);
-                const uint16_t c0 = ascii_cls[w & 0x7f], c1 = ascii_cls[(w >> 8) & 0x7f], c2 = ascii_cls[(w >> 16) & 0x7f], c3 = ascii_cls[(w >> 24) & 0x7f];
-                bool slow = (w & 0x80808080u) != 0;
-                slow |= (nb > 0 && c0 == 0xFFFE) | (nb > 1 && c1 == 0xFFFE) | (nb > 2 && c2 == 0xFFFE) | (nb > 3 && c3 == 0xFFFE);
-                if (!__any(slow)) {
-                    uint16_t *o = out + outc + lane * 4;
-                    if (nb == 4) { const uint64_t pk = (uint64_t)c0 | ((uint64_t)c1 << 16) | ((uint64_t)c2 << 32) | ((uint64_t)c3 << 48); __builtin_memcpy(o, &pk, 8); }
-                    else { if (nb > 0) o[0] = c0; if (nb > 1) o[1] = c1; if (nb > 2) o[2] = c2; }
-                    if (p.src_off) { int32_t *so = p.src_off + b + outc + lane * 4; for (int k = 0; k < nb; ++k) so[k] = q + k; }
-                    const int adv = (n - pos) < 256 ? (n - pos) : 256;
-                    outc += adv; pos += adv;
-                    continue;
-                }
+    for (int64_t d = wave0; d < p.b.ndocs; d += nwaves) { const int64_t b = p.b.doc_off[d]; prep_wp_doc(p, d, b, p.b.doc_off[d + 1] - b, lane, ascii_cls); }
+}
+
+// Two-pass form for the common case (no offsets wanted).  An all-ASCII document whose characters all map 1:1 has
+// stream position == byte position, so its class stream is a position-preserving byte -> class translation that
+// needs no document boundaries at all:
+//   pass 1 (k_prep_wp_flat)  streams the WHOLE text buffer, 16 bytes per lane, through the 128-entry LDS table into
+//                            cls[] and records one "dirty" bit per 16-byte chunk (a byte >= 0x80, or an ASCII
+//                            character that the charmap deletes / expands);
+//   pass 2 (k_prep_wp_docs)  lane per document: no dirty bit in the document's chunks -> nchars = nbytes, done;
+//                            otherwise the wave redoes that document with prep_wp_doc (which overwrites only the
+//                            document's own range).  A neighbour's dirty byte in a shared boundary chunk only costs
+//                            a redundant redo.
+__global__ __launch_bounds__(256) void k_prep_wp_flat(WpPrepParams p, int64_t total_bytes, unsigned long long *flags)
+{
+    __shared__ uint16_t ascii_cls[128];
+    prep_ascii_table(p, ascii_cls);
+    const int lane = lane_id();
+    const int64_t nchunks = (total_bytes + 15) >> 4;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t c0 = (int64_t)blockIdx.x * 256 + (threadIdx.x & ~63u); c0 < nchunks; c0 += stride) {
+        const int64_t c = c0 + lane;
+        bool dirty = false;
+        if (c < nchunks) {
+            const int64_t q = c << 4;
+            uint32_t w[4] = {0, 0, 0, 0};
+            if (q + 16 <= total_bytes) { const uint4 v = *(const uint4 *)(p.b.text + q); w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w; }
+            else for (int k = 0; q + k < total_bytes; ++k) w[k >> 2] |= (uint32_t)p.b.text[q + k] << (8 * (k & 3));
+            uint32_t o[8]; uint32_t acc = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const uint32_t c0_ = ascii_cls[w[k] & 0x7f], c1_ = ascii_cls[(w[k] >> 8) & 0x7f], c2_ = ascii_cls[(w[k] >> 16) & 0x7f], c3_ = ascii_cls[(w[k] >> 24) & 0x7f];
+                o[2 * k] = c0_ | (c1_ << 16); o[2 * k + 1] = c2_ | (c3_ << 16);
+                acc |= c0_ | c1_ | c2_ | c3_;
             }
-            // ---- general path: 64 bytes, one byte position per lane
-            const int q = pos + lane;
-            const bool in = q < n;
-            uint32_t b0 = 0, b1 = 0, b2 = 0, b3 = 0;
-            if (in) b0 = s[q];
-            if (q + 1 < n) b1 = s[q + 1];
-            if (q + 2 < n) b2 = s[q + 2];
-            if (q + 3 < n) b3 = s[q + 3];
-            const bool cont = (b0 & 0xC0) == 0x80;
-            bool start = in && !cont;
-            bool err = false;
-            int cp = (int)b0;
-            if (in && cont) {
-                // a continuation byte must be covered by a preceding lead (sequential decoder would
-                // otherwise meet it at a character start and reject it: FAUtf8Utils.cpp:152-165)
-                uint32_t p1 = (q - 1 >= bom) ? s[q - 1] : 0x80u, p2 = (q - 2 >= bom) ? s[q - 2] : 0x80u, p3 = (q - 3 >= bom) ? s[q - 3] : 0x80u;
-                bool ok;
-                if ((p1 & 0xC0) != 0x80) ok = (q - 1 >= bom) && p1 >= 0xC0;                 // any multi-byte lead covers +1
-                else if ((p2 & 0xC0) != 0x80) ok = (q - 2 >= bom) && p2 >= 0xE0;            // 3- or 4-byte lead covers +2
-                else if ((p3 & 0xC0) != 0x80) ok = (q - 3 >= bom) && p3 >= 0xF0;            // 4-byte lead covers +3
-                else ok = false;
-                err = !ok;                       // invalid leads (F8..FF) are rejected by their own lane
-            } else if (start && b0 >= 0x80) {
-                int len;
-                if ((b0 & 0xE0) == 0xC0) { len = 2; cp = (int)(b0 & 0x1F); }
-                else if ((b0 & 0xF0) == 0xE0) { len = 3; cp = (int)(b0 & 0x0F); }
-                else if ((b0 & 0xF8) == 0xF0) { len = 4; cp = (int)(b0 & 0x07); }
-                else { len = 1; err = true; }
-                if (q + len > n) err = true;                                                 // truncated tail (:167-171)
-                if (len >= 2) { if ((b1 & 0xC0) != 0x80) err = true; cp = (cp << 6) | (int)(b1 & 0x3F); }
-                if (len >= 3) { if ((b2 & 0xC0) != 0x80) err = true; cp = (cp << 6) | (int)(b2 & 0x3F); }
-                if (len >= 4) { if ((b3 & 0xC0) != 0x80) err = true; cp = (cp << 6) | (int)(b3 & 0x3F); }
-                const int need = cp <= 0x7F ? 1 : cp <= 0x7FF ? 2 : cp <= 0xFFFF ? 3 : cp <= 0x10FFFF ? 4 : 0;
-                if (need != len) err = true;                                                 // overlong / > U+10FFFF (:185-188)
-                if ((cp & 0xFFFFF800) == 0xD800) err = true;                                 // surrogate (:190-193)
-                if (err) cp = 0;
-            }
-            if (__any(err)) bad = true;
-            uint32_t v = LX_CLS_NONE; int w = 0;
-            if (start && !err) {
-                v = cpmap_get(p.cpmap, cp);
-                w = (v & 0x80000000u) ? (int)p.multi_pool[v & 0x7FFFFFFFu] : 1;
-            }
-            int idx, total;
-            if (!p.has_multi) {
-                const unsigned long long m = __ballot(w != 0);
-                idx = outc + __popcll(m & lanemask_lt());
-                total = __popcll(m);
-            } else {
-                const int inc = wave_incl_scan(w);
-                idx = outc + inc - w;
-                total = __shfl(inc, 63, 64);
-            }
-            if (w == 1 && !(v & 0x80000000u)) { if (idx < n) { out[idx] = (uint16_t)v; if (p.src_off) p.src_off[b + idx] = q; } }
-            else if (w > 0) {
-                const uint16_t *rec = p.multi_pool + (v & 0x7FFFFFFFu) + 1;
-                for (int k = 0; k < w; ++k) if (idx + k < n) { out[idx + k] = rec[k]; if (p.src_off) p.src_off[b + idx + k] = q; }
-            }
-            outc += total;
-            pos += 64;
+            dirty = (((w[0] | w[1] | w[2] | w[3]) & 0x80808080u) != 0) | ((acc & 0x8000u) != 0);     // 0xFFFE is the only entry with bit 15
+            uint4 *dst = (uint4 *)(p.cls + q);
+            dst[0] = make_uint4(o[0], o[1], o[2], o[3]);
+            dst[1] = make_uint4(o[4], o[5], o[6], o[7]);
         }
-        if (lane == 0) p.nchars[d] = (bad || outc > n) ? 0 : outc;     // tokdll:1151-1153,1185-1187
+        const unsigned long long m = __ballot(dirty);
+        if (lane == 0) flags[c0 >> 6] = m;
     }
 }
 
-void launch_prep_wp(const WpPrepParams &p, hipStream_t s)
+__global__ __launch_bounds__(256) void k_prep_wp_docs(WpPrepParams p, const unsigned long long *flags)
 {
+    __shared__ uint16_t ascii_cls[128];
+    prep_ascii_table(p, ascii_cls);
+    const int lane = lane_id();
+    const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * 4;
+    for (int64_t d0 = wave0 * 64; d0 < p.b.ndocs; d0 += nwaves * 64) {
+        const int64_t d = d0 + lane;
+        bool redo = false;
+        int64_t b = 0, n64 = 0;
+        if (d < p.b.ndocs) {
+            b = p.b.doc_off[d];
+            n64 = p.b.doc_off[d + 1] - b;
+            if (n64 <= 0 || n64 > 1000000000) p.nchars[d] = 0;                                   // tokdll:1121
+            else {
+                const int64_t cf = b >> 4, cl = (b + n64 - 1) >> 4;
+                bool any = false;
+                for (int64_t wi = cf >> 6; wi <= (cl >> 6) && !any; ++wi) {
+                    const int lo = wi == (cf >> 6) ? (int)(cf & 63) : 0, hi = wi == (cl >> 6) ? (int)(cl & 63) : 63;
+                    const unsigned long long mask = (hi == 63 ? ~0ull : ((1ull << (hi + 1)) - 1ull)) & ~((1ull << lo) - 1ull);
+                    any = (flags[wi] & mask) != 0;
+                }
+                if (any) redo = true; else p.nchars[d] = (int)n64;
+            }
+        }
+        unsigned long long m = __ballot(redo);
+        while (m) {
+            const int k = __ffsll((long long)m) - 1; m &= m - 1;
+            const int64_t bk = __shfl((long long)b, k, 64), nk = __shfl((long long)n64, k, 64);
+            prep_wp_doc(p, d0 + k, bk, nk, lane, ascii_cls);
+        }
+    }
+}
+
+void launch_prep_wp(const WpPrepParams &p, int64_t total_bytes, unsigned long long *flags, hipStream_t s)
+{
+    if (flags && !p.src_off && ((uintptr_t)p.b.text & 15) == 0 && ((uintptr_t)p.cls & 31) == 0 && total_bytes > 0) {
+        const int64_t nchunks = (total_bytes + 15) >> 4;
+        int64_t b1 = (nchunks + 255) / 256; if (b1 > 256 * 16) b1 = 256 * 16;
+        hipLaunchKernelGGL(k_prep_wp_flat, dim3((unsigned)b1), dim3(256), 0, s, p, total_bytes, flags);
+        int64_t b2 = (p.b.ndocs + 255) / 256; if (b2 > 256 * 16) b2 = 256 * 16; if (b2 < 1) b2 = 1;
+        hipLaunchKernelGGL(k_prep_wp_docs, dim3((unsigned)b2), dim3(256), 0, s, p, (const unsigned long long *)flags);
+        return;
+    }
     int64_t blocks = (p.b.ndocs + 3) / 4;
     if (blocks > 256 * 16) blocks = 256 * 16;
     if (blocks < 1) blocks = 1;
