@@ -886,6 +886,111 @@ __global__ __launch_bounds__(64) void k_bpe_apply(SpSegParams p)
     p.counts[d] = r;
 }
 
+// Unigram-LM with the Viterbi scores of the active window in LDS.  An arc from `start` ends before start + depth
+// (depth = longest dictionary entry, 16 for every shipped Unigram model), so only `depth` End2BestArc scores are
+// live at a time: they sit in a per-lane LDS ring of doubles (structure-of-arrays, ring >= depth, power of two) and
+// the relaxation of an arc -- the dependent tail of every final transition -- costs an LDS read / compare / write
+// instead of a 16-byte global load + store.  {begin, id} of a position go to global memory only when its score
+// improves (8-byte store, nothing waits for it) and are read back by the single backward pass.  A position that
+// leaves the window without any incoming arc gets the reference's sentinel {-1, -1} (..._1best_t.h:61-77,241-265).
+struct SegBI { int32_t begin, id; };
+
+__global__ __launch_bounds__(64) void k_seg_unigram_ring(SpSegParams p, int ring)
+{
+    extern __shared__ double seg_ring[];            // [ring][64]
+    enum { M_NEED = 0, M_WALK = 1, M_BACK = 2, M_EXIT = 3 };
+    const double neg_flt_max = -3.40282346638528859811704183484516925e+38;
+    const int depth = p.trie_depth, mask = ring - 1, lane = lane_id();
+    double *my = seg_ring + lane;
+    int mode = M_NEED;
+    int64_t doc = 0; SegBI *bi = nullptr; int32_t *ids = nullptr; int32_t *spans = nullptr;
+    ClsWin cls_at; cls_at.init(p.stream, 0);
+    int L = 0, cap = 0, start = 0, i = 0, sum = 0, cnt = 0, end = 0;
+    uint32_t state = 0; bool unknown = true; double prev = 0;
+    for (unsigned long long trip = 0; trip < (1ull << 34); ++trip) {
+        const unsigned long long m_need = __ballot(mode == M_NEED);
+        if (m_need) {
+            const unsigned long long m_busy = __ballot(mode == M_WALK || mode == M_BACK);
+            if (__popcll(m_need) >= 8 || m_busy == 0) {
+                if (mode == M_NEED) {
+                    const int c = __popcll(m_need);
+                    const int leader = __ffsll((long long)m_need) - 1;
+                    unsigned long long base = 0;
+                    if (lane == leader) base = atomicAdd(p.next_doc, (unsigned long long)c);
+                    base = __shfl(base, leader, 64);
+                    const int64_t idx = (int64_t)base + __popcll(m_need & lanemask_lt());
+                    if (idx >= p.b.ndocs) mode = M_EXIT;
+                    else {
+                        doc = p.perm[idx];
+                        const int64_t b = p.b.doc_off[doc];
+                        const int64_t slot = sp_slot(b, doc, p.slot_mul);
+                        cap = p.slot_mul * (int)(p.b.doc_off[doc + 1] - b + 1);
+                        L = p.lens[doc];
+                        bi = (SegBI *)(p.best + slot); ids = p.ids_tmp + slot; spans = p.span_tmp ? p.span_tmp + 2 * slot : nullptr; cls_at.init(p.stream, slot);
+                        if (L <= 0) { p.counts[doc] = 0; p.narcs[doc] = 0; }
+                        else {
+                            for (int k = 0; k < ring; ++k) my[k * 64] = neg_flt_max;
+                            start = 0; i = 0; state = p.S.initial; sum = 0; unknown = true; prev = 0;
+                            mode = M_WALK;
+                        }
+                    }
+                }
+                if (__ballot(mode != M_EXIT) == 0) break;
+            }
+        }
+        if (mode == M_WALK) {
+            const uint64_t e = sg_lookup(p.S, state, cls_at(i));
+            bool walk_ends = e == SG_MISS;
+            if (!walk_ends) {
+                state = (uint32_t)((e >> SG_NEXT_SHIFT) & SG_NEXT_MASK);
+                sum += (int)(e >> SG_OW_SHIFT);
+                if (e & SG_FINAL) {                                     // AddArc (..._1best_t.h:118-142)
+                    const SegInfo r = p.S.info[sum];
+                    const double cand = sg_bits_to_float(r.score_bits) + prev;
+                    double *q = my + (i & mask) * 64;
+                    if (*q < cand) { *q = cand; SegBI v; v.begin = start; v.id = r.id; bi[i] = v; }
+                    unknown = false;
+                }
+                ++i;
+                walk_ends = i >= L;
+            }
+            if (walk_ends) {
+                double *q = my + (start & mask) * 64;
+                double fin = *q;
+                if (unknown) {                                          // AddUnknownArc (..._1best_t.h:145-171)
+                    const float unk_score = -100000.0f;
+                    const double cand = unk_score + prev;
+                    if (fin < cand) {
+                        SegBI v; v.begin = start; v.id = -1;
+                        if (0 < start) { const SegBI pb = bi[start - 1]; if (-1 == pb.id) v.begin = pb.begin; }
+                        bi[start] = v; fin = cand;
+                    }
+                }
+                if (!(neg_flt_max < fin)) { SegBI z; z.begin = -1; z.id = -1; bi[start] = z; }      // no incoming arc at all
+                ++start;
+                if (start < L) {
+                    prev = fin;                                          // End2BestArc[start - 1] is final by now
+                    my[((start + depth - 1) & mask) * 64] = neg_flt_max; // the position that enters the reach of this start
+                    i = start; state = p.S.initial; sum = 0; unknown = true;
+                } else { mode = M_BACK; end = L - 1; cnt = 0; }
+            }
+        } else if (mode == M_BACK) {
+            const SegBI bb = bi[end];
+            const int id = bb.id != -1 ? bb.id : p.unk;
+            ids[cap - 1 - cnt] = id + p.S.id_offset;
+            if (spans) { spans[2 * (cap - 1 - cnt)] = bb.begin; spans[2 * (cap - 1 - cnt) + 1] = end; }
+            ++cnt;
+            end = bb.begin - 1;
+            if (end < 0) {
+                p.counts[doc] = cnt < p.max_ids ? cnt : p.max_ids;
+                p.narcs[doc] = cap - cnt;
+                mode = M_NEED;
+            }
+        }
+    }
+    if (mode != M_EXIT) atomicOr(p.status, 2);      // trip limit hit: never expected
+}
+
 void launch_seg_sp(const SpSegParams &p, hipStream_t s)
 {
     const unsigned b256 = (unsigned)((p.b.ndocs + 255) / 256);
@@ -896,7 +1001,16 @@ void launch_seg_sp(const SpSegParams &p, hipStream_t s)
     hipLaunchKernelGGL(k_sp_scatter, dim3(b256), dim3(256), 0, s, p);
     if (p.S.kind == SG_KIND_UNIGRAM) {
         if (p.variant == 1 || p.trie_depth <= 0 || p.trie_depth > 4096) hipLaunchKernelGGL(k_seg_unigram, dim3(b64), dim3(64), 0, s, p);
-        else {
+        else if (p.variant != 2 && p.trie_depth <= 32) {
+            int ring = 1; while (ring < p.trie_depth) ring <<= 1;
+            const size_t lds = (size_t)ring * 64 * sizeof(double);
+            int per_cu = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_seg_unigram_ring, 64, lds) != hipSuccess || per_cu <= 0) per_cu = 8;
+            (void)hipGetLastError();
+            unsigned blocks = 256u * (unsigned)per_cu;
+            if ((int64_t)blocks > (int64_t)b64) blocks = b64;
+            hipLaunchKernelGGL(k_seg_unigram_ring, dim3(blocks), dim3(64), lds, s, p, ring);
+        } else {
             int per_cu = 0;
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_seg_unigram_flat, 64, 0) != hipSuccess || per_cu <= 0) per_cu = 16;
             (void)hipGetLastError();

@@ -39,6 +39,7 @@ const char *bft_error(void *hv) { return ((Handle *)hv)->m.error.c_str(); }
 void bft_free(void *hv) { delete (Handle *)hv; }
 void bft_lookup_hist(unsigned long long *out, int n, int reset) { for (int i = 0; i < n && i < 4096; ++i) out[i] = g_lookup_hist[i]; if (reset) memset(g_lookup_hist, 0, sizeof(g_lookup_hist)); }
 long bft_table_len(void *hv) { return (long)((Handle *)hv)->m.wbd_t2.size(); }
+int bft_trie_depth(void *hv) { return ((Handle *)hv)->m.trie_max_depth; }
 int bft_kind(void *hv) { return ((Handle *)hv)->m.kind; }
 
 // sizes for reports: out[0]=wbd states, [1]=wbd transitions, [2]=wbd table entries, [3]=wbd classes,
