@@ -201,17 +201,19 @@ int run_device(Handle *h, const char *d_text, const int64_t *d_doc_off, int64_t 
         sg.S.cls_delim = m.sp_delim_code; sg.S.kind = m.kind; sg.S.id_offset = m.id_offset;
         sg.b = b; sg.stream = h->w_cls.as<uint16_t>(); sg.lens = h->w_nchars.as<int32_t>(); sg.slot_mul = mul;
         sg.ids_tmp = h->w_tmp.as<int32_t>(); sg.counts = h->w_counts.as<int32_t>(); sg.span_tmp = want_off ? h->w_span.as<int32_t>() : nullptr; sg.max_ids = max_ids; sg.unk = unk; sg.status = status;
-        sg.best = nullptr; sg.arcs = nullptr; sg.tos = nullptr; sg.idsv = nullptr; sg.inter = nullptr;
+        sg.best = nullptr; sg.arcs = nullptr; sg.tos = nullptr; sg.idsv = nullptr; sg.inter = nullptr; sg.bm_words = 0; sg.fb_list = nullptr; sg.fb_count = nullptr;
         if (m.kind == KIND_UNIGRAM) {
             if (!h->w_s1.reserve(cap * 16)) return BF_E_DEVICE;
             sg.best = h->w_s1.as<SegBest>();
         } else {
-            if (!h->w_s1.reserve((6 * cap + 32 * (size_t)ndocs + 64) * 16) || !h->w_s2.reserve(cap * 4) || !h->w_s3.reserve(cap * 4) ||
+            const size_t bm_words = (cap >> 5) + (size_t)ndocs + 4;         // per bitmap: capacity + 1 bits per document (k_bpe_apply_flat)
+            sg.bm_words = (int64_t)bm_words;
+            if (!h->w_s1.reserve((6 * cap + 32 * (size_t)ndocs + 64) * 16) || !h->w_s2.reserve(std::max(cap * 4, 2 * bm_words * 4) + ((size_t)ndocs + 16) * 4) || !h->w_s3.reserve(cap * 4) ||
                 !h->w_s4.reserve(cap)) return BF_E_DEVICE;
             sg.arcs = h->w_s1.as<SegArc>(); sg.tos = h->w_s2.as<int32_t>(); sg.idsv = h->w_s3.as<int32_t>(); sg.inter = h->w_s4.as<uint8_t>();
         }
         if (!h->w_perm.reserve((size_t)(ndocs + 1) * 4) || !h->w_hist.reserve(2048 * 4) || !h->w_narcs.reserve((size_t)(ndocs + 1) * 4)) return BF_E_DEVICE;
-        sg.narcs = h->w_narcs.as<int32_t>(); sg.next_doc = next_doc; sg.trie_depth = m.trie_max_depth; sg.variant = h->variant & 0xff;
+        sg.narcs = h->w_narcs.as<int32_t>(); sg.next_doc = next_doc; sg.trie_depth = m.trie_max_depth; sg.variant = h->variant & 0xff; sg.tune = (h->variant >> 8) & 0xff;
         if (m.kind == KIND_UNIGRAM && sg.variant != 1 && m.trie_max_depth > 0 && m.trie_max_depth <= 4096) first = h->w_narcs.as<int32_t>();
         sg.perm = h->w_perm.as<int32_t>(); sg.hist = h->w_hist.as<unsigned int>();
         if (ndocs > 0) launch_seg_sp(sg, s);

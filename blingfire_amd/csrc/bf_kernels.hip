@@ -831,8 +831,8 @@ __global__ __launch_bounds__(256) void k_bpe_sort(SpSegParams p)
         if (threadIdx.x == 0) s_doc = atomicAdd(p.next_doc, 1ull);
         __syncthreads();
         const unsigned long long i = s_doc;
-        if (i >= (unsigned long long)p.b.ndocs) break;
-        const int64_t d = p.perm[i];
+        if (i >= (p.fb_list ? (unsigned long long)*p.fb_count : (unsigned long long)p.b.ndocs)) break;
+        const int64_t d = p.fb_list ? p.fb_list[i] : p.perm[i];
         const int n = p.narcs[d];
         if (n <= 1) continue;
         SegArc *arcs = p.arcs + 6 * sp_slot(p.b.doc_off[d], d, p.slot_mul) + 32 * d;
@@ -884,6 +884,421 @@ __global__ __launch_bounds__(64) void k_bpe_apply(SpSegParams p)
         if (r < 0) { atomicOr(p.status, 2); r = 0; }
     }
     p.counts[d] = r;
+}
+
+constexpr int BPE_DONE = -2;     // narcs[d]: the document was finished by k_bpe_fused
+
+// pointer of lane `o` (uniform) to every lane, through v_readlane
+__device__ __forceinline__ const void *bcast_ptr(const void *q, int o)
+{
+    const unsigned long long v = (unsigned long long)q;
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, o), hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), o);
+    return (const void *)(((unsigned long long)hi << 32) | lo);
+}
+
+// BPE phase B2, divergence-free form: lane per document, persistent lanes, one sorted arc (or one emitted token) per trip.
+// State of the reference's three work arrays (..._bpe_t.h:258-296) kept as two lane-private bitmaps instead of 9 bytes per
+// position: `inter` (position is inside an applied arc) and `applied` (an arc was applied from this position); the end of
+// the token that starts at s is the position before the next non-interior one (equal to pTos[s]: an applied arc keeps its
+// end a boundary for as long as its start is one), so pTos is not stored at all and nothing is initialised per position.
+// Bitmap words of document d start at word (slot_d >> 5) + d of each bitmap (room for its capacity + 1 bits).
+__global__ __launch_bounds__(64) void k_bpe_apply_flat(SpSegParams p)
+{
+    enum { M_NEED = 0, M_ARCS = 1, M_EMIT = 2, M_EXIT = 3 };
+    int mode = M_NEED;
+    int64_t doc = 0; const SegArc *arcs = nullptr; uint32_t *bmi = nullptr, *bma = nullptr; int32_t *idsv = nullptr, *ids = nullptr, *spans = nullptr;
+    int L = 0, n = 0, k = 0, start = 0, cnt = 0; bool err = false;
+    SegArc cur; cur.start = cur.end = cur.id = 0; cur.rank_bits = 0;
+    for (unsigned long long trip = 0; trip < (1ull << 34); ++trip) {
+        const unsigned long long m_need = __ballot(mode == M_NEED);
+        if (m_need) {
+            const unsigned long long m_busy = __ballot(mode == M_ARCS || mode == M_EMIT);
+            if (__popcll(m_need) >= 8 || m_busy == 0) {
+                if (mode == M_NEED) {
+                    const int c = __popcll(m_need);
+                    const int leader = __ffsll((long long)m_need) - 1;
+                    unsigned long long base = 0;
+                    if (lane_id() == leader) base = atomicAdd(p.next_doc, (unsigned long long)c);
+                    base = __shfl(base, leader, 64);
+                    const int64_t idx = (int64_t)base + __popcll(m_need & lanemask_lt());
+                    if (idx >= (p.fb_list ? (int64_t)*p.fb_count : p.b.ndocs)) mode = M_EXIT;
+                    else {
+                        doc = p.fb_list ? p.fb_list[idx] : p.perm[idx];
+                        const int64_t slot = sp_slot(p.b.doc_off[doc], doc, p.slot_mul);
+                        L = p.lens[doc]; n = p.narcs[doc];
+                        if (n == BPE_DONE) {}                                        // finished by k_bpe_fused
+                        else if (n < 0) { atomicOr(p.status, 2); p.counts[doc] = 0; }
+                        else if (L <= 0) p.counts[doc] = 0;
+                        else {
+                            arcs = p.arcs + 6 * slot + 32 * doc;
+                            const int64_t w0 = (slot >> 5) + doc;
+                            bmi = (uint32_t *)p.tos + w0; bma = (uint32_t *)p.tos + p.bm_words + w0;
+                            idsv = p.idsv + slot; ids = p.ids_tmp + slot; spans = p.span_tmp ? p.span_tmp + 2 * slot : nullptr;
+                            const int nw = (L + 32) >> 5;                      // bits 0 .. L
+                            for (int q = 0; q < nw; ++q) { bmi[q] = 0; bma[q] = 0; }
+                            k = 0; start = 0; cnt = 0; err = false;
+                            if (n > 0) { cur = arcs[0]; mode = M_ARCS; } else mode = M_EMIT;
+                        }
+                    }
+                }
+                if (__ballot(mode != M_EXIT) == 0) break;
+            }
+        }
+        if (mode == M_ARCS) {                                           // ..._bpe_t.h:274-296, arc k of the sorted list
+            const int s_ = cur.start, e_ = cur.end, e1 = e_ + 1;
+            const uint32_t ws = bmi[s_ >> 5], we = bmi[e1 >> 5];
+            const SegArc nxt = arcs[k + 1 < n ? k + 1 : k];              // the next arc travels with the bitmap words
+            const bool free_s = ((ws >> (s_ & 31)) & 1u) == 0;
+            const bool free_e = e1 == L || ((we >> (e1 & 31)) & 1u) == 0;
+            if (free_s && free_e) {
+                for (int w = (s_ + 1) >> 5; w <= (e_ >> 5) && s_ < e_; ++w) {   // interior bits s+1 .. e
+                    const int lo = w == ((s_ + 1) >> 5) ? ((s_ + 1) & 31) : 0, hi = w == (e_ >> 5) ? (e_ & 31) : 31;
+                    bmi[w] |= (hi == 31 ? ~0u : ((1u << (hi + 1)) - 1u)) & ~((1u << lo) - 1u);
+                }
+                idsv[s_] = cur.id;
+                bma[s_ >> 5] |= 1u << (s_ & 31);
+            }
+            cur = nxt;
+            if (++k >= n) mode = M_EMIT;
+        } else if (mode == M_EMIT) {                                    // ..._bpe_t.h:299-313 + tokdll:1512-1516
+            const bool applied = (bma[start >> 5] >> (start & 31)) & 1u;
+            int e_ = start, id = p.unk;
+            if (applied) {
+                id = idsv[start];
+                int q = start + 1;                                       // first non-interior position after start (bit L is never set)
+                for (;;) {
+                    const uint32_t inv = ~bmi[q >> 5] & ~((1u << (q & 31)) - 1u);
+                    if (inv) { q = (q & ~31) + (__ffs((int)inv) - 1); break; }
+                    q = (q & ~31) + 32;
+                }
+                e_ = q - 1;
+            } else if (start > 0) err = true;                           // pTos[start] == 0 < start: the reference would walk backwards
+            else e_ = 0;                                                 // pTos[0] == 0, pIds[0] == UnkId
+            if (cnt < p.max_ids) { ids[cnt] = id + p.S.id_offset; if (spans) { spans[2 * cnt] = start; spans[2 * cnt + 1] = e_; } }
+            ++cnt;
+            start = e_ + 1;
+            if (start >= L || err) {
+                if (err) { atomicOr(p.status, 2); cnt = 0; }
+                p.counts[doc] = cnt < p.max_ids ? cnt : p.max_ids;
+                mode = M_NEED;
+            }
+        }
+    }
+    if (mode != M_EXIT) atomicOr(p.status, 2);      // trip limit hit: never expected
+}
+
+// ------------------------------------------------------------------------------------------
+// k_bpe_fused: BPE (all three flavours) in ONE pass for the common case.
+//
+// The reference collects every arc of the document, sorts them by merge priority and applies them in that order
+// (..._bpe_t.h:151-313).  Whether an arc [s, e] is applied depends only on the interior marks of positions s and
+// e + 1, and those are only ever set by arcs that cover them.  So at a CUT -- a start position s that no earlier arc
+// reaches (s > max end so far) -- the arc list splits into independent SEGMENTS, each of which can be sorted and
+// applied on its own, in position order, as soon as it is complete.  With the bpe-opt whole-token shortcut almost every
+// segment of real text is a single arc (= one token, always applied); the others are one out-of-vocabulary word wide.
+//
+//  * lane per document, persistent lanes, one trie transition per trip (the arc list itself is built exactly like
+//    seg_bpe_collect builds it, in the same global buffer, so that a document can still fall back to the full path);
+//  * a 1-arc segment is emitted by its lane; a longer one (<= 64 arcs, <= 63 positions) waits for a vote and is then
+//    solved by the WHOLE WAVE: lane j takes arc j, ranks come from an all-pairs key comparison through shuffles,
+//    the arcs are applied in rank order against a 64-bit interior mask held in a uniform register, and the tokens
+//    are emitted by the lanes that sit on the segment's non-interior positions (ballot prefix);
+//  * a segment can only be closed once the next start is known not to extend it (an unknown position merges into a
+//    preceding unknown arc, ..._bpe_t.h:217-225);
+//  * anything larger marks the document for the full path (k_bpe_sort + k_bpe_apply_flat redo it from its arc list).
+// narcs[d] on exit: -2 = finished here, -1 = arc capacity exceeded (loud error), >= 0 = arc count for the full path.
+// ------------------------------------------------------------------------------------------
+// lane-local arc window of the open segment (LDS, structure-of-arrays): entry = sort key, ascending == the reference's
+// comparator order.  plain BPE: [id:20 | start - seg_begin:6 | end - seg_begin:6]; with merges: [rank key:32 | the same 32 bits]
+template <bool MERGES> struct BpeLocal { typedef uint32_t Key; enum { CAP = 32 }; };
+template <> struct BpeLocal<true> { typedef uint64_t Key; enum { CAP = 16 }; };
+constexpr int BPE_LOCAL_ID_BITS = 20;
+
+// mirror arc `a` (index k of the arc list) in the lane's LDS window; `local` drops to false when the open segment no
+// longer fits (more than CAP arcs, a position more than 62 past the segment start, an id that needs more than 20 bits)
+// returns false when the arc does not fit (the window holds CAP arcs of the open segment, positions up to 62 past its
+// start, ids below 2^20)
+template <class LKey, int LCAP>
+__device__ __forceinline__ bool lds_put_t(LKey *ring, int k, int seg_begin, const SegArc &a, int seg_first, bool merges)
+{
+    const int s_rel = a.start - seg_begin, e_rel = a.end - seg_begin;
+    if (k - seg_first >= LCAP || e_rel > 62 || s_rel < 0 || (uint32_t)a.id >= (1u << BPE_LOCAL_ID_BITS)) return false;
+    const uint32_t pk = ((uint32_t)a.id << 12) | ((uint32_t)s_rel << 6) | (uint32_t)e_rel;
+    LKey key = (LKey)pk;
+    if (sizeof(LKey) == 8) key |= (LKey)((unsigned long long)sg_key_hi(a, merges) << 32);
+    ring[(k - seg_first) * 64] = key;
+    return true;
+}
+#define lds_put(ring, k, seg_begin, a, seg_first) lds_put_t<LKey, LCAP>(ring, k, seg_begin, a, seg_first, merges)
+
+template <bool MERGES, bool LOCAL>
+__global__ __launch_bounds__(64) void k_bpe_fused(SpSegParams p)
+{
+    typedef typename BpeLocal<MERGES>::Key LKey;
+    constexpr int LCAP = BpeLocal<MERGES>::CAP;
+    extern __shared__ unsigned char bpe_lds_raw[];
+    LKey *ring = (LKey *)bpe_lds_raw + lane_id();          // entry of arc index k at ring[(k - seg_first) * 64]
+    const int lthresh = p.tune ? p.tune : 16;
+    bool seg_local = LOCAL, cs_ok = true;                   // the open segment / the arcs of the current start are fully mirrored in the LDS window
+    enum { M_NEED = 0, M_WALK = 1, M_SOLVE = 2, M_POST = 3, M_EXIT = 4, M_LSOLVE = 5 };
+    const bool merges = MERGES;
+    const bool fast = p.S.kind == SG_KIND_BPE_OPT || merges;              // m_fFastBpe (..._bpe_t.h:110, ..._with_merges_t.h:113)
+    const int lane = lane_id();
+    int mode = M_NEED;
+    int64_t doc = 0; SegArc *arcs = nullptr; int32_t *ids = nullptr, *spans = nullptr;
+    ClsWin cls_at; cls_at.init(p.stream, 0);
+    int L = 0, arc_cap = 0, start = 0, i = 0, sum = 0, narcs = 0, count_at_start = 0, ff = 0, cnt = 0;
+    uint32_t state = 0; bool unknown = true, token_start = false, fallback = false, closing_last = false;
+    int last_id = 0;                                   // id of arcs[narcs - 1]
+    int seg_first = 0, seg_n = 0, seg_maxend = -1;     // current segment: arcs [seg_first, seg_first + seg_n), reach seg_maxend
+    int one_s = 0, one_e = 0, one_id = 0;              // copy of arcs[seg_first] (start, end, id)
+    int cs_first_e = 0, cs_first_id = 0, cs_last_e = 0;   // arcs of the current start: first (end, id) and largest end
+    for (unsigned long long trip = 0; trip < (1ull << 34); ++trip) {
+        const unsigned long long m_need = __ballot(mode == M_NEED);
+        if (m_need) {
+            const unsigned long long m_busy = __ballot(mode == M_WALK || mode == M_SOLVE || mode == M_POST || mode == M_LSOLVE);
+            if (__popcll(m_need) >= 8 || m_busy == 0) {
+                if (mode == M_NEED) {
+                    const int c = __popcll(m_need);
+                    const int leader = __ffsll((long long)m_need) - 1;
+                    unsigned long long base = 0;
+                    if (lane == leader) base = atomicAdd(p.next_doc, (unsigned long long)c);
+                    base = __shfl(base, leader, 64);
+                    const int64_t idx = (int64_t)base + __popcll(m_need & lanemask_lt());
+                    if (idx >= p.b.ndocs) mode = M_EXIT;
+                    else {
+                        doc = p.perm[idx];
+                        const int64_t b = p.b.doc_off[doc];
+                        const int64_t slot = sp_slot(b, doc, p.slot_mul);
+                        L = p.lens[doc];
+                        arc_cap = 6 * (int)(p.slot_mul * (p.b.doc_off[doc + 1] - b + 1)) + 32;
+                        arcs = p.arcs + 6 * slot + 32 * doc; ids = p.ids_tmp + slot; spans = p.span_tmp ? p.span_tmp + 2 * slot : nullptr;
+                        cls_at.init(p.stream, slot);
+                        if (L <= 0) { p.counts[doc] = 0; p.narcs[doc] = BPE_DONE; }
+                        else {
+                            start = 0; i = 0; state = p.S.initial; sum = 0; unknown = true; narcs = 0; count_at_start = 0; ff = 0; cnt = 0;
+                            token_start = cls_at(0) == p.S.cls_delim; fallback = false; closing_last = false; last_id = 0;
+                            seg_first = 0; seg_n = 0; seg_maxend = -1; seg_local = LOCAL; cs_ok = true;
+                            mode = M_WALK;
+                        }
+                    }
+                }
+                if (__ballot(mode != M_EXIT) == 0) break;
+            }
+        }
+        // ---- wave-cooperative solve of the waiting segments (their lanes continue at M_POST)
+        {
+            unsigned long long ms = __ballot(mode == M_SOLVE);
+            if (ms && (__popcll(ms) >= 16 || __ballot(mode == M_WALK || mode == M_POST || mode == M_LSOLVE) == 0)) {
+                __threadfence_block();                                    // the arcs the lanes appended are visible to the wave
+                while (ms) {
+                    const int o = __builtin_amdgcn_readfirstlane(__ffsll((long long)ms) - 1); ms &= ms - 1;
+                    const SegArc *oa = (const SegArc *)bcast_ptr(arcs + seg_first, o);
+                    const int n = __builtin_amdgcn_readlane(seg_n, o), begin = __builtin_amdgcn_readlane(one_s, o), Ls = __builtin_amdgcn_readlane(seg_maxend, o) - begin + 1;
+                    const int ocnt = __builtin_amdgcn_readlane(cnt, o);
+                    int32_t *oids = (int32_t *)bcast_ptr(ids, o), *ospans = (int32_t *)bcast_ptr(spans, o);
+                    SegArc a; a.start = begin; a.end = begin; a.id = 0; a.rank_bits = 0;
+                    if (lane < n) a = oa[lane];
+                    // all-pairs ranking through v_readlane (uniform source lane): the order is total; equal keys broken by index
+                    const uint32_t khi = sg_key_hi(a, merges); const uint64_t klo = sg_key_lo(a);
+                    const uint32_t kl0 = (uint32_t)klo, kl1 = (uint32_t)(klo >> 32);
+                    int rank = 0;
+                    for (int t = 0; t < n; ++t) {
+                        const uint32_t t1 = (uint32_t)__builtin_amdgcn_readlane((int)kl1, t), t0 = (uint32_t)__builtin_amdgcn_readlane((int)kl0, t);
+                        const uint32_t th = merges ? (uint32_t)__builtin_amdgcn_readlane((int)khi, t) : 0u;
+                        const bool lt = th < khi || (th == khi && (t1 < kl1 || (t1 == kl1 && (t0 < kl0 || (t0 == kl0 && t < lane)))));
+                        rank += lt ? 1 : 0;
+                    }
+                    if (lane >= n) rank = lane;                           // ranks form a permutation of the 64 lanes
+                    // lane r receives the arc of rank r
+                    const int sa_start = __builtin_amdgcn_ds_permute(rank << 2, a.start), sa_end = __builtin_amdgcn_ds_permute(rank << 2, a.end),
+                              sa_id = __builtin_amdgcn_ds_permute(rank << 2, a.id);
+                    unsigned long long inter = 0;                         // bit q: position begin + q is inside an applied arc (bit Ls is never set)
+                    int pos_id = p.unk; bool pos_applied = false;
+                    for (int r = 0; r < n; ++r) {                         // ..._bpe_t.h:274-296 in sorted order, on uniform registers
+                        const int s_rel = __builtin_amdgcn_readlane(sa_start, r) - begin, e_rel = __builtin_amdgcn_readlane(sa_end, r) - begin;
+                        if (!((inter >> s_rel) & 1ull) && !((inter >> (e_rel + 1)) & 1ull)) {
+                            if (e_rel > s_rel) inter |= ((1ull << (e_rel + 1)) - 1ull) & ~((1ull << (s_rel + 1)) - 1ull);
+                            const int id_r = __builtin_amdgcn_readlane(sa_id, r);
+                            if (lane == s_rel) { pos_id = id_r; pos_applied = true; }
+                        }
+                    }
+                    // tokens = the non-interior positions of the segment, in order (..._bpe_t.h:299-313 + tokdll:1512-1516)
+                    const bool is_tok = lane < Ls && !((inter >> lane) & 1ull);
+                    const unsigned long long mt = __ballot(is_tok);
+                    const bool bad = is_tok && !pos_applied && (begin + lane) > 0;     // pTos[start] == 0 < start: the reference walks backwards here
+                    const int kk = ocnt + __popcll(mt & lanemask_lt());
+                    if (is_tok && kk < p.max_ids) {
+                        oids[kk] = pos_id + p.S.id_offset;
+                        if (ospans) {
+                            const unsigned long long above = (mt | (1ull << Ls)) >> (lane + 1);
+                            ospans[2 * kk] = begin + lane; ospans[2 * kk + 1] = pos_applied ? begin + lane + __ffsll((long long)above) - 1 : begin + lane;
+                        }
+                    }
+                    const bool any_bad = __any(bad);
+                    if (lane == o) { cnt += __popcll(mt); if (any_bad) fallback = true; mode = M_POST; }
+                }
+            }
+        }
+
+        // ---- lane-local solve: every waiting lane sorts (selection by key) and applies the arcs of ITS segment from its LDS
+        //      window against a 64-bit interior mask, then emits the tokens; up to 64 segments per pass
+        if (LOCAL) {
+            const unsigned long long ml = __ballot(mode == M_LSOLVE);
+            if (ml && (__popcll(ml) >= lthresh || __ballot(mode == M_WALK || mode == M_POST) == 0)) {
+                if (mode == M_LSOLVE) {
+                    // Batcher's odd-even merge sort, in place in the LDS window: every compare-exchange moves the smaller key to the
+                    // lower index, so entries at or past seg_n (the arcs of the current start) act as +infinity and are left alone;
+                    // all offsets are compile-time constants, the network of one phase runs with its LDS reads in flight together
+#pragma unroll
+                    for (int pp = 1; pp < LCAP; pp <<= 1) {
+#pragma unroll
+                        for (int kq = pp; kq >= 1; kq >>= 1) {
+#pragma unroll
+                            for (int j = kq % pp; j <= LCAP - 1 - kq; j += 2 * kq) {
+#pragma unroll
+                                for (int i2 = 0; i2 <= (kq - 1 < LCAP - j - kq - 1 ? kq - 1 : LCAP - j - kq - 1); ++i2) {
+                                    if ((i2 + j) / (2 * pp) == (i2 + j + kq) / (2 * pp)) {
+                                        const int lo_i = i2 + j, hi_i = i2 + j + kq;
+                                        if (hi_i < seg_n) {
+                                            const LKey x = ring[lo_i * 64], y = ring[hi_i * 64];
+                                            if (y < x) { ring[lo_i * 64] = y; ring[hi_i * 64] = x; }
+                                        }
+                                    }
+                                }
+                            }
+                        }
+                    }
+                    unsigned long long inter = 0;                         // bit q: position seg_begin + q is inside an applied arc
+#pragma unroll
+                    for (int t = 0; t < LCAP; ++t) {                      // ..._bpe_t.h:274-296 in sorted order
+                        if (t < seg_n) {
+                            const uint32_t pk = (uint32_t)ring[t * 64]; const int s_rel = (int)((pk >> 6) & 63u), e_rel = (int)(pk & 63u);
+                            if (!((inter >> s_rel) & 1ull) && !((inter >> (e_rel + 1)) & 1ull) && e_rel > s_rel)
+                                inter |= ((1ull << (e_rel + 1)) - 1ull) & ~((1ull << (s_rel + 1)) - 1ull);
+                        }
+                    }
+                    // the token that starts at a non-interior position s is the arc [s, next non-interior position - 1]; an arc
+                    // shows exactly that pattern iff it was applied and never swallowed (arcs are unique by their span)
+                    const int Ls = seg_maxend - one_s + 1;
+                    const unsigned long long bound = ~inter & ((1ull << Ls) - 1ull);
+                    int found = 0;
+#pragma unroll
+                    for (int t = 0; t < LCAP; ++t) {                      // ..._bpe_t.h:299-313 + tokdll:1512-1516
+                        if (t < seg_n) {
+                            const uint32_t pk = (uint32_t)ring[t * 64];
+                            const int s_rel = (int)((pk >> 6) & 63u), e_rel = (int)(pk & 63u);
+                            const unsigned long long body = e_rel > s_rel ? (((1ull << (e_rel + 1)) - 1ull) & ~((1ull << (s_rel + 1)) - 1ull)) : 0ull;
+                            if (!((inter >> s_rel) & 1ull) && !((inter >> (e_rel + 1)) & 1ull) && (inter & body) == body) {
+                                const int kk = cnt + __popcll(bound & ((1ull << s_rel) - 1ull));
+                                if (kk < p.max_ids) { ids[kk] = (int)(pk >> 12) + p.S.id_offset; if (spans) { spans[2 * kk] = one_s + s_rel; spans[2 * kk + 1] = one_s + e_rel; } }
+                                ++found;
+                            }
+                        }
+                    }
+                    const int ntok = __popcll(bound);
+                    if (found != ntok) fallback = true;                   // a token start without an applied arc: the full path reproduces the reference there
+                    else cnt += ntok;
+                    mode = M_POST;
+                }
+            }
+        }
+        bool post = mode == M_POST, post_cut = true, post_merged = false;
+        if (mode == M_WALK) {
+            bool walk_ends = true, over = false;                           // over: the arc buffer is full (loud error, the document is dropped)
+            if (!closing_last) {
+                // ---- one transition of the walk from `start` (seg_bpe_collect, ..._bpe_t.h:151-232)
+                const uint64_t e = sg_lookup(p.S, state, cls_at(i));
+                walk_ends = e == SG_MISS;
+                if (!walk_ends) {
+                    state = (uint32_t)((e >> SG_NEXT_SHIFT) & SG_NEXT_MASK);
+                    sum += (int)(e >> SG_OW_SHIFT);
+                    if (e & SG_FINAL) {
+                        const SegInfo r = p.S.info[sum];
+                        const bool whole = fast && token_start && ((i < L - 1) ? cls_at(i + 1) == p.S.cls_delim : true) && count_at_start < narcs;
+                        SegArc a; a.start = start; a.end = i; a.id = r.id; a.rank_bits = r.score_bits;
+                        if (!whole) {
+                            if (narcs >= arc_cap) over = true;
+                            else {
+                                if (narcs == count_at_start) { cs_first_e = i; cs_first_id = r.id; }
+                                if (LOCAL) cs_ok = cs_ok && lds_put(ring, narcs, seg_n > 0 ? one_s : start, a, seg_first);
+                                arcs[narcs++] = a;
+                            }
+                        } else {                                            // whole-token arc replaces the pieces (..._bpe_t.h:189-206)
+                            if (LOCAL) cs_ok = lds_put(ring, count_at_start, seg_n > 0 ? one_s : start, a, seg_first);
+                            arcs[count_at_start] = a; narcs = count_at_start + 1; ff = i; cs_first_e = i; cs_first_id = r.id;
+                        }
+                        cs_last_e = i; last_id = r.id;
+                        unknown = false;
+                    }
+                    ++i;
+                    walk_ends = i >= L;
+                }
+            }
+            if (walk_ends && !over && !closing_last && unknown && !(0 < narcs && p.unk == last_id) && narcs >= arc_cap) over = true;
+            if (over) { p.counts[doc] = 0; p.narcs[doc] = -1; p.fb_list[atomicAdd(p.fb_count, 1u)] = (int32_t)doc; mode = M_NEED; }
+            else if (walk_ends) {
+                // ---- the walk from `start` is over: unknown arc, then the cut test
+                bool merged = false;
+                if (!closing_last && unknown) {                             // ..._bpe_t.h:212-225
+                    if (0 < narcs && p.unk == last_id) {
+                        arcs[narcs - 1].end = start; merged = true;
+                        if (narcs - 1 == seg_first) one_e = start;
+                        if (seg_maxend < start) seg_maxend = start;
+                        if (LOCAL) {                                        // the same extension in the LDS window
+                            if (start - one_s > 62) seg_local = false;
+                            else if (seg_local) { LKey *q = ring + (narcs - 1 - seg_first) * 64; *q = (*q & ~(LKey)63) | (LKey)(start - one_s); }
+                        }
+                    } else {
+                        SegArc a; a.start = start; a.end = start; a.id = p.unk; a.rank_bits = 0;
+                        if (LOCAL) cs_ok = cs_ok && lds_put(ring, narcs, seg_n > 0 ? one_s : start, a, seg_first);
+                        arcs[narcs++] = a; cs_first_e = start; cs_first_id = p.unk; cs_last_e = start; last_id = p.unk;
+                    }
+                }
+                const bool cut = seg_n > 0 && (closing_last || (!merged && start > seg_maxend));
+                if (cut && !fallback) {                                     // the previous segment is complete
+                    if (seg_n == 1) {                                       // one arc = one token (always applied)
+                        if (cnt < p.max_ids) { ids[cnt] = one_id + p.S.id_offset; if (spans) { spans[2 * cnt] = one_s; spans[2 * cnt + 1] = one_e; } }
+                        ++cnt;
+                    } else if (LOCAL && seg_local) mode = M_LSOLVE;
+                    else if (seg_n <= 64 && seg_maxend - one_s + 1 <= 63) mode = M_SOLVE;
+                    else fallback = true;
+                }
+                if (mode != M_SOLVE && mode != M_LSOLVE) { post = true; post_cut = cut; post_merged = merged; }
+            }
+        }
+        if (post) {
+            // ---- after the closure decision: the arcs of `start` open / join a segment; next start or end of document
+            if (closing_last) {
+                p.counts[doc] = fallback ? 0 : (cnt < p.max_ids ? cnt : p.max_ids);
+                p.narcs[doc] = fallback ? narcs : BPE_DONE;
+                if (fallback) p.fb_list[atomicAdd(p.fb_count, 1u)] = (int32_t)doc;       // the full path redoes it from its arc list
+                mode = M_NEED;
+            } else {
+                if (!post_merged) {
+                    if (post_cut || seg_n == 0) {
+                        if (LOCAL) {
+                            // the arcs of `start` were keyed relative to the old segment: re-base them to the new one (all of them start at `start`)
+                            const int d0 = seg_n > 0 ? start - one_s : 0, added = narcs - count_at_start;
+                            seg_local = cs_ok && added <= LCAP;
+                            const int old_n = count_at_start - seg_first;     // they sit behind the closed segment's entries: move them to the front
+                            if (seg_local && old_n > 0) for (int t = 0; t < added; ++t) ring[t * 64] = ring[(old_n + t) * 64] - (LKey)(d0 * 65);
+                        }
+                        seg_first = count_at_start; seg_n = narcs - count_at_start; one_s = start; one_e = cs_first_e; one_id = cs_first_id; seg_maxend = cs_last_e;
+                    }
+                    else { seg_n = narcs - seg_first; if (seg_maxend < cs_last_e) seg_maxend = cs_last_e; seg_local = seg_local && cs_ok; }
+                }
+                if (fast) start = ff;                                       // ..._bpe_t.h:228-230
+                ++start;
+                if (start < L) {
+                    i = start; state = p.S.initial; sum = 0; unknown = true; count_at_start = narcs; ff = start; cs_ok = true;
+                    token_start = cls_at(start) == p.S.cls_delim;
+                } else closing_last = true;                                 // one more trip closes the final segment
+                mode = M_WALK;
+            }
+        }
+    }
+    if (mode != M_EXIT) atomicOr(p.status, 2);      // trip limit hit: never expected
 }
 
 // Unigram-LM with the Viterbi scores of the active window in LDS.  An arc from `start` ends before start + depth
@@ -991,8 +1406,9 @@ __global__ __launch_bounds__(64) void k_seg_unigram_ring(SpSegParams p, int ring
     if (mode != M_EXIT) atomicOr(p.status, 2);      // trip limit hit: never expected
 }
 
-void launch_seg_sp(const SpSegParams &p, hipStream_t s)
+void launch_seg_sp(const SpSegParams &p_in, hipStream_t s)
 {
+    const SpSegParams &p = p_in;
     const unsigned b256 = (unsigned)((p.b.ndocs + 255) / 256);
     const unsigned b64 = (unsigned)((p.b.ndocs + 63) / 64);
     (void)hipMemsetAsync(p.hist, 0, 2048 * sizeof(unsigned int), s);
@@ -1019,11 +1435,36 @@ void launch_seg_sp(const SpSegParams &p, hipStream_t s)
             hipLaunchKernelGGL(k_seg_unigram_flat, dim3(blocks), dim3(64), 0, s, p);
         }
     } else {
-        hipLaunchKernelGGL(k_bpe_collect, dim3(b64), dim3(64), 0, s, p);
-        unsigned sort_blocks = 256 * 2;
+        SpSegParams p = p_in;
+        if (p.variant == 2) { p.fb_list = nullptr; p.fb_count = nullptr; hipLaunchKernelGGL(k_bpe_collect, dim3(b64), dim3(64), 0, s, p); }
+        else {
+            p.fb_count = p.hist; p.fb_list = p.tos + 2 * p.bm_words;    // behind the two bitmaps of k_bpe_apply_flat
+            (void)hipMemsetAsync(p.fb_count, 0, sizeof(unsigned int), s);
+            const bool mg = p.S.kind == SG_KIND_BPE_MERGES;
+            const bool local = p.variant != 4 && p.unk >= 0 && p.unk < (1 << BPE_LOCAL_ID_BITS);
+            const size_t lds = local ? (size_t)8 * 1024 : 0;           // CAP * sizeof(Key) * 64 lanes, both flavours
+            int per_cu = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_bpe_fused<false, true>, 64, lds) != hipSuccess || per_cu <= 0) per_cu = 12;
+            (void)hipGetLastError();
+            unsigned blocks = 256u * (unsigned)per_cu;
+            if ((int64_t)blocks > (int64_t)b64) blocks = b64;
+            if (mg) { if (local) hipLaunchKernelGGL((k_bpe_fused<true, true>), dim3(blocks), dim3(64), lds, s, p); else hipLaunchKernelGGL((k_bpe_fused<true, false>), dim3(blocks), dim3(64), lds, s, p); }
+            else { if (local) hipLaunchKernelGGL((k_bpe_fused<false, true>), dim3(blocks), dim3(64), lds, s, p); else hipLaunchKernelGGL((k_bpe_fused<false, false>), dim3(blocks), dim3(64), lds, s, p); }
+            (void)hipMemsetAsync(p.next_doc, 0, sizeof(unsigned long long), s);
+        }
+        unsigned sort_blocks = p.fb_list ? 64 : 256 * 2;                 // the fallback list is normally empty
         if ((int64_t)sort_blocks > p.b.ndocs) sort_blocks = (unsigned)p.b.ndocs;
         hipLaunchKernelGGL(k_bpe_sort, dim3(sort_blocks), dim3(256), 0, s, p);
-        hipLaunchKernelGGL(k_bpe_apply, dim3(b64), dim3(64), 0, s, p);
+        if (p.variant == 2) hipLaunchKernelGGL(k_bpe_apply, dim3(b64), dim3(64), 0, s, p);
+        else {
+            (void)hipMemsetAsync(p.next_doc, 0, sizeof(unsigned long long), s);
+            int per_cu = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_bpe_apply_flat, 64, 0) != hipSuccess || per_cu <= 0) per_cu = 16;
+            (void)hipGetLastError();
+            unsigned blocks = p.fb_list ? 256u : 256u * (unsigned)per_cu;
+            if ((int64_t)blocks > (int64_t)b64) blocks = b64;
+            hipLaunchKernelGGL(k_bpe_apply_flat, dim3(blocks), dim3(64), 0, s, p);
+        }
     }
 }
 

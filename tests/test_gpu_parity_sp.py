@@ -37,7 +37,9 @@ def test_adversarial_and_fuzz(model, checker):
     hck = checker.load(bfutil.model_path(model))
     try:
         docs = list(bfutil.ADVERSARIAL) + bfutil.fuzz_docs(2500, seed=13)
-        for max_ids, unk in ((2048, 0), (3, 0), (64, 3), (1, 1)):
+        # unk values: ordinary, equal to real token ids (the merge quirk of ..._bpe_t.h:217-225), negative and beyond 2^20
+        # (both switch the BPE kernel's lane-local window off)
+        for max_ids, unk in ((2048, 0), (3, 0), (64, 3), (1, 1), (2048, 262), (2048, -7), (2048, 3000000)):
             _compare(h, checker, hck, docs, max_ids, unk)
     finally:
         bf.free_model(h)
