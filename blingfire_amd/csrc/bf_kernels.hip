@@ -53,7 +53,7 @@ __device__ __forceinline__ void prep_ascii_table(const WpPrepParams &p, uint16_t
 //   lead byte          -> length from the lead, continuation bytes checked, truncated tail (:167-171), overlong and
 //                         > U+10FFFF (:185-188), surrogates (:190-193)
 // then the fused charmap+class map gives 0 / 1 / 2..10 stream elements per character, compacted with a wave scan.
-__device__ __forceinline__ void prep_wp_doc(const WpPrepParams &p, int64_t d, int64_t b, int64_t n64, int lane, const uint16_t *ascii_cls)
+__device__ __forceinline__ void prep_wp_doc(const WpPrepParams &p, int64_t d, int64_t b, int64_t n64, int lane, const uint16_t *ascii_cls, uint16_t *stage /* 512 elements of LDS, this wave's */)
 {
     if (n64 <= 0 || n64 > 1000000000) { if (lane == 0) p.nchars[d] = 0; return; }   // tokdll:1121
     const int n = (int)n64;
@@ -129,16 +129,30 @@ __device__ __forceinline__ void prep_wp_doc(const WpPrepParams &p, int64_t d, in
         err_any |= err;
         const int inc = wave_incl_scan(cnt);
         int idx = outc + inc - cnt;
+        const int total = __shfl(inc, 63, 64);
+        bool multi = false;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            if (w[k] == 1 && !(v[k] & 0x80000000u)) { if (idx < n) { out[idx] = (uint16_t)v[k]; if (p.src_off) p.src_off[b + idx] = q0 + k; } }
-            else if (w[k] > 0) {
-                const uint16_t *rec = p.multi_pool + (v[k] & 0x7FFFFFFFu) + 1;
-                for (int t = 0; t < w[k]; ++t) if (idx + t < n) { out[idx + t] = rec[t]; if (p.src_off) p.src_off[b + idx + t] = q0 + k; }
+        for (int k = 0; k < 8; ++k) multi |= w[k] > 0 && (v[k] & 0x80000000u) != 0;
+        if (!p.src_off && !__any(multi)) {
+            // the common case (every character gives one element): the window's elements are compacted in LDS and leave as
+            // whole 128-byte rows (a lane's own elements are 16 bytes apart in the stream: direct 2-byte stores would be
+            // 64 partial writes per instruction)
+            int li = inc - cnt;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { if (w[k] == 1) stage[li] = (uint16_t)v[k]; li += w[k]; }
+            for (int t = lane; t < total; t += 64) if (outc + t < n) out[outc + t] = stage[t];
+        } else {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                if (w[k] == 1 && !(v[k] & 0x80000000u)) { if (idx < n) { out[idx] = (uint16_t)v[k]; if (p.src_off) p.src_off[b + idx] = q0 + k; } }
+                else if (w[k] > 0) {
+                    const uint16_t *rec = p.multi_pool + (v[k] & 0x7FFFFFFFu) + 1;
+                    for (int t = 0; t < w[k]; ++t) if (idx + t < n) { out[idx + t] = rec[t]; if (p.src_off) p.src_off[b + idx + t] = q0 + k; }
+                }
+                idx += w[k];
             }
-            idx += w[k];
         }
-        outc += __shfl(inc, 63, 64);
+        outc += total;
     }
     const bool bad = __any(err_any);
     if (lane == 0) p.nchars[d] = (bad || outc > n) ? 0 : outc;     // tokdll:1151-1153,1185-1187
@@ -148,11 +162,12 @@ __device__ __forceinline__ void prep_wp_doc(const WpPrepParams &p, int64_t d, in
 __global__ __launch_bounds__(256) void k_prep_wp(WpPrepParams p)
 {
     __shared__ uint16_t ascii_cls[128];      // fused map of U+0000..U+007F; 0xFFFE = needs the general path
+    __shared__ uint16_t stage_all[4 * 512];
     prep_ascii_table(p, ascii_cls);
     const int lane = lane_id();
     const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int64_t nwaves = (int64_t)gridDim.x * 4;
-    for (int64_t d = wave0; d < p.b.ndocs; d += nwaves) { const int64_t b = p.b.doc_off[d]; prep_wp_doc(p, d, b, p.b.doc_off[d + 1] - b, lane, ascii_cls); }
+    for (int64_t d = wave0; d < p.b.ndocs; d += nwaves) { const int64_t b = p.b.doc_off[d]; prep_wp_doc(p, d, b, p.b.doc_off[d + 1] - b, lane, ascii_cls, stage_all + (threadIdx.x >> 6) * 512); }
 }
 
 // Two-pass form for the common case (no offsets wanted).  An all-ASCII document whose characters all map 1:1 has
@@ -200,6 +215,7 @@ __global__ __launch_bounds__(256) void k_prep_wp_flat(WpPrepParams p, int64_t to
 __global__ __launch_bounds__(256) void k_prep_wp_docs(WpPrepParams p, const unsigned long long *flags)
 {
     __shared__ uint16_t ascii_cls[128];
+    __shared__ uint16_t stage_all[4 * 512];
     prep_ascii_table(p, ascii_cls);
     const int lane = lane_id();
     const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -227,7 +243,7 @@ __global__ __launch_bounds__(256) void k_prep_wp_docs(WpPrepParams p, const unsi
         while (m) {
             const int k = __ffsll((long long)m) - 1; m &= m - 1;
             const int64_t bk = __shfl((long long)b, k, 64), nk = __shfl((long long)n64, k, 64);
-            prep_wp_doc(p, d0 + k, bk, nk, lane, ascii_cls);
+            prep_wp_doc(p, d0 + k, bk, nk, lane, ascii_cls, stage_all + (threadIdx.x >> 6) * 512);
         }
     }
 }
