@@ -64,6 +64,14 @@ def lib():
         L.TextToWordsWithOffsets.argtypes = [c_char_p, c_int, c_void_p, c_void_p, c_void_p, c_int]
         L.TextToWordsWithOffsetsWithModel.restype = c_int
         L.TextToWordsWithOffsetsWithModel.argtypes = [c_char_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p]
+        L.TextToSentences.restype = c_int
+        L.TextToSentences.argtypes = [c_char_p, c_int, c_void_p, c_int]
+        L.TextToSentencesWithModel.restype = c_int
+        L.TextToSentencesWithModel.argtypes = [c_char_p, c_int, c_void_p, c_int, c_void_p]
+        L.TextToSentencesWithOffsets.restype = c_int
+        L.TextToSentencesWithOffsets.argtypes = [c_char_p, c_int, c_void_p, c_void_p, c_void_p, c_int]
+        L.TextToSentencesWithOffsetsWithModel.restype = c_int
+        L.TextToSentencesWithOffsetsWithModel.argtypes = [c_char_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p]
         L.BfLastKernelMs.restype = c_int
         L.BfLastKernelMs.argtypes = [c_void_p, POINTER(c_float), c_int]
         L.BfLastStatus.restype = c_int
@@ -144,6 +152,39 @@ def text_to_words_with_offsets(s, h=None):
     lead = np.frombuffer(s_bytes, dtype=np.uint8) & 0xC0 != 0x80
     char_at = np.concatenate([[0], np.cumsum(lead)])          # byte offset -> number of characters that start before it
     return words, [(int(char_at[st[i]]), int(char_at[en[i] + 1])) for i in range(k)]
+
+
+def text_to_sentences(s):
+    """reference __init__.py:45-62: one sentence per line by the built-in sbd.bin; '' on error."""
+    s_bytes = s.encode("utf-8")
+    o = ctypes.create_string_buffer(len(s_bytes) * 2)
+    n = lib().TextToSentences(s_bytes, len(s_bytes), o, len(o))
+    return "" if n == -1 or n > len(o) else o.value.decode("utf-8")
+
+
+def text_to_sentences_with_model(h, s):
+    """reference __init__.py:65-82"""
+    s_bytes = s.encode("utf-8")
+    o = ctypes.create_string_buffer(len(s_bytes) * 2)
+    n = lib().TextToSentencesWithModel(s_bytes, len(s_bytes), o, len(o), c_void_p(h))
+    return "" if n == -1 or n > len(o) else o.value.decode("utf-8")
+
+
+def text_to_sentences_and_offsets(s, h=None):
+    """reference __init__.py:225-226: (string, [(begin, end) per sentence]) as character offsets into `s`, end exclusive."""
+    s_bytes = s.encode("utf-8")
+    cap = len(s_bytes) * 2
+    o = ctypes.create_string_buffer(max(cap, 1))
+    st = (c_int32 * max(cap, 1))()
+    en = (c_int32 * max(cap, 1))()
+    n = lib().TextToSentencesWithOffsetsWithModel(s_bytes, len(s_bytes), o, byref(st), byref(en), cap, c_void_p(h) if h else None)
+    if n == -1 or n > cap:
+        return "", []
+    sents = o.value.decode("utf-8")
+    k = sents.count("\n") + 1 if sents else 0
+    lead = np.frombuffer(s_bytes, dtype=np.uint8) & 0xC0 != 0x80
+    char_at = np.concatenate([[0], np.cumsum(lead)])
+    return sents, [(int(char_at[st[i]]), int(char_at[en[i] + 1])) for i in range(k)]
 
 
 def change_settings_dummy_prefix(h, add_prefix):

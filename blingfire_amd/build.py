@@ -40,12 +40,13 @@ def hipcc():
 def build_product(force=False):
     srcs = [os.path.join(CSRC, f) for f in ("bf_kernels.hip", "bf_capi.cpp", "bf_model.cpp")]
     deps = srcs + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + [
-        os.path.join(ROOT, "include", "blingfiretokdll_amd.h"), os.path.join(ROOT, "models", "wbd.bin")]
+        os.path.join(ROOT, "include", "blingfiretokdll_amd.h"), os.path.join(ROOT, "models", "wbd.bin"), os.path.join(ROOT, "models", "sbd.bin")]
     if force or _newer(PRODUCT, deps):
-        # the reference compiles its default word-breaking model (wbd.bin) into the library; same here (data, via .incbin)
+        # the reference compiles its default word- and sentence-breaking models (wbd.bin, sbd.bin) into the library; same here (data, via .incbin)
         wbd = os.path.join(ROOT, "models", "wbd.bin")
+        sbd = os.path.join(ROOT, "models", "sbd.bin")
         _run([hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
-              "-Wall", "-Wno-unused-result", '-DBF_DEFAULT_WBD_PATH="%s"' % wbd, "-x", "hip"] + srcs + ["-o", PRODUCT])
+              "-Wall", "-Wno-unused-result", '-DBF_DEFAULT_WBD_PATH="%s"' % wbd, '-DBF_DEFAULT_SBD_PATH="%s"' % sbd, "-x", "hip"] + srcs + ["-o", PRODUCT])
     return PRODUCT
 
 

@@ -92,7 +92,18 @@ Handle *make_handle(const uint8_t *img, size_t size);
 __asm__(".section .rodata\n.balign 16\n.global bf_default_wbd_begin\nbf_default_wbd_begin:\n.incbin \"" BF_DEFAULT_WBD_PATH "\"\n"
         ".global bf_default_wbd_end\nbf_default_wbd_end:\n.byte 0\n.previous\n");
 #endif
-extern "C" const unsigned char bf_default_wbd_begin[], bf_default_wbd_end[];
+__asm__(".section .rodata\n.balign 16\n.global bf_default_sbd_begin\nbf_default_sbd_begin:\n.incbin \"" BF_DEFAULT_SBD_PATH "\"\n"
+        ".global bf_default_sbd_end\nbf_default_sbd_end:\n.byte 0\n.previous\n");
+extern "C" const unsigned char bf_default_wbd_begin[], bf_default_wbd_end[], bf_default_sbd_begin[], bf_default_sbd_end[];
+
+Handle *default_sbd()
+{
+    // the reference's g_DefaultSbd (tokdll:38,124-136): sbd.bin compiled into the library, set up on first use
+    static std::mutex mu; static Handle *h = nullptr; static bool tried = false;
+    std::lock_guard<std::mutex> lock(mu);
+    if (!tried) { tried = true; h = make_handle(bf_default_sbd_begin, (size_t)(bf_default_sbd_end - bf_default_sbd_begin)); }
+    return h;
+}
 
 Handle *default_wbd()
 {
@@ -146,7 +157,7 @@ Handle *make_handle(const uint8_t *img, size_t size)
 // Enqueue the whole pipeline for a batch resident on the device.
 int run_device(Handle *h, const char *d_text, const int64_t *d_doc_off, int64_t ndocs, int64_t total_bytes,
                int32_t *d_ids_out, int64_t ids_cap, int64_t *d_id_off, int max_ids, int unk, hipStream_t s,
-               int32_t *d_starts = nullptr, int32_t *d_ends = nullptr, bool words = false)
+               int32_t *d_starts = nullptr, int32_t *d_ends = nullptr, int words = 0)
 {
     const bool want_off = d_starts && d_ends;                                  // fNeedOffsets (tokdll:1137,1381)
     if (words && (h->m.kind != KIND_WP || !want_off)) return BF_E_ARG;
@@ -177,7 +188,7 @@ int run_device(Handle *h, const char *d_text, const int64_t *d_doc_off, int64_t 
         lp.L.max_depth = m.max_depth; lp.L.max_token_length = m.max_token_length; lp.L.max_frames = m.lex_frames;
         lp.b = b; lp.cls = h->w_cls.as<uint16_t>(); lp.nchars = h->w_nchars.as<int32_t>();
         lp.ids_tmp = h->w_tmp.as<int32_t>(); lp.counts = h->w_counts.as<int32_t>(); lp.span_tmp = want_off ? h->w_span.as<int32_t>() : nullptr;
-        lp.max_ids = max_ids; lp.unk = unk; lp.next_doc = next_doc; lp.status = status; lp.ev_thresh = 0; lp.fetch_thresh = 0; lp.acts_n = (int)m.acts_pool.size(); lp.words = words ? 1 : 0;
+        lp.max_ids = max_ids; lp.unk = unk; lp.next_doc = next_doc; lp.status = status; lp.ev_thresh = 0; lp.fetch_thresh = 0; lp.acts_n = (int)m.acts_pool.size(); lp.words = words;
         lp.stats = getenv("BF_LEX_STATS") ? (unsigned long long *)(h->w_misc.as<char>() + 64) : nullptr;
         if (ndocs > 0) launch_lex_wp(lp, h->variant, s);
         (void)hipEventRecord(h->ev[EV_TOK], s);
@@ -232,7 +243,7 @@ int run_device(Handle *h, const char *d_text, const int64_t *d_doc_off, int64_t 
 }
 
 int64_t run_host(Handle *h, const char *text, const int64_t *doc_off, int64_t ndocs, int32_t *ids_out, int64_t ids_cap,
-                 int64_t *id_off_out, int max_ids, int unk, int32_t *starts_out = nullptr, int32_t *ends_out = nullptr, bool words = false)
+                 int64_t *id_off_out, int max_ids, int unk, int32_t *starts_out = nullptr, int32_t *ends_out = nullptr, int words = 0)
 {
     const bool want_off = starts_out && ends_out;
     if (ndocs < 0 || !doc_off || (ndocs > 0 && !text && doc_off[ndocs] > doc_off[0])) return BF_E_ARG;
@@ -356,7 +367,7 @@ int TextToWordsWithOffsetsWithModel(const char *s, int n, char *out, int *starts
     std::vector<int32_t> tags((size_t)n + 1), ws((size_t)n + 1), we((size_t)n + 1);
     const int64_t off[2] = {0, n};
     int64_t id_off[2] = {0, 0};
-    const int64_t w = run_host(h, s, off, 1, tags.data(), n + 1, id_off, 0x7fffffff, 0, ws.data(), we.data(), true);
+    const int64_t w = run_host(h, s, off, 1, tags.data(), n + 1, id_off, 0x7fffffff, 0, ws.data(), we.data(), 1);
     if (w < 0) { fprintf(stderr, "[blingfire_amd] TextToWords failed (%lld): %s\n", (long long)w, g_last_error.c_str()); return -1; }
     if (w == 0 && !h->last_nonempty) return -1;                                // invalid UTF-8 / nothing decoded (tokdll:477-480)
     std::string os;
@@ -378,6 +389,66 @@ int TextToWordsWithModel(const char *s, int n, char *out, const int max_out, voi
 { return TextToWordsWithOffsetsWithModel(s, n, out, nullptr, nullptr, max_out, hModel); }
 int TextToWords(const char *s, int n, char *out, const int max_out)
 { return TextToWordsWithOffsetsWithModel(s, n, out, nullptr, nullptr, max_out, nullptr); }
+
+/* ---- TextToSentences family (reference tokdll:163-402): the same GPU lexer, every token reported (Tag and From are ignored,
+ *      tokdll:262-266): a sentence ends at each token's last character and starts right after the previous one; leading white
+ *      space is dropped, '\n' inside a sentence becomes ' ', the rest of the paragraph is the last sentence. */
+static bool bf_is_ws(int c)      // blingfiretokdll.h:17-21 __FAIsWhiteSpace__
+{
+    return c <= 0x20 || c == 0xa0 || (c >= 0x2000 && c <= 0x200f) || c == 0x202f || c == 0x205f || c == 0x2060 || c == 0x2420 || c == 0x2424 ||
+           c == 0x3000 || c == 0xfeff;
+}
+int TextToSentencesWithOffsetsWithModel(const char *s, int n, char *out, int *starts, int *ends, const int max_out, void *hModel)
+{
+    Handle *h = hModel ? as_handle(hModel) : default_sbd();
+    if (!h || h->m.kind != KIND_WP) return -1;
+    if (n == 0) return 0;                                                      // tokdll:198-200
+    if (n < 0 || n > 1000000000 || !s) return -1;
+    if (starts && max_out > 0) memset(starts, 0, sizeof(int) * (size_t)max_out);   // tokdll:220-225
+    if (ends && max_out > 0) memset(ends, 0, sizeof(int) * (size_t)max_out);
+    std::vector<int32_t> tags((size_t)n + 1), ws((size_t)n + 1), we((size_t)n + 1);
+    const int64_t off[2] = {0, n};
+    int64_t id_off[2] = {0, 0};
+    const int64_t w = run_host(h, s, off, 1, tags.data(), n + 1, id_off, 0x7fffffff, 0, ws.data(), we.data(), 2);
+    if (w < 0) { fprintf(stderr, "[blingfire_amd] TextToSentences failed (%lld): %s\n", (long long)w, g_last_error.c_str()); return -1; }
+    if (w == 0 && !h->last_nonempty) return -1;                                // invalid UTF-8 / nothing decoded (tokdll:228-231)
+    const unsigned char *u = (const unsigned char *)s;
+    std::string os; os.reserve((size_t)n + 1);
+    int from = (n >= 3 && u[0] == 0xEF && u[1] == 0xBB && u[2] == 0xBF) ? 3 : 0, sents = 0; bool added = false;
+    for (int64_t k = 0; k <= w; ++k) {
+        int to;                                                                // last byte of the sentence's last character
+        if (k < w) to = we[(size_t)k];
+        else { if (!(from < n)) break; to = n - 1; }                           // tokdll:307-311
+        int q = from;                                                          // FAGetFirstNonWhiteSpace (tokdll:138-150) on the (valid) UTF-8
+        while (q <= to) {
+            const unsigned b0 = u[q]; int len = b0 < 0x80 ? 1 : b0 < 0xE0 ? 2 : b0 < 0xF0 ? 3 : 4, cp = b0;
+            if (len == 2) cp = ((b0 & 0x1F) << 6) | (u[q + 1] & 0x3F);
+            else if (len == 3) cp = ((b0 & 0x0F) << 12) | ((u[q + 1] & 0x3F) << 6) | (u[q + 2] & 0x3F);
+            else if (len == 4) cp = ((b0 & 0x07) << 18) | ((u[q + 1] & 0x3F) << 12) | ((u[q + 2] & 0x3F) << 6) | (u[q + 3] & 0x3F);
+            if (!bf_is_ws(cp)) break;                                          // (U+0000 counts as U+0020, tokdll:233)
+            q += len;
+        }
+        if (q <= to) {
+            if (starts && sents < max_out) starts[sents] = q;
+            if (ends && sents < max_out) ends[sents] = to;
+            ++sents;
+            if (added) os.push_back('\n');
+            for (int t = q; t <= to; ++t) { const char c = s[t]; os.push_back(c == '\n' ? ' ' : (c == 0 ? ' ' : c)); }
+            if (k < w) added = true;
+        }
+        from = to + 1;
+    }
+    os.push_back((char)0);
+    const int len = (int)os.size();
+    if (len <= max_out && out) memcpy(out, os.data(), (size_t)len);
+    return len;
+}
+int TextToSentencesWithOffsets(const char *s, int n, char *out, int *starts, int *ends, const int max_out)
+{ return TextToSentencesWithOffsetsWithModel(s, n, out, starts, ends, max_out, nullptr); }
+int TextToSentencesWithModel(const char *s, int n, char *out, const int max_out, void *hModel)
+{ return TextToSentencesWithOffsetsWithModel(s, n, out, nullptr, nullptr, max_out, hModel); }
+int TextToSentences(const char *s, int n, char *out, const int max_out)
+{ return TextToSentencesWithOffsetsWithModel(s, n, out, nullptr, nullptr, max_out, nullptr); }
 
 int SetNoDummyPrefix(void *p, int flag)
 {

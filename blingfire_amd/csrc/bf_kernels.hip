@@ -404,7 +404,7 @@ __global__ __launch_bounds__(THREADS) void k_lex_wp_seq(WpLexParams p)
     IdOutLds out; out.buf = lex_lds + (size_t)p.L.max_frames * LEX_FRAME_WORDS * THREADS + threadIdx.x; out.nthreads = THREADS;
     out.init(p.ids_tmp + ids_slot(b, d), p.span_tmp ? p.span_tmp + 2 * ids_slot(b, d) : nullptr);
     FramesLds frames{lex_lds, THREADS};
-    p.counts[d] = lex_doc(p.L, cls_at, n, out, cap, p.unk, frames, p.words != 0);
+    p.counts[d] = lex_doc(p.L, cls_at, n, out, cap, p.unk, frames, p.words);
 }
 
 // variant 3 (default): divergence-aware driver.  Lanes are persistent and pull documents from a global
@@ -481,7 +481,7 @@ __global__ __launch_bounds__(THREADS) void k_lex_wp_flat(WpLexParams p)
                         if (cap < 0) cap = 0;
                         cls_at.init(p.cls, b);
                         out.init(p.ids_tmp + ids_slot(b, doc), p.span_tmp ? p.span_tmp + 2 * ids_slot(b, doc) : nullptr);
-                        lane.init(n, cap, p.unk, p.words != 0);
+                        lane.init(n, cap, p.unk, p.words);
                         if (lane.prepare()) mode = M_WALK;
                         else p.counts[doc] = lane.finish();          // empty / invalid document: 0 ids, stay idle
                     }

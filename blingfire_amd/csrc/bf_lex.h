@@ -112,7 +112,7 @@ struct LexLane {
     uint32_t state, finfo; int j, lim, fp;                        // current walk (finfo: action info of the deepest final state;
                                                                   // lim: the walk goes on while the next position is < lim)
     bool stop;                                                    // nothing can change any more
-    bool words;                                                   // TextToWords mode: raw <tag,from,to> tokens instead of the _wp post-pass
+    int words;                                                    // 0: ids (_wp post-pass); 1: TextToWords (raw non-IGNORE <tag,from,to> tokens); 2: TextToSentences (all of them)
 
     BF_HD LexLane(const LexTables &L_, ClsAt &c, IdOut &o, Frames &f) : L(L_), cls_at(c), ids(o), frames(f), tab{L_.T} {}
     BF_HD LexLane(const LexTables &L_, ClsAt &c, IdOut &o, Frames &f, const Tab &t) : L(L_), cls_at(c), ids(o), frames(f), tab(t) {}
@@ -146,7 +146,7 @@ struct LexLane {
     }
 
     // Start a document of n normalised characters.  Follow with prepare().
-    BF_HD void init(int n, int max_ids_, int unk_, bool words_ = false)
+    BF_HD void init(int n, int max_ids_, int unk_, int words_ = 0)
     {
         max_ids = max_ids_; unk = unk_; words = words_;
         out_count = 0; scanning = 0; tok_from = tok_to = expected = nsub = word_out = 0;
@@ -265,7 +265,7 @@ struct LexLane {
             if (emitted >= max_triples) { stop = true; return; }      // output buffer full (FALexTools_t.h:337-340)
             ++emitted; last_to = to2 + off;
             if (words) {                                              // every non-IGNORE token is a word (tokdll:511-517)
-                if (tag != WBD_IGNORE_TAG && out_count < max_ids) { ids.put(out_count, tag); ids.span(out_count, from2 + off, to2 + off); ++out_count; }
+                if ((words == 2 || tag != WBD_IGNORE_TAG) && out_count < max_ids) { ids.put(out_count, tag); ids.span(out_count, from2 + off, to2 + off); ++out_count; }
             } else if (!sink_push(tag, from2 + off, to2 + off)) { stop = true; return; }   // id array full (tokdll:1308-1310)
         }
         fn_from = from2;                                              // FALexTools_t.h:347
@@ -304,7 +304,7 @@ struct LexLane {
 
 // Sequential driver (host emulation).  Returns the number of ids written (<= max_ids).
 template <bool HAS_ANY, class ClsAt, class IdOut, class Frames>
-BF_HD int lex_doc_t(const LexTables &L, ClsAt &cls_at, int n, IdOut &out, int max_ids, int unk, Frames &frames, bool words = false)
+BF_HD int lex_doc_t(const LexTables &L, ClsAt &cls_at, int n, IdOut &out, int max_ids, int unk, Frames &frames, int words = 0)
 {
     LexLane<ClsAt, IdOut, Frames, HAS_ANY> lane(L, cls_at, out, frames);
     lane.init(n, max_ids, unk, words);
@@ -316,7 +316,7 @@ BF_HD int lex_doc_t(const LexTables &L, ClsAt &cls_at, int n, IdOut &out, int ma
 }
 
 template <class ClsAt, class IdOut, class Frames>
-BF_HD int lex_doc(const LexTables &L, ClsAt &cls_at, int n, IdOut &out, int max_ids, int unk, Frames &frames, bool words = false)
+BF_HD int lex_doc(const LexTables &L, ClsAt &cls_at, int n, IdOut &out, int max_ids, int unk, Frames &frames, int words = 0)
 {
     return L.cls_any != LX_CLS_NONE ? lex_doc_t<true>(L, cls_at, n, out, max_ids, unk, frames, words)
                                     : lex_doc_t<false>(L, cls_at, n, out, max_ids, unk, frames, words);

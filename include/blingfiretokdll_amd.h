@@ -74,6 +74,18 @@ int TextToWordsWithOffsets(const char *pInUtf8Str, int InUtf8StrByteCount, char 
 int TextToWordsWithOffsetsWithModel(const char *pInUtf8Str, int InUtf8StrByteCount, char *pOutUtf8Str, int *pStartOffsets,
                                     int *pEndOffsets, const int MaxOutUtf8StrByteCount, void *hModel);
 
+/* reference tokdll:163-402 (blingfiretokdll.def: TextToSentences, TextToSentencesWithModel, TextToSentencesWithOffsets,
+ * TextToSentencesWithOffsetsWithModel): sentence breaking with the model behind hModel (a LoadModel handle of a [wbd]-type
+ * model such as sbd.bin; NULL = the built-in sbd.bin, embedded like the reference embeds it).  Output = sentences joined by
+ * '\n' (a '\n' inside a sentence -> ' ', leading white space dropped) + terminating 0; same return convention and offset
+ * arrays as TextToWords.  The sentence boundaries come from the GPU lexer; only the output string is assembled on the host. */
+int TextToSentences(const char *pInUtf8Str, int InUtf8StrByteCount, char *pOutUtf8Str, const int MaxOutUtf8StrByteCount);
+int TextToSentencesWithModel(const char *pInUtf8Str, int InUtf8StrByteCount, char *pOutUtf8Str, const int MaxOutUtf8StrByteCount, void *hModel);
+int TextToSentencesWithOffsets(const char *pInUtf8Str, int InUtf8StrByteCount, char *pOutUtf8Str, int *pStartOffsets, int *pEndOffsets,
+                               const int MaxOutUtf8StrByteCount);
+int TextToSentencesWithOffsetsWithModel(const char *pInUtf8Str, int InUtf8StrByteCount, char *pOutUtf8Str, int *pStartOffsets,
+                                        int *pEndOffsets, const int MaxOutUtf8StrByteCount, void *hModel);
+
 /* reference tokdll:1669-1679 */
 int SetNoDummyPrefix(void *ModelPtr, int fNoDummyPrefix);
 

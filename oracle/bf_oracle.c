@@ -1079,6 +1079,53 @@ int bfo_text_to_words_with_offsets(const bfo_model *m, const char *s, int n, cha
     return pos;
 }
 
+/* tokdll:163-355 TextToSentencesWithOffsetsWithModel: every triple's To ends a sentence (Tag and From are ignored,
+ * tokdll:262-266), a sentence starts right after the previous one, leading white space is dropped (tokdll:138-150,270),
+ * '\n' inside a sentence becomes ' ' (tokdll:296), the rest of the paragraph is the last sentence (tokdll:307-339) */
+int bfo_text_to_sentences_with_offsets(const bfo_model *m, const char *s, int n, char *out, int *starts, int *ends, int max_out)
+{
+    int *buf, *offs, *res, len, res_size, i, sents = 0, added = 0, pos = 0, prev_end = -1, pass;
+    char *tmp;
+    if (!m || !m->has_wbd) return -1;
+    if (n == 0) return 0;
+    if (n < 0 || n > MAX_ARR_SIZE || !s) return -1;
+    buf = (int *)malloc(sizeof(int) * (size_t)n);
+    offs = (int *)malloc(sizeof(int) * (size_t)n);
+    if (starts) memset(starts, 0, sizeof(int) * (size_t)(max_out > 0 ? max_out : 0));   /* tokdll:220-225 */
+    if (ends) memset(ends, 0, sizeof(int) * (size_t)(max_out > 0 ? max_out : 0));
+    len = utf8_to_utf32_off(s, n, buf, offs, n);
+    if (len <= 0 || len > n) { free(buf); free(offs); return -1; }
+    for (i = 0; i < len; ++i) if (buf[i] == 0) buf[i] = 0x20;                           /* tokdll:233 */
+    res = (int *)calloc((size_t)len * 3 + 8, sizeof(int));
+    res_size = bfo_lex_process(m, buf, len, res, len * 3);
+    if (res_size > len * 3 || res_size % 3 != 0 || res_size < 0) { free(buf); free(offs); free(res); return -1; }
+    tmp = (char *)malloc(4 * (size_t)len + (size_t)len + 8);
+    for (pass = 0; pass <= res_size; pass += 3) {
+        int from, to, sl, delta, k;
+        if (pass < res_size) { from = prev_end + 1; to = res[pass + 2]; prev_end = to; }
+        else { if (!(prev_end + 1 < len)) break; from = prev_end + 1; to = len - 1; }  /* tokdll:307-311 */
+        sl = to - from + 1;
+        for (delta = 0; delta < sl && is_ws(buf[from + delta]); ++delta) {}
+        if (!(delta < sl)) continue;
+        if (starts && sents < max_out) starts[sents] = offs[from + delta];
+        if (ends && sents < max_out) { int sz = utf8_size_at(s + offs[to]); ends[sents] = offs[to] + (0 < sz ? sz - 1 : 0); }
+        sents++;
+        if (added) tmp[pos++] = '\n';
+        for (k = from + delta; k <= to; ++k) {                                          /* FAArrayToStrUtf8 cl/src/FAUtf8Utils.cpp:530-557 */
+            unsigned c = (unsigned)buf[k];
+            if (c < 0x80) tmp[pos++] = (char)(c == '\n' ? ' ' : c);                     /* tokdll:296 */
+            else if (c < 0x800) { tmp[pos++] = (char)(0xC0 | (c >> 6)); tmp[pos++] = (char)(0x80 | (c & 0x3F)); }
+            else if (c < 0x10000) { tmp[pos++] = (char)(0xE0 | (c >> 12)); tmp[pos++] = (char)(0x80 | ((c >> 6) & 0x3F)); tmp[pos++] = (char)(0x80 | (c & 0x3F)); }
+            else { tmp[pos++] = (char)(0xF0 | (c >> 18)); tmp[pos++] = (char)(0x80 | ((c >> 12) & 0x3F)); tmp[pos++] = (char)(0x80 | ((c >> 6) & 0x3F)); tmp[pos++] = (char)(0x80 | (c & 0x3F)); }
+        }
+        if (pass < res_size) added = 1;
+    }
+    tmp[pos++] = 0;
+    if (pos <= max_out && out) memcpy(out, tmp, (size_t)pos);
+    free(buf); free(offs); free(res); free(tmp);
+    return pos;
+}
+
 /* ---------------- exported building blocks ---------------- */
 
 static const dfa_t *pick(const bfo_model *m, int which) { return which ? &m->dict_dfa : &m->wbd_dfa; }

@@ -47,6 +47,9 @@ int bfo_text_to_ids_with_offsets(const bfo_model *m, const char *utf8, int n,
 /* tokdll:415-566 TextToWordsWithOffsetsWithModel (the model is explicit here; the reference's NULL = its built-in wbd.bin) */
 int bfo_text_to_words_with_offsets(const bfo_model *m, const char *utf8, int n, char *out, int *starts, int *ends, int max_out);
 
+/* tokdll:163-355 TextToSentencesWithOffsetsWithModel (the model is explicit here; the reference's NULL = its built-in sbd.bin) */
+int bfo_text_to_sentences_with_offsets(const bfo_model *m, const char *utf8, int n, char *out, int *starts, int *ends, int max_out);
+
 /* tokdll:1669-1679 SetNoDummyPrefix */
 int bfo_set_no_dummy_prefix(bfo_model *m, int flag);
 

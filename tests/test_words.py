@@ -137,3 +137,70 @@ def test_gpu_python_mirror_words():
         assert bf.text_to_words_with_model(h, "unaffable!") == "unaffable un af fa ble ! !"   # word and sub-word tokens both reported
     finally:
         bf.free_model(h)
+
+
+# ---- TextToSentences family (reference tokdll:163-402): same machinery, every token ends a sentence
+
+SENT_MODELS = ["sbd.bin", "wbd.bin"]
+SENT_DOCS = [b"Hello world. This is a test! Is it? Yes.\nNew line here. And Mr. Smith went to Washington D.C. yesterday.",
+             b"  leading. trailing  ", "Привет мир. Как дела? 好的。谢谢".encode(), b"No terminator", b"One. Two.\n\nThree.\x00Four."]
+
+
+def _oracle_sent_fn():
+    ora = bfutil.oracle()
+    f = ora.lib.bfo_text_to_sentences_with_offsets
+    f.restype = ctypes.c_int
+    f.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+    return ora, f
+
+
+def test_sentences_readme_known_answer():
+    """reference README.md:60-75: text_to_sentences on the built-in model"""
+    ora, f = _oracle_sent_fn()
+    h = ora.load(bfutil.model_path("sbd.bin"))
+    s = ("After reading this post, you will know: What \"natural language\" is and how it is different from other types of data. "
+         "What makes working with natural language so challenging. [1]").encode()
+    r, out, _, _ = _call(f, (ctypes.c_void_p(h),), s, 4 * len(s))
+    assert out[:r - 1].decode() == ("After reading this post, you will know: What \"natural language\" is and how it is different from other types of data.\n"
+                                    "What makes working with natural language so challenging. [1]")
+    ora.free(h)
+
+
+@pytest.mark.skipif(not bfutil.have_ref(), reason="oracle/_ref not built (needs /root/reference)")
+@pytest.mark.parametrize("model", SENT_MODELS + [None])
+def test_oracle_sentences_vs_live_reference(model):
+    ora, f = _oracle_sent_fn()
+    ref = bfutil.reference()
+    g = ref.lib.TextToSentencesWithOffsetsWithModel
+    g.restype = ctypes.c_int
+    g.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+    ho = ora.load(bfutil.model_path(model or "sbd.bin"))
+    hr = ref.load(bfutil.model_path(model)) if model else None      # None = the reference's built-in model
+    for k, b in enumerate(_docs(1500, 83) + SENT_DOCS):
+        mx = (4 * len(b) + 8, 5, 0)[k % 3]
+        assert _call(f, (ctypes.c_void_p(ho),), b, mx) == _call(g, (), b, mx, (ctypes.c_void_p(hr) if hr else None,)), (model, b[:60], mx)
+    ora.free(ho)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("model", SENT_MODELS + [None])
+def test_gpu_text_to_sentences(model):
+    import blingfire_amd as bf
+    L = bf.lib()
+    g = L.TextToSentencesWithOffsetsWithModel
+    ora, f = _oracle_sent_fn()
+    ho = ora.load(bfutil.model_path(model or "sbd.bin"))
+    h = bf.load_model(bfutil.model_path(model)) if model else None
+    try:
+        for k, b in enumerate(_docs(400, 89) + SENT_DOCS):
+            mx = (4 * len(b) + 8, 5, 0)[k % 3]
+            assert _call(g, (), b, mx, (ctypes.c_void_p(h) if h else None,)) == _call(f, (ctypes.c_void_p(ho),), b, mx), (model, b[:60], mx)
+        if model is None:
+            s = "Hello wörld. This is a test! Is it?"
+            assert bf.text_to_sentences(s) == "Hello wörld.\nThis is a test!\nIs it?"
+            sents, spans = bf.text_to_sentences_and_offsets(s)
+            assert [s[b:e] for b, e in spans] == sents.split("\n")
+    finally:
+        if h:
+            bf.free_model(h)
+        ora.free(ho)
