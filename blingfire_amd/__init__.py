@@ -72,6 +72,12 @@ def lib():
         L.TextToSentencesWithOffsets.argtypes = [c_char_p, c_int, c_void_p, c_void_p, c_void_p, c_int]
         L.TextToSentencesWithOffsetsWithModel.restype = c_int
         L.TextToSentencesWithOffsetsWithModel.argtypes = [c_char_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p]
+        L.IdsToText.restype = c_int
+        L.IdsToText.argtypes = [c_void_p, c_void_p, c_int, c_void_p, c_int, ctypes.c_bool]
+        L.IdsToTextBatch.restype = c_int64
+        L.IdsToTextBatch.argtypes = [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int]
+        L.IdsToTextBatchDevice.restype = c_int
+        L.IdsToTextBatchDevice.argtypes = [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int, c_void_p]
         L.BfLastKernelMs.restype = c_int
         L.BfLastKernelMs.argtypes = [c_void_p, POINTER(c_float), c_int]
         L.BfLastStatus.restype = c_int
@@ -187,6 +193,37 @@ def text_to_sentences_and_offsets(s, h=None):
     return sents, [(int(char_at[st[i]]), int(char_at[en[i] + 1])) for i in range(k)]
 
 
+def ids_to_text(h, ids, skip_special_tokens=True, output_buffer_size=None):
+    """reference __init__.py:256-269: text of an id array (numpy int32 / uint32); '' on error or if the buffer is too small."""
+    ids = np.ascontiguousarray(ids).view(np.int32) if isinstance(ids, np.ndarray) and ids.dtype.itemsize == 4 else np.asarray(ids, dtype=np.int32)
+    if output_buffer_size is None:
+        output_buffer_size = len(ids) * 32
+    o = ctypes.create_string_buffer(max(output_buffer_size, 1))
+    n = lib().IdsToText(c_void_p(h), c_void_p(ids.ctypes.data), len(ids), o, output_buffer_size, bool(skip_special_tokens))
+    if n == -1 or n > output_buffer_size:
+        return ""
+    return o.value.decode("utf-8")
+
+
+def ids_to_text_batch(h, ids, id_off, skip_special_tokens=True):
+    """additive: (text bytes as uint8 array, text offsets int64[nseq+1]) for many id sequences at once (IdsToTextBatch)."""
+    ids = np.ascontiguousarray(ids, dtype=np.int32)
+    id_off = np.ascontiguousarray(id_off, dtype=np.int64)
+    nseq = len(id_off) - 1
+    t_off = np.zeros(nseq + 1, dtype=np.int64)
+    n = lib().IdsToTextBatch(c_void_p(h), c_void_p(ids.ctypes.data), c_void_p(id_off.ctypes.data), nseq, None, 0, c_void_p(t_off.ctypes.data),
+                             int(bool(skip_special_tokens)))
+    if n == -3:                                           # BF_E_CAPACITY: the offsets tell the size
+        text = np.empty(int(t_off[-1]), dtype=np.uint8)
+        n = lib().IdsToTextBatch(c_void_p(h), c_void_p(ids.ctypes.data), c_void_p(id_off.ctypes.data), nseq, c_void_p(text.ctypes.data), len(text),
+                                 c_void_p(t_off.ctypes.data), int(bool(skip_special_tokens)))
+    else:
+        text = np.empty(0, dtype=np.uint8)
+    if n < 0:
+        raise RuntimeError("IdsToTextBatch failed: %d (%s)" % (n, lib().BfLastError().decode("utf-8", "replace")))
+    return text, t_off
+
+
 def change_settings_dummy_prefix(h, add_prefix):
     lib().SetNoDummyPrefix(c_void_p(h), int(not add_prefix))
 
@@ -264,6 +301,23 @@ def text_to_ids_batch_device(h, d_text, d_doc_off, max_len, unk=0, out_ids=None,
     if r != 0:
         raise RuntimeError("TextToIdsBatchDevice failed (%d): %s" % (r, lib().BfLastError().decode("utf-8", "replace")))
     return out_ids, out_off
+
+
+def ids_to_text_batch_device(h, d_ids, d_id_off, out_text=None, out_off=None, skip_special_tokens=True, stream=None):
+    """Device-resident IdsToText: torch int32 ids + int64 offsets on the model's GPU -> (text uint8[cap], text offsets int64[nseq+1]).
+    Without `out_text` a buffer of 16 bytes per id is used (IdsToTextBatchDevice never writes past it)."""
+    import torch
+    nseq = d_id_off.numel() - 1
+    if out_text is None:
+        out_text = torch.empty(max(16 * d_ids.numel(), 1), dtype=torch.uint8, device=d_ids.device)
+    if out_off is None:
+        out_off = torch.empty(nseq + 1, dtype=torch.int64, device=d_ids.device)
+    s = stream if stream is not None else torch.cuda.current_stream(d_ids.device).cuda_stream
+    r = lib().IdsToTextBatchDevice(c_void_p(h), d_ids.data_ptr(), d_id_off.data_ptr(), nseq, out_text.data_ptr(), out_text.numel(),
+                                   out_off.data_ptr(), int(bool(skip_special_tokens)), c_void_p(s))
+    if r != 0:
+        raise RuntimeError("IdsToTextBatchDevice failed (%d): %s" % (r, lib().BfLastError().decode("utf-8", "replace")))
+    return out_text, out_off
 
 
 def last_kernel_ms(h):

@@ -62,7 +62,7 @@ struct Handle {
     int variant = 3;
     std::mutex mu;
     // device tables
-    DevBuf t_wbd, t_info, t_acts, t_cp_l1, t_cp_pages, t_multi;
+    DevBuf t_wbd, t_info, t_acts, t_cp_l1, t_cp_pages, t_multi, t_i2w_off, t_i2w_data;
     DevBuf t_wcp_l1, t_wcp_pages;                                // TextToWords: code point -> class without the charmap
     DevBuf t_dict, t_seginfo;                                    // _sp: Mealy table, I2Info rows (code-point maps reuse t_cp_*/t_multi)
     DevBuf w_s1, w_s2, w_s3, w_s4, w_perm, w_hist, w_narcs;      // _sp scratch
@@ -76,7 +76,7 @@ struct Handle {
     bool last_nonempty = false;                                 // TextToWords: the (single) document decoded to >= 1 character
     ~Handle()
     {
-        for (DevBuf *b : {&t_wbd, &t_info, &t_acts, &t_cp_l1, &t_cp_pages, &t_multi, &t_wcp_l1, &t_wcp_pages, &t_dict, &t_seginfo, &w_s1, &w_s2, &w_s3, &w_s4, &w_perm, &w_hist, &w_narcs, &w_cls, &w_nchars, &w_tmp, &w_counts, &w_flags,
+        for (DevBuf *b : {&t_i2w_off, &t_i2w_data, &t_wbd, &t_info, &t_acts, &t_cp_l1, &t_cp_pages, &t_multi, &t_wcp_l1, &t_wcp_pages, &t_dict, &t_seginfo, &w_s1, &w_s2, &w_s3, &w_s4, &w_perm, &w_hist, &w_narcs, &w_cls, &w_nchars, &w_tmp, &w_counts, &w_flags,
                           &w_bsums, &w_misc, &w_text, &w_docoff, &w_ids, &w_idoff, &w_starts, &w_ends, &w_srcoff, &w_span}) b->release();
         for (auto &e : ev) if (e) (void)hipEventDestroy(e);
         if (stream) (void)hipStreamDestroy(stream);
@@ -143,10 +143,11 @@ Handle *make_handle(const uint8_t *img, size_t size)
         ok = ok && upload(h->t_wbd, m.wbd_t2, 16) && upload(h->t_acts, m.acts_pool, 16) &&
              upload(h->t_cp_l1, m.wbd_cpmap.l1) && upload(h->t_cp_pages, m.wbd_cpmap.pages) && upload(h->t_multi, m.wbd_multi_pool, 16) &&
              upload(h->t_wcp_l1, m.words_cpmap.l1) && upload(h->t_wcp_pages, m.words_cpmap.pages);
-    } else {
+    } else if (m.kind != KIND_I2W) {
         ok = ok && upload(h->t_dict, m.dict.t64, 16) && upload(h->t_seginfo, m.seg_info, 16) &&
              upload(h->t_cp_l1, m.sp_cpmap.l1) && upload(h->t_cp_pages, m.sp_cpmap.pages) && upload(h->t_multi, m.sp_multi_pool, 16);
     }
+    if (m.has_i2w) ok = ok && upload(h->t_i2w_off, m.i2w_off, 4) && upload(h->t_i2w_data, m.i2w_data, 16);
     ok = ok && hip_ok(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking), "hipStreamCreate");
     for (auto &e : h->ev) ok = ok && hip_ok(hipEventCreate(&e), "hipEventCreate");
     ok = ok && h->w_misc.reserve(256) && hip_ok(hipMemset(h->w_misc.p, 0, 256), "hipMemset");
@@ -160,6 +161,7 @@ int run_device(Handle *h, const char *d_text, const int64_t *d_doc_off, int64_t 
                int32_t *d_starts = nullptr, int32_t *d_ends = nullptr, int words = 0)
 {
     const bool want_off = d_starts && d_ends;                                  // fNeedOffsets (tokdll:1137,1381)
+    if (h->m.kind == KIND_I2W) return BF_E_UNSUPPORTED;                        // an [i2w]-only model has no tokenizer
     if (words && (h->m.kind != KIND_WP || !want_off)) return BF_E_ARG;
     if (ndocs < 0 || total_bytes < 0 || !d_doc_off || !d_id_off || (ids_cap > 0 && !d_ids_out) || (total_bytes > 0 && !d_text)) return BF_E_ARG;
     if (max_ids < 0) max_ids = 0;
@@ -289,6 +291,68 @@ int64_t run_host(Handle *h, const char *text, const int64_t *doc_off, int64_t nd
                          !hip_ok(hipMemcpy(ends_out, h->w_ends.p, (size_t)nids * 4, hipMemcpyDeviceToHost), "D2H ends"))) return BF_E_DEVICE;
     }
     return nids;
+}
+
+// IdsToText on device buffers: lengths -> scan -> byte gather (bf_kernels.hip).  d_text may be NULL to size only.
+int run_i2t_device(Handle *h, const int32_t *d_ids, const int64_t *d_id_off, int64_t nseq, char *d_text, int64_t text_cap,
+                   int64_t *d_text_off, int skip_special, hipStream_t s)
+{
+    const Model &m = h->m;
+    if (!m.has_i2w) return BF_E_UNSUPPORTED;
+    if (nseq < 0 || !d_id_off || !d_text_off) return BF_E_ARG;
+    const int nblocks = scan_nblocks(nseq);
+    if (!h->w_counts.reserve((size_t)(nseq + 1) * 4) || !h->w_bsums.reserve((size_t)(nblocks + 1) * 8)) return BF_E_DEVICE;
+    I2tParams p;
+    p.tok_off = h->t_i2w_off.as<uint32_t>(); p.tok_data = h->t_i2w_data.as<uint8_t>(); p.ntok = (int)m.i2w_off.size() - 1;
+    p.min_id = m.min_token_id; p.max_id = m.max_token_id; p.skip_special = skip_special ? 1 : 0;
+    p.ids = d_ids; p.id_off = d_id_off; p.nseq = nseq; p.lens = h->w_counts.as<int32_t>();
+    p.text_off = d_text_off; p.text = (uint8_t *)d_text; p.text_cap = text_cap; p.status = (int *)(h->w_misc.as<char>() + 16);
+    if (nseq > 0 && !d_text) launch_i2t_len(p, s);
+    if (!d_text) {
+        ScanParams sp{h->w_counts.as<int32_t>(), nseq, d_text_off, h->w_bsums.as<int64_t>(), nblocks};
+        launch_scan(sp, s);
+    } else if (nseq > 0) launch_i2t_copy(p, s);
+    return hip_ok(hipGetLastError(), "IdsToText kernels") ? 0 : BF_E_DEVICE;
+}
+
+// host buffers: text of sequence d = text_out[text_off_out[d] .. text_off_out[d+1]); returns the total byte count
+int64_t run_i2t_host(Handle *h, const int32_t *ids, const int64_t *id_off, int64_t nseq, char *text_out, int64_t text_cap,
+                     int64_t *text_off_out, int skip_special, bool *unknown_id = nullptr)
+{
+    if (!h->m.has_i2w) return BF_E_UNSUPPORTED;
+    if (nseq < 0 || !id_off || (nseq > 0 && id_off[nseq] > id_off[0] && !ids)) return BF_E_ARG;
+    const int64_t base = id_off[0], total_ids = nseq > 0 ? id_off[nseq] - base : 0;
+    if (total_ids < 0) return BF_E_ARG;
+    std::lock_guard<std::mutex> lock(h->mu);
+    if (!hip_ok(hipSetDevice(h->device), "hipSetDevice")) return BF_E_DEVICE;
+    hipStream_t s = h->stream;
+    if (!h->w_ids.reserve((size_t)(total_ids + 1) * 4) || !h->w_docoff.reserve((size_t)(nseq + 1) * 8) || !h->w_idoff.reserve((size_t)(nseq + 1) * 8)) return BF_E_DEVICE;
+    std::vector<int64_t> rel((size_t)nseq + 1);
+    for (int64_t i = 0; i <= nseq; ++i) rel[(size_t)i] = id_off[i] - base;
+    if (!hip_ok(hipMemsetAsync(h->w_misc.p, 0, 64, s), "hipMemsetAsync")) return BF_E_DEVICE;
+    if (total_ids > 0 && !hip_ok(hipMemcpyAsync(h->w_ids.p, ids + base, (size_t)total_ids * 4, hipMemcpyHostToDevice, s), "H2D ids")) return BF_E_DEVICE;
+    if (!hip_ok(hipMemcpyAsync(h->w_docoff.p, rel.data(), (size_t)(nseq + 1) * 8, hipMemcpyHostToDevice, s), "H2D offsets")) return BF_E_DEVICE;
+    int rc = run_i2t_device(h, h->w_ids.as<int32_t>(), h->w_docoff.as<int64_t>(), nseq, nullptr, 0, h->w_idoff.as<int64_t>(), skip_special, s);
+    if (rc != 0) return rc;
+    std::vector<int64_t> tmp_off;
+    int64_t *dst_off = text_off_out;
+    if (!dst_off) { tmp_off.resize((size_t)nseq + 1); dst_off = tmp_off.data(); }
+    int status = 0;
+    if (!hip_ok(hipMemcpyAsync(dst_off, h->w_idoff.p, (size_t)(nseq + 1) * 8, hipMemcpyDeviceToHost, s), "D2H offsets") ||
+        !hip_ok(hipMemcpyAsync(&status, h->w_misc.as<char>() + 16, 4, hipMemcpyDeviceToHost, s), "D2H status") ||
+        !hip_ok(hipStreamSynchronize(s), "hipStreamSynchronize")) return BF_E_DEVICE;
+    if (unknown_id) *unknown_id = (status & 4) != 0;
+    const int64_t total = dst_off[nseq];
+    if (total > text_cap) return BF_E_CAPACITY;
+    if (total > 0) {
+        if (!text_out) return BF_E_ARG;
+        if (!h->w_text.reserve((size_t)total + 16)) return BF_E_DEVICE;
+        rc = run_i2t_device(h, h->w_ids.as<int32_t>(), h->w_docoff.as<int64_t>(), nseq, h->w_text.as<char>(), total, h->w_idoff.as<int64_t>(), skip_special, s);
+        if (rc != 0) return rc;
+        if (!hip_ok(hipMemcpyAsync(text_out, h->w_text.p, (size_t)total, hipMemcpyDeviceToHost, s), "D2H text") ||
+            !hip_ok(hipStreamSynchronize(s), "hipStreamSynchronize")) return BF_E_DEVICE;
+    }
+    return total;
 }
 
 int text_to_ids_one(void *hp, const char *s, int n, int32_t *ids, int max_ids, int unk, int want_kind /* -1 any, 0 wp, 1 sp */,
@@ -449,6 +513,50 @@ int TextToSentencesWithModel(const char *s, int n, char *out, const int max_out,
 { return TextToSentencesWithOffsetsWithModel(s, n, out, nullptr, nullptr, max_out, hModel); }
 int TextToSentences(const char *s, int n, char *out, const int max_out)
 { return TextToSentencesWithOffsetsWithModel(s, n, out, nullptr, nullptr, max_out, nullptr); }
+
+/* ---- IdsToText (reference tokdll:1689-1745) and its batch forms: a variable-length byte gather on the GPU */
+int IdsToText(void *p, const int32_t *ids, const int n, char *out, const int max_out, bool skip_special)
+{
+    Handle *h = as_handle(p);
+    if (!h) return 0;
+    if (n == 0 || !ids) return 0;
+    if (!h->m.has_i2w || n < 0) return 0;
+    const int64_t off[2] = {0, n};
+    int64_t toff[2] = {0, 0};
+    std::vector<char> tmp;
+    bool unknown = false;
+    // the text is assembled on the device at full length; what fits is handed to the caller
+    int64_t r = run_i2t_host(h, ids, off, 1, nullptr, 0, toff, skip_special ? 1 : 0, &unknown);
+    if (r == BF_E_CAPACITY) { tmp.resize((size_t)toff[1]); r = run_i2t_host(h, ids, off, 1, tmp.data(), toff[1], toff, skip_special ? 1 : 0, &unknown); }
+    if (r < 0) { fprintf(stderr, "[blingfire_amd] IdsToText failed (%lld): %s\n", (long long)r, g_last_error.c_str()); return 0; }
+    if (unknown) return 0;                                                     // unknown id (tokdll:1719-1721)
+    const int64_t len = toff[1];
+    if (out && max_out > 0 && len > 0) memcpy(out, tmp.data(), (size_t)std::min<int64_t>(len, max_out));
+    if (out && max_out > len) out[len] = 0;                                    // tokdll:1737-1739
+    return (int)(len + 1);
+}
+
+int64_t IdsToTextBatch(void *p, const int32_t *ids, const int64_t *id_offsets, int64_t nseq, char *text_out, int64_t text_cap,
+                       int64_t *text_offsets_out, int skip_special)
+{
+    Handle *h = as_handle(p);
+    if (!h) return BF_E_ARG;
+    return run_i2t_host(h, ids, id_offsets, nseq, text_out, text_cap, text_offsets_out, skip_special);
+}
+
+int IdsToTextBatchDevice(void *p, const int32_t *d_ids, const int64_t *d_id_offsets, int64_t nseq, char *d_text_out, int64_t text_cap,
+                         int64_t *d_text_offsets_out, int skip_special, void *stream)
+{
+    Handle *h = as_handle(p);
+    if (!h) return BF_E_ARG;
+    std::lock_guard<std::mutex> lock(h->mu);
+    if (!hip_ok(hipSetDevice(h->device), "hipSetDevice")) return BF_E_DEVICE;
+    hipStream_t s = (hipStream_t)stream;
+    if (!hip_ok(hipMemsetAsync(h->w_misc.p, 0, 64, s), "hipMemsetAsync")) return BF_E_DEVICE;
+    int rc = run_i2t_device(h, d_ids, d_id_offsets, nseq, nullptr, 0, d_text_offsets_out, skip_special, s);
+    if (rc != 0 || !d_text_out) return rc;
+    return run_i2t_device(h, d_ids, d_id_offsets, nseq, d_text_out, text_cap, d_text_offsets_out, skip_special, s);
+}
 
 int SetNoDummyPrefix(void *p, int flag)
 {

@@ -100,6 +100,19 @@ void launch_lex_wp(const WpLexParams &p, int variant, hipStream_t s);
 void launch_prep_sp(const SpPrepParams &p, hipStream_t s);
 void launch_seg_sp(const SpSegParams &p, hipStream_t s);
 void launch_scan(const ScanParams &p, hipStream_t s);
+
+// IdsToText (reference tokdll:1689-1745) as a batch: ids of sequence d are ids[id_off[d] .. id_off[d+1])
+struct I2tParams {
+    const uint32_t *tok_off; const uint8_t *tok_data; int ntok;   // [i2w] string array
+    int min_id, max_id, skip_special;
+    const int32_t *ids; const int64_t *id_off; int64_t nseq;
+    int32_t *lens;               // [nseq] bytes of text per sequence (no terminator); 0 for an empty / failed sequence
+    const int64_t *text_off;     // [nseq + 1] exclusive scan of lens (copy pass)
+    uint8_t *text; int64_t text_cap;
+    int *status;                 // bit 2: a sequence contains an id the model does not know (the reference returns 0 for it)
+};
+void launch_i2t_len(const I2tParams &p, hipStream_t s);
+void launch_i2t_copy(const I2tParams &p, hipStream_t s);
 void launch_compact(const CompactParams &p, hipStream_t s);
 int scan_nblocks(int64_t ndocs);
 

@@ -1485,6 +1485,108 @@ void launch_seg_sp(const SpSegParams &p_in, hipStream_t s)
 }
 
 // ------------------------------------------------------------------------------------------
+// IdsToText (reference tokdll:1689-1745), batch form: a variable-length byte gather.  Wave per sequence, 64 ids per
+// iteration.  The reference's one sequential rule -- "no space in the leading position": while nothing has been written,
+// a token loses one leading 0x20 -- only ever touches the tokens up to and including the first one that is neither
+// skipped, empty nor exactly " " (the ones before it vanish, it loses its leading space if it has one), so a uniform
+// `found` flag carried across iterations reproduces it.
+//   k_i2t_len   bytes per sequence (0 if it contains an unknown id)         -> scan -> text offsets
+//   k_i2t_copy  per iteration the 64 token lengths are prefix-summed in LDS; then byte b of the iteration's output is
+//               copied by lane b mod 64 (binary search of its token in the 64 prefix sums): stores are whole rows
+// ------------------------------------------------------------------------------------------
+struct I2tTok { int len; uint32_t src; bool bad; };
+
+// token `i` of the sequence [b, e): its length / source offset after the skip rule and the leading-space rule
+__device__ __forceinline__ I2tTok i2t_token(const I2tParams &p, int64_t i, int64_t e, bool &found)
+{
+    I2tTok t; t.len = 0; t.src = 0; t.bad = false;
+    bool solid = false, sp = false;
+    if (i < e) {
+        const int id = p.ids[i];
+        const bool skip = p.skip_special && (id < p.min_id || id > p.max_id);          // tokdll:1712-1714
+        if (!skip) {
+            if (id < 0 || id >= p.ntok) t.bad = true;                                     // unknown id: the call returns 0 (tokdll:1719-1721)
+            else {
+                const uint32_t o0 = p.tok_off[id], o1 = p.tok_off[id + 1];
+                t.len = (int)(o1 - o0); t.src = o0;
+                sp = t.len > 0 && p.tok_data[o0] == 0x20;
+                solid = t.len > 0 && !(t.len == 1 && sp);
+            }
+        }
+    }
+    // leading-space rule (tokdll:1724-1728), resolved across the wave
+    const unsigned long long ms = __ballot(solid);
+    if (!found) {
+        const int first = ms ? __ffsll((long long)ms) - 1 : 64;
+        const int l = lane_id();
+        if (l < first) t.len = 0;                                   // empty or " " before anything was written: nothing
+        else if (l == first && sp) { t.len -= 1; t.src += 1; }
+        if (ms) found = true;
+    }
+    return t;
+}
+
+__global__ __launch_bounds__(256) void k_i2t_len(I2tParams p)
+{
+    const int lane = lane_id();
+    const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (int64_t)gridDim.x * 4;
+    for (int64_t d = wave0; d < p.nseq; d += nwaves) {
+        const int64_t b = p.id_off[d], e = p.id_off[d + 1];
+        bool found = false, bad = false; long long total = 0;
+        for (int64_t i0 = b; i0 < e; i0 += 64) {
+            const I2tTok t = i2t_token(p, i0 + lane, e, found);
+            bad |= t.bad; total += t.len;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) total += __shfl_xor(total, o, 64);
+        const bool any_bad = __any(bad);
+        if (lane == 0) {
+            if (any_bad) atomicOr(p.status, 4);
+            p.lens[d] = (any_bad || total > 0x7ffffff0ll) ? 0 : (int32_t)total;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_i2t_copy(I2tParams p)
+{
+    __shared__ int s_pre[4][65];
+    __shared__ uint32_t s_src[4][64];
+    const int lane = lane_id(), wv = (int)(threadIdx.x >> 6);
+    const int64_t wave0 = (int64_t)blockIdx.x * 4 + wv, nwaves = (int64_t)gridDim.x * 4;
+    for (int64_t d = wave0; d < p.nseq; d += nwaves) {
+        const int64_t b = p.id_off[d], e = p.id_off[d + 1];
+        int64_t out = p.text_off[d];
+        const int64_t out_end = p.text_off[d + 1];
+        if (out_end <= out) continue;                                  // empty, failed or all-skipped sequence
+        bool found = false;
+        for (int64_t i0 = b; i0 < e; i0 += 64) {
+            const I2tTok t = i2t_token(p, i0 + lane, e, found);
+            const int inc = wave_incl_scan(t.len);
+            const int total = __shfl(inc, 63, 64);
+            s_pre[wv][lane] = inc - t.len; s_src[wv][lane] = t.src;
+            if (lane == 63) s_pre[wv][64] = total;
+            for (int q = lane; q < total; q += 64) {
+                int lo = 0, hi = 63;                                   // last token whose prefix is <= q (empty tokens share a prefix: the last one wins)
+                while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (s_pre[wv][mid] <= q) lo = mid; else hi = mid - 1; }
+                if (out + q < p.text_cap) p.text[out + q] = p.tok_data[s_src[wv][lo] + (uint32_t)(q - s_pre[wv][lo])];
+            }
+            out += total;
+        }
+    }
+}
+
+void launch_i2t_len(const I2tParams &p, hipStream_t s)
+{
+    int64_t blocks = (p.nseq + 3) / 4; if (blocks > 256 * 16) blocks = 256 * 16; if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(k_i2t_len, dim3((unsigned)blocks), dim3(256), 0, s, p);
+}
+void launch_i2t_copy(const I2tParams &p, hipStream_t s)
+{
+    int64_t blocks = (p.nseq + 3) / 4; if (blocks > 256 * 16) blocks = 256 * 16; if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(k_i2t_copy, dim3((unsigned)blocks), dim3(256), 0, s, p);
+}
+
+// ------------------------------------------------------------------------------------------
 // scan: counts[ndocs] (int32) -> id_off[ndocs+1] (int64), three small kernels
 // ------------------------------------------------------------------------------------------
 constexpr int SCAN_ITEMS = 4, SCAN_THREADS = 256, SCAN_TILE = SCAN_ITEMS * SCAN_THREADS;

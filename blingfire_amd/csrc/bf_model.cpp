@@ -798,9 +798,30 @@ bool build_model(Model &m, const uint8_t *img, size_t size)
         }
         fused(0x2581, m.sp_prefix);
     }
+    // ---- [i2w] (reference tokdll:998-1045): string array dump + the range of regular token ids
+    if (conf.get(35 /* FUNC_I2W */, vals)) {
+        for (size_t i = 0; i < vals.size(); ++i) {
+            if (vals[i] == 75 /* PARAM_STRING_ARRAY */ && i + 1 < vals.size()) {
+                Reader d = dump(vals[++i]);
+                const int cnt = d.i32(0);
+                if (d.n < 8 || cnt < 0 || !d.ok(4, 4 * ((size_t)cnt + 1))) return fail(m, "bad [i2w] string array");
+                m.i2w_off.resize((size_t)cnt + 1);
+                for (int k = 0; k <= cnt; ++k) m.i2w_off[(size_t)k] = d.u32(4 + 4 * (size_t)k);
+                for (int k = 0; k < cnt; ++k) if (m.i2w_off[(size_t)k + 1] < m.i2w_off[(size_t)k]) return fail(m, "bad [i2w] string array");
+                const size_t base = 4 + 4 * ((size_t)cnt + 1);
+                if (!d.ok(base, m.i2w_off[(size_t)cnt])) return fail(m, "bad [i2w] string array");
+                m.i2w_data.assign(d.p + base, d.p + base + m.i2w_off[(size_t)cnt]);
+                m.has_i2w = true;
+            } else if (vals[i] == 76 /* PARAM_TOKENID_MIN */ && i + 1 < vals.size()) m.min_token_id = vals[++i];
+            else if (vals[i] == 77 /* PARAM_TOKENID_MAX */ && i + 1 < vals.size()) m.max_token_id = vals[++i];
+        }
+    }
     if (!m.has_seg) {
         m.kind = KIND_WP;
-        if (!m.has_wbd || m.wbd.table_len() == 0) return fail(m, "model has neither a [wbd] lexer nor a [pos-dict] dictionary");
+        if (!m.has_wbd || m.wbd.table_len() == 0) {
+            if (!m.has_i2w) return fail(m, "model has neither a [wbd] lexer, a [pos-dict] dictionary nor an [i2w] string array");
+            m.kind = KIND_I2W;
+        }
     }
     return true;
 }

@@ -30,7 +30,7 @@ enum : int {
 };
 
 // kinds of TextToIds algorithm a model selects (reference tokdll:959-974, 1619-1646)
-enum ModelKind : int { KIND_WP = 0, KIND_UNIGRAM = 1, KIND_BPE = 2, KIND_BPE_OPT = 3, KIND_BPE_MERGES = 4 };
+enum ModelKind : int { KIND_WP = 0, KIND_UNIGRAM = 1, KIND_BPE = 2, KIND_BPE_OPT = 3, KIND_BPE_MERGES = 4, KIND_I2W = 5 /* [i2w] only: IdsToText */ };
 
 // Abstract automaton decoded from a packed dump (test hooks compare it with the oracle's readers).
 struct RawDfa {
@@ -94,6 +94,12 @@ struct Model {
     std::vector<size_t> dump_off;
     int kind = KIND_WP;
     std::string error;                 // why load failed
+
+    // ---- [i2w] id -> token text (reference tokdll:998-1045, FAStringArray_pack.cpp:23-50), for IdsToText
+    bool has_i2w = false;
+    std::vector<uint32_t> i2w_off;     // [count + 1] byte offsets into i2w_data
+    std::vector<uint8_t> i2w_data;
+    int min_token_id = 0, max_token_id = 1000000000;   // regular (non special) ids (FALimits::MaxArrSize default)
 
     // ---- [wbd] lexer (reference FAWbdConfKeeper.cpp:56-232, FALexTools_t.h:129-202)
     bool has_wbd = false;

@@ -86,6 +86,23 @@ int TextToSentencesWithOffsets(const char *pInUtf8Str, int InUtf8StrByteCount, c
 int TextToSentencesWithOffsetsWithModel(const char *pInUtf8Str, int InUtf8StrByteCount, char *pOutUtf8Str, int *pStartOffsets,
                                         int *pEndOffsets, const int MaxOutUtf8StrByteCount, void *hModel);
 
+/* reference tokdll:1689-1745 (blingfiretokdll.def: IdsToText): text of an id sequence.  ModelPtr = a LoadModel handle of a
+ * model with an [i2w] section (a *.i2w file, or a .bin that carries one).  Ids outside the model's regular range are left
+ * out when SkipSpecialTokens is set; a leading space is not written; returns the byte count needed including the
+ * terminating 0 (written when it fits), 0 on error (no [i2w], unknown id, ...).  Runs as a batch of one on the GPU. */
+int IdsToText(void *ModelPtr, const int32_t *pIdsArr, const int IdsCount, char *pOutUtf8Str, const int MaxOutUtf8StrByteCount,
+              bool SkipSpecialTokens);
+
+/* additive: many sequences at once.  ids of sequence d = ids[id_offsets[d] .. id_offsets[d+1]); its text (no terminator) =
+ * text_out[text_offsets_out[d] .. text_offsets_out[d+1]), exactly the bytes IdsToText produces for it; a sequence with an
+ * unknown id yields no text.  Returns the total byte count or BF_E_* (BF_E_CAPACITY if text_cap is too small: the offsets
+ * are valid then and tell the size).  The Device form takes device pointers and a hipStream_t; with d_text_out == NULL it
+ * only computes the offsets (size query). */
+int64_t IdsToTextBatch(void *ModelPtr, const int32_t *ids, const int64_t *id_offsets, int64_t nseq, char *text_out, int64_t text_cap,
+                       int64_t *text_offsets_out, int skip_special);
+int IdsToTextBatchDevice(void *ModelPtr, const int32_t *d_ids, const int64_t *d_id_offsets, int64_t nseq, char *d_text_out,
+                         int64_t text_cap, int64_t *d_text_offsets_out, int skip_special, void *stream);
+
 /* reference tokdll:1669-1679 */
 int SetNoDummyPrefix(void *ModelPtr, int fNoDummyPrefix);
 

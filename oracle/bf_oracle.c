@@ -388,6 +388,8 @@ struct bfo_model {
     /* [pos-dict] cl/src/FADictConfKeeper.cpp:57-228 */
     int has_seg; dfa_t dict_dfa; mmapf_t i2info; mmapf_t dict_charmap;
     int tok_algo, id_offset, use_bytes, no_dummy_prefix, fsm_type, k2i_count;
+    /* [i2w] tokdll:998-1045 */
+    int has_i2w, i2w_count, min_token_id, max_token_id; const uint8_t *i2w_offs, *i2w_data;
 };
 
 /* cl/src/FAUtils_cl.cpp:101-159 FAGetCrc32 -- standard reflected CRC-32 table, seedable */
@@ -516,6 +518,23 @@ static int set_model_data(bfo_model *m)
             }
         }
         if (m->fsm_type != TYPE_MEALY_DFA || !m->dict_dfa.set || !m->i2info.set) return 0;
+    }
+
+    /* [i2w] (tokdll:998-1045): FAStringArray_pack image = [count][offsets: count + 1][data] (cl/src/FAStringArray_pack.cpp:23-50) */
+    m->min_token_id = 0; m->max_token_id = MAX_ARR_SIZE;
+    n = mmap_get(&m->conf, 35 /* FUNC_I2W */, vals, 256);
+    if (n != -1) {
+        for (i = 0; i < n; ++i) {
+            if (vals[i] == 75 /* PARAM_STRING_ARRAY */ && i + 1 < n) {
+                const uint8_t *d;
+                int dn = vals[++i];
+                if (dn < 0 || dn >= count) return 0;
+                d = m->dumps[dn];
+                m->i2w_count = rd_i32(d); m->i2w_offs = d + 4; m->i2w_data = d + 4 + 4 * ((size_t)m->i2w_count + 1); m->has_i2w = 1;
+                if (m->i2w_count < 0) return 0;
+            } else if (vals[i] == 76 /* PARAM_TOKENID_MIN */ && i + 1 < n) m->min_token_id = vals[++i];
+            else if (vals[i] == 77 /* PARAM_TOKENID_MAX */ && i + 1 < n) m->max_token_id = vals[++i];
+        }
     }
     return 1;
 }
@@ -1125,6 +1144,30 @@ int bfo_text_to_sentences_with_offsets(const bfo_model *m, const char *s, int n,
     free(buf); free(offs); free(res); free(tmp);
     return pos;
 }
+
+/* tokdll:1689-1745 IdsToText */
+int bfo_ids_to_text(const bfo_model *m, const int32_t *ids, int n, char *out, int max_out, int skip_special)
+{
+    int i, actual = 0;
+    if (!m) return 0;
+    if (n == 0 || !ids) return 0;
+    if (!m->has_i2w) return 0;
+    for (i = 0; i < n; ++i) {
+        const int id = ids[i];
+        unsigned b, e; const uint8_t *tok; int len;
+        if (skip_special && (id < m->min_token_id || id > m->max_token_id)) continue;     /* tokdll:1712-1714 */
+        if (id < 0 || id >= m->i2w_count) return 0;                                       /* unknown id (tokdll:1719-1721) */
+        b = rd_u32(m->i2w_offs + 4 * (size_t)id); e = rd_u32(m->i2w_offs + 4 * ((size_t)id + 1));
+        tok = m->i2w_data + b; len = (int)(e - b);
+        if (actual == 0 && len > 0 && tok[0] == 0x20) { tok++; len--; }                   /* no space in the leading position */
+        if (len > 0 && max_out - actual >= len) memcpy(out + actual, tok, (size_t)len);
+        actual += len;
+    }
+    if (max_out > actual) out[actual] = 0;
+    return actual + 1;
+}
+int bfo_has_i2w(const bfo_model *m) { return m && m->has_i2w; }
+int bfo_i2w_count(const bfo_model *m) { return m ? m->i2w_count : 0; }
 
 /* ---------------- exported building blocks ---------------- */
 

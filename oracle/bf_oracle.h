@@ -50,6 +50,11 @@ int bfo_text_to_words_with_offsets(const bfo_model *m, const char *utf8, int n, 
 /* tokdll:163-355 TextToSentencesWithOffsetsWithModel (the model is explicit here; the reference's NULL = its built-in sbd.bin) */
 int bfo_text_to_sentences_with_offsets(const bfo_model *m, const char *utf8, int n, char *out, int *starts, int *ends, int max_out);
 
+/* tokdll:1689-1745 IdsToText (model: a .bin with an [i2w] section or a separate .i2w file) */
+int bfo_ids_to_text(const bfo_model *m, const int32_t *ids, int n, char *out, int max_out, int skip_special);
+int bfo_has_i2w(const bfo_model *m);
+int bfo_i2w_count(const bfo_model *m);
+
 /* tokdll:1669-1679 SetNoDummyPrefix */
 int bfo_set_no_dummy_prefix(bfo_model *m, int flag);
 
