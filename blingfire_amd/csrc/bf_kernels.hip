@@ -833,7 +833,7 @@ __global__ __launch_bounds__(64) void k_bpe_collect(SpSegParams p)
 
 // BPE phase B1: sort the arcs of one document per 256-thread block (bitonic sort in LDS on the integer keys of
 // bf_seg.h; the order is total, so the result equals the reference's qsort).  Documents with more arcs than the
-// LDS holds are sorted by one thread with the in-place heap sort (slow path, loud in the docs).
+// LDS holds are sorted in place in global memory by the same block (merge exchange).
 constexpr int BPE_NMAX = 4096;
 __global__ __launch_bounds__(256) void k_bpe_sort(SpSegParams p)
 {
@@ -852,7 +852,28 @@ __global__ __launch_bounds__(256) void k_bpe_sort(SpSegParams p)
         const int n = p.narcs[d];
         if (n <= 1) continue;
         SegArc *arcs = p.arcs + 6 * sp_slot(p.b.doc_off[d], d, p.slot_mul) + 32 * d;
-        if (n > BPE_NMAX) { if (threadIdx.x == 0) sg_sort_arcs(arcs, n, merges); continue; }
+        if (n > BPE_NMAX) {
+            // too many arcs for the LDS: Batcher's merge exchange (Knuth 5.2.2 M) in place in global memory, by the whole block.
+            // It sorts any n without padding and the compare-exchanges of one step are independent of each other.
+            int t = 0; while ((1 << t) < n) ++t;
+            for (int pp = 1 << (t - 1); pp > 0; pp >>= 1) {
+                int q = 1 << (t - 1), r = 0, dd = pp;
+                while (dd > 0) {
+                    for (int i = threadIdx.x; i < n - dd; i += 256) {
+                        if ((i & pp) == r) {
+                            const SegArc a = arcs[i], b = arcs[i + dd];
+                            const uint32_t ah = sg_key_hi(a, merges), bh = sg_key_hi(b, merges);
+                            const uint64_t al = sg_key_lo(a), bl = sg_key_lo(b);
+                            if (ah > bh || (ah == bh && al > bl)) { arcs[i] = b; arcs[i + dd] = a; }
+                        }
+                    }
+                    __threadfence_block();
+                    __syncthreads();
+                    dd = q - pp; q >>= 1; r = pp;
+                }
+            }
+            continue;
+        }
         int n2 = 256; while (n2 < n) n2 <<= 1;
         for (int k = threadIdx.x; k < n2; k += 256) {
             if (k < n) { const SegArc a = arcs[k]; k_hi[k] = sg_key_hi(a, merges); k_lo[k] = sg_key_lo(a); k_val[k] = (uint32_t)a.end; }
