@@ -67,7 +67,7 @@ struct Handle {
     DevBuf t_dict, t_seginfo;                                    // _sp: Mealy table, I2Info rows (code-point maps reuse t_cp_*/t_multi)
     DevBuf w_s1, w_s2, w_s3, w_s4, w_perm, w_hist, w_narcs;      // _sp scratch
     // workspaces
-    DevBuf w_cls, w_nchars, w_tmp, w_counts, w_bsums, w_misc, w_flags;   // w_misc: [0] next_doc (u64), [2] status (int)
+    DevBuf w_cls, w_nchars, w_tmp, w_counts, w_bsums, w_misc, w_flags, w_out, w_outoff;   // w_misc: [0] next_doc (u64), [2] status (int)
     DevBuf w_text, w_docoff, w_ids, w_idoff, w_starts, w_ends;  // host-API staging
     DevBuf w_srcoff, w_span;                                    // offsets API: source-offset stream, staged id spans
     hipStream_t stream = nullptr;
@@ -76,7 +76,7 @@ struct Handle {
     bool last_nonempty = false;                                 // TextToWords: the (single) document decoded to >= 1 character
     ~Handle()
     {
-        for (DevBuf *b : {&t_i2w_off, &t_i2w_data, &t_wbd, &t_info, &t_acts, &t_cp_l1, &t_cp_pages, &t_multi, &t_wcp_l1, &t_wcp_pages, &t_dict, &t_seginfo, &w_s1, &w_s2, &w_s3, &w_s4, &w_perm, &w_hist, &w_narcs, &w_cls, &w_nchars, &w_tmp, &w_counts, &w_flags,
+        for (DevBuf *b : {&t_i2w_off, &t_i2w_data, &t_wbd, &t_info, &t_acts, &t_cp_l1, &t_cp_pages, &t_multi, &t_wcp_l1, &t_wcp_pages, &t_dict, &t_seginfo, &w_s1, &w_s2, &w_s3, &w_s4, &w_perm, &w_hist, &w_narcs, &w_cls, &w_nchars, &w_tmp, &w_counts, &w_flags, &w_out, &w_outoff,
                           &w_bsums, &w_misc, &w_text, &w_docoff, &w_ids, &w_idoff, &w_starts, &w_ends, &w_srcoff, &w_span}) b->release();
         for (auto &e : ev) if (e) (void)hipEventDestroy(e);
         if (stream) (void)hipStreamDestroy(stream);
@@ -291,6 +291,32 @@ int64_t run_host(Handle *h, const char *text, const int64_t *doc_off, int64_t nd
                          !hip_ok(hipMemcpy(ends_out, h->w_ends.p, (size_t)nids * 4, hipMemcpyDeviceToHost), "D2H ends"))) return BF_E_DEVICE;
     }
     return nids;
+}
+
+// TextToWords for a batch resident on the device: lexer in words mode -> spans -> lengths -> scan -> byte gather.
+// The word tags / spans stay in the handle's buffers; d_out may be NULL to size only (d_out_off is always filled).
+int run_words_device(Handle *h, const char *d_text, const int64_t *d_doc_off, int64_t ndocs, int64_t total_bytes,
+                     char *d_out, int64_t out_cap, int64_t *d_out_off, hipStream_t s, bool tokenise)
+{
+    if (h->m.kind != KIND_WP) return BF_E_UNSUPPORTED;
+    if (ndocs < 0 || total_bytes < 0 || !d_doc_off || !d_out_off) return BF_E_ARG;
+    if (tokenise) {
+        if (!h->w_ids.reserve((size_t)(total_bytes + 1) * 4) || !h->w_starts.reserve((size_t)(total_bytes + 1) * 4) ||
+            !h->w_ends.reserve((size_t)(total_bytes + 1) * 4) || !h->w_idoff.reserve((size_t)(ndocs + 1) * 8)) return BF_E_DEVICE;
+        int rc = run_device(h, d_text, d_doc_off, ndocs, total_bytes, h->w_ids.as<int32_t>(), total_bytes, h->w_idoff.as<int64_t>(), 0x7fffffff, 0, s,
+                            h->w_starts.as<int32_t>(), h->w_ends.as<int32_t>(), 1);
+        if (rc != 0) return rc;
+    }
+    const int nblocks = scan_nblocks(ndocs);
+    W2tParams p{(const uint8_t *)d_text, d_doc_off, ndocs, h->w_idoff.as<int64_t>(), h->w_starts.as<int32_t>(), h->w_ends.as<int32_t>(),
+                h->w_counts.as<int32_t>(), d_out_off, (uint8_t *)d_out, out_cap};
+    if (tokenise) {
+        if (ndocs > 0) launch_w2t_len(p, s);
+        ScanParams sp{h->w_counts.as<int32_t>(), ndocs, d_out_off, h->w_bsums.as<int64_t>(), nblocks};
+        launch_scan(sp, s);
+    }
+    if (d_out && ndocs > 0) launch_w2t_copy(p, s);
+    return hip_ok(hipGetLastError(), "TextToWords kernels") ? 0 : BF_E_DEVICE;
 }
 
 // IdsToText on device buffers: lengths -> scan -> byte gather (bf_kernels.hip).  d_text may be NULL to size only.
@@ -513,6 +539,53 @@ int TextToSentencesWithModel(const char *s, int n, char *out, const int max_out,
 { return TextToSentencesWithOffsetsWithModel(s, n, out, nullptr, nullptr, max_out, hModel); }
 int TextToSentences(const char *s, int n, char *out, const int max_out)
 { return TextToSentencesWithOffsetsWithModel(s, n, out, nullptr, nullptr, max_out, nullptr); }
+
+/* ---- additive: TextToWords for many documents at once; the output string of document d (what TextToWordsWithModel writes,
+ *      without the terminating 0) = text_out[text_offsets_out[d] .. text_offsets_out[d+1]) */
+int64_t TextToWordsBatch(void *p, const char *text, const int64_t *doc_off, int64_t ndocs, char *text_out, int64_t text_cap, int64_t *text_off_out)
+{
+    Handle *h = p ? as_handle(p) : default_wbd();
+    if (!h) return BF_E_ARG;
+    if (ndocs < 0 || !doc_off || (ndocs > 0 && !text && doc_off[ndocs] > doc_off[0])) return BF_E_ARG;
+    const int64_t base = doc_off[0], total = ndocs > 0 ? doc_off[ndocs] - base : 0;
+    if (total < 0) return BF_E_ARG;
+    std::lock_guard<std::mutex> lock(h->mu);
+    if (!hip_ok(hipSetDevice(h->device), "hipSetDevice")) return BF_E_DEVICE;
+    hipStream_t s = h->stream;
+    if (!h->w_text.reserve((size_t)total + 16) || !h->w_docoff.reserve((size_t)(ndocs + 1) * 8) || !h->w_outoff.reserve((size_t)(ndocs + 1) * 8)) return BF_E_DEVICE;
+    std::vector<int64_t> rel((size_t)ndocs + 1);
+    for (int64_t i = 0; i <= ndocs; ++i) rel[(size_t)i] = doc_off[i] - base;
+    if (total > 0 && !hip_ok(hipMemcpyAsync(h->w_text.p, text + base, (size_t)total, hipMemcpyHostToDevice, s), "H2D text")) return BF_E_DEVICE;
+    if (!hip_ok(hipMemcpyAsync(h->w_docoff.p, rel.data(), (size_t)(ndocs + 1) * 8, hipMemcpyHostToDevice, s), "H2D offsets")) return BF_E_DEVICE;
+    int rc = run_words_device(h, h->w_text.as<char>(), h->w_docoff.as<int64_t>(), ndocs, total, nullptr, 0, h->w_outoff.as<int64_t>(), s, true);
+    if (rc != 0) return rc;
+    std::vector<int64_t> tmp_off;
+    int64_t *dst_off = text_off_out;
+    if (!dst_off) { tmp_off.resize((size_t)ndocs + 1); dst_off = tmp_off.data(); }
+    if (!hip_ok(hipMemcpyAsync(dst_off, h->w_outoff.p, (size_t)(ndocs + 1) * 8, hipMemcpyDeviceToHost, s), "D2H offsets") ||
+        !hip_ok(hipStreamSynchronize(s), "hipStreamSynchronize")) return BF_E_DEVICE;
+    const int64_t nout = dst_off[ndocs];
+    if (nout > text_cap) return BF_E_CAPACITY;
+    if (nout > 0) {
+        if (!text_out) return BF_E_ARG;
+        if (!h->w_out.reserve((size_t)nout + 16)) return BF_E_DEVICE;
+        rc = run_words_device(h, h->w_text.as<char>(), h->w_docoff.as<int64_t>(), ndocs, total, h->w_out.as<char>(), nout, h->w_outoff.as<int64_t>(), s, false);
+        if (rc != 0) return rc;
+        if (!hip_ok(hipMemcpyAsync(text_out, h->w_out.p, (size_t)nout, hipMemcpyDeviceToHost, s), "D2H text") ||
+            !hip_ok(hipStreamSynchronize(s), "hipStreamSynchronize")) return BF_E_DEVICE;
+    }
+    return nout;
+}
+
+int TextToWordsBatchDevice(void *p, const char *d_text, const int64_t *d_doc_off, int64_t ndocs, int64_t total_bytes, char *d_text_out,
+                           int64_t text_cap, int64_t *d_text_off_out, void *stream)
+{
+    Handle *h = p ? as_handle(p) : default_wbd();
+    if (!h) return BF_E_ARG;
+    std::lock_guard<std::mutex> lock(h->mu);
+    if (!hip_ok(hipSetDevice(h->device), "hipSetDevice")) return BF_E_DEVICE;
+    return run_words_device(h, d_text, d_doc_off, ndocs, total_bytes, d_text_out, text_cap, d_text_off_out, (hipStream_t)stream, true);
+}
 
 /* ---- IdsToText (reference tokdll:1689-1745) and its batch forms: a variable-length byte gather on the GPU */
 int IdsToText(void *p, const int32_t *ids, const int n, char *out, const int max_out, bool skip_special)

@@ -112,6 +112,16 @@ struct I2tParams {
     int *status;                 // bit 2: a sequence contains an id the model does not know (the reference returns 0 for it)
 };
 void launch_i2t_len(const I2tParams &p, hipStream_t s);
+
+// TextToWords output assembly as a batch (reference tokdll:502-565): words of document d = spans word_off[d] .. word_off[d+1]
+// (byte offsets relative to the document), joined by ' ', a ' ' or NUL inside a word written as '_'
+struct W2tParams {
+    const uint8_t *text; const int64_t *doc_off; int64_t ndocs;
+    const int64_t *word_off; const int32_t *starts, *ends;
+    int32_t *lens; const int64_t *text_off; uint8_t *out; int64_t out_cap;
+};
+void launch_w2t_len(const W2tParams &p, hipStream_t s);
+void launch_w2t_copy(const W2tParams &p, hipStream_t s);
 void launch_i2t_copy(const I2tParams &p, hipStream_t s);
 void launch_compact(const CompactParams &p, hipStream_t s);
 int scan_nblocks(int64_t ndocs);

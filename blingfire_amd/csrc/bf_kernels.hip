@@ -1596,6 +1596,66 @@ __global__ __launch_bounds__(256) void k_i2t_copy(I2tParams p)
     }
 }
 
+// TextToWords output assembly (reference tokdll:502-565) for a batch: the same byte-gather scheme as k_i2t_*; a word's bytes
+// come from the caller's text, every word but the first of its document is preceded by one ' '.
+__global__ __launch_bounds__(256) void k_w2t_len(W2tParams p)
+{
+    const int lane = lane_id();
+    const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (int64_t)gridDim.x * 4;
+    for (int64_t d = wave0; d < p.ndocs; d += nwaves) {
+        const int64_t b = p.word_off[d], e = p.word_off[d + 1];
+        long long total = 0;
+        for (int64_t i = b + lane; i < e; i += 64) total += (long long)(p.ends[i] - p.starts[i] + 1) + (i > b ? 1 : 0);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) total += __shfl_xor(total, o, 64);
+        if (lane == 0) p.lens[d] = total > 0x7ffffff0ll ? 0 : (int32_t)total;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_w2t_copy(W2tParams p)
+{
+    __shared__ int s_pre[4][65];
+    __shared__ int s_src[4][64];
+    const int lane = lane_id(), wv = (int)(threadIdx.x >> 6);
+    const int64_t wave0 = (int64_t)blockIdx.x * 4 + wv, nwaves = (int64_t)gridDim.x * 4;
+    for (int64_t d = wave0; d < p.ndocs; d += nwaves) {
+        const int64_t b = p.word_off[d], e = p.word_off[d + 1];
+        int64_t out = p.text_off[d];
+        if (p.text_off[d + 1] <= out) continue;
+        const uint8_t *src = p.text + p.doc_off[d];
+        for (int64_t i0 = b; i0 < e; i0 += 64) {
+            const int64_t i = i0 + lane;
+            int len = 0, st = 0;
+            if (i < e) { st = p.starts[i]; len = p.ends[i] - st + 1 + (i > b ? 1 : 0); }     // the separator is counted with the word it precedes
+            const int inc = wave_incl_scan(len);
+            const int total = __shfl(inc, 63, 64);
+            s_pre[wv][lane] = inc - len; s_src[wv][lane] = st - ((i > b) ? 1 : 0);
+            if (lane == 63) s_pre[wv][64] = total;
+            for (int q = lane; q < total; q += 64) {
+                int lo = 0, hi = 63;
+                while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (s_pre[wv][mid] <= q) lo = mid; else hi = mid - 1; }
+                const int k = q - s_pre[wv][lo];
+                uint8_t c;
+                if (k == 0 && i0 + lo > b) c = ' ';                                         // tokdll:529-531
+                else { c = src[s_src[wv][lo] + k]; if (c == ' ' || c == 0) c = '_'; }       // tokdll:482,543
+                if (out + q < p.out_cap) p.out[out + q] = c;
+            }
+            out += total;
+        }
+    }
+}
+
+void launch_w2t_len(const W2tParams &p, hipStream_t s)
+{
+    int64_t blocks = (p.ndocs + 3) / 4; if (blocks > 256 * 16) blocks = 256 * 16; if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(k_w2t_len, dim3((unsigned)blocks), dim3(256), 0, s, p);
+}
+void launch_w2t_copy(const W2tParams &p, hipStream_t s)
+{
+    int64_t blocks = (p.ndocs + 3) / 4; if (blocks > 256 * 16) blocks = 256 * 16; if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(k_w2t_copy, dim3((unsigned)blocks), dim3(256), 0, s, p);
+}
+
 void launch_i2t_len(const I2tParams &p, hipStream_t s)
 {
     int64_t blocks = (p.nseq + 3) / 4; if (blocks > 256 * 16) blocks = 256 * 16; if (blocks < 1) blocks = 1;

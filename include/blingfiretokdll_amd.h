@@ -74,6 +74,17 @@ int TextToWordsWithOffsets(const char *pInUtf8Str, int InUtf8StrByteCount, char 
 int TextToWordsWithOffsetsWithModel(const char *pInUtf8Str, int InUtf8StrByteCount, char *pOutUtf8Str, int *pStartOffsets,
                                     int *pEndOffsets, const int MaxOutUtf8StrByteCount, void *hModel);
 
+/* additive: TextToWords for many documents at once.  The output string of document d -- exactly
+ * what TextToWordsWithModel writes for it, without the terminating 0; nothing for a document it would reject -- is
+ * text_out[text_offsets_out[d] .. text_offsets_out[d+1]).  ModelPtr NULL = the built-in wbd.bin.  Returns the total byte count
+ * or BF_E_* (BF_E_CAPACITY: the offsets are valid and tell the size).  The Device form takes device pointers and a hipStream_t
+ * and never writes past text_cap; with d_text_out == NULL it only computes the offsets.  Tokenisation AND string assembly
+ * (a variable-length byte gather) run on the GPU. */
+int64_t TextToWordsBatch(void *ModelPtr, const char *text, const int64_t *doc_offsets, int64_t ndocs, char *text_out, int64_t text_cap,
+                         int64_t *text_offsets_out);
+int TextToWordsBatchDevice(void *ModelPtr, const char *d_text, const int64_t *d_doc_offsets, int64_t ndocs, int64_t total_bytes,
+                           char *d_text_out, int64_t text_cap, int64_t *d_text_offsets_out, void *stream);
+
 /* reference tokdll:163-402 (blingfiretokdll.def: TextToSentences, TextToSentencesWithModel, TextToSentencesWithOffsets,
  * TextToSentencesWithOffsetsWithModel): sentence breaking with the model behind hModel (a LoadModel handle of a [wbd]-type
  * model such as sbd.bin; NULL = the built-in sbd.bin, embedded like the reference embeds it).  Output = sentences joined by

@@ -204,3 +204,27 @@ def test_gpu_text_to_sentences(model):
         if h:
             bf.free_model(h)
         ora.free(ho)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("model", ["wbd.bin", "bert_base_cased_tok.bin", None])
+def test_gpu_text_to_words_batch(model):
+    """additive batch form: per document exactly the string TextToWordsWithModel produces (checked against the oracle)"""
+    import blingfire_amd as bf
+    ora, f = _oracle_fn()
+    ho = ora.load(bfutil.model_path(model or "wbd.bin"))
+    h = bf.load_model(bfutil.model_path(model)) if model else None
+    try:
+        docs = _docs(1500, 97) + [b"", b"Hello world . This is a test ."] * 3
+        text, off = bfutil.gen_corpus(3000, seed=5, mean=43, sd=12, minlen=8, maxlen=120)
+        raw = text.tobytes()
+        docs += [raw[off[d]:off[d + 1]] for d in range(3000)]
+        out, t_off = bf.text_to_words_batch(docs, h)
+        for d, b in enumerate(docs):
+            r, o, _, _ = _call(f, (ctypes.c_void_p(ho),), b, 4 * len(b) + 8)
+            want = o[:r - 1] if r > 0 else b""
+            assert out[t_off[d]:t_off[d + 1]].tobytes() == want, (model, d, b[:60])
+    finally:
+        if h:
+            bf.free_model(h)
+        ora.free(ho)
