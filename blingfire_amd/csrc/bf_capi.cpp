@@ -113,6 +113,30 @@ Handle *default_wbd()
     return h;
 }
 
+// model-free entry points (NormalizeSpaces, TextToHashes) run on a handle that owns only a stream and workspaces
+Handle *util_handle()
+{
+    static std::mutex mu; static Handle *h = nullptr; static bool tried = false;
+    std::lock_guard<std::mutex> lock(mu);
+    if (tried) return h;
+    tried = true;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        g_last_error = "no HIP device available: this library has no CPU path";
+        fprintf(stderr, "[blingfire_amd] %s\n", g_last_error.c_str());
+        return nullptr;
+    }
+    Handle *u = new Handle();
+    u->m.kind = KIND_I2W;                                   // no tokenizer behind it
+    if (hipGetDevice(&u->device) != hipSuccess) u->device = 0;
+    bool ok = hip_ok(hipStreamCreateWithFlags(&u->stream, hipStreamNonBlocking), "hipStreamCreate");
+    for (auto &e : u->ev) ok = ok && hip_ok(hipEventCreate(&e), "hipEventCreate");
+    ok = ok && u->w_misc.reserve(256) && hip_ok(hipMemset(u->w_misc.p, 0, 256), "hipMemset");
+    if (!ok) { fprintf(stderr, "[blingfire_amd] %s\n", g_last_error.c_str()); delete u; return nullptr; }
+    h = u;
+    return h;
+}
+
 Handle *as_handle(void *p)
 {
     Handle *h = (Handle *)p;
@@ -381,6 +405,68 @@ int64_t run_i2t_host(Handle *h, const int32_t *ids, const int64_t *id_off, int64
     return total;
 }
 
+// upload a batch of documents (host buffers) into the handle's text / offset buffers; returns the byte total or BF_E_*
+int64_t upload_docs(Handle *h, const char *text, const int64_t *doc_off, int64_t ndocs, hipStream_t s)
+{
+    if (ndocs < 0 || !doc_off || (ndocs > 0 && !text && doc_off[ndocs] > doc_off[0])) return BF_E_ARG;
+    const int64_t base = doc_off[0], total = ndocs > 0 ? doc_off[ndocs] - base : 0;
+    if (total < 0) return BF_E_ARG;
+    if (!h->w_text.reserve((size_t)total + 16) || !h->w_docoff.reserve((size_t)(ndocs + 1) * 8) || !h->w_outoff.reserve((size_t)(ndocs + 1) * 8)) return BF_E_DEVICE;
+    std::vector<int64_t> rel((size_t)ndocs + 1);
+    for (int64_t i = 0; i <= ndocs; ++i) rel[(size_t)i] = doc_off[i] - base;
+    if (total > 0 && !hip_ok(hipMemcpyAsync(h->w_text.p, text + base, (size_t)total, hipMemcpyHostToDevice, s), "H2D text")) return BF_E_DEVICE;
+    if (!hip_ok(hipMemcpyAsync(h->w_docoff.p, rel.data(), (size_t)(ndocs + 1) * 8, hipMemcpyHostToDevice, s), "H2D offsets")) return BF_E_DEVICE;
+    if (!hip_ok(hipStreamSynchronize(s), "hipStreamSynchronize")) return BF_E_DEVICE;     // `rel` goes out of scope
+    return total;
+}
+
+static int utf8_encode(int c, unsigned char *o)     // FAIntToUtf8 (cl/src/FAUtf8Utils.cpp:471-527); 0 = cannot be encoded
+{
+    const unsigned u = (unsigned)c;
+    if (u <= 0x7F) { o[0] = (unsigned char)u; return 1; }
+    if (u <= 0x7FF) { o[0] = (unsigned char)(0xC0 | (u >> 6)); o[1] = (unsigned char)(0x80 | (u & 0x3F)); return 2; }
+    if (u <= 0xFFFF) { if ((u & 0xFFFFF800u) == 0xD800u) return 0; o[0] = (unsigned char)(0xE0 | (u >> 12)); o[1] = (unsigned char)(0x80 | ((u >> 6) & 0x3F)); o[2] = (unsigned char)(0x80 | (u & 0x3F)); return 3; }
+    if (u <= 0x10FFFF) { o[0] = (unsigned char)(0xF0 | (u >> 18)); o[1] = (unsigned char)(0x80 | ((u >> 12) & 0x3F)); o[2] = (unsigned char)(0x80 | ((u >> 6) & 0x3F)); o[3] = (unsigned char)(0x80 | (u & 0x3F)); return 4; }
+    return 0;
+}
+
+// NormalizeSpaces on device buffers: size pass (+ scan) when `size` is set, write pass when d_out is given
+int run_normsp_device(Handle *h, const char *d_text, const int64_t *d_doc_off, int64_t ndocs, int u_space, char *d_out, int64_t out_cap,
+                      int64_t *d_out_off, hipStream_t s, bool size)
+{
+    if (ndocs < 0 || !d_doc_off || !d_out_off) return BF_E_ARG;
+    const int nblocks = scan_nblocks(ndocs);
+    if (!h->w_counts.reserve((size_t)(ndocs + 1) * 4) || !h->w_nchars.reserve((size_t)(ndocs + 1) * 4) || !h->w_bsums.reserve((size_t)(nblocks + 1) * 8)) return BF_E_DEVICE;
+    unsigned char ub[4] = {0, 0, 0, 0};
+    NormSpParams p;
+    p.text = (const uint8_t *)d_text; p.doc_off = d_doc_off; p.ndocs = ndocs; p.u_space = u_space; p.usp_len = utf8_encode(u_space, ub);
+    p.usp_bytes = (uint32_t)ub[0] | ((uint32_t)ub[1] << 8) | ((uint32_t)ub[2] << 16) | ((uint32_t)ub[3] << 24);
+    p.lens = h->w_counts.as<int32_t>(); p.aux = h->w_nchars.as<int32_t>(); p.out_off = d_out_off; p.out = (uint8_t *)d_out; p.out_cap = out_cap;
+    if (size) {
+        if (ndocs > 0) launch_normsp(p, false, s);
+        ScanParams sp{h->w_counts.as<int32_t>(), ndocs, d_out_off, h->w_bsums.as<int64_t>(), nblocks};
+        launch_scan(sp, s);
+    }
+    if (d_out && ndocs > 0) launch_normsp(p, true, s);
+    return hip_ok(hipGetLastError(), "NormalizeSpaces kernels") ? 0 : BF_E_DEVICE;
+}
+
+int run_hashes_device(Handle *h, const char *d_text, const int64_t *d_doc_off, int64_t ndocs, int ngrams, int bucket, int32_t *d_out, int64_t out_cap,
+                      int64_t *d_out_off, hipStream_t s, bool size)
+{
+    if (ndocs < 0 || !d_doc_off || !d_out_off || ngrams <= 0 || bucket == 0) return BF_E_ARG;
+    const int nblocks = scan_nblocks(ndocs);
+    if (!h->w_counts.reserve((size_t)(ndocs + 1) * 4) || !h->w_bsums.reserve((size_t)(nblocks + 1) * 8)) return BF_E_DEVICE;
+    HashParams p{(const uint8_t *)d_text, d_doc_off, ndocs, ngrams, bucket, h->w_counts.as<int32_t>(), d_out_off, d_out, out_cap};
+    if (size) {
+        if (ndocs > 0) launch_hash_count(p, s);
+        ScanParams sp{h->w_counts.as<int32_t>(), ndocs, d_out_off, h->w_bsums.as<int64_t>(), nblocks};
+        launch_scan(sp, s);
+    }
+    if (d_out && ndocs > 0) launch_hash_fill(p, s);
+    return hip_ok(hipGetLastError(), "TextToHashes kernels") ? 0 : BF_E_DEVICE;
+}
+
 int text_to_ids_one(void *hp, const char *s, int n, int32_t *ids, int max_ids, int unk, int want_kind /* -1 any, 0 wp, 1 sp */,
                     int32_t *starts = nullptr, int32_t *ends = nullptr)
 {
@@ -585,6 +671,114 @@ int TextToWordsBatchDevice(void *p, const char *d_text, const int64_t *d_doc_off
     std::lock_guard<std::mutex> lock(h->mu);
     if (!hip_ok(hipSetDevice(h->device), "hipSetDevice")) return BF_E_DEVICE;
     return run_words_device(h, d_text, d_doc_off, ndocs, total_bytes, d_text_out, text_cap, d_text_off_out, (hipStream_t)stream, true);
+}
+
+/* ---- NormalizeSpaces (reference tokdll:629-679), model-free; batch of one on the GPU + additive batch forms */
+int NormalizeSpaces(const char *s, int n, char *out, const int max_out, const int u_space)
+{
+    if (n == 0) return -1;                                                     // tokdll:634-636
+    if (n < 0 || n > 1000000000 || !s) return -1;
+    Handle *h = util_handle();
+    if (!h) return -1;
+    std::lock_guard<std::mutex> lock(h->mu);
+    if (!hip_ok(hipSetDevice(h->device), "hipSetDevice")) return -1;
+    hipStream_t st = h->stream;
+    const int64_t off[2] = {0, n};
+    if (upload_docs(h, s, off, 1, st) < 0) return -1;
+    if (run_normsp_device(h, h->w_text.as<char>(), h->w_docoff.as<int64_t>(), 1, u_space, nullptr, 0, h->w_outoff.as<int64_t>(), st, true) != 0) return -1;
+    int32_t len = 0, aux = 0;
+    if (!hip_ok(hipMemcpyAsync(&len, h->w_counts.p, 4, hipMemcpyDeviceToHost, st), "D2H") || !hip_ok(hipMemcpyAsync(&aux, h->w_nchars.p, 4, hipMemcpyDeviceToHost, st), "D2H") ||
+        !hip_ok(hipStreamSynchronize(st), "hipStreamSynchronize")) return -1;
+    if (aux & 1) return -1;                                                    // invalid UTF-8 / nothing decoded (tokdll:646-648)
+    unsigned char ub[4];
+    if ((aux >> 1) > 0 && utf8_encode(u_space, ub) == 0) return -1;            // a uSpace that cannot be encoded (FAUtf8Utils.cpp:549-552)
+    if (len > max_out) return -1;                                              // does not fit: FAArrayToStrUtf8 fails (FAUtf8Utils.cpp:547-552)
+    if (len > 0) {
+        if (!out || !h->w_out.reserve((size_t)len + 16)) return -1;
+        if (run_normsp_device(h, h->w_text.as<char>(), h->w_docoff.as<int64_t>(), 1, u_space, h->w_out.as<char>(), len, h->w_outoff.as<int64_t>(), st, false) != 0) return -1;
+        if (!hip_ok(hipMemcpyAsync(out, h->w_out.p, (size_t)len, hipMemcpyDeviceToHost, st), "D2H text") || !hip_ok(hipStreamSynchronize(st), "hipStreamSynchronize")) return -1;
+    }
+    if (out && len < max_out) out[len] = 0;                                    // tokdll:674-676
+    return len;
+}
+
+int64_t NormalizeSpacesBatch(const char *text, const int64_t *doc_off, int64_t ndocs, char *text_out, int64_t text_cap, int64_t *text_off_out, int u_space)
+{
+    Handle *h = util_handle();
+    if (!h) return BF_E_DEVICE;
+    std::lock_guard<std::mutex> lock(h->mu);
+    if (!hip_ok(hipSetDevice(h->device), "hipSetDevice")) return BF_E_DEVICE;
+    hipStream_t s = h->stream;
+    const int64_t total = upload_docs(h, text, doc_off, ndocs, s);
+    if (total < 0) return total;
+    int rc = run_normsp_device(h, h->w_text.as<char>(), h->w_docoff.as<int64_t>(), ndocs, u_space, nullptr, 0, h->w_outoff.as<int64_t>(), s, true);
+    if (rc != 0) return rc;
+    std::vector<int64_t> tmp_off; int64_t *dst_off = text_off_out;
+    if (!dst_off) { tmp_off.resize((size_t)ndocs + 1); dst_off = tmp_off.data(); }
+    if (!hip_ok(hipMemcpyAsync(dst_off, h->w_outoff.p, (size_t)(ndocs + 1) * 8, hipMemcpyDeviceToHost, s), "D2H offsets") || !hip_ok(hipStreamSynchronize(s), "hipStreamSynchronize")) return BF_E_DEVICE;
+    const int64_t nout = dst_off[ndocs];
+    if (nout > text_cap) return BF_E_CAPACITY;
+    if (nout > 0) {
+        if (!text_out || !h->w_out.reserve((size_t)nout + 16)) return text_out ? BF_E_DEVICE : BF_E_ARG;
+        rc = run_normsp_device(h, h->w_text.as<char>(), h->w_docoff.as<int64_t>(), ndocs, u_space, h->w_out.as<char>(), nout, h->w_outoff.as<int64_t>(), s, false);
+        if (rc != 0) return rc;
+        if (!hip_ok(hipMemcpyAsync(text_out, h->w_out.p, (size_t)nout, hipMemcpyDeviceToHost, s), "D2H text") || !hip_ok(hipStreamSynchronize(s), "hipStreamSynchronize")) return BF_E_DEVICE;
+    }
+    return nout;
+}
+
+/* ---- TextToHashes (reference tokdll:683-815), model-free */
+int TextToHashes(const char *s, int n, int32_t *hashes, const int max_hashes, int ngrams, int bucket)
+{
+    if (ngrams <= 0) return -1;          // the reference only rejects ngrams <= 0 together with a negative length (tokdll:786-789) and would
+                                         // otherwise write past the caller's array: refused here
+    if (n < 0) return ngrams >= max_hashes ? n * ngrams : 0;                   // one token counted, none hashed (tokdll:718-737,743)
+    if (bucket == 0 || !s || n > 1000000000) return -1;
+    int tokens = 0;
+    Handle *h = util_handle();
+    if (!h) return -1;
+    std::lock_guard<std::mutex> lock(h->mu);
+    if (!hip_ok(hipSetDevice(h->device), "hipSetDevice")) return -1;
+    hipStream_t st = h->stream;
+    const int64_t off[2] = {0, n};
+    if (upload_docs(h, s, off, 1, st) < 0) return -1;
+    if (run_hashes_device(h, h->w_text.as<char>(), h->w_docoff.as<int64_t>(), 1, ngrams, bucket, nullptr, 0, h->w_outoff.as<int64_t>(), st, true) != 0) return -1;
+    int32_t cnt = 0;
+    if (!hip_ok(hipMemcpyAsync(&cnt, h->w_counts.p, 4, hipMemcpyDeviceToHost, st), "D2H") || !hip_ok(hipStreamSynchronize(st), "hipStreamSynchronize")) return -1;
+    tokens = n == 0 ? 0 : cnt / ngrams;                                         // GetTokenCount (tokdll:718-737): 0 for an empty string
+    if ((int64_t)tokens * ngrams >= max_hashes) return n * ngrams;             // tokdll:795-798: "requested memory amount"
+    if (cnt > max_hashes || !hashes) return -1;                                // (n == 0: one empty token is hashed, tokdll:743-771)
+    if (!h->w_ids.reserve((size_t)cnt * 4 + 16)) return -1;
+    if (run_hashes_device(h, h->w_text.as<char>(), h->w_docoff.as<int64_t>(), 1, ngrams, bucket, h->w_ids.as<int32_t>(), cnt, h->w_outoff.as<int64_t>(), st, false) != 0) return -1;
+    if (!hip_ok(hipMemcpyAsync(hashes, h->w_ids.p, (size_t)cnt * 4, hipMemcpyDeviceToHost, st), "D2H hashes") || !hip_ok(hipStreamSynchronize(st), "hipStreamSynchronize")) return -1;
+    return cnt;
+}
+
+int64_t TextToHashesBatch(const char *text, const int64_t *doc_off, int64_t ndocs, int32_t *hashes_out, int64_t hashes_cap, int64_t *hash_off_out,
+                          int ngrams, int bucket)
+{
+    if (ngrams <= 0 || bucket == 0) return BF_E_ARG;
+    Handle *h = util_handle();
+    if (!h) return BF_E_DEVICE;
+    std::lock_guard<std::mutex> lock(h->mu);
+    if (!hip_ok(hipSetDevice(h->device), "hipSetDevice")) return BF_E_DEVICE;
+    hipStream_t s = h->stream;
+    const int64_t total = upload_docs(h, text, doc_off, ndocs, s);
+    if (total < 0) return total;
+    int rc = run_hashes_device(h, h->w_text.as<char>(), h->w_docoff.as<int64_t>(), ndocs, ngrams, bucket, nullptr, 0, h->w_outoff.as<int64_t>(), s, true);
+    if (rc != 0) return rc;
+    std::vector<int64_t> tmp_off; int64_t *dst_off = hash_off_out;
+    if (!dst_off) { tmp_off.resize((size_t)ndocs + 1); dst_off = tmp_off.data(); }
+    if (!hip_ok(hipMemcpyAsync(dst_off, h->w_outoff.p, (size_t)(ndocs + 1) * 8, hipMemcpyDeviceToHost, s), "D2H offsets") || !hip_ok(hipStreamSynchronize(s), "hipStreamSynchronize")) return BF_E_DEVICE;
+    const int64_t nout = dst_off[ndocs];
+    if (nout > hashes_cap) return BF_E_CAPACITY;
+    if (nout > 0) {
+        if (!hashes_out || !h->w_ids.reserve((size_t)nout * 4 + 16)) return hashes_out ? BF_E_DEVICE : BF_E_ARG;
+        rc = run_hashes_device(h, h->w_text.as<char>(), h->w_docoff.as<int64_t>(), ndocs, ngrams, bucket, h->w_ids.as<int32_t>(), nout, h->w_outoff.as<int64_t>(), s, false);
+        if (rc != 0) return rc;
+        if (!hip_ok(hipMemcpyAsync(hashes_out, h->w_ids.p, (size_t)nout * 4, hipMemcpyDeviceToHost, s), "D2H hashes") || !hip_ok(hipStreamSynchronize(s), "hipStreamSynchronize")) return BF_E_DEVICE;
+    }
+    return nout;
 }
 
 /* ---- IdsToText (reference tokdll:1689-1745) and its batch forms: a variable-length byte gather on the GPU */

@@ -122,6 +122,24 @@ struct W2tParams {
 };
 void launch_w2t_len(const W2tParams &p, hipStream_t s);
 void launch_w2t_copy(const W2tParams &p, hipStream_t s);
+
+// NormalizeSpaces (reference tokdll:629-679) and TextToHashes (tokdll:683-815) as batches; both are model-free
+struct NormSpParams {
+    const uint8_t *text; const int64_t *doc_off; int64_t ndocs;
+    int u_space, usp_len; uint32_t usp_bytes;   // uSpace, its UTF-8 length (0 if it cannot be encoded) and bytes (little end first)
+    int32_t *lens;               // [ndocs] output bytes (0 on error)
+    int32_t *aux;                // [ndocs] bit 0: error (empty / invalid UTF-8); bits 1..: normalised spaces left after the trim (saturating)
+    const int64_t *out_off; uint8_t *out; int64_t out_cap;      // write pass
+};
+void launch_normsp(const NormSpParams &p, bool write, hipStream_t s);
+struct HashParams {
+    const uint8_t *text; const int64_t *doc_off; int64_t ndocs;
+    int ngrams, bucket;
+    int32_t *lens;               // [ndocs] (spaces + 1) * ngrams
+    const int64_t *out_off; int32_t *out; int64_t out_cap;
+};
+void launch_hash_count(const HashParams &p, hipStream_t s);
+void launch_hash_fill(const HashParams &p, hipStream_t s);
 void launch_i2t_copy(const I2tParams &p, hipStream_t s);
 void launch_compact(const CompactParams &p, hipStream_t s);
 int scan_nblocks(int64_t ndocs);

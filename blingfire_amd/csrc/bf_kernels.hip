@@ -1656,6 +1656,187 @@ void launch_w2t_copy(const W2tParams &p, hipStream_t s)
     hipLaunchKernelGGL(k_w2t_copy, dim3((unsigned)blocks), dim3(256), 0, s, p);
 }
 
+// ------------------------------------------------------------------------------------------
+// NormalizeSpaces (reference tokdll:629-679), wave per document, 64 bytes per iteration.  The sequential rule "a white-space
+// character becomes uSpace unless nothing was written yet or the last written character equals uSpace" is local: a white-space
+// character is written iff the character before it exists, is not white space and is not uSpace itself.  One trailing uSpace
+// is trimmed (when more than one character was written).  Pass 1 sizes, pass 2 (WRITE) stores at the scanned offsets.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool dev_is_ws(int c)      // blingfiretokdll.h:17-21 __FAIsWhiteSpace__
+{
+    return c <= 0x20 || c == 0xa0 || (c >= 0x2000 && c <= 0x200f) || c == 0x202f || c == 0x205f || c == 0x2060 || c == 0x2420 || c == 0x2424 ||
+           c == 0x3000 || c == 0xfeff;
+}
+
+template <bool WRITE>
+__global__ __launch_bounds__(256) void k_normsp(NormSpParams p)
+{
+    const int lane = lane_id();
+    const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (int64_t)gridDim.x * 4;
+    for (int64_t d = wave0; d < p.ndocs; d += nwaves) {
+        const int64_t b = p.doc_off[d];
+        const int64_t n64 = p.doc_off[d + 1] - b;
+        if (n64 <= 0 || n64 > 1000000000) { if (!WRITE && lane == 0) { p.lens[d] = 0; p.aux[d] = 1; } continue; }   // tokdll:634-636
+        const int n = (int)n64;
+        const uint8_t *s = p.text + b;
+        uint8_t *out = WRITE ? p.out + p.out_off[d] : nullptr;
+        const int64_t room = WRITE ? p.out_off[d + 1] - p.out_off[d] : 0;
+        if (WRITE && room <= 0) continue;
+        const int bom = (n >= 3 && s[0] == 0xEF && s[1] == 0xBB && s[2] == 0xBF) ? 3 : 0;    // FAUtf8Utils.cpp:247-252
+        bool bad = false, c_exists = false, c_ws = false, c_eq = false;    // the last character of the previous window
+        int nchars = 0, nwritten = 0, nspaces = 0, last_len = 0; bool last_usp = false, last_norm = false;
+        long long total = 0;
+        for (int pos = bom; pos < n; pos += 64) {
+            const int q = pos + lane;
+            const bool in = q < n;
+            uint32_t b0 = 0, b1 = 0, b2 = 0, b3 = 0;
+            if (in) b0 = s[q];
+            if (q + 1 < n) b1 = s[q + 1];
+            if (q + 2 < n) b2 = s[q + 2];
+            if (q + 3 < n) b3 = s[q + 3];
+            const bool cont = (b0 & 0xC0) == 0x80;
+            const bool start = in && !cont;
+            bool err = false; int cp = (int)b0, len = 1;
+            if (in && cont) {                                            // must be covered by a lead (FAUtf8Utils.cpp:152-165)
+                const uint32_t p1 = (q - 1 >= bom) ? s[q - 1] : 0x80u, p2 = (q - 2 >= bom) ? s[q - 2] : 0x80u, p3 = (q - 3 >= bom) ? s[q - 3] : 0x80u;
+                bool ok;
+                if ((p1 & 0xC0) != 0x80) ok = (q - 1 >= bom) && p1 >= 0xC0;
+                else if ((p2 & 0xC0) != 0x80) ok = (q - 2 >= bom) && p2 >= 0xE0;
+                else if ((p3 & 0xC0) != 0x80) ok = (q - 3 >= bom) && p3 >= 0xF0;
+                else ok = false;
+                err = !ok;
+            } else if (start && b0 >= 0x80) {
+                if ((b0 & 0xE0) == 0xC0) { len = 2; cp = (int)(b0 & 0x1F); }
+                else if ((b0 & 0xF0) == 0xE0) { len = 3; cp = (int)(b0 & 0x0F); }
+                else if ((b0 & 0xF8) == 0xF0) { len = 4; cp = (int)(b0 & 0x07); }
+                else { len = 1; err = true; }
+                if (q + len > n) err = true;
+                if (len >= 2) { if ((b1 & 0xC0) != 0x80) err = true; cp = (cp << 6) | (int)(b1 & 0x3F); }
+                if (len >= 3) { if ((b2 & 0xC0) != 0x80) err = true; cp = (cp << 6) | (int)(b2 & 0x3F); }
+                if (len >= 4) { if ((b3 & 0xC0) != 0x80) err = true; cp = (cp << 6) | (int)(b3 & 0x3F); }
+                const int need = cp <= 0x7F ? 1 : cp <= 0x7FF ? 2 : cp <= 0xFFFF ? 3 : cp <= 0x10FFFF ? 4 : 0;
+                if (need != len) err = true;
+                if ((cp & 0xFFFFF800) == 0xD800) err = true;
+            }
+            bad |= err;
+            const bool ws = start && dev_is_ws(cp), eq = start && cp == p.u_space;
+            const unsigned long long m_start = __ballot(start);
+            const unsigned long long below = m_start & lanemask_lt();
+            const int prev = below ? 63 - __clzll((long long)below) : -1;
+            const int pws = __shfl((int)ws, prev < 0 ? 0 : prev, 64), peq = __shfl((int)eq, prev < 0 ? 0 : prev, 64);
+            const bool prev_exists = prev >= 0 || c_exists, prev_ws = prev >= 0 ? pws != 0 : c_ws, prev_eq = prev >= 0 ? peq != 0 : c_eq;
+            const bool norm = ws && prev_exists && !prev_ws && !prev_eq;                // this white space becomes one uSpace
+            const bool written = start && (!ws || norm);
+            const int ob = !written ? 0 : (ws ? p.usp_len : len);
+            const int inc = wave_incl_scan(ob);
+            const unsigned long long m_w = __ballot(written);
+            if (m_w) {
+                const int lw = 63 - __clzll((long long)m_w);
+                last_usp = __shfl((int)(ws ? (int)norm : (int)eq), lw, 64) != 0;        // value of the last written character == uSpace
+                last_norm = __shfl((int)norm, lw, 64) != 0;
+                last_len = __shfl(ob, lw, 64);
+            }
+            if (WRITE && written) {
+                const int64_t o = total + inc - ob;
+                if (!ws) { for (int k = 0; k < len; ++k) if (o + k < room) out[o + k] = s[q + k]; }
+                else for (int k = 0; k < p.usp_len; ++k) if (o + k < room) out[o + k] = (uint8_t)(p.usp_bytes >> (8 * k));
+            }
+            total += __shfl(inc, 63, 64);
+            nchars += __popcll(m_start); nwritten += __popcll(m_w); nspaces += __popcll(__ballot(norm));
+            if (m_start) { const int ls = 63 - __clzll((long long)m_start); c_exists = true; c_ws = __shfl((int)ws, ls, 64) != 0; c_eq = __shfl((int)eq, ls, 64) != 0; }
+        }
+        if (nwritten > 1 && last_usp) { total -= last_len; if (last_norm) --nspaces; }  // tokdll:667-669
+        const bool any_bad = __any(bad) || nchars <= 0;                                  // tokdll:646-648
+        if (!WRITE && lane == 0) {
+            p.lens[d] = (any_bad || total > 0x7ffffff0ll) ? 0 : (int32_t)total;
+            p.aux[d] = (any_bad ? 1 : 0) | ((nspaces > 0x3fffffff ? 0x3fffffff : (nspaces < 0 ? 0 : nspaces)) << 1);
+        }
+    }
+}
+
+void launch_normsp(const NormSpParams &p, bool write, hipStream_t s)
+{
+    int64_t blocks = (p.ndocs + 3) / 4; if (blocks > 256 * 16) blocks = 256 * 16; if (blocks < 1) blocks = 1;
+    if (write) hipLaunchKernelGGL(k_normsp<true>, dim3((unsigned)blocks), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL(k_normsp<false>, dim3((unsigned)blocks), dim3(256), 0, s, p);
+}
+
+// ------------------------------------------------------------------------------------------
+// TextToHashes (reference tokdll:683-815): tokens are the byte strings between single spaces; hash of a token = the
+// fasttext FNV-1a variant (bytes sign-extended); word n-grams are chained from the unigram hashes (sign-extended to 64 bits)
+// and stored modulo the bucket count in blocks of `tokens` entries behind the unigrams.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_hash_count(HashParams p)
+{
+    const int lane = lane_id();
+    const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (int64_t)gridDim.x * 4;
+    for (int64_t d = wave0; d < p.ndocs; d += nwaves) {
+        const int64_t b = p.doc_off[d], n = p.doc_off[d + 1] - b;
+        long long sp = 0;
+        for (int64_t q = lane; q < n; q += 64) sp += p.text[b + q] == ' ';
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) sp += __shfl_xor(sp, o, 64);
+        const long long cnt = (sp + 1) * (long long)p.ngrams;
+        if (lane == 0) p.lens[d] = (n < 0 || cnt > 0x7ffffff0ll) ? 0 : (int32_t)cnt;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_hash_fill(HashParams p)
+{
+    const int lane = lane_id();
+    const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (int64_t)gridDim.x * 4;
+    // hash of "</s>" (tokdll:696)
+    uint32_t eh = 2166136261u;
+    { const char e4[4] = {'<', '/', 's', '>'}; for (int k = 0; k < 4; ++k) { eh ^= (uint32_t)(int8_t)e4[k]; eh *= 16777619u; } }
+    const unsigned long long eos64 = (unsigned long long)(long long)(int32_t)eh;
+    for (int64_t d = wave0; d < p.ndocs; d += nwaves) {
+        const int64_t b = p.doc_off[d], n = p.doc_off[d + 1] - b;
+        const int64_t o0 = p.out_off[d], room = p.out_off[d + 1] - o0;
+        if (n < 0 || room <= 0) continue;
+        const uint8_t *s = p.text + b;
+        int32_t *out = p.out + o0;
+        const int64_t tc = room / p.ngrams;                              // tokens = spaces + 1
+        // unigrams: token 0 starts at 0, token k at the byte after the k-th space; its lane walks to the next space
+        int64_t base = 0;                                                // spaces before this window
+        for (int64_t pos = 0; pos < n || pos == 0; pos += 64) {
+            const int64_t q = pos + lane;
+            const bool sp = q < n && s[q] == ' ';
+            const unsigned long long m = __ballot(sp);
+            for (int r = 0; r < 2; ++r) {
+                const bool mine = r == 0 ? sp : (q == 0);                // the token after my space; lane of position 0 also owns token 0
+                if (mine) {
+                    const int64_t idx = r == 0 ? base + __popcll(m & lanemask_lt()) + 1 : 0;
+                    uint32_t h = 2166136261u;
+                    for (int64_t k = r == 0 ? q + 1 : 0; k < n && s[k] != ' '; ++k) { h ^= (uint32_t)(int8_t)s[k]; h *= 16777619u; }   // tokdll:684-692
+                    if (idx < tc) out[idx] = (int32_t)h;
+                }
+            }
+            base += __popcll(m);
+            if (n == 0) break;
+        }
+        __threadfence_block();                                           // the unigrams are read by other lanes below
+        for (int64_t i = lane; i < tc; i += 64) {                        // tokdll:699-714
+            unsigned long long h = (unsigned long long)(long long)out[i];
+            for (int j = 1; j < p.ngrams; ++j) {
+                const unsigned long long t = (i + j < tc) ? (unsigned long long)(long long)out[i + j] : eos64;
+                h = h * 116049371ull + t;
+                out[(int64_t)j * tc + i] = (int32_t)(h % (unsigned long long)(long long)p.bucket);
+            }
+        }
+    }
+}
+
+void launch_hash_count(const HashParams &p, hipStream_t s)
+{
+    int64_t blocks = (p.ndocs + 3) / 4; if (blocks > 256 * 16) blocks = 256 * 16; if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(k_hash_count, dim3((unsigned)blocks), dim3(256), 0, s, p);
+}
+void launch_hash_fill(const HashParams &p, hipStream_t s)
+{
+    int64_t blocks = (p.ndocs + 3) / 4; if (blocks > 256 * 16) blocks = 256 * 16; if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(k_hash_fill, dim3((unsigned)blocks), dim3(256), 0, s, p);
+}
+
 void launch_i2t_len(const I2tParams &p, hipStream_t s)
 {
     int64_t blocks = (p.nseq + 3) / 4; if (blocks > 256 * 16) blocks = 256 * 16; if (blocks < 1) blocks = 1;

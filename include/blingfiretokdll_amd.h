@@ -97,6 +97,24 @@ int TextToSentencesWithOffsets(const char *pInUtf8Str, int InUtf8StrByteCount, c
 int TextToSentencesWithOffsetsWithModel(const char *pInUtf8Str, int InUtf8StrByteCount, char *pOutUtf8Str, int *pStartOffsets,
                                         int *pEndOffsets, const int MaxOutUtf8StrByteCount, void *hModel);
 
+/* reference tokdll:629-679 (blingfiretokdll.def: NormalizeSpaces; model-free): every run of white space -> one uSpace (default
+ * U+2581 in the reference's header), leading white space dropped, one trailing uSpace trimmed; returns the output byte count
+ * (0-terminated when there is room), -1 for empty / invalid UTF-8 input or when the output does not fit.  Runs as a batch of
+ * one on the GPU; NormalizeSpacesBatch (additive) does many documents, output layout like TextToWordsBatch (a document the
+ * single call rejects yields nothing). */
+int NormalizeSpaces(const char *pInUtf8Str, int InUtf8StrByteCount, char *pOutUtf8Str, const int MaxOutUtf8StrByteCount, const int uSpace);
+int64_t NormalizeSpacesBatch(const char *text, const int64_t *doc_offsets, int64_t ndocs, char *text_out, int64_t text_cap,
+                             int64_t *text_offsets_out, int uSpace);
+
+/* reference tokdll:773-806 (blingfiretokdll.def: TextToHashes; model-free): fasttext-style hashes of the space-separated tokens
+ * of an already tokenised string, followed by the word n-gram hashes modulo bucketSize; returns the number of hashes,
+ * InUtf8StrByteCount * wordNgrams ("requested size") when MaxHashArrLength is too small, -1 on error.  Deviation: wordNgrams <= 0
+ * is refused (-1); the reference would write past the array.  TextToHashesBatch (additive): document d's hashes =
+ * hashes_out[hash_offsets_out[d] .. hash_offsets_out[d+1]), (spaces + 1) * wordNgrams of them. */
+int TextToHashes(const char *pInUtf8Str, int InUtf8StrByteCount, int32_t *pHashArr, const int MaxHashArrLength, int wordNgrams, int bucketSize);
+int64_t TextToHashesBatch(const char *text, const int64_t *doc_offsets, int64_t ndocs, int32_t *hashes_out, int64_t hashes_cap,
+                          int64_t *hash_offsets_out, int wordNgrams, int bucketSize);
+
 /* reference tokdll:1689-1745 (blingfiretokdll.def: IdsToText): text of an id sequence.  ModelPtr = a LoadModel handle of a
  * model with an [i2w] section (a *.i2w file, or a .bin that carries one).  Ids outside the model's regular range are left
  * out when SkipSpecialTokens is set; a leading space is not written; returns the byte count needed including the

@@ -1169,6 +1169,76 @@ int bfo_ids_to_text(const bfo_model *m, const int32_t *ids, int n, char *out, in
 int bfo_has_i2w(const bfo_model *m) { return m && m->has_i2w; }
 int bfo_i2w_count(const bfo_model *m) { return m ? m->i2w_count : 0; }
 
+/* tokdll:629-679 NormalizeSpaces (model-free): strict UTF-8 decode, every run of white space becomes one uSpace unless
+ * nothing was written yet or the previous written character already equals uSpace, one trailing uSpace is trimmed, re-encode;
+ * -1 on empty / invalid input or when the output does not fit (FAArrayToStrUtf8 cl/src/FAUtf8Utils.cpp:530-557) */
+static int int_to_utf8(int c, char *p, int room)
+{
+    unsigned u = (unsigned)c;
+    if (u <= 0x7F && room > 0) { p[0] = (char)u; return 1; }
+    if (u <= 0x7FF && room > 1) { p[0] = (char)(0xC0 | (u >> 6)); p[1] = (char)(0x80 | (u & 0x3F)); return 2; }
+    if (u <= 0xFFFF && room > 2) {
+        if ((u & 0xFFFFF800u) == 0xD800u) return -1;                                    /* surrogate (cl/src/FAUtf8Utils.cpp:498-501) */
+        p[0] = (char)(0xE0 | (u >> 12)); p[1] = (char)(0x80 | ((u >> 6) & 0x3F)); p[2] = (char)(0x80 | (u & 0x3F)); return 3;
+    }
+    if (u <= 0x10FFFF && room > 3) { p[0] = (char)(0xF0 | (u >> 18)); p[1] = (char)(0x80 | ((u >> 12) & 0x3F)); p[2] = (char)(0x80 | ((u >> 6) & 0x3F)); p[3] = (char)(0x80 | (u & 0x3F)); return 4; }
+    return -1;
+}
+int bfo_normalize_spaces(const char *s, int n, char *out, int max_out, int u_space)
+{
+    int *buf, len, i = 0, j = 0, pos = 0;
+    if (n == 0) return -1;                                                              /* tokdll:634-636 */
+    if (n < 0 || !s) return -1;
+    buf = (int *)malloc(sizeof(int) * (size_t)n);
+    len = bfo_utf8_to_utf32(s, n, buf, n);
+    if (len <= 0 || len > n) { free(buf); return -1; }
+    while (i < len) {                                                                   /* tokdll:651-664 */
+        const int c = buf[i++];
+        if (!is_ws(c)) buf[j++] = c;
+        else if (0 < j && u_space != buf[j - 1]) buf[j++] = u_space;
+    }
+    if (1 < j && buf[j - 1] == u_space) j--;                                            /* tokdll:667-669 */
+    for (i = 0; i < j; ++i) {
+        const int k = int_to_utf8(buf[i], out + pos, max_out - pos);
+        if (k < 0) { free(buf); return -1; }
+        pos += k;
+    }
+    if (pos < max_out) out[pos] = 0;
+    free(buf);
+    return pos;
+}
+
+/* tokdll:683-815 TextToHashes (model-free; the text is already tokenised, tokens separated by single spaces): fasttext-style
+ * FNV-1a hash of every token (bytes sign-extended, tokdll:684-692), then word n-grams h = h * 116049371 + next, stored modulo
+ * the bucket count behind the unigram hashes (tokdll:699-714); the n-gram arithmetic runs on sign-extended int32 values */
+static uint32_t ft_hash(const char *s, int n) { uint32_t h = 2166136261u; int i; for (i = 0; i < n; ++i) { h ^= (uint32_t)(int8_t)s[i]; h *= 16777619u; } return h; }
+int bfo_text_to_hashes(const char *s, int n, int32_t *out, int max_out, int ngrams, int bucket)
+{
+    int tokens, i, count = 0, pos, wlen = 0; const char *w;
+    const int32_t eos = (int32_t)ft_hash("</s>", 4);
+    if (ngrams <= 0 && n < 0) return -1;                                                /* tokdll:786-789 */
+    if (n == 0) tokens = 0; else { tokens = 1; for (i = 0; i < n; ++i) if (s[i] == ' ') tokens++; }   /* tokdll:718-737 */
+    if (tokens * ngrams >= max_out) return n * ngrams;                                  /* tokdll:795-798 */
+    w = s;
+    for (pos = 0; pos <= n; ++pos) {                                                    /* tokdll:743-771 */
+        if (pos == n || s[pos] == ' ') { out[count++] = (int32_t)ft_hash(w, wlen); w = s + pos + 1; wlen = 0; }
+        else ++wlen;
+    }
+    {
+        const int tc = count; int k, jn;
+        for (k = 0; k < tc; ++k) {
+            uint64_t h = (uint64_t)(int64_t)out[k];
+            for (jn = k + 1; jn < k + ngrams; ++jn) {
+                const uint64_t t = (jn < tc) ? (uint64_t)(int64_t)out[jn] : (uint64_t)(int64_t)eos;
+                h = h * 116049371ull + t;
+                out[(jn - k) * tc + k] = (int32_t)(h % (uint64_t)(int64_t)bucket);
+            }
+        }
+        count += (ngrams - 1) * tc;
+    }
+    return count;
+}
+
 /* ---------------- exported building blocks ---------------- */
 
 static const dfa_t *pick(const bfo_model *m, int which) { return which ? &m->dict_dfa : &m->wbd_dfa; }

@@ -55,6 +55,10 @@ int bfo_ids_to_text(const bfo_model *m, const int32_t *ids, int n, char *out, in
 int bfo_has_i2w(const bfo_model *m);
 int bfo_i2w_count(const bfo_model *m);
 
+/* tokdll:629-679 NormalizeSpaces and tokdll:683-815 TextToHashes (both model-free) */
+int bfo_normalize_spaces(const char *utf8, int n, char *out, int max_out, int u_space);
+int bfo_text_to_hashes(const char *utf8, int n, int32_t *out, int max_out, int ngrams, int bucket);
+
 /* tokdll:1669-1679 SetNoDummyPrefix */
 int bfo_set_no_dummy_prefix(bfo_model *m, int flag);
 
