@@ -91,7 +91,7 @@ def main_api():
                 r = g(ctypes.c_void_p(h), arr, n, o, 4096, skip)
                 out["ids_to_text"].append({"model": model, "ids": ids, "skip": int(skip), "ret": r, "out_hex": o.raw[:max(r, 0)].hex()})
         ref.free(h)
-    path = os.path.join(HERE, "api_fixtures.json")
+    path = os.path.join(HERE, "api", "fixtures.json")
     json.dump(out, open(path, "w"))
     print({k: len(v) for k, v in out.items() if isinstance(v, list)}, "->", path)
 

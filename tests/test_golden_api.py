@@ -1,4 +1,4 @@
-"""Committed fixtures of the non-TextToIds entry points (tests/golden/api_fixtures.json, generated from the compiled reference
+"""Committed fixtures of the non-TextToIds entry points (tests/golden/api/fixtures.json, generated from the compiled reference
 by tests/golden/make_golden.py): they pin the oracle where /root/reference is absent (the GPU box) and, on a GPU, the product."""
 import ctypes
 import json
@@ -8,7 +8,7 @@ import pytest
 
 import bfutil
 
-FIX = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "api_fixtures.json")))
+FIX = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "api", "fixtures.json")))
 
 
 def _impls(gpu):
