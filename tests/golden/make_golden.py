@@ -16,6 +16,7 @@ CASES = [  # (model, max_ids, unk)
     ("bert_base_tok.bin", 128, 100), ("bert_base_cased_tok.bin", 64, 100), ("bert_chinese.bin", 64, 100), ("wbd.bin", 64, 0),
     ("gpt2.bin", 64, 0), ("roberta.bin", 64, 0), ("xlnet.bin", 64, 0), ("xlnet_nonorm.bin", 64, 0), ("bpe_example.bin", 64, 1),
     ("laser100k.bin", 64, 0), ("xlm_roberta_base.bin", 128, 0), ("laser500k.bin", 64, 0),
+    ("uri100k.bin", 64, 0), ("uri100kint.bin", 64, 0), ("laser50k.bin", 64, 0), ("bpe_example2.bin", 64, 1),
 ]
 
 

@@ -10,7 +10,7 @@ import blingfire_amd as bf
 pytestmark = pytest.mark.gpu
 
 SP_MODELS = [m for m in ("gpt2.bin", "roberta.bin", "bpe_example.bin", "xlnet.bin", "xlnet_nonorm.bin", "laser100k.bin",
-                         "xlm_roberta_base.bin", "laser500k.bin") if bfutil.have_model(m)]
+                         "xlm_roberta_base.bin", "laser500k.bin", "uri100k.bin", "uri100kint.bin", "laser50k.bin", "bpe_example2.bin") if bfutil.have_model(m)]
 
 
 @pytest.fixture(scope="module")

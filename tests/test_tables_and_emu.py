@@ -9,7 +9,8 @@ import pytest
 import bfutil
 
 ALL_MODELS = ["wbd.bin", "wbd_chuni.bin", "sbd.bin", "bert_base_tok.bin", "bert_base_cased_tok.bin", "bert_chinese.bin", "gpt2.bin", "roberta.bin",
-              "xlnet.bin", "xlnet_nonorm.bin", "bpe_example.bin", "laser100k.bin", "xlm_roberta_base.bin", "laser500k.bin"]
+              "xlnet.bin", "xlnet_nonorm.bin", "bpe_example.bin", "laser100k.bin", "xlm_roberta_base.bin", "laser500k.bin",
+              "uri100k.bin", "uri100kint.bin", "laser50k.bin", "bpe_example2.bin"]
 
 
 @pytest.fixture(scope="module")
