@@ -548,6 +548,9 @@ __device__ __forceinline__ bool sp_delimish(uint32_t code, uint32_t delim) { ret
 
 __global__ __launch_bounds__(256) void k_prep_sp(SpPrepParams p)
 {
+    __shared__ uint32_t ascii_v[128];        // fused map of U+0000..U+007F (in bytes mode: of the bytes 0..127): no global gather for ASCII text
+    if (threadIdx.x < 128) ascii_v[threadIdx.x] = cpmap_get(p.cpmap, (int)threadIdx.x);
+    __syncthreads();
     const int lane = lane_id();
     const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int64_t nwaves = (int64_t)gridDim.x * 4;
@@ -614,7 +617,7 @@ __global__ __launch_bounds__(256) void k_prep_sp(SpPrepParams p)
             // ---- elements of this character
             uint32_t v = 0xFFFFu; int c = 0;
             if (start && !err) {
-                v = cpmap_get(p.cpmap, cp);
+                if (cp < 0x80) v = ascii_v[cp]; else v = cpmap_get(p.cpmap, cp);
                 c = (v & 0x80000000u) ? (int)p.multi_pool[v & 0x7FFFFFFFu] : 1;
             }
             const uint16_t *rec = p.multi_pool + (v & 0x7FFFFFFFu) + 1;
