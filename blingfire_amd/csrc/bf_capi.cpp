@@ -915,6 +915,18 @@ int BfLexStats(void *p, unsigned long long *out, int n)
     return n;
 }
 
+/* diagnostics: documents of the last BPE batch that k_bpe_fused handed to the full path */
+long long BfBpeFallbackDocs(void *p)
+{
+    Handle *h = as_handle(p);
+    if (!h || !h->w_hist.p) return BF_E_ARG;
+    std::lock_guard<std::mutex> lock(h->mu);
+    (void)hipDeviceSynchronize();
+    unsigned int v = 0;
+    if (!hip_ok(hipMemcpy(&v, h->w_hist.p, 4, hipMemcpyDeviceToHost), "D2H")) return BF_E_DEVICE;
+    return (long long)v;
+}
+
 int BfModelKind(void *p) { Handle *h = as_handle(p); return h ? h->m.kind : BF_E_ARG; }
 
 int BfSetVariant(void *p, int variant)

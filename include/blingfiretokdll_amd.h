@@ -178,6 +178,7 @@ int BfLastStatus(void *ModelPtr);
 const char *BfLastError(void);
 
 /* Model facts: 0 = WordPiece lexer, 1 = Unigram-LM, 2 = BPE, 3 = BPE-opt, 4 = BPE with merge ranks */
+long long BfBpeFallbackDocs(void *ModelPtr);   /* diagnostics: documents of the last BPE batch that took the full (sort + apply) path */
 int BfModelKind(void *ModelPtr);
 
 /* experiments: instrumentation counters of the lexer kernel when BF_LEX_STATS=1 is set in the environment */
