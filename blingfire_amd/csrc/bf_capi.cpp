@@ -55,6 +55,18 @@ template <class T> bool upload(DevBuf &b, const std::vector<T> &v, size_t pad_el
 
 enum { EV_BEGIN = 0, EV_PREP, EV_TOK, EV_SCAN, EV_COMPACT, EV_COUNT };
 
+// Makes the handle's device current for the duration of a call and puts the caller's device back afterwards (a drop-in
+// library must not change the calling thread's current device behind its back).
+struct DeviceGuard {
+    int prev = -1; bool switched = false, ok = true;
+    explicit DeviceGuard(int dev)
+    {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev) { ok = hip_ok(hipSetDevice(dev), "hipSetDevice"); switched = ok && prev >= 0; }
+    }
+    ~DeviceGuard() { if (switched) (void)hipSetDevice(prev); }
+};
+
 struct Handle {
     uint32_t magic = 0xB1F14E01u;
     Model m;
@@ -277,7 +289,7 @@ int64_t run_host(Handle *h, const char *text, const int64_t *doc_off, int64_t nd
     const int64_t total = ndocs > 0 ? doc_off[ndocs] - base : 0;
     if (total < 0) return BF_E_ARG;
     std::lock_guard<std::mutex> lock(h->mu);
-    if (!hip_ok(hipSetDevice(h->device), "hipSetDevice")) return BF_E_DEVICE;
+    DeviceGuard dg(h->device); if (!dg.ok) return BF_E_DEVICE;
     hipStream_t s = h->stream;
     // worst-case id count (every id covers >= 1 byte)
     // worst-case id count: _wp ids cover >= 1 byte each; _sp tokens cover >= 1 element of <= mul*(n+1) elements
@@ -374,7 +386,7 @@ int64_t run_i2t_host(Handle *h, const int32_t *ids, const int64_t *id_off, int64
     const int64_t base = id_off[0], total_ids = nseq > 0 ? id_off[nseq] - base : 0;
     if (total_ids < 0) return BF_E_ARG;
     std::lock_guard<std::mutex> lock(h->mu);
-    if (!hip_ok(hipSetDevice(h->device), "hipSetDevice")) return BF_E_DEVICE;
+    DeviceGuard dg(h->device); if (!dg.ok) return BF_E_DEVICE;
     hipStream_t s = h->stream;
     if (!h->w_ids.reserve((size_t)(total_ids + 1) * 4) || !h->w_docoff.reserve((size_t)(nseq + 1) * 8) || !h->w_idoff.reserve((size_t)(nseq + 1) * 8)) return BF_E_DEVICE;
     std::vector<int64_t> rel((size_t)nseq + 1);
@@ -511,7 +523,7 @@ int FreeModel(void *p)
 {
     Handle *h = as_handle(p);
     if (!h) return 0;
-    (void)hipSetDevice(h->device);
+    DeviceGuard dg(h->device);
     (void)hipDeviceSynchronize();
     delete h;
     return 1;
@@ -636,7 +648,7 @@ int64_t TextToWordsBatch(void *p, const char *text, const int64_t *doc_off, int6
     const int64_t base = doc_off[0], total = ndocs > 0 ? doc_off[ndocs] - base : 0;
     if (total < 0) return BF_E_ARG;
     std::lock_guard<std::mutex> lock(h->mu);
-    if (!hip_ok(hipSetDevice(h->device), "hipSetDevice")) return BF_E_DEVICE;
+    DeviceGuard dg(h->device); if (!dg.ok) return BF_E_DEVICE;
     hipStream_t s = h->stream;
     if (!h->w_text.reserve((size_t)total + 16) || !h->w_docoff.reserve((size_t)(ndocs + 1) * 8) || !h->w_outoff.reserve((size_t)(ndocs + 1) * 8)) return BF_E_DEVICE;
     std::vector<int64_t> rel((size_t)ndocs + 1);
@@ -669,7 +681,7 @@ int TextToWordsBatchDevice(void *p, const char *d_text, const int64_t *d_doc_off
     Handle *h = p ? as_handle(p) : default_wbd();
     if (!h) return BF_E_ARG;
     std::lock_guard<std::mutex> lock(h->mu);
-    if (!hip_ok(hipSetDevice(h->device), "hipSetDevice")) return BF_E_DEVICE;
+    DeviceGuard dg(h->device); if (!dg.ok) return BF_E_DEVICE;
     return run_words_device(h, d_text, d_doc_off, ndocs, total_bytes, d_text_out, text_cap, d_text_off_out, (hipStream_t)stream, true);
 }
 
@@ -681,7 +693,7 @@ int NormalizeSpaces(const char *s, int n, char *out, const int max_out, const in
     Handle *h = util_handle();
     if (!h) return -1;
     std::lock_guard<std::mutex> lock(h->mu);
-    if (!hip_ok(hipSetDevice(h->device), "hipSetDevice")) return -1;
+    DeviceGuard dg(h->device); if (!dg.ok) return -1;
     hipStream_t st = h->stream;
     const int64_t off[2] = {0, n};
     if (upload_docs(h, s, off, 1, st) < 0) return -1;
@@ -707,7 +719,7 @@ int64_t NormalizeSpacesBatch(const char *text, const int64_t *doc_off, int64_t n
     Handle *h = util_handle();
     if (!h) return BF_E_DEVICE;
     std::lock_guard<std::mutex> lock(h->mu);
-    if (!hip_ok(hipSetDevice(h->device), "hipSetDevice")) return BF_E_DEVICE;
+    DeviceGuard dg(h->device); if (!dg.ok) return BF_E_DEVICE;
     hipStream_t s = h->stream;
     const int64_t total = upload_docs(h, text, doc_off, ndocs, s);
     if (total < 0) return total;
@@ -738,7 +750,7 @@ int TextToHashes(const char *s, int n, int32_t *hashes, const int max_hashes, in
     Handle *h = util_handle();
     if (!h) return -1;
     std::lock_guard<std::mutex> lock(h->mu);
-    if (!hip_ok(hipSetDevice(h->device), "hipSetDevice")) return -1;
+    DeviceGuard dg(h->device); if (!dg.ok) return -1;
     hipStream_t st = h->stream;
     const int64_t off[2] = {0, n};
     if (upload_docs(h, s, off, 1, st) < 0) return -1;
@@ -761,7 +773,7 @@ int64_t TextToHashesBatch(const char *text, const int64_t *doc_off, int64_t ndoc
     Handle *h = util_handle();
     if (!h) return BF_E_DEVICE;
     std::lock_guard<std::mutex> lock(h->mu);
-    if (!hip_ok(hipSetDevice(h->device), "hipSetDevice")) return BF_E_DEVICE;
+    DeviceGuard dg(h->device); if (!dg.ok) return BF_E_DEVICE;
     hipStream_t s = h->stream;
     const int64_t total = upload_docs(h, text, doc_off, ndocs, s);
     if (total < 0) return total;
@@ -817,7 +829,7 @@ int IdsToTextBatchDevice(void *p, const int32_t *d_ids, const int64_t *d_id_offs
     Handle *h = as_handle(p);
     if (!h) return BF_E_ARG;
     std::lock_guard<std::mutex> lock(h->mu);
-    if (!hip_ok(hipSetDevice(h->device), "hipSetDevice")) return BF_E_DEVICE;
+    DeviceGuard dg(h->device); if (!dg.ok) return BF_E_DEVICE;
     hipStream_t s = (hipStream_t)stream;
     if (!hip_ok(hipMemsetAsync(h->w_misc.p, 0, 64, s), "hipMemsetAsync")) return BF_E_DEVICE;
     int rc = run_i2t_device(h, d_ids, d_id_offsets, nseq, nullptr, 0, d_text_offsets_out, skip_special, s);
@@ -857,7 +869,7 @@ int TextToIdsWithOffsetsBatchDevice(void *p, const char *d_text, const int64_t *
     Handle *h = as_handle(p);
     if (!h) return BF_E_ARG;
     std::lock_guard<std::mutex> lock(h->mu);
-    if (!hip_ok(hipSetDevice(h->device), "hipSetDevice")) return BF_E_DEVICE;
+    DeviceGuard dg(h->device); if (!dg.ok) return BF_E_DEVICE;
     return run_device(h, d_text, d_doc_offsets, ndocs, total_bytes, d_ids_out, cap, d_id_offsets_out, max_ids_per_doc, unk, (hipStream_t)stream,
                       d_starts_out, d_ends_out);
 }
@@ -868,7 +880,7 @@ int TextToIdsBatchDevice(void *p, const char *d_text, const int64_t *d_doc_offse
     Handle *h = as_handle(p);
     if (!h) return BF_E_ARG;
     std::lock_guard<std::mutex> lock(h->mu);
-    if (!hip_ok(hipSetDevice(h->device), "hipSetDevice")) return BF_E_DEVICE;
+    DeviceGuard dg(h->device); if (!dg.ok) return BF_E_DEVICE;
     return run_device(h, d_text, d_doc_offsets, ndocs, total_bytes, d_ids_out, ids_cap, d_id_offsets_out, max_ids_per_doc, unk, (hipStream_t)stream);
 }
 
