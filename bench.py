@@ -150,7 +150,7 @@ def main():
             "gb_input_per_sec": gb_in,
             "ids_per_sec": n_ids * max(world, 1) * args.steps / elapsed,
             "kernel_ms": {"prep": float(kms[0]), "tokenise": tok_ms, "scan": float(kms[2]), "compact": float(kms[3]), "total": float(kms[4])},
-            "roofline": {"bound": "hbm", "kernel": "tokenise (%s)" % ("k_lex_wp_flat" if "bert" in model_name or "wbd" in model_name else "k_seg_sp"), "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "kernel": "tokenise (%s)" % {0: "k_lex_wp_flat", 1: "k_seg_unigram_ring"}.get(bf.lib().BfModelKind(h), "k_bpe_fused"), "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": alg_bytes},
             "verified_docs": verified, "status": status,
