@@ -76,6 +76,10 @@ def lib():
         L.TextToWordsBatch.argtypes = [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p]
         L.TextToWordsBatchDevice.restype = c_int
         L.TextToWordsBatchDevice.argtypes = [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_void_p]
+        L.TextToSentencesBatch.restype = c_int64
+        L.TextToSentencesBatch.argtypes = [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p]
+        L.TextToSentencesBatchDevice.restype = c_int
+        L.TextToSentencesBatchDevice.argtypes = [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_void_p]
         L.IdsToText.restype = c_int
         L.IdsToText.argtypes = [c_void_p, c_void_p, c_int, c_void_p, c_int, ctypes.c_bool]
         L.IdsToTextBatch.restype = c_int64
@@ -197,7 +201,12 @@ def text_to_sentences_and_offsets(s, h=None):
     return sents, [(int(char_at[st[i]]), int(char_at[en[i] + 1])) for i in range(k)]
 
 
-def text_to_words_batch(docs, h=None):
+def text_to_sentences_batch(docs, h=None):
+    """additive: TextToSentences over many documents; h None = the built-in sbd.bin.  Same conventions as text_to_words_batch."""
+    return text_to_words_batch(docs, h, _fn="TextToSentencesBatch")
+
+
+def text_to_words_batch(docs, h=None, _fn="TextToWordsBatch"):
     """additive: TextToWords over many documents (list of bytes, or a (text uint8, offsets int64) pair) -> (text uint8, offsets int64[ndocs+1]);
     h None = the built-in wbd.bin."""
     text, off = docs if isinstance(docs, tuple) else pack_docs(docs)
@@ -205,13 +214,14 @@ def text_to_words_batch(docs, h=None):
     nd = len(off) - 1
     t_off = np.zeros(nd + 1, dtype=np.int64)
     hp = c_void_p(h) if h else None
-    n = lib().TextToWordsBatch(hp, c_void_p(text.ctypes.data), c_void_p(off.ctypes.data), nd, None, 0, c_void_p(t_off.ctypes.data))
+    fn = getattr(lib(), _fn)
+    n = fn(hp, c_void_p(text.ctypes.data), c_void_p(off.ctypes.data), nd, None, 0, c_void_p(t_off.ctypes.data))
     out = np.empty(0, dtype=np.uint8)
     if n == -3:                                           # BF_E_CAPACITY: the offsets tell the size
         out = np.empty(int(t_off[-1]), dtype=np.uint8)
-        n = lib().TextToWordsBatch(hp, c_void_p(text.ctypes.data), c_void_p(off.ctypes.data), nd, c_void_p(out.ctypes.data), len(out), c_void_p(t_off.ctypes.data))
+        n = fn(hp, c_void_p(text.ctypes.data), c_void_p(off.ctypes.data), nd, c_void_p(out.ctypes.data), len(out), c_void_p(t_off.ctypes.data))
     if n < 0:
-        raise RuntimeError("TextToWordsBatch failed: %d (%s)" % (n, lib().BfLastError().decode("utf-8", "replace")))
+        raise RuntimeError("%s failed: %d (%s)" % (_fn, n, lib().BfLastError().decode("utf-8", "replace")))
     return out, t_off
 
 

@@ -332,7 +332,7 @@ int64_t run_host(Handle *h, const char *text, const int64_t *doc_off, int64_t nd
 // TextToWords for a batch resident on the device: lexer in words mode -> spans -> lengths -> scan -> byte gather.
 // The word tags / spans stay in the handle's buffers; d_out may be NULL to size only (d_out_off is always filled).
 int run_words_device(Handle *h, const char *d_text, const int64_t *d_doc_off, int64_t ndocs, int64_t total_bytes,
-                     char *d_out, int64_t out_cap, int64_t *d_out_off, hipStream_t s, bool tokenise)
+                     char *d_out, int64_t out_cap, int64_t *d_out_off, hipStream_t s, bool tokenise, int mode = 1 /* 1 words, 2 sentences */)
 {
     if (h->m.kind != KIND_WP) return BF_E_UNSUPPORTED;
     if (ndocs < 0 || total_bytes < 0 || !d_doc_off || !d_out_off) return BF_E_ARG;
@@ -340,18 +340,18 @@ int run_words_device(Handle *h, const char *d_text, const int64_t *d_doc_off, in
         if (!h->w_ids.reserve((size_t)(total_bytes + 1) * 4) || !h->w_starts.reserve((size_t)(total_bytes + 1) * 4) ||
             !h->w_ends.reserve((size_t)(total_bytes + 1) * 4) || !h->w_idoff.reserve((size_t)(ndocs + 1) * 8)) return BF_E_DEVICE;
         int rc = run_device(h, d_text, d_doc_off, ndocs, total_bytes, h->w_ids.as<int32_t>(), total_bytes, h->w_idoff.as<int64_t>(), 0x7fffffff, 0, s,
-                            h->w_starts.as<int32_t>(), h->w_ends.as<int32_t>(), 1);
+                            h->w_starts.as<int32_t>(), h->w_ends.as<int32_t>(), mode);
         if (rc != 0) return rc;
     }
     const int nblocks = scan_nblocks(ndocs);
     W2tParams p{(const uint8_t *)d_text, d_doc_off, ndocs, h->w_idoff.as<int64_t>(), h->w_starts.as<int32_t>(), h->w_ends.as<int32_t>(),
-                h->w_counts.as<int32_t>(), d_out_off, (uint8_t *)d_out, out_cap};
+                h->w_counts.as<int32_t>(), d_out_off, (uint8_t *)d_out, out_cap, mode == 2 ? h->w_nchars.as<int32_t>() : nullptr};
     if (tokenise) {
-        if (ndocs > 0) launch_w2t_len(p, s);
+        if (ndocs > 0) { if (mode == 2) launch_s2t_len(p, s); else launch_w2t_len(p, s); }
         ScanParams sp{h->w_counts.as<int32_t>(), ndocs, d_out_off, h->w_bsums.as<int64_t>(), nblocks};
         launch_scan(sp, s);
     }
-    if (d_out && ndocs > 0) launch_w2t_copy(p, s);
+    if (d_out && ndocs > 0) { if (mode == 2) launch_s2t_copy(p, s); else launch_w2t_copy(p, s); }
     return hip_ok(hipGetLastError(), "TextToWords kernels") ? 0 : BF_E_DEVICE;
 }
 
@@ -495,6 +495,42 @@ int text_to_ids_one(void *hp, const char *s, int n, int32_t *ids, int max_ids, i
 }
 
 } // namespace
+
+int64_t text_batch_host(void *p, const char *text, const int64_t *doc_off, int64_t ndocs, char *text_out, int64_t text_cap, int64_t *text_off_out, int mode)
+{
+    Handle *h = p ? as_handle(p) : (mode == 2 ? default_sbd() : default_wbd());
+    if (!h) return BF_E_ARG;
+    if (ndocs < 0 || !doc_off || (ndocs > 0 && !text && doc_off[ndocs] > doc_off[0])) return BF_E_ARG;
+    const int64_t base = doc_off[0], total = ndocs > 0 ? doc_off[ndocs] - base : 0;
+    if (total < 0) return BF_E_ARG;
+    std::lock_guard<std::mutex> lock(h->mu);
+    DeviceGuard dg(h->device); if (!dg.ok) return BF_E_DEVICE;
+    hipStream_t s = h->stream;
+    if (!h->w_text.reserve((size_t)total + 16) || !h->w_docoff.reserve((size_t)(ndocs + 1) * 8) || !h->w_outoff.reserve((size_t)(ndocs + 1) * 8)) return BF_E_DEVICE;
+    std::vector<int64_t> rel((size_t)ndocs + 1);
+    for (int64_t i = 0; i <= ndocs; ++i) rel[(size_t)i] = doc_off[i] - base;
+    if (total > 0 && !hip_ok(hipMemcpyAsync(h->w_text.p, text + base, (size_t)total, hipMemcpyHostToDevice, s), "H2D text")) return BF_E_DEVICE;
+    if (!hip_ok(hipMemcpyAsync(h->w_docoff.p, rel.data(), (size_t)(ndocs + 1) * 8, hipMemcpyHostToDevice, s), "H2D offsets")) return BF_E_DEVICE;
+    int rc = run_words_device(h, h->w_text.as<char>(), h->w_docoff.as<int64_t>(), ndocs, total, nullptr, 0, h->w_outoff.as<int64_t>(), s, true, mode);
+    if (rc != 0) return rc;
+    std::vector<int64_t> tmp_off;
+    int64_t *dst_off = text_off_out;
+    if (!dst_off) { tmp_off.resize((size_t)ndocs + 1); dst_off = tmp_off.data(); }
+    if (!hip_ok(hipMemcpyAsync(dst_off, h->w_outoff.p, (size_t)(ndocs + 1) * 8, hipMemcpyDeviceToHost, s), "D2H offsets") ||
+        !hip_ok(hipStreamSynchronize(s), "hipStreamSynchronize")) return BF_E_DEVICE;
+    const int64_t nout = dst_off[ndocs];
+    if (nout > text_cap) return BF_E_CAPACITY;
+    if (nout > 0) {
+        if (!text_out) return BF_E_ARG;
+        if (!h->w_out.reserve((size_t)nout + 16)) return BF_E_DEVICE;
+        rc = run_words_device(h, h->w_text.as<char>(), h->w_docoff.as<int64_t>(), ndocs, total, h->w_out.as<char>(), nout, h->w_outoff.as<int64_t>(), s, false, mode);
+        if (rc != 0) return rc;
+        if (!hip_ok(hipMemcpyAsync(text_out, h->w_out.p, (size_t)nout, hipMemcpyDeviceToHost, s), "D2H text") ||
+            !hip_ok(hipStreamSynchronize(s), "hipStreamSynchronize")) return BF_E_DEVICE;
+    }
+    return nout;
+}
+
 
 extern "C" {
 
@@ -641,39 +677,9 @@ int TextToSentences(const char *s, int n, char *out, const int max_out)
 /* ---- additive: TextToWords for many documents at once; the output string of document d (what TextToWordsWithModel writes,
  *      without the terminating 0) = text_out[text_offsets_out[d] .. text_offsets_out[d+1]) */
 int64_t TextToWordsBatch(void *p, const char *text, const int64_t *doc_off, int64_t ndocs, char *text_out, int64_t text_cap, int64_t *text_off_out)
-{
-    Handle *h = p ? as_handle(p) : default_wbd();
-    if (!h) return BF_E_ARG;
-    if (ndocs < 0 || !doc_off || (ndocs > 0 && !text && doc_off[ndocs] > doc_off[0])) return BF_E_ARG;
-    const int64_t base = doc_off[0], total = ndocs > 0 ? doc_off[ndocs] - base : 0;
-    if (total < 0) return BF_E_ARG;
-    std::lock_guard<std::mutex> lock(h->mu);
-    DeviceGuard dg(h->device); if (!dg.ok) return BF_E_DEVICE;
-    hipStream_t s = h->stream;
-    if (!h->w_text.reserve((size_t)total + 16) || !h->w_docoff.reserve((size_t)(ndocs + 1) * 8) || !h->w_outoff.reserve((size_t)(ndocs + 1) * 8)) return BF_E_DEVICE;
-    std::vector<int64_t> rel((size_t)ndocs + 1);
-    for (int64_t i = 0; i <= ndocs; ++i) rel[(size_t)i] = doc_off[i] - base;
-    if (total > 0 && !hip_ok(hipMemcpyAsync(h->w_text.p, text + base, (size_t)total, hipMemcpyHostToDevice, s), "H2D text")) return BF_E_DEVICE;
-    if (!hip_ok(hipMemcpyAsync(h->w_docoff.p, rel.data(), (size_t)(ndocs + 1) * 8, hipMemcpyHostToDevice, s), "H2D offsets")) return BF_E_DEVICE;
-    int rc = run_words_device(h, h->w_text.as<char>(), h->w_docoff.as<int64_t>(), ndocs, total, nullptr, 0, h->w_outoff.as<int64_t>(), s, true);
-    if (rc != 0) return rc;
-    std::vector<int64_t> tmp_off;
-    int64_t *dst_off = text_off_out;
-    if (!dst_off) { tmp_off.resize((size_t)ndocs + 1); dst_off = tmp_off.data(); }
-    if (!hip_ok(hipMemcpyAsync(dst_off, h->w_outoff.p, (size_t)(ndocs + 1) * 8, hipMemcpyDeviceToHost, s), "D2H offsets") ||
-        !hip_ok(hipStreamSynchronize(s), "hipStreamSynchronize")) return BF_E_DEVICE;
-    const int64_t nout = dst_off[ndocs];
-    if (nout > text_cap) return BF_E_CAPACITY;
-    if (nout > 0) {
-        if (!text_out) return BF_E_ARG;
-        if (!h->w_out.reserve((size_t)nout + 16)) return BF_E_DEVICE;
-        rc = run_words_device(h, h->w_text.as<char>(), h->w_docoff.as<int64_t>(), ndocs, total, h->w_out.as<char>(), nout, h->w_outoff.as<int64_t>(), s, false);
-        if (rc != 0) return rc;
-        if (!hip_ok(hipMemcpyAsync(text_out, h->w_out.p, (size_t)nout, hipMemcpyDeviceToHost, s), "D2H text") ||
-            !hip_ok(hipStreamSynchronize(s), "hipStreamSynchronize")) return BF_E_DEVICE;
-    }
-    return nout;
-}
+{ return text_batch_host(p, text, doc_off, ndocs, text_out, text_cap, text_off_out, 1); }
+int64_t TextToSentencesBatch(void *p, const char *text, const int64_t *doc_off, int64_t ndocs, char *text_out, int64_t text_cap, int64_t *text_off_out)
+{ return text_batch_host(p, text, doc_off, ndocs, text_out, text_cap, text_off_out, 2); }
 
 int TextToWordsBatchDevice(void *p, const char *d_text, const int64_t *d_doc_off, int64_t ndocs, int64_t total_bytes, char *d_text_out,
                            int64_t text_cap, int64_t *d_text_off_out, void *stream)
@@ -683,6 +689,16 @@ int TextToWordsBatchDevice(void *p, const char *d_text, const int64_t *d_doc_off
     std::lock_guard<std::mutex> lock(h->mu);
     DeviceGuard dg(h->device); if (!dg.ok) return BF_E_DEVICE;
     return run_words_device(h, d_text, d_doc_off, ndocs, total_bytes, d_text_out, text_cap, d_text_off_out, (hipStream_t)stream, true);
+}
+
+int TextToSentencesBatchDevice(void *p, const char *d_text, const int64_t *d_doc_off, int64_t ndocs, int64_t total_bytes, char *d_text_out,
+                               int64_t text_cap, int64_t *d_text_off_out, void *stream)
+{
+    Handle *h = p ? as_handle(p) : default_sbd();
+    if (!h) return BF_E_ARG;
+    std::lock_guard<std::mutex> lock(h->mu);
+    DeviceGuard dg(h->device); if (!dg.ok) return BF_E_DEVICE;
+    return run_words_device(h, d_text, d_doc_off, ndocs, total_bytes, d_text_out, text_cap, d_text_off_out, (hipStream_t)stream, true, 2);
 }
 
 /* ---- NormalizeSpaces (reference tokdll:629-679), model-free; batch of one on the GPU + additive batch forms */

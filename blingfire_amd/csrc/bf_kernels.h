@@ -119,8 +119,14 @@ struct W2tParams {
     const uint8_t *text; const int64_t *doc_off; int64_t ndocs;
     const int64_t *word_off; const int32_t *starts, *ends;
     int32_t *lens; const int64_t *text_off; uint8_t *out; int64_t out_cap;
+    const int32_t *nvalid;       // sentences only: characters decoded per document (<= 0: the document is rejected)
 };
 void launch_w2t_len(const W2tParams &p, hipStream_t s);
+// TextToSentences output assembly (reference tokdll:257-339) on the same parameters: ends[] = last byte of every token of the
+// sentence breaker (starts[] unused); a sentence runs from the byte after the previous token to the token's last byte, the rest
+// of the document is the last sentence; leading white space dropped, '\n' / NUL -> ' ', sentences joined by '\n'
+void launch_s2t_len(const W2tParams &p, hipStream_t s);
+void launch_s2t_copy(const W2tParams &p, hipStream_t s);
 void launch_w2t_copy(const W2tParams &p, hipStream_t s);
 
 // NormalizeSpaces (reference tokdll:629-679) and TextToHashes (tokdll:683-815) as batches; both are model-free

@@ -1648,6 +1648,113 @@ __global__ __launch_bounds__(256) void k_w2t_copy(W2tParams p)
     }
 }
 
+__device__ __forceinline__ bool dev_is_ws(int c)      // blingfiretokdll.h:17-21 __FAIsWhiteSpace__
+{
+    return c <= 0x20 || c == 0xa0 || (c >= 0x2000 && c <= 0x200f) || c == 0x202f || c == 0x205f || c == 0x2060 || c == 0x2420 || c == 0x2424 ||
+           c == 0x3000 || c == 0xfeff;
+}
+
+// TextToSentences assembly (reference tokdll:257-339).  Sentence k of a document = bytes (end of token k-1) + 1 .. end of token k,
+// plus one more from the last token to the end of the document; its lane skips the leading white space (FAGetFirstNonWhiteSpace,
+// tokdll:138-150, on the valid UTF-8 the lexer accepted) and drops the sentence if nothing is left.  Every emitted sentence
+// but the first is preceded by '\n' (counted with it, like the separator of k_w2t_*).
+struct S2tTok { int len; int src; };
+__device__ __forceinline__ S2tTok s2t_sentence(const W2tParams &p, const uint8_t *src, int n, int bom, int64_t b, int64_t e, int64_t i, bool &any_before)
+{
+    S2tTok t; t.len = 0; t.src = 0;
+    bool emit = false;
+    if (i <= e) {                                                        // i == e: the rest of the document (tokdll:307-311)
+        const int from = i == b ? bom : p.ends[i - 1] + 1;
+        const int to = i < e ? p.ends[i] : n - 1;
+        int q = from;
+        if (i < e || from < n) {
+            while (q <= to) {
+                const unsigned b0 = src[q]; const int len = b0 < 0x80 ? 1 : b0 < 0xE0 ? 2 : b0 < 0xF0 ? 3 : 4; int cp = (int)b0;
+                if (len == 2) cp = ((b0 & 0x1F) << 6) | (src[q + 1] & 0x3F);
+                else if (len == 3) cp = ((b0 & 0x0F) << 12) | ((src[q + 1] & 0x3F) << 6) | (src[q + 2] & 0x3F);
+                else if (len == 4) cp = ((b0 & 0x07) << 18) | ((src[q + 1] & 0x3F) << 12) | ((src[q + 2] & 0x3F) << 6) | (src[q + 3] & 0x3F);
+                if (!dev_is_ws(cp)) break;                               // (U+0000 counts as U+0020, tokdll:233)
+                q += len;
+            }
+            if (q <= to) { emit = true; t.len = to - q + 1; t.src = q; }
+        }
+    }
+    const unsigned long long me = __ballot(emit);
+    const bool sep = emit && (any_before || (me & lanemask_lt()) != 0);
+    if (sep) { t.len += 1; t.src -= 1; }                                // the '\n' in front of it
+    else if (emit) t.src = -t.src - 2;                                  // marks "no separator" (decoded in the copy loop)
+    if (me) any_before = true;
+    return t;
+}
+
+__global__ __launch_bounds__(256) void k_s2t_len(W2tParams p)
+{
+    const int lane = lane_id();
+    const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (int64_t)gridDim.x * 4;
+    for (int64_t d = wave0; d < p.ndocs; d += nwaves) {
+        const int64_t b = p.word_off[d], e = p.word_off[d + 1];
+        const int64_t n64 = p.doc_off[d + 1] - p.doc_off[d];
+        const uint8_t *src = p.text + p.doc_off[d];
+        long long total = 0;
+        if (n64 > 0 && n64 <= 1000000000) {
+            const int n = (int)n64;
+            const int bom = (n >= 3 && src[0] == 0xEF && src[1] == 0xBB && src[2] == 0xBF) ? 3 : 0;
+            bool any_before = false;
+            for (int64_t i0 = b; i0 <= e; i0 += 64) { const S2tTok t = s2t_sentence(p, src, n, bom, b, e, i0 + lane, any_before); total += t.len; }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) total += __shfl_xor(total, o, 64);
+        // a document the single call rejects (invalid UTF-8: no characters decoded) yields nothing: its lens entry is forced to 0 by nvalid
+        if (lane == 0) p.lens[d] = (total > 0x7ffffff0ll || (p.nvalid && p.nvalid[d] <= 0)) ? 0 : (int32_t)total;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_s2t_copy(W2tParams p)
+{
+    __shared__ int s_pre[4][65];
+    __shared__ int s_src[4][64];
+    const int lane = lane_id(), wv = (int)(threadIdx.x >> 6);
+    const int64_t wave0 = (int64_t)blockIdx.x * 4 + wv, nwaves = (int64_t)gridDim.x * 4;
+    for (int64_t d = wave0; d < p.ndocs; d += nwaves) {
+        const int64_t b = p.word_off[d], e = p.word_off[d + 1];
+        int64_t out = p.text_off[d];
+        if (p.text_off[d + 1] <= out) continue;
+        const int n = (int)(p.doc_off[d + 1] - p.doc_off[d]);
+        const uint8_t *src = p.text + p.doc_off[d];
+        const int bom = (n >= 3 && src[0] == 0xEF && src[1] == 0xBB && src[2] == 0xBF) ? 3 : 0;
+        bool any_before = false;
+        for (int64_t i0 = b; i0 <= e; i0 += 64) {
+            const S2tTok t = s2t_sentence(p, src, n, bom, b, e, i0 + lane, any_before);
+            const int inc = wave_incl_scan(t.len);
+            const int total = __shfl(inc, 63, 64);
+            s_pre[wv][lane] = inc - t.len; s_src[wv][lane] = t.src;
+            if (lane == 63) s_pre[wv][64] = total;
+            for (int q = lane; q < total; q += 64) {
+                int lo = 0, hi = 63;
+                while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (s_pre[wv][mid] <= q) lo = mid; else hi = mid - 1; }
+                const int k = q - s_pre[wv][lo];
+                const int sv = s_src[wv][lo];
+                uint8_t c;
+                if (sv >= -1) { if (k == 0) c = '\n'; else { c = src[sv + k]; if (c == '\n' || c == 0) c = ' '; } }     // tokdll:291-296
+                else { c = src[(-sv - 2) + k]; if (c == '\n' || c == 0) c = ' '; }
+                if (out + q < p.out_cap) p.out[out + q] = c;
+            }
+            out += total;
+        }
+    }
+}
+
+void launch_s2t_len(const W2tParams &p, hipStream_t s)
+{
+    int64_t blocks = (p.ndocs + 3) / 4; if (blocks > 256 * 16) blocks = 256 * 16; if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(k_s2t_len, dim3((unsigned)blocks), dim3(256), 0, s, p);
+}
+void launch_s2t_copy(const W2tParams &p, hipStream_t s)
+{
+    int64_t blocks = (p.ndocs + 3) / 4; if (blocks > 256 * 16) blocks = 256 * 16; if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(k_s2t_copy, dim3((unsigned)blocks), dim3(256), 0, s, p);
+}
+
 void launch_w2t_len(const W2tParams &p, hipStream_t s)
 {
     int64_t blocks = (p.ndocs + 3) / 4; if (blocks > 256 * 16) blocks = 256 * 16; if (blocks < 1) blocks = 1;
@@ -1665,11 +1772,6 @@ void launch_w2t_copy(const W2tParams &p, hipStream_t s)
 // character is written iff the character before it exists, is not white space and is not uSpace itself.  One trailing uSpace
 // is trimmed (when more than one character was written).  Pass 1 sizes, pass 2 (WRITE) stores at the scanned offsets.
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ bool dev_is_ws(int c)      // blingfiretokdll.h:17-21 __FAIsWhiteSpace__
-{
-    return c <= 0x20 || c == 0xa0 || (c >= 0x2000 && c <= 0x200f) || c == 0x202f || c == 0x205f || c == 0x2060 || c == 0x2420 || c == 0x2424 ||
-           c == 0x3000 || c == 0xfeff;
-}
 
 template <bool WRITE>
 __global__ __launch_bounds__(256) void k_normsp(NormSpParams p)

@@ -84,6 +84,11 @@ int64_t TextToWordsBatch(void *ModelPtr, const char *text, const int64_t *doc_of
                          int64_t *text_offsets_out);
 int TextToWordsBatchDevice(void *ModelPtr, const char *d_text, const int64_t *d_doc_offsets, int64_t ndocs, int64_t total_bytes,
                            char *d_text_out, int64_t text_cap, int64_t *d_text_offsets_out, void *stream);
+/* the same for TextToSentences (ModelPtr NULL = the built-in sbd.bin): per document the string TextToSentencesWithModel writes */
+int64_t TextToSentencesBatch(void *ModelPtr, const char *text, const int64_t *doc_offsets, int64_t ndocs, char *text_out, int64_t text_cap,
+                             int64_t *text_offsets_out);
+int TextToSentencesBatchDevice(void *ModelPtr, const char *d_text, const int64_t *d_doc_offsets, int64_t ndocs, int64_t total_bytes,
+                               char *d_text_out, int64_t text_cap, int64_t *d_text_offsets_out, void *stream);
 
 /* reference tokdll:163-402 (blingfiretokdll.def: TextToSentences, TextToSentencesWithModel, TextToSentencesWithOffsets,
  * TextToSentencesWithOffsetsWithModel): sentence breaking with the model behind hModel (a LoadModel handle of a [wbd]-type

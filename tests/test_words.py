@@ -228,3 +228,27 @@ def test_gpu_text_to_words_batch(model):
         if h:
             bf.free_model(h)
         ora.free(ho)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("model", ["sbd.bin", None])
+def test_gpu_text_to_sentences_batch(model):
+    """additive batch form: per document exactly the string TextToSentencesWithModel produces (checked against the oracle)"""
+    import blingfire_amd as bf
+    ora, f = _oracle_sent_fn()
+    ho = ora.load(bfutil.model_path(model or "sbd.bin"))
+    h = bf.load_model(bfutil.model_path(model)) if model else None
+    try:
+        docs = _docs(1500, 101) + SENT_DOCS * 3 + [b""]
+        text, off = bfutil.gen_corpus(2000, seed=6, mean=300, sd=80, minlen=20, maxlen=900)
+        raw = text.tobytes()
+        docs += [raw[off[d]:off[d + 1]].replace(b" the ", b". The ") for d in range(2000)]
+        out, t_off = bf.text_to_sentences_batch(docs, h)
+        for d, b in enumerate(docs):
+            r, o, _, _ = _call(f, (ctypes.c_void_p(ho),), b, 4 * len(b) + 8)
+            want = o[:r - 1] if r > 0 else b""
+            assert out[t_off[d]:t_off[d + 1]].tobytes() == want, (model, d, b[:60])
+    finally:
+        if h:
+            bf.free_model(h)
+        ora.free(ho)
