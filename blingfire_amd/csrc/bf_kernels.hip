@@ -1,14 +1,18 @@
 // bf_kernels.hip -- HIP kernels for gfx950 (MI355X, wave64).  Integer / indexing work: no MFMA.
 //
-//  k_prep_wp   wave per document: strict UTF-8 validate + decode, BOM skip, fused charmap+class
-//              lookup, stream compaction of the class stream (ballot / prefix scan).  Streaming,
-//              coalesced: the HBM-shaped stage.                (reference: FAStrUtf8ToArray
-//              cl/src/FAUtf8Utils.cpp:233-270, FAUtf8ToInt :121-196, FANormalize cl/inc/FAUtils_cl.h:311-369,
-//              FAIwMap_pack::GetNewIw cl/inc/FAIwMap_pack.h:55-110)
-//  k_lex_wp_*  one document per lane: DFA lexer + WordPiece post-pass (bf_lex.h).  Latency/gather bound:
-//              one 4-byte gather per DFA transition into the displacement-packed table (L2 resident).
-//  k_scan_*    exclusive scan of per-document id counts -> id offsets.
+//  k_prep_wp_flat / _docs   WordPiece branch prep in two passes: byte -> class translation of the whole text buffer (HBM
+//              streaming) + per-document check; documents with multi-byte characters are redone by a wave (strict UTF-8
+//              decode, BOM skip, fused charmap+class lookup, wave scan).  k_prep_wp: the one-pass form (offsets API).
+//              (reference: FAStrUtf8ToArray cl/src/FAUtf8Utils.cpp:233-270, FAUtf8ToInt :121-196, FANormalize
+//              cl/inc/FAUtils_cl.h:311-369, FAIwMap_pack::GetNewIw cl/inc/FAIwMap_pack.h:55-110)
+//  k_lex_wp_*  one document per lane: DFA lexer + WordPiece post-pass (bf_lex.h).  Bound by the divergent-gather path:
+//              one 8-byte gather per DFA transition into the displacement-packed table.
+//  k_prep_sp, k_sp_hist/_scan/_scatter, k_seg_unigram_*, k_bpe_*   SentencePiece-style branch: prologue, document order,
+//              Unigram-LM (scores in an LDS ring) and BPE (one-pass segment solver + full path) segmenters (bf_seg.h).
+//  k_scan_*    exclusive scan of per-document counts -> offsets.
 //  k_compact   wave-cooperative gather of the per-document staging slots into one contiguous id array.
+//  k_i2t_*, k_w2t_*, k_s2t_*, k_normsp, k_hash_*   IdsToText / TextToWords / TextToSentences string assembly,
+//              NormalizeSpaces, TextToHashes: variable-length byte gathers and streaming kernels.
 #include <hip/hip_runtime.h>
 #include "bf_kernels.h"
 
@@ -295,47 +299,6 @@ struct ClsWin {
         const int t = (i + shift) >> 3;
         if (t != tag) { w = cls16[blk0 + t]; tag = t; }
     }
-};
-
-// 8-byte window (4 characters per refill): cheaper extraction, twice the refills
-struct ClsWin8 {
-    const uint2 *cls8; int64_t blk0; int shift; uint2 w; int tag;
-    __device__ __forceinline__ void init(const uint16_t *cls_buf, int64_t elem_off)
-    {
-        cls8 = (const uint2 *)cls_buf; blk0 = elem_off >> 2; shift = (int)(elem_off & 3); tag = -1; w = make_uint2(0, 0);
-    }
-    __device__ __forceinline__ uint32_t operator()(int i)
-    {
-        const int a = i + shift, t = a >> 2;
-        if (t != tag) { w = cls8[blk0 + t]; tag = t; }
-        return __builtin_amdgcn_perm(w.y, w.x, 0x0c0c0100u + 0x0202u * (uint32_t)(a & 3));
-    }
-    __device__ __forceinline__ void prefetch(int i)
-    {
-        const int t = (i + shift) >> 2;
-        if (t != tag) { w = cls8[blk0 + t]; tag = t; }
-    }
-};
-
-// 32-byte variant of the window (16 characters per refill)
-struct ClsWin32 {
-    const uint4 *cls16; int64_t blk0; int shift; uint4 w0, w1; int tag;
-    __device__ __forceinline__ void init(const uint16_t *cls_buf, int64_t elem_off)
-    {
-        cls16 = (const uint4 *)cls_buf; blk0 = (elem_off >> 4) * 2; shift = (int)(elem_off & 15); tag = -1;
-        w0 = make_uint4(0, 0, 0, 0); w1 = w0;
-    }
-    __device__ __forceinline__ uint32_t operator()(int i)
-    {
-        const int a = i + shift, t = a >> 4;
-        if (t != tag) { const uint4 *q = cls16 + blk0 + 2 * (int64_t)t; w0 = q[0]; w1 = q[1]; tag = t; }
-        const uint32_t l0 = (a & 2) ? w0.y : w0.x, h0 = (a & 2) ? w0.w : w0.z;
-        const uint32_t l1 = (a & 2) ? w1.y : w1.x, h1 = (a & 2) ? w1.w : w1.z;
-        const uint32_t d0 = (a & 4) ? h0 : l0, d1 = (a & 4) ? h1 : l1;
-        const uint32_t dw = (a & 8) ? d1 : d0;
-        return (a & 1) ? (dw >> 16) : (dw & 0xFFFFu);
-    }
-    __device__ __forceinline__ void prefetch(int) {}
 };
 
 // saved frames in LDS, structure-of-arrays (bank = lane): word (d, field) of lane t at [(d*12 + field) * nthreads + t]
