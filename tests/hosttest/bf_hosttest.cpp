@@ -196,6 +196,8 @@ static int emu_wp(const Model &m, const char *s, int n, int32_t *ids, int32_t *s
     return lex_doc(L, cls_at, nch, out, max_ids, unk, frames);
 }
 
+static std::vector<int32_t> *g_arc_dump = nullptr;
+
 // scalar restatement of the _sp prologue on the fused element-code map (the prep KERNEL is wave-parallel; GPU tests cover it)
 static int emu_sp(const Model &m, const char *s, int n, int32_t *ids, int32_t *spans, std::vector<int> *src_off, int max_ids, int unk)
 {
@@ -242,8 +244,28 @@ static int emu_sp(const Model &m, const char *s, int n, int32_t *ids, int32_t *s
     }
     const int cap = 6 * L + 32;
     std::vector<SegArc> arcs((size_t)cap); std::vector<int32_t> tos((size_t)L + 1), idsv((size_t)L + 1); std::vector<uint8_t> inter((size_t)L + 1);
+    if (g_arc_dump) {       // tests/test_parallel_formulations.py: the arc list in collection order, before the sort
+        const int na = L > 0 ? seg_bpe_collect(S, cls_at, L, arcs.data(), cap, unk) : 0;
+        g_arc_dump->assign({L, na, m.kind});
+        for (int k = 0; k < na; ++k) { g_arc_dump->push_back(arcs[(size_t)k].start); g_arc_dump->push_back(arcs[(size_t)k].end); g_arc_dump->push_back(arcs[(size_t)k].id); g_arc_dump->push_back((int32_t)arcs[(size_t)k].rank_bits); }
+    }
     int r = seg_bpe_doc(S, cls_at, L, arcs.data(), cap, tos.data(), idsv.data(), inter.data(), out, max_ids, unk);
     return r < 0 ? -2 : r;
+}
+
+// BPE models: ids as bft_emu_text_to_ids + the collected arc list: out = [L, narcs, kind, (start, end, id, rank bits) * narcs]; returns
+// the id count (-2: the reference would not terminate), *out_ints = ints written (0 if the buffer is too small)
+int bft_emu_bpe_arcs(void *hv, const char *s, int n, int32_t *ids, int max_ids, int unk, int32_t *out, int out_cap, int *out_ints)
+{
+    Model &m = ((Handle *)hv)->m;
+    *out_ints = 0;
+    if (!m.error.empty() || m.kind == KIND_WP || m.kind == KIND_UNIGRAM) return -1;
+    std::vector<int32_t> dump;
+    g_arc_dump = &dump;
+    const int r = emu_sp(m, s, n, ids, nullptr, nullptr, max_ids, unk);
+    g_arc_dump = nullptr;
+    if ((int)dump.size() <= out_cap) { memcpy(out, dump.data(), dump.size() * sizeof(int32_t)); *out_ints = (int)dump.size(); }
+    return r;
 }
 
 int bft_emu_text_to_ids(void *hv, const char *s, int n, int32_t *ids, int max_ids, int unk)
