@@ -85,7 +85,6 @@ struct Handle {
     hipStream_t stream = nullptr;
     hipEvent_t ev[EV_COUNT] = {};
     bool ev_valid = false;
-    bool last_nonempty = false;                                 // TextToWords: the (single) document decoded to >= 1 character
     ~Handle()
     {
         for (DevBuf *b : {&t_i2w_off, &t_i2w_data, &t_wbd, &t_info, &t_acts, &t_cp_l1, &t_cp_pages, &t_multi, &t_wcp_l1, &t_wcp_pages, &t_dict, &t_seginfo, &w_s1, &w_s2, &w_s3, &w_s4, &w_perm, &w_hist, &w_narcs, &w_cls, &w_nchars, &w_tmp, &w_counts, &w_flags, &w_out, &w_outoff,
@@ -281,7 +280,8 @@ int run_device(Handle *h, const char *d_text, const int64_t *d_doc_off, int64_t 
 }
 
 int64_t run_host(Handle *h, const char *text, const int64_t *doc_off, int64_t ndocs, int32_t *ids_out, int64_t ids_cap,
-                 int64_t *id_off_out, int max_ids, int unk, int32_t *starts_out = nullptr, int32_t *ends_out = nullptr, int words = 0)
+                 int64_t *id_off_out, int max_ids, int unk, int32_t *starts_out = nullptr, int32_t *ends_out = nullptr, int words = 0,
+                 bool *first_doc_nonempty = nullptr /* words modes: the first document decoded to >= 1 character */)
 {
     const bool want_off = starts_out && ends_out;
     if (ndocs < 0 || !doc_off || (ndocs > 0 && !text && doc_off[ndocs] > doc_off[0])) return BF_E_ARG;
@@ -316,7 +316,7 @@ int64_t run_host(Handle *h, const char *text, const int64_t *doc_off, int64_t nd
     int32_t nch0 = 0;
     if (words && ndocs == 1 && !hip_ok(hipMemcpyAsync(&nch0, h->w_nchars.p, 4, hipMemcpyDeviceToHost, s), "D2H nchars")) return BF_E_DEVICE;
     if (!hip_ok(hipStreamSynchronize(s), "hipStreamSynchronize")) return BF_E_DEVICE;
-    h->last_nonempty = nch0 > 0;
+    if (first_doc_nonempty) *first_doc_nonempty = nch0 > 0;
     if (status & 2) return BF_E_INTERNAL;
     const int64_t nids = dst_off[ndocs];
     if (nids > ids_cap) return BF_E_CAPACITY;
@@ -591,9 +591,10 @@ int TextToWordsWithOffsetsWithModel(const char *s, int n, char *out, int *starts
     std::vector<int32_t> tags((size_t)n + 1), ws((size_t)n + 1), we((size_t)n + 1);
     const int64_t off[2] = {0, n};
     int64_t id_off[2] = {0, 0};
-    const int64_t w = run_host(h, s, off, 1, tags.data(), n + 1, id_off, 0x7fffffff, 0, ws.data(), we.data(), 1);
+    bool nonempty = false;
+    const int64_t w = run_host(h, s, off, 1, tags.data(), n + 1, id_off, 0x7fffffff, 0, ws.data(), we.data(), 1, &nonempty);
     if (w < 0) { fprintf(stderr, "[blingfire_amd] TextToWords failed (%lld): %s\n", (long long)w, g_last_error.c_str()); return -1; }
-    if (w == 0 && !h->last_nonempty) return -1;                                // invalid UTF-8 / nothing decoded (tokdll:477-480)
+    if (w == 0 && !nonempty) return -1;                                // invalid UTF-8 / nothing decoded (tokdll:477-480)
     std::string os;
     os.reserve((size_t)n + (size_t)w + 1);
     for (int64_t k = 0; k < w; ++k) {
@@ -633,9 +634,10 @@ int TextToSentencesWithOffsetsWithModel(const char *s, int n, char *out, int *st
     std::vector<int32_t> tags((size_t)n + 1), ws((size_t)n + 1), we((size_t)n + 1);
     const int64_t off[2] = {0, n};
     int64_t id_off[2] = {0, 0};
-    const int64_t w = run_host(h, s, off, 1, tags.data(), n + 1, id_off, 0x7fffffff, 0, ws.data(), we.data(), 2);
+    bool nonempty = false;
+    const int64_t w = run_host(h, s, off, 1, tags.data(), n + 1, id_off, 0x7fffffff, 0, ws.data(), we.data(), 2, &nonempty);
     if (w < 0) { fprintf(stderr, "[blingfire_amd] TextToSentences failed (%lld): %s\n", (long long)w, g_last_error.c_str()); return -1; }
-    if (w == 0 && !h->last_nonempty) return -1;                                // invalid UTF-8 / nothing decoded (tokdll:228-231)
+    if (w == 0 && !nonempty) return -1;                                // invalid UTF-8 / nothing decoded (tokdll:228-231)
     const unsigned char *u = (const unsigned char *)s;
     std::string os; os.reserve((size_t)n + 1);
     int from = (n >= 3 && u[0] == 0xEF && u[1] == 0xBB && u[2] == 0xBF) ? 3 : 0, sents = 0; bool added = false;

@@ -156,7 +156,10 @@ int64_t TextToIdsBatch(void *ModelPtr, const char *text, const int64_t *doc_offs
  * 0 = enqueued, negative = error.  The total id count is d_id_offsets_out[ndocs].  ids_cap must be
  * >= min(2 * (total_bytes + ndocs), ndocs * max_ids_per_doc) to be safe for any input (WordPiece models never
  * need more than total_bytes); ids beyond ids_cap are dropped
- * and reported by BfLastStatus.  d_text needs no padding. */
+ * and reported by BfLastStatus.  d_text needs no padding.
+ * A handle owns ONE set of device workspaces: the ...Device calls on one handle must be ordered on the device (the same
+ * stream, or streams the caller synchronises); for concurrent batches use one handle per stream (LoadModel is cheap:
+ * a few MB of tables).  The host-buffer calls serialise on the handle's mutex and synchronise before they return. */
 int TextToIdsBatchDevice(void *ModelPtr, const char *d_text, const int64_t *d_doc_offsets, int64_t ndocs,
                          int64_t total_bytes, int32_t *d_ids_out, int64_t ids_cap, int64_t *d_id_offsets_out,
                          int max_ids_per_doc, int unk, void *stream);
