@@ -1,20 +1,28 @@
 #!/usr/bin/env python3
 """bench.py -- throughput of the batch TextToIds hot path on N MI355X (one process per GPU).
 
-A "step" = one pass of the whole pipeline (prep -> tokenise -> scan -> compact) over the rank's shard of
-the synthetic corpus, with the input text and document offsets already resident in HBM.  The corpus is
-statically range-sharded (rank r owns documents [r*D, (r+1)*D)), no data-path collective exists; the only
-torch.distributed traffic is the timing barrier and a MAX-reduce of the elapsed time.
+A "step" = one pass of the whole pipeline (prep -> tokenise -> scan -> compact) over the rank's shard of the synthetic
+corpus, with the input text and document offsets already resident in HBM.  The corpus has a FIXED size (strong scaling,
+BASELINE.json north_star: "throughput on a synthetic 10M-doc / ~512-byte-per-doc corpus is reported at 1/2/4/8 GPUs"):
+rank r of G owns documents [floor(r*N/G), floor((r+1)*N/G)); no data-path collective exists, the only torch.distributed
+traffic is the timing barrier, a MAX-reduce of the elapsed time and the gather of the per-rank facts.
 
-Default workload = the north-star headline (BASELINE.json): bert_base_tok.bin, ~512-byte documents,
-1.25 M documents per GPU (= the 10 M-document corpus at 8 GPUs), max_ids 512, unk 100.
-`--workload config2` selects BASELINE.json configs[1] (1 M docs ~128 bytes).
+    python bench.py                      # N=1: the metric's configuration (bert_base_tok.bin, 10 M documents of ~512 bytes)
+    python bench.py --gpus 4             # spawns 4 ranks itself (torch.distributed.run) -- or exits non-zero if the box has < 4 GPUs
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 4 ... bench.py --gpus 4     # the driver's form
 
-Prints ONE JSON line (rank 0) with the driver's contract keys plus `roofline` and `cpu_baseline`.
+`n_gpus` in the result is the number of ranks that actually ran (WORLD_SIZE), each on its own device (listed under
+`ranks`); `--gpus` that disagrees with WORLD_SIZE is an error.  Before timing, EVERY document of the shard is compared
+with the CPU checker (oracle/_ref = the compiled reference when present, else the oracle port): id counts exactly, ids
+through a 64-bit per-document hash computed on both sides -- a mismatch refuses to time.
+
+Prints ONE JSON line (rank 0) with the driver's contract keys plus `roofline`, `cpu_baseline` and `timings`.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -24,20 +32,77 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 
+# total documents of each workload; the corpus is sharded over the ranks
+TOTAL_DOCS = {"headline512": 10000000, "config2": 1000000, "config3": 1000000, "config4": 10000000, "config5": 10000000}
+DOMINANT = {0: "k_lex_wp_flat", 1: "k_seg_unigram_ring"}
 
-def main():
+
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="headline512", choices=["headline512", "config2", "config3", "config4", "config5"])
-    ap.add_argument("--docs-per-gpu", type=int, default=0, help="override the shard size (documents per GPU)")
+    ap.add_argument("--workload", default="headline512", choices=sorted(TOTAL_DOCS))
+    ap.add_argument("--docs", type=int, default=0, help="override the TOTAL number of documents of the corpus")
+    ap.add_argument("--docs-per-gpu", type=int, default=0, help="override the corpus size as documents per rank (total = this * ranks)")
+    ap.add_argument("--sub-batch-docs", type=int, default=0, help="documents per TextToIdsBatchDevice call (0 = auto: whole shard if the workspace fits)")
     ap.add_argument("--model", default="")
     ap.add_argument("--variant", type=int, default=-1, help="kernel variant (experiments)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-docs", type=int, default=0)
-    ap.add_argument("--verify", type=int, default=2000, help="documents checked bit-exact against the CPU checker before timing")
-    args = ap.parse_args()
+    ap.add_argument("--verify", default="full", help="'full' (default): every document of the shard against the CPU checker; N: the first N; 0: none")
+    ap.add_argument("--no-extra-timings", action="store_true", help="skip the PCIe-inclusive / host-API timings and the lexer transition count")
+    return ap.parse_args()
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start N ranks, one per GPU, or refuse."""
+    import torch
+    share = os.environ.get("BF_BENCH_SHARE_GPU") == "1"
+    have = torch.cuda.device_count()
+    if have < args.gpus and not share:
+        sys.stderr.write("bench: --gpus %d requested but this box exposes %d GPU(s); refusing to report an N-GPU number from fewer devices "
+                         "(BF_BENCH_SHARE_GPU=1 runs the ranks on one GPU over gloo, testing only)\n" % (args.gpus, have))
+        return 2
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def device_doc_hashes(torch, ids, id_off, ndocs):
+    """bfc_ids_hash (oracle/cpu_baseline.c) of every document, on the device ids: sum_j (id_j + C) * (2j + 1) mod 2^64.
+    Checker-side arithmetic only (torch ops on the outputs of the product path)."""
+    import bfutil
+    out = torch.zeros(ndocs, dtype=torch.int64, device=ids.device)
+    chunk = 1 << 20
+    for d0 in range(0, ndocs, chunk):
+        d1 = min(ndocs, d0 + chunk)
+        o = id_off[d0:d1 + 1]
+        a, b = int(o[0].item()), int(o[-1].item())
+        if b == a:
+            continue
+        counts = o[1:] - o[:-1]
+        doc = torch.repeat_interleave(torch.arange(d1 - d0, device=ids.device), counts)
+        j = torch.arange(b - a, device=ids.device, dtype=torch.int64) - (o[:-1] - a)[doc]
+        v = (ids[a:b].to(torch.int64) + bfutil.IDS_HASH_C) * (2 * j + 1)
+        out[d0:d1].index_add_(0, doc, v)
+    return out
+
+
+def main():
+    args = parse_args()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(spawn_ranks(args))
 
     import numpy as np
     import torch
@@ -47,14 +112,19 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    n_gpus = args.gpus
+    if world != args.gpus:
+        sys.stderr.write("bench: --gpus %d but WORLD_SIZE=%d: the two must agree (n_gpus is the number of ranks that really run)\n" % (args.gpus, world))
+        sys.exit(2)
+    share = os.environ.get("BF_BENCH_SHARE_GPU") == "1"      # testing only: several ranks on ONE GPU over gloo
+    dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        # BF_BENCH_SHARE_GPU=1 (testing only): several ranks on ONE GPU over gloo, to exercise the N>1 code path on a 1-GPU box
-        share = os.environ.get("BF_BENCH_SHARE_GPU") == "1"
         dev_index = 0 if share else local_rank
+        if dev_index >= torch.cuda.device_count():
+            sys.stderr.write("bench: rank %d wants cuda:%d but only %d device(s) are visible\n" % (rank, dev_index, torch.cuda.device_count()))
+            sys.exit(2)
         torch.cuda.set_device(dev_index)
         if share:
             dist.init_process_group(backend="gloo")
@@ -64,75 +134,118 @@ def main():
         dev_index = 0
         torch.cuda.set_device(0)
     dev = torch.device("cuda", dev_index)
+    props = torch.cuda.get_device_properties(dev)
 
     wl = bfutil.WORKLOADS[args.workload]
     model_name = args.model or wl["model"] or bfutil.bert_model_name()
+    if args.workload in ("headline512", "config2") and not args.model and model_name != "bert_base_tok.bin" and rank == 0:
+        sys.stderr.write("bench: models/bert_base_tok.bin is absent -- falling back to %s (NOT the metric's model)\n" % model_name)
     max_ids, unk = wl["max_ids"], wl["unk"]
-    default_docs = {"headline512": 1250000, "config2": 1000000, "config3": 1000000, "config4": 1250000, "config5": 1250000}[args.workload]
-    docs_per_gpu = args.docs_per_gpu or default_docs
+    total_docs = args.docs or (args.docs_per_gpu * world if args.docs_per_gpu else TOTAL_DOCS[args.workload])
+    first = rank * total_docs // world
+    ndocs = (rank + 1) * total_docs // world - first
 
     # ---- the rank's shard, generated on the host and made resident in HBM before any timing
-    text, off = bfutil.gen_corpus(docs_per_gpu, first_doc=rank * docs_per_gpu, **wl["gen"])
-    d_text = torch.from_numpy(text).to(dev)
-    d_off = torch.from_numpy(off).to(dev)
+    text, off = bfutil.gen_corpus(ndocs, first_doc=first, **wl["gen"])
+    total_bytes = int(off[-1])
     h = bf.load_model(bfutil.model_path(model_name))
+    kind = bf.lib().BfModelKind(h)
     if args.variant >= 0:
         bf.lib().BfSetVariant(h, args.variant)
-    ndocs = docs_per_gpu
-    total_bytes = int(off[-1])
-    cap = max(1, min(2 * (total_bytes + ndocs), ndocs * max_ids))
-    out_ids = torch.empty(cap, dtype=torch.int32, device=dev)
-    out_off = torch.empty(ndocs + 1, dtype=torch.int64, device=dev)
+    # sub-batches: one TextToIdsBatchDevice call each.  The _sp segmenters keep up to 16 bytes of workspace per stream element
+    # (2 elements per byte with a charmap), so a 5 GB shard is issued in pieces that keep the workspace under ~64 GB.
+    sub = args.sub_batch_docs
+    if sub <= 0:
+        per_doc_ws = (total_bytes / max(ndocs, 1) + 1) * (6 if kind == 0 else 44)
+        sub = max(1, min(ndocs, int(64e9 / per_doc_ws)))
+    d_text_all = torch.from_numpy(text).to(dev)
+    d_off_all = torch.from_numpy(off).to(dev)
+    batches = []
+    for d0 in range(0, ndocs, sub):
+        d1 = min(ndocs, d0 + sub)
+        b0, b1 = int(off[d0]), int(off[d1])
+        nb, nd = b1 - b0, d1 - d0
+        cap = max(1, min(2 * (nb + nd), nd * max_ids))
+        batches.append(dict(d0=d0, d1=d1, text=d_text_all[b0:b1], off=(d_off_all[d0:d1 + 1] - b0).contiguous(),
+                            ids=torch.empty(cap, dtype=torch.int32, device=dev), id_off=torch.empty(nd + 1, dtype=torch.int64, device=dev)))
 
-    def step():
-        bf.text_to_ids_batch_device(h, d_text, d_off, max_ids, unk, out_ids=out_ids, out_off=out_off)
+    def step(collect_ms=None):
+        for b in batches:
+            bf.text_to_ids_batch_device(h, b["text"], b["off"], max_ids, unk, out_ids=b["ids"], out_off=b["id_off"])
+            if collect_ms is not None:
+                collect_ms += np.array(bf.last_kernel_ms(h), dtype=np.float64)   # HIP events recorded on the launch stream
 
-    # ---- parity gate on a prefix of the shard (the checker is never inside the timed region)
-    verified = 0
-    if args.verify > 0:
-        nv = min(args.verify, ndocs)
-        lib_path, _kind = bfutil.checker_lib_path()
-        _, _, gids, goff = bfutil.cpu_text_to_ids_batch(lib_path, bfutil.model_path(model_name), text[:off[nv]], off[:nv + 1], max_ids, unk)
+    # ---- parity gate: EVERY document of the shard (the checker is never inside the timed region)
+    verified, verify_secs = 0, 0.0
+    nv = ndocs if args.verify == "full" else min(int(args.verify), ndocs)
+    lib_path, ck_kind = bfutil.checker_lib_path()
+    cpu_threads = max(1, bfutil.host_threads() // (world if not share else 1))
+    if nv > 0:
+        verify_secs, c_counts, c_hash = bfutil.cpu_doc_hashes(lib_path, bfutil.model_path(model_name), text[:off[nv]], off[:nv + 1], max_ids, unk,
+                                                              nthreads=cpu_threads)
         step()
         torch.cuda.synchronize(dev)
-        g_off = out_off[:nv + 1].cpu().numpy()
-        g_ids = out_ids[:int(g_off[-1])].cpu().numpy()
-        if not (np.array_equal(g_off, goff) and np.array_equal(g_ids, gids)):
-            raise SystemExit("bench: GPU ids differ from the CPU checker on the verification prefix -- refusing to time")
-        verified = nv
+        for b in batches:
+            if b["d0"] >= nv:
+                break
+            k = min(b["d1"], nv) - b["d0"]
+            g_counts = (b["id_off"][1:k + 1] - b["id_off"][:k]).cpu().numpy()
+            g_hash = device_doc_hashes(torch, b["ids"], b["id_off"], k).cpu().numpy().view(np.uint64)
+            ok_c = np.array_equal(g_counts, c_counts[b["d0"]:b["d0"] + k])
+            ok_h = np.array_equal(g_hash, c_hash[b["d0"]:b["d0"] + k])
+            if not (ok_c and ok_h):
+                bad = np.nonzero((g_counts != c_counts[b["d0"]:b["d0"] + k]) | (g_hash != c_hash[b["d0"]:b["d0"] + k]))[0]
+                d = int(bad[0]) + b["d0"]
+                raise SystemExit("bench: GPU ids differ from the CPU checker (%s) on %d document(s) of rank %d, first = shard document %d (%r...) -- refusing to time"
+                                 % (ck_kind, len(bad), rank, d, bytes(text[off[d]:off[d] + 64])))
+            verified += k
 
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize(dev)
-    if world > 1:
+    if dist:
         dist.barrier()
     kms = np.zeros(5, dtype=np.float64)
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step()
-        kms += np.array(bf.last_kernel_ms(h), dtype=np.float64)   # HIP events recorded on the launch stream
+        step(kms)
     torch.cuda.synchronize(dev)
-    if world > 1:
+    if dist:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    my_elapsed = elapsed
+    if dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     kms /= max(args.steps, 1)
-    n_ids = int(out_off[-1].item())
+    n_ids = sum(int(b["id_off"][-1].item()) for b in batches)
     status = bf.lib().BfLastStatus(h)
 
+    # ---- per-rank facts, gathered on rank 0
+    try:
+        pci = "%04x:%02x:%02x" % (props.pci_domain_id, props.pci_bus_id, props.pci_device_id)
+    except Exception:
+        pci = None
+    me = {"rank": rank, "device": dev_index, "name": props.name, "pci": pci, "cus": props.multi_processor_count,
+          "docs": ndocs, "bytes": total_bytes, "ids": n_ids, "verified_docs": verified, "seconds": my_elapsed, "status": status}
+    ranks = [me]
+    if dist:
+        ranks = [None] * world
+        dist.all_gather_object(ranks, me)
+
+    res = None
     if rank == 0:
-        docs_total = ndocs * max(world, 1)
-        value = docs_total * args.steps / elapsed
-        gb_in = total_bytes * max(world, 1) * args.steps / elapsed / 1e9
-        # algorithmic bytes of one launch of the dominant kernel: n_in + 4*n_ids + 16 per document
+        docs_all = sum(r["docs"] for r in ranks)
+        bytes_all = sum(r["bytes"] for r in ranks)
+        ids_all = sum(r["ids"] for r in ranks)
+        value = docs_all * args.steps / elapsed
+        # algorithmic bytes of one step's launches of the dominant kernel on THIS rank: n_in + 4*n_ids + 16 per document
         alg_bytes = total_bytes + 4 * n_ids + 16 * ndocs
         tok_ms = float(kms[1])
         achieved = alg_bytes / (tok_ms * 1e-3) / 1e9 if tok_ms > 0 else 0.0
         traffic = None
-        try:   # HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this same command
+        try:   # HBM bytes per step of the dominant kernel from the committed rocprofv3 PMC passes of this same command
             tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
             ent = tj.get("%s/%s/%d" % (args.workload, model_name, ndocs))
             if ent:
@@ -140,32 +253,120 @@ def main():
         except Exception:
             traffic = None
         res = {
-            "metric": "docs/sec", "value": value, "unit": "docs/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "metric": "docs/sec", "value": value, "unit": "docs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "int32", "data": "synthetic",
-            "config": {"workload": "%s: %s TextToIds, %d docs/GPU, %.0f B/doc avg, max_ids %d, unk %d" % (
-                args.workload, model_name, ndocs, total_bytes / ndocs, max_ids, unk),
-                "model_file": model_name, "docs_per_gpu": ndocs, "bytes_per_gpu": total_bytes, "ids_per_gpu": n_ids,
+            "config": {"workload": "%s: %s TextToIds, %d documents in total (%d on rank 0), %.0f B/doc avg, max_ids %d, unk %d" % (
+                args.workload, model_name, docs_all, ndocs, bytes_all / max(docs_all, 1), max_ids, unk),
+                "model_file": model_name, "total_docs": docs_all, "total_bytes": bytes_all, "total_ids": ids_all,
+                "docs_per_gpu": ndocs, "sub_batches_per_step": len(batches),
                 "sharding": "static contiguous document ranges, no collective"},
-            "gb_input_per_sec": gb_in,
-            "ids_per_sec": n_ids * max(world, 1) * args.steps / elapsed,
+            "gb_input_per_sec": bytes_all * args.steps / elapsed / 1e9,
+            "ids_per_sec": ids_all * args.steps / elapsed,
             "kernel_ms": {"prep": float(kms[0]), "tokenise": tok_ms, "scan": float(kms[2]), "compact": float(kms[3]), "total": float(kms[4])},
-            "roofline": {"bound": "hbm", "kernel": "tokenise (%s)" % {0: "k_lex_wp_flat", 1: "k_seg_unigram_ring"}.get(bf.lib().BfModelKind(h), "k_bpe_fused"), "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                         "algorithmic_bytes_per_launch": alg_bytes},
-            "verified_docs": verified, "status": status,
+            "roofline": {"bound": "hbm", "kernel": "tokenise (%s)" % DOMINANT.get(kind, "k_bpe_fused"), "achieved": achieved, "peak": HBM_PEAK_GBPS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes,
+                         "launches_per_step": len(batches)},
+            "verified_docs": sum(r["verified_docs"] for r in ranks), "verify": {"checker": ck_kind, "threads": cpu_threads, "seconds": verify_secs,
+                                                                               "method": "per-document id count + 64-bit hash of the ids, every document of the shard"},
+            "status": max(r["status"] for r in ranks), "ranks": ranks,
+            "backend": (dist.get_backend() if dist else None),
         }
-        if world == 1 and not args.no_cpu_baseline:
-            lib_path, kind = bfutil.checker_lib_path()
-            cores = os.cpu_count() or 1
-            ns = args.cpu_sample_docs or min(ndocs, 25000 * cores)
-            secs, _, _, _ = bfutil.cpu_text_to_ids_batch(lib_path, bfutil.model_path(model_name), text[:off[ns]], off[:ns + 1], max_ids, unk,
-                                                        nthreads=cores, passes=1, want_ids=False)
-            res["cpu_baseline"] = {"value": ns / secs, "unit": "docs/s", "cores": cores, "kind": kind,
-                                   "sample": "first %d documents of the same shard, one TextToIds call per document, %d threads sharing one model handle, %.2f s wall" % (ns, cores, secs)}
+
+    # ---- the other two timings of SURVEY.md section 8(d) and the work-rate roofline (rank 0, N=1 only; bounded sample)
+    if rank == 0 and world == 1 and not args.no_extra_timings:
+        ns = min(ndocs, 1250000)
+        nb = int(off[ns])
+        s_text, s_off = text[:nb], off[:ns + 1]
+        # (2) device end-to-end: pinned host buffers -> H2D -> pipeline -> D2H of ids and offsets
+        p_text = torch.from_numpy(s_text).pin_memory()
+        p_off = torch.from_numpy(s_off).pin_memory()
+        cap = max(1, min(2 * (nb + ns), ns * max_ids))
+        e_text = torch.empty(nb, dtype=torch.uint8, device=dev)
+        e_off = torch.empty(ns + 1, dtype=torch.int64, device=dev)
+        e_ids = torch.empty(cap, dtype=torch.int32, device=dev)
+        e_idoff = torch.empty(ns + 1, dtype=torch.int64, device=dev)
+        ph_ids = torch.empty(cap, dtype=torch.int32).pin_memory()
+        ph_off = torch.empty(ns + 1, dtype=torch.int64).pin_memory()
+        e2e = []
+        for it in range(4):
+            torch.cuda.synchronize(dev)
+            t1 = time.perf_counter()
+            e_text.copy_(p_text, non_blocking=True)
+            e_off.copy_(p_off, non_blocking=True)
+            bf.text_to_ids_batch_device(h, e_text, e_off, max_ids, unk, out_ids=e_ids, out_off=e_idoff)
+            ph_off.copy_(e_idoff, non_blocking=True)
+            torch.cuda.synchronize(dev)
+            nid = int(ph_off[-1])
+            ph_ids[:nid].copy_(e_ids[:nid], non_blocking=True)
+            torch.cuda.synchronize(dev)
+            if it:
+                e2e.append(time.perf_counter() - t1)
+        del e_text, e_off, e_ids, e_idoff, ph_ids, p_text, p_off
+        # (3) wall clock of the C call on pageable host buffers (TextToIdsBatch)
+        api = []
+        for it in range(3):
+            t1 = time.perf_counter()
+            bf.text_to_ids_batch(h, (s_text, s_off), max_ids, unk)
+            if it:
+                api.append(time.perf_counter() - t1)
+        res["timings"] = {
+            "kernel_only": {"docs_per_s": value, "ms_per_step": res["ms_per_step"], "what": "device-resident input and output, the whole shard (= value)"},
+            "device_e2e_pinned": {"docs_per_s": ns / min(e2e), "ms": min(e2e) * 1e3, "median_ms": float(np.median(e2e)) * 1e3, "sample_docs": ns,
+                                  "what": "pinned host text -> H2D -> kernels -> D2H ids+offsets, one batch, best of 3"},
+            "host_api_wall": {"docs_per_s": ns / min(api), "ms": min(api) * 1e3, "sample_docs": ns,
+                              "what": "wall clock of TextToIdsBatch(host pointers) incl. staging, best of 2"},
+        }
+        # work-rate roofline of the lexer: table gathers per second against the measured gather ceiling
+        if kind == 0:
+            try:
+                os.environ["BF_LEX_STATS"] = "1"
+                import ctypes
+                buf = (ctypes.c_ulonglong * 16)()
+                bf.lib().BfLexStats.restype = ctypes.c_int
+                bf.lib().BfLexStats.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+                bf.lib().BfLexStats(ctypes.c_void_p(h), buf, 16)
+                before = int(buf[1])
+                step()
+                torch.cuda.synchronize(dev)
+                bf.lib().BfLexStats(ctypes.c_void_p(h), buf, 16)
+                transitions = int(buf[1]) - before
+                del os.environ["BF_LEX_STATS"]
+                clk_hz = float(getattr(props, "clock_rate", 2400000)) * 1e3
+                rate = transitions / (tok_ms * 1e-3) / (props.multi_processor_count * clk_hz)
+                ceil = None
+                try:
+                    ceil = json.load(open(os.path.join(ROOT, "profiles", "gather_ceiling.json")))["ceiling_lane_gathers_per_clk_per_cu"]
+                except Exception:
+                    pass
+                res["roofline"]["gather"] = {"achieved": rate, "ceiling": ceil, "frac": (rate / ceil) if ceil else None,
+                                             "unit": "table lane-gathers / clk / CU", "transitions_per_step": transitions,
+                                             "transitions_per_input_byte": transitions / max(total_bytes, 1),
+                                             "ceiling_source": "tools/microbench/gather.hip on this GPU, table of the model's size (profiles/gather_ceiling.json)"}
+            except Exception as e:   # instrumentation is optional
+                os.environ.pop("BF_LEX_STATS", None)
+                res["roofline"]["gather"] = {"error": str(e)}
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        # reference CPU path on this box's host cores: bounded sample, best of 3 warm passes, 1 thread and all usable threads
+        T = bfutil.host_threads()
+        ns = args.cpu_sample_docs or min(ndocs, 20000 * T)
+        n1 = min(ndocs, 20000)
+        mp = bfutil.model_path(model_name)
+        s1, _, _, _ = bfutil.cpu_text_to_ids_batch(lib_path, mp, text[:off[n1]], off[:n1 + 1], max_ids, unk, nthreads=1, passes=3, want_ids=False)
+        sT, _, _, _ = bfutil.cpu_text_to_ids_batch(lib_path, mp, text[:off[ns]], off[:ns + 1], max_ids, unk, nthreads=T, passes=3, want_ids=False)
+        res["cpu_baseline"] = {"value": ns / sT, "unit": "docs/s", "cores": T, "kind": ck_kind,
+                               "sample": "first %d documents of the same corpus, one TextToIds call per document, %d threads sharing one model handle, best of 3 passes (%.2f s)" % (ns, T, sT),
+                               "one_thread": {"value": n1 / s1, "unit": "docs/s", "sample_docs": n1, "seconds": s1},
+                               "host": {"cpu": bfutil.cpu_model_string(), "os_cpu_count": os.cpu_count(),
+                                        "affinity": len(os.sched_getaffinity(0)), "cgroup_cpu_quota": bfutil.cgroup_cpu_quota()},
+                               "full_shard_pass": {"docs": nv, "threads": cpu_threads, "seconds": verify_secs,
+                                                   "docs_per_s": (nv / verify_secs) if verify_secs > 0 else None,
+                                                   "what": "the verification pass over the whole shard (one cold pass, includes thread start-up)"}}
+    if rank == 0:
         print(json.dumps(res), flush=True)
     bf.free_model(h)
-    if world > 1:
+    if dist:
         dist.destroy_process_group()
 
 

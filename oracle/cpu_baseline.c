@@ -20,10 +20,22 @@ typedef void *(*load_fn)(const char *);
 typedef int (*free_fn)(void *);
 typedef int (*t2i_fn)(void *, const char *, int, int32_t *, int, int);
 
+#define MAX_THREADS 1024
+
 typedef struct {
     t2i_fn t2i; void *model; const char *text; const int64_t *off; int64_t ndocs; int max_ids, unk;
     int tid, nthreads; int64_t ids; uint64_t checksum; int32_t *out_ids; int64_t *out_counts; int64_t stride;
+    uint64_t *out_hash;   /* optional: per-document hash of the ids (bfc_ids_hash) */
 } job_t;
+
+/* Order- and length-sensitive 64-bit hash of one document's ids: sum over j of (id_j + C) * (2j + 1), modulo 2^64.
+ * bench.py computes the same sum on the device ids (torch int64 arithmetic wraps the same way) for the full-shard check. */
+static uint64_t bfc_ids_hash(const int32_t *ids, int n)
+{
+    uint64_t h = 0;
+    for (int j = 0; j < n; ++j) h += ((uint64_t)(int64_t)ids[j] + 0x9E3779B97F4A7C15ull) * (uint64_t)(2 * (int64_t)j + 1);
+    return h;
+}
 
 static void *worker(void *arg)
 {
@@ -35,6 +47,7 @@ static void *worker(void *arg)
         j->ids += n;
         for (int k = 0; k < n; ++k) j->checksum = j->checksum * 1099511628211ull + (uint64_t)(uint32_t)dst[k] + (uint64_t)d;
         if (j->out_counts) j->out_counts[d] = n;
+        if (j->out_hash) j->out_hash[d] = bfc_ids_hash(dst, n);
     }
     free(buf);
     return NULL;
@@ -42,9 +55,9 @@ static void *worker(void *arg)
 
 /* Returns seconds of wall time for one pass (negative on error).  If out_ids != NULL it receives the ids of
  * document d at out_ids[d*max_ids ..] and out_counts[d] the count (golden-file generation). */
-double bfc_time_text_to_ids(const char *lib_path, const char *model_path, const char *text, const int64_t *doc_off,
-                            int64_t ndocs, int max_ids, int unk, int nthreads, int passes, int64_t *total_ids,
-                            int32_t *out_ids, int64_t *out_counts)
+static double run_passes(const char *lib_path, const char *model_path, const char *text, const int64_t *doc_off,
+                         int64_t ndocs, int max_ids, int unk, int nthreads, int passes, int64_t *total_ids,
+                         int32_t *out_ids, int64_t *out_counts, uint64_t *out_hash)
 {
     void *lib = dlopen(lib_path, RTLD_NOW | RTLD_LOCAL);
     if (!lib) { fprintf(stderr, "cpu_baseline: dlopen(%s): %s\n", lib_path, dlerror()); return -1.0; }
@@ -58,18 +71,18 @@ double bfc_time_text_to_ids(const char *lib_path, const char *model_path, const 
     void *model = load(model_path);
     if (!model) { fprintf(stderr, "cpu_baseline: LoadModel(%s) failed\n", model_path); return -3.0; }
     if (nthreads < 1) nthreads = 1;
-    if (nthreads > 256) nthreads = 256;
+    if (nthreads > MAX_THREADS) nthreads = MAX_THREADS;
     if (passes < 1) passes = 1;
     double best = 1e30; int64_t ids = 0;
     for (int p = 0; p < passes; ++p) {
-        pthread_t th[256]; job_t jobs[256];
+        static pthread_t th[MAX_THREADS]; static job_t jobs[MAX_THREADS];   /* not re-entrant: one measurement at a time */
         struct timespec t0, t1;
         clock_gettime(CLOCK_MONOTONIC, &t0);
         for (int t = 0; t < nthreads; ++t) {
             memset(&jobs[t], 0, sizeof(job_t));
             jobs[t].t2i = t2i; jobs[t].model = model; jobs[t].text = text; jobs[t].off = doc_off; jobs[t].ndocs = ndocs;
             jobs[t].max_ids = max_ids; jobs[t].unk = unk; jobs[t].tid = t; jobs[t].nthreads = nthreads;
-            jobs[t].out_ids = out_ids; jobs[t].out_counts = out_counts; jobs[t].stride = max_ids;
+            jobs[t].out_ids = out_ids; jobs[t].out_counts = out_counts; jobs[t].stride = max_ids; jobs[t].out_hash = out_hash;
             pthread_create(&th[t], NULL, worker, &jobs[t]);
         }
         ids = 0;
@@ -81,4 +94,20 @@ double bfc_time_text_to_ids(const char *lib_path, const char *model_path, const 
     if (total_ids) *total_ids = ids;
     fre(model);
     return best;
+}
+
+double bfc_time_text_to_ids(const char *lib_path, const char *model_path, const char *text, const int64_t *doc_off,
+                            int64_t ndocs, int max_ids, int unk, int nthreads, int passes, int64_t *total_ids,
+                            int32_t *out_ids, int64_t *out_counts)
+{
+    return run_passes(lib_path, model_path, text, doc_off, ndocs, max_ids, unk, nthreads, passes, total_ids, out_ids, out_counts, NULL);
+}
+
+/* One pass over the documents that keeps only the id count and bfc_ids_hash of every document (8 + 8 bytes per document
+ * instead of max_ids ints): the CPU side of bench.py's full-shard bit-exactness check.  Returns seconds (negative on error). */
+double bfc_text_to_ids_hashes(const char *lib_path, const char *model_path, const char *text, const int64_t *doc_off,
+                              int64_t ndocs, int max_ids, int unk, int nthreads, int64_t *total_ids,
+                              int64_t *out_counts, uint64_t *out_hash)
+{
+    return run_passes(lib_path, model_path, text, doc_off, ndocs, max_ids, unk, nthreads, 1, total_ids, NULL, out_counts, out_hash);
 }

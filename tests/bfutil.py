@@ -124,7 +124,7 @@ def cpu_text_to_ids_batch(lib_path, model, text, off, max_ids, unk, nthreads=Non
     off = np.ascontiguousarray(off, dtype=np.int64)
     ndocs = len(off) - 1
     if nthreads is None:
-        nthreads = os.cpu_count() or 1
+        nthreads = host_threads()
     total = ctypes.c_int64(0)
     out_ids = out_counts = None
     if want_ids:
@@ -142,6 +142,83 @@ def cpu_text_to_ids_batch(lib_path, model, text, off, max_ids, unk, nthreads=Non
     np.cumsum(out_counts, out=id_off[1:])
     mask = np.arange(out_ids.shape[1])[None, :] < out_counts[:, None]
     return secs, total.value, out_ids[mask], id_off
+
+
+def cpu_doc_hashes(lib_path, model, text, off, max_ids, unk, nthreads=None):
+    """One CPU pass that keeps, per document, the id count and the 64-bit hash of its ids (oracle/cpu_baseline.c
+    bfc_ids_hash) -- the checker side of bench.py's full-shard comparison.  Returns (seconds, counts int64[ndocs], hashes uint64[ndocs])."""
+    L = ctypes.CDLL(CPUBASE_LIB)
+    f = L.bfc_text_to_ids_hashes
+    f.restype = ctypes.c_double
+    f.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_int,
+                  ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+    text = np.ascontiguousarray(text, dtype=np.uint8)
+    off = np.ascontiguousarray(off, dtype=np.int64)
+    ndocs = len(off) - 1
+    counts = np.zeros(ndocs, dtype=np.int64)
+    hashes = np.zeros(ndocs, dtype=np.uint64)
+    total = ctypes.c_int64(0)
+    secs = f(lib_path.encode(), model.encode(), text.ctypes.data, off.ctypes.data, ndocs, max_ids, unk, nthreads or host_threads(),
+             ctypes.byref(total), counts.ctypes.data, hashes.ctypes.data)
+    if secs < 0:
+        raise RuntimeError("cpu baseline driver failed (%s)" % secs)
+    return secs, counts, hashes
+
+
+IDS_HASH_C = -7046029254386353131          # 0x9E3779B97F4A7C15 as int64 (oracle/cpu_baseline.c bfc_ids_hash)
+
+
+def ids_hash_np(ids, id_off):
+    """bfc_ids_hash of every document, numpy (tests)."""
+    ids = np.asarray(ids, dtype=np.int64)
+    id_off = np.asarray(id_off, dtype=np.int64)
+    nd = len(id_off) - 1
+    doc = np.repeat(np.arange(nd), np.diff(id_off))
+    j = np.arange(len(ids), dtype=np.int64) - id_off[:-1][doc]
+    with np.errstate(over="ignore"):
+        v = (ids.astype(np.uint64) + np.uint64(IDS_HASH_C & 0xFFFFFFFFFFFFFFFF)) * (2 * j + 1).astype(np.uint64)
+        h = np.zeros(nd, dtype=np.uint64)
+        np.add.at(h, doc, v)
+    return h
+
+
+def host_threads():
+    """CPU threads this process may actually use: the affinity mask, capped by a cgroup CPU quota if there is one."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    q = cgroup_cpu_quota()
+    if q:
+        n = max(1, min(n, int(q + 0.999)))
+    return n
+
+
+def cgroup_cpu_quota():
+    """CPU quota of the container in cores (cgroup v2 cpu.max or v1 cfs quota), None if unlimited / unknown."""
+    try:
+        a = open("/sys/fs/cgroup/cpu.max").read().split()
+        if a[0] != "max":
+            return float(a[0]) / float(a[1])
+        return None
+    except Exception:
+        pass
+    try:
+        q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return q / p if q > 0 else None
+    except Exception:
+        return None
+
+
+def cpu_model_string():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown"
 
 
 # ------------------------------------------------------------------------------------------------
@@ -180,7 +257,7 @@ def gen_corpus(ndocs, seed=20240202, mean=128, sd=16, minlen=32, maxlen=256, log
             1 if loguniform else 0, float(mean), float(sd), minlen, maxlen, 1 if multibyte else 0]
     total = f(*args, None, off.ctypes.data, 1)
     text = np.empty(total, dtype=np.uint8)
-    f(*args, text.ctypes.data, off.ctypes.data, nthreads or min(os.cpu_count() or 1, 16))
+    f(*args, text.ctypes.data, off.ctypes.data, nthreads or min(host_threads(), 64))
     return text, off
 
 
