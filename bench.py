@@ -146,7 +146,7 @@ def main():
     ndocs = (rank + 1) * total_docs // world - first
 
     # ---- the rank's shard, generated on the host and made resident in HBM before any timing
-    text, off = bfutil.gen_corpus(ndocs, first_doc=first, **wl["gen"])
+    text, off = bfutil.gen_workload(args.workload, ndocs, first_doc=first)
     total_bytes = int(off[-1])
     h = bf.load_model(bfutil.model_path(model_name))
     kind = bf.lib().BfModelKind(h)

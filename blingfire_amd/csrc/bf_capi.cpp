@@ -223,9 +223,12 @@ int run_device(Handle *h, const char *d_text, const int64_t *d_doc_off, int64_t 
         lp.L.T = h->t_wbd.as<uint64_t>(); lp.L.acts = h->t_acts.as<int32_t>();
         lp.L.initial = m.wbd.initial_base; lp.L.initial_l = m.initial_l; lp.L.cls_any = m.cls_any; lp.L.cls_l = m.cls_l; lp.L.cls_r = m.cls_r;
         lp.L.max_depth = m.max_depth; lp.L.max_token_length = m.max_token_length; lp.L.max_frames = m.lex_frames;
+        lp.L.loop_state = (h->variant & 0xff) == 4 ? LX_NO_STATE : m.loop_base;        // variant 4 (experiments): no fast-forward
+        lp.L.loop_info = m.loop_info; lp.L.loop_final = m.loop_final ? 1 : 0;
         lp.b = b; lp.cls = h->w_cls.as<uint16_t>(); lp.nchars = h->w_nchars.as<int32_t>();
         lp.ids_tmp = h->w_tmp.as<int32_t>(); lp.counts = h->w_counts.as<int32_t>(); lp.span_tmp = want_off ? h->w_span.as<int32_t>() : nullptr;
         lp.max_ids = max_ids; lp.unk = unk; lp.next_doc = next_doc; lp.status = status; lp.ev_thresh = 0; lp.fetch_thresh = 0; lp.acts_n = (int)m.acts_pool.size(); lp.words = words;
+        lp.table_n = (int)(m.wbd_t2.size() > (size_t)LX_T_CLS_MASK + 1 ? m.wbd_t2.size() - ((size_t)LX_T_CLS_MASK + 1) : 0);
         lp.stats = getenv("BF_LEX_STATS") ? (unsigned long long *)(h->w_misc.as<char>() + 64) : nullptr;
         if (ndocs > 0) launch_lex_wp(lp, h->variant, s);
         (void)hipEventRecord(h->ev[EV_TOK], s);

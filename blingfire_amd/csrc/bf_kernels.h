@@ -42,6 +42,8 @@ struct WpLexParams {
     int acts_n;                   // ints in L.acts (staged in LDS when small)
     int words;                    // TextToWords mode (bf_lex.h LexLane::words)
     unsigned long long *stats;    // optional instrumentation counters (experiments), else nullptr
+    int table_n;                  // entries of L.T that can hold a transition (the branch-free probe tail behind them is all empty):
+                                  // when they fit, the kernel stages them in LDS (bf_kernels.hip TabLds)
 };
 
 // _sp branch: element slot of document d (stream, DP arrays and the id staging slot share it):

@@ -14,11 +14,26 @@
 //  k_i2t_*, k_w2t_*, k_s2t_*, k_normsp, k_hash_*   IdsToText / TextToWords / TextToSentences string assembly,
 //              NormalizeSpaces, TextToHashes: variable-length byte gathers and streaming kernels.
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include "bf_kernels.h"
 
 namespace bfa {
 
 #define BF_WAVE 64
+
+// compute units of the current device (persistent kernels launch resident-waves-per-CU x CUs workgroups)
+static int device_cus()
+{
+    static int cached[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    if (cached[dev] <= 0) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        cached[dev] = n;
+    }
+    return cached[dev];
+}
 
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63u); }
 __device__ __forceinline__ unsigned long long lanemask_lt() { return (1ull << lane_id()) - 1ull; }
@@ -256,14 +271,14 @@ void launch_prep_wp(const WpPrepParams &p, int64_t total_bytes, unsigned long lo
 {
     if (flags && !p.src_off && ((uintptr_t)p.b.text & 15) == 0 && ((uintptr_t)p.cls & 31) == 0 && total_bytes > 0) {
         const int64_t nchunks = (total_bytes + 15) >> 4;
-        int64_t b1 = (nchunks + 255) / 256; if (b1 > 256 * 16) b1 = 256 * 16;
+        int64_t b1 = (nchunks + 255) / 256; if (b1 > device_cus() * 16) b1 = device_cus() * 16;
         hipLaunchKernelGGL(k_prep_wp_flat, dim3((unsigned)b1), dim3(256), 0, s, p, total_bytes, flags);
-        int64_t b2 = (p.b.ndocs + 255) / 256; if (b2 > 256 * 16) b2 = 256 * 16; if (b2 < 1) b2 = 1;
+        int64_t b2 = (p.b.ndocs + 255) / 256; if (b2 > device_cus() * 16) b2 = device_cus() * 16; if (b2 < 1) b2 = 1;
         hipLaunchKernelGGL(k_prep_wp_docs, dim3((unsigned)b2), dim3(256), 0, s, p, (const unsigned long long *)flags);
         return;
     }
     int64_t blocks = (p.b.ndocs + 3) / 4;
-    if (blocks > 256 * 16) blocks = 256 * 16;
+    if (blocks > device_cus() * 16) blocks = device_cus() * 16;
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(k_prep_wp, dim3((unsigned)blocks), dim3(256), 0, s, p);
 }
@@ -298,6 +313,17 @@ struct ClsWin {
     {
         const int t = (i + shift) >> 3;
         if (t != tag) { w = cls16[blk0 + t]; tag = t; }
+    }
+    __device__ __forceinline__ bool has(int i) const { return ((i + shift) >> 3) == tag; }
+    // number of consecutive elements flagged LX_C_LOOP starting at position i, as far as the window shows (0 .. 8)
+    __device__ __forceinline__ int run(int i)
+    {
+        const int a = i + shift, t = a >> 3;
+        if (t != tag) { w = cls16[blk0 + t]; tag = t; }
+        // bit 14 of the eight 16-bit elements -> one bit each; the run ends at the first clear one (bit 8 is a stopper)
+        const uint32_t f = ((w.x >> 14) & 1u) | ((w.x >> 29) & 2u) | ((w.y >> 12) & 4u) | ((w.y >> 27) & 8u) |
+                           ((w.z >> 10) & 16u) | ((w.z >> 25) & 32u) | ((w.w >> 8) & 64u) | ((w.w >> 23) & 128u);
+        return __builtin_ctz(((~f & 0xFFu) | 0x100u) >> (a & 7));
     }
 };
 
@@ -374,24 +400,32 @@ __global__ __launch_bounds__(THREADS) void k_lex_wp_seq(WpLexParams p)
 // counter; every loop iteration a lane in WALK mode makes exactly one DFA transition, while the heavier
 // "event" code (match handling, calls/returns, next start position) and the document fetch run only when
 // enough lanes of the wave are waiting for them (ballot vote), so that they execute with most lanes active.
-template <int THREADS, class WIN, bool HAS_ANY, int UNROLL, bool STATS>
+template <int THREADS, class WIN, bool HAS_ANY, int UNROLL, bool STATS, bool TLDS = false>
 __global__ __launch_bounds__(THREADS) void k_lex_wp_flat(WpLexParams p)
 {
     extern __shared__ int32_t lex_lds[];
     enum { M_NEED = 0, M_WALK = 1, M_EVENT = 2, M_EXIT = 3 };
+    typedef typename std::conditional<TLDS, TabLds, TabDirect>::type TAB;
     WIN cls_at; cls_at.init(p.cls, 0);
     IdOutLds out; out.buf = lex_lds + (size_t)p.L.max_frames * LEX_FRAME_WORDS * THREADS + threadIdx.x; out.nthreads = THREADS;
     out.init(p.ids_tmp);
     FramesLds frames{lex_lds, THREADS};
     // the (tiny) action pool is staged in LDS so that match handling touches no global memory
     LexTables L = p.L;
+    TAB tab;
     {
         int32_t *acts_lds = lex_lds + ((size_t)p.L.max_frames * LEX_FRAME_WORDS + 8) * THREADS;
         for (int i = threadIdx.x; i < p.acts_n; i += THREADS) acts_lds[i] = p.L.acts[i];
+        if constexpr (TLDS) {
+            // the whole transition table, staged once per workgroup (8-byte aligned behind the action pool)
+            uint64_t *tab_lds = (uint64_t *)(acts_lds + ((p.acts_n + 1) & ~1));
+            for (int i = threadIdx.x; i < p.table_n; i += THREADS) tab_lds[i] = p.L.T[i];
+            tab.lds = tab_lds; tab.n = (uint32_t)p.table_n;
+        } else tab.T = p.L.T;
         __syncthreads();
         L.acts = acts_lds;          // unconditionally LDS: the loads compile to ds_read, not flat_load
     }
-    LexLane<WIN, IdOutLds, FramesLds, HAS_ANY> lane(L, cls_at, out, frames);
+    LexLane<WIN, IdOutLds, FramesLds, HAS_ANY, TAB> lane(L, cls_at, out, frames, tab);
     lane.init(0, 0, 0);
     int mode = M_NEED;
     int64_t doc = -1;
@@ -461,7 +495,12 @@ __global__ __launch_bounds__(THREADS) void k_lex_wp_flat(WpLexParams p)
     }
 }
 
-static size_t lex_lds_bytes(const WpLexParams &p, int threads) { return (((size_t)p.L.max_frames * LEX_FRAME_WORDS + 8) * threads + (size_t)p.acts_n) * 4; }
+static size_t lex_lds_bytes(const WpLexParams &p, int threads, bool tlds = false)
+{
+    return (((size_t)p.L.max_frames * LEX_FRAME_WORDS + 8) * threads + (size_t)((p.acts_n + 1) & ~1)) * 4 + (tlds ? (size_t)p.table_n * 8 : 0);
+}
+constexpr int LEX_TLDS_THREADS = 512;            // workgroup of the LDS-table variant: 8 waves share one copy of the table
+constexpr size_t LEX_TLDS_MAX_BYTES = 64 * 1024; // LDS budget of one workgroup (two of them fit a CU's 160 KB)
 
 void launch_lex_wp(const WpLexParams &p, int variant, hipStream_t s)
 {
@@ -477,19 +516,31 @@ void launch_lex_wp(const WpLexParams &p, int variant, hipStream_t s)
         q.acts_n = p.acts_n;                                          // <= 4096 ints, checked at LoadModel
         int waves_per_cu = (variant >> 24) & 0x3f;
         if (waves_per_cu == 0) {                                      // persistent: exactly the resident waves
-            int per_cu = 0, ncu = 256;
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_lex_wp_flat<64, ClsWin, false, 1, false>, 64, lex_lds_bytes(q, 64)) != hipSuccess || per_cu <= 0) per_cu = 16;
-            hipDeviceProp_t prop; int dev = 0;
-            if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ncu = prop.multiProcessorCount;
-            static_cast<void>(ncu);
+            int per_cu = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_lex_wp_flat<64, ClsWin, false, 3, false>, 64, lex_lds_bytes(q, 64)) != hipSuccess || per_cu <= 0) per_cu = 16;
             waves_per_cu = per_cu;
             (void)hipGetLastError();
         }
-        int64_t blocks = 256 * (int64_t)waves_per_cu;
+        int64_t blocks = (int64_t)device_cus() * (int64_t)waves_per_cu;
         const int64_t need = (p.b.ndocs + 63) / 64;
         if (blocks > need) blocks = need;
         if (blocks < 1) blocks = 1;
         const bool has_any = p.L.cls_any != LX_CLS_NONE;
+        // small models (wbd.bin: TextToWords): the whole table lives in LDS
+        if (kind != 5 && !p.stats && p.table_n > 0 && lex_lds_bytes(q, LEX_TLDS_THREADS, true) <= LEX_TLDS_MAX_BYTES) {
+            constexpr int TH = LEX_TLDS_THREADS;
+            const size_t lds = lex_lds_bytes(q, TH, true);
+            int per_cu = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_lex_wp_flat<TH, ClsWin, false, 3, false, true>, TH, lds) != hipSuccess || per_cu <= 0) per_cu = 2;
+            (void)hipGetLastError();
+            int64_t nb = (int64_t)device_cus() * per_cu;
+            const int64_t need_b = (p.b.ndocs + TH - 1) / TH;
+            if (nb > need_b) nb = need_b;
+            if (nb < 1) nb = 1;
+            if (has_any) hipLaunchKernelGGL((k_lex_wp_flat<TH, ClsWin, true, 1, false, true>), dim3((unsigned)nb), dim3(TH), lds, s, q);
+            else hipLaunchKernelGGL((k_lex_wp_flat<TH, ClsWin, false, 3, false, true>), dim3((unsigned)nb), dim3(TH), lds, s, q);
+            return;
+        }
         const int usel = (variant >> 30) & 3;                // DFA transitions per vote: 0 = three (default; swept on MI355X), 1 = one, 2 = two, 3 = four
         const dim3 g((unsigned)blocks), t(64); const size_t lds = lex_lds_bytes(q, 64);
         if (has_any) hipLaunchKernelGGL((k_lex_wp_flat<64, ClsWin, true, 1, false>), g, t, lds, s, q);
@@ -635,7 +686,7 @@ __global__ __launch_bounds__(256) void k_prep_sp(SpPrepParams p)
 void launch_prep_sp(const SpPrepParams &p, hipStream_t s)
 {
     int64_t blocks = (p.b.ndocs + 3) / 4;
-    if (blocks > 256 * 16) blocks = 256 * 16;
+    if (blocks > device_cus() * 16) blocks = device_cus() * 16;
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(k_prep_sp, dim3((unsigned)blocks), dim3(256), 0, s, p);
 }
@@ -1343,8 +1394,6 @@ __global__ __launch_bounds__(64) void k_bpe_fused(SpSegParams p)
 // instead of a 16-byte global load + store.  {begin, id} of a position go to global memory only when its score
 // improves (8-byte store, nothing waits for it) and are read back by the single backward pass.  A position that
 // leaves the window without any incoming arc gets the reference's sentinel {-1, -1} (..._1best_t.h:61-77,241-265).
-struct SegBI { int32_t begin, id; };
-
 __global__ __launch_bounds__(64) void k_seg_unigram_ring(SpSegParams p, int ring)
 {
     extern __shared__ double seg_ring[];            // [ring][64]
@@ -1441,6 +1490,113 @@ __global__ __launch_bounds__(64) void k_seg_unigram_ring(SpSegParams p, int ring
     if (mode != M_EXIT) atomicOr(p.status, 2);      // trip limit hit: never expected
 }
 
+// 32-byte register window (two aligned 16-byte blocks) over a lane's class stream, positioned by seek(start): the walk from
+// `start` reads start .. start + depth - 1 and then jumps back to start + 1, so a window that follows `start` serves almost
+// every read from registers; seek() shifts it by one block when `start` crosses a block (one load, nothing waits for it).
+// Elements past the window (walks longer than 9..16 elements) are read directly.
+struct ClsWin2 {
+    const uint4 *cls16; int64_t blk0; int shift; uint4 w0, w1; int t0;
+    __device__ __forceinline__ void init(const uint16_t *cls_buf, int64_t elem_off)
+    {
+        cls16 = (const uint4 *)cls_buf; blk0 = elem_off >> 3; shift = (int)(elem_off & 7); t0 = -4; w0 = w1 = make_uint4(0, 0, 0, 0);
+    }
+    __device__ __forceinline__ void seek(int start)
+    {
+        const int t = (start + shift) >> 3;
+        if (t == t0) return;
+        if (t == t0 + 1) { w0 = w1; w1 = cls16[blk0 + t + 1]; }
+        else { w0 = cls16[blk0 + t]; w1 = cls16[blk0 + t + 1]; }
+        t0 = t;
+    }
+    __device__ __forceinline__ uint32_t operator()(int i) const
+    {
+        const int a = i + shift, r = a - (t0 << 3);
+        if ((unsigned)r >= 16u) return ((const uint16_t *)cls16)[(blk0 << 3) + a];
+        const bool hi = (r & 8) != 0, up = (r & 4) != 0;
+        const uint32_t x = hi ? w1.x : w0.x, y = hi ? w1.y : w0.y, z = hi ? w1.z : w0.z, w = hi ? w1.w : w0.w;
+        const uint32_t d0 = up ? z : x, d1 = up ? w : y;
+        return __builtin_amdgcn_perm(d1, d0, 0x0c0c0100u + 0x0202u * (uint32_t)(r & 3));
+    }
+};
+
+// Viterbi scores of the live window: per-lane ring of doubles in LDS, structure-of-arrays (bank pair = lane)
+struct RingLds {
+    double *my; int mask, n;
+    __device__ __forceinline__ double get(int pos) const { return my[(pos & mask) * 64]; }
+    __device__ __forceinline__ void set(int pos, double v) { my[(pos & mask) * 64] = v; }
+    __device__ __forceinline__ void fill(double v) { for (int k = 0; k < n; ++k) my[k * 64] = v; }
+};
+
+// Unigram-LM, default form: bf_seg.h UniLane per lane, persistent lanes pulling documents (longest first).  Every trip of
+// the loop a walking lane makes UNROLL trie transitions and a lane in its backward pass makes one hop whose record was
+// requested BEFORE the walk steps (its latency hides behind them); finished lanes fetch new documents by vote.
+template <int UNROLL>
+__global__ __launch_bounds__(64) void k_seg_unigram_lane(SpSegParams p, int ring_n)
+{
+    extern __shared__ double seg_ring[];            // [ring_n][64]
+    enum { M_NEED = 0, M_WALK = 1, M_BACK = 2, M_EXIT = 3 };
+    const int lane = lane_id();
+    RingLds ring{seg_ring + lane, ring_n - 1, ring_n};
+    ClsWin2 cls_at; cls_at.init(p.stream, 0);
+    UniLane<ClsWin2, RingLds> ul(p.S, cls_at, ring);
+    ul.L = 0; ul.depth = p.trie_depth; ul.start = ul.i = ul.sum = 0; ul.state = 0; ul.unknown = true; ul.pend = false; ul.prev = 0; ul.pend_i = 0;
+    ul.pend_r.id = 0; ul.pend_r.score_bits = 0; ul.end = 0; ul.cnt = 0;
+    int mode = M_NEED;
+    int64_t doc = 0; int32_t *ids = nullptr; int32_t *spans = nullptr; int cap = 0;
+    for (unsigned long long trip = 0; trip < (1ull << 34); ++trip) {
+        // ---- documents for idle lanes
+        const unsigned long long m_need = __ballot(mode == M_NEED);
+        if (m_need) {
+            const unsigned long long m_busy = __ballot(mode == M_WALK || mode == M_BACK);
+            if (__popcll(m_need) >= 8 || m_busy == 0) {
+                if (mode == M_NEED) {
+                    const int c = __popcll(m_need);
+                    const int leader = __ffsll((long long)m_need) - 1;
+                    unsigned long long base = 0;
+                    if (lane == leader) base = atomicAdd(p.next_doc, (unsigned long long)c);
+                    base = __shfl(base, leader, 64);
+                    const int64_t idx = (int64_t)base + __popcll(m_need & lanemask_lt());
+                    if (idx >= p.b.ndocs) mode = M_EXIT;
+                    else {
+                        doc = p.perm[idx];
+                        const int64_t b = p.b.doc_off[doc];
+                        const int64_t slot = sp_slot(b, doc, p.slot_mul);
+                        cap = p.slot_mul * (int)(p.b.doc_off[doc + 1] - b + 1);
+                        const int L = p.lens[doc];
+                        ids = p.ids_tmp + slot; spans = p.span_tmp ? p.span_tmp + 2 * slot : nullptr;
+                        if (L <= 0) { p.counts[doc] = 0; p.narcs[doc] = 0; }
+                        else { cls_at.init(p.stream, slot); ul.init(L, p.trie_depth, (SegBI *)p.best + slot); mode = M_WALK; }
+                    }
+                }
+                if (__ballot(mode != M_EXIT) == 0) break;
+            }
+        }
+        // ---- backward pass: request this trip's record now, use it after the walk steps
+        SegBI bb; bb.begin = 0; bb.id = 0;
+        const bool back = mode == M_BACK;
+        if (back) bb = ul.bi[ul.end];
+        // ---- forward pass: UNROLL trie transitions
+        if (mode == M_WALK) {
+            bool walk = true;
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) { if (walk) walk = ul.wstep(); }
+            if (!walk) { ul.begin_back(); mode = M_BACK; }
+        }
+        if (back) {
+            auto put = [&](int k, int id, int from, int to) {
+                ids[cap - 1 - k] = id;
+                if (spans) { spans[2 * (cap - 1 - k)] = from; spans[2 * (cap - 1 - k) + 1] = to; }
+            };
+            if (!ul.bstep(bb, put, p.unk)) {
+                p.counts[doc] = ul.cnt < p.max_ids ? ul.cnt : p.max_ids;
+                p.narcs[doc] = cap - ul.cnt;
+                mode = M_NEED;
+            }
+        }
+    }
+    if (mode != M_EXIT) atomicOr(p.status, 2);      // trip limit hit: never expected
+}
+
 void launch_seg_sp(const SpSegParams &p_in, hipStream_t s)
 {
     const SpSegParams &p = p_in;
@@ -1456,16 +1612,23 @@ void launch_seg_sp(const SpSegParams &p_in, hipStream_t s)
             int ring = 1; while (ring < p.trie_depth) ring <<= 1;
             const size_t lds = (size_t)ring * 64 * sizeof(double);
             int per_cu = 0;
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_seg_unigram_ring, 64, lds) != hipSuccess || per_cu <= 0) per_cu = 8;
+            const int unroll = p.tune ? p.tune : 3;
+            auto kern = p.variant == 6 ? (const void *)k_seg_unigram_ring : unroll == 1 ? (const void *)k_seg_unigram_lane<1> : unroll == 2 ? (const void *)k_seg_unigram_lane<2> :
+                        unroll == 4 ? (const void *)k_seg_unigram_lane<4> : (const void *)k_seg_unigram_lane<3>;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 64, lds) != hipSuccess || per_cu <= 0) per_cu = 8;
             (void)hipGetLastError();
-            unsigned blocks = 256u * (unsigned)per_cu;
+            unsigned blocks = (unsigned)device_cus() * (unsigned)per_cu;
             if ((int64_t)blocks > (int64_t)b64) blocks = b64;
-            hipLaunchKernelGGL(k_seg_unigram_ring, dim3(blocks), dim3(64), lds, s, p, ring);
+            if (p.variant == 6) hipLaunchKernelGGL(k_seg_unigram_ring, dim3(blocks), dim3(64), lds, s, p, ring);   // round-1 kernel (A/B)
+            else if (unroll == 1) hipLaunchKernelGGL(k_seg_unigram_lane<1>, dim3(blocks), dim3(64), lds, s, p, ring);
+            else if (unroll == 2) hipLaunchKernelGGL(k_seg_unigram_lane<2>, dim3(blocks), dim3(64), lds, s, p, ring);
+            else if (unroll == 4) hipLaunchKernelGGL(k_seg_unigram_lane<4>, dim3(blocks), dim3(64), lds, s, p, ring);
+            else hipLaunchKernelGGL(k_seg_unigram_lane<3>, dim3(blocks), dim3(64), lds, s, p, ring);
         } else {
             int per_cu = 0;
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_seg_unigram_flat, 64, 0) != hipSuccess || per_cu <= 0) per_cu = 16;
             (void)hipGetLastError();
-            unsigned blocks = 256u * (unsigned)per_cu;
+            unsigned blocks = (unsigned)device_cus() * (unsigned)per_cu;
             if ((int64_t)blocks > (int64_t)b64) blocks = b64;
             hipLaunchKernelGGL(k_seg_unigram_flat, dim3(blocks), dim3(64), 0, s, p);
         }
@@ -1481,13 +1644,13 @@ void launch_seg_sp(const SpSegParams &p_in, hipStream_t s)
             int per_cu = 0;
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_bpe_fused<false, true>, 64, lds) != hipSuccess || per_cu <= 0) per_cu = 12;
             (void)hipGetLastError();
-            unsigned blocks = 256u * (unsigned)per_cu;
+            unsigned blocks = (unsigned)device_cus() * (unsigned)per_cu;
             if ((int64_t)blocks > (int64_t)b64) blocks = b64;
             if (mg) { if (local) hipLaunchKernelGGL((k_bpe_fused<true, true>), dim3(blocks), dim3(64), lds, s, p); else hipLaunchKernelGGL((k_bpe_fused<true, false>), dim3(blocks), dim3(64), lds, s, p); }
             else { if (local) hipLaunchKernelGGL((k_bpe_fused<false, true>), dim3(blocks), dim3(64), lds, s, p); else hipLaunchKernelGGL((k_bpe_fused<false, false>), dim3(blocks), dim3(64), lds, s, p); }
             (void)hipMemsetAsync(p.next_doc, 0, sizeof(unsigned long long), s);
         }
-        unsigned sort_blocks = p.fb_list ? 64 : 256 * 2;                 // the fallback list is normally empty
+        unsigned sort_blocks = p.fb_list ? 64 : (unsigned)device_cus() * 2;                 // the fallback list is normally empty
         if ((int64_t)sort_blocks > p.b.ndocs) sort_blocks = (unsigned)p.b.ndocs;
         hipLaunchKernelGGL(k_bpe_sort, dim3(sort_blocks), dim3(256), 0, s, p);
         if (p.variant == 2) hipLaunchKernelGGL(k_bpe_apply, dim3(b64), dim3(64), 0, s, p);
@@ -1496,7 +1659,7 @@ void launch_seg_sp(const SpSegParams &p_in, hipStream_t s)
             int per_cu = 0;
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_bpe_apply_flat, 64, 0) != hipSuccess || per_cu <= 0) per_cu = 16;
             (void)hipGetLastError();
-            unsigned blocks = p.fb_list ? 256u : 256u * (unsigned)per_cu;
+            unsigned blocks = p.fb_list ? (unsigned)device_cus() : (unsigned)device_cus() * (unsigned)per_cu;
             if ((int64_t)blocks > (int64_t)b64) blocks = b64;
             hipLaunchKernelGGL(k_bpe_apply_flat, dim3(blocks), dim3(64), 0, s, p);
         }
@@ -1741,23 +1904,23 @@ __global__ __launch_bounds__(256) void k_s2t_copy(W2tParams p)
 
 void launch_s2t_len(const W2tParams &p, hipStream_t s)
 {
-    int64_t blocks = (p.ndocs + 3) / 4; if (blocks > 256 * 16) blocks = 256 * 16; if (blocks < 1) blocks = 1;
+    int64_t blocks = (p.ndocs + 3) / 4; if (blocks > device_cus() * 16) blocks = device_cus() * 16; if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(k_s2t_len, dim3((unsigned)blocks), dim3(256), 0, s, p);
 }
 void launch_s2t_copy(const W2tParams &p, hipStream_t s)
 {
-    int64_t blocks = (p.ndocs + 3) / 4; if (blocks > 256 * 16) blocks = 256 * 16; if (blocks < 1) blocks = 1;
+    int64_t blocks = (p.ndocs + 3) / 4; if (blocks > device_cus() * 16) blocks = device_cus() * 16; if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(k_s2t_copy, dim3((unsigned)blocks), dim3(256), 0, s, p);
 }
 
 void launch_w2t_len(const W2tParams &p, hipStream_t s)
 {
-    int64_t blocks = (p.ndocs + 3) / 4; if (blocks > 256 * 16) blocks = 256 * 16; if (blocks < 1) blocks = 1;
+    int64_t blocks = (p.ndocs + 3) / 4; if (blocks > device_cus() * 16) blocks = device_cus() * 16; if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(k_w2t_len, dim3((unsigned)blocks), dim3(256), 0, s, p);
 }
 void launch_w2t_copy(const W2tParams &p, hipStream_t s)
 {
-    int64_t blocks = (p.ndocs + 3) / 4; if (blocks > 256 * 16) blocks = 256 * 16; if (blocks < 1) blocks = 1;
+    int64_t blocks = (p.ndocs + 3) / 4; if (blocks > device_cus() * 16) blocks = device_cus() * 16; if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(k_w2t_copy, dim3((unsigned)blocks), dim3(256), 0, s, p);
 }
 
@@ -1856,7 +2019,7 @@ __global__ __launch_bounds__(256) void k_normsp(NormSpParams p)
 
 void launch_normsp(const NormSpParams &p, bool write, hipStream_t s)
 {
-    int64_t blocks = (p.ndocs + 3) / 4; if (blocks > 256 * 16) blocks = 256 * 16; if (blocks < 1) blocks = 1;
+    int64_t blocks = (p.ndocs + 3) / 4; if (blocks > device_cus() * 16) blocks = device_cus() * 16; if (blocks < 1) blocks = 1;
     if (write) hipLaunchKernelGGL(k_normsp<true>, dim3((unsigned)blocks), dim3(256), 0, s, p);
     else hipLaunchKernelGGL(k_normsp<false>, dim3((unsigned)blocks), dim3(256), 0, s, p);
 }
@@ -1928,23 +2091,23 @@ __global__ __launch_bounds__(256) void k_hash_fill(HashParams p)
 
 void launch_hash_count(const HashParams &p, hipStream_t s)
 {
-    int64_t blocks = (p.ndocs + 3) / 4; if (blocks > 256 * 16) blocks = 256 * 16; if (blocks < 1) blocks = 1;
+    int64_t blocks = (p.ndocs + 3) / 4; if (blocks > device_cus() * 16) blocks = device_cus() * 16; if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(k_hash_count, dim3((unsigned)blocks), dim3(256), 0, s, p);
 }
 void launch_hash_fill(const HashParams &p, hipStream_t s)
 {
-    int64_t blocks = (p.ndocs + 3) / 4; if (blocks > 256 * 16) blocks = 256 * 16; if (blocks < 1) blocks = 1;
+    int64_t blocks = (p.ndocs + 3) / 4; if (blocks > device_cus() * 16) blocks = device_cus() * 16; if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(k_hash_fill, dim3((unsigned)blocks), dim3(256), 0, s, p);
 }
 
 void launch_i2t_len(const I2tParams &p, hipStream_t s)
 {
-    int64_t blocks = (p.nseq + 3) / 4; if (blocks > 256 * 16) blocks = 256 * 16; if (blocks < 1) blocks = 1;
+    int64_t blocks = (p.nseq + 3) / 4; if (blocks > device_cus() * 16) blocks = device_cus() * 16; if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(k_i2t_len, dim3((unsigned)blocks), dim3(256), 0, s, p);
 }
 void launch_i2t_copy(const I2tParams &p, hipStream_t s)
 {
-    int64_t blocks = (p.nseq + 3) / 4; if (blocks > 256 * 16) blocks = 256 * 16; if (blocks < 1) blocks = 1;
+    int64_t blocks = (p.nseq + 3) / 4; if (blocks > device_cus() * 16) blocks = device_cus() * 16; if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(k_i2t_copy, dim3((unsigned)blocks), dim3(256), 0, s, p);
 }
 
@@ -2053,7 +2216,7 @@ __global__ __launch_bounds__(256) void k_compact(CompactParams p)
 void launch_compact(const CompactParams &p, hipStream_t s)
 {
     int64_t blocks = (p.b.ndocs + 3) / 4;
-    if (blocks > 256 * 16) blocks = 256 * 16;
+    if (blocks > device_cus() * 16) blocks = device_cus() * 16;
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(k_compact, dim3((unsigned)blocks), dim3(256), 0, s, p);
 }

@@ -44,6 +44,11 @@ struct LexTables {
     uint32_t cls_any, cls_l, cls_r;   // LX_CLS_NONE when the symbol is not in the alphabet
     int max_depth, max_token_length;
     int max_frames;           // saved frames the call graph can need (= call depth - 1, computed at load; <= LEX_MAX_DEPTH - 1)
+    // The model's "loop state" (LX_NO_STATE: none): a state that goes to ITSELF on every class flagged LX_C_LOOP in the class
+    // stream -- for the BERT lexers the state of the top-level rule `(AllLetters)+` after its first letter.  Walking through
+    // it is the same as skipping the run of flagged elements (fp / finfo follow the last one when the state is final), so
+    // step() does that from the class window alone, without one table gather per character.
+    uint32_t loop_state, loop_info; int loop_final;
 };
 
 // where table entries come from: a policy, so that the host build can count lookups per table index
@@ -58,6 +63,13 @@ struct TabDirect {
 #endif
         return T[idx];
     }
+};
+
+// LDS-resident table (models whose transitions fit: wbd.bin is 3.4 K entries = 27 KB): a gather costs ~7 CU-cycles per
+// wave instead of 60-100 from L2 (tools/microbench/gather.hip).  Entries at or past `n` are the empty probe tail.
+struct TabLds {
+    const uint64_t *lds; uint32_t n;
+    BF_HD uint64_t operator()(uint32_t idx) const { return idx < n ? lds[idx] : (uint64_t)LX_T_CLS_MASK; }
 };
 
 // one DFA transition: the table entry + whether it is a hit.  Branch-free and unclamped: the table is padded by
@@ -211,8 +223,21 @@ struct LexLane {
     // anchor (value unused): class streams carry at least one element of padding.
     BF_HD bool step()
     {
+        const int hi = lim < fn_ ? lim : fn_;          // letters are read at positions < hi
+        if (state == L.loop_state && j < hi) {
+            // fast-forward: every flagged element keeps the walk in this state (k transitions of FALexTools_t.h:255-277 at
+            // once; a final loop state is the deepest final state seen after each of them)
+            int k = cls_at.run(off + j);
+            k = k < hi - j ? k : hi - j;
+            if (k > 0) {
+                j += k;
+                if (L.loop_final) { fp = j - 1; finfo = L.loop_info; }
+                if (!(j < lim)) return false;
+                if (j < fn_ && !cls_at.has(off + j)) { cls_at.prefetch(off + j); return true; }   // next element: next trip
+            }
+        }
         const bool ra = j >= fn_;                      // feeding the right anchor (FALexTools_t.h:280-290)
-        uint32_t c = cls_at(off + j);                  // a letter (FALexTools_t.h:255-277)
+        uint32_t c = cls_at(off + j) & LX_T_CLS_MASK;  // a letter (FALexTools_t.h:255-277)
         c = ra ? L.cls_r : c;
         uint64_t e64 = tab(state + c);                 // the gather is issued ...
         cls_at.prefetch(off + j + 1);                  // ... and the refill of the class window for the next letter (when it

@@ -636,6 +636,36 @@ bool build_model(Model &m, const uint8_t *img, size_t size)
                 m.wbd_t2[i] = (uint64_t)lo | ((uint64_t)(fin ? m.wbd_info[next] : 0u) << 32);
             }
 
+            // loop state: the state with the most transitions to itself (ties: the first).  Only text classes matter: the anchors
+            // and IW_ANY never occur in a class stream.
+            m.loop_cls.assign((size_t)m.wbd.nclasses, 0);
+            {
+                const RawDfa &rw = m.wbd_raw;
+                int best_s = -1; uint32_t best_n = 0;
+                for (size_t st = 0; st < rw.state_off.size(); ++st) {
+                    uint32_t n = 0;
+                    for (uint32_t t = rw.tr_begin[st]; t < rw.tr_begin[st + 1]; ++t) n += rw.tr_dst[t] == (int)st;
+                    if (n > best_n) { best_n = n; best_s = (int)st; }
+                }
+                if (best_s >= 0 && best_n >= 8) {
+                    for (uint32_t t = rw.tr_begin[(size_t)best_s]; t < rw.tr_begin[(size_t)best_s + 1]; ++t) {
+                        if (rw.tr_dst[t] != best_s) continue;
+                        int c = rw.tr_sym[t];                               // class if remap, raw symbol otherwise
+                        if (!rw.remap) {
+                            auto &S = m.wbd.sym_of_class;
+                            auto it = std::lower_bound(S.begin(), S.end(), c);
+                            if (it == S.end() || *it != c) continue;
+                            c = (int)(it - S.begin());
+                        }
+                        if (c >= 0 && c < m.wbd.nclasses && (uint32_t)c != m.cls_any && (uint32_t)c != m.cls_l && (uint32_t)c != m.cls_r) m.loop_cls[(size_t)c] = 1;
+                    }
+                    m.loop_base = m.wbd.state_base[(size_t)best_s];
+                    m.loop_final = rw.is_final[(size_t)best_s] != 0;
+                    m.loop_info = m.loop_final ? m.wbd_info[m.loop_base] : 0;
+                }
+            }
+            auto flagged = [&](uint32_t k) -> uint32_t { return (k < m.loop_cls.size() && m.loop_cls[k]) ? (k | LX_C_LOOP) : k; };
+
             // fused code point -> class map (charmap semantics: reference FAUtils_cl.h:311-369 + FAMultiMap_pack_fixed.cpp:67-137)
             FixedMap cm;
             if (charmap_dump >= 0) { if (!cm.set(dump(charmap_dump))) return fail(m, "bad charmap"); m.wbd_has_charmap = true; }
@@ -643,18 +673,18 @@ bool build_model(Model &m, const uint8_t *img, size_t size)
             m.words_cpmap.init(CLS_NONE);
             for (int cp = 0; cp <= 0x10FFFF; ++cp) {
                 { const int wcp = cp == 0 ? 0x20 : cp;                          // tokdll:482, then FALexTools_t.h:258-261
-                  const uint32_t k = cls_sym(wcp < IW_EPSILON ? IW_EPSILON : wcp); if (k != CLS_NONE) m.words_cpmap.set(cp, k); }
+                  const uint32_t k = cls_sym(wcp < IW_EPSILON ? IW_EPSILON : wcp); if (k != CLS_NONE) m.words_cpmap.set(cp, flagged(k)); }
                 int norm[10]; int c = cm.set_ ? cm.get(cp, norm, 10) : -1;
                 auto cls_text = [&](int o) -> uint32_t { return cls_sym(o < IW_EPSILON ? IW_EPSILON : o); };
-                if (c == -1) { uint32_t k = cls_text(cp); if (k != CLS_NONE) m.wbd_cpmap.set(cp, k); }
-                else if (c == 1) { uint32_t k = cls_text(norm[0]); if (k != CLS_NONE) m.wbd_cpmap.set(cp, k); }
+                if (c == -1) { uint32_t k = cls_text(cp); if (k != CLS_NONE) m.wbd_cpmap.set(cp, flagged(k)); }
+                else if (c == 1) { uint32_t k = cls_text(norm[0]); if (k != CLS_NONE) m.wbd_cpmap.set(cp, flagged(k)); }
                 else {
                     if (c < 0 || c > 10) c = 0;    // silently dropped by FANormalize
                     m.wbd_charmap_multi = true;
                     if (m.wbd_multi_pool.size() > 0x7fff0000u) return fail(m, "charmap too large");
                     m.wbd_cpmap.set(cp, FUSED_MULTI | (uint32_t)m.wbd_multi_pool.size());
                     m.wbd_multi_pool.push_back((uint16_t)c);
-                    for (int k = 0; k < c; ++k) m.wbd_multi_pool.push_back((uint16_t)cls_text(norm[k]));
+                    for (int k = 0; k < c; ++k) m.wbd_multi_pool.push_back((uint16_t)flagged(cls_text(norm[k])));
                 }
             }
         }

@@ -111,6 +111,11 @@ struct Model {
     std::vector<int32_t> acts_pool;
     uint32_t cls_any = CLS_NONE, cls_l = CLS_NONE, cls_r = CLS_NONE;
     uint32_t initial_l = 0xFFFFFFFFu;  // state after the left anchor from the initial state (0xFFFFFFFF: none)
+    // "loop state" of the lexer (bf_lex.h LexTables::loop_state): the state with the most self-loop transitions (>= 8), e.g.
+    // the state of `(AllLetters)+` after its first letter in the BERT lexers (774 self-loops).  Classes that loop there carry
+    // LX_C_LOOP in the fused code-point maps below (and so in the class stream); 0xFFFFFFFF = the lexer has none.
+    uint32_t loop_base = 0xFFFFFFFFu, loop_info = 0; bool loop_final = false;
+    std::vector<uint8_t> loop_cls;     // [nclasses] 1 = self-loop of the loop state
     // fused "code point -> charmap -> (cp<3 ? 3 : cp) -> class" map:
     //   value = CLS_NONE | class (count 1 implicit) or FUSED_MULTI | pool offset for 0 or 2..10 outputs
     TwoLevelMap wbd_cpmap;

@@ -107,6 +107,101 @@ BF_HD int seg_unigram_doc(const SegTables &S, ClsAt &cls_at, int L, SegBest *bes
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Unigram-LM as a resumable lane program (the default GPU form; bf_kernels.hip k_seg_unigram_lane drives it, tests/hosttest
+// runs the same code on the host).  Same per-document order of operations as seg_unigram_doc above, cut into
+//   wstep()  one trie transition of the forward pass (AddArc / AddUnknownArc / next start absorbed), and
+//   bstep()  one hop of the backward pass,
+// with two changes of *mechanism* that keep every value identical:
+//  * only `depth` End2BestArc scores are live at a time (an arc from `start` ends before start + depth, depth = longest
+//    dictionary entry): they sit in a ring (LDS on the device); {begin, id} go to memory only when a score improves;
+//  * the relaxation of a final transition is DEFERRED by one step: the I2Info row is requested when the transition is taken
+//    and consumed at the beginning of the next step, behind the issue of that step's trie gather -- the two dependent
+//    gathers of a final transition overlap instead of adding up.  Relaxations still happen in arc order, and the pending one
+//    is flushed before anything reads the score it may change (the end of the walk from `start` reads position `start`).
+// ---------------------------------------------------------------------------------------------------
+struct SegBI { int32_t begin, id; };                  // {begin, id} of one End2BestArc entry
+
+template <class ClsAt, class Ring>
+struct UniLane {
+    const SegTables &S; ClsAt &cls_at; Ring &ring; SegBI *bi;
+    int L, depth, start, i, sum; uint32_t state; bool unknown, pend; double prev; SegInfo pend_r; int pend_i;
+    int end, cnt;                                      // backward pass
+
+    BF_HD UniLane(const SegTables &S_, ClsAt &c, Ring &r) : S(S_), cls_at(c), ring(r), bi(nullptr) {}
+
+    static BF_HD double neg_flt_max() { return -3.40282346638528859811704183484516925e+38; }   // (double)-FLT_MAX
+
+    // Start a document of L >= 1 stream elements; bi_ has room for L entries.
+    BF_HD void init(int L_, int depth_, SegBI *bi_)
+    {
+        L = L_; depth = depth_; bi = bi_;
+        ring.fill(neg_flt_max());
+        start = 0; i = 0; state = S.initial; sum = 0; unknown = true; prev = 0; pend = false; pend_i = 0; pend_r.id = 0; pend_r.score_bits = 0;
+        end = 0; cnt = 0;
+        cls_at.seek(0);
+    }
+
+    BF_HD void relax()                                 // AddArc (..._1best_t.h:118-142) of the pending final transition
+    {
+        const double cand = sg_bits_to_float(pend_r.score_bits) + prev;
+        if (ring.get(pend_i) < cand) { ring.set(pend_i, cand); SegBI v; v.begin = start; v.id = pend_r.id; bi[pend_i] = v; }
+        pend = false;
+    }
+
+    // One trie transition.  Returns false once the forward pass is complete (follow with begin_back / bstep).
+    BF_HD bool wstep()
+    {
+        const uint32_t c = cls_at(i);
+        const bool valid = c < SG_CLS_DELIM_ABSENT;                     // sg_lookup: symbols outside the alphabet never match
+        const uint64_t e = S.T[state + (valid ? c : 0u)];               // the gather is issued ...
+        if (pend) relax();                                              // ... and the previous arc is relaxed while it travels
+        const bool hit = valid && (e & SG_CLS_MASK) == c;
+        bool ends = !hit;
+        if (hit) {
+            state = (uint32_t)((e >> SG_NEXT_SHIFT) & SG_NEXT_MASK);
+            sum += (int)(e >> SG_OW_SHIFT);
+            if (e & SG_FINAL) { pend_r = S.info[sum]; pend_i = i; pend = true; unknown = false; }   // requested now, used next step
+            ++i;
+            ends = i >= L;
+        }
+        if (ends) {
+            if (pend) relax();                                          // only when the arc that ends the document is the last of its walk
+            double fin = ring.get(start);
+            if (unknown) {                                              // AddUnknownArc (..._1best_t.h:145-171)
+                const float unk_score = -100000.0f;
+                const double cand = unk_score + prev;
+                if (fin < cand) {
+                    SegBI v; v.begin = start; v.id = -1;
+                    if (0 < start) { const SegBI pb = bi[start - 1]; if (-1 == pb.id) v.begin = pb.begin; }
+                    bi[start] = v; fin = cand;
+                }
+            }
+            if (!(neg_flt_max() < fin)) { SegBI z; z.begin = -1; z.id = -1; bi[start] = z; }      // no incoming arc at all (..._1best_t.h:61-77)
+            ++start;
+            if (!(start < L)) return false;
+            prev = fin;                                                 // End2BestArc[start - 1] is final by now
+            ring.set(start + depth - 1, neg_flt_max());                 // the position that enters the reach of this start
+            i = start; state = S.initial; sum = 0; unknown = true;
+            cls_at.seek(start);
+        }
+        return true;
+    }
+
+    BF_HD void begin_back() { end = L - 1; cnt = 0; }
+    // One hop of the backward pass (..._1best_t.h:237-265) given bb = bi[end] (read by the caller, so that a GPU driver can
+    // request it early): id k-from-the-end goes to ids[cap - 1 - k].  Returns false after the last hop.
+    template <class IdPut>
+    BF_HD bool bstep(const SegBI &bb, IdPut &put, int unk)
+    {
+        const int id = bb.id != -1 ? bb.id : unk;
+        put(cnt, id + S.id_offset, bb.begin, end);
+        ++cnt;
+        end = bb.begin - 1;
+        return end >= 0;
+    }
+};
+
+// ---------------------------------------------------------------------------------------------------
 // BPE (both flavours).  arcs[] has room for arc_cap entries; tos/idsv/inter are the three work arrays of
 // …_bpe_t.h:258-296.  Returns -1 if arc_cap is exceeded (the host turns that into a loud error).
 // ---------------------------------------------------------------------------------------------------

@@ -169,7 +169,7 @@ IDS_HASH_C = -7046029254386353131          # 0x9E3779B97F4A7C15 as int64 (oracle
 
 
 def ids_hash_np(ids, id_off):
-    """bfc_ids_hash of every document, numpy (tests)."""
+    """bfc_ids_hash of every document, numpy (tests): sum_j (id_j + C) * (2j + 1) modulo 2^64 through a wrapping prefix sum."""
     ids = np.asarray(ids, dtype=np.int64)
     id_off = np.asarray(id_off, dtype=np.int64)
     nd = len(id_off) - 1
@@ -177,9 +177,8 @@ def ids_hash_np(ids, id_off):
     j = np.arange(len(ids), dtype=np.int64) - id_off[:-1][doc]
     with np.errstate(over="ignore"):
         v = (ids.astype(np.uint64) + np.uint64(IDS_HASH_C & 0xFFFFFFFFFFFFFFFF)) * (2 * j + 1).astype(np.uint64)
-        h = np.zeros(nd, dtype=np.uint64)
-        np.add.at(h, doc, v)
-    return h
+        cs = np.concatenate([np.zeros(1, dtype=np.uint64), np.cumsum(v, dtype=np.uint64)])
+        return cs[id_off[1:]] - cs[id_off[:-1]]
 
 
 def host_threads():
@@ -261,15 +260,81 @@ def gen_corpus(ndocs, seed=20240202, mean=128, sd=16, minlen=32, maxlen=256, log
     return text, off
 
 
+_pieces_cache = {}
+MULTI_BUCKETS = ["latin", "cyrillic", "cjk", "arabic", "devanagari", "greek", "thai"]
+MULTI_BUCKET_P = [0.50, 0.15, 0.10, 0.08, 0.05, 0.04, 0.03]          # + 5 % "mixed" 
+
+
+def _pieces(name):
+    """tests/data/pieces_<name>.tsv.gz (tools/make_piece_lists.py) as flat arrays for tools/corpusgen.c bfc_gen_multi"""
+    if name not in _pieces_cache:
+        import gzip
+        per = {b: [] for b in MULTI_BUCKETS}
+        cm = []
+        with gzip.open(os.path.join(ROOT, "tests", "data", "pieces_%s.tsv.gz" % name), "rb") as f:
+            for line in f:
+                b, piece = line.rstrip(b"\n").split(b"\t", 1)
+                if b == b"charmap":
+                    cm.append(piece)
+                else:
+                    per[b.decode()].append(piece)
+        pieces, boff, cdf = [], [0], []
+        for b in MULTI_BUCKETS:
+            ps = per[b]
+            pieces += ps
+            boff.append(len(pieces))
+            if ps:
+                w = np.arange(1, len(ps) + 1, dtype=np.float64) ** -1.07
+                c = np.cumsum(w / w.sum())
+                c[-1] = 1.0
+                cdf.append(c)
+        blob = np.frombuffer(b"".join(pieces), dtype=np.uint8).copy()
+        poff = np.zeros(len(pieces) + 1, dtype=np.int32)
+        np.cumsum([len(x) for x in pieces], out=poff[1:])
+        cm_blob = np.frombuffer(b"".join(cm) or b"\0", dtype=np.uint8).copy()
+        cm_off = np.zeros(len(cm) + 1, dtype=np.int32)
+        if cm:
+            np.cumsum([len(x) for x in cm], out=cm_off[1:])
+        bucket_cdf = np.cumsum(np.array(MULTI_BUCKET_P + [1.0 - sum(MULTI_BUCKET_P)], dtype=np.float64))
+        bucket_cdf[-1] = 1.0
+        _pieces_cache[name] = (blob, poff, np.array(boff, dtype=np.int32), np.concatenate(cdf), bucket_cdf, cm_blob, cm_off, len(cm))
+    return _pieces_cache[name]
+
+
+def gen_corpus_multi(ndocs, pieces="xlmr", seed=4, mean=512, sd=64, minlen=128, maxlen=1024, first_doc=0, nthreads=None):
+    """Deterministic multilingual corpus.  Returns (text uint8[total], doc_off int64[ndocs+1])."""
+    L = ctypes.CDLL(CORPUSGEN_LIB)
+    f = L.bfc_gen_multi
+    f.restype = ctypes.c_int64
+    f.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                  ctypes.c_int, ctypes.c_uint64, ctypes.c_int64, ctypes.c_int64, ctypes.c_double, ctypes.c_double, ctypes.c_int, ctypes.c_int,
+                  ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+    blob, poff, boff, cdf, bucket_cdf, cm_blob, cm_off, ncm = _pieces(pieces)
+    off = np.zeros(ndocs + 1, dtype=np.int64)
+    args = [blob.ctypes.data, poff.ctypes.data, boff.ctypes.data, len(MULTI_BUCKETS), cdf.ctypes.data, bucket_cdf.ctypes.data, cm_blob.ctypes.data,
+            cm_off.ctypes.data, ncm, seed, first_doc, ndocs, float(mean), float(sd), minlen, maxlen]
+    total = f(*args, None, off.ctypes.data, 1)
+    text = np.empty(total, dtype=np.uint8)
+    f(*args, text.ctypes.data, off.ctypes.data, nthreads or min(host_threads(), 64))
+    return text, off
+
+
+def gen_workload(name, ndocs, first_doc=0):
+    """the corpus of a named workload (WORKLOADS below): documents [first_doc, first_doc + ndocs)"""
+    wl = WORKLOADS[name]
+    if wl.get("multi"):
+        return gen_corpus_multi(ndocs, first_doc=first_doc, **wl["multi"])
+    return gen_corpus(ndocs, first_doc=first_doc, **wl["gen"])
+
+
 WORKLOADS = {
     # name: generator kwargs + tokenizer call parameters (SURVEY.md §8d)
     "headline512": dict(model=None, gen=dict(seed=20240201, mean=512, sd=64, minlen=128, maxlen=1024), max_ids=512, unk=100),
     "config2": dict(model=None, gen=dict(seed=20240202, mean=128, sd=16, minlen=32, maxlen=256), max_ids=512, unk=100),
     "config3": dict(model="gpt2.bin", gen=dict(seed=3, minlen=32, maxlen=2048, loguniform=True, multibyte=True), max_ids=2048, unk=0),
-    # configs 4/5 use the same 512-byte generator with multibyte runs (the multilingual generator of SURVEY.md §8d needs the
-    # reference's pos.dict files, which do not travel; script coverage is a later round)
-    "config4": dict(model="xlm_roberta_base.bin", gen=dict(seed=4, mean=512, sd=64, minlen=128, maxlen=1024, multibyte=True), max_ids=1024, unk=3),
-    "config5": dict(model="laser500k.bin", gen=dict(seed=5, mean=512, sd=64, minlen=128, maxlen=1024, multibyte=True), max_ids=1024, unk=0),
+    # configs 4 / 5: the multilingual generator of SURVEY.md section 8d over per-script piece lists derived from the models' vocabularies
+    "config4": dict(model="xlm_roberta_base.bin", multi=dict(pieces="xlmr", seed=4, mean=512, sd=64, minlen=128, maxlen=1024), max_ids=1024, unk=3),
+    "config5": dict(model="laser500k.bin", multi=dict(pieces="laser500k", seed=5, mean=512, sd=64, minlen=128, maxlen=1024), max_ids=1024, unk=0),
 }
 
 

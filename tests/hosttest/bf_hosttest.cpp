@@ -24,6 +24,19 @@ using namespace bfa;
 
 struct Handle { Model m; std::string path; };
 
+static int g_uni_seq = 0;     // bft_set_uni_seq(1): Unigram through the plain sequential restatement (seg_unigram_doc) instead of UniLane
+static int g_no_ff = 0;       // bft_set_no_ff(1): run the lexer emulation without the loop-state fast-forward (A/B in tests)
+
+// class stream of the host emulation, seen through the same 8-element aligned windows as the device's ClsWin: run() never
+// looks past the window that holds position i (nor past the stream, which ends with one unflagged element of padding)
+struct HostCls {
+    const uint16_t *cp; int n;
+    uint32_t operator()(int i) const { return cp[i]; }
+    void prefetch(int) const {}
+    bool has(int) const { return true; }
+    int run(int i) const { int k = 0; while (i + k < n && ((i + k) >> 3) == (i >> 3) && (cp[i + k] & LX_C_LOOP)) ++k; return k; }
+};
+
 extern "C" {
 
 void *bft_load(const char *path)
@@ -37,6 +50,10 @@ void *bft_load(const char *path)
 }
 const char *bft_error(void *hv) { return ((Handle *)hv)->m.error.c_str(); }
 void bft_free(void *hv) { delete (Handle *)hv; }
+void bft_set_no_ff(int v) { g_no_ff = v; }
+void bft_set_uni_seq(int v) { g_uni_seq = v; }
+// loop state facts: out[0] = base (-1: none), [1] = number of flagged classes, [2] = final, [3] = info
+void bft_loop_state(void *hv, long *out) { Model &m = ((Handle *)hv)->m; out[0] = m.loop_base == 0xFFFFFFFFu ? -1 : (long)m.loop_base; long n = 0; for (uint8_t b : m.loop_cls) n += b; out[1] = n; out[2] = m.loop_final; out[3] = m.loop_info; }
 void bft_lookup_hist(unsigned long long *out, int n, int reset) { for (int i = 0; i < n && i < 4096; ++i) out[i] = g_lookup_hist[i]; if (reset) memset(g_lookup_hist, 0, sizeof(g_lookup_hist)); }
 long bft_table_len(void *hv) { return (long)((Handle *)hv)->m.wbd_t2.size(); }
 int bft_trie_depth(void *hv) { return ((Handle *)hv)->m.trie_max_depth; }
@@ -115,8 +132,14 @@ long bft_verify_tables(void *hv, int verbose)
             else if (c >= 1 && c <= 10) for (int k = 0; k < c; ++k) want.push_back(cls(norm[k]));
             uint32_t v = m.wbd_cpmap.get(cp);
             std::vector<uint32_t> got;
-            if (v & FUSED_MULTI) { size_t off = v & 0x7fffffffu; int n = m.wbd_multi_pool[off]; for (int k = 0; k < n; ++k) got.push_back(m.wbd_multi_pool[off + 1 + (size_t)k]); }
-            else got.push_back(v);
+            if (v & FUSED_MULTI) { size_t off = v & 0x7fffffffu; int n = m.wbd_multi_pool[off]; for (int k = 0; k < n; ++k) got.push_back(m.wbd_multi_pool[off + 1 + (size_t)k] & ~LX_C_LOOP); }
+            else got.push_back(v & ~LX_C_LOOP);
+            // the loop flag marks exactly the self-loop classes of the loop state
+            if (!(v & FUSED_MULTI)) {
+                const uint32_t k = v & T32_CLS_MASK;
+                const bool want_flag = k < m.loop_cls.size() && m.loop_cls[k];
+                if (want_flag != ((v & LX_C_LOOP) != 0) && ++bad <= 10 && verbose) fprintf(stderr, "  [cpmap] U+%04X loop flag differs\n", cp);
+            }
             if (got != want) { if (++bad <= 10 && verbose) fprintf(stderr, "  [cpmap] U+%04X differs\n", cp); }
         }
         // actions of every final state
@@ -187,10 +210,10 @@ static int emu_wp(const Model &m, const char *s, int n, int32_t *ids, int32_t *s
     L.T = m.wbd_t2.data(); L.acts = m.acts_pool.data();
     L.initial = m.wbd.initial_base; L.initial_l = m.initial_l; L.cls_any = m.cls_any; L.cls_l = m.cls_l; L.cls_r = m.cls_r;
     L.max_depth = m.max_depth; L.max_token_length = m.max_token_length; L.max_frames = m.lex_frames;
+    L.loop_state = g_no_ff ? LX_NO_STATE : m.loop_base; L.loop_info = m.loop_info; L.loop_final = m.loop_final ? 1 : 0;
     const int nch = (int)cls.size();
     cls.push_back((uint16_t)CLS_NONE);        // one element of padding: step() reads (and ignores) position InSize under the right anchor
-    struct HostCls { const uint16_t *cp; uint32_t operator()(int i) const { return cp[i]; } void prefetch(int) const {} };
-    HostCls cls_at{cls.data()};
+    HostCls cls_at{cls.data(), nch + 1};
     IdOutDirect out{ids, spans};
     FramesArray frames;
     return lex_doc(L, cls_at, nch, out, max_ids, unk, frames);
@@ -238,9 +261,35 @@ static int emu_sp(const Model &m, const char *s, int n, int32_t *ids, int32_t *s
     const uint16_t *cp = st.data();
     auto cls_at = [cp](int i) -> uint32_t { return cp[i]; };
     IdOutDirect out{ids, spans};
-    if (m.kind == KIND_UNIGRAM) {
+    if (m.kind == KIND_UNIGRAM && g_uni_seq) {
         std::vector<SegBest> best((size_t)L + 1);
         return seg_unigram_doc(S, cls_at, L, best.data(), out, max_ids, unk);
+    }
+    if (m.kind == KIND_UNIGRAM) {
+        // the default GPU form (bf_seg.h UniLane: score ring + deferred relaxation), driven sequentially
+        if (L <= 0) return 0;
+        struct HostRing {
+            std::vector<double> v; int mask;
+            double get(int pos) const { return v[(size_t)(pos & mask)]; }
+            void set(int pos, double x) { v[(size_t)(pos & mask)] = x; }
+            void fill(double x) { for (auto &e : v) e = x; }
+        };
+        struct HostSeek { const uint16_t *cp; uint32_t operator()(int i) const { return cp[i]; } void seek(int) const {} };
+        int ring_n = 1; while (ring_n < m.trie_max_depth) ring_n <<= 1;
+        HostRing ring{std::vector<double>((size_t)ring_n), ring_n - 1};
+        HostSeek hs{cp};
+        std::vector<SegBI> bi((size_t)L);
+        UniLane<HostSeek, HostRing> ul(S, hs, ring);
+        ul.init(L, m.trie_max_depth, bi.data());
+        while (ul.wstep()) {}
+        ul.begin_back();
+        std::vector<int32_t> rid, rfrom, rto;              // ids in backward order, like the device's right-aligned slot
+        auto put = [&](int, int id, int from, int to) { rid.push_back(id); rfrom.push_back(from); rto.push_back(to); };
+        for (;;) { const SegBI bb = bi[(size_t)ul.end]; if (!ul.bstep(bb, put, unk)) break; }
+        const int cnt = (int)rid.size(), nout = cnt < max_ids ? cnt : max_ids;
+        for (int k = 0; k < nout; ++k) { out.put(k, rid[(size_t)(cnt - 1 - k)]); out.span(k, rfrom[(size_t)(cnt - 1 - k)], rto[(size_t)(cnt - 1 - k)]); }
+        out.finish(nout);
+        return nout;
     }
     const int cap = 6 * L + 32;
     std::vector<SegArc> arcs((size_t)cap); std::vector<int32_t> tos((size_t)L + 1), idsv((size_t)L + 1); std::vector<uint8_t> inter((size_t)L + 1);
@@ -294,9 +343,9 @@ int bft_emu_text_to_words(void *hv, const char *s, int n, char *out, int32_t *st
     LexTables L;
     L.T = m.wbd_t2.data(); L.acts = m.acts_pool.data(); L.initial = m.wbd.initial_base; L.initial_l = m.initial_l; L.cls_any = m.cls_any; L.cls_l = m.cls_l; L.cls_r = m.cls_r;
     L.max_depth = m.max_depth; L.max_token_length = m.max_token_length; L.max_frames = m.lex_frames;
-    struct HostCls { const uint16_t *cp; uint32_t operator()(int i) const { return cp[i]; } void prefetch(int) const {} };
+    L.loop_state = g_no_ff ? LX_NO_STATE : m.loop_base; L.loop_info = m.loop_info; L.loop_final = m.loop_final ? 1 : 0;
     cls.push_back((uint16_t)CLS_NONE);        // padding (see emu_wp)
-    HostCls cls_at{cls.data()};
+    HostCls cls_at{cls.data(), len + 1};
     std::vector<int32_t> tags((size_t)len + 1), spans(2 * (size_t)len + 2);
     IdOutDirect o{tags.data(), spans.data()};
     FramesArray frames;

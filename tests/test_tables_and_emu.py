@@ -59,3 +59,27 @@ def test_lane_programs_on_host_match_oracle(ht, model):
         assert c == gc and list(arr)[:c] == gbuf[:gc], (model, b[:60], mx, unk)
     ora.free(ho)
     ht.bft_free(h)
+
+
+@pytest.mark.parametrize("model,workload", [("xlm_roberta_base.bin", "config4"), ("laser500k.bin", "config5")])
+def test_lane_programs_on_multilingual_corpus(ht, model, workload):
+    """the default Unigram lane program (bf_seg.h UniLane: score ring + deferred relaxation) on the multilingual corpus of
+    configs 4 / 5 -- all seven script buckets and the charmap keys -- against the oracle, without a GPU"""
+    if not bfutil.have_model(model):
+        pytest.skip("%s not present" % model)
+    wl = bfutil.WORKLOADS[workload]
+    text, off = bfutil.gen_workload(workload, 1500)
+    raw = text.tobytes()
+    ora = bfutil.oracle()
+    h = ht.bft_load(bfutil.model_path(model).encode())
+    assert ht.bft_error(h) == b""
+    ho = ora.load(bfutil.model_path(model))
+    mx, unk = wl["max_ids"], wl["unk"]
+    arr = (ctypes.c_int32 * mx)()
+    for d in range(len(off) - 1):
+        b = raw[off[d]:off[d + 1]]
+        c = ht.bft_emu_text_to_ids(h, b, len(b), arr, mx, unk)
+        gc, gbuf = ora.text_to_ids(ho, b, mx, unk)
+        assert c == gc and list(arr)[:c] == gbuf[:gc], (model, d, b[:80])
+    ora.free(ho)
+    ht.bft_free(h)

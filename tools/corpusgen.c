@@ -76,6 +76,20 @@ static const char *MB_RUNS[] = {"\xE5\xA5\xBD\xE5\xA5\xBD\xE5\xAD\xA6\xE4\xB9\xA
                                 "\xD0\xBC\xD0\xB8\xD1\x80", "\xC3\xA0 la", "\xE3\x81\x93\xE3\x82\x93\xE3\x81\xAB\xE3\x81\xA1\xE3\x81\xAF",
                                 "na\xC3\xAFve", "\xCE\xB1\xCE\xB2\xCE\xB3"};
 
+/* never end on a partial UTF-8 sequence: overwrite a dangling tail with ASCII */
+static void fix_tail(uint8_t *dst, int n)
+{
+    for (int k = n - 1, back = 0; k >= 0 && back < 4; --k, ++back) {
+        uint8_t b = dst[k];
+        if ((b & 0xC0) == 0x80) continue;
+        if (b >= 0xC0) {
+            int need = b >= 0xF0 ? 4 : b >= 0xE0 ? 3 : 2;
+            if (k + need > n) for (int q = k; q < n; ++q) dst[q] = 'x';
+        }
+        break;
+    }
+}
+
 static void fill_doc(const job_t *j, int64_t doc, uint8_t *dst, int n)
 {
     rng_t r = doc_rng(j->seed, doc);
@@ -117,16 +131,7 @@ static void fill_doc(const job_t *j, int64_t doc, uint8_t *dst, int n)
         memcpy(dst + pos, tmp, (size_t)len);
         pos += len;
     }
-    /* never end on a partial UTF-8 sequence: overwrite a dangling tail with ASCII */
-    for (int k = n - 1, back = 0; k >= 0 && back < 4; --k, ++back) {
-        uint8_t b = dst[k];
-        if ((b & 0xC0) == 0x80) continue;
-        if (b >= 0xC0) {
-            int need = b >= 0xF0 ? 4 : b >= 0xE0 ? 3 : 2;
-            if (k + need > n) for (int q = k; q < n; ++q) dst[q] = 'x';
-        }
-        break;
-    }
+    fix_tail(dst, n);
 }
 
 static void *worker(void *arg)
@@ -154,6 +159,84 @@ int64_t bfc_gen(const uint8_t *words, const int32_t *woff, int nwords, const dou
         if (nthreads > 64) nthreads = 64;
         pthread_t th[64]; job_t jobs[64];
         for (int t = 0; t < nthreads; ++t) { jobs[t] = base; jobs[t].tid = t; jobs[t].nthreads = nthreads; pthread_create(&th[t], NULL, worker, &jobs[t]); }
+        for (int t = 0; t < nthreads; ++t) pthread_join(th[t], NULL);
+    }
+    return doc_off[ndocs];
+}
+
+/*
+ * kind "multi" (configs 4 / 5): every document picks a script bucket (bucket_cdf has nb + 1 entries,
+ * the last one = "mixed": a new bucket for every piece) and is a concatenation of vocabulary pieces of that bucket drawn
+ * Zipf(s) over their rank (cdf[] holds one cumulative distribution per bucket, laid end to end like the pieces); a piece
+ * that starts with U+2581 starts a new word (the mark becomes a space), any other piece continues the current word; after
+ * a piece, with probability 1 % per character of it, one character that is a key of the model's charmap is appended
+ * (ncm == 0: none).  Lengths as in bfc_gen (normal, clipped); documents are cut at their target length on a character
+ * boundary.  Piece lists: tests/data/pieces_*.tsv.gz (tools/make_piece_lists.py).
+ */
+typedef struct {
+    const uint8_t *blob; const int32_t *poff; const int32_t *boff; int nb; const double *cdf; const double *bucket_cdf;
+    const uint8_t *cm_blob; const int32_t *cm_off; int ncm;
+    job_t base;
+} mjob_t;
+
+static void fill_doc_multi(const mjob_t *m, int64_t doc, uint8_t *dst, int n)
+{
+    rng_t r = doc_rng(m->base.seed, doc);
+    int pos = 0;
+    double ub = rng_unit(&r);
+    int b = 0;
+    while (b < m->nb && m->bucket_cdf[b] < ub) ++b;              /* b == nb: mixed */
+    while (pos < n) {
+        const int bb = b < m->nb ? b : (int)(splitmix64(&r) % (uint64_t)m->nb);
+        const int p0 = m->boff[bb], p1 = m->boff[bb + 1];
+        if (p1 <= p0) { dst[pos++] = ' '; continue; }
+        const double u = rng_unit(&r);
+        int lo = p0, hi = p1 - 1;
+        while (lo < hi) { int mid = (lo + hi) >> 1; if (m->cdf[mid] < u) lo = mid + 1; else hi = mid; }
+        const uint8_t *s = m->blob + m->poff[lo];
+        int len = m->poff[lo + 1] - m->poff[lo], nch = 0;
+        if (len >= 3 && s[0] == 0xE2 && s[1] == 0x96 && s[2] == 0x81) { dst[pos++] = ' '; s += 3; len -= 3; nch = 1; }
+        for (int k = 0; k < len; ++k) nch += (s[k] & 0xC0) != 0x80;
+        if (len > n - pos) len = n - pos;
+        memcpy(dst + pos, s, (size_t)len);
+        pos += len;
+        if (m->ncm > 0 && pos < n && rng_unit(&r) < 0.01 * nch) {
+            const int c = (int)(splitmix64(&r) % (uint64_t)m->ncm);
+            int cl = m->cm_off[c + 1] - m->cm_off[c];
+            if (cl > n - pos) cl = n - pos;
+            memcpy(dst + pos, m->cm_blob + m->cm_off[c], (size_t)cl);
+            pos += cl;
+        }
+    }
+    fix_tail(dst, n);
+}
+
+static void *worker_multi(void *arg)
+{
+    const mjob_t *m = (const mjob_t *)arg;
+    const job_t *j = &m->base;
+    for (int64_t d = j->tid; d < j->ndocs; d += j->nthreads)
+        fill_doc_multi(m, j->first_doc + d, j->out + j->doc_off[d], (int)(j->doc_off[d + 1] - j->doc_off[d]));
+    return NULL;
+}
+
+int64_t bfc_gen_multi(const uint8_t *blob, const int32_t *poff, const int32_t *boff, int nb, const double *cdf, const double *bucket_cdf,
+                      const uint8_t *cm_blob, const int32_t *cm_off, int ncm, uint64_t seed, int64_t first_doc, int64_t ndocs,
+                      double mean, double sd, int minlen, int maxlen, uint8_t *out, int64_t *doc_off, int nthreads)
+{
+    mjob_t base;
+    memset(&base, 0, sizeof(base));
+    base.blob = blob; base.poff = poff; base.boff = boff; base.nb = nb; base.cdf = cdf; base.bucket_cdf = bucket_cdf;
+    base.cm_blob = cm_blob; base.cm_off = cm_off; base.ncm = ncm;
+    base.base.seed = seed; base.base.first_doc = first_doc; base.base.ndocs = ndocs; base.base.len_mode = BFC_LEN_NORMAL;
+    base.base.p0 = mean; base.base.p1 = sd; base.base.minlen = minlen; base.base.maxlen = maxlen; base.base.out = out; base.base.doc_off = doc_off;
+    doc_off[0] = 0;
+    for (int64_t d = 0; d < ndocs; ++d) doc_off[d + 1] = doc_off[d] + doc_len(&base.base, first_doc + d);
+    if (out) {
+        if (nthreads < 1) nthreads = 1;
+        if (nthreads > 64) nthreads = 64;
+        pthread_t th[64]; static mjob_t jobs[64];
+        for (int t = 0; t < nthreads; ++t) { jobs[t] = base; jobs[t].base.tid = t; jobs[t].base.nthreads = nthreads; pthread_create(&th[t], NULL, worker_multi, &jobs[t]); }
         for (int t = 0; t < nthreads; ++t) pthread_join(th[t], NULL);
     }
     return doc_off[ndocs];
