@@ -95,6 +95,14 @@ def lib():
         L.BfModelKind.argtypes = [c_void_p]
         L.BfSetVariant.restype = c_int
         L.BfSetVariant.argtypes = [c_void_p, c_int]
+        L.BfReserve.restype = c_int
+        L.BfReserve.argtypes = [c_void_p, c_int64, c_int64, c_int]
+        L.NormalizeSpaces.restype = c_int
+        L.NormalizeSpaces.argtypes = [c_char_p, c_int, c_void_p, c_int, c_int]
+        L.TextToHashes.restype = c_int
+        L.TextToHashes.argtypes = [c_char_p, c_int, c_void_p, c_int, c_int, c_int]
+        L.WordHyphenationWithModel.restype = c_int
+        L.WordHyphenationWithModel.argtypes = [c_char_p, c_int, c_void_p, c_int, c_void_p, c_int]
         _lib = L
     return _lib
 
@@ -133,6 +141,34 @@ def utf8text_to_ids_with_offsets(h, s_bytes, max_len, unk=0, no_padding=False):
     n = min(max_len, t) if no_padding else max_len
     return (np.frombuffer(o, dtype=np.uint32, count=n), np.frombuffer(o_s, dtype=np.int32, count=n),
             np.frombuffer(o_e, dtype=np.int32, count=n))
+
+
+def normalize_spaces(s, uSpace=0x20):
+    """reference __init__.py:65-82: runs of white space -> one uSpace, leading / trailing dropped; '' on error."""
+    s_bytes = s.encode("utf-8")
+    o = ctypes.create_string_buffer(len(s_bytes) * 2 + 4)
+    n = lib().NormalizeSpaces(s_bytes, len(s_bytes), o, len(o), uSpace)
+    return "" if n == -1 or n > len(o) else o.value.decode("utf-8")
+
+
+def text_to_hashes(s, word_n_grams, bucketSize):
+    """reference __init__.py:151-167: int32 array of the token hashes followed by the word n-gram hashes; '' on error."""
+    s_bytes = s.encode("utf-8")
+    cap = max(word_n_grams * len(s_bytes), 1)
+    o = (c_int32 * cap)()
+    n = lib().TextToHashes(s_bytes, len(s_bytes), byref(o), cap, word_n_grams, bucketSize)
+    if n == -1 or n > cap:
+        return ""
+    return np.frombuffer(o, dtype=np.int32, count=n)
+
+
+def word_hyphenation_with_model(h, s, uHy=0x2D):
+    """reference __init__.py:125-142.  The hyphenation engine is not part of this library (not on the TextToIds path): the C entry
+    point exists and returns the reference's error value, so this returns '' for every non-empty word."""
+    s_bytes = s.encode("utf-8")
+    o = ctypes.create_string_buffer(len(s_bytes) * 4 + 1)
+    n = lib().WordHyphenationWithModel(s_bytes, len(s_bytes), o, len(o), c_void_p(h) if h else None, uHy)
+    return "" if n == -1 or n > len(o) else o.value.decode("utf-8")
 
 
 def text_to_words(s):
@@ -350,6 +386,13 @@ def ids_to_text_batch_device(h, d_ids, d_id_off, out_text=None, out_off=None, sk
     if r != 0:
         raise RuntimeError("IdsToTextBatchDevice failed (%d): %s" % (r, lib().BfLastError().decode("utf-8", "replace")))
     return out_text, out_off
+
+
+def reserve(h, max_docs, max_bytes, want_offsets=False):
+    """additive: size the handle's workspaces once (BfReserve) so that later device-resident batches of that size allocate nothing."""
+    r = lib().BfReserve(c_void_p(h), int(max_docs), int(max_bytes), int(bool(want_offsets)))
+    if r != 0:
+        raise RuntimeError("BfReserve failed (%d): %s" % (r, lib().BfLastError().decode("utf-8", "replace")))
 
 
 def last_kernel_ms(h):

@@ -40,13 +40,13 @@ def hipcc():
 def build_product(force=False):
     srcs = [os.path.join(CSRC, f) for f in ("bf_kernels.hip", "bf_capi.cpp", "bf_model.cpp")]
     deps = srcs + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + [
-        os.path.join(ROOT, "include", "blingfiretokdll_amd.h"), os.path.join(ROOT, "models", "wbd.bin"), os.path.join(ROOT, "models", "sbd.bin")]
+        os.path.join(ROOT, "include", "blingfiretokdll_amd.h"), os.path.join(CSRC, "exports.map"), os.path.join(ROOT, "models", "wbd.bin"), os.path.join(ROOT, "models", "sbd.bin")]
     if force or _newer(PRODUCT, deps):
         # the reference compiles its default word- and sentence-breaking models (wbd.bin, sbd.bin) into the library; same here (data, via .incbin)
         wbd = os.path.join(ROOT, "models", "wbd.bin")
         sbd = os.path.join(ROOT, "models", "sbd.bin")
         _run([hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
-              "-Wall", "-Wno-unused-result", '-DBF_DEFAULT_WBD_PATH="%s"' % wbd, '-DBF_DEFAULT_SBD_PATH="%s"' % sbd, "-x", "hip"] + srcs + ["-o", PRODUCT])
+              "-Wall", "-Wno-unused-result", "-fvisibility=hidden", "-Wl,--version-script=" + os.path.join(CSRC, "exports.map"), '-DBF_DEFAULT_WBD_PATH="%s"' % wbd, '-DBF_DEFAULT_SBD_PATH="%s"' % sbd, "-x", "hip"] + srcs + ["-o", PRODUCT])
     return PRODUCT
 
 
@@ -70,7 +70,8 @@ def build_test_infra(force=False):
         _run(["gcc", "-O2", "-std=c99", "-fPIC", "-c", os.path.join(odir, "bf_oracle.c"), "-o", obj])
         _run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-o", ht] + ht_src + [obj])
     ref = os.path.join(odir, "_ref", "libblingfiretokdll_ref.so")
-    if os.path.isdir(os.path.join(REF_DIR, "blingfireclient.library")) and (force or not os.path.exists(ref)):
+    wrapper = os.path.join(odir, "_ref", "blingfire", "__init__.py")
+    if os.path.isdir(os.path.join(REF_DIR, "blingfireclient.library")) and (force or not os.path.exists(ref) or not os.path.exists(wrapper)):
         _run(["make", "-C", odir, "ref", "REF=" + REF_DIR])
 
 

@@ -3,6 +3,7 @@
 // stream/event plumbing.  No CPU tokenisation path exists here: every entry point that
 // produces ids launches the HIP kernels, and fails loudly if there is no device.
 #include "../../include/blingfiretokdll_amd.h"
+#include "bf_internal.h"
 #include "bf_kernels.h"
 #include "bf_model.h"
 
@@ -31,14 +32,16 @@ bool hip_ok(hipError_t e, const char *what)
 
 struct DevBuf {
     void *p = nullptr; size_t cap = 0;
+    // Grow-only.  Growing is a hipMalloc + hipFree (both synchronise the device): callers that must not synchronise size the
+    // workspaces once with BfReserve.  The old buffer is released only after the new one exists.
     bool reserve(size_t bytes)
     {
         if (bytes <= cap) return true;
-        if (p) (void)hipFree(p);
-        p = nullptr; cap = 0;
         size_t want = bytes + bytes / 8 + 256;
-        if (!hip_ok(hipMalloc(&p, want), "hipMalloc(workspace)")) return false;
-        cap = want; return true;
+        void *q = nullptr;
+        if (!hip_ok(hipMalloc(&q, want), "hipMalloc(workspace)")) return false;
+        if (p) (void)hipFree(p);
+        p = q; cap = want; return true;
     }
     void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
     template <class T> T *as() const { return (T *)p; }
@@ -190,6 +193,33 @@ Handle *make_handle(const uint8_t *img, size_t size)
     return h;
 }
 
+// Workspaces of the TextToIds pipeline for a batch of ndocs documents / total_bytes bytes (grow-only; see DevBuf::reserve).
+bool reserve_ids_workspaces(Handle *h, int64_t ndocs, int64_t total_bytes, bool want_off)
+{
+    const Model &m = h->m;
+    const int nblocks = scan_nblocks(ndocs);
+    if (!h->w_nchars.reserve((size_t)(ndocs + 1) * 4) || !h->w_counts.reserve((size_t)(ndocs + 1) * 4) ||
+        !h->w_bsums.reserve((size_t)(nblocks + 1) * 8) || !h->w_tmp.reserve((size_t)(total_bytes + 8 * ndocs + 64) * 4)) return false;
+    if (m.kind == KIND_WP) {
+        if (!h->w_cls.reserve((size_t)(total_bytes + 64) * 2) || !h->w_flags.reserve((size_t)((total_bytes >> 10) + 2) * 8)) return false;
+        if (want_off && (!h->w_srcoff.reserve((size_t)(total_bytes + 64) * 4) || !h->w_span.reserve((size_t)(total_bytes + 8 * ndocs + 64) * 8))) return false;
+        return true;
+    }
+    const size_t cap = (size_t)(m.dict_has_charmap ? 2 : 1) * (size_t)(total_bytes + ndocs) + 64;      // stream elements over all documents
+    if (!h->w_cls.reserve(cap * 2) || !h->w_tmp.reserve(cap * 4)) return false;
+    if (want_off && (!h->w_srcoff.reserve(cap * 4) || !h->w_span.reserve(cap * 8))) return false;
+    if (m.kind == KIND_UNIGRAM) {
+        // {begin, id} per stream element (bf_seg.h SegBI); the sequential / flat variants (experiments) keep 16-byte records
+        const bool lane_form = (h->variant & 0xff) != 1 && (h->variant & 0xff) != 2 && (h->variant & 0xff) != 6 && m.trie_max_depth > 0 && m.trie_max_depth <= 32;
+        if (!h->w_s1.reserve(cap * (lane_form ? 8 : 16))) return false;
+    } else {
+        const size_t bm_words = (cap >> 5) + (size_t)ndocs + 4;
+        if (!h->w_s1.reserve((6 * cap + 32 * (size_t)ndocs + 64) * 16) || !h->w_s2.reserve(std::max(cap * 4, 2 * bm_words * 4) + ((size_t)ndocs + 16) * 4) ||
+            !h->w_s3.reserve(cap * 4) || !h->w_s4.reserve(cap)) return false;
+    }
+    return h->w_perm.reserve((size_t)(ndocs + 1) * 4) && h->w_hist.reserve(2048 * 4) && h->w_narcs.reserve((size_t)(ndocs + 1) * 4);
+}
+
 // Enqueue the whole pipeline for a batch resident on the device.
 int run_device(Handle *h, const char *d_text, const int64_t *d_doc_off, int64_t ndocs, int64_t total_bytes,
                int32_t *d_ids_out, int64_t ids_cap, int64_t *d_id_off, int max_ids, int unk, hipStream_t s,
@@ -202,21 +232,17 @@ int run_device(Handle *h, const char *d_text, const int64_t *d_doc_off, int64_t 
     if (max_ids < 0) max_ids = 0;
     Model &m = h->m;
     const int nblocks = scan_nblocks(ndocs);
-    if (!h->w_nchars.reserve((size_t)(ndocs + 1) * 4) || !h->w_counts.reserve((size_t)(ndocs + 1) * 4) ||
-        !h->w_bsums.reserve((size_t)(nblocks + 1) * 8) || !h->w_tmp.reserve((size_t)(total_bytes + 8 * ndocs + 64) * 4)) return BF_E_DEVICE;
-    Batch b{(const uint8_t *)d_text, d_doc_off, ndocs};
+    if (!reserve_ids_workspaces(h, ndocs, total_bytes, want_off)) return BF_E_DEVICE;
     int slot_mul = 0; const int32_t *first = nullptr;
     unsigned long long *next_doc = h->w_misc.as<unsigned long long>();
     int *status = (int *)(h->w_misc.as<char>() + 16);
+    Batch b{(const uint8_t *)d_text, d_doc_off, ndocs, total_bytes, status};
     if (!hip_ok(hipMemsetAsync(h->w_misc.p, 0, 64, s), "hipMemsetAsync")) return BF_E_DEVICE;
     (void)hipEventRecord(h->ev[EV_BEGIN], s);
     if (m.kind == KIND_WP) {
-        if (!h->w_cls.reserve((size_t)(total_bytes + 64) * 2)) return BF_E_DEVICE;
-        if (want_off && (!h->w_srcoff.reserve((size_t)(total_bytes + 64) * 4) || !h->w_span.reserve((size_t)(total_bytes + 8 * ndocs + 64) * 8))) return BF_E_DEVICE;
         WpPrepParams pp{b, DevCpMap{h->t_cp_l1.as<uint16_t>(), h->t_cp_pages.as<uint32_t>()}, h->t_multi.as<uint16_t>(),
                         m.wbd_charmap_multi ? 1 : 0, h->w_cls.as<uint16_t>(), want_off ? h->w_srcoff.as<int32_t>() : nullptr, h->w_nchars.as<int32_t>()};
         if (words) { pp.cpmap = DevCpMap{h->t_wcp_l1.as<uint16_t>(), h->t_wcp_pages.as<uint32_t>()}; pp.has_multi = 0; }   // no charmap (tokdll:476-499)
-        if (!h->w_flags.reserve((size_t)((total_bytes >> 10) + 2) * 8)) return BF_E_DEVICE;
         if (ndocs > 0) launch_prep_wp(pp, total_bytes, h->w_flags.as<unsigned long long>(), s);
         (void)hipEventRecord(h->ev[EV_PREP], s);
         WpLexParams lp;
@@ -236,8 +262,6 @@ int run_device(Handle *h, const char *d_text, const int64_t *d_doc_off, int64_t 
         const int mul = m.dict_has_charmap ? 2 : 1;
         slot_mul = mul;
         const size_t cap = (size_t)mul * (size_t)(total_bytes + ndocs) + 64;      // elements over all documents
-        if (!h->w_cls.reserve(cap * 2) || !h->w_tmp.reserve(cap * 4)) return BF_E_DEVICE;
-        if (want_off && (!h->w_srcoff.reserve(cap * 4) || !h->w_span.reserve(cap * 8))) return BF_E_DEVICE;
         SpPrepParams pp;
         pp.b = b; pp.cpmap = DevCpMap{h->t_cp_l1.as<uint16_t>(), h->t_cp_pages.as<uint32_t>()}; pp.multi_pool = h->t_multi.as<uint16_t>();
         pp.has_multi = m.sp_has_multi ? 1 : 0; pp.use_bytes = m.use_bytes ? 1 : 0; pp.has_charmap = m.dict_has_charmap ? 1 : 0;
@@ -253,17 +277,12 @@ int run_device(Handle *h, const char *d_text, const int64_t *d_doc_off, int64_t 
         sg.b = b; sg.stream = h->w_cls.as<uint16_t>(); sg.lens = h->w_nchars.as<int32_t>(); sg.slot_mul = mul;
         sg.ids_tmp = h->w_tmp.as<int32_t>(); sg.counts = h->w_counts.as<int32_t>(); sg.span_tmp = want_off ? h->w_span.as<int32_t>() : nullptr; sg.max_ids = max_ids; sg.unk = unk; sg.status = status;
         sg.best = nullptr; sg.arcs = nullptr; sg.tos = nullptr; sg.idsv = nullptr; sg.inter = nullptr; sg.bm_words = 0; sg.fb_list = nullptr; sg.fb_count = nullptr;
-        if (m.kind == KIND_UNIGRAM) {
-            if (!h->w_s1.reserve(cap * 16)) return BF_E_DEVICE;
-            sg.best = h->w_s1.as<SegBest>();
-        } else {
+        if (m.kind == KIND_UNIGRAM) sg.best = h->w_s1.as<SegBest>();
+        else {
             const size_t bm_words = (cap >> 5) + (size_t)ndocs + 4;         // per bitmap: capacity + 1 bits per document (k_bpe_apply_flat)
             sg.bm_words = (int64_t)bm_words;
-            if (!h->w_s1.reserve((6 * cap + 32 * (size_t)ndocs + 64) * 16) || !h->w_s2.reserve(std::max(cap * 4, 2 * bm_words * 4) + ((size_t)ndocs + 16) * 4) || !h->w_s3.reserve(cap * 4) ||
-                !h->w_s4.reserve(cap)) return BF_E_DEVICE;
             sg.arcs = h->w_s1.as<SegArc>(); sg.tos = h->w_s2.as<int32_t>(); sg.idsv = h->w_s3.as<int32_t>(); sg.inter = h->w_s4.as<uint8_t>();
         }
-        if (!h->w_perm.reserve((size_t)(ndocs + 1) * 4) || !h->w_hist.reserve(2048 * 4) || !h->w_narcs.reserve((size_t)(ndocs + 1) * 4)) return BF_E_DEVICE;
         sg.narcs = h->w_narcs.as<int32_t>(); sg.next_doc = next_doc; sg.trie_depth = m.trie_max_depth; sg.variant = h->variant & 0xff; sg.tune = (h->variant >> 8) & 0xff;
         if (m.kind == KIND_UNIGRAM && sg.variant != 1 && m.trie_max_depth > 0 && m.trie_max_depth <= 4096) first = h->w_narcs.as<int32_t>();
         sg.perm = h->w_perm.as<int32_t>(); sg.hist = h->w_hist.as<unsigned int>();
@@ -305,11 +324,11 @@ int64_t run_host(Handle *h, const char *text, const int64_t *doc_off, int64_t nd
     const int64_t *src_off = doc_off;
     if (base != 0) { rel.resize((size_t)ndocs + 1); for (int64_t i = 0; i <= ndocs; ++i) rel[(size_t)i] = doc_off[i] - base; src_off = rel.data(); }
     if (total > 0 && !hip_ok(hipMemcpyAsync(h->w_text.p, text + base, (size_t)total, hipMemcpyHostToDevice, s), "H2D text")) return BF_E_DEVICE;
-    if (!hip_ok(hipMemcpyAsync(h->w_docoff.p, src_off, (size_t)(ndocs + 1) * 8, hipMemcpyHostToDevice, s), "H2D offsets")) return BF_E_DEVICE;
+    if (!hip_ok(hipMemcpyAsync(h->w_docoff.p, src_off, (size_t)(ndocs + 1) * 8, hipMemcpyHostToDevice, s), "H2D offsets")) { (void)hipStreamSynchronize(s); return BF_E_DEVICE; }
     int rc = run_device(h, h->w_text.as<char>(), h->w_docoff.as<int64_t>(), ndocs, total, h->w_ids.as<int32_t>(), worst,
                         h->w_idoff.as<int64_t>(), max_ids, unk, s, want_off ? h->w_starts.as<int32_t>() : nullptr,
                         want_off ? h->w_ends.as<int32_t>() : nullptr, words);
-    if (rc != 0) return rc;
+    if (rc != 0) { (void)hipStreamSynchronize(s); return rc; }     // `rel` may still be the source of the pending offsets copy
     std::vector<int64_t> tmp_off;
     int64_t *dst_off = id_off_out;
     if (!dst_off) { tmp_off.resize((size_t)ndocs + 1); dst_off = tmp_off.data(); }
@@ -398,7 +417,7 @@ int64_t run_i2t_host(Handle *h, const int32_t *ids, const int64_t *id_off, int64
     if (total_ids > 0 && !hip_ok(hipMemcpyAsync(h->w_ids.p, ids + base, (size_t)total_ids * 4, hipMemcpyHostToDevice, s), "H2D ids")) return BF_E_DEVICE;
     if (!hip_ok(hipMemcpyAsync(h->w_docoff.p, rel.data(), (size_t)(nseq + 1) * 8, hipMemcpyHostToDevice, s), "H2D offsets")) return BF_E_DEVICE;
     int rc = run_i2t_device(h, h->w_ids.as<int32_t>(), h->w_docoff.as<int64_t>(), nseq, nullptr, 0, h->w_idoff.as<int64_t>(), skip_special, s);
-    if (rc != 0) return rc;
+    if (rc != 0) { (void)hipStreamSynchronize(s); return rc; }
     std::vector<int64_t> tmp_off;
     int64_t *dst_off = text_off_out;
     if (!dst_off) { tmp_off.resize((size_t)nseq + 1); dst_off = tmp_off.data(); }
@@ -497,8 +516,6 @@ int text_to_ids_one(void *hp, const char *s, int n, int32_t *ids, int max_ids, i
     return (int)r;
 }
 
-} // namespace
-
 int64_t text_batch_host(void *p, const char *text, const int64_t *doc_off, int64_t ndocs, char *text_out, int64_t text_cap, int64_t *text_off_out, int mode)
 {
     Handle *h = p ? as_handle(p) : (mode == 2 ? default_sbd() : default_wbd());
@@ -515,7 +532,7 @@ int64_t text_batch_host(void *p, const char *text, const int64_t *doc_off, int64
     if (total > 0 && !hip_ok(hipMemcpyAsync(h->w_text.p, text + base, (size_t)total, hipMemcpyHostToDevice, s), "H2D text")) return BF_E_DEVICE;
     if (!hip_ok(hipMemcpyAsync(h->w_docoff.p, rel.data(), (size_t)(ndocs + 1) * 8, hipMemcpyHostToDevice, s), "H2D offsets")) return BF_E_DEVICE;
     int rc = run_words_device(h, h->w_text.as<char>(), h->w_docoff.as<int64_t>(), ndocs, total, nullptr, 0, h->w_outoff.as<int64_t>(), s, true, mode);
-    if (rc != 0) return rc;
+    if (rc != 0) { (void)hipStreamSynchronize(s); return rc; }
     std::vector<int64_t> tmp_off;
     int64_t *dst_off = text_off_out;
     if (!dst_off) { tmp_off.resize((size_t)ndocs + 1); dst_off = tmp_off.data(); }
@@ -534,6 +551,7 @@ int64_t text_batch_host(void *p, const char *text, const int64_t *doc_off, int64
     return nout;
 }
 
+} // namespace
 
 extern "C" {
 
@@ -856,6 +874,26 @@ int IdsToTextBatchDevice(void *p, const int32_t *d_ids, const int64_t *d_id_offs
     int rc = run_i2t_device(h, d_ids, d_id_offsets, nseq, nullptr, 0, d_text_offsets_out, skip_special, s);
     if (rc != 0 || !d_text_out) return rc;
     return run_i2t_device(h, d_ids, d_id_offsets, nseq, d_text_out, text_cap, d_text_offsets_out, skip_special, s);
+}
+
+/* reference tokdll:818-915.  Not on the TextToIds path, no hyphenation engine here: resolves, fails loudly. */
+int WordHyphenationWithModel(const char *, int n, char *, const int, void *, const int)
+{
+    if (n == 0) return 0;                                                      // tokdll:832-834
+    static bool warned = false;
+    if (!warned) { warned = true; fprintf(stderr, "[blingfire_amd] WordHyphenationWithModel: the hyphenation engine is not part of this library (TextToIds path only); returning -1\n"); }
+    g_last_error = "WordHyphenationWithModel is not implemented by this library";
+    return -1;
+}
+
+int BfReserve(void *p, int64_t max_docs, int64_t max_bytes, int want_offsets)
+{
+    Handle *h = as_handle(p);
+    if (!h || max_docs < 0 || max_bytes < 0) return BF_E_ARG;
+    if (h->m.kind == KIND_I2W) return BF_E_UNSUPPORTED;
+    std::lock_guard<std::mutex> lock(h->mu);
+    DeviceGuard dg(h->device); if (!dg.ok) return BF_E_DEVICE;
+    return reserve_ids_workspaces(h, max_docs, max_bytes, want_offsets != 0) ? 0 : BF_E_DEVICE;
 }
 
 int SetNoDummyPrefix(void *p, int flag)

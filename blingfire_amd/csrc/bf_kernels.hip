@@ -43,6 +43,16 @@ __device__ __forceinline__ uint32_t cpmap_get(const DevCpMap &m, int cp)
     return m.pages[(uint32_t)m.l1[cp >> 8] * 256u + (uint32_t)(cp & 255)];
 }
 
+// Hand-off between the lanes of ONE wave through LDS (or global memory): the producer's stores are released and the consumer's
+// loads acquired at wavefront scope, and the compiler may not move either across this point.  (The lanes of a wave run in
+// lockstep and DS operations of a wave complete in order, so this costs nothing at run time; it pins what the code relies on.)
+__device__ __forceinline__ void wave_handoff()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // inclusive wave scan by shuffles (6 steps)
 __device__ __forceinline__ int wave_incl_scan(int v)
 {
@@ -75,6 +85,10 @@ __device__ __forceinline__ void prep_ascii_table(const WpPrepParams &p, uint16_t
 __device__ __forceinline__ void prep_wp_doc(const WpPrepParams &p, int64_t d, int64_t b, int64_t n64, int lane, const uint16_t *ascii_cls, uint16_t *stage /* 512 elements of LDS, this wave's */)
 {
     if (n64 <= 0 || n64 > 1000000000) { if (lane == 0) p.nchars[d] = 0; return; }   // tokdll:1121
+    if (b < 0 || b + n64 > p.b.total_bytes) {                                         // outside the caller's buffer: empty + status
+        if (lane == 0) { p.nchars[d] = 0; atomicOr(p.b.status, BF_STATUS_BAD_OFFSETS); }
+        return;
+    }
     const int n = (int)n64;
     const uint8_t *s = p.b.text + b;
     uint16_t *out = p.cls + b;
@@ -159,7 +173,9 @@ __device__ __forceinline__ void prep_wp_doc(const WpPrepParams &p, int64_t d, in
             int li = inc - cnt;
 #pragma unroll
             for (int k = 0; k < 8; ++k) { if (w[k] == 1) stage[li] = (uint16_t)v[k]; li += w[k]; }
+            wave_handoff();
             for (int t = lane; t < total; t += 64) if (outc + t < n) out[outc + t] = stage[t];
+            wave_handoff();                                               // the next window overwrites the stage
         } else {
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
@@ -247,6 +263,7 @@ __global__ __launch_bounds__(256) void k_prep_wp_docs(WpPrepParams p, const unsi
             b = p.b.doc_off[d];
             n64 = p.b.doc_off[d + 1] - b;
             if (n64 <= 0 || n64 > 1000000000) p.nchars[d] = 0;                                   // tokdll:1121
+            else if (b < 0 || b + n64 > p.b.total_bytes) { p.nchars[d] = 0; atomicOr(p.b.status, BF_STATUS_BAD_OFFSETS); }
             else {
                 const int64_t cf = b >> 4, cl = (b + n64 - 1) >> 4;
                 bool any = false;
@@ -573,6 +590,7 @@ __global__ __launch_bounds__(256) void k_prep_sp(SpPrepParams p)
         const int64_t b = p.b.doc_off[d];
         const int64_t n64 = p.b.doc_off[d + 1] - b;
         if (n64 <= 0 || n64 > 1000000000) { if (lane == 0) p.lens[d] = 0; continue; }     // tokdll:1361-1363
+        if (b < 0 || b + n64 > p.b.total_bytes) { if (lane == 0) { p.lens[d] = 0; atomicOr(p.b.status, BF_STATUS_BAD_OFFSETS); } continue; }
         const int n = (int)n64;
         const uint8_t *s = p.b.text + b;
         uint16_t *out = p.stream + sp_slot(b, d, p.slot_mul);
@@ -1747,12 +1765,14 @@ __global__ __launch_bounds__(256) void k_i2t_copy(I2tParams p)
             const int total = __shfl(inc, 63, 64);
             s_pre[wv][lane] = inc - t.len; s_src[wv][lane] = t.src;
             if (lane == 63) s_pre[wv][64] = total;
+            wave_handoff();
             for (int q = lane; q < total; q += 64) {
                 int lo = 0, hi = 63;                                   // last token whose prefix is <= q (empty tokens share a prefix: the last one wins)
                 while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (s_pre[wv][mid] <= q) lo = mid; else hi = mid - 1; }
                 if (out + q < p.text_cap) p.text[out + q] = p.tok_data[s_src[wv][lo] + (uint32_t)(q - s_pre[wv][lo])];
             }
             out += total;
+            wave_handoff();                                            // the next iteration overwrites s_pre / s_src
         }
     }
 }
@@ -1792,6 +1812,7 @@ __global__ __launch_bounds__(256) void k_w2t_copy(W2tParams p)
             const int total = __shfl(inc, 63, 64);
             s_pre[wv][lane] = inc - len; s_src[wv][lane] = st - ((i > b) ? 1 : 0);
             if (lane == 63) s_pre[wv][64] = total;
+            wave_handoff();
             for (int q = lane; q < total; q += 64) {
                 int lo = 0, hi = 63;
                 while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (s_pre[wv][mid] <= q) lo = mid; else hi = mid - 1; }
@@ -1802,6 +1823,7 @@ __global__ __launch_bounds__(256) void k_w2t_copy(W2tParams p)
                 if (out + q < p.out_cap) p.out[out + q] = c;
             }
             out += total;
+            wave_handoff();                                            // the next iteration overwrites s_pre / s_src
         }
     }
 }
@@ -1887,6 +1909,7 @@ __global__ __launch_bounds__(256) void k_s2t_copy(W2tParams p)
             const int total = __shfl(inc, 63, 64);
             s_pre[wv][lane] = inc - t.len; s_src[wv][lane] = t.src;
             if (lane == 63) s_pre[wv][64] = total;
+            wave_handoff();
             for (int q = lane; q < total; q += 64) {
                 int lo = 0, hi = 63;
                 while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (s_pre[wv][mid] <= q) lo = mid; else hi = mid - 1; }
@@ -1898,6 +1921,7 @@ __global__ __launch_bounds__(256) void k_s2t_copy(W2tParams p)
                 if (out + q < p.out_cap) p.out[out + q] = c;
             }
             out += total;
+            wave_handoff();                                            // the next iteration overwrites s_pre / s_src
         }
     }
 }
@@ -2078,6 +2102,7 @@ __global__ __launch_bounds__(256) void k_hash_fill(HashParams p)
             if (n == 0) break;
         }
         __threadfence_block();                                           // the unigrams are read by other lanes below
+        wave_handoff();
         for (int64_t i = lane; i < tc; i += 64) {                        // tokdll:699-714
             unsigned long long h = (unsigned long long)(long long)out[i];
             for (int j = 1; j < p.ngrams; ++j) {

@@ -19,6 +19,14 @@
 
 #include <stdint.h>
 
+/* The library is built with -fvisibility=hidden: only the entry points declared here (and the experiment knobs of
+ * blingfire_amd/csrc/bf_internal.h) are exported. */
+#if defined(__GNUC__)
+#define BF_API __attribute__((visibility("default")))
+#else
+#define BF_API
+#endif
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -26,28 +34,28 @@ extern "C" {
 /* ---- reference entry points (same names, argument meaning and error behaviour) ---- */
 
 /* reference tokdll:107-111: returns 18000 for v0.1.8-compatible behaviour */
-int GetBlingFireTokVersion(void);
+BF_API int GetBlingFireTokVersion(void);
 
 /* reference tokdll:1077-1094.  Returns an opaque handle or NULL.  (The reference throws a C++
  * exception through the C boundary for a nonexistent file; this returns NULL instead.) */
-void *LoadModel(const char *pszLdbFileName);
+BF_API void *LoadModel(const char *pszLdbFileName);
 
 /* reference tokdll:1056-1070.  The image is copied (the reference borrows it). */
-void *SetModel(const unsigned char *pImgBytes, int ModelByteCount);
+BF_API void *SetModel(const unsigned char *pImgBytes, int ModelByteCount);
 
 /* reference tokdll:1650-1662.  Returns 1, or 0 for a NULL handle. */
-int FreeModel(void *ModelPtr);
+BF_API int FreeModel(void *ModelPtr);
 
 /* reference tokdll:1619-1646.  Writes at most MaxIdsArrLength ids, leaves the rest of pIdsArr
  * untouched, returns the number written; 0 on any error (NULL model/text, n <= 0, n > 1e9,
  * invalid UTF-8 for non-byte models). */
-int TextToIds(void *ModelPtr, const char *pInUtf8Str, int InUtf8StrByteCount,
+BF_API int TextToIds(void *ModelPtr, const char *pInUtf8Str, int InUtf8StrByteCount,
               int32_t *pIdsArr, const int MaxIdsArrLength, const int UnkId);
 
 /* reference tokdll:1320-1331 and 1541-1552: the two algorithm-specific spellings */
-int TextToIds_wp(void *ModelPtr, const char *pInUtf8Str, int InUtf8StrByteCount,
+BF_API int TextToIds_wp(void *ModelPtr, const char *pInUtf8Str, int InUtf8StrByteCount,
                  int32_t *pIdsArr, const int MaxIdsArrLength, const int UnkId);
-int TextToIds_sp(void *ModelPtr, const char *pInUtf8Str, int InUtf8StrByteCount,
+BF_API int TextToIds_sp(void *ModelPtr, const char *pInUtf8Str, int InUtf8StrByteCount,
                  int32_t *pIdsArr, const int MaxIdsArrLength, const int UnkId);
 
 /* reference tokdll:1562-1609 (dispatch), 1108-1314 (_wp), 1349-1535 (_sp): ids plus, for every id, the byte offset of its first
@@ -55,11 +63,11 @@ int TextToIds_sp(void *ModelPtr, const char *pInUtf8Str, int InUtf8StrByteCount,
  * dummy prefix has offset -1).  NULL pStartOffsets / pEndOffsets = ids only, exactly like the reference.  One deviation: for a
  * token made of the dummy prefix alone the reference adds the UTF-8 size of the byte BEFORE the caller's buffer (undefined);
  * this library reports end = -1. */
-int TextToIdsWithOffsets(void *ModelPtr, const char *pInUtf8Str, int InUtf8StrByteCount, int32_t *pIdsArr,
+BF_API int TextToIdsWithOffsets(void *ModelPtr, const char *pInUtf8Str, int InUtf8StrByteCount, int32_t *pIdsArr,
                          int *pStartOffsets, int *pEndOffsets, const int MaxIdsArrLength, const int UnkId);
-int TextToIdsWithOffsets_wp(void *ModelPtr, const char *pInUtf8Str, int InUtf8StrByteCount, int32_t *pIdsArr,
+BF_API int TextToIdsWithOffsets_wp(void *ModelPtr, const char *pInUtf8Str, int InUtf8StrByteCount, int32_t *pIdsArr,
                             int *pStartOffsets, int *pEndOffsets, const int MaxIdsArrLength, const int UnkId);
-int TextToIdsWithOffsets_sp(void *ModelPtr, const char *pInUtf8Str, int InUtf8StrByteCount, int32_t *pIdsArr,
+BF_API int TextToIdsWithOffsets_sp(void *ModelPtr, const char *pInUtf8Str, int InUtf8StrByteCount, int32_t *pIdsArr,
                             int *pStartOffsets, int *pEndOffsets, const int MaxIdsArrLength, const int UnkId);
 
 /* reference tokdll:610-614, 585-591, 569-575, 415-566: splits text into words with a lexer model (hModel == NULL: the built-in
@@ -67,11 +75,11 @@ int TextToIdsWithOffsets_sp(void *ModelPtr, const char *pInUtf8Str, int InUtf8St
  * the byte count needed (terminator included; copied only if it fits), 0 for empty input, -1 on error (invalid UTF-8, ...).
  * pStartOffsets / pEndOffsets (MaxOutUtf8StrByteCount entries each, may be NULL) receive the byte span of every word.
  * The tokenisation runs on the GPU; only the output string is assembled on the host. */
-int TextToWords(const char *pInUtf8Str, int InUtf8StrByteCount, char *pOutUtf8Str, const int MaxOutUtf8StrByteCount);
-int TextToWordsWithModel(const char *pInUtf8Str, int InUtf8StrByteCount, char *pOutUtf8Str, const int MaxOutUtf8StrByteCount, void *hModel);
-int TextToWordsWithOffsets(const char *pInUtf8Str, int InUtf8StrByteCount, char *pOutUtf8Str, int *pStartOffsets, int *pEndOffsets,
+BF_API int TextToWords(const char *pInUtf8Str, int InUtf8StrByteCount, char *pOutUtf8Str, const int MaxOutUtf8StrByteCount);
+BF_API int TextToWordsWithModel(const char *pInUtf8Str, int InUtf8StrByteCount, char *pOutUtf8Str, const int MaxOutUtf8StrByteCount, void *hModel);
+BF_API int TextToWordsWithOffsets(const char *pInUtf8Str, int InUtf8StrByteCount, char *pOutUtf8Str, int *pStartOffsets, int *pEndOffsets,
                            const int MaxOutUtf8StrByteCount);
-int TextToWordsWithOffsetsWithModel(const char *pInUtf8Str, int InUtf8StrByteCount, char *pOutUtf8Str, int *pStartOffsets,
+BF_API int TextToWordsWithOffsetsWithModel(const char *pInUtf8Str, int InUtf8StrByteCount, char *pOutUtf8Str, int *pStartOffsets,
                                     int *pEndOffsets, const int MaxOutUtf8StrByteCount, void *hModel);
 
 /* additive: TextToWords for many documents at once.  The output string of document d -- exactly
@@ -80,14 +88,14 @@ int TextToWordsWithOffsetsWithModel(const char *pInUtf8Str, int InUtf8StrByteCou
  * or BF_E_* (BF_E_CAPACITY: the offsets are valid and tell the size).  The Device form takes device pointers and a hipStream_t
  * and never writes past text_cap; with d_text_out == NULL it only computes the offsets.  Tokenisation AND string assembly
  * (a variable-length byte gather) run on the GPU. */
-int64_t TextToWordsBatch(void *ModelPtr, const char *text, const int64_t *doc_offsets, int64_t ndocs, char *text_out, int64_t text_cap,
+BF_API int64_t TextToWordsBatch(void *ModelPtr, const char *text, const int64_t *doc_offsets, int64_t ndocs, char *text_out, int64_t text_cap,
                          int64_t *text_offsets_out);
-int TextToWordsBatchDevice(void *ModelPtr, const char *d_text, const int64_t *d_doc_offsets, int64_t ndocs, int64_t total_bytes,
+BF_API int TextToWordsBatchDevice(void *ModelPtr, const char *d_text, const int64_t *d_doc_offsets, int64_t ndocs, int64_t total_bytes,
                            char *d_text_out, int64_t text_cap, int64_t *d_text_offsets_out, void *stream);
 /* the same for TextToSentences (ModelPtr NULL = the built-in sbd.bin): per document the string TextToSentencesWithModel writes */
-int64_t TextToSentencesBatch(void *ModelPtr, const char *text, const int64_t *doc_offsets, int64_t ndocs, char *text_out, int64_t text_cap,
+BF_API int64_t TextToSentencesBatch(void *ModelPtr, const char *text, const int64_t *doc_offsets, int64_t ndocs, char *text_out, int64_t text_cap,
                              int64_t *text_offsets_out);
-int TextToSentencesBatchDevice(void *ModelPtr, const char *d_text, const int64_t *d_doc_offsets, int64_t ndocs, int64_t total_bytes,
+BF_API int TextToSentencesBatchDevice(void *ModelPtr, const char *d_text, const int64_t *d_doc_offsets, int64_t ndocs, int64_t total_bytes,
                                char *d_text_out, int64_t text_cap, int64_t *d_text_offsets_out, void *stream);
 
 /* reference tokdll:163-402 (blingfiretokdll.def: TextToSentences, TextToSentencesWithModel, TextToSentencesWithOffsets,
@@ -95,11 +103,11 @@ int TextToSentencesBatchDevice(void *ModelPtr, const char *d_text, const int64_t
  * model such as sbd.bin; NULL = the built-in sbd.bin, embedded like the reference embeds it).  Output = sentences joined by
  * '\n' (a '\n' inside a sentence -> ' ', leading white space dropped) + terminating 0; same return convention and offset
  * arrays as TextToWords.  The sentence boundaries come from the GPU lexer; only the output string is assembled on the host. */
-int TextToSentences(const char *pInUtf8Str, int InUtf8StrByteCount, char *pOutUtf8Str, const int MaxOutUtf8StrByteCount);
-int TextToSentencesWithModel(const char *pInUtf8Str, int InUtf8StrByteCount, char *pOutUtf8Str, const int MaxOutUtf8StrByteCount, void *hModel);
-int TextToSentencesWithOffsets(const char *pInUtf8Str, int InUtf8StrByteCount, char *pOutUtf8Str, int *pStartOffsets, int *pEndOffsets,
+BF_API int TextToSentences(const char *pInUtf8Str, int InUtf8StrByteCount, char *pOutUtf8Str, const int MaxOutUtf8StrByteCount);
+BF_API int TextToSentencesWithModel(const char *pInUtf8Str, int InUtf8StrByteCount, char *pOutUtf8Str, const int MaxOutUtf8StrByteCount, void *hModel);
+BF_API int TextToSentencesWithOffsets(const char *pInUtf8Str, int InUtf8StrByteCount, char *pOutUtf8Str, int *pStartOffsets, int *pEndOffsets,
                                const int MaxOutUtf8StrByteCount);
-int TextToSentencesWithOffsetsWithModel(const char *pInUtf8Str, int InUtf8StrByteCount, char *pOutUtf8Str, int *pStartOffsets,
+BF_API int TextToSentencesWithOffsetsWithModel(const char *pInUtf8Str, int InUtf8StrByteCount, char *pOutUtf8Str, int *pStartOffsets,
                                         int *pEndOffsets, const int MaxOutUtf8StrByteCount, void *hModel);
 
 /* reference tokdll:629-679 (blingfiretokdll.def: NormalizeSpaces; model-free): every run of white space -> one uSpace (default
@@ -107,8 +115,8 @@ int TextToSentencesWithOffsetsWithModel(const char *pInUtf8Str, int InUtf8StrByt
  * (0-terminated when there is room), -1 for empty / invalid UTF-8 input or when the output does not fit.  Runs as a batch of
  * one on the GPU; NormalizeSpacesBatch (additive) does many documents, output layout like TextToWordsBatch (a document the
  * single call rejects yields nothing). */
-int NormalizeSpaces(const char *pInUtf8Str, int InUtf8StrByteCount, char *pOutUtf8Str, const int MaxOutUtf8StrByteCount, const int uSpace);
-int64_t NormalizeSpacesBatch(const char *text, const int64_t *doc_offsets, int64_t ndocs, char *text_out, int64_t text_cap,
+BF_API int NormalizeSpaces(const char *pInUtf8Str, int InUtf8StrByteCount, char *pOutUtf8Str, const int MaxOutUtf8StrByteCount, const int uSpace);
+BF_API int64_t NormalizeSpacesBatch(const char *text, const int64_t *doc_offsets, int64_t ndocs, char *text_out, int64_t text_cap,
                              int64_t *text_offsets_out, int uSpace);
 
 /* reference tokdll:773-806 (blingfiretokdll.def: TextToHashes; model-free): fasttext-style hashes of the space-separated tokens
@@ -116,15 +124,15 @@ int64_t NormalizeSpacesBatch(const char *text, const int64_t *doc_offsets, int64
  * InUtf8StrByteCount * wordNgrams ("requested size") when MaxHashArrLength is too small, -1 on error.  Deviation: wordNgrams <= 0
  * is refused (-1); the reference would write past the array.  TextToHashesBatch (additive): document d's hashes =
  * hashes_out[hash_offsets_out[d] .. hash_offsets_out[d+1]), (spaces + 1) * wordNgrams of them. */
-int TextToHashes(const char *pInUtf8Str, int InUtf8StrByteCount, int32_t *pHashArr, const int MaxHashArrLength, int wordNgrams, int bucketSize);
-int64_t TextToHashesBatch(const char *text, const int64_t *doc_offsets, int64_t ndocs, int32_t *hashes_out, int64_t hashes_cap,
+BF_API int TextToHashes(const char *pInUtf8Str, int InUtf8StrByteCount, int32_t *pHashArr, const int MaxHashArrLength, int wordNgrams, int bucketSize);
+BF_API int64_t TextToHashesBatch(const char *text, const int64_t *doc_offsets, int64_t ndocs, int32_t *hashes_out, int64_t hashes_cap,
                           int64_t *hash_offsets_out, int wordNgrams, int bucketSize);
 
 /* reference tokdll:1689-1745 (blingfiretokdll.def: IdsToText): text of an id sequence.  ModelPtr = a LoadModel handle of a
  * model with an [i2w] section (a *.i2w file, or a .bin that carries one).  Ids outside the model's regular range are left
  * out when SkipSpecialTokens is set; a leading space is not written; returns the byte count needed including the
  * terminating 0 (written when it fits), 0 on error (no [i2w], unknown id, ...).  Runs as a batch of one on the GPU. */
-int IdsToText(void *ModelPtr, const int32_t *pIdsArr, const int IdsCount, char *pOutUtf8Str, const int MaxOutUtf8StrByteCount,
+BF_API int IdsToText(void *ModelPtr, const int32_t *pIdsArr, const int IdsCount, char *pOutUtf8Str, const int MaxOutUtf8StrByteCount,
               bool SkipSpecialTokens);
 
 /* additive: many sequences at once.  ids of sequence d = ids[id_offsets[d] .. id_offsets[d+1]); its text (no terminator) =
@@ -132,13 +140,20 @@ int IdsToText(void *ModelPtr, const int32_t *pIdsArr, const int IdsCount, char *
  * unknown id yields no text.  Returns the total byte count or BF_E_* (BF_E_CAPACITY if text_cap is too small: the offsets
  * are valid then and tell the size).  The Device form takes device pointers and a hipStream_t; with d_text_out == NULL it
  * only computes the offsets (size query). */
-int64_t IdsToTextBatch(void *ModelPtr, const int32_t *ids, const int64_t *id_offsets, int64_t nseq, char *text_out, int64_t text_cap,
+BF_API int64_t IdsToTextBatch(void *ModelPtr, const int32_t *ids, const int64_t *id_offsets, int64_t nseq, char *text_out, int64_t text_cap,
                        int64_t *text_offsets_out, int skip_special);
-int IdsToTextBatchDevice(void *ModelPtr, const int32_t *d_ids, const int64_t *d_id_offsets, int64_t nseq, char *d_text_out,
+BF_API int IdsToTextBatchDevice(void *ModelPtr, const int32_t *d_ids, const int64_t *d_id_offsets, int64_t nseq, char *d_text_out,
                          int64_t text_cap, int64_t *d_text_offsets_out, int skip_special, void *stream);
 
 /* reference tokdll:1669-1679 */
-int SetNoDummyPrefix(void *ModelPtr, int fNoDummyPrefix);
+BF_API int SetNoDummyPrefix(void *ModelPtr, int fNoDummyPrefix);
+
+/* reference tokdll:818-915 (blingfiretokdll.def: WordHyphenationWithModel).  The hyphenation engine is NOT on the TextToIds path
+ * and is not part of this library: the symbol exists so that consumers that bind every export by name
+ * resolve, and fails loudly -- 0 for an empty input like the reference, -1 (the reference's error value) otherwise, with one
+ * diagnostic on stderr. */
+BF_API int WordHyphenationWithModel(const char *pInUtf8Str, int InUtf8StrByteCount, char *pOutUtf8Str, const int MaxOutUtf8StrByteCount,
+                             void *hModel, const int uHy);
 
 /* ---- additive batch entry points (a GPU wants batches; semantics = "for every document,
  *      exactly what TextToIds(h, doc, len, buf, max_ids_per_doc, unk) would have written",
@@ -147,7 +162,7 @@ int SetNoDummyPrefix(void *ModelPtr, int fNoDummyPrefix);
 /* Host buffers.  text = concatenated documents; doc_offsets[ndocs+1] = byte offsets.
  * ids_out[ids_cap] receives the concatenated ids, id_offsets_out[ndocs+1] their boundaries.
  * Returns the total number of ids, or a negative error code (BF_E_*). */
-int64_t TextToIdsBatch(void *ModelPtr, const char *text, const int64_t *doc_offsets, int64_t ndocs,
+BF_API int64_t TextToIdsBatch(void *ModelPtr, const char *text, const int64_t *doc_offsets, int64_t ndocs,
                        int32_t *ids_out, int64_t ids_cap, int64_t *id_offsets_out,
                        int max_ids_per_doc, int unk);
 
@@ -157,18 +172,21 @@ int64_t TextToIdsBatch(void *ModelPtr, const char *text, const int64_t *doc_offs
  * >= min(2 * (total_bytes + ndocs), ndocs * max_ids_per_doc) to be safe for any input (WordPiece models never
  * need more than total_bytes); ids beyond ids_cap are dropped
  * and reported by BfLastStatus.  d_text needs no padding.
+ * PRECONDITION of every ...BatchDevice call: d_doc_offsets[0] == 0 and d_doc_offsets[ndocs] == total_bytes (offsets are relative to
+ * d_text; pass d_text + first_byte and rebased offsets for a sub-range).  The kernels index their workspaces by these offsets; a
+ * document whose range falls outside [0, total_bytes] is treated as empty and reported through BfLastStatus (bit 3).
  * A handle owns ONE set of device workspaces: the ...Device calls on one handle must be ordered on the device (the same
  * stream, or streams the caller synchronises); for concurrent batches use one handle per stream (LoadModel is cheap:
  * a few MB of tables).  The host-buffer calls serialise on the handle's mutex and synchronise before they return. */
-int TextToIdsBatchDevice(void *ModelPtr, const char *d_text, const int64_t *d_doc_offsets, int64_t ndocs,
+BF_API int TextToIdsBatchDevice(void *ModelPtr, const char *d_text, const int64_t *d_doc_offsets, int64_t ndocs,
                          int64_t total_bytes, int32_t *d_ids_out, int64_t ids_cap, int64_t *d_id_offsets_out,
                          int max_ids_per_doc, int unk, void *stream);
 
 /* Batch forms of TextToIdsWithOffsets: starts_out / ends_out are parallel to ids_out (same offsets array). */
-int64_t TextToIdsWithOffsetsBatch(void *ModelPtr, const char *text, const int64_t *doc_offsets, int64_t ndocs,
+BF_API int64_t TextToIdsWithOffsetsBatch(void *ModelPtr, const char *text, const int64_t *doc_offsets, int64_t ndocs,
                                   int32_t *ids_out, int32_t *starts_out, int32_t *ends_out, int64_t cap,
                                   int64_t *id_offsets_out, int max_ids_per_doc, int unk);
-int TextToIdsWithOffsetsBatchDevice(void *ModelPtr, const char *d_text, const int64_t *d_doc_offsets, int64_t ndocs,
+BF_API int TextToIdsWithOffsetsBatchDevice(void *ModelPtr, const char *d_text, const int64_t *d_doc_offsets, int64_t ndocs,
                                     int64_t total_bytes, int32_t *d_ids_out, int32_t *d_starts_out, int32_t *d_ends_out,
                                     int64_t cap, int64_t *d_id_offsets_out, int max_ids_per_doc, int unk, void *stream);
 
@@ -176,24 +194,25 @@ int TextToIdsWithOffsetsBatchDevice(void *ModelPtr, const char *d_text, const in
  * call's own stream.  Synchronises with those events.  Fills up to n floats (milliseconds):
  * [0] prep (decode+normalise+classify)  [1] tokenise (lexer / segmenter)  [2] scan  [3] compact  [4] total.
  * Returns the number of values written, or a negative error. */
-int BfLastKernelMs(void *ModelPtr, float *ms, int n);
+BF_API int BfLastKernelMs(void *ModelPtr, float *ms, int n);
 
 /* Status word of the last batch call (synchronises): 0 = ok; bit 0 = ids_cap overflow; bit 1 = an internal
- * per-document capacity was exceeded (results are not trustworthy; never expected for shipped models). */
-int BfLastStatus(void *ModelPtr);
+ * per-document capacity was exceeded (results are not trustworthy; never expected for shipped models); bit 3 = a document's
+ * byte range was outside [0, total_bytes] (Device calls: see the precondition above) and was treated as empty. */
+BF_API int BfLastStatus(void *ModelPtr);
 
 /* Last load error message of the calling thread ("" if none). */
-const char *BfLastError(void);
+BF_API const char *BfLastError(void);
 
 /* Model facts: 0 = WordPiece lexer, 1 = Unigram-LM, 2 = BPE, 3 = BPE-opt, 4 = BPE with merge ranks */
-long long BfBpeFallbackDocs(void *ModelPtr);   /* diagnostics: documents of the last BPE batch that took the full (sort + apply) path */
-int BfModelKind(void *ModelPtr);
+BF_API long long BfBpeFallbackDocs(void *ModelPtr);   /* diagnostics: documents of the last BPE batch that took the full (sort + apply) path */
+BF_API int BfModelKind(void *ModelPtr);
 
-/* experiments: instrumentation counters of the lexer kernel when BF_LEX_STATS=1 is set in the environment */
-int BfLexStats(void *ModelPtr, unsigned long long *out, int n);
-
-/* tuning knob for experiments: selects a kernel variant (0 = default). Returns the previous value. */
-int BfSetVariant(void *ModelPtr, int variant);
+/* Optional: size every workspace of the handle for batches of up to max_docs documents / max_bytes bytes of text now, so that
+ * later ...BatchDevice calls of that size allocate nothing (workspaces only ever grow; growing means hipMalloc, which
+ * synchronises the device and is not allowed inside a stream capture).  want_offsets != 0 also sizes the offsets API.
+ * Returns 0 or BF_E_*. */
+BF_API int BfReserve(void *ModelPtr, int64_t max_docs, int64_t max_bytes, int want_offsets);
 
 #define BF_E_ARG      (-1)   /* bad argument */
 #define BF_E_DEVICE   (-2)   /* HIP error */

@@ -103,3 +103,51 @@ def test_device_api_on_torch_tensors():
         assert len(ms) == 5 and ms[4] > 0
     finally:
         bf.free_model(h)
+
+
+@pytest.mark.parametrize("model,unk", [(None, 100), ("xlnet.bin", 0)])
+def test_device_api_rejects_ranges_outside_the_buffer(model, unk):
+    """...BatchDevice precondition (include/blingfiretokdll_amd.h): offsets are relative to d_text and end at total_bytes.  A
+    document whose byte range leaves [0, total_bytes] must not be read: it yields no ids and BfLastStatus reports bit 3; the
+    other documents are unaffected."""
+    import torch
+    name = model or bfutil.bert_model_name()
+    h = bf.load_model(bfutil.model_path(name))
+    try:
+        docs = [b"hello world", b"unaffable telescope", b"I saw a girl"]
+        text, off = bf.pack_docs(docs)
+        good_ids, good_off = bf.text_to_ids_batch(h, (text, off), 32, unk)
+        d_text = torch.from_numpy(text.copy()).cuda()
+        bad = off.copy()
+        bad[-1] += 1000                                    # the last document claims bytes past the end of the buffer
+        out_ids, out_off = bf.text_to_ids_batch_device(h, d_text, torch.from_numpy(bad).cuda(), 32, unk)
+        torch.cuda.synchronize()
+        assert bf.lib().BfLastStatus(ctypes.c_void_p(h)) & 8
+        o = out_off.cpu().numpy()
+        assert np.array_equal(o[:3], good_off[:3]) and o[3] == o[2]      # the first two documents as usual, the bad one empty
+        assert np.array_equal(out_ids[:int(o[2])].cpu().numpy(), good_ids[:int(good_off[2])])
+        neg = off.copy() - 5                               # offsets that do not start at 0: the first document begins before the buffer
+        out_ids, out_off = bf.text_to_ids_batch_device(h, d_text, torch.from_numpy(neg).cuda(), 32, unk)
+        torch.cuda.synchronize()
+        assert bf.lib().BfLastStatus(ctypes.c_void_p(h)) & 8
+        assert int(out_off[1].item()) == 0
+        out_ids, out_off = bf.text_to_ids_batch_device(h, d_text, torch.from_numpy(off).cuda(), 32, unk)     # and a clean call resets the status
+        torch.cuda.synchronize()
+        assert bf.lib().BfLastStatus(ctypes.c_void_p(h)) == 0
+        assert np.array_equal(out_off.cpu().numpy(), good_off)
+    finally:
+        bf.free_model(h)
+
+
+def test_reserve_then_no_growth():
+    """BfReserve sizes the workspaces once; a later batch within those bounds gives the same ids"""
+    h = bf.load_model(bfutil.model_path(bfutil.bert_model_name()))
+    try:
+        bf.reserve(h, 1000, 1 << 20)
+        docs = [b"hello world", b"unaffable telescope"] * 100
+        a = bf.text_to_ids_batch(h, docs, 32, 100)
+        bf.reserve(h, 10, 100)                             # never shrinks
+        b = bf.text_to_ids_batch(h, docs, 32, 100)
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    finally:
+        bf.free_model(h)
