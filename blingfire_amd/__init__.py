@@ -95,6 +95,10 @@ def lib():
         L.BfModelKind.argtypes = [c_void_p]
         L.BfSetVariant.restype = c_int
         L.BfSetVariant.argtypes = [c_void_p, c_int]
+        L.DictGetInfoBatch.restype = c_int64
+        L.DictGetInfoBatch.argtypes = [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]
+        L.DictGetInfoBatchDevice.restype = c_int
+        L.DictGetInfoBatchDevice.argtypes = [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p]
         L.BfReserve.restype = c_int
         L.BfReserve.argtypes = [c_void_p, c_int64, c_int64, c_int]
         L.NormalizeSpaces.restype = c_int
@@ -386,6 +390,35 @@ def ids_to_text_batch_device(h, d_ids, d_id_off, out_text=None, out_off=None, sk
     if r != 0:
         raise RuntimeError("IdsToTextBatchDevice failed (%d): %s" % (r, lib().BfLastError().decode("utf-8", "replace")))
     return out_text, out_off
+
+
+def dict_get_info_batch(h, keys):
+    """additive: the reference's FADictInterpreter_t<int>::GetInfo over the model's [pos-dict] for many keys at once (DictGetInfoBatch).
+    keys: list of str (code points) or of int sequences, or an (int32 array, int64 offsets) pair.
+    Returns (ret int32[nkeys] = value count or -1, info_ids int32[nkeys], values int32[total], value_offsets int64[nkeys+1])."""
+    if isinstance(keys, tuple):
+        flat, off = keys
+    else:
+        seqs = [[ord(c) for c in k] if isinstance(k, str) else list(k) for k in keys]
+        off = np.zeros(len(seqs) + 1, dtype=np.int64)
+        if seqs:
+            np.cumsum([len(q) for q in seqs], out=off[1:])
+        flat = np.array([c for q in seqs for c in q], dtype=np.int32)
+    flat = np.ascontiguousarray(flat, dtype=np.int32)
+    off = np.ascontiguousarray(off, dtype=np.int64)
+    nk = len(off) - 1
+    ret = np.zeros(nk, dtype=np.int32)
+    ids = np.zeros(nk, dtype=np.int32)
+    v_off = np.zeros(nk + 1, dtype=np.int64)
+    L = lib()
+    n = L.DictGetInfoBatch(c_void_p(h), flat.ctypes.data, off.ctypes.data, nk, ret.ctypes.data, ids.ctypes.data, None, 0, v_off.ctypes.data)
+    vals = np.empty(0, dtype=np.int32)
+    if n == -3:                                           # BF_E_CAPACITY: the offsets tell the size
+        vals = np.empty(int(v_off[-1]), dtype=np.int32)
+        n = L.DictGetInfoBatch(c_void_p(h), flat.ctypes.data, off.ctypes.data, nk, ret.ctypes.data, ids.ctypes.data, vals.ctypes.data, len(vals), v_off.ctypes.data)
+    if n < 0:
+        raise RuntimeError("DictGetInfoBatch failed: %d (%s)" % (n, L.BfLastError().decode("utf-8", "replace")))
+    return ret, ids, vals, v_off
 
 
 def reserve(h, max_docs, max_bytes, want_offsets=False):

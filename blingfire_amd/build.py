@@ -71,7 +71,9 @@ def build_test_infra(force=False):
         _run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-o", ht] + ht_src + [obj])
     ref = os.path.join(odir, "_ref", "libblingfiretokdll_ref.so")
     wrapper = os.path.join(odir, "_ref", "blingfire", "__init__.py")
-    if os.path.isdir(os.path.join(REF_DIR, "blingfireclient.library")) and (force or not os.path.exists(ref) or not os.path.exists(wrapper)):
+    dictref = os.path.join(odir, "_ref", "libdictref.so")
+    if os.path.isdir(os.path.join(REF_DIR, "blingfireclient.library")) and (
+            force or not os.path.exists(ref) or not os.path.exists(wrapper) or _newer(dictref, [os.path.join(odir, "ref_dict_glue.cpp")])):
         _run(["make", "-C", odir, "ref", "REF=" + REF_DIR])
 
 

@@ -80,6 +80,9 @@ struct Handle {
     DevBuf t_wbd, t_info, t_acts, t_cp_l1, t_cp_pages, t_multi, t_i2w_off, t_i2w_data;
     DevBuf t_wcp_l1, t_wcp_pages;                                // TextToWords: code point -> class without the charmap
     DevBuf t_dict, t_seginfo;                                    // _sp: Mealy table, I2Info rows (code-point maps reuse t_cp_*/t_multi)
+    DevBuf t_dk_l1, t_dk_pages, t_dn_l1, t_dn_pages, t_dn_pool, t_k2i, t_rows;   // key -> info lookup (uploaded on first use)
+    bool dict_ready = false;
+    DevBuf w_keys, w_keyoff, w_dids, w_dret, w_vals;              // DictGetInfoBatch staging
     DevBuf w_s1, w_s2, w_s3, w_s4, w_perm, w_hist, w_narcs;      // _sp scratch
     // workspaces
     DevBuf w_cls, w_nchars, w_tmp, w_counts, w_bsums, w_misc, w_flags, w_out, w_outoff;   // w_misc: [0] next_doc (u64), [2] status (int)
@@ -90,7 +93,7 @@ struct Handle {
     bool ev_valid = false;
     ~Handle()
     {
-        for (DevBuf *b : {&t_i2w_off, &t_i2w_data, &t_wbd, &t_info, &t_acts, &t_cp_l1, &t_cp_pages, &t_multi, &t_wcp_l1, &t_wcp_pages, &t_dict, &t_seginfo, &w_s1, &w_s2, &w_s3, &w_s4, &w_perm, &w_hist, &w_narcs, &w_cls, &w_nchars, &w_tmp, &w_counts, &w_flags, &w_out, &w_outoff,
+        for (DevBuf *b : {&t_dk_l1, &t_dk_pages, &t_dn_l1, &t_dn_pages, &t_dn_pool, &t_k2i, &t_rows, &w_keys, &w_keyoff, &w_dids, &w_dret, &w_vals, &t_i2w_off, &t_i2w_data, &t_wbd, &t_info, &t_acts, &t_cp_l1, &t_cp_pages, &t_multi, &t_wcp_l1, &t_wcp_pages, &t_dict, &t_seginfo, &w_s1, &w_s2, &w_s3, &w_s4, &w_perm, &w_hist, &w_narcs, &w_cls, &w_nchars, &w_tmp, &w_counts, &w_flags, &w_out, &w_outoff,
                           &w_bsums, &w_misc, &w_text, &w_docoff, &w_ids, &w_idoff, &w_starts, &w_ends, &w_srcoff, &w_span}) b->release();
         for (auto &e : ev) if (e) (void)hipEventDestroy(e);
         if (stream) (void)hipStreamDestroy(stream);
@@ -501,6 +504,46 @@ int run_hashes_device(Handle *h, const char *d_text, const int64_t *d_doc_off, i
     return hip_ok(hipGetLastError(), "TextToHashes kernels") ? 0 : BF_E_DEVICE;
 }
 
+// key -> info lookup: tables of the [pos-dict] in their lookup form, uploaded when the first call arrives
+bool ensure_dict_tables(Handle *h)
+{
+    if (h->dict_ready) return true;
+    const Model &m = h->m;
+    bool ok = upload(h->t_dk_l1, m.dict_clsmap.l1) && upload(h->t_dk_pages, m.dict_clsmap.pages) && upload(h->t_k2i, m.k2i, 4) && upload(h->t_rows, m.info_rows, 4);
+    if (m.dict_direction != 0 && m.dict_has_charmap)
+        ok = ok && upload(h->t_dn_l1, m.dict_charmap.l1) && upload(h->t_dn_pages, m.dict_charmap.pages) && upload(h->t_dn_pool, m.dict_norm_pool, 4);
+    h->dict_ready = ok;
+    return ok;
+}
+
+int run_dict_device(Handle *h, const int32_t *d_keys, const int64_t *d_key_off, int64_t nkeys, int32_t *d_ret, int32_t *d_info_ids,
+                    int32_t *d_vals, int64_t vals_cap, int64_t *d_val_off, hipStream_t s, bool size)
+{
+    const Model &m = h->m;
+    if (!m.has_seg || m.k2i.empty()) return BF_E_UNSUPPORTED;
+    if (nkeys < 0 || !d_key_off || !d_val_off) return BF_E_ARG;
+    const int nblocks = scan_nblocks(nkeys);
+    if (!ensure_dict_tables(h) || !h->w_counts.reserve((size_t)(nkeys + 1) * 4) || !h->w_bsums.reserve((size_t)(nblocks + 1) * 8) ||
+        !h->w_dids.reserve((size_t)(nkeys + 1) * 4) || !h->w_dret.reserve((size_t)(nkeys + 1) * 4)) return BF_E_DEVICE;
+    DictParams p;
+    p.D.T = h->t_dict.as<uint64_t>(); p.D.initial = m.dict.initial_base; p.D.initial_final = m.dict_raw.is_final[(size_t)m.dict_raw.initial] ? 1 : 0;
+    p.D.cls_l1 = h->t_dk_l1.as<uint16_t>(); p.D.cls_pages = h->t_dk_pages.as<uint32_t>();
+    const bool nrm = m.dict_direction != 0 && m.dict_has_charmap;
+    p.D.nrm_l1 = nrm ? h->t_dn_l1.as<uint16_t>() : nullptr; p.D.nrm_pages = nrm ? h->t_dn_pages.as<uint32_t>() : nullptr; p.D.nrm_pool = nrm ? h->t_dn_pool.as<int32_t>() : nullptr;
+    p.D.k2i = h->t_k2i.as<int32_t>(); p.D.k2i_n = (int)m.k2i.size(); p.D.r2l = m.dict_direction != 0 ? 1 : 0;
+    p.rows = h->t_rows.as<int32_t>(); p.stride = m.info_stride; p.min_key = m.info_min_key; p.nrows = m.info_stride > 0 ? (int)(m.info_rows.size() / (size_t)m.info_stride) : 0;
+    p.keys = d_keys; p.key_off = d_key_off; p.nkeys = nkeys;
+    p.info_ids = d_info_ids ? d_info_ids : h->w_dids.as<int32_t>(); p.ret = d_ret ? d_ret : h->w_dret.as<int32_t>(); p.counts = h->w_counts.as<int32_t>();
+    p.val_off = d_val_off; p.vals = d_vals; p.vals_cap = vals_cap;
+    if (size) {
+        if (nkeys > 0) launch_dict_ids(p, s);
+        ScanParams sp{h->w_counts.as<int32_t>(), nkeys, d_val_off, h->w_bsums.as<int64_t>(), nblocks};
+        launch_scan(sp, s);
+    }
+    if (d_vals && nkeys > 0) launch_dict_fill(p, s);
+    return hip_ok(hipGetLastError(), "dictionary lookup kernels") ? 0 : BF_E_DEVICE;
+}
+
 int text_to_ids_one(void *hp, const char *s, int n, int32_t *ids, int max_ids, int unk, int want_kind /* -1 any, 0 wp, 1 sp */,
                     int32_t *starts = nullptr, int32_t *ends = nullptr)
 {
@@ -874,6 +917,52 @@ int IdsToTextBatchDevice(void *p, const int32_t *d_ids, const int64_t *d_id_offs
     int rc = run_i2t_device(h, d_ids, d_id_offsets, nseq, nullptr, 0, d_text_offsets_out, skip_special, s);
     if (rc != 0 || !d_text_out) return rc;
     return run_i2t_device(h, d_ids, d_id_offsets, nseq, d_text_out, text_cap, d_text_offsets_out, skip_special, s);
+}
+
+/* ---- additive: FADictInterpreter_t<int>::GetInfo for many keys at once over the model's [pos-dict] */
+int DictGetInfoBatchDevice(void *p, const int32_t *d_keys, const int64_t *d_key_offsets, int64_t nkeys, int32_t *d_ret_out, int32_t *d_info_ids_out,
+                           int32_t *d_values_out, int64_t values_cap, int64_t *d_value_offsets_out, void *stream)
+{
+    Handle *h = as_handle(p);
+    if (!h) return BF_E_ARG;
+    std::lock_guard<std::mutex> lock(h->mu);
+    DeviceGuard dg(h->device); if (!dg.ok) return BF_E_DEVICE;
+    return run_dict_device(h, d_keys, d_key_offsets, nkeys, d_ret_out, d_info_ids_out, d_values_out, values_cap, d_value_offsets_out, (hipStream_t)stream, true);
+}
+
+int64_t DictGetInfoBatch(void *p, const int32_t *keys, const int64_t *key_offsets, int64_t nkeys, int32_t *ret_out, int32_t *info_ids_out,
+                         int32_t *values_out, int64_t values_cap, int64_t *value_offsets_out)
+{
+    Handle *h = as_handle(p);
+    if (!h) return BF_E_ARG;
+    if (nkeys < 0 || !key_offsets || (nkeys > 0 && key_offsets[nkeys] > key_offsets[0] && !keys)) return BF_E_ARG;
+    const int64_t base = key_offsets[0], total = nkeys > 0 ? key_offsets[nkeys] - base : 0;
+    if (total < 0) return BF_E_ARG;
+    std::lock_guard<std::mutex> lock(h->mu);
+    DeviceGuard dg(h->device); if (!dg.ok) return BF_E_DEVICE;
+    hipStream_t s = h->stream;
+    if (!h->w_keys.reserve((size_t)(total + 1) * 4) || !h->w_keyoff.reserve((size_t)(nkeys + 1) * 8) || !h->w_outoff.reserve((size_t)(nkeys + 1) * 8)) return BF_E_DEVICE;
+    std::vector<int64_t> rel((size_t)nkeys + 1);
+    for (int64_t i = 0; i <= nkeys; ++i) rel[(size_t)i] = key_offsets[i] - base;
+    if (total > 0 && !hip_ok(hipMemcpyAsync(h->w_keys.p, keys + base, (size_t)total * 4, hipMemcpyHostToDevice, s), "H2D keys")) { (void)hipStreamSynchronize(s); return BF_E_DEVICE; }
+    if (!hip_ok(hipMemcpyAsync(h->w_keyoff.p, rel.data(), (size_t)(nkeys + 1) * 8, hipMemcpyHostToDevice, s), "H2D offsets")) { (void)hipStreamSynchronize(s); return BF_E_DEVICE; }
+    int rc = run_dict_device(h, h->w_keys.as<int32_t>(), h->w_keyoff.as<int64_t>(), nkeys, nullptr, nullptr, nullptr, 0, h->w_outoff.as<int64_t>(), s, true);
+    if (rc != 0) { (void)hipStreamSynchronize(s); return rc; }
+    std::vector<int64_t> tmp_off; int64_t *dst_off = value_offsets_out;
+    if (!dst_off) { tmp_off.resize((size_t)nkeys + 1); dst_off = tmp_off.data(); }
+    if (!hip_ok(hipMemcpyAsync(dst_off, h->w_outoff.p, (size_t)(nkeys + 1) * 8, hipMemcpyDeviceToHost, s), "D2H offsets") ||
+        (ret_out && nkeys > 0 && !hip_ok(hipMemcpyAsync(ret_out, h->w_dret.p, (size_t)nkeys * 4, hipMemcpyDeviceToHost, s), "D2H ret")) ||
+        (info_ids_out && nkeys > 0 && !hip_ok(hipMemcpyAsync(info_ids_out, h->w_dids.p, (size_t)nkeys * 4, hipMemcpyDeviceToHost, s), "D2H ids")) ||
+        !hip_ok(hipStreamSynchronize(s), "hipStreamSynchronize")) return BF_E_DEVICE;
+    const int64_t nvals = dst_off[nkeys];
+    if (nvals > values_cap) return BF_E_CAPACITY;
+    if (nvals > 0) {
+        if (!values_out || !h->w_vals.reserve((size_t)nvals * 4 + 16)) return values_out ? BF_E_DEVICE : BF_E_ARG;
+        rc = run_dict_device(h, h->w_keys.as<int32_t>(), h->w_keyoff.as<int64_t>(), nkeys, nullptr, nullptr, h->w_vals.as<int32_t>(), nvals, h->w_outoff.as<int64_t>(), s, false);
+        if (rc != 0) return rc;
+        if (!hip_ok(hipMemcpyAsync(values_out, h->w_vals.p, (size_t)nvals * 4, hipMemcpyDeviceToHost, s), "D2H values") || !hip_ok(hipStreamSynchronize(s), "hipStreamSynchronize")) return BF_E_DEVICE;
+    }
+    return nvals;
 }
 
 /* reference tokdll:818-915.  Not on the TextToIds path, no hyphenation engine here: resolves, fails loudly. */

@@ -88,6 +88,19 @@ struct SpSegParams {
     unsigned long long *next_doc;
 };
 
+// key -> info lookup (reference FADictInterpreter_t<int>::GetInfo) for a batch of keys: key k = keys[key_off[k] .. key_off[k+1])
+struct DictParams {
+    DictTables D;
+    const int32_t *rows; int stride, min_key, nrows;          // I2Info rows: [count or -1, values...]
+    const int32_t *keys; const int64_t *key_off; int64_t nkeys;
+    int32_t *info_ids;            // [nkeys] GetInfoId
+    int32_t *ret;                 // [nkeys] GetInfo return value: value count, -1 = no such key / row
+    int32_t *counts;              // [nkeys] values written for the key (max(ret, 0)) -> scanned into val_off
+    const int64_t *val_off; int32_t *vals; int64_t vals_cap;
+};
+void launch_dict_ids(const DictParams &p, hipStream_t s);
+void launch_dict_fill(const DictParams &p, hipStream_t s);
+
 struct ScanParams { const int32_t *counts; int64_t ndocs; int64_t *id_off; int64_t *block_sums; int nblocks; };
 
 struct CompactParams {

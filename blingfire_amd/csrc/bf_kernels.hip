@@ -2137,6 +2137,46 @@ void launch_i2t_copy(const I2tParams &p, hipStream_t s)
 }
 
 // ------------------------------------------------------------------------------------------
+// Dictionary key -> info (reference FADictInterpreter_t<int>::GetInfo, cl/inc/FADictInterpreter_t.h:369-390): one key per lane
+// (bf_seg.h dict_info_id), then the I2Info row of the id (FAMultiMap_pack_fixed::Get); values are gathered after a scan.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_dict_ids(DictParams p)
+{
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < p.nkeys; k += stride) {
+        const int64_t b = p.key_off[k], n64 = p.key_off[k + 1] - b;
+        int id = -1;
+        if (n64 > 0 && n64 <= DICT_MAX_WORD && b >= 0) id = dict_info_id(p.D, p.keys + b, (int)n64);
+        int r = -1;
+        if (id != -1 && id >= p.min_key && id - p.min_key < p.nrows) r = p.rows[(int64_t)(id - p.min_key) * p.stride];
+        p.info_ids[k] = id; p.ret[k] = r; p.counts[k] = r > 0 ? r : 0;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_dict_fill(DictParams p)
+{
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < p.nkeys; k += stride) {
+        const int c = p.counts[k];
+        if (c <= 0) continue;
+        const int32_t *row = p.rows + (int64_t)(p.info_ids[k] - p.min_key) * p.stride + 1;
+        const int64_t o = p.val_off[k];
+        for (int q = 0; q < c; ++q) if (o + q < p.vals_cap) p.vals[o + q] = row[q];
+    }
+}
+
+void launch_dict_ids(const DictParams &p, hipStream_t s)
+{
+    int64_t blocks = (p.nkeys + 255) / 256; if (blocks > device_cus() * 16) blocks = device_cus() * 16; if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(k_dict_ids, dim3((unsigned)blocks), dim3(256), 0, s, p);
+}
+void launch_dict_fill(const DictParams &p, hipStream_t s)
+{
+    int64_t blocks = (p.nkeys + 255) / 256; if (blocks > device_cus() * 16) blocks = device_cus() * 16; if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(k_dict_fill, dim3((unsigned)blocks), dim3(256), 0, s, p);
+}
+
+// ------------------------------------------------------------------------------------------
 // scan: counts[ndocs] (int32) -> id_off[ndocs+1] (int64), three small kernels
 // ------------------------------------------------------------------------------------------
 constexpr int SCAN_ITEMS = 4, SCAN_THREADS = 256, SCAN_TILE = SCAN_ITEMS * SCAN_THREADS;

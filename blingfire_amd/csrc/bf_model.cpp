@@ -703,7 +703,7 @@ bool build_model(Model &m, const uint8_t *img, size_t size)
             if (i + 1 >= vals.size()) return fail(m, "truncated [pos-dict] parameters");
             const int v = vals[++i];
             switch (p) {
-            case PARAM_DIRECTION: break;
+            case PARAM_DIRECTION: m.dict_direction = v; break;
             case PARAM_TOKENIZATION_TYPE: m.tok_algo = v; break;
             case PARAM_ID_OFFSET: m.id_offset = v; break;
             case PARAM_FSM_TYPE: fsm_type = v; break;
@@ -734,6 +734,36 @@ bool build_model(Model &m, const uint8_t *img, size_t size)
             int v[2] = {0, 0}; int c = info.get(info.min_key + (int)k, v, 2);
             if (c < 1 || c > 2) continue;
             m.i2info_id[k] = v[0]; m.i2info_score[k] = (uint32_t)v[1]; m.i2info_valid[k] = (uint8_t)c;
+        }
+        // general form of the same rows + the K2I array, for the key -> info lookup (FADictInterpreter_t::GetInfo)
+        m.info_stride = info.max_count + 1; m.info_min_key = info.min_key;
+        if ((double)rows * (double)m.info_stride > 2.0e8) return fail(m, "I2Info too large");
+        m.info_rows.assign(rows * (size_t)m.info_stride, 0);
+        {
+            std::vector<int> tmp((size_t)info.max_count + 1);
+            for (size_t k = 0; k < rows; ++k) {
+                const int c = info.get(info.min_key + (int)k, tmp.data(), info.max_count);
+                int32_t *row = m.info_rows.data() + k * (size_t)m.info_stride;
+                row[0] = c < 0 ? -1 : c;
+                for (int q = 0; q < c && q < info.max_count; ++q) row[1 + q] = tmp[(size_t)q];
+            }
+        }
+        {   // K2I (format: reference FAArray_pack.cpp:27-65; GetAt :68-95)
+            const Reader kr = dump(k2i_dump);
+            const int M = kr.i32(0), soi = kr.i32(4), sov = kr.i32(8), count = kr.i32(12);
+            if (M < 1 || M > 8 || soi < 0 || soi > 4 || sov < 1 || sov > 4 || count <= 0 || count > 100000000 || (M == 1) != (soi == 0)) return fail(m, "bad K2I array");
+            const size_t index_bytes = M == 1 ? 0 : (size_t)((count + M - 1) / M) * (size_t)soi;
+            auto dec = [&](size_t base, size_t idx, int size) -> uint32_t { return kr.be(base + idx * (size_t)size, size); };   // FADecode_1_2_3_4_idx: big-endian (FAEncodeUtils.h:418-450)
+            m.k2i.resize((size_t)count);
+            for (int i = 0; i < count; ++i) {
+                if (M == 1) { if (!kr.ok(16 + (size_t)i * (size_t)sov, (size_t)sov)) return fail(m, "truncated K2I array"); m.k2i[(size_t)i] = (int32_t)dec(16, (size_t)i, sov); }
+                else {
+                    const uint32_t chain = dec(16, (size_t)(i / M), soi);
+                    const size_t base = 16 + index_bytes + (size_t)chain * (size_t)(M * sov);
+                    if (!kr.ok(base, (size_t)(M * sov))) return fail(m, "truncated K2I array");
+                    m.k2i[(size_t)i] = (int32_t)dec(base, (size_t)(i % M), sov);
+                }
+            }
         }
         // every reachable final state's MPH index must have a usable row (else the reference LogAsserts at run time)
         {

@@ -135,6 +135,11 @@ struct Model {
     TwoLevelMap dict_charmap; std::vector<int32_t> dict_norm_pool; bool dict_has_charmap = false;
     TwoLevelMap dict_clsmap;           // code point (or byte) -> class of the dictionary alphabet, CLS_NONE_W if absent
     int trie_max_depth = 0;            // longest path from the initial state (bounds every arc length)
+    // ---- key -> info lookup over the same [pos-dict] (reference FADictInterpreter_t.h:334-390; additive DictGetInfoBatch)
+    int dict_direction = 0;            // PARAM_DIRECTION: 0 = l2r (FAFsmConst.h DIR_L2R); else keys are normalised and reversed
+    std::vector<int32_t> k2i;          // K2I array, decoded (reference FAArray_pack.cpp:27-95): MPH index -> info id
+    std::vector<int32_t> info_rows;    // I2Info rows, decoded: row r = [count or -1, values ...], info_stride ints each
+    int info_stride = 0, info_min_key = 0;
     // device forms
     std::vector<uint64_t> seg_info;    // I2Info rows as (id | score_bits << 32), key = MPH index
     // fused "code point (or byte) -> charmap -> element code" map of the _sp prologue.  Element codes (u16):

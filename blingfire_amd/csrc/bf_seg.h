@@ -339,4 +339,75 @@ BF_HD uint32_t sg_key_hi(const SegArc &a, bool merges)
 }
 BF_HD uint64_t sg_key_lo(const SegArc &a) { return ((uint64_t)((uint32_t)a.id ^ 0x80000000u) << 32) | (uint32_t)a.start; }
 
+// ---------------------------------------------------------------------------------------------------
+// Dictionary key -> info id (reference FADictInterpreter_t<int>::GetInfoId, cl/inc/FADictInterpreter_t.h:334-366, configured
+// without a transformation like blingfiretokdll would: SetConf(conf, NULL)) on the same packed Mealy table:
+//   :347-349  empty key / longer than FALimits::MaxWordSize (300) -> -1
+//   :203-205  an l2r dictionary without ignore-case is looked up AS IS (m_NoNorm): the [pos-dict] charmap is NOT applied
+//   :211-279  otherwise (r2l): FANormalizeWord with the charmap (a result longer than 600 elements counts as empty,
+//             FAUtils_cl.h:441-487), then the symbols are fed last to first
+//   :283-301  FAMphInterpretTools_t::GetId (cl/inc/FAMphInterpretTools_t.h:97-122): every symbol must have a transition, the
+//             output weights add up to the MPH index K, the last state must be final; info id = K2I[K]
+// One key per lane on the GPU (bf_kernels.hip k_dict_ids); tests/hosttest runs the same code on the host.
+// ---------------------------------------------------------------------------------------------------
+struct DictTables {
+    const uint64_t *T; uint32_t initial; int initial_final;   // Mealy table; whether the initial state is final (empty normalised key)
+    const uint16_t *cls_l1; const uint32_t *cls_pages;         // code point -> class of the dictionary alphabet (bf_model.h dict_clsmap), 0xFFFFF = none
+    const uint16_t *nrm_l1; const uint32_t *nrm_pages; const int32_t *nrm_pool;   // [pos-dict] charmap (bf_model.h dict_charmap), nullptr = none
+    const int32_t *k2i; int k2i_n;
+    int r2l;                                                    // PARAM_DIRECTION != l2r
+};
+constexpr int DICT_MAX_WORD = 300, DICT_NORM_BUF = 600;
+constexpr uint32_t DICT_CLS_NONE = 0xFFFFFu, DICT_NORM_NONE = 0xFFFFFFFFu;
+
+BF_HD uint32_t dict_map_get(const uint16_t *l1, const uint32_t *pages, int cp, uint32_t def)
+{
+    if ((unsigned)cp > 0x10FFFFu) return def;
+    return pages[(uint32_t)l1[cp >> 8] * 256u + (uint32_t)(cp & 255)];
+}
+
+struct DictWalk {
+    uint32_t state; int sum; bool ok, fin;
+    BF_HD void start(const DictTables &D) { state = D.initial; sum = 0; ok = true; fin = D.initial_final != 0; }
+    BF_HD void feed(const DictTables &D, int sym)
+    {
+        if (!ok) return;
+        const uint32_t c = dict_map_get(D.cls_l1, D.cls_pages, sym, DICT_CLS_NONE);
+        if (c == DICT_CLS_NONE) { ok = false; return; }
+        const uint64_t e = D.T[state + c];
+        if ((e & SG_CLS_MASK) != c) { ok = false; return; }
+        state = (uint32_t)((e >> SG_NEXT_SHIFT) & SG_NEXT_MASK);
+        sum += (int)(e >> SG_OW_SHIFT);
+        fin = (e & SG_FINAL) != 0;
+    }
+    BF_HD int id(const DictTables &D) const { return (ok && fin && sum >= 0 && sum < D.k2i_n) ? D.k2i[sum] : -1; }
+};
+
+BF_HD int dict_info_id(const DictTables &D, const int32_t *key, int n)
+{
+    if (n <= 0 || n > DICT_MAX_WORD) return -1;
+    DictWalk w; w.start(D);
+    if (!D.r2l) { for (int i = 0; i < n; ++i) w.feed(D, key[i]); return w.id(D); }
+    // r2l: length of the normalised word first (FANormalizeWord gives up beyond the buffer), then its symbols last to first
+    int len = n;
+    if (D.nrm_l1) {
+        len = 0;
+        for (int i = 0; i < n; ++i) {
+            const uint32_t v = dict_map_get(D.nrm_l1, D.nrm_pages, key[i], DICT_NORM_NONE);
+            const int c = v == DICT_NORM_NONE ? 1 : (int)(v >> 24) == 11 ? 1 : (int)(v >> 24);
+            len += c;
+        }
+        if (len > DICT_NORM_BUF) return w.id(D);              // counts as the empty word
+    }
+    for (int i = n - 1; i >= 0; --i) {
+        const uint32_t v = D.nrm_l1 ? dict_map_get(D.nrm_l1, D.nrm_pages, key[i], DICT_NORM_NONE) : DICT_NORM_NONE;
+        if (v == DICT_NORM_NONE) { w.feed(D, key[i]); continue; }
+        const int c = (int)(v >> 24); const uint32_t pay = v & 0xFFFFFFu;
+        if (c == 1) w.feed(D, (int)pay);
+        else if (c == 11) w.feed(D, D.nrm_pool[pay]);
+        else for (int q = c - 1; q >= 0; --q) w.feed(D, D.nrm_pool[pay + (uint32_t)q]);
+    }
+    return w.id(D);
+}
+
 } // namespace bfa

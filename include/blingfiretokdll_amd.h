@@ -190,6 +190,23 @@ BF_API int TextToIdsWithOffsetsBatchDevice(void *ModelPtr, const char *d_text, c
                                     int64_t total_bytes, int32_t *d_ids_out, int32_t *d_starts_out, int32_t *d_ends_out,
                                     int64_t cap, int64_t *d_id_offsets_out, int max_ids_per_doc, int unk, void *stream);
 
+/* additive: the reference's dictionary interpreter, FADictInterpreter_t<int>::GetInfo
+ * (blingfireclient.library/inc/FADictInterpreter_t.h:31-66,334-390; FAMphInterpretTools_t.h:97-122), for many keys at once over the
+ * [pos-dict] of a tokenizer model (gpt2.bin, xlm_roberta_base.bin, ...) -- the same Mealy automaton / K2I / I2Info the segmenters use.
+ * Key k = keys[key_offsets[k] .. key_offsets[k+1]) as int code points (the reference's Ty = int; byte-encoded models such as gpt2.bin
+ * store bytes and U+2581 as their symbols), configured like blingfiretokdll would configure it (SetConf without a transformation):
+ * an l2r dictionary is looked up as is (the [pos-dict] charmap is not applied, FADictInterpreter_t.h:203-205), an r2l one after
+ * charmap normalisation and reversal.  ret_out[k] = GetInfo's return value (value count, -1 = no such key: not in the dictionary,
+ * empty or longer than 300 symbols); info_ids_out[k] = GetInfoId (-1 = none); the values of key k (for the tokenizer dictionaries:
+ * [token id, float score bits]) = values_out[value_offsets_out[k] .. value_offsets_out[k+1]).  ret_out / info_ids_out may be NULL.
+ * Returns the total value count or BF_E_* (BF_E_CAPACITY: the offsets are valid and tell the size).  The Device form takes device
+ * pointers + a hipStream_t, never writes past values_cap and returns 0 / BF_E_*; with d_values_out == NULL it only fills the
+ * per-key results and the offsets. */
+BF_API int64_t DictGetInfoBatch(void *ModelPtr, const int32_t *keys, const int64_t *key_offsets, int64_t nkeys, int32_t *ret_out, int32_t *info_ids_out,
+                                int32_t *values_out, int64_t values_cap, int64_t *value_offsets_out);
+BF_API int DictGetInfoBatchDevice(void *ModelPtr, const int32_t *d_keys, const int64_t *d_key_offsets, int64_t nkeys, int32_t *d_ret_out,
+                                  int32_t *d_info_ids_out, int32_t *d_values_out, int64_t values_cap, int64_t *d_value_offsets_out, void *stream);
+
 /* Per-kernel GPU time of the last batch call on this handle, measured with HIP events recorded on the
  * call's own stream.  Synchronises with those events.  Fills up to n floats (milliseconds):
  * [0] prep (decode+normalise+classify)  [1] tokenise (lexer / segmenter)  [2] scan  [3] compact  [4] total.

@@ -388,6 +388,7 @@ struct bfo_model {
     /* [pos-dict] cl/src/FADictConfKeeper.cpp:57-228 */
     int has_seg; dfa_t dict_dfa; mmapf_t i2info; mmapf_t dict_charmap;
     int tok_algo, id_offset, use_bytes, no_dummy_prefix, fsm_type, k2i_count;
+    const uint8_t *k2i; int direction;   /* K2I array image (cl/src/FAArray_pack.cpp:27-65), PARAM_DIRECTION (0 = l2r, FAFsmConst.h DIR_L2R) */
     /* [i2w] tokdll:998-1045 */
     int has_i2w, i2w_count, min_token_id, max_token_id; const uint8_t *i2w_offs, *i2w_data;
 };
@@ -501,7 +502,7 @@ static int set_model_data(bfo_model *m)
             switch (vals[i]) {
             case PARAM_IGNORE_CASE: m->ignore_case = 1; break;
             case 18 /* PARAM_NO_TR */: break;
-            case 11 /* PARAM_DIRECTION */: ++i; break;
+            case 11 /* PARAM_DIRECTION */: m->direction = vals[++i]; break;
             case PARAM_USE_BYTE_ENCODING: m->use_bytes = 1; break;
             case PARAM_NO_DUMMY_PREFIX: m->no_dummy_prefix = 1; break;
             case PARAM_TOKENIZATION_TYPE: m->tok_algo = vals[++i]; break;
@@ -509,7 +510,7 @@ static int set_model_data(bfo_model *m)
             case PARAM_FSM_TYPE: m->fsm_type = vals[++i]; break;
             case PARAM_MAP_MODE: mode = vals[++i]; break;
             case PARAM_FSM: dfa_set(&m->dict_dfa, m->dumps[vals[++i]]); break;
-            case PARAM_ARRAY: { const uint8_t *d = m->dumps[vals[++i]]; m->k2i_count = rd_i32(d + 12); break; } /* cl/src/FAArray_pack.cpp:27-65 */
+            case PARAM_ARRAY: { const uint8_t *d = m->dumps[vals[++i]]; m->k2i = d; m->k2i_count = rd_i32(d + 12); break; } /* cl/src/FAArray_pack.cpp:27-65 */
             case PARAM_CHARMAP: mmapf_set(&m->dict_charmap, m->dumps[vals[++i]]); break;
             case PARAM_MULTI_MAP:
                 if (mode != MODE_PACK_FIXED) return 0;      /* all tokenizer models use fixed-dump */
@@ -1266,3 +1267,59 @@ int bfo_model_kind(const bfo_model *m)
 }
 int bfo_model_uses_bytes(const bfo_model *m) { return m->use_bytes; }
 int bfo_model_id_offset(const bfo_model *m) { return m->id_offset; }
+
+/* ---------------- dictionary key -> info lookup ---------------- */
+
+/* cl/src/FAArray_pack.cpp:68-95 GetAt on the K2I image (header :27-65: M, SizeOfIndex, SizeOfValue, Count) */
+static int k2i_get_at(const uint8_t *img, int idx)
+{
+    const int M = rd_i32(img), soi = rd_i32(img + 4), sov = rd_i32(img + 8), count = rd_i32(img + 12);
+    const uint8_t *p = img + 16;
+    if (M == 1) return (int)dec_1234_idx(p, (unsigned)idx, sov);
+    {
+        const uint8_t *data = p + (size_t)((count + M - 1) / M) * (size_t)soi;
+        const int chain = (int)dec_1234_idx(p, (unsigned)(idx / M), soi);
+        return (int)dec_1234_idx(data + (size_t)chain * (size_t)(M * sov), (unsigned)(idx % M), sov);
+    }
+}
+
+/* cl/inc/FADictInterpreter_t.h:334-366 GetInfoId for a Mealy [pos-dict] configured like tokdll configures it (SetConf with no
+ * transformation, tokdll:953-956 / FADictInterpreter_t.h:155-206): returns the info id or -1.
+ *   :347-349  empty / longer than FALimits::MaxWordSize (300) -> -1
+ *   :203-205  m_NoNorm = no transformation && !ignore-case && direction == l2r: then the word is looked up AS IS -- the
+ *             [pos-dict] charmap is NOT applied (it only is inside Normalize(), i.e. for r2l / ignore-case dictionaries)
+ *   :211-279  Normalize: lower-casing (ignore-case), FANormalizeWord with the charmap (FAUtils_cl.h:441-487: a result longer
+ *             than the 600-element buffer counts as length 0), reversal for r2l
+ *   :283-301  GetInfoId_mph: FAMphInterpretTools_t::GetId (FAMphInterpretTools_t.h:97-122: walk every symbol, add the output
+ *             weights, the last state must be final) then K2I */
+int bfo_dict_get_info_id(const bfo_model *m, const int *in, int n)
+{
+    int buf[600], tmp[600];
+    const int *w = in;
+    int len = n, i, state, ow, id = 0;
+    if (!m || !m->has_seg || !m->k2i || n <= 0 || n > 300 || !in) return -1;
+    if (m->ignore_case) return -1;                 /* FAUtf32ToLower tables are not restated: such models are refused by the product too */
+    if (m->direction != 0) {
+        if (m->dict_charmap.set) { len = normalize(in, n, tmp, NULL, 600, &m->dict_charmap); if (len < 0 || len > 600) len = 0; w = tmp; }
+        for (i = 0; i < len; ++i) buf[i] = w[len - 1 - i];
+        w = buf;
+    }
+    state = m->dict_dfa.initial;
+    for (i = 0; i < len; ++i) {
+        state = mealy_dest_ow(&m->dict_dfa, state, w[i], &ow);
+        if (state == -1) return -1;
+        id += ow;
+    }
+    if (!dfa_is_final(&m->dict_dfa, state)) return -1;
+    if (id < 0 || id >= m->k2i_count) return -1;   /* DebugLogAssert in the reference (:295) */
+    return k2i_get_at(m->k2i, id);
+}
+
+/* cl/inc/FADictInterpreter_t.h:369-390 GetInfo: info id -> I2Info row (FAMultiMap_pack_fixed.cpp:67-137: the values are copied
+ * only if max_out >= count; returns count, -1 = no such word / row) */
+int bfo_dict_get_info(const bfo_model *m, const int *in, int n, int *out, int max_out)
+{
+    const int id = bfo_dict_get_info_id(m, in, n);
+    if (id == -1) return -1;
+    return mmapf_get(&m->i2info, id, out, max_out);
+}

@@ -86,6 +86,11 @@ int bfo_charmap_get(const bfo_model *m, int which, int key, int *out, int max_ou
 /* cl/src/FAMultiMap_pack_fixed.cpp:140-160 on I2Info: returns count, fills id/score bits */
 int bfo_i2info_get(const bfo_model *m, int key, int *id, uint32_t *score_bits);
 
+/* cl/inc/FADictInterpreter_t.h:334-366 / :369-390 over the model's [pos-dict] (word = int code points, like the reference's
+ * Ty = int instantiation; no transformation, as tokdll would configure it): info id or -1; value count or -1 */
+int bfo_dict_get_info_id(const bfo_model *m, const int *word, int n);
+int bfo_dict_get_info(const bfo_model *m, const int *word, int n, int *out, int max_out);
+
 /* model facts (for tests / reports) */
 int bfo_model_kind(const bfo_model *m);      /* 0 = _wp lexer, 1 = unigram, 2 = bpe, 3 = bpe-opt, 4 = bpe-with-merges */
 int bfo_model_uses_bytes(const bfo_model *m);

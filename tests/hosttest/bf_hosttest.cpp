@@ -325,6 +325,26 @@ int bft_emu_text_to_ids(void *hv, const char *s, int n, int32_t *ids, int max_id
     return emu_sp(m, s, n, ids, nullptr, nullptr, max_ids, unk);
 }
 
+// key -> info id through the device program of bf_seg.h (dict_info_id) on the host, and the row count GetInfo would return
+int bft_emu_dict_get_info(void *hv, const int32_t *key, int n, int32_t *info_id, int32_t *vals, int max_vals)
+{
+    Model &m = ((Handle *)hv)->m;
+    if (!m.error.empty() || !m.has_seg || m.k2i.empty()) return -2;
+    DictTables D;
+    D.T = m.dict.t64.data(); D.initial = m.dict.initial_base; D.initial_final = m.dict_raw.is_final[(size_t)m.dict_raw.initial] ? 1 : 0;
+    D.cls_l1 = m.dict_clsmap.l1.data(); D.cls_pages = m.dict_clsmap.pages.data();
+    const bool nrm = m.dict_direction != 0 && m.dict_has_charmap;
+    D.nrm_l1 = nrm ? m.dict_charmap.l1.data() : nullptr; D.nrm_pages = nrm ? m.dict_charmap.pages.data() : nullptr; D.nrm_pool = nrm ? m.dict_norm_pool.data() : nullptr;
+    D.k2i = m.k2i.data(); D.k2i_n = (int)m.k2i.size(); D.r2l = m.dict_direction != 0;
+    const int id = dict_info_id(D, key, n);
+    *info_id = id;
+    const int nrows = m.info_stride > 0 ? (int)(m.info_rows.size() / (size_t)m.info_stride) : 0;
+    if (id == -1 || id < m.info_min_key || id - m.info_min_key >= nrows) return -1;
+    const int32_t *row = m.info_rows.data() + (size_t)(id - m.info_min_key) * (size_t)m.info_stride;
+    for (int q = 0; q < row[0] && q < max_vals; ++q) vals[q] = row[1 + q];
+    return row[0];
+}
+
 // TextToWords on the host: words-mode lane program on the unfused class map + the output formatting of the product
 int bft_emu_text_to_words(void *hv, const char *s, int n, char *out, int32_t *starts, int32_t *ends, int max_out)
 {
