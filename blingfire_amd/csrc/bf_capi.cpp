@@ -11,6 +11,7 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <condition_variable>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -88,6 +89,9 @@ struct Handle {
     DevBuf w_cls, w_nchars, w_tmp, w_counts, w_bsums, w_misc, w_flags, w_out, w_outoff;   // w_misc: [0] next_doc (u64), [2] status (int)
     DevBuf w_text, w_docoff, w_ids, w_idoff, w_starts, w_ends;  // host-API staging
     DevBuf w_srcoff, w_span;                                    // offsets API: source-offset stream, staged id spans
+    // single-document calls that arrive while a batch is in flight are combined into the next launch (text_to_ids_one)
+    struct OneReq { const char *s; int n; int32_t *ids; int max_ids, unk; int32_t *starts, *ends; int result; bool done; };
+    std::mutex q_mu; std::condition_variable q_cv; std::vector<OneReq *> q; bool q_leader = false;
     hipStream_t stream = nullptr;
     hipEvent_t ev[EV_COUNT] = {};
     bool ev_valid = false;
@@ -544,6 +548,37 @@ int run_dict_device(Handle *h, const int32_t *d_keys, const int64_t *d_key_off, 
     return hip_ok(hipGetLastError(), "dictionary lookup kernels") ? 0 : BF_E_DEVICE;
 }
 
+// One launch for a group of single-document requests that share (max_ids, unk, offsets wanted): the documents are packed,
+// run as one batch, and every caller gets exactly what its own TextToIds call would have written.
+void run_one_group(Handle *h, std::vector<Handle::OneReq *> &g)
+{
+    const int max_ids = g[0]->max_ids, unk = g[0]->unk; const bool want_off = g[0]->starts && g[0]->ends;
+    const int64_t nd = (int64_t)g.size();
+    std::vector<int64_t> off((size_t)nd + 1, 0), id_off((size_t)nd + 1, 0);
+    for (int64_t i = 0; i < nd; ++i) off[(size_t)i + 1] = off[(size_t)i] + g[(size_t)i]->n;
+    std::string packed; const char *text = g[0]->s;
+    if (nd > 1) { packed.resize((size_t)off[(size_t)nd]); for (int64_t i = 0; i < nd; ++i) memcpy(&packed[(size_t)off[(size_t)i]], g[(size_t)i]->s, (size_t)g[(size_t)i]->n); text = packed.data(); }
+    const int64_t cap = nd * (int64_t)max_ids;
+    std::vector<int32_t> ids, st, en; int32_t *pi = g[0]->ids, *ps = g[0]->starts, *pe = g[0]->ends;
+    if (nd > 1) { ids.resize((size_t)cap); pi = ids.data(); if (want_off) { st.resize((size_t)cap); en.resize((size_t)cap); ps = st.data(); pe = en.data(); } }
+    const int64_t r = run_host(h, text, off.data(), nd, pi, cap, id_off.data(), max_ids, unk, want_off ? ps : nullptr, want_off ? pe : nullptr);
+    if (r < 0) fprintf(stderr, "[blingfire_amd] TextToIds failed (%lld): %s\n", (long long)r, g_last_error.c_str());
+    for (int64_t i = 0; i < nd; ++i) {
+        Handle::OneReq *q = g[(size_t)i];
+        if (r < 0) { q->result = 0; continue; }
+        const int64_t b = id_off[(size_t)i], c = id_off[(size_t)i + 1] - b;
+        if (nd > 1 && c > 0) {
+            memcpy(q->ids, pi + b, (size_t)c * 4);
+            if (want_off) { memcpy(q->starts, ps + b, (size_t)c * 4); memcpy(q->ends, pe + b, (size_t)c * 4); }
+        }
+        q->result = (int)c;
+    }
+}
+
+// TextToIds for one document.  The GPU runs batches: a call that arrives while another one is in flight on the same handle
+// waits in a queue, and whoever finishes next launches everything that queued up as ONE batch (flat combining) -- so that
+// concurrent callers of the drop-in entry points (C#, Python threads: SURVEY.md section 8b "Threading") share launches instead
+// of serialising one ~60 us launch each.  A lone caller simply runs its own batch of one.
 int text_to_ids_one(void *hp, const char *s, int n, int32_t *ids, int max_ids, int unk, int want_kind /* -1 any, 0 wp, 1 sp */,
                     int32_t *starts = nullptr, int32_t *ends = nullptr)
 {
@@ -553,10 +588,33 @@ int text_to_ids_one(void *hp, const char *s, int n, int32_t *ids, int max_ids, i
     if (want_kind == 0 && h->m.kind != KIND_WP) return 0;
     if (want_kind == 1 && h->m.kind == KIND_WP) return 0;
     if (max_ids <= 0 || !ids) return 0;
-    const int64_t off[2] = {0, n};
-    int64_t r = run_host(h, s, off, 1, ids, max_ids, nullptr, max_ids, unk, starts, ends);
-    if (r < 0) { fprintf(stderr, "[blingfire_amd] TextToIds failed (%lld): %s\n", (long long)r, g_last_error.c_str()); return 0; }
-    return (int)r;
+    Handle::OneReq me{s, n, ids, max_ids, unk, starts, ends, 0, false};
+    std::unique_lock<std::mutex> lk(h->q_mu);
+    h->q.push_back(&me);
+    while (h->q_leader && !me.done) h->q_cv.wait(lk);
+    if (me.done) return me.result;
+    h->q_leader = true;                                       // lead: serve everything queued (at least my own request)
+    for (int round = 0; round < 4 && !h->q.empty(); ++round) {
+        std::vector<Handle::OneReq *> all; all.swap(h->q);
+        lk.unlock();
+        while (!all.empty()) {                                // groups of requests with the same call parameters
+            std::vector<Handle::OneReq *> g, rest; int64_t bytes = 0;
+            for (Handle::OneReq *q : all) {
+                const bool same = q->max_ids == all[0]->max_ids && q->unk == all[0]->unk && ((q->starts && q->ends) == (all[0]->starts && all[0]->ends));
+                if (same && bytes + q->n <= 1000000000 && (int64_t)(g.size() + 1) * q->max_ids <= 2000000000) { g.push_back(q); bytes += q->n; } else rest.push_back(q);
+            }
+            run_one_group(h, g);
+            lk.lock();
+            for (Handle::OneReq *q : g) q->done = true;
+            h->q_cv.notify_all();
+            lk.unlock();
+            all.swap(rest);
+        }
+        lk.lock();
+    }
+    h->q_leader = false;                                      // anything still queued is led by one of its own callers
+    h->q_cv.notify_all();
+    return me.result;
 }
 
 int64_t text_batch_host(void *p, const char *text, const int64_t *doc_off, int64_t ndocs, char *text_out, int64_t text_cap, int64_t *text_off_out, int mode)

@@ -151,3 +151,43 @@ def test_reserve_then_no_growth():
         assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
     finally:
         bf.free_model(h)
+
+
+def test_single_document_calls_from_many_threads_are_combined_correctly():
+    """text_to_ids_one (bf_capi.cpp): concurrent TextToIds / TextToIdsWithOffsets calls on ONE handle share launches; every caller
+    must still get exactly its own answer -- different documents, max_ids and unk values in flight at the same time"""
+    name = bfutil.bert_model_name()
+    h = bf.load_model(bfutil.model_path(name))
+    ora = bfutil.oracle()
+    ho = ora.load(bfutil.model_path(name))
+    docs = [d for d in bfutil.fuzz_docs(600, seed=41) if len(d) < 3000]
+    params = [(64, 100), (8, 100), (64, 7), (300, 100)]
+    want = {}
+    for k, d in enumerate(docs):
+        mx, unk = params[k % 4]
+        c, buf = ora.text_to_ids(ho, d, mx, unk)
+        want[k] = buf[:c]
+    ora.free(ho)
+    errs = []
+
+    def work(t):
+        try:
+            for k in range(t, len(docs), 12):
+                mx, unk = params[k % 4]
+                got = bf.text_to_ids(h, docs[k], mx, unk, no_padding=True).view(np.int32).tolist()
+                if got != want[k]:
+                    errs.append("doc %d: %r != %r" % (k, got[:8], want[k][:8]))
+                if k % 5 == 0:
+                    i, s, e = bf.utf8text_to_ids_with_offsets(h, docs[k], mx, unk, no_padding=True)
+                    if i.view(np.int32).tolist() != want[k]:
+                        errs.append("doc %d (offsets form) differs" % k)
+        except Exception as ex:   # noqa: BLE001
+            errs.append(repr(ex))
+
+    ts = [threading.Thread(target=work, args=(t,)) for t in range(12)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    bf.free_model(h)
+    assert not errs, errs[:5]
