@@ -258,6 +258,7 @@ int run_device(Handle *h, const char *d_text, const int64_t *d_doc_off, int64_t 
         lp.L.max_depth = m.max_depth; lp.L.max_token_length = m.max_token_length; lp.L.max_frames = m.lex_frames;
         lp.L.loop_state = (h->variant & 0xff) == 4 ? LX_NO_STATE : m.loop_base;        // variant 4 (experiments): no fast-forward
         lp.L.loop_info = m.loop_info; lp.L.loop_final = m.loop_final ? 1 : 0;
+        lp.L.two_level = (m.two_level && (h->variant & 0xff) != 7) ? 1 : 0;                // variant 7 (experiments): the general machine
         lp.b = b; lp.cls = h->w_cls.as<uint16_t>(); lp.nchars = h->w_nchars.as<int32_t>();
         lp.ids_tmp = h->w_tmp.as<int32_t>(); lp.counts = h->w_counts.as<int32_t>(); lp.span_tmp = want_off ? h->w_span.as<int32_t>() : nullptr;
         lp.max_ids = max_ids; lp.unk = unk; lp.next_doc = next_doc; lp.status = status; lp.ev_thresh = 0; lp.fetch_thresh = 0; lp.acts_n = (int)m.acts_pool.size(); lp.words = words;
@@ -290,7 +291,7 @@ int run_device(Handle *h, const char *d_text, const int64_t *d_doc_off, int64_t 
             sg.bm_words = (int64_t)bm_words;
             sg.arcs = h->w_s1.as<SegArc>(); sg.tos = h->w_s2.as<int32_t>(); sg.idsv = h->w_s3.as<int32_t>(); sg.inter = h->w_s4.as<uint8_t>();
         }
-        sg.narcs = h->w_narcs.as<int32_t>(); sg.next_doc = next_doc; sg.trie_depth = m.trie_max_depth; sg.variant = h->variant & 0xff; sg.tune = (h->variant >> 8) & 0xff;
+        sg.narcs = h->w_narcs.as<int32_t>(); sg.next_doc = next_doc; sg.trie_depth = m.trie_max_depth; sg.variant = h->variant & 0xff; sg.tune = (h->variant >> 8) & 0xff; sg.tune2 = (h->variant >> 16) & 0xff;
         if (m.kind == KIND_UNIGRAM && sg.variant != 1 && m.trie_max_depth > 0 && m.trie_max_depth <= 4096) first = h->w_narcs.as<int32_t>();
         sg.perm = h->w_perm.as<int32_t>(); sg.hist = h->w_hist.as<unsigned int>();
         if (ndocs > 0) launch_seg_sp(sg, s);

@@ -84,7 +84,8 @@ struct SpSegParams {
     int64_t bm_words;           // BPE apply: words per bitmap (the two bitmaps live in the `tos` buffer)
     int32_t *fb_list; unsigned int *fb_count;   // BPE: documents k_bpe_fused hands to the full path (set by launch_seg_sp)
     int variant;
-    int tune;                   // experiments: vote threshold of the lane-local BPE solve (0 = default)
+    int tune;                   // experiments: vote threshold of the lane-local BPE solve / Unigram transitions per trip (0 = default)
+    int tune2;                  // experiments: resident waves per CU of the persistent segmenter kernels (0 = what fits)
     unsigned long long *next_doc;
 };
 

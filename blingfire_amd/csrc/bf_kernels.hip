@@ -417,7 +417,7 @@ __global__ __launch_bounds__(THREADS) void k_lex_wp_seq(WpLexParams p)
 // counter; every loop iteration a lane in WALK mode makes exactly one DFA transition, while the heavier
 // "event" code (match handling, calls/returns, next start position) and the document fetch run only when
 // enough lanes of the wave are waiting for them (ballot vote), so that they execute with most lanes active.
-template <int THREADS, class WIN, bool HAS_ANY, int UNROLL, bool STATS, bool TLDS = false>
+template <int THREADS, class WIN, bool HAS_ANY, int UNROLL, bool STATS, bool TLDS = false, bool TWO = false>
 __global__ __launch_bounds__(THREADS) void k_lex_wp_flat(WpLexParams p)
 {
     extern __shared__ int32_t lex_lds[];
@@ -468,8 +468,10 @@ __global__ __launch_bounds__(THREADS) void k_lex_wp_flat(WpLexParams p)
         if (STATS) { st_ev_rounds += 1; st_ev_lanes += __popcll(m_event); const unsigned long long t1 = __builtin_readcyclecounter(); tk_walk += t1 - tk0; tk0 = t1; }
         // ---- events: match handling, calls / returns, next start position
         if (mode == M_EVENT) {
-            lane.after_walk();
-            if (lane.prepare()) mode = M_WALK;
+            bool more;
+            if constexpr (TWO) { lane.after_walk2(); more = lane.prepare2(); }      // two-level lexers (every WordPiece model): no frame stack
+            else { lane.after_walk(); more = lane.prepare(); }
+            if (more) mode = M_WALK;
             else { p.counts[doc] = lane.finish(); mode = M_NEED; }
         }
         if (STATS) { const unsigned long long t1 = __builtin_readcyclecounter(); tk_event += t1 - tk0; tk0 = t1; }
@@ -496,7 +498,9 @@ __global__ __launch_bounds__(THREADS) void k_lex_wp_flat(WpLexParams p)
                         cls_at.init(p.cls, b);
                         out.init(p.ids_tmp + ids_slot(b, doc), p.span_tmp ? p.span_tmp + 2 * ids_slot(b, doc) : nullptr);
                         lane.init(n, cap, p.unk, p.words);
-                        if (lane.prepare()) mode = M_WALK;
+                        bool more;
+                        if constexpr (TWO) more = lane.prepare2(); else more = lane.prepare();
+                        if (more) mode = M_WALK;
                         else p.counts[doc] = lane.finish();          // empty / invalid document: 0 ids, stay idle
                     }
                 }
@@ -559,6 +563,26 @@ void launch_lex_wp(const WpLexParams &p, int variant, hipStream_t s)
             return;
         }
         const int usel = (variant >> 30) & 3;                // DFA transitions per vote: 0 = three (default; swept on MI355X), 1 = one, 2 = two, 3 = four
+        if (p.L.two_level && !p.stats) {
+            // two-level lexers: no saved frames in LDS, cheap events -> a lower event threshold pays (swept on MI355X)
+            WpLexParams q2 = q; q2.L.max_frames = 0;
+            if (((variant >> 8) & 0xff) == 0) q2.ev_thresh = 16;
+            const size_t lds2 = lex_lds_bytes(q2, 64);
+            int per_cu = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_lex_wp_flat<64, ClsWin, false, 3, false, false, true>, 64, lds2) != hipSuccess || per_cu <= 0) per_cu = 16;
+            (void)hipGetLastError();
+            if (((variant >> 24) & 0x3f) != 0) per_cu = (variant >> 24) & 0x3f;
+            int64_t nb = (int64_t)device_cus() * per_cu;
+            if (nb > need) nb = need;
+            if (nb < 1) nb = 1;
+            const dim3 g2((unsigned)nb), t2(64);
+            if (has_any) hipLaunchKernelGGL((k_lex_wp_flat<64, ClsWin, true, 1, false, false, true>), g2, t2, lds2, s, q2);
+            else if (usel == 2) hipLaunchKernelGGL((k_lex_wp_flat<64, ClsWin, false, 2, false, false, true>), g2, t2, lds2, s, q2);
+            else if (usel == 3) hipLaunchKernelGGL((k_lex_wp_flat<64, ClsWin, false, 4, false, false, true>), g2, t2, lds2, s, q2);
+            else if (usel == 1) hipLaunchKernelGGL((k_lex_wp_flat<64, ClsWin, false, 1, false, false, true>), g2, t2, lds2, s, q2);
+            else hipLaunchKernelGGL((k_lex_wp_flat<64, ClsWin, false, 3, false, false, true>), g2, t2, lds2, s, q2);
+            return;
+        }
         const dim3 g((unsigned)blocks), t(64); const size_t lds = lex_lds_bytes(q, 64);
         if (has_any) hipLaunchKernelGGL((k_lex_wp_flat<64, ClsWin, true, 1, false>), g, t, lds, s, q);
         else if (p.stats) hipLaunchKernelGGL((k_lex_wp_flat<64, ClsWin, false, 3, true>), g, t, lds, s, q);
@@ -1635,6 +1659,7 @@ void launch_seg_sp(const SpSegParams &p_in, hipStream_t s)
                         unroll == 4 ? (const void *)k_seg_unigram_lane<4> : (const void *)k_seg_unigram_lane<3>;
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 64, lds) != hipSuccess || per_cu <= 0) per_cu = 8;
             (void)hipGetLastError();
+            if (p.tune2 > 0 && p.tune2 < per_cu) per_cu = p.tune2;
             unsigned blocks = (unsigned)device_cus() * (unsigned)per_cu;
             if ((int64_t)blocks > (int64_t)b64) blocks = b64;
             if (p.variant == 6) hipLaunchKernelGGL(k_seg_unigram_ring, dim3(blocks), dim3(64), lds, s, p, ring);   // round-1 kernel (A/B)

@@ -49,6 +49,11 @@ struct LexTables {
     // it is the same as skipping the run of flagged elements (fp / finfo follow the last one when the state is final), so
     // step() does that from the class window alone, without one table gather per character.
     uint32_t loop_state, loop_info; int loop_final;
+    // "Two-level" lexer (load-time fact, bf_model.cpp): every action with functions is [left 0, right 0, tag != 0, ONE function]
+    // and no rule of a called function calls anything -- the shape of every WordPiece model (top-level rules find the word and
+    // call FnTokWord, whose rules are the vocabulary).  The call stack then never holds more than the top-level frame, which is a
+    // constant: prepare2() / after_walk2() run the same algorithm without the frame stack and the general action decoding.
+    int two_level;
 };
 
 // where table entries come from: a policy, so that the host build can count lookups per table index
@@ -118,7 +123,7 @@ struct LexLane {
     int max_ids, unk;
     int out_count, scanning, tok_from, tok_to, expected, nsub, word_out;
     // ---- lexer
-    int max_triples, emitted, last_to, d;
+    int max_triples, emitted, last_to, d, n_doc;
     uint32_t ini, ini_l; int off, fn_, from, once;                // current frame (ini_l is only needed by its first walk)
     int a_idx, a_end, to2, fn_once, fp_r, fn_from;                // action being executed in it
     uint32_t state, finfo; int j, lim, fp;                        // current walk (finfo: action info of the deepest final state;
@@ -163,7 +168,7 @@ struct LexLane {
         max_ids = max_ids_; unk = unk_; words = words_;
         out_count = 0; scanning = 0; tok_from = tok_to = expected = nsub = word_out = 0;
         // WbdRes holds 6*BuffSize ints = 2*BuffSize triples for TextToIds (tokdll:1194), 3*BuffSize ints for TextToWords (tokdll:494-499)
-        max_triples = words_ ? n : 2 * n;
+        max_triples = words_ ? n : 2 * n; n_doc = n;
         emitted = 0; last_to = 0; d = 0;
         ini = L.initial; ini_l = L.initial_l; off = 0; fn_ = n; from = -1; once = 0;
         a_idx = a_end = 0; to2 = 0; fn_once = 0; fp_r = 0; fn_from = 0;
@@ -319,6 +324,82 @@ struct LexLane {
         ++from;
     }
 
+    // ---- two-level form (L.two_level): the same operations as prepare() / after_walk() / after_action() for the only two
+    //      situations that can occur -- the top-level frame (d == 0) and one function frame on top of it (d == 1).
+    //      `to2` doubles as the saved top-level resume position while the function runs.
+    BF_HD bool prepare2()
+    {
+        if (stop) return false;
+        for (;;) {
+            if (from >= fn_) {
+                if (d == 0) return false;                          // Process_int returns (FALexTools_t.h:399)
+                // the function returns into the top-level frame; its action has no further function and left = right = 0:
+                // after_action() there is "from = max(fp, from) + 1" (FALexTools_t.h:390-393), precomputed at the call
+                d = 0; ini = L.initial; off = 0; fn_ = n_doc; from = to2;
+                continue;
+            }
+            state = ini; fp = -1; finfo = 0; j = from;
+            set_lim(from);
+            if (j < 0) {
+                if (ini_l == LX_NO_STATE || !(0 < lim)) { ++from; continue; }
+                state = ini_l; j = 0;
+                cls_at.prefetch(off);
+                return true;
+            }
+            if (!(j < lim)) { ++from; continue; }
+            cls_at.prefetch(off + j);
+            return true;
+        }
+    }
+    BF_HD void after_walk2()
+    {
+        if (fp == -1) { ++from; return; }
+        const uint32_t inf = finfo;
+        const bool call = !(inf & LX_INFO_SIMPLE);
+        int tag; uint32_t f_ini = 0, f_ini_l = 0;
+        if (!call) tag = (int)(inf & 0x7FFFFFFFu);
+        else { const int32_t *a = L.acts + inf; tag = a[2]; f_ini = (uint32_t)a[5]; f_ini_l = (uint32_t)a[6]; }
+        int from2 = from; if (from2 < 0) from2 = 0;                  // left = right = 0: the clamps of FALexTools_t.h:316-329 only see from == -1
+        const int t2 = fp;
+        // tag != 0 always (a SIMPLE action has tag > 0, a calling one tag != 0: checked at load)
+        if (emitted >= max_triples) { stop = true; return; }         // output buffer full (FALexTools_t.h:337-340)
+        ++emitted; last_to = t2 + off;
+        // the streaming post-pass (sink_push / sink_finalize_word above) with its single possible id store hoisted out, so that the
+        // store (an LDS chunk buffer with a flush path on the GPU) is instantiated once
+        const int tf = from2 + off, tt = t2 + off;
+        bool put_on = false, full = false; int put_k = 0, put_v = 0, put_f = 0, put_t = 0;
+        if (words) {
+            if ((words == 2 || tag != WBD_IGNORE_TAG) && out_count < max_ids) { put_on = true; put_k = out_count; put_v = tag; put_f = tf; put_t = tt; ++out_count; }
+        } else {
+            bool consumed = false;
+            if (scanning) {
+                if (tag > WBD_IGNORE_TAG && expected == tf) {            // a sub-token of the open word (tokdll:1239)
+                    const int k = word_out + nsub;
+                    if (k < max_ids) { put_on = true; put_k = k; put_v = tag; put_f = tf; put_t = tt; }
+                    nsub++; expected = tt + 1; consumed = true;
+                } else {                                                 // the open word is complete (tokdll:1252-1301)
+                    if (nsub > 0 && expected - 1 == tok_to) { const int c = word_out + nsub; out_count = c < max_ids ? c : max_ids; }
+                    else if (word_out < max_ids) { put_on = true; put_k = word_out; put_v = unk; put_f = tok_from; put_t = tok_to; out_count = word_out + 1; }
+                    scanning = 0;
+                    full = out_count >= max_ids;
+                }
+            }
+            if (!consumed && !full) {
+                if (tag == WBD_WORD_TAG) { scanning = 1; tok_from = tf; tok_to = tt; expected = tf; nsub = 0; word_out = out_count; }
+                full = !(out_count < max_ids || scanning);
+            }
+        }
+        if (put_on) { ids.put(put_k, put_v); ids.span(put_k, put_f, put_t); }
+        if (full) { stop = true; return; }                           // id array full (tokdll:1308-1310)
+        if (call && d == 0 && L.max_depth >= 2) {
+            // enter the function on [from2, t2] (FALexTools_t.h:350-382); remember where the top level goes on
+            to2 = fp + 1;                                            // where the top level goes on
+            d = 1; ini = f_ini; ini_l = f_ini_l; off = from2 + off; fn_ = t2 - from2 + 1; from = -1;
+            return;
+        }
+        from = fp + 1;                                               // FALexTools_t.h:390-393 with right = 0
+    }
+
     BF_HD int finish()
     {
         if (scanning && !words) sink_finalize_word();
@@ -333,6 +414,13 @@ BF_HD int lex_doc_t(const LexTables &L, ClsAt &cls_at, int n, IdOut &out, int ma
 {
     LexLane<ClsAt, IdOut, Frames, HAS_ANY> lane(L, cls_at, out, frames);
     lane.init(n, max_ids, unk, words);
+    if (L.two_level) {
+        while (lane.prepare2()) {
+            while (lane.step_r()) {}
+            lane.after_walk2();
+        }
+        return lane.finish();
+    }
     while (lane.prepare()) {
         while (lane.step_r()) {}
         lane.after_walk();

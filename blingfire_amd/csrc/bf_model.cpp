@@ -636,6 +636,38 @@ bool build_model(Model &m, const uint8_t *img, size_t size)
                 m.wbd_t2[i] = (uint64_t)lo | ((uint64_t)(fin ? m.wbd_info[next] : 0u) << 32);
             }
 
+            // two-level shape (bf_lex.h LexTables::two_level): (1) every action with functions is [0, 0, tag != 0, one function],
+            // (2) from a called function's initial states (plain and after the left anchor) only final states with SIMPLE actions
+            // can be reached -- whatever symbols are fed.  Then the call depth is exactly 1 and the caller is the top-level frame.
+            {
+                bool ok = m.max_depth >= 2 && !m.acts_pool.empty();
+                std::vector<uint32_t> fn_starts;
+                for (size_t id = 0; ok && id < actions.size(); ++id) {
+                    if (act_info[id] & INFO_SIMPLE_BIT) continue;
+                    const int32_t *a = m.acts_pool.data() + act_info[id];
+                    if (a[0] != 0 || a[1] != 0 || a[2] == 0 || a[3] != 1) { ok = false; break; }
+                    fn_starts.push_back((uint32_t)a[5]);
+                    if ((uint32_t)a[6] != 0xFFFFFFFFu) fn_starts.push_back((uint32_t)a[6]);
+                }
+                if (ok && !fn_starts.empty()) {
+                    const RawDfa &rw = m.wbd_raw;
+                    std::vector<int> base2idx(m.wbd.table_len(), -1);
+                    for (size_t st = 0; st < rw.state_off.size(); ++st) base2idx[m.wbd.state_base[st]] = (int)st;
+                    std::vector<uint8_t> seen(rw.state_off.size(), 0);
+                    std::vector<int> stack;
+                    for (uint32_t b : fn_starts) { const int st = b < base2idx.size() ? base2idx[b] : -1; if (st >= 0 && !seen[(size_t)st]) { seen[(size_t)st] = 1; stack.push_back(st); } }
+                    while (ok && !stack.empty()) {
+                        const int st = stack.back(); stack.pop_back();
+                        if (rw.is_final[(size_t)st] && !(m.wbd_info[m.wbd.state_base[(size_t)st]] & INFO_SIMPLE_BIT)) { ok = false; break; }
+                        for (uint32_t t = rw.tr_begin[(size_t)st]; t < rw.tr_begin[(size_t)st + 1]; ++t) {
+                            const int dst = rw.tr_dst[t];
+                            if (dst >= 0 && !seen[(size_t)dst]) { seen[(size_t)dst] = 1; stack.push_back(dst); }
+                        }
+                    }
+                } else ok = false;          // no calling action at all: the general machine is already flat
+                m.two_level = ok;
+            }
+
             // loop state: the state with the most transitions to itself (ties: the first).  Only text classes matter: the anchors
             // and IW_ANY never occur in a class stream.
             m.loop_cls.assign((size_t)m.wbd.nclasses, 0);

@@ -3,7 +3,7 @@
 #   tools/gpu_pmc2.sh <tag> "<bench args>"
 # writes gpurun_out/pmc2_<tag>/summary.txt (per kernel: every counter averaged over the dispatches, + avg duration)
 set -u
-tag=$1; args=$2
+tag=$1; args=$2; passes=${3:-all}
 export TMPDIR=/tmp
 out=$PWD/gpurun_out/pmc2_$tag
 mkdir -p "$out"
@@ -18,6 +18,7 @@ for c in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_
          "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum" \
          "FETCH_SIZE" "WRITE_SIZE"; do
   i=$((i+1))
+  if [ "$passes" != "all" ] && ! echo " $passes " | grep -q " $i "; then continue; fi
   timeout 400 rocprofv3 --pmc $c --kernel-trace -d "$out/p$i" -o pmc -- python $root/bench.py --no-cpu-baseline --no-extra-timings --verify 0 --steps 3 --warmup 1 $args > "$out/p$i.log" 2>&1
 done
 cd "$root"
@@ -39,5 +40,4 @@ for k in sorted(rows, key=lambda k: -max(v[1] for v in rows[k].values())):
     for n in sorted(rows[k]):
         print("    %-40s %18.0f   (%d dispatches)" % (n, rows[k][n][0], rows[k][n][2]))
 PY
-find "$out" -name "*.db" -size +4M -delete
-find "$out" -name "*.csv" -size +4M -delete
+rm -rf "$out"/p[0-9]*     # only summary.txt travels back (gpurun_out/ is capped at 64 MiB)
