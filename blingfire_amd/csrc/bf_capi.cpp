@@ -200,6 +200,9 @@ Handle *make_handle(const uint8_t *img, size_t size)
     return h;
 }
 
+// the Unigram lane program (bf_seg.h UniLane) keeps `depth` window entries in LDS and packs id + 1 into 20 bits
+bool uni_lane_ok(const Model &m) { return m.trie_max_depth > 0 && m.trie_max_depth <= 32 && m.max_info_id <= UNI_MAX_ID; }
+
 // Workspaces of the TextToIds pipeline for a batch of ndocs documents / total_bytes bytes (grow-only; see DevBuf::reserve).
 bool reserve_ids_workspaces(Handle *h, int64_t ndocs, int64_t total_bytes, bool want_off)
 {
@@ -216,9 +219,9 @@ bool reserve_ids_workspaces(Handle *h, int64_t ndocs, int64_t total_bytes, bool 
     if (!h->w_cls.reserve(cap * 2) || !h->w_tmp.reserve(cap * 4)) return false;
     if (want_off && (!h->w_srcoff.reserve(cap * 4) || !h->w_span.reserve(cap * 8))) return false;
     if (m.kind == KIND_UNIGRAM) {
-        // {begin, id} per stream element (bf_seg.h SegBI); the sequential / flat variants (experiments) keep 16-byte records
-        const bool lane_form = (h->variant & 0xff) != 1 && (h->variant & 0xff) != 2 && (h->variant & 0xff) != 6 && m.trie_max_depth > 0 && m.trie_max_depth <= 32;
-        if (!h->w_s1.reserve(cap * (lane_form ? 8 : 16))) return false;
+        // one packed 4-byte record per stream element (bf_seg.h uni_rec; 8 bytes reserved); the sequential / flat variants keep 16-byte records
+        const bool lane_form = (h->variant & 0xff) != 1 && uni_lane_ok(m);
+        if (!h->w_s1.reserve(cap * (lane_form ? 4 : 16) + 64)) return false;
     } else {
         const size_t bm_words = (cap >> 5) + (size_t)ndocs + 4;
         if (!h->w_s1.reserve((6 * cap + 32 * (size_t)ndocs + 64) * 16) || !h->w_s2.reserve(std::max(cap * 4, 2 * bm_words * 4) + ((size_t)ndocs + 16) * 4) ||
@@ -292,7 +295,8 @@ int run_device(Handle *h, const char *d_text, const int64_t *d_doc_off, int64_t 
             sg.arcs = h->w_s1.as<SegArc>(); sg.tos = h->w_s2.as<int32_t>(); sg.idsv = h->w_s3.as<int32_t>(); sg.inter = h->w_s4.as<uint8_t>();
         }
         sg.narcs = h->w_narcs.as<int32_t>(); sg.next_doc = next_doc; sg.trie_depth = m.trie_max_depth; sg.variant = h->variant & 0xff; sg.tune = (h->variant >> 8) & 0xff; sg.tune2 = (h->variant >> 16) & 0xff;
-        if (m.kind == KIND_UNIGRAM && sg.variant != 1 && m.trie_max_depth > 0 && m.trie_max_depth <= 4096) first = h->w_narcs.as<int32_t>();
+        sg.lane_ok = uni_lane_ok(m) ? 1 : 0;
+        if (m.kind == KIND_UNIGRAM && sg.variant != 1 && sg.lane_ok) first = h->w_narcs.as<int32_t>();
         sg.perm = h->w_perm.as<int32_t>(); sg.hist = h->w_hist.as<unsigned int>();
         if (ndocs > 0) launch_seg_sp(sg, s);
         (void)hipEventRecord(h->ev[EV_TOK], s);

@@ -81,6 +81,7 @@ struct SpSegParams {
     int32_t *perm; unsigned int *hist;
     int32_t *narcs;             // [ndocs] BPE arc count per document (-1 = capacity exceeded); Unigram: first id index within the slot
     int trie_depth;             // longest dictionary entry (bounds every arc length)
+    int lane_ok;                // Unigram: the model fits the lane program (bf_seg.h UniLane: entries <= 32 symbols, ids < 2^20 - 2)
     int64_t bm_words;           // BPE apply: words per bitmap (the two bitmaps live in the `tos` buffer)
     int32_t *fb_list; unsigned int *fb_count;   // BPE: documents k_bpe_fused hands to the full path (set by launch_seg_sp)
     int variant;

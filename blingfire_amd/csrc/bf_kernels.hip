@@ -533,7 +533,7 @@ void launch_lex_wp(const WpLexParams &p, int variant, hipStream_t s)
     } else {
         WpLexParams q = p;
         q.ev_thresh = (variant >> 8) & 0xff; if (q.ev_thresh == 0) q.ev_thresh = 32;
-        q.fetch_thresh = (variant >> 16) & 0xff; if (q.fetch_thresh == 0) q.fetch_thresh = 8;
+        q.fetch_thresh = (variant >> 16) & 0xf; if (q.fetch_thresh == 0) q.fetch_thresh = 8;      // bits 20..23: transitions per vote (two-level form)
         q.acts_n = p.acts_n;                                          // <= 4096 ints, checked at LoadModel
         int waves_per_cu = (variant >> 24) & 0x3f;
         if (waves_per_cu == 0) {                                      // persistent: exactly the resident waves
@@ -569,18 +569,24 @@ void launch_lex_wp(const WpLexParams &p, int variant, hipStream_t s)
             if (((variant >> 8) & 0xff) == 0) q2.ev_thresh = 16;
             const size_t lds2 = lex_lds_bytes(q2, 64);
             int per_cu = 0;
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_lex_wp_flat<64, ClsWin, false, 3, false, false, true>, 64, lds2) != hipSuccess || per_cu <= 0) per_cu = 16;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_lex_wp_flat<64, ClsWin, false, 4, false, false, true>, 64, lds2) != hipSuccess || per_cu <= 0) per_cu = 16;
             (void)hipGetLastError();
             if (((variant >> 24) & 0x3f) != 0) per_cu = (variant >> 24) & 0x3f;
             int64_t nb = (int64_t)device_cus() * per_cu;
             if (nb > need) nb = need;
             if (nb < 1) nb = 1;
             const dim3 g2((unsigned)nb), t2(64);
+            // transitions per vote: swept on MI355X with the two-level event code (2: 8.50 ms, 3: 7.67, 4: 6.86 on the 1.25 M-doc shard);
+            // bits 20..23 of the variant select 5..8 for experiments
+            const int un = ((variant >> 20) & 0xf) ? ((variant >> 20) & 0xf) : (usel == 1 ? 1 : usel == 2 ? 2 : usel == 3 ? 4 : 4);
             if (has_any) hipLaunchKernelGGL((k_lex_wp_flat<64, ClsWin, true, 1, false, false, true>), g2, t2, lds2, s, q2);
-            else if (usel == 2) hipLaunchKernelGGL((k_lex_wp_flat<64, ClsWin, false, 2, false, false, true>), g2, t2, lds2, s, q2);
-            else if (usel == 3) hipLaunchKernelGGL((k_lex_wp_flat<64, ClsWin, false, 4, false, false, true>), g2, t2, lds2, s, q2);
-            else if (usel == 1) hipLaunchKernelGGL((k_lex_wp_flat<64, ClsWin, false, 1, false, false, true>), g2, t2, lds2, s, q2);
-            else hipLaunchKernelGGL((k_lex_wp_flat<64, ClsWin, false, 3, false, false, true>), g2, t2, lds2, s, q2);
+            else if (un == 1) hipLaunchKernelGGL((k_lex_wp_flat<64, ClsWin, false, 1, false, false, true>), g2, t2, lds2, s, q2);
+            else if (un == 2) hipLaunchKernelGGL((k_lex_wp_flat<64, ClsWin, false, 2, false, false, true>), g2, t2, lds2, s, q2);
+            else if (un == 3) hipLaunchKernelGGL((k_lex_wp_flat<64, ClsWin, false, 3, false, false, true>), g2, t2, lds2, s, q2);
+            else if (un == 5) hipLaunchKernelGGL((k_lex_wp_flat<64, ClsWin, false, 5, false, false, true>), g2, t2, lds2, s, q2);
+            else if (un == 6) hipLaunchKernelGGL((k_lex_wp_flat<64, ClsWin, false, 6, false, false, true>), g2, t2, lds2, s, q2);
+            else if (un == 8) hipLaunchKernelGGL((k_lex_wp_flat<64, ClsWin, false, 8, false, false, true>), g2, t2, lds2, s, q2);
+            else hipLaunchKernelGGL((k_lex_wp_flat<64, ClsWin, false, 4, false, false, true>), g2, t2, lds2, s, q2);
             return;
         }
         const dim3 g((unsigned)blocks), t(64); const size_t lds = lex_lds_bytes(q, 64);
@@ -803,108 +809,6 @@ __global__ __launch_bounds__(64) void k_seg_unigram(SpSegParams p)
     ClsWin cls_at; cls_at.init(p.stream, slot);
     IdOutDirect out{p.ids_tmp + slot, p.span_tmp ? p.span_tmp + 2 * slot : nullptr};
     p.counts[d] = seg_unigram_doc(p.S, cls_at, p.lens[d], p.best + slot, out, p.max_ids, p.unk);
-}
-
-// Unigram-LM, divergence-aware form (default): persistent lanes pull documents (longest first) from a counter;
-// every loop trip a lane makes ONE micro-step -- a trie transition with its AddArc / AddUnknownArc, or one hop of
-// the backward pass -- so walks of different lengths and documents of different sizes do not idle the wave.
-// Per-document order of operations is exactly seg_unigram_doc's.  Best-arc entries are initialised lazily,
-// `depth` positions ahead of the current start (an arc from `start` ends before start + depth); ids are written
-// right-aligned in the document's slot during the single backward pass (first[d] = index of the first one).
-__global__ __launch_bounds__(64) void k_seg_unigram_flat(SpSegParams p)
-{
-    enum { M_NEED = 0, M_WALK = 1, M_BACK = 2, M_EXIT = 3 };
-    const double neg_flt_max = -3.40282346638528859811704183484516925e+38;
-    const int depth = p.trie_depth;
-    int mode = M_NEED;
-    int64_t doc = 0; SegBest *best = nullptr; int32_t *ids = nullptr; int32_t *spans = nullptr;
-    ClsWin cls_at; cls_at.init(p.stream, 0);
-    int L = 0, cap = 0, start = 0, i = 0, sum = 0, cnt = 0, end = 0, pb_begin = -1, pb_id = 0;
-    uint32_t state = 0; bool unknown = true; double prev = 0;
-    for (unsigned long long trip = 0; trip < (1ull << 34); ++trip) {
-        const unsigned long long m_need = __ballot(mode == M_NEED);
-        if (m_need) {
-            const unsigned long long m_busy = __ballot(mode == M_WALK || mode == M_BACK);
-            if (__popcll(m_need) >= 8 || m_busy == 0) {
-                if (mode == M_NEED) {
-                    const int c = __popcll(m_need);
-                    const int leader = __ffsll((long long)m_need) - 1;
-                    unsigned long long base = 0;
-                    if (lane_id() == leader) base = atomicAdd(p.next_doc, (unsigned long long)c);
-                    base = __shfl(base, leader, 64);
-                    const int64_t idx = (int64_t)base + __popcll(m_need & lanemask_lt());
-                    if (idx >= p.b.ndocs) mode = M_EXIT;
-                    else {
-                        doc = p.perm[idx];
-                        const int64_t b = p.b.doc_off[doc];
-                        const int64_t slot = sp_slot(b, doc, p.slot_mul);
-                        cap = p.slot_mul * (int)(p.b.doc_off[doc + 1] - b + 1);
-                        L = p.lens[doc];
-                        best = p.best + slot; ids = p.ids_tmp + slot; spans = p.span_tmp ? p.span_tmp + 2 * slot : nullptr; cls_at.init(p.stream, slot);
-                        if (L <= 0) { p.counts[doc] = 0; p.narcs[doc] = 0; }
-                        else {
-                            SegBest z; z.score = neg_flt_max; z.begin = -1; z.id = -1;
-                            const int n0 = depth < L ? depth : L;
-                            for (int k = 0; k < n0; ++k) best[k] = z;
-                            start = 0; i = 0; state = p.S.initial; sum = 0; unknown = true; prev = 0; pb_begin = -1; pb_id = 0;
-                            mode = M_WALK;
-                        }
-                    }
-                }
-                if (__ballot(mode != M_EXIT) == 0) break;
-            }
-        }
-        if (mode == M_WALK) {
-            const uint64_t e = sg_lookup(p.S, state, cls_at(i));
-            bool walk_ends = e == SG_MISS;
-            if (!walk_ends) {
-                state = (uint32_t)((e >> SG_NEXT_SHIFT) & SG_NEXT_MASK);
-                sum += (int)(e >> SG_OW_SHIFT);
-                if (e & SG_FINAL) {                                     // AddArc
-                    const SegInfo r = p.S.info[sum];
-                    const double cand = sg_bits_to_float(r.score_bits) + prev;
-                    SegBest bb = best[i];
-                    if (bb.score < cand) { bb.begin = start; bb.id = r.id; bb.score = cand; best[i] = bb; }
-                    unknown = false;
-                }
-                ++i;
-                walk_ends = i >= L;
-            }
-            if (walk_ends) {
-                if (unknown) {                                          // AddUnknownArc
-                    const float unk_score = -100000.0f;
-                    const double cand = unk_score + prev;
-                    SegBest bb = best[start];
-                    if (bb.score < cand) {
-                        bb.begin = start;
-                        if (0 < start && -1 == pb_id) bb.begin = pb_begin;
-                        bb.id = -1; bb.score = cand; best[start] = bb;
-                    }
-                }
-                ++start;
-                if (start < L) {
-                    const SegBest pb = best[start - 1];
-                    prev = pb.score; pb_begin = pb.begin; pb_id = pb.id;
-                    const int fresh = start + depth - 1;                 // enters the reach of this start
-                    if (fresh < L) { SegBest z; z.score = neg_flt_max; z.begin = -1; z.id = -1; best[fresh] = z; }
-                    i = start; state = p.S.initial; sum = 0; unknown = true;
-                } else { mode = M_BACK; end = L - 1; cnt = 0; }
-            }
-        } else if (mode == M_BACK) {
-            const SegBest bb = best[end];
-            const int id = bb.id != -1 ? bb.id : p.unk;
-            ids[cap - 1 - cnt] = id + p.S.id_offset;
-            if (spans) { spans[2 * (cap - 1 - cnt)] = bb.begin; spans[2 * (cap - 1 - cnt) + 1] = end; }
-            ++cnt;
-            end = bb.begin - 1;
-            if (end < 0) {
-                p.counts[doc] = cnt < p.max_ids ? cnt : p.max_ids;
-                p.narcs[doc] = cap - cnt;
-                mode = M_NEED;
-            }
-        }
-    }
-    if (mode != M_EXIT) atomicOr(p.status, 2);      // trip limit hit: never expected
 }
 
 // BPE phase A: collect arcs, one document per lane
@@ -1429,109 +1333,6 @@ __global__ __launch_bounds__(64) void k_bpe_fused(SpSegParams p)
     if (mode != M_EXIT) atomicOr(p.status, 2);      // trip limit hit: never expected
 }
 
-// Unigram-LM with the Viterbi scores of the active window in LDS.  An arc from `start` ends before start + depth
-// (depth = longest dictionary entry, 16 for every shipped Unigram model), so only `depth` End2BestArc scores are
-// live at a time: they sit in a per-lane LDS ring of doubles (structure-of-arrays, ring >= depth, power of two) and
-// the relaxation of an arc -- the dependent tail of every final transition -- costs an LDS read / compare / write
-// instead of a 16-byte global load + store.  {begin, id} of a position go to global memory only when its score
-// improves (8-byte store, nothing waits for it) and are read back by the single backward pass.  A position that
-// leaves the window without any incoming arc gets the reference's sentinel {-1, -1} (..._1best_t.h:61-77,241-265).
-__global__ __launch_bounds__(64) void k_seg_unigram_ring(SpSegParams p, int ring)
-{
-    extern __shared__ double seg_ring[];            // [ring][64]
-    enum { M_NEED = 0, M_WALK = 1, M_BACK = 2, M_EXIT = 3 };
-    const double neg_flt_max = -3.40282346638528859811704183484516925e+38;
-    const int depth = p.trie_depth, mask = ring - 1, lane = lane_id();
-    double *my = seg_ring + lane;
-    int mode = M_NEED;
-    int64_t doc = 0; SegBI *bi = nullptr; int32_t *ids = nullptr; int32_t *spans = nullptr;
-    ClsWin cls_at; cls_at.init(p.stream, 0);
-    int L = 0, cap = 0, start = 0, i = 0, sum = 0, cnt = 0, end = 0;
-    uint32_t state = 0; bool unknown = true; double prev = 0;
-    for (unsigned long long trip = 0; trip < (1ull << 34); ++trip) {
-        const unsigned long long m_need = __ballot(mode == M_NEED);
-        if (m_need) {
-            const unsigned long long m_busy = __ballot(mode == M_WALK || mode == M_BACK);
-            if (__popcll(m_need) >= 8 || m_busy == 0) {
-                if (mode == M_NEED) {
-                    const int c = __popcll(m_need);
-                    const int leader = __ffsll((long long)m_need) - 1;
-                    unsigned long long base = 0;
-                    if (lane == leader) base = atomicAdd(p.next_doc, (unsigned long long)c);
-                    base = __shfl(base, leader, 64);
-                    const int64_t idx = (int64_t)base + __popcll(m_need & lanemask_lt());
-                    if (idx >= p.b.ndocs) mode = M_EXIT;
-                    else {
-                        doc = p.perm[idx];
-                        const int64_t b = p.b.doc_off[doc];
-                        const int64_t slot = sp_slot(b, doc, p.slot_mul);
-                        cap = p.slot_mul * (int)(p.b.doc_off[doc + 1] - b + 1);
-                        L = p.lens[doc];
-                        bi = (SegBI *)(p.best + slot); ids = p.ids_tmp + slot; spans = p.span_tmp ? p.span_tmp + 2 * slot : nullptr; cls_at.init(p.stream, slot);
-                        if (L <= 0) { p.counts[doc] = 0; p.narcs[doc] = 0; }
-                        else {
-                            for (int k = 0; k < ring; ++k) my[k * 64] = neg_flt_max;
-                            start = 0; i = 0; state = p.S.initial; sum = 0; unknown = true; prev = 0;
-                            mode = M_WALK;
-                        }
-                    }
-                }
-                if (__ballot(mode != M_EXIT) == 0) break;
-            }
-        }
-        if (mode == M_WALK) {
-            const uint64_t e = sg_lookup(p.S, state, cls_at(i));
-            bool walk_ends = e == SG_MISS;
-            if (!walk_ends) {
-                state = (uint32_t)((e >> SG_NEXT_SHIFT) & SG_NEXT_MASK);
-                sum += (int)(e >> SG_OW_SHIFT);
-                if (e & SG_FINAL) {                                     // AddArc (..._1best_t.h:118-142)
-                    const SegInfo r = p.S.info[sum];
-                    const double cand = sg_bits_to_float(r.score_bits) + prev;
-                    double *q = my + (i & mask) * 64;
-                    if (*q < cand) { *q = cand; SegBI v; v.begin = start; v.id = r.id; bi[i] = v; }
-                    unknown = false;
-                }
-                ++i;
-                walk_ends = i >= L;
-            }
-            if (walk_ends) {
-                double *q = my + (start & mask) * 64;
-                double fin = *q;
-                if (unknown) {                                          // AddUnknownArc (..._1best_t.h:145-171)
-                    const float unk_score = -100000.0f;
-                    const double cand = unk_score + prev;
-                    if (fin < cand) {
-                        SegBI v; v.begin = start; v.id = -1;
-                        if (0 < start) { const SegBI pb = bi[start - 1]; if (-1 == pb.id) v.begin = pb.begin; }
-                        bi[start] = v; fin = cand;
-                    }
-                }
-                if (!(neg_flt_max < fin)) { SegBI z; z.begin = -1; z.id = -1; bi[start] = z; }      // no incoming arc at all
-                ++start;
-                if (start < L) {
-                    prev = fin;                                          // End2BestArc[start - 1] is final by now
-                    my[((start + depth - 1) & mask) * 64] = neg_flt_max; // the position that enters the reach of this start
-                    i = start; state = p.S.initial; sum = 0; unknown = true;
-                } else { mode = M_BACK; end = L - 1; cnt = 0; }
-            }
-        } else if (mode == M_BACK) {
-            const SegBI bb = bi[end];
-            const int id = bb.id != -1 ? bb.id : p.unk;
-            ids[cap - 1 - cnt] = id + p.S.id_offset;
-            if (spans) { spans[2 * (cap - 1 - cnt)] = bb.begin; spans[2 * (cap - 1 - cnt) + 1] = end; }
-            ++cnt;
-            end = bb.begin - 1;
-            if (end < 0) {
-                p.counts[doc] = cnt < p.max_ids ? cnt : p.max_ids;
-                p.narcs[doc] = cap - cnt;
-                mode = M_NEED;
-            }
-        }
-    }
-    if (mode != M_EXIT) atomicOr(p.status, 2);      // trip limit hit: never expected
-}
-
 // 32-byte register window (two aligned 16-byte blocks) over a lane's class stream, positioned by seek(start): the walk from
 // `start` reads start .. start + depth - 1 and then jumps back to start + 1, so a window that follows `start` serves almost
 // every read from registers; seek() shifts it by one block when `start` crosses a block (one load, nothing waits for it).
@@ -1561,12 +1362,13 @@ struct ClsWin2 {
     }
 };
 
-// Viterbi scores of the live window: per-lane ring of doubles in LDS, structure-of-arrays (bank pair = lane)
+// End2BestArc entries of the live window: per-lane rings in LDS, structure-of-arrays (scores: bank pair = lane; records: bank = lane)
 struct RingLds {
-    double *my; int mask, n;
-    __device__ __forceinline__ double get(int pos) const { return my[(pos & mask) * 64]; }
-    __device__ __forceinline__ void set(int pos, double v) { my[(pos & mask) * 64] = v; }
-    __device__ __forceinline__ void fill(double v) { for (int k = 0; k < n; ++k) my[k * 64] = v; }
+    double *sc; uint32_t *rc; int mask, n;
+    __device__ __forceinline__ double score(int pos) const { return sc[(pos & mask) * 64]; }
+    __device__ __forceinline__ uint32_t rec(int pos) const { return rc[(pos & mask) * 64]; }
+    __device__ __forceinline__ void set(int pos, double v, uint32_t r) { sc[(pos & mask) * 64] = v; rc[(pos & mask) * 64] = r; }
+    __device__ __forceinline__ void fill(double v) { for (int k = 0; k < n; ++k) { sc[k * 64] = v; rc[k * 64] = UNI_REC_NONE; } }
 };
 
 // Unigram-LM, default form: bf_seg.h UniLane per lane, persistent lanes pulling documents (longest first).  Every trip of
@@ -1575,14 +1377,14 @@ struct RingLds {
 template <int UNROLL>
 __global__ __launch_bounds__(64) void k_seg_unigram_lane(SpSegParams p, int ring_n)
 {
-    extern __shared__ double seg_ring[];            // [ring_n][64]
+    extern __shared__ double seg_ring[];            // [ring_n][64] scores, then [ring_n][64] packed records
     enum { M_NEED = 0, M_WALK = 1, M_BACK = 2, M_EXIT = 3 };
     const int lane = lane_id();
-    RingLds ring{seg_ring + lane, ring_n - 1, ring_n};
+    RingLds ring{seg_ring + lane, (uint32_t *)(seg_ring + (size_t)ring_n * 64) + lane, ring_n - 1, ring_n};
     ClsWin2 cls_at; cls_at.init(p.stream, 0);
     UniLane<ClsWin2, RingLds> ul(p.S, cls_at, ring);
     ul.L = 0; ul.depth = p.trie_depth; ul.start = ul.i = ul.sum = 0; ul.state = 0; ul.unknown = true; ul.pend = false; ul.prev = 0; ul.pend_i = 0;
-    ul.pend_r.id = 0; ul.pend_r.score_bits = 0; ul.end = 0; ul.cnt = 0;
+    ul.pend_r.id = 0; ul.pend_r.score_bits = 0; ul.end = 0; ul.cnt = 0; ul.unk_run = 0; ul.q0 = ul.q1 = ul.q2 = ul.q3 = 0; ul.qn = 0; ul.abs0 = 0;
     int mode = M_NEED;
     int64_t doc = 0; int32_t *ids = nullptr; int32_t *spans = nullptr; int cap = 0;
     for (unsigned long long trip = 0; trip < (1ull << 34); ++trip) {
@@ -1607,16 +1409,16 @@ __global__ __launch_bounds__(64) void k_seg_unigram_lane(SpSegParams p, int ring
                         const int L = p.lens[doc];
                         ids = p.ids_tmp + slot; spans = p.span_tmp ? p.span_tmp + 2 * slot : nullptr;
                         if (L <= 0) { p.counts[doc] = 0; p.narcs[doc] = 0; }
-                        else { cls_at.init(p.stream, slot); ul.init(L, p.trie_depth, (SegBI *)p.best + slot); mode = M_WALK; }
+                        else { cls_at.init(p.stream, slot); ul.init(L, p.trie_depth, (uint32_t *)p.best + slot, slot); mode = M_WALK; }
                     }
                 }
                 if (__ballot(mode != M_EXIT) == 0) break;
             }
         }
         // ---- backward pass: request this trip's record now, use it after the walk steps
-        SegBI bb; bb.begin = 0; bb.id = 0;
+        uint32_t br = 0;
         const bool back = mode == M_BACK;
-        if (back) bb = ul.bi[ul.end];
+        if (back) br = ul.recs[ul.end];
         // ---- forward pass: UNROLL trie transitions
         if (mode == M_WALK) {
             bool walk = true;
@@ -1629,7 +1431,7 @@ __global__ __launch_bounds__(64) void k_seg_unigram_lane(SpSegParams p, int ring
                 ids[cap - 1 - k] = id;
                 if (spans) { spans[2 * (cap - 1 - k)] = from; spans[2 * (cap - 1 - k) + 1] = to; }
             };
-            if (!ul.bstep(bb, put, p.unk)) {
+            if (!ul.bstep(br, put, p.unk)) {
                 p.counts[doc] = ul.cnt < p.max_ids ? ul.cnt : p.max_ids;
                 p.narcs[doc] = cap - ul.cnt;
                 mode = M_NEED;
@@ -1649,31 +1451,24 @@ void launch_seg_sp(const SpSegParams &p_in, hipStream_t s)
     hipLaunchKernelGGL(k_sp_hist_scan, dim3(1), dim3(1024), 0, s, p);
     hipLaunchKernelGGL(k_sp_scatter, dim3(bsort), dim3(256), 0, s, p);
     if (p.S.kind == SG_KIND_UNIGRAM) {
-        if (p.variant == 1 || p.trie_depth <= 0 || p.trie_depth > 4096) hipLaunchKernelGGL(k_seg_unigram, dim3(b64), dim3(64), 0, s, p);
-        else if (p.variant != 2 && p.trie_depth <= 32) {
+        // sequential form (experiments, and models outside the lane program's limits: entries longer than 32 symbols or ids >= 2^20 - 2)
+        if (p.variant == 1 || !p.lane_ok) hipLaunchKernelGGL(k_seg_unigram, dim3(b64), dim3(64), 0, s, p);
+        else {
             int ring = 1; while (ring < p.trie_depth) ring <<= 1;
-            const size_t lds = (size_t)ring * 64 * sizeof(double);
+            const size_t lds = (size_t)ring * 64 * (sizeof(double) + sizeof(uint32_t));
             int per_cu = 0;
             const int unroll = p.tune ? p.tune : 3;
-            auto kern = p.variant == 6 ? (const void *)k_seg_unigram_ring : unroll == 1 ? (const void *)k_seg_unigram_lane<1> : unroll == 2 ? (const void *)k_seg_unigram_lane<2> :
+            auto kern = unroll == 1 ? (const void *)k_seg_unigram_lane<1> : unroll == 2 ? (const void *)k_seg_unigram_lane<2> :
                         unroll == 4 ? (const void *)k_seg_unigram_lane<4> : (const void *)k_seg_unigram_lane<3>;
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 64, lds) != hipSuccess || per_cu <= 0) per_cu = 8;
             (void)hipGetLastError();
             if (p.tune2 > 0 && p.tune2 < per_cu) per_cu = p.tune2;
             unsigned blocks = (unsigned)device_cus() * (unsigned)per_cu;
             if ((int64_t)blocks > (int64_t)b64) blocks = b64;
-            if (p.variant == 6) hipLaunchKernelGGL(k_seg_unigram_ring, dim3(blocks), dim3(64), lds, s, p, ring);   // round-1 kernel (A/B)
-            else if (unroll == 1) hipLaunchKernelGGL(k_seg_unigram_lane<1>, dim3(blocks), dim3(64), lds, s, p, ring);
+            if (unroll == 1) hipLaunchKernelGGL(k_seg_unigram_lane<1>, dim3(blocks), dim3(64), lds, s, p, ring);
             else if (unroll == 2) hipLaunchKernelGGL(k_seg_unigram_lane<2>, dim3(blocks), dim3(64), lds, s, p, ring);
             else if (unroll == 4) hipLaunchKernelGGL(k_seg_unigram_lane<4>, dim3(blocks), dim3(64), lds, s, p, ring);
             else hipLaunchKernelGGL(k_seg_unigram_lane<3>, dim3(blocks), dim3(64), lds, s, p, ring);
-        } else {
-            int per_cu = 0;
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_seg_unigram_flat, 64, 0) != hipSuccess || per_cu <= 0) per_cu = 16;
-            (void)hipGetLastError();
-            unsigned blocks = (unsigned)device_cus() * (unsigned)per_cu;
-            if ((int64_t)blocks > (int64_t)b64) blocks = b64;
-            hipLaunchKernelGGL(k_seg_unigram_flat, dim3(blocks), dim3(64), 0, s, p);
         }
     } else {
         SpSegParams p = p_in;

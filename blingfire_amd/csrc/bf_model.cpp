@@ -766,6 +766,8 @@ bool build_model(Model &m, const uint8_t *img, size_t size)
             int v[2] = {0, 0}; int c = info.get(info.min_key + (int)k, v, 2);
             if (c < 1 || c > 2) continue;
             m.i2info_id[k] = v[0]; m.i2info_score[k] = (uint32_t)v[1]; m.i2info_valid[k] = (uint8_t)c;
+            if (v[0] > m.max_info_id) m.max_info_id = v[0];
+            if (v[0] < -1) m.max_info_id = 0x7fffffff;            // negative ids: outside the packed record format
         }
         // general form of the same rows + the K2I array, for the key -> info lookup (FADictInterpreter_t::GetInfo)
         m.info_stride = info.max_count + 1; m.info_min_key = info.min_key;

@@ -136,6 +136,7 @@ struct Model {
     TwoLevelMap dict_charmap; std::vector<int32_t> dict_norm_pool; bool dict_has_charmap = false;
     TwoLevelMap dict_clsmap;           // code point (or byte) -> class of the dictionary alphabet, CLS_NONE_W if absent
     int trie_max_depth = 0;            // longest path from the initial state (bounds every arc length)
+    int max_info_id = 0;               // largest token id in I2Info (the Unigram lane program packs id + 1 into 20 bits)
     // ---- key -> info lookup over the same [pos-dict] (reference FADictInterpreter_t.h:334-390; additive DictGetInfoBatch)
     int dict_direction = 0;            // PARAM_DIRECTION: 0 = l2r (FAFsmConst.h DIR_L2R); else keys are normalised and reversed
     std::vector<int32_t> k2i;          // K2I array, decoded (reference FAArray_pack.cpp:27-95): MPH index -> info id

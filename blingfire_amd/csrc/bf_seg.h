@@ -111,32 +111,44 @@ BF_HD int seg_unigram_doc(const SegTables &S, ClsAt &cls_at, int L, SegBest *bes
 // runs the same code on the host).  Same per-document order of operations as seg_unigram_doc above, cut into
 //   wstep()  one trie transition of the forward pass (AddArc / AddUnknownArc / next start absorbed), and
 //   bstep()  one hop of the backward pass,
-// with two changes of *mechanism* that keep every value identical:
-//  * only `depth` End2BestArc scores are live at a time (an arc from `start` ends before start + depth, depth = longest
-//    dictionary entry): they sit in a ring (LDS on the device); {begin, id} go to memory only when a score improves;
+// with changes of *mechanism* that keep every value identical:
+//  * only `depth` End2BestArc entries are live at a time (an arc from `start` ends before start + depth, depth = longest
+//    dictionary entry): score AND {begin, id} sit in a ring (LDS on the device).  An entry is final when `start` moves past its
+//    position -- it is then written to memory ONCE, packed into 32 bits, four positions per 16-byte store (measured on MI355X:
+//    8-byte records stored on every improvement cost 12.5 GB of write traffic per 0.3 GB of text and evicted the tables from L2);
 //  * the relaxation of a final transition is DEFERRED by one step: the I2Info row is requested when the transition is taken
 //    and consumed at the beginning of the next step, behind the issue of that step's trie gather -- the two dependent
 //    gathers of a final transition overlap instead of adding up.  Relaxations still happen in arc order, and the pending one
 //    is flushed before anything reads the score it may change (the end of the walk from `start` reads position `start`).
+// Packed record of a position: [len - 1 : 12 | id + 1 : 20], len = position - begin + 1; id + 1 == 0 is the unknown arc (id -1);
+// a length field of 4095 means "4096 or more" -- only possible for a merged run of unknown positions, every position of which
+// carries the run's begin, so the backward pass hops 4095 positions back and adds up (bstep_len); 0xFFFFFFFF = no incoming arc
+// (the reference's {-1, -1} sentinel).  Needs ids below 2^20 - 2 (checked at load; other models use the sequential form).
 // ---------------------------------------------------------------------------------------------------
-struct SegBI { int32_t begin, id; };                  // {begin, id} of one End2BestArc entry
+constexpr uint32_t UNI_REC_NONE = 0xFFFFFFFFu, UNI_LEN_MAX = 4095u;
+constexpr int UNI_MAX_ID = (1 << 20) - 3;
+BF_HD uint32_t uni_rec(int id, int len) { const uint32_t l = (uint32_t)(len - 1); return ((uint32_t)(id + 1) & 0xFFFFFu) | ((l < UNI_LEN_MAX ? l : UNI_LEN_MAX) << 20); }
 
 template <class ClsAt, class Ring>
 struct UniLane {
-    const SegTables &S; ClsAt &cls_at; Ring &ring; SegBI *bi;
+    const SegTables &S; ClsAt &cls_at; Ring &ring; uint32_t *recs;
     int L, depth, start, i, sum; uint32_t state; bool unknown, pend; double prev; SegInfo pend_r; int pend_i;
+    int unk_run;                                       // length of the unknown run that ends at start - 1 (0: that position is not unknown)
+    uint32_t q0, q1, q2, q3; int qn;                   // final records of the last positions, not yet stored (qn of them, q3 newest)
+    int64_t abs0;                                      // absolute element index of position 0 (16-byte store groups are aligned on it)
     int end, cnt;                                      // backward pass
 
-    BF_HD UniLane(const SegTables &S_, ClsAt &c, Ring &r) : S(S_), cls_at(c), ring(r), bi(nullptr) {}
+    BF_HD UniLane(const SegTables &S_, ClsAt &c, Ring &r) : S(S_), cls_at(c), ring(r), recs(nullptr) {}
 
     static BF_HD double neg_flt_max() { return -3.40282346638528859811704183484516925e+38; }   // (double)-FLT_MAX
 
-    // Start a document of L >= 1 stream elements; bi_ has room for L entries.
-    BF_HD void init(int L_, int depth_, SegBI *bi_)
+    // Start a document of L >= 1 stream elements; recs_ has room for L records and is element abs0_ of a 16-byte aligned array.
+    BF_HD void init(int L_, int depth_, uint32_t *recs_, int64_t abs0_)
     {
-        L = L_; depth = depth_; bi = bi_;
+        L = L_; depth = depth_; recs = recs_; abs0 = abs0_;
         ring.fill(neg_flt_max());
         start = 0; i = 0; state = S.initial; sum = 0; unknown = true; prev = 0; pend = false; pend_i = 0; pend_r.id = 0; pend_r.score_bits = 0;
+        unk_run = 0; q0 = q1 = q2 = q3 = 0; qn = 0;
         end = 0; cnt = 0;
         cls_at.seek(0);
     }
@@ -144,8 +156,30 @@ struct UniLane {
     BF_HD void relax()                                 // AddArc (..._1best_t.h:118-142) of the pending final transition
     {
         const double cand = sg_bits_to_float(pend_r.score_bits) + prev;
-        if (ring.get(pend_i) < cand) { ring.set(pend_i, cand); SegBI v; v.begin = start; v.id = pend_r.id; bi[pend_i] = v; }
+        if (ring.score(pend_i) < cand) ring.set(pend_i, cand, uni_rec(pend_r.id, pend_i - start + 1));
         pend = false;
+    }
+
+    // the record of position p (= start) is final: queue it, store whole aligned groups of four
+    BF_HD void finalize(int p, uint32_t r)
+    {
+        q0 = q1; q1 = q2; q2 = q3; q3 = r; ++qn;
+        const int64_t a = abs0 + p;
+        if ((a & 3) == 3 || p == L - 1) {
+            if (qn == 4 && (a & 3) == 3) {
+#if defined(__HIP_DEVICE_COMPILE__)
+                *(uint4 *)(recs + (p - 3)) = make_uint4(q0, q1, q2, q3);
+#else
+                recs[p - 3] = q0; recs[p - 2] = q1; recs[p - 1] = q2; recs[p] = q3;
+#endif
+            } else {                                   // a group that the document only partly owns (its first / last positions)
+                if (qn > 3) recs[p - 3] = q0;
+                if (qn > 2) recs[p - 2] = q1;
+                if (qn > 1) recs[p - 1] = q2;
+                recs[p] = q3;
+            }
+            qn = 0;
+        }
     }
 
     // One trie transition.  Returns false once the forward pass is complete (follow with begin_back / bstep).
@@ -166,21 +200,24 @@ struct UniLane {
         }
         if (ends) {
             if (pend) relax();                                          // only when the arc that ends the document is the last of its walk
-            double fin = ring.get(start);
+            double fin = ring.score(start);
+            uint32_t r = ring.rec(start);
+            int run = 0;
             if (unknown) {                                              // AddUnknownArc (..._1best_t.h:145-171)
                 const float unk_score = -100000.0f;
                 const double cand = unk_score + prev;
-                if (fin < cand) {
-                    SegBI v; v.begin = start; v.id = -1;
-                    if (0 < start) { const SegBI pb = bi[start - 1]; if (-1 == pb.id) v.begin = pb.begin; }
-                    bi[start] = v; fin = cand;
+                if (fin < cand) {                                       // begin = start, or the begin of the unknown arc that ends just before
+                    run = unk_run + 1;
+                    r = uni_rec(-1, run); fin = cand;
                 }
             }
-            if (!(neg_flt_max() < fin)) { SegBI z; z.begin = -1; z.id = -1; bi[start] = z; }      // no incoming arc at all (..._1best_t.h:61-77)
+            if (!(neg_flt_max() < fin)) r = UNI_REC_NONE;               // no incoming arc at all (..._1best_t.h:61-77)
+            unk_run = run;
+            finalize(start, r);
             ++start;
             if (!(start < L)) return false;
             prev = fin;                                                 // End2BestArc[start - 1] is final by now
-            ring.set(start + depth - 1, neg_flt_max());                 // the position that enters the reach of this start
+            ring.set(start + depth - 1, neg_flt_max(), UNI_REC_NONE);   // the position that enters the reach of this start
             i = start; state = S.initial; sum = 0; unknown = true;
             cls_at.seek(start);
         }
@@ -188,15 +225,25 @@ struct UniLane {
     }
 
     BF_HD void begin_back() { end = L - 1; cnt = 0; }
-    // One hop of the backward pass (..._1best_t.h:237-265) given bb = bi[end] (read by the caller, so that a GPU driver can
-    // request it early): id k-from-the-end goes to ids[cap - 1 - k].  Returns false after the last hop.
+    // One hop of the backward pass (..._1best_t.h:237-265) given r = recs[end] (read by the caller, so that a GPU driver can
+    // request it early): id k-from-the-end goes to put(k, ...).  Returns false after the last hop.
     template <class IdPut>
-    BF_HD bool bstep(const SegBI &bb, IdPut &put, int unk)
+    BF_HD bool bstep(uint32_t r, IdPut &put, int unk)
     {
-        const int id = bb.id != -1 ? bb.id : unk;
-        put(cnt, id + S.id_offset, bb.begin, end);
+        int id = -1, begin = -1;
+        if (r != UNI_REC_NONE) {
+            id = (int)(r & 0xFFFFFu) - 1;
+            int64_t len = (int64_t)(r >> 20) + 1;
+            if ((r >> 20) == UNI_LEN_MAX) {                             // a long unknown run: add up 4095-position hops
+                int e = end; uint32_t rr = r; len = 0;
+                while ((rr >> 20) == UNI_LEN_MAX && e - (int)UNI_LEN_MAX >= 0) { len += UNI_LEN_MAX; e -= (int)UNI_LEN_MAX; rr = recs[e]; }
+                len += (int64_t)(rr >> 20) + 1;
+            }
+            begin = (int)((int64_t)end - len + 1);
+        }
+        put(cnt, (id != -1 ? id : unk) + S.id_offset, begin, end);
         ++cnt;
-        end = bb.begin - 1;
+        end = begin - 1;
         return end >= 0;
     }
 };

@@ -272,23 +272,28 @@ static int emu_sp(const Model &m, const char *s, int n, int32_t *ids, int32_t *s
         // the default GPU form (bf_seg.h UniLane: score ring + deferred relaxation), driven sequentially
         if (L <= 0) return 0;
         struct HostRing {
-            std::vector<double> v; int mask;
-            double get(int pos) const { return v[(size_t)(pos & mask)]; }
-            void set(int pos, double x) { v[(size_t)(pos & mask)] = x; }
-            void fill(double x) { for (auto &e : v) e = x; }
+            std::vector<double> v; std::vector<uint32_t> r; int mask;
+            double score(int pos) const { return v[(size_t)(pos & mask)]; }
+            uint32_t rec(int pos) const { return r[(size_t)(pos & mask)]; }
+            void set(int pos, double x, uint32_t rr) { v[(size_t)(pos & mask)] = x; r[(size_t)(pos & mask)] = rr; }
+            void fill(double x) { for (auto &e : v) e = x; for (auto &e : r) e = UNI_REC_NONE; }
         };
         struct HostSeek { const uint16_t *cp; uint32_t operator()(int i) const { return cp[i]; } void seek(int) const {} };
         int ring_n = 1; while (ring_n < m.trie_max_depth) ring_n <<= 1;
-        HostRing ring{std::vector<double>((size_t)ring_n), ring_n - 1};
+        HostRing ring{std::vector<double>((size_t)ring_n), std::vector<uint32_t>((size_t)ring_n), ring_n - 1};
         HostSeek hs{cp};
-        std::vector<SegBI> bi((size_t)L);
+        // the record array starts at an arbitrary element of a 16-byte aligned array, like a document slot on the device
+        const int64_t abs0 = (int64_t)(n % 7);
+        std::vector<uint32_t> recs_all((size_t)L + 16, 0xDEADBEEFu);
+        uint32_t *recs = recs_all.data() + 8;
         UniLane<HostSeek, HostRing> ul(S, hs, ring);
-        ul.init(L, m.trie_max_depth, bi.data());
+        ul.init(L, m.trie_max_depth, recs, abs0);
         while (ul.wstep()) {}
+        if (recs_all[7] != 0xDEADBEEFu || recs_all[(size_t)L + 8] != 0xDEADBEEFu) return -3;     // a group store left the document's own range
         ul.begin_back();
         std::vector<int32_t> rid, rfrom, rto;              // ids in backward order, like the device's right-aligned slot
         auto put = [&](int, int id, int from, int to) { rid.push_back(id); rfrom.push_back(from); rto.push_back(to); };
-        for (;;) { const SegBI bb = bi[(size_t)ul.end]; if (!ul.bstep(bb, put, unk)) break; }
+        for (;;) { const uint32_t br = recs[(size_t)ul.end]; if (!ul.bstep(br, put, unk)) break; }
         const int cnt = (int)rid.size(), nout = cnt < max_ids ? cnt : max_ids;
         for (int k = 0; k < nout; ++k) { out.put(k, rid[(size_t)(cnt - 1 - k)]); out.span(k, rfrom[(size_t)(cnt - 1 - k)], rto[(size_t)(cnt - 1 - k)]); }
         out.finish(nout);

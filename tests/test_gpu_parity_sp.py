@@ -86,3 +86,24 @@ def test_no_dummy_prefix_switch(checker):
     finally:
         bf.free_model(h)
         checker.free(hck)
+
+
+@pytest.mark.parametrize("model", ["xlnet.bin", "xlm_roberta_base.bin", "laser500k.bin"])
+def test_long_unknown_runs(model, checker):
+    """unknown runs around and beyond the 4095-position limit of the packed Viterbi record (bf_seg.h uni_rec): escape hops in the
+    backward pass; also documents whose slots start at every alignment of the 16-byte record groups"""
+    if not bfutil.have_model(model):
+        pytest.skip("%s not present" % model)
+    docs = []
+    for n in (4094, 4095, 4096, 4097, 8191, 12290):
+        docs.append(("hello " + "\U000F0000" * n + " world " + "\U000F0000" * 3 + "x").encode("utf-8"))
+    for k in range(1, 40):
+        docs.append(("a" * k + " \U000F0000" * (k % 5) + " the end").encode("utf-8"))
+    h = bf.load_model(bfutil.model_path(model))
+    hck = checker.load(bfutil.model_path(model))
+    try:
+        _compare(h, checker, hck, docs, 8192, 3)
+        _compare(h, checker, hck, docs, 5, 0)
+    finally:
+        bf.free_model(h)
+        checker.free(hck)

@@ -83,3 +83,23 @@ def test_lane_programs_on_multilingual_corpus(ht, model, workload):
         assert c == gc and list(arr)[:c] == gbuf[:gc], (model, d, b[:80])
     ora.free(ho)
     ht.bft_free(h)
+
+
+@pytest.mark.parametrize("model", ["xlnet.bin", "xlm_roberta_base.bin", "laser100k.bin"])
+def test_unigram_long_unknown_runs(ht, model):
+    """merged unknown runs longer than the 12-bit length field of the packed End2BestArc record (bf_seg.h uni_rec): the backward pass
+    adds up 4095-position hops; lengths around the field's limit and its multiples, against the oracle"""
+    if not bfutil.have_model(model):
+        pytest.skip("%s not present" % model)
+    ora = bfutil.oracle()
+    h = ht.bft_load(bfutil.model_path(model).encode())
+    ho = ora.load(bfutil.model_path(model))
+    arr = (ctypes.c_int32 * 4096)()
+    for n in (4094, 4095, 4096, 4097, 8190, 8191, 8192, 12290):
+        for unk_char in ("", "\U000F0000"):
+            b = ("hello " + unk_char * n + " world " + unk_char * 3 + "x").encode("utf-8")
+            c = ht.bft_emu_text_to_ids(h, b, len(b), arr, 4096, 7)
+            gc, gbuf = ora.text_to_ids(ho, b, 4096, 7)
+            assert c == gc and list(arr)[:c] == gbuf[:gc], (model, n)
+    ora.free(ho)
+    ht.bft_free(h)
