@@ -646,13 +646,24 @@ __global__ __launch_bounds__(256) void k_prep_sp(SpPrepParams p)
             if (in) b0 = s[q];
             bool start = in; bool err = false; int cp = (int)b0;
             if (!p.use_bytes) {
-                if (q + 1 < n) b1 = s[q + 1];
-                if (q + 2 < n) b2 = s[q + 2];
-                if (q + 3 < n) b3 = s[q + 3];
+                // the three bytes on either side come from the neighbouring lanes (one byte load per lane instead of seven); only the
+                // lanes at the edges of the 64-byte window load theirs
+                b1 = __shfl_down(b0, 1, 64); b2 = __shfl_down(b0, 2, 64); b3 = __shfl_down(b0, 3, 64);
+                uint32_t u1 = __shfl_up(b0, 1, 64), u2 = __shfl_up(b0, 2, 64), u3 = __shfl_up(b0, 3, 64);
+                if (lane >= 61) {
+                    if (lane + 1 > 63) b1 = q + 1 < n ? s[q + 1] : 0u;
+                    if (lane + 2 > 63) b2 = q + 2 < n ? s[q + 2] : 0u;
+                    b3 = q + 3 < n ? s[q + 3] : 0u;
+                }
+                if (lane < 3) {
+                    if (lane < 1) u1 = q - 1 >= bom ? s[q - 1] : 0x80u;
+                    if (lane < 2) u2 = q - 2 >= bom ? s[q - 2] : 0x80u;
+                    u3 = q - 3 >= bom ? s[q - 3] : 0x80u;
+                }
                 const bool cont = (b0 & 0xC0) == 0x80;
                 start = in && !cont;
                 if (in && cont) {
-                    uint32_t p1 = (q - 1 >= bom) ? s[q - 1] : 0x80u, p2 = (q - 2 >= bom) ? s[q - 2] : 0x80u, p3 = (q - 3 >= bom) ? s[q - 3] : 0x80u;
+                    const uint32_t p1 = (q - 1 >= bom) ? u1 : 0x80u, p2 = (q - 2 >= bom) ? u2 : 0x80u, p3 = (q - 3 >= bom) ? u3 : 0x80u;
                     bool ok;
                     if ((p1 & 0xC0) != 0x80) ok = (q - 1 >= bom) && p1 >= 0xC0;
                     else if ((p2 & 0xC0) != 0x80) ok = (q - 2 >= bom) && p2 >= 0xE0;
@@ -704,7 +715,11 @@ __global__ __launch_bounds__(256) void k_prep_sp(SpPrepParams p)
                     pe = e; hp = true;
                 }
             }
-            const int inc = wave_incl_scan(kept);
+            // prefix sum of the kept counts: almost always every lane keeps 0 or 1 element -> one ballot instead of a 6-step scan
+            const bool any_multi = __any(c > 1);
+            int inc;
+            if (!any_multi) inc = __popcll(__ballot(kept != 0) & (lanemask_lt() | (1ull << lane)));
+            else inc = wave_incl_scan(kept);
             int idx = outc + inc - kept;
             {
                 uint32_t pe2 = below ? pl_last : prev; bool hp2 = below ? true : have_prev;
@@ -717,7 +732,7 @@ __global__ __launch_bounds__(256) void k_prep_sp(SpPrepParams p)
                 }
             }
             outc += __shfl(inc, 63, 64);
-            normc += __shfl(wave_incl_scan(c), 63, 64);
+            normc += any_multi ? __shfl(wave_incl_scan(c), 63, 64) : __popcll(m_has);
             decoded += __popcll(__ballot(start && !err));
             if (m_has) { const int hl = 63 - __clzll((long long)m_has); prev = __shfl(last, hl, 64); have_prev = true; }
             pos += 64;
@@ -1387,6 +1402,7 @@ __global__ __launch_bounds__(64) void k_seg_unigram_lane(SpSegParams p, int ring
     ul.pend_r.id = 0; ul.pend_r.score_bits = 0; ul.end = 0; ul.cnt = 0; ul.unk_run = 0; ul.q0 = ul.q1 = ul.q2 = ul.q3 = 0; ul.qn = 0; ul.abs0 = 0;
     int mode = M_NEED;
     int64_t doc = 0; int32_t *ids = nullptr; int32_t *spans = nullptr; int cap = 0;
+    int32_t g0 = 0, g1 = 0, g2 = 0, g3 = 0; int gn = 0;     // ids of the backward pass waiting for their 16-byte group
     for (unsigned long long trip = 0; trip < (1ull << 34); ++trip) {
         // ---- documents for idle lanes
         const unsigned long long m_need = __ballot(mode == M_NEED);
@@ -1427,11 +1443,21 @@ __global__ __launch_bounds__(64) void k_seg_unigram_lane(SpSegParams p, int ring
             if (!walk) { ul.begin_back(); mode = M_BACK; }
         }
         if (back) {
+            // ids leave in descending address order (right-aligned in the slot): they are queued and stored as whole aligned
+            // 16-byte groups (g0 = newest = lowest address), single words only at the two ends of the sequence
+            int32_t *dst = nullptr;
             auto put = [&](int k, int id, int from, int to) {
-                ids[cap - 1 - k] = id;
+                g3 = g2; g2 = g1; g1 = g0; g0 = id; ++gn;
+                dst = ids + (cap - 1 - k);
                 if (spans) { spans[2 * (cap - 1 - k)] = from; spans[2 * (cap - 1 - k) + 1] = to; }
             };
-            if (!ul.bstep(br, put, p.unk)) {
+            const bool more = ul.bstep(br, put, p.unk);
+            if (!more || (((uintptr_t)dst >> 2) & 3) == 0) {
+                if (gn == 4 && (((uintptr_t)dst >> 2) & 3) == 0) *(int4 *)dst = make_int4(g0, g1, g2, g3);
+                else { dst[0] = g0; if (gn > 1) dst[1] = g1; if (gn > 2) dst[2] = g2; if (gn > 3) dst[3] = g3; }
+                gn = 0;
+            }
+            if (!more) {
                 p.counts[doc] = ul.cnt < p.max_ids ? ul.cnt : p.max_ids;
                 p.narcs[doc] = cap - ul.cnt;
                 mode = M_NEED;
