@@ -33,7 +33,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 
 # total documents of each workload; the corpus is sharded over the ranks
-TOTAL_DOCS = {"headline512": 10000000, "config2": 1000000, "config3": 1000000, "config4": 10000000, "config5": 10000000}
+TOTAL_DOCS = {"config1": 10000, "headline512": 10000000, "config2": 1000000, "config3": 1000000, "config4": 10000000, "config5": 10000000}
 DOMINANT = {0: "k_lex_wp_flat", 1: "k_seg_unigram_ring"}
 
 
@@ -99,8 +99,88 @@ def device_doc_hashes(torch, ids, id_off, ndocs):
     return out
 
 
+def run_config1(args):
+    """BASELINE.json configs[0]: the default pattern tokenizer (TextToWords, built-in wbd.bin) on short English lines.  The config names
+    the reference's CPU path; the GPU batch entry point (TextToWordsBatchDevice: lexer with the table in LDS + string assembly) is timed
+    beside it.  One GPU only (10,000 lines are one launch)."""
+    import ctypes
+    import numpy as np
+    import torch
+    import bfutil
+    import blingfire_amd as bf
+    if args.gpus != 1 or int(os.environ.get("WORLD_SIZE", "1")) != 1:
+        sys.stderr.write("bench: config1 is a single-launch workload; run it with --gpus 1\n")
+        sys.exit(2)
+    nl = args.docs or TOTAL_DOCS["config1"]
+    text, off = bfutil.gen_workload("config1", nl)
+    dev = torch.device("cuda", 0)
+    L = bf.lib()
+    dt, do = torch.from_numpy(text).to(dev), torch.from_numpy(off).to(dev)
+    out = torch.empty(2 * len(text) + 64, dtype=torch.uint8, device=dev)
+    t_off = torch.empty(nl + 1, dtype=torch.int64, device=dev)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+
+    def step():
+        r = L.TextToWordsBatchDevice(None, dt.data_ptr(), do.data_ptr(), nl, len(text), out.data_ptr(), out.numel(), t_off.data_ptr(), ctypes.c_void_p(stream))
+        assert r == 0, r
+
+    # every line against the reference's TextToWords (the checker never runs inside the timed region)
+    verified = 0
+    lib_path, ck_kind = bfutil.checker_lib_path()
+    if args.verify != "0" and ck_kind == "reference":
+        step()
+        torch.cuda.synchronize(dev)
+        g_off = t_off.cpu().numpy()
+        g_out = out[:int(g_off[-1])].cpu().numpy().tobytes()
+        R = ctypes.CDLL(lib_path)
+        R.TextToWords.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int]
+        raw = text.tobytes()
+        nv = nl if args.verify == "full" else min(nl, int(args.verify))
+        nv = min(nv, 200000)
+        buf = ctypes.create_string_buffer(4096)
+        for d in range(nv):
+            line = raw[off[d]:off[d + 1]]
+            n = R.TextToWords(line, len(line), buf, 4096)
+            want = buf.raw[:n - 1] if n > 0 else b""
+            if g_out[g_off[d]:g_off[d + 1]] != want:
+                raise SystemExit("bench: TextToWords output of line %d differs from the reference -- refusing to time" % d)
+        verified = nv
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize(dev)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()
+    for _ in range(args.steps):
+        step()
+    e1.record()
+    torch.cuda.synchronize(dev)
+    elapsed = time.perf_counter() - t0
+    gpu_ms = e0.elapsed_time(e1) / args.steps
+    out_bytes = int(t_off[-1].item())
+    alg = len(text) + out_bytes + 16 * nl
+    res = {"metric": "lines/sec", "value": nl * args.steps / elapsed, "unit": "lines/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+           "config": {"workload": "config1: built-in wbd.bin TextToWords (TextToWordsBatchDevice), %d lines, %.1f B/line" % (nl, len(text) / nl), "model_file": "wbd.bin (built in)",
+                      "total_docs": nl, "total_bytes": int(len(text)), "output_bytes": out_bytes},
+           "gb_input_per_sec": len(text) * args.steps / elapsed / 1e9, "gpu_ms_per_step": gpu_ms,
+           "roofline": {"bound": "hbm", "kernel": "whole step (lexer with the table in LDS + scan + string assembly)", "achieved": alg / (gpu_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                        "frac": alg / (gpu_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "traffic": None, "algorithmic_bytes_per_launch": alg},
+           "verified_docs": verified}
+    if not args.no_cpu_baseline and ck_kind == "reference":
+        T = bfutil.host_threads()
+        s1, _ = bfutil.cpu_text_to_words_time(lib_path, text, off, 1, 5)
+        sT, _ = bfutil.cpu_text_to_words_time(lib_path, text, off, T, 5)
+        res["cpu_baseline"] = {"value": nl / s1, "unit": "lines/s", "cores": 1, "kind": "reference",
+                               "sample": "all %d lines, one TextToWords call per line, 1 thread, best of 5 passes (%.4f s)" % (nl, s1),
+                               "all_threads": {"value": nl / sT, "threads": T, "seconds": sT}}
+    print(json.dumps(res), flush=True)
+
+
 def main():
     args = parse_args()
+    if args.workload == "config1":
+        return run_config1(args)
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(spawn_ranks(args))
 

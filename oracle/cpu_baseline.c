@@ -111,3 +111,50 @@ double bfc_text_to_ids_hashes(const char *lib_path, const char *model_path, cons
 {
     return run_passes(lib_path, model_path, text, doc_off, ndocs, max_ids, unk, nthreads, 1, total_ids, NULL, out_counts, out_hash);
 }
+
+/* ---- TextToWords (BASELINE.json configs[0]): one call per line from T threads, the library's built-in model (tokdll:610-614) ---- */
+typedef int (*t2w_fn)(const char *, int, char *, int);
+typedef struct { t2w_fn f; const char *text; const int64_t *off; int64_t nlines; int tid, nthreads; int64_t out_bytes; } wjob_t;
+
+static void *wworker(void *arg)
+{
+    wjob_t *j = (wjob_t *)arg;
+    char *buf = (char *)malloc(1 << 16);
+    for (int64_t d = j->tid; d < j->nlines; d += j->nthreads) {
+        int n = (int)(j->off[d + 1] - j->off[d]);
+        int cap = 3 * n + 4; if (cap > (1 << 16)) cap = 1 << 16;
+        int r = j->f(j->text + j->off[d], n, buf, cap);
+        if (r > 0) j->out_bytes += r;
+    }
+    free(buf);
+    return NULL;
+}
+
+/* seconds of the best of `passes` passes over the lines (negative on error); *out_bytes = output bytes of one pass */
+double bfc_time_text_to_words(const char *lib_path, const char *text, const int64_t *line_off, int64_t nlines, int nthreads, int passes, int64_t *out_bytes)
+{
+    void *lib = dlopen(lib_path, RTLD_NOW | RTLD_LOCAL);
+    if (!lib) { fprintf(stderr, "cpu_baseline: dlopen(%s): %s\n", lib_path, dlerror()); return -1.0; }
+    t2w_fn f = (t2w_fn)dlsym(lib, "TextToWords");
+    if (!f) { fprintf(stderr, "cpu_baseline: no TextToWords in %s\n", lib_path); return -2.0; }
+    if (nthreads < 1) nthreads = 1;
+    if (nthreads > MAX_THREADS) nthreads = MAX_THREADS;
+    double best = 1e30; int64_t ob = 0;
+    for (int p = 0; p < (passes < 1 ? 1 : passes); ++p) {
+        static pthread_t th[MAX_THREADS]; static wjob_t jobs[MAX_THREADS];
+        struct timespec t0, t1;
+        clock_gettime(CLOCK_MONOTONIC, &t0);
+        for (int t = 0; t < nthreads; ++t) {
+            memset(&jobs[t], 0, sizeof(wjob_t));
+            jobs[t].f = f; jobs[t].text = text; jobs[t].off = line_off; jobs[t].nlines = nlines; jobs[t].tid = t; jobs[t].nthreads = nthreads;
+            pthread_create(&th[t], NULL, wworker, &jobs[t]);
+        }
+        ob = 0;
+        for (int t = 0; t < nthreads; ++t) { pthread_join(th[t], NULL); ob += jobs[t].out_bytes; }
+        clock_gettime(CLOCK_MONOTONIC, &t1);
+        double s = (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+        if (s < best) best = s;
+    }
+    if (out_bytes) *out_bytes = ob;
+    return best;
+}

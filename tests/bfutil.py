@@ -165,6 +165,21 @@ def cpu_doc_hashes(lib_path, model, text, off, max_ids, unk, nthreads=None):
     return secs, counts, hashes
 
 
+def cpu_text_to_words_time(lib_path, text, off, nthreads=1, passes=3):
+    """best-of-`passes` seconds for one TextToWords call per line (built-in model) through oracle/libcpubaseline.so; returns (seconds, output bytes)"""
+    L = ctypes.CDLL(CPUBASE_LIB)
+    f = L.bfc_time_text_to_words
+    f.restype = ctypes.c_double
+    f.argtypes = [ctypes.c_char_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+    text = np.ascontiguousarray(text, dtype=np.uint8)
+    off = np.ascontiguousarray(off, dtype=np.int64)
+    ob = ctypes.c_int64(0)
+    secs = f(lib_path.encode(), text.ctypes.data, off.ctypes.data, len(off) - 1, nthreads, passes, ctypes.byref(ob))
+    if secs < 0:
+        raise RuntimeError("cpu baseline driver failed (%s)" % secs)
+    return secs, ob.value
+
+
 IDS_HASH_C = -7046029254386353131          # 0x9E3779B97F4A7C15 as int64 (oracle/cpu_baseline.c bfc_ids_hash)
 
 
@@ -328,6 +343,9 @@ def gen_workload(name, ndocs, first_doc=0):
 
 
 WORKLOADS = {
+    # BASELINE.json configs[0]: the default pattern tokenizer (built-in wbd.bin), TextToWords on short English lines (SURVEY.md section 8d
+    # names 10,000 lines of a reference corpus that does not travel; same shape from the generator: ~43 bytes per line)
+    "config1": dict(model="wbd.bin", gen=dict(seed=1, mean=43, sd=12, minlen=8, maxlen=120), max_ids=0, unk=0),
     # name: generator kwargs + tokenizer call parameters
     "headline512": dict(model=None, gen=dict(seed=20240201, mean=512, sd=64, minlen=128, maxlen=1024), max_ids=512, unk=100),
     "config2": dict(model=None, gen=dict(seed=20240202, mean=128, sd=16, minlen=32, maxlen=256), max_ids=512, unk=100),
