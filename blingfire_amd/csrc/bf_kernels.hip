@@ -417,7 +417,8 @@ __global__ __launch_bounds__(THREADS) void k_lex_wp_seq(WpLexParams p)
 // counter; every loop iteration a lane in WALK mode makes exactly one DFA transition, while the heavier
 // "event" code (match handling, calls/returns, next start position) and the document fetch run only when
 // enough lanes of the wave are waiting for them (ballot vote), so that they execute with most lanes active.
-template <int THREADS, class WIN, bool HAS_ANY, int UNROLL, bool STATS, bool TLDS = false, bool TWO = false>
+// PLAIN: ids only (no TextToWords mode, no offsets): `words` and the span pointer become compile-time constants
+template <int THREADS, class WIN, bool HAS_ANY, int UNROLL, bool STATS, bool TLDS = false, bool TWO = false, bool PLAIN = false>
 __global__ __launch_bounds__(THREADS) void k_lex_wp_flat(WpLexParams p)
 {
     extern __shared__ int32_t lex_lds[];
@@ -496,8 +497,8 @@ __global__ __launch_bounds__(THREADS) void k_lex_wp_flat(WpLexParams p)
                         int cap = p.max_ids; if ((int64_t)cap > nbytes) cap = (int)nbytes;
                         if (cap < 0) cap = 0;
                         cls_at.init(p.cls, b);
-                        out.init(p.ids_tmp + ids_slot(b, doc), p.span_tmp ? p.span_tmp + 2 * ids_slot(b, doc) : nullptr);
-                        lane.init(n, cap, p.unk, p.words);
+                        if constexpr (PLAIN) { out.init(p.ids_tmp + ids_slot(b, doc), nullptr); lane.init(n, cap, p.unk, 0); }
+                        else { out.init(p.ids_tmp + ids_slot(b, doc), p.span_tmp ? p.span_tmp + 2 * ids_slot(b, doc) : nullptr); lane.init(n, cap, p.unk, p.words); }
                         bool more;
                         if constexpr (TWO) more = lane.prepare2(); else more = lane.prepare();
                         if (more) mode = M_WALK;
@@ -579,7 +580,11 @@ void launch_lex_wp(const WpLexParams &p, int variant, hipStream_t s)
             // transitions per vote: swept on MI355X with the two-level event code (2: 8.50 ms, 3: 7.67, 4: 6.86 on the 1.25 M-doc shard);
             // bits 20..23 of the variant select 5..8 for experiments
             const int un = ((variant >> 20) & 0xf) ? ((variant >> 20) & 0xf) : (usel == 1 ? 1 : usel == 2 ? 2 : usel == 3 ? 4 : 4);
+            const bool plain = !q2.words && !q2.span_tmp && kind != 8;               // variant 8 (experiments): the general instance
             if (has_any) hipLaunchKernelGGL((k_lex_wp_flat<64, ClsWin, true, 1, false, false, true>), g2, t2, lds2, s, q2);
+            else if (plain && un == 4) hipLaunchKernelGGL((k_lex_wp_flat<64, ClsWin, false, 4, false, false, true, true>), g2, t2, lds2, s, q2);
+            else if (plain && un == 5) hipLaunchKernelGGL((k_lex_wp_flat<64, ClsWin, false, 5, false, false, true, true>), g2, t2, lds2, s, q2);
+            else if (plain && un == 3) hipLaunchKernelGGL((k_lex_wp_flat<64, ClsWin, false, 3, false, false, true, true>), g2, t2, lds2, s, q2);
             else if (un == 1) hipLaunchKernelGGL((k_lex_wp_flat<64, ClsWin, false, 1, false, false, true>), g2, t2, lds2, s, q2);
             else if (un == 2) hipLaunchKernelGGL((k_lex_wp_flat<64, ClsWin, false, 2, false, false, true>), g2, t2, lds2, s, q2);
             else if (un == 3) hipLaunchKernelGGL((k_lex_wp_flat<64, ClsWin, false, 3, false, false, true>), g2, t2, lds2, s, q2);
@@ -645,7 +650,9 @@ __global__ __launch_bounds__(256) void k_prep_sp(SpPrepParams p)
             uint32_t b0 = 0, b1 = 0, b2 = 0, b3 = 0;
             if (in) b0 = s[q];
             bool start = in; bool err = false; int cp = (int)b0;
-            if (!p.use_bytes) {
+            // a window of plain ASCII (most of Latin-script text) needs no UTF-8 decoding at all: every byte is a character
+            // (a continuation byte that straddles INTO the window from a previous lead is >= 0x80 itself, so it takes the full path)
+            if (!p.use_bytes && __any(b0 >= 0x80u)) {
                 // the three bytes on either side come from the neighbouring lanes (one byte load per lane instead of seven); only the
                 // lanes at the edges of the 64-byte window load theirs
                 b1 = __shfl_down(b0, 1, 64); b2 = __shfl_down(b0, 2, 64); b3 = __shfl_down(b0, 3, 64);

@@ -226,21 +226,30 @@ struct LexLane {
     // Written with selects instead of branches: on the GPU this is the hot loop body (VALU-issue bound) and every
     // divergent branch costs scalar instructions for the whole wave.  Reads position off + InSize under the right
     // anchor (value unused): class streams carry at least one element of padding.
-    BF_HD bool step()
+    // Optional accelerator, valid at any point of a walk: while the walk sits in the model's loop state, every element flagged
+    // LX_C_LOOP keeps it there (k transitions of FALexTools_t.h:255-277 at once; a final loop state is the deepest final state
+    // seen after each of them), so the run is skipped from the class window alone.  Returns false if the walk ended that way.
+    // step() starts with it.
+    BF_HD bool ff()
     {
         const int hi = lim < fn_ ? lim : fn_;          // letters are read at positions < hi
         if (state == L.loop_state && j < hi) {
-            // fast-forward: every flagged element keeps the walk in this state (k transitions of FALexTools_t.h:255-277 at
-            // once; a final loop state is the deepest final state seen after each of them)
             int k = cls_at.run(off + j);
             k = k < hi - j ? k : hi - j;
             if (k > 0) {
                 j += k;
                 if (L.loop_final) { fp = j - 1; finfo = L.loop_info; }
                 if (!(j < lim)) return false;
-                if (j < fn_ && !cls_at.has(off + j)) { cls_at.prefetch(off + j); return true; }   // next element: next trip
+                if (j < fn_) cls_at.prefetch(off + j);
             }
         }
+        return true;
+    }
+
+    BF_HD bool step()
+    {
+        // measured on MI355X (1.25 M documents, bert_base_tok.bin): fast-forward inside every step 6.5 ms, none 6.74, once per vote 7.01
+        if (!ff()) return false;
         const bool ra = j >= fn_;                      // feeding the right anchor (FALexTools_t.h:280-290)
         uint32_t c = cls_at(off + j) & LX_T_CLS_MASK;  // a letter (FALexTools_t.h:255-277)
         c = ra ? L.cls_r : c;
