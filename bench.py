@@ -329,7 +329,7 @@ def main():
             tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
             ent = tj.get("%s/%s/%d" % (args.workload, model_name, ndocs))
             if ent:
-                traffic = ent["hbm_bytes_per_launch"]
+                traffic = ent.get("hbm_bytes_per_step", ent["hbm_bytes_per_launch"])
         except Exception:
             traffic = None
         res = {
@@ -346,7 +346,8 @@ def main():
             "kernel_ms": {"prep": float(kms[0]), "tokenise": tok_ms, "scan": float(kms[2]), "compact": float(kms[3]), "total": float(kms[4])},
             "roofline": {"bound": "hbm", "kernel": "tokenise (%s)" % DOMINANT.get(kind, "k_bpe_fused"), "achieved": achieved, "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes,
-                         "launches_per_step": len(batches)},
+                         "launches_per_step": len(batches),
+                         "note": "achieved = algorithmic bytes of one step (all its launches) / tokenise-kernel time of one step; traffic = FETCH_SIZE + WRITE_SIZE of the same, from profiles/traffic.json"},
             "verified_docs": sum(r["verified_docs"] for r in ranks), "verify": {"checker": ck_kind, "threads": cpu_threads, "seconds": verify_secs,
                                                                                "method": "per-document id count + 64-bit hash of the ids, every document of the shard"},
             "status": max(r["status"] for r in ranks), "ranks": ranks,

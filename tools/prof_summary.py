@@ -29,6 +29,15 @@ def main():
         out.append("%-44s %5s %12s %12s %12s %5s %5s %8s %6s %10s %4s" % ("kernel", "n", "avg_ns", "min_ns", "max_ns", "vgpr", "sgpr", "scratch", "lds", "grid", "wg"))
         for r in rs:
             out.append("%-44s %5d %12.0f %12.0f %12.0f %5d %5d %8d %6d %10d %4d" % (r[0][:44], r[1], r[2], r[3], r[4], r[5] or 0, r[6] or 0, r[7] or 0, r[8] or 0, r[9] or 0, r[10] or 0))
+        # bench.py launches the tokenising kernels on two batch sizes (the shard; the 1.25 M-document sample of the PCIe timings):
+        # the launches that last at least half as long as the longest one are the shard's
+        out.append("")
+        out.append("full-size launches (duration >= 0.5 x the kernel's longest): the ones the bench line's kernel_ms is about")
+        out.append("%-44s %5s %12s %12s %12s" % ("kernel", "n", "avg_ns", "min_ns", "max_ns"))
+        _, ks = rows(db, "select name, max(duration) from kernels where name like '%bfa::%' group by name order by sum(duration) desc")
+        for name, mx in ks:
+            _, q = rows(db, "select count(*), avg(duration), min(duration), max(duration) from kernels where name = '%s' and duration >= %f" % (name.replace("'", "''"), 0.5 * mx))
+            out.append("%-44s %5d %12.0f %12.0f %12.0f" % (name[:44], q[0][0], q[0][1], q[0][2], q[0][3]))
     for d in sorted(glob.glob(os.path.join(src, "pmc_*"))):
         if not os.path.isdir(d):
             continue
