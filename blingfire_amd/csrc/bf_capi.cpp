@@ -261,6 +261,7 @@ int run_device(Handle *h, const char *d_text, const int64_t *d_doc_off, int64_t 
         lp.L.max_depth = m.max_depth; lp.L.max_token_length = m.max_token_length; lp.L.max_frames = m.lex_frames;
         lp.L.loop_state = (h->variant & 0xff) == 4 ? LX_NO_STATE : m.loop_base;        // variant 4 (experiments): no fast-forward
         lp.L.loop_info = m.loop_info; lp.L.loop_final = m.loop_final ? 1 : 0;
+        lp.L.fn_no_ra = (m.fn_no_ra && (h->variant & 0xff) != 9) ? 1 : 0;                      // variant 9 (experiments): always feed the right anchor
         lp.L.two_level = (m.two_level && (h->variant & 0xff) != 7) ? 1 : 0;                // variant 7 (experiments): the general machine
         lp.b = b; lp.cls = h->w_cls.as<uint16_t>(); lp.nchars = h->w_nchars.as<int32_t>();
         lp.ids_tmp = h->w_tmp.as<int32_t>(); lp.counts = h->w_counts.as<int32_t>(); lp.span_tmp = want_off ? h->w_span.as<int32_t>() : nullptr;

@@ -54,6 +54,10 @@ struct LexTables {
     // call FnTokWord, whose rules are the vocabulary).  The call stack then never holds more than the top-level frame, which is a
     // constant: prepare2() / after_walk2() run the same algorithm without the frame stack and the general action decoding.
     int two_level;
+    // No state reachable from a called function's initial states has a transition on the right anchor (load-time fact; true for the
+    // WordPiece vocabularies, whose rules are `^piece` / `piece`): feeding the anchor at the end of a function's input can only miss
+    // (FALexTools_t.h:280-290 would look it up and find nothing), so walks inside a function stop at the last letter instead.
+    int fn_no_ra;
 };
 
 // where table entries come from: a policy, so that the host build can count lookups per table index
@@ -219,7 +223,8 @@ struct LexLane {
     BF_HD void set_lim(int f)
     {
         const int b = f + L.max_token_length;
-        lim = b < fn_ ? b : fn_ + 1;
+        const int ra = (d > 0 && L.fn_no_ra) ? 0 : 1;          // inside a function whose rules never use the right anchor: no anchor step
+        lim = b < fn_ ? b : fn_ + ra;
     }
 
     // Exactly one DFA transition on a letter or on the right anchor.  Returns true while the walk continues.

@@ -667,6 +667,38 @@ bool build_model(Model &m, const uint8_t *img, size_t size)
                 } else ok = false;          // no calling action at all: the general machine is already flat
                 m.two_level = ok;
             }
+            // fn_no_ra: from the initial states of EVERY function an action can call (plain and after the left anchor), following
+            // all transitions, no state has a transition on the right anchor
+            {
+                const RawDfa &rw = m.wbd_raw;
+                const int r_sym = rw.remap ? rw.class_of(IW_R_ANCHOR) : IW_R_ANCHOR;
+                std::vector<uint32_t> starts;
+                for (size_t id = 0; id < actions.size(); ++id) {
+                    if (act_info[id] & INFO_SIMPLE_BIT) continue;
+                    const int32_t *a = m.acts_pool.data() + act_info[id];
+                    for (int k = 0; k < a[3]; ++k) {            // per function: (id, initial state, initial state after the left anchor)
+                        starts.push_back((uint32_t)a[5 + 3 * k]);
+                        if ((uint32_t)a[6 + 3 * k] != 0xFFFFFFFFu) starts.push_back((uint32_t)a[6 + 3 * k]);
+                    }
+                }
+                bool ok = !starts.empty();
+                if (ok && r_sym >= 0) {
+                    std::vector<int> base2idx(m.wbd.table_len(), -1);
+                    for (size_t st = 0; st < rw.state_off.size(); ++st) base2idx[m.wbd.state_base[st]] = (int)st;
+                    std::vector<uint8_t> seen(rw.state_off.size(), 0);
+                    std::vector<int> stack;
+                    for (uint32_t b : starts) { const int st = b < base2idx.size() ? base2idx[b] : -1; if (st >= 0 && !seen[(size_t)st]) { seen[(size_t)st] = 1; stack.push_back(st); } }
+                    while (ok && !stack.empty()) {
+                        const int st = stack.back(); stack.pop_back();
+                        for (uint32_t t = rw.tr_begin[(size_t)st]; t < rw.tr_begin[(size_t)st + 1]; ++t) {
+                            if (rw.tr_sym[t] == r_sym) { ok = false; break; }
+                            const int dst = rw.tr_dst[t];
+                            if (dst >= 0 && !seen[(size_t)dst]) { seen[(size_t)dst] = 1; stack.push_back(dst); }
+                        }
+                    }
+                }
+                m.fn_no_ra = ok;
+            }
 
             // loop state: the state with the most transitions to itself (ties: the first).  Only text classes matter: the anchors
             // and IW_ANY never occur in a class stream.

@@ -116,6 +116,7 @@ struct Model {
     // LX_C_LOOP in the fused code-point maps below (and so in the class stream); 0xFFFFFFFF = the lexer has none.
     uint32_t loop_base = 0xFFFFFFFFu, loop_info = 0; bool loop_final = false;
     std::vector<uint8_t> loop_cls;     // [nclasses] 1 = self-loop of the loop state
+    bool fn_no_ra = false;             // bf_lex.h LexTables::fn_no_ra: no right-anchor transition below any function's initial states
     bool two_level = false;            // bf_lex.h LexTables::two_level: calls are one level deep, one function per action, no contexts
     // fused "code point -> charmap -> (cp<3 ? 3 : cp) -> class" map:
     //   value = CLS_NONE | class (count 1 implicit) or FUSED_MULTI | pool offset for 0 or 2..10 outputs

@@ -54,6 +54,7 @@ void bft_free(void *hv) { delete (Handle *)hv; }
 void bft_set_no_ff(int v) { g_no_ff = v; }
 void bft_set_general(int v) { g_general = v; }
 int bft_two_level(void *hv) { return ((Handle *)hv)->m.two_level ? 1 : 0; }
+int bft_fn_no_ra(void *hv) { return ((Handle *)hv)->m.fn_no_ra ? 1 : 0; }
 void bft_set_uni_seq(int v) { g_uni_seq = v; }
 // loop state facts: out[0] = base (-1: none), [1] = number of flagged classes, [2] = final, [3] = info
 void bft_loop_state(void *hv, long *out) { Model &m = ((Handle *)hv)->m; out[0] = m.loop_base == 0xFFFFFFFFu ? -1 : (long)m.loop_base; long n = 0; for (uint8_t b : m.loop_cls) n += b; out[1] = n; out[2] = m.loop_final; out[3] = m.loop_info; }
@@ -213,7 +214,7 @@ static int emu_wp(const Model &m, const char *s, int n, int32_t *ids, int32_t *s
     L.T = m.wbd_t2.data(); L.acts = m.acts_pool.data();
     L.initial = m.wbd.initial_base; L.initial_l = m.initial_l; L.cls_any = m.cls_any; L.cls_l = m.cls_l; L.cls_r = m.cls_r;
     L.max_depth = m.max_depth; L.max_token_length = m.max_token_length; L.max_frames = m.lex_frames;
-    L.loop_state = g_no_ff ? LX_NO_STATE : m.loop_base; L.loop_info = m.loop_info; L.loop_final = m.loop_final ? 1 : 0; L.two_level = (m.two_level && !g_general) ? 1 : 0;
+    L.loop_state = g_no_ff ? LX_NO_STATE : m.loop_base; L.loop_info = m.loop_info; L.loop_final = m.loop_final ? 1 : 0; L.two_level = (m.two_level && !g_general) ? 1 : 0; L.fn_no_ra = (m.fn_no_ra && !g_general) ? 1 : 0;
     const int nch = (int)cls.size();
     cls.push_back((uint16_t)CLS_NONE);        // one element of padding: step() reads (and ignores) position InSize under the right anchor
     HostCls cls_at{cls.data(), nch + 1};
@@ -371,7 +372,7 @@ int bft_emu_text_to_words(void *hv, const char *s, int n, char *out, int32_t *st
     LexTables L;
     L.T = m.wbd_t2.data(); L.acts = m.acts_pool.data(); L.initial = m.wbd.initial_base; L.initial_l = m.initial_l; L.cls_any = m.cls_any; L.cls_l = m.cls_l; L.cls_r = m.cls_r;
     L.max_depth = m.max_depth; L.max_token_length = m.max_token_length; L.max_frames = m.lex_frames;
-    L.loop_state = g_no_ff ? LX_NO_STATE : m.loop_base; L.loop_info = m.loop_info; L.loop_final = m.loop_final ? 1 : 0; L.two_level = (m.two_level && !g_general) ? 1 : 0;
+    L.loop_state = g_no_ff ? LX_NO_STATE : m.loop_base; L.loop_info = m.loop_info; L.loop_final = m.loop_final ? 1 : 0; L.two_level = (m.two_level && !g_general) ? 1 : 0; L.fn_no_ra = (m.fn_no_ra && !g_general) ? 1 : 0;
     cls.push_back((uint16_t)CLS_NONE);        // padding (see emu_wp)
     HostCls cls_at{cls.data(), len + 1};
     std::vector<int32_t> tags((size_t)len + 1), spans(2 * (size_t)len + 2);

@@ -103,3 +103,33 @@ def test_unigram_long_unknown_runs(ht, model):
             assert c == gc and list(arr)[:c] == gbuf[:gc], (model, n)
     ora.free(ho)
     ht.bft_free(h)
+
+
+@pytest.mark.parametrize("model", ["bert_base_tok.bin", "bert_base_cased_tok.bin", "bert_chinese.bin", "wbd.bin"])
+def test_lexer_shortcuts_are_equivalent(ht, model):
+    """the load-time shortcuts of the lexer lane program (bf_lex.h: loop-state fast-forward, two-level form, no right-anchor step
+    inside functions whose rules never use it) against the same program without them -- and both against the oracle"""
+    if not bfutil.have_model(model):
+        pytest.skip("%s not present" % model)
+    ht.bft_two_level.argtypes = [ctypes.c_void_p]
+    ht.bft_fn_no_ra.argtypes = [ctypes.c_void_p]
+    ora = bfutil.oracle()
+    h = ht.bft_load(bfutil.model_path(model).encode())
+    ho = ora.load(bfutil.model_path(model))
+    is_bert = model.startswith("bert")
+    assert bool(ht.bft_two_level(h)) == is_bert and bool(ht.bft_fn_no_ra(h)) == is_bert
+    docs = list(bfutil.ADVERSARIAL) + bfutil.fuzz_docs(1500, seed=77)
+    arr = (ctypes.c_int32 * 512)()
+    try:
+        for general, no_ff in ((1, 1), (1, 0), (0, 1)):
+            ht.bft_set_general(general)
+            ht.bft_set_no_ff(no_ff)
+            for b in docs:
+                c = ht.bft_emu_text_to_ids(h, b, len(b), arr, 512, 100)
+                gc, gbuf = ora.text_to_ids(ho, b, 512, 100)
+                assert c == gc and list(arr)[:c] == gbuf[:gc], (model, general, no_ff, b[:60])
+    finally:
+        ht.bft_set_general(0)
+        ht.bft_set_no_ff(0)
+    ora.free(ho)
+    ht.bft_free(h)

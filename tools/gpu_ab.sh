@@ -1,9 +1,12 @@
 #!/bin/bash
-# A/B builds of the product library in ONE GPU session (same box, interleaved): tools/gpu_ab.sh libA libB ... -- [bench args]
-libs=(); while [ $# -gt 0 ] && [ "$1" != "--" ]; do libs+=("$1"); shift; done; [ "$1" == "--" ] && shift
-cp blingfire_amd/libblingfiretokdll.so /tmp/lib_keep.so
-for rep in 1 2; do for l in "${libs[@]}"; do
-  cp $l blingfire_amd/libblingfiretokdll.so
-  timeout 300 python bench.py --no-cpu-baseline "$@" 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('$l', '%.1f M docs/s' % (d['value']/1e6), {k: round(x,3) for k,x in d['kernel_ms'].items()})"
-done; done
-cp /tmp/lib_keep.so blingfire_amd/libblingfiretokdll.so
+# quick A/B of kernel variants on the default workload: tools/gpu_ab.sh "<variant> <variant> ..." (-1 = product default)
+set -u
+O=$PWD/gpurun_out/ab; mkdir -p $O
+Q="--no-cpu-baseline --no-extra-timings --verify 0 --steps 5 --warmup 2"
+for v in $1; do
+  timeout 300 python bench.py $Q --variant $v > $O/v_$v.json 2> $O/v_$v.err
+  python - $O/v_$v.json $v <<'PY'
+import json, sys
+j = json.load(open(sys.argv[1])); print("variant", sys.argv[2], "ms/step %.2f" % j["ms_per_step"], j["kernel_ms"])
+PY
+done
