@@ -9,12 +9,15 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <condition_variable>
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 using namespace bfa;
@@ -57,7 +60,60 @@ template <class T> bool upload(DevBuf &b, const std::vector<T> &v, size_t pad_el
     return true;
 }
 
+// page-locked host memory (grow-only), the staging side of the chunked host-buffer path
+struct PinBuf {
+    void *p = nullptr; size_t cap = 0;
+    bool reserve(size_t bytes)
+    {
+        if (bytes <= cap) return true;
+        const size_t want = bytes + bytes / 4 + 4096;
+        void *q = nullptr;
+        if (!hip_ok(hipHostMalloc(&q, want, hipHostMallocDefault), "hipHostMalloc(staging)")) return false;
+        if (p) (void)hipHostFree(p);
+        p = q; cap = want; return true;
+    }
+    void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
+    template <class T> T *as() const { return (T *)p; }
+};
+
 enum { EV_BEGIN = 0, EV_PREP, EV_TOK, EV_SCAN, EV_COMPACT, EV_COUNT };
+
+// TextToIdsBatch on host buffers, large batches: the batch is cut into chunks that flow through NS slots of page-locked staging
+// and device buffers -- while chunk k is tokenised, chunk k+1 is copied in (CPU threads -> pinned -> DMA) and the ids of the chunks
+// before it are copied out (DMA -> pinned -> CPU threads).  Created on first use.
+struct HostPipe {
+    static constexpr int NS = 3;        // slots: chunk k is copied in while k-1 waits for / runs its tokenisation and the ids of k-2 leave
+    PinBuf pin_text[NS], pin_off[NS], pin_idoff[NS], pin_ids[NS], pin_status;
+    DevBuf dev_text[NS], dev_off[NS], dev_ids[NS], dev_idoff[NS];
+    hipStream_t s_in = nullptr, s_out = nullptr, s_meta = nullptr;     // copies in, ids out, per-chunk offsets out (never behind a bulk copy)
+    hipEvent_t ev_h2d[NS] = {}, ev_cmp[NS] = {}, ev_d2h[NS] = {};
+    bool ready = false;
+    bool init()
+    {
+        if (ready) return true;
+        if (!hip_ok(hipStreamCreateWithFlags(&s_in, hipStreamNonBlocking), "hipStreamCreate") || !hip_ok(hipStreamCreateWithFlags(&s_out, hipStreamNonBlocking), "hipStreamCreate") ||
+            !hip_ok(hipStreamCreateWithFlags(&s_meta, hipStreamNonBlocking), "hipStreamCreate")) return false;
+        for (int i = 0; i < NS; ++i)
+            if (!hip_ok(hipEventCreateWithFlags(&ev_h2d[i], hipEventDisableTiming), "hipEventCreate") || !hip_ok(hipEventCreateWithFlags(&ev_cmp[i], hipEventDisableTiming), "hipEventCreate") ||
+                !hip_ok(hipEventCreateWithFlags(&ev_d2h[i], hipEventDisableTiming), "hipEventCreate")) return false;
+        if (!pin_status.reserve(64)) return false;
+        ready = true; return true;
+    }
+    void release()
+    {
+        for (int i = 0; i < NS; ++i) {
+            pin_text[i].release(); pin_off[i].release(); pin_idoff[i].release(); pin_ids[i].release();
+            dev_text[i].release(); dev_off[i].release(); dev_ids[i].release(); dev_idoff[i].release();
+            if (ev_h2d[i]) (void)hipEventDestroy(ev_h2d[i]);
+            if (ev_cmp[i]) (void)hipEventDestroy(ev_cmp[i]);
+            if (ev_d2h[i]) (void)hipEventDestroy(ev_d2h[i]);
+        }
+        pin_status.release();
+        if (s_in) (void)hipStreamDestroy(s_in);
+        if (s_out) (void)hipStreamDestroy(s_out);
+        if (s_meta) (void)hipStreamDestroy(s_meta);
+    }
+};
 
 // Makes the handle's device current for the duration of a call and puts the caller's device back afterwards (a drop-in
 // library must not change the calling thread's current device behind its back).
@@ -95,8 +151,11 @@ struct Handle {
     hipStream_t stream = nullptr;
     hipEvent_t ev[EV_COUNT] = {};
     bool ev_valid = false;
+    HostPipe pipe;                                              // chunked host-buffer path (run_host_chunked)
+    int64_t host_chunk_bytes = 64ll << 20;                      // its chunk size (BfSetHostChunkBytes; 0 = never chunk)
     ~Handle()
     {
+        pipe.release();
         for (DevBuf *b : {&t_dk_l1, &t_dk_pages, &t_dn_l1, &t_dn_pages, &t_dn_pool, &t_k2i, &t_rows, &w_keys, &w_keyoff, &w_dids, &w_dret, &w_vals, &t_i2w_off, &t_i2w_data, &t_wbd, &t_info, &t_acts, &t_cp_l1, &t_cp_pages, &t_multi, &t_wcp_l1, &t_wcp_pages, &t_dict, &t_seginfo, &w_s1, &w_s2, &w_s3, &w_s4, &w_perm, &w_hist, &w_narcs, &w_cls, &w_nchars, &w_tmp, &w_counts, &w_flags, &w_out, &w_outoff,
                           &w_bsums, &w_misc, &w_text, &w_docoff, &w_ids, &w_idoff, &w_starts, &w_ends, &w_srcoff, &w_span}) b->release();
         for (auto &e : ev) if (e) (void)hipEventDestroy(e);
@@ -314,6 +373,152 @@ int run_device(Handle *h, const char *d_text, const int64_t *d_doc_off, int64_t 
     return 0;
 }
 
+// memcpy with a few threads: one core moves ~10 GB/s, PCIe wants ~50
+void par_memcpy(void *dst, const void *src, size_t n)
+{
+    if (n == 0) return;
+    unsigned hw = std::thread::hardware_concurrency();
+    size_t nt = hw >= 16 ? 8 : hw >= 8 ? 4 : hw >= 4 ? 2 : 1;
+    if (n < (size_t)(8u << 20)) nt = 1;
+    if (nt == 1) { memcpy(dst, src, n); return; }
+    const size_t part = ((n + nt - 1) / nt + 4095) & ~(size_t)4095;
+    std::vector<std::thread> th;
+    for (size_t t = 1; t < nt; ++t) {
+        const size_t a = t * part; if (a >= n) break;
+        const size_t len = n - a < part ? n - a : part;
+        th.emplace_back([=] { memcpy((char *)dst + a, (const char *)src + a, len); });
+    }
+    memcpy(dst, src, part < n ? part : n);
+    for (auto &x : th) x.join();
+}
+
+// The chunked form of run_host (ids only).  Same results as one TextToIdsBatchDevice call over the whole batch: documents are
+// independent, chunk boundaries are document boundaries.  Returns the number of ids or a BF_E_* code; id_off_out (if given) is
+// complete even when the ids do not fit ids_cap (BF_E_CAPACITY), like the unchunked path.
+int64_t run_host_chunked(Handle *h, const char *text, const int64_t *doc_off, int64_t ndocs, int32_t *ids_out, int64_t ids_cap,
+                         int64_t *id_off_out, int max_ids, int unk)
+{
+    HostPipe &P = h->pipe;
+    constexpr int NS = HostPipe::NS;
+    if (!P.init()) return BF_E_DEVICE;
+    hipStream_t s = h->stream;
+    // ---- chunks: whole documents, about host_chunk_bytes each
+    struct Chunk { int64_t d0, d1; };
+    std::vector<Chunk> chunks;
+    int64_t max_bytes = 0, max_docs = 0;
+    for (int64_t d = 0; d < ndocs;) {
+        const int64_t lim = doc_off[d] + h->host_chunk_bytes;
+        int64_t e = (int64_t)(std::upper_bound(doc_off + d + 1, doc_off + ndocs + 1, lim) - doc_off) - 1;      // last boundary <= lim
+        if (e <= d) e = d + 1;                                                                                  // one document larger than a chunk
+        if (e - d > (1ll << 30)) e = d + (1ll << 30);
+        chunks.push_back({d, e});
+        max_bytes = std::max(max_bytes, doc_off[e] - doc_off[d]); max_docs = std::max(max_docs, e - d);
+        d = e;
+    }
+    auto worst_ids = [&](int64_t bytes, int64_t nd) {
+        int64_t w = h->m.kind == KIND_WP ? bytes : (int64_t)(h->m.dict_has_charmap ? 2 : 1) * (bytes + nd);
+        if (max_ids >= 0 && nd * (int64_t)max_ids < w) w = nd * (int64_t)(max_ids < 0 ? 0 : max_ids);
+        return w;
+    };
+    int64_t max_worst = 0;
+    for (const Chunk &c : chunks) max_worst = std::max(max_worst, worst_ids(doc_off[c.d1] - doc_off[c.d0], c.d1 - c.d0));
+    for (int i = 0; i < NS; ++i)
+        if (!P.pin_text[i].reserve((size_t)max_bytes + 16) || !P.pin_off[i].reserve((size_t)(max_docs + 1) * 8) || !P.pin_idoff[i].reserve((size_t)(max_docs + 1) * 8) ||
+            !P.dev_text[i].reserve((size_t)max_bytes + 16) || !P.dev_off[i].reserve((size_t)(max_docs + 1) * 8) || !P.dev_idoff[i].reserve((size_t)(max_docs + 1) * 8) ||
+            !P.dev_ids[i].reserve((size_t)(max_worst + 1) * 4)) return BF_E_DEVICE;
+    if (!reserve_ids_workspaces(h, max_docs, max_bytes, false)) return BF_E_DEVICE;      // no allocation (= device synchronisation) inside the pipeline
+    const int K = (int)chunks.size();
+    std::vector<int64_t> nids_of((size_t)K, 0);
+    const bool trace = getenv("BF_TRACE_HOST") != nullptr;          // stderr: where the wall time of this call went
+    double t_in = 0, t_out = 0, t_wait_cmp = 0, t_meta = 0, t_wait_d2h = 0, t_wait_worker = 0, t_enq = 0;
+    auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t_begin = now();
+    // ---- the way out runs on a second host thread, chunk after chunk: wait for the ids of chunk j in pinned memory, copy them and the
+    //      rebased offsets into the caller's arrays.  `done` = chunks it has finished (their pinned slots are free again).
+    std::mutex wmu; std::condition_variable wcv;
+    int issued = 0, done = 0; bool quit = false;                   // guarded by wmu
+    int64_t base_ids = 0; bool overflow = false; int64_t worker_err = 0;
+    std::thread worker([&] {
+        (void)hipSetDevice(h->device);
+        for (int j = 0;; ++j) {
+            { std::unique_lock<std::mutex> lk(wmu); wcv.wait(lk, [&] { return issued > j || quit; }); if (issued <= j) return; }
+            const int sl = j % NS; const Chunk &c = chunks[(size_t)j]; const int64_t nd = c.d1 - c.d0, nids = nids_of[(size_t)j];
+            const double t0 = now();
+            if (!worker_err && !hip_ok(hipEventSynchronize(P.ev_d2h[sl]), "hipEventSynchronize")) worker_err = BF_E_DEVICE;
+            const double t1 = now(); t_wait_d2h += t1 - t0;
+            if (!worker_err) {
+                if (base_ids + nids > ids_cap) overflow = true;
+                if (nids > 0 && !overflow) {
+                    if (!ids_out) worker_err = BF_E_ARG;
+                    else par_memcpy(ids_out + base_ids, P.pin_ids[sl].p, (size_t)nids * 4);
+                }
+                if (id_off_out) { const int64_t *o = P.pin_idoff[sl].as<int64_t>(); for (int64_t i = 0; i < nd; ++i) id_off_out[c.d0 + i] = base_ids + o[i]; }
+                base_ids += nids;
+            }
+            t_out += now() - t1;
+            { std::lock_guard<std::mutex> lk(wmu); done = j + 1; }
+            wcv.notify_all();
+        }
+    });
+    auto stop_worker = [&] { { std::lock_guard<std::mutex> lk(wmu); quit = true; } wcv.notify_all(); if (worker.joinable()) worker.join(); };
+    auto fail = [&](int64_t rc) { stop_worker(); (void)hipStreamSynchronize(P.s_in); (void)hipStreamSynchronize(s); (void)hipStreamSynchronize(P.s_meta); (void)hipStreamSynchronize(P.s_out); return rc; };
+    int64_t rc_err = 0;
+    // ids of chunk j: device -> pinned, started as soon as its tokenisation is done; the worker takes it from there
+    auto start_out = [&](int j) -> bool {
+        const int sl = j % NS; const Chunk &c = chunks[(size_t)j]; const int64_t nd = c.d1 - c.d0;
+        { const double t0 = now(); std::unique_lock<std::mutex> lk(wmu); wcv.wait(lk, [&] { return done >= j - NS + 1; }); t_wait_worker += now() - t0; }   // pin_idoff[sl] / pin_ids[sl]: chunk j-NS is out
+        const double t0 = now();
+        if (!hip_ok(hipEventSynchronize(P.ev_cmp[sl]), "hipEventSynchronize")) return false;
+        const double t0b = now(); t_wait_cmp += t0b - t0;
+        if (!hip_ok(hipMemcpyAsync(P.pin_idoff[sl].p, P.dev_idoff[sl].p, (size_t)(nd + 1) * 8, hipMemcpyDeviceToHost, P.s_meta), "D2H offsets") ||
+            !hip_ok(hipStreamSynchronize(P.s_meta), "hipStreamSynchronize")) return false;
+        t_meta += now() - t0b;
+        if (P.pin_status.as<int>()[sl] & 2) { rc_err = BF_E_INTERNAL; return false; }
+        const int64_t nids = P.pin_idoff[sl].as<int64_t>()[nd];
+        nids_of[(size_t)j] = nids;
+        if (nids > 0 && ids_out && nids <= ids_cap) {               // (a chunk larger than the whole capacity cannot be delivered anyway)
+            if (!P.pin_ids[sl].reserve((size_t)nids * 4)) return false;
+            if (!hip_ok(hipMemcpyAsync(P.pin_ids[sl].p, P.dev_ids[sl].p, (size_t)nids * 4, hipMemcpyDeviceToHost, P.s_out), "D2H ids")) return false;
+        }
+        if (!hip_ok(hipEventRecord(P.ev_d2h[sl], P.s_out), "hipEventRecord")) return false;
+        { std::lock_guard<std::mutex> lk(wmu); issued = j + 1; }
+        wcv.notify_all();
+        return true;
+    };
+    constexpr int LAG = NS - 1;                                     // the way out of chunk k-LAG starts after chunk k is on its way in
+    for (int k = 0; k < K + LAG; ++k) {
+        if (k < K) {
+            const int sl = k % NS; const Chunk &c = chunks[(size_t)k];
+            const int64_t nd = c.d1 - c.d0, b0 = doc_off[c.d0], bytes = doc_off[c.d1] - b0;
+            if (k >= NS && !hip_ok(hipEventSynchronize(P.ev_h2d[sl]), "hipEventSynchronize")) return fail(BF_E_DEVICE);             // pin_text[sl] / pin_off[sl]: chunk k-NS is on the device
+            const double t0 = now();
+            par_memcpy(P.pin_text[sl].p, text + b0, (size_t)bytes);
+            { int64_t *o = P.pin_off[sl].as<int64_t>(); for (int64_t i = 0; i <= nd; ++i) o[i] = doc_off[c.d0 + i] - b0; }
+            const double t0e = now(); t_in += t0e - t0;
+            if (k >= NS && !hip_ok(hipStreamWaitEvent(P.s_in, P.ev_cmp[sl], 0), "hipStreamWaitEvent")) return fail(BF_E_DEVICE);    // chunk k-NS no longer reads dev_text[sl]
+            if ((bytes > 0 && !hip_ok(hipMemcpyAsync(P.dev_text[sl].p, P.pin_text[sl].p, (size_t)bytes, hipMemcpyHostToDevice, P.s_in), "H2D text")) ||
+                !hip_ok(hipMemcpyAsync(P.dev_off[sl].p, P.pin_off[sl].p, (size_t)(nd + 1) * 8, hipMemcpyHostToDevice, P.s_in), "H2D offsets") ||
+                !hip_ok(hipEventRecord(P.ev_h2d[sl], P.s_in), "hipEventRecord") || !hip_ok(hipStreamWaitEvent(s, P.ev_h2d[sl], 0), "hipStreamWaitEvent")) return fail(BF_E_DEVICE);
+            if (k >= NS && !hip_ok(hipStreamWaitEvent(s, P.ev_d2h[sl], 0), "hipStreamWaitEvent")) return fail(BF_E_DEVICE);        // the ids of chunk k-NS have left dev_ids[sl]
+            const int rc = run_device(h, P.dev_text[sl].as<char>(), P.dev_off[sl].as<int64_t>(), nd, bytes, P.dev_ids[sl].as<int32_t>(), worst_ids(bytes, nd),
+                                      P.dev_idoff[sl].as<int64_t>(), max_ids, unk, s);
+            if (rc != 0) return fail(rc);
+            if (!hip_ok(hipMemcpyAsync(P.pin_status.as<int>() + sl, h->w_misc.as<char>() + 16, 4, hipMemcpyDeviceToHost, s), "D2H status") ||
+                !hip_ok(hipEventRecord(P.ev_cmp[sl], s), "hipEventRecord")) return fail(BF_E_DEVICE);
+            t_enq += now() - t0e;
+        }
+        if (k >= LAG && !start_out(k - LAG)) return fail(rc_err ? rc_err : BF_E_DEVICE);
+    }
+    { const double t0 = now(); std::unique_lock<std::mutex> lk(wmu); wcv.wait(lk, [&] { return done >= K; }); t_wait_worker += now() - t0; }
+    stop_worker();
+    if (!hip_ok(hipStreamSynchronize(s), "hipStreamSynchronize")) return BF_E_DEVICE;
+    if (worker_err) return worker_err;
+    if (id_off_out) id_off_out[ndocs] = base_ids;
+    if (trace) fprintf(stderr, "[blingfire_amd] chunked host batch: %d chunks, %.1f ms; caller's thread: copy-in %.1f, enqueueing %.1f, waiting for tokenisation %.1f, offsets D2H %.1f, waiting for the way out %.1f; "
+                       "second thread: waiting for D2H %.1f, copy-out %.1f\n", K, now() - t_begin, t_in, t_enq, t_wait_cmp, t_meta, t_wait_worker, t_wait_d2h, t_out);
+    return overflow ? BF_E_CAPACITY : base_ids;
+}
+
 int64_t run_host(Handle *h, const char *text, const int64_t *doc_off, int64_t ndocs, int32_t *ids_out, int64_t ids_cap,
                  int64_t *id_off_out, int max_ids, int unk, int32_t *starts_out = nullptr, int32_t *ends_out = nullptr, int words = 0,
                  bool *first_doc_nonempty = nullptr /* words modes: the first document decoded to >= 1 character */)
@@ -326,6 +531,8 @@ int64_t run_host(Handle *h, const char *text, const int64_t *doc_off, int64_t nd
     std::lock_guard<std::mutex> lock(h->mu);
     DeviceGuard dg(h->device); if (!dg.ok) return BF_E_DEVICE;
     hipStream_t s = h->stream;
+    if (!want_off && !words && h->m.kind != KIND_I2W && h->host_chunk_bytes > 0 && total >= 2 * h->host_chunk_bytes && ndocs >= 2)
+        return run_host_chunked(h, text, doc_off, ndocs, ids_out, ids_cap, id_off_out, max_ids, unk);
     // worst-case id count (every id covers >= 1 byte)
     // worst-case id count: _wp ids cover >= 1 byte each; _sp tokens cover >= 1 element of <= mul*(n+1) elements
     int64_t worst = h->m.kind == KIND_WP ? total : (int64_t)(h->m.dict_has_charmap ? 2 : 1) * (total + ndocs);
@@ -1112,6 +1319,16 @@ int BfLastKernelMs(void *p, float *ms, int n)
     int k = n < 5 ? n : 5;
     for (int i = 0; i < k; ++i) ms[i] = v[i];
     return k;
+}
+
+int64_t BfSetHostChunkBytes(void *p, int64_t bytes)
+{
+    Handle *h = as_handle(p);
+    if (!h || bytes < 0) return BF_E_ARG;
+    std::lock_guard<std::mutex> lock(h->mu);
+    const int64_t old = h->host_chunk_bytes;
+    h->host_chunk_bytes = bytes;
+    return old;
 }
 
 int BfLastStatus(void *p)

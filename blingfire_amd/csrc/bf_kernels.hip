@@ -419,7 +419,7 @@ __global__ __launch_bounds__(THREADS) void k_lex_wp_seq(WpLexParams p)
 // enough lanes of the wave are waiting for them (ballot vote), so that they execute with most lanes active.
 // PLAIN: ids only (no TextToWords mode, no offsets): `words` and the span pointer become compile-time constants
 template <int THREADS, class WIN, bool HAS_ANY, int UNROLL, bool STATS, bool TLDS = false, bool TWO = false, bool PLAIN = false>
-__global__ __launch_bounds__(THREADS) void k_lex_wp_flat(WpLexParams p)
+__device__ __forceinline__ void lex_wp_flat_body(const WpLexParams &p)
 {
     extern __shared__ int32_t lex_lds[];
     enum { M_NEED = 0, M_WALK = 1, M_EVENT = 2, M_EXIT = 3 };
@@ -517,6 +517,21 @@ __global__ __launch_bounds__(THREADS) void k_lex_wp_flat(WpLexParams p)
     }
 }
 
+template <int THREADS, class WIN, bool HAS_ANY, int UNROLL, bool STATS, bool TLDS = false, bool TWO = false>
+__global__ __launch_bounds__(THREADS) void k_lex_wp_flat(WpLexParams p)
+{
+    lex_wp_flat_body<THREADS, WIN, HAS_ANY, UNROLL, STATS, TLDS, TWO, false>(p);
+}
+
+// The headline instance (two-level lexer, ids only) at 8 waves per SIMD: the lane program needs 65 VGPRs as the compiler allocates it
+// freely (7 waves) and fits 64 without scratch when asked to.  Measured on MI355X, default workload: tokenise 39.3 ms at 7 waves,
+// 35.2 ms at 8 -- the kernel hides table-gather latency with resident waves.  The other instances would spill (12..44 B of scratch).
+template <int UNROLL>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_lex_wp_plain(WpLexParams p)
+{
+    lex_wp_flat_body<64, ClsWin, false, UNROLL, false, false, true, true>(p);
+}
+
 static size_t lex_lds_bytes(const WpLexParams &p, int threads, bool tlds = false)
 {
     return (((size_t)p.L.max_frames * LEX_FRAME_WORDS + 8) * threads + (size_t)((p.acts_n + 1) & ~1)) * 4 + (tlds ? (size_t)p.table_n * 8 : 0);
@@ -563,44 +578,36 @@ void launch_lex_wp(const WpLexParams &p, int variant, hipStream_t s)
             else hipLaunchKernelGGL((k_lex_wp_flat<TH, ClsWin, false, 3, false, true>), dim3((unsigned)nb), dim3(TH), lds, s, q);
             return;
         }
-        const int usel = (variant >> 30) & 3;                // DFA transitions per vote: 0 = three (default; swept on MI355X), 1 = one, 2 = two, 3 = four
         if (p.L.two_level && !p.stats) {
             // two-level lexers: no saved frames in LDS, cheap events -> a lower event threshold pays (swept on MI355X)
             WpLexParams q2 = q; q2.L.max_frames = 0;
             if (((variant >> 8) & 0xff) == 0) q2.ev_thresh = 16;
             const size_t lds2 = lex_lds_bytes(q2, 64);
+            // transitions per vote: swept on MI355X with the two-level event code (2: 8.50 ms, 3: 7.67, 4: 6.86 on the 1.25 M-doc shard);
+            // bits 20..23 of the variant select 3 or 5 for experiments (ids-only instance)
+            const int un = (variant >> 20) & 0xf;
+            const bool plain = !has_any && !q2.words && !q2.span_tmp && kind != 8;   // variant 8 (experiments): the general instance
             int per_cu = 0;
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_lex_wp_flat<64, ClsWin, false, 4, false, false, true>, 64, lds2) != hipSuccess || per_cu <= 0) per_cu = 16;
+            const hipError_t oe = plain ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_lex_wp_plain<4>, 64, lds2)
+                                        : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_lex_wp_flat<64, ClsWin, false, 4, false, false, true>, 64, lds2);
+            if (oe != hipSuccess || per_cu <= 0) per_cu = 16;
             (void)hipGetLastError();
             if (((variant >> 24) & 0x3f) != 0) per_cu = (variant >> 24) & 0x3f;
             int64_t nb = (int64_t)device_cus() * per_cu;
             if (nb > need) nb = need;
             if (nb < 1) nb = 1;
             const dim3 g2((unsigned)nb), t2(64);
-            // transitions per vote: swept on MI355X with the two-level event code (2: 8.50 ms, 3: 7.67, 4: 6.86 on the 1.25 M-doc shard);
-            // bits 20..23 of the variant select 5..8 for experiments
-            const int un = ((variant >> 20) & 0xf) ? ((variant >> 20) & 0xf) : (usel == 1 ? 1 : usel == 2 ? 2 : usel == 3 ? 4 : 4);
-            const bool plain = !q2.words && !q2.span_tmp && kind != 8;               // variant 8 (experiments): the general instance
             if (has_any) hipLaunchKernelGGL((k_lex_wp_flat<64, ClsWin, true, 1, false, false, true>), g2, t2, lds2, s, q2);
-            else if (plain && un == 4) hipLaunchKernelGGL((k_lex_wp_flat<64, ClsWin, false, 4, false, false, true, true>), g2, t2, lds2, s, q2);
-            else if (plain && un == 5) hipLaunchKernelGGL((k_lex_wp_flat<64, ClsWin, false, 5, false, false, true, true>), g2, t2, lds2, s, q2);
-            else if (plain && un == 3) hipLaunchKernelGGL((k_lex_wp_flat<64, ClsWin, false, 3, false, false, true, true>), g2, t2, lds2, s, q2);
-            else if (un == 1) hipLaunchKernelGGL((k_lex_wp_flat<64, ClsWin, false, 1, false, false, true>), g2, t2, lds2, s, q2);
-            else if (un == 2) hipLaunchKernelGGL((k_lex_wp_flat<64, ClsWin, false, 2, false, false, true>), g2, t2, lds2, s, q2);
-            else if (un == 3) hipLaunchKernelGGL((k_lex_wp_flat<64, ClsWin, false, 3, false, false, true>), g2, t2, lds2, s, q2);
-            else if (un == 5) hipLaunchKernelGGL((k_lex_wp_flat<64, ClsWin, false, 5, false, false, true>), g2, t2, lds2, s, q2);
-            else if (un == 6) hipLaunchKernelGGL((k_lex_wp_flat<64, ClsWin, false, 6, false, false, true>), g2, t2, lds2, s, q2);
-            else if (un == 8) hipLaunchKernelGGL((k_lex_wp_flat<64, ClsWin, false, 8, false, false, true>), g2, t2, lds2, s, q2);
+            else if (plain && un == 5) hipLaunchKernelGGL(k_lex_wp_plain<5>, g2, t2, lds2, s, q2);
+            else if (plain && un == 3) hipLaunchKernelGGL(k_lex_wp_plain<3>, g2, t2, lds2, s, q2);
+            else if (plain) hipLaunchKernelGGL(k_lex_wp_plain<4>, g2, t2, lds2, s, q2);
             else hipLaunchKernelGGL((k_lex_wp_flat<64, ClsWin, false, 4, false, false, true>), g2, t2, lds2, s, q2);
             return;
         }
         const dim3 g((unsigned)blocks), t(64); const size_t lds = lex_lds_bytes(q, 64);
         if (has_any) hipLaunchKernelGGL((k_lex_wp_flat<64, ClsWin, true, 1, false>), g, t, lds, s, q);
         else if (p.stats) hipLaunchKernelGGL((k_lex_wp_flat<64, ClsWin, false, 3, true>), g, t, lds, s, q);
-        else if (usel == 0) hipLaunchKernelGGL((k_lex_wp_flat<64, ClsWin, false, 3, false>), g, t, lds, s, q);
-        else if (usel == 2) hipLaunchKernelGGL((k_lex_wp_flat<64, ClsWin, false, 2, false>), g, t, lds, s, q);
-        else if (usel == 3) hipLaunchKernelGGL((k_lex_wp_flat<64, ClsWin, false, 4, false>), g, t, lds, s, q);
-        else hipLaunchKernelGGL((k_lex_wp_flat<64, ClsWin, false, 1, false>), g, t, lds, s, q);
+        else hipLaunchKernelGGL((k_lex_wp_flat<64, ClsWin, false, 3, false>), g, t, lds, s, q);     // three transitions per vote: swept on MI355X
     }
 }
 
@@ -611,6 +618,75 @@ void launch_lex_wp(const WpLexParams &p, int variant, hipStream_t s)
 __host__ __device__ __forceinline__ int64_t sp_slot(int64_t doc_off_d, int64_t d, int mul) { return (int64_t)mul * (doc_off_d + d); }
 
 __device__ __forceinline__ bool sp_delimish(uint32_t code, uint32_t delim) { return code == 0xFFFDu || code == delim; }
+
+// one 64-byte window of a document, lane = byte: what its characters map to.  Nothing here depends on the windows before it
+// (the whitespace collapse does, and runs afterwards), so the loads and map gathers of several windows are in flight together.
+struct SpWin { uint32_t v; int c; uint32_t first, last; bool ok; };
+
+__device__ __forceinline__ SpWin sp_window(const SpPrepParams &p, const uint32_t *ascii_v, const uint8_t *s, int n, int bom, int q, int lane, bool &bad)
+{
+    const bool in = q < n;
+    uint32_t b0 = 0, b1 = 0, b2 = 0, b3 = 0;
+    if (in) b0 = s[q];
+    bool start = in; bool err = false; int cp = (int)b0;
+    // a window of plain ASCII (most of Latin-script text) needs no UTF-8 decoding at all: every byte is a character
+    // (a continuation byte that straddles INTO the window from a previous lead is >= 0x80 itself, so it takes the full path)
+    if (!p.use_bytes && __any(b0 >= 0x80u)) {
+        // the three bytes on either side come from the neighbouring lanes (one byte load per lane instead of seven); only the
+        // lanes at the edges of the 64-byte window load theirs
+        b1 = __shfl_down(b0, 1, 64); b2 = __shfl_down(b0, 2, 64); b3 = __shfl_down(b0, 3, 64);
+        uint32_t u1 = __shfl_up(b0, 1, 64), u2 = __shfl_up(b0, 2, 64), u3 = __shfl_up(b0, 3, 64);
+        if (lane >= 61) {
+            if (lane + 1 > 63) b1 = q + 1 < n ? s[q + 1] : 0u;
+            if (lane + 2 > 63) b2 = q + 2 < n ? s[q + 2] : 0u;
+            b3 = q + 3 < n ? s[q + 3] : 0u;
+        }
+        if (lane < 3) {
+            if (lane < 1) u1 = q - 1 >= bom ? s[q - 1] : 0x80u;
+            if (lane < 2) u2 = q - 2 >= bom ? s[q - 2] : 0x80u;
+            u3 = q - 3 >= bom ? s[q - 3] : 0x80u;
+        }
+        const bool cont = (b0 & 0xC0) == 0x80;
+        start = in && !cont;
+        if (in && cont) {
+            const uint32_t p1 = (q - 1 >= bom) ? u1 : 0x80u, p2 = (q - 2 >= bom) ? u2 : 0x80u, p3 = (q - 3 >= bom) ? u3 : 0x80u;
+            bool ok;
+            if ((p1 & 0xC0) != 0x80) ok = (q - 1 >= bom) && p1 >= 0xC0;
+            else if ((p2 & 0xC0) != 0x80) ok = (q - 2 >= bom) && p2 >= 0xE0;
+            else if ((p3 & 0xC0) != 0x80) ok = (q - 3 >= bom) && p3 >= 0xF0;
+            else ok = false;
+            err = !ok;
+        } else if (start && b0 >= 0x80) {
+            int len;
+            if ((b0 & 0xE0) == 0xC0) { len = 2; cp = (int)(b0 & 0x1F); }
+            else if ((b0 & 0xF0) == 0xE0) { len = 3; cp = (int)(b0 & 0x0F); }
+            else if ((b0 & 0xF8) == 0xF0) { len = 4; cp = (int)(b0 & 0x07); }
+            else { len = 1; err = true; }
+            if (q + len > n) err = true;
+            if (len >= 2) { if ((b1 & 0xC0) != 0x80) err = true; cp = (cp << 6) | (int)(b1 & 0x3F); }
+            if (len >= 3) { if ((b2 & 0xC0) != 0x80) err = true; cp = (cp << 6) | (int)(b2 & 0x3F); }
+            if (len >= 4) { if ((b3 & 0xC0) != 0x80) err = true; cp = (cp << 6) | (int)(b3 & 0x3F); }
+            const int need = cp <= 0x7F ? 1 : cp <= 0x7FF ? 2 : cp <= 0xFFFF ? 3 : cp <= 0x10FFFF ? 4 : 0;
+            if (need != len) err = true;
+            if ((cp & 0xFFFFF800) == 0xD800) err = true;
+            if (err) cp = 0;
+        }
+        if (__any(err)) bad = true;
+    }
+    // ---- elements of this character
+    SpWin w; w.v = 0xFFFFu; w.c = 0; w.ok = start && !err;
+    if (w.ok) {
+        if (cp < 0x80) w.v = ascii_v[cp]; else w.v = cpmap_get(p.cpmap, cp);
+        w.c = (w.v & 0x80000000u) ? (int)p.multi_pool[w.v & 0x7FFFFFFFu] : 1;
+    }
+    const uint16_t *rec = p.multi_pool + (w.v & 0x7FFFFFFFu) + 1;
+    const bool multi = (w.v & 0x80000000u) != 0;
+    w.first = w.c > 0 ? (multi ? (uint32_t)rec[0] : w.v) : 0u;
+    w.last = w.c > 0 ? (multi ? (uint32_t)rec[w.c - 1] : w.v) : 0u;
+    return w;
+}
+
+constexpr int SP_PREP_WINDOWS = 4;      // windows whose loads / map gathers are issued before the (sequential) collapse pass
 
 __global__ __launch_bounds__(256) void k_prep_sp(SpPrepParams p)
 {
@@ -645,104 +721,60 @@ __global__ __launch_bounds__(256) void k_prep_sp(SpPrepParams p)
         }
         bool bad = false;
         while (pos < n) {
-            const int q = pos + lane;
-            const bool in = q < n;
-            uint32_t b0 = 0, b1 = 0, b2 = 0, b3 = 0;
-            if (in) b0 = s[q];
-            bool start = in; bool err = false; int cp = (int)b0;
-            // a window of plain ASCII (most of Latin-script text) needs no UTF-8 decoding at all: every byte is a character
-            // (a continuation byte that straddles INTO the window from a previous lead is >= 0x80 itself, so it takes the full path)
-            if (!p.use_bytes && __any(b0 >= 0x80u)) {
-                // the three bytes on either side come from the neighbouring lanes (one byte load per lane instead of seven); only the
-                // lanes at the edges of the 64-byte window load theirs
-                b1 = __shfl_down(b0, 1, 64); b2 = __shfl_down(b0, 2, 64); b3 = __shfl_down(b0, 3, 64);
-                uint32_t u1 = __shfl_up(b0, 1, 64), u2 = __shfl_up(b0, 2, 64), u3 = __shfl_up(b0, 3, 64);
-                if (lane >= 61) {
-                    if (lane + 1 > 63) b1 = q + 1 < n ? s[q + 1] : 0u;
-                    if (lane + 2 > 63) b2 = q + 2 < n ? s[q + 2] : 0u;
-                    b3 = q + 3 < n ? s[q + 3] : 0u;
-                }
-                if (lane < 3) {
-                    if (lane < 1) u1 = q - 1 >= bom ? s[q - 1] : 0x80u;
-                    if (lane < 2) u2 = q - 2 >= bom ? s[q - 2] : 0x80u;
-                    u3 = q - 3 >= bom ? s[q - 3] : 0x80u;
-                }
-                const bool cont = (b0 & 0xC0) == 0x80;
-                start = in && !cont;
-                if (in && cont) {
-                    const uint32_t p1 = (q - 1 >= bom) ? u1 : 0x80u, p2 = (q - 2 >= bom) ? u2 : 0x80u, p3 = (q - 3 >= bom) ? u3 : 0x80u;
-                    bool ok;
-                    if ((p1 & 0xC0) != 0x80) ok = (q - 1 >= bom) && p1 >= 0xC0;
-                    else if ((p2 & 0xC0) != 0x80) ok = (q - 2 >= bom) && p2 >= 0xE0;
-                    else if ((p3 & 0xC0) != 0x80) ok = (q - 3 >= bom) && p3 >= 0xF0;
-                    else ok = false;
-                    err = !ok;
-                } else if (start && b0 >= 0x80) {
-                    int len;
-                    if ((b0 & 0xE0) == 0xC0) { len = 2; cp = (int)(b0 & 0x1F); }
-                    else if ((b0 & 0xF0) == 0xE0) { len = 3; cp = (int)(b0 & 0x0F); }
-                    else if ((b0 & 0xF8) == 0xF0) { len = 4; cp = (int)(b0 & 0x07); }
-                    else { len = 1; err = true; }
-                    if (q + len > n) err = true;
-                    if (len >= 2) { if ((b1 & 0xC0) != 0x80) err = true; cp = (cp << 6) | (int)(b1 & 0x3F); }
-                    if (len >= 3) { if ((b2 & 0xC0) != 0x80) err = true; cp = (cp << 6) | (int)(b2 & 0x3F); }
-                    if (len >= 4) { if ((b3 & 0xC0) != 0x80) err = true; cp = (cp << 6) | (int)(b3 & 0x3F); }
-                    const int need = cp <= 0x7F ? 1 : cp <= 0x7FF ? 2 : cp <= 0xFFFF ? 3 : cp <= 0x10FFFF ? 4 : 0;
-                    if (need != len) err = true;
-                    if ((cp & 0xFFFFF800) == 0xD800) err = true;
-                    if (err) cp = 0;
-                }
-                if (__any(err)) bad = true;
+            // ---- the next SP_PREP_WINDOWS windows: bytes -> characters -> map entries (independent of each other)
+            SpWin win[SP_PREP_WINDOWS];
+#pragma unroll
+            for (int wi = 0; wi < SP_PREP_WINDOWS; ++wi) {
+                win[wi].v = 0xFFFFu; win[wi].c = 0; win[wi].first = win[wi].last = 0; win[wi].ok = false;
+                if (pos + 64 * wi < n) win[wi] = sp_window(p, ascii_v, s, n, bom, pos + 64 * wi + lane, lane, bad);
             }
-            // ---- elements of this character
-            uint32_t v = 0xFFFFu; int c = 0;
-            if (start && !err) {
-                if (cp < 0x80) v = ascii_v[cp]; else v = cpmap_get(p.cpmap, cp);
-                c = (v & 0x80000000u) ? (int)p.multi_pool[v & 0x7FFFFFFFu] : 1;
-            }
-            const uint16_t *rec = p.multi_pool + (v & 0x7FFFFFFFu) + 1;
-            const bool multi = (v & 0x80000000u) != 0;
-            const uint32_t first = c > 0 ? (multi ? (uint32_t)rec[0] : v) : 0u;
-            const uint32_t last = c > 0 ? (multi ? (uint32_t)rec[c - 1] : v) : 0u;
-            // previous element = last element of the nearest earlier lane that produced any, else the carry
-            const unsigned long long m_has = __ballot(c > 0);
-            const unsigned long long below = m_has & lanemask_lt();
-            const int pl = below ? 63 - __clzll((long long)below) : 0;
-            const uint32_t pl_last = __shfl(last, pl, 64);
-            uint32_t pe = below ? pl_last : prev;
-            bool hp = below ? true : have_prev;
-            // keep flags
-            int kept = 0;
-            {
-                uint32_t e = first;
-                for (int k = 0; k < c; ++k) {
-                    if (k > 0) e = rec[k];
-                    const bool ws = e == 0xFFFDu;
-                    if (!ws || !hp || !sp_delimish(pe, D)) ++kept;
-                    pe = e; hp = true;
+            // ---- whitespace collapse and output, window after window (carry: prev element, output count)
+#pragma unroll
+            for (int wi = 0; wi < SP_PREP_WINDOWS; ++wi) {
+                if (!(pos + 64 * wi < n)) break;
+                const int q = pos + 64 * wi + lane;
+                const uint32_t v = win[wi].v; const int c = win[wi].c; const uint32_t first = win[wi].first, last = win[wi].last;
+                const uint16_t *rec = p.multi_pool + (v & 0x7FFFFFFFu) + 1;
+                // previous element = last element of the nearest earlier lane that produced any, else the carry
+                const unsigned long long m_has = __ballot(c > 0);
+                const unsigned long long below = m_has & lanemask_lt();
+                const int pl = below ? 63 - __clzll((long long)below) : 0;
+                const uint32_t pl_last = __shfl(last, pl, 64);
+                uint32_t pe = below ? pl_last : prev;
+                bool hp = below ? true : have_prev;
+                // keep flags
+                int kept = 0;
+                {
+                    uint32_t e = first;
+                    for (int k = 0; k < c; ++k) {
+                        if (k > 0) e = rec[k];
+                        const bool ws = e == 0xFFFDu;
+                        if (!ws || !hp || !sp_delimish(pe, D)) ++kept;
+                        pe = e; hp = true;
+                    }
                 }
-            }
-            // prefix sum of the kept counts: almost always every lane keeps 0 or 1 element -> one ballot instead of a 6-step scan
-            const bool any_multi = __any(c > 1);
-            int inc;
-            if (!any_multi) inc = __popcll(__ballot(kept != 0) & (lanemask_lt() | (1ull << lane)));
-            else inc = wave_incl_scan(kept);
-            int idx = outc + inc - kept;
-            {
-                uint32_t pe2 = below ? pl_last : prev; bool hp2 = below ? true : have_prev;
-                uint32_t e = first;
-                for (int k = 0; k < c; ++k) {
-                    if (k > 0) e = rec[k];
-                    const bool ws = e == 0xFFFDu;
-                    if (!ws || !hp2 || !sp_delimish(pe2, D)) { if (idx < cap) { out[idx] = (uint16_t)(ws ? D : e); if (p.src_off) p.src_off[sp_slot(b, d, p.slot_mul) + idx] = q; } ++idx; }
-                    pe2 = e; hp2 = true;
+                // prefix sum of the kept counts: almost always every lane keeps 0 or 1 element -> one ballot instead of a 6-step scan
+                const bool any_multi = __any(c > 1);
+                int inc;
+                if (!any_multi) inc = __popcll(__ballot(kept != 0) & (lanemask_lt() | (1ull << lane)));
+                else inc = wave_incl_scan(kept);
+                int idx = outc + inc - kept;
+                {
+                    uint32_t pe2 = below ? pl_last : prev; bool hp2 = below ? true : have_prev;
+                    uint32_t e = first;
+                    for (int k = 0; k < c; ++k) {
+                        if (k > 0) e = rec[k];
+                        const bool ws = e == 0xFFFDu;
+                        if (!ws || !hp2 || !sp_delimish(pe2, D)) { if (idx < cap) { out[idx] = (uint16_t)(ws ? D : e); if (p.src_off) p.src_off[sp_slot(b, d, p.slot_mul) + idx] = q; } ++idx; }
+                        pe2 = e; hp2 = true;
+                    }
                 }
+                outc += __shfl(inc, 63, 64);
+                normc += any_multi ? __shfl(wave_incl_scan(c), 63, 64) : __popcll(m_has);
+                decoded += __popcll(__ballot(win[wi].ok));
+                if (m_has) { const int hl = 63 - __clzll((long long)m_has); prev = __shfl(last, hl, 64); have_prev = true; }
             }
-            outc += __shfl(inc, 63, 64);
-            normc += any_multi ? __shfl(wave_incl_scan(c), 63, 64) : __popcll(m_has);
-            decoded += __popcll(__ballot(start && !err));
-            if (m_has) { const int hl = 63 - __clzll((long long)m_has); prev = __shfl(last, hl, 64); have_prev = true; }
-            pos += 64;
+            pos += 64 * SP_PREP_WINDOWS;
         }
         int len = outc;
         if (len > 1 && have_prev && sp_delimish(prev, D)) --len;                          // tokdll:1491-1493

@@ -245,7 +245,6 @@ struct LexLane {
                 j += k;
                 if (L.loop_final) { fp = j - 1; finfo = L.loop_info; }
                 if (!(j < lim)) return false;
-                if (j < fn_) cls_at.prefetch(off + j);
             }
         }
         return true;

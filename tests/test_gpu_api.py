@@ -191,3 +191,44 @@ def test_single_document_calls_from_many_threads_are_combined_correctly():
         t.join()
     bf.free_model(h)
     assert not errs, errs[:5]
+
+
+@pytest.mark.parametrize("model", ["bert_base_tok.bin", "xlnet.bin", "gpt2.bin"])
+def test_chunked_host_batch_equals_unchunked(model):
+    """TextToIdsBatch on host buffers cuts large batches into chunks that flow through pinned staging (bf_capi.cpp run_host_chunked);
+    with a tiny chunk size the boundaries fall everywhere -- ids and offsets must be those of the unchunked path and of the oracle,
+    including empty documents at chunk edges, a document larger than a chunk, and the capacity error"""
+    if not bfutil.have_model(model):
+        pytest.skip("%s not present" % model)
+    L = bf.lib()
+    L.BfSetHostChunkBytes.restype = ctypes.c_int64
+    L.BfSetHostChunkBytes.argtypes = [ctypes.c_void_p, ctypes.c_int64]
+    h = bf.load_model(bfutil.model_path(model))
+    try:
+        docs = bfutil.fuzz_docs(3000, seed=5) + [b""] * 3 + [b"one big document " * 400] + [b"", b"tail"]
+        text, off = bf.pack_docs(docs)
+        old = L.BfSetHostChunkBytes(ctypes.c_void_p(h), 0)
+        assert old == 64 << 20
+        want_ids, want_off = bf.text_to_ids_batch(h, (text, off), 48, 7)
+        ora = bfutil.oracle()
+        ho = ora.load(bfutil.model_path(model))
+        gids, goff = ora.batch(ho, text, off, 48, 7)
+        ora.free(ho)
+        assert np.array_equal(want_ids, gids) and np.array_equal(want_off, goff)
+        for chunk in (1, 700, 4096, 50000):
+            L.BfSetHostChunkBytes(ctypes.c_void_p(h), chunk)
+            for _ in range(2):                                   # twice: staging buffers are reused
+                ids, ioff = bf.text_to_ids_batch(h, (text, off), 48, 7)
+                assert np.array_equal(ids, want_ids) and np.array_equal(ioff, want_off), (model, chunk)
+        # a sub-range of a larger buffer (doc_offsets[0] != 0)
+        sub = off[100:2001].copy()
+        L.BfSetHostChunkBytes(ctypes.c_void_p(h), 2000)
+        ids, ioff = bf.text_to_ids_batch(h, (text, sub), 48, 7)
+        assert np.array_equal(ids, want_ids[want_off[100]:want_off[2000]]) and np.array_equal(ioff, want_off[100:2001] - want_off[100])
+        # capacity error: offsets are still complete
+        small = np.zeros(100, dtype=np.int32)
+        ioff = np.zeros(len(off), dtype=np.int64)
+        r = L.TextToIdsBatch(ctypes.c_void_p(h), text.ctypes.data, off.ctypes.data, len(off) - 1, small.ctypes.data, 100, ioff.ctypes.data, 48, 7)
+        assert r == -3 and np.array_equal(ioff, want_off)
+    finally:
+        bf.free_model(h)
