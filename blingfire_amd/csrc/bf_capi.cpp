@@ -152,7 +152,7 @@ struct Handle {
     hipEvent_t ev[EV_COUNT] = {};
     bool ev_valid = false;
     HostPipe pipe;                                              // chunked host-buffer path (run_host_chunked)
-    int64_t host_chunk_bytes = 64ll << 20;                      // its chunk size (BfSetHostChunkBytes; 0 = never chunk)
+    int64_t host_chunk_bytes = 128ll << 20;                     // its largest chunk (BfSetHostChunkBytes; 0 = never chunk); batches of at least this size take it
     ~Handle()
     {
         pipe.release();
@@ -406,8 +406,12 @@ int64_t run_host_chunked(Handle *h, const char *text, const int64_t *doc_off, in
     struct Chunk { int64_t d0, d1; };
     std::vector<Chunk> chunks;
     int64_t max_bytes = 0, max_docs = 0;
+    // every chunk costs about a millisecond of stream hand-overs on top of its copies (measured on MI355X: 16 / 32 / 64 / 128 MiB chunks
+    // -> 22 / 39 / 60 / 66 M docs/s on the 640 MB sample of the default workload), so chunks are large -- but at least five per batch
+    const int64_t total_bytes = doc_off[ndocs] - doc_off[0];
+    const int64_t chunk_bytes = std::min(h->host_chunk_bytes, std::max(h->host_chunk_bytes / 2, total_bytes / 5));
     for (int64_t d = 0; d < ndocs;) {
-        const int64_t lim = doc_off[d] + h->host_chunk_bytes;
+        const int64_t lim = doc_off[d] + chunk_bytes;
         int64_t e = (int64_t)(std::upper_bound(doc_off + d + 1, doc_off + ndocs + 1, lim) - doc_off) - 1;      // last boundary <= lim
         if (e <= d) e = d + 1;                                                                                  // one document larger than a chunk
         if (e - d > (1ll << 30)) e = d + (1ll << 30);
@@ -531,7 +535,7 @@ int64_t run_host(Handle *h, const char *text, const int64_t *doc_off, int64_t nd
     std::lock_guard<std::mutex> lock(h->mu);
     DeviceGuard dg(h->device); if (!dg.ok) return BF_E_DEVICE;
     hipStream_t s = h->stream;
-    if (!want_off && !words && h->m.kind != KIND_I2W && h->host_chunk_bytes > 0 && total >= 2 * h->host_chunk_bytes && ndocs >= 2)
+    if (!want_off && !words && h->m.kind != KIND_I2W && h->host_chunk_bytes > 0 && total >= h->host_chunk_bytes && ndocs >= 2)
         return run_host_chunked(h, text, doc_off, ndocs, ids_out, ids_cap, id_off_out, max_ids, unk);
     // worst-case id count (every id covers >= 1 byte)
     // worst-case id count: _wp ids cover >= 1 byte each; _sp tokens cover >= 1 element of <= mul*(n+1) elements

@@ -10,7 +10,8 @@ BF_API int BfLexStats(void *ModelPtr, unsigned long long *out, int n);
 /* selects a kernel variant (3 = default): lexer 1 = sequential driver, 4 = no loop-state fast-forward, 5 = no LDS-resident table;
  * Unigram 1 = sequential, 2 = flat, 6 = round-1 ring kernel; bits 8.. carry tuning values.  Returns the previous value. */
 BF_API int BfSetVariant(void *ModelPtr, int variant);
-/* chunk size of the pipelined host-buffer path of TextToIdsBatch (default 64 MiB; batches of at least two chunks take it; 0 = never).
+/* largest chunk of the pipelined host-buffer path of TextToIdsBatch (default 128 MiB; batches of at least that size take it, cut into
+ * chunks of half to all of it; 0 = never).
  * Tests use small values to put chunk boundaries everywhere.  Returns the previous value. */
 BF_API int64_t BfSetHostChunkBytes(void *ModelPtr, int64_t bytes);
 }

@@ -740,37 +740,46 @@ __global__ __launch_bounds__(256) void k_prep_sp(SpPrepParams p)
                 const unsigned long long below = m_has & lanemask_lt();
                 const int pl = below ? 63 - __clzll((long long)below) : 0;
                 const uint32_t pl_last = __shfl(last, pl, 64);
-                uint32_t pe = below ? pl_last : prev;
-                bool hp = below ? true : have_prev;
-                // keep flags
-                int kept = 0;
-                {
-                    uint32_t e = first;
-                    for (int k = 0; k < c; ++k) {
-                        if (k > 0) e = rec[k];
-                        const bool ws = e == 0xFFFDu;
-                        if (!ws || !hp || !sp_delimish(pe, D)) ++kept;
-                        pe = e; hp = true;
-                    }
-                }
-                // prefix sum of the kept counts: almost always every lane keeps 0 or 1 element -> one ballot instead of a 6-step scan
+                const uint32_t pe0 = below ? pl_last : prev;
+                const bool hp0 = below ? true : have_prev;
                 const bool any_multi = __any(c > 1);
-                int inc;
-                if (!any_multi) inc = __popcll(__ballot(kept != 0) & (lanemask_lt() | (1ull << lane)));
-                else inc = wave_incl_scan(kept);
-                int idx = outc + inc - kept;
-                {
-                    uint32_t pe2 = below ? pl_last : prev; bool hp2 = below ? true : have_prev;
-                    uint32_t e = first;
-                    for (int k = 0; k < c; ++k) {
-                        if (k > 0) e = rec[k];
-                        const bool ws = e == 0xFFFDu;
-                        if (!ws || !hp2 || !sp_delimish(pe2, D)) { if (idx < cap) { out[idx] = (uint16_t)(ws ? D : e); if (p.src_off) p.src_off[sp_slot(b, d, p.slot_mul) + idx] = q; } ++idx; }
-                        pe2 = e; hp2 = true;
+                if (!any_multi) {
+                    // the common window: every character is one element (or none) -- straight-line, one ballot for the output positions
+                    const bool ws = first == 0xFFFDu;
+                    const bool keep = c > 0 && (!ws || !hp0 || !sp_delimish(pe0, D));
+                    const unsigned long long m_keep = __ballot(keep);
+                    const int idx = outc + __popcll(m_keep & lanemask_lt());
+                    if (keep && idx < cap) { out[idx] = (uint16_t)(ws ? D : first); if (p.src_off) p.src_off[sp_slot(b, d, p.slot_mul) + idx] = q; }
+                    outc += __popcll(m_keep);
+                    normc += __popcll(m_has);
+                } else {
+                    uint32_t pe = pe0; bool hp = hp0;
+                    // keep flags
+                    int kept = 0;
+                    {
+                        uint32_t e = first;
+                        for (int k = 0; k < c; ++k) {
+                            if (k > 0) e = rec[k];
+                            const bool ws = e == 0xFFFDu;
+                            if (!ws || !hp || !sp_delimish(pe, D)) ++kept;
+                            pe = e; hp = true;
+                        }
                     }
+                    const int inc = wave_incl_scan(kept);
+                    int idx = outc + inc - kept;
+                    {
+                        uint32_t pe2 = pe0; bool hp2 = hp0;
+                        uint32_t e = first;
+                        for (int k = 0; k < c; ++k) {
+                            if (k > 0) e = rec[k];
+                            const bool ws = e == 0xFFFDu;
+                            if (!ws || !hp2 || !sp_delimish(pe2, D)) { if (idx < cap) { out[idx] = (uint16_t)(ws ? D : e); if (p.src_off) p.src_off[sp_slot(b, d, p.slot_mul) + idx] = q; } ++idx; }
+                            pe2 = e; hp2 = true;
+                        }
+                    }
+                    outc += __shfl(inc, 63, 64);
+                    normc += __shfl(wave_incl_scan(c), 63, 64);
                 }
-                outc += __shfl(inc, 63, 64);
-                normc += any_multi ? __shfl(wave_incl_scan(c), 63, 64) : __popcll(m_has);
                 decoded += __popcll(__ballot(win[wi].ok));
                 if (m_has) { const int hl = 63 - __clzll((long long)m_has); prev = __shfl(last, hl, 64); have_prev = true; }
             }

@@ -208,7 +208,7 @@ def test_chunked_host_batch_equals_unchunked(model):
         docs = bfutil.fuzz_docs(3000, seed=5) + [b""] * 3 + [b"one big document " * 400] + [b"", b"tail"]
         text, off = bf.pack_docs(docs)
         old = L.BfSetHostChunkBytes(ctypes.c_void_p(h), 0)
-        assert old == 64 << 20
+        assert old == 128 << 20
         want_ids, want_off = bf.text_to_ids_batch(h, (text, off), 48, 7)
         ora = bfutil.oracle()
         ho = ora.load(bfutil.model_path(model))
