@@ -347,6 +347,50 @@ struct ClsWin {
     }
 };
 
+// The same window over 32 bytes = 16 elements (two aligned 16-byte loads): half the refills, and a word that is read twice (top
+// level, then the vocabulary function) usually stays inside it.  Costs four more VGPRs; used by the headline instance only.
+struct ClsWin32 {
+    const uint4 *cls16; int64_t blk0; int shift; uint4 w0, w1; int tag;
+    __device__ __forceinline__ void init(const uint16_t *cls_buf, int64_t elem_off)
+    {
+        cls16 = (const uint4 *)cls_buf; blk0 = (elem_off >> 4) * 2; shift = (int)(elem_off & 15); tag = -1; w0 = w1 = make_uint4(0, 0, 0, 0);
+    }
+    __device__ __forceinline__ void load(int t) { const uint4 *q = cls16 + blk0 + 2 * (int64_t)t; w0 = q[0]; w1 = q[1]; tag = t; }
+    __device__ __forceinline__ uint32_t operator()(int i)
+    {
+        const int a = i + shift, t = a >> 4;
+        if (t != tag) load(t);
+        const bool hi = (a & 8) != 0, up = (a & 4) != 0;
+        const uint32_t x = hi ? w1.x : w0.x, y = hi ? w1.y : w0.y, z = hi ? w1.z : w0.z, w = hi ? w1.w : w0.w;
+        const uint32_t d0 = up ? z : x, d1 = up ? w : y;
+        return __builtin_amdgcn_perm(d1, d0, 0x0c0c0100u + 0x0202u * (uint32_t)(a & 3));
+    }
+    __device__ __forceinline__ void prefetch(int i)
+    {
+        const int t = (i + shift) >> 4;
+        if (t != tag) load(t);
+    }
+    __device__ __forceinline__ bool has(int i) const { return ((i + shift) >> 4) == tag; }
+    // number of consecutive elements flagged LX_C_LOOP starting at position i, as far as the window shows (0 .. 16)
+    __device__ __forceinline__ int run(int i)
+    {
+        const int a = i + shift, t = a >> 4;
+        if (t != tag) load(t);
+        const unsigned long long lo = ((unsigned long long)(~__builtin_amdgcn_perm(w0.w, w0.z, 0x07050301u) & 0x40404040u) << 32) |
+                                      (~__builtin_amdgcn_perm(w0.y, w0.x, 0x07050301u) & 0x40404040u);
+        const unsigned long long hi = ((unsigned long long)(~__builtin_amdgcn_perm(w1.w, w1.z, 0x07050301u) & 0x40404040u) << 32) |
+                                      (~__builtin_amdgcn_perm(w1.y, w1.x, 0x07050301u) & 0x40404040u);
+        const int e = a & 15;
+        if (e < 8) {
+            const unsigned long long c = lo >> (8 * e);
+            if (c) return __builtin_ctzll(c) >> 3;
+            return (8 - e) + (hi ? (__builtin_ctzll(hi) >> 3) : 8);
+        }
+        const unsigned long long c = hi >> (8 * (e - 8));
+        return c ? (__builtin_ctzll(c) >> 3) : 16 - e;
+    }
+};
+
 // saved frames in LDS, structure-of-arrays (bank = lane): word (d, field) of lane t at [(d*12 + field) * nthreads + t]
 struct FramesLds {
     int32_t *lds; int nthreads;
@@ -532,7 +576,7 @@ __global__ __launch_bounds__(THREADS) void k_lex_wp_flat(WpLexParams p)
 template <int UNROLL>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_lex_wp_plain(WpLexParams p)
 {
-    lex_wp_flat_body<64, ClsWin, false, UNROLL, false, false, true, true>(p);
+    lex_wp_flat_body<64, ClsWin32, false, UNROLL, false, false, true, true>(p);
 }
 
 static size_t lex_lds_bytes(const WpLexParams &p, int threads, bool tlds = false)
