@@ -392,6 +392,8 @@ void par_memcpy(void *dst, const void *src, size_t n)
     for (auto &x : th) x.join();
 }
 
+constexpr int64_t HOST_PIPE_UNAVAILABLE = INT64_MIN;      // run_host_chunked could not set up its staging: the caller takes the one-copy path
+
 // The chunked form of run_host (ids only).  Same results as one TextToIdsBatchDevice call over the whole batch: documents are
 // independent, chunk boundaries are document boundaries.  Returns the number of ids or a BF_E_* code; id_off_out (if given) is
 // complete even when the ids do not fit ids_cap (BF_E_CAPACITY), like the unchunked path.
@@ -400,7 +402,7 @@ int64_t run_host_chunked(Handle *h, const char *text, const int64_t *doc_off, in
 {
     HostPipe &P = h->pipe;
     constexpr int NS = HostPipe::NS;
-    if (!P.init()) return BF_E_DEVICE;
+    if (!P.init()) return HOST_PIPE_UNAVAILABLE;
     hipStream_t s = h->stream;
     // ---- chunks: whole documents, about host_chunk_bytes each
     struct Chunk { int64_t d0, d1; };
@@ -429,7 +431,7 @@ int64_t run_host_chunked(Handle *h, const char *text, const int64_t *doc_off, in
     for (int i = 0; i < NS; ++i)
         if (!P.pin_text[i].reserve((size_t)max_bytes + 16) || !P.pin_off[i].reserve((size_t)(max_docs + 1) * 8) || !P.pin_idoff[i].reserve((size_t)(max_docs + 1) * 8) ||
             !P.dev_text[i].reserve((size_t)max_bytes + 16) || !P.dev_off[i].reserve((size_t)(max_docs + 1) * 8) || !P.dev_idoff[i].reserve((size_t)(max_docs + 1) * 8) ||
-            !P.dev_ids[i].reserve((size_t)(max_worst + 1) * 4)) return BF_E_DEVICE;
+            !P.dev_ids[i].reserve((size_t)(max_worst + 1) * 4)) return HOST_PIPE_UNAVAILABLE;   // (page-locked memory is a limited resource)
     if (!reserve_ids_workspaces(h, max_docs, max_bytes, false)) return BF_E_DEVICE;      // no allocation (= device synchronisation) inside the pipeline
     const int K = (int)chunks.size();
     std::vector<int64_t> nids_of((size_t)K, 0);
@@ -535,9 +537,10 @@ int64_t run_host(Handle *h, const char *text, const int64_t *doc_off, int64_t nd
     std::lock_guard<std::mutex> lock(h->mu);
     DeviceGuard dg(h->device); if (!dg.ok) return BF_E_DEVICE;
     hipStream_t s = h->stream;
-    if (!want_off && !words && h->m.kind != KIND_I2W && h->host_chunk_bytes > 0 && total >= h->host_chunk_bytes && ndocs >= 2)
-        return run_host_chunked(h, text, doc_off, ndocs, ids_out, ids_cap, id_off_out, max_ids, unk);
-    // worst-case id count (every id covers >= 1 byte)
+    if (!want_off && !words && h->m.kind != KIND_I2W && h->host_chunk_bytes > 0 && total >= h->host_chunk_bytes && ndocs >= 2) {
+        const int64_t r = run_host_chunked(h, text, doc_off, ndocs, ids_out, ids_cap, id_off_out, max_ids, unk);
+        if (r != HOST_PIPE_UNAVAILABLE) return r;
+    }
     // worst-case id count: _wp ids cover >= 1 byte each; _sp tokens cover >= 1 element of <= mul*(n+1) elements
     int64_t worst = h->m.kind == KIND_WP ? total : (int64_t)(h->m.dict_has_charmap ? 2 : 1) * (total + ndocs);
     if (max_ids >= 0 && ndocs * (int64_t)max_ids < worst) worst = ndocs * (int64_t)(max_ids < 0 ? 0 : max_ids);
