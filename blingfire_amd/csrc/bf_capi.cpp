@@ -141,6 +141,7 @@ struct Handle {
     bool dict_ready = false;
     DevBuf w_keys, w_keyoff, w_dids, w_dret, w_vals;              // DictGetInfoBatch staging
     DevBuf w_s1, w_s2, w_s3, w_s4, w_perm, w_hist, w_narcs;      // _sp scratch
+    DevBuf w_big;                                                // BPE: pool of the documents beyond the per-document arc reserve (k_bpe_big)
     // workspaces
     DevBuf w_cls, w_nchars, w_tmp, w_counts, w_bsums, w_misc, w_flags, w_out, w_outoff;   // w_misc: [0] next_doc (u64), [2] status (int)
     DevBuf w_text, w_docoff, w_ids, w_idoff, w_starts, w_ends;  // host-API staging
@@ -156,7 +157,7 @@ struct Handle {
     ~Handle()
     {
         pipe.release();
-        for (DevBuf *b : {&t_dk_l1, &t_dk_pages, &t_dn_l1, &t_dn_pages, &t_dn_pool, &t_k2i, &t_rows, &w_keys, &w_keyoff, &w_dids, &w_dret, &w_vals, &t_i2w_off, &t_i2w_data, &t_wbd, &t_info, &t_acts, &t_cp_l1, &t_cp_pages, &t_multi, &t_wcp_l1, &t_wcp_pages, &t_dict, &t_seginfo, &w_s1, &w_s2, &w_s3, &w_s4, &w_perm, &w_hist, &w_narcs, &w_cls, &w_nchars, &w_tmp, &w_counts, &w_flags, &w_out, &w_outoff,
+        for (DevBuf *b : {&t_dk_l1, &t_dk_pages, &t_dn_l1, &t_dn_pages, &t_dn_pool, &t_k2i, &t_rows, &w_keys, &w_keyoff, &w_dids, &w_dret, &w_vals, &t_i2w_off, &t_i2w_data, &t_wbd, &t_info, &t_acts, &t_cp_l1, &t_cp_pages, &t_multi, &t_wcp_l1, &t_wcp_pages, &t_dict, &t_seginfo, &w_s1, &w_s2, &w_s3, &w_s4, &w_big, &w_perm, &w_hist, &w_narcs, &w_cls, &w_nchars, &w_tmp, &w_counts, &w_flags, &w_out, &w_outoff,
                           &w_bsums, &w_misc, &w_text, &w_docoff, &w_ids, &w_idoff, &w_starts, &w_ends, &w_srcoff, &w_span}) b->release();
         for (auto &e : ev) if (e) (void)hipEventDestroy(e);
         if (stream) (void)hipStreamDestroy(stream);
@@ -263,6 +264,8 @@ Handle *make_handle(const uint8_t *img, size_t size)
 bool uni_lane_ok(const Model &m) { return m.trie_max_depth > 0 && m.trie_max_depth <= 32 && m.max_info_id <= UNI_MAX_ID; }
 
 // Workspaces of the TextToIds pipeline for a batch of ndocs documents / total_bytes bytes (grow-only; see DevBuf::reserve).
+constexpr size_t BPE_BIG_POOL_BYTES = (size_t)64 << 20;       // per batch; a document of L elements takes <= 16 * (its arcs) + 9 * L bytes of it
+
 bool reserve_ids_workspaces(Handle *h, int64_t ndocs, int64_t total_bytes, bool want_off)
 {
     const Model &m = h->m;
@@ -284,7 +287,7 @@ bool reserve_ids_workspaces(Handle *h, int64_t ndocs, int64_t total_bytes, bool 
     } else {
         const size_t bm_words = (cap >> 5) + (size_t)ndocs + 4;
         if (!h->w_s1.reserve((6 * cap + 32 * (size_t)ndocs + 64) * 16) || !h->w_s2.reserve(std::max(cap * 4, 2 * bm_words * 4) + ((size_t)ndocs + 16) * 4) ||
-            !h->w_s3.reserve(cap * 4) || !h->w_s4.reserve(cap)) return false;
+            !h->w_s3.reserve(cap * 4) || !h->w_s4.reserve(cap) || !h->w_big.reserve(BPE_BIG_POOL_BYTES)) return false;
     }
     return h->w_perm.reserve((size_t)(ndocs + 1) * 4) && h->w_hist.reserve(2048 * 4) && h->w_narcs.reserve((size_t)(ndocs + 1) * 4);
 }
@@ -348,11 +351,13 @@ int run_device(Handle *h, const char *d_text, const int64_t *d_doc_off, int64_t 
         sg.b = b; sg.stream = h->w_cls.as<uint16_t>(); sg.lens = h->w_nchars.as<int32_t>(); sg.slot_mul = mul;
         sg.ids_tmp = h->w_tmp.as<int32_t>(); sg.counts = h->w_counts.as<int32_t>(); sg.span_tmp = want_off ? h->w_span.as<int32_t>() : nullptr; sg.max_ids = max_ids; sg.unk = unk; sg.status = status;
         sg.best = nullptr; sg.arcs = nullptr; sg.tos = nullptr; sg.idsv = nullptr; sg.inter = nullptr; sg.bm_words = 0; sg.fb_list = nullptr; sg.fb_count = nullptr;
+        sg.big_pool = nullptr; sg.big_cap = 0; sg.big_used = (unsigned long long *)(h->w_misc.as<char>() + 32);     // zeroed with the status word above
         if (m.kind == KIND_UNIGRAM) sg.best = h->w_s1.as<SegBest>();
         else {
             const size_t bm_words = (cap >> 5) + (size_t)ndocs + 4;         // per bitmap: capacity + 1 bits per document (k_bpe_apply_flat)
             sg.bm_words = (int64_t)bm_words;
             sg.arcs = h->w_s1.as<SegArc>(); sg.tos = h->w_s2.as<int32_t>(); sg.idsv = h->w_s3.as<int32_t>(); sg.inter = h->w_s4.as<uint8_t>();
+            sg.big_pool = h->w_big.as<uint8_t>(); sg.big_cap = BPE_BIG_POOL_BYTES;
         }
         sg.narcs = h->w_narcs.as<int32_t>(); sg.next_doc = next_doc; sg.trie_depth = m.trie_max_depth; sg.variant = h->variant & 0xff; sg.tune = (h->variant >> 8) & 0xff; sg.tune2 = (h->variant >> 16) & 0xff;
         sg.lane_ok = uni_lane_ok(m) ? 1 : 0;

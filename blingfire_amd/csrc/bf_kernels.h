@@ -84,6 +84,7 @@ struct SpSegParams {
     int lane_ok;                // Unigram: the model fits the lane program (bf_seg.h UniLane: entries <= 32 symbols, ids < 2^20 - 2)
     int64_t bm_words;           // BPE apply: words per bitmap (the two bitmaps live in the `tos` buffer)
     int32_t *fb_list; unsigned int *fb_count;   // BPE: documents k_bpe_fused hands to the full path (set by launch_seg_sp)
+    uint8_t *big_pool; unsigned long long big_cap; unsigned long long *big_used;   // BPE: pool of the documents whose arcs exceed the per-document reserve (k_bpe_big)
     int variant;
     int tune;                   // experiments: vote threshold of the lane-local BPE solve / Unigram transitions per trip (0 = default)
     int tune2;                  // experiments: resident waves per CU of the persistent segmenter kernels (0 = what fits)

@@ -1069,7 +1069,7 @@ __global__ __launch_bounds__(64) void k_bpe_apply_flat(SpSegParams p)
                         const int64_t slot = sp_slot(p.b.doc_off[doc], doc, p.slot_mul);
                         L = p.lens[doc]; n = p.narcs[doc];
                         if (n == BPE_DONE) {}                                        // finished by k_bpe_fused
-                        else if (n < 0) { atomicOr(p.status, 2); p.counts[doc] = 0; }
+                        else if (n < 0) p.counts[doc] = 0;                           // arc reserve exceeded: k_bpe_big takes the document
                         else if (L <= 0) p.counts[doc] = 0;
                         else {
                             arcs = p.arcs + 6 * slot + 32 * doc;
@@ -1562,6 +1562,35 @@ __global__ __launch_bounds__(64) void k_seg_unigram_lane(SpSegParams p, int ring
     if (mode != M_EXIT) atomicOr(p.status, 2);      // trip limit hit: never expected
 }
 
+// BPE, documents whose arcs exceed the per-document reserve (narcs == -1 on the fallback list; a long run of one character whose
+// run-length tokens are all in the vocabulary): the plain sequential program per lane (bf_seg.h seg_bpe_doc_big, the same code the
+// host tests run against the oracle), arcs and work arrays claimed from a pool shared by the batch.  Rare and slow by design; a
+// pool that runs out is the loud error the reserve used to be.
+struct BigClaim {
+    uint8_t *pool; unsigned long long cap; unsigned long long *used;
+    __device__ uint8_t *operator()(size_t bytes)
+    {
+        const unsigned long long at = atomicAdd(used, (unsigned long long)bytes);
+        return at + bytes <= cap ? pool + at : nullptr;
+    }
+};
+
+__global__ __launch_bounds__(64) void k_bpe_big(SpSegParams p)
+{
+    const unsigned int nfb = *p.fb_count;
+    for (unsigned int idx = blockIdx.x * 64u + threadIdx.x; idx < nfb; idx += gridDim.x * 64u) {
+        const int64_t d = p.fb_list[idx];
+        if (p.narcs[d] != -1) continue;
+        const int64_t slot = sp_slot(p.b.doc_off[d], d, p.slot_mul);
+        ClsWin cls_at; cls_at.init(p.stream, slot);
+        IdOutDirect out{p.ids_tmp + slot, p.span_tmp ? p.span_tmp + 2 * slot : nullptr};
+        BigClaim claim{p.big_pool, p.big_cap, p.big_used};
+        int r = seg_bpe_doc_big(p.S, cls_at, p.lens[d], claim, out, p.max_ids, p.unk);
+        if (r < 0) { atomicOr(p.status, 2); r = 0; }
+        p.counts[d] = r;
+    }
+}
+
 void launch_seg_sp(const SpSegParams &p_in, hipStream_t s)
 {
     const SpSegParams &p = p_in;
@@ -1621,6 +1650,7 @@ void launch_seg_sp(const SpSegParams &p_in, hipStream_t s)
             unsigned blocks = p.fb_list ? (unsigned)device_cus() : (unsigned)device_cus() * (unsigned)per_cu;
             if ((int64_t)blocks > (int64_t)b64) blocks = b64;
             hipLaunchKernelGGL(k_bpe_apply_flat, dim3(blocks), dim3(64), 0, s, p);
+            hipLaunchKernelGGL(k_bpe_big, dim3(64), dim3(64), 0, s, p);
         }
     }
 }

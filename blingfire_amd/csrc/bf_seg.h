@@ -374,6 +374,39 @@ BF_HD int seg_bpe_doc(const SegTables &S, ClsAt &cls_at, int L, SegArc *arcs, in
     return seg_bpe_finish(S, L, arcs, narcs, tos, idsv, inter, out, max_ids, unk);
 }
 
+// A document whose arcs do not fit the 6 * L + 32 the batch workspace reserves per document (a long run of one character whose
+// run-length tokens are all in the vocabulary: '-' * 15 with gpt2.bin).  The reference collects into a std::vector
+// (..._bpe_t.h:144,197); here the document gets its arcs and the three work arrays of ..._bpe_t.h:258-296 from a pool through
+// `claim(bytes)` (nullptr = the pool is exhausted -> -1, a loud error) and runs the plain sequential program.  The claim is sized by
+// an upper bound of the arc count: every final state of every start, plus one unknown arc per start without any (the whole-token
+// replacement and the fast-forward of ..._bpe_t.h:189-206,228-230 only ever remove arcs).
+constexpr long long SEG_BIG_MAX_ARCS = 1ll << 20;
+template <class ClsAt, class IdOut, class Claim>
+BF_HD int seg_bpe_doc_big(const SegTables &S, ClsAt &cls_at, int L, Claim &claim, IdOut &out, int max_ids, int unk)
+{
+    if (L <= 0) return 0;
+    long long bound = 0;
+    for (int start = 0; start < L; ++start) {
+        uint32_t state = S.initial; bool any = false;
+        for (int i = start; i < L; ++i) {
+            const uint64_t e = sg_lookup(S, state, cls_at(i));
+            if (e == SG_MISS) break;
+            state = (uint32_t)((e >> SG_NEXT_SHIFT) & SG_NEXT_MASK);
+            if (e & SG_FINAL) { ++bound; any = true; }
+        }
+        if (!any) ++bound;
+    }
+    if (bound > SEG_BIG_MAX_ARCS) return -1;                         // sequential work: a loud error beyond ~1 M arcs rather than a launch that runs for minutes
+    const size_t arcs_bytes = ((size_t)bound * sizeof(SegArc) + 15) & ~(size_t)15, ints_bytes = ((size_t)L * 4 + 15) & ~(size_t)15,
+                 flag_bytes = ((size_t)L + 15) & ~(size_t)15;
+    uint8_t *mem = claim(arcs_bytes + 2 * ints_bytes + flag_bytes);
+    if (!mem) return -1;
+    SegArc *arcs = (SegArc *)mem;
+    int32_t *tos = (int32_t *)(mem + arcs_bytes), *idsv = (int32_t *)(mem + arcs_bytes + ints_bytes);
+    uint8_t *inter = mem + arcs_bytes + 2 * ints_bytes;
+    return seg_bpe_doc(S, cls_at, L, arcs, (int)bound, tos, idsv, inter, out, max_ids, unk);
+}
+
 // Sort key of an arc as unsigned integers, ascending == the reference's comparator order:
 //   hi = merge rank, descending (0 for plain BPE);  lo = (id ascending) << 32 | start ascending
 BF_HD uint32_t sg_key_hi(const SegArc &a, bool merges)

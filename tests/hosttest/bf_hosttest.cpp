@@ -24,6 +24,7 @@ using namespace bfa;
 
 struct Handle { Model m; std::string path; };
 
+static long g_big_pool = 64l << 20;   // bft_set_big_pool: bytes of the pool behind seg_bpe_doc_big (the device's is 64 MiB per batch)
 static int g_uni_seq = 0;     // bft_set_uni_seq(1): Unigram through the plain sequential restatement (seg_unigram_doc) instead of UniLane
 static int g_general = 0;     // bft_set_general(1): the general lexer machine even for two-level models (A/B in tests)
 static int g_no_ff = 0;       // bft_set_no_ff(1): run the lexer emulation without the loop-state fast-forward (A/B in tests)
@@ -56,6 +57,7 @@ void bft_set_general(int v) { g_general = v; }
 int bft_two_level(void *hv) { return ((Handle *)hv)->m.two_level ? 1 : 0; }
 int bft_fn_no_ra(void *hv) { return ((Handle *)hv)->m.fn_no_ra ? 1 : 0; }
 void bft_set_uni_seq(int v) { g_uni_seq = v; }
+void bft_set_big_pool(long v) { g_big_pool = v; }
 // loop state facts: out[0] = base (-1: none), [1] = number of flagged classes, [2] = final, [3] = info
 void bft_loop_state(void *hv, long *out) { Model &m = ((Handle *)hv)->m; out[0] = m.loop_base == 0xFFFFFFFFu ? -1 : (long)m.loop_base; long n = 0; for (uint8_t b : m.loop_cls) n += b; out[1] = n; out[2] = m.loop_final; out[3] = m.loop_info; }
 void bft_lookup_hist(unsigned long long *out, int n, int reset) { for (int i = 0; i < n && i < 4096; ++i) out[i] = g_lookup_hist[i]; if (reset) memset(g_lookup_hist, 0, sizeof(g_lookup_hist)); }
@@ -308,6 +310,21 @@ static int emu_sp(const Model &m, const char *s, int n, int32_t *ids, int32_t *s
         for (int k = 0; k < na; ++k) { g_arc_dump->push_back(arcs[(size_t)k].start); g_arc_dump->push_back(arcs[(size_t)k].end); g_arc_dump->push_back(arcs[(size_t)k].id); g_arc_dump->push_back((int32_t)arcs[(size_t)k].rank_bits); }
     }
     int r = seg_bpe_doc(S, cls_at, L, arcs.data(), cap, tos.data(), idsv.data(), inter.data(), out, max_ids, unk);
+    if (r == -1) {
+        // more arcs than the per-document reserve: the pool path of the device (k_bpe_big), with a host pool and canaries around every claim
+        struct HostClaim {
+            std::vector<std::vector<uint8_t>> blocks; size_t budget;
+            uint8_t *operator()(size_t bytes) {
+                if (bytes > budget) return nullptr;
+                budget -= bytes;
+                blocks.emplace_back(bytes + 32, (uint8_t)0xCD);
+                return blocks.back().data() + 16;
+            }
+            bool intact() const { for (auto &b : blocks) for (int k = 0; k < 16; ++k) if (b[(size_t)k] != 0xCD || b[b.size() - 1 - (size_t)k] != 0xCD) return false; return true; }
+        } claim{{}, (size_t)g_big_pool};
+        r = seg_bpe_doc_big(S, cls_at, L, claim, out, max_ids, unk);
+        if (!claim.intact()) return -3;
+    }
     return r < 0 ? -2 : r;
 }
 

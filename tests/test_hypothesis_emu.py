@@ -36,12 +36,6 @@ def _check(model, b, mx, unk):
 text_st = st.text(alphabet=st.characters(blacklist_categories=("Cs",)), max_size=200)
 runs_st = st.lists(st.tuples(st.sampled_from(["a", " ", ".", "é", "中", "▁", "\U0001F600", "##", "ing", " ", "​", "-"]),
                              st.integers(min_value=1, max_value=70)), max_size=12).map(lambda xs: "".join(c * n for c, n in xs))
-# BPE models: a document dominated by one long run of a character whose run-length tokens are in the vocabulary ('#' * 94 with gpt2.bin)
-# collects more than the 6 * L + 32 arcs the product reserves per document -- a LOUD error there (BF_E_INTERNAL), pinned by
-# test_bpe_arc_capacity_is_a_loud_error below; the generated runs stay under it for those models
-short_runs_st = st.lists(st.tuples(st.sampled_from(["a", " ", ".", "é", "中", "▁", "\U0001F600", "##", "ing", " ", "​", "-"]),
-                                   st.integers(min_value=1, max_value=5)), max_size=24).map(lambda xs: "".join(c * n for c, n in xs))
-BPE_MODELS = ("gpt2.bin", "roberta.bin")
 mx_st = st.sampled_from([0, 1, 2, 7, 64, 512])
 unk_st = st.sampled_from([0, 1, 100, 3, 50256])
 
@@ -52,7 +46,7 @@ def test_lane_programs_any_text(model):
         pytest.skip("%s not present" % model)
 
     @settings(max_examples=250, deadline=None, suppress_health_check=list(HealthCheck))
-    @given(t=st.one_of(text_st, short_runs_st if model in BPE_MODELS else runs_st), mx=mx_st, unk=unk_st)
+    @given(t=st.one_of(text_st, runs_st), mx=mx_st, unk=unk_st)
     def run(t, mx, unk):
         _check(model, t.encode("utf-8"), mx, unk)
 
@@ -72,22 +66,47 @@ def test_lane_programs_any_bytes(model):
     run()
 
 
-def test_bpe_arc_capacity_is_a_loud_error():
-    """KNOWN LIMIT: the BPE lane programs reserve 6 * L + 32 arcs per document; '#' * 94 with gpt2.bin (its vocabulary
-    has '#', '##', '###', ... run tokens: about 9 arcs per start) needs more.  The product reports a loud error for the batch (status
-    bit 1 -> BF_E_INTERNAL), the host emulation -2 -- never wrong ids.  The oracle (unbounded, like the reference's std::vector) gives
-    the answer the fix has to reproduce."""
-    model = "gpt2.bin"
+@pytest.mark.parametrize("model", ["gpt2.bin", "roberta.bin"])
+def test_bpe_documents_beyond_the_arc_reserve(model):
+    """The BPE lane programs reserve 6 * L + 32 arcs per document; a document that is mostly one long run of a character whose run-length
+    tokens are in the vocabulary needs more ('-' * 15, '.' * 19, '=' * 36, '#' * 93 with gpt2.bin -- found by the property tests above).
+    Such documents take the pool path (bf_seg.h seg_bpe_doc_big; on the device k_bpe_big) and must give the reference's ids; a pool
+    that is exhausted is a loud error (-2 here, BF_E_INTERNAL in the product), never wrong ids."""
     if not bfutil.have_model(model):
         pytest.skip("%s not present" % model)
     L, h, ora, ho = _handles(model)
-    b = b"#" * 94
-    arr = (ctypes.c_int32 * 512)()
-    assert L.bft_emu_text_to_ids(h, b, len(b), arr, 512, 0) == -2
-    gc, gbuf = ora.text_to_ids(ho, b, 512, 0)
-    assert gc == 7
-    # just under the limit the lane program agrees with the oracle
-    b = b"#" * 40
-    c = L.bft_emu_text_to_ids(h, b, len(b), arr, 512, 0)
-    gc, gbuf = ora.text_to_ids(ho, b, 512, 0)
-    assert c == gc and list(arr)[:c] == gbuf[:gc]
+    L.bft_set_big_pool.argtypes = [ctypes.c_long]
+    arr = (ctypes.c_int32 * 4096)()
+    for ch in (b"-", b".", b"=", b"*", b"_", b"#", b"-=", b". ", "—".encode("utf-8")):
+        for n in list(range(1, 130, 3)) + [200, 513, 2000]:
+            b = ch * n
+            c = L.bft_emu_text_to_ids(h, b, len(b), arr, 4096, 0)
+            gc, gbuf = ora.text_to_ids(ho, b, 4096, 0)
+            assert c == gc and list(arr)[:c] == gbuf[:gc], (model, ch, n)
+    try:
+        L.bft_set_big_pool(1000)
+        b = b"-" * 300
+        assert L.bft_emu_text_to_ids(h, b, len(b), arr, 4096, 0) == -2
+    finally:
+        L.bft_set_big_pool(64 << 20)
+
+
+@pytest.mark.parametrize("model", ["bert_base_tok.bin", "bert_chinese.bin", "xlnet.bin", "xlm_roberta_base.bin", "gpt2.bin"])
+def test_lane_programs_offsets_any_text(model):
+    """TextToIdsWithOffsets: ids AND the inclusive byte spans of every id, any text / any bytes"""
+    if not bfutil.have_model(model):
+        pytest.skip("%s not present" % model)
+    L, h, ora, ho = _handles(model)
+    f = L.bft_emu_text_to_ids_with_offsets
+    f.restype = ctypes.c_int
+    f.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int] + [ctypes.c_void_p] * 3 + [ctypes.c_int, ctypes.c_int]
+
+    @settings(max_examples=200, deadline=None, suppress_health_check=list(HealthCheck))
+    @given(b=st.one_of(text_st.map(lambda t: t.encode("utf-8")), runs_st.map(lambda t: t.encode("utf-8")), st.binary(max_size=80)),
+           mx=st.sampled_from([1, 3, 64, 512]), unk=unk_st)
+    def run(b, mx, unk):
+        i = (ctypes.c_int32 * mx)(); s = (ctypes.c_int32 * mx)(); e = (ctypes.c_int32 * mx)()
+        c = f(h, b, len(b), i, s, e, mx, unk)
+        assert (c, list(i)[:c], list(s)[:c], list(e)[:c]) == ora.with_offsets(ho, b, mx, unk, "bfo_text_to_ids_with_offsets"), (model, b[:60], mx)
+
+    run()
