@@ -380,7 +380,7 @@ BF_HD int seg_bpe_doc(const SegTables &S, ClsAt &cls_at, int L, SegArc *arcs, in
 // `claim(bytes)` (nullptr = the pool is exhausted -> -1, a loud error) and runs the plain sequential program.  The claim is sized by
 // an upper bound of the arc count: every final state of every start, plus one unknown arc per start without any (the whole-token
 // replacement and the fast-forward of ..._bpe_t.h:189-206,228-230 only ever remove arcs).
-constexpr long long SEG_BIG_MAX_ARCS = 1ll << 20;
+constexpr long long SEG_BIG_MAX_ARCS = 1ll << 18;        // ~10 k characters of one run; one lane sorts them in a few seconds
 template <class ClsAt, class IdOut, class Claim>
 BF_HD int seg_bpe_doc_big(const SegTables &S, ClsAt &cls_at, int L, Claim &claim, IdOut &out, int max_ids, int unk)
 {
@@ -396,7 +396,7 @@ BF_HD int seg_bpe_doc_big(const SegTables &S, ClsAt &cls_at, int L, Claim &claim
         }
         if (!any) ++bound;
     }
-    if (bound > SEG_BIG_MAX_ARCS) return -1;                         // sequential work: a loud error beyond ~1 M arcs rather than a launch that runs for minutes
+    if (bound > SEG_BIG_MAX_ARCS) return -1;                         // sequential work: a loud error beyond that rather than a launch that runs for a minute
     const size_t arcs_bytes = ((size_t)bound * sizeof(SegArc) + 15) & ~(size_t)15, ints_bytes = ((size_t)L * 4 + 15) & ~(size_t)15,
                  flag_bytes = ((size_t)L + 15) & ~(size_t)15;
     uint8_t *mem = claim(arcs_bytes + 2 * ints_bytes + flag_bytes);

@@ -166,7 +166,7 @@ BF_API int WordHyphenationWithModel(const char *pInUtf8Str, int InUtf8StrByteCou
  * whole documents through page-locked staging; the call returns when everything is in the caller's arrays.
  * BPE models (gpt2.bin, roberta.bin, ...): a document that needs more than 6 * L + 32 candidate arcs (L = its length in stream
  * elements; e.g. nothing but one long run of '-') is tokenised by a slower sequential kernel out of a 64 MiB pool per batch; only a
- * document with more than 2^20 arcs, or an exhausted pool, fails the call with BF_E_INTERNAL. */
+ * document with more than 2^18 arcs, or an exhausted pool, fails the call with BF_E_INTERNAL. */
 BF_API int64_t TextToIdsBatch(void *ModelPtr, const char *text, const int64_t *doc_offsets, int64_t ndocs,
                        int32_t *ids_out, int64_t ids_cap, int64_t *id_offsets_out,
                        int max_ids_per_doc, int unk);
