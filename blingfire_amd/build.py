@@ -63,8 +63,9 @@ def build_test_infra(force=False):
         _run(["gcc", "-O2", "-Wall", "-std=gnu99", "-fPIC", "-shared", "corpusgen.c", "-o", "libcorpusgen.so", "-lm", "-lpthread"],
              cwd=os.path.join(ROOT, "tools"))
     ht = os.path.join(ROOT, "tests", "hosttest", "libbf_hosttest.so")
-    ht_src = [os.path.join(ROOT, "tests", "hosttest", "bf_hosttest.cpp"), os.path.join(CSRC, "bf_model.cpp")]
-    ht_dep = ht_src + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + [os.path.join(odir, "bf_oracle.c")]
+    ht_src = [os.path.join(ROOT, "tests", "hosttest", "bf_hosttest.cpp"), os.path.join(ROOT, "tests", "hosttest", "bf_wavetest.cpp"), os.path.join(CSRC, "bf_model.cpp")]
+    ht_dep = ht_src + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + [os.path.join(odir, "bf_oracle.c"),
+                                                                                              os.path.join(ROOT, "tests", "hosttest", "wave_emu.h"), os.path.join(ROOT, "tests", "hosttest", "hosttest.h")]
     if force or _newer(ht, ht_dep):
         obj = os.path.join(ROOT, "tests", "hosttest", "bf_oracle.o")
         _run(["gcc", "-O2", "-std=c99", "-fPIC", "-c", os.path.join(odir, "bf_oracle.c"), "-o", obj])

@@ -135,6 +135,8 @@ struct Handle {
     std::mutex mu;
     // device tables
     DevBuf t_wbd, t_info, t_acts, t_cp_l1, t_cp_pages, t_multi, t_i2w_off, t_i2w_data;
+    DevBuf t_kind;                                               // unit-form lexers: what a walk that starts on each class does (bf_wave.h)
+    bool lex_stats = false;                                      // BF_LEX_STATS=1 at LoadModel: instrumented kernel instances (experiments)
     DevBuf t_wcp_l1, t_wcp_pages;                                // TextToWords: code point -> class without the charmap
     DevBuf t_dict, t_seginfo;                                    // _sp: Mealy table, I2Info rows (code-point maps reuse t_cp_*/t_multi)
     DevBuf t_dk_l1, t_dk_pages, t_dn_l1, t_dn_pages, t_dn_pool, t_k2i, t_rows;   // key -> info lookup (uploaded on first use)
@@ -157,7 +159,7 @@ struct Handle {
     ~Handle()
     {
         pipe.release();
-        for (DevBuf *b : {&t_dk_l1, &t_dk_pages, &t_dn_l1, &t_dn_pages, &t_dn_pool, &t_k2i, &t_rows, &w_keys, &w_keyoff, &w_dids, &w_dret, &w_vals, &t_i2w_off, &t_i2w_data, &t_wbd, &t_info, &t_acts, &t_cp_l1, &t_cp_pages, &t_multi, &t_wcp_l1, &t_wcp_pages, &t_dict, &t_seginfo, &w_s1, &w_s2, &w_s3, &w_s4, &w_big, &w_perm, &w_hist, &w_narcs, &w_cls, &w_nchars, &w_tmp, &w_counts, &w_flags, &w_out, &w_outoff,
+        for (DevBuf *b : {&t_dk_l1, &t_dk_pages, &t_dn_l1, &t_dn_pages, &t_dn_pool, &t_k2i, &t_rows, &w_keys, &w_keyoff, &w_dids, &w_dret, &w_vals, &t_i2w_off, &t_i2w_data, &t_kind, &t_wbd, &t_info, &t_acts, &t_cp_l1, &t_cp_pages, &t_multi, &t_wcp_l1, &t_wcp_pages, &t_dict, &t_seginfo, &w_s1, &w_s2, &w_s3, &w_s4, &w_big, &w_perm, &w_hist, &w_narcs, &w_cls, &w_nchars, &w_tmp, &w_counts, &w_flags, &w_out, &w_outoff,
                           &w_bsums, &w_misc, &w_text, &w_docoff, &w_ids, &w_idoff, &w_starts, &w_ends, &w_srcoff, &w_span}) b->release();
         for (auto &e : ev) if (e) (void)hipEventDestroy(e);
         if (stream) (void)hipStreamDestroy(stream);
@@ -240,6 +242,7 @@ Handle *make_handle(const uint8_t *img, size_t size)
     }
     if (hipGetDevice(&h->device) != hipSuccess) h->device = 0;
     if (const char *v = getenv("BF_LEX_VARIANT")) h->variant = atoi(v);      // experiments only
+    h->lex_stats = getenv("BF_LEX_STATS") != nullptr;
     Model &m = h->m;
     bool ok = true;
     if (m.kind == KIND_WP) {
@@ -247,7 +250,7 @@ Handle *make_handle(const uint8_t *img, size_t size)
         if (m.max_depth > LEX_MAX_DEPTH) { g_last_error = "lexer max-depth exceeds the supported 4"; fprintf(stderr, "[blingfire_amd] %s\n", g_last_error.c_str()); delete h; return nullptr; }
         ok = ok && upload(h->t_wbd, m.wbd_t2, 16) && upload(h->t_acts, m.acts_pool, 16) &&
              upload(h->t_cp_l1, m.wbd_cpmap.l1) && upload(h->t_cp_pages, m.wbd_cpmap.pages) && upload(h->t_multi, m.wbd_multi_pool, 16) &&
-             upload(h->t_wcp_l1, m.words_cpmap.l1) && upload(h->t_wcp_pages, m.words_cpmap.pages);
+             upload(h->t_wcp_l1, m.words_cpmap.l1) && upload(h->t_wcp_pages, m.words_cpmap.pages) && upload(h->t_kind, m.wave_kind, 16);
     } else if (m.kind != KIND_I2W) {
         ok = ok && upload(h->t_dict, m.dict.t64, 16) && upload(h->t_seginfo, m.seg_info, 16) &&
              upload(h->t_cp_l1, m.sp_cpmap.l1) && upload(h->t_cp_pages, m.sp_cpmap.pages) && upload(h->t_multi, m.sp_multi_pool, 16);
@@ -266,13 +269,22 @@ bool uni_lane_ok(const Model &m) { return m.trie_max_depth > 0 && m.trie_max_dep
 // Workspaces of the TextToIds pipeline for a batch of ndocs documents / total_bytes bytes (grow-only; see DevBuf::reserve).
 constexpr size_t BPE_BIG_POOL_BYTES = (size_t)64 << 20;       // per batch; a document of L elements takes <= 16 * (its arcs) + 9 * L bytes of it
 
-bool reserve_ids_workspaces(Handle *h, int64_t ndocs, int64_t total_bytes, bool want_off)
+// The WordPiece path of a unit-form lexer (every BERT model) is the wave program of bf_wave.h: ids only.  The offsets API and the
+// TextToWords forms, and lexers outside the unit form, take the lane-per-document kernels (bf_lex.h).  Variant 2 (experiments, A/B):
+// the lane-per-document kernels for every model.
+bool use_wave(const Handle *h, bool want_off, int words)
+{
+    return h->m.kind == KIND_WP && h->m.wave_ok && !want_off && !words && (h->variant & 0xff) != 2;
+}
+
+bool reserve_ids_workspaces(Handle *h, int64_t ndocs, int64_t total_bytes, bool want_off, int words = 0)
 {
     const Model &m = h->m;
     const int nblocks = scan_nblocks(ndocs);
     if (!h->w_nchars.reserve((size_t)(ndocs + 1) * 4) || !h->w_counts.reserve((size_t)(ndocs + 1) * 4) ||
         !h->w_bsums.reserve((size_t)(nblocks + 1) * 8) || !h->w_tmp.reserve((size_t)(total_bytes + 8 * ndocs + 64) * 4)) return false;
     if (m.kind == KIND_WP) {
+        if (use_wave(h, want_off, words)) return true;                 // no class stream, no dirty flags
         if (!h->w_cls.reserve((size_t)(total_bytes + 64) * 2) || !h->w_flags.reserve((size_t)((total_bytes >> 10) + 2) * 8)) return false;
         if (want_off && (!h->w_srcoff.reserve((size_t)(total_bytes + 64) * 4) || !h->w_span.reserve((size_t)(total_bytes + 8 * ndocs + 64) * 8))) return false;
         return true;
@@ -304,14 +316,26 @@ int run_device(Handle *h, const char *d_text, const int64_t *d_doc_off, int64_t 
     if (max_ids < 0) max_ids = 0;
     Model &m = h->m;
     const int nblocks = scan_nblocks(ndocs);
-    if (!reserve_ids_workspaces(h, ndocs, total_bytes, want_off)) return BF_E_DEVICE;
+    if (!reserve_ids_workspaces(h, ndocs, total_bytes, want_off, words)) return BF_E_DEVICE;
     int slot_mul = 0; const int32_t *first = nullptr;
     unsigned long long *next_doc = h->w_misc.as<unsigned long long>();
     int *status = (int *)(h->w_misc.as<char>() + 16);
     Batch b{(const uint8_t *)d_text, d_doc_off, ndocs, total_bytes, status};
     if (!hip_ok(hipMemsetAsync(h->w_misc.p, 0, 64, s), "hipMemsetAsync")) return BF_E_DEVICE;
     (void)hipEventRecord(h->ev[EV_BEGIN], s);
-    if (m.kind == KIND_WP) {
+    if (use_wave(h, want_off, words)) {
+        (void)hipEventRecord(h->ev[EV_PREP], s);                       // decoding is part of the wave program
+        WpWaveParams wp;
+        wp.T = h->t_wbd.as<uint64_t>(); wp.acts = h->t_acts.as<int32_t>();
+        wp.cpmap = DevCpMap{h->t_cp_l1.as<uint16_t>(), h->t_cp_pages.as<uint32_t>()};
+        wp.kind = h->t_kind.as<uint8_t>(); wp.nclasses = m.wbd.nclasses;
+        wp.initial = m.wbd.initial_base; wp.loop_info = m.loop_info; wp.max_token_length = m.max_token_length;
+        wp.b = b; wp.ids_tmp = h->w_tmp.as<int32_t>(); wp.counts = h->w_counts.as<int32_t>(); wp.max_ids = max_ids; wp.unk = unk;
+        wp.next_doc = next_doc;
+        wp.stats = h->lex_stats ? (unsigned long long *)(h->w_misc.as<char>() + 64) : nullptr;
+        if (ndocs > 0) launch_wp_wave(wp, h->variant, s);
+        (void)hipEventRecord(h->ev[EV_TOK], s);
+    } else if (m.kind == KIND_WP) {
         WpPrepParams pp{b, DevCpMap{h->t_cp_l1.as<uint16_t>(), h->t_cp_pages.as<uint32_t>()}, h->t_multi.as<uint16_t>(),
                         m.wbd_charmap_multi ? 1 : 0, h->w_cls.as<uint16_t>(), want_off ? h->w_srcoff.as<int32_t>() : nullptr, h->w_nchars.as<int32_t>()};
         if (words) { pp.cpmap = DevCpMap{h->t_wcp_l1.as<uint16_t>(), h->t_wcp_pages.as<uint32_t>()}; pp.has_multi = 0; }   // no charmap (tokdll:476-499)
@@ -329,7 +353,7 @@ int run_device(Handle *h, const char *d_text, const int64_t *d_doc_off, int64_t 
         lp.ids_tmp = h->w_tmp.as<int32_t>(); lp.counts = h->w_counts.as<int32_t>(); lp.span_tmp = want_off ? h->w_span.as<int32_t>() : nullptr;
         lp.max_ids = max_ids; lp.unk = unk; lp.next_doc = next_doc; lp.status = status; lp.ev_thresh = 0; lp.fetch_thresh = 0; lp.acts_n = (int)m.acts_pool.size(); lp.words = words;
         lp.table_n = (int)(m.wbd_t2.size() > (size_t)LX_T_CLS_MASK + 1 ? m.wbd_t2.size() - ((size_t)LX_T_CLS_MASK + 1) : 0);
-        lp.stats = getenv("BF_LEX_STATS") ? (unsigned long long *)(h->w_misc.as<char>() + 64) : nullptr;
+        lp.stats = h->lex_stats ? (unsigned long long *)(h->w_misc.as<char>() + 64) : nullptr;
         if (ndocs > 0) launch_lex_wp(lp, h->variant, s);
         (void)hipEventRecord(h->ev[EV_TOK], s);
     } else {

@@ -4,21 +4,10 @@
 #include <hip/hip_runtime_api.h>
 #include "bf_lex.h"
 #include "bf_seg.h"
+#include "bf_batch.h"
+#include "bf_wave.h"
 
 namespace bfa {
-
-// Inputs shared by the prep kernels: the batch (concatenated documents) and where results go.
-struct Batch {
-    const uint8_t *text;        // concatenated UTF-8 documents
-    const int64_t *doc_off;     // [ndocs+1] byte offsets, doc_off[0] == 0 and doc_off[ndocs] == total_bytes (include/*.h: precondition)
-    int64_t ndocs;
-    int64_t total_bytes;        // bytes of `text`; a document whose range leaves [0, total_bytes] is treated as empty (status bit 3)
-    int *status;
-};
-constexpr int BF_STATUS_BAD_OFFSETS = 8;
-
-// code point map (TwoLevelMap on the device)
-struct DevCpMap { const uint16_t *l1; const uint32_t *pages; };
 
 struct WpPrepParams {
     Batch b;
@@ -118,6 +107,7 @@ struct CompactParams {
 // flags: one bit per 16-byte chunk of the text (u64 per KiB, + 1), or nullptr for the one-pass wave-per-document form
 void launch_prep_wp(const WpPrepParams &p, int64_t total_bytes, unsigned long long *flags, hipStream_t s);
 void launch_lex_wp(const WpLexParams &p, int variant, hipStream_t s);
+void launch_wp_wave(const WpWaveParams &p, int variant, hipStream_t s);     // unit-form lexers (bf_wave.h): replaces prep + lexer
 void launch_prep_sp(const SpPrepParams &p, hipStream_t s);
 void launch_seg_sp(const SpSegParams &p, hipStream_t s);
 void launch_scan(const ScanParams &p, hipStream_t s);

@@ -659,6 +659,73 @@ void launch_lex_wp(const WpLexParams &p, int variant, hipStream_t s)
 }
 
 // ------------------------------------------------------------------------------------------
+// k_wp_wave: the WordPiece path of unit-form lexers (bf_wave.h): wave-cooperative decode -> top-level tokens -> one word per
+// lane slot -> ids in document order.  No class stream in HBM, no prep kernel.  namespace wv = the wave intrinsics of gfx950
+// behind the names the wave program (bf_wave_body.h) uses; the test build supplies a simulator behind the same names.
+// ------------------------------------------------------------------------------------------
+} // namespace bfa
+namespace wv {
+__device__ __forceinline__ int lane() { return (int)(threadIdx.x & 63u); }
+__device__ __forceinline__ unsigned long long ballot(bool b) { return __ballot(b); }
+__device__ __forceinline__ bool any(bool b) { return __ballot(b) != 0ull; }
+__device__ __forceinline__ void sync() { bfa::wave_handoff(); }
+template <class T> __device__ __forceinline__ T shfl(T v, int src) { return __shfl(v, src, 64); }
+__device__ __forceinline__ int bcast(int v, int src) { return __builtin_amdgcn_readlane(v, src); }
+__device__ __forceinline__ uint32_t bcast(uint32_t v, int src) { return (uint32_t)__builtin_amdgcn_readlane((int)v, src); }
+__device__ __forceinline__ unsigned long long bcast(unsigned long long v, int src)
+{
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, src), hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), src);
+    return ((unsigned long long)hi << 32) | lo;
+}
+template <class T> __device__ __forceinline__ T shfl_up(T v, int delta) { return __shfl_up(v, (unsigned)delta, 64); }
+template <class T> __device__ __forceinline__ T shfl_down(T v, int delta) { return __shfl_down(v, (unsigned)delta, 64); }
+__device__ __forceinline__ int incl_scan(int v) { return bfa::wave_incl_scan(v); }
+__device__ __forceinline__ unsigned long long atomic_add(unsigned long long *p, unsigned long long v) { return atomicAdd(p, v); }
+__device__ __forceinline__ void atomic_or(int *p, int v) { atomicOr(p, v); }
+} // namespace wv
+#include "bf_wave_body.h"
+namespace bfa {
+
+template <class LDS, int UNROLL, int WAVES, bool STATS>
+__global__ __launch_bounds__(64 * WAVES) void k_wp_wave(WpWaveParams p, int grab)
+{
+    __shared__ LDS lds[WAVES];
+    __shared__ uint16_t ascii[128];
+    wv_init_ascii(p, ascii, (int)threadIdx.x, 64 * WAVES);
+    __syncthreads();
+    WpWave<LDS, UNROLL, STATS> w(p, lds[threadIdx.x >> 6], ascii);
+    w.run(grab);
+}
+
+template <class LDS, int UNROLL, int WAVES>
+static void launch_wp_wave_cfg(const WpWaveParams &p, int grab, int per_cu_override, hipStream_t s)
+{
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_wp_wave<LDS, UNROLL, WAVES, false>, 64 * WAVES, 0) != hipSuccess || per_cu <= 0) per_cu = 2;
+    (void)hipGetLastError();
+    if (per_cu_override > 0) per_cu = per_cu_override;
+    int64_t blocks = (int64_t)device_cus() * per_cu;
+    const int64_t need = (p.b.ndocs + (int64_t)grab * WAVES - 1) / ((int64_t)grab * WAVES);
+    if (blocks > need) blocks = need;
+    if (blocks < 1) blocks = 1;
+    if (p.stats) hipLaunchKernelGGL((k_wp_wave<LDS, UNROLL, WAVES, true>), dim3((unsigned)blocks), dim3(64 * WAVES), 0, s, p, grab);
+    else hipLaunchKernelGGL((k_wp_wave<LDS, UNROLL, WAVES, false>), dim3((unsigned)blocks), dim3(64 * WAVES), 0, s, p, grab);
+}
+
+// variant (experiments): bits 8..11 = queue/ring configuration, bits 12..15 = documents per grab (0 = 8), bits 24..29 = workgroups per CU
+void launch_wp_wave(const WpWaveParams &p, int variant, hipStream_t s)
+{
+    const int cfg = (variant >> 8) & 0xf;
+    int grab = (variant >> 12) & 0xf; if (grab == 0) grab = 8;
+    const int per_cu = (variant >> 24) & 0x3f;
+    if (cfg == 1) launch_wp_wave_cfg<WvLds<2048, 256, 64>, 2, 4>(p, grab, per_cu, s);
+    else if (cfg == 2) launch_wp_wave_cfg<WvLds<1024, 128, 64>, 3, 4>(p, grab, per_cu, s);
+    else if (cfg == 3) launch_wp_wave_cfg<WvLds<2048, 256, 64>, 3, 4>(p, grab, per_cu, s);
+    else if (cfg == 4) launch_wp_wave_cfg<WvLds<1024, 128, 64>, 1, 4>(p, grab, per_cu, s);
+    else launch_wp_wave_cfg<WvLds<1024, 128, 64>, 2, 4>(p, grab, per_cu, s);
+}
+
+// ------------------------------------------------------------------------------------------
 // k_prep_sp: wave per document.  bytes / strict UTF-8 -> fused charmap+element-code map -> dummy prefix ->
 // whitespace collapse (local keep-predicate) -> trailing trim  (tokdll:1367-1496).
 // ------------------------------------------------------------------------------------------

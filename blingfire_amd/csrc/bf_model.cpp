@@ -751,6 +751,87 @@ bool build_model(Model &m, const uint8_t *img, size_t size)
                     for (int k = 0; k < c; ++k) m.wbd_multi_pool.push_back((uint16_t)flagged(cls_text(norm[k])));
                 }
             }
+
+            // ---- unit form (bf_wave.h): which conditions hold, and what a walk that starts on each class does
+            {
+                const RawDfa &rw = m.wbd_raw;
+                const int nst = (int)rw.state_off.size();
+                std::vector<int> base2idx(m.wbd.table_len(), -1);
+                for (int st = 0; st < nst; ++st) base2idx[m.wbd.state_base[(size_t)st]] = st;
+                auto cls_of_tr = [&](uint32_t t) -> int {          // class of transition t in the packed table's numbering, -1 if none
+                    int c = rw.tr_sym[t];
+                    if (!rw.remap) { auto &S = m.wbd.sym_of_class; auto it = std::lower_bound(S.begin(), S.end(), c); if (it == S.end() || *it != c) return -1; c = (int)(it - S.begin()); }
+                    return c;
+                };
+                auto is_text = [&](int c) { return c >= 0 && (uint32_t)c != m.cls_any && (uint32_t)c != m.cls_l && (uint32_t)c != m.cls_r; };
+                std::string why;
+                if (!m.two_level) why = "not a two-level lexer";
+                else if (m.cls_any != CLS_NONE) why = "IW_ANY is in the alphabet";
+                else if (m.initial_l != 0xFFFFFFFFu) why = "the top level takes the left anchor";
+                else if (m.wbd_charmap_multi) why = "the charmap deletes or expands characters";
+                else if (!m.fn_no_ra) why = "a function rule uses the right anchor";
+                else if (m.max_depth < 2) why = "max-depth < 2";
+                else if (m.max_token_length < 1 || m.max_token_length > 496) why = "max token length outside 1..496";
+                // C = states behind at least one letter from the initial state (text classes only): what a top-level walk can be in
+                std::vector<uint8_t> inC((size_t)nst, 0);
+                if (why.empty()) {
+                    std::vector<int> stack;
+                    auto push_text_dsts = [&](int st) {
+                        for (uint32_t t = rw.tr_begin[(size_t)st]; t < rw.tr_begin[(size_t)st + 1]; ++t) {
+                            const int dst = rw.tr_dst[t];
+                            if (dst < 0 || !is_text(cls_of_tr(t))) continue;
+                            if (!inC[(size_t)dst]) { inC[(size_t)dst] = 1; stack.push_back(dst); }
+                        }
+                    };
+                    push_text_dsts(rw.initial);
+                    while (!stack.empty()) { const int st = stack.back(); stack.pop_back(); push_text_dsts(st); }
+                    for (int st = 0; st < nst && why.empty(); ++st) {
+                        if (!inC[(size_t)st]) continue;
+                        for (uint32_t t = rw.tr_begin[(size_t)st]; t < rw.tr_begin[(size_t)st + 1]; ++t)
+                            if (m.cls_r != CLS_NONE && cls_of_tr(t) == (int)m.cls_r) { why = "a top-level rule uses the right anchor"; break; }
+                        if (!why.empty() || !rw.is_final[(size_t)st]) continue;
+                        const uint32_t inf = m.wbd_info[m.wbd.state_base[(size_t)st]];
+                        const int tag = (inf & INFO_SIMPLE_BIT) ? (int)(inf & 0x7FFFFFFFu) : m.acts_pool[(size_t)inf + 2];
+                        if (tag < 1 || tag > 4) why = "a top-level tag outside 1..4";
+                    }
+                }
+                // every final state below a function's initial states carries a vocabulary tag (> 4: never a word, always a sub-token)
+                if (why.empty()) {
+                    std::vector<uint8_t> seen((size_t)nst, 0); std::vector<int> stack;
+                    for (size_t id = 0; id < actions.size(); ++id) {
+                        if (act_info[id] & INFO_SIMPLE_BIT) continue;
+                        const int32_t *a = m.acts_pool.data() + act_info[id];
+                        for (uint32_t b : {(uint32_t)a[5], (uint32_t)a[6]}) { const int st = b < base2idx.size() ? base2idx[b] : -1; if (st >= 0 && !seen[(size_t)st]) { seen[(size_t)st] = 1; stack.push_back(st); } }
+                    }
+                    while (!stack.empty() && why.empty()) {
+                        const int st = stack.back(); stack.pop_back();
+                        if (rw.is_final[(size_t)st]) {
+                            const uint32_t inf = m.wbd_info[m.wbd.state_base[(size_t)st]];
+                            if (!(inf & INFO_SIMPLE_BIT) || (int)(inf & 0x7FFFFFFFu) <= 4) why = "a vocabulary tag <= 4";
+                        }
+                        for (uint32_t t = rw.tr_begin[(size_t)st]; t < rw.tr_begin[(size_t)st + 1]; ++t) { const int dst = rw.tr_dst[t]; if (dst >= 0 && !seen[(size_t)dst]) { seen[(size_t)dst] = 1; stack.push_back(dst); } }
+                    }
+                }
+                m.wave_ok = why.empty(); m.wave_why = why;
+                m.wave_kind.assign((size_t)m.wbd.nclasses, 0 /* WK_GENERAL */);
+                if (m.wave_ok) {
+                    // the loop state is usable as a run when it is closed (nothing but its self-loops), final, and every class that
+                    // loops there also ENTERS it from the initial state (so "run of flagged elements" == "what the walk consumes")
+                    const int ls = m.loop_base == 0xFFFFFFFFu ? -1 : base2idx[m.loop_base];
+                    bool loop_ok = ls >= 0 && m.loop_final;
+                    if (loop_ok) for (uint32_t t = rw.tr_begin[(size_t)ls]; t < rw.tr_begin[(size_t)ls + 1]; ++t) if (rw.tr_dst[t] != ls || !is_text(cls_of_tr(t))) { loop_ok = false; break; }
+                    if (loop_ok) for (int c = 0; c < m.wbd.nclasses; ++c) if (m.loop_cls[(size_t)c] && m.wbd.step(m.wbd.initial_base, (uint32_t)c, nullptr, nullptr) != (long)m.loop_base) { loop_ok = false; break; }
+                    for (int c = 0; c < m.wbd.nclasses; ++c) {
+                        if (!is_text(c)) { m.wave_kind[(size_t)c] = 2; continue; }           // never in a class stream
+                        int fin = 0;
+                        const long d = m.wbd.step(m.wbd.initial_base, (uint32_t)c, &fin, nullptr);
+                        if (d < 0) { m.wave_kind[(size_t)c] = 2 /* WK_NOMATCH */; continue; }
+                        const int st = base2idx[(size_t)d];
+                        if (loop_ok && d == (long)m.loop_base && m.loop_cls[(size_t)c]) m.wave_kind[(size_t)c] = 1 /* WK_LOOP */;
+                        else if (st >= 0 && fin && rw.tr_begin[(size_t)st] == rw.tr_begin[(size_t)st + 1]) m.wave_kind[(size_t)c] = 3 /* WK_SOLO */;
+                    }
+                }
+            }
         }
     }
 

@@ -123,6 +123,12 @@ struct Model {
     TwoLevelMap wbd_cpmap;
     std::vector<uint16_t> wbd_multi_pool;   // [count, cls0, cls1 ...] records for 1:n / deleted chars
     bool wbd_has_charmap = false, wbd_charmap_multi = false;
+    // "Unit form" (bf_wave.h): the lexer is two-level, every top-level token is a unit of its own for the WordPiece post-pass
+    // (top-level tags in 1..4, vocabulary tags > 4, no left anchor at the top level, no right-anchor transition behind a letter,
+    // no IW_ANY), so top-level tokens can be found for many start positions at once and every word can be looked up by a lane
+    // of its own.  wave_kind[class]: what a walk that STARTS on this class does (bf_wave.h WK_*), proven from the automaton.
+    bool wave_ok = false; std::string wave_why;        // wave_why: the first condition that failed (diagnostics, tests)
+    std::vector<uint8_t> wave_kind;
     // TextToWords view of the same lexer (tokdll:415-566): NO charmap, U+0000 is fed as U+0020 -> plain code point -> class map
     TwoLevelMap words_cpmap;
 

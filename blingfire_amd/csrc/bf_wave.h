@@ -1,0 +1,89 @@
+// bf_wave.h -- WordPiece TextToIds for "unit form" lexers (every BERT model), one WAVE per stream of documents.
+//
+// Reproduces the same reference path as bf_lex.h --
+//   FAStrUtf8ToArray (cl/src/FAUtf8Utils.cpp:233-270) -> FANormalize (cl/inc/FAUtils_cl.h:311-369)
+//   -> FALexTools_t<int>::Process_int (cl/inc/FALexTools_t.h:205-400) -> the _wp post-pass (tokdll:1207-1313)
+// -- but organised around what the load-time analysis proves for these models (bf_model.h Model::wave_ok):
+//
+//   * the lexer is two-level: top-level rules find a token <tag, from, to> and call ONE function (the vocabulary) on it;
+//   * a top-level token is a unit of its own for the post-pass: top-level tags are 1..4 (WORD .. IGNORE), vocabulary tags are
+//     > 4, so a word's sub-tokens are exactly the tokens its own function call emits, and "the sub-tokens tile the word, else
+//     UNK" (tokdll:1239-1301) is decided inside the unit;
+//   * no left anchor at the top level, no right-anchor transition behind a letter, no IW_ANY, 1:1 charmap.
+//
+// So the work splits into three data-parallel phases per wave, none of which keeps a class stream in HBM:
+//   decode   64 lanes x 8 bytes: UTF-8 -> code point -> fused charmap/class map -> a ring of 16-bit elements in LDS
+//            (class | what a walk that starts on this class does: WK_LOOP / WK_NOMATCH / WK_SOLO / WK_GENERAL);
+//   phase A  top level, one start position per lane: runs of WK_LOOP elements are words (one ballot, no table access), WK_SOLO /
+//            WK_NOMATCH elements are decided by their class alone, WK_GENERAL elements walk the automaton; the chain of start
+//            positions is closed from the masks (or serially in the rare window that holds a multi-character general token);
+//            tokens are queued in LDS;
+//   phase B  vocabulary, one WORD per lane slot (two slots per lane, so two independent table gathers are in flight per lane):
+//            the function frame of Process_int on the word, leftmost-longest piece by piece, result = pieces or UNK;
+//   phase C  in queue order: segmented prefix sum of the id counts per document -> ids to the document's staging slot.
+// Text is read once, coalesced (8 consecutive bytes per lane); ids leave in document order.
+//
+// The same source runs on the GPU (bf_kernels.hip supplies namespace wv with the wave intrinsics) and, for tests only, on the host
+// inside a 64-fibre wave simulator (tests/hosttest/wave_emu.h) where it is fuzzed against the oracle.  Rule of the house: every
+// wv:: collective is called in wave-uniform control flow.
+#pragma once
+#include <stdint.h>
+#include "bf_layout.h"
+#include "bf_lex.h"
+#include "bf_batch.h"
+
+#if defined(__HIPCC__)
+#define BF_WV __host__ __device__ __forceinline__
+#define BF_WVD __device__ __forceinline__
+#else
+#define BF_WV inline
+#define BF_WVD inline
+#endif
+
+namespace bfa {
+
+// what a top-level walk that STARTS on an element of this class does (bf_model.cpp, "unit form")
+constexpr uint32_t WK_GENERAL = 0;   // walk the automaton
+constexpr uint32_t WK_LOOP = 1;      // enters the closed, final loop state: the token is the run of WK_LOOP elements (capped by max-length)
+constexpr uint32_t WK_NOMATCH = 2;   // no transition from the initial state: no token, next start = next element
+constexpr uint32_t WK_SOLO = 3;      // a final state without transitions: a one-element token
+constexpr int WK_SHIFT = 14;
+
+constexpr int WV_CHUNK = 512;        // bytes decoded per step (8 per lane)
+constexpr uint32_t WV_DT_CLOSED = 1, WV_DT_BAD = 2;
+
+struct WpWaveParams {
+    const uint64_t *T;               // lexer table, bf_layout.h entries (high word: action info of a final destination)
+    const int32_t *acts;             // action records [left, right, tag, nfn, (fn, ini, ini_l)*]
+    DevCpMap cpmap;                  // fused code point -> charmap -> class map
+    const uint8_t *kind;             // [nclasses] WK_* per class
+    int nclasses;
+    uint32_t initial, loop_info;
+    int max_token_length;
+    Batch b;
+    int32_t *ids_tmp;                // staging: document d writes ids_tmp[ids_slot(doc_off[d], d) ..)
+    int32_t *counts;                 // [ndocs]
+    int max_ids, unk;
+    unsigned long long *next_doc;    // work counter
+    unsigned long long *stats;       // optional (experiments): [0] windows [1] slow windows [2] flushes [3] tokens [4] phase-B trips [5] lane-steps [6] rewalks
+};
+
+BF_WV int64_t wv_ids_slot(int64_t doc_off_d, int64_t d) { return ((doc_off_d + 7) & ~(int64_t)7) + 8 * d; }
+
+BF_WV uint32_t wv_cpmap_get(const DevCpMap &m, int cp) { return m.pages[(uint32_t)m.l1[cp >> 8] * 256u + (uint32_t)(cp & 255)]; }
+
+// ring element of a code point: class | kind << 14
+BF_WV uint32_t wv_element(const WpWaveParams &p, int cp)
+{
+    const uint32_t c = wv_cpmap_get(p.cpmap, cp) & LX_T_CLS_MASK;
+    const uint32_t k = c < (uint32_t)p.nclasses ? (uint32_t)p.kind[c] : WK_NOMATCH;      // LX_CLS_NONE: not in the alphabet
+    return c | (k << WK_SHIFT);
+}
+
+// per-workgroup table of the 128 ASCII code points (LDS)
+BF_WV void wv_init_ascii(const WpWaveParams &p, uint16_t *ascii, int tid, int nthreads)
+{
+    for (int i = tid; i < 128; i += nthreads) ascii[i] = (uint16_t)wv_element(p, i);
+}
+
+} // namespace bfa

@@ -22,7 +22,7 @@ static unsigned long long g_lookup_hist[4096];
 
 using namespace bfa;
 
-struct Handle { Model m; std::string path; };
+#include "hosttest.h"
 
 static long g_big_pool = 64l << 20;   // bft_set_big_pool: bytes of the pool behind seg_bpe_doc_big (the device's is 64 MiB per batch)
 static int g_uni_seq = 0;     // bft_set_uni_seq(1): Unigram through the plain sequential restatement (seg_unigram_doc) instead of UniLane

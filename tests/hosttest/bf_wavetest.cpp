@@ -1,0 +1,81 @@
+// bf_wavetest.cpp -- TEST-ONLY (part of libbf_hosttest.so, never linked into the product).
+//
+// Runs the wave kernel of bf_wave.h -- the very source the GPU executes -- inside the 64-fibre wave simulator of wave_emu.h,
+// followed by a scalar restatement of the scan + compaction kernels, so that the whole WordPiece batch path of a unit-form model
+// can be fuzzed against the oracle without a GPU.
+#include "wave_emu.h"
+#include "../../blingfire_amd/csrc/bf_wave_body.h"
+#include "hosttest.h"
+
+#include <vector>
+
+using namespace bfa;
+
+template <class LDS, int UNROLL>
+static void run_cfg(const WpWaveParams &p, int nwaves, int grab)
+{
+    std::vector<LDS *> lds;
+    std::vector<uint16_t> ascii(128);
+    for (int i = 0; i < 128; ++i) ascii[(size_t)i] = (uint16_t)wv_element(p, i);
+    int next_wave = 0;
+    std::vector<LDS *> of_wave((size_t)nwaves);
+    for (int i = 0; i < nwaves; ++i) { of_wave[(size_t)i] = new LDS(); memset((void *)of_wave[(size_t)i], 0xA5, sizeof(LDS)); }
+    // every fibre of a wave must see the same LDS block: the wave object's address identifies the wave
+    std::vector<const void *> wave_ids;
+    auto body = [&]() {
+        const void *wid = (const void *)wvemu::g_cur->wave;
+        size_t k = 0;
+        for (; k < wave_ids.size(); ++k) if (wave_ids[k] == wid) break;
+        if (k == wave_ids.size()) { wave_ids.push_back(wid); (void)next_wave; }
+        WpWave<LDS, UNROLL, true> w(p, *of_wave[k], ascii.data());
+        w.run(grab);
+    };
+    wvemu::run_waves(nwaves, body);
+    for (auto *q : of_wave) delete q;
+}
+
+extern "C" {
+
+int bft_wave_ok(void *hv) { return ((Handle *)hv)->m.wave_ok ? 1 : 0; }
+const char *bft_wave_why(void *hv) { return ((Handle *)hv)->m.wave_why.c_str(); }
+
+// TextToIdsBatch through the wave kernel on the host.  cfg: 0 = the shipped configuration, 1 = a small queue / document table (flushes
+// everywhere), 2 = a large ring.  Returns the total id count, or < 0 (-1: model not in unit form, -5: the kernel raised a status bit).
+// stats (optional, 8 counters): see bf_wave.h WpWaveParams::stats.
+long bft_emu_wave_batch(void *hv, const uint8_t *text, const int64_t *doc_off, long ndocs, int max_ids, int unk, int nwaves, int grab, int cfg,
+                        int32_t *ids_out, long ids_cap, int64_t *id_off, unsigned long long *stats)
+{
+    Model &m = ((Handle *)hv)->m;
+    if (!m.error.empty() || m.kind != KIND_WP || !m.wave_ok) return -1;
+    if (max_ids < 0) max_ids = 0;
+    const int64_t total = ndocs > 0 ? doc_off[ndocs] : 0;
+    std::vector<int32_t> tmp((size_t)(total + 8 * ndocs + 64), -77), counts((size_t)ndocs + 1, -55);
+    unsigned long long next_doc = 0; int status = 0;
+    WpWaveParams p;
+    p.T = m.wbd_t2.data(); p.acts = m.acts_pool.data();
+    p.cpmap = DevCpMap{m.wbd_cpmap.l1.data(), m.wbd_cpmap.pages.data()};
+    p.kind = m.wave_kind.data(); p.nclasses = m.wbd.nclasses;
+    p.initial = m.wbd.initial_base; p.loop_info = m.loop_info; p.max_token_length = m.max_token_length;
+    p.b = Batch{text, doc_off, ndocs, total, &status};
+    p.ids_tmp = tmp.data(); p.counts = counts.data(); p.max_ids = max_ids; p.unk = unk; p.next_doc = &next_doc; p.stats = stats;
+    if (ndocs > 0) {
+        if (cfg == 1) run_cfg<WvLds<1024, 72, 3>, 1>(p, nwaves, grab);
+        else if (cfg == 2) run_cfg<WvLds<4096, 256, 64>, 3>(p, nwaves, grab);
+        else run_cfg<WvLds<1024, 128, 64>, 2>(p, nwaves, grab);
+    }
+    if (status) return -5;
+    // k_scan + k_compact, restated
+    long o = 0;
+    for (long d = 0; d < ndocs; ++d) {
+        id_off[d] = o;
+        const int c = counts[(size_t)d];
+        if (c < 0) return -6;                                // a document nobody wrote a count for
+        const int64_t slot = wv_ids_slot(doc_off[d], d);
+        for (int i = 0; i < c; ++i) { if (o + i < ids_cap) ids_out[o + i] = tmp[(size_t)(slot + i)]; }
+        o += c;
+    }
+    id_off[ndocs] = o;
+    return o;
+}
+
+} // extern "C"
