@@ -16,6 +16,7 @@
 #include <condition_variable>
 #include <cstring>
 #include <mutex>
+#include <new>
 #include <string>
 #include <thread>
 #include <vector>
@@ -797,17 +798,19 @@ int run_dict_device(Handle *h, const int32_t *d_keys, const int64_t *d_key_off, 
     return hip_ok(hipGetLastError(), "dictionary lookup kernels") ? 0 : BF_E_DEVICE;
 }
 
-// One launch for a group of single-document requests that share (max_ids, unk, offsets wanted): the documents are packed,
-// run as one batch, and every caller gets exactly what its own TextToIds call would have written.
-void run_one_group(Handle *h, std::vector<Handle::OneReq *> &g)
+// ids one document of n bytes can produce at most (WordPiece: one per character; SentencePiece-style: the dummy prefix and a
+// charmap that expands 1:2 -- the same bound the device workspaces use), capped by the caller's array
+static int64_t one_doc_cap(int n, int max_ids) { const int64_t w = 2 * ((int64_t)n + 1); return w < max_ids ? w : (int64_t)max_ids; }
+
+void run_one_group_impl(Handle *h, std::vector<Handle::OneReq *> &g)
 {
     const int max_ids = g[0]->max_ids, unk = g[0]->unk; const bool want_off = g[0]->starts && g[0]->ends;
     const int64_t nd = (int64_t)g.size();
     std::vector<int64_t> off((size_t)nd + 1, 0), id_off((size_t)nd + 1, 0);
-    for (int64_t i = 0; i < nd; ++i) off[(size_t)i + 1] = off[(size_t)i] + g[(size_t)i]->n;
+    int64_t cap = 0;
+    for (int64_t i = 0; i < nd; ++i) { off[(size_t)i + 1] = off[(size_t)i] + g[(size_t)i]->n; cap += one_doc_cap(g[(size_t)i]->n, max_ids); }
     std::string packed; const char *text = g[0]->s;
     if (nd > 1) { packed.resize((size_t)off[(size_t)nd]); for (int64_t i = 0; i < nd; ++i) memcpy(&packed[(size_t)off[(size_t)i]], g[(size_t)i]->s, (size_t)g[(size_t)i]->n); text = packed.data(); }
-    const int64_t cap = nd * (int64_t)max_ids;
     std::vector<int32_t> ids, st, en; int32_t *pi = g[0]->ids, *ps = g[0]->starts, *pe = g[0]->ends;
     if (nd > 1) { ids.resize((size_t)cap); pi = ids.data(); if (want_off) { st.resize((size_t)cap); en.resize((size_t)cap); ps = st.data(); pe = en.data(); } }
     const int64_t r = run_host(h, text, off.data(), nd, pi, cap, id_off.data(), max_ids, unk, want_off ? ps : nullptr, want_off ? pe : nullptr);
@@ -821,6 +824,20 @@ void run_one_group(Handle *h, std::vector<Handle::OneReq *> &g)
             if (want_off) { memcpy(q->starts, ps + b, (size_t)c * 4); memcpy(q->ends, pe + b, (size_t)c * 4); }
         }
         q->result = (int)c;
+    }
+}
+
+// One launch for a group of single-document requests that share (max_ids, unk, offsets wanted): the documents are packed,
+// run as one batch, and every caller gets exactly what its own TextToIds call would have written.  Nothing may leave through the
+// extern "C" entry points: when the temporaries of a combined launch cannot be allocated, the requests are served one by one
+// (a batch of one writes straight into the caller's arrays).
+void run_one_group(Handle *h, std::vector<Handle::OneReq *> &g)
+{
+    try { run_one_group_impl(h, g); return; }
+    catch (const std::bad_alloc &) {}
+    for (Handle::OneReq *q : g) {
+        std::vector<Handle::OneReq *> one{q};
+        try { run_one_group_impl(h, one); } catch (const std::bad_alloc &) { q->result = 0; }
     }
 }
 
@@ -847,10 +864,13 @@ int text_to_ids_one(void *hp, const char *s, int n, int32_t *ids, int max_ids, i
         std::vector<Handle::OneReq *> all; all.swap(h->q);
         lk.unlock();
         while (!all.empty()) {                                // groups of requests with the same call parameters
-            std::vector<Handle::OneReq *> g, rest; int64_t bytes = 0;
+            std::vector<Handle::OneReq *> g, rest; int64_t bytes = 0, idcap = 0;
             for (Handle::OneReq *q : all) {
                 const bool same = q->max_ids == all[0]->max_ids && q->unk == all[0]->unk && ((q->starts && q->ends) == (all[0]->starts && all[0]->ends));
-                if (same && bytes + q->n <= 1000000000 && (int64_t)(g.size() + 1) * q->max_ids <= 2000000000) { g.push_back(q); bytes += q->n; } else rest.push_back(q);
+                const int64_t c = one_doc_cap(q->n, q->max_ids);
+                // the first request of a group is always admitted (whatever its max_ids: INT_MAX means "no limit"); the others while
+                // the combined batch stays within the limits of one launch
+                if (g.empty() || (same && bytes + q->n <= 1000000000 && idcap + c <= 1000000000)) { g.push_back(q); bytes += q->n; idcap += c; } else rest.push_back(q);
             }
             run_one_group(h, g);
             lk.lock();

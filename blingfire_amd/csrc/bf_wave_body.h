@@ -399,13 +399,13 @@ struct WpWave {
         wv::sync();
     }
 
-    BF_WVD void document(int64_t d)
+    // starts document d; false: nothing to tokenise (its count is written here)
+    BF_WVD bool open_document(int64_t d)
     {
         const int64_t b = p.b.doc_off[d];
         const int64_t n64 = p.b.doc_off[d + 1] - b;
-        if (n64 <= 0 || n64 > 1000000000) { if (lane == 0) p.counts[d] = 0; return; }                                // tokdll:1121
-        if (b < 0 || b + n64 > p.b.total_bytes) { if (lane == 0) { p.counts[d] = 0; wv::atomic_or(p.b.status, BF_STATUS_BAD_OFFSETS); } return; }
-        if (dn == DTN) flush();
+        if (n64 <= 0 || n64 > 1000000000) { if (lane == 0) p.counts[d] = 0; return false; }                                // tokdll:1121
+        if (b < 0 || b + n64 > p.b.total_bytes) { if (lane == 0) { p.counts[d] = 0; wv::atomic_or(p.b.status, BF_STATUS_BAD_OFFSETS); } return false; }
         n = (int)n64; s = p.b.text + b;
         int cap = p.max_ids; if ((int64_t)cap > n64) cap = n; if (cap < 0) cap = 0;
         curk = dn++;
@@ -413,37 +413,55 @@ struct WpWave {
         rhi = (rhi + 7u) & ~7u; rbase = rhi;
         dec_bytes = dec = done = bom = 0; err = false;
         wv::sync();
-        for (;;) {
-            while (dec_bytes < n && ring_free() >= WV_CHUNK) decode_chunk();
-            const bool fully = dec_bytes >= n;
-            while (done < dec) {
-                if (qn + 64 > QCAP) { flush(); continue; }
-                if (!phase_a(fully)) break;
-            }
-            if (fully && done >= dec) break;
-            // the token at `done` reaches past what is decoded: make room (the ring then holds less than a token) and decode on
-            if (ring_free() < WV_CHUNK || fully) flush();
-            if (fully || ring_free() < WV_CHUNK) {                // cannot happen (max token length <= RING - chunk - 16, checked at load)
-                if (lane == 0) wv::atomic_or(p.b.status, BF_STATUS_INTERNAL);
-                break;
-            }
-        }
+        return true;
+    }
+    BF_WVD void close_document()
+    {
         const bool bad = wv::any(err);
         if (lane == 0) S.dt_flags[curk] = WV_DT_CLOSED | (bad ? WV_DT_BAD : 0u);
         wv::sync();
     }
 
+    // One loop, every phase in it exactly once (the program is inlined into the kernel: what is called from two places is there
+    // twice): each trip does the one thing that can be done next -- fetch a document, decode a chunk, resolve a window of start
+    // positions, or flush (tokenise what is queued) when the queue, the document table or the ring is full.
     BF_WVD void run(int grab)
     {
+        int64_t dnext = 0, dend = 0;
+        bool have_doc = false, exiting = false;
         for (;;) {
-            unsigned long long base = 0;
-            if (lane == 0) base = wv::atomic_add(p.next_doc, (unsigned long long)grab);
-            base = wv::bcast(base, 0);
-            if ((int64_t)base >= p.b.ndocs) break;
-            const int64_t end = (int64_t)base + grab < p.b.ndocs ? (int64_t)base + grab : p.b.ndocs;
-            for (int64_t d = (int64_t)base; d < end; ++d) document(d);
+            bool do_flush = false;
+            if (!have_doc) {
+                if (exiting) { if (qn == 0 && dn == 0) break; do_flush = true; }
+                else if (dn == DTN) do_flush = true;
+                else {
+                    if (dnext >= dend) {
+                        unsigned long long base = 0;
+                        if (lane == 0) base = wv::atomic_add(p.next_doc, (unsigned long long)grab);
+                        base = wv::bcast(base, 0);
+                        dnext = (int64_t)base; dend = dnext + grab < p.b.ndocs ? dnext + grab : p.b.ndocs;
+                        if (dnext >= p.b.ndocs) { exiting = true; continue; }
+                    }
+                    have_doc = open_document(dnext++);
+                    continue;
+                }
+            } else {
+                if (dec_bytes < n && ring_free() >= WV_CHUNK) { decode_chunk(); continue; }
+                const bool fully = dec_bytes >= n;
+                if (done < dec) {
+                    if (qn + 64 > QCAP) do_flush = true;
+                    else if (phase_a(fully)) continue;
+                    else do_flush = true;                       // the token at `done` reaches past what is decoded and the ring has no room
+                } else if (fully) { close_document(); have_doc = false; continue; }
+                else do_flush = true;                           // everything decoded is resolved, the ring has no room for the next chunk
+                if (do_flush && qn == 0 && rlo == rbase + (uint32_t)done) {
+                    // nothing to flush and nothing to free: cannot happen (max token length <= RING - chunk - 16, checked at load)
+                    if (lane == 0) wv::atomic_or(p.b.status, BF_STATUS_INTERNAL);
+                    close_document(); have_doc = false; continue;
+                }
+            }
+            if (do_flush) flush();
         }
-        flush();
         if (STATS && lane == 0) {
             wv::atomic_add(&p.stats[0], st_win); wv::atomic_add(&p.stats[1], st_slow); wv::atomic_add(&p.stats[2], st_flush); wv::atomic_add(&p.stats[3], st_tok);
             wv::atomic_add(&p.stats[4], st_trips); wv::atomic_add(&p.stats[5], st_steps);

@@ -42,14 +42,14 @@ const char *bft_wave_why(void *hv) { return ((Handle *)hv)->m.wave_why.c_str(); 
 // TextToIdsBatch through the wave kernel on the host.  cfg: 0 = the shipped configuration, 1 = a small queue / document table (flushes
 // everywhere), 2 = a large ring.  Returns the total id count, or < 0 (-1: model not in unit form, -5: the kernel raised a status bit).
 // stats (optional, 8 counters): see bf_wave.h WpWaveParams::stats.
-long bft_emu_wave_batch(void *hv, const uint8_t *text, const int64_t *doc_off, long ndocs, int max_ids, int unk, int nwaves, int grab, int cfg,
+long bft_emu_wave_batch(void *hv, const uint8_t *text, long text_bytes, const int64_t *doc_off, long ndocs, int max_ids, int unk, int nwaves, int grab, int cfg,
                         int32_t *ids_out, long ids_cap, int64_t *id_off, unsigned long long *stats)
 {
     Model &m = ((Handle *)hv)->m;
     if (!m.error.empty() || m.kind != KIND_WP || !m.wave_ok) return -1;
     if (max_ids < 0) max_ids = 0;
-    const int64_t total = ndocs > 0 ? doc_off[ndocs] : 0;
-    std::vector<int32_t> tmp((size_t)(total + 8 * ndocs + 64), -77), counts((size_t)ndocs + 1, -55);
+    const int64_t total = text_bytes;                              // what the caller's buffer really holds
+    std::vector<int32_t> tmp((size_t)(total + 8 * ndocs + 64 + 8), -77), counts((size_t)ndocs + 1, -55);
     unsigned long long next_doc = 0; int status = 0;
     WpWaveParams p;
     p.T = m.wbd_t2.data(); p.acts = m.acts_pool.data();
@@ -70,6 +70,7 @@ long bft_emu_wave_batch(void *hv, const uint8_t *text, const int64_t *doc_off, l
         id_off[d] = o;
         const int c = counts[(size_t)d];
         if (c < 0) return -6;                                // a document nobody wrote a count for
+        if (c == 0) continue;
         const int64_t slot = wv_ids_slot(doc_off[d], d);
         for (int i = 0; i < c; ++i) { if (o + i < ids_cap) ids_out[o + i] = tmp[(size_t)(slot + i)]; }
         o += c;

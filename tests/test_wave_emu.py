@@ -1,0 +1,125 @@
+"""CPU: the wave program of the WordPiece path (blingfire_amd/csrc/bf_wave_body.h -- the source the GPU kernel k_wp_wave runs) executed
+inside the 64-fibre wave simulator of tests/hosttest/wave_emu.h, followed by a scalar restatement of scan + compaction, against the
+oracle.  Covers what a per-lane host emulation cannot: the ballot / prefix-scan logic, the LDS ring and queue, flushes in the middle of a
+document, several waves pulling documents from one counter, and every queue / ring configuration.  The simulator aborts on a collective
+reached in divergent control flow, so these tests also pin the wave-uniformity of the program."""
+import ctypes
+import random
+
+import numpy as np
+import pytest
+
+import bfutil
+import blingfire_amd as bf
+
+WP_MODELS = ["bert_base_tok.bin", "bert_base_cased_tok.bin", "bert_chinese.bin"]
+# (max_ids, unk, waves, documents per grab, configuration: 0 = shipped, 1 = tiny queue and document table, 2 = large ring)
+CONFS = [(512, 100, 1, 8, 0), (512, 100, 4, 2, 1), (64, 5, 2, 8, 2), (1, 100, 1, 3, 1), (0, 100, 2, 8, 0)]
+
+
+@pytest.fixture(scope="module")
+def ht():
+    L = ctypes.CDLL(bfutil.HOSTTEST_LIB)
+    L.bft_load.restype = ctypes.c_void_p
+    L.bft_load.argtypes = [ctypes.c_char_p]
+    L.bft_free.argtypes = [ctypes.c_void_p]
+    L.bft_wave_ok.argtypes = [ctypes.c_void_p]
+    L.bft_wave_why.restype = ctypes.c_char_p
+    L.bft_wave_why.argtypes = [ctypes.c_void_p]
+    L.bft_emu_wave_batch.restype = ctypes.c_long
+    L.bft_emu_wave_batch.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_long, ctypes.c_void_p, ctypes.c_long, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                     ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_long, ctypes.c_void_p, ctypes.c_void_p]
+    return L
+
+
+def wave_batch(ht, h, text, off, max_ids, unk, nwaves, grab, cfg):
+    nd = len(off) - 1
+    cap = len(text) + 16
+    ids = np.full(cap, -9, dtype=np.int32)
+    ido = np.zeros(nd + 1, dtype=np.int64)
+    st = np.zeros(8, dtype=np.uint64)
+    r = ht.bft_emu_wave_batch(h, text.ctypes.data, len(text), off.ctypes.data, nd, max_ids, unk, nwaves, grab, cfg, ids.ctypes.data, cap, ido.ctypes.data, st.ctypes.data)
+    return r, ids[:max(r, 0)], ido, st
+
+
+def check(ht, model, docs, confs):
+    mp = bfutil.model_path(model)
+    h = ht.bft_load(mp.encode())
+    assert ht.bft_wave_ok(h) == 1, ht.bft_wave_why(h)
+    ora = bfutil.oracle()
+    ho = ora.load(mp)
+    text, off = docs if isinstance(docs, tuple) else bf.pack_docs(docs)
+    for (mx, unk, nw, grab, cfg) in confs:
+        r, ids, ido, _ = wave_batch(ht, h, text, off, mx, unk, nw, grab, cfg)
+        gids, goff = ora.batch(ho, text, off, mx, unk)
+        assert r >= 0, (model, r)
+        if not (np.array_equal(ido, goff) and np.array_equal(ids, gids)):
+            for d in range(len(off) - 1):
+                a, b = ids[ido[d]:ido[d + 1]], gids[goff[d]:goff[d + 1]]
+                assert np.array_equal(a, b), (model, (mx, unk, nw, grab, cfg), d, bytes(text[off[d]:off[d + 1]])[:80], a.tolist()[:20], b.tolist()[:20])
+    ora.free(ho)
+    ht.bft_free(h)
+
+
+def test_unit_form_is_proven_for_the_bert_lexers_only(ht):
+    for model, want in [(m, 1) for m in WP_MODELS] + [("wbd.bin", 0), ("sbd.bin", 0), ("wbd_chuni.bin", 0)]:
+        if not bfutil.have_model(model):
+            continue
+        h = ht.bft_load(bfutil.model_path(model).encode())
+        assert ht.bft_wave_ok(h) == want, (model, ht.bft_wave_why(h))
+        if not want:
+            assert ht.bft_wave_why(h) != b""
+        ht.bft_free(h)
+
+
+@pytest.mark.parametrize("model", WP_MODELS)
+def test_adversarial_and_fuzz(ht, model):
+    if not bfutil.have_model(model):
+        pytest.skip("%s not present" % model)
+    check(ht, model, list(bfutil.ADVERSARIAL) + bfutil.fuzz_docs(1500, seed=11), CONFS)
+
+
+@pytest.mark.parametrize("model", WP_MODELS)
+def test_long_words_window_edges_and_large_documents(ht, model):
+    if not bfutil.have_model(model):
+        pytest.skip("%s not present" % model)
+    rnd = random.Random(7)
+    alpha = "abcdefghijklmnopqrstuvwxyz"
+    docs = []
+    for L in [63, 64, 65, 127, 128, 129, 299, 300, 301, 511, 512, 513, 600, 1023, 1024, 1025, 2000]:
+        docs += [("a" * L).encode(), (" " + "b" * L + " c").encode(), ("x y " + "é" * L).encode(), "".join(rnd.choice(alpha) for _ in range(L)).encode(),
+                 ("好" * L).encode(), ("." * L).encode(), (" " * L).encode(), ("[UNK]" * L).encode(), ("[UN" * L).encode()]
+    docs.append(" ".join("".join(rnd.choice(alpha) for _ in range(rnd.randint(1, 12))) for _ in range(30000)).encode())      # ~200 KB
+    docs.append(b"\xef\xbb\xbf" + ("word é " * 3000).encode())
+    docs.append(("w" * 700 + " ").encode() * 40)
+    check(ht, model, docs, CONFS[:3])
+
+
+@pytest.mark.parametrize("model", WP_MODELS)
+def test_many_tiny_documents(ht, model):
+    if not bfutil.have_model(model):
+        pytest.skip("%s not present" % model)
+    rnd = random.Random(3)
+    docs = [bytes([rnd.randrange(32, 127)]) for _ in range(500)] + [b"ab"] * 100 + [b"\xff"] * 5 + [b"a b"] * 70
+    check(ht, model, docs, CONFS[:3])
+
+
+def test_headline_and_config2_corpora(ht):
+    model = bfutil.bert_model_name()
+    check(ht, model, bfutil.gen_workload("headline512", 1200), [(512, 100, 3, 8, 0), (512, 100, 2, 8, 1)])
+    check(ht, model, bfutil.gen_workload("config2", 3000), [(512, 100, 3, 8, 0)])
+    check(ht, model, bfutil.gen_corpus_multi(500), [(512, 100, 3, 8, 0)])
+
+
+def test_documents_outside_the_buffer_and_empty_documents(ht):
+    """offsets that leave the text buffer make the document empty (status bit 3 on the device; the host harness reports -5)"""
+    model = bfutil.bert_model_name()
+    h = ht.bft_load(bfutil.model_path(model).encode())
+    text = np.frombuffer(b"hello world", dtype=np.uint8).copy()
+    off = np.array([0, 5, 5, 11], dtype=np.int64)              # an empty document in the middle
+    r, ids, ido, _ = wave_batch(ht, h, text, off, 16, 100, 1, 8, 0)
+    assert r == 2 and ido.tolist() == [0, 1, 1, 2]
+    bad = np.array([0, 5, 40], dtype=np.int64)
+    r, _, _, _ = wave_batch(ht, h, text, bad, 16, 100, 1, 8, 0)
+    assert r == -5
+    ht.bft_free(h)
