@@ -677,6 +677,7 @@ __device__ __forceinline__ unsigned long long bcast(unsigned long long v, int sr
     const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, src), hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), src);
     return ((unsigned long long)hi << 32) | lo;
 }
+__device__ __forceinline__ int64_t bcast(int64_t v, int src) { return (int64_t)bcast((unsigned long long)v, src); }
 template <class T> __device__ __forceinline__ T shfl_up(T v, int delta) { return __shfl_up(v, (unsigned)delta, 64); }
 template <class T> __device__ __forceinline__ T shfl_down(T v, int delta) { return __shfl_down(v, (unsigned)delta, 64); }
 __device__ __forceinline__ int incl_scan(int v) { return bfa::wave_incl_scan(v); }
@@ -686,43 +687,46 @@ __device__ __forceinline__ void atomic_or(int *p, int v) { atomicOr(p, v); }
 #include "bf_wave_body.h"
 namespace bfa {
 
-template <class LDS, int UNROLL, int WAVES, bool STATS>
+template <class LDS, int NU, int WAVES, bool STATS>
 __global__ __launch_bounds__(64 * WAVES) void k_wp_wave(WpWaveParams p, int grab)
 {
     __shared__ LDS lds[WAVES];
     __shared__ uint16_t ascii[128];
+    __shared__ int32_t acts[WV_ACTS_MAX];
     wv_init_ascii(p, ascii, (int)threadIdx.x, 64 * WAVES);
+    for (int i = (int)threadIdx.x; i < p.acts_n; i += 64 * WAVES) acts[i] = p.acts[i];
     __syncthreads();
-    WpWave<LDS, UNROLL, STATS> w(p, lds[threadIdx.x >> 6], ascii);
+    WpWave<LDS, NU, STATS> w(p, lds[threadIdx.x >> 6], ascii, acts);
     w.run(grab);
 }
 
-template <class LDS, int UNROLL, int WAVES>
+template <class LDS, int NU, int WAVES>
 static void launch_wp_wave_cfg(const WpWaveParams &p, int grab, int per_cu_override, hipStream_t s)
 {
     int per_cu = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_wp_wave<LDS, UNROLL, WAVES, false>, 64 * WAVES, 0) != hipSuccess || per_cu <= 0) per_cu = 2;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_wp_wave<LDS, NU, WAVES, false>, 64 * WAVES, 0) != hipSuccess || per_cu <= 0) per_cu = 2;
     (void)hipGetLastError();
     if (per_cu_override > 0) per_cu = per_cu_override;
     int64_t blocks = (int64_t)device_cus() * per_cu;
     const int64_t need = (p.b.ndocs + (int64_t)grab * WAVES - 1) / ((int64_t)grab * WAVES);
     if (blocks > need) blocks = need;
     if (blocks < 1) blocks = 1;
-    if (p.stats) hipLaunchKernelGGL((k_wp_wave<LDS, UNROLL, WAVES, true>), dim3((unsigned)blocks), dim3(64 * WAVES), 0, s, p, grab);
-    else hipLaunchKernelGGL((k_wp_wave<LDS, UNROLL, WAVES, false>), dim3((unsigned)blocks), dim3(64 * WAVES), 0, s, p, grab);
+    if (p.stats) hipLaunchKernelGGL((k_wp_wave<LDS, NU, WAVES, true>), dim3((unsigned)blocks), dim3(64 * WAVES), 0, s, p, grab);
+    else hipLaunchKernelGGL((k_wp_wave<LDS, NU, WAVES, false>), dim3((unsigned)blocks), dim3(64 * WAVES), 0, s, p, grab);
 }
 
-// variant (experiments): bits 8..11 = queue/ring configuration, bits 12..15 = documents per grab (0 = 8), bits 24..29 = workgroups per CU
+// variant (experiments): bits 8..11 = configuration (units per lane, queue / ring sizes), bits 12..15 = documents per grab (0 = 8),
+// bits 24..29 = workgroups per CU
 void launch_wp_wave(const WpWaveParams &p, int variant, hipStream_t s)
 {
     const int cfg = (variant >> 8) & 0xf;
     int grab = (variant >> 12) & 0xf; if (grab == 0) grab = 8;
     const int per_cu = (variant >> 24) & 0x3f;
-    if (cfg == 1) launch_wp_wave_cfg<WvLds<2048, 256, 64>, 2, 4>(p, grab, per_cu, s);
-    else if (cfg == 2) launch_wp_wave_cfg<WvLds<1024, 128, 64>, 3, 4>(p, grab, per_cu, s);
-    else if (cfg == 3) launch_wp_wave_cfg<WvLds<2048, 256, 64>, 3, 4>(p, grab, per_cu, s);
-    else if (cfg == 4) launch_wp_wave_cfg<WvLds<1024, 128, 64>, 1, 4>(p, grab, per_cu, s);
-    else launch_wp_wave_cfg<WvLds<1024, 128, 64>, 2, 4>(p, grab, per_cu, s);
+    if (cfg == 1) launch_wp_wave_cfg<WvLds<1024, 128, 64, 8>, 1, 4>(p, grab, per_cu, s);
+    else if (cfg == 2) launch_wp_wave_cfg<WvLds<1024, 128, 64, 8>, 3, 4>(p, grab, per_cu, s);
+    else if (cfg == 3) launch_wp_wave_cfg<WvLds<2048, 256, 64, 8>, 2, 4>(p, grab, per_cu, s);
+    else if (cfg == 4) launch_wp_wave_cfg<WvLds<1024, 128, 64, 4>, 2, 4>(p, grab, per_cu, s);
+    else launch_wp_wave_cfg<WvLds<1024, 128, 64, 8>, 2, 4>(p, grab, per_cu, s);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -772,6 +772,7 @@ bool build_model(Model &m, const uint8_t *img, size_t size)
                 else if (!m.fn_no_ra) why = "a function rule uses the right anchor";
                 else if (m.max_depth < 2) why = "max-depth < 2";
                 else if (m.max_token_length < 1 || m.max_token_length > 496) why = "max token length outside 1..496";
+                else if (m.acts_pool.size() > 512) why = "more than 512 ints of action records";
                 // C = states behind at least one letter from the initial state (text classes only): what a top-level walk can be in
                 std::vector<uint8_t> inC((size_t)nst, 0);
                 if (why.empty()) {
@@ -830,6 +831,20 @@ bool build_model(Model &m, const uint8_t *img, size_t size)
                         if (loop_ok && d == (long)m.loop_base && m.loop_cls[(size_t)c]) m.wave_kind[(size_t)c] = 1 /* WK_LOOP */;
                         else if (st >= 0 && fin && rw.tr_begin[(size_t)st] == rw.tr_begin[(size_t)st + 1]) m.wave_kind[(size_t)c] = 3 /* WK_SOLO */;
                     }
+                    // WK_SOLO tokens carry ONE action (the most frequent among the solo destinations; the BERT lexers have one);
+                    // a solo class with another action is left to the general walk
+                    std::vector<std::pair<uint32_t, int>> freq;
+                    auto solo_inf = [&](int c) { return m.wbd_info[(size_t)m.wbd.step(m.wbd.initial_base, (uint32_t)c, nullptr, nullptr)]; };
+                    for (int c = 0; c < m.wbd.nclasses; ++c) {
+                        if (m.wave_kind[(size_t)c] != 3) continue;
+                        const uint32_t inf = solo_inf(c);
+                        size_t k = 0; for (; k < freq.size(); ++k) if (freq[k].first == inf) break;
+                        if (k == freq.size()) freq.push_back({inf, 0});
+                        ++freq[k].second;
+                    }
+                    int best = -1; for (size_t k = 0; k < freq.size(); ++k) if (best < 0 || freq[k].second > freq[(size_t)best].second) best = (int)k;
+                    m.wave_solo_info = best >= 0 ? freq[(size_t)best].first : 0;
+                    for (int c = 0; c < m.wbd.nclasses; ++c) if (m.wave_kind[(size_t)c] == 3 && solo_inf(c) != m.wave_solo_info) m.wave_kind[(size_t)c] = 0;
                 }
             }
         }

@@ -129,6 +129,7 @@ struct Model {
     // of its own.  wave_kind[class]: what a walk that STARTS on this class does (bf_wave.h WK_*), proven from the automaton.
     bool wave_ok = false; std::string wave_why;        // wave_why: the first condition that failed (diagnostics, tests)
     std::vector<uint8_t> wave_kind;
+    uint32_t wave_solo_info = 0;                       // action info of every WK_SOLO token
     // TextToWords view of the same lexer (tokdll:415-566): NO charmap, U+0000 is fed as U+0020 -> plain code point -> class map
     TwoLevelMap words_cpmap;
 

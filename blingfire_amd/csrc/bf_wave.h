@@ -50,6 +50,7 @@ constexpr uint32_t WK_SOLO = 3;      // a final state without transitions: a one
 constexpr int WK_SHIFT = 14;
 
 constexpr int WV_CHUNK = 512;        // bytes decoded per step (8 per lane)
+constexpr int WV_ACTS_MAX = 512;     // ints of action records a unit-form lexer may have (bf_model.cpp)
 constexpr uint32_t WV_DT_CLOSED = 1, WV_DT_BAD = 2;
 
 struct WpWaveParams {
@@ -58,14 +59,16 @@ struct WpWaveParams {
     DevCpMap cpmap;                  // fused code point -> charmap -> class map
     const uint8_t *kind;             // [nclasses] WK_* per class
     int nclasses;
-    uint32_t initial, loop_info;
+    uint32_t initial, loop_info, solo_info;
+    int acts_n;                      // ints in acts (<= WV_ACTS_MAX: staged in LDS)
     int max_token_length;
     Batch b;
     int32_t *ids_tmp;                // staging: document d writes ids_tmp[ids_slot(doc_off[d], d) ..)
     int32_t *counts;                 // [ndocs]
     int max_ids, unk;
     unsigned long long *next_doc;    // work counter
-    unsigned long long *stats;       // optional (experiments): [0] windows [1] slow windows [2] flushes [3] tokens [4] phase-B trips [5] lane-steps [6] rewalks
+    unsigned long long *stats;       // optional (experiments): [0] trips [1] fast windows [2] general windows [3] tokens [4] unit-steps issued [5] retire rounds
+                                     // [6] rewalks [7] trips without a produce action [8] decode steps
 };
 
 BF_WV int64_t wv_ids_slot(int64_t doc_off_d, int64_t d) { return ((doc_off_d + 7) & ~(int64_t)7) + 8 * d; }

@@ -1,47 +1,68 @@
 // bf_wave_body.h -- the wave program of bf_wave.h (see there).  Include AFTER a definition of namespace wv:
 //   bf_kernels.hip   wave intrinsics of gfx950
 //   tests/hosttest   wave_emu.h, the 64-fibre simulator (test only)
+//
+// One wave is a little pipeline.  Every trip of its main loop
+//   1. issues the table gather of the next transition for each of its word units (NU per lane),
+//   2. does ONE producing action while those gathers are in flight: fetch a range of documents, open a document, decode a chunk of
+//      text into the LDS ring (its bytes were loaded a trip earlier), or resolve a window of start positions into tokens (phase A),
+//   3. completes the transitions (piece found / word finished), hands queued tokens to idle units,
+//   4. when enough tokens are finished at the head of the queue, writes their ids in order (retire, phase C).
+// Nothing in the loop waits for a memory access it has just issued: text, document offsets and the work counter are fetched one
+// action ahead, table gathers overlap the producing action, stores are fire-and-forget.
 #pragma once
 #include "bf_wave.h"
 
 namespace bfa {
 
-// LDS of one wave
-template <int RING_, int QCAP_, int DTN_>
+// LDS of one wave.  QCAP / DTN / RING are powers of two; K = pieces of a word that are kept (a word of more pieces is walked again
+// when its ids are written).
+template <int RING_, int QCAP_, int DTN_, int K_ = 8>
 struct WvLds {
-    static constexpr int RING = RING_, QCAP = QCAP_, DTN = DTN_;
+    static constexpr int RING = RING_, QCAP = QCAP_, DTN = DTN_, K = K_;
     alignas(16) uint16_t ring[RING];
     int64_t dt_slot[DTN], dt_doc[DTN];
-    uint32_t q0[QCAP], q1[QCAP];     // token: ring position | length << 16; action info
-    int32_t rcnt[QCAP], rid[4 * QCAP];
+    uint32_t q0[QCAP], q1[QCAP];     // token: ring position (low 16 bits of the absolute position) | length << 16; action info
+    int32_t rcnt[QCAP];              // -1: not finished; else the number of ids of the unit
+    int32_t rid[K * QCAP];           // piece k of token slot t at [k * QCAP + t]
     int32_t dt_cap[DTN], dt_cnt[DTN]; uint32_t dt_flags[DTN];
-    uint16_t q2[QCAP];               // token: document table entry
+    uint16_t q2[QCAP];               // token: document table entry (low 16 bits of the absolute entry number)
 };
 
-template <class LDS, int UNROLL = 2, bool STATS = false>
+template <class LDS, int NU = 2, bool STATS = false>
 struct WpWave {
-    static constexpr int RING = LDS::RING, QCAP = LDS::QCAP, DTN = LDS::DTN;
-    static constexpr uint32_t RMASK = RING - 1;
+    static constexpr int RING = LDS::RING, QCAP = LDS::QCAP, DTN = LDS::DTN, K = LDS::K;
+    static constexpr uint32_t RMASK = RING - 1, QMASK = QCAP - 1, DMASK = DTN - 1;
     static_assert((RING & (RING - 1)) == 0 && RING >= 1024 && RING <= 32768, "ring size");
+    static_assert((QCAP & (QCAP - 1)) == 0 && QCAP >= 128 && (DTN & (DTN - 1)) == 0 && DTN <= 64, "queue / document table size");
 
-    const WpWaveParams &p; LDS &S; const uint16_t *ascii;
+    const WpWaveParams &p; LDS &S; const uint16_t *ascii; const int32_t *acts;      // ascii, acts: per-workgroup LDS tables
     int lane;
     // ---- wave-uniform state
     uint32_t rhi, rlo;               // absolute ring positions: next element to write / oldest element still needed
-    int qn, dn;
+    uint32_t q_tail, q_issue, q_retire;   // tokens: queued / handed to a unit / retired (absolute counters; slot = counter & QMASK)
+    uint32_t dt_head, dt_tail;       // document table entries in use (absolute counters)
     // current document
-    const uint8_t *s; int n; uint32_t rbase; int dec_bytes, dec, done, bom, curk;
+    const uint8_t *s; int n; uint32_t rbase; int dec_bytes, dec, done, open_start, bom; uint32_t curk;
     bool err;                        // per lane: this lane saw invalid UTF-8 in the current document
-    unsigned long long st_win, st_slow, st_flush, st_tok, st_trips, st_steps, st_rewalk;
+    uint64_t pf_own;                 // per lane: its 8 bytes of the next chunk
+    unsigned long long st_trips, st_win, st_slow, st_tok, st_steps, st_ret, st_rewalk, st_idle, st_dec;
 
-    BF_WVD WpWave(const WpWaveParams &p_, LDS &S_, const uint16_t *ascii_) : p(p_), S(S_), ascii(ascii_)
+    BF_WVD WpWave(const WpWaveParams &p_, LDS &S_, const uint16_t *ascii_, const int32_t *acts_) : p(p_), S(S_), ascii(ascii_), acts(acts_)
     {
-        lane = wv::lane(); rhi = rlo = 0; qn = dn = 0; s = nullptr; n = 0; rbase = 0; dec_bytes = dec = done = bom = curk = 0; err = false;
-        st_win = st_slow = st_flush = st_tok = st_trips = st_steps = st_rewalk = 0;
+        lane = wv::lane(); rhi = rlo = 0; q_tail = q_issue = q_retire = 0; dt_head = dt_tail = 0;
+        s = nullptr; n = 0; rbase = 0; dec_bytes = dec = done = bom = 0; open_start = -1; curk = 0; err = false; pf_own = 0;
+        st_trips = st_win = st_slow = st_tok = st_steps = st_ret = st_rewalk = st_idle = st_dec = 0;
     }
 
     BF_WVD int ring_free() const { return RING - (int)(rhi - rlo); }
     BF_WVD uint32_t ring_at(uint32_t abs_pos) const { return S.ring[abs_pos & RMASK]; }
+    BF_WVD void put_token(uint32_t t, int pos, int len, uint32_t info)
+    {
+        const uint32_t sl = t & QMASK;
+        S.q0[sl] = ((rbase + (uint32_t)pos) & 0xFFFFu) | ((uint32_t)len << 16);
+        S.q1[sl] = info; S.q2[sl] = (uint16_t)curk; S.rcnt[sl] = -1;
+    }
 
     // ------------------------------------------------------------------------------------------------------------------
     // decode: the next WV_CHUNK bytes of the current document -> ring elements.  Strict UTF-8, the rules of the sequential
@@ -49,14 +70,22 @@ struct WpWave {
     // no character and must be covered by a lead 1..3 bytes before it; a lead byte gives length, checks its continuation
     // bytes, truncation (:167-171), overlong / > U+10FFFF (:185-188), surrogates (:190-193).  One leading BOM is skipped.
     // ------------------------------------------------------------------------------------------------------------------
-    BF_WVD void decode_chunk()
+    BF_WVD void prefetch_chunk(int pos)
     {
-        const int pos = dec_bytes;
         const int q0 = pos + lane * 8;
         uint64_t own = 0;
         int nb = n - q0; nb = nb < 0 ? 0 : (nb > 8 ? 8 : nb);
         if (nb == 8) __builtin_memcpy(&own, s + q0, 8);
         else for (int k = 0; k < nb; ++k) own |= (uint64_t)s[q0 + k] << (8 * k);
+        pf_own = own;
+    }
+    BF_WVD void decode_chunk()
+    {
+        if (STATS) ++st_dec;
+        const int pos = dec_bytes;
+        const int q0 = pos + lane * 8;
+        const uint64_t own = pf_own;                                // loaded a trip ago (prefetch_chunk)
+        int nb = n - q0; nb = nb < 0 ? 0 : (nb > 8 ? 8 : nb);
         const uint32_t w0 = rbase + (uint32_t)dec;                  // absolute ring position of this chunk's first element
         if (!wv::any((own & 0x8080808080808080ull) != 0)) {
             // plain ASCII (a BOM is not): stream position == byte position, every byte through the 128-entry table
@@ -73,6 +102,7 @@ struct WpWave {
             }
             const int total = n - pos < WV_CHUNK ? n - pos : WV_CHUNK;
             dec += total; dec_bytes = pos + WV_CHUNK; rhi = rbase + (uint32_t)dec;
+            if (dec_bytes < n) prefetch_chunk(dec_bytes);
             wv::sync();
             return;
         }
@@ -134,15 +164,67 @@ struct WpWave {
         for (int k = 0; k < 8; ++k) if (wm & (1u << k)) { S.ring[r & RMASK] = (uint16_t)v[k]; ++r; }
         const int total = wv::bcast(inc, 63);
         dec += total; dec_bytes = pos + WV_CHUNK; rhi = rbase + (uint32_t)dec;
+        if (dec_bytes < n) prefetch_chunk(dec_bytes);
         wv::sync();
     }
 
     // ------------------------------------------------------------------------------------------------------------------
-    // phase A: one window of up to 64 start positions, the first of which (`done`) is a start position of the reference's
-    // loop (FALexTools_t.h:229).  Queues the tokens whose extent is known and moves `done` behind them.  Returns false when
-    // the token at `done` itself needs elements that are not decoded yet.  `fully`: the whole document is decoded.
+    // phase A, fast form: the next (up to) 64 elements, none of them WK_GENERAL.  A token is then decided by the masks alone:
+    // a run of WK_LOOP elements is a word (reported by the lane at its END; its head is the nearest run start at or before it, or
+    // `open_start` when the run came in from the window before), a WK_SOLO element is a token, a WK_NOMATCH element is nothing
+    // (FALexTools_t.h:229-293 with the facts of bf_model.cpp "unit form").  A run that touches the end of the window stays open
+    // (`open_start`); nothing is read twice.  Returns false (nothing changed) when the window holds a WK_GENERAL element or a run
+    // that max-length cuts: the general form then takes over at the last certain start position.
     // ------------------------------------------------------------------------------------------------------------------
-    BF_WVD bool phase_a(bool fully)
+    BF_WVD bool phase_a_fast(bool fully)
+    {
+        const int w0 = done;
+        const int nv = dec - w0 < 64 ? dec - w0 : 64;
+        const int maxtok = p.max_token_length;
+        const int pos = w0 + lane;
+        const uint32_t el = lane < nv ? ring_at(rbase + (uint32_t)pos) : (WK_NOMATCH << WK_SHIFT);
+        const uint32_t kind = el >> WK_SHIFT;
+        if (wv::any(kind == WK_GENERAL)) return false;
+        const unsigned long long M = wv::ballot(kind == WK_LOOP), SO = wv::ballot(kind == WK_SOLO);
+        const bool at_end = fully && w0 + nv == dec;
+        const unsigned long long last = 1ull << (nv - 1);
+        unsigned long long E = M & ~(M >> 1);                                    // run ends
+        const bool stays_open = (E & last) != 0 && !at_end;                     // the run at the end of the window may go on
+        if (stays_open) E &= ~last;
+        unsigned long long H = M & ~(M << 1);                                    // run starts
+        const bool cont = open_start >= 0;
+        if (cont) H &= ~1ull;                                                    // lane 0 continues the open run (or the run ended just before it)
+        const bool carry_end = cont && !(M & 1ull);                              // the open run ended with the previous window
+        const unsigned long long hm = H & ((2ull << lane) - 1ull);
+        const int hpos = hm ? w0 + 63 - __builtin_clzll(hm) : open_start;
+        const bool is_end = (E >> lane) & 1ull;
+        const int wlen = pos - hpos + 1;
+        int new_open = -1;
+        if (stays_open) { const unsigned long long hl = H & (last | (last - 1ull)); new_open = hl ? w0 + 63 - __builtin_clzll(hl) : open_start; }
+        // max-length: a finished run longer than the limit, or an open one that has reached it
+        if (wv::any(is_end && wlen > maxtok) || (carry_end && w0 - open_start > maxtok) || (stays_open && w0 + nv - new_open >= maxtok)) return false;
+        if (STATS) ++st_win;
+        const unsigned long long TK = E | SO;
+        const uint32_t base = q_tail + (carry_end ? 1u : 0u);
+        if (carry_end && lane == 0) put_token(q_tail, open_start, w0 - open_start, p.loop_info);
+        if ((TK >> lane) & 1ull) {
+            const uint32_t t = base + (uint32_t)__builtin_popcountll(TK & ((1ull << lane) - 1ull));
+            if (is_end) put_token(t, hpos, wlen, p.loop_info); else put_token(t, pos, 1, p.solo_info);
+        }
+        q_tail = base + (uint32_t)__builtin_popcountll(TK);
+        open_start = new_open; done = w0 + nv;
+        wv::sync();
+        return true;
+    }
+
+    // ------------------------------------------------------------------------------------------------------------------
+    // phase A, general form: one window of up to 64 start positions, the first of which (`done`) is a start position of the
+    // reference's loop (FALexTools_t.h:229); every lane finds the token a walk from its position gives (the automaton itself for
+    // WK_GENERAL elements), the chain of start positions is followed through the window.  Queues the tokens whose extent is known
+    // and moves `done` behind them.  Returns false when the token at `done` itself needs elements that are not decoded yet.
+    // `fully`: the whole document is decoded.  Used for the windows phase_a_fast() declines.
+    // ------------------------------------------------------------------------------------------------------------------
+    BF_WVD bool phase_a_general(bool fully)
     {
         const int w0 = done;
         const int nv = dec - w0 < 64 ? dec - w0 : 64;
@@ -150,11 +232,11 @@ struct WpWave {
         const bool valid = lane < nv;
         const int pos = w0 + lane;
         const uint32_t el = valid ? ring_at(rbase + (uint32_t)pos) : (WK_NOMATCH << WK_SHIFT);
-        const uint32_t kind = el >> WK_SHIFT, cls = el & LX_T_CLS_MASK;
+        const uint32_t kind = el >> WK_SHIFT;
         const unsigned long long M = wv::ballot(valid && kind == WK_LOOP);
         const unsigned long long G = wv::ballot(valid && kind == WK_GENERAL);
         const bool at_end = fully && w0 + nv == dec;                    // the window reaches the end of the document
-        if (STATS) ++st_win;
+        if (STATS) ++st_slow;
         // ---- per lane: the token a walk from this position finds (has / len / info), whether its extent is certain, next start
         bool has = false, complete = true; int len = 1; uint32_t info = 0;
         if (kind == WK_LOOP) {
@@ -165,7 +247,7 @@ struct WpWave {
             len = r < maxtok ? r : maxtok;
             complete = r >= maxtok || lane + r < nv || at_end;          // a run that touches the end of the window may go on
         } else if (kind == WK_SOLO) {
-            has = true; info = (uint32_t)(p.T[p.initial + cls] >> 32);
+            has = true; info = p.solo_info;
         }
         // a run that fills the whole window: look further (words of 64 characters and more)
         if (M == ~0ull && nv < maxtok) {
@@ -211,7 +293,6 @@ struct WpWave {
             St = (V & ~M) | (M & ~(M << 1));            // every non-run element, and the first element of every run
         } else {
             // a multi-element general token or a run cut by max-length: follow the chain (FALexTools_t.h:229, 390-393)
-            if (STATS) ++st_slow;
             St = 0; int cur = w0;
             while (cur < w0 + nv) { St |= 1ull << (cur - w0); cur = wv::bcast(nxt, cur - w0); }
         }
@@ -226,12 +307,8 @@ struct WpWave {
         } else new_done = wv::bcast(nxt, 63 - __builtin_clzll(St));
         // ---- queue the tokens
         const unsigned long long TK = St & wv::ballot(has);
-        if ((TK >> lane) & 1ull) {
-            const int t = qn + __builtin_popcountll(TK & ((1ull << lane) - 1ull));
-            S.q0[t] = ((rbase + (uint32_t)pos) & RMASK) | ((uint32_t)len << 16);
-            S.q1[t] = info; S.q2[t] = (uint16_t)curk;
-        }
-        qn += __builtin_popcountll(TK);
+        if ((TK >> lane) & 1ull) put_token(q_tail + (uint32_t)__builtin_popcountll(TK & ((1ull << lane) - 1ull)), pos, len, info);
+        q_tail += (uint32_t)__builtin_popcountll(TK);
         done = new_done;
         wv::sync();
         return true;
@@ -241,13 +318,15 @@ struct WpWave {
     // phase B: the function frame of Process_int (FALexTools_t.h:229-393 at depth 1) on one word, and the post-pass on its
     // sub-tokens (tokdll:1239-1301): from = -1 takes the left anchor (resolved at load), a walk that matches emits a piece
     // and continues behind it, a walk that fails at from >= 0 leaves a gap, so the pieces cannot tile the word: UNK.
+    // A unit is resumable: issue() starts the gather of its next transition, complete() consumes it.
     // ------------------------------------------------------------------------------------------------------------------
     struct Unit {
-        int tok;                         // queue index, -1: idle
+        int tok;                         // token (absolute queue counter, as int), -1: idle
         uint32_t rs; int L; uint32_t ini, ini_l;
         int from, j, lim; uint32_t state; int fp; uint32_t ftag;
-        int cnt; int32_t id0, id1, id2, id3;
-        int32_t *dst; int room;          // emit form (phase C, words of more than four pieces): pieces go straight to dst[0 .. room)
+        int cnt;
+        uint32_t c; uint64_t e64;        // the transition in flight: class fed, table entry
+        int32_t *dst; int room;          // emit form (retire, words of more than K pieces): pieces go straight to dst[0 .. room)
     };
 
     BF_WVD bool unit_setup(Unit &u) const
@@ -264,207 +343,243 @@ struct WpWave {
             return true;
         }
     }
-    BF_WVD void unit_finish(Unit &u)
+    BF_WVD void unit_finish(Unit &u, int cnt)
     {
-        if (!u.dst) {
-            const int t = u.tok;
-            S.rcnt[t] = u.cnt; S.rid[t] = u.id0; S.rid[QCAP + t] = u.id1; S.rid[2 * QCAP + t] = u.id2; S.rid[3 * QCAP + t] = u.id3;
-        }
+        if (!u.dst) S.rcnt[(uint32_t)u.tok & QMASK] = cnt;
         u.tok = -1;
     }
-    // starts the unit of queue entry t; false: finished at once (not a word / a word without a vocabulary call)
-    BF_WVD bool unit_begin(Unit &u, int t)
+    BF_WVD void unit_unk(Unit &u)
     {
-        u.tok = t; u.dst = nullptr; u.room = 0;
-        const uint32_t w0 = S.q0[t], info = S.q1[t];
-        u.rs = w0 & 0xFFFFu; u.L = (int)(w0 >> 16); u.cnt = 0; u.id0 = u.id1 = u.id2 = u.id3 = 0;
+        if (!u.dst) S.rid[(uint32_t)u.tok & QMASK] = p.unk;
+        unit_finish(u, 1);
+    }
+    // starts the unit of token t; false: finished at once (not a word / a word without a vocabulary call)
+    BF_WVD bool unit_begin(Unit &u, uint32_t t)
+    {
+        u.tok = (int)t; u.dst = nullptr; u.room = 0;
+        const uint32_t sl = t & QMASK;
+        const uint32_t w0 = S.q0[sl], info = S.q1[sl];
+        u.rs = w0 & 0xFFFFu; u.L = (int)(w0 >> 16); u.cnt = 0;
         int tag; bool call = false;
         if (info & LX_INFO_SIMPLE) tag = (int)(info & 0x7FFFFFFFu);
-        else { const int32_t *a = p.acts + info; tag = a[2]; u.ini = (uint32_t)a[5]; u.ini_l = (uint32_t)a[6]; call = true; }
-        if (tag != WBD_WORD_TAG) { unit_finish(u); return false; }              // tags 2..4: neither a word nor a sub-token
-        if (!call) { u.cnt = 1; u.id0 = p.unk; unit_finish(u); return false; }  // a word without sub-tokens (tokdll:1282-1301)
+        else { const int32_t *a = acts + info; tag = a[2]; u.ini = (uint32_t)a[5]; u.ini_l = (uint32_t)a[6]; call = true; }
+        if (tag != WBD_WORD_TAG) { unit_finish(u, 0); return false; }          // tags 2..4: neither a word nor a sub-token
+        if (!call) { unit_unk(u); return false; }                              // a word without sub-tokens (tokdll:1282-1301)
         u.from = -1;
-        if (!unit_setup(u)) { u.cnt = 1; u.id0 = p.unk; unit_finish(u); return false; }
+        if (!unit_setup(u)) { unit_unk(u); return false; }
         return true;
     }
-    // one transition (FALexTools_t.h:255-277); when the walk ends, its result and the next walk's start
-    BF_WVD void unit_step(Unit &u)
+    BF_WVD void unit_issue(Unit &u) const
     {
-        const uint32_t c = (uint32_t)S.ring[(u.rs + (uint32_t)u.j) & RMASK] & LX_T_CLS_MASK;
-        const uint64_t e64 = p.T[u.state + c];
-        const uint32_t e = (uint32_t)e64;
-        const bool hit = (e & LX_T_CLS_MASK) == c;
-        if (hit && (int32_t)e < 0) { u.fp = u.j; u.ftag = (uint32_t)(e64 >> 32); }
+        u.c = (uint32_t)S.ring[(u.rs + (uint32_t)u.j) & RMASK] & LX_T_CLS_MASK;
+        u.e64 = p.T[u.state + u.c];
+    }
+    // consumes the transition in flight (FALexTools_t.h:255-277); when the walk ends, its result and the next walk's start
+    BF_WVD void unit_complete(Unit &u)
+    {
+        const uint32_t e = (uint32_t)u.e64;
+        const bool hit = (e & LX_T_CLS_MASK) == u.c;
+        if (hit && (int32_t)e < 0) { u.fp = u.j; u.ftag = (uint32_t)(u.e64 >> 32); }
         if (hit) { u.state = (e >> LX_T_NEXT_SHIFT) & LX_T_NEXT_MASK; ++u.j; }
         if (hit && u.j < u.lim) return;
         // ---- the walk is over
         if (u.fp < 0) {
-            if (u.from >= 0) { u.cnt = 1; u.id0 = p.unk; unit_finish(u); return; }      // a gap: the word is UNK whatever follows
+            if (u.from >= 0) { unit_unk(u); return; }                                    // a gap: the word is UNK whatever follows
             u.from = 0;                                                                  // the anchored walk found nothing (FALexTools_t.h:293)
         } else {
             const int32_t tag = (int32_t)(u.ftag & 0x7FFFFFFFu);
             if (u.dst) { if (u.cnt < u.room) u.dst[u.cnt] = tag; }
-            else { if (u.cnt == 0) u.id0 = tag; else if (u.cnt == 1) u.id1 = tag; else if (u.cnt == 2) u.id2 = tag; else if (u.cnt == 3) u.id3 = tag; }
+            else if (u.cnt < K) S.rid[u.cnt * QCAP + ((uint32_t)u.tok & QMASK)] = tag;
             ++u.cnt;
             u.from = u.fp + 1;
         }
-        if (!unit_setup(u)) unit_finish(u);                                              // from == L: the pieces tile the word
+        if (!unit_setup(u)) unit_finish(u, u.cnt);                                       // from == L: the pieces tile the word
     }
-    BF_WVD void unit_refill(Unit &u, int &head)
+    // hands queued tokens to the lanes whose unit is idle
+    BF_WVD void unit_refill(Unit &u)
     {
         const unsigned long long m = wv::ballot(u.tok < 0);
-        if (m == 0 || head >= qn) return;
-        const int t = head + __builtin_popcountll(m & ((1ull << lane) - 1ull));
-        if (u.tok < 0 && t < qn) unit_begin(u, t);
-        const int k = __builtin_popcountll(m);
-        head = head + k < qn ? head + k : qn;
-    }
-
-    BF_WVD void phase_b()
-    {
-        Unit a, b; a.tok = b.tok = -1; a.dst = b.dst = nullptr;
-        int head = 0;
-        for (;;) {
-            unit_refill(a, head); unit_refill(b, head);
-            if (!wv::any(a.tok >= 0 || b.tok >= 0)) { if (head >= qn) break; continue; }
-            if (STATS) { ++st_trips; st_steps += (unsigned long long)__builtin_popcountll(wv::ballot(a.tok >= 0)) + (unsigned long long)__builtin_popcountll(wv::ballot(b.tok >= 0)); }
-#pragma unroll
-            for (int u = 0; u < UNROLL; ++u) {
-                if (a.tok >= 0) unit_step(a);
-                if (b.tok >= 0) unit_step(b);
-            }
-        }
-        wv::sync();
+        const uint32_t avail = q_tail - q_issue;
+        if (m == 0 || avail == 0) return;
+        const uint32_t r = (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1ull));
+        if (u.tok < 0 && r < avail) unit_begin(u, q_issue + r);
+        const uint32_t k = (uint32_t)__builtin_popcountll(m);
+        q_issue += k < avail ? k : avail;
     }
 
     // ------------------------------------------------------------------------------------------------------------------
-    // phase C: ids in queue order.  Position of a unit's ids = ids its document has so far + ids of the units before it in the
-    // document (segmented prefix sum over the queue); nothing is written at or behind the document's cap (tokdll:1308-1310 is
-    // then the prefix rule: what a full output array cuts off does not change what came before).
+    // retire (phase C): the finished tokens at the head of the queue, in order.  Position of a unit's ids = ids its document has
+    // so far + ids of the units before it in the document (segmented prefix sum); nothing is written at or behind the document's
+    // cap (tokdll:1308-1310 is then the prefix rule: what a full output array cuts off does not change what came before).
+    // Documents all of whose tokens are retired and that are closed get their count written.  Returns whether anything moved
+    // (tokens retired, documents completed, ring space freed).
     // ------------------------------------------------------------------------------------------------------------------
-    BF_WVD void phase_c()
+    BF_WVD bool retire(bool have_doc)
     {
-        for (int base = 0; base < qn; base += 64) {
-            const int t = base + lane;
-            const bool act = t < qn;
-            const int cnt = act ? S.rcnt[t] : 0;
-            const int k = act ? (int)S.q2[t] : -1;
+        bool moved = false;
+        const uint32_t navail = q_tail - q_retire < 64u ? q_tail - q_retire : 64u;
+        const uint32_t t = q_retire + (uint32_t)lane, sl = t & QMASK;
+        const int cnt0 = (uint32_t)lane < navail ? S.rcnt[sl] : -1;
+        const unsigned long long fin = wv::ballot(cnt0 >= 0);
+        const int nret = fin == ~0ull ? 64 : __builtin_ctzll(~fin);                  // the finished prefix
+        if (nret > 0) {
+            moved = true;
+            if (STATS) ++st_ret;
+            const bool act = lane < nret;
+            const int cnt = act ? cnt0 : 0;
+            const int k = act ? (int)S.q2[sl] : -1;
             const int inc = wv::incl_scan(cnt), exc = inc - cnt;
             const int kp = wv::shfl_up(k, 1), kn = wv::shfl_down(k, 1);
             const unsigned long long hm = wv::ballot(lane == 0 || k != kp);
             const int head = 63 - __builtin_clzll(hm & ((2ull << lane) - 1ull));
             const int segbase = wv::shfl(exc, head);
+            const uint32_t ke = (uint32_t)k & DMASK;
             int pos = 0; int64_t slot = 0; int cap = 0;
-            if (act) { pos = S.dt_cnt[k] + (exc - segbase); slot = S.dt_slot[k]; cap = S.dt_cap[k]; }
+            if (act) { pos = S.dt_cnt[ke] + (exc - segbase); slot = S.dt_slot[ke]; cap = S.dt_cap[ke]; }
             wv::sync();                                                   // every lane has read its document's count
-            if (act && (lane == 63 || k != kn)) S.dt_cnt[k] = pos + cnt;
-            wv::sync();
+            if (act && (lane == 63 || k != kn)) S.dt_cnt[ke] = pos + cnt;
             if (act && cnt > 0 && pos < cap) {
                 int32_t *dst = p.ids_tmp + slot + pos;
                 const int room = cap - pos;
-                if (cnt <= 4) {
-                    dst[0] = S.rid[t];
-                    if (cnt > 1 && room > 1) dst[1] = S.rid[QCAP + t];
-                    if (cnt > 2 && room > 2) dst[2] = S.rid[2 * QCAP + t];
-                    if (cnt > 3 && room > 3) dst[3] = S.rid[3 * QCAP + t];
+                if (cnt <= K) {
+#pragma unroll
+                    for (int i = 0; i < K; ++i) if (i < cnt && i < room) dst[i] = S.rid[i * QCAP + sl];
                 } else {
-                    // more than four pieces: walk the word again, this time straight into its place
+                    // more than K pieces: walk the word again, this time straight into its place
                     if (STATS) ++st_rewalk;
                     Unit u;
                     unit_begin(u, t);                                     // a word with a call: never finishes at once
                     u.dst = dst; u.room = room;
-                    while (u.tok >= 0) unit_step(u);
+                    while (u.tok >= 0) { unit_issue(u); unit_complete(u); }
                 }
             }
+            q_retire += (uint32_t)nret;
+            wv::sync();
         }
+        // ---- documents that are complete: closed, and in front of the document of the oldest token still queued
+        uint32_t limit;
+        if (q_retire != q_tail) limit = dt_head + (((uint32_t)S.q2[q_retire & QMASK] - dt_head) & 0xFFFFu);
+        else limit = have_doc ? curk : dt_tail;
+        if (limit != dt_head) {
+            const uint32_t kk = dt_head + (uint32_t)lane;
+            if (kk - dt_head < limit - dt_head) {
+                const uint32_t e = kk & DMASK, f = S.dt_flags[e];
+                const int c = S.dt_cnt[e], cap = S.dt_cap[e];
+                p.counts[S.dt_doc[e]] = (f & WV_DT_BAD) ? 0 : (c < cap ? c : cap);
+            }
+            dt_head = limit; moved = true;
+        }
+        // ---- the ring is needed from the oldest queued token on (or from the first unresolved position of the document)
+        const uint32_t old_lo = rlo;
+        if (q_retire != q_tail) rlo = rhi - ((rhi - (S.q0[q_retire & QMASK] & 0xFFFFu)) & 0xFFFFu);
+        else rlo = have_doc ? rbase + (uint32_t)(open_start >= 0 ? open_start : done) : rhi;
+        wv::sync();
+        return moved || rlo != old_lo;
     }
 
-    // tokenises what is queued, writes the counts of the documents that are closed, frees the queue and the ring behind `done`
-    BF_WVD void flush()
+    // starts the document [b, e) of the text; false: nothing to tokenise (its count is written here)
+    BF_WVD bool open_document(int64_t d, int64_t b, int64_t e)
     {
-        if (STATS) { ++st_flush; st_tok += (unsigned long long)qn; }
-        if (qn > 0) { phase_b(); phase_c(); }
-        wv::sync();
-        for (int k = lane; k < dn; k += 64) {
-            const uint32_t f = S.dt_flags[k];
-            if (f & WV_DT_CLOSED) { const int c = S.dt_cnt[k], cap = S.dt_cap[k]; p.counts[S.dt_doc[k]] = (f & WV_DT_BAD) ? 0 : (c < cap ? c : cap); }
-        }
-        const bool open = dn > 0 && !(S.dt_flags[dn - 1] & WV_DT_CLOSED);
-        wv::sync();
-        if (open) {
-            if (lane == 0 && dn > 1) { S.dt_slot[0] = S.dt_slot[dn - 1]; S.dt_doc[0] = S.dt_doc[dn - 1]; S.dt_cap[0] = S.dt_cap[dn - 1]; S.dt_cnt[0] = S.dt_cnt[dn - 1]; S.dt_flags[0] = 0; }
-            dn = 1; curk = 0; rlo = rbase + (uint32_t)done;
-        } else { dn = 0; rlo = rhi; }
-        qn = 0;
-        wv::sync();
-    }
-
-    // starts document d; false: nothing to tokenise (its count is written here)
-    BF_WVD bool open_document(int64_t d)
-    {
-        const int64_t b = p.b.doc_off[d];
-        const int64_t n64 = p.b.doc_off[d + 1] - b;
+        const int64_t n64 = e - b;
         if (n64 <= 0 || n64 > 1000000000) { if (lane == 0) p.counts[d] = 0; return false; }                                // tokdll:1121
         if (b < 0 || b + n64 > p.b.total_bytes) { if (lane == 0) { p.counts[d] = 0; wv::atomic_or(p.b.status, BF_STATUS_BAD_OFFSETS); } return false; }
         n = (int)n64; s = p.b.text + b;
         int cap = p.max_ids; if ((int64_t)cap > n64) cap = n; if (cap < 0) cap = 0;
-        curk = dn++;
-        if (lane == 0) { S.dt_slot[curk] = wv_ids_slot(b, d); S.dt_doc[curk] = d; S.dt_cap[curk] = cap; S.dt_cnt[curk] = 0; S.dt_flags[curk] = 0; }
+        curk = dt_tail++;
+        const uint32_t ke = curk & DMASK;
+        if (lane == 0) { S.dt_slot[ke] = wv_ids_slot(b, d); S.dt_doc[ke] = d; S.dt_cap[ke] = cap; S.dt_cnt[ke] = 0; S.dt_flags[ke] = 0; }
         rhi = (rhi + 7u) & ~7u; rbase = rhi;
-        dec_bytes = dec = done = bom = 0; err = false;
+        dec_bytes = dec = done = bom = 0; open_start = -1; err = false;
+        prefetch_chunk(0);
         wv::sync();
         return true;
     }
     BF_WVD void close_document()
     {
+        // a run that was still open when the decoded text ended without another element (possible only behind invalid UTF-8 or a
+        // character that straddles the last chunk boundary)
+        if (open_start >= 0) { if (lane == 0) put_token(q_tail, open_start, dec - open_start, p.loop_info); ++q_tail; open_start = -1; }
         const bool bad = wv::any(err);
-        if (lane == 0) S.dt_flags[curk] = WV_DT_CLOSED | (bad ? WV_DT_BAD : 0u);
+        if (lane == 0) S.dt_flags[curk & DMASK] = WV_DT_CLOSED | (bad ? WV_DT_BAD : 0u);
         wv::sync();
     }
 
-    // One loop, every phase in it exactly once (the program is inlined into the kernel: what is called from two places is there
-    // twice): each trip does the one thing that can be done next -- fetch a document, decode a chunk, resolve a window of start
-    // positions, or flush (tokenise what is queued) when the queue, the document table or the ring is full.
     BF_WVD void run(int grab)
     {
+        Unit u[NU];
+#pragma unroll
+        for (int i = 0; i < NU; ++i) { u[i].tok = -1; u[i].dst = nullptr; u[i].room = 0; }
+        // the work counter is read one range ahead, the offsets of a range's documents when the range is taken
         int64_t dnext = 0, dend = 0;
+        unsigned long long pre_base = 0;
+        if (lane == 0) pre_base = wv::atomic_add(p.next_doc, (unsigned long long)grab);
+        int64_t off_lane = 0;                                            // doc_off[dnext0 + lane] of the current range
+        int64_t dbase = 0;
         bool have_doc = false, exiting = false;
         for (;;) {
-            bool do_flush = false;
+            if (STATS) ++st_trips;
+            // ---- 1. gathers of the transitions in flight
+#pragma unroll
+            for (int i = 0; i < NU; ++i) if (u[i].tok >= 0) unit_issue(u[i]);
+            if (STATS) { for (int i = 0; i < NU; ++i) st_steps += (unsigned long long)__builtin_popcountll(wv::ballot(u[i].tok >= 0)); }
+            // ---- 2. one producing action
+            bool produced = false;
             if (!have_doc) {
-                if (exiting) { if (qn == 0 && dn == 0) break; do_flush = true; }
-                else if (dn == DTN) do_flush = true;
-                else {
+                if (!exiting && dt_tail - dt_head < (uint32_t)DTN) {
                     if (dnext >= dend) {
-                        unsigned long long base = 0;
-                        if (lane == 0) base = wv::atomic_add(p.next_doc, (unsigned long long)grab);
-                        base = wv::bcast(base, 0);
-                        dnext = (int64_t)base; dend = dnext + grab < p.b.ndocs ? dnext + grab : p.b.ndocs;
-                        if (dnext >= p.b.ndocs) { exiting = true; continue; }
+                        const unsigned long long base = wv::bcast(pre_base, 0);
+                        if ((int64_t)base >= p.b.ndocs) exiting = true;
+                        else {
+                            dbase = (int64_t)base; dnext = dbase; dend = dbase + grab < p.b.ndocs ? dbase + grab : p.b.ndocs;
+                            if (lane <= (int)(dend - dbase)) off_lane = p.b.doc_off[dbase + lane];
+                            if (lane == 0) pre_base = wv::atomic_add(p.next_doc, (unsigned long long)grab);
+                        }
+                        produced = true;
+                    } else {
+                        const int i = (int)(dnext - dbase);
+                        const int64_t b = wv::bcast(off_lane, i), e = wv::bcast(off_lane, i + 1);
+                        have_doc = open_document(dnext, b, e);
+                        ++dnext; produced = true;
                     }
-                    have_doc = open_document(dnext++);
-                    continue;
                 }
             } else {
-                if (dec_bytes < n && ring_free() >= WV_CHUNK) { decode_chunk(); continue; }
                 const bool fully = dec_bytes >= n;
-                if (done < dec) {
-                    if (qn + 64 > QCAP) do_flush = true;
-                    else if (phase_a(fully)) continue;
-                    else do_flush = true;                       // the token at `done` reaches past what is decoded and the ring has no room
-                } else if (fully) { close_document(); have_doc = false; continue; }
-                else do_flush = true;                           // everything decoded is resolved, the ring has no room for the next chunk
-                if (do_flush && qn == 0 && rlo == rbase + (uint32_t)done) {
-                    // nothing to flush and nothing to free: cannot happen (max token length <= RING - chunk - 16, checked at load)
-                    if (lane == 0) wv::atomic_or(p.b.status, BF_STATUS_INTERNAL);
-                    close_document(); have_doc = false; continue;
+                const bool room_q = (q_tail - q_retire) + 66u <= (uint32_t)QCAP;
+                if (done < dec && room_q) {
+                    if (phase_a_fast(fully)) produced = true;
+                    else {
+                        if (open_start >= 0) { done = open_start; open_start = -1; }     // the general form starts at a certain start position
+                        if (phase_a_general(fully)) produced = true;
+                    }
+                }
+                if (!produced) {
+                    if (dec_bytes < n) { if (ring_free() >= WV_CHUNK) { decode_chunk(); produced = true; } }
+                    else if (done >= dec) { if (open_start < 0 || room_q) { close_document(); have_doc = false; produced = true; } }
                 }
             }
-            if (do_flush) flush();
+            // ---- 3. transitions done; idle units take queued tokens
+            bool busy = false;
+#pragma unroll
+            for (int i = 0; i < NU; ++i) {
+                if (u[i].tok >= 0) unit_complete(u[i]);
+                unit_refill(u[i]);
+                busy = busy || u[i].tok >= 0;
+            }
+            const bool any_busy = wv::any(busy);
+            // ---- 4. retire
+            bool moved = false;
+            const uint32_t queued = q_tail - q_retire;
+            if (queued >= 64u || (!produced && queued > 0) || (exiting && !have_doc) || (!produced && dt_tail != dt_head)) moved = retire(have_doc);
+            if (exiting && !have_doc && q_tail == q_retire && dt_head == dt_tail && !any_busy) break;
+            if (!produced && !any_busy && !moved && !(exiting && !have_doc)) {
+                if (STATS) ++st_idle;
+                // nothing can move: cannot happen (the ring holds a whole token and a chunk, the queue a whole window; checked at load)
+                if (q_tail == q_retire && q_issue == q_tail) { if (lane == 0) wv::atomic_or(p.b.status, BF_STATUS_INTERNAL); break; }
+            }
         }
         if (STATS && lane == 0) {
-            wv::atomic_add(&p.stats[0], st_win); wv::atomic_add(&p.stats[1], st_slow); wv::atomic_add(&p.stats[2], st_flush); wv::atomic_add(&p.stats[3], st_tok);
-            wv::atomic_add(&p.stats[4], st_trips); wv::atomic_add(&p.stats[5], st_steps);
+            wv::atomic_add(&p.stats[0], st_trips); wv::atomic_add(&p.stats[1], st_win); wv::atomic_add(&p.stats[2], st_slow); wv::atomic_add(&p.stats[3], (unsigned long long)q_tail);
+            wv::atomic_add(&p.stats[4], st_steps); wv::atomic_add(&p.stats[5], st_ret); wv::atomic_add(&p.stats[7], st_idle); wv::atomic_add(&p.stats[8], st_dec);
         }
         if (STATS) { const unsigned long long r = st_rewalk; if (r) wv::atomic_add(&p.stats[6], r); }
     }

@@ -11,7 +11,7 @@
 
 using namespace bfa;
 
-template <class LDS, int UNROLL>
+template <class LDS, int NU>
 static void run_cfg(const WpWaveParams &p, int nwaves, int grab)
 {
     std::vector<LDS *> lds;
@@ -27,7 +27,7 @@ static void run_cfg(const WpWaveParams &p, int nwaves, int grab)
         size_t k = 0;
         for (; k < wave_ids.size(); ++k) if (wave_ids[k] == wid) break;
         if (k == wave_ids.size()) { wave_ids.push_back(wid); (void)next_wave; }
-        WpWave<LDS, UNROLL, true> w(p, *of_wave[k], ascii.data());
+        WpWave<LDS, NU, true> w(p, *of_wave[k], ascii.data(), p.acts);
         w.run(grab);
     };
     wvemu::run_waves(nwaves, body);
@@ -39,9 +39,9 @@ extern "C" {
 int bft_wave_ok(void *hv) { return ((Handle *)hv)->m.wave_ok ? 1 : 0; }
 const char *bft_wave_why(void *hv) { return ((Handle *)hv)->m.wave_why.c_str(); }
 
-// TextToIdsBatch through the wave kernel on the host.  cfg: 0 = the shipped configuration, 1 = a small queue / document table (flushes
-// everywhere), 2 = a large ring.  Returns the total id count, or < 0 (-1: model not in unit form, -5: the kernel raised a status bit).
-// stats (optional, 8 counters): see bf_wave.h WpWaveParams::stats.
+// TextToIdsBatch through the wave kernel on the host.  cfg: 0 = the shipped configuration, 1 = one unit per lane, a two-entry document table and one kept
+// piece per word (every longer word is walked again), 2 = three units per lane, a large ring and queue.  Returns the total id count, or < 0 (-1: model not in unit form, -5: the kernel raised a status bit).
+// stats (optional, 16 counters): see bf_wave.h WpWaveParams::stats.
 long bft_emu_wave_batch(void *hv, const uint8_t *text, long text_bytes, const int64_t *doc_off, long ndocs, int max_ids, int unk, int nwaves, int grab, int cfg,
                         int32_t *ids_out, long ids_cap, int64_t *id_off, unsigned long long *stats)
 {
@@ -55,13 +55,13 @@ long bft_emu_wave_batch(void *hv, const uint8_t *text, long text_bytes, const in
     p.T = m.wbd_t2.data(); p.acts = m.acts_pool.data();
     p.cpmap = DevCpMap{m.wbd_cpmap.l1.data(), m.wbd_cpmap.pages.data()};
     p.kind = m.wave_kind.data(); p.nclasses = m.wbd.nclasses;
-    p.initial = m.wbd.initial_base; p.loop_info = m.loop_info; p.max_token_length = m.max_token_length;
+    p.initial = m.wbd.initial_base; p.loop_info = m.loop_info; p.solo_info = m.wave_solo_info; p.acts_n = (int)m.acts_pool.size(); p.max_token_length = m.max_token_length;
     p.b = Batch{text, doc_off, ndocs, total, &status};
     p.ids_tmp = tmp.data(); p.counts = counts.data(); p.max_ids = max_ids; p.unk = unk; p.next_doc = &next_doc; p.stats = stats;
     if (ndocs > 0) {
-        if (cfg == 1) run_cfg<WvLds<1024, 72, 3>, 1>(p, nwaves, grab);
-        else if (cfg == 2) run_cfg<WvLds<4096, 256, 64>, 3>(p, nwaves, grab);
-        else run_cfg<WvLds<1024, 128, 64>, 2>(p, nwaves, grab);
+        if (cfg == 1) run_cfg<WvLds<1024, 128, 2, 1>, 1>(p, nwaves, grab);
+        else if (cfg == 2) run_cfg<WvLds<4096, 256, 64, 4>, 3>(p, nwaves, grab);
+        else run_cfg<WvLds<1024, 128, 64, 8>, 2>(p, nwaves, grab);
     }
     if (status) return -5;
     // k_scan + k_compact, restated

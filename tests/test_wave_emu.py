@@ -13,7 +13,8 @@ import bfutil
 import blingfire_amd as bf
 
 WP_MODELS = ["bert_base_tok.bin", "bert_base_cased_tok.bin", "bert_chinese.bin"]
-# (max_ids, unk, waves, documents per grab, configuration: 0 = shipped, 1 = tiny queue and document table, 2 = large ring)
+# (max_ids, unk, waves, documents per grab, configuration: 0 = shipped, 1 = one unit per lane / two-entry document table / one kept piece,
+#  2 = three units per lane / large ring and queue)
 CONFS = [(512, 100, 1, 8, 0), (512, 100, 4, 2, 1), (64, 5, 2, 8, 2), (1, 100, 1, 3, 1), (0, 100, 2, 8, 0)]
 
 
@@ -37,7 +38,7 @@ def wave_batch(ht, h, text, off, max_ids, unk, nwaves, grab, cfg):
     cap = len(text) + 16
     ids = np.full(cap, -9, dtype=np.int32)
     ido = np.zeros(nd + 1, dtype=np.int64)
-    st = np.zeros(8, dtype=np.uint64)
+    st = np.zeros(16, dtype=np.uint64)
     r = ht.bft_emu_wave_batch(h, text.ctypes.data, len(text), off.ctypes.data, nd, max_ids, unk, nwaves, grab, cfg, ids.ctypes.data, cap, ido.ctypes.data, st.ctypes.data)
     return r, ids[:max(r, 0)], ido, st
 

@@ -14,7 +14,6 @@ bf.text_to_ids_batch_device(h, d_text, d_off, 512, 100); torch.cuda.synchronize(
 out = (ctypes.c_ulonglong * 16)()
 bf.lib().BfLexStats.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
 bf.lib().BfLexStats(h, out, 16)
-win, slow, flush, tok, trips, steps, rewalk = [out[i] for i in range(7)]
-print("docs", ndocs, "bytes", int(off[-1]), "windows/doc %.2f" % (win / ndocs), "slow windows %.4f" % (slow / max(win, 1)), "flushes/doc %.2f" % (flush / ndocs),
-      "tokens/doc %.1f" % (tok / ndocs), "tokens/flush %.1f" % (tok / max(flush, 1)), "phase-B trips/flush %.2f" % (trips / max(flush, 1)),
-      "active slots per trip %.1f of 128" % (steps / max(trips, 1)), "rewalks/doc %.3f" % (rewalk / ndocs))
+st = [int(out[i]) for i in range(9)]
+print("docs", ndocs, "bytes", int(off[-1]), "trips/doc %.1f fast windows/doc %.2f general windows/doc %.3f tokens/doc %.1f unit-steps/doc %.0f (per trip %.1f) retires/doc %.2f rewalks/doc %.3f "
+      "trips without progress/doc %.3f decodes/doc %.2f" % (st[0] / ndocs, st[1] / ndocs, st[2] / ndocs, st[3] / ndocs, st[4] / ndocs, st[4] / max(st[0], 1), st[5] / ndocs, st[6] / ndocs, st[7] / ndocs, st[8] / ndocs))
