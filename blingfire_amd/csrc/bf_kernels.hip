@@ -683,6 +683,7 @@ template <class T> __device__ __forceinline__ T shfl_down(T v, int delta) { retu
 __device__ __forceinline__ int incl_scan(int v) { return bfa::wave_incl_scan(v); }
 __device__ __forceinline__ unsigned long long atomic_add(unsigned long long *p, unsigned long long v) { return atomicAdd(p, v); }
 __device__ __forceinline__ void atomic_or(int *p, int v) { atomicOr(p, v); }
+__device__ __forceinline__ unsigned long long clock() { return __builtin_readcyclecounter(); }
 } // namespace wv
 #include "bf_wave_body.h"
 namespace bfa {
@@ -722,11 +723,11 @@ void launch_wp_wave(const WpWaveParams &p, int variant, hipStream_t s)
     const int cfg = (variant >> 8) & 0xf;
     int grab = (variant >> 12) & 0xf; if (grab == 0) grab = 8;
     const int per_cu = (variant >> 24) & 0x3f;
-    if (cfg == 1) launch_wp_wave_cfg<WvLds<1024, 128, 64, 8>, 1, 4>(p, grab, per_cu, s);
-    else if (cfg == 2) launch_wp_wave_cfg<WvLds<1024, 128, 64, 8>, 3, 4>(p, grab, per_cu, s);
-    else if (cfg == 3) launch_wp_wave_cfg<WvLds<2048, 256, 64, 8>, 2, 4>(p, grab, per_cu, s);
-    else if (cfg == 4) launch_wp_wave_cfg<WvLds<1024, 128, 64, 4>, 2, 4>(p, grab, per_cu, s);
-    else launch_wp_wave_cfg<WvLds<1024, 128, 64, 8>, 2, 4>(p, grab, per_cu, s);
+    if (cfg == 1) launch_wp_wave_cfg<WvLds<2048, 256, 32>, 2, 4>(p, grab, per_cu, s);
+    else if (cfg == 2) launch_wp_wave_cfg<WvLds<1024, 128, 32>, 1, 4>(p, grab, per_cu, s);
+    else if (cfg == 3) launch_wp_wave_cfg<WvLds<4096, 512, 64>, 2, 4>(p, grab, per_cu, s);
+    else if (cfg == 4) launch_wp_wave_cfg<WvLds<4096, 512, 64>, 1, 4>(p, grab, per_cu, s);
+    else launch_wp_wave_cfg<WvLds<2048, 256, 32>, 1, 4>(p, grab, per_cu, s);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -2,36 +2,40 @@
 //   bf_kernels.hip   wave intrinsics of gfx950
 //   tests/hosttest   wave_emu.h, the 64-fibre simulator (test only)
 //
-// One wave is a little pipeline.  Every trip of its main loop
-//   1. issues the table gather of the next transition for each of its word units (NU per lane),
-//   2. does ONE producing action while those gathers are in flight: fetch a range of documents, open a document, decode a chunk of
-//      text into the LDS ring (its bytes were loaded a trip earlier), or resolve a window of start positions into tokens (phase A),
-//   3. completes the transitions (piece found / word finished), hands queued tokens to idle units,
-//   4. when enough tokens are finished at the head of the queue, writes their ids in order (retire, phase C).
-// Nothing in the loop waits for a memory access it has just issued: text, document offsets and the work counter are fetched one
-// action ahead, table gathers overlap the producing action, stores are fire-and-forget.
+// One wave works in batches, each phase a tight loop of its own so that every instruction is issued for (nearly) 64 busy lanes:
+//   fill     documents are opened, decoded into the LDS ring and resolved into tokens (phase A) until the token queue is full;
+//   units    every lane owns NU word units; a unit walks the vocabulary automaton over one token, one table gather per trip for
+//            each unit (NU independent gathers in flight per lane), and takes the next queued token when its word is finished.
+//            The loop ends when the queue is handed out and only a few long words are still walking: those keep their units
+//            and go on together with the next batch;
+//   retire   the finished tokens at the head of the queue, 64 at a time and in order: ids to their documents' staging slots.
+// Measured on MI355X (profiles/r03_*): a first form that drained every batch ran the units at 17 % lane occupancy; a form with
+// one producing action, one transition and one retire check per trip issued 4,000 VALU + 4,000 SALU instructions per 512-byte
+// document (21 trips).  Instruction count per document is what this structure is about.
 #pragma once
 #include "bf_wave.h"
 
 namespace bfa {
 
-// LDS of one wave.  QCAP / DTN / RING are powers of two; K = pieces of a word that are kept (a word of more pieces is walked again
-// when its ids are written).
-template <int RING_, int QCAP_, int DTN_, int K_ = 8>
+constexpr uint32_t WV_TK_SOLO = 1u << 31, WV_TK_INFO = 1u << 30, WV_TK_LEN_MASK = 0x1FFu;    // token flags: action = solo_info / stored in rid[]; else loop_info
+
+// LDS of one wave.  QCAP / DTN / RING are powers of two.  A token: q0 = ring position (low 16 bits of the absolute position) |
+// length << 16 | WV_TK_* flags; q1 = position of its first character in the document; qd = document table entry (low 8 bits of the
+// absolute entry number); qc = set by the unit: 0 while it walks, then 1 + the number of ids; qi = action info (WV_TK_INFO tokens only).
+template <int RING_, int QCAP_, int DTN_>
 struct WvLds {
-    static constexpr int RING = RING_, QCAP = QCAP_, DTN = DTN_, K = K_;
+    static constexpr int RING = RING_, QCAP = QCAP_, DTN = DTN_;
     alignas(16) uint16_t ring[RING];
     int64_t dt_slot[DTN], dt_doc[DTN];
-    uint32_t q0[QCAP], q1[QCAP];     // token: ring position (low 16 bits of the absolute position) | length << 16; action info
-    int32_t rcnt[QCAP];              // -1: not finished; else the number of ids of the unit
-    int32_t rid[K * QCAP];           // piece k of token slot t at [k * QCAP + t]
+    uint32_t q0[QCAP], q1[QCAP], qi[QCAP];
     int32_t dt_cap[DTN], dt_cnt[DTN]; uint32_t dt_flags[DTN];
-    uint16_t q2[QCAP];               // token: document table entry (low 16 bits of the absolute entry number)
+    uint16_t qc[QCAP];
+    uint8_t qd[QCAP];
 };
 
 template <class LDS, int NU = 2, bool STATS = false>
 struct WpWave {
-    static constexpr int RING = LDS::RING, QCAP = LDS::QCAP, DTN = LDS::DTN, K = LDS::K;
+    static constexpr int RING = LDS::RING, QCAP = LDS::QCAP, DTN = LDS::DTN;
     static constexpr uint32_t RMASK = RING - 1, QMASK = QCAP - 1, DMASK = DTN - 1;
     static_assert((RING & (RING - 1)) == 0 && RING >= 1024 && RING <= 32768, "ring size");
     static_assert((QCAP & (QCAP - 1)) == 0 && QCAP >= 128 && (DTN & (DTN - 1)) == 0 && DTN <= 64, "queue / document table size");
@@ -42,6 +46,8 @@ struct WpWave {
     uint32_t rhi, rlo;               // absolute ring positions: next element to write / oldest element still needed
     uint32_t q_tail, q_issue, q_retire;   // tokens: queued / handed to a unit / retired (absolute counters; slot = counter & QMASK)
     uint32_t dt_head, dt_tail;       // document table entries in use (absolute counters)
+    int64_t dnext, dend, dbase, off_lane;   // the range of documents this wave took from the work counter; off_lane (per lane): doc_off[dbase + lane]
+    bool have_doc, exiting;
     // current document
     const uint8_t *s; int n; uint32_t rbase; int dec_bytes, dec, done, open_start, bom; uint32_t curk;
     bool err;                        // per lane: this lane saw invalid UTF-8 in the current document
@@ -51,17 +57,23 @@ struct WpWave {
     BF_WVD WpWave(const WpWaveParams &p_, LDS &S_, const uint16_t *ascii_, const int32_t *acts_) : p(p_), S(S_), ascii(ascii_), acts(acts_)
     {
         lane = wv::lane(); rhi = rlo = 0; q_tail = q_issue = q_retire = 0; dt_head = dt_tail = 0;
+        dnext = dend = dbase = off_lane = 0; have_doc = exiting = false;
         s = nullptr; n = 0; rbase = 0; dec_bytes = dec = done = bom = 0; open_start = -1; curk = 0; err = false; pf_own = 0;
         st_trips = st_win = st_slow = st_tok = st_steps = st_ret = st_rewalk = st_idle = st_dec = 0;
     }
 
     BF_WVD int ring_free() const { return RING - (int)(rhi - rlo); }
     BF_WVD uint32_t ring_at(uint32_t abs_pos) const { return S.ring[abs_pos & RMASK]; }
-    BF_WVD void put_token(uint32_t t, int pos, int len, uint32_t info)
+    BF_WVD void put_token(uint32_t t, int pos, int len, uint32_t flags)
     {
         const uint32_t sl = t & QMASK;
-        S.q0[sl] = ((rbase + (uint32_t)pos) & 0xFFFFu) | ((uint32_t)len << 16);
-        S.q1[sl] = info; S.q2[sl] = (uint16_t)curk; S.rcnt[sl] = -1;
+        S.q0[sl] = ((rbase + (uint32_t)pos) & 0xFFFFu) | ((uint32_t)len << 16) | flags;
+        S.q1[sl] = (uint32_t)pos; S.qd[sl] = (uint8_t)curk;
+    }
+    BF_WVD void put_token_info(uint32_t t, int pos, int len, uint32_t info)      // general form: any action
+    {
+        put_token(t, pos, len, WV_TK_INFO);
+        S.qi[t & QMASK] = info;
     }
 
     // ------------------------------------------------------------------------------------------------------------------
@@ -84,7 +96,8 @@ struct WpWave {
         if (STATS) ++st_dec;
         const int pos = dec_bytes;
         const int q0 = pos + lane * 8;
-        const uint64_t own = pf_own;                                // loaded a trip ago (prefetch_chunk)
+        prefetch_chunk(pos);
+        const uint64_t own = pf_own;
         int nb = n - q0; nb = nb < 0 ? 0 : (nb > 8 ? 8 : nb);
         const uint32_t w0 = rbase + (uint32_t)dec;                  // absolute ring position of this chunk's first element
         if (!wv::any((own & 0x8080808080808080ull) != 0)) {
@@ -102,7 +115,6 @@ struct WpWave {
             }
             const int total = n - pos < WV_CHUNK ? n - pos : WV_CHUNK;
             dec += total; dec_bytes = pos + WV_CHUNK; rhi = rbase + (uint32_t)dec;
-            if (dec_bytes < n) prefetch_chunk(dec_bytes);
             wv::sync();
             return;
         }
@@ -164,7 +176,6 @@ struct WpWave {
         for (int k = 0; k < 8; ++k) if (wm & (1u << k)) { S.ring[r & RMASK] = (uint16_t)v[k]; ++r; }
         const int total = wv::bcast(inc, 63);
         dec += total; dec_bytes = pos + WV_CHUNK; rhi = rbase + (uint32_t)dec;
-        if (dec_bytes < n) prefetch_chunk(dec_bytes);
         wv::sync();
     }
 
@@ -206,10 +217,10 @@ struct WpWave {
         if (STATS) ++st_win;
         const unsigned long long TK = E | SO;
         const uint32_t base = q_tail + (carry_end ? 1u : 0u);
-        if (carry_end && lane == 0) put_token(q_tail, open_start, w0 - open_start, p.loop_info);
+        if (carry_end && lane == 0) put_token(q_tail, open_start, w0 - open_start, 0u);
         if ((TK >> lane) & 1ull) {
             const uint32_t t = base + (uint32_t)__builtin_popcountll(TK & ((1ull << lane) - 1ull));
-            if (is_end) put_token(t, hpos, wlen, p.loop_info); else put_token(t, pos, 1, p.solo_info);
+            if (is_end) put_token(t, hpos, wlen, 0u); else put_token(t, pos, 1, WV_TK_SOLO);
         }
         q_tail = base + (uint32_t)__builtin_popcountll(TK);
         open_start = new_open; done = w0 + nv;
@@ -307,7 +318,7 @@ struct WpWave {
         } else new_done = wv::bcast(nxt, 63 - __builtin_clzll(St));
         // ---- queue the tokens
         const unsigned long long TK = St & wv::ballot(has);
-        if ((TK >> lane) & 1ull) put_token(q_tail + (uint32_t)__builtin_popcountll(TK & ((1ull << lane) - 1ull)), pos, len, info);
+        if ((TK >> lane) & 1ull) put_token_info(q_tail + (uint32_t)__builtin_popcountll(TK & ((1ull << lane) - 1ull)), pos, len, info);
         q_tail += (uint32_t)__builtin_popcountll(TK);
         done = new_done;
         wv::sync();
@@ -315,18 +326,21 @@ struct WpWave {
     }
 
     // ------------------------------------------------------------------------------------------------------------------
-    // phase B: the function frame of Process_int (FALexTools_t.h:229-393 at depth 1) on one word, and the post-pass on its
+    // units: the function frame of Process_int (FALexTools_t.h:229-393 at depth 1) on one word, and the post-pass on its
     // sub-tokens (tokdll:1239-1301): from = -1 takes the left anchor (resolved at load), a walk that matches emits a piece
     // and continues behind it, a walk that fails at from >= 0 leaves a gap, so the pieces cannot tile the word: UNK.
     // A unit is resumable: issue() starts the gather of its next transition, complete() consumes it.
     // ------------------------------------------------------------------------------------------------------------------
+    // Ids have a provisional home in global memory: piece k of the word whose first character is at position f of document d goes
+    // to ids_tmp[slot(d) + f + k] (a piece is at least one character, so homes never collide and never leave the slot); retire moves
+    // them down to their place in the document.  Nothing about a word's ids is kept in LDS but their number.
     struct Unit {
         int tok;                         // token (absolute queue counter, as int), -1: idle
         uint32_t rs; int L; uint32_t ini, ini_l;
         int from, j, lim; uint32_t state; int fp; uint32_t ftag;
         int cnt;
         uint32_t c; uint64_t e64;        // the transition in flight: class fed, table entry
-        int32_t *dst; int room;          // emit form (retire, words of more than K pieces): pieces go straight to dst[0 .. room)
+        int32_t *home;                   // provisional home of piece 0
     };
 
     BF_WVD bool unit_setup(Unit &u) const
@@ -345,21 +359,24 @@ struct WpWave {
     }
     BF_WVD void unit_finish(Unit &u, int cnt)
     {
-        if (!u.dst) S.rcnt[(uint32_t)u.tok & QMASK] = cnt;
+        S.qc[(uint32_t)u.tok & QMASK] = (uint16_t)(cnt + 1);
         u.tok = -1;
     }
     BF_WVD void unit_unk(Unit &u)
     {
-        if (!u.dst) S.rid[(uint32_t)u.tok & QMASK] = p.unk;
+        u.home[0] = p.unk;
         unit_finish(u, 1);
     }
     // starts the unit of token t; false: finished at once (not a word / a word without a vocabulary call)
     BF_WVD bool unit_begin(Unit &u, uint32_t t)
     {
-        u.tok = (int)t; u.dst = nullptr; u.room = 0;
+        u.tok = (int)t;
         const uint32_t sl = t & QMASK;
-        const uint32_t w0 = S.q0[sl], info = S.q1[sl];
-        u.rs = w0 & 0xFFFFu; u.L = (int)(w0 >> 16); u.cnt = 0;
+        const uint32_t w0 = S.q0[sl];
+        const uint32_t info = (w0 & WV_TK_INFO) ? S.qi[sl] : ((w0 & WV_TK_SOLO) ? p.solo_info : p.loop_info);
+        u.rs = w0 & 0xFFFFu; u.L = (int)((w0 >> 16) & WV_TK_LEN_MASK); u.cnt = 0;
+        u.home = p.ids_tmp + S.dt_slot[(uint32_t)S.qd[sl] & DMASK] + (int64_t)S.q1[sl];
+        S.qc[sl] = 0;
         int tag; bool call = false;
         if (info & LX_INFO_SIMPLE) tag = (int)(info & 0x7FFFFFFFu);
         else { const int32_t *a = acts + info; tag = a[2]; u.ini = (uint32_t)a[5]; u.ini_l = (uint32_t)a[6]; call = true; }
@@ -387,9 +404,7 @@ struct WpWave {
             if (u.from >= 0) { unit_unk(u); return; }                                    // a gap: the word is UNK whatever follows
             u.from = 0;                                                                  // the anchored walk found nothing (FALexTools_t.h:293)
         } else {
-            const int32_t tag = (int32_t)(u.ftag & 0x7FFFFFFFu);
-            if (u.dst) { if (u.cnt < u.room) u.dst[u.cnt] = tag; }
-            else if (u.cnt < K) S.rid[u.cnt * QCAP + ((uint32_t)u.tok & QMASK)] = tag;
+            u.home[u.cnt] = (int32_t)(u.ftag & 0x7FFFFFFFu);
             ++u.cnt;
             u.from = u.fp + 1;
         }
@@ -398,67 +413,110 @@ struct WpWave {
     // hands queued tokens to the lanes whose unit is idle
     BF_WVD void unit_refill(Unit &u)
     {
-        const unsigned long long m = wv::ballot(u.tok < 0);
         const uint32_t avail = q_tail - q_issue;
-        if (m == 0 || avail == 0) return;
+        if (avail == 0) return;
+        const unsigned long long m = wv::ballot(u.tok < 0);
+        if (m == 0) return;
         const uint32_t r = (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1ull));
         if (u.tok < 0 && r < avail) unit_begin(u, q_issue + r);
         const uint32_t k = (uint32_t)__builtin_popcountll(m);
         q_issue += k < avail ? k : avail;
     }
+    // Runs the units until the queue is handed out and fewer than UNIT_MIN of them are still walking (`drain`: until all are
+    // done).  Returns whether a transition was made.
+    BF_WVD bool units_phase(Unit (&u)[NU], bool drain)
+    {
+        bool ran = false;
+        for (;;) {
+            int nb = 0;
+#pragma unroll
+            for (int i = 0; i < NU; ++i) { unit_refill(u[i]); nb += __builtin_popcountll(wv::ballot(u[i].tok >= 0)); }
+            if (nb == 0) break;
+            if (!drain && q_issue == q_tail && nb < UNIT_MIN) break;
+            if (STATS) { ++st_trips; st_steps += (unsigned long long)nb; }
+#pragma unroll
+            for (int i = 0; i < NU; ++i) if (u[i].tok >= 0) unit_issue(u[i]);
+#pragma unroll
+            for (int i = 0; i < NU; ++i) if (u[i].tok >= 0) unit_complete(u[i]);
+            ran = true;
+        }
+        wv::sync();
+        return ran;
+    }
+    static constexpr int UNIT_MIN = 12 * NU;
 
     // ------------------------------------------------------------------------------------------------------------------
     // retire (phase C): the finished tokens at the head of the queue, in order.  Position of a unit's ids = ids its document has
-    // so far + ids of the units before it in the document (segmented prefix sum); nothing is written at or behind the document's
-    // cap (tokdll:1308-1310 is then the prefix rule: what a full output array cuts off does not change what came before).
-    // Documents all of whose tokens are retired and that are closed get their count written.  Returns whether anything moved
-    // (tokens retired, documents completed, ring space freed).
+    // so far + ids of the units before it in the document (segmented prefix sum); the ids move from their provisional homes down
+    // to that position (never up: a document has at most as many ids as characters before any point), all lanes reading before
+    // any lane writes; nothing is written at or behind the document's cap (tokdll:1308-1310 is then the prefix rule: what a full
+    // output array cuts off does not change what came before).  `all`: any finished prefix; else only a full group of 64.
+    // Returns the number of tokens retired.
     // ------------------------------------------------------------------------------------------------------------------
-    BF_WVD bool retire(bool have_doc)
+    BF_WVD int retire(bool all)
     {
-        bool moved = false;
-        const uint32_t navail = q_tail - q_retire < 64u ? q_tail - q_retire : 64u;
+        const uint32_t navail = q_issue - q_retire < 64u ? q_issue - q_retire : 64u;       // tokens a unit has taken
+        if (navail == 0 || (!all && navail < 64u)) return 0;
         const uint32_t t = q_retire + (uint32_t)lane, sl = t & QMASK;
-        const int cnt0 = (uint32_t)lane < navail ? S.rcnt[sl] : -1;
+        const int cnt0 = (uint32_t)lane < navail ? (int)S.qc[sl] - 1 : -1;
         const unsigned long long fin = wv::ballot(cnt0 >= 0);
         const int nret = fin == ~0ull ? 64 : __builtin_ctzll(~fin);                  // the finished prefix
-        if (nret > 0) {
-            moved = true;
-            if (STATS) ++st_ret;
-            const bool act = lane < nret;
-            const int cnt = act ? cnt0 : 0;
-            const int k = act ? (int)S.q2[sl] : -1;
-            const int inc = wv::incl_scan(cnt), exc = inc - cnt;
-            const int kp = wv::shfl_up(k, 1), kn = wv::shfl_down(k, 1);
-            const unsigned long long hm = wv::ballot(lane == 0 || k != kp);
-            const int head = 63 - __builtin_clzll(hm & ((2ull << lane) - 1ull));
-            const int segbase = wv::shfl(exc, head);
-            const uint32_t ke = (uint32_t)k & DMASK;
-            int pos = 0; int64_t slot = 0; int cap = 0;
-            if (act) { pos = S.dt_cnt[ke] + (exc - segbase); slot = S.dt_slot[ke]; cap = S.dt_cap[ke]; }
-            wv::sync();                                                   // every lane has read its document's count
-            if (act && (lane == 63 || k != kn)) S.dt_cnt[ke] = pos + cnt;
-            if (act && cnt > 0 && pos < cap) {
-                int32_t *dst = p.ids_tmp + slot + pos;
-                const int room = cap - pos;
-                if (cnt <= K) {
-#pragma unroll
-                    for (int i = 0; i < K; ++i) if (i < cnt && i < room) dst[i] = S.rid[i * QCAP + sl];
-                } else {
-                    // more than K pieces: walk the word again, this time straight into its place
-                    if (STATS) ++st_rewalk;
-                    Unit u;
-                    unit_begin(u, t);                                     // a word with a call: never finishes at once
-                    u.dst = dst; u.room = room;
-                    while (u.tok >= 0) { unit_issue(u); unit_complete(u); }
-                }
+        if (nret == 0 || (!all && nret < 64)) return 0;
+        if (STATS) ++st_ret;
+        const bool act = lane < nret;
+        const int cnt = act ? cnt0 : 0;
+        const int k = act ? (int)S.qd[sl] : -1;
+        const uint32_t ke = (uint32_t)k & DMASK;
+        int64_t slot = 0; int cap = 0, dcnt = 0; uint32_t f = 0;
+        if (act) { slot = S.dt_slot[ke]; cap = S.dt_cap[ke]; dcnt = S.dt_cnt[ke]; f = S.q1[sl]; }
+        const int32_t *src = p.ids_tmp + slot + (int64_t)f;
+        int32_t v0 = 0, v1 = 0, v2 = 0, v3 = 0;
+        if (cnt > 0) v0 = src[0];
+        if (cnt > 1) v1 = src[1];
+        if (cnt > 2) v2 = src[2];
+        if (cnt > 3) v3 = src[3];
+        const int inc = wv::incl_scan(cnt), exc = inc - cnt;
+        const int kp = wv::shfl_up(k, 1), kn = wv::shfl_down(k, 1);
+        const unsigned long long hm = wv::ballot(lane == 0 || k != kp);
+        const int head = 63 - __builtin_clzll(hm & ((2ull << lane) - 1ull));
+        const int segbase = wv::shfl(exc, head);
+        const int pos = dcnt + (exc - segbase);
+        wv::sync();                                                   // every lane has read its document's count and its first four ids
+        if (act && (lane == 63 || k != kn)) S.dt_cnt[ke] = pos + cnt;
+        const int room = cap - pos;
+        // words of more than four pieces first, one after the other and in order, the whole wave moving 64 ids at a time (reads
+        // before writes, lowest first): the place of a LATER token may reach into the provisional home of such a word's last ids
+        unsigned long long big = wv::ballot(cnt > 4);
+        while (big) {
+            const int l = __builtin_ctzll(big); big &= big - 1ull;
+            const int bc = wv::bcast(cnt, l), br = wv::bcast(room, l);
+            const int64_t bs = wv::bcast(slot + (int64_t)f, l), bd = wv::bcast(slot + (int64_t)pos, l);
+            if (STATS && lane == 0) ++st_rewalk;
+            for (int o = 4; o < bc; o += 64) {
+                const int i = o + lane;
+                int32_t v = 0;
+                if (i < bc) v = p.ids_tmp[bs + i];
+                wv::sync();
+                if (i < bc && i < br) p.ids_tmp[bd + i] = v;
+                wv::sync();
             }
-            q_retire += (uint32_t)nret;
-            wv::sync();
         }
-        // ---- documents that are complete: closed, and in front of the document of the oldest token still queued
+        int32_t *dst = p.ids_tmp + slot + pos;
+        if (cnt > 0 && room > 0) dst[0] = v0;
+        if (cnt > 1 && room > 1) dst[1] = v1;
+        if (cnt > 2 && room > 2) dst[2] = v2;
+        if (cnt > 3 && room > 3) dst[3] = v3;
+        q_retire += (uint32_t)nret;
+        wv::sync();
+        return nret;
+    }
+    // documents that are complete (closed, and in front of the document of the oldest token still queued) get their count; the
+    // ring is needed from the oldest queued token on (or from the first unresolved position of the open document)
+    BF_WVD bool settle()
+    {
+        bool moved = false;
         uint32_t limit;
-        if (q_retire != q_tail) limit = dt_head + (((uint32_t)S.q2[q_retire & QMASK] - dt_head) & 0xFFFFu);
+        if (q_retire != q_tail) limit = dt_head + (((uint32_t)S.qd[q_retire & QMASK] - dt_head) & 0xFFu);
         else limit = have_doc ? curk : dt_tail;
         if (limit != dt_head) {
             const uint32_t kk = dt_head + (uint32_t)lane;
@@ -469,11 +527,9 @@ struct WpWave {
             }
             dt_head = limit; moved = true;
         }
-        // ---- the ring is needed from the oldest queued token on (or from the first unresolved position of the document)
         const uint32_t old_lo = rlo;
         if (q_retire != q_tail) rlo = rhi - ((rhi - (S.q0[q_retire & QMASK] & 0xFFFFu)) & 0xFFFFu);
         else rlo = have_doc ? rbase + (uint32_t)(open_start >= 0 ? open_start : done) : rhi;
-        wv::sync();
         return moved || rlo != old_lo;
     }
 
@@ -490,7 +546,6 @@ struct WpWave {
         if (lane == 0) { S.dt_slot[ke] = wv_ids_slot(b, d); S.dt_doc[ke] = d; S.dt_cap[ke] = cap; S.dt_cnt[ke] = 0; S.dt_flags[ke] = 0; }
         rhi = (rhi + 7u) & ~7u; rbase = rhi;
         dec_bytes = dec = done = bom = 0; open_start = -1; err = false;
-        prefetch_chunk(0);
         wv::sync();
         return true;
     }
@@ -498,83 +553,64 @@ struct WpWave {
     {
         // a run that was still open when the decoded text ended without another element (possible only behind invalid UTF-8 or a
         // character that straddles the last chunk boundary)
-        if (open_start >= 0) { if (lane == 0) put_token(q_tail, open_start, dec - open_start, p.loop_info); ++q_tail; open_start = -1; }
+        if (open_start >= 0) { if (lane == 0) put_token(q_tail, open_start, dec - open_start, 0u); ++q_tail; open_start = -1; }
         const bool bad = wv::any(err);
         if (lane == 0) S.dt_flags[curk & DMASK] = WV_DT_CLOSED | (bad ? WV_DT_BAD : 0u);
         wv::sync();
+    }
+
+    // one producing action: take a range of documents, open / decode / resolve a window / close.  false: nothing can be produced now
+    // (the queue, the document table or the ring is full, or the input is exhausted)
+    BF_WVD bool fill_step(int grab)
+    {
+        if (!have_doc) {
+            if (exiting || dt_tail - dt_head >= (uint32_t)DTN) return false;
+            if (dnext >= dend) {
+                unsigned long long base = 0;
+                if (lane == 0) base = wv::atomic_add(p.next_doc, (unsigned long long)grab);
+                base = wv::bcast(base, 0);
+                if ((int64_t)base >= p.b.ndocs) { exiting = true; return false; }
+                dbase = (int64_t)base; dnext = dbase; dend = dbase + grab < p.b.ndocs ? dbase + grab : p.b.ndocs;
+                if (lane <= (int)(dend - dbase)) off_lane = p.b.doc_off[dbase + lane];
+            }
+            const int i = (int)(dnext - dbase);
+            const int64_t b = wv::bcast(off_lane, i), e = wv::bcast(off_lane, i + 1);
+            have_doc = open_document(dnext, b, e);
+            ++dnext;
+            return true;
+        }
+        const bool fully = dec_bytes >= n;
+        const bool room_q = (q_tail - q_retire) + 66u <= (uint32_t)QCAP;
+        if (done < dec) {
+            if (!room_q) return false;
+            if (phase_a_fast(fully)) return true;
+            if (open_start >= 0) { done = open_start; open_start = -1; }     // the general form starts at a certain start position
+            if (phase_a_general(fully)) return true;
+        }
+        if (dec_bytes < n) { if (ring_free() < WV_CHUNK) return false; decode_chunk(); return true; }
+        if (done >= dec) { if (open_start >= 0 && !room_q) return false; close_document(); have_doc = false; return true; }
+        return false;
     }
 
     BF_WVD void run(int grab)
     {
         Unit u[NU];
 #pragma unroll
-        for (int i = 0; i < NU; ++i) { u[i].tok = -1; u[i].dst = nullptr; u[i].room = 0; }
-        // the work counter is read one range ahead, the offsets of a range's documents when the range is taken
-        int64_t dnext = 0, dend = 0;
-        unsigned long long pre_base = 0;
-        if (lane == 0) pre_base = wv::atomic_add(p.next_doc, (unsigned long long)grab);
-        int64_t off_lane = 0;                                            // doc_off[dnext0 + lane] of the current range
-        int64_t dbase = 0;
-        bool have_doc = false, exiting = false;
+        for (int i = 0; i < NU; ++i) u[i].tok = -1;
         for (;;) {
-            if (STATS) ++st_trips;
-            // ---- 1. gathers of the transitions in flight
-#pragma unroll
-            for (int i = 0; i < NU; ++i) if (u[i].tok >= 0) unit_issue(u[i]);
-            if (STATS) { for (int i = 0; i < NU; ++i) st_steps += (unsigned long long)__builtin_popcountll(wv::ballot(u[i].tok >= 0)); }
-            // ---- 2. one producing action
-            bool produced = false;
-            if (!have_doc) {
-                if (!exiting && dt_tail - dt_head < (uint32_t)DTN) {
-                    if (dnext >= dend) {
-                        const unsigned long long base = wv::bcast(pre_base, 0);
-                        if ((int64_t)base >= p.b.ndocs) exiting = true;
-                        else {
-                            dbase = (int64_t)base; dnext = dbase; dend = dbase + grab < p.b.ndocs ? dbase + grab : p.b.ndocs;
-                            if (lane <= (int)(dend - dbase)) off_lane = p.b.doc_off[dbase + lane];
-                            if (lane == 0) pre_base = wv::atomic_add(p.next_doc, (unsigned long long)grab);
-                        }
-                        produced = true;
-                    } else {
-                        const int i = (int)(dnext - dbase);
-                        const int64_t b = wv::bcast(off_lane, i), e = wv::bcast(off_lane, i + 1);
-                        have_doc = open_document(dnext, b, e);
-                        ++dnext; produced = true;
-                    }
-                }
-            } else {
-                const bool fully = dec_bytes >= n;
-                const bool room_q = (q_tail - q_retire) + 66u <= (uint32_t)QCAP;
-                if (done < dec && room_q) {
-                    if (phase_a_fast(fully)) produced = true;
-                    else {
-                        if (open_start >= 0) { done = open_start; open_start = -1; }     // the general form starts at a certain start position
-                        if (phase_a_general(fully)) produced = true;
-                    }
-                }
-                if (!produced) {
-                    if (dec_bytes < n) { if (ring_free() >= WV_CHUNK) { decode_chunk(); produced = true; } }
-                    else if (done >= dec) { if (open_start < 0 || room_q) { close_document(); have_doc = false; produced = true; } }
-                }
-            }
-            // ---- 3. transitions done; idle units take queued tokens
-            bool busy = false;
-#pragma unroll
-            for (int i = 0; i < NU; ++i) {
-                if (u[i].tok >= 0) unit_complete(u[i]);
-                unit_refill(u[i]);
-                busy = busy || u[i].tok >= 0;
-            }
-            const bool any_busy = wv::any(busy);
-            // ---- 4. retire
-            bool moved = false;
-            const uint32_t queued = q_tail - q_retire;
-            if (queued >= 64u || (!produced && queued > 0) || (exiting && !have_doc) || (!produced && dt_tail != dt_head)) moved = retire(have_doc);
-            if (exiting && !have_doc && q_tail == q_retire && dt_head == dt_tail && !any_busy) break;
-            if (!produced && !any_busy && !moved && !(exiting && !have_doc)) {
-                if (STATS) ++st_idle;
+            bool moved = settle();
+            bool filled = false;
+            while (fill_step(grab)) filled = true;
+            const bool drain = !filled;          // nothing could be produced: what blocks is freed only by finishing and retiring tokens
+            if (units_phase(u, drain)) moved = true;
+            for (;;) { const int r = retire(drain); if (r == 0) break; moved = true; if (r < 64) break; }
+            if (settle()) moved = true;
+            if (exiting && !have_doc && q_tail == q_retire && dt_head == dt_tail) break;
+            if (!filled && !moved) {
                 // nothing can move: cannot happen (the ring holds a whole token and a chunk, the queue a whole window; checked at load)
-                if (q_tail == q_retire && q_issue == q_tail) { if (lane == 0) wv::atomic_or(p.b.status, BF_STATUS_INTERNAL); break; }
+                if (STATS) ++st_idle;
+                if (lane == 0) wv::atomic_or(p.b.status, BF_STATUS_INTERNAL);
+                break;
             }
         }
         if (STATS && lane == 0) {

@@ -39,8 +39,8 @@ extern "C" {
 int bft_wave_ok(void *hv) { return ((Handle *)hv)->m.wave_ok ? 1 : 0; }
 const char *bft_wave_why(void *hv) { return ((Handle *)hv)->m.wave_why.c_str(); }
 
-// TextToIdsBatch through the wave kernel on the host.  cfg: 0 = the shipped configuration, 1 = one unit per lane, a two-entry document table and one kept
-// piece per word (every longer word is walked again), 2 = three units per lane, a large ring and queue.  Returns the total id count, or < 0 (-1: model not in unit form, -5: the kernel raised a status bit).
+// TextToIdsBatch through the wave kernel on the host.  cfg: 0 = the shipped configuration, 1 = two units per lane, the smallest ring and queue, a two-entry
+// document table, 2 = three units per lane, a large ring and queue.  Returns the total id count, or < 0 (-1: model not in unit form, -5: the kernel raised a status bit).
 // stats (optional, 16 counters): see bf_wave.h WpWaveParams::stats.
 long bft_emu_wave_batch(void *hv, const uint8_t *text, long text_bytes, const int64_t *doc_off, long ndocs, int max_ids, int unk, int nwaves, int grab, int cfg,
                         int32_t *ids_out, long ids_cap, int64_t *id_off, unsigned long long *stats)
@@ -59,9 +59,9 @@ long bft_emu_wave_batch(void *hv, const uint8_t *text, long text_bytes, const in
     p.b = Batch{text, doc_off, ndocs, total, &status};
     p.ids_tmp = tmp.data(); p.counts = counts.data(); p.max_ids = max_ids; p.unk = unk; p.next_doc = &next_doc; p.stats = stats;
     if (ndocs > 0) {
-        if (cfg == 1) run_cfg<WvLds<1024, 128, 2, 1>, 1>(p, nwaves, grab);
-        else if (cfg == 2) run_cfg<WvLds<4096, 256, 64, 4>, 3>(p, nwaves, grab);
-        else run_cfg<WvLds<1024, 128, 64, 8>, 2>(p, nwaves, grab);
+        if (cfg == 1) run_cfg<WvLds<1024, 128, 2>, 2>(p, nwaves, grab);
+        else if (cfg == 2) run_cfg<WvLds<4096, 512, 64>, 3>(p, nwaves, grab);
+        else run_cfg<WvLds<2048, 256, 32>, 1>(p, nwaves, grab);
     }
     if (status) return -5;
     // k_scan + k_compact, restated

@@ -172,4 +172,5 @@ __attribute__((noinline)) static int incl_scan(int v WV_SITE_ARG)
 }
 static inline unsigned long long atomic_add(unsigned long long *p, unsigned long long v) { unsigned long long o = *p; *p = o + v; return o; }
 static inline void atomic_or(int *p, int v) { *p |= v; }
+static inline unsigned long long clock() { return 0; }
 } // namespace wv

@@ -13,8 +13,8 @@ import bfutil
 import blingfire_amd as bf
 
 WP_MODELS = ["bert_base_tok.bin", "bert_base_cased_tok.bin", "bert_chinese.bin"]
-# (max_ids, unk, waves, documents per grab, configuration: 0 = shipped, 1 = one unit per lane / two-entry document table / one kept piece,
-#  2 = three units per lane / large ring and queue)
+# (max_ids, unk, waves, documents per grab, configuration: 0 = shipped, 1 = two units per lane / smallest ring and queue / two-entry
+#  document table, 2 = three units per lane / large ring and queue)
 CONFS = [(512, 100, 1, 8, 0), (512, 100, 4, 2, 1), (64, 5, 2, 8, 2), (1, 100, 1, 3, 1), (0, 100, 2, 8, 0)]
 
 

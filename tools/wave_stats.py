@@ -14,6 +14,6 @@ bf.text_to_ids_batch_device(h, d_text, d_off, 512, 100); torch.cuda.synchronize(
 out = (ctypes.c_ulonglong * 16)()
 bf.lib().BfLexStats.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
 bf.lib().BfLexStats(h, out, 16)
-st = [int(out[i]) for i in range(9)]
-print("docs", ndocs, "bytes", int(off[-1]), "trips/doc %.1f fast windows/doc %.2f general windows/doc %.3f tokens/doc %.1f unit-steps/doc %.0f (per trip %.1f) retires/doc %.2f rewalks/doc %.3f "
+st = [int(out[i]) for i in range(16)]
+print("docs", ndocs, "bytes", int(off[-1]), "unit trips/doc %.1f fast windows/doc %.2f general windows/doc %.3f tokens/doc %.1f unit-steps/doc %.0f (per trip %.1f) retires/doc %.2f rewalks/doc %.3f "
       "trips without progress/doc %.3f decodes/doc %.2f" % (st[0] / ndocs, st[1] / ndocs, st[2] / ndocs, st[3] / ndocs, st[4] / ndocs, st[4] / max(st[0], 1), st[5] / ndocs, st[6] / ndocs, st[7] / ndocs, st[8] / ndocs))
