@@ -332,7 +332,7 @@ int run_device(Handle *h, const char *d_text, const int64_t *d_doc_off, int64_t 
         wp.kind = h->t_kind.as<uint8_t>(); wp.nclasses = m.wbd.nclasses;
         wp.initial = m.wbd.initial_base; wp.loop_info = m.loop_info; wp.solo_info = m.wave_solo_info; wp.acts_n = (int)m.acts_pool.size(); wp.max_token_length = m.max_token_length;
         wp.b = b; wp.ids_tmp = h->w_tmp.as<int32_t>(); wp.counts = h->w_counts.as<int32_t>(); wp.max_ids = max_ids; wp.unk = unk;
-        wp.next_doc = next_doc;
+        wp.next_doc = next_doc; wp.no_fast = 0;
         wp.stats = h->lex_stats ? (unsigned long long *)(h->w_misc.as<char>() + 64) : nullptr;
         if (ndocs > 0) launch_wp_wave(wp, h->variant, s);
         (void)hipEventRecord(h->ev[EV_TOK], s);

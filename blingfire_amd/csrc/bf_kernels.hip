@@ -684,6 +684,9 @@ __device__ __forceinline__ int incl_scan(int v) { return bfa::wave_incl_scan(v);
 __device__ __forceinline__ unsigned long long atomic_add(unsigned long long *p, unsigned long long v) { return atomicAdd(p, v); }
 __device__ __forceinline__ void atomic_or(int *p, int v) { atomicOr(p, v); }
 __device__ __forceinline__ unsigned long long clock() { return __builtin_readcyclecounter(); }
+__device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ uint32_t mbcnt(unsigned long long m) { return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)); }
 } // namespace wv
 #include "bf_wave_body.h"
 namespace bfa {

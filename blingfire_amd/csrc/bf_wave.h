@@ -67,6 +67,7 @@ struct WpWaveParams {
     int32_t *counts;                 // [ndocs]
     int max_ids, unk;
     unsigned long long *next_doc;    // work counter
+    int no_fast;                     // tests: every token carries its action explicitly (the path of lexers whose run / solo actions differ)
     unsigned long long *stats;       // optional (experiments): [0] trips [1] fast windows [2] general windows [3] tokens [4] unit-steps issued [5] retire rounds
                                      // [6] rewalks [7] trips without a produce action [8] decode steps
 };

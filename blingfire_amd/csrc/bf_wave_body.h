@@ -17,20 +17,19 @@
 
 namespace bfa {
 
-constexpr uint32_t WV_TK_SOLO = 1u << 31, WV_TK_INFO = 1u << 30, WV_TK_LEN_MASK = 0x1FFu;    // token flags: action = solo_info / stored in rid[]; else loop_info
+constexpr uint32_t WV_TK_INFO = 1u << 30, WV_TK_LEN_MASK = 0x1FFu;    // token flags (WV_TK_INFO: the action is in qi[]; else the common word kind)
 
-// LDS of one wave.  QCAP / DTN / RING are powers of two.  A token: q0 = ring position (low 16 bits of the absolute position) |
-// length << 16 | WV_TK_* flags; q1 = position of its first character in the document; qd = document table entry (low 8 bits of the
-// absolute entry number); qc = set by the unit: 0 while it walks, then 1 + the number of ids; qi = action info (WV_TK_INFO tokens only).
+// LDS of one wave.  QCAP / DTN / RING are powers of two.  A token: q0 = absolute ring position of its first character; q1 = length |
+// document table entry (low 8 bits of the absolute entry number) << 16 | WV_TK_* flags; qc = set by the unit: 0 while it walks, then
+// 1 + the number of ids; qi = action info (WV_TK_INFO tokens only).
 template <int RING_, int QCAP_, int DTN_>
 struct WvLds {
     static constexpr int RING = RING_, QCAP = QCAP_, DTN = DTN_;
     alignas(16) uint16_t ring[RING];
     int64_t dt_slot[DTN], dt_doc[DTN];
     uint32_t q0[QCAP], q1[QCAP], qi[QCAP];
-    int32_t dt_cap[DTN], dt_cnt[DTN]; uint32_t dt_flags[DTN];
+    int32_t dt_cap[DTN], dt_cnt[DTN]; uint32_t dt_flags[DTN], dt_rbase[DTN];      // dt_rbase: ring position of the document's first character
     uint16_t qc[QCAP];
-    uint8_t qd[QCAP];
 };
 
 template <class LDS, int NU = 2, bool STATS = false>
@@ -50,6 +49,8 @@ struct WpWave {
     bool have_doc, exiting;
     // current document
     const uint8_t *s; int n; uint32_t rbase; int dec_bytes, dec, done, open_start, bom; uint32_t curk;
+    uint32_t fn_ini, fn_ini_l;       // the vocabulary function of the common word kinds (run and solo tokens), when fast_ok
+    bool fast_ok;                    // run and solo tokens are both "WORD, call the same function": their units need no action lookup
     bool err;                        // per lane: this lane saw invalid UTF-8 in the current document
     uint64_t pf_own;                 // per lane: its 8 bytes of the next chunk
     unsigned long long st_trips, st_win, st_slow, st_tok, st_steps, st_ret, st_rewalk, st_idle, st_dec;
@@ -60,6 +61,12 @@ struct WpWave {
         dnext = dend = dbase = off_lane = 0; have_doc = exiting = false;
         s = nullptr; n = 0; rbase = 0; dec_bytes = dec = done = bom = 0; open_start = -1; curk = 0; err = false; pf_own = 0;
         st_trips = st_win = st_slow = st_tok = st_steps = st_ret = st_rewalk = st_idle = st_dec = 0;
+        // the action of a run token and of a solo token (bf_model.cpp): the usual case is one calling WORD action for both
+        fast_ok = false; fn_ini = 0; fn_ini_l = LX_NO_STATE;
+        if (!p.no_fast && !(p.loop_info & LX_INFO_SIMPLE) && !(p.solo_info & LX_INFO_SIMPLE)) {
+            const int32_t *a = acts + p.loop_info, *c = acts + p.solo_info;
+            if (a[2] == WBD_WORD_TAG && c[2] == WBD_WORD_TAG && a[5] == c[5] && a[6] == c[6]) { fast_ok = true; fn_ini = (uint32_t)a[5]; fn_ini_l = (uint32_t)a[6]; }
+        }
     }
 
     BF_WVD int ring_free() const { return RING - (int)(rhi - rlo); }
@@ -67,8 +74,12 @@ struct WpWave {
     BF_WVD void put_token(uint32_t t, int pos, int len, uint32_t flags)
     {
         const uint32_t sl = t & QMASK;
-        S.q0[sl] = ((rbase + (uint32_t)pos) & 0xFFFFu) | ((uint32_t)len << 16) | flags;
-        S.q1[sl] = (uint32_t)pos; S.qd[sl] = (uint8_t)curk;
+        S.q0[sl] = rbase + (uint32_t)pos;
+        S.q1[sl] = (uint32_t)len | ((curk & 0xFFu) << 16) | flags;
+    }
+    BF_WVD void put_word(uint32_t t, int pos, int len, bool solo)                 // a run / solo token of the mask form
+    {
+        if (fast_ok) put_token(t, pos, len, 0u); else put_token_info(t, pos, len, solo ? p.solo_info : p.loop_info);
     }
     BF_WVD void put_token_info(uint32_t t, int pos, int len, uint32_t info)      // general form: any action
     {
@@ -82,6 +93,70 @@ struct WpWave {
     // no character and must be covered by a lead 1..3 bytes before it; a lead byte gives length, checks its continuation
     // bytes, truncation (:167-171), overlong / > U+10FFFF (:185-188), surrogates (:190-193).  One leading BOM is skipped.
     // ------------------------------------------------------------------------------------------------------------------
+    // The top level over a whole chunk of plain ASCII at once (what phase_a_fast does for 64 positions, here for 512 with eight
+    // elements per lane): kinds as 2-bit fields of a 16-bit word per lane; a run of WK_LOOP elements that crosses lanes is closed
+    // with one ballot (which lanes hold a run start) and one shuffle (the start position of the nearest one); token numbers from a
+    // prefix sum of the per-lane counts; every lane then writes its own tokens.  Leaves everything untouched (the window forms take
+    // the chunk) when it holds a WK_GENERAL element, a run that max-length cuts, or more tokens than the queue has room for.
+    BF_WVD void chunk_tokens(const uint32_t (&e)[8], int nb, int cb, int total)
+    {
+        uint32_t kk = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) kk |= (e[k] >> WK_SHIFT) << (2 * k);
+        const uint32_t vm = nb >= 8 ? 0x5555u : (((1u << (2 * nb)) - 1u) & 0x5555u);
+        const uint32_t lo = kk & 0x5555u, hi = (kk >> 1) & 0x5555u;
+        const uint32_t loopm = lo & ~hi & vm, solom = lo & hi & vm, genm = ~lo & ~hi & vm;
+        if (wv::any(genm != 0)) return;
+        const int maxtok = p.max_token_length;
+        const bool at_end = dec_bytes >= n;                            // the document ends with this chunk
+        const bool cont = open_start >= 0;
+        uint32_t prev_last = wv::shfl_up((loopm >> 14) & 1u, 1), next_first = wv::shfl_down(loopm & 1u, 1);
+        if (lane == 0) prev_last = cont ? 1u : 0u;
+        if (lane == 63) next_first = 0u;
+        const uint32_t h = loopm & ~((loopm << 2) | prev_last);        // run starts
+        uint32_t en = loopm & ~((loopm >> 2) | (next_first << 14));    // run ends
+        const int last_lane = (total - 1) >> 3; const uint32_t last_bit = 1u << (2 * ((total - 1) & 7));
+        const bool stays_open = !at_end && wv::any(lane == last_lane && (en & last_bit) != 0);
+        if (stays_open && lane == last_lane) en &= ~last_bit;
+        // the start of the run a lane's first end belongs to, when it lies in an earlier lane (or chunk)
+        const int hl = h ? cb + lane * 8 + ((31 - __builtin_clz(h)) >> 1) : -1;           // this lane's last run start
+        const unsigned long long HB = wv::ballot(h != 0);
+        const unsigned long long hb_lt = HB & ((1ull << lane) - 1ull);
+        const int hsrc = hb_lt ? 63 - __builtin_clzll(hb_lt) : 0;
+        int hprev = wv::shfl(hl, hsrc);
+        if (!hb_lt) hprev = open_start;
+        const int new_open = stays_open ? (HB ? wv::bcast(hl, 63 - __builtin_clzll(HB)) : open_start) : -1;
+        const bool carry_end = cont && !wv::any(lane == 0 && (loopm & 1u) != 0);           // the open run ended with the chunk before
+        uint32_t tk = en | solom;
+        const int c = __builtin_popcount(tk);
+        const int inc = wv::incl_scan(c);
+        const uint32_t ntok = (uint32_t)wv::bcast(inc, 63) + (carry_end ? 1u : 0u);
+        if ((q_tail - q_retire) + ntok > (uint32_t)QCAP) return;
+        if ((carry_end && cb - open_start > maxtok) || (stays_open && cb + total - new_open >= maxtok)) return;
+        // a finished run longer than max-length: found while writing, nothing is committed then
+        uint32_t t = q_tail + (carry_end ? 1u : 0u) + (uint32_t)(inc - c);
+        bool toolong = false;
+        if (carry_end && lane == 0) put_word(q_tail, open_start, cb - open_start, false);
+        while (wv::any(tk != 0)) {
+            if (tk) {
+                const int bit = __builtin_ctz(tk); tk &= tk - 1u;
+                const int bpos = cb + lane * 8 + (bit >> 1);
+                if ((en >> bit) & 1u) {
+                    const uint32_t hm = h & ((2u << bit) - 1u);
+                    const int start = hm ? cb + lane * 8 + ((31 - __builtin_clz(hm)) >> 1) : hprev;
+                    const int len = bpos - start + 1;
+                    toolong |= len > maxtok;
+                    put_word(t, start, len, false);
+                } else put_word(t, bpos, 1, true);
+                ++t;
+            }
+        }
+        wv::sync();
+        if (wv::any(toolong)) return;
+        if (STATS) ++st_win;
+        q_tail += ntok; done = dec; open_start = new_open;
+    }
+
     BF_WVD void prefetch_chunk(int pos)
     {
         const int q0 = pos + lane * 8;
@@ -114,8 +189,11 @@ struct WpWave {
                 for (int k = 0; k < 8; ++k) if (k < nb) S.ring[(r + (uint32_t)k) & RMASK] = (uint16_t)e[k];
             }
             const int total = n - pos < WV_CHUNK ? n - pos : WV_CHUNK;
+            const int cb = dec;                                        // position of this chunk's first element
+            const bool caught_up = done == dec;
             dec += total; dec_bytes = pos + WV_CHUNK; rhi = rbase + (uint32_t)dec;
             wv::sync();
+            if (caught_up) chunk_tokens(e, nb, cb, total);
             return;
         }
         uint32_t nxt = wv::shfl_down((uint32_t)own, 1);
@@ -217,10 +295,10 @@ struct WpWave {
         if (STATS) ++st_win;
         const unsigned long long TK = E | SO;
         const uint32_t base = q_tail + (carry_end ? 1u : 0u);
-        if (carry_end && lane == 0) put_token(q_tail, open_start, w0 - open_start, 0u);
+        if (carry_end && lane == 0) put_word(q_tail, open_start, w0 - open_start, false);
         if ((TK >> lane) & 1ull) {
             const uint32_t t = base + (uint32_t)__builtin_popcountll(TK & ((1ull << lane) - 1ull));
-            if (is_end) put_token(t, hpos, wlen, 0u); else put_token(t, pos, 1, WV_TK_SOLO);
+            if (is_end) put_word(t, hpos, wlen, false); else put_word(t, pos, 1, true);
         }
         q_tail = base + (uint32_t)__builtin_popcountll(TK);
         open_start = new_open; done = w0 + nv;
@@ -334,105 +412,105 @@ struct WpWave {
     // Ids have a provisional home in global memory: piece k of the word whose first character is at position f of document d goes
     // to ids_tmp[slot(d) + f + k] (a piece is at least one character, so homes never collide and never leave the slot); retire moves
     // them down to their place in the document.  Nothing about a word's ids is kept in LDS but their number.
+    //
+    // A unit runs the frame of ONE function call: walks start at `j0` (first the anchored walk from ini_l at character 0, if the
+    // function has a left-anchor transition; then the plain walks from ini), read letters while j < lim = min(start + max-length, L).
+    // Written with selects: the walk loop is what every lane executes on every trip.
     struct Unit {
         int tok;                         // token (absolute queue counter, as int), -1: idle
-        uint32_t rs; int L; uint32_t ini, ini_l;
-        int from, j, lim; uint32_t state; int fp; uint32_t ftag;
-        int cnt;
+        uint32_t rs; int L; uint32_t ini;
+        int j, lim; uint32_t state; int fp; uint32_t ftag;
+        int cnt, anch;                   // pieces so far; 1 while the anchored walk runs
         uint32_t c; uint64_t e64;        // the transition in flight: class fed, table entry
         int32_t *home;                   // provisional home of piece 0
     };
 
-    BF_WVD bool unit_setup(Unit &u) const
-    {
-        for (;;) {
-            if (u.from >= u.L) return false;
-            const int b = u.from + p.max_token_length;
-            u.lim = b < u.L ? b : u.L;                               // no right-anchor step inside a function (fn_no_ra)
-            if (u.from < 0) {
-                if (u.ini_l == LX_NO_STATE || !(0 < u.lim)) { u.from = 0; continue; }
-                u.state = u.ini_l; u.j = 0;
-            } else { u.state = u.ini; u.j = u.from; }
-            u.fp = -1;
-            return true;
-        }
-    }
     BF_WVD void unit_finish(Unit &u, int cnt)
     {
         S.qc[(uint32_t)u.tok & QMASK] = (uint16_t)(cnt + 1);
         u.tok = -1;
     }
-    BF_WVD void unit_unk(Unit &u)
+    // the frame of a call to the function (ini, ini_l) on the unit's word
+    BF_WVD void unit_call(Unit &u, uint32_t ini, uint32_t ini_l)
     {
-        u.home[0] = p.unk;
-        unit_finish(u, 1);
+        const int maxtok = p.max_token_length;
+        const bool anchored = ini_l != LX_NO_STATE && maxtok > 1;     // else "from = -1" goes straight on to from = 0 (FALexTools_t.h:244-252)
+        const int cap = anchored ? maxtok - 1 : maxtok;
+        u.ini = ini; u.state = anchored ? ini_l : ini; u.anch = anchored ? 1 : 0;
+        u.j = 0; u.lim = cap < u.L ? cap : u.L; u.fp = -1; u.cnt = 0;
     }
-    // starts the unit of token t; false: finished at once (not a word / a word without a vocabulary call)
-    BF_WVD bool unit_begin(Unit &u, uint32_t t)
+    // starts the unit of token t
+    BF_WVD void unit_begin(Unit &u, uint32_t t)
     {
         u.tok = (int)t;
         const uint32_t sl = t & QMASK;
-        const uint32_t w0 = S.q0[sl];
-        const uint32_t info = (w0 & WV_TK_INFO) ? S.qi[sl] : ((w0 & WV_TK_SOLO) ? p.solo_info : p.loop_info);
-        u.rs = w0 & 0xFFFFu; u.L = (int)((w0 >> 16) & WV_TK_LEN_MASK); u.cnt = 0;
-        u.home = p.ids_tmp + S.dt_slot[(uint32_t)S.qd[sl] & DMASK] + (int64_t)S.q1[sl];
+        const uint32_t w1 = S.q1[sl];
+        const uint32_t ke = (w1 >> 16) & DMASK;
+        u.rs = S.q0[sl]; u.L = (int)(w1 & WV_TK_LEN_MASK);
+        u.home = p.ids_tmp + S.dt_slot[ke] + (int64_t)(u.rs - S.dt_rbase[ke]);
         S.qc[sl] = 0;
-        int tag; bool call = false;
+        if (!(w1 & WV_TK_INFO)) { unit_call(u, fn_ini, fn_ini_l); return; }       // a word of the common kind: the vocabulary function
+        // any other action (general form of phase A; lexers whose run / solo actions differ)
+        const uint32_t info = S.qi[sl];
+        int tag; bool call = false; uint32_t ini = 0, ini_l = LX_NO_STATE;
         if (info & LX_INFO_SIMPLE) tag = (int)(info & 0x7FFFFFFFu);
-        else { const int32_t *a = acts + info; tag = a[2]; u.ini = (uint32_t)a[5]; u.ini_l = (uint32_t)a[6]; call = true; }
-        if (tag != WBD_WORD_TAG) { unit_finish(u, 0); return false; }          // tags 2..4: neither a word nor a sub-token
-        if (!call) { unit_unk(u); return false; }                              // a word without sub-tokens (tokdll:1282-1301)
-        u.from = -1;
-        if (!unit_setup(u)) { unit_unk(u); return false; }
-        return true;
+        else { const int32_t *a = acts + info; tag = a[2]; ini = (uint32_t)a[5]; ini_l = (uint32_t)a[6]; call = true; }
+        if (tag != WBD_WORD_TAG) { unit_finish(u, 0); return; }                    // tags 2..4: neither a word nor a sub-token
+        if (!call) { u.home[0] = p.unk; unit_finish(u, 1); return; }               // a word without sub-tokens (tokdll:1282-1301)
+        unit_call(u, ini, ini_l);
     }
     BF_WVD void unit_issue(Unit &u) const
     {
         u.c = (uint32_t)S.ring[(u.rs + (uint32_t)u.j) & RMASK] & LX_T_CLS_MASK;
         u.e64 = p.T[u.state + u.c];
     }
-    // consumes the transition in flight (FALexTools_t.h:255-277); when the walk ends, its result and the next walk's start
+    // consumes the transition in flight (FALexTools_t.h:255-277); when the walk ends, its result and the next walk's start:
+    // a match is a piece and the next walk starts behind it (:390-393); the anchored walk without a match is followed by the
+    // plain walk at 0 (:293); any other walk without a match leaves a gap, the pieces cannot tile the word: UNK (tokdll:1252-1301)
     BF_WVD void unit_complete(Unit &u)
     {
         const uint32_t e = (uint32_t)u.e64;
         const bool hit = (e & LX_T_CLS_MASK) == u.c;
-        if (hit && (int32_t)e < 0) { u.fp = u.j; u.ftag = (uint32_t)(u.e64 >> 32); }
-        if (hit) { u.state = (e >> LX_T_NEXT_SHIFT) & LX_T_NEXT_MASK; ++u.j; }
+        const bool fin = hit && (int32_t)e < 0;
+        u.fp = fin ? u.j : u.fp; u.ftag = fin ? (uint32_t)(u.e64 >> 32) : u.ftag;
+        u.state = hit ? ((e >> LX_T_NEXT_SHIFT) & LX_T_NEXT_MASK) : u.state;
+        u.j += hit ? 1 : 0;
         if (hit && u.j < u.lim) return;
-        // ---- the walk is over
-        if (u.fp < 0) {
-            if (u.from >= 0) { unit_unk(u); return; }                                    // a gap: the word is UNK whatever follows
-            u.from = 0;                                                                  // the anchored walk found nothing (FALexTools_t.h:293)
-        } else {
-            u.home[u.cnt] = (int32_t)(u.ftag & 0x7FFFFFFFu);
-            ++u.cnt;
-            u.from = u.fp + 1;
-        }
-        if (!unit_setup(u)) unit_finish(u, u.cnt);                                       // from == L: the pieces tile the word
-    }
-    // hands queued tokens to the lanes whose unit is idle
-    BF_WVD void unit_refill(Unit &u)
-    {
-        const uint32_t avail = q_tail - q_issue;
-        if (avail == 0) return;
-        const unsigned long long m = wv::ballot(u.tok < 0);
-        if (m == 0) return;
-        const uint32_t r = (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1ull));
-        if (u.tok < 0 && r < avail) unit_begin(u, q_issue + r);
-        const uint32_t k = (uint32_t)__builtin_popcountll(m);
-        q_issue += k < avail ? k : avail;
+        const bool matched = u.fp >= 0, gap = !matched && !u.anch;
+        if (matched) u.home[u.cnt] = (int32_t)(u.ftag & 0x7FFFFFFFu);
+        u.cnt += matched ? 1 : 0;
+        const int nf = matched ? u.fp + 1 : 0;
+        if (gap) u.home[0] = p.unk;
+        if (gap || nf >= u.L) { unit_finish(u, gap ? 1 : u.cnt); return; }
+        const int b = nf + p.max_token_length;
+        u.state = u.ini; u.j = nf; u.lim = b < u.L ? b : u.L; u.fp = -1; u.anch = 0;
     }
     // Runs the units until the queue is handed out and fewer than UNIT_MIN of them are still walking (`drain`: until all are
-    // done).  Returns whether a transition was made.
+    // done).  Every trip: idle units take the next queued tokens (rank among the idle lanes = order in the queue), then every
+    // busy unit makes one transition.  Returns whether a transition was made.
     BF_WVD bool units_phase(Unit (&u)[NU], bool drain)
     {
         bool ran = false;
+        const uint32_t tail = wv::uni(q_tail);
+        uint32_t issue = wv::uni(q_issue);
         for (;;) {
             int nb = 0;
 #pragma unroll
-            for (int i = 0; i < NU; ++i) { unit_refill(u[i]); nb += __builtin_popcountll(wv::ballot(u[i].tok >= 0)); }
+            for (int i = 0; i < NU; ++i) {
+                const uint32_t avail = tail - issue;
+                unsigned long long idle = wv::ballot(u[i].tok < 0);
+                if (avail != 0 && idle != 0) {
+                    const uint32_t r = wv::mbcnt(idle);
+                    const bool take = u[i].tok < 0 && r < avail;
+                    if (take) unit_begin(u[i], issue + r);
+                    const uint32_t k = (uint32_t)__builtin_popcountll(idle);
+                    issue += k < avail ? k : avail;
+                    idle = wv::ballot(u[i].tok < 0);
+                }
+                nb += 64 - __builtin_popcountll(idle);
+            }
             if (nb == 0) break;
-            if (!drain && q_issue == q_tail && nb < UNIT_MIN) break;
+            if (!drain && issue == tail && nb < UNIT_MIN) break;
             if (STATS) { ++st_trips; st_steps += (unsigned long long)nb; }
 #pragma unroll
             for (int i = 0; i < NU; ++i) if (u[i].tok >= 0) unit_issue(u[i]);
@@ -440,10 +518,12 @@ struct WpWave {
             for (int i = 0; i < NU; ++i) if (u[i].tok >= 0) unit_complete(u[i]);
             ran = true;
         }
+        q_issue = issue;
         wv::sync();
         return ran;
     }
     static constexpr int UNIT_MIN = 12 * NU;
+    static constexpr int CHUNK_ROOM = QCAP >= 512 ? 256 : (QCAP * 15) / 32;
 
     // ------------------------------------------------------------------------------------------------------------------
     // retire (phase C): the finished tokens at the head of the queue, in order.  Position of a unit's ids = ids its document has
@@ -465,10 +545,10 @@ struct WpWave {
         if (STATS) ++st_ret;
         const bool act = lane < nret;
         const int cnt = act ? cnt0 : 0;
-        const int k = act ? (int)S.qd[sl] : -1;
+        const int k = act ? (int)((S.q1[sl] >> 16) & 0xFFu) : -1;
         const uint32_t ke = (uint32_t)k & DMASK;
         int64_t slot = 0; int cap = 0, dcnt = 0; uint32_t f = 0;
-        if (act) { slot = S.dt_slot[ke]; cap = S.dt_cap[ke]; dcnt = S.dt_cnt[ke]; f = S.q1[sl]; }
+        if (act) { slot = S.dt_slot[ke]; cap = S.dt_cap[ke]; dcnt = S.dt_cnt[ke]; f = S.q0[sl] - S.dt_rbase[ke]; }
         const int32_t *src = p.ids_tmp + slot + (int64_t)f;
         int32_t v0 = 0, v1 = 0, v2 = 0, v3 = 0;
         if (cnt > 0) v0 = src[0];
@@ -516,7 +596,7 @@ struct WpWave {
     {
         bool moved = false;
         uint32_t limit;
-        if (q_retire != q_tail) limit = dt_head + (((uint32_t)S.qd[q_retire & QMASK] - dt_head) & 0xFFu);
+        if (q_retire != q_tail) limit = dt_head + ((((S.q1[q_retire & QMASK] >> 16) & 0xFFu) - dt_head) & 0xFFu);
         else limit = have_doc ? curk : dt_tail;
         if (limit != dt_head) {
             const uint32_t kk = dt_head + (uint32_t)lane;
@@ -528,7 +608,7 @@ struct WpWave {
             dt_head = limit; moved = true;
         }
         const uint32_t old_lo = rlo;
-        if (q_retire != q_tail) rlo = rhi - ((rhi - (S.q0[q_retire & QMASK] & 0xFFFFu)) & 0xFFFFu);
+        if (q_retire != q_tail) rlo = S.q0[q_retire & QMASK];
         else rlo = have_doc ? rbase + (uint32_t)(open_start >= 0 ? open_start : done) : rhi;
         return moved || rlo != old_lo;
     }
@@ -543,8 +623,8 @@ struct WpWave {
         int cap = p.max_ids; if ((int64_t)cap > n64) cap = n; if (cap < 0) cap = 0;
         curk = dt_tail++;
         const uint32_t ke = curk & DMASK;
-        if (lane == 0) { S.dt_slot[ke] = wv_ids_slot(b, d); S.dt_doc[ke] = d; S.dt_cap[ke] = cap; S.dt_cnt[ke] = 0; S.dt_flags[ke] = 0; }
         rhi = (rhi + 7u) & ~7u; rbase = rhi;
+        if (lane == 0) { S.dt_slot[ke] = wv_ids_slot(b, d); S.dt_doc[ke] = d; S.dt_cap[ke] = cap; S.dt_cnt[ke] = 0; S.dt_flags[ke] = 0; S.dt_rbase[ke] = rbase; }
         dec_bytes = dec = done = bom = 0; open_start = -1; err = false;
         wv::sync();
         return true;
@@ -553,7 +633,7 @@ struct WpWave {
     {
         // a run that was still open when the decoded text ended without another element (possible only behind invalid UTF-8 or a
         // character that straddles the last chunk boundary)
-        if (open_start >= 0) { if (lane == 0) put_token(q_tail, open_start, dec - open_start, 0u); ++q_tail; open_start = -1; }
+        if (open_start >= 0) { if (lane == 0) put_word(q_tail, open_start, dec - open_start, false); ++q_tail; open_start = -1; }
         const bool bad = wv::any(err);
         if (lane == 0) S.dt_flags[curk & DMASK] = WV_DT_CLOSED | (bad ? WV_DT_BAD : 0u);
         wv::sync();
@@ -587,7 +667,11 @@ struct WpWave {
             if (open_start >= 0) { done = open_start; open_start = -1; }     // the general form starts at a certain start position
             if (phase_a_general(fully)) return true;
         }
-        if (dec_bytes < n) { if (ring_free() < WV_CHUNK) return false; decode_chunk(); return true; }
+        if (dec_bytes < n) {
+            // a chunk is taken when the ring has room for it and the queue for the tokens it usually holds (the chunk-wide pass writes them at once)
+            if (ring_free() < WV_CHUNK || (q_tail - q_retire) + (uint32_t)CHUNK_ROOM > (uint32_t)QCAP) return false;
+            decode_chunk(); return true;
+        }
         if (done >= dec) { if (open_start >= 0 && !room_q) return false; close_document(); have_doc = false; return true; }
         return false;
     }

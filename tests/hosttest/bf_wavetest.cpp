@@ -40,7 +40,7 @@ int bft_wave_ok(void *hv) { return ((Handle *)hv)->m.wave_ok ? 1 : 0; }
 const char *bft_wave_why(void *hv) { return ((Handle *)hv)->m.wave_why.c_str(); }
 
 // TextToIdsBatch through the wave kernel on the host.  cfg: 0 = the shipped configuration, 1 = two units per lane, the smallest ring and queue, a two-entry
-// document table, 2 = three units per lane, a large ring and queue.  Returns the total id count, or < 0 (-1: model not in unit form, -5: the kernel raised a status bit).
+// document table, every token with an explicit action, 2 = three units per lane, a large ring and queue.  Returns the total id count, or < 0 (-1: model not in unit form, -5: the kernel raised a status bit).
 // stats (optional, 16 counters): see bf_wave.h WpWaveParams::stats.
 long bft_emu_wave_batch(void *hv, const uint8_t *text, long text_bytes, const int64_t *doc_off, long ndocs, int max_ids, int unk, int nwaves, int grab, int cfg,
                         int32_t *ids_out, long ids_cap, int64_t *id_off, unsigned long long *stats)
@@ -57,7 +57,7 @@ long bft_emu_wave_batch(void *hv, const uint8_t *text, long text_bytes, const in
     p.kind = m.wave_kind.data(); p.nclasses = m.wbd.nclasses;
     p.initial = m.wbd.initial_base; p.loop_info = m.loop_info; p.solo_info = m.wave_solo_info; p.acts_n = (int)m.acts_pool.size(); p.max_token_length = m.max_token_length;
     p.b = Batch{text, doc_off, ndocs, total, &status};
-    p.ids_tmp = tmp.data(); p.counts = counts.data(); p.max_ids = max_ids; p.unk = unk; p.next_doc = &next_doc; p.stats = stats;
+    p.ids_tmp = tmp.data(); p.counts = counts.data(); p.max_ids = max_ids; p.unk = unk; p.next_doc = &next_doc; p.stats = stats; p.no_fast = cfg == 1 ? 1 : 0;
     if (ndocs > 0) {
         if (cfg == 1) run_cfg<WvLds<1024, 128, 2>, 2>(p, nwaves, grab);
         else if (cfg == 2) run_cfg<WvLds<4096, 512, 64>, 3>(p, nwaves, grab);

@@ -170,6 +170,14 @@ __attribute__((noinline)) static int incl_scan(int v WV_SITE_ARG)
     int64_t a = 0; for (int i = 0; i <= me; ++i) a += (int64_t)s[i];
     return (int)a;
 }
+// a value every lane holds alike (the device moves it to a scalar register): checked
+template <class T> __attribute__((noinline)) static T uni(T v WV_SITE_ARG)
+{
+    const uint64_t *s = wvemu::collective(to_u64(v), WV_SITE);
+    for (int i = 1; i < 64; ++i) if (s[i] != s[0]) { fprintf(stderr, "wave_emu: uni() of a value that differs between lanes (line %ld)\n", site); abort(); }
+    return v;
+}
+static inline uint32_t mbcnt(unsigned long long m) { return (uint32_t)__builtin_popcountll(m & ((1ull << wvemu::g_cur->lane) - 1ull)); }
 static inline unsigned long long atomic_add(unsigned long long *p, unsigned long long v) { unsigned long long o = *p; *p = o + v; return o; }
 static inline void atomic_or(int *p, int v) { *p |= v; }
 static inline unsigned long long clock() { return 0; }
