@@ -691,7 +691,7 @@ __device__ __forceinline__ uint32_t mbcnt(unsigned long long m) { return __built
 #include "bf_wave_body.h"
 namespace bfa {
 
-template <class LDS, int NU, int WAVES, bool STATS>
+template <class LDS, int NU, int WAVES, bool STATS, int DBG = 0>
 __global__ __launch_bounds__(64 * WAVES) void k_wp_wave(WpWaveParams p, int grab)
 {
     __shared__ LDS lds[WAVES];
@@ -700,7 +700,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_wp_wave(WpWaveParams p, int grab
     wv_init_ascii(p, ascii, (int)threadIdx.x, 64 * WAVES);
     for (int i = (int)threadIdx.x; i < p.acts_n; i += 64 * WAVES) acts[i] = p.acts[i];
     __syncthreads();
-    WpWave<LDS, NU, STATS> w(p, lds[threadIdx.x >> 6], ascii, acts);
+    WpWave<LDS, NU, STATS, DBG> w(p, lds[threadIdx.x >> 6], ascii, acts);
     w.run(grab);
 }
 
@@ -726,6 +726,12 @@ void launch_wp_wave(const WpWaveParams &p, int variant, hipStream_t s)
     const int cfg = (variant >> 8) & 0xf;
     int grab = (variant >> 12) & 0xf; if (grab == 0) grab = 8;
     const int per_cu = (variant >> 24) & 0x3f;
+    if (cfg == 14 || cfg == 15) {       // experiments: phase costs by difference (results are wrong by design)
+        typedef WvLds<2048, 256, 32> L; const int64_t nb = (int64_t)device_cus() * 4;
+        if (cfg == 14) hipLaunchKernelGGL((k_wp_wave<L, 1, 4, false, 1>), dim3((unsigned)nb), dim3(256), 0, s, p, grab);
+        else hipLaunchKernelGGL((k_wp_wave<L, 1, 4, false, 2>), dim3((unsigned)nb), dim3(256), 0, s, p, grab);
+        return;
+    }
     if (cfg == 1) launch_wp_wave_cfg<WvLds<2048, 256, 32>, 2, 4>(p, grab, per_cu, s);
     else if (cfg == 2) launch_wp_wave_cfg<WvLds<1024, 128, 32>, 1, 4>(p, grab, per_cu, s);
     else if (cfg == 3) launch_wp_wave_cfg<WvLds<4096, 512, 64>, 2, 4>(p, grab, per_cu, s);

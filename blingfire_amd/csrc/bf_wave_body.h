@@ -32,7 +32,9 @@ struct WvLds {
     uint16_t qc[QCAP];
 };
 
-template <class LDS, int NU = 2, bool STATS = false>
+// DBG (experiments, wrong results by design): 1 = units finish at once without walking, 2 = also nothing is moved at retire:
+// instruction counts of the phases by difference (profiles/r03_phase_costs.txt)
+template <class LDS, int NU = 2, bool STATS = false, int DBG = 0, int STEPS = 3>
 struct WpWave {
     static constexpr int RING = LDS::RING, QCAP = LDS::QCAP, DTN = LDS::DTN;
     static constexpr uint32_t RMASK = RING - 1, QMASK = QCAP - 1, DMASK = DTN - 1;
@@ -420,15 +422,14 @@ struct WpWave {
         int tok;                         // token (absolute queue counter, as int), -1: idle
         uint32_t rs; int L; uint32_t ini;
         int j, lim; uint32_t state; int fp; uint32_t ftag;
-        int cnt, anch;                   // pieces so far; 1 while the anchored walk runs
-        uint32_t c; uint64_t e64;        // the transition in flight: class fed, table entry
+        int cnt, anch, walk;             // pieces so far; 1 while the anchored walk runs; 1 while a walk is under way (0 with tok >= 0: its end waits for unit_event)
         int32_t *home;                   // provisional home of piece 0
     };
 
     BF_WVD void unit_finish(Unit &u, int cnt)
     {
         S.qc[(uint32_t)u.tok & QMASK] = (uint16_t)(cnt + 1);
-        u.tok = -1;
+        u.tok = -1; u.walk = 0;
     }
     // the frame of a call to the function (ini, ini_l) on the unit's word
     BF_WVD void unit_call(Unit &u, uint32_t ini, uint32_t ini_l)
@@ -437,7 +438,7 @@ struct WpWave {
         const bool anchored = ini_l != LX_NO_STATE && maxtok > 1;     // else "from = -1" goes straight on to from = 0 (FALexTools_t.h:244-252)
         const int cap = anchored ? maxtok - 1 : maxtok;
         u.ini = ini; u.state = anchored ? ini_l : ini; u.anch = anchored ? 1 : 0;
-        u.j = 0; u.lim = cap < u.L ? cap : u.L; u.fp = -1; u.cnt = 0;
+        u.j = 0; u.lim = cap < u.L ? cap : u.L; u.fp = -1; u.cnt = 0; u.walk = 1;
     }
     // starts the unit of token t
     BF_WVD void unit_begin(Unit &u, uint32_t t)
@@ -449,6 +450,7 @@ struct WpWave {
         u.rs = S.q0[sl]; u.L = (int)(w1 & WV_TK_LEN_MASK);
         u.home = p.ids_tmp + S.dt_slot[ke] + (int64_t)(u.rs - S.dt_rbase[ke]);
         S.qc[sl] = 0;
+        if (DBG >= 1) { unit_finish(u, 1); return; }
         if (!(w1 & WV_TK_INFO)) { unit_call(u, fn_ini, fn_ini_l); return; }       // a word of the common kind: the vocabulary function
         // any other action (general form of phase A; lexers whose run / solo actions differ)
         const uint32_t info = S.qi[sl];
@@ -459,23 +461,26 @@ struct WpWave {
         if (!call) { u.home[0] = p.unk; unit_finish(u, 1); return; }               // a word without sub-tokens (tokdll:1282-1301)
         unit_call(u, ini, ini_l);
     }
-    BF_WVD void unit_issue(Unit &u) const
+    // One transition (FALexTools_t.h:255-277) for every lane at once, written without a branch: a lane whose unit is not walking
+    // feeds its old state to the table as well and keeps everything it has.  walk = 0 afterwards: the walk is over (a miss, or the
+    // next position is not < lim) and waits for unit_event().
+    BF_WVD void unit_step(Unit &u) const
     {
-        u.c = (uint32_t)S.ring[(u.rs + (uint32_t)u.j) & RMASK] & LX_T_CLS_MASK;
-        u.e64 = p.T[u.state + u.c];
-    }
-    // consumes the transition in flight (FALexTools_t.h:255-277); when the walk ends, its result and the next walk's start:
-    // a match is a piece and the next walk starts behind it (:390-393); the anchored walk without a match is followed by the
-    // plain walk at 0 (:293); any other walk without a match leaves a gap, the pieces cannot tile the word: UNK (tokdll:1252-1301)
-    BF_WVD void unit_complete(Unit &u)
-    {
-        const uint32_t e = (uint32_t)u.e64;
-        const bool hit = (e & LX_T_CLS_MASK) == u.c;
+        const uint32_t c = (uint32_t)S.ring[(u.rs + (uint32_t)u.j) & RMASK] & LX_T_CLS_MASK;
+        const uint64_t e64 = p.T[u.state + c];
+        const uint32_t e = (uint32_t)e64;
+        const bool hit = u.walk != 0 && (e & LX_T_CLS_MASK) == c;
         const bool fin = hit && (int32_t)e < 0;
-        u.fp = fin ? u.j : u.fp; u.ftag = fin ? (uint32_t)(u.e64 >> 32) : u.ftag;
+        u.fp = fin ? u.j : u.fp; u.ftag = fin ? (uint32_t)(e64 >> 32) : u.ftag;
         u.state = hit ? ((e >> LX_T_NEXT_SHIFT) & LX_T_NEXT_MASK) : u.state;
         u.j += hit ? 1 : 0;
-        if (hit && u.j < u.lim) return;
+        u.walk = (hit && u.j < u.lim) ? 1 : 0;
+    }
+    // The end of a walk: a match is a piece and the next walk starts behind it (FALexTools_t.h:390-393); the anchored walk without
+    // a match is followed by the plain walk at 0 (:293); any other walk without a match leaves a gap, the pieces cannot tile the
+    // word: UNK (tokdll:1252-1301)
+    BF_WVD void unit_event(Unit &u)
+    {
         const bool matched = u.fp >= 0, gap = !matched && !u.anch;
         if (matched) u.home[u.cnt] = (int32_t)(u.ftag & 0x7FFFFFFFu);
         u.cnt += matched ? 1 : 0;
@@ -483,11 +488,14 @@ struct WpWave {
         if (gap) u.home[0] = p.unk;
         if (gap || nf >= u.L) { unit_finish(u, gap ? 1 : u.cnt); return; }
         const int b = nf + p.max_token_length;
-        u.state = u.ini; u.j = nf; u.lim = b < u.L ? b : u.L; u.fp = -1; u.anch = 0;
+        u.state = u.ini; u.j = nf; u.lim = b < u.L ? b : u.L; u.fp = -1; u.anch = 0; u.walk = 1;
     }
-    // Runs the units until the queue is handed out and fewer than UNIT_MIN of them are still walking (`drain`: until all are
-    // done).  Every trip: idle units take the next queued tokens (rank among the idle lanes = order in the queue), then every
-    // busy unit makes one transition.  Returns whether a transition was made.
+    // Runs the units until the queue is handed out and fewer than UNIT_MIN of them are still busy (`drain`: until all are done).
+    // A round: the units whose walk is over take its result (piece / next walk / word finished), idle units take the next queued
+    // tokens (rank among the idle lanes = order in the queue), then every walking unit makes STEPS transitions.  The event code
+    // is branchy and runs once per round for all the lanes that need it; the transitions are straight-line code.
+    // (Measured on MI355X, profiles/r03_phase_costs.txt: with the event code inside every transition the loop cost 1,340 issued
+    // instructions per 512-byte document, a third of them for the transitions themselves.)  Returns whether a transition was made.
     BF_WVD bool units_phase(Unit (&u)[NU], bool drain)
     {
         bool ran = false;
@@ -497,6 +505,7 @@ struct WpWave {
             int nb = 0;
 #pragma unroll
             for (int i = 0; i < NU; ++i) {
+                if (u[i].tok >= 0 && !u[i].walk) unit_event(u[i]);
                 const uint32_t avail = tail - issue;
                 unsigned long long idle = wv::ballot(u[i].tok < 0);
                 if (avail != 0 && idle != 0) {
@@ -513,9 +522,10 @@ struct WpWave {
             if (!drain && issue == tail && nb < UNIT_MIN) break;
             if (STATS) { ++st_trips; st_steps += (unsigned long long)nb; }
 #pragma unroll
-            for (int i = 0; i < NU; ++i) if (u[i].tok >= 0) unit_issue(u[i]);
+            for (int st = 0; st < STEPS; ++st) {
 #pragma unroll
-            for (int i = 0; i < NU; ++i) if (u[i].tok >= 0) unit_complete(u[i]);
+                for (int i = 0; i < NU; ++i) unit_step(u[i]);
+            }
             ran = true;
         }
         q_issue = issue;
@@ -542,6 +552,7 @@ struct WpWave {
         const unsigned long long fin = wv::ballot(cnt0 >= 0);
         const int nret = fin == ~0ull ? 64 : __builtin_ctzll(~fin);                  // the finished prefix
         if (nret == 0 || (!all && nret < 64)) return 0;
+        if (DBG >= 2) { q_retire += (uint32_t)nret; return nret; }
         if (STATS) ++st_ret;
         const bool act = lane < nret;
         const int cnt = act ? cnt0 : 0;
@@ -680,7 +691,7 @@ struct WpWave {
     {
         Unit u[NU];
 #pragma unroll
-        for (int i = 0; i < NU; ++i) u[i].tok = -1;
+        for (int i = 0; i < NU; ++i) { u[i].tok = -1; u[i].walk = 0; u[i].rs = 0; u[i].j = 0; u[i].state = 0; u[i].lim = 0; u[i].fp = -1; u[i].ftag = 0; }
         for (;;) {
             bool moved = settle();
             bool filled = false;
