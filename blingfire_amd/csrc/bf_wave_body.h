@@ -95,22 +95,36 @@ struct WpWave {
     // no character and must be covered by a lead 1..3 bytes before it; a lead byte gives length, checks its continuation
     // bytes, truncation (:167-171), overlong / > U+10FFFF (:185-188), surrogates (:190-193).  One leading BOM is skipped.
     // ------------------------------------------------------------------------------------------------------------------
-    // The top level over a whole chunk of plain ASCII at once (what phase_a_fast does for 64 positions, here for 512 with eight
-    // elements per lane): kinds as 2-bit fields of a 16-bit word per lane; a run of WK_LOOP elements that crosses lanes is closed
-    // with one ballot (which lanes hold a run start) and one shuffle (the start position of the nearest one); token numbers from a
-    // prefix sum of the per-lane counts; every lane then writes its own tokens.  Leaves everything untouched (the window forms take
-    // the chunk) when it holds a WK_GENERAL element, a run that max-length cuts, or more tokens than the queue has room for.
-    BF_WVD void chunk_tokens(const uint32_t (&e)[8], int nb, int cb, int total)
+    // ------------------------------------------------------------------------------------------------------------------
+    // phase A, wide form: the next (up to) 512 elements at once, eight per lane, none of them WK_GENERAL .  Kinds as 2-bit fields of a 16-bit word per lane; a run of WK_LOOP elements
+    // that crosses lanes is closed with one ballot (which lanes hold a run start) and one shuffle (the start position of the
+    // nearest one); token numbers from a prefix sum of the per-lane counts; every lane then writes its own tokens.  Returns false
+    // and leaves everything untouched (the window forms take over) when the elements hold a WK_GENERAL one, a run that
+    // max-length cuts, or more tokens than the queue has room for.
+    // ------------------------------------------------------------------------------------------------------------------
+    BF_WVD bool phase_a_wide(bool fully)
     {
+        const int cb = done;
+        const int total = dec - cb < WV_CHUNK ? dec - cb : WV_CHUNK;
+        int nb = total - lane * 8; nb = nb < 0 ? 0 : (nb > 8 ? 8 : nb);
+        const uint32_t r = rbase + (uint32_t)cb + (uint32_t)(lane * 8);
         uint32_t kk = 0;
+        if (((rbase + (uint32_t)cb) & 7u) == 0) {
+            const uint32_t *src = (const uint32_t *)(S.ring + (r & RMASK));          // 8 elements = one 16-byte row, never wraps
+            const uint32_t d0 = src[0], d1 = src[1], d2 = src[2], d3 = src[3];
+            // kinds: bits 15:14 and 31:30 of every dword -> 2-bit fields 2k, 2k+1
+            kk = ((d0 >> 14) & 3u) | ((d0 >> 28) & 0xCu) | (((d1 >> 14) & 3u) << 4) | (((d1 >> 28) & 0xCu) << 4) |
+                 (((d2 >> 14) & 3u) << 8) | (((d2 >> 28) & 0xCu) << 8) | (((d3 >> 14) & 3u) << 12) | (((d3 >> 28) & 0xCu) << 12);
+        } else {
 #pragma unroll
-        for (int k = 0; k < 8; ++k) kk |= (e[k] >> WK_SHIFT) << (2 * k);
+            for (int k = 0; k < 8; ++k) kk |= ((uint32_t)S.ring[(r + (uint32_t)k) & RMASK] >> WK_SHIFT) << (2 * k);
+        }
         const uint32_t vm = nb >= 8 ? 0x5555u : (((1u << (2 * nb)) - 1u) & 0x5555u);
         const uint32_t lo = kk & 0x5555u, hi = (kk >> 1) & 0x5555u;
         const uint32_t loopm = lo & ~hi & vm, solom = lo & hi & vm, genm = ~lo & ~hi & vm;
-        if (wv::any(genm != 0)) return;
+        if (wv::any(genm != 0)) return false;
         const int maxtok = p.max_token_length;
-        const bool at_end = dec_bytes >= n;                            // the document ends with this chunk
+        const bool at_end = fully && cb + total == dec;                // the document ends with these elements
         const bool cont = open_start >= 0;
         uint32_t prev_last = wv::shfl_up((loopm >> 14) & 1u, 1), next_first = wv::shfl_down(loopm & 1u, 1);
         if (lane == 0) prev_last = cont ? 1u : 0u;
@@ -120,7 +134,7 @@ struct WpWave {
         const int last_lane = (total - 1) >> 3; const uint32_t last_bit = 1u << (2 * ((total - 1) & 7));
         const bool stays_open = !at_end && wv::any(lane == last_lane && (en & last_bit) != 0);
         if (stays_open && lane == last_lane) en &= ~last_bit;
-        // the start of the run a lane's first end belongs to, when it lies in an earlier lane (or chunk)
+        // the start of the run a lane's first end belongs to, when it lies in an earlier lane (or before these elements)
         const int hl = h ? cb + lane * 8 + ((31 - __builtin_clz(h)) >> 1) : -1;           // this lane's last run start
         const unsigned long long HB = wv::ballot(h != 0);
         const unsigned long long hb_lt = HB & ((1ull << lane) - 1ull);
@@ -128,13 +142,13 @@ struct WpWave {
         int hprev = wv::shfl(hl, hsrc);
         if (!hb_lt) hprev = open_start;
         const int new_open = stays_open ? (HB ? wv::bcast(hl, 63 - __builtin_clzll(HB)) : open_start) : -1;
-        const bool carry_end = cont && !wv::any(lane == 0 && (loopm & 1u) != 0);           // the open run ended with the chunk before
+        const bool carry_end = cont && !wv::any(lane == 0 && (loopm & 1u) != 0);           // the open run ended just before these elements
         uint32_t tk = en | solom;
         const int c = __builtin_popcount(tk);
         const int inc = wv::incl_scan(c);
         const uint32_t ntok = (uint32_t)wv::bcast(inc, 63) + (carry_end ? 1u : 0u);
-        if ((q_tail - q_retire) + ntok > (uint32_t)QCAP) return;
-        if ((carry_end && cb - open_start > maxtok) || (stays_open && cb + total - new_open >= maxtok)) return;
+        if ((q_tail - q_retire) + ntok > (uint32_t)QCAP) return false;
+        if ((carry_end && cb - open_start > maxtok) || (stays_open && cb + total - new_open >= maxtok)) return false;
         // a finished run longer than max-length: found while writing, nothing is committed then
         uint32_t t = q_tail + (carry_end ? 1u : 0u) + (uint32_t)(inc - c);
         bool toolong = false;
@@ -154,9 +168,10 @@ struct WpWave {
             }
         }
         wv::sync();
-        if (wv::any(toolong)) return;
+        if (wv::any(toolong)) return false;
         if (STATS) ++st_win;
-        q_tail += ntok; done = dec; open_start = new_open;
+        q_tail += ntok; done = cb + total; open_start = new_open;
+        return true;
     }
 
     BF_WVD void prefetch_chunk(int pos)
@@ -183,19 +198,16 @@ struct WpWave {
 #pragma unroll
             for (int k = 0; k < 8; ++k) e[k] = ascii[(uint32_t)(own >> (8 * k)) & 0x7f];
             const uint32_t r = w0 + (uint32_t)(lane * 8);
-            if ((w0 & 7) == 0 && nb == 8) {
-                uint32_t *dst = (uint32_t *)(S.ring + (r & RMASK));  // 8 elements = one 16-byte row, never wraps (RING % 8 == 0)
+            if ((w0 & 7) == 0) {                                     // (wave-uniform) rows of 8 elements: what lies behind the text is never read
+                uint32_t *dst = (uint32_t *)(S.ring + (r & RMASK));  // one 16-byte row, never wraps (RING % 8 == 0)
                 dst[0] = e[0] | (e[1] << 16); dst[1] = e[2] | (e[3] << 16); dst[2] = e[4] | (e[5] << 16); dst[3] = e[6] | (e[7] << 16);
             } else {
 #pragma unroll
                 for (int k = 0; k < 8; ++k) if (k < nb) S.ring[(r + (uint32_t)k) & RMASK] = (uint16_t)e[k];
             }
             const int total = n - pos < WV_CHUNK ? n - pos : WV_CHUNK;
-            const int cb = dec;                                        // position of this chunk's first element
-            const bool caught_up = done == dec;
             dec += total; dec_bytes = pos + WV_CHUNK; rhi = rbase + (uint32_t)dec;
             wv::sync();
-            if (caught_up) chunk_tokens(e, nb, cb, total);
             return;
         }
         uint32_t nxt = wv::shfl_down((uint32_t)own, 1);
@@ -260,60 +272,11 @@ struct WpWave {
     }
 
     // ------------------------------------------------------------------------------------------------------------------
-    // phase A, fast form: the next (up to) 64 elements, none of them WK_GENERAL.  A token is then decided by the masks alone:
-    // a run of WK_LOOP elements is a word (reported by the lane at its END; its head is the nearest run start at or before it, or
-    // `open_start` when the run came in from the window before), a WK_SOLO element is a token, a WK_NOMATCH element is nothing
-    // (FALexTools_t.h:229-293 with the facts of bf_model.cpp "unit form").  A run that touches the end of the window stays open
-    // (`open_start`); nothing is read twice.  Returns false (nothing changed) when the window holds a WK_GENERAL element or a run
-    // that max-length cuts: the general form then takes over at the last certain start position.
-    // ------------------------------------------------------------------------------------------------------------------
-    BF_WVD bool phase_a_fast(bool fully)
-    {
-        const int w0 = done;
-        const int nv = dec - w0 < 64 ? dec - w0 : 64;
-        const int maxtok = p.max_token_length;
-        const int pos = w0 + lane;
-        const uint32_t el = lane < nv ? ring_at(rbase + (uint32_t)pos) : (WK_NOMATCH << WK_SHIFT);
-        const uint32_t kind = el >> WK_SHIFT;
-        if (wv::any(kind == WK_GENERAL)) return false;
-        const unsigned long long M = wv::ballot(kind == WK_LOOP), SO = wv::ballot(kind == WK_SOLO);
-        const bool at_end = fully && w0 + nv == dec;
-        const unsigned long long last = 1ull << (nv - 1);
-        unsigned long long E = M & ~(M >> 1);                                    // run ends
-        const bool stays_open = (E & last) != 0 && !at_end;                     // the run at the end of the window may go on
-        if (stays_open) E &= ~last;
-        unsigned long long H = M & ~(M << 1);                                    // run starts
-        const bool cont = open_start >= 0;
-        if (cont) H &= ~1ull;                                                    // lane 0 continues the open run (or the run ended just before it)
-        const bool carry_end = cont && !(M & 1ull);                              // the open run ended with the previous window
-        const unsigned long long hm = H & ((2ull << lane) - 1ull);
-        const int hpos = hm ? w0 + 63 - __builtin_clzll(hm) : open_start;
-        const bool is_end = (E >> lane) & 1ull;
-        const int wlen = pos - hpos + 1;
-        int new_open = -1;
-        if (stays_open) { const unsigned long long hl = H & (last | (last - 1ull)); new_open = hl ? w0 + 63 - __builtin_clzll(hl) : open_start; }
-        // max-length: a finished run longer than the limit, or an open one that has reached it
-        if (wv::any(is_end && wlen > maxtok) || (carry_end && w0 - open_start > maxtok) || (stays_open && w0 + nv - new_open >= maxtok)) return false;
-        if (STATS) ++st_win;
-        const unsigned long long TK = E | SO;
-        const uint32_t base = q_tail + (carry_end ? 1u : 0u);
-        if (carry_end && lane == 0) put_word(q_tail, open_start, w0 - open_start, false);
-        if ((TK >> lane) & 1ull) {
-            const uint32_t t = base + (uint32_t)__builtin_popcountll(TK & ((1ull << lane) - 1ull));
-            if (is_end) put_word(t, hpos, wlen, false); else put_word(t, pos, 1, true);
-        }
-        q_tail = base + (uint32_t)__builtin_popcountll(TK);
-        open_start = new_open; done = w0 + nv;
-        wv::sync();
-        return true;
-    }
-
-    // ------------------------------------------------------------------------------------------------------------------
     // phase A, general form: one window of up to 64 start positions, the first of which (`done`) is a start position of the
     // reference's loop (FALexTools_t.h:229); every lane finds the token a walk from its position gives (the automaton itself for
     // WK_GENERAL elements), the chain of start positions is followed through the window.  Queues the tokens whose extent is known
     // and moves `done` behind them.  Returns false when the token at `done` itself needs elements that are not decoded yet.
-    // `fully`: the whole document is decoded.  Used for the windows phase_a_fast() declines.
+    // `fully`: the whole document is decoded.  Used for what phase_a_wide() declines.
     // ------------------------------------------------------------------------------------------------------------------
     BF_WVD bool phase_a_general(bool fully)
     {
@@ -673,8 +636,8 @@ struct WpWave {
         const bool fully = dec_bytes >= n;
         const bool room_q = (q_tail - q_retire) + 66u <= (uint32_t)QCAP;
         if (done < dec) {
+            if (phase_a_wide(fully)) return true;
             if (!room_q) return false;
-            if (phase_a_fast(fully)) return true;
             if (open_start >= 0) { done = open_start; open_start = -1; }     // the general form starts at a certain start position
             if (phase_a_general(fully)) return true;
         }
