@@ -327,13 +327,14 @@ int run_device(Handle *h, const char *d_text, const int64_t *d_doc_off, int64_t 
     if (use_wave(h, want_off, words)) {
         (void)hipEventRecord(h->ev[EV_PREP], s);                       // decoding is part of the wave program
         WpWaveParams wp;
-        wp.T = h->t_wbd.as<uint64_t>(); wp.acts = h->t_acts.as<int32_t>();
-        wp.cpmap = DevCpMap{h->t_cp_l1.as<uint16_t>(), h->t_cp_pages.as<uint32_t>()};
-        wp.kind = h->t_kind.as<uint8_t>(); wp.nclasses = m.wbd.nclasses;
-        wp.initial = m.wbd.initial_base; wp.loop_info = m.loop_info; wp.solo_info = m.wave_solo_info; wp.acts_n = (int)m.acts_pool.size(); wp.max_token_length = m.max_token_length;
-        wp.b = b; wp.ids_tmp = h->w_tmp.as<int32_t>(); wp.counts = h->w_counts.as<int32_t>(); wp.max_ids = max_ids; wp.unk = unk;
-        wp.next_doc = next_doc; wp.no_fast = 0;
-        wp.stats = h->lex_stats ? (unsigned long long *)(h->w_misc.as<char>() + 64) : nullptr;
+        wp.T = h->t_wbd.as<uint64_t>(); wp.acts = h->t_acts.as<int32_t>(); wp.acts_n = (int)m.acts_pool.size();
+        wp.initial = m.wbd.initial_base; wp.loop_info = m.loop_info; wp.solo_info = m.wave_solo_info; wp.max_token_length = m.max_token_length;
+        wp.text = b.text; wp.doc_off = b.doc_off; wp.ndocs = b.ndocs; wp.total_bytes = b.total_bytes;
+        wp.ids_tmp = h->w_tmp.as<int32_t>(); wp.counts = h->w_counts.as<int32_t>(); wp.max_ids = max_ids; wp.unk = unk;
+        wp.next_doc = next_doc;
+        wp.cold.cpmap = DevCpMap{h->t_cp_l1.as<uint16_t>(), h->t_cp_pages.as<uint32_t>()};
+        wp.cold.kind = h->t_kind.as<uint8_t>(); wp.cold.nclasses = m.wbd.nclasses; wp.cold.status = status; wp.cold.no_fast = 0;
+        wp.cold.stats = h->lex_stats ? (unsigned long long *)(h->w_misc.as<char>() + 64) : nullptr;
         if (ndocs > 0) launch_wp_wave(wp, h->variant, s);
         (void)hipEventRecord(h->ev[EV_TOK], s);
     } else if (m.kind == KIND_WP) {

@@ -680,7 +680,17 @@ __device__ __forceinline__ unsigned long long bcast(unsigned long long v, int sr
 __device__ __forceinline__ int64_t bcast(int64_t v, int src) { return (int64_t)bcast((unsigned long long)v, src); }
 template <class T> __device__ __forceinline__ T shfl_up(T v, int delta) { return __shfl_up(v, (unsigned)delta, 64); }
 template <class T> __device__ __forceinline__ T shfl_down(T v, int delta) { return __shfl_down(v, (unsigned)delta, 64); }
-__device__ __forceinline__ int incl_scan(int v) { return bfa::wave_incl_scan(v); }
+// inclusive prefix sum over the wave in six data-parallel-primitive adds (row shifts inside the rows of 16 lanes, then the two row broadcasts)
+__device__ __forceinline__ int incl_scan(int v)
+{
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);      // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);      // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);      // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);      // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);      // row_bcast:15 -> rows 1, 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);      // row_bcast:31 -> rows 2, 3
+    return v;
+}
 __device__ __forceinline__ unsigned long long atomic_add(unsigned long long *p, unsigned long long v) { return atomicAdd(p, v); }
 __device__ __forceinline__ void atomic_or(int *p, int v) { atomicOr(p, v); }
 __device__ __forceinline__ unsigned long long clock() { return __builtin_readcyclecounter(); }
@@ -691,52 +701,67 @@ __device__ __forceinline__ uint32_t mbcnt(unsigned long long m) { return __built
 #include "bf_wave_body.h"
 namespace bfa {
 
-template <class LDS, int NU, int WAVES, bool STATS, int DBG = 0>
-__global__ __launch_bounds__(64 * WAVES) void k_wp_wave(WpWaveParams p, int grab)
+// WPE: waves per SIMD the register allocation is asked to allow (a workgroup is four waves, one per SIMD: WPE workgroups per CU)
+template <class LDS, int NU, int STEPS, int WPE, bool STATS, int DBG = 0, int UMIN = 12, int CROOM = 0>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_wp_wave(WpWaveParams p, int grab)
 {
-    __shared__ LDS lds[WAVES];
+    __shared__ LDS lds[4];
     __shared__ uint16_t ascii[128];
     __shared__ int32_t acts[WV_ACTS_MAX];
-    wv_init_ascii(p, ascii, (int)threadIdx.x, 64 * WAVES);
-    for (int i = (int)threadIdx.x; i < p.acts_n; i += 64 * WAVES) acts[i] = p.acts[i];
+    __shared__ WpWaveCold cold;
+    if (threadIdx.x == 0) cold = p.cold;
+    wv_init_ascii(p.cold, ascii, (int)threadIdx.x, 256);
+    for (int i = (int)threadIdx.x; i < p.acts_n; i += 256) acts[i] = p.acts[i];
     __syncthreads();
-    WpWave<LDS, NU, STATS, DBG> w(p, lds[threadIdx.x >> 6], ascii, acts);
+    WpWave<LDS, NU, STATS, DBG, STEPS, UMIN, CROOM> w(p, cold, lds[threadIdx.x >> 6], ascii, acts);
     w.run(grab);
 }
 
-template <class LDS, int NU, int WAVES>
+template <class LDS, int NU, int STEPS, int WPE>
 static void launch_wp_wave_cfg(const WpWaveParams &p, int grab, int per_cu_override, hipStream_t s)
 {
     int per_cu = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_wp_wave<LDS, NU, WAVES, false>, 64 * WAVES, 0) != hipSuccess || per_cu <= 0) per_cu = 2;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_wp_wave<LDS, NU, STEPS, WPE, false>, 256, 0) != hipSuccess || per_cu <= 0) per_cu = 2;
     (void)hipGetLastError();
     if (per_cu_override > 0) per_cu = per_cu_override;
     int64_t blocks = (int64_t)device_cus() * per_cu;
-    const int64_t need = (p.b.ndocs + (int64_t)grab * WAVES - 1) / ((int64_t)grab * WAVES);
+    const int64_t need = (p.ndocs + (int64_t)grab * 4 - 1) / ((int64_t)grab * 4);
     if (blocks > need) blocks = need;
     if (blocks < 1) blocks = 1;
-    if (p.stats) hipLaunchKernelGGL((k_wp_wave<LDS, NU, WAVES, true>), dim3((unsigned)blocks), dim3(64 * WAVES), 0, s, p, grab);
-    else hipLaunchKernelGGL((k_wp_wave<LDS, NU, WAVES, false>), dim3((unsigned)blocks), dim3(64 * WAVES), 0, s, p, grab);
+    if (p.cold.stats) hipLaunchKernelGGL((k_wp_wave<LDS, NU, STEPS, WPE, true>), dim3((unsigned)blocks), dim3(256), 0, s, p, grab);
+    else hipLaunchKernelGGL((k_wp_wave<LDS, NU, STEPS, WPE, false>), dim3((unsigned)blocks), dim3(256), 0, s, p, grab);
 }
 
-// variant (experiments): bits 8..11 = configuration (units per lane, queue / ring sizes), bits 12..15 = documents per grab (0 = 8),
-// bits 24..29 = workgroups per CU
+// variant (experiments): bits 8..11 = configuration, bits 12..15 = documents per grab (0 = 8), bits 24..29 = workgroups per CU
 void launch_wp_wave(const WpWaveParams &p, int variant, hipStream_t s)
 {
     const int cfg = (variant >> 8) & 0xf;
     int grab = (variant >> 12) & 0xf; if (grab == 0) grab = 8;
     const int per_cu = (variant >> 24) & 0x3f;
+    typedef WvLds<2048, 256, 32> L;
     if (cfg == 14 || cfg == 15) {       // experiments: phase costs by difference (results are wrong by design)
-        typedef WvLds<2048, 256, 32> L; const int64_t nb = (int64_t)device_cus() * 4;
-        if (cfg == 14) hipLaunchKernelGGL((k_wp_wave<L, 1, 4, false, 1>), dim3((unsigned)nb), dim3(256), 0, s, p, grab);
-        else hipLaunchKernelGGL((k_wp_wave<L, 1, 4, false, 2>), dim3((unsigned)nb), dim3(256), 0, s, p, grab);
+        const int64_t nb = (int64_t)device_cus() * 4;
+        if (cfg == 14) hipLaunchKernelGGL((k_wp_wave<L, 1, 3, 4, false, 1>), dim3((unsigned)nb), dim3(256), 0, s, p, grab);
+        else hipLaunchKernelGGL((k_wp_wave<L, 1, 3, 4, false, 2>), dim3((unsigned)nb), dim3(256), 0, s, p, grab);
         return;
     }
-    if (cfg == 1) launch_wp_wave_cfg<WvLds<2048, 256, 32>, 2, 4>(p, grab, per_cu, s);
-    else if (cfg == 2) launch_wp_wave_cfg<WvLds<1024, 128, 32>, 1, 4>(p, grab, per_cu, s);
-    else if (cfg == 3) launch_wp_wave_cfg<WvLds<4096, 512, 64>, 2, 4>(p, grab, per_cu, s);
-    else if (cfg == 4) launch_wp_wave_cfg<WvLds<4096, 512, 64>, 1, 4>(p, grab, per_cu, s);
-    else launch_wp_wave_cfg<WvLds<2048, 256, 32>, 1, 4>(p, grab, per_cu, s);
+    if (cfg >= 6 && cfg <= 11) {        // experiments: straggler threshold / queue room kept for a chunk
+        const int64_t nb = (int64_t)device_cus() * 4;
+        const dim3 g((unsigned)nb), t(256);
+        if (cfg == 6) hipLaunchKernelGGL((k_wp_wave<L, 1, 3, 4, false, 0, 24, 0>), g, t, 0, s, p, grab);
+        else if (cfg == 7) hipLaunchKernelGGL((k_wp_wave<L, 1, 3, 4, false, 0, 6, 0>), g, t, 0, s, p, grab);
+        else if (cfg == 8) hipLaunchKernelGGL((k_wp_wave<L, 1, 3, 4, false, 0, 12, 96>), g, t, 0, s, p, grab);
+        else if (cfg == 9) hipLaunchKernelGGL((k_wp_wave<L, 1, 3, 4, false, 0, 12, 150>), g, t, 0, s, p, grab);
+        else if (cfg == 10) hipLaunchKernelGGL((k_wp_wave<L, 1, 3, 4, false, 0, 32, 96>), g, t, 0, s, p, grab);
+        else hipLaunchKernelGGL((k_wp_wave<WvLds<2048, 256, 16>, 1, 3, 4, false, 0, 12, 0>), g, t, 0, s, p, grab);
+        return;
+    }
+    if (cfg == 1) launch_wp_wave_cfg<L, 2, 3, 4>(p, grab, per_cu, s);
+    else if (cfg == 2) launch_wp_wave_cfg<L, 1, 4, 4>(p, grab, per_cu, s);
+    else if (cfg == 3) launch_wp_wave_cfg<L, 1, 2, 4>(p, grab, per_cu, s);
+    else if (cfg == 4) launch_wp_wave_cfg<L, 1, 3, 5>(p, grab, per_cu, s);
+    else if (cfg == 5) launch_wp_wave_cfg<L, 2, 2, 4>(p, grab, per_cu, s);
+    else launch_wp_wave_cfg<L, 1, 3, 4>(p, grab, per_cu, s);
 }
 
 // ------------------------------------------------------------------------------------------

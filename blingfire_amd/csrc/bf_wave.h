@@ -53,23 +53,28 @@ constexpr int WV_CHUNK = 512;        // bytes decoded per step (8 per lane)
 constexpr int WV_ACTS_MAX = 512;     // ints of action records a unit-form lexer may have (bf_model.cpp)
 constexpr uint32_t WV_DT_CLOSED = 1, WV_DT_BAD = 2;
 
-struct WpWaveParams {
-    const uint64_t *T;               // lexer table, bf_layout.h entries (high word: action info of a final destination)
-    const int32_t *acts;             // action records [left, right, tag, nfn, (fn, ini, ini_l)*]
+// what the rare paths need (non-ASCII characters, status reports, experiments): the kernel keeps a copy in LDS instead of scalar registers
+struct WpWaveCold {
     DevCpMap cpmap;                  // fused code point -> charmap -> class map
     const uint8_t *kind;             // [nclasses] WK_* per class
     int nclasses;
+    int *status;                     // batch status word (Batch::status)
+    unsigned long long *stats;       // optional (experiments): [0] unit rounds [1] wide passes [2] general windows [3] tokens [4] busy units summed over the rounds
+                                     // [5] retire rounds [6] words of more than four pieces [7] trips without progress [8] decode steps
+    int no_fast;                     // tests: every token carries its action explicitly (the path of lexers whose run / solo actions differ)
+};
+
+struct WpWaveParams {
+    const uint64_t *T;               // lexer table, bf_layout.h entries (high word: action info of a final destination)
     uint32_t initial, loop_info, solo_info;
-    int acts_n;                      // ints in acts (<= WV_ACTS_MAX: staged in LDS)
     int max_token_length;
-    Batch b;
+    const uint8_t *text; const int64_t *doc_off; int64_t ndocs, total_bytes;       // the batch (bf_batch.h Batch)
     int32_t *ids_tmp;                // staging: document d writes ids_tmp[ids_slot(doc_off[d], d) ..)
     int32_t *counts;                 // [ndocs]
     int max_ids, unk;
     unsigned long long *next_doc;    // work counter
-    int no_fast;                     // tests: every token carries its action explicitly (the path of lexers whose run / solo actions differ)
-    unsigned long long *stats;       // optional (experiments): [0] trips [1] fast windows [2] general windows [3] tokens [4] unit-steps issued [5] retire rounds
-                                     // [6] rewalks [7] trips without a produce action [8] decode steps
+    const int32_t *acts; int acts_n; // action records [left, right, tag, nfn, (fn, ini, ini_l)*] (<= WV_ACTS_MAX ints: staged in LDS)
+    WpWaveCold cold;
 };
 
 BF_WV int64_t wv_ids_slot(int64_t doc_off_d, int64_t d) { return ((doc_off_d + 7) & ~(int64_t)7) + 8 * d; }
@@ -77,7 +82,7 @@ BF_WV int64_t wv_ids_slot(int64_t doc_off_d, int64_t d) { return ((doc_off_d + 7
 BF_WV uint32_t wv_cpmap_get(const DevCpMap &m, int cp) { return m.pages[(uint32_t)m.l1[cp >> 8] * 256u + (uint32_t)(cp & 255)]; }
 
 // ring element of a code point: class | kind << 14
-BF_WV uint32_t wv_element(const WpWaveParams &p, int cp)
+BF_WV uint32_t wv_element(const WpWaveCold &p, int cp)
 {
     const uint32_t c = wv_cpmap_get(p.cpmap, cp) & LX_T_CLS_MASK;
     const uint32_t k = c < (uint32_t)p.nclasses ? (uint32_t)p.kind[c] : WK_NOMATCH;      // LX_CLS_NONE: not in the alphabet
@@ -85,7 +90,7 @@ BF_WV uint32_t wv_element(const WpWaveParams &p, int cp)
 }
 
 // per-workgroup table of the 128 ASCII code points (LDS)
-BF_WV void wv_init_ascii(const WpWaveParams &p, uint16_t *ascii, int tid, int nthreads)
+BF_WV void wv_init_ascii(const WpWaveCold &p, uint16_t *ascii, int tid, int nthreads)
 {
     for (int i = tid; i < 128; i += nthreads) ascii[i] = (uint16_t)wv_element(p, i);
 }

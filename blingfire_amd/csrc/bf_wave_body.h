@@ -34,14 +34,14 @@ struct WvLds {
 
 // DBG (experiments, wrong results by design): 1 = units finish at once without walking, 2 = also nothing is moved at retire:
 // instruction counts of the phases by difference (profiles/r03_phase_costs.txt)
-template <class LDS, int NU = 2, bool STATS = false, int DBG = 0, int STEPS = 3>
+template <class LDS, int NU = 2, bool STATS = false, int DBG = 0, int STEPS = 3, int UMIN = 12, int CROOM = 0>
 struct WpWave {
     static constexpr int RING = LDS::RING, QCAP = LDS::QCAP, DTN = LDS::DTN;
     static constexpr uint32_t RMASK = RING - 1, QMASK = QCAP - 1, DMASK = DTN - 1;
     static_assert((RING & (RING - 1)) == 0 && RING >= 1024 && RING <= 32768, "ring size");
     static_assert((QCAP & (QCAP - 1)) == 0 && QCAP >= 128 && (DTN & (DTN - 1)) == 0 && DTN <= 64, "queue / document table size");
 
-    const WpWaveParams &p; LDS &S; const uint16_t *ascii; const int32_t *acts;      // ascii, acts: per-workgroup LDS tables
+    const WpWaveParams &p; const WpWaveCold &cold; LDS &S; const uint16_t *ascii; const int32_t *acts;      // cold, ascii, acts: per-workgroup LDS copies / tables
     int lane;
     // ---- wave-uniform state
     uint32_t rhi, rlo;               // absolute ring positions: next element to write / oldest element still needed
@@ -57,7 +57,7 @@ struct WpWave {
     uint64_t pf_own;                 // per lane: its 8 bytes of the next chunk
     unsigned long long st_trips, st_win, st_slow, st_tok, st_steps, st_ret, st_rewalk, st_idle, st_dec;
 
-    BF_WVD WpWave(const WpWaveParams &p_, LDS &S_, const uint16_t *ascii_, const int32_t *acts_) : p(p_), S(S_), ascii(ascii_), acts(acts_)
+    BF_WVD WpWave(const WpWaveParams &p_, const WpWaveCold &cold_, LDS &S_, const uint16_t *ascii_, const int32_t *acts_) : p(p_), cold(cold_), S(S_), ascii(ascii_), acts(acts_)
     {
         lane = wv::lane(); rhi = rlo = 0; q_tail = q_issue = q_retire = 0; dt_head = dt_tail = 0;
         dnext = dend = dbase = off_lane = 0; have_doc = exiting = false;
@@ -65,7 +65,7 @@ struct WpWave {
         st_trips = st_win = st_slow = st_tok = st_steps = st_ret = st_rewalk = st_idle = st_dec = 0;
         // the action of a run token and of a solo token (bf_model.cpp): the usual case is one calling WORD action for both
         fast_ok = false; fn_ini = 0; fn_ini_l = LX_NO_STATE;
-        if (!p.no_fast && !(p.loop_info & LX_INFO_SIMPLE) && !(p.solo_info & LX_INFO_SIMPLE)) {
+        if (!cold.no_fast && !(p.loop_info & LX_INFO_SIMPLE) && !(p.solo_info & LX_INFO_SIMPLE)) {
             const int32_t *a = acts + p.loop_info, *c = acts + p.solo_info;
             if (a[2] == WBD_WORD_TAG && c[2] == WBD_WORD_TAG && a[5] == c[5] && a[6] == c[6]) { fast_ok = true; fn_ini = (uint32_t)a[5]; fn_ini_l = (uint32_t)a[6]; }
         }
@@ -256,7 +256,7 @@ struct WpWave {
                     if (need != len) e = true;                                                 // overlong / > U+10FFFF (:185-188)
                     if ((cp & 0xFFFFF800) == 0xD800) e = true;                                 // surrogate (:190-193)
                     e_any |= e;
-                    if (!e) { vv = wv_element(p, cp); has = true; }
+                    if (!e) { vv = wv_element(cold, cp); has = true; }
                 }
             }
             v[k] = vv; if (has) { wm |= 1u << k; ++cnt; }
@@ -495,8 +495,8 @@ struct WpWave {
         wv::sync();
         return ran;
     }
-    static constexpr int UNIT_MIN = 12 * NU;
-    static constexpr int CHUNK_ROOM = QCAP >= 512 ? 256 : (QCAP * 15) / 32;
+    static constexpr int UNIT_MIN = UMIN * NU;
+    static constexpr int CHUNK_ROOM = CROOM > 0 ? CROOM : (QCAP >= 512 ? 256 : (QCAP * 15) / 32);
 
     // ------------------------------------------------------------------------------------------------------------------
     // retire (phase C): the finished tokens at the head of the queue, in order.  Position of a unit's ids = ids its document has
@@ -592,8 +592,8 @@ struct WpWave {
     {
         const int64_t n64 = e - b;
         if (n64 <= 0 || n64 > 1000000000) { if (lane == 0) p.counts[d] = 0; return false; }                                // tokdll:1121
-        if (b < 0 || b + n64 > p.b.total_bytes) { if (lane == 0) { p.counts[d] = 0; wv::atomic_or(p.b.status, BF_STATUS_BAD_OFFSETS); } return false; }
-        n = (int)n64; s = p.b.text + b;
+        if (b < 0 || b + n64 > p.total_bytes) { if (lane == 0) { p.counts[d] = 0; wv::atomic_or(cold.status, BF_STATUS_BAD_OFFSETS); } return false; }
+        n = (int)n64; s = p.text + b;
         int cap = p.max_ids; if ((int64_t)cap > n64) cap = n; if (cap < 0) cap = 0;
         curk = dt_tail++;
         const uint32_t ke = curk & DMASK;
@@ -623,9 +623,9 @@ struct WpWave {
                 unsigned long long base = 0;
                 if (lane == 0) base = wv::atomic_add(p.next_doc, (unsigned long long)grab);
                 base = wv::bcast(base, 0);
-                if ((int64_t)base >= p.b.ndocs) { exiting = true; return false; }
-                dbase = (int64_t)base; dnext = dbase; dend = dbase + grab < p.b.ndocs ? dbase + grab : p.b.ndocs;
-                if (lane <= (int)(dend - dbase)) off_lane = p.b.doc_off[dbase + lane];
+                if ((int64_t)base >= p.ndocs) { exiting = true; return false; }
+                dbase = (int64_t)base; dnext = dbase; dend = dbase + grab < p.ndocs ? dbase + grab : p.ndocs;
+                if (lane <= (int)(dend - dbase)) off_lane = p.doc_off[dbase + lane];
             }
             const int i = (int)(dnext - dbase);
             const int64_t b = wv::bcast(off_lane, i), e = wv::bcast(off_lane, i + 1);
@@ -667,15 +667,15 @@ struct WpWave {
             if (!filled && !moved) {
                 // nothing can move: cannot happen (the ring holds a whole token and a chunk, the queue a whole window; checked at load)
                 if (STATS) ++st_idle;
-                if (lane == 0) wv::atomic_or(p.b.status, BF_STATUS_INTERNAL);
+                if (lane == 0) wv::atomic_or(cold.status, BF_STATUS_INTERNAL);
                 break;
             }
         }
         if (STATS && lane == 0) {
-            wv::atomic_add(&p.stats[0], st_trips); wv::atomic_add(&p.stats[1], st_win); wv::atomic_add(&p.stats[2], st_slow); wv::atomic_add(&p.stats[3], (unsigned long long)q_tail);
-            wv::atomic_add(&p.stats[4], st_steps); wv::atomic_add(&p.stats[5], st_ret); wv::atomic_add(&p.stats[7], st_idle); wv::atomic_add(&p.stats[8], st_dec);
+            wv::atomic_add(&cold.stats[0], st_trips); wv::atomic_add(&cold.stats[1], st_win); wv::atomic_add(&cold.stats[2], st_slow); wv::atomic_add(&cold.stats[3], (unsigned long long)q_tail);
+            wv::atomic_add(&cold.stats[4], st_steps); wv::atomic_add(&cold.stats[5], st_ret); wv::atomic_add(&cold.stats[7], st_idle); wv::atomic_add(&cold.stats[8], st_dec);
         }
-        if (STATS) { const unsigned long long r = st_rewalk; if (r) wv::atomic_add(&p.stats[6], r); }
+        if (STATS) { const unsigned long long r = st_rewalk; if (r) wv::atomic_add(&cold.stats[6], r); }
     }
 };
 

@@ -16,7 +16,7 @@ static void run_cfg(const WpWaveParams &p, int nwaves, int grab)
 {
     std::vector<LDS *> lds;
     std::vector<uint16_t> ascii(128);
-    for (int i = 0; i < 128; ++i) ascii[(size_t)i] = (uint16_t)wv_element(p, i);
+    for (int i = 0; i < 128; ++i) ascii[(size_t)i] = (uint16_t)wv_element(p.cold, i);
     int next_wave = 0;
     std::vector<LDS *> of_wave((size_t)nwaves);
     for (int i = 0; i < nwaves; ++i) { of_wave[(size_t)i] = new LDS(); memset((void *)of_wave[(size_t)i], 0xA5, sizeof(LDS)); }
@@ -27,7 +27,7 @@ static void run_cfg(const WpWaveParams &p, int nwaves, int grab)
         size_t k = 0;
         for (; k < wave_ids.size(); ++k) if (wave_ids[k] == wid) break;
         if (k == wave_ids.size()) { wave_ids.push_back(wid); (void)next_wave; }
-        WpWave<LDS, NU, true> w(p, *of_wave[k], ascii.data(), p.acts);
+        WpWave<LDS, NU, true> w(p, p.cold, *of_wave[k], ascii.data(), p.acts);
         w.run(grab);
     };
     wvemu::run_waves(nwaves, body);
@@ -52,12 +52,12 @@ long bft_emu_wave_batch(void *hv, const uint8_t *text, long text_bytes, const in
     std::vector<int32_t> tmp((size_t)(total + 8 * ndocs + 64 + 8), -77), counts((size_t)ndocs + 1, -55);
     unsigned long long next_doc = 0; int status = 0;
     WpWaveParams p;
-    p.T = m.wbd_t2.data(); p.acts = m.acts_pool.data();
-    p.cpmap = DevCpMap{m.wbd_cpmap.l1.data(), m.wbd_cpmap.pages.data()};
-    p.kind = m.wave_kind.data(); p.nclasses = m.wbd.nclasses;
-    p.initial = m.wbd.initial_base; p.loop_info = m.loop_info; p.solo_info = m.wave_solo_info; p.acts_n = (int)m.acts_pool.size(); p.max_token_length = m.max_token_length;
-    p.b = Batch{text, doc_off, ndocs, total, &status};
-    p.ids_tmp = tmp.data(); p.counts = counts.data(); p.max_ids = max_ids; p.unk = unk; p.next_doc = &next_doc; p.stats = stats; p.no_fast = cfg == 1 ? 1 : 0;
+    p.T = m.wbd_t2.data(); p.acts = m.acts_pool.data(); p.acts_n = (int)m.acts_pool.size();
+    p.initial = m.wbd.initial_base; p.loop_info = m.loop_info; p.solo_info = m.wave_solo_info; p.max_token_length = m.max_token_length;
+    p.text = text; p.doc_off = doc_off; p.ndocs = ndocs; p.total_bytes = total;
+    p.ids_tmp = tmp.data(); p.counts = counts.data(); p.max_ids = max_ids; p.unk = unk; p.next_doc = &next_doc;
+    p.cold.cpmap = DevCpMap{m.wbd_cpmap.l1.data(), m.wbd_cpmap.pages.data()};
+    p.cold.kind = m.wave_kind.data(); p.cold.nclasses = m.wbd.nclasses; p.cold.status = &status; p.cold.stats = stats; p.cold.no_fast = cfg == 1 ? 1 : 0;
     if (ndocs > 0) {
         if (cfg == 1) run_cfg<WvLds<1024, 128, 2>, 2>(p, nwaves, grab);
         else if (cfg == 2) run_cfg<WvLds<4096, 512, 64>, 3>(p, nwaves, grab);
