@@ -13,12 +13,13 @@ traffic is the timing barrier, a MAX-reduce of the elapsed time and the gather o
 
 `n_gpus` in the result is the number of ranks that actually ran (WORLD_SIZE), each on its own device (listed under
 `ranks`); `--gpus` that disagrees with WORLD_SIZE is an error.  Before timing, EVERY document of the shard is compared
-with the CPU checker (oracle/_ref = the compiled reference when present, else the oracle port): id counts exactly, ids
-through a 64-bit per-document hash computed on both sides -- a mismatch refuses to time.
+with the CPU checker (oracle/_ref = the compiled reference when present, else the oracle port): id offsets and every id,
+exactly -- a mismatch refuses to time.
 
 Prints ONE JSON line (rank 0) with the driver's contract keys plus `roofline`, `cpu_baseline` and `timings`.
 """
 import argparse
+import ctypes
 import json
 import os
 import socket
@@ -34,14 +35,24 @@ HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MIC
 
 # total documents of each workload; the corpus is sharded over the ranks
 TOTAL_DOCS = {"config1": 10000, "headline512": 10000000, "config2": 1000000, "config3": 1000000, "config4": 10000000, "config5": 10000000}
-DOMINANT = {0: "k_lex_wp_flat", 1: "k_seg_unigram_ring"}
+
+
+def csrc_sha():
+    """identity of the kernels a profile was taken of: sha256 over blingfire_amd/csrc (sorted file names + contents), first 16 hex digits"""
+    import hashlib
+    d = os.path.join(ROOT, "blingfire_amd", "csrc")
+    hsh = hashlib.sha256()
+    for f in sorted(os.listdir(d)):
+        hsh.update(f.encode())
+        hsh.update(open(os.path.join(d, f), "rb").read())
+    return hsh.hexdigest()[:16]
 
 
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=10)      # SURVEY.md section 8(d): 3 warm-up + 10 timed passes
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="headline512", choices=sorted(TOTAL_DOCS))
     ap.add_argument("--docs", type=int, default=0, help="override the TOTAL number of documents of the corpus")
     ap.add_argument("--docs-per-gpu", type=int, default=0, help="override the corpus size as documents per rank (total = this * ranks)")
@@ -261,24 +272,43 @@ def main():
     lib_path, ck_kind = bfutil.checker_lib_path()
     cpu_threads = max(1, bfutil.host_threads() // (world if not share else 1))
     if nv > 0:
-        verify_secs, c_counts, c_hash = bfutil.cpu_doc_hashes(lib_path, bfutil.model_path(model_name), text[:off[nv]], off[:nv + 1], max_ids, unk,
-                                                              nthreads=cpu_threads)
+        # exact: every id of every document (SURVEY.md section 8(d) "memcmp"), the reference's ids compact and in document order,
+        # compared on the device with the ids of the sub-batch; the CPU side works through the shard in pieces of <= 1 M documents
         step()
         torch.cuda.synchronize(dev)
+        piece = 1000000
         for b in batches:
             if b["d0"] >= nv:
                 break
-            k = min(b["d1"], nv) - b["d0"]
-            g_counts = (b["id_off"][1:k + 1] - b["id_off"][:k]).cpu().numpy()
-            g_hash = device_doc_hashes(torch, b["ids"], b["id_off"], k).cpu().numpy().view(np.uint64)
-            ok_c = np.array_equal(g_counts, c_counts[b["d0"]:b["d0"] + k])
-            ok_h = np.array_equal(g_hash, c_hash[b["d0"]:b["d0"] + k])
-            if not (ok_c and ok_h):
-                bad = np.nonzero((g_counts != c_counts[b["d0"]:b["d0"] + k]) | (g_hash != c_hash[b["d0"]:b["d0"] + k]))[0]
-                d = int(bad[0]) + b["d0"]
-                raise SystemExit("bench: GPU ids differ from the CPU checker (%s) on %d document(s) of rank %d, first = shard document %d (%r...) -- refusing to time"
-                                 % (ck_kind, len(bad), rank, d, bytes(text[off[d]:off[d] + 64])))
-            verified += k
+            k_all = min(b["d1"], nv) - b["d0"]
+            g_off = b["id_off"][:k_all + 1].cpu().numpy()
+            for p0 in range(0, k_all, piece):
+                p1 = min(k_all, p0 + piece)
+                a, z = b["d0"] + p0, b["d0"] + p1
+                secs, c_ids, c_off = bfutil.cpu_ids_compact(lib_path, bfutil.model_path(model_name), text[off[a]:off[z]], off[a:z + 1] - off[a], max_ids, unk,
+                                                            nthreads=cpu_threads)
+                verify_secs += secs
+                ok_c = np.array_equal(g_off[p0:p1 + 1] - g_off[p0], c_off)
+                ok_i = False
+                if ok_c:
+                    lo, hi = int(g_off[p0]), int(g_off[p1])
+                    ok_i = bool(torch.equal(b["ids"][lo:hi], torch.from_numpy(c_ids).to(dev)))
+                if not (ok_c and ok_i):
+                    cnt_g, cnt_c = np.diff(g_off[p0:p1 + 1]), np.diff(c_off)
+                    bad = np.nonzero(cnt_g != cnt_c)[0]
+                    if len(bad):
+                        d = int(bad[0])
+                    else:
+                        g_ids = b["ids"][int(g_off[p0]):int(g_off[p1])].cpu().numpy()
+                        ne = np.nonzero(g_ids != c_ids)[0]
+                        d = int(np.searchsorted(c_off, ne[0], side="right") - 1) if len(ne) else 0
+                    dd = a + d
+                    lo, hi = int(g_off[p0 + d]), int(g_off[p0 + d + 1])
+                    raise SystemExit("bench: GPU ids differ from the CPU checker (%s), rank %d, first = shard document %d (%r...): GPU %s, CPU %s -- refusing to time"
+                                     % (ck_kind, rank, dd, bytes(text[off[dd]:off[dd] + 64]), b["ids"][lo:hi].cpu().numpy().tolist()[:32],
+                                        c_ids[int(c_off[d]):int(c_off[d + 1])].tolist()[:32]))
+                verified += p1 - p0
+                del c_ids
 
     for _ in range(args.warmup):
         step()
@@ -286,9 +316,13 @@ def main():
     if dist:
         dist.barrier()
     kms = np.zeros(5, dtype=np.float64)
+    per_step = []                       # HIP-event time of every timed step (all its launches), for the median / min of SURVEY.md section 8(d)
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step(kms)
+        one = np.zeros(5, dtype=np.float64)
+        step(one)
+        kms += one
+        per_step.append(float(one[4]))
     torch.cuda.synchronize(dev)
     if dist:
         dist.barrier()
@@ -324,12 +358,18 @@ def main():
         alg_bytes = total_bytes + 4 * n_ids + 16 * ndocs
         tok_ms = float(kms[1])
         achieved = alg_bytes / (tok_ms * 1e-3) / 1e9 if tok_ms > 0 else 0.0
-        traffic = None
+        traffic, traffic_stale, l2_hit = None, None, None
+        bf.lib().BfTokeniseKernel.restype = ctypes.c_char_p
+        bf.lib().BfTokeniseKernel.argtypes = [ctypes.c_void_p]
+        kernel_name = (bf.lib().BfTokeniseKernel(ctypes.c_void_p(h)) or b"").decode()
         try:   # HBM bytes per step of the dominant kernel from the committed rocprofv3 PMC passes of this same command
             tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
             ent = tj.get("%s/%s/%d" % (args.workload, model_name, ndocs))
             if ent:
                 traffic = ent.get("hbm_bytes_per_step", ent["hbm_bytes_per_launch"])
+                l2_hit = ent.get("l2_hit_rate")
+                # the counters belong to the kernels they were taken of: a profile of another build of csrc/ is flagged
+                traffic_stale = ent.get("csrc_sha") != csrc_sha() or ent.get("kernel") != kernel_name
         except Exception:
             traffic = None
         res = {
@@ -344,12 +384,16 @@ def main():
             "gb_input_per_sec": bytes_all * args.steps / elapsed / 1e9,
             "ids_per_sec": ids_all * args.steps / elapsed,
             "kernel_ms": {"prep": float(kms[0]), "tokenise": tok_ms, "scan": float(kms[2]), "compact": float(kms[3]), "total": float(kms[4])},
-            "roofline": {"bound": "hbm", "kernel": "tokenise (%s)" % DOMINANT.get(kind, "k_bpe_fused"), "achieved": achieved, "peak": HBM_PEAK_GBPS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes,
-                         "launches_per_step": len(batches),
-                         "note": "achieved = algorithmic bytes of one step (all its launches) / tokenise-kernel time of one step; traffic = FETCH_SIZE + WRITE_SIZE of the same, from profiles/traffic.json"},
+            "kernel_ms_per_step": {"median": float(np.median(per_step)) if per_step else None, "min": float(np.min(per_step)) if per_step else None,
+                                   "max": float(np.max(per_step)) if per_step else None, "n": len(per_step),
+                                   "what": "HIP-event time of one step's launches (prep .. compact), every timed step"},
+            "roofline": {"bound": "hbm", "kernel": "tokenise (%s)" % kernel_name, "achieved": achieved, "peak": HBM_PEAK_GBPS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_stale": traffic_stale, "l2_hit_rate": l2_hit,
+                         "algorithmic_bytes_per_launch": alg_bytes, "launches_per_step": len(batches),
+                         "note": "achieved = algorithmic bytes of one step (all its launches) / tokenise-kernel time of one step; traffic = FETCH_SIZE + WRITE_SIZE "
+                                 "of the same command (separate rocprofv3 --pmc passes, profiles/traffic.json; traffic_stale: the profile is of another build of csrc/)"},
             "verified_docs": sum(r["verified_docs"] for r in ranks), "verify": {"checker": ck_kind, "threads": cpu_threads, "seconds": verify_secs,
-                                                                               "method": "per-document id count + 64-bit hash of the ids, every document of the shard"},
+                                                                               "method": "exact: id offsets and every id of every document against the CPU checker (array equality)"},
             "status": max(r["status"] for r in ranks), "ranks": ranks,
             "backend": (dist.get_backend() if dist else None),
         }
@@ -406,34 +450,34 @@ def main():
             "host_api_wall": {"docs_per_s": ns / min(api), "ms": min(api) * 1e3, "sample_docs": ns,
                               "what": "wall clock of TextToIdsBatch on pageable host arrays (chunked through pinned staging, bf_capi.cpp run_host_chunked), output arrays reused, best of 3"},
         }
-        # work-rate roofline of the lexer: table gathers per second against the measured gather ceiling
+        # work-rate roofline of the lexer: table gathers per second against the measured gather ceiling.
+        # Counted by the instrumented instance of the SAME kernel in one extra untimed step (BfSetLexStats).
         if kind == 0:
             try:
-                os.environ["BF_LEX_STATS"] = "1"
-                import ctypes
                 buf = (ctypes.c_ulonglong * 16)()
                 bf.lib().BfLexStats.restype = ctypes.c_int
                 bf.lib().BfLexStats.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
-                bf.lib().BfLexStats(ctypes.c_void_p(h), buf, 16)
-                before = int(buf[1])
+                bf.lib().BfSetLexStats(ctypes.c_void_p(h), 1)
                 step()
                 torch.cuda.synchronize(dev)
                 bf.lib().BfLexStats(ctypes.c_void_p(h), buf, 16)
-                transitions = int(buf[1]) - before
-                del os.environ["BF_LEX_STATS"]
+                bf.lib().BfSetLexStats(ctypes.c_void_p(h), 0)
+                wave = kernel_name == "k_wp_wave"
+                issued = int(buf[9]) if wave else int(buf[1])          # gathers issued (the wave program's transition step loads on all 64 lanes)
+                transitions = int(buf[10]) if wave else int(buf[1])    # transitions made
                 clk_hz = float(getattr(props, "clock_rate", 2400000)) * 1e3
-                rate = transitions / (tok_ms * 1e-3) / (props.multi_processor_count * clk_hz)
+                rate = issued / (tok_ms * 1e-3) / (props.multi_processor_count * clk_hz)
                 ceil = None
                 try:
                     ceil = json.load(open(os.path.join(ROOT, "profiles", "gather_ceiling.json")))["ceiling_lane_gathers_per_clk_per_cu"]
                 except Exception:
                     pass
                 res["roofline"]["gather"] = {"achieved": rate, "ceiling": ceil, "frac": (rate / ceil) if ceil else None,
-                                             "unit": "table lane-gathers / clk / CU", "transitions_per_step": transitions,
+                                             "unit": "table lane-gathers issued / clk / CU", "gathers_per_step": issued, "transitions_per_step": transitions,
                                              "transitions_per_input_byte": transitions / max(total_bytes, 1),
+                                             "counted_by": "the STATS instance of %s (every gather the kernel issues; idle lanes of a transition step included)" % kernel_name,
                                              "ceiling_source": "tools/microbench/gather.hip on this GPU, table of the model's size (profiles/gather_ceiling.json)"}
             except Exception as e:   # instrumentation is optional
-                os.environ.pop("BF_LEX_STATS", None)
                 res["roofline"]["gather"] = {"error": str(e)}
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -49,7 +49,7 @@ def lib():
         L.TextToIdsWithOffsetsBatchDevice.argtypes = [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_int64,
                                                       c_void_p, c_int, c_int, c_void_p]
         L.SetNoDummyPrefix.restype = c_int
-        L.SetNoDummyPrefix.argtypes = [c_void_p, c_int]
+        L.SetNoDummyPrefix.argtypes = [c_void_p, ctypes.c_bool]
         L.GetBlingFireTokVersion.restype = c_int
         L.TextToIdsBatch.restype = c_int64
         L.TextToIdsBatch.argtypes = [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int, c_int]
@@ -297,7 +297,7 @@ def ids_to_text_batch(h, ids, id_off, skip_special_tokens=True):
 
 
 def change_settings_dummy_prefix(h, add_prefix):
-    lib().SetNoDummyPrefix(c_void_p(h), int(not add_prefix))
+    lib().SetNoDummyPrefix(c_void_p(h), bool(not add_prefix))
 
 
 # ---------------------------------------------------------------------------------------------

@@ -38,14 +38,18 @@ bool hip_ok(hipError_t e, const char *what)
 struct DevBuf {
     void *p = nullptr; size_t cap = 0;
     // Grow-only.  Growing is a hipMalloc + hipFree (both synchronise the device): callers that must not synchronise size the
-    // workspaces once with BfReserve.  The old buffer is released only after the new one exists.
+    // workspaces once with BfReserve.
     bool reserve(size_t bytes)
     {
         if (bytes <= cap) return true;
         size_t want = bytes + bytes / 8 + 256;
         void *q = nullptr;
-        if (!hip_ok(hipMalloc(&q, want), "hipMalloc(workspace)")) return false;
-        if (p) (void)hipFree(p);
+        // the contents are never kept across a grow; the old buffer goes first when both do not fit
+        if (hipMalloc(&q, want) != hipSuccess) {
+            (void)hipGetLastError();
+            if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+            if (!hip_ok(hipMalloc(&q, want), "hipMalloc(workspace)")) return false;
+        } else if (p) (void)hipFree(p);
         p = q; cap = want; return true;
     }
     void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
@@ -295,7 +299,7 @@ bool reserve_ids_workspaces(Handle *h, int64_t ndocs, int64_t total_bytes, bool 
     if (want_off && (!h->w_srcoff.reserve(cap * 4) || !h->w_span.reserve(cap * 8))) return false;
     if (m.kind == KIND_UNIGRAM) {
         // one packed 4-byte record per stream element (bf_seg.h uni_rec; 8 bytes reserved); the sequential / flat variants keep 16-byte records
-        const bool lane_form = (h->variant & 0xff) != 1 && uni_lane_ok(m);
+        const bool lane_form = uni_lane_ok(m);
         if (!h->w_s1.reserve(cap * (lane_form ? 4 : 16) + 64)) return false;
     } else {
         const size_t bm_words = (cap >> 5) + (size_t)ndocs + 4;
@@ -347,10 +351,10 @@ int run_device(Handle *h, const char *d_text, const int64_t *d_doc_off, int64_t 
         lp.L.T = h->t_wbd.as<uint64_t>(); lp.L.acts = h->t_acts.as<int32_t>();
         lp.L.initial = m.wbd.initial_base; lp.L.initial_l = m.initial_l; lp.L.cls_any = m.cls_any; lp.L.cls_l = m.cls_l; lp.L.cls_r = m.cls_r;
         lp.L.max_depth = m.max_depth; lp.L.max_token_length = m.max_token_length; lp.L.max_frames = m.lex_frames;
-        lp.L.loop_state = (h->variant & 0xff) == 4 ? LX_NO_STATE : m.loop_base;        // variant 4 (experiments): no fast-forward
+        lp.L.loop_state = m.loop_base;
         lp.L.loop_info = m.loop_info; lp.L.loop_final = m.loop_final ? 1 : 0;
-        lp.L.fn_no_ra = (m.fn_no_ra && (h->variant & 0xff) != 9) ? 1 : 0;                      // variant 9 (experiments): always feed the right anchor
-        lp.L.two_level = (m.two_level && (h->variant & 0xff) != 7) ? 1 : 0;                // variant 7 (experiments): the general machine
+        lp.L.fn_no_ra = m.fn_no_ra ? 1 : 0;
+        lp.L.two_level = m.two_level ? 1 : 0;
         lp.b = b; lp.cls = h->w_cls.as<uint16_t>(); lp.nchars = h->w_nchars.as<int32_t>();
         lp.ids_tmp = h->w_tmp.as<int32_t>(); lp.counts = h->w_counts.as<int32_t>(); lp.span_tmp = want_off ? h->w_span.as<int32_t>() : nullptr;
         lp.max_ids = max_ids; lp.unk = unk; lp.next_doc = next_doc; lp.status = status; lp.ev_thresh = 0; lp.fetch_thresh = 0; lp.acts_n = (int)m.acts_pool.size(); lp.words = words;
@@ -387,7 +391,7 @@ int run_device(Handle *h, const char *d_text, const int64_t *d_doc_off, int64_t 
         }
         sg.narcs = h->w_narcs.as<int32_t>(); sg.next_doc = next_doc; sg.trie_depth = m.trie_max_depth; sg.variant = h->variant & 0xff; sg.tune = (h->variant >> 8) & 0xff; sg.tune2 = (h->variant >> 16) & 0xff;
         sg.lane_ok = uni_lane_ok(m) ? 1 : 0;
-        if (m.kind == KIND_UNIGRAM && sg.variant != 1 && sg.lane_ok) first = h->w_narcs.as<int32_t>();
+        if (m.kind == KIND_UNIGRAM && sg.lane_ok) first = h->w_narcs.as<int32_t>();
         sg.perm = h->w_perm.as<int32_t>(); sg.hist = h->w_hist.as<unsigned int>();
         if (ndocs > 0) launch_seg_sp(sg, s);
         (void)hipEventRecord(h->ev[EV_TOK], s);
@@ -776,6 +780,10 @@ int run_dict_device(Handle *h, const int32_t *d_keys, const int64_t *d_key_off, 
 {
     const Model &m = h->m;
     if (!m.has_seg || m.k2i.empty()) return BF_E_UNSUPPORTED;
+    // the reference looks a key up as it is only for (no ignore-case, left-to-right) dictionaries, lower-cases for ignore-case ones and
+    // reverses only right-to-left ones (FADictInterpreter_t.h:203-205, FAFsmConst.h DIR_L2R = 0, DIR_R2L = 1): the other combinations are
+    // refused here instead of being looked up wrongly
+    if (m.ignore_case || (m.dict_direction != 0 && m.dict_direction != 1)) { g_last_error = "dictionary lookup: ignore-case / direction other than l2r, r2l is not supported"; return BF_E_UNSUPPORTED; }
     if (nkeys < 0 || !d_key_off || !d_val_off) return BF_E_ARG;
     const int nblocks = scan_nblocks(nkeys);
     if (!ensure_dict_tables(h) || !h->w_counts.reserve((size_t)(nkeys + 1) * 4) || !h->w_bsums.reserve((size_t)(nblocks + 1) * 8) ||
@@ -1313,12 +1321,12 @@ int BfReserve(void *p, int64_t max_docs, int64_t max_bytes, int want_offsets)
     return reserve_ids_workspaces(h, max_docs, max_bytes, want_offsets != 0) ? 0 : BF_E_DEVICE;
 }
 
-int SetNoDummyPrefix(void *p, int flag)
+int SetNoDummyPrefix(void *p, bool flag)          /* reference signature: blingfiretokdll.h:103 */
 {
     Handle *h = as_handle(p);
     if (!h) return 0;
     std::lock_guard<std::mutex> lock(h->mu);
-    h->m.no_dummy_prefix = flag != 0;
+    h->m.no_dummy_prefix = flag;
     return 1;
 }
 
@@ -1433,6 +1441,32 @@ int BfSetVariant(void *p, int variant)
     if (!h) return BF_E_ARG;
     std::lock_guard<std::mutex> lock(h->mu);
     int old = h->variant; h->variant = variant; return old;
+}
+
+/* experiments: switches the instrumented kernel instances on / off (what BF_LEX_STATS=1 at LoadModel does) and clears the counters */
+int BfSetLexStats(void *p, int on)
+{
+    Handle *h = as_handle(p);
+    if (!h) return BF_E_ARG;
+    std::lock_guard<std::mutex> lock(h->mu);
+    (void)hipDeviceSynchronize();
+    const int old = h->lex_stats ? 1 : 0;
+    h->lex_stats = on != 0;
+    if (!hip_ok(hipMemset(h->w_misc.as<char>() + 64, 0, 128), "hipMemset(stats)")) return BF_E_DEVICE;
+    return old;
+}
+
+/* the kernel that tokenises a plain TextToIds batch of this model (the one a bench line's roofline is about) */
+const char *BfTokeniseKernel(void *p)
+{
+    Handle *h = as_handle(p);
+    if (!h) return "";
+    switch (h->m.kind) {
+    case KIND_WP: return use_wave(h, false, 0) ? "k_wp_wave" : (h->m.two_level ? "k_lex_wp_plain" : "k_lex_wp_flat");
+    case KIND_UNIGRAM: return "k_seg_unigram_lane";
+    case KIND_I2W: return "";
+    default: return "k_bpe_fused";
+    }
 }
 
 } // extern "C"

@@ -3,13 +3,21 @@
 #include "../../include/blingfiretokdll_amd.h"
 
 extern "C" {
-/* instrumentation counters of the lexer kernel when BF_LEX_STATS=1 is set in the environment (accumulated since LoadModel):
- * [0] walk trips  [1] lane-steps (table probes / fast-forward runs)  [2] event rounds  [3] event lanes  [4] fetch rounds
- * [5] idle lane-steps  [6..8] cycles in walk / event / fetch */
+/* instrumentation counters of the tokenising kernel of a WordPiece model (BF_LEX_STATS=1 in the environment at LoadModel, or
+ * BfSetLexStats), accumulated since then.  Wave program (bf_wave.h WpWaveCold::stats): [0] unit rounds [1] wide passes [2] general windows
+ * [3] tokens [4] busy units summed over the rounds [5] retire rounds [6] words of more than four pieces [7] trips without progress
+ * [8] decode steps [9] table gathers issued (64 per transition step and unit) [10] transitions made (walking lanes).
+ * Lane-per-document kernels: [0] walk trips [1] lane-steps [2] event rounds [3] event lanes [4] fetch rounds [5] idle lane-steps
+ * [6..8] cycles in walk / event / fetch */
 BF_API int BfLexStats(void *ModelPtr, unsigned long long *out, int n);
-/* selects a kernel variant (3 = default): lexer 1 = sequential driver, 4 = no loop-state fast-forward, 5 = no LDS-resident table;
- * Unigram 1 = sequential, 2 = flat, 6 = round-1 ring kernel; bits 8.. carry tuning values.  Returns the previous value. */
+/* experiments / A-B runs.  Low byte: 3 = default; 2 = the lane-per-document WordPiece kernels (bf_lex.h) also for unit-form lexers, whose
+ * default is the wave program (bf_wave.h).  The higher bits carry tuning values (bf_kernels.hip launch_wp_wave / launch_lex_wp / launch_seg_sp).
+ * Returns the previous value. */
 BF_API int BfSetVariant(void *ModelPtr, int variant);
+/* switches the instrumented kernel instances on / off for this handle and clears the counters; returns the previous setting */
+BF_API int BfSetLexStats(void *ModelPtr, int on);
+/* name of the kernel that tokenises a plain TextToIds batch of this model */
+BF_API const char *BfTokeniseKernel(void *ModelPtr);
 /* largest chunk of the pipelined host-buffer path of TextToIdsBatch (default 128 MiB; batches of at least that size take it, cut into
  * chunks of half to all of it; 0 = never).
  * Tests use small values to put chunk boundaries everywhere.  Returns the previous value. */

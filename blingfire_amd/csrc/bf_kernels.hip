@@ -440,27 +440,7 @@ struct IdOutLds {
     __device__ __forceinline__ void finish(int count) { if (cb >= 0 && cb * 8 < count) flush(); }
 };
 
-// variant 1: sequential driver (bf_lex.h lex_doc), static document-per-thread assignment.  The compiler's
-// reconvergence makes every wave walk until ALL its lanes' walks end, then handle matches.
-template <int THREADS>
-__global__ __launch_bounds__(THREADS) void k_lex_wp_seq(WpLexParams p)
-{
-    extern __shared__ int32_t lex_lds[];
-    const int64_t d = (int64_t)blockIdx.x * THREADS + threadIdx.x;
-    if (d >= p.b.ndocs) return;
-    const int64_t b = p.b.doc_off[d];
-    const int64_t nbytes = p.b.doc_off[d + 1] - b;
-    const int n = p.nchars[d];
-    int cap = p.max_ids; if ((int64_t)cap > nbytes) cap = (int)nbytes;
-    if (cap < 0) cap = 0;
-    ClsWin cls_at; cls_at.init(p.cls, b);
-    IdOutLds out; out.buf = lex_lds + (size_t)p.L.max_frames * LEX_FRAME_WORDS * THREADS + threadIdx.x; out.nthreads = THREADS;
-    out.init(p.ids_tmp + ids_slot(b, d), p.span_tmp ? p.span_tmp + 2 * ids_slot(b, d) : nullptr);
-    FramesLds frames{lex_lds, THREADS};
-    p.counts[d] = lex_doc(p.L, cls_at, n, out, cap, p.unk, frames, p.words);
-}
-
-// variant 3 (default): divergence-aware driver.  Lanes are persistent and pull documents from a global
+// Divergence-aware driver.  Lanes are persistent and pull documents from a global
 // counter; every loop iteration a lane in WALK mode makes exactly one DFA transition, while the heavier
 // "event" code (match handling, calls/returns, next start position) and the document fetch run only when
 // enough lanes of the wave are waiting for them (ballot vote), so that they execute with most lanes active.
@@ -586,76 +566,70 @@ static size_t lex_lds_bytes(const WpLexParams &p, int threads, bool tlds = false
 constexpr int LEX_TLDS_THREADS = 512;            // workgroup of the LDS-table variant: 8 waves share one copy of the table
 constexpr size_t LEX_TLDS_MAX_BYTES = 64 * 1024; // LDS budget of one workgroup (two of them fit a CU's 160 KB)
 
+// variant (experiments): bits 8..15 = event threshold, bits 16..19 = fetch threshold, bits 20..23 = transitions per vote (two-level
+// ids-only instance: 3 or 5), bits 24..29 = resident waves per CU
 void launch_lex_wp(const WpLexParams &p, int variant, hipStream_t s)
 {
-    const int kind = variant & 0xff;
-    if (kind == 1) {
-        const int64_t blocks = (p.b.ndocs + 63) / 64;
-        WpLexParams q = p; q.acts_n = 0;
-        hipLaunchKernelGGL(k_lex_wp_seq<64>, dim3((unsigned)blocks), dim3(64), lex_lds_bytes(q, 64), s, q);
-    } else {
-        WpLexParams q = p;
-        q.ev_thresh = (variant >> 8) & 0xff; if (q.ev_thresh == 0) q.ev_thresh = 32;
-        q.fetch_thresh = (variant >> 16) & 0xf; if (q.fetch_thresh == 0) q.fetch_thresh = 8;      // bits 20..23: transitions per vote (two-level form)
-        q.acts_n = p.acts_n;                                          // <= 4096 ints, checked at LoadModel
-        int waves_per_cu = (variant >> 24) & 0x3f;
-        if (waves_per_cu == 0) {                                      // persistent: exactly the resident waves
-            int per_cu = 0;
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_lex_wp_flat<64, ClsWin, false, 3, false>, 64, lex_lds_bytes(q, 64)) != hipSuccess || per_cu <= 0) per_cu = 16;
-            waves_per_cu = per_cu;
-            (void)hipGetLastError();
-        }
-        int64_t blocks = (int64_t)device_cus() * (int64_t)waves_per_cu;
-        const int64_t need = (p.b.ndocs + 63) / 64;
-        if (blocks > need) blocks = need;
-        if (blocks < 1) blocks = 1;
-        const bool has_any = p.L.cls_any != LX_CLS_NONE;
-        // small models (wbd.bin: TextToWords): the whole table lives in LDS
-        if (kind != 5 && !p.stats && p.table_n > 0 && lex_lds_bytes(q, LEX_TLDS_THREADS, true) <= LEX_TLDS_MAX_BYTES) {
-            constexpr int TH = LEX_TLDS_THREADS;
-            const size_t lds = lex_lds_bytes(q, TH, true);
-            int per_cu = 0;
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_lex_wp_flat<TH, ClsWin, false, 3, false, true>, TH, lds) != hipSuccess || per_cu <= 0) per_cu = 2;
-            (void)hipGetLastError();
-            int64_t nb = (int64_t)device_cus() * per_cu;
-            const int64_t need_b = (p.b.ndocs + TH - 1) / TH;
-            if (nb > need_b) nb = need_b;
-            if (nb < 1) nb = 1;
-            if (has_any) hipLaunchKernelGGL((k_lex_wp_flat<TH, ClsWin, true, 1, false, true>), dim3((unsigned)nb), dim3(TH), lds, s, q);
-            else hipLaunchKernelGGL((k_lex_wp_flat<TH, ClsWin, false, 3, false, true>), dim3((unsigned)nb), dim3(TH), lds, s, q);
-            return;
-        }
-        if (p.L.two_level && !p.stats) {
-            // two-level lexers: no saved frames in LDS, cheap events -> a lower event threshold pays (swept on MI355X)
-            WpLexParams q2 = q; q2.L.max_frames = 0;
-            if (((variant >> 8) & 0xff) == 0) q2.ev_thresh = 16;
-            const size_t lds2 = lex_lds_bytes(q2, 64);
-            // transitions per vote: swept on MI355X with the two-level event code (2: 8.50 ms, 3: 7.67, 4: 6.86 on the 1.25 M-doc shard);
-            // bits 20..23 of the variant select 3 or 5 for experiments (ids-only instance)
-            const int un = (variant >> 20) & 0xf;
-            const bool plain = !has_any && !q2.words && !q2.span_tmp && kind != 8;   // variant 8 (experiments): the general instance
-            int per_cu = 0;
-            const hipError_t oe = plain ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_lex_wp_plain<4>, 64, lds2)
-                                        : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_lex_wp_flat<64, ClsWin, false, 4, false, false, true>, 64, lds2);
-            if (oe != hipSuccess || per_cu <= 0) per_cu = 16;
-            (void)hipGetLastError();
-            if (((variant >> 24) & 0x3f) != 0) per_cu = (variant >> 24) & 0x3f;
-            int64_t nb = (int64_t)device_cus() * per_cu;
-            if (nb > need) nb = need;
-            if (nb < 1) nb = 1;
-            const dim3 g2((unsigned)nb), t2(64);
-            if (has_any) hipLaunchKernelGGL((k_lex_wp_flat<64, ClsWin, true, 1, false, false, true>), g2, t2, lds2, s, q2);
-            else if (plain && un == 5) hipLaunchKernelGGL(k_lex_wp_plain<5>, g2, t2, lds2, s, q2);
-            else if (plain && un == 3) hipLaunchKernelGGL(k_lex_wp_plain<3>, g2, t2, lds2, s, q2);
-            else if (plain) hipLaunchKernelGGL(k_lex_wp_plain<4>, g2, t2, lds2, s, q2);
-            else hipLaunchKernelGGL((k_lex_wp_flat<64, ClsWin, false, 4, false, false, true>), g2, t2, lds2, s, q2);
-            return;
-        }
-        const dim3 g((unsigned)blocks), t(64); const size_t lds = lex_lds_bytes(q, 64);
-        if (has_any) hipLaunchKernelGGL((k_lex_wp_flat<64, ClsWin, true, 1, false>), g, t, lds, s, q);
-        else if (p.stats) hipLaunchKernelGGL((k_lex_wp_flat<64, ClsWin, false, 3, true>), g, t, lds, s, q);
-        else hipLaunchKernelGGL((k_lex_wp_flat<64, ClsWin, false, 3, false>), g, t, lds, s, q);     // three transitions per vote: swept on MI355X
+    WpLexParams q = p;
+    q.ev_thresh = (variant >> 8) & 0xff; if (q.ev_thresh == 0) q.ev_thresh = 32;
+    q.fetch_thresh = (variant >> 16) & 0xf; if (q.fetch_thresh == 0) q.fetch_thresh = 8;
+    q.acts_n = p.acts_n;                                          // <= 4096 ints, checked at LoadModel
+    int waves_per_cu = (variant >> 24) & 0x3f;
+    if (waves_per_cu == 0) {                                      // persistent: exactly the resident waves
+        int per_cu = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_lex_wp_flat<64, ClsWin, false, 3, false>, 64, lex_lds_bytes(q, 64)) != hipSuccess || per_cu <= 0) per_cu = 16;
+        waves_per_cu = per_cu;
+        (void)hipGetLastError();
     }
+    int64_t blocks = (int64_t)device_cus() * (int64_t)waves_per_cu;
+    const int64_t need = (p.b.ndocs + 63) / 64;
+    if (blocks > need) blocks = need;
+    if (blocks < 1) blocks = 1;
+    const bool has_any = p.L.cls_any != LX_CLS_NONE;
+    // small models (wbd.bin: TextToWords): the whole table lives in LDS
+    if (!p.stats && p.table_n > 0 && lex_lds_bytes(q, LEX_TLDS_THREADS, true) <= LEX_TLDS_MAX_BYTES) {
+        constexpr int TH = LEX_TLDS_THREADS;
+        const size_t lds = lex_lds_bytes(q, TH, true);
+        int per_cu = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_lex_wp_flat<TH, ClsWin, false, 3, false, true>, TH, lds) != hipSuccess || per_cu <= 0) per_cu = 2;
+        (void)hipGetLastError();
+        int64_t nb = (int64_t)device_cus() * per_cu;
+        const int64_t need_b = (p.b.ndocs + TH - 1) / TH;
+        if (nb > need_b) nb = need_b;
+        if (nb < 1) nb = 1;
+        if (has_any) hipLaunchKernelGGL((k_lex_wp_flat<TH, ClsWin, true, 1, false, true>), dim3((unsigned)nb), dim3(TH), lds, s, q);
+        else hipLaunchKernelGGL((k_lex_wp_flat<TH, ClsWin, false, 3, false, true>), dim3((unsigned)nb), dim3(TH), lds, s, q);
+        return;
+    }
+    if (p.L.two_level && !p.stats) {
+        // two-level lexers: no saved frames in LDS, cheap events -> a lower event threshold pays (swept on MI355X)
+        WpLexParams q2 = q; q2.L.max_frames = 0;
+        if (((variant >> 8) & 0xff) == 0) q2.ev_thresh = 16;
+        const size_t lds2 = lex_lds_bytes(q2, 64);
+        // transitions per vote: swept on MI355X with the two-level event code (2: 8.50 ms, 3: 7.67, 4: 6.86 on the 1.25 M-doc shard)
+        const int un = (variant >> 20) & 0xf;
+        const bool plain = !has_any && !q2.words && !q2.span_tmp;
+        int per_cu = 0;
+        const hipError_t oe = plain ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_lex_wp_plain<4>, 64, lds2)
+                                    : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_lex_wp_flat<64, ClsWin, false, 4, false, false, true>, 64, lds2);
+        if (oe != hipSuccess || per_cu <= 0) per_cu = 16;
+        (void)hipGetLastError();
+        if (((variant >> 24) & 0x3f) != 0) per_cu = (variant >> 24) & 0x3f;
+        int64_t nb = (int64_t)device_cus() * per_cu;
+        if (nb > need) nb = need;
+        if (nb < 1) nb = 1;
+        const dim3 g2((unsigned)nb), t2(64);
+        if (has_any) hipLaunchKernelGGL((k_lex_wp_flat<64, ClsWin, true, 1, false, false, true>), g2, t2, lds2, s, q2);
+        else if (plain && un == 5) hipLaunchKernelGGL(k_lex_wp_plain<5>, g2, t2, lds2, s, q2);
+        else if (plain && un == 3) hipLaunchKernelGGL(k_lex_wp_plain<3>, g2, t2, lds2, s, q2);
+        else if (plain) hipLaunchKernelGGL(k_lex_wp_plain<4>, g2, t2, lds2, s, q2);
+        else hipLaunchKernelGGL((k_lex_wp_flat<64, ClsWin, false, 4, false, false, true>), g2, t2, lds2, s, q2);
+        return;
+    }
+    const dim3 g((unsigned)blocks), t(64); const size_t lds = lex_lds_bytes(q, 64);
+    if (has_any) hipLaunchKernelGGL((k_lex_wp_flat<64, ClsWin, true, 1, false>), g, t, lds, s, q);
+    else if (p.stats) hipLaunchKernelGGL((k_lex_wp_flat<64, ClsWin, false, 3, true>), g, t, lds, s, q);
+    else hipLaunchKernelGGL((k_lex_wp_flat<64, ClsWin, false, 3, false>), g, t, lds, s, q);     // three transitions per vote: swept on MI355X
 }
 
 // ------------------------------------------------------------------------------------------
@@ -759,7 +733,6 @@ void launch_wp_wave(const WpWaveParams &p, int variant, hipStream_t s)
     if (cfg == 1) launch_wp_wave_cfg<L, 2, 3, 4>(p, grab, per_cu, s);
     else if (cfg == 2) launch_wp_wave_cfg<L, 1, 4, 4>(p, grab, per_cu, s);
     else if (cfg == 3) launch_wp_wave_cfg<L, 1, 2, 4>(p, grab, per_cu, s);
-    else if (cfg == 4) launch_wp_wave_cfg<L, 1, 3, 5>(p, grab, per_cu, s);
     else if (cfg == 5) launch_wp_wave_cfg<L, 2, 2, 4>(p, grab, per_cu, s);
     else launch_wp_wave_cfg<L, 1, 3, 4>(p, grab, per_cu, s);
 }
@@ -1708,7 +1681,7 @@ void launch_seg_sp(const SpSegParams &p_in, hipStream_t s)
     hipLaunchKernelGGL(k_sp_scatter, dim3(bsort), dim3(256), 0, s, p);
     if (p.S.kind == SG_KIND_UNIGRAM) {
         // sequential form (experiments, and models outside the lane program's limits: entries longer than 32 symbols or ids >= 2^20 - 2)
-        if (p.variant == 1 || !p.lane_ok) hipLaunchKernelGGL(k_seg_unigram, dim3(b64), dim3(64), 0, s, p);
+        if (!p.lane_ok) hipLaunchKernelGGL(k_seg_unigram, dim3(b64), dim3(64), 0, s, p);
         else {
             int ring = 1; while (ring < p.trie_depth) ring <<= 1;
             const size_t lds = (size_t)ring * 64 * (sizeof(double) + sizeof(uint32_t));

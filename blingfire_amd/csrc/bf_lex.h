@@ -372,8 +372,8 @@ struct LexLane {
         int tag; uint32_t f_ini = 0, f_ini_l = 0;
         if (!call) tag = (int)(inf & 0x7FFFFFFFu);
         else { const int32_t *a = L.acts + inf; tag = a[2]; f_ini = (uint32_t)a[5]; f_ini_l = (uint32_t)a[6]; }
-        int from2 = from; if (from2 < 0) from2 = 0;                  // left = right = 0: the clamps of FALexTools_t.h:316-329 only see from == -1
-        const int t2 = fp;
+        int from2 = from; if (from2 < 0) from2 = 0;                  // left = right = 0: the clamps of FALexTools_t.h:316-329 only see from == -1 ...
+        const int t2 = fp < fn_ ? fp : fn_ - 1;                      // ... and a match on the right anchor (FinalPos == InSize, :280-290)
         // tag != 0 always (a SIMPLE action has tag > 0, a calling one tag != 0: checked at load)
         if (emitted >= max_triples) { stop = true; return; }         // output buffer full (FALexTools_t.h:337-340)
         ++emitted; last_to = t2 + off;

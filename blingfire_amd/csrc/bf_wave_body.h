@@ -55,14 +55,14 @@ struct WpWave {
     bool fast_ok;                    // run and solo tokens are both "WORD, call the same function": their units need no action lookup
     bool err;                        // per lane: this lane saw invalid UTF-8 in the current document
     uint64_t pf_own;                 // per lane: its 8 bytes of the next chunk
-    unsigned long long st_trips, st_win, st_slow, st_tok, st_steps, st_ret, st_rewalk, st_idle, st_dec;
+    unsigned long long st_trips, st_win, st_slow, st_tok, st_steps, st_ret, st_rewalk, st_idle, st_dec, st_gath, st_trans;
 
     BF_WVD WpWave(const WpWaveParams &p_, const WpWaveCold &cold_, LDS &S_, const uint16_t *ascii_, const int32_t *acts_) : p(p_), cold(cold_), S(S_), ascii(ascii_), acts(acts_)
     {
         lane = wv::lane(); rhi = rlo = 0; q_tail = q_issue = q_retire = 0; dt_head = dt_tail = 0;
         dnext = dend = dbase = off_lane = 0; have_doc = exiting = false;
         s = nullptr; n = 0; rbase = 0; dec_bytes = dec = done = bom = 0; open_start = -1; curk = 0; err = false; pf_own = 0;
-        st_trips = st_win = st_slow = st_tok = st_steps = st_ret = st_rewalk = st_idle = st_dec = 0;
+        st_trips = st_win = st_slow = st_tok = st_steps = st_ret = st_rewalk = st_idle = st_dec = st_gath = st_trans = 0;
         // the action of a run token and of a solo token (bf_model.cpp): the usual case is one calling WORD action for both
         fast_ok = false; fn_ini = 0; fn_ini_l = LX_NO_STATE;
         if (!cold.no_fast && !(p.loop_info & LX_INFO_SIMPLE) && !(p.solo_info & LX_INFO_SIMPLE)) {
@@ -487,7 +487,10 @@ struct WpWave {
 #pragma unroll
             for (int st = 0; st < STEPS; ++st) {
 #pragma unroll
-                for (int i = 0; i < NU; ++i) unit_step(u[i]);
+                for (int i = 0; i < NU; ++i) {
+                    if (STATS) { st_gath += 64; st_trans += (unsigned long long)__builtin_popcountll(wv::ballot(u[i].walk != 0)); }
+                    unit_step(u[i]);
+                }
             }
             ran = true;
         }
@@ -674,6 +677,7 @@ struct WpWave {
         if (STATS && lane == 0) {
             wv::atomic_add(&cold.stats[0], st_trips); wv::atomic_add(&cold.stats[1], st_win); wv::atomic_add(&cold.stats[2], st_slow); wv::atomic_add(&cold.stats[3], (unsigned long long)q_tail);
             wv::atomic_add(&cold.stats[4], st_steps); wv::atomic_add(&cold.stats[5], st_ret); wv::atomic_add(&cold.stats[7], st_idle); wv::atomic_add(&cold.stats[8], st_dec);
+            wv::atomic_add(&cold.stats[9], st_gath); wv::atomic_add(&cold.stats[10], st_trans);
         }
         if (STATS) { const unsigned long long r = st_rewalk; if (r) wv::atomic_add(&cold.stats[6], r); }
     }

@@ -18,6 +18,9 @@
 #define BLINGFIRETOKDLL_AMD_H
 
 #include <stdint.h>
+#ifndef __cplusplus
+#include <stdbool.h>
+#endif
 
 /* The library is built with -fvisibility=hidden: only the entry points declared here (and the experiment knobs of
  * blingfire_amd/csrc/bf_internal.h) are exported. */
@@ -146,7 +149,7 @@ BF_API int IdsToTextBatchDevice(void *ModelPtr, const int32_t *d_ids, const int6
                          int64_t text_cap, int64_t *d_text_offsets_out, int skip_special, void *stream);
 
 /* reference tokdll:1669-1679 */
-BF_API int SetNoDummyPrefix(void *ModelPtr, int fNoDummyPrefix);
+BF_API int SetNoDummyPrefix(void *ModelPtr, bool fNoDummyPrefix);
 
 /* reference tokdll:818-915 (blingfiretokdll.def: WordHyphenationWithModel).  The hyphenation engine is NOT on the TextToIds path
  * and is not part of this library: the symbol exists so that consumers that bind every export by name

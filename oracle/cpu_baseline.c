@@ -112,6 +112,73 @@ double bfc_text_to_ids_hashes(const char *lib_path, const char *model_path, cons
     return run_passes(lib_path, model_path, text, doc_off, ndocs, max_ids, unk, nthreads, 1, total_ids, NULL, out_counts, out_hash);
 }
 
+/* ---- exact form of the full-shard check: every id of every document, compact, in document order.
+ * Thread t tokenises the contiguous range [t*ndocs/T, (t+1)*ndocs/T) into a buffer of its own; the buffers are then laid end to end.
+ * *out_ids is malloc()ed here (release it with bfc_free); out_off[ndocs + 1] receives the id offsets.  Returns seconds (negative on error). */
+typedef struct { t2i_fn t2i; void *model; const char *text; const int64_t *off; int64_t d0, d1; int max_ids, unk; int32_t *ids; int64_t n, cap; int64_t *counts; int err; } cjob_t;
+
+static void *cworker(void *arg)
+{
+    cjob_t *j = (cjob_t *)arg;
+    for (int64_t d = j->d0; d < j->d1; ++d) {
+        if (j->n + j->max_ids > j->cap) {
+            int64_t nc = j->cap * 2 + j->max_ids + 1024;
+            int32_t *q = (int32_t *)realloc(j->ids, sizeof(int32_t) * (size_t)nc);
+            if (!q) { j->err = 1; return NULL; }
+            j->ids = q; j->cap = nc;
+        }
+        int n = j->t2i(j->model, j->text + j->off[d], (int)(j->off[d + 1] - j->off[d]), j->ids + j->n, j->max_ids, j->unk);
+        if (n < 0) n = 0;
+        j->counts[d] = n; j->n += n;
+    }
+    return NULL;
+}
+
+double bfc_text_to_ids_compact(const char *lib_path, const char *model_path, const char *text, const int64_t *doc_off, int64_t ndocs,
+                               int max_ids, int unk, int nthreads, int32_t **out_ids, int64_t *out_off)
+{
+    void *lib = dlopen(lib_path, RTLD_NOW | RTLD_LOCAL);
+    if (!lib) { fprintf(stderr, "cpu_baseline: dlopen(%s): %s\n", lib_path, dlerror()); return -1.0; }
+    load_fn load = (load_fn)dlsym(lib, "LoadModel");
+    free_fn fre = (free_fn)dlsym(lib, "FreeModel");
+    t2i_fn t2i = (t2i_fn)dlsym(lib, "TextToIds");
+    if (!load) { load = (load_fn)dlsym(lib, "bfo_load_model"); fre = (free_fn)dlsym(lib, "bfo_free_model"); t2i = (t2i_fn)dlsym(lib, "bfo_text_to_ids"); }
+    if (!load || !fre || !t2i) { fprintf(stderr, "cpu_baseline: missing symbols in %s\n", lib_path); return -2.0; }
+    void *model = load(model_path);
+    if (!model) { fprintf(stderr, "cpu_baseline: LoadModel(%s) failed\n", model_path); return -3.0; }
+    if (nthreads < 1) nthreads = 1;
+    if (nthreads > MAX_THREADS) nthreads = MAX_THREADS;
+    if (max_ids < 0) max_ids = 0;
+    static pthread_t th[MAX_THREADS]; static cjob_t jobs[MAX_THREADS];
+    struct timespec t0, t1;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    for (int t = 0; t < nthreads; ++t) {
+        memset(&jobs[t], 0, sizeof(cjob_t));
+        jobs[t].t2i = t2i; jobs[t].model = model; jobs[t].text = text; jobs[t].off = doc_off; jobs[t].max_ids = max_ids; jobs[t].unk = unk;
+        jobs[t].d0 = ndocs * t / nthreads; jobs[t].d1 = ndocs * (t + 1) / nthreads; jobs[t].counts = out_off;     /* counts first, offsets below */
+        pthread_create(&th[t], NULL, cworker, &jobs[t]);
+    }
+    int64_t total = 0; int err = 0;
+    for (int t = 0; t < nthreads; ++t) { pthread_join(th[t], NULL); total += jobs[t].n; err |= jobs[t].err; }
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    fre(model);
+    int32_t *all = err ? NULL : (int32_t *)malloc(sizeof(int32_t) * (size_t)(total > 0 ? total : 1));
+    if (!all) err = 1;
+    int64_t at = 0;
+    for (int t = 0; t < nthreads; ++t) {
+        if (!err && jobs[t].n > 0) memcpy(all + at, jobs[t].ids, sizeof(int32_t) * (size_t)jobs[t].n);
+        at += jobs[t].n;
+        free(jobs[t].ids);
+    }
+    if (err) { free(all); return -4.0; }
+    int64_t acc = 0;
+    for (int64_t d = 0; d < ndocs; ++d) { const int64_t c = out_off[d]; out_off[d] = acc; acc += c; }
+    out_off[ndocs] = acc;
+    *out_ids = all;
+    return (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+}
+void bfc_free(void *p) { free(p); }
+
 /* ---- TextToWords (BASELINE.json configs[0]): one call per line from T threads, the library's built-in model (tokdll:610-614) ---- */
 typedef int (*t2w_fn)(const char *, int, char *, int);
 typedef struct { t2w_fn f; const char *text; const int64_t *off; int64_t nlines; int tid, nthreads; int64_t out_bytes; } wjob_t;

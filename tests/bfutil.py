@@ -165,6 +165,29 @@ def cpu_doc_hashes(lib_path, model, text, off, max_ids, unk, nthreads=None):
     return secs, counts, hashes
 
 
+def cpu_ids_compact(lib_path, model, text, off, max_ids, unk, nthreads=None):
+    """TextToIds per document on host threads, every id kept: (seconds, ids int32[total], id_offsets int64[ndocs + 1]) -- the CPU side
+    of bench.py's exact full-shard check (oracle/cpu_baseline.c bfc_text_to_ids_compact)."""
+    L = ctypes.CDLL(CPUBASE_LIB)
+    f = L.bfc_text_to_ids_compact
+    f.restype = ctypes.c_double
+    f.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                  ctypes.POINTER(ctypes.POINTER(ctypes.c_int32)), ctypes.c_void_p]
+    L.bfc_free.argtypes = [ctypes.c_void_p]
+    text = np.ascontiguousarray(text, dtype=np.uint8)
+    off = np.ascontiguousarray(off, dtype=np.int64)
+    ndocs = len(off) - 1
+    id_off = np.zeros(ndocs + 1, dtype=np.int64)
+    ptr = ctypes.POINTER(ctypes.c_int32)()
+    secs = f(lib_path.encode(), model.encode(), text.ctypes.data, off.ctypes.data, ndocs, max_ids, unk, nthreads or host_threads(), ctypes.byref(ptr), id_off.ctypes.data)
+    if secs < 0:
+        raise RuntimeError("cpu baseline driver failed (%s)" % secs)
+    n = int(id_off[-1])
+    ids = np.ctypeslib.as_array(ptr, shape=(max(n, 1),))[:n].copy()
+    L.bfc_free(ptr)
+    return secs, ids, id_off
+
+
 def cpu_text_to_words_time(lib_path, text, off, nthreads=1, passes=3):
     """best-of-`passes` seconds for one TextToWords call per line (built-in model) through oracle/libcpubaseline.so; returns (seconds, output bytes)"""
     L = ctypes.CDLL(CPUBASE_LIB)
