@@ -63,6 +63,7 @@ def parse_args():
     ap.add_argument("--cpu-sample-docs", type=int, default=0)
     ap.add_argument("--verify", default="full", help="'full' (default): every document of the shard against the CPU checker; N: the first N; 0: none")
     ap.add_argument("--no-extra-timings", action="store_true", help="skip the PCIe-inclusive / host-API timings and the lexer transition count")
+    ap.add_argument("--inproc", action="store_true", help="N GPUs from ONE process through the library (BfSetDevices + the per-range handles, a thread per device) instead of N ranks")
     return ap.parse_args()
 
 
@@ -188,10 +189,140 @@ def run_config1(args):
     print(json.dumps(res), flush=True)
 
 
+def run_inproc(args):
+    """N GPUs of this node from ONE process, through the library's own multi-device state (BfSetDevices): the corpus is split into the
+    library's ranges (BfShardRanges: contiguous, byte-balanced), range g is made resident on device g and tokenised by a host thread of
+    its own through the per-range handle (BfShardHandle) -- same static shard, no collective, as the N-rank form, with the tables
+    replicated by the library instead of by N processes.  BF_BENCH_SHARE_GPU=1 (testing only) puts every range on device 0."""
+    import threading
+    import numpy as np
+    import torch
+    import bfutil
+    import blingfire_amd as bf
+    share = os.environ.get("BF_BENCH_SHARE_GPU") == "1"
+    G = args.gpus
+    have = torch.cuda.device_count()
+    if have < G and not share:
+        sys.stderr.write("bench: --gpus %d --inproc but this box exposes %d GPU(s)\n" % (G, have))
+        sys.exit(2)
+    dev_ids = [0 if share else g for g in range(G)]
+    wl = bfutil.WORKLOADS[args.workload]
+    model_name = args.model or wl["model"] or bfutil.bert_model_name()
+    max_ids, unk = wl["max_ids"], wl["unk"]
+    total_docs = args.docs or (args.docs_per_gpu * G if args.docs_per_gpu else TOTAL_DOCS[args.workload])
+    text, off = bfutil.gen_workload(args.workload, total_docs)
+    torch.cuda.set_device(dev_ids[0])
+    h = bf.load_model(bfutil.model_path(model_name))
+    kind = bf.lib().BfModelKind(h)
+    if args.variant >= 0:
+        bf.lib().BfSetVariant(h, args.variant)
+    bf.set_devices(h, dev_ids)
+    bounds = bf.shard_ranges(off, G)
+    per_doc_ws = (int(off[-1]) / max(total_docs, 1) + 1) * (6 if kind == 0 else 44)
+    parts = []
+    for g in range(G):
+        lo, hi = int(bounds[g]), int(bounds[g + 1])
+        dev = torch.device("cuda", dev_ids[g])
+        nd = hi - lo
+        sub = max(1, min(max(nd, 1), int(64e9 / per_doc_ws)))
+        batches = []
+        for d0 in range(lo, hi, sub):
+            d1 = min(hi, d0 + sub)
+            b0, b1 = int(off[d0]), int(off[d1])
+            cap = max(1, min(2 * (b1 - b0 + d1 - d0), (d1 - d0) * max_ids))
+            batches.append(dict(d0=d0, d1=d1, text=torch.from_numpy(text[b0:b1]).to(dev), off=torch.from_numpy(off[d0:d1 + 1] - b0).to(dev),
+                                ids=torch.empty(cap, dtype=torch.int32, device=dev), id_off=torch.empty(d1 - d0 + 1, dtype=torch.int64, device=dev)))
+        parts.append(dict(g=g, dev=dev, h=bf.shard_handle(h, g), lo=lo, hi=hi, batches=batches, secs=0.0, kms=np.zeros(5)))
+
+    def run_part(pt, steps, barrier=None, collect=False):
+        torch.cuda.set_device(pt["dev"])
+        st = torch.cuda.Stream(pt["dev"])
+        with torch.cuda.stream(st):
+            if barrier is not None:
+                barrier.wait()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                for b in pt["batches"]:
+                    bf.text_to_ids_batch_device(pt["h"], b["text"], b["off"], max_ids, unk, out_ids=b["ids"], out_off=b["id_off"])
+                    if collect:
+                        pt["kms"] += np.array(bf.last_kernel_ms(pt["h"]), dtype=np.float64)
+            st.synchronize()
+            pt["secs"] = time.perf_counter() - t0
+
+    def run_all(steps, collect=False):
+        bar = threading.Barrier(G + 1)
+        th = [threading.Thread(target=run_part, args=(pt, steps, bar, collect)) for pt in parts]
+        for t in th:
+            t.start()
+        bar.wait()
+        t0 = time.perf_counter()
+        for t in th:
+            t.join()
+        return time.perf_counter() - t0
+
+    # ---- parity gate: every document of every range, exactly
+    run_all(1)
+    lib_path, ck_kind = bfutil.checker_lib_path()
+    nv = total_docs if args.verify == "full" else min(int(args.verify), total_docs)
+    verified, verify_secs = 0, 0.0
+    for pt in parts:
+        for b in pt["batches"]:
+            if b["d0"] >= nv:
+                break
+            z = min(b["d1"], nv)
+            k = z - b["d0"]
+            secs, c_ids, c_off = bfutil.cpu_ids_compact(lib_path, bfutil.model_path(model_name), text[off[b["d0"]]:off[z]], off[b["d0"]:z + 1] - off[b["d0"]], max_ids, unk)
+            verify_secs += secs
+            g_off = b["id_off"][:k + 1].cpu().numpy()
+            if not (np.array_equal(g_off, c_off) and bool(torch.equal(b["ids"][:int(g_off[k])], torch.from_numpy(c_ids).to(pt["dev"])))):
+                raise SystemExit("bench: GPU ids of range %d differ from the CPU checker (%s) -- refusing to time" % (pt["g"], ck_kind))
+            verified += k
+    if args.warmup:
+        run_all(args.warmup)
+    for pt in parts:
+        pt["kms"][:] = 0
+    elapsed = run_all(args.steps, collect=True)
+    ranks = []
+    for pt in parts:
+        props = torch.cuda.get_device_properties(pt["dev"])
+        try:
+            pci = "%04x:%02x:%02x" % (props.pci_domain_id, props.pci_bus_id, props.pci_device_id)
+        except Exception:
+            pci = None
+        n_ids = sum(int(b["id_off"][-1].item()) for b in pt["batches"])
+        ranks.append({"rank": pt["g"], "device": pt["dev"].index, "name": props.name, "pci": pci, "cus": props.multi_processor_count, "docs": pt["hi"] - pt["lo"],
+                      "bytes": int(off[pt["hi"]] - off[pt["lo"]]), "ids": n_ids, "seconds": pt["secs"], "status": bf.lib().BfLastStatus(pt["h"]),
+                      "kernel_ms": [float(x) / max(args.steps, 1) for x in pt["kms"]]})
+    bytes_all, ids_all = int(off[-1]), sum(r["ids"] for r in ranks)
+    slow = max(parts, key=lambda q: q["secs"])
+    tok_ms = float(slow["kms"][1]) / max(args.steps, 1)
+    alg = int(off[slow["hi"]] - off[slow["lo"]]) + 4 * ranks[slow["g"]]["ids"] + 16 * (slow["hi"] - slow["lo"])
+    bf.lib().BfTokeniseKernel.restype = ctypes.c_char_p
+    bf.lib().BfTokeniseKernel.argtypes = [ctypes.c_void_p]
+    kernel_name = (bf.lib().BfTokeniseKernel(ctypes.c_void_p(h)) or b"").decode()
+    achieved = alg / (tok_ms * 1e-3) / 1e9 if tok_ms > 0 else 0.0
+    res = {"metric": "docs/sec", "value": total_docs * args.steps / elapsed, "unit": "docs/s", "n_gpus": G, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
+           "config": {"workload": "%s: %s TextToIds, %d documents in total, %.0f B/doc avg, max_ids %d, unk %d" % (args.workload, model_name, total_docs, bytes_all / max(total_docs, 1), max_ids, unk),
+                      "model_file": model_name, "total_docs": total_docs, "total_bytes": bytes_all, "total_ids": ids_all, "launcher": "inproc",
+                      "sharding": "BfSetDevices: contiguous byte-balanced document ranges (BfShardRanges), a host thread per device, no collective"},
+           "gb_input_per_sec": bytes_all * args.steps / elapsed / 1e9, "ids_per_sec": ids_all * args.steps / elapsed,
+           "roofline": {"bound": "hbm", "kernel": "tokenise (%s), slowest range" % kernel_name, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                        "frac": achieved / HBM_PEAK_GBPS, "traffic": None, "algorithmic_bytes_per_launch": alg},
+           "cpu_baseline": None,
+           "verified_docs": verified, "verify": {"checker": ck_kind, "seconds": verify_secs, "method": "exact: id offsets and every id of every document against the CPU checker (array equality)"},
+           "status": max(r["status"] for r in ranks), "ranks": ranks, "backend": None}
+    bf.free_model(h)
+    print(json.dumps(res))
+    return 0
+
+
 def main():
     args = parse_args()
     if args.workload == "config1":
         return run_config1(args)
+    if args.inproc:
+        return run_inproc(args)
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(spawn_ranks(args))
 

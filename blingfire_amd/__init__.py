@@ -99,6 +99,14 @@ def lib():
         L.DictGetInfoBatch.argtypes = [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]
         L.DictGetInfoBatchDevice.restype = c_int
         L.DictGetInfoBatchDevice.argtypes = [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p]
+        L.BfSetDevices.restype = c_int
+        L.BfSetDevices.argtypes = [c_void_p, c_void_p, c_int]
+        L.BfShardHandle.restype = c_void_p
+        L.BfShardHandle.argtypes = [c_void_p, c_int]
+        L.BfShardRanges.restype = c_int
+        L.BfShardRanges.argtypes = [c_void_p, c_int64, c_int, c_void_p]
+        L.BfSetLexStats.restype = c_int
+        L.BfSetLexStats.argtypes = [c_void_p, c_int]
         L.BfReserve.restype = c_int
         L.BfReserve.argtypes = [c_void_p, c_int64, c_int64, c_int]
         L.NormalizeSpaces.restype = c_int
@@ -312,6 +320,30 @@ def pack_docs(docs):
         np.cumsum([len(b) for b in bs], out=off[1:])
     text = np.frombuffer(b"".join(bs), dtype=np.uint8) if bs else np.zeros(0, dtype=np.uint8)
     return text, off
+
+
+def set_devices(h, device_ids):
+    """Range-shards the host-buffer batch calls of h over the listed devices of this node (BfSetDevices: tables replicated, contiguous
+    byte-balanced document ranges, one host thread per device, no collective).  A device may be listed more than once."""
+    arr = (c_int * len(device_ids))(*[int(d) for d in device_ids])
+    r = lib().BfSetDevices(c_void_p(h), arr, len(device_ids))
+    if r != 0:
+        raise RuntimeError("BfSetDevices failed (%d): %s" % (r, lib().BfLastError().decode("utf-8", "replace")))
+
+
+def shard_handle(h, g):
+    """the handle that tokenises range g after set_devices (None past the last range); owned by h"""
+    return lib().BfShardHandle(c_void_p(h), int(g))
+
+
+def shard_ranges(doc_offsets, G):
+    """document ranges a batch is split into over G devices: int64[G + 1] (BfShardRanges; no device needed)"""
+    off = np.ascontiguousarray(doc_offsets, dtype=np.int64)
+    bounds = np.zeros(G + 1, dtype=np.int64)
+    r = lib().BfShardRanges(off.ctypes.data, len(off) - 1, G, bounds.ctypes.data)
+    if r != 0:
+        raise RuntimeError("BfShardRanges failed (%d)" % r)
+    return bounds
 
 
 def text_to_ids_batch(h, docs, max_len, unk=0):

@@ -159,10 +159,15 @@ struct Handle {
     hipStream_t stream = nullptr;
     hipEvent_t ev[EV_COUNT] = {};
     bool ev_valid = false;
+    // BfSetDevices: the devices a host batch is range-sharded over.  shards[g] tokenises range g; entry 0 is this handle itself when the
+    // first device is its own, every other entry a handle of its own (tables, workspaces, streams) on its device
+    std::vector<Handle *> shards;
     HostPipe pipe;                                              // chunked host-buffer path (run_host_chunked)
     int64_t host_chunk_bytes = 128ll << 20;                     // its largest chunk (BfSetHostChunkBytes; 0 = never chunk); batches of at least this size take it
     ~Handle()
     {
+        for (Handle *c : shards) if (c && c != this) { DeviceGuard dg(c->device); (void)hipDeviceSynchronize(); delete c; }
+        shards.clear();
         pipe.release();
         for (DevBuf *b : {&t_dk_l1, &t_dk_pages, &t_dn_l1, &t_dn_pages, &t_dn_pool, &t_k2i, &t_rows, &w_keys, &w_keyoff, &w_dids, &w_dret, &w_vals, &t_i2w_off, &t_i2w_data, &t_kind, &t_wbd, &t_info, &t_acts, &t_cp_l1, &t_cp_pages, &t_multi, &t_wcp_l1, &t_wcp_pages, &t_dict, &t_seginfo, &w_s1, &w_s2, &w_s3, &w_s4, &w_big, &w_perm, &w_hist, &w_narcs, &w_cls, &w_nchars, &w_tmp, &w_counts, &w_flags, &w_out, &w_outoff,
                           &w_bsums, &w_misc, &w_text, &w_docoff, &w_ids, &w_idoff, &w_starts, &w_ends, &w_srcoff, &w_span}) b->release();
@@ -895,6 +900,79 @@ int text_to_ids_one(void *hp, const char *s, int n, int32_t *ids, int max_ids, i
     return me.result;
 }
 
+// Static contiguous range shard of a batch over G devices, byte-balanced: range g = documents
+// [bounds[g], bounds[g + 1]), where bounds[g] is the document boundary closest to g/G of the text (the earlier one on a tie).
+void shard_bounds(const int64_t *doc_off, int64_t ndocs, int G, int64_t *bounds)
+{
+    const int64_t base = ndocs > 0 ? doc_off[0] : 0, total = ndocs > 0 ? doc_off[ndocs] - base : 0;
+    bounds[0] = 0; bounds[G] = ndocs;
+    for (int g = 1; g < G; ++g) {
+        const int64_t target = base + (int64_t)((__int128)total * g / G);
+        const int64_t *it = std::lower_bound(doc_off, doc_off + ndocs + 1, target);       // first boundary at or behind the target
+        int64_t d = it - doc_off;
+        if (d > ndocs) d = ndocs;
+        if (d > 0 && target - doc_off[d - 1] <= doc_off[d] - target) --d;                 // the boundary before it is at least as close
+        if (d < bounds[g - 1]) d = bounds[g - 1];
+        bounds[g] = d;
+    }
+}
+
+// TextToIdsBatch of a handle with several devices: one host thread per range, each through its own handle (run_host: copies in,
+// kernels, copies out on that device); the ranges' ids are then laid end to end and the offsets rebased -- the caller sees exactly
+// what one device would have returned.
+int64_t run_host_sharded(Handle *h, const char *text, const int64_t *doc_off, int64_t ndocs, int32_t *ids_out, int64_t ids_cap,
+                         int64_t *id_off_out, int max_ids, int unk, int32_t *starts_out, int32_t *ends_out)
+{
+    const int G = (int)h->shards.size();
+    const bool want_off = starts_out && ends_out;
+    if (ndocs < 0 || !doc_off || (ndocs > 0 && !text && doc_off[ndocs] > doc_off[0])) return BF_E_ARG;
+    std::vector<int64_t> bounds((size_t)G + 1);
+    shard_bounds(doc_off, ndocs, G, bounds.data());
+    struct Part { std::vector<int32_t> ids, st, en; std::vector<int64_t> off; int64_t r = 0; };
+    std::vector<Part> parts((size_t)G);
+    try {
+        for (int g = 0; g < G; ++g) {
+            const int64_t nd = bounds[(size_t)g + 1] - bounds[(size_t)g];
+            const int64_t bytes = nd > 0 ? doc_off[bounds[(size_t)g + 1]] - doc_off[bounds[(size_t)g]] : 0;
+            int64_t worst = h->m.kind == KIND_WP ? bytes : (int64_t)(h->m.dict_has_charmap ? 2 : 1) * (bytes + nd);
+            if (max_ids >= 0 && nd * (int64_t)max_ids < worst) worst = nd * (int64_t)max_ids;
+            parts[(size_t)g].ids.resize((size_t)worst + 1);
+            if (want_off) { parts[(size_t)g].st.resize((size_t)worst + 1); parts[(size_t)g].en.resize((size_t)worst + 1); }
+            parts[(size_t)g].off.assign((size_t)nd + 1, 0);
+        }
+    } catch (const std::bad_alloc &) { g_last_error = "out of host memory for the per-device id buffers"; return BF_E_DEVICE; }
+    std::vector<std::thread> th;
+    for (int g = 0; g < G; ++g) {
+        th.emplace_back([&, g]() {
+            Part &pt = parts[(size_t)g];
+            const int64_t lo = bounds[(size_t)g], nd = bounds[(size_t)g + 1] - lo;
+            pt.r = nd == 0 ? 0 : run_host(h->shards[(size_t)g], text, doc_off + lo, nd, pt.ids.data(), (int64_t)pt.ids.size(), pt.off.data(), max_ids, unk,
+                                          want_off ? pt.st.data() : nullptr, want_off ? pt.en.data() : nullptr);
+        });
+    }
+    for (auto &t : th) t.join();
+    int64_t total = 0;
+    for (int g = 0; g < G; ++g) { if (parts[(size_t)g].r < 0) return parts[(size_t)g].r; total += parts[(size_t)g].r; }
+    if (total > ids_cap) return BF_E_CAPACITY;
+    if (total > 0 && !ids_out) return BF_E_ARG;
+    std::vector<std::thread> cp;
+    int64_t at = 0;
+    for (int g = 0; g < G; ++g) {
+        const int64_t base = at; at += parts[(size_t)g].r;
+        cp.emplace_back([&, g, base]() {
+            Part &pt = parts[(size_t)g];
+            if (pt.r > 0) {
+                memcpy(ids_out + base, pt.ids.data(), (size_t)pt.r * 4);
+                if (want_off) { memcpy(starts_out + base, pt.st.data(), (size_t)pt.r * 4); memcpy(ends_out + base, pt.en.data(), (size_t)pt.r * 4); }
+            }
+            if (id_off_out) { const int64_t lo = bounds[(size_t)g], nd = bounds[(size_t)g + 1] - lo; for (int64_t i = 0; i < nd; ++i) id_off_out[lo + i] = base + pt.off[(size_t)i]; }
+        });
+    }
+    for (auto &t : cp) t.join();
+    if (id_off_out) id_off_out[ndocs] = total;
+    return total;
+}
+
 int64_t text_batch_host(void *p, const char *text, const int64_t *doc_off, int64_t ndocs, char *text_out, int64_t text_cap, int64_t *text_off_out, int mode)
 {
     Handle *h = p ? as_handle(p) : (mode == 2 ? default_sbd() : default_wbd());
@@ -1335,7 +1413,55 @@ int64_t TextToIdsBatch(void *p, const char *text, const int64_t *doc_offsets, in
 {
     Handle *h = as_handle(p);
     if (!h) return BF_E_ARG;
+    if (h->shards.size() > 1) return run_host_sharded(h, text, doc_offsets, ndocs, ids_out, ids_cap, id_offsets_out, max_ids_per_doc, unk, nullptr, nullptr);
     return run_host(h, text, doc_offsets, ndocs, ids_out, ids_cap, id_offsets_out, max_ids_per_doc, unk);
+}
+
+/* Range-shards the host-buffer batch calls of this handle over n devices: the model's tables are replicated
+ * on every listed device, TextToIdsBatch / TextToIdsWithOffsetsBatch split a batch into n contiguous byte-balanced document ranges,
+ * one host thread, stream set and workspace per device, and return exactly what one device would have returned.  A device may be
+ * listed more than once (logical shards).  n == 1 with the handle's own device ends sharding.  The ...BatchDevice calls and the
+ * single-document calls stay on the handle's own device; BfShardHandle(h, g) is the handle of range g for callers that keep their
+ * shards resident on the devices themselves.  Returns 0 or BF_E_*. */
+int BfSetDevices(void *p, const int *device_ids, int n)
+{
+    Handle *h = as_handle(p);
+    if (!h || !device_ids || n < 1 || n > 64) return BF_E_ARG;
+    if (h->m.kind == KIND_I2W) return BF_E_UNSUPPORTED;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess) return BF_E_DEVICE;
+    for (int i = 0; i < n; ++i) if (device_ids[i] < 0 || device_ids[i] >= ndev) return BF_E_ARG;
+    std::lock_guard<std::mutex> lock(h->mu);
+    for (Handle *c : h->shards) if (c && c != h) { DeviceGuard dg(c->device); (void)hipDeviceSynchronize(); delete c; }
+    h->shards.clear();
+    if (n == 1 && device_ids[0] == h->device) return 0;
+    std::vector<Handle *> sh;
+    for (int i = 0; i < n; ++i) {
+        if (i == 0 && device_ids[0] == h->device) { sh.push_back(h); continue; }
+        DeviceGuard dg(device_ids[i]);
+        Handle *c = dg.ok ? make_handle(h->m.image.data(), h->m.image.size()) : nullptr;
+        if (!c) { for (Handle *q : sh) if (q != h) delete q; return BF_E_DEVICE; }
+        c->m.no_dummy_prefix = h->m.no_dummy_prefix; c->variant = h->variant; c->host_chunk_bytes = h->host_chunk_bytes;
+        sh.push_back(c);
+    }
+    h->shards.swap(sh);
+    return 0;
+}
+
+void *BfShardHandle(void *p, int g)
+{
+    Handle *h = as_handle(p);
+    if (!h) return nullptr;
+    if (h->shards.empty()) return g == 0 ? (void *)h : nullptr;
+    return (g >= 0 && (size_t)g < h->shards.size()) ? (void *)h->shards[(size_t)g] : nullptr;
+}
+
+/* the document ranges a batch would be split into over G devices: bounds[0 .. G], range g = [bounds[g], bounds[g + 1]) (pure host arithmetic) */
+int BfShardRanges(const int64_t *doc_offsets, int64_t ndocs, int G, int64_t *bounds)
+{
+    if (!doc_offsets || !bounds || ndocs < 0 || G < 1) return BF_E_ARG;
+    shard_bounds(doc_offsets, ndocs, G, bounds);
+    return 0;
 }
 
 int64_t TextToIdsWithOffsetsBatch(void *p, const char *text, const int64_t *doc_offsets, int64_t ndocs, int32_t *ids_out, int32_t *starts_out,
@@ -1343,6 +1469,7 @@ int64_t TextToIdsWithOffsetsBatch(void *p, const char *text, const int64_t *doc_
 {
     Handle *h = as_handle(p);
     if (!h) return BF_E_ARG;
+    if (h->shards.size() > 1 && starts_out && ends_out) return run_host_sharded(h, text, doc_offsets, ndocs, ids_out, cap, id_offsets_out, max_ids_per_doc, unk, starts_out, ends_out);
     return run_host(h, text, doc_offsets, ndocs, ids_out, cap, id_offsets_out, max_ids_per_doc, unk, starts_out, ends_out);
 }
 

@@ -239,6 +239,21 @@ BF_API int BfModelKind(void *ModelPtr);
  * Returns 0 or BF_E_*. */
 BF_API int BfReserve(void *ModelPtr, int64_t max_docs, int64_t max_bytes, int want_offsets);
 
+/* Multi-GPU (SURVEY.md section 8b "SetDevices", 8e): range-shards the HOST-buffer batch calls of this handle (TextToIdsBatch,
+ * TextToIdsWithOffsetsBatch) over n devices of this node.  The tables are replicated on every listed device; a batch is split into
+ * n contiguous, byte-balanced document ranges (BfShardRanges), each tokenised by a host thread of its own on its own device, stream set
+ * and workspace; ids and offsets come back exactly as one device would have returned them (no collective: documents are independent).
+ * A device may be listed more than once (logical shards on one device).  BfSetDevices(h, &own_device, 1) ends sharding.
+ * The ...BatchDevice calls (their buffers live on ONE device) and the single-document calls stay on the handle's own device; a caller
+ * that keeps its shards resident on the devices itself takes the per-range handles with BfShardHandle(h, g) (NULL past the last range;
+ * owned by h, released by FreeModel(h) / the next BfSetDevices) and calls TextToIdsBatchDevice on each from a thread of its own.
+ * Reference semantics preserved per document: blingfiretokdll.cpp:1619-1646.  Returns 0 or BF_E_*. */
+BF_API int BfSetDevices(void *ModelPtr, const int *device_ids, int n);
+BF_API void *BfShardHandle(void *ModelPtr, int g);
+/* the ranges a batch is split into over G devices: bounds[0 .. G], range g = documents [bounds[g], bounds[g + 1]): bounds[g] is the
+ * document boundary closest to g / G of the text (pure host arithmetic, no device needed) */
+BF_API int BfShardRanges(const int64_t *doc_offsets, int64_t ndocs, int G, int64_t *bounds);
+
 #define BF_E_ARG      (-1)   /* bad argument */
 #define BF_E_DEVICE   (-2)   /* HIP error */
 #define BF_E_CAPACITY (-3)   /* ids_cap too small */

@@ -99,3 +99,42 @@ def test_headline_corpus_properties():
             assert np.array_equal(tids[toff[d]:toff[d + 1]], ids[id_off[d]:id_off[d] + cnt[d]])
     finally:
         bf.free_model(h)
+
+
+@pytest.mark.parametrize("model", [m for m in ("bert_base_tok.bin", "bert_base_cased_tok.bin", "bert_chinese.bin") if bfutil.have_model(m)])
+def test_lane_per_document_kernels_on_unit_form_models(model, checker):
+    """the BERT lexers take the wave program (bf_wave.h) for plain ids; variant 2 keeps the lane-per-document kernels (bf_lex.h: what the
+    offsets API, TextToWords and lexers outside the unit form run) under the same parity bar on the same inputs"""
+    h = bf.load_model(bfutil.model_path(model))
+    hck = checker.load(bfutil.model_path(model))
+    try:
+        bf.lib().BfSetVariant(h, 2)
+        docs = list(bfutil.ADVERSARIAL) + bfutil.fuzz_docs(2000, seed=13)
+        for max_ids, unk in ((512, 100), (3, 100)):
+            _compare(h, checker, hck, docs, max_ids, unk)
+    finally:
+        bf.free_model(h)
+        checker.free(hck)
+
+
+def test_wave_program_long_words_and_documents(checker):
+    """what the wave program treats specially: words of 64 .. 2000 letters (window / chunk edges, the max-length cut at 300), long runs of
+    one-character tokens, a 200 KB document among short ones, documents of one byte"""
+    import random
+    rnd = random.Random(7)
+    alpha = "abcdefghijklmnopqrstuvwxyz"
+    docs = []
+    for L in [63, 64, 65, 127, 128, 129, 299, 300, 301, 511, 512, 513, 600, 1023, 1024, 1025, 2000]:
+        docs += [("a" * L).encode(), (" " + "b" * L + " c").encode(), ("x y " + "é" * L).encode(), "".join(rnd.choice(alpha) for _ in range(L)).encode(),
+                 ("好" * L).encode(), ("." * L).encode(), (" " * L).encode(), ("[UNK]" * L).encode(), ("[UN" * L).encode()]
+    docs.append(" ".join("".join(rnd.choice(alpha) for _ in range(rnd.randint(1, 12))) for _ in range(30000)).encode())
+    docs += [bytes([rnd.randrange(32, 127)]) for _ in range(300)]
+    for model in [m for m in ("bert_base_tok.bin", "bert_chinese.bin") if bfutil.have_model(m)]:
+        h = bf.load_model(bfutil.model_path(model))
+        hck = checker.load(bfutil.model_path(model))
+        try:
+            for max_ids, unk in ((1 << 20, 100), (64, 100)):
+                _compare(h, checker, hck, docs, max_ids, unk)
+        finally:
+            bf.free_model(h)
+            checker.free(hck)
