@@ -562,7 +562,6 @@ def main():
         # (3) wall clock of the C call on pageable host buffers (TextToIdsBatch)
         # -- the caller's arrays are allocated (and touched) once, outside the timed calls, like a C caller that reuses its buffers: the
         #    Python wrapper bf.text_to_ids_batch allocates a worst-case array per call, whose page faults would be most of the time
-        import ctypes
         api = []
         a_ids = np.zeros(cap, dtype=np.int32)
         a_off = np.zeros(ns + 1, dtype=np.int64)
