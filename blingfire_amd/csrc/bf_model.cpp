@@ -772,7 +772,7 @@ bool build_model(Model &m, const uint8_t *img, size_t size)
                 else if (!m.fn_no_ra) why = "a function rule uses the right anchor";
                 else if (m.max_depth < 2) why = "max-depth < 2";
                 else if (m.max_token_length < 1 || m.max_token_length > 496) why = "max token length outside 1..496";
-                else if (m.acts_pool.size() > 512) why = "more than 512 ints of action records";
+                else if (m.acts_pool.size() > 64) why = "more than 64 ints of action records";
                 // C = states behind at least one letter from the initial state (text classes only): what a top-level walk can be in
                 std::vector<uint8_t> inC((size_t)nst, 0);
                 if (why.empty()) {

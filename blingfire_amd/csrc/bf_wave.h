@@ -50,7 +50,7 @@ constexpr uint32_t WK_SOLO = 3;      // a final state without transitions: a one
 constexpr int WK_SHIFT = 14;
 
 constexpr int WV_CHUNK = 512;        // bytes decoded per step (8 per lane)
-constexpr int WV_ACTS_MAX = 512;     // ints of action records a unit-form lexer may have (bf_model.cpp)
+constexpr int WV_ACTS_MAX = 64;      // ints of action records a unit-form lexer may have (bf_model.cpp)
 constexpr uint32_t WV_DT_CLOSED = 1, WV_DT_BAD = 2;
 
 // what the rare paths need (non-ASCII characters, status reports, experiments): the kernel keeps a copy in LDS instead of scalar registers

@@ -17,17 +17,20 @@
 
 namespace bfa {
 
-constexpr uint32_t WV_TK_INFO = 1u << 30, WV_TK_LEN_MASK = 0x1FFu;    // token flags (WV_TK_INFO: the action is in qi[]; else the common word kind)
+constexpr uint32_t WV_TK_INFO = 1u << 30, WV_TK_LEN_MASK = 0x1FFu;
+// the action info of a top-level token in 16 bits: a SIMPLE action has a tag in 1..4, any other is an index into <= WV_ACTS_MAX ints (bf_model.cpp "unit form")
+BF_WVD uint16_t wv_pack_info(uint32_t info) { return (uint16_t)((info & LX_INFO_SIMPLE) ? (0x8000u | (info & 0x7FFFu)) : (info & 0x7FFFu)); }
+BF_WVD uint32_t wv_unpack_info(uint32_t v) { return (v & 0x8000u) ? (LX_INFO_SIMPLE | (v & 0x7FFFu)) : v; }    // token flags (WV_TK_INFO: the action is in qi[]; else the common word kind)
 
 // LDS of one wave.  QCAP / DTN / RING are powers of two.  A token: q0 = absolute ring position of its first character; q1 = length |
 // document table entry (low 8 bits of the absolute entry number) << 16 | WV_TK_* flags; qc = set by the unit: 0 while it walks, then
-// 1 + the number of ids; qi = action info (WV_TK_INFO tokens only).
+// 1 + the number of ids -- and, until the unit starts, the action of a WV_TK_INFO token (wv_pack_info: tags and action indices are small).
 template <int RING_, int QCAP_, int DTN_>
 struct WvLds {
     static constexpr int RING = RING_, QCAP = QCAP_, DTN = DTN_;
     alignas(16) uint16_t ring[RING];
     int64_t dt_slot[DTN], dt_doc[DTN];
-    uint32_t q0[QCAP], q1[QCAP], qi[QCAP];
+    uint32_t q0[QCAP], q1[QCAP];
     int32_t dt_cap[DTN], dt_cnt[DTN]; uint32_t dt_flags[DTN], dt_rbase[DTN];      // dt_rbase: ring position of the document's first character
     uint16_t qc[QCAP];
 };
@@ -86,7 +89,7 @@ struct WpWave {
     BF_WVD void put_token_info(uint32_t t, int pos, int len, uint32_t info)      // general form: any action
     {
         put_token(t, pos, len, WV_TK_INFO);
-        S.qi[t & QMASK] = info;
+        S.qc[t & QMASK] = wv_pack_info(info);
     }
 
     // ------------------------------------------------------------------------------------------------------------------
@@ -412,11 +415,12 @@ struct WpWave {
         const uint32_t ke = (w1 >> 16) & DMASK;
         u.rs = S.q0[sl]; u.L = (int)(w1 & WV_TK_LEN_MASK);
         u.home = p.ids_tmp + S.dt_slot[ke] + (int64_t)(u.rs - S.dt_rbase[ke]);
+        const uint32_t info16 = wv_unpack_info(S.qc[sl]);
         S.qc[sl] = 0;
         if (DBG >= 1) { unit_finish(u, 1); return; }
         if (!(w1 & WV_TK_INFO)) { unit_call(u, fn_ini, fn_ini_l); return; }       // a word of the common kind: the vocabulary function
         // any other action (general form of phase A; lexers whose run / solo actions differ)
-        const uint32_t info = S.qi[sl];
+        const uint32_t info = info16;
         int tag; bool call = false; uint32_t ini = 0, ini_l = LX_NO_STATE;
         if (info & LX_INFO_SIMPLE) tag = (int)(info & 0x7FFFFFFFu);
         else { const int32_t *a = acts + info; tag = a[2]; ini = (uint32_t)a[5]; ini_l = (uint32_t)a[6]; call = true; }
@@ -430,7 +434,9 @@ struct WpWave {
     BF_WVD void unit_step(Unit &u) const
     {
         const uint32_t c = (uint32_t)S.ring[(u.rs + (uint32_t)u.j) & RMASK] & LX_T_CLS_MASK;
-        const uint64_t e64 = p.T[u.state + c];
+        // a lane that is not walking reads entry 0 like every other such lane (one cache line for all of them: a divergent gather costs
+        // the memory pipeline about a cycle per distinct lane address, MI355X tools/microbench/gather.hip)
+        const uint64_t e64 = p.T[u.walk != 0 ? u.state + c : 0u];
         const uint32_t e = (uint32_t)e64;
         const bool hit = u.walk != 0 && (e & LX_T_CLS_MASK) == c;
         const bool fin = hit && (int32_t)e < 0;
