@@ -1007,6 +1007,21 @@ __global__ __launch_bounds__(64) void k_bpe_collect(SpSegParams p)
     p.narcs[d] = L > 0 ? seg_bpe_collect(p.S, cls_at, L, p.arcs + 6 * slot + 32 * d, arc_cap, p.unk) : 0;
 }
 
+// the same for the documents the arc-free k_bpe_fused handed over (narcs == BPE_COLLECT on the fallback list)
+__global__ __launch_bounds__(64) void k_bpe_collect_list(SpSegParams p)
+{
+    const unsigned int nfb = *p.fb_count;
+    for (unsigned int idx = blockIdx.x * 64u + threadIdx.x; idx < nfb; idx += gridDim.x * 64u) {
+        const int64_t d = p.fb_list[idx];
+        if (p.narcs[d] != -3 /* BPE_COLLECT */) continue;
+        const int64_t b = p.b.doc_off[d];
+        const int64_t slot = sp_slot(b, d, p.slot_mul);
+        const int arc_cap = 6 * (int)(p.slot_mul * (p.b.doc_off[d + 1] - b + 1)) + 32;
+        ClsWin cls_at; cls_at.init(p.stream, slot);
+        p.narcs[d] = seg_bpe_collect(p.S, cls_at, p.lens[d], p.arcs + 6 * slot + 32 * d, arc_cap, p.unk);
+    }
+}
+
 // BPE phase B1: sort the arcs of one document per 256-thread block (bitonic sort in LDS on the integer keys of
 // bf_seg.h; the order is total, so the result equals the reference's qsort).  Documents with more arcs than the
 // LDS holds are sorted in place in global memory by the same block (merge exchange).
@@ -1100,6 +1115,7 @@ __global__ __launch_bounds__(64) void k_bpe_apply(SpSegParams p)
 }
 
 constexpr int BPE_DONE = -2;     // narcs[d]: the document was finished by k_bpe_fused
+constexpr int BPE_COLLECT = -3;  // narcs[d]: the arc-free k_bpe_fused hands the document to the full path, which collects its arcs first (k_bpe_collect_list)
 
 // pointer of lane `o` (uniform) to every lane, through v_readlane
 __device__ __forceinline__ const void *bcast_ptr(const void *q, int o)
@@ -1244,14 +1260,33 @@ __device__ __forceinline__ bool lds_put_t(LKey *ring, int k, int seg_begin, cons
 }
 #define lds_put(ring, k, seg_begin, a, seg_first) lds_put_t<LKey, LCAP>(ring, k, seg_begin, a, seg_first, merges)
 
-template <bool MERGES, bool LOCAL>
+// ARCS = false (the default when the lane-local window can be used): the arc list is written to global memory only where somebody
+// reads it.  It used to be 16 bytes per arc for every document (29.8 GB per 1 M documents of BASELINE config 3,
+// profiles/r02_final_config3.txt) for the sake of the segments that outgrow the lane's LDS window (the wave-cooperative solve reads
+// them from global memory) and of the few documents (17 of 200,000) that fall back.  Now a lane starts writing when its open segment
+// stops fitting the window (`spill`: the arcs the window holds are written out once, the later ones as they come) and stops at the
+// next segment that fits; a document that falls back goes on the list with narcs = BPE_COLLECT and the full path collects its arcs
+// itself (k_bpe_collect_list).
+template <bool MERGES, bool LOCAL, bool ARCS = true>
 __global__ __launch_bounds__(64) void k_bpe_fused(SpSegParams p)
 {
+    static_assert(ARCS || LOCAL, "the arc-free form needs the lane-local window");
+    bool spill = ARCS;                                  // arcs of the open segment (and of the current start) go to global memory
     typedef typename BpeLocal<MERGES>::Key LKey;
     constexpr int LCAP = BpeLocal<MERGES>::CAP;
     extern __shared__ unsigned char bpe_lds_raw[];
     LKey *ring = (LKey *)bpe_lds_raw + lane_id();          // entry of arc index k at ring[(k - seg_first) * 64]
     const int lthresh = p.tune ? p.tune : 16;
+    // writes the arcs the LDS window holds ([first, first + n), keyed relative to `base`) to the document's arc list, in the reference's form
+    auto spill_window = [&](SegArc *dst, int first, int n, int base, bool mg) {
+        for (int t = 0; t < n; ++t) {
+            const LKey key = ring[t * 64];
+            const uint32_t pk = (uint32_t)key;
+            SegArc a; a.start = base + (int)((pk >> 6) & 63u); a.end = base + (int)(pk & 63u); a.id = (int32_t)(pk >> 12); a.rank_bits = 0;
+            if (mg && sizeof(LKey) == 8) { const uint32_t asc = ~(uint32_t)((unsigned long long)key >> 32); a.rank_bits = (asc & 0x80000000u) ? (asc & 0x7FFFFFFFu) : ~asc; }   // inverse of sg_key_hi
+            dst[first + t] = a;
+        }
+    };
     bool seg_local = LOCAL, cs_ok = true;                   // the open segment / the arcs of the current start are fully mirrored in the LDS window
     enum { M_NEED = 0, M_WALK = 1, M_SOLVE = 2, M_POST = 3, M_EXIT = 4, M_LSOLVE = 5 };
     const bool merges = MERGES;
@@ -1291,7 +1326,7 @@ __global__ __launch_bounds__(64) void k_bpe_fused(SpSegParams p)
                         else {
                             start = 0; i = 0; state = p.S.initial; sum = 0; unknown = true; narcs = 0; count_at_start = 0; ff = 0; cnt = 0;
                             token_start = cls_at(0) == p.S.cls_delim; fallback = false; closing_last = false; last_id = 0;
-                            seg_first = 0; seg_n = 0; seg_maxend = -1; seg_local = LOCAL; cs_ok = true;
+                            seg_first = 0; seg_n = 0; seg_maxend = -1; seg_local = LOCAL; cs_ok = true; spill = ARCS;
                             mode = M_WALK;
                         }
                     }
@@ -1435,11 +1470,15 @@ __global__ __launch_bounds__(64) void k_bpe_fused(SpSegParams p)
                             else {
                                 if (narcs == count_at_start) { cs_first_e = i; cs_first_id = r.id; }
                                 if (LOCAL) cs_ok = cs_ok && lds_put(ring, narcs, seg_n > 0 ? one_s : start, a, seg_first);
-                                arcs[narcs++] = a;
+                                if (!ARCS && !cs_ok && !spill) { spill_window(arcs, seg_first, narcs - seg_first, seg_n > 0 ? one_s : start, merges); spill = true; }
+                                if (spill) arcs[narcs] = a;
+                                ++narcs;
                             }
                         } else {                                            // whole-token arc replaces the pieces (..._bpe_t.h:189-206)
                             if (LOCAL) cs_ok = lds_put(ring, count_at_start, seg_n > 0 ? one_s : start, a, seg_first);
-                            arcs[count_at_start] = a; narcs = count_at_start + 1; ff = i; cs_first_e = i; cs_first_id = r.id;
+                            if (!ARCS && !cs_ok && !spill) { spill_window(arcs, seg_first, count_at_start - seg_first, seg_n > 0 ? one_s : start, merges); spill = true; }
+                            if (spill) arcs[count_at_start] = a;
+                            narcs = count_at_start + 1; ff = i; cs_first_e = i; cs_first_id = r.id;
                         }
                         cs_last_e = i; last_id = r.id;
                         unknown = false;
@@ -1455,17 +1494,25 @@ __global__ __launch_bounds__(64) void k_bpe_fused(SpSegParams p)
                 bool merged = false;
                 if (!closing_last && unknown) {                             // ..._bpe_t.h:212-225
                     if (0 < narcs && p.unk == last_id) {
-                        arcs[narcs - 1].end = start; merged = true;
+                        if (spill) arcs[narcs - 1].end = start;
+                        merged = true;
                         if (narcs - 1 == seg_first) one_e = start;
                         if (seg_maxend < start) seg_maxend = start;
                         if (LOCAL) {                                        // the same extension in the LDS window
-                            if (start - one_s > 62) seg_local = false;
+                            if (start - one_s > 62) {
+                                if (!ARCS && seg_local && !spill) {      // the window still holds the segment with the arc's old end: write it out, then the new end
+                                    spill_window(arcs, seg_first, narcs - seg_first, one_s, merges); arcs[narcs - 1].end = start; spill = true;
+                                }
+                                seg_local = false;
+                            }
                             else if (seg_local) { LKey *q = ring + (narcs - 1 - seg_first) * 64; *q = (*q & ~(LKey)63) | (LKey)(start - one_s); }
                         }
                     } else {
                         SegArc a; a.start = start; a.end = start; a.id = p.unk; a.rank_bits = 0;
                         if (LOCAL) cs_ok = cs_ok && lds_put(ring, narcs, seg_n > 0 ? one_s : start, a, seg_first);
-                        arcs[narcs++] = a; cs_first_e = start; cs_first_id = p.unk; cs_last_e = start; last_id = p.unk;
+                        if (!ARCS && !cs_ok && !spill) { spill_window(arcs, seg_first, narcs - seg_first, seg_n > 0 ? one_s : start, merges); spill = true; }
+                        if (spill) arcs[narcs] = a;
+                        ++narcs; cs_first_e = start; cs_first_id = p.unk; cs_last_e = start; last_id = p.unk;
                     }
                 }
                 const bool cut = seg_n > 0 && (closing_last || (!merged && start > seg_maxend));
@@ -1484,7 +1531,7 @@ __global__ __launch_bounds__(64) void k_bpe_fused(SpSegParams p)
             // ---- after the closure decision: the arcs of `start` open / join a segment; next start or end of document
             if (closing_last) {
                 p.counts[doc] = fallback ? 0 : (cnt < p.max_ids ? cnt : p.max_ids);
-                p.narcs[doc] = fallback ? narcs : BPE_DONE;
+                p.narcs[doc] = fallback ? (ARCS ? narcs : BPE_COLLECT) : BPE_DONE;
                 if (fallback) p.fb_list[atomicAdd(p.fb_count, 1u)] = (int32_t)doc;       // the full path redoes it from its arc list
                 mode = M_NEED;
             } else {
@@ -1494,6 +1541,7 @@ __global__ __launch_bounds__(64) void k_bpe_fused(SpSegParams p)
                             // the arcs of `start` were keyed relative to the old segment: re-base them to the new one (all of them start at `start`)
                             const int d0 = seg_n > 0 ? start - one_s : 0, added = narcs - count_at_start;
                             seg_local = cs_ok && added <= LCAP;
+                            if (!ARCS) spill = !seg_local;                   // a segment that fits the window again: nothing more is written
                             const int old_n = count_at_start - seg_first;     // they sit behind the closed segment's entries: move them to the front
                             if (seg_local && old_n > 0) for (int t = 0; t < added; ++t) ring[t * 64] = ring[(old_n + t) * 64] - (LKey)(d0 * 65);
                         }
@@ -1705,8 +1753,17 @@ void launch_seg_sp(const SpSegParams &p_in, hipStream_t s)
             (void)hipGetLastError();
             unsigned blocks = (unsigned)device_cus() * (unsigned)per_cu;
             if ((int64_t)blocks > (int64_t)b64) blocks = b64;
-            if (mg) { if (local) hipLaunchKernelGGL((k_bpe_fused<true, true>), dim3(blocks), dim3(64), lds, s, p); else hipLaunchKernelGGL((k_bpe_fused<true, false>), dim3(blocks), dim3(64), lds, s, p); }
-            else { if (local) hipLaunchKernelGGL((k_bpe_fused<false, true>), dim3(blocks), dim3(64), lds, s, p); else hipLaunchKernelGGL((k_bpe_fused<false, false>), dim3(blocks), dim3(64), lds, s, p); }
+            const bool arcs = p.variant == 5;                          // variant 5 (A/B runs): the instances that write every document's arc list
+            if (mg) {
+                if (local && !arcs) hipLaunchKernelGGL((k_bpe_fused<true, true, false>), dim3(blocks), dim3(64), lds, s, p);
+                else if (local) hipLaunchKernelGGL((k_bpe_fused<true, true>), dim3(blocks), dim3(64), lds, s, p);
+                else hipLaunchKernelGGL((k_bpe_fused<true, false>), dim3(blocks), dim3(64), lds, s, p);
+            } else {
+                if (local && !arcs) hipLaunchKernelGGL((k_bpe_fused<false, true, false>), dim3(blocks), dim3(64), lds, s, p);
+                else if (local) hipLaunchKernelGGL((k_bpe_fused<false, true>), dim3(blocks), dim3(64), lds, s, p);
+                else hipLaunchKernelGGL((k_bpe_fused<false, false>), dim3(blocks), dim3(64), lds, s, p);
+            }
+            if (local && !arcs) hipLaunchKernelGGL(k_bpe_collect_list, dim3(64), dim3(64), 0, s, p);
             (void)hipMemsetAsync(p.next_doc, 0, sizeof(unsigned long long), s);
         }
         unsigned sort_blocks = p.fb_list ? 64 : (unsigned)device_cus() * 2;                 // the fallback list is normally empty
