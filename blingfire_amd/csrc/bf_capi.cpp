@@ -162,13 +162,18 @@ struct Handle {
     // BfSetDevices: the devices a host batch is range-sharded over.  shards[g] tokenises range g; entry 0 is this handle itself when the
     // first device is its own, every other entry a handle of its own (tables, workspaces, streams) on its device
     std::vector<Handle *> shards;
+    // small host batches of a unit-form WordPiece model (the single-document entry points above all): text, offsets, counts and the id
+    // staging live in ONE block of mapped page-locked memory that the wave kernel reads and writes directly -- a call is one launch
+    // and one synchronisation, no copies, no scan / compaction kernels (run_host_mapped)
+    PinBuf m_small; void *m_small_dev = nullptr;
+    int small_status = -1;                                     // status word of the last batch when it took that path (BfLastStatus), else -1
     HostPipe pipe;                                              // chunked host-buffer path (run_host_chunked)
     int64_t host_chunk_bytes = 128ll << 20;                     // its largest chunk (BfSetHostChunkBytes; 0 = never chunk); batches of at least this size take it
     ~Handle()
     {
         for (Handle *c : shards) if (c && c != this) { DeviceGuard dg(c->device); (void)hipDeviceSynchronize(); delete c; }
         shards.clear();
-        pipe.release();
+        pipe.release(); m_small.release();
         for (DevBuf *b : {&t_dk_l1, &t_dk_pages, &t_dn_l1, &t_dn_pages, &t_dn_pool, &t_k2i, &t_rows, &w_keys, &w_keyoff, &w_dids, &w_dret, &w_vals, &t_i2w_off, &t_i2w_data, &t_kind, &t_wbd, &t_info, &t_acts, &t_cp_l1, &t_cp_pages, &t_multi, &t_wcp_l1, &t_wcp_pages, &t_dict, &t_seginfo, &w_s1, &w_s2, &w_s3, &w_s4, &w_big, &w_perm, &w_hist, &w_narcs, &w_cls, &w_nchars, &w_tmp, &w_counts, &w_flags, &w_out, &w_outoff,
                           &w_bsums, &w_misc, &w_text, &w_docoff, &w_ids, &w_idoff, &w_starts, &w_ends, &w_srcoff, &w_span}) b->release();
         for (auto &e : ev) if (e) (void)hipEventDestroy(e);
@@ -332,6 +337,7 @@ int run_device(Handle *h, const char *d_text, const int64_t *d_doc_off, int64_t 
     int *status = (int *)(h->w_misc.as<char>() + 16);
     Batch b{(const uint8_t *)d_text, d_doc_off, ndocs, total_bytes, status};
     if (!hip_ok(hipMemsetAsync(h->w_misc.p, 0, 64, s), "hipMemsetAsync")) return BF_E_DEVICE;
+    h->small_status = -1;
     (void)hipEventRecord(h->ev[EV_BEGIN], s);
     if (use_wave(h, want_off, words)) {
         (void)hipEventRecord(h->ev[EV_PREP], s);                       // decoding is part of the wave program
@@ -565,6 +571,63 @@ int64_t run_host_chunked(Handle *h, const char *text, const int64_t *doc_off, in
     return overflow ? BF_E_CAPACITY : base_ids;
 }
 
+// ---- small batches through mapped host memory (see Handle::m_small)
+constexpr int64_t SMALL_MAX_DOCS = 256, SMALL_MAX_BYTES = 64 * 1024;
+struct SmallLayout {
+    static constexpr size_t ctrl = 0, off = 64, counts = off + (SMALL_MAX_DOCS + 1) * 8, text = counts + SMALL_MAX_DOCS * 4,
+                            ids = (text + SMALL_MAX_BYTES + 63) & ~(size_t)63, total = ids + (SMALL_MAX_BYTES + 8 * SMALL_MAX_DOCS + 64) * 4;
+};
+
+bool small_ready(Handle *h)
+{
+    if (h->m_small.p) return true;
+    void *q = nullptr;
+    if (!hip_ok(hipHostMalloc(&q, SmallLayout::total, hipHostMallocMapped), "hipHostMalloc(mapped)")) return false;
+    void *d = nullptr;
+    if (!hip_ok(hipHostGetDevicePointer(&d, q, 0), "hipHostGetDevicePointer")) { (void)hipHostFree(q); return false; }
+    h->m_small.p = q; h->m_small.cap = SmallLayout::total; h->m_small_dev = d;
+    return true;
+}
+
+// caller holds h->mu and has made h->device current; the batch fits SmallLayout.  Returns the id count or BF_E_*.
+int64_t run_host_mapped(Handle *h, const char *text, const int64_t *doc_off, int64_t ndocs, int32_t *ids_out, int64_t ids_cap, int64_t *id_off_out, int max_ids, int unk)
+{
+    const Model &m = h->m;
+    char *hp = h->m_small.as<char>(), *dp = (char *)h->m_small_dev;
+    const int64_t base = doc_off[0], total = doc_off[ndocs] - base;
+    memset(hp + SmallLayout::ctrl, 0, 64);
+    int64_t *off = (int64_t *)(hp + SmallLayout::off);
+    for (int64_t i = 0; i <= ndocs; ++i) off[i] = doc_off[i] - base;
+    if (total > 0) memcpy(hp + SmallLayout::text, text + base, (size_t)total);
+    WpWaveParams wp;
+    wp.T = h->t_wbd.as<uint64_t>(); wp.acts = h->t_acts.as<int32_t>(); wp.acts_n = (int)m.acts_pool.size();
+    wp.initial = m.wbd.initial_base; wp.loop_info = m.loop_info; wp.solo_info = m.wave_solo_info; wp.max_token_length = m.max_token_length;
+    wp.text = (const uint8_t *)(dp + SmallLayout::text); wp.doc_off = (const int64_t *)(dp + SmallLayout::off); wp.ndocs = ndocs; wp.total_bytes = total;
+    wp.ids_tmp = (int32_t *)(dp + SmallLayout::ids); wp.counts = (int32_t *)(dp + SmallLayout::counts); wp.max_ids = max_ids < 0 ? 0 : max_ids; wp.unk = unk;
+    wp.next_doc = (unsigned long long *)(dp + SmallLayout::ctrl);
+    wp.cold.cpmap = DevCpMap{h->t_cp_l1.as<uint16_t>(), h->t_cp_pages.as<uint32_t>()};
+    wp.cold.kind = h->t_kind.as<uint8_t>(); wp.cold.nclasses = m.wbd.nclasses; wp.cold.status = (int *)(dp + SmallLayout::ctrl + 16); wp.cold.no_fast = 0; wp.cold.stats = nullptr;
+    launch_wp_wave(wp, h->variant, h->stream);
+    h->ev_valid = false;
+    if (!hip_ok(hipGetLastError(), "kernel launch") || !hip_ok(hipStreamSynchronize(h->stream), "hipStreamSynchronize")) return BF_E_DEVICE;
+    h->small_status = *(const int *)(hp + SmallLayout::ctrl + 16);
+    if (h->small_status & (2 | BF_STATUS_INTERNAL)) return BF_E_INTERNAL;
+    const int32_t *counts = (const int32_t *)(hp + SmallLayout::counts), *ids = (const int32_t *)(hp + SmallLayout::ids);
+    int64_t n = 0;
+    for (int64_t d = 0; d < ndocs; ++d) {
+        if (id_off_out) id_off_out[d] = n;
+        const int c = counts[d];
+        if (c > 0) {
+            if (n + c > ids_cap) return BF_E_CAPACITY;
+            if (!ids_out) return BF_E_ARG;
+            memcpy(ids_out + n, ids + wv_ids_slot(off[d], d), (size_t)c * 4);
+        }
+        n += c;
+    }
+    if (id_off_out) id_off_out[ndocs] = n;
+    return n;
+}
+
 int64_t run_host(Handle *h, const char *text, const int64_t *doc_off, int64_t ndocs, int32_t *ids_out, int64_t ids_cap,
                  int64_t *id_off_out, int max_ids, int unk, int32_t *starts_out = nullptr, int32_t *ends_out = nullptr, int words = 0,
                  bool *first_doc_nonempty = nullptr /* words modes: the first document decoded to >= 1 character */)
@@ -577,6 +640,8 @@ int64_t run_host(Handle *h, const char *text, const int64_t *doc_off, int64_t nd
     std::lock_guard<std::mutex> lock(h->mu);
     DeviceGuard dg(h->device); if (!dg.ok) return BF_E_DEVICE;
     hipStream_t s = h->stream;
+    if (ndocs >= 1 && ndocs <= SMALL_MAX_DOCS && total <= SMALL_MAX_BYTES && use_wave(h, want_off, words) && small_ready(h))
+        return run_host_mapped(h, text, doc_off, ndocs, ids_out, ids_cap, id_off_out, max_ids, unk);
     if (!want_off && !words && h->m.kind != KIND_I2W && h->host_chunk_bytes > 0 && total >= h->host_chunk_bytes && ndocs >= 2) {
         const int64_t r = run_host_chunked(h, text, doc_off, ndocs, ids_out, ids_cap, id_off_out, max_ids, unk);
         if (r != HOST_PIPE_UNAVAILABLE) return r;
@@ -1528,6 +1593,7 @@ int BfLastStatus(void *p)
     Handle *h = as_handle(p);
     if (!h) return BF_E_ARG;
     std::lock_guard<std::mutex> lock(h->mu);
+    if (h->small_status >= 0) return h->small_status;
     if (h->ev_valid) (void)hipEventSynchronize(h->ev[EV_COMPACT]);
     int status = 0;
     if (!hip_ok(hipMemcpy(&status, h->w_misc.as<char>() + 16, 4, hipMemcpyDeviceToHost), "D2H status")) return BF_E_DEVICE;

@@ -694,9 +694,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
 template <class LDS, int NU, int STEPS, int WPE>
 static void launch_wp_wave_cfg(const WpWaveParams &p, int grab, int per_cu_override, hipStream_t s)
 {
-    int per_cu = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_wp_wave<LDS, NU, STEPS, WPE, false>, 256, 0) != hipSuccess || per_cu <= 0) per_cu = 2;
-    (void)hipGetLastError();
+    static int per_cu_cached = 0;                 // per instance; a property of the kernel and the device kind
+    if (per_cu_cached <= 0) {
+        int q = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&q, k_wp_wave<LDS, NU, STEPS, WPE, false>, 256, 0) != hipSuccess || q <= 0) q = 2;
+        (void)hipGetLastError();
+        per_cu_cached = q;
+    }
+    int per_cu = per_cu_cached;
     if (per_cu_override > 0) per_cu = per_cu_override;
     int64_t blocks = (int64_t)device_cus() * per_cu;
     const int64_t need = (p.ndocs + (int64_t)grab * 4 - 1) / ((int64_t)grab * 4);
