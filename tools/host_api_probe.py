@@ -15,7 +15,7 @@ L = bf.lib()
 cap = int(off[-1]) + 1
 ids = np.zeros(cap, dtype=np.int32)
 ioff = np.zeros(n + 1, dtype=np.int64)
-for chunk in (128 << 20, 64 << 20, 256 << 20, 0):
+for chunk in (128 << 20, 256 << 20):
     L.BfSetHostChunkBytes.restype = ctypes.c_int64
     L.BfSetHostChunkBytes.argtypes = [ctypes.c_void_p, ctypes.c_int64]
     L.BfSetHostChunkBytes(ctypes.c_void_p(h), chunk)
