@@ -42,7 +42,7 @@ def csrc_sha():
     import hashlib
     d = os.path.join(ROOT, "blingfire_amd", "csrc")
     hsh = hashlib.sha256()
-    for f in sorted(os.listdir(d)):
+    for f in sorted(f for f in os.listdir(d) if f.endswith((".h", ".hip", ".cpp", ".map"))):
         hsh.update(f.encode())
         hsh.update(open(os.path.join(d, f), "rb").read())
     return hsh.hexdigest()[:16]

@@ -33,6 +33,7 @@ struct WvLds {
     uint32_t q0[QCAP], q1[QCAP];
     int32_t dt_cap[DTN], dt_cnt[DTN]; uint32_t dt_flags[DTN], dt_rbase[DTN];      // dt_rbase: ring position of the document's first character
     uint16_t qc[QCAP];
+    uint16_t spare;                  // where a lane writes when it has nothing to write (decode)
 };
 
 // DBG (experiments, wrong results by design): 1 = units finish at once without walking, 2 = also nothing is moved at retire:
@@ -213,62 +214,75 @@ struct WpWave {
             wv::sync();
             return;
         }
+        // ---- a chunk with bytes >= 0x80.  Every byte that is not a continuation byte is an element; the ASCII ones come from the table
+        //      as above, the lead bytes are decoded one per lane and trip (a lane of Latin text holds one or two, a lane of CJK three);
+        //      a continuation byte is legal exactly when it is one of the (length - 1) bytes behind a lead byte
         uint32_t nxt = wv::shfl_down((uint32_t)own, 1);
         if (lane == 63) { nxt = 0; for (int k = 0; k < 3; ++k) if (q0 + 8 + k < n) nxt |= (uint32_t)s[q0 + 8 + k] << (8 * k); }
-        const uint32_t tail3 = (uint32_t)(own >> 40);                     // own bytes 5, 6, 7
-        uint32_t prv = wv::shfl_up(tail3, 1);
-        if (lane == 0) { prv = 0; for (int k = 0; k < 3; ++k) if (pos - 3 + k >= 0) prv |= (uint32_t)s[pos - 3 + k] << (8 * k); }
         if (pos == 0) {                                                   // FAUtf8Utils.cpp:247-252
             const int has_bom = (n >= 3 && ((uint32_t)own & 0xFFFFFFu) == 0xBFBBEFu) ? 3 : 0;
             bom = wv::bcast(has_bom, 0);
         }
-        uint32_t X[14];                                                   // X[i] = byte at q0 - 3 + i
-        X[0] = prv & 0xFF; X[1] = (prv >> 8) & 0xFF; X[2] = (prv >> 16) & 0xFF;
+        const uint64_t h80 = own & 0x8080808080808080ull, h40 = (own << 1) & 0x8080808080808080ull;
+        // one bit per byte: >= 0x80, continuation (10xxxxxx), lead (11xxxxxx); bytes of this lane that belong to the text (a BOM does not)
+        uint32_t m80 = 0, m40 = 0;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) X[3 + k] = (uint32_t)(own >> (8 * k)) & 0xFF;
-        X[11] = nxt & 0xFF; X[12] = (nxt >> 8) & 0xFF; X[13] = (nxt >> 16) & 0xFF;
-        uint32_t v[8]; int cnt = 0; uint32_t wm = 0; bool e_any = false;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const int q = q0 + k;
-            const bool in = q >= bom && q < n;
-            const uint32_t b0 = X[3 + k], b1 = X[4 + k], b2 = X[5 + k], b3 = X[6 + k];
-            const bool cont = (b0 & 0xC0) == 0x80;
-            uint32_t vv = 0; bool has = false;
-            if (in && cont) {
-                const uint32_t p1 = X[2 + k], p2 = X[1 + k], p3 = X[k];
-                bool ok;
-                if ((p1 & 0xC0) != 0x80 || q - 1 < bom) ok = (q - 1 >= bom) && p1 >= 0xC0;                 // any multi-byte lead covers +1
-                else if ((p2 & 0xC0) != 0x80 || q - 2 < bom) ok = (q - 2 >= bom) && p2 >= 0xE0;            // 3- or 4-byte lead covers +2
-                else if ((p3 & 0xC0) != 0x80 || q - 3 < bom) ok = (q - 3 >= bom) && p3 >= 0xF0;            // 4-byte lead covers +3
-                else ok = false;
-                e_any |= !ok;                     // invalid leads (F8..FF) are rejected at their own position
-            } else if (in) {
-                if (b0 < 0x80) { vv = ascii[b0]; has = true; }
-                else {
-                    int len, cp; bool e = false;
-                    if ((b0 & 0xE0) == 0xC0) { len = 2; cp = (int)(b0 & 0x1F); }
-                    else if ((b0 & 0xF0) == 0xE0) { len = 3; cp = (int)(b0 & 0x0F); }
-                    else if ((b0 & 0xF8) == 0xF0) { len = 4; cp = (int)(b0 & 0x07); }
-                    else { len = 1; cp = 0; e = true; }
-                    if (q + len > n) e = true;                                                 // truncated tail (:167-171)
-                    if (len >= 2) { if ((b1 & 0xC0) != 0x80) e = true; cp = (cp << 6) | (int)(b1 & 0x3F); }
-                    if (len >= 3) { if ((b2 & 0xC0) != 0x80) e = true; cp = (cp << 6) | (int)(b2 & 0x3F); }
-                    if (len >= 4) { if ((b3 & 0xC0) != 0x80) e = true; cp = (cp << 6) | (int)(b3 & 0x3F); }
-                    const int need = cp <= 0x7F ? 1 : cp <= 0x7FF ? 2 : cp <= 0xFFFF ? 3 : cp <= 0x10FFFF ? 4 : 0;
-                    if (need != len) e = true;                                                 // overlong / > U+10FFFF (:185-188)
-                    if ((cp & 0xFFFFF800) == 0xD800) e = true;                                 // surrogate (:190-193)
-                    e_any |= e;
-                    if (!e) { vv = wv_element(cold, cp); has = true; }
-                }
-            }
-            v[k] = vv; if (has) { wm |= 1u << k; ++cnt; }
-        }
-        err |= e_any;
+        for (int k = 0; k < 8; ++k) { m80 |= (uint32_t)((h80 >> (8 * k + 7)) & 1ull) << k; m40 |= (uint32_t)((h40 >> (8 * k + 7)) & 1ull) << k; }
+        uint32_t vmask = nb >= 8 ? 0xFFu : ((1u << nb) - 1u);
+        if (pos == 0 && lane == 0 && bom) vmask &= ~7u;
+        const uint32_t contm = m80 & ~m40 & vmask, leadm = m80 & m40 & vmask, em = vmask & ~contm;
+        const int cnt = __builtin_popcount(em);
         const int inc = wv::incl_scan(cnt);
-        uint32_t r = w0 + (uint32_t)(inc - cnt);
+        const uint32_t base = w0 + (uint32_t)(inc - cnt);
+        uint32_t e[8];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) if (wm & (1u << k)) { S.ring[r & RMASK] = (uint16_t)v[k]; ++r; }
+        for (int k = 0; k < 8; ++k) e[k] = ascii[(uint32_t)(own >> (8 * k)) & 0x7f];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {                                     // the ASCII elements (a lane without one writes into the spare slot)
+            const bool on = ((em & ~leadm) >> k) & 1u;
+            uint16_t *dst = on ? &S.ring[(base + (uint32_t)__builtin_popcount(em & ((1u << k) - 1u))) & RMASK] : &S.spare;
+            *dst = (uint16_t)e[k];
+        }
+        uint32_t cov = 0;                                                 // bytes behind a lead that belong to its character (bits 8..10: in the next lane)
+        bool e_any = false;
+        for (uint32_t lm = leadm; wv::any(lm != 0);) {
+            if (lm) {
+                const int k = __builtin_ctz(lm); lm &= lm - 1u;
+                const int q = q0 + k;
+                uint64_t w = own >> (8 * k);
+                if (k) w |= (uint64_t)nxt << (64 - 8 * k);
+                const uint32_t b0 = (uint32_t)w & 0xFF, b1 = (uint32_t)(w >> 8) & 0xFF, b2 = (uint32_t)(w >> 16) & 0xFF, b3 = (uint32_t)(w >> 24) & 0xFF;
+                int len, cp; bool er = false;
+                if ((b0 & 0xE0) == 0xC0) { len = 2; cp = (int)(b0 & 0x1F); }
+                else if ((b0 & 0xF0) == 0xE0) { len = 3; cp = (int)(b0 & 0x0F); }
+                else if ((b0 & 0xF8) == 0xF0) { len = 4; cp = (int)(b0 & 0x07); }
+                else { len = 1; cp = 0; er = true; }                                            // F8 .. FF
+                if (q + len > n) er = true;                                                    // truncated tail (:167-171)
+                if (len >= 2) { if ((b1 & 0xC0) != 0x80) er = true; cp = (cp << 6) | (int)(b1 & 0x3F); }
+                if (len >= 3) { if ((b2 & 0xC0) != 0x80) er = true; cp = (cp << 6) | (int)(b2 & 0x3F); }
+                if (len >= 4) { if ((b3 & 0xC0) != 0x80) er = true; cp = (cp << 6) | (int)(b3 & 0x3F); }
+                const int need = cp <= 0x7F ? 1 : cp <= 0x7FF ? 2 : cp <= 0xFFFF ? 3 : cp <= 0x10FFFF ? 4 : 0;
+                if (need != len) er = true;                                                    // overlong / > U+10FFFF (:185-188)
+                if ((cp & 0xFFFFF800) == 0xD800) er = true;                                    // surrogate (:190-193)
+                e_any |= er;
+                cov |= (((1u << len) - 1u) & ~1u) << k;
+                S.ring[(base + (uint32_t)__builtin_popcount(em & ((1u << k) - 1u))) & RMASK] = (uint16_t)(er ? (LX_CLS_NONE | (WK_NOMATCH << WK_SHIFT)) : wv_element(cold, cp));
+            }
+        }
+        // continuation bytes at the start of the lane may belong to a lead in the lane before (lane 0: in the bytes before the chunk)
+        uint32_t spill = wv::shfl_up(cov >> 8, 1);
+        if (lane == 0) {
+            spill = 0;
+            for (int back = 1; back <= 3 && pos - back >= bom; ++back) {
+                const uint32_t c0 = s[pos - back];
+                if ((c0 & 0xC0) == 0x80) continue;                                             // a continuation byte: look further back
+                const int len = (c0 & 0xE0) == 0xC0 ? 2 : (c0 & 0xF0) == 0xE0 ? 3 : (c0 & 0xF8) == 0xF0 ? 4 : 1;
+                if (c0 >= 0xC0 && len > back) spill = (1u << (len - back)) - 1u;
+                break;
+            }
+        }
+        if (contm & ~(cov | spill)) e_any = true;                          // a continuation byte no lead accounts for (:152-165)
+        err |= e_any;
         const int total = wv::bcast(inc, 63);
         dec += total; dec_bytes = pos + WV_CHUNK; rhi = rbase + (uint32_t)dec;
         wv::sync();

@@ -15,7 +15,7 @@ per_step = int(sys.argv[4]) if len(sys.argv) > 4 else 1
 def csrc_sha():
     d = os.path.join(ROOT, "blingfire_amd", "csrc")
     h = hashlib.sha256()
-    for f in sorted(os.listdir(d)):
+    for f in sorted(f for f in os.listdir(d) if f.endswith((".h", ".hip", ".cpp", ".map"))):
         h.update(f.encode())
         h.update(open(os.path.join(d, f), "rb").read())
     return h.hexdigest()[:16]
