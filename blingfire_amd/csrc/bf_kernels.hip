@@ -665,6 +665,15 @@ __device__ __forceinline__ int incl_scan(int v)
     v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);      // row_bcast:31 -> rows 2, 3
     return v;
 }
+// the smallest value of the wave: the same six steps with min (lanes without a source keep their own value)
+__device__ __forceinline__ uint32_t min_all(uint32_t v)
+{
+    int x = (int)v;
+#define BF_WV_MIN_STEP(ctrl, rows) { const uint32_t o = (uint32_t)__builtin_amdgcn_update_dpp(x, x, ctrl, rows, 0xf, false); x = (int)((uint32_t)x < o ? (uint32_t)x : o); }
+    BF_WV_MIN_STEP(0x111, 0xf) BF_WV_MIN_STEP(0x112, 0xf) BF_WV_MIN_STEP(0x114, 0xf) BF_WV_MIN_STEP(0x118, 0xf) BF_WV_MIN_STEP(0x142, 0xa) BF_WV_MIN_STEP(0x143, 0xc)
+#undef BF_WV_MIN_STEP
+    return (uint32_t)__builtin_amdgcn_readlane(x, 63);
+}
 __device__ __forceinline__ unsigned long long atomic_add(unsigned long long *p, unsigned long long v) { return atomicAdd(p, v); }
 __device__ __forceinline__ void atomic_or(int *p, int v) { atomicOr(p, v); }
 __device__ __forceinline__ unsigned long long clock() { return __builtin_readcyclecounter(); }
@@ -687,17 +696,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
     wv_init_ascii(p.cold, ascii, (int)threadIdx.x, 256);
     for (int i = (int)threadIdx.x; i < p.acts_n; i += 256) acts[i] = p.acts[i];
     __syncthreads();
-    WpWave<LDS, NU, STATS, DBG, STEPS, UMIN, CROOM> w(p, cold, lds[threadIdx.x >> 6], ascii, acts);
+    // the wave number as a scalar: what a wave reads of its own LDS block at a wave-uniform index is then wave-uniform for the compiler too
+    WpWave<LDS, NU, STATS, DBG, STEPS, UMIN, CROOM> w(p, cold, lds[__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))], ascii, acts);
     w.run(grab);
 }
 
-template <class LDS, int NU, int STEPS, int WPE>
+template <class LDS, int NU, int STEPS, int WPE, int UMIN = 12>
 static void launch_wp_wave_cfg(const WpWaveParams &p, int grab, int per_cu_override, hipStream_t s)
 {
     static int per_cu_cached = 0;                 // per instance; a property of the kernel and the device kind
     if (per_cu_cached <= 0) {
         int q = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&q, k_wp_wave<LDS, NU, STEPS, WPE, false>, 256, 0) != hipSuccess || q <= 0) q = 2;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&q, k_wp_wave<LDS, NU, STEPS, WPE, false, 0, UMIN>, 256, 0) != hipSuccess || q <= 0) q = 2;
         (void)hipGetLastError();
         per_cu_cached = q;
     }
@@ -707,31 +717,35 @@ static void launch_wp_wave_cfg(const WpWaveParams &p, int grab, int per_cu_overr
     const int64_t need = (p.ndocs + (int64_t)grab * 4 - 1) / ((int64_t)grab * 4);
     if (blocks > need) blocks = need;
     if (blocks < 1) blocks = 1;
-    if (p.cold.stats) hipLaunchKernelGGL((k_wp_wave<LDS, NU, STEPS, WPE, true>), dim3((unsigned)blocks), dim3(256), 0, s, p, grab);
-    else hipLaunchKernelGGL((k_wp_wave<LDS, NU, STEPS, WPE, false>), dim3((unsigned)blocks), dim3(256), 0, s, p, grab);
+    if (p.cold.stats) hipLaunchKernelGGL((k_wp_wave<LDS, NU, STEPS, WPE, true, 0, UMIN>), dim3((unsigned)blocks), dim3(256), 0, s, p, grab);
+    else hipLaunchKernelGGL((k_wp_wave<LDS, NU, STEPS, WPE, false, 0, UMIN>), dim3((unsigned)blocks), dim3(256), 0, s, p, grab);
 }
 
 // variant (experiments): bits 8..11 = configuration, bits 12..15 = documents per grab (0 = 8), bits 24..29 = workgroups per CU
 void launch_wp_wave(const WpWaveParams &p, int variant, hipStream_t s)
 {
     const int cfg = (variant >> 8) & 0xf;
-    int grab = (variant >> 12) & 0xf; if (grab == 0) grab = 8;
+    int grab = (variant >> 12) & 0xf; if (grab == 0 || grab > WV_GRAB_MAX) grab = WV_GRAB_MAX;
     const int per_cu = (variant >> 24) & 0x3f;
-    typedef WvLds<2048, 256, 16> L;
+    // Shipped: a ring of 1,024 elements (the longest word + one chunk fit: bf_model.cpp "unit form"), a queue of 256 tokens, a table of 8
+    // open documents, eight workgroups per CU (eight waves per SIMD: 64 VGPRs, 20 KB of LDS per workgroup).  Measured on 10 M documents
+    // of 512 bytes (profiles/r03_*): 25.9 ms; seven workgroups (72 VGPRs) 27.7; six 29.9; a ring of 2,048 and five workgroups 32.3; a
+    // queue of 128 tokens and seven / eight workgroups 35.1 / 33.1; transitions per round 2 / 3 / 4 / 6 (at five workgroups): 33.9 /
+    // 33.0 / 33.6 / 36.6; two units per lane 39.4; leaving the units phase with fewer than 12 / 24 / 32 / 48 busy units 27.7 / 28.1 /
+    // 28.2 / 28.8 (at seven workgroups).
+    typedef WvLds<1024, 256, 8> L;
     if (cfg == 14 || cfg == 15) {       // experiments: phase costs by difference (results are wrong by design)
-        const int64_t nb = (int64_t)device_cus() * 5;
-        if (cfg == 14) hipLaunchKernelGGL((k_wp_wave<L, 1, 3, 5, false, 1>), dim3((unsigned)nb), dim3(256), 0, s, p, grab);
-        else hipLaunchKernelGGL((k_wp_wave<L, 1, 3, 5, false, 2>), dim3((unsigned)nb), dim3(256), 0, s, p, grab);
+        const int64_t nb = (int64_t)device_cus() * 8;
+        if (cfg == 14) hipLaunchKernelGGL((k_wp_wave<L, 1, 3, 8, false, 1>), dim3((unsigned)nb), dim3(256), 0, s, p, grab);
+        else hipLaunchKernelGGL((k_wp_wave<L, 1, 3, 8, false, 2>), dim3((unsigned)nb), dim3(256), 0, s, p, grab);
         return;
     }
-    if (cfg == 6) { launch_wp_wave_cfg<WvLds<1024, 128, 16>, 1, 3, 6>(p, grab, per_cu, s); return; }      // experiments: occupancy against batch size
-    if (cfg == 7) { launch_wp_wave_cfg<WvLds<1024, 128, 16>, 1, 3, 5>(p, grab, per_cu, s); return; }
-    if (cfg == 8) { launch_wp_wave_cfg<L, 1, 3, 4>(p, grab, per_cu, s); return; }
-    if (cfg == 1) launch_wp_wave_cfg<L, 2, 3, 4>(p, grab, per_cu, s);
-    else if (cfg == 2) launch_wp_wave_cfg<L, 1, 4, 4>(p, grab, per_cu, s);
-    else if (cfg == 3) launch_wp_wave_cfg<L, 1, 2, 4>(p, grab, per_cu, s);
-    else if (cfg == 5) launch_wp_wave_cfg<L, 2, 2, 4>(p, grab, per_cu, s);
-    else launch_wp_wave_cfg<L, 1, 3, 5>(p, grab, per_cu, s);     // five workgroups per CU: measured 39.2 ms against 44.3 at four (10 M documents, profiles/r03_*)
+    if (cfg == 1) launch_wp_wave_cfg<WvLds<1024, 256, 16>, 1, 3, 7>(p, grab, per_cu, s);                    // experiments: occupancy
+    else if (cfg == 2) launch_wp_wave_cfg<WvLds<1024, 256, 16>, 1, 3, 6>(p, grab, per_cu, s);
+    else if (cfg == 4) launch_wp_wave_cfg<WvLds<2048, 256, 16>, 1, 3, 5>(p, grab, per_cu, s);
+    else if (cfg == 5) launch_wp_wave_cfg<L, 1, 3, 8, 4>(p, grab, per_cu, s);                                 // experiments: when the units phase ends
+    else if (cfg == 6) launch_wp_wave_cfg<L, 1, 3, 8, 24>(p, grab, per_cu, s);
+    else launch_wp_wave_cfg<L, 1, 3, 8>(p, grab, per_cu, s);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2382,8 +2396,58 @@ __global__ __launch_bounds__(256) void k_compact(CompactParams p)
     }
 }
 
+// k_compact_ids: the same copy when only ids are asked for (no offsets).  A wave takes 64 consecutive documents: their count, slot and
+// place in the output are read once, one document per lane (three coalesced loads instead of three dependent loads per document),
+// then handed round with readlane; the copies of two documents are in flight together.  Measured on the 10 M x 512 B workload
+// (profiles/r03_*): 3.56 ms with the wave-per-document form, whose waves spend most of their time waiting for those three loads.
+__global__ __launch_bounds__(256) void k_compact_ids(CompactParams p)
+{
+    const int lane = lane_id();
+    const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * 4;
+    const int32_t *__restrict__ tmp = p.ids_tmp;
+    int32_t *__restrict__ out = p.ids_out;
+    bool over = false;
+    for (int64_t base = wave0 * 64; base < p.b.ndocs; base += nwaves * 64) {
+        const int64_t d = base + lane;
+        int c = 0; int64_t slot = 0, o = 0;
+        if (d < p.b.ndocs) {
+            c = p.counts[d];
+            const int64_t b = p.b.doc_off[d];
+            slot = (p.slot_mul > 0 ? sp_slot(b, d, p.slot_mul) : ids_slot(b, d)) + (p.first ? p.first[d] : 0);
+            o = p.id_off[d];
+            if (o + c > p.ids_cap) { over = true; c = o < p.ids_cap ? (int)(p.ids_cap - o) : 0; }
+        }
+        const int nd = p.b.ndocs - base < 64 ? (int)(p.b.ndocs - base) : 64;
+        for (int k = 0; k < nd; k += 2) {
+            const int k1 = k + 1 < nd ? k + 1 : k;
+            const int c0 = __builtin_amdgcn_readlane(c, k), c1 = k + 1 < nd ? __builtin_amdgcn_readlane(c, k1) : 0;
+            const int64_t s0 = wv::bcast(slot, k), s1 = wv::bcast(slot, k1), o0 = wv::bcast(o, k), o1 = wv::bcast(o, k1);
+            int32_t a0 = 0, a1 = 0, b0 = 0, b1 = 0;
+            if (lane < c0) a0 = tmp[s0 + lane];
+            if (lane + 64 < c0) a1 = tmp[s0 + lane + 64];
+            if (lane < c1) b0 = tmp[s1 + lane];
+            if (lane + 64 < c1) b1 = tmp[s1 + lane + 64];
+            if (lane < c0) out[o0 + lane] = a0;
+            if (lane + 64 < c0) out[o0 + lane + 64] = a1;
+            if (lane < c1) out[o1 + lane] = b0;
+            if (lane + 64 < c1) out[o1 + lane + 64] = b1;
+            for (int i = lane + 128; i < c0; i += 64) out[o0 + i] = tmp[s0 + i];
+            for (int i = lane + 128; i < c1; i += 64) out[o1 + i] = tmp[s1 + i];
+        }
+    }
+    if (over) atomicOr(p.status, 1);
+}
+
 void launch_compact(const CompactParams &p, hipStream_t s)
 {
+    if (!p.starts_out) {
+        int64_t blocks = (p.b.ndocs + 255) / 256;
+        if (blocks > device_cus() * 8) blocks = device_cus() * 8;
+        if (blocks < 1) blocks = 1;
+        hipLaunchKernelGGL(k_compact_ids, dim3((unsigned)blocks), dim3(256), 0, s, p);
+        return;
+    }
     int64_t blocks = (p.b.ndocs + 3) / 4;
     if (blocks > device_cus() * 16) blocks = device_cus() * 16;
     if (blocks < 1) blocks = 1;

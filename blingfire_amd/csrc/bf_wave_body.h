@@ -22,18 +22,23 @@ constexpr uint32_t WV_TK_INFO = 1u << 30, WV_TK_LEN_MASK = 0x1FFu;
 BF_WVD uint16_t wv_pack_info(uint32_t info) { return (uint16_t)((info & LX_INFO_SIMPLE) ? (0x8000u | (info & 0x7FFFu)) : (info & 0x7FFFu)); }
 BF_WVD uint32_t wv_unpack_info(uint32_t v) { return (v & 0x8000u) ? (LX_INFO_SIMPLE | (v & 0x7FFFu)) : v; }    // token flags (WV_TK_INFO: the action is in qi[]; else the common word kind)
 
-// LDS of one wave.  QCAP / DTN / RING are powers of two.  A token: q0 = absolute ring position of its first character; q1 = length |
-// document table entry (low 8 bits of the absolute entry number) << 16 | WV_TK_* flags; qc = set by the unit: 0 while it walks, then
-// 1 + the number of ids -- and, until the unit starts, the action of a WV_TK_INFO token (wv_pack_info: tags and action indices are small).
+// LDS of one wave.  QCAP / DTN / RING are powers of two.  A token: q[].pos = absolute ring position of its first character (later,
+// for a word of one piece: its id, unit_event); q[].w = length | document table entry (low 8 bits of the absolute entry number) << 16 |
+// WV_TK_* flags; qc = set by the unit: 0 while it walks, then 1 + the number of ids -- and, until the unit starts, the action of a
+// WV_TK_INFO token (wv_pack_info: tags and action indices are small).
+struct WvTok { uint32_t pos, w; };
+constexpr int WV_GRAB_MAX = 8;         // documents a wave takes from the work counter at once, at most
 template <int RING_, int QCAP_, int DTN_>
 struct WvLds {
     static constexpr int RING = RING_, QCAP = QCAP_, DTN = DTN_;
     alignas(16) uint16_t ring[RING];
     int64_t dt_slot[DTN], dt_doc[DTN];
-    uint32_t q0[QCAP], q1[QCAP];
+    alignas(8) WvTok q[QCAP];
     int32_t dt_cap[DTN], dt_cnt[DTN]; uint32_t dt_flags[DTN], dt_rbase[DTN];      // dt_rbase: ring position of the document's first character
     uint16_t qc[QCAP];
-    uint16_t spare;                  // where a lane writes when it has nothing to write (decode)
+    int64_t doff[WV_GRAB_MAX + 1];   // text offsets of the documents taken from the work counter
+    uint32_t spare32;
+    uint16_t spare;                  // spare, spare32: where a lane writes when it has nothing to write
 };
 
 // DBG (experiments, wrong results by design): 1 = units finish at once without walking, 2 = also nothing is moved at retire:
@@ -48,10 +53,11 @@ struct WpWave {
     const WpWaveParams &p; const WpWaveCold &cold; LDS &S; const uint16_t *ascii; const int32_t *acts;      // cold, ascii, acts: per-workgroup LDS copies / tables
     int lane;
     // ---- wave-uniform state
+    uint32_t u_need;                 // distance from rlo to the lowest ring position a busy unit reads (0xFFFFFFFF: none is busy)
     uint32_t rhi, rlo;               // absolute ring positions: next element to write / oldest element still needed
     uint32_t q_tail, q_issue, q_retire;   // tokens: queued / handed to a unit / retired (absolute counters; slot = counter & QMASK)
     uint32_t dt_head, dt_tail;       // document table entries in use (absolute counters)
-    int64_t dnext, dend, dbase, off_lane;   // the range of documents this wave took from the work counter; off_lane (per lane): doc_off[dbase + lane]
+    int64_t dnext, dend, dbase;      // the range of documents this wave took from the work counter (their offsets: S.doff[])
     bool have_doc, exiting;
     // current document
     const uint8_t *s; int n; uint32_t rbase; int dec_bytes, dec, done, open_start, bom; uint32_t curk;
@@ -63,8 +69,8 @@ struct WpWave {
 
     BF_WVD WpWave(const WpWaveParams &p_, const WpWaveCold &cold_, LDS &S_, const uint16_t *ascii_, const int32_t *acts_) : p(p_), cold(cold_), S(S_), ascii(ascii_), acts(acts_)
     {
-        lane = wv::lane(); rhi = rlo = 0; q_tail = q_issue = q_retire = 0; dt_head = dt_tail = 0;
-        dnext = dend = dbase = off_lane = 0; have_doc = exiting = false;
+        lane = wv::lane(); rhi = rlo = 0; u_need = 0xFFFFFFFFu; q_tail = q_issue = q_retire = 0; dt_head = dt_tail = 0;
+        dnext = dend = dbase = 0; have_doc = exiting = false;
         s = nullptr; n = 0; rbase = 0; dec_bytes = dec = done = bom = 0; open_start = -1; curk = 0; err = false; pf_own = 0;
         st_trips = st_win = st_slow = st_tok = st_steps = st_ret = st_rewalk = st_idle = st_dec = st_gath = st_trans = 0;
         // the action of a run token and of a solo token (bf_model.cpp): the usual case is one calling WORD action for both
@@ -80,8 +86,8 @@ struct WpWave {
     BF_WVD void put_token(uint32_t t, int pos, int len, uint32_t flags)
     {
         const uint32_t sl = t & QMASK;
-        S.q0[sl] = rbase + (uint32_t)pos;
-        S.q1[sl] = (uint32_t)len | ((curk & 0xFFu) << 16) | flags;
+        WvTok e; e.pos = rbase + (uint32_t)pos; e.w = (uint32_t)len | ((curk & 0xFFu) << 16) | flags;
+        S.q[sl] = e;
     }
     BF_WVD void put_word(uint32_t t, int pos, int len, bool solo)                 // a run / solo token of the mask form
     {
@@ -157,17 +163,25 @@ struct WpWave {
         uint32_t t = q_tail + (carry_end ? 1u : 0u) + (uint32_t)(inc - c);
         bool toolong = false;
         if (carry_end && lane == 0) put_word(q_tail, open_start, cb - open_start, false);
+        // every token of the lane, lowest first; a run token (its end is here) starts at the nearest run start before the end, a solo
+        // token is its own element.  Straight-line code: the only divergence is between lanes that have a token left and those that do not
+        const uint32_t w_hi = ((curk & 0xFFu) << 16) | (fast_ok ? 0u : WV_TK_INFO);
+        const uint16_t li = wv_pack_info(p.loop_info), si = wv_pack_info(p.solo_info);
+        const int lane0 = cb + lane * 8;
         while (wv::any(tk != 0)) {
             if (tk) {
                 const int bit = __builtin_ctz(tk); tk &= tk - 1u;
-                const int bpos = cb + lane * 8 + (bit >> 1);
-                if ((en >> bit) & 1u) {
-                    const uint32_t hm = h & ((2u << bit) - 1u);
-                    const int start = hm ? cb + lane * 8 + ((31 - __builtin_clz(hm)) >> 1) : hprev;
-                    const int len = bpos - start + 1;
-                    toolong |= len > maxtok;
-                    put_word(t, start, len, false);
-                } else put_word(t, bpos, 1, true);
+                const int bpos = lane0 + (bit >> 1);
+                const bool is_end = (en >> bit) & 1u;
+                const uint32_t hm = h & ((2u << bit) - 1u);
+                const int hs = hm ? lane0 + ((31 - __builtin_clz(hm | 1u)) >> 1) : hprev;
+                const int start = is_end ? hs : bpos;
+                const int len = bpos - start + 1;
+                toolong |= len > maxtok;
+                const uint32_t sl = t & QMASK;
+                WvTok e; e.pos = rbase + (uint32_t)start; e.w = (uint32_t)len | w_hi;
+                S.q[sl] = e;
+                if (!fast_ok) S.qc[sl] = is_end ? li : si;
                 ++t;
             }
         }
@@ -393,54 +407,63 @@ struct WpWave {
     // ------------------------------------------------------------------------------------------------------------------
     // Ids have a provisional home in global memory: piece k of the word whose first character is at position f of document d goes
     // to ids_tmp[slot(d) + f + k] (a piece is at least one character, so homes never collide and never leave the slot); retire moves
-    // them down to their place in the document.  Nothing about a word's ids is kept in LDS but their number.
+    // them down to their place in the document.  The id of a word that is a single piece (most are) never leaves LDS before that: it takes
+    // the place of the word's ring position in its queue entry (unit_event).
     //
     // A unit runs the frame of ONE function call: walks start at `j0` (first the anchored walk from ini_l at character 0, if the
     // function has a left-anchor transition; then the plain walks from ini), read letters while j < lim = min(start + max-length, L).
     // Written with selects: the walk loop is what every lane executes on every trip.
     struct Unit {
         int tok;                         // token (absolute queue counter, as int), -1: idle
-        uint32_t rs; int L; uint32_t ini;
+        uint32_t rs; int Lk; uint32_t ini;       // Lk: length of the word | its document's table entry << 16
         int j, lim; uint32_t state; int fp; uint32_t ftag;
-        int cnt, anch, walk;             // pieces so far; 1 while the anchored walk runs; 1 while a walk is under way (0 with tok >= 0: its end waits for unit_event)
-        int32_t *home;                   // provisional home of piece 0
+        int ca, walk;                    // ca: pieces so far | 1 << 16 while the anchored walk runs; walk: 1 while a walk is under way (0 with tok >= 0: its end waits for unit_event)
     };
 
+    // What follows runs for all lanes of the wave at once and is written with selects: a lane that has nothing to do (pred false)
+    // executes the same instructions, keeps what it has and writes to the spare words.  (Measured, profiles/r03_*: as nested
+    // conditionals the code of a round cost 127 scalar instructions, most of them execution-mask bookkeeping.)
     BF_WVD void unit_finish(Unit &u, int cnt)
     {
         S.qc[(uint32_t)u.tok & QMASK] = (uint16_t)(cnt + 1);
         u.tok = -1; u.walk = 0;
     }
     // the frame of a call to the function (ini, ini_l) on the unit's word
-    BF_WVD void unit_call(Unit &u, uint32_t ini, uint32_t ini_l)
+    BF_WVD void unit_call(Unit &u, uint32_t ini, uint32_t ini_l, bool pred)
     {
         const int maxtok = p.max_token_length;
         const bool anchored = ini_l != LX_NO_STATE && maxtok > 1;     // else "from = -1" goes straight on to from = 0 (FALexTools_t.h:244-252)
         const int cap = anchored ? maxtok - 1 : maxtok;
-        u.ini = ini; u.state = anchored ? ini_l : ini; u.anch = anchored ? 1 : 0;
-        u.j = 0; u.lim = cap < u.L ? cap : u.L; u.fp = -1; u.cnt = 0; u.walk = 1;
+        const int L = u.Lk & 0xFFFF;
+        u.ini = pred ? ini : u.ini; u.state = pred ? (anchored ? ini_l : ini) : u.state; u.ca = pred ? (anchored ? 0x10000 : 0) : u.ca;
+        u.j = pred ? 0 : u.j; u.lim = pred ? (cap < L ? cap : L) : u.lim; u.fp = pred ? -1 : u.fp; u.walk = pred ? 1 : u.walk;
     }
-    // starts the unit of token t
-    BF_WVD void unit_begin(Unit &u, uint32_t t)
+    // starts the unit of token t (take: this lane takes one)
+    BF_WVD void unit_begin(Unit &u, uint32_t t, bool take)
     {
-        u.tok = (int)t;
         const uint32_t sl = t & QMASK;
-        const uint32_t w1 = S.q1[sl];
-        const uint32_t ke = (w1 >> 16) & DMASK;
-        u.rs = S.q0[sl]; u.L = (int)(w1 & WV_TK_LEN_MASK);
-        u.home = p.ids_tmp + S.dt_slot[ke] + (int64_t)(u.rs - S.dt_rbase[ke]);
+        const WvTok e = S.q[sl];
+        const uint32_t w1 = e.w;
         const uint32_t info16 = wv_unpack_info(S.qc[sl]);
-        S.qc[sl] = 0;
-        if (DBG >= 1) { unit_finish(u, 1); return; }
-        if (!(w1 & WV_TK_INFO)) { unit_call(u, fn_ini, fn_ini_l); return; }       // a word of the common kind: the vocabulary function
-        // any other action (general form of phase A; lexers whose run / solo actions differ)
-        const uint32_t info = info16;
-        int tag; bool call = false; uint32_t ini = 0, ini_l = LX_NO_STATE;
-        if (info & LX_INFO_SIMPLE) tag = (int)(info & 0x7FFFFFFFu);
-        else { const int32_t *a = acts + info; tag = a[2]; ini = (uint32_t)a[5]; ini_l = (uint32_t)a[6]; call = true; }
-        if (tag != WBD_WORD_TAG) { unit_finish(u, 0); return; }                    // tags 2..4: neither a word nor a sub-token
-        if (!call) { u.home[0] = p.unk; unit_finish(u, 1); return; }               // a word without sub-tokens (tokdll:1282-1301)
-        unit_call(u, ini, ini_l);
+        uint16_t *zq = take ? &S.qc[sl] : &S.spare;
+        *zq = 0;
+        u.tok = take ? (int)t : u.tok;
+        u.rs = take ? e.pos : u.rs; u.Lk = take ? (int)((w1 & WV_TK_LEN_MASK) | (((w1 >> 16) & DMASK) << 16)) : u.Lk;
+        if (DBG >= 1) { if (take) unit_finish(u, 1); return; }
+        const bool other = take && (w1 & WV_TK_INFO) != 0;
+        unit_call(u, fn_ini, fn_ini_l, take && !other);                            // a word of the common kind: the vocabulary function
+        if (wv::any(other)) {
+            // any other action (general form of phase A; lexers whose run / solo actions differ)
+            if (other) {
+                const uint32_t info = info16;
+                int tag; bool call = false; uint32_t ini = 0, ini_l = LX_NO_STATE;
+                if (info & LX_INFO_SIMPLE) tag = (int)(info & 0x7FFFFFFFu);
+                else { const int32_t *a = acts + info; tag = a[2]; ini = (uint32_t)a[5]; ini_l = (uint32_t)a[6]; call = true; }
+                if (tag != WBD_WORD_TAG) unit_finish(u, 0);                            // tags 2..4: neither a word nor a sub-token
+                else if (!call) { S.q[sl].pos = (uint32_t)p.unk; unit_finish(u, 1); }  // a word without sub-tokens (tokdll:1282-1301)
+                else unit_call(u, ini, ini_l, true);
+            }
+        }
     }
     // One transition (FALexTools_t.h:255-277) for every lane at once, written without a branch: a lane whose unit is not walking
     // feeds its old state to the table as well and keeps everything it has.  walk = 0 afterwards: the walk is over (a miss, or the
@@ -459,19 +482,36 @@ struct WpWave {
         u.j += hit ? 1 : 0;
         u.walk = (hit && u.j < u.lim) ? 1 : 0;
     }
-    // The end of a walk: a match is a piece and the next walk starts behind it (FALexTools_t.h:390-393); the anchored walk without
-    // a match is followed by the plain walk at 0 (:293); any other walk without a match leaves a gap, the pieces cannot tile the
-    // word: UNK (tokdll:1252-1301)
-    BF_WVD void unit_event(Unit &u)
+    // The end of a walk (ev: this lane's unit has one): a match is a piece and the next walk starts behind it (FALexTools_t.h:390-393);
+    // the anchored walk without a match is followed by the plain walk at 0 (:293); any other walk without a match leaves a gap, the
+    // pieces cannot tile the word: UNK (tokdll:1252-1301)
+    BF_WVD void unit_event(Unit &u, bool ev)
     {
-        const bool matched = u.fp >= 0, gap = !matched && !u.anch;
-        if (matched) u.home[u.cnt] = (int32_t)(u.ftag & 0x7FFFFFFFu);
-        u.cnt += matched ? 1 : 0;
+        const int cnt0 = u.ca & 0xFFFF, L = u.Lk & 0xFFFF;
+        const bool matched = ev && u.fp >= 0, gap = ev && u.fp < 0 && !(u.ca >> 16);
+        const uint32_t sl = (uint32_t)u.tok & QMASK;
+        const int32_t id = (int32_t)(u.ftag & 0x7FFFFFFFu);
+        // The id of a word's only piece stays in LDS (in the queue entry's pos: the unit holds the word's ring position itself); with
+        // the second piece the first one moves to its provisional home and the entry gets the position back (retire finds the home by it)
+        const bool more = matched && cnt0 >= 1;
+        if (wv::any(more)) {
+            if (more) {
+                const uint32_t ke = (uint32_t)u.Lk >> 16;
+                int32_t *home = p.ids_tmp + S.dt_slot[ke] + (int64_t)(u.rs - S.dt_rbase[ke]);
+                if (cnt0 == 1) { home[0] = (int32_t)S.q[sl].pos; S.q[sl].pos = u.rs; }
+                home[cnt0] = id;
+            }
+        }
+        uint32_t *wp = (gap || (matched && cnt0 == 0)) ? &S.q[sl].pos : &S.spare32;
+        *wp = gap ? (uint32_t)p.unk : (uint32_t)id;
+        const int cnt = cnt0 + (matched ? 1 : 0);
         const int nf = matched ? u.fp + 1 : 0;
-        if (gap) u.home[0] = p.unk;
-        if (gap || nf >= u.L) { unit_finish(u, gap ? 1 : u.cnt); return; }
+        const bool fin = gap || (ev && nf >= L), go = ev && !fin;
+        uint16_t *cq = fin ? &S.qc[sl] : &S.spare;
+        *cq = (uint16_t)((gap ? 1 : cnt) + 1);
         const int b = nf + p.max_token_length;
-        u.state = u.ini; u.j = nf; u.lim = b < u.L ? b : u.L; u.fp = -1; u.anch = 0; u.walk = 1;
+        u.state = go ? u.ini : u.state; u.j = go ? nf : u.j; u.lim = go ? (b < L ? b : L) : u.lim; u.fp = go ? -1 : u.fp;
+        u.ca = go ? cnt : u.ca; u.walk = go ? 1 : u.walk; u.tok = fin ? -1 : u.tok;
     }
     // Runs the units until the queue is handed out and fewer than UNIT_MIN of them are still busy (`drain`: until all are done).
     // A round: the units whose walk is over take its result (piece / next walk / word finished), idle units take the next queued
@@ -488,13 +528,14 @@ struct WpWave {
             int nb = 0;
 #pragma unroll
             for (int i = 0; i < NU; ++i) {
-                if (u[i].tok >= 0 && !u[i].walk) unit_event(u[i]);
+                const bool ev = u[i].tok >= 0 && !u[i].walk;
+                if (wv::any(ev)) unit_event(u[i], ev);
                 const uint32_t avail = tail - issue;
                 unsigned long long idle = wv::ballot(u[i].tok < 0);
                 if (avail != 0 && idle != 0) {
                     const uint32_t r = wv::mbcnt(idle);
                     const bool take = u[i].tok < 0 && r < avail;
-                    if (take) unit_begin(u[i], issue + r);
+                    unit_begin(u[i], issue + r, take);
                     const uint32_t k = (uint32_t)__builtin_popcountll(idle);
                     issue += k < avail ? k : avail;
                     idle = wv::ballot(u[i].tok < 0);
@@ -515,6 +556,14 @@ struct WpWave {
             ran = true;
         }
         q_issue = issue;
+        // what the units that stay busy still read of the ring (the queue entry of a token a unit has taken no longer holds its position)
+        u_need = 0xFFFFFFFFu;
+        {
+            uint32_t need = 0xFFFFFFFFu;
+#pragma unroll
+            for (int i = 0; i < NU; ++i) if (u[i].tok >= 0) { const uint32_t d = u[i].rs - rlo; need = d < need ? d : need; }
+            if (wv::any(need != 0xFFFFFFFFu)) u_need = wv::min_all(need);
+        }
         wv::sync();
         return ran;
     }
@@ -542,14 +591,15 @@ struct WpWave {
         if (STATS) ++st_ret;
         const bool act = lane < nret;
         const int cnt = act ? cnt0 : 0;
-        const int k = act ? (int)((S.q1[sl] >> 16) & 0xFFu) : -1;
+        const WvTok te = S.q[sl];
+        const int k = act ? (int)((te.w >> 16) & 0xFFu) : -1;
         const uint32_t ke = (uint32_t)k & DMASK;
         int64_t slot = 0; int cap = 0, dcnt = 0; uint32_t f = 0;
-        if (act) { slot = S.dt_slot[ke]; cap = S.dt_cap[ke]; dcnt = S.dt_cnt[ke]; f = S.q0[sl] - S.dt_rbase[ke]; }
-        const int32_t *src = p.ids_tmp + slot + (int64_t)f;
-        int32_t v0 = 0, v1 = 0, v2 = 0, v3 = 0;
-        if (cnt > 0) v0 = src[0];
-        if (cnt > 1) v1 = src[1];
+        uint32_t w0 = 0;
+        if (act) { slot = S.dt_slot[ke]; cap = S.dt_cap[ke]; dcnt = S.dt_cnt[ke]; w0 = te.pos; f = w0 - S.dt_rbase[ke]; }
+        const int32_t *src = p.ids_tmp + slot + (int64_t)f;          // used by words of two and more pieces only (unit_event)
+        int32_t v0 = (int32_t)w0, v1 = 0, v2 = 0, v3 = 0;            // a single piece is in q0 itself
+        if (cnt > 1) { v0 = src[0]; v1 = src[1]; }
         if (cnt > 2) v2 = src[2];
         if (cnt > 3) v3 = src[3];
         const int inc = wv::incl_scan(cnt), exc = inc - cnt;
@@ -593,7 +643,7 @@ struct WpWave {
     {
         bool moved = false;
         uint32_t limit;
-        if (q_retire != q_tail) limit = dt_head + ((((S.q1[q_retire & QMASK] >> 16) & 0xFFu) - dt_head) & 0xFFu);
+        if (q_retire != q_tail) limit = dt_head + ((((S.q[q_retire & QMASK].w >> 16) & 0xFFu) - dt_head) & 0xFFu);
         else limit = have_doc ? curk : dt_tail;
         if (limit != dt_head) {
             const uint32_t kk = dt_head + (uint32_t)lane;
@@ -604,10 +654,12 @@ struct WpWave {
             }
             dt_head = limit; moved = true;
         }
+        // the ring is needed from: the units still busy, the oldest token no unit has taken, the open document's unresolved part
         const uint32_t old_lo = rlo;
-        if (q_retire != q_tail) rlo = S.q0[q_retire & QMASK];
-        else rlo = have_doc ? rbase + (uint32_t)(open_start >= 0 ? open_start : done) : rhi;
-        return moved || rlo != old_lo;
+        uint32_t keep = q_issue != q_tail ? S.q[q_issue & QMASK].pos - old_lo : (have_doc ? rbase + (uint32_t)(open_start >= 0 ? open_start : done) : rhi) - old_lo;
+        if (u_need < keep) keep = u_need;
+        rlo = old_lo + keep; u_need -= u_need == 0xFFFFFFFFu ? 0u : keep;
+        return moved || keep != 0;
     }
 
     // starts the document [b, e) of the text; false: nothing to tokenise (its count is written here)
@@ -648,10 +700,11 @@ struct WpWave {
                 base = wv::bcast(base, 0);
                 if ((int64_t)base >= p.ndocs) { exiting = true; return false; }
                 dbase = (int64_t)base; dnext = dbase; dend = dbase + grab < p.ndocs ? dbase + grab : p.ndocs;
-                if (lane <= (int)(dend - dbase)) off_lane = p.doc_off[dbase + lane];
+                if (lane <= (int)(dend - dbase)) S.doff[lane] = p.doc_off[dbase + lane];
+                wv::sync();
             }
             const int i = (int)(dnext - dbase);
-            const int64_t b = wv::bcast(off_lane, i), e = wv::bcast(off_lane, i + 1);
+            const int64_t b = S.doff[i], e = S.doff[i + 1];
             have_doc = open_document(dnext, b, e);
             ++dnext;
             return true;
@@ -675,9 +728,10 @@ struct WpWave {
 
     BF_WVD void run(int grab)
     {
+        grab = grab < 1 ? 1 : (grab > WV_GRAB_MAX ? WV_GRAB_MAX : grab);
         Unit u[NU];
 #pragma unroll
-        for (int i = 0; i < NU; ++i) { u[i].tok = -1; u[i].walk = 0; u[i].rs = 0; u[i].j = 0; u[i].state = 0; u[i].lim = 0; u[i].fp = -1; u[i].ftag = 0; }
+        for (int i = 0; i < NU; ++i) { u[i].tok = -1; u[i].walk = 0; u[i].rs = 0; u[i].j = 0; u[i].state = 0; u[i].lim = 0; u[i].fp = -1; u[i].ftag = 0; u[i].Lk = 0; u[i].ca = 0; u[i].ini = 0; }
         for (;;) {
             bool moved = settle();
             bool filled = false;

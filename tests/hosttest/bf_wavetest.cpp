@@ -61,7 +61,7 @@ long bft_emu_wave_batch(void *hv, const uint8_t *text, long text_bytes, const in
     if (ndocs > 0) {
         if (cfg == 1) run_cfg<WvLds<1024, 128, 2>, 2>(p, nwaves, grab);
         else if (cfg == 2) run_cfg<WvLds<4096, 512, 64>, 3>(p, nwaves, grab);
-        else run_cfg<WvLds<2048, 256, 16>, 1>(p, nwaves, grab);
+        else run_cfg<WvLds<1024, 256, 8>, 1>(p, nwaves, grab);
     }
     if (status) return -5;
     // k_scan + k_compact, restated

@@ -170,6 +170,13 @@ __attribute__((noinline)) static int incl_scan(int v WV_SITE_ARG)
     int64_t a = 0; for (int i = 0; i <= me; ++i) a += (int64_t)s[i];
     return (int)a;
 }
+// the smallest value any lane holds
+__attribute__((noinline)) static uint32_t min_all(uint32_t v WV_SITE_ARG)
+{
+    const uint64_t *s = wvemu::collective((uint64_t)v, WV_SITE);
+    uint32_t m = 0xFFFFFFFFu; for (int i = 0; i < 64; ++i) if ((uint32_t)s[i] < m) m = (uint32_t)s[i];
+    return m;
+}
 // a value every lane holds alike (the device moves it to a scalar register): checked
 template <class T> __attribute__((noinline)) static T uni(T v WV_SITE_ARG)
 {
