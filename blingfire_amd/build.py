@@ -4,6 +4,7 @@
   oracle/liboracle.so                   TEST INFRA: plain-C restatement of the reference path
   oracle/libcpubaseline.so              TEST INFRA: multi-threaded driver that times a TextToIds .so on host cores
   tools/libcorpusgen.so                 TEST INFRA: deterministic synthetic corpus generator
+  tools/single_calls                    TEST INFRA: native-thread harness for single-document calls through the C-ABI
   tests/hosttest/libbf_hosttest.so      TEST INFRA: table-equivalence + host emulation of the lane programs
   oracle/_ref/libblingfiretokdll_ref.so TEST INFRA: the unmodified reference, only when /root/reference exists
 """
@@ -62,6 +63,9 @@ def build_test_infra(force=False):
     if force or _newer(cg, [os.path.join(ROOT, "tools", "corpusgen.c")]):
         _run(["gcc", "-O2", "-Wall", "-std=gnu99", "-fPIC", "-shared", "corpusgen.c", "-o", "libcorpusgen.so", "-lm", "-lpthread"],
              cwd=os.path.join(ROOT, "tools"))
+    sc = os.path.join(ROOT, "tools", "single_calls")
+    if force or _newer(sc, [os.path.join(ROOT, "tools", "single_calls.c")]):
+        _run(["gcc", "-O2", "-Wall", "-o", "single_calls", "single_calls.c", "-ldl", "-lpthread"], cwd=os.path.join(ROOT, "tools"))
     ht = os.path.join(ROOT, "tests", "hosttest", "libbf_hosttest.so")
     ht_src = [os.path.join(ROOT, "tests", "hosttest", "bf_hosttest.cpp"), os.path.join(ROOT, "tests", "hosttest", "bf_wavetest.cpp"), os.path.join(CSRC, "bf_model.cpp")]
     ht_dep = ht_src + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + [os.path.join(odir, "bf_oracle.c"),

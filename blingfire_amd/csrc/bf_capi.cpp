@@ -10,6 +10,10 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
+#include <linux/futex.h>
+#include <sys/syscall.h>
+#include <unistd.h>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -154,8 +158,9 @@ struct Handle {
     DevBuf w_text, w_docoff, w_ids, w_idoff, w_starts, w_ends;  // host-API staging
     DevBuf w_srcoff, w_span;                                    // offsets API: source-offset stream, staged id spans
     // single-document calls that arrive while a batch is in flight are combined into the next launch (text_to_ids_one)
-    struct OneReq { const char *s; int n; int32_t *ids; int max_ids, unk; int32_t *starts, *ends; int result; bool done; };
-    std::mutex q_mu; std::condition_variable q_cv; std::vector<OneReq *> q; bool q_leader = false;
+    struct OneReq { const char *s; int n; int32_t *ids; int max_ids, unk; int32_t *starts, *ends; int result; std::atomic<int> state; };
+    std::mutex q_mu; std::vector<OneReq *> q; bool q_leader = false; std::atomic<int> q_spinners{0}, q_sleepers{0};
+    std::atomic<long long> one_rounds{0}, one_reqs{0}, one_ns{0};          // BF_TRACE_ONE=1: launches for single-document calls, requests served, time inside them
     hipStream_t stream = nullptr;
     hipEvent_t ev[EV_COUNT] = {};
     bool ev_valid = false;
@@ -622,7 +627,7 @@ int64_t run_host_mapped(Handle *h, const char *text, const int64_t *doc_off, int
     wp.initial = m.wbd.initial_base; wp.loop_info = m.loop_info; wp.solo_info = m.wave_solo_info; wp.max_token_length = m.max_token_length;
     wp.text = (const uint8_t *)(dp + SmallLayout::text); wp.doc_off = (const int64_t *)(dp + SmallLayout::off); wp.ndocs = ndocs; wp.total_bytes = total;
     wp.ids_tmp = (int32_t *)(dp + SmallLayout::ids); wp.counts = (int32_t *)(dp + SmallLayout::counts); wp.max_ids = max_ids < 0 ? 0 : max_ids; wp.unk = unk;
-    wp.next_doc = (unsigned long long *)(dp + SmallLayout::ctrl);
+    wp.next_doc = nullptr;              // no work counter: an atomic on host memory costs every wave a trip over the bus
     wp.cold.cpmap = DevCpMap{h->t_cp_l1.as<uint16_t>(), h->t_cp_pages.as<uint32_t>()};
     wp.cold.kind = h->t_kind.as<uint8_t>(); wp.cold.nclasses = m.wbd.nclasses; wp.cold.status = (int *)(dp + SmallLayout::ctrl + 16); wp.cold.no_fast = 0; wp.cold.stats = nullptr;
     launch_wp_wave(wp, h->variant, h->stream);
@@ -938,10 +943,24 @@ void run_one_group(Handle *h, std::vector<Handle::OneReq *> &g)
     }
 }
 
+static const int g_max_spinners = []() { const unsigned hc = std::thread::hardware_concurrency(); const int k = (int)(hc / 4); return k < 1 ? 1 : (k > 64 ? 64 : k); }();
+
+// a request's state word: the caller sleeps on it (futex), the leader that served the request -- or hands the lead over -- changes it
+enum { ONE_WAITING = 0, ONE_DONE = 1, ONE_LEAD = 2 };
+static void one_wait_word(std::atomic<int> *w, int timeout_us)
+{
+    struct timespec ts = {0, (long)timeout_us * 1000};
+    (void)syscall(SYS_futex, (int *)w, FUTEX_WAIT_PRIVATE, ONE_WAITING, &ts, nullptr, 0);
+}
+static void one_wake_word(std::atomic<int> *w) { (void)syscall(SYS_futex, (int *)w, FUTEX_WAKE_PRIVATE, 1, nullptr, nullptr, 0); }
+
 // TextToIds for one document.  The GPU runs batches: a call that arrives while another one is in flight on the same handle
-// waits in a queue, and whoever finishes next launches everything that queued up as ONE batch (flat combining) -- so that
-// concurrent callers of the drop-in entry points (C#, Python threads: SURVEY.md section 8b "Threading") share launches instead
-// of serialising one ~60 us launch each.  A lone caller simply runs its own batch of one.
+// waits in a queue, and whoever leads launches everything that queued up as ONE batch (flat combining) -- so that concurrent
+// callers of the drop-in entry points (C#, Python threads: SURVEY.md section 8b "Threading") share launches instead of serialising
+// one ~30 us launch each.  A lone caller simply runs its own batch of one.  A waiting caller watches its own state word: for about
+// the length of a launch without a system call (up to g_max_spinners callers at a time), then asleep on it; whoever served it
+// wakes that one word.  (Measured with 64 native threads, profiles/r03_single_calls.txt: one condition variable for all callers
+// cost ~340 us per launch in wake-ups and mutex hand-overs, against ~45 us for the launch itself.)
 int text_to_ids_one(void *hp, const char *s, int n, int32_t *ids, int max_ids, int unk, int want_kind /* -1 any, 0 wp, 1 sp */,
                     int32_t *starts = nullptr, int32_t *ends = nullptr)
 {
@@ -951,11 +970,31 @@ int text_to_ids_one(void *hp, const char *s, int n, int32_t *ids, int max_ids, i
     if (want_kind == 0 && h->m.kind != KIND_WP) return 0;
     if (want_kind == 1 && h->m.kind == KIND_WP) return 0;
     if (max_ids <= 0 || !ids) return 0;
-    Handle::OneReq me{s, n, ids, max_ids, unk, starts, ends, 0, false};
+    Handle::OneReq me{s, n, ids, max_ids, unk, starts, ends, 0, {ONE_WAITING}};
     std::unique_lock<std::mutex> lk(h->q_mu);
     h->q.push_back(&me);
-    while (h->q_leader && !me.done) h->q_cv.wait(lk);
-    if (me.done) return me.result;
+    if (h->q_leader) {
+        lk.unlock();
+        for (;;) {
+            if (h->q_spinners.fetch_add(1) < g_max_spinners) {
+                for (int spin = 0; spin < 3000 && me.state.load(std::memory_order_acquire) == ONE_WAITING; ++spin) __builtin_ia32_pause();
+            }
+            h->q_spinners.fetch_sub(1);
+            if (me.state.load(std::memory_order_acquire) != ONE_WAITING) break;
+            h->q_sleepers.fetch_add(1);
+            if (me.state.load() == ONE_WAITING) one_wait_word(&me.state, 2000);
+            h->q_sleepers.fetch_sub(1);
+            if (me.state.load(std::memory_order_acquire) != ONE_WAITING) break;
+            // nothing after 2 ms (or a stray wake-up): the lead may be free -- it is handed over, never dropped with requests queued,
+            // so this is only a safeguard
+            lk.lock();
+            if (me.state.load(std::memory_order_acquire) != ONE_WAITING) { lk.unlock(); break; }
+            if (!h->q_leader) { h->q_leader = true; me.state.store(ONE_LEAD); lk.unlock(); break; }
+            lk.unlock();
+        }
+        if (me.state.load(std::memory_order_acquire) == ONE_DONE) return me.result;
+        lk.lock();                                            // ONE_LEAD: the lead was handed to this caller (q_leader stays set)
+    }
     h->q_leader = true;                                       // lead: serve everything queued (at least my own request)
     for (int round = 0; round < 4 && !h->q.empty(); ++round) {
         std::vector<Handle::OneReq *> all; all.swap(h->q);
@@ -969,17 +1008,28 @@ int text_to_ids_one(void *hp, const char *s, int n, int32_t *ids, int max_ids, i
                 // the combined batch stays within the limits of one launch
                 if (g.empty() || (same && bytes + q->n <= 1000000000 && idcap + c <= 1000000000)) { g.push_back(q); bytes += q->n; idcap += c; } else rest.push_back(q);
             }
+            const auto t0 = std::chrono::steady_clock::now();
             run_one_group(h, g);
-            lk.lock();
-            for (Handle::OneReq *q : g) q->done = true;
-            h->q_cv.notify_all();
-            lk.unlock();
+            h->one_rounds.fetch_add(1, std::memory_order_relaxed); h->one_reqs.fetch_add((long long)g.size(), std::memory_order_relaxed);
+            h->one_ns.fetch_add(std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count(), std::memory_order_relaxed);
+            // a request is gone once its caller has seen ONE_DONE: nothing of *q is read afterwards (waking a word nobody sleeps on
+            // is harmless, also when its stack frame is no longer live)
+            for (Handle::OneReq *q : g) {
+                if (q == &me) continue;
+                std::atomic<int> *w = &q->state;
+                w->store(ONE_DONE);
+                if (h->q_sleepers.load() > 0) one_wake_word(w);
+            }
             all.swap(rest);
         }
         lk.lock();
     }
-    h->q_leader = false;                                      // anything still queued is led by one of its own callers
-    h->q_cv.notify_all();
+    // requests still queued are led by one of their own callers: the lead is handed to the oldest of them
+    if (!h->q.empty()) {
+        std::atomic<int> *w = &h->q.front()->state;
+        w->store(ONE_LEAD);
+        if (h->q_sleepers.load() > 0) one_wake_word(w);
+    } else h->q_leader = false;
     return me.result;
 }
 
@@ -1122,6 +1172,9 @@ int FreeModel(void *p)
     if (!h) return 0;
     DeviceGuard dg(h->device);
     (void)hipDeviceSynchronize();
+    if (getenv("BF_TRACE_ONE") && h->one_rounds.load() > 0)
+        fprintf(stderr, "[blingfire_amd] single-document calls: %lld requests in %lld launches (%.1f per launch), %.1f us per launch\n", h->one_reqs.load(), h->one_rounds.load(),
+                (double)h->one_reqs.load() / (double)h->one_rounds.load(), 1e-3 * (double)h->one_ns.load() / (double)h->one_rounds.load());
     delete h;
     return 1;
 }

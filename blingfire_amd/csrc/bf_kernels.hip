@@ -685,7 +685,7 @@ __device__ __forceinline__ uint32_t mbcnt(unsigned long long m) { return __built
 namespace bfa {
 
 // WPE: waves per SIMD the register allocation is asked to allow (a workgroup is four waves, one per SIMD: WPE workgroups per CU)
-template <class LDS, int NU, int STEPS, int WPE, bool STATS, int DBG = 0, int UMIN = 12, int CROOM = 0>
+template <class LDS, int NU, int STEPS, int WPE, bool STATS, int DBG = 0, int UMIN = 4, int CROOM = 0>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_wp_wave(WpWaveParams p, int grab)
 {
     __shared__ LDS lds[4];
@@ -698,10 +698,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
     __syncthreads();
     // the wave number as a scalar: what a wave reads of its own LDS block at a wave-uniform index is then wave-uniform for the compiler too
     WpWave<LDS, NU, STATS, DBG, STEPS, UMIN, CROOM> w(p, cold, lds[__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))], ascii, acts);
-    w.run(grab);
+    w.run(grab, __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6))), (int)(gridDim.x * 4));
 }
 
-template <class LDS, int NU, int STEPS, int WPE, int UMIN = 12>
+template <class LDS, int NU, int STEPS, int WPE, int UMIN = 4>
 static void launch_wp_wave_cfg(const WpWaveParams &p, int grab, int per_cu_override, hipStream_t s)
 {
     static int per_cu_cached = 0;                 // per instance; a property of the kernel and the device kind
@@ -725,14 +725,20 @@ static void launch_wp_wave_cfg(const WpWaveParams &p, int grab, int per_cu_overr
 void launch_wp_wave(const WpWaveParams &p, int variant, hipStream_t s)
 {
     const int cfg = (variant >> 8) & 0xf;
-    int grab = (variant >> 12) & 0xf; if (grab == 0 || grab > WV_GRAB_MAX) grab = WV_GRAB_MAX;
+    int grab = (variant >> 12) & 0xf;
+    if (grab == 0 || grab > WV_GRAB_MAX) {
+        // documents a wave takes from the work counter at once: eight in a large batch (one atomic per 4 KB of text); a batch with fewer
+        // documents than that would give every wave is spread over the waves one by one (a batch of 64 single sentences: 64 waves)
+        const int64_t per_wave = p.ndocs / ((int64_t)device_cus() * 32);
+        grab = per_wave >= WV_GRAB_MAX ? WV_GRAB_MAX : per_wave < 1 ? 1 : (int)per_wave;
+    }
     const int per_cu = (variant >> 24) & 0x3f;
     // Shipped: a ring of 1,024 elements (the longest word + one chunk fit: bf_model.cpp "unit form"), a queue of 256 tokens, a table of 8
     // open documents, eight workgroups per CU (eight waves per SIMD: 64 VGPRs, 20 KB of LDS per workgroup).  Measured on 10 M documents
     // of 512 bytes (profiles/r03_*): 25.9 ms; seven workgroups (72 VGPRs) 27.7; six 29.9; a ring of 2,048 and five workgroups 32.3; a
     // queue of 128 tokens and seven / eight workgroups 35.1 / 33.1; transitions per round 2 / 3 / 4 / 6 (at five workgroups): 33.9 /
     // 33.0 / 33.6 / 36.6; two units per lane 39.4; leaving the units phase with fewer than 12 / 24 / 32 / 48 busy units 27.7 / 28.1 /
-    // 28.2 / 28.8 (at seven workgroups).
+    // 28.2 / 28.8 (at seven workgroups), 4 / 12 / 24: 25.7 / 26.0 / 26.3 (at eight).
     typedef WvLds<1024, 256, 8> L;
     if (cfg == 14 || cfg == 15) {       // experiments: phase costs by difference (results are wrong by design)
         const int64_t nb = (int64_t)device_cus() * 8;
@@ -743,8 +749,8 @@ void launch_wp_wave(const WpWaveParams &p, int variant, hipStream_t s)
     if (cfg == 1) launch_wp_wave_cfg<WvLds<1024, 256, 16>, 1, 3, 7>(p, grab, per_cu, s);                    // experiments: occupancy
     else if (cfg == 2) launch_wp_wave_cfg<WvLds<1024, 256, 16>, 1, 3, 6>(p, grab, per_cu, s);
     else if (cfg == 4) launch_wp_wave_cfg<WvLds<2048, 256, 16>, 1, 3, 5>(p, grab, per_cu, s);
-    else if (cfg == 5) launch_wp_wave_cfg<L, 1, 3, 8, 4>(p, grab, per_cu, s);                                 // experiments: when the units phase ends
-    else if (cfg == 6) launch_wp_wave_cfg<L, 1, 3, 8, 24>(p, grab, per_cu, s);
+    else if (cfg == 5) launch_wp_wave_cfg<L, 1, 3, 8, 1>(p, grab, per_cu, s);                                 // experiments: when the units phase ends
+    else if (cfg == 6) launch_wp_wave_cfg<L, 1, 3, 8, 12>(p, grab, per_cu, s);
     else launch_wp_wave_cfg<L, 1, 3, 8>(p, grab, per_cu, s);
 }
 

@@ -43,7 +43,7 @@ struct WvLds {
 
 // DBG (experiments, wrong results by design): 1 = units finish at once without walking, 2 = also nothing is moved at retire:
 // instruction counts of the phases by difference (profiles/r03_phase_costs.txt)
-template <class LDS, int NU = 2, bool STATS = false, int DBG = 0, int STEPS = 3, int UMIN = 12, int CROOM = 0>
+template <class LDS, int NU = 2, bool STATS = false, int DBG = 0, int STEPS = 3, int UMIN = 4, int CROOM = 0>
 struct WpWave {
     static constexpr int RING = LDS::RING, QCAP = LDS::QCAP, DTN = LDS::DTN;
     static constexpr uint32_t RMASK = RING - 1, QMASK = QCAP - 1, DMASK = DTN - 1;
@@ -58,6 +58,7 @@ struct WpWave {
     uint32_t q_tail, q_issue, q_retire;   // tokens: queued / handed to a unit / retired (absolute counters; slot = counter & QMASK)
     uint32_t dt_head, dt_tail;       // document table entries in use (absolute counters)
     int64_t dnext, dend, dbase;      // the range of documents this wave took from the work counter (their offsets: S.doff[])
+    int64_t st_next, st_step;        // without a work counter: the next range of this wave, and the stride to the one after
     bool have_doc, exiting;
     // current document
     const uint8_t *s; int n; uint32_t rbase; int dec_bytes, dec, done, open_start, bom; uint32_t curk;
@@ -696,8 +697,10 @@ struct WpWave {
             if (exiting || dt_tail - dt_head >= (uint32_t)DTN) return false;
             if (dnext >= dend) {
                 unsigned long long base = 0;
-                if (lane == 0) base = wv::atomic_add(p.next_doc, (unsigned long long)grab);
-                base = wv::bcast(base, 0);
+                if (p.next_doc) {
+                    if (lane == 0) base = wv::atomic_add(p.next_doc, (unsigned long long)grab);
+                    base = wv::bcast(base, 0);
+                } else { base = (unsigned long long)st_next; st_next += st_step; }       // no work counter: ranges dealt out round-robin (small batches)
                 if ((int64_t)base >= p.ndocs) { exiting = true; return false; }
                 dbase = (int64_t)base; dnext = dbase; dend = dbase + grab < p.ndocs ? dbase + grab : p.ndocs;
                 if (lane <= (int)(dend - dbase)) S.doff[lane] = p.doc_off[dbase + lane];
@@ -726,9 +729,11 @@ struct WpWave {
         return false;
     }
 
-    BF_WVD void run(int grab)
+    // wave_id / n_waves: this wave's number and the number of waves of the launch (used when the batch has no work counter)
+    BF_WVD void run(int grab, int wave_id, int n_waves)
     {
         grab = grab < 1 ? 1 : (grab > WV_GRAB_MAX ? WV_GRAB_MAX : grab);
+        st_next = (int64_t)wave_id * grab; st_step = (int64_t)n_waves * grab;
         Unit u[NU];
 #pragma unroll
         for (int i = 0; i < NU; ++i) { u[i].tok = -1; u[i].walk = 0; u[i].rs = 0; u[i].j = 0; u[i].state = 0; u[i].lim = 0; u[i].fp = -1; u[i].ftag = 0; u[i].Lk = 0; u[i].ca = 0; u[i].ini = 0; }

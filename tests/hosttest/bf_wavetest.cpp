@@ -28,7 +28,7 @@ static void run_cfg(const WpWaveParams &p, int nwaves, int grab)
         for (; k < wave_ids.size(); ++k) if (wave_ids[k] == wid) break;
         if (k == wave_ids.size()) { wave_ids.push_back(wid); (void)next_wave; }
         WpWave<LDS, NU, true> w(p, p.cold, *of_wave[k], ascii.data(), p.acts);
-        w.run(grab);
+        w.run(grab, (int)k, nwaves);
     };
     wvemu::run_waves(nwaves, body);
     for (auto *q : of_wave) delete q;
@@ -56,6 +56,7 @@ long bft_emu_wave_batch(void *hv, const uint8_t *text, long text_bytes, const in
     p.initial = m.wbd.initial_base; p.loop_info = m.loop_info; p.solo_info = m.wave_solo_info; p.max_token_length = m.max_token_length;
     p.text = text; p.doc_off = doc_off; p.ndocs = ndocs; p.total_bytes = total;
     p.ids_tmp = tmp.data(); p.counts = counts.data(); p.max_ids = max_ids; p.unk = unk; p.next_doc = &next_doc;
+    if (cfg >= 16) { p.next_doc = nullptr; cfg -= 16; }            // cfg + 16: no work counter, the waves take their ranges round-robin
     p.cold.cpmap = DevCpMap{m.wbd_cpmap.l1.data(), m.wbd_cpmap.pages.data()};
     p.cold.kind = m.wave_kind.data(); p.cold.nclasses = m.wbd.nclasses; p.cold.status = &status; p.cold.stats = stats; p.cold.no_fast = cfg == 1 ? 1 : 0;
     if (ndocs > 0) {

@@ -14,8 +14,9 @@ import blingfire_amd as bf
 
 WP_MODELS = ["bert_base_tok.bin", "bert_base_cased_tok.bin", "bert_chinese.bin"]
 # (max_ids, unk, waves, documents per grab, configuration: 0 = shipped, 1 = two units per lane / smallest ring and queue / two-entry
-#  document table, 2 = three units per lane / large ring and queue)
-CONFS = [(512, 100, 1, 8, 0), (512, 100, 4, 2, 1), (64, 5, 2, 8, 2), (1, 100, 1, 3, 1), (0, 100, 2, 8, 0)]
+#  document table, 2 = three units per lane / large ring and queue; + 16 = no work counter, the waves take their ranges round-robin
+#  -- the form small host batches run in)
+CONFS = [(512, 100, 1, 8, 0), (512, 100, 4, 2, 1), (64, 5, 2, 8, 2), (1, 100, 1, 3, 1), (0, 100, 2, 8, 0), (512, 100, 5, 1, 16)]
 
 
 @pytest.fixture(scope="module")
@@ -93,7 +94,7 @@ def test_long_words_window_edges_and_large_documents(ht, model):
     docs.append(" ".join("".join(rnd.choice(alpha) for _ in range(rnd.randint(1, 12))) for _ in range(30000)).encode())      # ~200 KB
     docs.append(b"\xef\xbb\xbf" + ("word é " * 3000).encode())
     docs.append(("w" * 700 + " ").encode() * 40)
-    check(ht, model, docs, CONFS[:3])
+    check(ht, model, docs, CONFS[:3] + CONFS[5:])
 
 
 @pytest.mark.parametrize("model", WP_MODELS)
@@ -102,7 +103,7 @@ def test_many_tiny_documents(ht, model):
         pytest.skip("%s not present" % model)
     rnd = random.Random(3)
     docs = [bytes([rnd.randrange(32, 127)]) for _ in range(500)] + [b"ab"] * 100 + [b"\xff"] * 5 + [b"a b"] * 70
-    check(ht, model, docs, CONFS[:3])
+    check(ht, model, docs, CONFS[:3] + CONFS[5:])
 
 
 def test_headline_and_config2_corpora(ht):
