@@ -46,6 +46,11 @@ __device__ __forceinline__ uint32_t cpmap_get(const DevCpMap &m, int cp)
 // Hand-off between the lanes of ONE wave through LDS (or global memory): the producer's stores are released and the consumer's
 // loads acquired at wavefront scope, and the compiler may not move either across this point.  (The lanes of a wave run in
 // lockstep and DS operations of a wave complete in order, so this costs nothing at run time; it pins what the code relies on.)
+// the number of this wave inside its workgroup AS A SCALAR: threadIdx.x / 64 is the same in all lanes of a wave, but only readfirstlane
+// tells the compiler so -- what a wave-per-document kernel derives from it (document number, lengths, loop bounds, LDS block) then
+// stays in scalar registers and its loops are scalar branches instead of execution-mask loops (k_wp_wave: 96 -> 78 VGPRs, 39 -> 33 ms)
+__device__ __forceinline__ int wave_in_block() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
+
 __device__ __forceinline__ void wave_handoff()
 {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -200,9 +205,9 @@ __global__ __launch_bounds__(256) void k_prep_wp(WpPrepParams p)
     __shared__ uint16_t stage_all[4 * 512];
     prep_ascii_table(p, ascii_cls);
     const int lane = lane_id();
-    const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t wave0 = (int64_t)blockIdx.x * 4 + wave_in_block();
     const int64_t nwaves = (int64_t)gridDim.x * 4;
-    for (int64_t d = wave0; d < p.b.ndocs; d += nwaves) { const int64_t b = p.b.doc_off[d]; prep_wp_doc(p, d, b, p.b.doc_off[d + 1] - b, lane, ascii_cls, stage_all + (threadIdx.x >> 6) * 512); }
+    for (int64_t d = wave0; d < p.b.ndocs; d += nwaves) { const int64_t b = p.b.doc_off[d]; prep_wp_doc(p, d, b, p.b.doc_off[d + 1] - b, lane, ascii_cls, stage_all + wave_in_block() * 512); }
 }
 
 // Two-pass form for the common case (no offsets wanted).  An all-ASCII document whose characters all map 1:1 has
@@ -253,7 +258,7 @@ __global__ __launch_bounds__(256) void k_prep_wp_docs(WpPrepParams p, const unsi
     __shared__ uint16_t stage_all[4 * 512];
     prep_ascii_table(p, ascii_cls);
     const int lane = lane_id();
-    const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t wave0 = (int64_t)blockIdx.x * 4 + wave_in_block();
     const int64_t nwaves = (int64_t)gridDim.x * 4;
     for (int64_t d0 = wave0 * 64; d0 < p.b.ndocs; d0 += nwaves * 64) {
         const int64_t d = d0 + lane;
@@ -279,7 +284,7 @@ __global__ __launch_bounds__(256) void k_prep_wp_docs(WpPrepParams p, const unsi
         while (m) {
             const int k = __ffsll((long long)m) - 1; m &= m - 1;
             const int64_t bk = __shfl((long long)b, k, 64), nk = __shfl((long long)n64, k, 64);
-            prep_wp_doc(p, d0 + k, bk, nk, lane, ascii_cls, stage_all + (threadIdx.x >> 6) * 512);
+            prep_wp_doc(p, d0 + k, bk, nk, lane, ascii_cls, stage_all + wave_in_block() * 512);
         }
     }
 }
@@ -679,6 +684,8 @@ __device__ __forceinline__ void atomic_or(int *p, int v) { atomicOr(p, v); }
 __device__ __forceinline__ unsigned long long clock() { return __builtin_readcyclecounter(); }
 __device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+// a wave-uniform value the compiler may not trace back to where it came from (it then lives in a scalar register of its own)
+__device__ __forceinline__ int own(int v) { asm volatile("" : "+s"(v)); return v; }
 __device__ __forceinline__ uint32_t mbcnt(unsigned long long m) { return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)); }
 } // namespace wv
 #include "bf_wave_body.h"
@@ -697,8 +704,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
     for (int i = (int)threadIdx.x; i < p.acts_n; i += 256) acts[i] = p.acts[i];
     __syncthreads();
     // the wave number as a scalar: what a wave reads of its own LDS block at a wave-uniform index is then wave-uniform for the compiler too
-    WpWave<LDS, NU, STATS, DBG, STEPS, UMIN, CROOM> w(p, cold, lds[__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))], ascii, acts);
-    w.run(grab, __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6))), (int)(gridDim.x * 4));
+    WpWave<LDS, NU, STATS, DBG, STEPS, UMIN, CROOM> w(p, cold, lds[wave_in_block()], ascii, acts);
+    w.run(grab, (int)(blockIdx.x * 4) + wave_in_block(), (int)(gridDim.x * 4));
 }
 
 template <class LDS, int NU, int STEPS, int WPE, int UMIN = 4>
@@ -837,7 +844,7 @@ __global__ __launch_bounds__(256) void k_prep_sp(SpPrepParams p)
     if (threadIdx.x < 128) ascii_v[threadIdx.x] = cpmap_get(p.cpmap, (int)threadIdx.x);
     __syncthreads();
     const int lane = lane_id();
-    const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t wave0 = (int64_t)blockIdx.x * 4 + wave_in_block();
     const int64_t nwaves = (int64_t)gridDim.x * 4;
     const uint32_t D = p.delim_code;
     for (int64_t d = wave0; d < p.b.ndocs; d += nwaves) {
@@ -1853,7 +1860,7 @@ __device__ __forceinline__ I2tTok i2t_token(const I2tParams &p, int64_t i, int64
 __global__ __launch_bounds__(256) void k_i2t_len(I2tParams p)
 {
     const int lane = lane_id();
-    const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (int64_t)gridDim.x * 4;
+    const int64_t wave0 = (int64_t)blockIdx.x * 4 + wave_in_block(), nwaves = (int64_t)gridDim.x * 4;
     for (int64_t d = wave0; d < p.nseq; d += nwaves) {
         const int64_t b = p.id_off[d], e = p.id_off[d + 1];
         bool found = false, bad = false; long long total = 0;
@@ -1875,7 +1882,7 @@ __global__ __launch_bounds__(256) void k_i2t_copy(I2tParams p)
 {
     __shared__ int s_pre[4][65];
     __shared__ uint32_t s_src[4][64];
-    const int lane = lane_id(), wv = (int)(threadIdx.x >> 6);
+    const int lane = lane_id(), wv = wave_in_block();
     const int64_t wave0 = (int64_t)blockIdx.x * 4 + wv, nwaves = (int64_t)gridDim.x * 4;
     for (int64_t d = wave0; d < p.nseq; d += nwaves) {
         const int64_t b = p.id_off[d], e = p.id_off[d + 1];
@@ -1906,7 +1913,7 @@ __global__ __launch_bounds__(256) void k_i2t_copy(I2tParams p)
 __global__ __launch_bounds__(256) void k_w2t_len(W2tParams p)
 {
     const int lane = lane_id();
-    const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (int64_t)gridDim.x * 4;
+    const int64_t wave0 = (int64_t)blockIdx.x * 4 + wave_in_block(), nwaves = (int64_t)gridDim.x * 4;
     for (int64_t d = wave0; d < p.ndocs; d += nwaves) {
         const int64_t b = p.word_off[d], e = p.word_off[d + 1];
         long long total = 0;
@@ -1921,7 +1928,7 @@ __global__ __launch_bounds__(256) void k_w2t_copy(W2tParams p)
 {
     __shared__ int s_pre[4][65];
     __shared__ int s_src[4][64];
-    const int lane = lane_id(), wv = (int)(threadIdx.x >> 6);
+    const int lane = lane_id(), wv = wave_in_block();
     const int64_t wave0 = (int64_t)blockIdx.x * 4 + wv, nwaves = (int64_t)gridDim.x * 4;
     for (int64_t d = wave0; d < p.ndocs; d += nwaves) {
         const int64_t b = p.word_off[d], e = p.word_off[d + 1];
@@ -1994,7 +2001,7 @@ __device__ __forceinline__ S2tTok s2t_sentence(const W2tParams &p, const uint8_t
 __global__ __launch_bounds__(256) void k_s2t_len(W2tParams p)
 {
     const int lane = lane_id();
-    const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (int64_t)gridDim.x * 4;
+    const int64_t wave0 = (int64_t)blockIdx.x * 4 + wave_in_block(), nwaves = (int64_t)gridDim.x * 4;
     for (int64_t d = wave0; d < p.ndocs; d += nwaves) {
         const int64_t b = p.word_off[d], e = p.word_off[d + 1];
         const int64_t n64 = p.doc_off[d + 1] - p.doc_off[d];
@@ -2017,7 +2024,7 @@ __global__ __launch_bounds__(256) void k_s2t_copy(W2tParams p)
 {
     __shared__ int s_pre[4][65];
     __shared__ int s_src[4][64];
-    const int lane = lane_id(), wv = (int)(threadIdx.x >> 6);
+    const int lane = lane_id(), wv = wave_in_block();
     const int64_t wave0 = (int64_t)blockIdx.x * 4 + wv, nwaves = (int64_t)gridDim.x * 4;
     for (int64_t d = wave0; d < p.ndocs; d += nwaves) {
         const int64_t b = p.word_off[d], e = p.word_off[d + 1];
@@ -2083,7 +2090,7 @@ template <bool WRITE>
 __global__ __launch_bounds__(256) void k_normsp(NormSpParams p)
 {
     const int lane = lane_id();
-    const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (int64_t)gridDim.x * 4;
+    const int64_t wave0 = (int64_t)blockIdx.x * 4 + wave_in_block(), nwaves = (int64_t)gridDim.x * 4;
     for (int64_t d = wave0; d < p.ndocs; d += nwaves) {
         const int64_t b = p.doc_off[d];
         const int64_t n64 = p.doc_off[d + 1] - b;
@@ -2180,7 +2187,7 @@ void launch_normsp(const NormSpParams &p, bool write, hipStream_t s)
 __global__ __launch_bounds__(256) void k_hash_count(HashParams p)
 {
     const int lane = lane_id();
-    const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (int64_t)gridDim.x * 4;
+    const int64_t wave0 = (int64_t)blockIdx.x * 4 + wave_in_block(), nwaves = (int64_t)gridDim.x * 4;
     for (int64_t d = wave0; d < p.ndocs; d += nwaves) {
         const int64_t b = p.doc_off[d], n = p.doc_off[d + 1] - b;
         long long sp = 0;
@@ -2195,7 +2202,7 @@ __global__ __launch_bounds__(256) void k_hash_count(HashParams p)
 __global__ __launch_bounds__(256) void k_hash_fill(HashParams p)
 {
     const int lane = lane_id();
-    const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (int64_t)gridDim.x * 4;
+    const int64_t wave0 = (int64_t)blockIdx.x * 4 + wave_in_block(), nwaves = (int64_t)gridDim.x * 4;
     // hash of "</s>" (tokdll:696)
     uint32_t eh = 2166136261u;
     { const char e4[4] = {'<', '/', 's', '>'}; for (int k = 0; k < 4; ++k) { eh ^= (uint32_t)(int8_t)e4[k]; eh *= 16777619u; } }
@@ -2310,7 +2317,7 @@ int scan_nblocks(int64_t ndocs) { return (int)((ndocs + SCAN_TILE - 1) / SCAN_TI
 __device__ __forceinline__ long long block_excl_scan(long long v, long long *total, long long *sh /*[4]*/)
 {
     // exclusive scan of one value per thread across a 256-thread block
-    const int lane = lane_id(), wv = (int)(threadIdx.x >> 6);
+    const int lane = lane_id(), wv = wave_in_block();
     long long inc = v;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) { long long t = __shfl_up(inc, o, 64); if (lane >= o) inc += t; }
@@ -2375,7 +2382,7 @@ void launch_scan(const ScanParams &p, hipStream_t s)
 __global__ __launch_bounds__(256) void k_compact(CompactParams p)
 {
     const int lane = lane_id();
-    const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t wave0 = (int64_t)blockIdx.x * 4 + wave_in_block();
     const int64_t nwaves = (int64_t)gridDim.x * 4;
     for (int64_t d = wave0; d < p.b.ndocs; d += nwaves) {
         const int c = p.counts[d];
@@ -2409,7 +2416,7 @@ __global__ __launch_bounds__(256) void k_compact(CompactParams p)
 __global__ __launch_bounds__(256) void k_compact_ids(CompactParams p)
 {
     const int lane = lane_id();
-    const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t wave0 = (int64_t)blockIdx.x * 4 + wave_in_block();
     const int64_t nwaves = (int64_t)gridDim.x * 4;
     const int32_t *__restrict__ tmp = p.ids_tmp;
     int32_t *__restrict__ out = p.ids_out;

@@ -51,6 +51,9 @@ struct WpWave {
     static_assert((QCAP & (QCAP - 1)) == 0 && QCAP >= 128 && (DTN & (DTN - 1)) == 0 && DTN <= 64, "queue / document table size");
 
     const WpWaveParams &p; const WpWaveCold &cold; LDS &S; const uint16_t *ascii; const int32_t *acts;      // cold, ascii, acts: per-workgroup LDS copies / tables
+    // the launch constants the loops use, each as a value of its own: the kernel arguments arrive as 8- and 16-dword tuples, and a tuple
+    // that does not stay in scalar registers is reloaded whole for one member (wv::own() hides where the value came from)
+    const uint64_t *T; int32_t *ids_tmp; int unk, maxtok;
     int lane;
     // ---- wave-uniform state
     uint32_t u_need;                 // distance from rlo to the lowest ring position a busy unit reads (0xFFFFFFFF: none is busy)
@@ -70,6 +73,8 @@ struct WpWave {
 
     BF_WVD WpWave(const WpWaveParams &p_, const WpWaveCold &cold_, LDS &S_, const uint16_t *ascii_, const int32_t *acts_) : p(p_), cold(cold_), S(S_), ascii(ascii_), acts(acts_)
     {
+        T = p.T; ids_tmp = p.ids_tmp;       // pointers stay what they are: behind wv::own() the compiler would no longer know they point to global memory
+        unk = wv::own(p.unk); maxtok = wv::own(p.max_token_length);
         lane = wv::lane(); rhi = rlo = 0; u_need = 0xFFFFFFFFu; q_tail = q_issue = q_retire = 0; dt_head = dt_tail = 0;
         dnext = dend = dbase = 0; have_doc = exiting = false;
         s = nullptr; n = 0; rbase = 0; dec_bytes = dec = done = bom = 0; open_start = -1; curk = 0; err = false; pf_own = 0;
@@ -134,7 +139,6 @@ struct WpWave {
         const uint32_t lo = kk & 0x5555u, hi = (kk >> 1) & 0x5555u;
         const uint32_t loopm = lo & ~hi & vm, solom = lo & hi & vm, genm = ~lo & ~hi & vm;
         if (wv::any(genm != 0)) return false;
-        const int maxtok = p.max_token_length;
         const bool at_end = fully && cb + total == dec;                // the document ends with these elements
         const bool cont = open_start >= 0;
         uint32_t prev_last = wv::shfl_up((loopm >> 14) & 1u, 1), next_first = wv::shfl_down(loopm & 1u, 1);
@@ -314,7 +318,6 @@ struct WpWave {
     {
         const int w0 = done;
         const int nv = dec - w0 < 64 ? dec - w0 : 64;
-        const int maxtok = p.max_token_length;
         const bool valid = lane < nv;
         const int pos = w0 + lane;
         const uint32_t el = valid ? ring_at(rbase + (uint32_t)pos) : (WK_NOMATCH << WK_SHIFT);
@@ -360,7 +363,7 @@ struct WpWave {
                     if (j >= b) break;
                     if (j >= dec) { complete = fully; break; }
                     const uint32_t c = ring_at(rbase + (uint32_t)j) & LX_T_CLS_MASK;
-                    const uint64_t e64 = p.T[state + c];
+                    const uint64_t e64 = T[state + c];
                     const uint32_t e = (uint32_t)e64;
                     if ((e & LX_T_CLS_MASK) != c) break;
                     if ((int32_t)e < 0) { fp = j; finfo = (uint32_t)(e64 >> 32); }
@@ -432,7 +435,6 @@ struct WpWave {
     // the frame of a call to the function (ini, ini_l) on the unit's word
     BF_WVD void unit_call(Unit &u, uint32_t ini, uint32_t ini_l, bool pred)
     {
-        const int maxtok = p.max_token_length;
         const bool anchored = ini_l != LX_NO_STATE && maxtok > 1;     // else "from = -1" goes straight on to from = 0 (FALexTools_t.h:244-252)
         const int cap = anchored ? maxtok - 1 : maxtok;
         const int L = u.Lk & 0xFFFF;
@@ -461,7 +463,7 @@ struct WpWave {
                 if (info & LX_INFO_SIMPLE) tag = (int)(info & 0x7FFFFFFFu);
                 else { const int32_t *a = acts + info; tag = a[2]; ini = (uint32_t)a[5]; ini_l = (uint32_t)a[6]; call = true; }
                 if (tag != WBD_WORD_TAG) unit_finish(u, 0);                            // tags 2..4: neither a word nor a sub-token
-                else if (!call) { S.q[sl].pos = (uint32_t)p.unk; unit_finish(u, 1); }  // a word without sub-tokens (tokdll:1282-1301)
+                else if (!call) { S.q[sl].pos = (uint32_t)unk; unit_finish(u, 1); }  // a word without sub-tokens (tokdll:1282-1301)
                 else unit_call(u, ini, ini_l, true);
             }
         }
@@ -474,7 +476,7 @@ struct WpWave {
         const uint32_t c = (uint32_t)S.ring[(u.rs + (uint32_t)u.j) & RMASK] & LX_T_CLS_MASK;
         // a lane that is not walking reads entry 0 like every other such lane (one cache line for all of them: a divergent gather costs
         // the memory pipeline about a cycle per distinct lane address, MI355X tools/microbench/gather.hip)
-        const uint64_t e64 = p.T[u.walk != 0 ? u.state + c : 0u];
+        const uint64_t e64 = T[u.walk != 0 ? u.state + c : 0u];
         const uint32_t e = (uint32_t)e64;
         const bool hit = u.walk != 0 && (e & LX_T_CLS_MASK) == c;
         const bool fin = hit && (int32_t)e < 0;
@@ -498,19 +500,19 @@ struct WpWave {
         if (wv::any(more)) {
             if (more) {
                 const uint32_t ke = (uint32_t)u.Lk >> 16;
-                int32_t *home = p.ids_tmp + S.dt_slot[ke] + (int64_t)(u.rs - S.dt_rbase[ke]);
+                int32_t *home = ids_tmp + S.dt_slot[ke] + (int64_t)(u.rs - S.dt_rbase[ke]);
                 if (cnt0 == 1) { home[0] = (int32_t)S.q[sl].pos; S.q[sl].pos = u.rs; }
                 home[cnt0] = id;
             }
         }
         uint32_t *wp = (gap || (matched && cnt0 == 0)) ? &S.q[sl].pos : &S.spare32;
-        *wp = gap ? (uint32_t)p.unk : (uint32_t)id;
+        *wp = gap ? (uint32_t)unk : (uint32_t)id;
         const int cnt = cnt0 + (matched ? 1 : 0);
         const int nf = matched ? u.fp + 1 : 0;
         const bool fin = gap || (ev && nf >= L), go = ev && !fin;
         uint16_t *cq = fin ? &S.qc[sl] : &S.spare;
         *cq = (uint16_t)((gap ? 1 : cnt) + 1);
-        const int b = nf + p.max_token_length;
+        const int b = nf + maxtok;
         u.state = go ? u.ini : u.state; u.j = go ? nf : u.j; u.lim = go ? (b < L ? b : L) : u.lim; u.fp = go ? -1 : u.fp;
         u.ca = go ? cnt : u.ca; u.walk = go ? 1 : u.walk; u.tok = fin ? -1 : u.tok;
     }
@@ -598,7 +600,7 @@ struct WpWave {
         int64_t slot = 0; int cap = 0, dcnt = 0; uint32_t f = 0;
         uint32_t w0 = 0;
         if (act) { slot = S.dt_slot[ke]; cap = S.dt_cap[ke]; dcnt = S.dt_cnt[ke]; w0 = te.pos; f = w0 - S.dt_rbase[ke]; }
-        const int32_t *src = p.ids_tmp + slot + (int64_t)f;          // used by words of two and more pieces only (unit_event)
+        const int32_t *src = ids_tmp + slot + (int64_t)f;          // used by words of two and more pieces only (unit_event)
         int32_t v0 = (int32_t)w0, v1 = 0, v2 = 0, v3 = 0;            // a single piece is in q0 itself
         if (cnt > 1) { v0 = src[0]; v1 = src[1]; }
         if (cnt > 2) v2 = src[2];
@@ -623,13 +625,13 @@ struct WpWave {
             for (int o = 4; o < bc; o += 64) {
                 const int i = o + lane;
                 int32_t v = 0;
-                if (i < bc) v = p.ids_tmp[bs + i];
+                if (i < bc) v = ids_tmp[bs + i];
                 wv::sync();
-                if (i < bc && i < br) p.ids_tmp[bd + i] = v;
+                if (i < bc && i < br) ids_tmp[bd + i] = v;
                 wv::sync();
             }
         }
-        int32_t *dst = p.ids_tmp + slot + pos;
+        int32_t *dst = ids_tmp + slot + pos;
         if (cnt > 0 && room > 0) dst[0] = v0;
         if (cnt > 1 && room > 1) dst[1] = v1;
         if (cnt > 2 && room > 2) dst[2] = v2;

@@ -184,6 +184,7 @@ template <class T> __attribute__((noinline)) static T uni(T v WV_SITE_ARG)
     for (int i = 1; i < 64; ++i) if (s[i] != s[0]) { fprintf(stderr, "wave_emu: uni() of a value that differs between lanes (line %ld)\n", site); abort(); }
     return v;
 }
+static inline int own(int v) { return v; }
 static inline uint32_t mbcnt(unsigned long long m) { return (uint32_t)__builtin_popcountll(m & ((1ull << wvemu::g_cur->lane) - 1ull)); }
 static inline unsigned long long atomic_add(unsigned long long *p, unsigned long long v) { unsigned long long o = *p; *p = o + v; return o; }
 static inline void atomic_or(int *p, int v) { *p |= v; }
