@@ -5,10 +5,14 @@
 # usage: tools/gpu_evidence.sh <tag> [quick]       outputs: gpurun_out/<tag>/ (text summaries only; copy what is to be judged into profiles/)
 set -u
 export TMPDIR=/tmp
-tag=${1:-evidence}; quick=${2:-}
+tag=${1:-evidence}; quick=${2:-}      # quick: "quick" = the default command only, "lines" = only the bench lines of configs 1..5 (profiles/traffic.json as it is)
 O=$PWD/gpurun_out/$tag; mkdir -p $O
 root=${GRAFT_REPO_ROOT:-$PWD}
 git -C $root rev-parse HEAD > $O/head.txt 2>/dev/null
+if [ "$quick" = lines ]; then
+  for w in config2 config1 config3 config4 config5; do timeout 600 python bench.py --workload $w > $O/bench_$w.json 2> $O/bench_$w.err; tail -c 200 $O/bench_$w.json; echo; done
+  exit 0
+fi
 timeout 900 python -m pytest tests -m gpu -x -q > $O/pytest_gpu.txt 2>&1; tail -2 $O/pytest_gpu.txt
 timeout 200 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.txt 2>&1; tail -1 $O/smoke.txt
 # ---- calibration: known bytes / counter for 8-byte-per-lane reads (the text read of k_wp_wave), 16-byte reads, 4-byte writes
@@ -54,15 +58,7 @@ rm -f $O/stats.err
 # ---- the lines
 timeout 600 python bench.py > $O/bench_default.json 2> $O/bench_default.err; tail -c 300 $O/bench_default.json; echo
 if [ -z "$quick" ]; then
-  for w in config2 config1 config3 config4 config5; do
-    timeout 600 python bench.py --workload $w > $O/bench_$w.json 2> $O/bench_$w.err; python - $O/bench_$w.json $w <<'PY'
-import json, sys
-try:
-    j = json.load(open(sys.argv[1])); print(sys.argv[2], "value %.1f M/s" % (j["value"] / 1e6), "ms/step %.2f" % j["ms_per_step"], "verified", j.get("verified_docs"), "status", j.get("status"))
-except Exception as e: print(sys.argv[2], "failed", e)
-PY
-  done
-  # traffic of the SentencePiece-style kernels (one sub-batch launch each) and of config 2
+  # traffic of the SentencePiece-style kernels (one sub-batch launch each): before their bench lines, which quote it
   for spec in "config3 gpt2.bin 1000000 k_bpe_fused 1" "config4 xlm_roberta_base.bin 10000000 k_seg_unigram_lane 4" "config5 laser500k.bin 10000000 k_seg_unigram_lane 4"; do
     set -- $spec
     Q=/tmp/prof_${tag}_$1; rm -rf $Q
@@ -73,6 +69,14 @@ PY
     done
     cd $root
     python tools/prof_traffic.py $Q "$1/$2/$3" $4 $5 > $O/traffic_$1.txt 2>&1; tail -1 $O/traffic_$1.txt
+  done
+  for w in config2 config1 config3 config4 config5; do
+    timeout 600 python bench.py --workload $w > $O/bench_$w.json 2> $O/bench_$w.err; python - $O/bench_$w.json $w <<'PY'
+import json, sys
+try:
+    j = json.load(open(sys.argv[1])); print(sys.argv[2], "value %.1f M/s" % (j["value"] / 1e6), "ms/step %.2f" % j["ms_per_step"], "verified", j.get("verified_docs"), "status", j.get("status"))
+except Exception as e: print(sys.argv[2], "failed", e)
+PY
   done
 fi
 cp profiles/traffic.json profiles/fetch_calibration.json $O/ 2>/dev/null
