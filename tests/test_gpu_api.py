@@ -232,3 +232,26 @@ def test_chunked_host_batch_equals_unchunked(model):
         assert r == -3 and np.array_equal(ioff, want_off)
     finally:
         bf.free_model(h)
+
+
+def test_single_document_calls_from_64_native_threads(tmp_path):
+    """tools/single_calls.c: 1 / 4 / 16 / 64 native threads call TextToIds on ONE handle back to back (no interpreter lock between
+    them: the lead of the combined launches changes hands thousands of times per second, callers spin and sleep on their own state
+    words); every result is compared with what a quiet single-threaded pass returned for the same document"""
+    import os
+    import subprocess
+    exe = os.path.join(bfutil.ROOT, "tools", "single_calls")
+    if not os.path.exists(exe):
+        pytest.skip("tools/single_calls not built")
+    text, off = bfutil.gen_workload("config2", 1500)
+    raw = text.tobytes()
+    docs = tmp_path / "docs.txt"
+    with open(docs, "wb") as f:
+        for i in range(1500):
+            d = raw[off[i]:off[i + 1]].replace(b"\n", b" ").replace(b"\r", b" ")
+            if d.strip():
+                f.write(d + b"\n")
+    lib = os.path.join(bfutil.ROOT, "blingfire_amd", "libblingfiretokdll.so")
+    r = subprocess.run([exe, lib, bfutil.model_path(bfutil.bert_model_name()), str(docs), "0.4"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "64 threads" in r.stdout and " 0 results that differ" in r.stdout.splitlines()[-1], r.stdout
