@@ -1,9 +1,9 @@
 #!/bin/bash
 # A/B of k_wp_wave configurations: WordPiece GPU parity tests, the default workload (2 M documents verified), variants, config2,
-# the counters of the STATS instance.   usage: tools/gpu_r3m.sh "<variants>"
+# the counters of the STATS instance.   usage: tools/gpu_wave_ab.sh "<variants>"
 set -u
 export TMPDIR=/tmp
-O=$PWD/gpurun_out/r3m; mkdir -p $O
+O=$PWD/gpurun_out/wave_ab; mkdir -p $O
 timeout 600 python -m pytest tests/test_gpu_parity_wp.py tests/test_gpu_large_docs.py -m gpu -x -q > $O/pytest_wp.txt 2>&1; tail -3 $O/pytest_wp.txt
 Q="--no-cpu-baseline --no-extra-timings --steps 5 --warmup 2"
 show() { python - $1 "$2" <<'PY'

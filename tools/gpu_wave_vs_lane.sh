@@ -2,7 +2,7 @@
 # wave program against the lane-per-document kernels (variant 2) on the other WordPiece shapes: config 2 (128-byte documents), one 200 KB document
 set -u
 export TMPDIR=/tmp
-O=$PWD/gpurun_out/r3l; mkdir -p $O
+O=$PWD/gpurun_out/wave_vs_lane; mkdir -p $O
 Q="--no-cpu-baseline --no-extra-timings --steps 5 --warmup 2"
 for v in 3 2; do
   timeout 300 python bench.py $Q --workload config2 --variant $v > $O/config2_v$v.json 2> $O/config2_v$v.err

@@ -1,9 +1,9 @@
 #!/bin/bash
-# A/B of one workload over kernel variants.   usage: tools/gpu_r3n.sh <workload> "<variants>" [pytest file]
+# A/B of one workload over kernel variants.   usage: tools/gpu_workload_ab.sh <workload> "<variants>" [pytest file]
 set -u
 export TMPDIR=/tmp
 w=${1:-config3}
-O=$PWD/gpurun_out/r3n; mkdir -p $O
+O=$PWD/gpurun_out/workload_ab; mkdir -p $O
 Q="--no-cpu-baseline --no-extra-timings --steps 5 --warmup 2 --workload $w"
 show() { python - $1 "$2" <<'PY'
 import json, sys
