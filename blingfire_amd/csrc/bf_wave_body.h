@@ -60,15 +60,14 @@ struct WpWave {
     uint32_t rhi, rlo;               // absolute ring positions: next element to write / oldest element still needed
     uint32_t q_tail, q_issue, q_retire;   // tokens: queued / handed to a unit / retired (absolute counters; slot = counter & QMASK)
     uint32_t dt_head, dt_tail;       // document table entries in use (absolute counters)
-    int64_t dnext, dend, dbase;      // the range of documents this wave took from the work counter (their offsets: S.doff[])
-    int64_t st_next, st_step;        // without a work counter: the next range of this wave, and the stride to the one after
+    int64_t dbase; int di, dn;       // the range of documents this wave took from the work counter: [dbase, dbase + dn), di of them opened (offsets: S.doff[])
+    int st_round, st_wave, st_waves; // without a work counter: range number st_wave + st_round * st_waves is this wave's next one
     bool have_doc, exiting;
     // current document
     const uint8_t *s; int n; uint32_t rbase; int dec_bytes, dec, done, open_start, bom; uint32_t curk;
     uint32_t fn_ini, fn_ini_l;       // the vocabulary function of the common word kinds (run and solo tokens), when fast_ok
     bool fast_ok;                    // run and solo tokens are both "WORD, call the same function": their units need no action lookup
     bool err;                        // per lane: this lane saw invalid UTF-8 in the current document
-    uint64_t pf_own;                 // per lane: its 8 bytes of the next chunk
     unsigned long long st_trips, st_win, st_slow, st_tok, st_steps, st_ret, st_rewalk, st_idle, st_dec, st_gath, st_trans;
 
     BF_WVD WpWave(const WpWaveParams &p_, const WpWaveCold &cold_, LDS &S_, const uint16_t *ascii_, const int32_t *acts_) : p(p_), cold(cold_), S(S_), ascii(ascii_), acts(acts_)
@@ -76,8 +75,8 @@ struct WpWave {
         T = p.T; ids_tmp = p.ids_tmp;       // pointers stay what they are: behind wv::own() the compiler would no longer know they point to global memory
         unk = wv::own(p.unk); maxtok = wv::own(p.max_token_length);
         lane = wv::lane(); rhi = rlo = 0; u_need = 0xFFFFFFFFu; q_tail = q_issue = q_retire = 0; dt_head = dt_tail = 0;
-        dnext = dend = dbase = 0; have_doc = exiting = false;
-        s = nullptr; n = 0; rbase = 0; dec_bytes = dec = done = bom = 0; open_start = -1; curk = 0; err = false; pf_own = 0;
+        dbase = 0; di = dn = 0; st_round = st_wave = 0; st_waves = 1; have_doc = exiting = false;
+        s = nullptr; n = 0; rbase = 0; dec_bytes = dec = done = bom = 0; open_start = -1; curk = 0; err = false;
         st_trips = st_win = st_slow = st_tok = st_steps = st_ret = st_rewalk = st_idle = st_dec = st_gath = st_trans = 0;
         // the action of a run token and of a solo token (bf_model.cpp): the usual case is one calling WORD action for both
         fast_ok = false; fn_ini = 0; fn_ini_l = LX_NO_STATE;
@@ -118,14 +117,15 @@ struct WpWave {
     // and leaves everything untouched (the window forms take over) when the elements hold a WK_GENERAL one, a run that
     // max-length cuts, or more tokens than the queue has room for.
     // ------------------------------------------------------------------------------------------------------------------
-    BF_WVD bool phase_a_wide(bool fully)
+    BF_WVD bool phase_a_wide(bool fully, bool have_kk = false, uint32_t kk_in = 0)
     {
         const int cb = done;
         const int total = dec - cb < WV_CHUNK ? dec - cb : WV_CHUNK;
         int nb = total - lane * 8; nb = nb < 0 ? 0 : (nb > 8 ? 8 : nb);
         const uint32_t r = rbase + (uint32_t)cb + (uint32_t)(lane * 8);
         uint32_t kk = 0;
-        if (((rbase + (uint32_t)cb) & 7u) == 0) {
+        if (have_kk) kk = kk_in;                                       // straight from the decoder: these are the elements it just wrote
+        else if (((rbase + (uint32_t)cb) & 7u) == 0) {
             const uint32_t *src = (const uint32_t *)(S.ring + (r & RMASK));          // 8 elements = one 16-byte row, never wraps
             const uint32_t d0 = src[0], d1 = src[1], d2 = src[2], d3 = src[3];
             // kinds: bits 15:14 and 31:30 of every dword -> 2-bit fields 2k, 2k+1
@@ -197,22 +197,27 @@ struct WpWave {
         return true;
     }
 
-    BF_WVD void prefetch_chunk(int pos)
+    // this lane's 8 bytes of the chunk at `pos` of the text [t, t + tn)
+    BF_WVD uint64_t load_chunk(const uint8_t *t, int tn, int pos) const
     {
         const int q0 = pos + lane * 8;
         uint64_t own = 0;
-        int nb = n - q0; nb = nb < 0 ? 0 : (nb > 8 ? 8 : nb);
-        if (nb == 8) __builtin_memcpy(&own, s + q0, 8);
-        else for (int k = 0; k < nb; ++k) own |= (uint64_t)s[q0 + k] << (8 * k);
-        pf_own = own;
+        int nb = tn - q0; nb = nb < 0 ? 0 : (nb > 8 ? 8 : nb);
+        if (nb == 8) __builtin_memcpy(&own, t + q0, 8);
+        else for (int k = 0; k < nb; ++k) own |= (uint64_t)t[q0 + k] << (8 * k);
+        return own;
     }
-    BF_WVD void decode_chunk()
+    // Returns true when the chunk was plain ASCII; kk_out then holds the kinds of this lane's eight elements as 2-bit fields (what
+    // phase_a_wide() would read back from the ring).
+    BF_WVD bool decode_chunk(uint32_t &kk_out)
     {
+        kk_out = 0;
         if (STATS) ++st_dec;
         const int pos = dec_bytes;
         const int q0 = pos + lane * 8;
-        prefetch_chunk(pos);
-        const uint64_t own = pf_own;
+        // (Issuing this load one chunk -- or one document -- ahead was built and measured: the two registers that then live through
+        // every phase cost 7 % more vector instructions in spill code at 64 VGPRs, 6.86 against 6.66 ms per 2.5 M documents.)
+        const uint64_t own = load_chunk(s, n, pos);
         int nb = n - q0; nb = nb < 0 ? 0 : (nb > 8 ? 8 : nb);
         const uint32_t w0 = rbase + (uint32_t)dec;                  // absolute ring position of this chunk's first element
         if (!wv::any((own & 0x8080808080808080ull) != 0)) {
@@ -230,8 +235,10 @@ struct WpWave {
             }
             const int total = n - pos < WV_CHUNK ? n - pos : WV_CHUNK;
             dec += total; dec_bytes = pos + WV_CHUNK; rhi = rbase + (uint32_t)dec;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) kk_out |= (e[k] >> WK_SHIFT) << (2 * k);
             wv::sync();
-            return;
+            return true;
         }
         // ---- a chunk with bytes >= 0x80.  Every byte that is not a continuation byte is an element; the ASCII ones come from the table
         //      as above, the lead bytes are decoded one per lane and trip (a lane of Latin text holds one or two, a lane of CJK three);
@@ -305,6 +312,7 @@ struct WpWave {
         const int total = wv::bcast(inc, 63);
         dec += total; dec_bytes = pos + WV_CHUNK; rhi = rbase + (uint32_t)dec;
         wv::sync();
+        return false;
     }
 
     // ------------------------------------------------------------------------------------------------------------------
@@ -421,7 +429,8 @@ struct WpWave {
         int tok;                         // token (absolute queue counter, as int), -1: idle
         uint32_t rs; int Lk; uint32_t ini;       // Lk: length of the word | its document's table entry << 16
         int j, lim; uint32_t state; int fp; uint32_t ftag;
-        int ca, walk;                    // ca: pieces so far | 1 << 16 while the anchored walk runs; walk: 1 while a walk is under way (0 with tok >= 0: its end waits for unit_event)
+        int ca;                          // pieces so far | 1 << 16 while the anchored walk runs
+        // a walk is under way while j < lim; j >= lim with tok >= 0: its end waits for unit_event (a miss sets j = lim)
     };
 
     // What follows runs for all lanes of the wave at once and is written with selects: a lane that has nothing to do (pred false)
@@ -430,7 +439,7 @@ struct WpWave {
     BF_WVD void unit_finish(Unit &u, int cnt)
     {
         S.qc[(uint32_t)u.tok & QMASK] = (uint16_t)(cnt + 1);
-        u.tok = -1; u.walk = 0;
+        u.tok = -1; u.j = u.lim;
     }
     // the frame of a call to the function (ini, ini_l) on the unit's word
     BF_WVD void unit_call(Unit &u, uint32_t ini, uint32_t ini_l, bool pred)
@@ -439,7 +448,7 @@ struct WpWave {
         const int cap = anchored ? maxtok - 1 : maxtok;
         const int L = u.Lk & 0xFFFF;
         u.ini = pred ? ini : u.ini; u.state = pred ? (anchored ? ini_l : ini) : u.state; u.ca = pred ? (anchored ? 0x10000 : 0) : u.ca;
-        u.j = pred ? 0 : u.j; u.lim = pred ? (cap < L ? cap : L) : u.lim; u.fp = pred ? -1 : u.fp; u.walk = pred ? 1 : u.walk;
+        u.j = pred ? 0 : u.j; u.lim = pred ? (cap < L ? cap : L) : u.lim; u.fp = pred ? -1 : u.fp;
     }
     // starts the unit of token t (take: this lane takes one)
     BF_WVD void unit_begin(Unit &u, uint32_t t, bool take)
@@ -469,21 +478,21 @@ struct WpWave {
         }
     }
     // One transition (FALexTools_t.h:255-277) for every lane at once, written without a branch: a lane whose unit is not walking
-    // feeds its old state to the table as well and keeps everything it has.  walk = 0 afterwards: the walk is over (a miss, or the
+    // feeds its old state to the table as well and keeps everything it has.  j >= lim afterwards: the walk is over (a miss, or the
     // next position is not < lim) and waits for unit_event().
     BF_WVD void unit_step(Unit &u) const
     {
         const uint32_t c = (uint32_t)S.ring[(u.rs + (uint32_t)u.j) & RMASK] & LX_T_CLS_MASK;
         // a lane that is not walking reads entry 0 like every other such lane (one cache line for all of them: a divergent gather costs
         // the memory pipeline about a cycle per distinct lane address, MI355X tools/microbench/gather.hip)
-        const uint64_t e64 = T[u.walk != 0 ? u.state + c : 0u];
+        const bool act = u.j < u.lim;
+        const uint64_t e64 = T[act ? u.state + c : 0u];
         const uint32_t e = (uint32_t)e64;
-        const bool hit = u.walk != 0 && (e & LX_T_CLS_MASK) == c;
+        const bool hit = act && (e & LX_T_CLS_MASK) == c;
         const bool fin = hit && (int32_t)e < 0;
         u.fp = fin ? u.j : u.fp; u.ftag = fin ? (uint32_t)(e64 >> 32) : u.ftag;
         u.state = hit ? ((e >> LX_T_NEXT_SHIFT) & LX_T_NEXT_MASK) : u.state;
-        u.j += hit ? 1 : 0;
-        u.walk = (hit && u.j < u.lim) ? 1 : 0;
+        u.j = hit ? u.j + 1 : u.lim;                                      // a miss ends the walk
     }
     // The end of a walk (ev: this lane's unit has one): a match is a piece and the next walk starts behind it (FALexTools_t.h:390-393);
     // the anchored walk without a match is followed by the plain walk at 0 (:293); any other walk without a match leaves a gap, the
@@ -514,7 +523,7 @@ struct WpWave {
         *cq = (uint16_t)((gap ? 1 : cnt) + 1);
         const int b = nf + maxtok;
         u.state = go ? u.ini : u.state; u.j = go ? nf : u.j; u.lim = go ? (b < L ? b : L) : u.lim; u.fp = go ? -1 : u.fp;
-        u.ca = go ? cnt : u.ca; u.walk = go ? 1 : u.walk; u.tok = fin ? -1 : u.tok;
+        u.ca = go ? cnt : u.ca; u.tok = fin ? -1 : u.tok;
     }
     // Runs the units until the queue is handed out and fewer than UNIT_MIN of them are still busy (`drain`: until all are done).
     // A round: the units whose walk is over take its result (piece / next walk / word finished), idle units take the next queued
@@ -531,7 +540,7 @@ struct WpWave {
             int nb = 0;
 #pragma unroll
             for (int i = 0; i < NU; ++i) {
-                const bool ev = u[i].tok >= 0 && !u[i].walk;
+                const bool ev = u[i].tok >= 0 && u[i].j >= u[i].lim;
                 if (wv::any(ev)) unit_event(u[i], ev);
                 const uint32_t avail = tail - issue;
                 unsigned long long idle = wv::ballot(u[i].tok < 0);
@@ -552,7 +561,7 @@ struct WpWave {
             for (int st = 0; st < STEPS; ++st) {
 #pragma unroll
                 for (int i = 0; i < NU; ++i) {
-                    if (STATS) { st_gath += 64; st_trans += (unsigned long long)__builtin_popcountll(wv::ballot(u[i].walk != 0)); }
+                    if (STATS) { st_gath += 64; st_trans += (unsigned long long)__builtin_popcountll(wv::ballot(u[i].j < u[i].lim)); }
                     unit_step(u[i]);
                 }
             }
@@ -697,21 +706,20 @@ struct WpWave {
     {
         if (!have_doc) {
             if (exiting || dt_tail - dt_head >= (uint32_t)DTN) return false;
-            if (dnext >= dend) {
+            if (di >= dn) {
                 unsigned long long base = 0;
                 if (p.next_doc) {
                     if (lane == 0) base = wv::atomic_add(p.next_doc, (unsigned long long)grab);
                     base = wv::bcast(base, 0);
-                } else { base = (unsigned long long)st_next; st_next += st_step; }       // no work counter: ranges dealt out round-robin (small batches)
+                } else { base = ((unsigned long long)st_wave + (unsigned long long)st_round * (unsigned long long)st_waves) * (unsigned long long)grab; ++st_round; }   // no work counter: ranges dealt out round-robin (small batches)
                 if ((int64_t)base >= p.ndocs) { exiting = true; return false; }
-                dbase = (int64_t)base; dnext = dbase; dend = dbase + grab < p.ndocs ? dbase + grab : p.ndocs;
-                if (lane <= (int)(dend - dbase)) S.doff[lane] = p.doc_off[dbase + lane];
+                dbase = (int64_t)base; di = 0; dn = dbase + grab < p.ndocs ? grab : (int)(p.ndocs - dbase);
+                if (lane <= dn) S.doff[lane] = p.doc_off[dbase + lane];
                 wv::sync();
             }
-            const int i = (int)(dnext - dbase);
-            const int64_t b = S.doff[i], e = S.doff[i + 1];
-            have_doc = open_document(dnext, b, e);
-            ++dnext;
+            const int64_t b = S.doff[di], e = S.doff[di + 1];
+            have_doc = open_document(dbase + di, b, e);
+            ++di;
             return true;
         }
         const bool fully = dec_bytes >= n;
@@ -725,7 +733,11 @@ struct WpWave {
         if (dec_bytes < n) {
             // a chunk is taken when the ring has room for it and the queue for the tokens it usually holds (the chunk-wide pass writes them at once)
             if (ring_free() < WV_CHUNK || (q_tail - q_retire) + (uint32_t)CHUNK_ROOM > (uint32_t)QCAP) return false;
-            decode_chunk(); return true;
+            const bool fresh = done == dec;                            // nothing older is unresolved: the wide pass covers exactly the new chunk
+            uint32_t kk = 0;
+            const bool ascii_chunk = decode_chunk(kk);
+            if (fresh && ascii_chunk) (void)phase_a_wide(dec_bytes >= n, true, kk);    // declined (a long run, a full queue): the next step sorts it out
+            return true;
         }
         if (done >= dec) { if (open_start >= 0 && !room_q) return false; close_document(); have_doc = false; return true; }
         return false;
@@ -735,10 +747,10 @@ struct WpWave {
     BF_WVD void run(int grab, int wave_id, int n_waves)
     {
         grab = grab < 1 ? 1 : (grab > WV_GRAB_MAX ? WV_GRAB_MAX : grab);
-        st_next = (int64_t)wave_id * grab; st_step = (int64_t)n_waves * grab;
+        st_wave = wave_id; st_waves = n_waves; st_round = 0;
         Unit u[NU];
 #pragma unroll
-        for (int i = 0; i < NU; ++i) { u[i].tok = -1; u[i].walk = 0; u[i].rs = 0; u[i].j = 0; u[i].state = 0; u[i].lim = 0; u[i].fp = -1; u[i].ftag = 0; u[i].Lk = 0; u[i].ca = 0; u[i].ini = 0; }
+        for (int i = 0; i < NU; ++i) { u[i].tok = -1; u[i].rs = 0; u[i].j = 0; u[i].state = 0; u[i].lim = 0; u[i].fp = -1; u[i].ftag = 0; u[i].Lk = 0; u[i].ca = 0; u[i].ini = 0; }
         for (;;) {
             bool moved = settle();
             bool filled = false;
