@@ -108,6 +108,8 @@ struct CompactParams {
 void launch_prep_wp(const WpPrepParams &p, int64_t total_bytes, unsigned long long *flags, hipStream_t s);
 void launch_lex_wp(const WpLexParams &p, int variant, hipStream_t s);
 void launch_wp_wave(const WpWaveParams &p, int variant, hipStream_t s);     // unit-form lexers (bf_wave.h): replaces prep + lexer
+struct BpeWaveParams;
+void launch_bpe_wave(const BpeWaveParams &p, hipStream_t s);                  // bpe-opt models (bf_bpe_wave_body.h); not wired into the C-ABI yet
 void launch_prep_sp(const SpPrepParams &p, hipStream_t s);
 void launch_seg_sp(const SpSegParams &p, hipStream_t s);
 void launch_scan(const ScanParams &p, hipStream_t s);

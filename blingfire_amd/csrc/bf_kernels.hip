@@ -761,6 +761,40 @@ void launch_wp_wave(const WpWaveParams &p, int variant, hipStream_t s)
     else launch_wp_wave_cfg<L, 1, 3, 8>(p, grab, per_cu, s);
 }
 
+} // namespace bfa
+#include "bf_bpe_wave_body.h"
+namespace bfa {
+
+// k_bpe_wave: the BPE wave program (bf_bpe_wave_body.h) on the class streams k_prep_sp wrote.  NOT WIRED INTO THE C-ABI YET: the
+// program is validated in the test simulator (tests/test_bpe_wave_emu.py); what is missing on the device side is the pass that redoes
+// the documents it hands back (flags[d] = 1) with the lane-per-document kernels over a list, and the GPU parity + timing runs.
+template <class LDS, int WPE>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_bpe_wave(BpeWaveParams p, int grab)
+{
+    __shared__ LDS lds[4];
+    BpeWave<LDS> w(p, lds[wave_in_block()]);
+    w.run(grab, (int)(blockIdx.x * 4) + wave_in_block(), (int)(gridDim.x * 4));
+}
+
+void launch_bpe_wave(const BpeWaveParams &p, hipStream_t s)
+{
+    typedef BwLds<1024, 256, 8> L;
+    static int per_cu = 0;
+    if (per_cu <= 0) {
+        int q = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&q, k_bpe_wave<L, 3>, 256, 0) != hipSuccess || q <= 0) q = 2;
+        (void)hipGetLastError();
+        per_cu = q;
+    }
+    const int64_t per_wave = p.ndocs / ((int64_t)device_cus() * per_cu * 4);
+    const int grab = per_wave >= WV_GRAB_MAX ? WV_GRAB_MAX : per_wave < 1 ? 1 : (int)per_wave;
+    int64_t blocks = (int64_t)device_cus() * per_cu;
+    const int64_t need = (p.ndocs + (int64_t)grab * 4 - 1) / ((int64_t)grab * 4);
+    if (blocks > need) blocks = need;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL((k_bpe_wave<L, 3>), dim3((unsigned)blocks), dim3(256), 0, s, p, grab);
+}
+
 // ------------------------------------------------------------------------------------------
 // k_prep_sp: wave per document.  bytes / strict UTF-8 -> fused charmap+element-code map -> dummy prefix ->
 // whitespace collapse (local keep-predicate) -> trailing trim  (tokdll:1367-1496).
