@@ -28,7 +28,7 @@
 // Include AFTER a definition of namespace wv (bf_kernels.hip on the device, tests/hosttest/wave_emu.h in the test simulator).
 #pragma once
 #include "bf_wave_body.h"
-#include "bf_seg.h"
+#include "bf_bpe_wave.h"
 
 namespace bfa {
 
@@ -37,14 +37,6 @@ constexpr int BW_WIN = 32;               // arcs of more than one element a lane
                                          // one entry (<= 16: 83 %, <= 24: 96 %); a word with more sends its document back
 constexpr uint32_t BW_TK_TS = 1u << 29;  // token flag: the word starts with U+2581 (token_start of :176)
 constexpr uint32_t BW_DT_FALLBACK = 4;
-
-struct BpeWaveParams {
-    const uint64_t *T; const SegInfo *info; uint32_t initial, cls_delim; int id_offset;
-    const uint16_t *stream; const int32_t *lens; const int64_t *doc_off; int slot_mul; int64_t ndocs;
-    int32_t *ids_tmp; int32_t *counts; int32_t *flags; int max_ids; unsigned long long *next_doc; int *status;
-    unsigned long long *stats;       // optional (tests, experiments): [0] words, [1] taken whole, [2..7] documents handed back because of: a symbol outside the
-                                     // alphabet, a word too long, a window overflow, a start without an arc, a position without an applied arc, (spare)
-};
 
 template <int RING_, int QCAP_, int DTN_>
 struct BwLds {

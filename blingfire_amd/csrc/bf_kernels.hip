@@ -765,15 +765,37 @@ void launch_wp_wave(const WpWaveParams &p, int variant, hipStream_t s)
 #include "bf_bpe_wave_body.h"
 namespace bfa {
 
-// k_bpe_wave: the BPE wave program (bf_bpe_wave_body.h) on the class streams k_prep_sp wrote.  NOT WIRED INTO THE C-ABI YET: the
-// program is validated in the test simulator (tests/test_bpe_wave_emu.py); what is missing on the device side is the pass that redoes
-// the documents it hands back (flags[d] = 1) with the lane-per-document kernels over a list, and the GPU parity + timing runs.
+// k_bpe_wave: the BPE wave program (bf_bpe_wave_body.h) on the class streams k_prep_sp wrote.  The program is validated in the test
+// simulator (tests/test_bpe_wave_emu.py); the device path (bf_capi.cpp, behind BfSetVariant bit 0x40 until it has had its GPU parity
+// and timing runs) redoes the documents it hands back (flags[d] = 1) with the lane-per-document kernels.
 template <class LDS, int WPE>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_bpe_wave(BpeWaveParams p, int grab)
 {
     __shared__ LDS lds[4];
     BpeWave<LDS> w(p, lds[wave_in_block()]);
     w.run(grab, (int)(blockIdx.x * 4) + wave_in_block(), (int)(gridDim.x * 4));
+}
+
+// around the lane-per-document pass that redoes the documents the wave program handed back: before it, a document that is done
+// gets length 0 in a copy of the lengths (the lane kernels skip it and write their 0 into a copy of the counts); after it, the counts
+// of the handed-back documents are taken over
+__global__ __launch_bounds__(256) void k_bpe_wave_mask(const int32_t *lens, const int32_t *flags, int32_t *lens2, int64_t ndocs)
+{
+    const int64_t d = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (d < ndocs) lens2[d] = flags[d] ? lens[d] : 0;
+}
+__global__ __launch_bounds__(256) void k_bpe_wave_merge(int32_t *counts, const int32_t *counts2, const int32_t *flags, int64_t ndocs)
+{
+    const int64_t d = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (d < ndocs && flags[d]) counts[d] = counts2[d];
+}
+void launch_bpe_wave_mask(const int32_t *lens, const int32_t *flags, int32_t *lens2, int64_t ndocs, hipStream_t s)
+{
+    if (ndocs > 0) hipLaunchKernelGGL(k_bpe_wave_mask, dim3((unsigned)((ndocs + 255) / 256)), dim3(256), 0, s, lens, flags, lens2, ndocs);
+}
+void launch_bpe_wave_merge(int32_t *counts, const int32_t *counts2, const int32_t *flags, int64_t ndocs, hipStream_t s)
+{
+    if (ndocs > 0) hipLaunchKernelGGL(k_bpe_wave_merge, dim3((unsigned)((ndocs + 255) / 256)), dim3(256), 0, s, counts, counts2, flags, ndocs);
 }
 
 void launch_bpe_wave(const BpeWaveParams &p, hipStream_t s)
