@@ -89,7 +89,12 @@ struct BpeWave {
         int nb = total - lane * 8; nb = nb < 0 ? 0 : (nb > 8 ? 8 : nb);
         const uint16_t *src = p.stream + slot + pos + lane * 8;
         const uint32_t r = rbase + (uint32_t)pos + (uint32_t)(lane * 8);
-        for (int k = 0; k < nb; ++k) S.ring[(r + (uint32_t)k) & RMASK] = src[k];
+        if (nb == 8 && (r & 7u) == 0) {                                 // a whole row: 16 bytes in (the slot is 2-byte aligned only), one 16-byte row out
+            uint32_t d[4];
+            __builtin_memcpy(d, src, 16);
+            uint32_t *dst = (uint32_t *)(S.ring + (r & RMASK));
+            dst[0] = d[0]; dst[1] = d[1]; dst[2] = d[2]; dst[3] = d[3];
+        } else for (int k = 0; k < nb; ++k) S.ring[(r + (uint32_t)k) & RMASK] = src[k];
         dec += total; rhi = rbase + (uint32_t)dec;
         wv::sync();
     }
@@ -213,14 +218,17 @@ struct BpeWave {
     }
 
     // ------------------------------------------------------------------------------------------------------------------
-    // units.  mode: 0 idle, 1 the walk of the whole word, 2 collecting the arcs of start position s0, 3 collected: sort / apply / emit
+    // units.  mode: 0 idle, 1 the walk of the whole word, 2 collecting the arcs of start position s0, 3 collected: waits for the
+    // solve pass (sort / apply / emit).  As in bf_wave_body.h a round is: events (the lanes whose walk is over, by vote), new words
+    // for idle lanes, STEPS transitions for every lane in straight-line code; the solve pass runs when enough lanes wait for it.
+    // (Measured on MI355X with the event and solve code inside every transition: 58.9 ms per 1 M documents of config 3.)
     // ------------------------------------------------------------------------------------------------------------------
     struct Unit {
-        int tok; uint32_t rs; int L; uint32_t ke; bool ts;
-        int mode, s0, j; uint32_t state; int sum; bool seen, last_final; int narc;
+        int tok; uint32_t rs; int L; uint32_t ke;
+        int mode, s0, j; uint32_t state; int sum; bool seen, last_final, ovf; int narc;
         unsigned long long single;       // bit s: the element at position s is an entry by itself (its one-element arc is not stored)
     };
-    BF_WVD void unit_finish(Unit &u, int cnt) { S.qc[(uint32_t)u.tok & QMASK] = (uint16_t)(cnt + 1); u.tok = -1; u.mode = 0; }
+    BF_WVD void unit_finish(Unit &u, int cnt) { S.qc[(uint32_t)u.tok & QMASK] = (uint16_t)(cnt + 1); u.tok = -1; u.mode = 0; u.j = u.L; }
     BF_WVD void unit_fallback(Unit &u, int why)
     {
         if (p.stats) wv::atomic_add(&p.stats[why], 1ull);
@@ -231,58 +239,71 @@ struct BpeWave {
     {
         u.tok = (int)t;
         const WvTok e = S.q[t & QMASK];
-        u.rs = e.pos; u.L = (int)(e.w & WV_TK_LEN_MASK); u.ke = (e.w >> 16) & DMASK; u.ts = (e.w & BW_TK_TS) != 0;
+        u.rs = e.pos; u.L = (int)(e.w & WV_TK_LEN_MASK); u.ke = (e.w >> 16) & DMASK;
         S.qc[t & QMASK] = 0;
-        u.state = p.initial; u.sum = 0; u.j = 0; u.s0 = 0; u.seen = false; u.last_final = false; u.narc = 0; u.single = 0;
-        u.mode = u.ts ? 1 : 2;
-        if (p.stats) wv::atomic_add(&p.stats[0], 1ull);                                          // only a word that starts with U+2581 can be taken whole (:176,189)
+        u.state = p.initial; u.sum = 0; u.j = 0; u.s0 = 0; u.seen = false; u.last_final = false; u.ovf = false; u.narc = 0; u.single = 0;
+        u.mode = (e.w & BW_TK_TS) ? 1 : 2;                              // only a word that starts with U+2581 can be taken whole (:176,189)
+        if (p.stats) wv::atomic_add(&p.stats[0], 1ull);
     }
-    // one transition of the unit's walk; true while the walk goes on
-    BF_WVD bool unit_step(Unit &u)
+    // One transition for every lane at once, straight-line: a lane that is not walking (idle, waiting for the solve pass, walk over)
+    // gathers entry 0 and keeps what it has.  j >= L afterwards: the walk is over (a miss sets j = L) and waits for unit_event().
+    // An arc of collection mode is stored as [MPH index : 20 | start : 6 | end : 6]; the solve pass turns the index into the id.
+    BF_WVD void unit_step(Unit &u)
     {
+        const bool act = u.tok >= 0 && u.mode != 3 && u.j < u.L;
         const uint32_t c = (uint32_t)S.ring[(u.rs + (uint32_t)u.j) & RMASK];
-        const uint64_t e = p.T[u.state + (c < SG_CLS_DELIM_ABSENT ? c : 0u)];
-        if (!(c < SG_CLS_DELIM_ABSENT && (e & SG_CLS_MASK) == c)) return false;
-        u.state = (uint32_t)((e >> SG_NEXT_SHIFT) & SG_NEXT_MASK);
-        u.sum += (int)(e >> SG_OW_SHIFT);
-        const bool fin = (e & SG_FINAL) != 0;
-        if (u.mode == 1) {
-            u.last_final = fin && u.j == u.L - 1 && u.seen;            // :189: a final state on the word's last element, after an earlier arc of this start
-            if (fin) u.seen = true;
-        } else if (fin) {
-            u.seen = true;
-            if (u.j == u.s0) u.single |= 1ull << u.s0;                  // a one-element arc never marks an interior and is overridden by any applied
-            else {                                                      // arc of its start: it is looked up again if its position ends up a token of its own
-                const SegInfo r = p.info[u.sum];
-                if (u.narc >= BW_WIN || (uint32_t)r.id >= (1u << BPE_LOCAL_ID_BITS_W)) { u.narc = BW_WIN + 1; return false; }
-                S.win[u.narc * 64 + lane] = ((uint32_t)r.id << 12) | ((uint32_t)u.s0 << 6) | (uint32_t)u.j;
-                ++u.narc;
-            }
-        }
-        ++u.j;
-        return u.j < u.L;
+        const bool valid = act && c < SG_CLS_DELIM_ABSENT;
+        const uint64_t e = p.T[valid ? u.state + c : 0u];
+        const bool hit = valid && (e & SG_CLS_MASK) == c;
+        const bool fin = hit && (e & SG_FINAL) != 0;
+        u.state = hit ? (uint32_t)((e >> SG_NEXT_SHIFT) & SG_NEXT_MASK) : u.state;
+        u.sum += hit ? (int)(e >> SG_OW_SHIFT) : 0;
+        u.last_final = (u.mode == 1 && act) ? (fin && u.j == u.L - 1 && u.seen) : u.last_final;   // :189: final on the word's last element, after an earlier arc
+        const bool arc = fin && u.mode == 2 && u.j > u.s0;
+        const bool room = u.narc < BW_WIN && (uint32_t)u.sum < (1u << 20);
+        uint32_t *dst = (arc && room) ? &S.win[u.narc * 64 + lane] : &S.spare32;
+        *dst = ((uint32_t)u.sum << 12) | ((uint32_t)u.s0 << 6) | (uint32_t)u.j;
+        u.narc += (arc && room) ? 1 : 0;
+        u.ovf = u.ovf || (arc && !room);
+        u.single |= (fin && u.mode == 2 && u.j == u.s0) ? (1ull << u.s0) : 0ull;
+        u.seen = u.seen || fin;
+        u.j = act ? (hit ? u.j + 1 : u.L) : u.j;
     }
-    static constexpr int BPE_LOCAL_ID_BITS_W = 20;
-    // the walk of the unit is over
-    BF_WVD void unit_event(Unit &u)
+    // the walk of the unit is over (ev): the whole word matched / go on collecting / all arcs collected
+    BF_WVD void unit_event(Unit &u, bool ev)
     {
-        if (u.mode == 1) {
-            if (u.last_final && u.j == u.L) {                           // the word is one entry
+        const bool whole = ev && u.mode == 1 && u.last_final;
+        if (wv::any(whole)) {
+            if (whole) {                                                // the word is one entry
                 const SegInfo r = p.info[u.sum];
                 S.q[(uint32_t)u.tok & QMASK].pos = (uint32_t)(r.id + p.id_offset);
                 if (p.stats) wv::atomic_add(&p.stats[1], 1ull);
                 unit_finish(u, 1);
-                return;
             }
-            u.mode = 2; u.s0 = 0; u.j = 0; u.state = p.initial; u.sum = 0; u.seen = false; u.narc = 0; u.single = 0;
-            return;
         }
-        // mode 2: the arcs of start s0 are in the window
-        if (u.narc > BW_WIN || !u.seen) { unit_fallback(u, u.narc > BW_WIN ? 4 : 5); return; }   // too many arcs / a start without an arc (an unknown arc)
-        ++u.s0;
-        if (u.s0 < u.L) { u.j = u.s0; u.state = p.initial; u.sum = 0; u.seen = false; return; }
-        // ---- all arcs collected: sort by key (insertion sort in the window), apply, emit
+        const bool bad = ev && !whole && u.mode == 2 && (!u.seen || u.ovf);      // a start without an arc (an unknown arc, :212-225) / the window is full
+        if (wv::any(bad)) { if (bad) unit_fallback(u, u.ovf ? 4 : 5); }
+        const bool go = ev && !whole && !bad;
+        const bool first = go && u.mode == 1;                           // not one entry: collect, from the word's first position
+        const int ns0 = first ? 0 : u.s0 + 1;
+        const bool more = go && ns0 < u.L;
+        u.single = first ? 0ull : u.single; u.narc = first ? 0 : u.narc; u.ovf = first ? false : u.ovf;
+        u.s0 = go ? ns0 : u.s0; u.j = more ? ns0 : u.j; u.state = more ? p.initial : u.state; u.sum = more ? 0 : u.sum; u.seen = more ? false : u.seen;
+        u.mode = go ? (more ? 2 : 3) : u.mode;
+    }
+    // the solve pass of the lanes in mode 3: ids of the collected arcs, sort by key (:238-255), apply against the interior mask
+    // (:274-296), emit the pieces in position order (:299-313)
+    BF_WVD void unit_solve(Unit &u)
+    {
         const int na = u.narc;
+        bool bigid = false;
+        for (int a = 0; a < na; ++a) {
+            const uint32_t key = S.win[a * 64 + lane];
+            const SegInfo r = p.info[key >> 12];
+            if ((uint32_t)r.id >= (1u << BPE_LOCAL_ID_BITS_W)) bigid = true;
+            S.win[a * 64 + lane] = ((uint32_t)r.id << 12) | (key & 0xFFFu);
+        }
+        if (bigid) { unit_fallback(u, 4); return; }
         if (p.stats) wv::atomic_add(&p.stats[8 + (na <= 16 ? 0 : na <= 24 ? 1 : na <= 32 ? 2 : na <= 48 ? 3 : 4)], 1ull);
         for (int a = 1; a < na; ++a) {
             const uint32_t key = S.win[a * 64 + lane];
@@ -290,13 +311,13 @@ struct BpeWave {
             while (b >= 0 && S.win[b * 64 + lane] > key) { S.win[(b + 1) * 64 + lane] = S.win[b * 64 + lane]; --b; }
             S.win[(b + 1) * 64 + lane] = key;
         }
-        unsigned long long inter = 0; unsigned long long applied = 0;
+        unsigned long long inter = 0; uint32_t applied = 0;
         for (int a = 0; a < na; ++a) {                                   // :274-296
             const uint32_t key = S.win[a * 64 + lane];
             const int s = (int)((key >> 6) & 63u), e = (int)(key & 63u);
             if (!((inter >> s) & 1ull) && !((inter >> (e + 1)) & 1ull)) {
                 if (e > s) inter |= ((1ull << (e + 1)) - 1ull) & ~((1ull << (s + 1)) - 1ull);
-                applied |= 1ull << a;
+                applied |= 1u << a;
             }
         }
         const uint32_t ke = u.ke;
@@ -322,13 +343,16 @@ struct BpeWave {
         if (cnt == 1) S.q[(uint32_t)u.tok & QMASK].pos = (uint32_t)first;
         unit_finish(u, cnt);
     }
+    static constexpr int BPE_LOCAL_ID_BITS_W = 20;
+    static constexpr int SOLVE_MIN = 16;                                 // lanes that wait for the solve pass before it runs (or nothing else is left to do)
     BF_WVD bool units_phase(Unit &u, bool drain)
     {
         bool ran = false;
         const uint32_t tail = wv::uni(q_tail);
         uint32_t issue = wv::uni(q_issue);
         for (;;) {
-            // a unit that is in mode 3 .. (none: events are taken at once)
+            const bool ev = u.tok >= 0 && u.mode != 3 && u.j >= u.L;
+            if (wv::any(ev)) unit_event(u, ev);
             const uint32_t avail = tail - issue;
             unsigned long long idle = wv::ballot(u.tok < 0);
             if (avail != 0 && idle != 0) {
@@ -340,11 +364,16 @@ struct BpeWave {
                 idle = wv::ballot(u.tok < 0);
             }
             const int nb = 64 - __builtin_popcountll(idle);
+            const unsigned long long ready = wv::ballot(u.tok >= 0 && u.mode == 3);
+            const int nready = __builtin_popcountll(ready);
+            if (nready != 0 && (nready >= SOLVE_MIN || nready == nb)) {  // enough of them, or nothing but them is busy
+                if (u.tok >= 0 && u.mode == 3) unit_solve(u);
+                ran = true;
+                continue;
+            }
             if (nb == 0) break;
             if (!drain && issue == tail && nb < UMIN) break;
-            for (int st = 0; st < STEPS; ++st) {
-                if (u.tok >= 0) { if (!unit_step(u)) unit_event(u); }
-            }
+            for (int st = 0; st < STEPS; ++st) unit_step(u);
             ran = true;
         }
         q_issue = issue;
@@ -442,7 +471,7 @@ struct BpeWave {
     {
         grab = grab < 1 ? 1 : (grab > WV_GRAB_MAX ? WV_GRAB_MAX : grab);
         st_wave = wave_id; st_waves = n_waves; st_round = 0;
-        Unit u; u.tok = -1; u.mode = 0; u.rs = 0; u.L = 0; u.ke = 0; u.ts = false; u.s0 = u.j = 0; u.state = 0; u.sum = 0; u.seen = u.last_final = false; u.narc = 0; u.single = 0;
+        Unit u; u.tok = -1; u.mode = 0; u.rs = 0; u.L = 0; u.ke = 0; u.s0 = u.j = 0; u.state = 0; u.sum = 0; u.seen = u.last_final = u.ovf = false; u.narc = 0; u.single = 0;
         for (;;) {
             bool moved = settle();
             bool filled = false;
