@@ -33,8 +33,8 @@
 namespace bfa {
 
 constexpr int BW_WORD_MAX = 62;          // positions of a word (the interior mask has 64 bits: position + 1 must fit)
-constexpr int BW_WIN = 32;               // arcs of more than one element a lane's window holds: 99.7 % of the words of the config-3 corpus that are not
-                                         // one entry (<= 16: 83 %, <= 24: 96 %); a word with more sends its document back
+constexpr int BW_WIN = 48;               // arcs of more than one element a lane's window holds: of the words of the config-3 corpus that are not one entry
+                                         // 83 % have <= 16, 96 % <= 24, 99.7 % <= 32, all but 1 in 10,000 <= 48; a word with more sends its document back
 constexpr uint32_t BW_TK_TS = 1u << 29;  // token flag: the word starts with U+2581 (token_start of :176)
 constexpr uint32_t BW_DT_FALLBACK = 4;
 
@@ -297,11 +297,17 @@ struct BpeWave {
     {
         const int na = u.narc;
         bool bigid = false;
-        for (int a = 0; a < na; ++a) {
-            const uint32_t key = S.win[a * 64 + lane];
-            const SegInfo r = p.info[key >> 12];
-            if ((uint32_t)r.id >= (1u << BPE_LOCAL_ID_BITS_W)) bigid = true;
-            S.win[a * 64 + lane] = ((uint32_t)r.id << 12) | (key & 0xFFFu);
+        for (int a0 = 0; a0 < na; a0 += 8) {                             // eight I2Info gathers in flight, then their ids into the keys
+            uint32_t key[8]; int32_t id[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) key[k] = a0 + k < na ? S.win[(a0 + k) * 64 + lane] : 0u;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) id[k] = p.info[a0 + k < na ? (key[k] >> 12) : 0u].id;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) if (a0 + k < na) {
+                if ((uint32_t)id[k] >= (1u << BPE_LOCAL_ID_BITS_W)) bigid = true;
+                S.win[(a0 + k) * 64 + lane] = ((uint32_t)id[k] << 12) | (key[k] & 0xFFFu);
+            }
         }
         if (bigid) { unit_fallback(u, 4); return; }
         if (p.stats) wv::atomic_add(&p.stats[8 + (na <= 16 ? 0 : na <= 24 ? 1 : na <= 32 ? 2 : na <= 48 ? 3 : 4)], 1ull);
@@ -311,24 +317,23 @@ struct BpeWave {
             while (b >= 0 && S.win[b * 64 + lane] > key) { S.win[(b + 1) * 64 + lane] = S.win[b * 64 + lane]; --b; }
             S.win[(b + 1) * 64 + lane] = key;
         }
-        unsigned long long inter = 0; uint32_t applied = 0;
+        unsigned long long inter = 0, applied = 0;
         for (int a = 0; a < na; ++a) {                                   // :274-296
             const uint32_t key = S.win[a * 64 + lane];
             const int s = (int)((key >> 6) & 63u), e = (int)(key & 63u);
             if (!((inter >> s) & 1ull) && !((inter >> (e + 1)) & 1ull)) {
                 if (e > s) inter |= ((1ull << (e + 1)) - 1ull) & ~((1ull << (s + 1)) - 1ull);
-                applied |= 1u << a;
+                applied |= 1ull << a;
             }
         }
         const uint32_t ke = u.ke;
         int32_t *home = p.ids_tmp + S.dt_slot[ke] + (int64_t)(u.rs - S.dt_rbase[ke]);
         int cnt = 0; bool bad = false; int32_t first = 0;
-        for (int pos = 0; pos < u.L; ++pos) {                            // :299-313: the non-interior positions, in order
-            if ((inter >> pos) & 1ull) continue;
-            int id = -1;
+        for (int pos = 0; pos < u.L;) {                                  // :299-313: token by token (a token's positions behind its first are interior)
+            int id = -1, end = pos;
             for (int a = 0; a < na; ++a) {                               // the LAST applied arc that starts here set tos / ids (:291-292)
                 const uint32_t key = S.win[a * 64 + lane];
-                if (((applied >> a) & 1u) && (int)((key >> 6) & 63u) == pos) id = (int)(key >> 12);
+                if (((applied >> a) & 1ull) && (int)((key >> 6) & 63u) == pos) { id = (int)(key >> 12); end = (int)(key & 63u); }
             }
             if (id < 0) {                                                // no applied arc of more than one element starts here: the one-element arc
                 if (!((u.single >> pos) & 1ull)) { bad = true; break; }  // none: pTos[start] == 0 < start, the reference does not come back from here
@@ -338,6 +343,7 @@ struct BpeWave {
             }
             if (cnt == 0) first = id + p.id_offset; else { if (cnt == 1) home[0] = first; home[cnt] = id + p.id_offset; }
             ++cnt;
+            pos = end + 1;
         }
         if (bad || cnt == 0) { unit_fallback(u, 6); return; }
         if (cnt == 1) S.q[(uint32_t)u.tok & QMASK].pos = (uint32_t)first;
