@@ -14,6 +14,7 @@ try:
 except Exception as e: print("variant", sys.argv[2], "failed", e); print(open(sys.argv[1].replace('.json', '.err')).read()[-600:])
 PY
 done
+timeout 200 python tools/bpe_wave_stats.py 200000 2>&1 | tail -1
 # kernel split of the variant (rocprofv3 --kernel-trace --stats)
 cd /tmp; rm -rf /tmp/prof_bw
 timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/prof_bw/stats -o stats -- python $OLDPWD/bench.py --no-cpu-baseline --no-extra-timings --verify 0 --steps 3 --warmup 1 --workload config3 --variant 64 > /dev/null 2> $O/prof.err
