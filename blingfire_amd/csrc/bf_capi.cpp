@@ -425,7 +425,7 @@ int run_device(Handle *h, const char *d_text, const int64_t *d_doc_off, int64_t 
             bw.ids_tmp = sg.ids_tmp; bw.counts = sg.counts; bw.flags = h->w_bwflags.as<int32_t>(); bw.max_ids = max_ids; bw.next_doc = next_doc; bw.status = status; bw.stats = h->lex_stats ? (unsigned long long *)(h->w_misc.as<char>() + 64) : nullptr;
             launch_bpe_wave(bw, s);
             (void)hipMemsetAsync(next_doc, 0, sizeof(unsigned long long), s);
-            launch_bpe_wave_mask(sg.lens, bw.flags, h->w_bwlens.as<int32_t>(), ndocs, s);
+            launch_bpe_wave_mask(sg.lens, bw.flags, h->w_bwlens.as<int32_t>(), ndocs, bw.stats, s);
             sg.lens = h->w_bwlens.as<int32_t>(); sg.counts = h->w_bwcounts.as<int32_t>();
         }
         if (ndocs > 0) launch_seg_sp(sg, s);

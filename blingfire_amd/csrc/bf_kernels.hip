@@ -779,19 +779,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
 // around the lane-per-document pass that redoes the documents the wave program handed back: before it, a document that is done
 // gets length 0 in a copy of the lengths (the lane kernels skip it and write their 0 into a copy of the counts); after it, the counts
 // of the handed-back documents are taken over
-__global__ __launch_bounds__(256) void k_bpe_wave_mask(const int32_t *lens, const int32_t *flags, int32_t *lens2, int64_t ndocs)
+__global__ __launch_bounds__(256) void k_bpe_wave_mask(const int32_t *lens, const int32_t *flags, int32_t *lens2, int64_t ndocs, unsigned long long *stats)
 {
     const int64_t d = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (d < ndocs) lens2[d] = flags[d] ? lens[d] : 0;
+    if (d < ndocs) {
+        lens2[d] = flags[d] ? lens[d] : 0;
+        if (stats && flags[d]) atomicAdd(&stats[13], 1ull);            // experiments: documents the lane kernels are asked to redo
+        if (stats && flags[d] && lens[d] > 0) atomicAdd(&stats[14], 1ull);
+    }
 }
 __global__ __launch_bounds__(256) void k_bpe_wave_merge(int32_t *counts, const int32_t *counts2, const int32_t *flags, int64_t ndocs)
 {
     const int64_t d = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (d < ndocs && flags[d]) counts[d] = counts2[d];
 }
-void launch_bpe_wave_mask(const int32_t *lens, const int32_t *flags, int32_t *lens2, int64_t ndocs, hipStream_t s)
+void launch_bpe_wave_mask(const int32_t *lens, const int32_t *flags, int32_t *lens2, int64_t ndocs, unsigned long long *stats, hipStream_t s)
 {
-    if (ndocs > 0) hipLaunchKernelGGL(k_bpe_wave_mask, dim3((unsigned)((ndocs + 255) / 256)), dim3(256), 0, s, lens, flags, lens2, ndocs);
+    if (ndocs > 0) hipLaunchKernelGGL(k_bpe_wave_mask, dim3((unsigned)((ndocs + 255) / 256)), dim3(256), 0, s, lens, flags, lens2, ndocs, stats);
 }
 void launch_bpe_wave_merge(int32_t *counts, const int32_t *counts2, const int32_t *flags, int64_t ndocs, hipStream_t s)
 {

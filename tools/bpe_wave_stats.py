@@ -14,4 +14,4 @@ bf.lib().BfLexStats.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
 bf.lib().BfLexStats(h, out, 16)
 st = [int(out[i]) for i in range(16)]
 print("docs", ndocs, "words", st[0], "taken whole", st[1], "handed back: symbol", st[2], "word too long", st[3], "window", st[4], "start without arc", st[5], "no applied arc", st[6],
-      "| solved words by arcs <=16/24/32/48/more", st[8:13])
+      "| solved words by arcs <=16/24/32/48/more", st[8:13], "| documents flagged", st[13], "of which with text", st[14])
