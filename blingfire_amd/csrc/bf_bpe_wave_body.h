@@ -33,8 +33,9 @@
 namespace bfa {
 
 constexpr int BW_WORD_MAX = 62;          // positions of a word (the interior mask has 64 bits: position + 1 must fit)
-constexpr int BW_WIN = 48;               // arcs of more than one element a lane's window holds: of the words of the config-3 corpus that are not one entry
-                                         // 83 % have <= 16, 96 % <= 24, 99.7 % <= 32, all but 1 in 10,000 <= 48; a word with more sends its document back
+constexpr int BW_PRIV = 16;              // arcs of more than one element in a lane's own window: 85 % of the words of the config-3 corpus that are not one entry
+constexpr int BW_POOL_N = 8, BW_POOL_ARCS = 32;   // the wave's overflow windows: 8 of 32 more arcs each (12 % of those words have 17-24 arcs, 2.7 % 25-32,
+constexpr int BW_WIN = BW_PRIV + BW_POOL_ARCS;    // 0.4 % 33-48); a word with more than 48 sends its document back
 constexpr uint32_t BW_TK_TS = 1u << 29;  // token flag: the word starts with U+2581 (token_start of :176)
 constexpr uint32_t BW_DT_FALLBACK = 4;
 
@@ -45,7 +46,9 @@ struct BwLds {
     int64_t dt_slot[DTN], dt_doc[DTN];
     alignas(8) WvTok q[QCAP];
     int32_t dt_cap[DTN], dt_cnt[DTN]; uint32_t dt_flags[DTN], dt_rbase[DTN];
-    uint32_t win[BW_WIN * 64];           // arc windows, structure-of-arrays: arc k of lane l at win[k * 64 + l]
+    uint32_t win[BW_PRIV * 64];          // arc windows, structure-of-arrays: arc k (< BW_PRIV) of lane l at win[k * 64 + l]
+    uint32_t pool[BW_POOL_ARCS * BW_POOL_N];   // overflow windows: arc BW_PRIV + k of the lane that holds window w at pool[k * BW_POOL_N + w]
+    uint32_t pool_free;                  // bit w: overflow window w is free
     uint16_t qc[QCAP];
     int64_t dslot[WV_GRAB_MAX]; int32_t dlen[WV_GRAB_MAX];     // stream slot and length of the documents taken from the work counter
     uint32_t spare32; uint16_t spare;
@@ -225,10 +228,13 @@ struct BpeWave {
     // ------------------------------------------------------------------------------------------------------------------
     struct Unit {
         int tok; uint32_t rs; int L; uint32_t ke;
-        int mode, s0, j; uint32_t state; int sum; bool seen, last_final, ovf; int narc;
+        int mode, s0, j; uint32_t state; int sum; bool seen, last_final, ovf; int narc, narc0, pw;   // narc0: arcs before the walk of s0; pw: overflow window (-1: none)
         unsigned long long single;       // bit s: the element at position s is an entry by itself (its one-element arc is not stored)
     };
-    BF_WVD void unit_finish(Unit &u, int cnt) { S.qc[(uint32_t)u.tok & QMASK] = (uint16_t)(cnt + 1); u.tok = -1; u.mode = 0; u.j = u.L; }
+    BF_WVD uint32_t *arc_at(const Unit &u, int a) { return a < BW_PRIV ? &S.win[a * 64 + lane] : &S.pool[(a - BW_PRIV) * BW_POOL_N + u.pw]; }
+    BF_WVD void unit_finish(Unit &u, int cnt) {
+        if (u.pw >= 0) { wv::lds_or(&S.pool_free, 1u << u.pw); u.pw = -1; }          // (lanes that finish in the same instruction return different windows)
+        S.qc[(uint32_t)u.tok & QMASK] = (uint16_t)(cnt + 1); u.tok = -1; u.mode = 0; u.j = u.L; }
     BF_WVD void unit_fallback(Unit &u, int why)
     {
         if (p.stats) wv::atomic_add(&p.stats[why], 1ull);
@@ -241,7 +247,7 @@ struct BpeWave {
         const WvTok e = S.q[t & QMASK];
         u.rs = e.pos; u.L = (int)(e.w & WV_TK_LEN_MASK); u.ke = (e.w >> 16) & DMASK;
         S.qc[t & QMASK] = 0;
-        u.state = p.initial; u.sum = 0; u.j = 0; u.s0 = 0; u.seen = false; u.last_final = false; u.ovf = false; u.narc = 0; u.single = 0;
+        u.state = p.initial; u.sum = 0; u.j = 0; u.s0 = 0; u.seen = false; u.last_final = false; u.ovf = false; u.narc = 0; u.narc0 = 0; u.pw = -1; u.single = 0;
         u.mode = (e.w & BW_TK_TS) ? 1 : 2;                              // only a word that starts with U+2581 can be taken whole (:176,189)
         if (p.stats) wv::atomic_add(&p.stats[0], 1ull);
     }
@@ -260,14 +266,14 @@ struct BpeWave {
         u.sum += hit ? (int)(e >> SG_OW_SHIFT) : 0;
         u.last_final = (u.mode == 1 && act) ? (fin && u.j == u.L - 1 && u.seen) : u.last_final;   // :189: final on the word's last element, after an earlier arc
         const bool arc = fin && u.mode == 2 && u.j > u.s0;
-        const bool room = u.narc < BW_WIN && (uint32_t)u.sum < (1u << 20);
-        uint32_t *dst = (arc && room) ? &S.win[u.narc * 64 + lane] : &S.spare32;
+        const bool room = (u.narc < BW_PRIV || (u.pw >= 0 && u.narc < BW_WIN)) && (uint32_t)u.sum < (1u << 20);
+        uint32_t *dst = (arc && room) ? arc_at(u, u.narc) : &S.spare32;
         *dst = ((uint32_t)u.sum << 12) | ((uint32_t)u.s0 << 6) | (uint32_t)u.j;
         u.narc += (arc && room) ? 1 : 0;
         u.ovf = u.ovf || (arc && !room);
         u.single |= (fin && u.mode == 2 && u.j == u.s0) ? (1ull << u.s0) : 0ull;
         u.seen = u.seen || fin;
-        u.j = act ? (hit ? u.j + 1 : u.L) : u.j;
+        u.j = act ? ((hit && !(arc && !room)) ? u.j + 1 : u.L) : u.j;     // an arc that found no room ends the walk: unit_event gets a window or gives up
     }
     // the walk of the unit is over (ev): the whole word matched / go on collecting / all arcs collected
     BF_WVD void unit_event(Unit &u, bool ev)
@@ -281,13 +287,33 @@ struct BpeWave {
                 unit_finish(u, 1);
             }
         }
-        const bool bad = ev && !whole && u.mode == 2 && (!u.seen || u.ovf);      // a start without an arc (an unknown arc, :212-225) / the window is full
+        // a walk that ran out of window: with an overflow window of the wave it is repeated from its start position; a lane that holds one
+        // already (BW_WIN arcs) gives up, a lane that gets none waits (mode 2 with j >= L: it asks again in the next round)
+        const bool want = ev && !whole && u.mode == 2 && u.ovf && u.pw < 0 && (uint32_t)u.sum < (1u << 20);
+        bool retry = false, wait = false;
+        if (wv::any(want)) {
+            const uint32_t freem = wv::uni(S.pool_free);
+            const unsigned long long wm = wv::ballot(want);
+            const int r = (int)wv::mbcnt(wm);
+            uint32_t f = freem; int w = -1;
+            for (int k = 0; k <= r && f; ++k) { w = __builtin_ctz(f); f &= f - 1u; if (k < r) w = -1; }
+            if (want && w >= 0) { u.pw = w; retry = true; } else if (want) wait = true;
+            const unsigned long long got = wv::ballot(want && w >= 0);
+            uint32_t taken = 0, ff = freem;
+            for (int k = __builtin_popcountll(got); k > 0 && ff; --k) { taken |= ff & (0u - ff); ff &= ff - 1u; }
+            wv::sync();
+            if (lane == 0) S.pool_free = freem & ~taken;
+            wv::sync();
+        }
+        if (retry) { u.narc = u.narc0; u.ovf = false; u.j = u.s0; u.state = p.initial; u.sum = 0; u.seen = false; u.single &= ~(1ull << u.s0); }
+        const bool bad = ev && !whole && !retry && !wait && u.mode == 2 && (!u.seen || u.ovf);      // a start without an arc (an unknown arc, :212-225) / no window left
         if (wv::any(bad)) { if (bad) unit_fallback(u, u.ovf ? 4 : 5); }
-        const bool go = ev && !whole && !bad;
+        const bool go = ev && !whole && !bad && !retry && !wait;
         const bool first = go && u.mode == 1;                           // not one entry: collect, from the word's first position
         const int ns0 = first ? 0 : u.s0 + 1;
         const bool more = go && ns0 < u.L;
         u.single = first ? 0ull : u.single; u.narc = first ? 0 : u.narc; u.ovf = first ? false : u.ovf;
+        u.narc0 = go ? u.narc : u.narc0;
         u.s0 = go ? ns0 : u.s0; u.j = more ? ns0 : u.j; u.state = more ? p.initial : u.state; u.sum = more ? 0 : u.sum; u.seen = more ? false : u.seen;
         u.mode = go ? (more ? 2 : 3) : u.mode;
     }
@@ -300,26 +326,26 @@ struct BpeWave {
         for (int a0 = 0; a0 < na; a0 += 8) {                             // eight I2Info gathers in flight, then their ids into the keys
             uint32_t key[8]; int32_t id[8];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) key[k] = a0 + k < na ? S.win[(a0 + k) * 64 + lane] : 0u;
+            for (int k = 0; k < 8; ++k) key[k] = a0 + k < na ? *arc_at(u, a0 + k) : 0u;
 #pragma unroll
             for (int k = 0; k < 8; ++k) id[k] = p.info[a0 + k < na ? (key[k] >> 12) : 0u].id;
 #pragma unroll
             for (int k = 0; k < 8; ++k) if (a0 + k < na) {
                 if ((uint32_t)id[k] >= (1u << BPE_LOCAL_ID_BITS_W)) bigid = true;
-                S.win[(a0 + k) * 64 + lane] = ((uint32_t)id[k] << 12) | (key[k] & 0xFFFu);
+                *arc_at(u, a0 + k) = ((uint32_t)id[k] << 12) | (key[k] & 0xFFFu);
             }
         }
         if (bigid) { unit_fallback(u, 4); return; }
         if (p.stats) wv::atomic_add(&p.stats[8 + (na <= 16 ? 0 : na <= 24 ? 1 : na <= 32 ? 2 : na <= 48 ? 3 : 4)], 1ull);
         for (int a = 1; a < na; ++a) {
-            const uint32_t key = S.win[a * 64 + lane];
+            const uint32_t key = *arc_at(u, a);
             int b = a - 1;
-            while (b >= 0 && S.win[b * 64 + lane] > key) { S.win[(b + 1) * 64 + lane] = S.win[b * 64 + lane]; --b; }
-            S.win[(b + 1) * 64 + lane] = key;
+            while (b >= 0 && *arc_at(u, b) > key) { *arc_at(u, b + 1) = *arc_at(u, b); --b; }
+            *arc_at(u, b + 1) = key;
         }
         unsigned long long inter = 0, applied = 0;
         for (int a = 0; a < na; ++a) {                                   // :274-296
-            const uint32_t key = S.win[a * 64 + lane];
+            const uint32_t key = *arc_at(u, a);
             const int s = (int)((key >> 6) & 63u), e = (int)(key & 63u);
             if (!((inter >> s) & 1ull) && !((inter >> (e + 1)) & 1ull)) {
                 if (e > s) inter |= ((1ull << (e + 1)) - 1ull) & ~((1ull << (s + 1)) - 1ull);
@@ -332,7 +358,7 @@ struct BpeWave {
         for (int pos = 0; pos < u.L;) {                                  // :299-313: token by token (a token's positions behind its first are interior)
             int id = -1, end = pos;
             for (int a = 0; a < na; ++a) {                               // the LAST applied arc that starts here set tos / ids (:291-292)
-                const uint32_t key = S.win[a * 64 + lane];
+                const uint32_t key = *arc_at(u, a);
                 if (((applied >> a) & 1ull) && (int)((key >> 6) & 63u) == pos) { id = (int)(key >> 12); end = (int)(key & 63u); }
             }
             if (id < 0) {                                                // no applied arc of more than one element starts here: the one-element arc
@@ -372,7 +398,8 @@ struct BpeWave {
             const int nb = 64 - __builtin_popcountll(idle);
             const unsigned long long ready = wv::ballot(u.tok >= 0 && u.mode == 3);
             const int nready = __builtin_popcountll(ready);
-            if (nready != 0 && (nready >= SOLVE_MIN || nready == nb)) {  // enough of them, or nothing but them is busy
+            const bool walking = wv::any(u.tok >= 0 && u.mode != 3 && u.j < u.L);
+            if (nready != 0 && (nready >= SOLVE_MIN || !walking)) {      // enough of them, or nobody walks (the others wait for an overflow window)
                 if (u.tok >= 0 && u.mode == 3) unit_solve(u);
                 ran = true;
                 continue;
@@ -477,7 +504,9 @@ struct BpeWave {
     {
         grab = grab < 1 ? 1 : (grab > WV_GRAB_MAX ? WV_GRAB_MAX : grab);
         st_wave = wave_id; st_waves = n_waves; st_round = 0;
-        Unit u; u.tok = -1; u.mode = 0; u.rs = 0; u.L = 0; u.ke = 0; u.s0 = u.j = 0; u.state = 0; u.sum = 0; u.seen = u.last_final = u.ovf = false; u.narc = 0; u.single = 0;
+        if (lane == 0) S.pool_free = (1u << BW_POOL_N) - 1u;
+        wv::sync();
+        Unit u; u.narc0 = 0; u.pw = -1; u.tok = -1; u.mode = 0; u.rs = 0; u.L = 0; u.ke = 0; u.s0 = u.j = 0; u.state = 0; u.sum = 0; u.seen = u.last_final = u.ovf = false; u.narc = 0; u.single = 0;
         for (;;) {
             bool moved = settle();
             bool filled = false;

@@ -681,6 +681,7 @@ __device__ __forceinline__ uint32_t min_all(uint32_t v)
 }
 __device__ __forceinline__ unsigned long long atomic_add(unsigned long long *p, unsigned long long v) { return atomicAdd(p, v); }
 __device__ __forceinline__ void atomic_or(int *p, int v) { atomicOr(p, v); }
+__device__ __forceinline__ void lds_or(uint32_t *p, uint32_t v) { atomicOr(p, v); }      // a word in LDS, from divergent lanes
 __device__ __forceinline__ unsigned long long clock() { return __builtin_readcyclecounter(); }
 __device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
@@ -808,7 +809,7 @@ void launch_bpe_wave(const BpeWaveParams &p, hipStream_t s)
     static int per_cu = 0;
     if (per_cu <= 0) {
         int q = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&q, k_bpe_wave<L, 3>, 256, 0) != hipSuccess || q <= 0) q = 2;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&q, k_bpe_wave<L, 4>, 256, 0) != hipSuccess || q <= 0) q = 2;
         (void)hipGetLastError();
         per_cu = q;
     }
@@ -818,7 +819,7 @@ void launch_bpe_wave(const BpeWaveParams &p, hipStream_t s)
     const int64_t need = (p.ndocs + (int64_t)grab * 4 - 1) / ((int64_t)grab * 4);
     if (blocks > need) blocks = need;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL((k_bpe_wave<L, 3>), dim3((unsigned)blocks), dim3(256), 0, s, p, grab);
+    hipLaunchKernelGGL((k_bpe_wave<L, 4>), dim3((unsigned)blocks), dim3(256), 0, s, p, grab);
 }
 
 // ------------------------------------------------------------------------------------------
