@@ -319,37 +319,48 @@ struct BpeWave {
     }
     // the solve pass of the lanes in mode 3: ids of the collected arcs, sort by key (:238-255), apply against the interior mask
     // (:274-296), emit the pieces in position order (:299-313)
-    BF_WVD void unit_solve(Unit &u)
+    // Words with at most BW_PRIV arcs, every waiting lane its own: ids of the arcs, Batcher's odd-even merge sort over the BW_PRIV slots
+    // of the lane's window (the slots behind the last arc hold the largest key), apply, emit.  Fixed trip counts: a pass costs the same
+    // whatever the lanes hold (by insertion sort it cost what its largest word cost -- measured: the pass was 3/4 of the kernel).
+    BF_WVD void unit_solve_small(Unit &u)
     {
         const int na = u.narc;
         bool bigid = false;
-        for (int a0 = 0; a0 < na; a0 += 8) {                             // eight I2Info gathers in flight, then their ids into the keys
+#pragma unroll
+        for (int a0 = 0; a0 < BW_PRIV; a0 += 8) {                        // eight I2Info gathers in flight, then their ids into the keys
             uint32_t key[8]; int32_t id[8];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) key[k] = a0 + k < na ? *arc_at(u, a0 + k) : 0u;
+            for (int k = 0; k < 8; ++k) key[k] = a0 + k < na ? S.win[(a0 + k) * 64 + lane] : 0u;
 #pragma unroll
             for (int k = 0; k < 8; ++k) id[k] = p.info[a0 + k < na ? (key[k] >> 12) : 0u].id;
 #pragma unroll
-            for (int k = 0; k < 8; ++k) if (a0 + k < na) {
-                if ((uint32_t)id[k] >= (1u << BPE_LOCAL_ID_BITS_W)) bigid = true;
-                *arc_at(u, a0 + k) = ((uint32_t)id[k] << 12) | (key[k] & 0xFFFu);
+            for (int k = 0; k < 8; ++k) {
+                if (a0 + k < na && (uint32_t)id[k] >= (1u << BPE_LOCAL_ID_BITS_W)) bigid = true;
+                S.win[(a0 + k) * 64 + lane] = a0 + k < na ? (((uint32_t)id[k] << 12) | (key[k] & 0xFFFu)) : 0xFFFFFFFFu;
             }
         }
         if (bigid) { unit_fallback(u, 4); return; }
-        if (p.stats) wv::atomic_add(&p.stats[8 + (na <= 16 ? 0 : na <= 24 ? 1 : na <= 32 ? 2 : na <= 48 ? 3 : 4)], 1ull);
-        for (int a = 1; a < na; ++a) {
-            const uint32_t key = *arc_at(u, a);
-            int b = a - 1;
-            while (b >= 0 && *arc_at(u, b) > key) { *arc_at(u, b + 1) = *arc_at(u, b); --b; }
-            *arc_at(u, b + 1) = key;
-        }
-        unsigned long long inter = 0, applied = 0;
-        for (int a = 0; a < na; ++a) {                                   // :274-296
-            const uint32_t key = *arc_at(u, a);
+        if (p.stats) wv::atomic_add(&p.stats[8], 1ull);
+#pragma unroll
+        for (int pp = 1; pp < BW_PRIV; pp <<= 1)
+#pragma unroll
+            for (int kq = pp; kq >= 1; kq >>= 1)
+#pragma unroll
+                for (int jj = kq % pp; jj <= BW_PRIV - 1 - kq; jj += 2 * kq)
+#pragma unroll
+                    for (int i2 = 0; i2 <= (kq - 1 < BW_PRIV - jj - kq - 1 ? kq - 1 : BW_PRIV - jj - kq - 1); ++i2)
+                        if ((i2 + jj) / (2 * pp) == (i2 + jj + kq) / (2 * pp)) {
+                            const uint32_t x = S.win[(i2 + jj) * 64 + lane], y = S.win[(i2 + jj + kq) * 64 + lane];
+                            S.win[(i2 + jj) * 64 + lane] = x < y ? x : y; S.win[(i2 + jj + kq) * 64 + lane] = x < y ? y : x;
+                        }
+        unsigned long long inter = 0; uint32_t applied = 0;
+#pragma unroll
+        for (int a = 0; a < BW_PRIV; ++a) {                              // :274-296
+            const uint32_t key = S.win[a * 64 + lane];
             const int s = (int)((key >> 6) & 63u), e = (int)(key & 63u);
-            if (!((inter >> s) & 1ull) && !((inter >> (e + 1)) & 1ull)) {
+            if (a < na && !((inter >> s) & 1ull) && !((inter >> (e + 1)) & 1ull)) {
                 if (e > s) inter |= ((1ull << (e + 1)) - 1ull) & ~((1ull << (s + 1)) - 1ull);
-                applied |= 1ull << a;
+                applied |= 1u << a;
             }
         }
         const uint32_t ke = u.ke;
@@ -357,9 +368,10 @@ struct BpeWave {
         int cnt = 0; bool bad = false; int32_t first = 0;
         for (int pos = 0; pos < u.L;) {                                  // :299-313: token by token (a token's positions behind its first are interior)
             int id = -1, end = pos;
-            for (int a = 0; a < na; ++a) {                               // the LAST applied arc that starts here set tos / ids (:291-292)
-                const uint32_t key = *arc_at(u, a);
-                if (((applied >> a) & 1ull) && (int)((key >> 6) & 63u) == pos) { id = (int)(key >> 12); end = (int)(key & 63u); }
+#pragma unroll
+            for (int a = 0; a < BW_PRIV; ++a) {                          // the LAST applied arc that starts here set tos / ids (:291-292)
+                const uint32_t key = S.win[a * 64 + lane];
+                if (((applied >> a) & 1u) && (int)((key >> 6) & 63u) == pos) { id = (int)(key >> 12); end = (int)(key & 63u); }
             }
             if (id < 0) {                                                // no applied arc of more than one element starts here: the one-element arc
                 if (!((u.single >> pos) & 1ull)) { bad = true; break; }  // none: pTos[start] == 0 < start, the reference does not come back from here
@@ -374,6 +386,55 @@ struct BpeWave {
         if (bad || cnt == 0) { unit_fallback(u, 6); return; }
         if (cnt == 1) S.q[(uint32_t)u.tok & QMASK].pos = (uint32_t)first;
         unit_finish(u, cnt);
+    }
+    // Words with more arcs, one after the other by the whole wave: lane j takes arc j (BW_WIN <= 64), its rank among the keys from an
+    // all-pairs comparison through broadcasts, the sorted keys go back into the word's windows, the apply runs on wave-uniform values,
+    // lane q stands for position q of the word when the pieces are emitted (BW_WORD_MAX < 64).
+    BF_WVD void solve_big(Unit &u, unsigned long long bigm)
+    {
+        while (bigm) {
+            const int o = __builtin_ctzll(bigm); bigm &= bigm - 1ull;
+            const int na = wv::bcast(u.narc, o), pw = wv::bcast(u.pw, o), L = wv::bcast(u.L, o), tok = wv::bcast(u.tok, o);
+            const uint32_t rs = wv::bcast(u.rs, o), ke = wv::bcast(u.ke, o);
+            const unsigned long long single = wv::bcast(u.single, o);
+            uint32_t *slot = lane < BW_PRIV ? &S.win[lane * 64 + o] : &S.pool[((lane - BW_PRIV) * BW_POOL_N + pw) % (BW_POOL_ARCS * BW_POOL_N)];
+            uint32_t key = 0xFFFFFFFFu;
+            if (lane < na) key = *slot;
+            int32_t id = 0;
+            if (lane < na) id = p.info[key >> 12].id;
+            const bool bigid = lane < na && (uint32_t)id >= (1u << BPE_LOCAL_ID_BITS_W);
+            if (wv::any(bigid)) { if (lane == o) unit_fallback(u, 4); wv::sync(); continue; }
+            if (lane < na) key = ((uint32_t)id << 12) | (key & 0xFFFu);
+            if (p.stats && lane == o) wv::atomic_add(&p.stats[8 + (na <= 24 ? 1 : na <= 32 ? 2 : 3)], 1ull);
+            int rank = 0;
+            for (int t = 0; t < na; ++t) { const uint32_t kt = wv::bcast(key, t); rank += kt < key ? 1 : 0; }       // the keys of a word are distinct
+            wv::sync();                                                  // every lane has read its arc: the windows take the sorted order
+            if (lane < na) { uint32_t *dst = rank < BW_PRIV ? &S.win[rank * 64 + o] : &S.pool[(rank - BW_PRIV) * BW_POOL_N + pw]; *dst = key; }
+            wv::sync();
+            unsigned long long inter = 0; int my_id = -1;
+            for (int r = 0; r < na; ++r) {                               // :274-296, in sorted order, on wave-uniform values
+                const uint32_t kr = wv::uni(r < BW_PRIV ? S.win[r * 64 + o] : S.pool[(r - BW_PRIV) * BW_POOL_N + pw]);
+                const int s = (int)((kr >> 6) & 63u), e = (int)(kr & 63u);
+                if (!((inter >> s) & 1ull) && !((inter >> (e + 1)) & 1ull)) {
+                    if (e > s) inter |= ((1ull << (e + 1)) - 1ull) & ~((1ull << (s + 1)) - 1ull);
+                    if (lane == s) my_id = (int)(kr >> 12);             // the last applied arc of a start stays (:291-292)
+                }
+            }
+            const bool is_tok = lane < L && !((inter >> lane) & 1ull);   // :299-313: the non-interior positions, lane = position
+            bool bad = false; int idv = my_id;
+            if (is_tok && my_id < 0) {                                   // no applied arc of more than one element starts here: the one-element arc
+                if (!((single >> lane) & 1ull)) bad = true;
+                else { const uint32_t c = (uint32_t)S.ring[(rs + (uint32_t)lane) & RMASK]; const uint64_t e1 = p.T[p.initial + c]; idv = p.info[(int)(e1 >> SG_OW_SHIFT)].id; }
+            }
+            const unsigned long long mt = wv::ballot(is_tok);
+            const int cnt = __builtin_popcountll(mt), k = __builtin_popcountll(mt & ((1ull << lane) - 1ull));
+            if (wv::any(bad) || cnt == 0) { if (lane == o) unit_fallback(u, 6); wv::sync(); continue; }
+            int32_t *home = p.ids_tmp + S.dt_slot[ke] + (int64_t)(rs - S.dt_rbase[ke]);
+            if (is_tok) { if (cnt == 1) S.q[(uint32_t)tok & QMASK].pos = (uint32_t)(idv + p.id_offset); else home[k] = idv + p.id_offset; }
+            wv::sync();
+            if (lane == o) unit_finish(u, cnt);
+            wv::sync();
+        }
     }
     static constexpr int BPE_LOCAL_ID_BITS_W = 20;
     static constexpr int SOLVE_MIN = 16;                                 // lanes that wait for the solve pass before it runs (or nothing else is left to do)
@@ -400,7 +461,11 @@ struct BpeWave {
             const int nready = __builtin_popcountll(ready);
             const bool walking = wv::any(u.tok >= 0 && u.mode != 3 && u.j < u.L);
             if (nready != 0 && (nready >= SOLVE_MIN || !walking)) {      // enough of them, or nobody walks (the others wait for an overflow window)
-                if (u.tok >= 0 && u.mode == 3) unit_solve(u);
+                const bool rdy = u.tok >= 0 && u.mode == 3;
+                const unsigned long long bigm = wv::ballot(rdy && u.narc > BW_PRIV);
+                if (rdy && u.narc <= BW_PRIV) unit_solve_small(u);
+                wv::sync();
+                if (bigm) solve_big(u, bigm);
                 ran = true;
                 continue;
             }
