@@ -34,8 +34,9 @@ namespace bfa {
 
 constexpr int BW_WORD_MAX = 62;          // positions of a word (the interior mask has 64 bits: position + 1 must fit)
 constexpr int BW_PRIV = 16;              // arcs of more than one element in a lane's own window: 85 % of the words of the config-3 corpus that are not one entry
-constexpr int BW_POOL_N = 8, BW_POOL_ARCS = 32;   // the wave's overflow windows: 8 of 32 more arcs each (12 % of those words have 17-24 arcs, 2.7 % 25-32,
-constexpr int BW_WIN = BW_PRIV + BW_POOL_ARCS;    // 0.4 % 33-48); a word with more than 48 sends its document back
+constexpr int BW_POOL_N = 5, BW_POOL_ARCS = 48;   // the wave's overflow windows: 5 of 48 more arcs each (12 % of those words have 17-24 arcs, 2.7 % 25-32,
+constexpr int BW_WIN = BW_PRIV + BW_POOL_ARCS;    // 0.4 % 33-48, one in a million more than 64): BW_WIN = 64 = one arc per lane in solve_big(); a word
+                                                  // with more is solved by its lane alone, its arcs in global memory (unit_huge)
 constexpr uint32_t BW_TK_TS = 1u << 29;  // token flag: the word starts with U+2581 (token_start of :176)
 constexpr uint32_t BW_DT_FALLBACK = 4;
 
@@ -275,6 +276,75 @@ struct BpeWave {
         u.seen = u.seen || fin;
         u.j = act ? ((hit && !(arc && !room)) ? u.j + 1 : u.L) : u.j;     // an arc that found no room ends the walk: unit_event gets a window or gives up
     }
+    // A word with more than BW_WIN arcs (a run of one letter whose run lengths are all entries: one word in a million of the config-3
+    // corpus): its lane does the whole word alone, the plain sequential program of :151-313 restricted to the word, with the arcs in global
+    // memory -- 6 keys per position of the word in the batch's arc workspace, the per-position result behind them.  Slow (every access is
+    // a round trip to memory) and rare; the alternative was to hand the document to a lane kernel that needs 13 us per byte.
+    BF_WVD void unit_huge(Unit &u)
+    {
+        if (p.stats) wv::atomic_add(&p.stats[7], 1ull);
+        const uint32_t ke = u.ke;
+        const int64_t f = (int64_t)(u.rs - S.dt_rbase[ke]);
+        uint32_t *buf = p.scratch + 6 * (S.dt_slot[ke] + f);
+        const int cap = 6 * u.L - u.L;                                   // keys; the last L words hold the per-position result
+        int n = 0; unsigned long long single = 0; bool give_up = false;
+        for (int s0 = 0; s0 < u.L && !give_up; ++s0) {                   // :151-232 on the word (no unknown arc: a start without an arc gives up)
+            uint32_t state = p.initial; int sum = 0; bool seen = false;
+            for (int j = s0; j < u.L; ++j) {
+                const uint32_t c = (uint32_t)S.ring[(u.rs + (uint32_t)j) & RMASK];
+                if (c >= SG_CLS_DELIM_ABSENT) break;
+                const uint64_t e = p.T[state + c];
+                if ((e & SG_CLS_MASK) != c) break;
+                state = (uint32_t)((e >> SG_NEXT_SHIFT) & SG_NEXT_MASK); sum += (int)(e >> SG_OW_SHIFT);
+                if (e & SG_FINAL) {
+                    seen = true;
+                    if (j == s0) single |= 1ull << s0;
+                    else {
+                        const int32_t id = p.info[sum].id;
+                        if (n >= cap || (uint32_t)id >= (1u << BPE_LOCAL_ID_BITS_W)) { give_up = true; break; }
+                        buf[n++] = ((uint32_t)id << 12) | ((uint32_t)s0 << 6) | (uint32_t)j;
+                    }
+                }
+            }
+            if (!seen) give_up = true;
+        }
+        if (give_up) { unit_fallback(u, 4); return; }
+        for (int a = 1; a < n; ++a) {                                    // :234-256 (insertion sort: the keys are distinct, any correct sort gives the same order)
+            const uint32_t key = buf[a];
+            int b = a - 1;
+            while (b >= 0 && buf[b] > key) { buf[b + 1] = buf[b]; --b; }
+            buf[b + 1] = key;
+        }
+        uint32_t *res = buf + n;                                         // per position: id << 6 | end of the last applied arc that starts there
+        for (int q = 0; q < u.L; ++q) res[q] = 0xFFFFFFFFu;
+        unsigned long long inter = 0;
+        for (int a = 0; a < n; ++a) {                                    // :274-296
+            const uint32_t key = buf[a];
+            const int s = (int)((key >> 6) & 63u), e = (int)(key & 63u);
+            if (!((inter >> s) & 1ull) && !((inter >> (e + 1)) & 1ull)) {
+                inter |= ((1ull << (e + 1)) - 1ull) & ~((1ull << (s + 1)) - 1ull);
+                res[s] = ((key >> 12) << 6) | (uint32_t)e;
+            }
+        }
+        int32_t *home = p.ids_tmp + S.dt_slot[ke] + f;
+        int cnt = 0; bool bad = false; int32_t first = 0;
+        for (int pos = 0; pos < u.L;) {                                  // :299-313
+            const uint32_t v = res[pos];
+            int id, end = pos;
+            if (v != 0xFFFFFFFFu) { id = (int)(v >> 6); end = (int)(v & 63u); }
+            else {
+                if (!((single >> pos) & 1ull)) { bad = true; break; }
+                const uint32_t c = (uint32_t)S.ring[(u.rs + (uint32_t)pos) & RMASK];
+                id = p.info[(int)(p.T[p.initial + c] >> SG_OW_SHIFT)].id;
+            }
+            if (cnt == 0) first = id + p.id_offset; else { if (cnt == 1) home[0] = first; home[cnt] = id + p.id_offset; }
+            ++cnt;
+            pos = end + 1;
+        }
+        if (bad || cnt == 0) { unit_fallback(u, 6); return; }
+        if (cnt == 1) S.q[(uint32_t)u.tok & QMASK].pos = (uint32_t)first;
+        unit_finish(u, cnt);
+    }
     // the walk of the unit is over (ev): the whole word matched / go on collecting / all arcs collected
     BF_WVD void unit_event(Unit &u, bool ev)
     {
@@ -306,9 +376,11 @@ struct BpeWave {
             wv::sync();
         }
         if (retry) { u.narc = u.narc0; u.ovf = false; u.j = u.s0; u.state = p.initial; u.sum = 0; u.seen = false; u.single &= ~(1ull << u.s0); }
-        const bool bad = ev && !whole && !retry && !wait && u.mode == 2 && (!u.seen || u.ovf);      // a start without an arc (an unknown arc, :212-225) / no window left
+        const bool huge = ev && !whole && !retry && !wait && u.mode == 2 && u.ovf && u.pw >= 0 && (uint32_t)u.sum < (1u << 20);   // more than BW_WIN arcs
+        if (wv::any(huge)) { if (huge) unit_huge(u); }
+        const bool bad = ev && !whole && !retry && !wait && !huge && u.mode == 2 && (!u.seen || u.ovf);      // a start without an arc (an unknown arc, :212-225)
         if (wv::any(bad)) { if (bad) unit_fallback(u, u.ovf ? 4 : 5); }
-        const bool go = ev && !whole && !bad && !retry && !wait;
+        const bool go = ev && !whole && !bad && !retry && !wait && !huge;
         const bool first = go && u.mode == 1;                           // not one entry: collect, from the word's first position
         const int ns0 = first ? 0 : u.s0 + 1;
         const bool more = go && ns0 < u.L;
@@ -397,7 +469,7 @@ struct BpeWave {
             const int na = wv::bcast(u.narc, o), pw = wv::bcast(u.pw, o), L = wv::bcast(u.L, o), tok = wv::bcast(u.tok, o);
             const uint32_t rs = wv::bcast(u.rs, o), ke = wv::bcast(u.ke, o);
             const unsigned long long single = wv::bcast(u.single, o);
-            uint32_t *slot = lane < BW_PRIV ? &S.win[lane * 64 + o] : &S.pool[((lane - BW_PRIV) * BW_POOL_N + pw) % (BW_POOL_ARCS * BW_POOL_N)];
+            uint32_t *slot = lane < BW_PRIV ? &S.win[lane * 64 + o] : &S.pool[(lane - BW_PRIV) * BW_POOL_N + pw];
             uint32_t key = 0xFFFFFFFFu;
             if (lane < na) key = *slot;
             int32_t id = 0;

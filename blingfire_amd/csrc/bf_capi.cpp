@@ -422,7 +422,7 @@ int run_device(Handle *h, const char *d_text, const int64_t *d_doc_off, int64_t 
             BpeWaveParams bw;
             bw.T = sg.S.T; bw.info = sg.S.info; bw.initial = sg.S.initial; bw.cls_delim = sg.S.cls_delim; bw.id_offset = sg.S.id_offset;
             bw.stream = sg.stream; bw.lens = sg.lens; bw.doc_off = b.doc_off; bw.slot_mul = mul; bw.ndocs = ndocs;
-            bw.ids_tmp = sg.ids_tmp; bw.counts = sg.counts; bw.flags = h->w_bwflags.as<int32_t>(); bw.max_ids = max_ids; bw.next_doc = next_doc; bw.status = status; bw.stats = h->lex_stats ? (unsigned long long *)(h->w_misc.as<char>() + 64) : nullptr;
+            bw.ids_tmp = sg.ids_tmp; bw.counts = sg.counts; bw.flags = h->w_bwflags.as<int32_t>(); bw.max_ids = max_ids; bw.next_doc = next_doc; bw.status = status; bw.scratch = (uint32_t *)sg.arcs; bw.stats = h->lex_stats ? (unsigned long long *)(h->w_misc.as<char>() + 64) : nullptr;
             launch_bpe_wave(bw, s);
             (void)hipMemsetAsync(next_doc, 0, sizeof(unsigned long long), s);
             launch_bpe_wave_mask(sg.lens, bw.flags, h->w_bwlens.as<int32_t>(), ndocs, bw.stats, s);

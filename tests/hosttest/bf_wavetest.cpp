@@ -107,10 +107,11 @@ long bft_emu_bpe_wave_batch(void *hv, const uint8_t *text, long text_bytes, cons
         memcpy(stream.data() + (size_t)mul * (size_t)(doc_off[d] + d), st.data(), st.size() * 2);
     }
     unsigned long long next_doc = 0; int status = 0;
+    std::vector<uint32_t> scratch(6 * cells, 0xABABABABu);
     BpeWaveParams p;
     p.T = m.dict.t64.data(); p.info = (const SegInfo *)m.seg_info.data(); p.initial = m.dict.initial_base; p.cls_delim = m.sp_delim_code; p.id_offset = m.id_offset;
     p.stream = stream.data(); p.lens = lens.data(); p.doc_off = doc_off; p.slot_mul = mul; p.ndocs = ndocs;
-    p.ids_tmp = tmp.data(); p.counts = counts.data(); p.flags = flags.data(); p.max_ids = max_ids; p.next_doc = &next_doc; p.status = &status; p.stats = stats;
+    p.ids_tmp = tmp.data(); p.counts = counts.data(); p.flags = flags.data(); p.max_ids = max_ids; p.next_doc = &next_doc; p.status = &status; p.stats = stats; p.scratch = scratch.data();
     if (cfg >= 16) { p.next_doc = nullptr; cfg -= 16; }
     if (ndocs > 0) {
         auto run = [&](auto *lds_tag) {
