@@ -1749,7 +1749,7 @@ const char *BfTokeniseKernel(void *p)
     case KIND_WP: return use_wave(h, false, 0) ? "k_wp_wave" : (h->m.two_level ? "k_lex_wp_plain" : "k_lex_wp_flat");
     case KIND_UNIGRAM: return "k_seg_unigram_lane";
     case KIND_I2W: return "";
-    default: return "k_bpe_fused";
+    default: return use_bpe_wave(h, false) ? "k_bpe_wave" : "k_bpe_fused";
     }
 }
 
