@@ -1,0 +1,17 @@
+// bf_bpe_wave.h -- launch parameters of the BPE wave program (bf_bpe_wave_body.h; see there)
+#pragma once
+#include <stdint.h>
+#include "bf_seg.h"
+
+namespace bfa {
+
+struct BpeWaveParams {
+    const uint64_t *T; const SegInfo *info; uint32_t initial, cls_delim; int id_offset;
+    const uint16_t *stream; const int32_t *lens; const int64_t *doc_off; int slot_mul; int64_t ndocs;
+    int32_t *ids_tmp; int32_t *counts; int32_t *flags; int max_ids; unsigned long long *next_doc; int *status;
+    uint32_t *scratch;               // 6 words per stream cell (the batch's arc workspace): the arcs of a word with more than 64 of them (unit_huge)
+    unsigned long long *stats;       // optional (tests, experiments): [0] words, [1] taken whole, [2..7] documents handed back because of: a symbol outside the
+                                     // alphabet, a word too long, a window overflow, a start without an arc, a position without an applied arc; [7] words solved by unit_huge
+};
+
+} // namespace bfa

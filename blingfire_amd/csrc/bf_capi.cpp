@@ -152,6 +152,7 @@ struct Handle {
     bool dict_ready = false;
     DevBuf w_keys, w_keyoff, w_dids, w_dret, w_vals;              // DictGetInfoBatch staging
     DevBuf w_s1, w_s2, w_s3, w_s4, w_perm, w_hist, w_narcs;      // _sp scratch
+    DevBuf w_bwflags, w_bwlens, w_bwcounts;                     // BPE wave program: documents handed back, and the masked lengths / counts of the pass that redoes them
     DevBuf w_big;                                                // BPE: pool of the documents beyond the per-document arc reserve (k_bpe_big)
     // workspaces
     DevBuf w_cls, w_nchars, w_tmp, w_counts, w_bsums, w_misc, w_flags, w_out, w_outoff;   // w_misc: [0] next_doc (u64), [2] status (int)
@@ -179,7 +180,7 @@ struct Handle {
         for (Handle *c : shards) if (c && c != this) { DeviceGuard dg(c->device); (void)hipDeviceSynchronize(); delete c; }
         shards.clear();
         pipe.release(); m_small.release();
-        for (DevBuf *b : {&t_dk_l1, &t_dk_pages, &t_dn_l1, &t_dn_pages, &t_dn_pool, &t_k2i, &t_rows, &w_keys, &w_keyoff, &w_dids, &w_dret, &w_vals, &t_i2w_off, &t_i2w_data, &t_kind, &t_wbd, &t_info, &t_acts, &t_cp_l1, &t_cp_pages, &t_multi, &t_wcp_l1, &t_wcp_pages, &t_dict, &t_seginfo, &w_s1, &w_s2, &w_s3, &w_s4, &w_big, &w_perm, &w_hist, &w_narcs, &w_cls, &w_nchars, &w_tmp, &w_counts, &w_flags, &w_out, &w_outoff,
+        for (DevBuf *b : {&t_dk_l1, &t_dk_pages, &t_dn_l1, &t_dn_pages, &t_dn_pool, &t_k2i, &t_rows, &w_keys, &w_keyoff, &w_dids, &w_dret, &w_vals, &t_i2w_off, &t_i2w_data, &t_kind, &t_wbd, &t_info, &t_acts, &t_cp_l1, &t_cp_pages, &t_multi, &t_wcp_l1, &t_wcp_pages, &t_dict, &t_seginfo, &w_s1, &w_s2, &w_s3, &w_s4, &w_big, &w_perm, &w_hist, &w_narcs, &w_bwflags, &w_bwlens, &w_bwcounts, &w_cls, &w_nchars, &w_tmp, &w_counts, &w_flags, &w_out, &w_outoff,
                           &w_bsums, &w_misc, &w_text, &w_docoff, &w_ids, &w_idoff, &w_starts, &w_ends, &w_srcoff, &w_span}) b->release();
         for (auto &e : ev) if (e) (void)hipEventDestroy(e);
         if (stream) (void)hipStreamDestroy(stream);
@@ -297,6 +298,10 @@ bool use_wave(const Handle *h, bool want_off, int words)
     return h->m.kind == KIND_WP && h->m.wave_ok && !want_off && !words && (h->variant & 0xff) != 2;
 }
 
+// the BPE wave program (bf_bpe_wave_body.h) in front of the lane-per-document kernels: EXPERIMENTAL until it has had its GPU parity and
+// timing runs -- only with BfSetVariant bit 0x40
+bool use_bpe_wave(const Handle *h, bool want_off) { return h->m.bpe_wave_ok && !want_off && (h->variant & 0x40) != 0; }
+
 bool reserve_ids_workspaces(Handle *h, int64_t ndocs, int64_t total_bytes, bool want_off, int words = 0)
 {
     const Model &m = h->m;
@@ -321,6 +326,7 @@ bool reserve_ids_workspaces(Handle *h, int64_t ndocs, int64_t total_bytes, bool 
         if (!h->w_s1.reserve((6 * cap + 32 * (size_t)ndocs + 64) * 16) || !h->w_s2.reserve(std::max(cap * 4, 2 * bm_words * 4) + ((size_t)ndocs + 16) * 4) ||
             !h->w_s3.reserve(cap * 4) || !h->w_s4.reserve(cap) || !h->w_big.reserve(BPE_BIG_POOL_BYTES)) return false;
     }
+    if (use_bpe_wave(h, want_off) && !(h->w_bwflags.reserve((size_t)(ndocs + 1) * 4) && h->w_bwlens.reserve((size_t)(ndocs + 1) * 4) && h->w_bwcounts.reserve((size_t)(ndocs + 1) * 4))) return false;
     return h->w_perm.reserve((size_t)(ndocs + 1) * 4) && h->w_hist.reserve(2048 * 4) && h->w_narcs.reserve((size_t)(ndocs + 1) * 4);
 }
 
@@ -409,7 +415,21 @@ int run_device(Handle *h, const char *d_text, const int64_t *d_doc_off, int64_t 
         sg.lane_ok = uni_lane_ok(m) ? 1 : 0;
         if (m.kind == KIND_UNIGRAM && sg.lane_ok) first = h->w_narcs.as<int32_t>();
         sg.perm = h->w_perm.as<int32_t>(); sg.hist = h->w_hist.as<unsigned int>();
+        const bool bwave = use_bpe_wave(h, want_off);
+        if (bwave && ndocs > 0) {
+            // words that are one vocabulary entry (most are) and short words that are not: the wave program; the documents it hands back
+            // (flags): the lane-per-document kernels below, for which every other document has length 0
+            BpeWaveParams bw;
+            bw.T = sg.S.T; bw.info = sg.S.info; bw.initial = sg.S.initial; bw.cls_delim = sg.S.cls_delim; bw.id_offset = sg.S.id_offset;
+            bw.stream = sg.stream; bw.lens = sg.lens; bw.doc_off = b.doc_off; bw.slot_mul = mul; bw.ndocs = ndocs;
+            bw.ids_tmp = sg.ids_tmp; bw.counts = sg.counts; bw.flags = h->w_bwflags.as<int32_t>(); bw.max_ids = max_ids; bw.next_doc = next_doc; bw.status = status; bw.scratch = (uint32_t *)sg.arcs; bw.stats = h->lex_stats ? (unsigned long long *)(h->w_misc.as<char>() + 64) : nullptr;
+            launch_bpe_wave(bw, s);
+            (void)hipMemsetAsync(next_doc, 0, sizeof(unsigned long long), s);
+            launch_bpe_wave_mask(sg.lens, bw.flags, h->w_bwlens.as<int32_t>(), ndocs, bw.stats, s);
+            sg.lens = h->w_bwlens.as<int32_t>(); sg.counts = h->w_bwcounts.as<int32_t>();
+        }
         if (ndocs > 0) launch_seg_sp(sg, s);
+        if (bwave && ndocs > 0) launch_bpe_wave_merge(h->w_counts.as<int32_t>(), h->w_bwcounts.as<int32_t>(), h->w_bwflags.as<int32_t>(), ndocs, s);
         (void)hipEventRecord(h->ev[EV_TOK], s);
     }
     ScanParams sp{h->w_counts.as<int32_t>(), ndocs, d_id_off, h->w_bsums.as<int64_t>(), nblocks};
@@ -1729,7 +1749,7 @@ const char *BfTokeniseKernel(void *p)
     case KIND_WP: return use_wave(h, false, 0) ? "k_wp_wave" : (h->m.two_level ? "k_lex_wp_plain" : "k_lex_wp_flat");
     case KIND_UNIGRAM: return "k_seg_unigram_lane";
     case KIND_I2W: return "";
-    default: return "k_bpe_fused";
+    default: return use_bpe_wave(h, false) ? "k_bpe_wave" : "k_bpe_fused";
     }
 }
 

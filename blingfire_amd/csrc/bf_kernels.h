@@ -6,6 +6,7 @@
 #include "bf_seg.h"
 #include "bf_batch.h"
 #include "bf_wave.h"
+#include "bf_bpe_wave.h"
 
 namespace bfa {
 
@@ -108,6 +109,9 @@ struct CompactParams {
 void launch_prep_wp(const WpPrepParams &p, int64_t total_bytes, unsigned long long *flags, hipStream_t s);
 void launch_lex_wp(const WpLexParams &p, int variant, hipStream_t s);
 void launch_wp_wave(const WpWaveParams &p, int variant, hipStream_t s);     // unit-form lexers (bf_wave.h): replaces prep + lexer
+void launch_bpe_wave(const BpeWaveParams &p, hipStream_t s);                  // bpe-opt models (bf_bpe_wave_body.h)
+void launch_bpe_wave_mask(const int32_t *lens, const int32_t *flags, int32_t *lens2, int64_t ndocs, unsigned long long *stats, hipStream_t s);
+void launch_bpe_wave_merge(int32_t *counts, const int32_t *counts2, const int32_t *flags, int64_t ndocs, hipStream_t s);
 void launch_prep_sp(const SpPrepParams &p, hipStream_t s);
 void launch_seg_sp(const SpSegParams &p, hipStream_t s);
 void launch_scan(const ScanParams &p, hipStream_t s);

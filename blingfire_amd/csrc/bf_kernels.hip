@@ -681,6 +681,7 @@ __device__ __forceinline__ uint32_t min_all(uint32_t v)
 }
 __device__ __forceinline__ unsigned long long atomic_add(unsigned long long *p, unsigned long long v) { return atomicAdd(p, v); }
 __device__ __forceinline__ void atomic_or(int *p, int v) { atomicOr(p, v); }
+__device__ __forceinline__ void lds_or(uint32_t *p, uint32_t v) { atomicOr(p, v); }      // a word in LDS, from divergent lanes
 __device__ __forceinline__ unsigned long long clock() { return __builtin_readcyclecounter(); }
 __device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
@@ -759,6 +760,66 @@ void launch_wp_wave(const WpWaveParams &p, int variant, hipStream_t s)
     else if (cfg == 5) launch_wp_wave_cfg<L, 1, 3, 8, 1>(p, grab, per_cu, s);                                 // experiments: when the units phase ends
     else if (cfg == 6) launch_wp_wave_cfg<L, 1, 3, 8, 12>(p, grab, per_cu, s);
     else launch_wp_wave_cfg<L, 1, 3, 8>(p, grab, per_cu, s);
+}
+
+} // namespace bfa
+#include "bf_bpe_wave_body.h"
+namespace bfa {
+
+// k_bpe_wave: the BPE wave program (bf_bpe_wave_body.h) on the class streams k_prep_sp wrote.  The program is validated in the test
+// simulator (tests/test_bpe_wave_emu.py); the device path (bf_capi.cpp, behind BfSetVariant bit 0x40 until it has had its GPU parity
+// and timing runs) redoes the documents it hands back (flags[d] = 1) with the lane-per-document kernels.
+template <class LDS, int WPE>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_bpe_wave(BpeWaveParams p, int grab)
+{
+    __shared__ LDS lds[4];
+    BpeWave<LDS> w(p, lds[wave_in_block()]);
+    w.run(grab, (int)(blockIdx.x * 4) + wave_in_block(), (int)(gridDim.x * 4));
+}
+
+// around the lane-per-document pass that redoes the documents the wave program handed back: before it, a document that is done
+// gets length 0 in a copy of the lengths (the lane kernels skip it and write their 0 into a copy of the counts); after it, the counts
+// of the handed-back documents are taken over
+__global__ __launch_bounds__(256) void k_bpe_wave_mask(const int32_t *lens, const int32_t *flags, int32_t *lens2, int64_t ndocs, unsigned long long *stats)
+{
+    const int64_t d = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (d < ndocs) {
+        lens2[d] = flags[d] ? lens[d] : 0;
+        if (stats && flags[d]) atomicAdd(&stats[13], 1ull);            // experiments: documents the lane kernels are asked to redo
+        if (stats && flags[d] && lens[d] > 0) atomicAdd(&stats[14], 1ull);
+    }
+}
+__global__ __launch_bounds__(256) void k_bpe_wave_merge(int32_t *counts, const int32_t *counts2, const int32_t *flags, int64_t ndocs)
+{
+    const int64_t d = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (d < ndocs && flags[d]) counts[d] = counts2[d];
+}
+void launch_bpe_wave_mask(const int32_t *lens, const int32_t *flags, int32_t *lens2, int64_t ndocs, unsigned long long *stats, hipStream_t s)
+{
+    if (ndocs > 0) hipLaunchKernelGGL(k_bpe_wave_mask, dim3((unsigned)((ndocs + 255) / 256)), dim3(256), 0, s, lens, flags, lens2, ndocs, stats);
+}
+void launch_bpe_wave_merge(int32_t *counts, const int32_t *counts2, const int32_t *flags, int64_t ndocs, hipStream_t s)
+{
+    if (ndocs > 0) hipLaunchKernelGGL(k_bpe_wave_merge, dim3((unsigned)((ndocs + 255) / 256)), dim3(256), 0, s, counts, counts2, flags, ndocs);
+}
+
+void launch_bpe_wave(const BpeWaveParams &p, hipStream_t s)
+{
+    typedef BwLds<1024, 256, 8> L;
+    static int per_cu = 0;
+    if (per_cu <= 0) {
+        int q = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&q, k_bpe_wave<L, 4>, 256, 0) != hipSuccess || q <= 0) q = 2;
+        (void)hipGetLastError();
+        per_cu = q;
+    }
+    const int64_t per_wave = p.ndocs / ((int64_t)device_cus() * per_cu * 4);
+    const int grab = per_wave >= WV_GRAB_MAX ? WV_GRAB_MAX : per_wave < 1 ? 1 : (int)per_wave;
+    int64_t blocks = (int64_t)device_cus() * per_cu;
+    const int64_t need = (p.ndocs + (int64_t)grab * 4 - 1) / ((int64_t)grab * 4);
+    if (blocks > need) blocks = need;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL((k_bpe_wave<L, 4>), dim3((unsigned)blocks), dim3(256), 0, s, p, grab);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -945,6 +945,12 @@ bool build_model(Model &m, const uint8_t *img, size_t size)
             // iterative-safe: tries are shallow (<= 128), recursion depth == path length
             m.trie_max_depth = dfs(rw.initial);
             if (cyclic) m.trie_max_depth = 0x7fffffff;
+            // bf_bpe_wave_body.h: an arc never crosses a word when no state but the initial one has a transition on U+2581
+            bool inner_delim = false;
+            for (size_t s = 0; s < ns && !inner_delim; ++s)
+                if ((int)s != rw.initial)
+                    for (uint32_t t = rw.tr_begin[s]; t < rw.tr_begin[s + 1]; ++t) if (rw.tr_dst[t] >= 0 && rw.tr_sym[t] == 0x2581) { inner_delim = true; break; }
+            m.bpe_wave_ok = m.kind == KIND_BPE_OPT && !cyclic && !inner_delim;
         }
         const int need = m.kind == KIND_UNIGRAM || m.kind == KIND_BPE_MERGES ? 2 : 1;
         size_t nvalid = 0; for (uint8_t v : m.i2info_valid) if (v >= need) ++nvalid;

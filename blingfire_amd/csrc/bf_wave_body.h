@@ -707,6 +707,7 @@ struct WpWave {
         if (!have_doc) {
             if (exiting || dt_tail - dt_head >= (uint32_t)DTN) return false;
             if (di >= dn) {
+                wv::sync();                                             // every lane has read the offsets of the range before (an empty last document returns without a hand-off)
                 unsigned long long base = 0;
                 if (p.next_doc) {
                     if (lane == 0) base = wv::atomic_add(p.next_doc, (unsigned long long)grab);

@@ -227,10 +227,12 @@ static int emu_wp(const Model &m, const char *s, int n, int32_t *ids, int32_t *s
 
 static std::vector<int32_t> *g_arc_dump = nullptr;
 
-// scalar restatement of the _sp prologue on the fused element-code map (the prep KERNEL is wave-parallel; GPU tests cover it)
-static int emu_sp(const Model &m, const char *s, int n, int32_t *ids, int32_t *spans, std::vector<int> *src_off, int max_ids, int unk)
+// scalar restatement of the _sp prologue on the fused element-code map (the prep KERNEL is wave-parallel; GPU tests cover it):
+// the class stream of one document.  false: TextToIds returns 0 for it (tokdll:1409-1411,1440-1444)
+bool bft_sp_stream(const Model &m, const char *s, int n, std::vector<uint16_t> &st, std::vector<int> *src_off)
 {
-    if (n <= 0 || !s) return 0;
+    st.clear();
+    if (n <= 0 || !s) return false;
     std::vector<int> cps((size_t)n);
     int len;
     if (m.use_bytes) {
@@ -238,7 +240,7 @@ static int emu_sp(const Model &m, const char *s, int n, int32_t *ids, int32_t *s
         if (n >= 3 && p[0] == 0xEF && p[1] == 0xBB && p[2] == 0xBF) k = 3;
         len = 0; for (; k < n; ++k) cps[(size_t)len++] = p[k];
     } else len = bfo_utf8_to_utf32(s, n, cps.data(), n);
-    if (len <= 0) return 0;
+    if (len <= 0) return false;
     std::vector<uint16_t> el; std::vector<int> eoff;
     if (!m.no_dummy_prefix) { el = m.sp_prefix; eoff.assign(el.size(), -1); }
     {
@@ -251,8 +253,7 @@ static int emu_sp(const Model &m, const char *s, int n, int32_t *ids, int32_t *s
             p += m.use_bytes ? 1 : (c0 < 0x80 ? 1 : c0 < 0x800 ? 2 : c0 < 0x10000 ? 3 : 4);
         }
     }
-    if (m.dict_has_charmap && (el.empty() || (long)el.size() > 2L * (n + 1))) return 0;
-    std::vector<uint16_t> st;
+    if (m.dict_has_charmap && (el.empty() || (long)el.size() > 2L * (n + 1))) return false;
     const uint16_t D = m.sp_delim_code;
     for (size_t i = 0; i < el.size(); ++i) {
         const uint16_t e = el[i];
@@ -260,6 +261,14 @@ static int emu_sp(const Model &m, const char *s, int n, int32_t *ids, int32_t *s
         else if (i == 0 || !(el[i - 1] == SP_WS || el[i - 1] == D)) { st.push_back(D); if (src_off) src_off->push_back(eoff[i]); }
     }
     if (st.size() > 1 && st.back() == D) st.pop_back();
+    return true;
+}
+
+static int emu_sp(const Model &m, const char *s, int n, int32_t *ids, int32_t *spans, std::vector<int> *src_off, int max_ids, int unk)
+{
+    std::vector<uint16_t> st;
+    if (!bft_sp_stream(m, s, n, st, src_off)) return 0;
+    const uint16_t D = m.sp_delim_code;
     const int L = (int)st.size();
     SegTables S;
     S.T = m.dict.t64.data(); S.info = (const SegInfo *)m.seg_info.data(); S.initial = m.dict.initial_base; S.cls_delim = D;
@@ -327,6 +336,8 @@ static int emu_sp(const Model &m, const char *s, int n, int32_t *ids, int32_t *s
     }
     return r < 0 ? -2 : r;
 }
+
+int bft_emu_sp_doc(const Model &m, const char *s, int n, int32_t *ids, int max_ids, int unk) { return emu_sp(m, s, n, ids, nullptr, nullptr, max_ids, unk); }
 
 // BPE models: ids as bft_emu_text_to_ids + the collected arc list: out = [L, narcs, kind, (start, end, id, rank bits) * narcs]; returns
 // the id count (-2: the reference would not terminate), *out_ints = ints written (0 if the buffer is too small)

@@ -5,6 +5,7 @@
 // can be fuzzed against the oracle without a GPU.
 #include "wave_emu.h"
 #include "../../blingfire_amd/csrc/bf_wave_body.h"
+#include "../../blingfire_amd/csrc/bf_bpe_wave_body.h"
 #include "hosttest.h"
 
 #include <vector>
@@ -38,6 +39,7 @@ extern "C" {
 
 int bft_wave_ok(void *hv) { return ((Handle *)hv)->m.wave_ok ? 1 : 0; }
 const char *bft_wave_why(void *hv) { return ((Handle *)hv)->m.wave_why.c_str(); }
+int bft_bpe_wave_ok(void *hv) { return ((Handle *)hv)->m.bpe_wave_ok ? 1 : 0; }
 
 // TextToIdsBatch through the wave kernel on the host.  cfg: 0 = the shipped configuration, 1 = two units per lane, the smallest ring and queue, a two-entry
 // document table, every token with an explicit action, 2 = three units per lane, a large ring and queue.  Returns the total id count, or < 0 (-1: model not in unit form, -5: the kernel raised a status bit).
@@ -74,6 +76,78 @@ long bft_emu_wave_batch(void *hv, const uint8_t *text, long text_bytes, const in
         if (c == 0) continue;
         const int64_t slot = wv_ids_slot(doc_off[d], d);
         for (int i = 0; i < c; ++i) { if (o + i < ids_cap) ids_out[o + i] = tmp[(size_t)(slot + i)]; }
+        o += c;
+    }
+    id_off[ndocs] = o;
+    return o;
+}
+
+// The same for a bpe-opt model (bf_bpe_wave_body.h): the _sp prologue restated per document (bft_sp_stream) lays the class streams out as
+// the prologue kernel does (slot of document d = mul * (doc_off[d] + d)), the BPE wave program runs in the simulator, the documents it
+// hands back (flags) are redone by the sequential restatement of the lane-per-document path, then scan + compaction.  cfg: 0 = ring 1,024 /
+// queue 256 / 8 open documents, 1 = queue 128 / 2 open documents; + 16 = no work counter.  flags_out[d] = 1: document d was handed back.
+// Returns the total id count, -1: the model is not eligible, -5: the kernel raised a status bit.
+long bft_emu_bpe_wave_batch(void *hv, const uint8_t *text, long text_bytes, const int64_t *doc_off, long ndocs, int max_ids, int unk, int nwaves, int grab, int cfg,
+                            int32_t *ids_out, long ids_cap, int64_t *id_off, int32_t *flags_out, unsigned long long *stats)
+{
+    Model &m = ((Handle *)hv)->m;
+    if (!m.error.empty() || !m.bpe_wave_ok) return -1;
+    if (max_ids < 0) max_ids = 0;
+    (void)text_bytes;
+    const int mul = m.dict_has_charmap ? 2 : 1;
+    const int64_t total = ndocs > 0 ? doc_off[ndocs] : 0;
+    const size_t cells = (size_t)(mul * (total + ndocs + 1) + 64);
+    std::vector<uint16_t> stream(cells, (uint16_t)0xEEEE); std::vector<int32_t> tmp(cells, -77), lens((size_t)ndocs + 1, 0), counts((size_t)ndocs + 1, -55), flags((size_t)ndocs + 1, -55);
+    std::vector<uint16_t> st;
+    for (long d = 0; d < ndocs; ++d) {
+        const int n = (int)(doc_off[d + 1] - doc_off[d]);
+        if (!bft_sp_stream(m, (const char *)text + doc_off[d], n, st, nullptr)) { lens[(size_t)d] = 0; continue; }
+        lens[(size_t)d] = (int32_t)st.size();
+        if ((int64_t)st.size() > (int64_t)mul * (n + 1)) return -6;
+        memcpy(stream.data() + (size_t)mul * (size_t)(doc_off[d] + d), st.data(), st.size() * 2);
+    }
+    unsigned long long next_doc = 0; int status = 0;
+    std::vector<uint32_t> scratch(6 * cells, 0xABABABABu);
+    BpeWaveParams p;
+    p.T = m.dict.t64.data(); p.info = (const SegInfo *)m.seg_info.data(); p.initial = m.dict.initial_base; p.cls_delim = m.sp_delim_code; p.id_offset = m.id_offset;
+    p.stream = stream.data(); p.lens = lens.data(); p.doc_off = doc_off; p.slot_mul = mul; p.ndocs = ndocs;
+    p.ids_tmp = tmp.data(); p.counts = counts.data(); p.flags = flags.data(); p.max_ids = max_ids; p.next_doc = &next_doc; p.status = &status; p.stats = stats; p.scratch = scratch.data();
+    if (cfg >= 16) { p.next_doc = nullptr; cfg -= 16; }
+    if (ndocs > 0) {
+        auto run = [&](auto *lds_tag) {
+            typedef typename std::remove_pointer<decltype(lds_tag)>::type LDS;
+            std::vector<LDS *> of_wave((size_t)nwaves);
+            for (int i = 0; i < nwaves; ++i) { of_wave[(size_t)i] = new LDS(); memset((void *)of_wave[(size_t)i], 0xA5, sizeof(LDS)); }
+            std::vector<const void *> wave_ids;
+            auto body = [&]() {
+                const void *wid = (const void *)wvemu::g_cur->wave;
+                size_t k = 0;
+                for (; k < wave_ids.size(); ++k) if (wave_ids[k] == wid) break;
+                if (k == wave_ids.size()) wave_ids.push_back(wid);
+                BpeWave<LDS> w(p, *of_wave[k]);
+                w.run(grab, (int)k, nwaves);
+            };
+            wvemu::run_waves(nwaves, body);
+            for (auto *q : of_wave) delete q;
+        };
+        if (cfg == 1) run((BwLds<1024, 128, 2> *)nullptr); else run((BwLds<1024, 256, 8> *)nullptr);
+    }
+    if (status) return -5;
+    long o = 0;
+    std::vector<int32_t> one((size_t)(max_ids > 0 ? max_ids : 1));
+    for (long d = 0; d < ndocs; ++d) {
+        id_off[d] = o;
+        if (counts[(size_t)d] < 0 || flags[(size_t)d] < 0) return -7;                 // a document the kernel never settled
+        if (flags_out) flags_out[d] = flags[(size_t)d];
+        int c = counts[(size_t)d];
+        const int32_t *src = tmp.data() + (size_t)mul * (size_t)(doc_off[d] + d);
+        if (flags[(size_t)d]) {                                                        // handed back: the lane-per-document path
+            c = bft_emu_sp_doc(m, (const char *)text + doc_off[d], (int)(doc_off[d + 1] - doc_off[d]), one.data(), max_ids, unk);
+            if (c < 0) return -8;
+            src = one.data();
+        }
+        if (o + c > ids_cap) return -9;
+        for (int k = 0; k < c; ++k) ids_out[o + k] = src[k];
         o += c;
     }
     id_off[ndocs] = o;

@@ -1,0 +1,104 @@
+"""CPU: the BPE wave program (blingfire_amd/csrc/bf_bpe_wave_body.h) in the 64-fibre wave simulator against the oracle: the class streams
+come from the scalar restatement of the _sp prologue, the documents the wave program hands back are redone by the sequential
+restatement of the lane-per-document path (as the device does), scan + compaction restated.  Checks both the ids and that ordinary text
+is NOT handed back (the point of the wave program)."""
+import ctypes
+import random
+
+import numpy as np
+import pytest
+
+import bfutil
+import blingfire_amd as bf
+
+MODELS = ["gpt2.bin", "bpe_example.bin", "bpe_example2.bin"]
+# (max_ids, unk, waves, documents per range, configuration: 0 = queue 256 / 8 open documents, 1 = queue 128 / 2 open documents; + 16 = no work counter)
+CONFS = [(512, 0, 1, 8, 0), (512, 3, 3, 2, 1), (7, 5, 2, 3, 16), (0, 0, 1, 8, 0), (2048, 0, 4, 8, 17), (1, 1, 2, 1, 1)]
+
+
+@pytest.fixture(scope="module")
+def ht():
+    L = ctypes.CDLL(bfutil.HOSTTEST_LIB)
+    L.bft_load.restype = ctypes.c_void_p
+    L.bft_load.argtypes = [ctypes.c_char_p]
+    L.bft_free.argtypes = [ctypes.c_void_p]
+    L.bft_bpe_wave_ok.argtypes = [ctypes.c_void_p]
+    L.bft_emu_bpe_wave_batch.restype = ctypes.c_long
+    L.bft_emu_bpe_wave_batch.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_long, ctypes.c_void_p, ctypes.c_long, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                         ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_long, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+    return L
+
+
+def run(ht, h, text, off, mx, unk, nw, grab, cfg):
+    nd = len(off) - 1
+    cap = 2 * len(text) + 2 * nd + 16
+    ids = np.full(cap, -9, dtype=np.int32)
+    ido = np.zeros(nd + 1, dtype=np.int64)
+    fl = np.zeros(nd + 1, dtype=np.int32)
+    st = np.zeros(16, dtype=np.uint64)
+    r = ht.bft_emu_bpe_wave_batch(h, text.ctypes.data, len(text), off.ctypes.data, nd, mx, unk, nw, grab, cfg, ids.ctypes.data, cap, ido.ctypes.data, fl.ctypes.data, st.ctypes.data)
+    return r, ids[:max(r, 0)], ido, fl[:nd], st
+
+
+def check(ht, model, docs, confs, max_back=None):
+    mp = bfutil.model_path(model)
+    h = ht.bft_load(mp.encode())
+    assert ht.bft_bpe_wave_ok(h) == 1
+    ora = bfutil.oracle()
+    ho = ora.load(mp)
+    text, off = docs if isinstance(docs, tuple) else bf.pack_docs(docs)
+    for (mx, unk, nw, grab, cfg) in confs:
+        r, ids, ido, fl, _ = run(ht, h, text, off, mx, unk, nw, grab, cfg)
+        gids, goff = ora.batch(ho, text, off, mx, unk)
+        assert r >= 0, (model, r)
+        if not (np.array_equal(ido, goff) and np.array_equal(ids, gids)):
+            for d in range(len(off) - 1):
+                a, b = ids[ido[d]:ido[d + 1]], gids[goff[d]:goff[d + 1]]
+                assert np.array_equal(a, b), (model, (mx, unk, nw, grab, cfg), d, int(fl[d]), bytes(text[off[d]:off[d + 1]])[:80], a.tolist()[:20], b.tolist()[:20])
+        if max_back is not None:
+            assert int(fl.sum()) <= max_back, (model, "documents handed back", int(fl.sum()), len(fl))
+    ora.free(ho)
+    ht.bft_free(h)
+
+
+def test_eligibility(ht):
+    for model, want in [("gpt2.bin", 1), ("bpe_example.bin", 1), ("bpe_example2.bin", 1), ("roberta.bin", 0), ("xlnet.bin", 0), ("bert_base_tok.bin", 0)]:
+        if not bfutil.have_model(model):
+            continue
+        h = ht.bft_load(bfutil.model_path(model).encode())
+        assert ht.bft_bpe_wave_ok(h) == want, model
+        ht.bft_free(h)
+
+
+def test_config3_corpus_is_not_handed_back(ht):
+    text, off = bfutil.gen_workload("config3", 400)
+    check(ht, "gpt2.bin", (text, off), CONFS[:3], max_back=40)          # words of more than 32 multi-element arcs: a few per hundred documents
+
+
+@pytest.mark.parametrize("model", MODELS)
+def test_adversarial_and_fuzz(ht, model):
+    if not bfutil.have_model(model):
+        pytest.skip("%s not present" % model)
+    check(ht, model, list(bfutil.ADVERSARIAL) + bfutil.fuzz_docs(800, seed=23), CONFS)
+
+
+@pytest.mark.parametrize("model", MODELS)
+def test_long_words_runs_and_tiny_documents(ht, model):
+    if not bfutil.have_model(model):
+        pytest.skip("%s not present" % model)
+    rnd = random.Random(9)
+    alpha = "abcdefghijklmnopqrstuvwxyz"
+    docs = []
+    for L in [1, 2, 7, 8, 9, 31, 61, 62, 63, 64, 65, 127, 300, 511, 512, 513, 1025]:
+        docs += [("a" * L).encode(), (" " + "b" * L + " c").encode(), "".join(rnd.choice(alpha) for _ in range(L)).encode(), ("-" * L).encode(),
+                 (" " * L).encode(), ("a " * L).encode(), ("the quick brown fox " * (L // 8 + 1)).encode(), ("▁" * (L % 40 + 1)).encode()]
+    docs += [bytes([rnd.randrange(32, 127)]) for _ in range(300)] + [b"", b" ", b"\xff", b"\xef\xbb\xbf", b"\xef\xbb\xbfhello world"]
+    docs.append(" ".join("".join(rnd.choice(alpha) for _ in range(rnd.randint(1, 12))) for _ in range(6000)).encode())       # ~40 KB
+    check(ht, model, docs, CONFS[:4])
+
+
+def test_multilingual_and_charmap_model(ht):
+    if not bfutil.have_model("bpe_example2.bin"):
+        pytest.skip("bpe_example2.bin not present")
+    check(ht, "bpe_example2.bin", bfutil.gen_corpus_multi(300), CONFS[:3])
+    check(ht, "bpe_example.bin", bfutil.gen_corpus_multi(300), CONFS[:3])

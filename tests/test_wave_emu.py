@@ -130,11 +130,7 @@ def test_documents_outside_the_buffer_and_empty_documents(ht):
 def test_wave_program_any_batch(ht):
     """property-based: batches of hypothesis-drawn documents (arbitrary Unicode, arbitrary bytes, long runs of one character) through the
     wave program in the simulator, with drawn max_ids / unk / number of waves / documents per range / configuration, against the oracle.
-    Documents are at least one byte long here: an EMPTY document as the last one of a range, with another range behind it, trips the
-    simulator's lock-step check -- the fibre that runs ahead stores the next range's offsets (S.doff) before the others have read the
-    empty document's; on the device the lanes of a wave execute that load before that store, in program order, so nothing can go wrong
-    there.  Found by this test; the hand-off (one wv::sync() before the store) goes in with the next change of the kernel sources, whose
-    hash the committed profiles are keyed by.  Empty documents elsewhere are covered by test_documents_outside_the_buffer_and_empty_documents."""
+    (This test found that an empty document at the end of a range needed a hand-off before the next range's offsets are stored.)"""
     from hypothesis import HealthCheck, given, settings, strategies as st
     model = bfutil.bert_model_name()
     mp = bfutil.model_path(model)
@@ -142,10 +138,10 @@ def test_wave_program_any_batch(ht):
     h = L.bft_load(mp.encode())
     ora = bfutil.oracle()
     ho = ora.load(mp)
-    text_st = st.text(alphabet=st.characters(blacklist_categories=("Cs",)), min_size=1, max_size=120).map(lambda t: t.encode("utf-8"))
+    text_st = st.text(alphabet=st.characters(blacklist_categories=("Cs",)), max_size=120).map(lambda t: t.encode("utf-8"))
     runs_st = st.lists(st.tuples(st.sampled_from(["a", " ", ".", "é", "中", "\U0001F600", "##", "ing", "​", "-", "[UNK]", "x" * 40]),
-                                 st.integers(min_value=1, max_value=90)), min_size=1, max_size=10).map(lambda xs: "".join(c * n for c, n in xs).encode("utf-8"))
-    bytes_st = st.binary(min_size=1, max_size=60)
+                                 st.integers(min_value=1, max_value=90)), max_size=10).map(lambda xs: "".join(c * n for c, n in xs).encode("utf-8"))
+    bytes_st = st.binary(max_size=60)
     docs_st = st.lists(st.one_of(text_st, runs_st, bytes_st), min_size=1, max_size=24)
 
     @settings(max_examples=120, deadline=None, suppress_health_check=list(HealthCheck))
