@@ -5,6 +5,7 @@
   oracle/libcpubaseline.so              TEST INFRA: multi-threaded driver that times a TextToIds .so on host cores
   tools/libcorpusgen.so                 TEST INFRA: deterministic synthetic corpus generator
   tools/single_calls                    TEST INFRA: native-thread harness for single-document calls through the C-ABI
+  tools/microbench/{stream,gather,valu_issue}  MEASUREMENT: counter calibration, gather ceiling, VALU / SALU issue rate
   tests/hosttest/libbf_hosttest.so      TEST INFRA: table-equivalence + host emulation of the lane programs
   oracle/_ref/libblingfiretokdll_ref.so TEST INFRA: the unmodified reference, only when /root/reference exists
 """
@@ -66,6 +67,12 @@ def build_test_infra(force=False):
     sc = os.path.join(ROOT, "tools", "single_calls")
     if force or _newer(sc, [os.path.join(ROOT, "tools", "single_calls.c")]):
         _run(["gcc", "-O2", "-Wall", "-o", "single_calls", "single_calls.c", "-ldl", "-lpthread"], cwd=os.path.join(ROOT, "tools"))
+    # microbenchmarks the evidence scripts run on the GPU box (counter calibration, gather ceiling, issue rate): binaries, not tracked
+    mb = os.path.join(ROOT, "tools", "microbench")
+    for name in ("stream", "gather", "valu_issue"):
+        src, out = os.path.join(mb, name + ".hip"), os.path.join(mb, name)
+        if os.path.exists(src) and (force or _newer(out, [src])):
+            _run([hipcc(), "--offload-arch=gfx950", "-O2", "-w", "-o", out, src])
     ht = os.path.join(ROOT, "tests", "hosttest", "libbf_hosttest.so")
     ht_src = [os.path.join(ROOT, "tests", "hosttest", "bf_hosttest.cpp"), os.path.join(ROOT, "tests", "hosttest", "bf_wavetest.cpp"), os.path.join(CSRC, "bf_model.cpp")]
     ht_dep = ht_src + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + [os.path.join(odir, "bf_oracle.c"),

@@ -298,9 +298,9 @@ bool use_wave(const Handle *h, bool want_off, int words)
     return h->m.kind == KIND_WP && h->m.wave_ok && !want_off && !words && (h->variant & 0xff) != 2;
 }
 
-// the BPE wave program (bf_bpe_wave_body.h) in front of the lane-per-document kernels: EXPERIMENTAL until it has had its GPU parity and
-// timing runs -- only with BfSetVariant bit 0x40
-bool use_bpe_wave(const Handle *h, bool want_off) { return h->m.bpe_wave_ok && !want_off && (h->variant & 0x40) != 0; }
+// the BPE wave program (bf_bpe_wave_body.h) in front of the lane-per-document kernels, for the models its load-time analysis admits
+// (Model::bpe_wave_ok); BfSetVariant bit 0x40 switches it off (A/B runs against the lane-per-document kernels alone)
+bool use_bpe_wave(const Handle *h, bool want_off) { return h->m.bpe_wave_ok && !want_off && (h->variant & 0x40) == 0; }
 
 bool reserve_ids_workspaces(Handle *h, int64_t ndocs, int64_t total_bytes, bool want_off, int words = 0)
 {
@@ -550,7 +550,7 @@ int64_t run_host_chunked(Handle *h, const char *text, const int64_t *doc_off, in
         if (!hip_ok(hipMemcpyAsync(P.pin_idoff[sl].p, P.dev_idoff[sl].p, (size_t)(nd + 1) * 8, hipMemcpyDeviceToHost, P.s_meta), "D2H offsets") ||
             !hip_ok(hipStreamSynchronize(P.s_meta), "hipStreamSynchronize")) return false;
         t_meta += now() - t0b;
-        if (P.pin_status.as<int>()[sl] & 2) { rc_err = BF_E_INTERNAL; return false; }
+        if (P.pin_status.as<int>()[sl] & (2 | BF_STATUS_INTERNAL)) { rc_err = BF_E_INTERNAL; return false; }
         const int64_t nids = P.pin_idoff[sl].as<int64_t>()[nd];
         nids_of[(size_t)j] = nids;
         if (nids > 0 && ids_out && nids <= ids_cap) {               // (a chunk larger than the whole capacity cannot be delivered anyway)
@@ -714,7 +714,7 @@ int64_t run_host(Handle *h, const char *text, const int64_t *doc_off, int64_t nd
     if (words && ndocs == 1 && !hip_ok(hipMemcpyAsync(&nch0, h->w_nchars.p, 4, hipMemcpyDeviceToHost, s), "D2H nchars")) return BF_E_DEVICE;
     if (!hip_ok(hipStreamSynchronize(s), "hipStreamSynchronize")) return BF_E_DEVICE;
     if (first_doc_nonempty) *first_doc_nonempty = nch0 > 0;
-    if (status & 2) return BF_E_INTERNAL;
+    if (status & (2 | BF_STATUS_INTERNAL)) return BF_E_INTERNAL;
     const int64_t nids = dst_off[ndocs];
     if (nids > ids_cap) return BF_E_CAPACITY;
     if (nids > 0) {
@@ -1561,6 +1561,7 @@ int SetNoDummyPrefix(void *p, bool flag)          /* reference signature: blingf
     if (!h) return 0;
     std::lock_guard<std::mutex> lock(h->mu);
     h->m.no_dummy_prefix = flag;
+    for (Handle *c : h->shards) if (c && c != h) { std::lock_guard<std::mutex> lc(c->mu); c->m.no_dummy_prefix = flag; }      // every range of a sharded batch sees the same setting
     return 1;
 }
 
@@ -1676,6 +1677,7 @@ int64_t BfSetHostChunkBytes(void *p, int64_t bytes)
     std::lock_guard<std::mutex> lock(h->mu);
     const int64_t old = h->host_chunk_bytes;
     h->host_chunk_bytes = bytes;
+    for (Handle *c : h->shards) if (c && c != h) { std::lock_guard<std::mutex> lc(c->mu); c->host_chunk_bytes = bytes; }
     return old;
 }
 
@@ -1724,7 +1726,9 @@ int BfSetVariant(void *p, int variant)
     Handle *h = as_handle(p);
     if (!h) return BF_E_ARG;
     std::lock_guard<std::mutex> lock(h->mu);
-    int old = h->variant; h->variant = variant; return old;
+    int old = h->variant; h->variant = variant;
+    for (Handle *c : h->shards) if (c && c != h) { std::lock_guard<std::mutex> lc(c->mu); c->variant = variant; }
+    return old;
 }
 
 /* experiments: switches the instrumented kernel instances on / off (what BF_LEX_STATS=1 at LoadModel does) and clears the counters */

@@ -111,19 +111,21 @@ def test_long_unknown_runs(model, checker):
 
 @pytest.mark.parametrize("model", [m for m in ("gpt2.bin", "bpe_example.bin", "bpe_example2.bin") if bfutil.have_model(m)])
 def test_bpe_wave_program_variant(model, checker):
-    """BfSetVariant bit 0x40: the BPE wave program (bf_bpe_wave_body.h) in front of the lane-per-document kernels, which redo the documents
-    it hands back -- same ids as the default path and as the CPU checker, on adversarial input, fuzz and the config-3 corpus"""
+    """The BPE wave program (bf_bpe_wave_body.h) is the default path of the models its load-time analysis admits; BfSetVariant bit 0x40
+    switches it off (the lane-per-document kernels alone).  Both give the ids of the CPU checker on adversarial input, fuzz and the
+    config-3 corpus"""
     h = bf.load_model(bfutil.model_path(model))
     hck = checker.load(bfutil.model_path(model))
     try:
-        bf.lib().BfSetVariant(h, 0x40)
         docs = list(bfutil.ADVERSARIAL) + bfutil.fuzz_docs(2500, seed=17)
-        for max_ids, unk in ((2048, 0), (3, 0), (64, 3), (1, 1), (2048, 262)):
-            _compare(h, checker, hck, docs, max_ids, unk)
         text, off = bfutil.gen_workload("config3", 20000)
-        ids, id_off = bf.text_to_ids_batch(h, (text, off), 2048, 0)
         gids, goff = checker.batch(hck, text, off, 2048, 0)
-        assert np.array_equal(id_off, goff) and np.array_equal(ids, gids)
+        for variant in (3, 3 | 0x40):
+            bf.lib().BfSetVariant(h, variant)
+            for max_ids, unk in ((2048, 0), (3, 0), (64, 3), (1, 1), (2048, 262)):
+                _compare(h, checker, hck, docs, max_ids, unk)
+            ids, id_off = bf.text_to_ids_batch(h, (text, off), 2048, 0)
+            assert np.array_equal(id_off, goff) and np.array_equal(ids, gids)
     finally:
         bf.free_model(h)
         checker.free(hck)

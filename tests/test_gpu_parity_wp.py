@@ -138,3 +138,24 @@ def test_wave_program_long_words_and_documents(checker):
         finally:
             bf.free_model(h)
             checker.free(hck)
+
+
+@pytest.mark.parametrize("workload", ["headline512", "config3"])
+def test_bench_generators_pinned_to_the_reference(workload):
+    """50 k documents of the generators bench.py times -- the metric's 512-byte corpus and config 3's 32-2048-byte mix -- through the
+    C-ABI: every id equals the compiled reference's (the oracle port when the reference binary is absent).  bench.py's verify gate
+    makes the same comparison on the whole shard; this pins it in the GPU tier as well."""
+    wl = bfutil.WORKLOADS[workload]
+    model = wl["model"] or bfutil.bert_model_name()
+    if not bfutil.have_model(model):
+        pytest.skip(model + " not present")
+    text, off = bfutil.gen_workload(workload, 50000)
+    lib_path, _ = bfutil.checker_lib_path()
+    _, gids, goff = bfutil.cpu_ids_compact(lib_path, bfutil.model_path(model), text, off, wl["max_ids"], wl["unk"])
+    h = bf.load_model(bfutil.model_path(model))
+    try:
+        ids, id_off = bf.text_to_ids_batch(h, (text, off), wl["max_ids"], wl["unk"])
+        assert np.array_equal(id_off, goff)
+        assert np.array_equal(ids, gids)
+    finally:
+        bf.free_model(h)

@@ -1,4 +1,4 @@
-"""Counters of the BPE wave program on the config-3 corpus (BF_LEX_STATS=1, variant bit 0x40): tools/bpe_wave_stats.py [ndocs]"""
+"""Counters of the BPE wave program on the config-3 corpus (BF_LEX_STATS=1): tools/bpe_wave_stats.py [ndocs]"""
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 os.environ["BF_LEX_STATS"] = "1"
@@ -6,7 +6,6 @@ import numpy as np, torch, bfutil, blingfire_amd as bf
 ndocs = int(sys.argv[1]) if len(sys.argv) > 1 else 200000
 text, off = bfutil.gen_workload("config3", ndocs)
 h = bf.load_model(bfutil.model_path("gpt2.bin"))
-bf.lib().BfSetVariant(h, 0x40)
 d_text = torch.from_numpy(text).cuda(); d_off = torch.from_numpy(off).cuda()
 bf.text_to_ids_batch_device(h, d_text, d_off, 2048, 0); torch.cuda.synchronize()
 out = (ctypes.c_ulonglong * 16)()
