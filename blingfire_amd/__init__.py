@@ -107,6 +107,8 @@ def lib():
         L.BfShardRanges.argtypes = [c_void_p, c_int64, c_int, c_void_p]
         L.BfSetLexStats.restype = c_int
         L.BfSetLexStats.argtypes = [c_void_p, c_int]
+        L.BfSetBpePoolBytes.restype = c_int64
+        L.BfSetBpePoolBytes.argtypes = [c_void_p, c_int64]
         L.BfReserve.restype = c_int
         L.BfReserve.argtypes = [c_void_p, c_int64, c_int64, c_int]
         L.NormalizeSpaces.restype = c_int

@@ -14,6 +14,8 @@ struct Batch {
     int *status;
 };
 constexpr int BF_STATUS_BAD_OFFSETS = 8;
+constexpr int BF_STATUS_DOC_FAILED = 32;   // a BPE document has no answer (the reference does not terminate on it, ..._bpe_t.h:299-313); its count is 0
+constexpr int BF_STATUS_POOL = 64;         // a BPE document's arcs did not fit the pool (bf_bpe_seg_body.h); its count is 0, the need is added up for the host
 constexpr int BF_STATUS_INTERNAL = 16;   // a kernel met a state its load-time checks exclude (results of the batch are not to be trusted)
 
 // code point map (TwoLevelMap on the device)

@@ -7,6 +7,7 @@ namespace bfa {
 
 struct BpeWaveParams {
     const uint64_t *T; const SegInfo *info; uint32_t initial, cls_delim; int id_offset;
+    const uint32_t *prio; const int32_t *place_id;   // with merge ranks (bf_model.h bpe_prio / bpe_place_id): the arcs are ordered by the entry's place in "rank descending, id ascending"; nullptr: by id
     const uint16_t *stream; const int32_t *lens; const int64_t *doc_off; int slot_mul; int64_t ndocs;
     int32_t *ids_tmp; int32_t *counts; int32_t *flags; int max_ids; unsigned long long *next_doc; int *status;
     uint32_t *scratch;               // 6 words per stream cell (the batch's arc workspace): the arcs of a word with more than 64 of them (unit_huge)

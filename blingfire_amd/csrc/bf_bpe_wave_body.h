@@ -76,6 +76,9 @@ struct BpeWave {
         slot = 0; n = 0; rbase = 0; dec = done = 0; open_start = -1; curk = 0; fall = false;
     }
     BF_WVD int ring_free() const { return RING - (int)(rhi - rlo); }
+    // what orders the arcs (:238-255; with merges ..._with_merges_t.h:242-262): the id, or the entry's place in the order by rank
+    BF_WVD int32_t order_of(uint32_t mph) const { return p.prio ? (int32_t)(p.prio[mph] >> 1) : p.info[mph].id; }
+    BF_WVD int id_of_order(int o) const { return p.place_id ? p.place_id[o] : o; }
 
     // ------------------------------------------------------------------------------------------------------------------
     // fill
@@ -300,7 +303,7 @@ struct BpeWave {
                     seen = true;
                     if (j == s0) single |= 1ull << s0;
                     else {
-                        const int32_t id = p.info[sum].id;
+                        const int32_t id = order_of((uint32_t)sum);
                         if (n >= cap || (uint32_t)id >= (1u << BPE_LOCAL_ID_BITS_W)) { give_up = true; break; }
                         buf[n++] = ((uint32_t)id << 12) | ((uint32_t)s0 << 6) | (uint32_t)j;
                     }
@@ -331,7 +334,7 @@ struct BpeWave {
         for (int pos = 0; pos < u.L;) {                                  // :299-313
             const uint32_t v = res[pos];
             int id, end = pos;
-            if (v != 0xFFFFFFFFu) { id = (int)(v >> 6); end = (int)(v & 63u); }
+            if (v != 0xFFFFFFFFu) { id = id_of_order((int)(v >> 6)); end = (int)(v & 63u); }
             else {
                 if (!((single >> pos) & 1ull)) { bad = true; break; }
                 const uint32_t c = (uint32_t)S.ring[(u.rs + (uint32_t)pos) & RMASK];
@@ -404,7 +407,7 @@ struct BpeWave {
 #pragma unroll
             for (int k = 0; k < 8; ++k) key[k] = a0 + k < na ? S.win[(a0 + k) * 64 + lane] : 0u;
 #pragma unroll
-            for (int k = 0; k < 8; ++k) id[k] = p.info[a0 + k < na ? (key[k] >> 12) : 0u].id;
+            for (int k = 0; k < 8; ++k) id[k] = order_of(a0 + k < na ? (key[k] >> 12) : 0u);
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
                 if (a0 + k < na && (uint32_t)id[k] >= (1u << BPE_LOCAL_ID_BITS_W)) bigid = true;
@@ -450,7 +453,7 @@ struct BpeWave {
                 const uint32_t c = (uint32_t)S.ring[(u.rs + (uint32_t)pos) & RMASK];
                 const uint64_t e1 = p.T[p.initial + c];
                 id = p.info[(int)(e1 >> SG_OW_SHIFT)].id;
-            }
+            } else id = id_of_order(id);
             if (cnt == 0) first = id + p.id_offset; else { if (cnt == 1) home[0] = first; home[cnt] = id + p.id_offset; }
             ++cnt;
             pos = end + 1;
@@ -473,7 +476,7 @@ struct BpeWave {
             uint32_t key = 0xFFFFFFFFu;
             if (lane < na) key = *slot;
             int32_t id = 0;
-            if (lane < na) id = p.info[key >> 12].id;
+            if (lane < na) id = order_of(key >> 12);
             const bool bigid = lane < na && (uint32_t)id >= (1u << BPE_LOCAL_ID_BITS_W);
             if (wv::any(bigid)) { if (lane == o) unit_fallback(u, 4); wv::sync(); continue; }
             if (lane < na) key = ((uint32_t)id << 12) | (key & 0xFFFu);
@@ -489,7 +492,7 @@ struct BpeWave {
                 const int s = (int)((kr >> 6) & 63u), e = (int)(kr & 63u);
                 if (!((inter >> s) & 1ull) && !((inter >> (e + 1)) & 1ull)) {
                     if (e > s) inter |= ((1ull << (e + 1)) - 1ull) & ~((1ull << (s + 1)) - 1ull);
-                    if (lane == s) my_id = (int)(kr >> 12);             // the last applied arc of a start stays (:291-292)
+                    if (lane == s) my_id = id_of_order((int)(kr >> 12));   // the last applied arc of a start stays (:291-292)
                 }
             }
             const bool is_tok = lane < L && !((inter >> lane) & 1ull);   // :299-313: the non-interior positions, lane = position

@@ -152,8 +152,10 @@ struct Handle {
     bool dict_ready = false;
     DevBuf w_keys, w_keyoff, w_dids, w_dret, w_vals;              // DictGetInfoBatch staging
     DevBuf w_s1, w_s2, w_s3, w_s4, w_perm, w_hist, w_narcs;      // _sp scratch
-    DevBuf w_bwflags, w_bwlens, w_bwcounts;                     // BPE wave program: documents handed back, and the masked lengths / counts of the pass that redoes them
-    DevBuf w_big;                                                // BPE: pool of the documents beyond the per-document arc reserve (k_bpe_big)
+    DevBuf w_bwflags;                                            // BPE wave program: documents handed back
+    DevBuf w_big;                                                // BPE: pool of the documents beyond the per-document arc reserve (k_bpe_seg)
+    size_t bpe_pool_bytes = (size_t)64 << 20;                    // its size (BfSetBpePoolBytes; the host-buffer calls grow it when a batch needs more)
+    DevBuf t_bpe_prio, t_bpe_place;                              // BPE with merges: the arc order as integers (bf_model.h bpe_prio / bpe_place_id)
     // workspaces
     DevBuf w_cls, w_nchars, w_tmp, w_counts, w_bsums, w_misc, w_flags, w_out, w_outoff;   // w_misc: [0] next_doc (u64), [2] status (int)
     DevBuf w_text, w_docoff, w_ids, w_idoff, w_starts, w_ends;  // host-API staging
@@ -180,7 +182,7 @@ struct Handle {
         for (Handle *c : shards) if (c && c != this) { DeviceGuard dg(c->device); (void)hipDeviceSynchronize(); delete c; }
         shards.clear();
         pipe.release(); m_small.release();
-        for (DevBuf *b : {&t_dk_l1, &t_dk_pages, &t_dn_l1, &t_dn_pages, &t_dn_pool, &t_k2i, &t_rows, &w_keys, &w_keyoff, &w_dids, &w_dret, &w_vals, &t_i2w_off, &t_i2w_data, &t_kind, &t_wbd, &t_info, &t_acts, &t_cp_l1, &t_cp_pages, &t_multi, &t_wcp_l1, &t_wcp_pages, &t_dict, &t_seginfo, &w_s1, &w_s2, &w_s3, &w_s4, &w_big, &w_perm, &w_hist, &w_narcs, &w_bwflags, &w_bwlens, &w_bwcounts, &w_cls, &w_nchars, &w_tmp, &w_counts, &w_flags, &w_out, &w_outoff,
+        for (DevBuf *b : {&t_bpe_prio, &t_bpe_place, &t_dk_l1, &t_dk_pages, &t_dn_l1, &t_dn_pages, &t_dn_pool, &t_k2i, &t_rows, &w_keys, &w_keyoff, &w_dids, &w_dret, &w_vals, &t_i2w_off, &t_i2w_data, &t_kind, &t_wbd, &t_info, &t_acts, &t_cp_l1, &t_cp_pages, &t_multi, &t_wcp_l1, &t_wcp_pages, &t_dict, &t_seginfo, &w_s1, &w_s2, &w_s3, &w_s4, &w_big, &w_perm, &w_hist, &w_narcs, &w_bwflags, &w_cls, &w_nchars, &w_tmp, &w_counts, &w_flags, &w_out, &w_outoff,
                           &w_bsums, &w_misc, &w_text, &w_docoff, &w_ids, &w_idoff, &w_starts, &w_ends, &w_srcoff, &w_span}) b->release();
         for (auto &e : ev) if (e) (void)hipEventDestroy(e);
         if (stream) (void)hipStreamDestroy(stream);
@@ -275,6 +277,7 @@ Handle *make_handle(const uint8_t *img, size_t size)
     } else if (m.kind != KIND_I2W) {
         ok = ok && upload(h->t_dict, m.dict.t64, 16) && upload(h->t_seginfo, m.seg_info, 16) &&
              upload(h->t_cp_l1, m.sp_cpmap.l1) && upload(h->t_cp_pages, m.sp_cpmap.pages) && upload(h->t_multi, m.sp_multi_pool, 16);
+        if (m.kind == KIND_BPE_MERGES) ok = ok && upload(h->t_bpe_prio, m.bpe_prio, 16) && upload(h->t_bpe_place, m.bpe_place_id, 16);
     }
     if (m.has_i2w) ok = ok && upload(h->t_i2w_off, m.i2w_off, 4) && upload(h->t_i2w_data, m.i2w_data, 16);
     ok = ok && hip_ok(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking), "hipStreamCreate");
@@ -288,7 +291,6 @@ Handle *make_handle(const uint8_t *img, size_t size)
 bool uni_lane_ok(const Model &m) { return m.trie_max_depth > 0 && m.trie_max_depth <= 32 && m.max_info_id <= UNI_MAX_ID; }
 
 // Workspaces of the TextToIds pipeline for a batch of ndocs documents / total_bytes bytes (grow-only; see DevBuf::reserve).
-constexpr size_t BPE_BIG_POOL_BYTES = (size_t)64 << 20;       // per batch; a document of L elements takes <= 16 * (its arcs) + 9 * L bytes of it
 
 // The WordPiece path of a unit-form lexer (every BERT model) is the wave program of bf_wave.h: ids only.  The offsets API and the
 // TextToWords forms, and lexers outside the unit form, take the lane-per-document kernels (bf_lex.h).  Variant 2 (experiments, A/B):
@@ -324,9 +326,9 @@ bool reserve_ids_workspaces(Handle *h, int64_t ndocs, int64_t total_bytes, bool 
     } else {
         const size_t bm_words = (cap >> 5) + (size_t)ndocs + 4;
         if (!h->w_s1.reserve((6 * cap + 32 * (size_t)ndocs + 64) * 16) || !h->w_s2.reserve(std::max(cap * 4, 2 * bm_words * 4) + ((size_t)ndocs + 16) * 4) ||
-            !h->w_s3.reserve(cap * 4) || !h->w_s4.reserve(cap) || !h->w_big.reserve(BPE_BIG_POOL_BYTES)) return false;
+            !h->w_s3.reserve(cap * 4) || !h->w_s4.reserve(cap) || !h->w_big.reserve(h->bpe_pool_bytes)) return false;
     }
-    if (use_bpe_wave(h, want_off) && !(h->w_bwflags.reserve((size_t)(ndocs + 1) * 4) && h->w_bwlens.reserve((size_t)(ndocs + 1) * 4) && h->w_bwcounts.reserve((size_t)(ndocs + 1) * 4))) return false;
+    if (use_bpe_wave(h, want_off) && !h->w_bwflags.reserve((size_t)(ndocs + 1) * 4)) return false;
     return h->w_perm.reserve((size_t)(ndocs + 1) * 4) && h->w_hist.reserve(2048 * 4) && h->w_narcs.reserve((size_t)(ndocs + 1) * 4);
 }
 
@@ -404,12 +406,16 @@ int run_device(Handle *h, const char *d_text, const int64_t *d_doc_off, int64_t 
         sg.ids_tmp = h->w_tmp.as<int32_t>(); sg.counts = h->w_counts.as<int32_t>(); sg.span_tmp = want_off ? h->w_span.as<int32_t>() : nullptr; sg.max_ids = max_ids; sg.unk = unk; sg.status = status;
         sg.best = nullptr; sg.arcs = nullptr; sg.tos = nullptr; sg.idsv = nullptr; sg.inter = nullptr; sg.bm_words = 0; sg.fb_list = nullptr; sg.fb_count = nullptr;
         sg.big_pool = nullptr; sg.big_cap = 0; sg.big_used = (unsigned long long *)(h->w_misc.as<char>() + 32);     // zeroed with the status word above
+        sg.big_need = (unsigned long long *)(h->w_misc.as<char>() + 40);
+        sg.bpe_prio = nullptr; sg.bpe_place_id = nullptr; sg.bpe_unk_prio = 0; sg.bpe_prio_bits = m.bpe_prio_bits; sg.seg_stats = nullptr;
         if (m.kind == KIND_UNIGRAM) sg.best = h->w_s1.as<SegBest>();
         else {
             const size_t bm_words = (cap >> 5) + (size_t)ndocs + 4;         // per bitmap: capacity + 1 bits per document (k_bpe_apply_flat)
             sg.bm_words = (int64_t)bm_words;
             sg.arcs = h->w_s1.as<SegArc>(); sg.tos = h->w_s2.as<int32_t>(); sg.idsv = h->w_s3.as<int32_t>(); sg.inter = h->w_s4.as<uint8_t>();
-            sg.big_pool = h->w_big.as<uint8_t>(); sg.big_cap = BPE_BIG_POOL_BYTES;
+            sg.big_pool = h->w_big.as<uint8_t>(); sg.big_cap = h->w_big.cap;
+            if (m.kind == KIND_BPE_MERGES) { sg.bpe_prio = h->t_bpe_prio.as<uint32_t>(); sg.bpe_place_id = h->t_bpe_place.as<int32_t>(); }
+            sg.bpe_unk_prio = bpe_unk_prio(m, unk);
         }
         sg.narcs = h->w_narcs.as<int32_t>(); sg.next_doc = next_doc; sg.trie_depth = m.trie_max_depth; sg.variant = h->variant & 0xff; sg.tune = (h->variant >> 8) & 0xff; sg.tune2 = (h->variant >> 16) & 0xff;
         sg.lane_ok = uni_lane_ok(m) ? 1 : 0;
@@ -418,18 +424,15 @@ int run_device(Handle *h, const char *d_text, const int64_t *d_doc_off, int64_t 
         const bool bwave = use_bpe_wave(h, want_off);
         if (bwave && ndocs > 0) {
             // words that are one vocabulary entry (most are) and short words that are not: the wave program; the documents it hands back
-            // (flags): the lane-per-document kernels below, for which every other document has length 0
+            // (flags: a word of more than 62 elements, a symbol outside the alphabet, ...): one wave per document (bf_bpe_seg_body.h)
             BpeWaveParams bw;
             bw.T = sg.S.T; bw.info = sg.S.info; bw.initial = sg.S.initial; bw.cls_delim = sg.S.cls_delim; bw.id_offset = sg.S.id_offset;
+            bw.prio = sg.bpe_prio; bw.place_id = sg.bpe_place_id;
             bw.stream = sg.stream; bw.lens = sg.lens; bw.doc_off = b.doc_off; bw.slot_mul = mul; bw.ndocs = ndocs;
             bw.ids_tmp = sg.ids_tmp; bw.counts = sg.counts; bw.flags = h->w_bwflags.as<int32_t>(); bw.max_ids = max_ids; bw.next_doc = next_doc; bw.status = status; bw.scratch = (uint32_t *)sg.arcs; bw.stats = h->lex_stats ? (unsigned long long *)(h->w_misc.as<char>() + 64) : nullptr;
             launch_bpe_wave(bw, s);
-            (void)hipMemsetAsync(next_doc, 0, sizeof(unsigned long long), s);
-            launch_bpe_wave_mask(sg.lens, bw.flags, h->w_bwlens.as<int32_t>(), ndocs, bw.stats, s);
-            sg.lens = h->w_bwlens.as<int32_t>(); sg.counts = h->w_bwcounts.as<int32_t>();
-        }
-        if (ndocs > 0) launch_seg_sp(sg, s);
-        if (bwave && ndocs > 0) launch_bpe_wave_merge(h->w_counts.as<int32_t>(), h->w_bwcounts.as<int32_t>(), h->w_bwflags.as<int32_t>(), ndocs, s);
+            launch_bpe_seg_flags(sg, bw.flags, h->w_perm.as<int32_t>(), h->w_hist.as<unsigned int>(), s);
+        } else if (ndocs > 0) launch_seg_sp(sg, s);
         (void)hipEventRecord(h->ev[EV_TOK], s);
     }
     ScanParams sp{h->w_counts.as<int32_t>(), ndocs, d_id_off, h->w_bsums.as<int64_t>(), nblocks};
@@ -463,6 +466,7 @@ void par_memcpy(void *dst, const void *src, size_t n)
     for (auto &x : th) x.join();
 }
 
+constexpr int64_t BF_RETRY_POOL = INT64_MIN + 1;            // internal: a BPE document did not fit the arc pool (BF_STATUS_POOL); the need is in w_misc
 constexpr int64_t HOST_PIPE_UNAVAILABLE = INT64_MIN;      // run_host_chunked could not set up its staging: the caller takes the one-copy path
 
 // The chunked form of run_host (ids only).  Same results as one TextToIdsBatchDevice call over the whole batch: documents are
@@ -551,6 +555,7 @@ int64_t run_host_chunked(Handle *h, const char *text, const int64_t *doc_off, in
             !hip_ok(hipStreamSynchronize(P.s_meta), "hipStreamSynchronize")) return false;
         t_meta += now() - t0b;
         if (P.pin_status.as<int>()[sl] & (2 | BF_STATUS_INTERNAL)) { rc_err = BF_E_INTERNAL; return false; }
+        if (P.pin_status.as<int>()[sl] & BF_STATUS_POOL) { rc_err = BF_RETRY_POOL; return false; }     // run_host grows the pool and runs the batch again
         const int64_t nids = P.pin_idoff[sl].as<int64_t>()[nd];
         nids_of[(size_t)j] = nids;
         if (nids > 0 && ids_out && nids <= ids_cap) {               // (a chunk larger than the whole capacity cannot be delivered anyway)
@@ -671,17 +676,39 @@ int64_t run_host_mapped(Handle *h, const char *text, const int64_t *doc_off, int
     return n;
 }
 
+int64_t run_host_locked(Handle *h, const char *text, const int64_t *doc_off, int64_t ndocs, int32_t *ids_out, int64_t ids_cap,
+                        int64_t *id_off_out, int max_ids, int unk, int32_t *starts_out, int32_t *ends_out, int words, bool *first_doc_nonempty);
+
 int64_t run_host(Handle *h, const char *text, const int64_t *doc_off, int64_t ndocs, int32_t *ids_out, int64_t ids_cap,
                  int64_t *id_off_out, int max_ids, int unk, int32_t *starts_out = nullptr, int32_t *ends_out = nullptr, int words = 0,
                  bool *first_doc_nonempty = nullptr /* words modes: the first document decoded to >= 1 character */)
 {
-    const bool want_off = starts_out && ends_out;
     if (ndocs < 0 || !doc_off || (ndocs > 0 && !text && doc_off[ndocs] > doc_off[0])) return BF_E_ARG;
-    const int64_t base = doc_off[0];
-    const int64_t total = ndocs > 0 ? doc_off[ndocs] - base : 0;
-    if (total < 0) return BF_E_ARG;
+    if (ndocs > 0 && doc_off[ndocs] - doc_off[0] < 0) return BF_E_ARG;
     std::lock_guard<std::mutex> lock(h->mu);
     DeviceGuard dg(h->device); if (!dg.ok) return BF_E_DEVICE;
+    // A BPE document whose arcs do not fit the pool costs that document only (count 0, BF_STATUS_POOL) -- a caller of the host-buffer
+    // API never sees it: the pool grows by what did not fit and the batch runs again (the reference collects into an unbounded
+    // std::vector, ..._bpe_t.h:143-144)
+    for (int attempt = 0; attempt < 8; ++attempt) {
+        const int64_t r = run_host_locked(h, text, doc_off, ndocs, ids_out, ids_cap, id_off_out, max_ids, unk, starts_out, ends_out, words, first_doc_nonempty);
+        if (r != BF_RETRY_POOL) return r;
+        (void)hipDeviceSynchronize();
+        unsigned long long need = 0;
+        if (!hip_ok(hipMemcpy(&need, h->w_misc.as<char>() + 40, 8, hipMemcpyDeviceToHost), "D2H pool need")) return BF_E_DEVICE;
+        const size_t want = std::max(h->w_big.cap * 2, h->w_big.cap + (size_t)need + (size_t)(need >> 2) + ((size_t)1 << 20));
+        h->bpe_pool_bytes = want;
+        if (!h->w_big.reserve(want)) { g_last_error = "the arc pool of a BPE document does not fit the device memory"; return BF_E_DEVICE; }
+    }
+    g_last_error = "BPE arc pool: still too small after eight rounds of growing"; return BF_E_INTERNAL;
+}
+
+int64_t run_host_locked(Handle *h, const char *text, const int64_t *doc_off, int64_t ndocs, int32_t *ids_out, int64_t ids_cap,
+                        int64_t *id_off_out, int max_ids, int unk, int32_t *starts_out, int32_t *ends_out, int words, bool *first_doc_nonempty)
+{
+    const bool want_off = starts_out && ends_out;
+    const int64_t base = doc_off[0];
+    const int64_t total = ndocs > 0 ? doc_off[ndocs] - base : 0;
     hipStream_t s = h->stream;
     if (ndocs >= 1 && ndocs <= SMALL_MAX_DOCS && total <= SMALL_MAX_BYTES && use_wave(h, want_off, words) && small_ready(h))
         return run_host_mapped(h, text, doc_off, ndocs, ids_out, ids_cap, id_off_out, max_ids, unk);
@@ -715,6 +742,7 @@ int64_t run_host(Handle *h, const char *text, const int64_t *doc_off, int64_t nd
     if (!hip_ok(hipStreamSynchronize(s), "hipStreamSynchronize")) return BF_E_DEVICE;
     if (first_doc_nonempty) *first_doc_nonempty = nch0 > 0;
     if (status & (2 | BF_STATUS_INTERNAL)) return BF_E_INTERNAL;
+    if (status & BF_STATUS_POOL) return BF_RETRY_POOL;
     const int64_t nids = dst_off[ndocs];
     if (nids > ids_cap) return BF_E_CAPACITY;
     if (nids > 0) {
@@ -1668,6 +1696,17 @@ int BfLastKernelMs(void *p, float *ms, int n)
     int k = n < 5 ? n : 5;
     for (int i = 0; i < k; ++i) ms[i] = v[i];
     return k;
+}
+
+int64_t BfSetBpePoolBytes(void *p, int64_t bytes)
+{
+    Handle *h = as_handle(p);
+    if (!h || bytes < 0) return BF_E_ARG;
+    std::lock_guard<std::mutex> lock(h->mu);
+    const int64_t old = (int64_t)h->bpe_pool_bytes;
+    h->bpe_pool_bytes = (size_t)bytes;
+    for (Handle *c : h->shards) if (c && c != h) { std::lock_guard<std::mutex> lc(c->mu); c->bpe_pool_bytes = (size_t)bytes; }
+    return old;
 }
 
 int64_t BfSetHostChunkBytes(void *p, int64_t bytes)

@@ -74,7 +74,9 @@ struct SpSegParams {
     int lane_ok;                // Unigram: the model fits the lane program (bf_seg.h UniLane: entries <= 32 symbols, ids < 2^20 - 2)
     int64_t bm_words;           // BPE apply: words per bitmap (the two bitmaps live in the `tos` buffer)
     int32_t *fb_list; unsigned int *fb_count;   // BPE: documents k_bpe_fused hands to the full path (set by launch_seg_sp)
-    uint8_t *big_pool; unsigned long long big_cap; unsigned long long *big_used;   // BPE: pool of the documents whose arcs exceed the per-document reserve (k_bpe_big)
+    uint8_t *big_pool; unsigned long long big_cap; unsigned long long *big_used, *big_need;   // BPE: pool of the documents whose arcs exceed the per-document reserve (k_bpe_seg); *big_need: bytes that did not fit
+    const uint32_t *bpe_prio; const int32_t *bpe_place_id; uint32_t bpe_unk_prio; int bpe_prio_bits;   // bf_bpe_seg_body.h: the arc order as integers (bf_model.h)
+    unsigned long long *seg_stats;   // optional (experiments): counters of k_bpe_seg
     int variant;
     int tune;                   // experiments: vote threshold of the lane-local BPE solve / Unigram transitions per trip (0 = default)
     int tune2;                  // experiments: resident waves per CU of the persistent segmenter kernels (0 = what fits)
@@ -110,8 +112,7 @@ void launch_prep_wp(const WpPrepParams &p, int64_t total_bytes, unsigned long lo
 void launch_lex_wp(const WpLexParams &p, int variant, hipStream_t s);
 void launch_wp_wave(const WpWaveParams &p, int variant, hipStream_t s);     // unit-form lexers (bf_wave.h): replaces prep + lexer
 void launch_bpe_wave(const BpeWaveParams &p, hipStream_t s);                  // bpe-opt models (bf_bpe_wave_body.h)
-void launch_bpe_wave_mask(const int32_t *lens, const int32_t *flags, int32_t *lens2, int64_t ndocs, unsigned long long *stats, hipStream_t s);
-void launch_bpe_wave_merge(int32_t *counts, const int32_t *counts2, const int32_t *flags, int64_t ndocs, hipStream_t s);
+void launch_bpe_seg_flags(const SpSegParams &p, const int32_t *flags, int32_t *list, unsigned int *count, hipStream_t s);   // the documents it hands back: bf_bpe_seg_body.h
 void launch_prep_sp(const SpPrepParams &p, hipStream_t s);
 void launch_seg_sp(const SpSegParams &p, hipStream_t s);
 void launch_scan(const ScanParams &p, hipStream_t s);

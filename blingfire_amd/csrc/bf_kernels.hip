@@ -683,6 +683,11 @@ __device__ __forceinline__ unsigned long long atomic_add(unsigned long long *p, 
 __device__ __forceinline__ void atomic_or(int *p, int v) { atomicOr(p, v); }
 __device__ __forceinline__ void lds_or(uint32_t *p, uint32_t v) { atomicOr(p, v); }      // a word in LDS, from divergent lanes
 __device__ __forceinline__ unsigned long long clock() { return __builtin_readcyclecounter(); }
+// a word that other lanes of the wave update with atomics (executed in the L2): read past the CU's vector cache
+__device__ __forceinline__ uint32_t load_l2(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void atomic_or_u32(uint32_t *p, uint32_t v) { atomicOr(p, v); }
+__device__ __forceinline__ void atomic_max_u32(uint32_t *p, uint32_t v) { atomicMax(p, v); }
+__device__ __forceinline__ void lds_add(uint32_t *p, uint32_t v) { atomicAdd(p, v); }
 __device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 // a wave-uniform value the compiler may not trace back to where it came from (it then lives in a scalar register of its own)
@@ -775,32 +780,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
     __shared__ LDS lds[4];
     BpeWave<LDS> w(p, lds[wave_in_block()]);
     w.run(grab, (int)(blockIdx.x * 4) + wave_in_block(), (int)(gridDim.x * 4));
-}
-
-// around the lane-per-document pass that redoes the documents the wave program handed back: before it, a document that is done
-// gets length 0 in a copy of the lengths (the lane kernels skip it and write their 0 into a copy of the counts); after it, the counts
-// of the handed-back documents are taken over
-__global__ __launch_bounds__(256) void k_bpe_wave_mask(const int32_t *lens, const int32_t *flags, int32_t *lens2, int64_t ndocs, unsigned long long *stats)
-{
-    const int64_t d = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (d < ndocs) {
-        lens2[d] = flags[d] ? lens[d] : 0;
-        if (stats && flags[d]) atomicAdd(&stats[13], 1ull);            // experiments: documents the lane kernels are asked to redo
-        if (stats && flags[d] && lens[d] > 0) atomicAdd(&stats[14], 1ull);
-    }
-}
-__global__ __launch_bounds__(256) void k_bpe_wave_merge(int32_t *counts, const int32_t *counts2, const int32_t *flags, int64_t ndocs)
-{
-    const int64_t d = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (d < ndocs && flags[d]) counts[d] = counts2[d];
-}
-void launch_bpe_wave_mask(const int32_t *lens, const int32_t *flags, int32_t *lens2, int64_t ndocs, unsigned long long *stats, hipStream_t s)
-{
-    if (ndocs > 0) hipLaunchKernelGGL(k_bpe_wave_mask, dim3((unsigned)((ndocs + 255) / 256)), dim3(256), 0, s, lens, flags, lens2, ndocs, stats);
-}
-void launch_bpe_wave_merge(int32_t *counts, const int32_t *counts2, const int32_t *flags, int64_t ndocs, hipStream_t s)
-{
-    if (ndocs > 0) hipLaunchKernelGGL(k_bpe_wave_merge, dim3((unsigned)((ndocs + 255) / 256)), dim3(256), 0, s, counts, counts2, flags, ndocs);
 }
 
 void launch_bpe_wave(const BpeWaveParams &p, hipStream_t s)
@@ -1775,32 +1754,52 @@ __global__ __launch_bounds__(64) void k_seg_unigram_lane(SpSegParams p, int ring
 }
 
 // BPE, documents whose arcs exceed the per-document reserve (narcs == -1 on the fallback list; a long run of one character whose
-// run-length tokens are all in the vocabulary): the plain sequential program per lane (bf_seg.h seg_bpe_doc_big, the same code the
-// host tests run against the oracle), arcs and work arrays claimed from a pool shared by the batch.  Rare and slow by design; a
-// pool that runs out is the loud error the reserve used to be.
-struct BigClaim {
-    uint8_t *pool; unsigned long long cap; unsigned long long *used;
-    __device__ uint8_t *operator()(size_t bytes)
-    {
-        const unsigned long long at = atomicAdd(used, (unsigned long long)bytes);
-        return at + bytes <= cap ? pool + at : nullptr;
-    }
-};
+// run-length tokens are all in the vocabulary): one wave per document, every step wave-cooperative, arcs in a block claimed from the
+// batch's pool at its exact size (bf_bpe_seg_body.h; the same source runs in the test simulator against the oracle).  A pool that
+// runs out costs the document (count 0, BF_STATUS_POOL), not the batch; the host grows the pool and runs the batch again.
+} // namespace bfa
+#include "bf_bpe_seg_body.h"
+namespace bfa {
 
-__global__ __launch_bounds__(64) void k_bpe_big(SpSegParams p)
+__global__ __launch_bounds__(64) void k_bpe_seg(BpeSegParams p)
 {
-    const unsigned int nfb = *p.fb_count;
-    for (unsigned int idx = blockIdx.x * 64u + threadIdx.x; idx < nfb; idx += gridDim.x * 64u) {
-        const int64_t d = p.fb_list[idx];
-        if (p.narcs[d] != -1) continue;
-        const int64_t slot = sp_slot(p.b.doc_off[d], d, p.slot_mul);
-        ClsWin cls_at; cls_at.init(p.stream, slot);
-        IdOutDirect out{p.ids_tmp + slot, p.span_tmp ? p.span_tmp + 2 * slot : nullptr};
-        BigClaim claim{p.big_pool, p.big_cap, p.big_used};
-        int r = seg_bpe_doc_big(p.S, cls_at, p.lens[d], claim, out, p.max_ids, p.unk);
-        if (r < 0) { atomicOr(p.status, 2); r = 0; }
-        p.counts[d] = r;
-    }
+    __shared__ BsLds lds;
+    BpeSeg<BsLds> w(p, lds);
+    w.run();
+}
+
+static BpeSegParams bpe_seg_params(const SpSegParams &p)
+{
+    BpeSegParams q;
+    q.T = p.S.T; q.info = p.S.info; q.initial = p.S.initial; q.cls_delim = p.S.cls_delim; q.id_offset = p.S.id_offset; q.kind = p.S.kind;
+    q.prio = p.bpe_prio; q.place_id = p.bpe_place_id; q.unk_prio = p.bpe_unk_prio; q.prio_bits = p.bpe_prio_bits;
+    q.stream = p.stream; q.lens = p.lens; q.doc_off = p.b.doc_off; q.slot_mul = p.slot_mul;
+    q.list = p.fb_list; q.list_n = p.fb_count; q.narcs = p.narcs; q.narcs_want = -1; q.ndocs = p.b.ndocs;
+    q.ids_tmp = p.ids_tmp; q.span_tmp = p.span_tmp; q.counts = p.counts; q.max_ids = p.max_ids; q.unk = p.unk;
+    q.next_doc = p.next_doc; q.status = p.status;
+    q.pool = p.big_pool; q.pool_bytes = p.big_cap; q.pool_used = p.big_used; q.pool_need = p.big_need; q.stats = p.seg_stats;
+    return q;
+}
+
+// the documents the BPE wave program handed back (flags[d] != 0) as a list for k_bpe_seg
+__global__ __launch_bounds__(256) void k_bpe_flag_list(const int32_t *flags, int64_t ndocs, int32_t *list, unsigned int *count)
+{
+    const int64_t d = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (d < ndocs && flags[d]) list[atomicAdd(count, 1u)] = (int32_t)d;
+}
+
+// BPE wave program models: the handed-back documents go straight to the one-wave-per-document program (no lane kernels: one lane
+// walks one document at ~13 us per byte, a wave at ~1 us per 64 bytes)
+void launch_bpe_seg_flags(const SpSegParams &p_in, const int32_t *flags, int32_t *list, unsigned int *count, hipStream_t s)
+{
+    SpSegParams p = p_in;
+    (void)hipMemsetAsync(count, 0, sizeof(unsigned int), s);
+    (void)hipMemsetAsync(p.next_doc, 0, sizeof(unsigned long long), s);
+    hipLaunchKernelGGL(k_bpe_flag_list, dim3((unsigned)((p.b.ndocs + 255) / 256)), dim3(256), 0, s, flags, p.b.ndocs, list, count);
+    p.fb_list = list; p.fb_count = count;
+    BpeSegParams q = bpe_seg_params(p);
+    q.narcs = nullptr;
+    hipLaunchKernelGGL(k_bpe_seg, dim3((unsigned)device_cus() * 2u), dim3(64), 0, s, q);
 }
 
 void launch_seg_sp(const SpSegParams &p_in, hipStream_t s)
@@ -1871,7 +1870,8 @@ void launch_seg_sp(const SpSegParams &p_in, hipStream_t s)
             unsigned blocks = p.fb_list ? (unsigned)device_cus() : (unsigned)device_cus() * (unsigned)per_cu;
             if ((int64_t)blocks > (int64_t)b64) blocks = b64;
             hipLaunchKernelGGL(k_bpe_apply_flat, dim3(blocks), dim3(64), 0, s, p);
-            hipLaunchKernelGGL(k_bpe_big, dim3(64), dim3(64), 0, s, p);
+            (void)hipMemsetAsync(p.next_doc, 0, sizeof(unsigned long long), s);
+            hipLaunchKernelGGL(k_bpe_seg, dim3((unsigned)device_cus()), dim3(64), 0, s, bpe_seg_params(p));      // idle unless the list holds a document with narcs == -1
         }
     }
 }

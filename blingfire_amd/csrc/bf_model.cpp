@@ -950,7 +950,7 @@ bool build_model(Model &m, const uint8_t *img, size_t size)
             for (size_t s = 0; s < ns && !inner_delim; ++s)
                 if ((int)s != rw.initial)
                     for (uint32_t t = rw.tr_begin[s]; t < rw.tr_begin[s + 1]; ++t) if (rw.tr_dst[t] >= 0 && rw.tr_sym[t] == 0x2581) { inner_delim = true; break; }
-            m.bpe_wave_ok = m.kind == KIND_BPE_OPT && !cyclic && !inner_delim;
+            m.bpe_wave_ok = (m.kind == KIND_BPE_OPT || m.kind == KIND_BPE_MERGES) && !cyclic && !inner_delim;       // both collect with m_fFastBpe (..._bpe_t.h:110, ..._with_merges_t.h:113)
         }
         const int need = m.kind == KIND_UNIGRAM || m.kind == KIND_BPE_MERGES ? 2 : 1;
         size_t nvalid = 0; for (uint8_t v : m.i2info_valid) if (v >= need) ++nvalid;
@@ -995,6 +995,34 @@ bool build_model(Model &m, const uint8_t *img, size_t size)
         }
         m.seg_info.resize(m.i2info_id.size());
         for (size_t k = 0; k < m.i2info_id.size(); ++k) m.seg_info[k] = (uint64_t)(uint32_t)m.i2info_id[k] | ((uint64_t)m.i2info_score[k] << 32);
+        if (m.kind == KIND_BPE || m.kind == KIND_BPE_OPT || m.kind == KIND_BPE_MERGES) {
+            bool ids_ok = true;
+            for (size_t k = 0; k < m.i2info_id.size(); ++k) if (m.i2info_valid[k] && (m.i2info_id[k] < 0 || m.i2info_id[k] >= (1 << 20))) ids_ok = false;
+            m.bpe_seg_ok = ids_ok && m.trie_max_depth > 0 && m.trie_max_depth <= 256;
+            m.bpe_prio_bits = 22;
+            if (m.kind == KIND_BPE_MERGES) {
+                // the order of ..._with_merges_t.h:242-262 over the entries: bigger ranks first (float comparison), then smaller ids
+                std::vector<uint32_t> order;
+                for (size_t k = 0; k < m.i2info_id.size(); ++k) if (m.i2info_valid[k]) order.push_back((uint32_t)k);
+                auto rank_of = [&](uint32_t k) { float f; const uint32_t b = m.i2info_score[k]; memcpy(&f, &b, 4); return f; };
+                std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
+                    const float ra = rank_of(a), rb = rank_of(b);
+                    if (ra > rb) return true;
+                    if (!(ra == rb)) return false;
+                    return m.i2info_id[a] < m.i2info_id[b];
+                });
+                m.bpe_prio.assign(m.i2info_id.size(), 0u); m.bpe_place_id.resize(order.size()); m.bpe_place_rank.resize(order.size());
+                // entries that compare equal (same rank, same id) share a place: the reference orders their arcs by start alone
+                uint32_t place = 0;
+                for (size_t q = 0; q < order.size(); ++q) {
+                    if (q > 0) { const uint32_t a = order[q - 1], b = order[q]; if (!(rank_of(a) == rank_of(b) && m.i2info_id[a] == m.i2info_id[b])) ++place; }
+                    m.bpe_prio[order[q]] = 2u * place + 1u; m.bpe_place_id[place] = m.i2info_id[order[q]]; m.bpe_place_rank[place] = m.i2info_score[order[q]];
+                }
+                m.bpe_place_id.resize(order.empty() ? 0 : place + 1); m.bpe_place_rank.resize(m.bpe_place_id.size());
+                if (2ull * (m.bpe_place_id.size() + 1) >= (1ull << 22)) m.bpe_seg_ok = false;
+                for (size_t k = 0; k < m.i2info_id.size(); ++k) if (m.i2info_valid[k] && rank_of((uint32_t)k) != rank_of((uint32_t)k)) m.bpe_seg_ok = false;   // NaN ranks: no order
+            }
+        }
         auto is_ws = [](int c) { return c <= 0x20 || c == 0xa0 || (c >= 0x2000 && c <= 0x200f) || c == 0x202f || c == 0x205f || c == 0x2060 ||
                                         c == 0x2420 || c == 0x2424 || c == 0x3000 || c == 0xfeff; };   // blingfiretokdll.h:17-21
         auto code_of = [&](int c) -> uint16_t {
@@ -1054,4 +1082,30 @@ bool build_model(Model &m, const uint8_t *img, size_t size)
     return true;
 }
 
+} // namespace bfa
+
+namespace bfa {
+uint32_t bpe_unk_prio(const Model &m, int unk)
+{
+    if (m.kind != KIND_BPE_MERGES) {
+        // ids order the arcs (..._bpe_t.h:238-255); an entry's priority is 2 * id + 1
+        if (unk < 0) return 0u;
+        if (unk >= (1 << 20)) return 1u << 21;
+        return 2u * (uint32_t)unk + 1u;
+    }
+    // (rank 0.0f, id unk) among the places: places before it have a bigger rank, or rank 0.0f and a smaller id
+    auto before = [&](size_t place) {
+        float r; const uint32_t b = m.bpe_place_rank[place]; memcpy(&r, &b, 4);
+        if (r > 0.0f) return true;
+        if (!(r == 0.0f)) return false;
+        return m.bpe_place_id[place] < unk;
+    };
+    size_t lo = 0, hi = m.bpe_place_id.size();
+    while (lo < hi) { const size_t mid = (lo + hi) / 2; if (before(mid)) lo = mid + 1; else hi = mid; }
+    if (lo < m.bpe_place_id.size()) {
+        float r; const uint32_t b = m.bpe_place_rank[lo]; memcpy(&r, &b, 4);
+        if (r == 0.0f && m.bpe_place_id[lo] == unk) return 2u * (uint32_t)lo + 1u;      // compares equal to that entry: ordered by start among its arcs
+    }
+    return 2u * (uint32_t)lo;
+}
 } // namespace bfa

@@ -153,6 +153,12 @@ struct Model {
     int info_stride = 0, info_min_key = 0;
     // device forms
     std::vector<uint64_t> seg_info;    // I2Info rows as (id | score_bits << 32), key = MPH index
+    // bf_bpe_seg_body.h: the arc order of the BPE flavours as one integer per entry.  Plain BPE / bpe-opt sort by id (..._bpe_t.h:238-255):
+    // priority = 2 * id + 1, no table.  With merges (..._with_merges_t.h:242-262: rank descending, then id ascending): bpe_prio[MPH index]
+    // = 2 * place + 1, place = the entry's position in that order; bpe_place_id[place] = its id.  Even priorities are for the unknown arc
+    // of a call (bpe_unk_prio).  bpe_seg_ok: ids and depth fit the arc keys (ids in [0, 2^20), entries of <= 256 symbols).
+    std::vector<uint32_t> bpe_prio; std::vector<int32_t> bpe_place_id; std::vector<uint32_t> bpe_place_rank;   // bpe_place_rank: rank bits of the entry at a place
+    int bpe_prio_bits = 0; bool bpe_seg_ok = false;
     // fused "code point (or byte) -> charmap -> element code" map of the _sp prologue.  Element codes (u16):
     //   class of the dictionary alphabet | SP_NONE (not in alphabet) | SP_WS (whitespace, tokdll.h:17-21) |
     //   SP_DELIM_ABSENT (U+2581 when the alphabet lacks it).  Value = code, or FUSED_MULTI | pool offset
@@ -170,5 +176,7 @@ constexpr uint16_t SP_NONE = 0xFFFF, SP_DELIM_ABSENT = 0xFFFE, SP_WS = 0xFFFD;
 // Parses and re-lays-out a model image.  Returns false and sets m.error on failure.
 bool build_model(Model &m, const uint8_t *img, size_t size);
 bool load_file(const char *path, std::vector<uint8_t> &out);
+// priority of the unknown arc (id UnkId, rank 0.0f) among the entries' priorities: where the reference's comparator sorts it
+uint32_t bpe_unk_prio(const Model &m, int unk);
 
 } // namespace bfa

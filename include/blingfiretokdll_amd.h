@@ -167,9 +167,11 @@ BF_API int WordHyphenationWithModel(const char *pInUtf8Str, int InUtf8StrByteCou
  * Returns the total number of ids, or a negative error code (BF_E_*); with BF_E_CAPACITY id_offsets_out is still complete
  * (id_offsets_out[ndocs] = the ids_cap that would have sufficed).  Large batches (>= 128 MiB of text) are pipelined in chunks of
  * whole documents through page-locked staging; the call returns when everything is in the caller's arrays.
- * BPE models (gpt2.bin, roberta.bin, ...): a document that needs more than 6 * L + 32 candidate arcs (L = its length in stream
- * elements; e.g. nothing but one long run of '-') is tokenised by a slower sequential kernel out of a 64 MiB pool per batch; only a
- * document with more than 2^18 arcs, or an exhausted pool, fails the call with BF_E_INTERNAL. */
+ * BPE models (gpt2.bin, roberta.bin, ...): every document has an answer, as with the reference, whose arc list is an unbounded
+ * std::vector (FATokenSegmentationTools_1best_bpe_t.h:143-144,197).  A document that needs more candidate arcs than the batch
+ * workspace reserves per document (e.g. nothing but one long run of '-') is tokenised by one wave out of a pool of the handle
+ * (64 MiB at first, BfSetBpePoolBytes); when a batch needs more, this call grows the pool and runs again.  The ...BatchDevice form
+ * cannot allocate: there such a document gets 0 ids and BfLastStatus reports bit 64 (size the pool with BfSetBpePoolBytes first). */
 BF_API int64_t TextToIdsBatch(void *ModelPtr, const char *text, const int64_t *doc_offsets, int64_t ndocs,
                        int32_t *ids_out, int64_t ids_cap, int64_t *id_offsets_out,
                        int max_ids_per_doc, int unk);
@@ -238,6 +240,10 @@ BF_API int BfModelKind(void *ModelPtr);
  * synchronises the device and is not allowed inside a stream capture).  want_offsets != 0 also sizes the offsets API.
  * Returns 0 or BF_E_*. */
 BF_API int BfReserve(void *ModelPtr, int64_t max_docs, int64_t max_bytes, int want_offsets);
+/* BPE models: the size of the pool from which documents with very many candidate arcs claim their working memory (about 16 bytes per
+ * arc: a run of 10^6 identical characters whose run lengths are vocabulary entries takes ~350 MB).  Takes effect with the next batch
+ * (the pool only grows).  Returns the previous size or BF_E_*. */
+BF_API int64_t BfSetBpePoolBytes(void *ModelPtr, int64_t bytes);
 
 /* Multi-GPU (SURVEY.md section 8b "SetDevices", 8e): range-shards the HOST-buffer batch calls of this handle (TextToIdsBatch,
  * TextToIdsWithOffsetsBatch) over n devices of this node.  The tables are replicated on every listed device; a batch is split into

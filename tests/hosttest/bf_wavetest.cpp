@@ -6,6 +6,7 @@
 #include "wave_emu.h"
 #include "../../blingfire_amd/csrc/bf_wave_body.h"
 #include "../../blingfire_amd/csrc/bf_bpe_wave_body.h"
+#include "../../blingfire_amd/csrc/bf_bpe_seg_body.h"
 #include "hosttest.h"
 
 #include <vector>
@@ -110,6 +111,7 @@ long bft_emu_bpe_wave_batch(void *hv, const uint8_t *text, long text_bytes, cons
     std::vector<uint32_t> scratch(6 * cells, 0xABABABABu);
     BpeWaveParams p;
     p.T = m.dict.t64.data(); p.info = (const SegInfo *)m.seg_info.data(); p.initial = m.dict.initial_base; p.cls_delim = m.sp_delim_code; p.id_offset = m.id_offset;
+    p.prio = m.kind == KIND_BPE_MERGES ? m.bpe_prio.data() : nullptr; p.place_id = m.kind == KIND_BPE_MERGES ? m.bpe_place_id.data() : nullptr;
     p.stream = stream.data(); p.lens = lens.data(); p.doc_off = doc_off; p.slot_mul = mul; p.ndocs = ndocs;
     p.ids_tmp = tmp.data(); p.counts = counts.data(); p.flags = flags.data(); p.max_ids = max_ids; p.next_doc = &next_doc; p.status = &status; p.stats = stats; p.scratch = scratch.data();
     if (cfg >= 16) { p.next_doc = nullptr; cfg -= 16; }
@@ -148,6 +150,75 @@ long bft_emu_bpe_wave_batch(void *hv, const uint8_t *text, long text_bytes, cons
         }
         if (o + c > ids_cap) return -9;
         for (int k = 0; k < c; ++k) ids_out[o + k] = src[k];
+        o += c;
+    }
+    id_off[ndocs] = o;
+    return o;
+}
+
+
+int bft_bpe_seg_ok(void *hv) { return ((Handle *)hv)->m.bpe_seg_ok ? 1 : 0; }
+
+// Every document of the batch through the one-wave-per-document BPE program (bf_bpe_seg_body.h) in the simulator: prologue restated per
+// document, the program, scan + compaction restated.  pool_bytes: the pool the documents claim their blocks from.  spans_out (optional):
+// [first, last] stream position of every id.  Returns the total id count; -1: model not eligible; -5: a status bit other than
+// BF_STATUS_DOC_FAILED / BF_STATUS_POOL was raised; *status_out = the status word; *pool_used_out = bytes claimed + bytes of the claims that did not fit (a pool of that size holds the batch).
+long bft_emu_bpe_seg_batch(void *hv, const uint8_t *text, const int64_t *doc_off, long ndocs, int max_ids, int unk, int nwaves, long pool_bytes,
+                           int32_t *ids_out, long ids_cap, int64_t *id_off, int32_t *spans_out, int *status_out, unsigned long long *pool_used_out, unsigned long long *stats)
+{
+    Model &m = ((Handle *)hv)->m;
+    if (!m.error.empty() || !m.bpe_seg_ok) return -1;
+    if (max_ids < 0) max_ids = 0;
+    const int mul = m.dict_has_charmap ? 2 : 1;
+    const int64_t total = ndocs > 0 ? doc_off[ndocs] : 0;
+    const size_t cells = (size_t)(mul * (total + ndocs + 1) + 64);
+    std::vector<uint16_t> stream(cells, (uint16_t)0xEEEE); std::vector<int32_t> tmp(cells, -77), spans(2 * cells, -77), lens((size_t)ndocs + 1, 0), counts((size_t)ndocs + 1, -55);
+    std::vector<uint16_t> st;
+    for (long d = 0; d < ndocs; ++d) {
+        const int n = (int)(doc_off[d + 1] - doc_off[d]);
+        if (!bft_sp_stream(m, (const char *)text + doc_off[d], n, st, nullptr)) { lens[(size_t)d] = 0; continue; }
+        lens[(size_t)d] = (int32_t)st.size();
+        if ((int64_t)st.size() > (int64_t)mul * (n + 1)) return -6;
+        memcpy(stream.data() + (size_t)mul * (size_t)(doc_off[d] + d), st.data(), st.size() * 2);
+    }
+    unsigned long long next_doc = 0, pool_used = 0, pool_need = 0; int status = 0;
+    std::vector<uint8_t> pool((size_t)pool_bytes + 64, (uint8_t)0xCD);
+    BpeSegParams p;
+    p.T = m.dict.t64.data(); p.info = (const SegInfo *)m.seg_info.data(); p.initial = m.dict.initial_base; p.cls_delim = m.sp_delim_code; p.id_offset = m.id_offset; p.kind = m.kind;
+    p.prio = m.kind == KIND_BPE_MERGES ? m.bpe_prio.data() : nullptr; p.place_id = m.kind == KIND_BPE_MERGES ? m.bpe_place_id.data() : nullptr;
+    p.unk_prio = bpe_unk_prio(m, unk); p.prio_bits = m.bpe_prio_bits;
+    p.stream = stream.data(); p.lens = lens.data(); p.doc_off = doc_off; p.slot_mul = mul;
+    p.list = nullptr; p.list_n = nullptr; p.narcs = nullptr; p.narcs_want = 0; p.ndocs = ndocs;
+    p.ids_tmp = tmp.data(); p.span_tmp = spans_out ? spans.data() : nullptr; p.counts = counts.data(); p.max_ids = max_ids; p.unk = unk;
+    p.next_doc = &next_doc; p.status = &status;
+    p.pool = pool.data(); p.pool_bytes = (unsigned long long)pool_bytes; p.pool_used = &pool_used; p.pool_need = &pool_need; p.stats = stats;
+    if (ndocs > 0) {
+        std::vector<BsLds *> of_wave((size_t)nwaves);
+        for (int i = 0; i < nwaves; ++i) { of_wave[(size_t)i] = new BsLds(); memset((void *)of_wave[(size_t)i], 0xA5, sizeof(BsLds)); }
+        std::vector<const void *> wave_ids;
+        auto body = [&]() {
+            const void *wid = (const void *)wvemu::g_cur->wave;
+            size_t k = 0;
+            for (; k < wave_ids.size(); ++k) if (wave_ids[k] == wid) break;
+            if (k == wave_ids.size()) wave_ids.push_back(wid);
+            BpeSeg<BsLds> w(p, *of_wave[k]);
+            w.run();
+        };
+        wvemu::run_waves(nwaves, body);
+        for (auto *q : of_wave) delete q;
+    }
+    for (size_t k = 0; k < 64; ++k) if (pool[(size_t)pool_bytes + k] != 0xCD) return -10;       // a block that left the pool
+    if (status_out) *status_out = status;
+    if (pool_used_out) *pool_used_out = pool_used + pool_need;
+    if (status & ~(BF_STATUS_DOC_FAILED | BF_STATUS_POOL)) return -5;
+    long o = 0;
+    for (long d = 0; d < ndocs; ++d) {
+        id_off[d] = o;
+        const int c = counts[(size_t)d];
+        if (c < 0) return -7;
+        const size_t slot = (size_t)mul * (size_t)(doc_off[d] + d);
+        if (o + c > ids_cap) return -9;
+        for (int k = 0; k < c; ++k) { ids_out[o + k] = tmp[slot + (size_t)k]; if (spans_out) { spans_out[2 * (o + k)] = spans[2 * (slot + (size_t)k)]; spans_out[2 * (o + k) + 1] = spans[2 * (slot + (size_t)k) + 1]; } }
         o += c;
     }
     id_off[ndocs] = o;

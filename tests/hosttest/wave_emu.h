@@ -190,4 +190,8 @@ static inline unsigned long long atomic_add(unsigned long long *p, unsigned long
 static inline void atomic_or(int *p, int v) { *p |= v; }
 static inline void lds_or(uint32_t *p, uint32_t v) { *p |= v; }
 static inline unsigned long long clock() { return 0; }
+static inline uint32_t load_l2(const uint32_t *p) { return *p; }
+static inline void atomic_or_u32(uint32_t *p, uint32_t v) { *p |= v; }
+static inline void atomic_max_u32(uint32_t *p, uint32_t v) { if (v > *p) *p = v; }
+static inline void lds_add(uint32_t *p, uint32_t v) { *p += v; }
 } // namespace wv

@@ -11,7 +11,7 @@ import pytest
 import bfutil
 import blingfire_amd as bf
 
-MODELS = ["gpt2.bin", "bpe_example.bin", "bpe_example2.bin"]
+MODELS = ["gpt2.bin", "roberta.bin", "bpe_example.bin", "bpe_example2.bin"]
 # (max_ids, unk, waves, documents per range, configuration: 0 = queue 256 / 8 open documents, 1 = queue 128 / 2 open documents; + 16 = no work counter)
 CONFS = [(512, 0, 1, 8, 0), (512, 3, 3, 2, 1), (7, 5, 2, 3, 16), (0, 0, 1, 8, 0), (2048, 0, 4, 8, 17), (1, 1, 2, 1, 1)]
 
@@ -62,7 +62,7 @@ def check(ht, model, docs, confs, max_back=None):
 
 
 def test_eligibility(ht):
-    for model, want in [("gpt2.bin", 1), ("bpe_example.bin", 1), ("bpe_example2.bin", 1), ("roberta.bin", 0), ("xlnet.bin", 0), ("bert_base_tok.bin", 0)]:
+    for model, want in [("gpt2.bin", 1), ("bpe_example.bin", 1), ("bpe_example2.bin", 1), ("roberta.bin", 1), ("xlnet.bin", 0), ("bert_base_tok.bin", 0)]:
         if not bfutil.have_model(model):
             continue
         h = ht.bft_load(bfutil.model_path(model).encode())

@@ -1,7 +1,7 @@
-"""GPU parity, BPE documents beyond the per-document arc reserve (bf_kernels.hip k_bpe_big -> bf_seg.h seg_bpe_doc_big).  Written at the
-very end of round 2, after the GPU budget was spent: the host form of the same code is tested against the oracle
-(tests/test_hypothesis_emu.py::test_bpe_documents_beyond_the_arc_reserve); this file is the device-side check and sorts last so that
-the rest of the GPU tier runs before it."""
+"""GPU parity, BPE documents beyond the per-document arc reserve: bf_kernels.hip k_bpe_seg (bf_bpe_seg_body.h: one wave per document, arcs
+from a pool that the host-buffer calls grow on demand).  The same source runs in the wave simulator against the oracle
+(tests/test_bpe_seg_emu.py); this file is the device-side check against the compiled reference, up to 10^6 identical characters, and
+sorts last so that the rest of the GPU tier runs before it."""
 import ctypes
 
 import numpy as np
@@ -34,7 +34,7 @@ def _compare(h, ck, hck, docs, max_ids, unk):
 @pytest.mark.parametrize("model", [m for m in ("gpt2.bin", "roberta.bin") if bfutil.have_model(m)])
 def test_bpe_documents_beyond_the_arc_reserve(model, checker):
     """documents that are mostly one long run of a character whose run-length tokens are in the vocabulary ('-' * 15, '.' * 19,
-    '=' * 36, '#' * 93 ...) collect more arcs than the 6 * L + 32 reserved per document: they take the pool path (k_bpe_big) and must
+    '=' * 36, '#' * 93 ...) collect more arcs than the 6 * L + 32 reserved per document: they take the pool path (k_bpe_seg) and must
     come out like the reference's, inside a batch of ordinary documents, with and without offsets"""
     h = bf.load_model(bfutil.model_path(model))
     hck = checker.load(bfutil.model_path(model))
@@ -59,3 +59,50 @@ def test_bpe_documents_beyond_the_arc_reserve(model, checker):
     finally:
         bf.free_model(h)
         checker.free(hck)
+
+
+@pytest.mark.parametrize("model", [m for m in ("gpt2.bin", "roberta.bin") if bfutil.have_model(m)])
+@pytest.mark.parametrize("n", [10000, 50000, 1000000])
+def test_long_runs_of_one_character_inside_a_batch(model, n, checker):
+    """10^4, 5 * 10^4 and 10^6 identical characters (the reference tokenises anything up to FALimits::MaxArrSize: its arc list is a
+    std::vector, ..._bpe_t.h:143-144,197) inside a batch of ordinary documents: every id of every document equals the reference's.
+    The 10^6 case needs ~350 MB of arcs: TextToIdsBatch grows the pool and runs the batch again."""
+    h = bf.load_model(bfutil.model_path(model))
+    hck = checker.load(bfutil.model_path(model))
+    try:
+        docs = bfutil.fuzz_docs(60, seed=11)
+        runs = [b"-" * n] if n >= 1000000 else [b"-" * n, b"=" * n, b"see " + b"." * n + b" end", b"ab" * (n // 2)]
+        mixed = docs[:30] + runs + docs[30:]
+        _compare(h, checker, hck, mixed, 1 << 22, 0)
+        _compare(h, checker, hck, mixed, 7, 0)
+        assert bf.lib().BfLastStatus(ctypes.c_void_p(h)) & (2 | 16 | 32 | 64) == 0
+    finally:
+        bf.free_model(h)
+        checker.free(hck)
+
+
+def test_device_batch_reports_a_full_pool_per_document():
+    """...BatchDevice cannot allocate: with a pool too small for one document that document gets 0 ids and BfLastStatus bit 64, every
+    other document its ids; after BfSetBpePoolBytes the same batch is complete"""
+    import torch
+    model = "gpt2.bin"
+    ck = bfutil.reference() if bfutil.have_ref() else bfutil.oracle()
+    h = bf.load_model(bfutil.model_path(model))
+    hck = ck.load(bfutil.model_path(model))
+    try:
+        docs = [b"hello world", b"=" * 200000, b"the quick brown fox", b"#" * 50]
+        text, off = bf.pack_docs(docs)
+        gids, goff = ck.batch(hck, text, off, 1 << 20, 0)
+        assert bf.lib().BfSetBpePoolBytes(ctypes.c_void_p(h), 1 << 20) == 64 << 20
+        d_text = torch.from_numpy(text).cuda(); d_off = torch.from_numpy(off).cuda()
+        ids, id_off = bf.text_to_ids_batch_device(h, d_text, d_off, 1 << 20, 0); torch.cuda.synchronize()
+        id_off = id_off.cpu().numpy(); cnt, gcnt = np.diff(id_off), np.diff(goff)
+        assert bf.lib().BfLastStatus(ctypes.c_void_p(h)) & 64
+        assert cnt[1] == 0 and cnt[0] == gcnt[0] and cnt[2] == gcnt[2] and cnt[3] == gcnt[3]
+        bf.lib().BfSetBpePoolBytes(ctypes.c_void_p(h), 256 << 20)
+        ids, id_off = bf.text_to_ids_batch_device(h, d_text, d_off, 1 << 20, 0); torch.cuda.synchronize()
+        assert bf.lib().BfLastStatus(ctypes.c_void_p(h)) & (2 | 16 | 32 | 64) == 0
+        assert np.array_equal(id_off.cpu().numpy(), goff) and np.array_equal(ids.cpu().numpy()[:len(gids)], gids)
+    finally:
+        bf.free_model(h)
+        ck.free(hck)
