@@ -7,6 +7,7 @@
 #include "../../blingfire_amd/csrc/bf_wave_body.h"
 #include "../../blingfire_amd/csrc/bf_bpe_wave_body.h"
 #include "../../blingfire_amd/csrc/bf_bpe_seg_body.h"
+#include "../../blingfire_amd/csrc/bf_uni_walk_body.h"
 #include "hosttest.h"
 
 #include <vector>
@@ -220,6 +221,112 @@ long bft_emu_bpe_seg_batch(void *hv, const uint8_t *text, const int64_t *doc_off
         if (o + c > ids_cap) return -9;
         for (int k = 0; k < c; ++k) { ids_out[o + k] = tmp[slot + (size_t)k]; if (spans_out) { spans_out[2 * (o + k)] = spans[2 * (slot + (size_t)k)]; spans_out[2 * (o + k) + 1] = spans[2 * (slot + (size_t)k) + 1]; } }
         o += c;
+    }
+    id_off[ndocs] = o;
+    return o;
+}
+
+
+// Unigram-LM through the two-stage device path on the host: the walks of bf_uni_walk_body.h in the wave simulator (arc records + round
+// table), then bf_seg.h UniArcLane per document, driven sequentially (what k_uni_dp runs per lane), backward pass, scan + compaction
+// restated.  pool_recs: records the pool holds (documents that do not fit are flagged and redone by the sequential restatement of the
+// lane-per-document path, as the device does).  rows: 16 or 32 (entries per start the stage holds).  flags_out[d] = 1: redone.
+// Returns the total id count; -1: the model is not eligible (not Unigram, entries longer than `rows`, ids >= 2^20 - 2).
+long bft_emu_uni_walk_batch(void *hv, const uint8_t *text, const int64_t *doc_off, long ndocs, int max_ids, int unk, int nwaves, long pool_recs, int rows,
+                            int32_t *ids_out, long ids_cap, int64_t *id_off, int32_t *flags_out, unsigned long long *stats)
+{
+    Model &m = ((Handle *)hv)->m;
+    if (!m.error.empty() || m.kind != KIND_UNIGRAM || m.trie_max_depth <= 0 || m.trie_max_depth > rows || m.max_info_id > UNI_MAX_ID) return -1;
+    if (max_ids < 0) max_ids = 0;
+    const int mul = m.dict_has_charmap ? 2 : 1;
+    const int64_t total = ndocs > 0 ? doc_off[ndocs] : 0;
+    const size_t cells = (size_t)(mul * (total + ndocs + 1) + 64);
+    std::vector<uint16_t> stream(cells, (uint16_t)0xEEEE); std::vector<int32_t> lens((size_t)ndocs + 1, 0), flags((size_t)ndocs + 1, -55);
+    std::vector<uint16_t> st;
+    for (long d = 0; d < ndocs; ++d) {
+        const int n = (int)(doc_off[d + 1] - doc_off[d]);
+        if (!bft_sp_stream(m, (const char *)text + doc_off[d], n, st, nullptr)) { lens[(size_t)d] = 0; continue; }
+        lens[(size_t)d] = (int32_t)st.size();
+        memcpy(stream.data() + (size_t)mul * (size_t)(doc_off[d] + d), st.data(), st.size() * 2);
+    }
+    unsigned long long next_doc = 0, cursor = 0;
+    std::vector<uint64_t> pool((size_t)pool_recs + 8, 0xCDCDCDCDCDCDCDCDull), rounds((cells >> 6) + (size_t)ndocs + 8, ~0ull);
+    UniWalkParams p;
+    p.T = m.dict.t64.data(); p.info = (const SegInfo *)m.seg_info.data(); p.initial = m.dict.initial_base;
+    p.stream = stream.data(); p.lens = lens.data(); p.doc_off = doc_off; p.slot_mul = mul; p.ndocs = ndocs; p.perm = nullptr;
+    p.pool = pool.data(); p.pool_recs = (unsigned long long)pool_recs; p.pool_cursor = &cursor; p.rounds = rounds.data(); p.flags = flags.data();
+    p.next_doc = &next_doc; p.stats = stats;
+    if (ndocs > 0) {
+        auto run = [&](auto *tag, auto rows_c) {
+            typedef typename std::remove_pointer<decltype(tag)>::type LDS;
+            std::vector<LDS *> of_wave((size_t)nwaves);
+            for (int i = 0; i < nwaves; ++i) { of_wave[(size_t)i] = new LDS(); memset((void *)of_wave[(size_t)i], 0xA5, sizeof(LDS)); }
+            std::vector<const void *> wave_ids;
+            auto body = [&]() {
+                const void *wid = (const void *)wvemu::g_cur->wave;
+                size_t k = 0;
+                for (; k < wave_ids.size(); ++k) if (wave_ids[k] == wid) break;
+                if (k == wave_ids.size()) wave_ids.push_back(wid);
+                UniWalk<LDS, decltype(rows_c)::value> w(p, *of_wave[k]);
+                w.run();
+            };
+            wvemu::run_waves(nwaves, body);
+            for (auto *q : of_wave) delete q;
+        };
+        if (rows <= 16) run((UwLds<16> *)nullptr, std::integral_constant<int, 16>()); else run((UwLds<32> *)nullptr, std::integral_constant<int, 32>());
+    }
+    for (size_t k = 0; k < 8; ++k) if (pool[(size_t)pool_recs + k] != 0xCDCDCDCDCDCDCDCDull) return -10;
+    // ---- the relaxations per document (k_uni_dp, one lane), the backward pass, compaction
+    struct HostRing {
+        std::vector<double> v; std::vector<uint32_t> r; int mask;
+        double score(int pos) const { return v[(size_t)(pos & mask)]; }
+        uint32_t rec(int pos) const { return r[(size_t)(pos & mask)]; }
+        void set(int pos, double x, uint32_t rr) { v[(size_t)(pos & mask)] = x; r[(size_t)(pos & mask)] = rr; }
+        void fill(double x) { for (auto &e : v) e = x; for (auto &e : r) e = UNI_REC_NONE; }
+    };
+    int ring_n = 1; while (ring_n < m.trie_max_depth) ring_n <<= 1;
+    long o = 0;
+    std::vector<int32_t> one((size_t)(max_ids > 0 ? max_ids : 1));
+    for (long d = 0; d < ndocs; ++d) {
+        id_off[d] = o;
+        const int L = lens[(size_t)d];
+        if (flags_out) flags_out[d] = L > 0 ? flags[(size_t)d] : 0;
+        if (L <= 0) continue;
+        if (flags[(size_t)d] < 0) return -7;
+        if (flags[(size_t)d]) {
+            const int c = bft_emu_sp_doc(m, (const char *)text + doc_off[d], (int)(doc_off[d + 1] - doc_off[d]), one.data(), max_ids, unk);
+            if (c < 0) return -8;
+            if (o + c > ids_cap) return -9;
+            for (int k = 0; k < c; ++k) ids_out[o + k] = one[(size_t)k];
+            o += c; continue;
+        }
+        const int64_t slot = (int64_t)mul * (doc_off[d] + d);
+        HostRing ring{std::vector<double>((size_t)ring_n), std::vector<uint32_t>((size_t)ring_n), ring_n - 1};
+        std::vector<uint32_t> recs_all((size_t)L + 16, 0xDEADBEEFu);
+        uint32_t *recs = recs_all.data() + 8;
+        UniArcLane<HostRing> ul(ring, m.id_offset);
+        ul.init(L, m.trie_max_depth, recs, (int64_t)(d % 5));
+        const uint64_t *rt = rounds.data() + uw_round_base(slot, d);
+        bool more = true;
+        for (int r = 0; more; ++r) {
+            if (rt[r] == ~0ull || rt[r] >= (uint64_t)pool_recs) return -11;
+            const uint64_t *q = pool.data() + rt[r];
+            const int starts = L - r * 64 < 64 ? L - r * 64 : 64;
+            for (int done = 0; done < starts && more;) {
+                const uint64_t rec = *q++;
+                if ((uint32_t)rec & (UA_LAST | UA_UNK)) ++done;
+                more = ul.astep((uint32_t)rec, (uint32_t)(rec >> 32));
+            }
+        }
+        if (recs_all[7] != 0xDEADBEEFu || recs_all[(size_t)L + 8] != 0xDEADBEEFu) return -3;
+        ul.begin_back();
+        std::vector<int32_t> rid;
+        auto put = [&](int, int id, int, int) { rid.push_back(id); };
+        for (;;) { const uint32_t br = recs[(size_t)ul.end]; if (!ul.bstep(br, put, unk)) break; }
+        const int cnt = (int)rid.size(), nout = cnt < max_ids ? cnt : max_ids;
+        if (o + nout > ids_cap) return -9;
+        for (int k = 0; k < nout; ++k) ids_out[o + k] = rid[(size_t)(cnt - 1 - k)];
+        o += nout;
     }
     id_off[ndocs] = o;
     return o;
