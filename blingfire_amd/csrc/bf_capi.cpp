@@ -152,7 +152,8 @@ struct Handle {
     bool dict_ready = false;
     DevBuf w_keys, w_keyoff, w_dids, w_dret, w_vals;              // DictGetInfoBatch staging
     DevBuf w_s1, w_s2, w_s3, w_s4, w_perm, w_hist, w_narcs;      // _sp scratch
-    DevBuf w_bwflags;                                            // BPE wave program: documents handed back
+    DevBuf w_bwflags;                                            // BPE wave program: documents handed back; Unigram: documents whose arc records did not fit
+    DevBuf w_uarcs, w_urounds, w_ulist;                          // Unigram in two stages (bf_uni_walk_body.h): arc records, round table, list of the flagged documents
     DevBuf w_big;                                                // BPE: pool of the documents beyond the per-document arc reserve (k_bpe_seg)
     size_t bpe_pool_bytes = (size_t)64 << 20;                    // its size (BfSetBpePoolBytes; the host-buffer calls grow it when a batch needs more)
     DevBuf t_bpe_prio, t_bpe_place;                              // BPE with merges: the arc order as integers (bf_model.h bpe_prio / bpe_place_id)
@@ -182,7 +183,7 @@ struct Handle {
         for (Handle *c : shards) if (c && c != this) { DeviceGuard dg(c->device); (void)hipDeviceSynchronize(); delete c; }
         shards.clear();
         pipe.release(); m_small.release();
-        for (DevBuf *b : {&t_bpe_prio, &t_bpe_place, &t_dk_l1, &t_dk_pages, &t_dn_l1, &t_dn_pages, &t_dn_pool, &t_k2i, &t_rows, &w_keys, &w_keyoff, &w_dids, &w_dret, &w_vals, &t_i2w_off, &t_i2w_data, &t_kind, &t_wbd, &t_info, &t_acts, &t_cp_l1, &t_cp_pages, &t_multi, &t_wcp_l1, &t_wcp_pages, &t_dict, &t_seginfo, &w_s1, &w_s2, &w_s3, &w_s4, &w_big, &w_perm, &w_hist, &w_narcs, &w_bwflags, &w_cls, &w_nchars, &w_tmp, &w_counts, &w_flags, &w_out, &w_outoff,
+        for (DevBuf *b : {&t_bpe_prio, &t_bpe_place, &t_dk_l1, &t_dk_pages, &t_dn_l1, &t_dn_pages, &t_dn_pool, &t_k2i, &t_rows, &w_keys, &w_keyoff, &w_dids, &w_dret, &w_vals, &t_i2w_off, &t_i2w_data, &t_kind, &t_wbd, &t_info, &t_acts, &t_cp_l1, &t_cp_pages, &t_multi, &t_wcp_l1, &t_wcp_pages, &t_dict, &t_seginfo, &w_s1, &w_s2, &w_s3, &w_s4, &w_big, &w_perm, &w_hist, &w_narcs, &w_bwflags, &w_uarcs, &w_urounds, &w_ulist, &w_cls, &w_nchars, &w_tmp, &w_counts, &w_flags, &w_out, &w_outoff,
                           &w_bsums, &w_misc, &w_text, &w_docoff, &w_ids, &w_idoff, &w_starts, &w_ends, &w_srcoff, &w_span}) b->release();
         for (auto &e : ev) if (e) (void)hipEventDestroy(e);
         if (stream) (void)hipStreamDestroy(stream);
@@ -304,6 +305,14 @@ bool use_wave(const Handle *h, bool want_off, int words)
 // (Model::bpe_wave_ok); BfSetVariant bit 0x40 switches it off (A/B runs against the lane-per-document kernels alone)
 bool use_bpe_wave(const Handle *h, bool want_off) { return h->m.bpe_wave_ok && !want_off && (h->variant & 0x40) == 0; }
 
+// arc records of the two-stage Unigram path: ~1.6 - 1.9 per byte of multilingual text measured (tests/test_uni_walk_emu.py corpora); three per
+// byte reserved, plus the piece every wave may leave unfinished.  Documents that do not fit fall back to the lane-per-document program.
+size_t uni_pool_recs(int64_t ndocs, int64_t total_bytes)
+{
+    const int64_t waves = std::min<int64_t>(ndocs + 4, 256 * 32);
+    return (size_t)(3 * total_bytes + 2 * ndocs + 8192 * waves + 64);
+}
+
 bool reserve_ids_workspaces(Handle *h, int64_t ndocs, int64_t total_bytes, bool want_off, int words = 0)
 {
     const Model &m = h->m;
@@ -323,6 +332,8 @@ bool reserve_ids_workspaces(Handle *h, int64_t ndocs, int64_t total_bytes, bool 
         // one packed 4-byte record per stream element (bf_seg.h uni_rec; 8 bytes reserved); the sequential / flat variants keep 16-byte records
         const bool lane_form = uni_lane_ok(m);
         if (!h->w_s1.reserve(cap * (lane_form ? 4 : 16) + 64)) return false;
+        if (lane_form && !(h->w_uarcs.reserve(uni_pool_recs(ndocs, total_bytes) * 8) && h->w_urounds.reserve(((cap >> 6) + (size_t)ndocs + 8) * 8) &&
+                           h->w_bwflags.reserve((size_t)(ndocs + 1) * 4) && h->w_ulist.reserve((size_t)(ndocs + 1) * 4))) return false;
     } else {
         const size_t bm_words = (cap >> 5) + (size_t)ndocs + 4;
         if (!h->w_s1.reserve((6 * cap + 32 * (size_t)ndocs + 64) * 16) || !h->w_s2.reserve(std::max(cap * 4, 2 * bm_words * 4) + ((size_t)ndocs + 16) * 4) ||
@@ -408,7 +419,15 @@ int run_device(Handle *h, const char *d_text, const int64_t *d_doc_off, int64_t 
         sg.big_pool = nullptr; sg.big_cap = 0; sg.big_used = (unsigned long long *)(h->w_misc.as<char>() + 32);     // zeroed with the status word above
         sg.big_need = (unsigned long long *)(h->w_misc.as<char>() + 40);
         sg.bpe_prio = nullptr; sg.bpe_place_id = nullptr; sg.bpe_unk_prio = 0; sg.bpe_prio_bits = m.bpe_prio_bits; sg.seg_stats = nullptr;
-        if (m.kind == KIND_UNIGRAM) sg.best = h->w_s1.as<SegBest>();
+        sg.uw_pool = nullptr; sg.uw_pool_recs = 0; sg.uw_cursor = nullptr; sg.uw_rounds = nullptr; sg.uw_flags = nullptr; sg.uw_list = nullptr; sg.uw_list_n = nullptr;
+        if (m.kind == KIND_UNIGRAM) {
+            sg.best = h->w_s1.as<SegBest>();
+            if (uni_lane_ok(m)) {
+                sg.uw_pool = h->w_uarcs.as<uint64_t>(); sg.uw_pool_recs = uni_pool_recs(ndocs, total_bytes); sg.uw_cursor = (unsigned long long *)(h->w_misc.as<char>() + 32);
+                sg.uw_rounds = h->w_urounds.as<uint64_t>(); sg.uw_flags = h->w_bwflags.as<int32_t>(); sg.uw_list = h->w_ulist.as<int32_t>(); sg.uw_list_n = (unsigned int *)(h->w_misc.as<char>() + 48);
+                sg.seg_stats = h->lex_stats ? (unsigned long long *)(h->w_misc.as<char>() + 64) : nullptr;
+            }
+        }
         else {
             const size_t bm_words = (cap >> 5) + (size_t)ndocs + 4;         // per bitmap: capacity + 1 bits per document (k_bpe_apply_flat)
             sg.bm_words = (int64_t)bm_words;

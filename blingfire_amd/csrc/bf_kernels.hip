@@ -1702,9 +1702,9 @@ __global__ __launch_bounds__(64) void k_seg_unigram_lane(SpSegParams p, int ring
                     if (lane == leader) base = atomicAdd(p.next_doc, (unsigned long long)c);
                     base = __shfl(base, leader, 64);
                     const int64_t idx = (int64_t)base + __popcll(m_need & lanemask_lt());
-                    if (idx >= p.b.ndocs) mode = M_EXIT;
+                    if (idx >= (p.fb_list ? (int64_t)*p.fb_count : p.b.ndocs)) mode = M_EXIT;      // fb_list: only the documents the walk kernel flagged (k_uni_walk)
                     else {
-                        doc = p.perm[idx];
+                        doc = p.fb_list ? p.fb_list[idx] : p.perm[idx];
                         const int64_t b = p.b.doc_off[doc];
                         const int64_t slot = sp_slot(b, doc, p.slot_mul);
                         cap = p.slot_mul * (int)(p.b.doc_off[doc + 1] - b + 1);
@@ -1751,6 +1751,122 @@ __global__ __launch_bounds__(64) void k_seg_unigram_lane(SpSegParams p, int ring
         }
     }
     if (mode != M_EXIT) atomicOr(p.status, 2);      // trip limit hit: never expected
+}
+
+// ------------------------------------------------------------------------------------------
+// Unigram-LM in two stages (the default for models the lane program fits: entries of <= 32 symbols, ids < 2^20 - 2):
+//   k_uni_walk  bf_uni_walk_body.h: a wave walks the trie from 64 start positions at a time and leaves arc records -- every gather of
+//               the path, none of them dependent on a score, at an occupancy LDS does not limit;
+//   k_uni_dp    bf_seg.h UniArcLane per lane: the relaxations in the reference's arc order from those records (a sequential read of
+//               8 bytes per arc, no table), then the backward pass of k_seg_unigram_lane.
+// A document whose records do not fit the pool is flagged by the first stage and done by k_seg_unigram_lane afterwards.
+// ------------------------------------------------------------------------------------------
+} // namespace bfa
+#include "bf_uni_walk_body.h"
+namespace bfa {
+
+template <int ROWS>
+__global__ __launch_bounds__(256) void k_uni_walk(UniWalkParams p)
+{
+    __shared__ UwLds<ROWS> lds[4];
+    UniWalk<UwLds<ROWS>, ROWS> w(p, lds[wave_in_block()]);
+    w.run();
+}
+
+template <int UNROLL>
+__global__ __launch_bounds__(64) void k_uni_dp(SpSegParams p, const uint64_t *pool, const uint64_t *rounds, const int32_t *flags, int ring_n)
+{
+    extern __shared__ double seg_ring[];            // [ring_n][64] scores, then [ring_n][64] packed records
+    enum { M_NEED = 0, M_WALK = 1, M_BACK = 2, M_EXIT = 3 };
+    const int lane = lane_id();
+    RingLds ring{seg_ring + lane, (uint32_t *)(seg_ring + (size_t)ring_n * 64) + lane, ring_n - 1, ring_n};
+    UniArcLane<RingLds> ul(ring, p.S.id_offset);
+    ul.L = 0; ul.depth = p.trie_depth; ul.start = 0; ul.prev = 0; ul.unk_run = 0; ul.q0 = ul.q1 = ul.q2 = ul.q3 = 0; ul.qn = 0; ul.abs0 = 0; ul.end = 0; ul.cnt = 0; ul.recs = nullptr;
+    int mode = M_NEED;
+    int64_t doc = 0; int32_t *ids = nullptr; int32_t *spans = nullptr; int cap = 0;
+    const uint64_t *rp = nullptr, *rt = nullptr; int left = 0, rnd = 0; uint64_t cur = 0;     // next record, the document's round table, starts left in the round
+    int32_t g0 = 0, g1 = 0, g2 = 0, g3 = 0; int gn = 0;
+    for (unsigned long long trip = 0; trip < (1ull << 34); ++trip) {
+        const unsigned long long m_need = __ballot(mode == M_NEED);
+        if (m_need) {
+            const unsigned long long m_busy = __ballot(mode == M_WALK || mode == M_BACK);
+            if (__popcll(m_need) >= 8 || m_busy == 0) {
+                if (mode == M_NEED) {
+                    const int c = __popcll(m_need);
+                    const int leader = __ffsll((long long)m_need) - 1;
+                    unsigned long long base = 0;
+                    if (lane == leader) base = atomicAdd(p.next_doc, (unsigned long long)c);
+                    base = __shfl(base, leader, 64);
+                    const int64_t idx = (int64_t)base + __popcll(m_need & lanemask_lt());
+                    if (idx >= p.b.ndocs) mode = M_EXIT;
+                    else {
+                        doc = p.perm[idx];
+                        const int64_t b = p.b.doc_off[doc];
+                        const int64_t slot = sp_slot(b, doc, p.slot_mul);
+                        cap = p.slot_mul * (int)(p.b.doc_off[doc + 1] - b + 1);
+                        const int L = p.lens[doc];
+                        ids = p.ids_tmp + slot; spans = p.span_tmp ? p.span_tmp + 2 * slot : nullptr;
+                        if (L <= 0) { p.counts[doc] = 0; p.narcs[doc] = 0; }
+                        else if (flags[doc]) {}                                   // its records did not fit: k_seg_unigram_lane does it
+                        else {
+                            ul.init(L, p.trie_depth, (uint32_t *)p.best + slot, slot);
+                            rt = rounds + uw_round_base(slot, doc); rnd = 0; rp = pool + rt[0]; left = L < 64 ? L : 64; cur = *rp;
+                            mode = M_WALK;
+                        }
+                    }
+                }
+                if (__ballot(mode != M_EXIT) == 0) break;
+            }
+        }
+        uint32_t br = 0;
+        const bool back = mode == M_BACK;
+        if (back) br = ul.recs[ul.end];
+        if (mode == M_WALK) {
+            bool walk = true;
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) {
+                if (walk) {
+                    const uint64_t rec = cur;
+                    const bool ends = ((uint32_t)rec & (UA_LAST | UA_UNK)) != 0;
+                    if (ends) --left;
+                    const bool doc_done = ends && ul.start + 1 >= ul.L;
+                    if (!doc_done) {                                               // the next record travels while this one is relaxed
+                        if (left == 0) { ++rnd; rp = pool + rt[rnd]; const int rest = ul.L - rnd * 64; left = rest < 64 ? rest : 64; } else ++rp;
+                        cur = *rp;
+                    }
+                    walk = ul.astep((uint32_t)rec, (uint32_t)(rec >> 32));
+                }
+            }
+            if (!walk) { ul.begin_back(); mode = M_BACK; }
+        }
+        if (back) {
+            int32_t *dst = nullptr;
+            auto put = [&](int k, int id, int from, int to) {
+                g3 = g2; g2 = g1; g1 = g0; g0 = id; ++gn;
+                dst = ids + (cap - 1 - k);
+                if (spans) { spans[2 * (cap - 1 - k)] = from; spans[2 * (cap - 1 - k) + 1] = to; }
+            };
+            const bool more = ul.bstep(br, put, p.unk);
+            if (!more || (((uintptr_t)dst >> 2) & 3) == 0) {
+                if (gn == 4 && (((uintptr_t)dst >> 2) & 3) == 0) *(int4 *)dst = make_int4(g0, g1, g2, g3);
+                else { dst[0] = g0; if (gn > 1) dst[1] = g1; if (gn > 2) dst[2] = g2; if (gn > 3) dst[3] = g3; }
+                gn = 0;
+            }
+            if (!more) {
+                p.counts[doc] = ul.cnt < p.max_ids ? ul.cnt : p.max_ids;
+                p.narcs[doc] = cap - ul.cnt;
+                mode = M_NEED;
+            }
+        }
+    }
+    if (mode != M_EXIT) atomicOr(p.status, 2);      // trip limit hit: never expected
+}
+
+// flags (set by k_uni_walk) -> the list k_seg_unigram_lane takes its documents from
+__global__ __launch_bounds__(256) void k_uni_flag_list(const int32_t *flags, const int32_t *lens, int64_t ndocs, int32_t *list, unsigned int *count)
+{
+    const int64_t d = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (d < ndocs && lens[d] > 0 && flags[d]) list[atomicAdd(count, 1u)] = (int32_t)d;
 }
 
 // BPE, documents whose arcs exceed the per-document reserve (narcs == -1 on the fallback list; a long run of one character whose
@@ -1817,19 +1933,58 @@ void launch_seg_sp(const SpSegParams &p_in, hipStream_t s)
         else {
             int ring = 1; while (ring < p.trie_depth) ring <<= 1;
             const size_t lds = (size_t)ring * 64 * (sizeof(double) + sizeof(uint32_t));
-            int per_cu = 0;
             const int unroll = p.tune ? p.tune : 3;
-            auto kern = unroll == 1 ? (const void *)k_seg_unigram_lane<1> : unroll == 2 ? (const void *)k_seg_unigram_lane<2> :
-                        unroll == 4 ? (const void *)k_seg_unigram_lane<4> : (const void *)k_seg_unigram_lane<3>;
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 64, lds) != hipSuccess || per_cu <= 0) per_cu = 8;
-            (void)hipGetLastError();
-            if (p.tune2 > 0 && p.tune2 < per_cu) per_cu = p.tune2;
-            unsigned blocks = (unsigned)device_cus() * (unsigned)per_cu;
-            if ((int64_t)blocks > (int64_t)b64) blocks = b64;
-            if (unroll == 1) hipLaunchKernelGGL(k_seg_unigram_lane<1>, dim3(blocks), dim3(64), lds, s, p, ring);
-            else if (unroll == 2) hipLaunchKernelGGL(k_seg_unigram_lane<2>, dim3(blocks), dim3(64), lds, s, p, ring);
-            else if (unroll == 4) hipLaunchKernelGGL(k_seg_unigram_lane<4>, dim3(blocks), dim3(64), lds, s, p, ring);
-            else hipLaunchKernelGGL(k_seg_unigram_lane<3>, dim3(blocks), dim3(64), lds, s, p, ring);
+            auto lane_kernel = [&](const SpSegParams &q, unsigned want_blocks) {
+                int per_cu = 0;
+                auto kern = unroll == 1 ? (const void *)k_seg_unigram_lane<1> : unroll == 2 ? (const void *)k_seg_unigram_lane<2> :
+                            unroll == 4 ? (const void *)k_seg_unigram_lane<4> : (const void *)k_seg_unigram_lane<3>;
+                if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 64, lds) != hipSuccess || per_cu <= 0) per_cu = 8;
+                (void)hipGetLastError();
+                if (p.tune2 > 0 && p.tune2 < per_cu) per_cu = p.tune2;
+                unsigned blocks = (unsigned)device_cus() * (unsigned)per_cu;
+                if (blocks > want_blocks) blocks = want_blocks;
+                if (unroll == 1) hipLaunchKernelGGL(k_seg_unigram_lane<1>, dim3(blocks), dim3(64), lds, s, q, ring);
+                else if (unroll == 2) hipLaunchKernelGGL(k_seg_unigram_lane<2>, dim3(blocks), dim3(64), lds, s, q, ring);
+                else if (unroll == 4) hipLaunchKernelGGL(k_seg_unigram_lane<4>, dim3(blocks), dim3(64), lds, s, q, ring);
+                else hipLaunchKernelGGL(k_seg_unigram_lane<3>, dim3(blocks), dim3(64), lds, s, q, ring);
+            };
+            if (!p.uw_pool || p.variant == 6) lane_kernel(p, b64);          // variant 6 (A/B runs): the lane-per-document program alone
+            else {
+                // ---- stage 1: the walks
+                UniWalkParams w;
+                w.T = p.S.T; w.info = p.S.info; w.initial = p.S.initial;
+                w.stream = p.stream; w.lens = p.lens; w.doc_off = p.b.doc_off; w.slot_mul = p.slot_mul; w.ndocs = p.b.ndocs; w.perm = p.perm;
+                w.pool = p.uw_pool; w.pool_recs = p.uw_pool_recs; w.pool_cursor = p.uw_cursor; w.rounds = p.uw_rounds; w.flags = p.uw_flags;
+                w.next_doc = p.next_doc; w.stats = p.seg_stats;
+                {
+                    int per_cu = 0;
+                    const void *kern = p.trie_depth <= 16 ? (const void *)k_uni_walk<16> : (const void *)k_uni_walk<32>;
+                    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 256, 0) != hipSuccess || per_cu <= 0) per_cu = 4;
+                    (void)hipGetLastError();
+                    if (p.tune2 > 0 && p.tune2 < per_cu) per_cu = p.tune2;
+                    unsigned blocks = (unsigned)device_cus() * (unsigned)per_cu;
+                    const unsigned need = (unsigned)((p.b.ndocs + 3) / 4);
+                    if (blocks > need) blocks = need;
+                    if (p.trie_depth <= 16) hipLaunchKernelGGL(k_uni_walk<16>, dim3(blocks), dim3(256), 0, s, w);
+                    else hipLaunchKernelGGL(k_uni_walk<32>, dim3(blocks), dim3(256), 0, s, w);
+                }
+                // ---- stage 2: the relaxations and the backward pass
+                (void)hipMemsetAsync(p.next_doc, 0, sizeof(unsigned long long), s);
+                {
+                    int per_cu = 0;
+                    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_uni_dp<4>, 64, lds) != hipSuccess || per_cu <= 0) per_cu = 8;
+                    (void)hipGetLastError();
+                    unsigned blocks = (unsigned)device_cus() * (unsigned)per_cu;
+                    if ((int64_t)blocks > (int64_t)b64) blocks = b64;
+                    hipLaunchKernelGGL(k_uni_dp<4>, dim3(blocks), dim3(64), lds, s, p, (const uint64_t *)p.uw_pool, (const uint64_t *)p.uw_rounds, (const int32_t *)p.uw_flags, ring);
+                }
+                // ---- the documents whose records did not fit (normally none): the lane-per-document program
+                (void)hipMemsetAsync(p.next_doc, 0, sizeof(unsigned long long), s);
+                (void)hipMemsetAsync(p.uw_list_n, 0, sizeof(unsigned int), s);
+                hipLaunchKernelGGL(k_uni_flag_list, dim3((unsigned)((p.b.ndocs + 255) / 256)), dim3(256), 0, s, (const int32_t *)p.uw_flags, p.lens, p.b.ndocs, p.uw_list, p.uw_list_n);
+                SpSegParams q = p; q.fb_list = p.uw_list; q.fb_count = p.uw_list_n;
+                lane_kernel(q, (unsigned)device_cus());
+            }
         }
     } else {
         SpSegParams p = p_in;
