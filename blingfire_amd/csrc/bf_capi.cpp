@@ -696,11 +696,13 @@ int64_t run_host_mapped(Handle *h, const char *text, const int64_t *doc_off, int
 }
 
 int64_t run_host_locked(Handle *h, const char *text, const int64_t *doc_off, int64_t ndocs, int32_t *ids_out, int64_t ids_cap,
-                        int64_t *id_off_out, int max_ids, int unk, int32_t *starts_out, int32_t *ends_out, int words, bool *first_doc_nonempty);
+                        int64_t *id_off_out, int max_ids, int unk, int32_t *starts_out, int32_t *ends_out, int words, bool *first_doc_nonempty, bool defer_ids);
 
+// defer_ids (the sharded path): tokenise only -- offsets to the host, ids (and their spans when starts_out / ends_out are non-NULL,
+// which are then only flags) stay in the handle's device buffers w_ids / w_starts / w_ends for fetch_deferred_ids()
 int64_t run_host(Handle *h, const char *text, const int64_t *doc_off, int64_t ndocs, int32_t *ids_out, int64_t ids_cap,
                  int64_t *id_off_out, int max_ids, int unk, int32_t *starts_out = nullptr, int32_t *ends_out = nullptr, int words = 0,
-                 bool *first_doc_nonempty = nullptr /* words modes: the first document decoded to >= 1 character */)
+                 bool *first_doc_nonempty = nullptr /* words modes: the first document decoded to >= 1 character */, bool defer_ids = false)
 {
     if (ndocs < 0 || !doc_off || (ndocs > 0 && !text && doc_off[ndocs] > doc_off[0])) return BF_E_ARG;
     if (ndocs > 0 && doc_off[ndocs] - doc_off[0] < 0) return BF_E_ARG;
@@ -710,7 +712,7 @@ int64_t run_host(Handle *h, const char *text, const int64_t *doc_off, int64_t nd
     // API never sees it: the pool grows by what did not fit and the batch runs again (the reference collects into an unbounded
     // std::vector, ..._bpe_t.h:143-144)
     for (int attempt = 0; attempt < 8; ++attempt) {
-        const int64_t r = run_host_locked(h, text, doc_off, ndocs, ids_out, ids_cap, id_off_out, max_ids, unk, starts_out, ends_out, words, first_doc_nonempty);
+        const int64_t r = run_host_locked(h, text, doc_off, ndocs, ids_out, ids_cap, id_off_out, max_ids, unk, starts_out, ends_out, words, first_doc_nonempty, defer_ids);
         if (r != BF_RETRY_POOL) return r;
         (void)hipDeviceSynchronize();
         unsigned long long need = 0;
@@ -723,15 +725,15 @@ int64_t run_host(Handle *h, const char *text, const int64_t *doc_off, int64_t nd
 }
 
 int64_t run_host_locked(Handle *h, const char *text, const int64_t *doc_off, int64_t ndocs, int32_t *ids_out, int64_t ids_cap,
-                        int64_t *id_off_out, int max_ids, int unk, int32_t *starts_out, int32_t *ends_out, int words, bool *first_doc_nonempty)
+                        int64_t *id_off_out, int max_ids, int unk, int32_t *starts_out, int32_t *ends_out, int words, bool *first_doc_nonempty, bool defer_ids)
 {
     const bool want_off = starts_out && ends_out;
     const int64_t base = doc_off[0];
     const int64_t total = ndocs > 0 ? doc_off[ndocs] - base : 0;
     hipStream_t s = h->stream;
-    if (ndocs >= 1 && ndocs <= SMALL_MAX_DOCS && total <= SMALL_MAX_BYTES && use_wave(h, want_off, words) && small_ready(h))
+    if (!defer_ids && ndocs >= 1 && ndocs <= SMALL_MAX_DOCS && total <= SMALL_MAX_BYTES && use_wave(h, want_off, words) && small_ready(h))
         return run_host_mapped(h, text, doc_off, ndocs, ids_out, ids_cap, id_off_out, max_ids, unk);
-    if (!want_off && !words && h->m.kind != KIND_I2W && h->host_chunk_bytes > 0 && total >= h->host_chunk_bytes && ndocs >= 2) {
+    if (!defer_ids && !want_off && !words && h->m.kind != KIND_I2W && h->host_chunk_bytes > 0 && total >= h->host_chunk_bytes && ndocs >= 2) {
         const int64_t r = run_host_chunked(h, text, doc_off, ndocs, ids_out, ids_cap, id_off_out, max_ids, unk);
         if (r != HOST_PIPE_UNAVAILABLE) return r;
     }
@@ -763,6 +765,7 @@ int64_t run_host_locked(Handle *h, const char *text, const int64_t *doc_off, int
     if (status & (2 | BF_STATUS_INTERNAL)) return BF_E_INTERNAL;
     if (status & BF_STATUS_POOL) return BF_RETRY_POOL;
     const int64_t nids = dst_off[ndocs];
+    if (defer_ids) return nids;
     if (nids > ids_cap) return BF_E_CAPACITY;
     if (nids > 0) {
         if (!ids_out) return BF_E_ARG;
@@ -1117,59 +1120,72 @@ void shard_bounds(const int64_t *doc_off, int64_t ndocs, int G, int64_t *bounds)
     }
 }
 
-// TextToIdsBatch of a handle with several devices: one host thread per range, each through its own handle (run_host: copies in,
-// kernels, copies out on that device); the ranges' ids are then laid end to end and the offsets rebased -- the caller sees exactly
-// what one device would have returned.
-int64_t run_host_sharded(Handle *h, const char *text, const int64_t *doc_off, int64_t ndocs, int32_t *ids_out, int64_t ids_cap,
+// TextToIdsBatch of a handle with several devices: one host thread per range, each through its own handle, in two phases around one
+// barrier.  Phase 1: text in, kernels, id offsets out -- the ids stay in the range's device buffer; once every range knows its id count
+// the ranges' places in the caller's array are known.  Phase 2: every range copies its ids straight into its place and rebases its
+// offsets in place.  The host holds the caller's input and output and nothing else (a worst-case id array per range -- 4 bytes per
+// input byte for WordPiece -- lives on the device, where it costs nothing but HBM); the caller sees exactly what one device would
+// have returned.
+int64_t run_host_sharded(Handle *h, const std::vector<Handle *> &shards, const char *text, const int64_t *doc_off, int64_t ndocs, int32_t *ids_out, int64_t ids_cap,
                          int64_t *id_off_out, int max_ids, int unk, int32_t *starts_out, int32_t *ends_out)
 {
-    const int G = (int)h->shards.size();
+    (void)h;
+    const int G = (int)shards.size();
     const bool want_off = starts_out && ends_out;
     if (ndocs < 0 || !doc_off || (ndocs > 0 && !text && doc_off[ndocs] > doc_off[0])) return BF_E_ARG;
-    std::vector<int64_t> bounds((size_t)G + 1);
+    std::vector<int64_t> bounds((size_t)G + 1), nids((size_t)G, 0), base((size_t)G + 1, 0);
     shard_bounds(doc_off, ndocs, G, bounds.data());
-    struct Part { std::vector<int32_t> ids, st, en; std::vector<int64_t> off; int64_t r = 0; };
-    std::vector<Part> parts((size_t)G);
-    try {
-        for (int g = 0; g < G; ++g) {
-            const int64_t nd = bounds[(size_t)g + 1] - bounds[(size_t)g];
-            const int64_t bytes = nd > 0 ? doc_off[bounds[(size_t)g + 1]] - doc_off[bounds[(size_t)g]] : 0;
-            int64_t worst = h->m.kind == KIND_WP ? bytes : (int64_t)(h->m.dict_has_charmap ? 2 : 1) * (bytes + nd);
-            if (max_ids >= 0 && nd * (int64_t)max_ids < worst) worst = nd * (int64_t)max_ids;
-            parts[(size_t)g].ids.resize((size_t)worst + 1);
-            if (want_off) { parts[(size_t)g].st.resize((size_t)worst + 1); parts[(size_t)g].en.resize((size_t)worst + 1); }
-            parts[(size_t)g].off.assign((size_t)nd + 1, 0);
-        }
-    } catch (const std::bad_alloc &) { g_last_error = "out of host memory for the per-device id buffers"; return BF_E_DEVICE; }
-    std::vector<std::thread> th;
-    for (int g = 0; g < G; ++g) {
-        th.emplace_back([&, g]() {
-            Part &pt = parts[(size_t)g];
-            const int64_t lo = bounds[(size_t)g], nd = bounds[(size_t)g + 1] - lo;
-            pt.r = nd == 0 ? 0 : run_host(h->shards[(size_t)g], text, doc_off + lo, nd, pt.ids.data(), (int64_t)pt.ids.size(), pt.off.data(), max_ids, unk,
-                                          want_off ? pt.st.data() : nullptr, want_off ? pt.en.data() : nullptr);
-        });
+    std::vector<int64_t> tmp_off;                                 // only when the caller wants no offsets
+    int64_t *offs = id_off_out;
+    if (!offs) { try { tmp_off.resize((size_t)ndocs + 1); } catch (const std::bad_alloc &) { g_last_error = "out of host memory"; return BF_E_DEVICE; } offs = tmp_off.data(); }
+    std::vector<std::string> errs((size_t)G);
+    int32_t flag = 0;                                             // non-NULL marker for "with spans" in phase 1
+    {
+        std::vector<std::thread> th;
+        for (int g = 0; g < G; ++g)
+            th.emplace_back([&, g]() {
+                const int64_t lo = bounds[(size_t)g], nd = bounds[(size_t)g + 1] - lo;
+                // the range's offsets land in the caller's array at once, relative to the range (rebased in phase 2).  Entry lo + nd is also
+                // the first entry of the next range (which writes its 0 there): it is set after the join
+                if (nd == 0) { nids[(size_t)g] = 0; return; }
+                const int64_t r = run_host(shards[(size_t)g], text, doc_off + lo, nd, nullptr, 0, offs + lo, max_ids, unk, want_off ? &flag : nullptr, want_off ? &flag : nullptr, 0, nullptr, true);
+                if (r < 0) errs[(size_t)g] = g_last_error;
+                nids[(size_t)g] = r;
+            });
+        for (auto &t : th) t.join();
     }
-    for (auto &t : th) t.join();
+    for (int g = 0; g < G; ++g) offs[bounds[(size_t)g]] = 0;
     int64_t total = 0;
-    for (int g = 0; g < G; ++g) { if (parts[(size_t)g].r < 0) return parts[(size_t)g].r; total += parts[(size_t)g].r; }
-    if (total > ids_cap) return BF_E_CAPACITY;
-    if (total > 0 && !ids_out) return BF_E_ARG;
-    std::vector<std::thread> cp;
-    int64_t at = 0;
     for (int g = 0; g < G; ++g) {
-        const int64_t base = at; at += parts[(size_t)g].r;
-        cp.emplace_back([&, g, base]() {
-            Part &pt = parts[(size_t)g];
-            if (pt.r > 0) {
-                memcpy(ids_out + base, pt.ids.data(), (size_t)pt.r * 4);
-                if (want_off) { memcpy(starts_out + base, pt.st.data(), (size_t)pt.r * 4); memcpy(ends_out + base, pt.en.data(), (size_t)pt.r * 4); }
-            }
-            if (id_off_out) { const int64_t lo = bounds[(size_t)g], nd = bounds[(size_t)g + 1] - lo; for (int64_t i = 0; i < nd; ++i) id_off_out[lo + i] = base + pt.off[(size_t)i]; }
-        });
+        if (nids[(size_t)g] < 0) { g_last_error = errs[(size_t)g]; return nids[(size_t)g]; }      // the failing thread's message reaches the caller
+        base[(size_t)g] = total; total += nids[(size_t)g];
     }
-    for (auto &t : cp) t.join();
+    base[(size_t)G] = total;
     if (id_off_out) id_off_out[ndocs] = total;
+    if (total > ids_cap) {                                        // the offsets are complete (rebased) even so
+        if (id_off_out) for (int g = 0; g < G; ++g) { const int64_t lo = bounds[(size_t)g], nd = bounds[(size_t)g + 1] - lo; for (int64_t i = 0; i < nd; ++i) id_off_out[lo + i] += base[(size_t)g]; }
+        return BF_E_CAPACITY;
+    }
+    if (total > 0 && !ids_out) return BF_E_ARG;
+    std::vector<int> rc((size_t)G, 0);
+    {
+        std::vector<std::thread> th;
+        for (int g = 0; g < G; ++g)
+            th.emplace_back([&, g]() {
+                Handle *c = shards[(size_t)g];
+                const int64_t n = nids[(size_t)g], at = base[(size_t)g];
+                if (n > 0) {
+                    std::lock_guard<std::mutex> lock(c->mu);
+                    DeviceGuard dg(c->device);
+                    if (!dg.ok || !hip_ok(hipMemcpy(ids_out + at, c->w_ids.p, (size_t)n * 4, hipMemcpyDeviceToHost), "D2H ids") ||
+                        (want_off && (!hip_ok(hipMemcpy(starts_out + at, c->w_starts.p, (size_t)n * 4, hipMemcpyDeviceToHost), "D2H starts") ||
+                                      !hip_ok(hipMemcpy(ends_out + at, c->w_ends.p, (size_t)n * 4, hipMemcpyDeviceToHost), "D2H ends")))) { rc[(size_t)g] = BF_E_DEVICE; errs[(size_t)g] = g_last_error; }
+                }
+                if (id_off_out && at != 0) { const int64_t lo = bounds[(size_t)g], nd = bounds[(size_t)g + 1] - lo; for (int64_t i = 0; i < nd; ++i) id_off_out[lo + i] += at; }
+            });
+        for (auto &t : th) t.join();
+    }
+    for (int g = 0; g < G; ++g) if (rc[(size_t)g] != 0) { g_last_error = errs[(size_t)g]; return rc[(size_t)g]; }
     return total;
 }
 
@@ -1617,7 +1633,9 @@ int64_t TextToIdsBatch(void *p, const char *text, const int64_t *doc_offsets, in
 {
     Handle *h = as_handle(p);
     if (!h) return BF_E_ARG;
-    if (h->shards.size() > 1) return run_host_sharded(h, text, doc_offsets, ndocs, ids_out, ids_cap, id_offsets_out, max_ids_per_doc, unk, nullptr, nullptr);
+    std::vector<Handle *> shards;
+    { std::lock_guard<std::mutex> lock(h->mu); shards = h->shards; }      // a snapshot: BfSetDevices may replace the list (not while a batch call runs: documented)
+    if (shards.size() > 1) return run_host_sharded(h, shards, text, doc_offsets, ndocs, ids_out, ids_cap, id_offsets_out, max_ids_per_doc, unk, nullptr, nullptr);
     return run_host(h, text, doc_offsets, ndocs, ids_out, ids_cap, id_offsets_out, max_ids_per_doc, unk);
 }
 
@@ -1673,7 +1691,9 @@ int64_t TextToIdsWithOffsetsBatch(void *p, const char *text, const int64_t *doc_
 {
     Handle *h = as_handle(p);
     if (!h) return BF_E_ARG;
-    if (h->shards.size() > 1 && starts_out && ends_out) return run_host_sharded(h, text, doc_offsets, ndocs, ids_out, cap, id_offsets_out, max_ids_per_doc, unk, starts_out, ends_out);
+    std::vector<Handle *> shards;
+    { std::lock_guard<std::mutex> lock(h->mu); shards = h->shards; }
+    if (shards.size() > 1 && starts_out && ends_out) return run_host_sharded(h, shards, text, doc_offsets, ndocs, ids_out, cap, id_offsets_out, max_ids_per_doc, unk, starts_out, ends_out);
     return run_host(h, text, doc_offsets, ndocs, ids_out, cap, id_offsets_out, max_ids_per_doc, unk, starts_out, ends_out);
 }
 
