@@ -1765,11 +1765,11 @@ __global__ __launch_bounds__(64) void k_seg_unigram_lane(SpSegParams p, int ring
 #include "bf_uni_walk_body.h"
 namespace bfa {
 
-template <int ROWS>
+template <int ROWS, int NS>
 __global__ __launch_bounds__(256) void k_uni_walk(UniWalkParams p)
 {
-    __shared__ UwLds<ROWS> lds[4];
-    UniWalk<UwLds<ROWS>, ROWS> w(p, lds[wave_in_block()]);
+    __shared__ UwLds<ROWS, NS> lds[4];
+    UniWalk<UwLds<ROWS, NS>, ROWS, NS> w(p, lds[wave_in_block()]);
     w.run();
 }
 
@@ -1784,7 +1784,9 @@ __global__ __launch_bounds__(64) void k_uni_dp(SpSegParams p, const uint64_t *po
     ul.L = 0; ul.depth = p.trie_depth; ul.start = 0; ul.prev = 0; ul.unk_run = 0; ul.q0 = ul.q1 = ul.q2 = ul.q3 = 0; ul.qn = 0; ul.abs0 = 0; ul.end = 0; ul.cnt = 0; ul.recs = nullptr;
     int mode = M_NEED;
     int64_t doc = 0; int32_t *ids = nullptr; int32_t *spans = nullptr; int cap = 0;
-    const uint64_t *rp = nullptr, *rt = nullptr; int left = 0, rnd = 0; uint64_t cur = 0;     // next record, the document's round table, starts left in the round
+    // the records of a round are read four at a time, one group ahead: c0 .. c3 = the group being relaxed (c0 next), n0 .. n3 = the group
+    // behind it, np = where the group after that starts; a group that reaches past the round's end is dropped at the round change
+    const uint64_t *np = nullptr, *rt = nullptr; int left = 0, rnd = 0, ci = 0; uint64_t c0 = 0, c1 = 0, c2 = 0, c3 = 0, n0 = 0, n1 = 0, n2 = 0, n3 = 0;
     int32_t g0 = 0, g1 = 0, g2 = 0, g3 = 0; int gn = 0;
     for (unsigned long long trip = 0; trip < (1ull << 34); ++trip) {
         const unsigned long long m_need = __ballot(mode == M_NEED);
@@ -1810,7 +1812,9 @@ __global__ __launch_bounds__(64) void k_uni_dp(SpSegParams p, const uint64_t *po
                         else if (flags[doc]) {}                                   // its records did not fit: k_seg_unigram_lane does it
                         else {
                             ul.init(L, p.trie_depth, (uint32_t *)p.best + slot, slot);
-                            rt = rounds + uw_round_base(slot, doc); rnd = 0; rp = pool + rt[0]; left = L < 64 ? L : 64; cur = *rp;
+                            rt = rounds + uw_round_base(slot, doc); rnd = 0; left = L < 64 ? L : 64; ci = 0;
+                            np = pool + rt[0];
+                            c0 = np[0]; c1 = np[1]; c2 = np[2]; c3 = np[3]; n0 = np[4]; n1 = np[5]; n2 = np[6]; n3 = np[7]; np += 8;
                             mode = M_WALK;
                         }
                     }
@@ -1826,13 +1830,16 @@ __global__ __launch_bounds__(64) void k_uni_dp(SpSegParams p, const uint64_t *po
 #pragma unroll
             for (int u = 0; u < UNROLL; ++u) {
                 if (walk) {
-                    const uint64_t rec = cur;
+                    const uint64_t rec = c0;
                     const bool ends = ((uint32_t)rec & (UA_LAST | UA_UNK)) != 0;
                     if (ends) --left;
                     const bool doc_done = ends && ul.start + 1 >= ul.L;
-                    if (!doc_done) {                                               // the next record travels while this one is relaxed
-                        if (left == 0) { ++rnd; rp = pool + rt[rnd]; const int rest = ul.L - rnd * 64; left = rest < 64 ? rest : 64; } else ++rp;
-                        cur = *rp;
+                    if (!doc_done) {
+                        if (left == 0) {                                           // the next round starts somewhere else
+                            ++rnd; np = pool + rt[rnd]; const int rest = ul.L - rnd * 64; left = rest < 64 ? rest : 64; ci = 0;
+                            c0 = np[0]; c1 = np[1]; c2 = np[2]; c3 = np[3]; n0 = np[4]; n1 = np[5]; n2 = np[6]; n3 = np[7]; np += 8;
+                        } else if (++ci == 4) { c0 = n0; c1 = n1; c2 = n2; c3 = n3; n0 = np[0]; n1 = np[1]; n2 = np[2]; n3 = np[3]; np += 4; ci = 0; }   // the group after next travels while this one is relaxed
+                        else { c0 = c1; c1 = c2; c2 = c3; }
                     }
                     walk = ul.astep((uint32_t)rec, (uint32_t)(rec >> 32));
                 }
@@ -1948,7 +1955,7 @@ void launch_seg_sp(const SpSegParams &p_in, hipStream_t s)
                 else if (unroll == 4) hipLaunchKernelGGL(k_seg_unigram_lane<4>, dim3(blocks), dim3(64), lds, s, q, ring);
                 else hipLaunchKernelGGL(k_seg_unigram_lane<3>, dim3(blocks), dim3(64), lds, s, q, ring);
             };
-            if (!p.uw_pool || p.variant == 6) lane_kernel(p, b64);          // variant 6 (A/B runs): the lane-per-document program alone
+            if (!p.uw_pool || (p.variant != 7 && p.variant != 8 && p.variant != 9)) lane_kernel(p, b64);      // the two-stage form is not the default yet (variants 7 / 8 / 9)
             else {
                 // ---- stage 1: the walks
                 UniWalkParams w;
@@ -1957,16 +1964,21 @@ void launch_seg_sp(const SpSegParams &p_in, hipStream_t s)
                 w.pool = p.uw_pool; w.pool_recs = p.uw_pool_recs; w.pool_cursor = p.uw_cursor; w.rounds = p.uw_rounds; w.flags = p.uw_flags;
                 w.next_doc = p.next_doc; w.stats = p.seg_stats;
                 {
+                    // instances: 16 entries per start x 2 starts per lane (exact for every model with entries of <= 16 symbols), 8 x 4 (a start
+                    // with more than 8 entries sends its document to the lane program), 32 x 1 (entries of up to 32 symbols)
+                    const int inst = p.trie_depth > 16 ? 0 : p.variant == 8 ? 2 : p.variant == 9 ? 3 : 1;
+                    const void *kern = inst == 0 ? (const void *)k_uni_walk<32, 1> : inst == 2 ? (const void *)k_uni_walk<8, 4> : inst == 3 ? (const void *)k_uni_walk<16, 1> : (const void *)k_uni_walk<16, 2>;
                     int per_cu = 0;
-                    const void *kern = p.trie_depth <= 16 ? (const void *)k_uni_walk<16> : (const void *)k_uni_walk<32>;
                     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 256, 0) != hipSuccess || per_cu <= 0) per_cu = 4;
                     (void)hipGetLastError();
                     if (p.tune2 > 0 && p.tune2 < per_cu) per_cu = p.tune2;
                     unsigned blocks = (unsigned)device_cus() * (unsigned)per_cu;
                     const unsigned need = (unsigned)((p.b.ndocs + 3) / 4);
                     if (blocks > need) blocks = need;
-                    if (p.trie_depth <= 16) hipLaunchKernelGGL(k_uni_walk<16>, dim3(blocks), dim3(256), 0, s, w);
-                    else hipLaunchKernelGGL(k_uni_walk<32>, dim3(blocks), dim3(256), 0, s, w);
+                    if (inst == 0) hipLaunchKernelGGL((k_uni_walk<32, 1>), dim3(blocks), dim3(256), 0, s, w);
+                    else if (inst == 2) hipLaunchKernelGGL((k_uni_walk<8, 4>), dim3(blocks), dim3(256), 0, s, w);
+                    else if (inst == 3) hipLaunchKernelGGL((k_uni_walk<16, 1>), dim3(blocks), dim3(256), 0, s, w);
+                    else hipLaunchKernelGGL((k_uni_walk<16, 2>), dim3(blocks), dim3(256), 0, s, w);
                 }
                 // ---- stage 2: the relaxations and the backward pass
                 (void)hipMemsetAsync(p.next_doc, 0, sizeof(unsigned long long), s);

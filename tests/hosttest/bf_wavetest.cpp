@@ -236,7 +236,7 @@ long bft_emu_uni_walk_batch(void *hv, const uint8_t *text, const int64_t *doc_of
                             int32_t *ids_out, long ids_cap, int64_t *id_off, int32_t *flags_out, unsigned long long *stats)
 {
     Model &m = ((Handle *)hv)->m;
-    if (!m.error.empty() || m.kind != KIND_UNIGRAM || m.trie_max_depth <= 0 || m.trie_max_depth > rows || m.max_info_id > UNI_MAX_ID) return -1;
+    if (!m.error.empty() || m.kind != KIND_UNIGRAM || m.trie_max_depth <= 0 || m.trie_max_depth > UA_MAX_DEPTH || (rows < 100 && m.trie_max_depth > rows) || m.max_info_id > UNI_MAX_ID) return -1;
     if (max_ids < 0) max_ids = 0;
     const int mul = m.dict_has_charmap ? 2 : 1;
     const int64_t total = ndocs > 0 ? doc_off[ndocs] : 0;
@@ -257,7 +257,7 @@ long bft_emu_uni_walk_batch(void *hv, const uint8_t *text, const int64_t *doc_of
     p.pool = pool.data(); p.pool_recs = (unsigned long long)pool_recs; p.pool_cursor = &cursor; p.rounds = rounds.data(); p.flags = flags.data();
     p.next_doc = &next_doc; p.stats = stats;
     if (ndocs > 0) {
-        auto run = [&](auto *tag, auto rows_c) {
+        auto run = [&](auto *tag, auto rows_c, auto ns_c) {
             typedef typename std::remove_pointer<decltype(tag)>::type LDS;
             std::vector<LDS *> of_wave((size_t)nwaves);
             for (int i = 0; i < nwaves; ++i) { of_wave[(size_t)i] = new LDS(); memset((void *)of_wave[(size_t)i], 0xA5, sizeof(LDS)); }
@@ -267,13 +267,18 @@ long bft_emu_uni_walk_batch(void *hv, const uint8_t *text, const int64_t *doc_of
                 size_t k = 0;
                 for (; k < wave_ids.size(); ++k) if (wave_ids[k] == wid) break;
                 if (k == wave_ids.size()) wave_ids.push_back(wid);
-                UniWalk<LDS, decltype(rows_c)::value> w(p, *of_wave[k]);
+                UniWalk<LDS, decltype(rows_c)::value, decltype(ns_c)::value> w(p, *of_wave[k]);
                 w.run();
             };
             wvemu::run_waves(nwaves, body);
             for (auto *q : of_wave) delete q;
         };
-        if (rows <= 16) run((UwLds<16> *)nullptr, std::integral_constant<int, 16>()); else run((UwLds<32> *)nullptr, std::integral_constant<int, 32>());
+        // rows + 100 * starts per lane: the device instances (16 x 2, 8 x 4, 32 x 1) and one that overflows its stage often (2 x 3)
+        if (rows == 216) run((UwLds<16, 2> *)nullptr, std::integral_constant<int, 16>(), std::integral_constant<int, 2>());
+        else if (rows == 408) run((UwLds<8, 4> *)nullptr, std::integral_constant<int, 8>(), std::integral_constant<int, 4>());
+        else if (rows == 302) run((UwLds<2, 3> *)nullptr, std::integral_constant<int, 2>(), std::integral_constant<int, 3>());
+        else if (rows <= 16) run((UwLds<16, 1> *)nullptr, std::integral_constant<int, 16>(), std::integral_constant<int, 1>());
+        else run((UwLds<32, 1> *)nullptr, std::integral_constant<int, 32>(), std::integral_constant<int, 1>());
     }
     for (size_t k = 0; k < 8; ++k) if (pool[(size_t)pool_recs + k] != 0xCDCDCDCDCDCDCDCDull) return -10;
     // ---- the relaxations per document (k_uni_dp, one lane), the backward pass, compaction

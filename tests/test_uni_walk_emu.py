@@ -63,7 +63,8 @@ def test_adversarial_and_fuzz(ht, model):
     if not bfutil.have_model(model):
         pytest.skip(model)
     docs = list(bfutil.ADVERSARIAL) + bfutil.fuzz_docs(300, seed=29) + [b"", b"a"]
-    check(ht, model, docs, [(2048, 3, 32), (3, 0, 16), (1, 1, 32), (2048, -5, 16)])
+    check(ht, model, docs, [(2048, 3, 32), (3, 0, 16), (1, 1, 216), (2048, -5, 408)], max_back=None)
+    check(ht, model, docs[:120], [(2048, 3, 302)], max_back=None)          # a stage of two entries per start: many documents are flagged and redone
 
 
 @pytest.mark.parametrize("model", ["xlm_roberta_base.bin", "laser500k.bin"])
@@ -73,7 +74,7 @@ def test_long_unknown_runs_and_long_documents(ht, model):
     docs = ["\U000F0000".encode() * k for k in (1, 2, 63, 64, 65, 4094, 4095, 4096, 4097, 9000)]
     docs += [("a" * k + " \U000F0000" * (k % 5) + " the end").encode("utf-8") for k in range(1, 40)]
     docs += [("word " * 3000).encode(), ("中文" * 2000).encode()]
-    check(ht, model, docs, [(1 << 20, 3, 32), (5, 3, 16)], nw=3)
+    check(ht, model, docs, [(1 << 20, 3, 32), (5, 3, 216), (1 << 20, 3, 408)], nw=3, max_back=None)
 
 
 @pytest.mark.parametrize("wl", ["config4", "config5"])
@@ -81,7 +82,8 @@ def test_corpora(ht, wl):
     w = bfutil.WORKLOADS[wl]
     if not bfutil.have_model(w["model"]):
         pytest.skip(w["model"])
-    check(ht, w["model"], bfutil.gen_workload(wl, 120), [(w["max_ids"], w["unk"], 16), (w["max_ids"], w["unk"], 32)], nw=4)
+    check(ht, w["model"], bfutil.gen_workload(wl, 120), [(w["max_ids"], w["unk"], 216), (w["max_ids"], w["unk"], 32)], nw=4)
+    check(ht, w["model"], bfutil.gen_workload(wl, 120), [(w["max_ids"], w["unk"], 408)], nw=4, max_back=None)
 
 
 def test_a_pool_that_is_too_small_flags_documents(ht):
