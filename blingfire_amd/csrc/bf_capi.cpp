@@ -156,6 +156,7 @@ struct Handle {
     DevBuf w_uarcs, w_urounds, w_ulist;                          // Unigram in two stages (bf_uni_walk_body.h): arc records, round table, list of the flagged documents
     DevBuf w_big;                                                // BPE: pool of the documents beyond the per-document arc reserve (k_bpe_seg)
     size_t bpe_pool_bytes = (size_t)64 << 20;                    // its size (BfSetBpePoolBytes; the host-buffer calls grow it when a batch needs more)
+    DevBuf t_hot_tag, t_hot_t, t_hot_i;                          // Unigram: hot tables of the lane program (bf_seg.h SG_HOT_*)
     DevBuf t_bpe_prio, t_bpe_place;                              // BPE with merges: the arc order as integers (bf_model.h bpe_prio / bpe_place_id)
     // workspaces
     DevBuf w_cls, w_nchars, w_tmp, w_counts, w_bsums, w_misc, w_flags, w_out, w_outoff;   // w_misc: [0] next_doc (u64), [2] status (int)
@@ -183,7 +184,7 @@ struct Handle {
         for (Handle *c : shards) if (c && c != this) { DeviceGuard dg(c->device); (void)hipDeviceSynchronize(); delete c; }
         shards.clear();
         pipe.release(); m_small.release();
-        for (DevBuf *b : {&t_bpe_prio, &t_bpe_place, &t_dk_l1, &t_dk_pages, &t_dn_l1, &t_dn_pages, &t_dn_pool, &t_k2i, &t_rows, &w_keys, &w_keyoff, &w_dids, &w_dret, &w_vals, &t_i2w_off, &t_i2w_data, &t_kind, &t_wbd, &t_info, &t_acts, &t_cp_l1, &t_cp_pages, &t_multi, &t_wcp_l1, &t_wcp_pages, &t_dict, &t_seginfo, &w_s1, &w_s2, &w_s3, &w_s4, &w_big, &w_perm, &w_hist, &w_narcs, &w_bwflags, &w_uarcs, &w_urounds, &w_ulist, &w_cls, &w_nchars, &w_tmp, &w_counts, &w_flags, &w_out, &w_outoff,
+        for (DevBuf *b : {&t_hot_tag, &t_hot_t, &t_hot_i, &t_bpe_prio, &t_bpe_place, &t_dk_l1, &t_dk_pages, &t_dn_l1, &t_dn_pages, &t_dn_pool, &t_k2i, &t_rows, &w_keys, &w_keyoff, &w_dids, &w_dret, &w_vals, &t_i2w_off, &t_i2w_data, &t_kind, &t_wbd, &t_info, &t_acts, &t_cp_l1, &t_cp_pages, &t_multi, &t_wcp_l1, &t_wcp_pages, &t_dict, &t_seginfo, &w_s1, &w_s2, &w_s3, &w_s4, &w_big, &w_perm, &w_hist, &w_narcs, &w_bwflags, &w_uarcs, &w_urounds, &w_ulist, &w_cls, &w_nchars, &w_tmp, &w_counts, &w_flags, &w_out, &w_outoff,
                           &w_bsums, &w_misc, &w_text, &w_docoff, &w_ids, &w_idoff, &w_starts, &w_ends, &w_srcoff, &w_span}) b->release();
         for (auto &e : ev) if (e) (void)hipEventDestroy(e);
         if (stream) (void)hipStreamDestroy(stream);
@@ -279,6 +280,7 @@ Handle *make_handle(const uint8_t *img, size_t size)
         ok = ok && upload(h->t_dict, m.dict.t64, 16) && upload(h->t_seginfo, m.seg_info, 16) &&
              upload(h->t_cp_l1, m.sp_cpmap.l1) && upload(h->t_cp_pages, m.sp_cpmap.pages) && upload(h->t_multi, m.sp_multi_pool, 16);
         if (m.kind == KIND_BPE_MERGES) ok = ok && upload(h->t_bpe_prio, m.bpe_prio, 16) && upload(h->t_bpe_place, m.bpe_place_id, 16);
+        if (!m.uni_hot_t.empty()) ok = ok && upload(h->t_hot_tag, m.uni_hot_tag) && upload(h->t_hot_t, m.uni_hot_t) && upload(h->t_hot_i, m.uni_hot_i);
     }
     if (m.has_i2w) ok = ok && upload(h->t_i2w_off, m.i2w_off, 4) && upload(h->t_i2w_data, m.i2w_data, 16);
     ok = ok && hip_ok(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking), "hipStreamCreate");
@@ -412,7 +414,8 @@ int run_device(Handle *h, const char *d_text, const int64_t *d_doc_off, int64_t 
         (void)hipEventRecord(h->ev[EV_PREP], s);
         SpSegParams sg;
         sg.S.T = h->t_dict.as<uint64_t>(); sg.S.info = h->t_seginfo.as<SegInfo>(); sg.S.initial = m.dict.initial_base;
-        sg.S.cls_delim = m.sp_delim_code; sg.S.kind = m.kind; sg.S.id_offset = m.id_offset;
+        sg.S.cls_delim = m.sp_delim_code; sg.S.kind = m.kind; sg.S.id_offset = m.id_offset; sg.S.hot_tag = nullptr; sg.S.hot_t = nullptr; sg.S.hot_i = nullptr;
+        sg.hot_tag = m.uni_hot_t.empty() ? nullptr : h->t_hot_tag.as<uint16_t>(); sg.hot_t = m.uni_hot_t.empty() ? nullptr : h->t_hot_t.as<uint64_t>(); sg.hot_i = m.uni_hot_t.empty() ? nullptr : h->t_hot_i.as<uint64_t>();
         sg.b = b; sg.stream = h->w_cls.as<uint16_t>(); sg.lens = h->w_nchars.as<int32_t>(); sg.slot_mul = mul;
         sg.ids_tmp = h->w_tmp.as<int32_t>(); sg.counts = h->w_counts.as<int32_t>(); sg.span_tmp = want_off ? h->w_span.as<int32_t>() : nullptr; sg.max_ids = max_ids; sg.unk = unk; sg.status = status;
         sg.best = nullptr; sg.arcs = nullptr; sg.tos = nullptr; sg.idsv = nullptr; sg.inter = nullptr; sg.bm_words = 0; sg.fb_list = nullptr; sg.fb_count = nullptr;

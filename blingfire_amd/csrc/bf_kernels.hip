@@ -1675,15 +1675,27 @@ struct RingLds {
 // Unigram-LM, default form: bf_seg.h UniLane per lane, persistent lanes pulling documents (longest first).  Every trip of
 // the loop a walking lane makes UNROLL trie transitions and a lane in its backward pass makes one hop whose record was
 // requested BEFORE the walk steps (its latency hides behind them); finished lanes fetch new documents by vote.
-template <int UNROLL>
-__global__ __launch_bounds__(64) void k_seg_unigram_lane(SpSegParams p, int ring_n)
+// NW waves per workgroup share the LDS copies of the model's hottest transitions and I2Info rows (bf_seg.h SG_HOT_*, when the model has
+// them: p.hot_t != nullptr and NW > 1); every wave has its own rings and is a persistent wave of its own otherwise
+template <int UNROLL, int NW>
+__global__ __launch_bounds__(64 * NW) void k_seg_unigram_lane(SpSegParams p, int ring_n)
 {
-    extern __shared__ double seg_ring[];            // [ring_n][64] scores, then [ring_n][64] packed records
+    extern __shared__ double seg_ring[];            // per wave: [ring_n][64] scores, then [ring_n][64] packed records; behind the NW waves: the hot tables
     enum { M_NEED = 0, M_WALK = 1, M_BACK = 2, M_EXIT = 3 };
     const int lane = lane_id();
-    RingLds ring{seg_ring + lane, (uint32_t *)(seg_ring + (size_t)ring_n * 64) + lane, ring_n - 1, ring_n};
+    const size_t wave_doubles = (size_t)ring_n * 64 + (size_t)ring_n * 32;          // 8 + 4 bytes per slot and lane
+    double *my = seg_ring + (size_t)(NW > 1 ? wave_in_block() : 0) * wave_doubles;
+    RingLds ring{my + lane, (uint32_t *)(my + (size_t)ring_n * 64) + lane, ring_n - 1, ring_n};
+    SegTables S = p.S;
+    if (NW > 1 && p.hot_t) {
+        uint64_t *ht = (uint64_t *)(seg_ring + (size_t)NW * wave_doubles), *hi = ht + SG_HOT_T; uint16_t *hg = (uint16_t *)(hi + SG_HOT_I);
+        for (int k = (int)threadIdx.x; k < SG_HOT_T; k += 64 * NW) { ht[k] = p.hot_t[k]; hg[k] = p.hot_tag[k]; }
+        for (int k = (int)threadIdx.x; k < SG_HOT_I; k += 64 * NW) hi[k] = p.hot_i[k];
+        __syncthreads();
+        S.hot_t = ht; S.hot_i = hi; S.hot_tag = hg;
+    } else { S.hot_t = nullptr; S.hot_i = nullptr; S.hot_tag = nullptr; }
     ClsWin2 cls_at; cls_at.init(p.stream, 0);
-    UniLane<ClsWin2, RingLds> ul(p.S, cls_at, ring);
+    UniLane<ClsWin2, RingLds> ul(S, cls_at, ring);
     ul.L = 0; ul.depth = p.trie_depth; ul.start = ul.i = ul.sum = 0; ul.state = 0; ul.unknown = true; ul.pend = false; ul.prev = 0; ul.pend_i = 0;
     ul.pend_r.id = 0; ul.pend_r.score_bits = 0; ul.end = 0; ul.cnt = 0; ul.unk_run = 0; ul.q0 = ul.q1 = ul.q2 = ul.q3 = 0; ul.qn = 0; ul.abs0 = 0;
     int mode = M_NEED;
@@ -1941,19 +1953,36 @@ void launch_seg_sp(const SpSegParams &p_in, hipStream_t s)
             int ring = 1; while (ring < p.trie_depth) ring <<= 1;
             const size_t lds = (size_t)ring * 64 * (sizeof(double) + sizeof(uint32_t));
             const int unroll = p.tune ? p.tune : 3;
+            // the lane program: one wave per workgroup, or (models with hot tables, bf_seg.h SG_HOT_*; variant 6 switches it off for A/B runs)
+            // eight waves per workgroup sharing the LDS copies of the tables: 8 x 12 KB of rings + 56 KB of tables = one workgroup per CU
             auto lane_kernel = [&](const SpSegParams &q, unsigned want_blocks) {
+                const bool hot = q.hot_t && q.variant != 6 && ring <= 16;
+                if (hot) {
+                    constexpr int NW = 8;
+                    const size_t lds8 = (size_t)NW * lds + (size_t)SG_HOT_T * 10 + (size_t)SG_HOT_I * 8;
+                    static bool attr_set = false;
+                    if (!attr_set) { (void)hipFuncSetAttribute((const void *)k_seg_unigram_lane<3, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8); (void)hipGetLastError(); attr_set = true; }
+                    int per_cu = 0;
+                    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k_seg_unigram_lane<3, NW>, 64 * NW, lds8) != hipSuccess || per_cu <= 0) per_cu = 1;
+                    (void)hipGetLastError();
+                    unsigned blocks = (unsigned)device_cus() * (unsigned)per_cu;
+                    const unsigned wb = (want_blocks + NW - 1) / NW;
+                    if (blocks > wb) blocks = wb;
+                    hipLaunchKernelGGL((k_seg_unigram_lane<3, NW>), dim3(blocks), dim3(64 * NW), lds8, s, q, ring);
+                    return;
+                }
                 int per_cu = 0;
-                auto kern = unroll == 1 ? (const void *)k_seg_unigram_lane<1> : unroll == 2 ? (const void *)k_seg_unigram_lane<2> :
-                            unroll == 4 ? (const void *)k_seg_unigram_lane<4> : (const void *)k_seg_unigram_lane<3>;
+                auto kern = unroll == 1 ? (const void *)k_seg_unigram_lane<1, 1> : unroll == 2 ? (const void *)k_seg_unigram_lane<2, 1> :
+                            unroll == 4 ? (const void *)k_seg_unigram_lane<4, 1> : (const void *)k_seg_unigram_lane<3, 1>;
                 if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 64, lds) != hipSuccess || per_cu <= 0) per_cu = 8;
                 (void)hipGetLastError();
                 if (p.tune2 > 0 && p.tune2 < per_cu) per_cu = p.tune2;
                 unsigned blocks = (unsigned)device_cus() * (unsigned)per_cu;
                 if (blocks > want_blocks) blocks = want_blocks;
-                if (unroll == 1) hipLaunchKernelGGL(k_seg_unigram_lane<1>, dim3(blocks), dim3(64), lds, s, q, ring);
-                else if (unroll == 2) hipLaunchKernelGGL(k_seg_unigram_lane<2>, dim3(blocks), dim3(64), lds, s, q, ring);
-                else if (unroll == 4) hipLaunchKernelGGL(k_seg_unigram_lane<4>, dim3(blocks), dim3(64), lds, s, q, ring);
-                else hipLaunchKernelGGL(k_seg_unigram_lane<3>, dim3(blocks), dim3(64), lds, s, q, ring);
+                if (unroll == 1) hipLaunchKernelGGL((k_seg_unigram_lane<1, 1>), dim3(blocks), dim3(64), lds, s, q, ring);
+                else if (unroll == 2) hipLaunchKernelGGL((k_seg_unigram_lane<2, 1>), dim3(blocks), dim3(64), lds, s, q, ring);
+                else if (unroll == 4) hipLaunchKernelGGL((k_seg_unigram_lane<4, 1>), dim3(blocks), dim3(64), lds, s, q, ring);
+                else hipLaunchKernelGGL((k_seg_unigram_lane<3, 1>), dim3(blocks), dim3(64), lds, s, q, ring);
             };
             if (!p.uw_pool || (p.variant != 7 && p.variant != 8 && p.variant != 9)) lane_kernel(p, b64);      // the two-stage form is not the default yet (variants 7 / 8 / 9)
             else {

@@ -36,7 +36,39 @@ struct SegTables {
     uint32_t initial;
     uint32_t cls_delim;         // class-stream value of U+2581
     int kind, id_offset;
+    // optional (Unigram lane program): the model's hottest transitions and I2Info rows, direct-mapped by the low bits of the table index /
+    // MPH index (bf_model.cpp uni_hot_*; in LDS on the device).  nullptr: none
+    const uint16_t *hot_tag; const uint64_t *hot_t, *hot_i;
 };
+
+// The lane program's gathers are bound by the number of L2 requests (measured on MI355X, profiles/r04_*: three different kernels with the
+// same gathers take the same 33.6 ms per 2.5 M documents), and the vector L1 holds a few hundred 128-byte lines for 8-byte entries.  A table
+// of a few thousand eight-byte words in LDS, filled at load with the edges / rows that carry the most probability mass (exp(score) summed
+// over the entries below an edge), answers about half of the transition gathers and three quarters of the I2Info gathers of multilingual
+// text (tests/hosttest bft_uni_static_cache_sim).
+//   transitions: slot = index & (SG_HOT_T - 1), hot_tag[slot] = index >> SG_HOT_T_LOG (0xFFFF: empty), hot_t[slot] = the table entry itself
+//   (so the class check of a lookup is the one the table gets);  rows: slot = MPH index & (SG_HOT_I - 1), hot_i[slot] = sg_hot_i_word();
+//   an empty slot is all ones (no MPH index reaches the tag 0x7FF: checked when the table is made)
+constexpr int SG_HOT_T_LOG = 12, SG_HOT_T = 1 << SG_HOT_T_LOG, SG_HOT_I_LOG = 11, SG_HOT_I = 1 << SG_HOT_I_LOG;
+// rows: [63:53] MPH index >> SG_HOT_I_LOG (MPH indices are < 2^22), [52:32] id + 1, [31:0] score bits
+BF_HD uint64_t sg_hot_i_word(uint32_t mph, int32_t id, uint32_t score_bits) { return ((uint64_t)(mph >> SG_HOT_I_LOG) << 53) | ((uint64_t)((uint32_t)(id + 1) & 0x1FFFFFu) << 32) | (uint64_t)score_bits; }
+// the entry at table index idx (the caller checks its class)
+BF_HD uint64_t sg_entry(const SegTables &S, uint32_t idx)
+{
+    if (S.hot_t) {
+        const uint32_t slot = idx & (uint32_t)(SG_HOT_T - 1);
+        if ((uint32_t)S.hot_tag[slot] == (idx >> SG_HOT_T_LOG)) return S.hot_t[slot];
+    }
+    return S.T[idx];
+}
+BF_HD SegInfo sg_info(const SegTables &S, int mph)
+{
+    if (S.hot_i) {
+        const uint64_t w = S.hot_i[(uint32_t)mph & (uint32_t)(SG_HOT_I - 1)];
+        if ((w >> 53) == (uint64_t)((uint32_t)mph >> SG_HOT_I_LOG)) { SegInfo r; r.id = (int32_t)((w >> 32) & 0x1FFFFFu) - 1; r.score_bits = (uint32_t)w; return r; }
+    }
+    return S.info[mph];
+}
 
 struct SegArc { int32_t start, end, id; uint32_t rank_bits; };   // BPE arc (…_bpe_t.h:66-88, …_with_merges_t.h)
 
@@ -216,14 +248,14 @@ struct UniLane : UniRecOut {
     {
         const uint32_t c = cls_at(i);
         const bool valid = c < SG_CLS_DELIM_ABSENT;                     // sg_lookup: symbols outside the alphabet never match
-        const uint64_t e = S.T[state + (valid ? c : 0u)];               // the gather is issued ...
+        const uint64_t e = sg_entry(S, state + (valid ? c : 0u));       // the gather is issued (unless the hot table has the edge) ...
         if (pend) relax();                                              // ... and the previous arc is relaxed while it travels
         const bool hit = valid && (e & SG_CLS_MASK) == c;
         bool ends = !hit;
         if (hit) {
             state = (uint32_t)((e >> SG_NEXT_SHIFT) & SG_NEXT_MASK);
             sum += (int)(e >> SG_OW_SHIFT);
-            if (e & SG_FINAL) { pend_r = S.info[sum]; pend_i = i; pend = true; unknown = false; }   // requested now, used next step
+            if (e & SG_FINAL) { pend_r = sg_info(S, sum); pend_i = i; pend = true; unknown = false; }   // requested now, used next step
             ++i;
             ends = i >= L;
         }

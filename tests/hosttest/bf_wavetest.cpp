@@ -11,6 +11,8 @@
 #include "hosttest.h"
 
 #include <vector>
+#include <functional>
+#include <algorithm>
 
 using namespace bfa;
 
@@ -335,6 +337,101 @@ long bft_emu_uni_walk_batch(void *hv, const uint8_t *text, const int64_t *doc_of
     }
     id_off[ndocs] = o;
     return o;
+}
+
+
+// EXPERIMENT (design aid, not a test of the product): what a direct-mapped cache of 2^log_slots table entries (index low bits = slot) would
+// catch of the Unigram walks' table gathers and I2Info gathers on a batch.  out[0..5] = T gathers, T cache hits, gathers at depth 0,
+// info gathers, info hits, starts; out[8 + j] = gathers at depth j (j < 8), out[16 + j] = hits (transitions made) at depth j
+void bft_uni_cache_sim(void *hv, const uint8_t *text, const int64_t *doc_off, long ndocs, int log_slots, unsigned long long *out)
+{
+    Model &m = ((Handle *)hv)->m;
+    std::vector<uint32_t> tagT((size_t)1 << log_slots, 0xFFFFFFFFu), tagI((size_t)1 << log_slots, 0xFFFFFFFFu);
+    const uint32_t mask = (1u << log_slots) - 1u;
+    std::vector<uint16_t> st;
+    const uint64_t *T = m.dict.t64.data();
+    for (long d = 0; d < ndocs; ++d) {
+        if (!bft_sp_stream(m, (const char *)text + doc_off[d], (int)(doc_off[d + 1] - doc_off[d]), st, nullptr)) continue;
+        const int L = (int)st.size();
+        for (int s = 0; s < L; ++s) {
+            ++out[5];
+            uint32_t state = m.dict.initial_base; int sum = 0;
+            for (int i = s, j = 0; i < L; ++i, ++j) {
+                const uint32_t c = st[(size_t)i];
+                if (c >= SG_CLS_DELIM_ABSENT) break;
+                const uint32_t idx = state + c;
+                ++out[0]; if (j == 0) ++out[2]; if (j < 8) ++out[8 + j];
+                if (tagT[idx & mask] == idx) ++out[1]; else tagT[idx & mask] = idx;
+                const uint64_t e = T[idx];
+                if ((e & SG_CLS_MASK) != c) break;
+                if (j < 8) ++out[16 + j];
+                state = (uint32_t)((e >> SG_NEXT_SHIFT) & SG_NEXT_MASK); sum += (int)(e >> SG_OW_SHIFT);
+                if (e & SG_FINAL) { ++out[3]; const uint32_t k = (uint32_t)sum; if (tagI[k & mask] == k) ++out[4]; else tagI[k & mask] = k; }
+            }
+        }
+    }
+}
+
+
+// EXPERIMENT (design aid): a STATIC direct-mapped table of the 2^log_slots hottest transitions / I2Info rows, chosen at load from the
+// model alone (mass of an edge = sum of exp(score) over the entries below it; a slot keeps the heaviest edge that maps to it), against
+// the walks of a batch.  out[0..5] = T gathers, T hits, -, info gathers, info hits, starts
+#include <cmath>
+void bft_uni_static_cache_sim(void *hv, const uint8_t *text, const int64_t *doc_off, long ndocs, int log_slots, unsigned long long *out)
+{
+    Model &m = ((Handle *)hv)->m;
+    const RawDfa &rw = m.dict_raw;
+    const size_t ns = rw.state_off.size();
+    const uint32_t mask = (1u << log_slots) - 1u;
+    std::vector<uint32_t> tagT((size_t)1 << log_slots, 0xFFFFFFFFu), tagI((size_t)1 << log_slots, 0xFFFFFFFFu);
+    std::vector<double> massT((size_t)1 << log_slots, -1.0), massI((size_t)1 << log_slots, -1.0);
+    // class of a raw symbol
+    std::vector<int> cls_of_sym;
+    { int mx = 0; for (int sy : m.dict.sym_of_class) mx = std::max(mx, sy); cls_of_sym.assign((size_t)mx + 1, -1); for (size_t c = 0; c < m.dict.sym_of_class.size(); ++c) cls_of_sym[(size_t)m.dict.sym_of_class[c]] = (int)c; }
+    // subtree mass by DFS with the accumulated MPH index
+    std::function<double(int, int)> dfs = [&](int st, int sum) -> double {
+        double mass = 0;
+        for (uint32_t t = rw.tr_begin[(size_t)st]; t < rw.tr_begin[(size_t)st + 1]; ++t) {
+            const int dst = rw.tr_dst[t]; if (dst < 0) continue;
+            const int sum2 = sum + rw.tr_ow[t];
+            double sub = dfs(dst, sum2);
+            if (rw.is_final[(size_t)dst]) {
+                float f; const uint32_t b = m.i2info_score[(size_t)sum2]; memcpy(&f, &b, 4);
+                const double pm = std::exp((double)f);
+                sub += pm;
+                const uint32_t k = (uint32_t)sum2;
+                if (pm > massI[k & mask]) { massI[k & mask] = pm; tagI[k & mask] = k; }
+            }
+            const int sy = rw.tr_sym[t];
+            const int c = sy >= 0 && (size_t)sy < cls_of_sym.size() ? cls_of_sym[(size_t)sy] : -1;
+            if (c >= 0) { const uint32_t idx = m.dict.state_base[(size_t)st] + (uint32_t)c; if (sub > massT[idx & mask]) { massT[idx & mask] = sub; tagT[idx & mask] = idx; } }
+            mass += sub;
+        }
+        return mass;
+    };
+    (void)ns;
+    dfs(rw.initial, 0);
+    std::vector<uint16_t> st;
+    const uint64_t *T = m.dict.t64.data();
+    for (long d = 0; d < ndocs; ++d) {
+        if (!bft_sp_stream(m, (const char *)text + doc_off[d], (int)(doc_off[d + 1] - doc_off[d]), st, nullptr)) continue;
+        const int L = (int)st.size();
+        for (int s = 0; s < L; ++s) {
+            ++out[5];
+            uint32_t state = m.dict.initial_base; int sum = 0;
+            for (int i = s; i < L; ++i) {
+                const uint32_t c = st[(size_t)i];
+                if (c >= SG_CLS_DELIM_ABSENT) break;
+                const uint32_t idx = state + c;
+                ++out[0];
+                if (tagT[idx & mask] == idx) ++out[1];
+                const uint64_t e = T[idx];
+                if ((e & SG_CLS_MASK) != c) break;
+                state = (uint32_t)((e >> SG_NEXT_SHIFT) & SG_NEXT_MASK); sum += (int)(e >> SG_OW_SHIFT);
+                if (e & SG_FINAL) { ++out[3]; const uint32_t k = (uint32_t)sum; if (tagI[k & mask] == k) ++out[4]; }
+            }
+        }
+    }
 }
 
 } // extern "C"

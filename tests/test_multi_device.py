@@ -82,6 +82,29 @@ def test_logical_shards_on_one_device_return_the_same_bytes(model, max_ids, unk)
 
 
 @pytest.mark.gpu
+def test_settings_changed_after_set_devices_reach_every_shard():
+    """SetNoDummyPrefix after BfSetDevices: every range of a sharded batch is tokenised with the new setting (the ranges' handles follow
+    the parent's settings), i.e. exactly what one device returns with that setting -- and differently from the old setting"""
+    model = "xlm_roberta_base.bin"
+    if not bfutil.have_model(model):
+        pytest.skip(model)
+    text, off = _batch(model, 3000, 5)
+    h = bf.load_model(bfutil.model_path(model))
+    try:
+        with_prefix, _ = bf.text_to_ids_batch(h, (text, off), 64, 3)
+        bf.change_settings_dummy_prefix(h, False)
+        one_ids, one_off = bf.text_to_ids_batch(h, (text, off), 64, 3)
+        assert not np.array_equal(one_ids, with_prefix)
+        bf.change_settings_dummy_prefix(h, True)
+        bf.set_devices(h, [0, 0, 0])
+        bf.change_settings_dummy_prefix(h, False)                  # after the shards exist
+        g_ids, g_off = bf.text_to_ids_batch(h, (text, off), 64, 3)
+        assert np.array_equal(g_off, one_off) and np.array_equal(g_ids, one_ids)
+    finally:
+        bf.free_model(h)
+
+
+@pytest.mark.gpu
 def test_set_devices_rejects_devices_the_box_does_not_have():
     import torch
     h = bf.load_model(bfutil.model_path(bfutil.bert_model_name()))
