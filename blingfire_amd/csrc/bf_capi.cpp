@@ -152,11 +152,9 @@ struct Handle {
     bool dict_ready = false;
     DevBuf w_keys, w_keyoff, w_dids, w_dret, w_vals;              // DictGetInfoBatch staging
     DevBuf w_s1, w_s2, w_s3, w_s4, w_perm, w_hist, w_narcs;      // _sp scratch
-    DevBuf w_bwflags;                                            // BPE wave program: documents handed back; Unigram: documents whose arc records did not fit
-    DevBuf w_uarcs, w_urounds, w_ulist;                          // Unigram in two stages (bf_uni_walk_body.h): arc records, round table, list of the flagged documents
+    DevBuf w_bwflags;                                            // BPE wave program: documents handed back
     DevBuf w_big;                                                // BPE: pool of the documents beyond the per-document arc reserve (k_bpe_seg)
     size_t bpe_pool_bytes = (size_t)64 << 20;                    // its size (BfSetBpePoolBytes; the host-buffer calls grow it when a batch needs more)
-    DevBuf t_hot_tag, t_hot_t, t_hot_i;                          // Unigram: hot tables of the lane program (bf_seg.h SG_HOT_*)
     DevBuf t_bpe_prio, t_bpe_place;                              // BPE with merges: the arc order as integers (bf_model.h bpe_prio / bpe_place_id)
     // workspaces
     DevBuf w_cls, w_nchars, w_tmp, w_counts, w_bsums, w_misc, w_flags, w_out, w_outoff;   // w_misc: [0] next_doc (u64), [2] status (int)
@@ -184,7 +182,7 @@ struct Handle {
         for (Handle *c : shards) if (c && c != this) { DeviceGuard dg(c->device); (void)hipDeviceSynchronize(); delete c; }
         shards.clear();
         pipe.release(); m_small.release();
-        for (DevBuf *b : {&t_hot_tag, &t_hot_t, &t_hot_i, &t_bpe_prio, &t_bpe_place, &t_dk_l1, &t_dk_pages, &t_dn_l1, &t_dn_pages, &t_dn_pool, &t_k2i, &t_rows, &w_keys, &w_keyoff, &w_dids, &w_dret, &w_vals, &t_i2w_off, &t_i2w_data, &t_kind, &t_wbd, &t_info, &t_acts, &t_cp_l1, &t_cp_pages, &t_multi, &t_wcp_l1, &t_wcp_pages, &t_dict, &t_seginfo, &w_s1, &w_s2, &w_s3, &w_s4, &w_big, &w_perm, &w_hist, &w_narcs, &w_bwflags, &w_uarcs, &w_urounds, &w_ulist, &w_cls, &w_nchars, &w_tmp, &w_counts, &w_flags, &w_out, &w_outoff,
+        for (DevBuf *b : {&t_bpe_prio, &t_bpe_place, &t_dk_l1, &t_dk_pages, &t_dn_l1, &t_dn_pages, &t_dn_pool, &t_k2i, &t_rows, &w_keys, &w_keyoff, &w_dids, &w_dret, &w_vals, &t_i2w_off, &t_i2w_data, &t_kind, &t_wbd, &t_info, &t_acts, &t_cp_l1, &t_cp_pages, &t_multi, &t_wcp_l1, &t_wcp_pages, &t_dict, &t_seginfo, &w_s1, &w_s2, &w_s3, &w_s4, &w_big, &w_perm, &w_hist, &w_narcs, &w_bwflags, &w_cls, &w_nchars, &w_tmp, &w_counts, &w_flags, &w_out, &w_outoff,
                           &w_bsums, &w_misc, &w_text, &w_docoff, &w_ids, &w_idoff, &w_starts, &w_ends, &w_srcoff, &w_span}) b->release();
         for (auto &e : ev) if (e) (void)hipEventDestroy(e);
         if (stream) (void)hipStreamDestroy(stream);
@@ -280,7 +278,6 @@ Handle *make_handle(const uint8_t *img, size_t size)
         ok = ok && upload(h->t_dict, m.dict.t64, 16) && upload(h->t_seginfo, m.seg_info, 16) &&
              upload(h->t_cp_l1, m.sp_cpmap.l1) && upload(h->t_cp_pages, m.sp_cpmap.pages) && upload(h->t_multi, m.sp_multi_pool, 16);
         if (m.kind == KIND_BPE_MERGES) ok = ok && upload(h->t_bpe_prio, m.bpe_prio, 16) && upload(h->t_bpe_place, m.bpe_place_id, 16);
-        if (!m.uni_hot_t.empty()) ok = ok && upload(h->t_hot_tag, m.uni_hot_tag) && upload(h->t_hot_t, m.uni_hot_t) && upload(h->t_hot_i, m.uni_hot_i);
     }
     if (m.has_i2w) ok = ok && upload(h->t_i2w_off, m.i2w_off, 4) && upload(h->t_i2w_data, m.i2w_data, 16);
     ok = ok && hip_ok(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking), "hipStreamCreate");
@@ -307,14 +304,6 @@ bool use_wave(const Handle *h, bool want_off, int words)
 // (Model::bpe_wave_ok); BfSetVariant bit 0x40 switches it off (A/B runs against the lane-per-document kernels alone)
 bool use_bpe_wave(const Handle *h, bool want_off) { return h->m.bpe_wave_ok && !want_off && (h->variant & 0x40) == 0; }
 
-// arc records of the two-stage Unigram path: ~1.6 - 1.9 per byte of multilingual text measured (tests/test_uni_walk_emu.py corpora); three per
-// byte reserved, plus the piece every wave may leave unfinished.  Documents that do not fit fall back to the lane-per-document program.
-size_t uni_pool_recs(int64_t ndocs, int64_t total_bytes)
-{
-    const int64_t waves = std::min<int64_t>(ndocs + 4, 256 * 32);
-    return (size_t)(3 * total_bytes + 2 * ndocs + 8192 * waves + 64);
-}
-
 bool reserve_ids_workspaces(Handle *h, int64_t ndocs, int64_t total_bytes, bool want_off, int words = 0)
 {
     const Model &m = h->m;
@@ -334,8 +323,6 @@ bool reserve_ids_workspaces(Handle *h, int64_t ndocs, int64_t total_bytes, bool 
         // one packed 4-byte record per stream element (bf_seg.h uni_rec; 8 bytes reserved); the sequential / flat variants keep 16-byte records
         const bool lane_form = uni_lane_ok(m);
         if (!h->w_s1.reserve(cap * (lane_form ? 4 : 16) + 64)) return false;
-        if (lane_form && !(h->w_uarcs.reserve(uni_pool_recs(ndocs, total_bytes) * 8) && h->w_urounds.reserve(((cap >> 6) + (size_t)ndocs + 8) * 8) &&
-                           h->w_bwflags.reserve((size_t)(ndocs + 1) * 4) && h->w_ulist.reserve((size_t)(ndocs + 1) * 4))) return false;
     } else {
         const size_t bm_words = (cap >> 5) + (size_t)ndocs + 4;
         if (!h->w_s1.reserve((6 * cap + 32 * (size_t)ndocs + 64) * 16) || !h->w_s2.reserve(std::max(cap * 4, 2 * bm_words * 4) + ((size_t)ndocs + 16) * 4) ||
@@ -414,23 +401,14 @@ int run_device(Handle *h, const char *d_text, const int64_t *d_doc_off, int64_t 
         (void)hipEventRecord(h->ev[EV_PREP], s);
         SpSegParams sg;
         sg.S.T = h->t_dict.as<uint64_t>(); sg.S.info = h->t_seginfo.as<SegInfo>(); sg.S.initial = m.dict.initial_base;
-        sg.S.cls_delim = m.sp_delim_code; sg.S.kind = m.kind; sg.S.id_offset = m.id_offset; sg.S.hot_tag = nullptr; sg.S.hot_t = nullptr; sg.S.hot_i = nullptr;
-        sg.hot_tag = m.uni_hot_t.empty() ? nullptr : h->t_hot_tag.as<uint16_t>(); sg.hot_t = m.uni_hot_t.empty() ? nullptr : h->t_hot_t.as<uint64_t>(); sg.hot_i = m.uni_hot_t.empty() ? nullptr : h->t_hot_i.as<uint64_t>();
+        sg.S.cls_delim = m.sp_delim_code; sg.S.kind = m.kind; sg.S.id_offset = m.id_offset;
         sg.b = b; sg.stream = h->w_cls.as<uint16_t>(); sg.lens = h->w_nchars.as<int32_t>(); sg.slot_mul = mul;
         sg.ids_tmp = h->w_tmp.as<int32_t>(); sg.counts = h->w_counts.as<int32_t>(); sg.span_tmp = want_off ? h->w_span.as<int32_t>() : nullptr; sg.max_ids = max_ids; sg.unk = unk; sg.status = status;
         sg.best = nullptr; sg.arcs = nullptr; sg.tos = nullptr; sg.idsv = nullptr; sg.inter = nullptr; sg.bm_words = 0; sg.fb_list = nullptr; sg.fb_count = nullptr;
         sg.big_pool = nullptr; sg.big_cap = 0; sg.big_used = (unsigned long long *)(h->w_misc.as<char>() + 32);     // zeroed with the status word above
         sg.big_need = (unsigned long long *)(h->w_misc.as<char>() + 40);
         sg.bpe_prio = nullptr; sg.bpe_place_id = nullptr; sg.bpe_unk_prio = 0; sg.bpe_prio_bits = m.bpe_prio_bits; sg.seg_stats = nullptr;
-        sg.uw_pool = nullptr; sg.uw_pool_recs = 0; sg.uw_cursor = nullptr; sg.uw_rounds = nullptr; sg.uw_flags = nullptr; sg.uw_list = nullptr; sg.uw_list_n = nullptr;
-        if (m.kind == KIND_UNIGRAM) {
-            sg.best = h->w_s1.as<SegBest>();
-            if (uni_lane_ok(m)) {
-                sg.uw_pool = h->w_uarcs.as<uint64_t>(); sg.uw_pool_recs = uni_pool_recs(ndocs, total_bytes); sg.uw_cursor = (unsigned long long *)(h->w_misc.as<char>() + 32);
-                sg.uw_rounds = h->w_urounds.as<uint64_t>(); sg.uw_flags = h->w_bwflags.as<int32_t>(); sg.uw_list = h->w_ulist.as<int32_t>(); sg.uw_list_n = (unsigned int *)(h->w_misc.as<char>() + 48);
-                sg.seg_stats = h->lex_stats ? (unsigned long long *)(h->w_misc.as<char>() + 64) : nullptr;
-            }
-        }
+        if (m.kind == KIND_UNIGRAM) sg.best = h->w_s1.as<SegBest>();
         else {
             const size_t bm_words = (cap >> 5) + (size_t)ndocs + 4;         // per bitmap: capacity + 1 bits per document (k_bpe_apply_flat)
             sg.bm_words = (int64_t)bm_words;
@@ -759,6 +737,10 @@ int64_t run_host_locked(Handle *h, const char *text, const int64_t *doc_off, int
     int64_t *dst_off = id_off_out;
     if (!dst_off) { tmp_off.resize((size_t)ndocs + 1); dst_off = tmp_off.data(); }
     if (!hip_ok(hipMemcpyAsync(dst_off, h->w_idoff.p, (size_t)(ndocs + 1) * 8, hipMemcpyDeviceToHost, s), "D2H offsets")) return BF_E_DEVICE;
+    // the id count through a word of its own: in the sharded path dst_off[ndocs] is also the first entry of the next range, which that
+    // range's thread writes concurrently
+    int64_t nids_word = 0;
+    if (!hip_ok(hipMemcpyAsync(&nids_word, h->w_idoff.as<int64_t>() + ndocs, 8, hipMemcpyDeviceToHost, s), "D2H id count")) return BF_E_DEVICE;
     int status = 0;
     if (!hip_ok(hipMemcpyAsync(&status, h->w_misc.as<char>() + 16, 4, hipMemcpyDeviceToHost, s), "D2H status")) return BF_E_DEVICE;
     int32_t nch0 = 0;
@@ -767,7 +749,7 @@ int64_t run_host_locked(Handle *h, const char *text, const int64_t *doc_off, int
     if (first_doc_nonempty) *first_doc_nonempty = nch0 > 0;
     if (status & (2 | BF_STATUS_INTERNAL)) return BF_E_INTERNAL;
     if (status & BF_STATUS_POOL) return BF_RETRY_POOL;
-    const int64_t nids = dst_off[ndocs];
+    const int64_t nids = nids_word;
     if (defer_ids) return nids;
     if (nids > ids_cap) return BF_E_CAPACITY;
     if (nids > 0) {

@@ -76,10 +76,7 @@ struct SpSegParams {
     int32_t *fb_list; unsigned int *fb_count;   // BPE: documents k_bpe_fused hands to the full path (set by launch_seg_sp)
     uint8_t *big_pool; unsigned long long big_cap; unsigned long long *big_used, *big_need;   // BPE: pool of the documents whose arcs exceed the per-document reserve (k_bpe_seg); *big_need: bytes that did not fit
     const uint32_t *bpe_prio; const int32_t *bpe_place_id; uint32_t bpe_unk_prio; int bpe_prio_bits;   // bf_bpe_seg_body.h: the arc order as integers (bf_model.h)
-    unsigned long long *seg_stats;   // optional (experiments): counters of k_bpe_seg / k_uni_walk
-    const uint16_t *hot_tag; const uint64_t *hot_t, *hot_i;      // Unigram: the model's hot tables in device memory (bf_seg.h SG_HOT_*), nullptr: none
-    // Unigram in two stages (bf_uni_walk_body.h): arc records, round table, flags + list of the documents whose records did not fit
-    uint64_t *uw_pool; unsigned long long uw_pool_recs; unsigned long long *uw_cursor; uint64_t *uw_rounds; int32_t *uw_flags; int32_t *uw_list; unsigned int *uw_list_n;
+    unsigned long long *seg_stats;   // optional (experiments): counters of k_bpe_seg
     int variant;
     int tune;                   // experiments: vote threshold of the lane-local BPE solve / Unigram transitions per trip (0 = default)
     int tune2;                  // experiments: resident waves per CU of the persistent segmenter kernels (0 = what fits)

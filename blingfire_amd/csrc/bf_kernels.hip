@@ -1675,27 +1675,15 @@ struct RingLds {
 // Unigram-LM, default form: bf_seg.h UniLane per lane, persistent lanes pulling documents (longest first).  Every trip of
 // the loop a walking lane makes UNROLL trie transitions and a lane in its backward pass makes one hop whose record was
 // requested BEFORE the walk steps (its latency hides behind them); finished lanes fetch new documents by vote.
-// NW waves per workgroup share the LDS copies of the model's hottest transitions and I2Info rows (bf_seg.h SG_HOT_*, when the model has
-// them: p.hot_t != nullptr and NW > 1); every wave has its own rings and is a persistent wave of its own otherwise
-template <int UNROLL, int NW>
-__global__ __launch_bounds__(64 * NW) void k_seg_unigram_lane(SpSegParams p, int ring_n)
+template <int UNROLL>
+__global__ __launch_bounds__(64) void k_seg_unigram_lane(SpSegParams p, int ring_n)
 {
-    extern __shared__ double seg_ring[];            // per wave: [ring_n][64] scores, then [ring_n][64] packed records; behind the NW waves: the hot tables
+    extern __shared__ double seg_ring[];            // [ring_n][64] scores, then [ring_n][64] packed records
     enum { M_NEED = 0, M_WALK = 1, M_BACK = 2, M_EXIT = 3 };
     const int lane = lane_id();
-    const size_t wave_doubles = (size_t)ring_n * 64 + (size_t)ring_n * 32;          // 8 + 4 bytes per slot and lane
-    double *my = seg_ring + (size_t)(NW > 1 ? wave_in_block() : 0) * wave_doubles;
-    RingLds ring{my + lane, (uint32_t *)(my + (size_t)ring_n * 64) + lane, ring_n - 1, ring_n};
-    SegTables S = p.S;
-    if (NW > 1 && p.hot_t) {
-        uint64_t *ht = (uint64_t *)(seg_ring + (size_t)NW * wave_doubles), *hi = ht + SG_HOT_T; uint16_t *hg = (uint16_t *)(hi + SG_HOT_I);
-        for (int k = (int)threadIdx.x; k < SG_HOT_T; k += 64 * NW) { ht[k] = p.hot_t[k]; hg[k] = p.hot_tag[k]; }
-        for (int k = (int)threadIdx.x; k < SG_HOT_I; k += 64 * NW) hi[k] = p.hot_i[k];
-        __syncthreads();
-        S.hot_t = ht; S.hot_i = hi; S.hot_tag = hg;
-    } else { S.hot_t = nullptr; S.hot_i = nullptr; S.hot_tag = nullptr; }
+    RingLds ring{seg_ring + lane, (uint32_t *)(seg_ring + (size_t)ring_n * 64) + lane, ring_n - 1, ring_n};
     ClsWin2 cls_at; cls_at.init(p.stream, 0);
-    UniLane<ClsWin2, RingLds> ul(S, cls_at, ring);
+    UniLane<ClsWin2, RingLds> ul(p.S, cls_at, ring);
     ul.L = 0; ul.depth = p.trie_depth; ul.start = ul.i = ul.sum = 0; ul.state = 0; ul.unknown = true; ul.pend = false; ul.prev = 0; ul.pend_i = 0;
     ul.pend_r.id = 0; ul.pend_r.score_bits = 0; ul.end = 0; ul.cnt = 0; ul.unk_run = 0; ul.q0 = ul.q1 = ul.q2 = ul.q3 = 0; ul.qn = 0; ul.abs0 = 0;
     int mode = M_NEED;
@@ -1714,9 +1702,9 @@ __global__ __launch_bounds__(64 * NW) void k_seg_unigram_lane(SpSegParams p, int
                     if (lane == leader) base = atomicAdd(p.next_doc, (unsigned long long)c);
                     base = __shfl(base, leader, 64);
                     const int64_t idx = (int64_t)base + __popcll(m_need & lanemask_lt());
-                    if (idx >= (p.fb_list ? (int64_t)*p.fb_count : p.b.ndocs)) mode = M_EXIT;      // fb_list: only the documents the walk kernel flagged (k_uni_walk)
+                    if (idx >= p.b.ndocs) mode = M_EXIT;
                     else {
-                        doc = p.fb_list ? p.fb_list[idx] : p.perm[idx];
+                        doc = p.perm[idx];
                         const int64_t b = p.b.doc_off[doc];
                         const int64_t slot = sp_slot(b, doc, p.slot_mul);
                         cap = p.slot_mul * (int)(p.b.doc_off[doc + 1] - b + 1);
@@ -1763,129 +1751,6 @@ __global__ __launch_bounds__(64 * NW) void k_seg_unigram_lane(SpSegParams p, int
         }
     }
     if (mode != M_EXIT) atomicOr(p.status, 2);      // trip limit hit: never expected
-}
-
-// ------------------------------------------------------------------------------------------
-// Unigram-LM in two stages (the default for models the lane program fits: entries of <= 32 symbols, ids < 2^20 - 2):
-//   k_uni_walk  bf_uni_walk_body.h: a wave walks the trie from 64 start positions at a time and leaves arc records -- every gather of
-//               the path, none of them dependent on a score, at an occupancy LDS does not limit;
-//   k_uni_dp    bf_seg.h UniArcLane per lane: the relaxations in the reference's arc order from those records (a sequential read of
-//               8 bytes per arc, no table), then the backward pass of k_seg_unigram_lane.
-// A document whose records do not fit the pool is flagged by the first stage and done by k_seg_unigram_lane afterwards.
-// ------------------------------------------------------------------------------------------
-} // namespace bfa
-#include "bf_uni_walk_body.h"
-namespace bfa {
-
-template <int ROWS, int NS>
-__global__ __launch_bounds__(256) void k_uni_walk(UniWalkParams p)
-{
-    __shared__ UwLds<ROWS, NS> lds[4];
-    UniWalk<UwLds<ROWS, NS>, ROWS, NS> w(p, lds[wave_in_block()]);
-    w.run();
-}
-
-template <int UNROLL>
-__global__ __launch_bounds__(64) void k_uni_dp(SpSegParams p, const uint64_t *pool, const uint64_t *rounds, const int32_t *flags, int ring_n)
-{
-    extern __shared__ double seg_ring[];            // [ring_n][64] scores, then [ring_n][64] packed records
-    enum { M_NEED = 0, M_WALK = 1, M_BACK = 2, M_EXIT = 3 };
-    const int lane = lane_id();
-    RingLds ring{seg_ring + lane, (uint32_t *)(seg_ring + (size_t)ring_n * 64) + lane, ring_n - 1, ring_n};
-    UniArcLane<RingLds> ul(ring, p.S.id_offset);
-    ul.L = 0; ul.depth = p.trie_depth; ul.start = 0; ul.prev = 0; ul.unk_run = 0; ul.q0 = ul.q1 = ul.q2 = ul.q3 = 0; ul.qn = 0; ul.abs0 = 0; ul.end = 0; ul.cnt = 0; ul.recs = nullptr;
-    int mode = M_NEED;
-    int64_t doc = 0; int32_t *ids = nullptr; int32_t *spans = nullptr; int cap = 0;
-    // the records of a round are read four at a time, one group ahead: c0 .. c3 = the group being relaxed (c0 next), n0 .. n3 = the group
-    // behind it, np = where the group after that starts; a group that reaches past the round's end is dropped at the round change
-    const uint64_t *np = nullptr, *rt = nullptr; int left = 0, rnd = 0, ci = 0; uint64_t c0 = 0, c1 = 0, c2 = 0, c3 = 0, n0 = 0, n1 = 0, n2 = 0, n3 = 0;
-    int32_t g0 = 0, g1 = 0, g2 = 0, g3 = 0; int gn = 0;
-    for (unsigned long long trip = 0; trip < (1ull << 34); ++trip) {
-        const unsigned long long m_need = __ballot(mode == M_NEED);
-        if (m_need) {
-            const unsigned long long m_busy = __ballot(mode == M_WALK || mode == M_BACK);
-            if (__popcll(m_need) >= 8 || m_busy == 0) {
-                if (mode == M_NEED) {
-                    const int c = __popcll(m_need);
-                    const int leader = __ffsll((long long)m_need) - 1;
-                    unsigned long long base = 0;
-                    if (lane == leader) base = atomicAdd(p.next_doc, (unsigned long long)c);
-                    base = __shfl(base, leader, 64);
-                    const int64_t idx = (int64_t)base + __popcll(m_need & lanemask_lt());
-                    if (idx >= p.b.ndocs) mode = M_EXIT;
-                    else {
-                        doc = p.perm[idx];
-                        const int64_t b = p.b.doc_off[doc];
-                        const int64_t slot = sp_slot(b, doc, p.slot_mul);
-                        cap = p.slot_mul * (int)(p.b.doc_off[doc + 1] - b + 1);
-                        const int L = p.lens[doc];
-                        ids = p.ids_tmp + slot; spans = p.span_tmp ? p.span_tmp + 2 * slot : nullptr;
-                        if (L <= 0) { p.counts[doc] = 0; p.narcs[doc] = 0; }
-                        else if (flags[doc]) {}                                   // its records did not fit: k_seg_unigram_lane does it
-                        else {
-                            ul.init(L, p.trie_depth, (uint32_t *)p.best + slot, slot);
-                            rt = rounds + uw_round_base(slot, doc); rnd = 0; left = L < 64 ? L : 64; ci = 0;
-                            np = pool + rt[0];
-                            c0 = np[0]; c1 = np[1]; c2 = np[2]; c3 = np[3]; n0 = np[4]; n1 = np[5]; n2 = np[6]; n3 = np[7]; np += 8;
-                            mode = M_WALK;
-                        }
-                    }
-                }
-                if (__ballot(mode != M_EXIT) == 0) break;
-            }
-        }
-        uint32_t br = 0;
-        const bool back = mode == M_BACK;
-        if (back) br = ul.recs[ul.end];
-        if (mode == M_WALK) {
-            bool walk = true;
-#pragma unroll
-            for (int u = 0; u < UNROLL; ++u) {
-                if (walk) {
-                    const uint64_t rec = c0;
-                    const bool ends = ((uint32_t)rec & (UA_LAST | UA_UNK)) != 0;
-                    if (ends) --left;
-                    const bool doc_done = ends && ul.start + 1 >= ul.L;
-                    if (!doc_done) {
-                        if (left == 0) {                                           // the next round starts somewhere else
-                            ++rnd; np = pool + rt[rnd]; const int rest = ul.L - rnd * 64; left = rest < 64 ? rest : 64; ci = 0;
-                            c0 = np[0]; c1 = np[1]; c2 = np[2]; c3 = np[3]; n0 = np[4]; n1 = np[5]; n2 = np[6]; n3 = np[7]; np += 8;
-                        } else if (++ci == 4) { c0 = n0; c1 = n1; c2 = n2; c3 = n3; n0 = np[0]; n1 = np[1]; n2 = np[2]; n3 = np[3]; np += 4; ci = 0; }   // the group after next travels while this one is relaxed
-                        else { c0 = c1; c1 = c2; c2 = c3; }
-                    }
-                    walk = ul.astep((uint32_t)rec, (uint32_t)(rec >> 32));
-                }
-            }
-            if (!walk) { ul.begin_back(); mode = M_BACK; }
-        }
-        if (back) {
-            int32_t *dst = nullptr;
-            auto put = [&](int k, int id, int from, int to) {
-                g3 = g2; g2 = g1; g1 = g0; g0 = id; ++gn;
-                dst = ids + (cap - 1 - k);
-                if (spans) { spans[2 * (cap - 1 - k)] = from; spans[2 * (cap - 1 - k) + 1] = to; }
-            };
-            const bool more = ul.bstep(br, put, p.unk);
-            if (!more || (((uintptr_t)dst >> 2) & 3) == 0) {
-                if (gn == 4 && (((uintptr_t)dst >> 2) & 3) == 0) *(int4 *)dst = make_int4(g0, g1, g2, g3);
-                else { dst[0] = g0; if (gn > 1) dst[1] = g1; if (gn > 2) dst[2] = g2; if (gn > 3) dst[3] = g3; }
-                gn = 0;
-            }
-            if (!more) {
-                p.counts[doc] = ul.cnt < p.max_ids ? ul.cnt : p.max_ids;
-                p.narcs[doc] = cap - ul.cnt;
-                mode = M_NEED;
-            }
-        }
-    }
-    if (mode != M_EXIT) atomicOr(p.status, 2);      // trip limit hit: never expected
-}
-
-// flags (set by k_uni_walk) -> the list k_seg_unigram_lane takes its documents from
-__global__ __launch_bounds__(256) void k_uni_flag_list(const int32_t *flags, const int32_t *lens, int64_t ndocs, int32_t *list, unsigned int *count)
-{
-    const int64_t d = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (d < ndocs && lens[d] > 0 && flags[d]) list[atomicAdd(count, 1u)] = (int32_t)d;
 }
 
 // BPE, documents whose arcs exceed the per-document reserve (narcs == -1 on the fallback list; a long run of one character whose
@@ -1952,80 +1817,19 @@ void launch_seg_sp(const SpSegParams &p_in, hipStream_t s)
         else {
             int ring = 1; while (ring < p.trie_depth) ring <<= 1;
             const size_t lds = (size_t)ring * 64 * (sizeof(double) + sizeof(uint32_t));
+            int per_cu = 0;
             const int unroll = p.tune ? p.tune : 3;
-            // the lane program: one wave per workgroup, or (models with hot tables, bf_seg.h SG_HOT_*; variant 6 switches it off for A/B runs)
-            // eight waves per workgroup sharing the LDS copies of the tables: 8 x 12 KB of rings + 56 KB of tables = one workgroup per CU
-            auto lane_kernel = [&](const SpSegParams &q, unsigned want_blocks) {
-                const bool hot = q.hot_t && q.variant != 6 && ring <= 16;
-                if (hot) {
-                    constexpr int NW = 8;
-                    const size_t lds8 = (size_t)NW * lds + (size_t)SG_HOT_T * 10 + (size_t)SG_HOT_I * 8;
-                    static bool attr_set = false;
-                    if (!attr_set) { (void)hipFuncSetAttribute((const void *)k_seg_unigram_lane<3, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8); (void)hipGetLastError(); attr_set = true; }
-                    int per_cu = 0;
-                    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k_seg_unigram_lane<3, NW>, 64 * NW, lds8) != hipSuccess || per_cu <= 0) per_cu = 1;
-                    (void)hipGetLastError();
-                    unsigned blocks = (unsigned)device_cus() * (unsigned)per_cu;
-                    const unsigned wb = (want_blocks + NW - 1) / NW;
-                    if (blocks > wb) blocks = wb;
-                    hipLaunchKernelGGL((k_seg_unigram_lane<3, NW>), dim3(blocks), dim3(64 * NW), lds8, s, q, ring);
-                    return;
-                }
-                int per_cu = 0;
-                auto kern = unroll == 1 ? (const void *)k_seg_unigram_lane<1, 1> : unroll == 2 ? (const void *)k_seg_unigram_lane<2, 1> :
-                            unroll == 4 ? (const void *)k_seg_unigram_lane<4, 1> : (const void *)k_seg_unigram_lane<3, 1>;
-                if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 64, lds) != hipSuccess || per_cu <= 0) per_cu = 8;
-                (void)hipGetLastError();
-                if (p.tune2 > 0 && p.tune2 < per_cu) per_cu = p.tune2;
-                unsigned blocks = (unsigned)device_cus() * (unsigned)per_cu;
-                if (blocks > want_blocks) blocks = want_blocks;
-                if (unroll == 1) hipLaunchKernelGGL((k_seg_unigram_lane<1, 1>), dim3(blocks), dim3(64), lds, s, q, ring);
-                else if (unroll == 2) hipLaunchKernelGGL((k_seg_unigram_lane<2, 1>), dim3(blocks), dim3(64), lds, s, q, ring);
-                else if (unroll == 4) hipLaunchKernelGGL((k_seg_unigram_lane<4, 1>), dim3(blocks), dim3(64), lds, s, q, ring);
-                else hipLaunchKernelGGL((k_seg_unigram_lane<3, 1>), dim3(blocks), dim3(64), lds, s, q, ring);
-            };
-            if (!p.uw_pool || (p.variant != 7 && p.variant != 8 && p.variant != 9)) lane_kernel(p, b64);      // the two-stage form is not the default yet (variants 7 / 8 / 9)
-            else {
-                // ---- stage 1: the walks
-                UniWalkParams w;
-                w.T = p.S.T; w.info = p.S.info; w.initial = p.S.initial;
-                w.stream = p.stream; w.lens = p.lens; w.doc_off = p.b.doc_off; w.slot_mul = p.slot_mul; w.ndocs = p.b.ndocs; w.perm = p.perm;
-                w.pool = p.uw_pool; w.pool_recs = p.uw_pool_recs; w.pool_cursor = p.uw_cursor; w.rounds = p.uw_rounds; w.flags = p.uw_flags;
-                w.next_doc = p.next_doc; w.stats = p.seg_stats;
-                {
-                    // instances: 16 entries per start x 2 starts per lane (exact for every model with entries of <= 16 symbols), 8 x 4 (a start
-                    // with more than 8 entries sends its document to the lane program), 32 x 1 (entries of up to 32 symbols)
-                    const int inst = p.trie_depth > 16 ? 0 : p.variant == 8 ? 2 : p.variant == 9 ? 3 : 1;
-                    const void *kern = inst == 0 ? (const void *)k_uni_walk<32, 1> : inst == 2 ? (const void *)k_uni_walk<8, 4> : inst == 3 ? (const void *)k_uni_walk<16, 1> : (const void *)k_uni_walk<16, 2>;
-                    int per_cu = 0;
-                    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 256, 0) != hipSuccess || per_cu <= 0) per_cu = 4;
-                    (void)hipGetLastError();
-                    if (p.tune2 > 0 && p.tune2 < per_cu) per_cu = p.tune2;
-                    unsigned blocks = (unsigned)device_cus() * (unsigned)per_cu;
-                    const unsigned need = (unsigned)((p.b.ndocs + 3) / 4);
-                    if (blocks > need) blocks = need;
-                    if (inst == 0) hipLaunchKernelGGL((k_uni_walk<32, 1>), dim3(blocks), dim3(256), 0, s, w);
-                    else if (inst == 2) hipLaunchKernelGGL((k_uni_walk<8, 4>), dim3(blocks), dim3(256), 0, s, w);
-                    else if (inst == 3) hipLaunchKernelGGL((k_uni_walk<16, 1>), dim3(blocks), dim3(256), 0, s, w);
-                    else hipLaunchKernelGGL((k_uni_walk<16, 2>), dim3(blocks), dim3(256), 0, s, w);
-                }
-                // ---- stage 2: the relaxations and the backward pass
-                (void)hipMemsetAsync(p.next_doc, 0, sizeof(unsigned long long), s);
-                {
-                    int per_cu = 0;
-                    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_uni_dp<4>, 64, lds) != hipSuccess || per_cu <= 0) per_cu = 8;
-                    (void)hipGetLastError();
-                    unsigned blocks = (unsigned)device_cus() * (unsigned)per_cu;
-                    if ((int64_t)blocks > (int64_t)b64) blocks = b64;
-                    hipLaunchKernelGGL(k_uni_dp<4>, dim3(blocks), dim3(64), lds, s, p, (const uint64_t *)p.uw_pool, (const uint64_t *)p.uw_rounds, (const int32_t *)p.uw_flags, ring);
-                }
-                // ---- the documents whose records did not fit (normally none): the lane-per-document program
-                (void)hipMemsetAsync(p.next_doc, 0, sizeof(unsigned long long), s);
-                (void)hipMemsetAsync(p.uw_list_n, 0, sizeof(unsigned int), s);
-                hipLaunchKernelGGL(k_uni_flag_list, dim3((unsigned)((p.b.ndocs + 255) / 256)), dim3(256), 0, s, (const int32_t *)p.uw_flags, p.lens, p.b.ndocs, p.uw_list, p.uw_list_n);
-                SpSegParams q = p; q.fb_list = p.uw_list; q.fb_count = p.uw_list_n;
-                lane_kernel(q, (unsigned)device_cus());
-            }
+            auto kern = unroll == 1 ? (const void *)k_seg_unigram_lane<1> : unroll == 2 ? (const void *)k_seg_unigram_lane<2> :
+                        unroll == 4 ? (const void *)k_seg_unigram_lane<4> : (const void *)k_seg_unigram_lane<3>;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 64, lds) != hipSuccess || per_cu <= 0) per_cu = 8;
+            (void)hipGetLastError();
+            if (p.tune2 > 0 && p.tune2 < per_cu) per_cu = p.tune2;
+            unsigned blocks = (unsigned)device_cus() * (unsigned)per_cu;
+            if ((int64_t)blocks > (int64_t)b64) blocks = b64;
+            if (unroll == 1) hipLaunchKernelGGL(k_seg_unigram_lane<1>, dim3(blocks), dim3(64), lds, s, p, ring);
+            else if (unroll == 2) hipLaunchKernelGGL(k_seg_unigram_lane<2>, dim3(blocks), dim3(64), lds, s, p, ring);
+            else if (unroll == 4) hipLaunchKernelGGL(k_seg_unigram_lane<4>, dim3(blocks), dim3(64), lds, s, p, ring);
+            else hipLaunchKernelGGL(k_seg_unigram_lane<3>, dim3(blocks), dim3(64), lds, s, p, ring);
         }
     } else {
         SpSegParams p = p_in;

@@ -2,13 +2,8 @@
 // build the displacement-packed tables and code-point maps the kernels consume.
 #include "bf_model.h"
 #include "bf_layout.h"
-#if defined(__HIPCC__)
-#include <hip/hip_runtime.h>      // bf_seg.h is host + device code
-#endif
-#include "bf_seg.h"
 
 #include <algorithm>
-#include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <functional>
@@ -1000,39 +995,6 @@ bool build_model(Model &m, const uint8_t *img, size_t size)
         }
         m.seg_info.resize(m.i2info_id.size());
         for (size_t k = 0; k < m.i2info_id.size(); ++k) m.seg_info[k] = (uint64_t)(uint32_t)m.i2info_id[k] | ((uint64_t)m.i2info_score[k] << 32);
-        if (m.kind == KIND_UNIGRAM && m.trie_max_depth > 0 && m.trie_max_depth < 0x7fffffff && m.dict.t64.size() < ((size_t)1 << 22) && m.seg_info.size() < ((size_t)0x7FF << SG_HOT_I_LOG)) {
-            // bf_seg.h SG_HOT_*: the mass of an edge = sum of exp(score) over the entries in the subtree below it (the unigram scores are log
-            // probabilities: how often a walk takes the edge); a slot keeps the heaviest edge / row that maps to it
-            const RawDfa &rw = m.dict_raw;
-            std::vector<int> cls_of_sym;
-            { int mx = 0; for (int sy : m.dict.sym_of_class) mx = std::max(mx, sy); cls_of_sym.assign((size_t)mx + 1, -1); for (size_t c = 0; c < m.dict.sym_of_class.size(); ++c) cls_of_sym[(size_t)m.dict.sym_of_class[c]] = (int)c; }
-            m.uni_hot_tag.assign((size_t)SG_HOT_T, (uint16_t)0xFFFF); m.uni_hot_t.assign((size_t)SG_HOT_T, ~0ull); m.uni_hot_i.assign((size_t)SG_HOT_I, ~0ull);
-            std::vector<double> mass_t((size_t)SG_HOT_T, -1.0), mass_i((size_t)SG_HOT_I, -1.0);
-            std::function<double(int, int)> dfs = [&](int st, int sum) -> double {
-                double mass = 0;
-                for (uint32_t t = rw.tr_begin[(size_t)st]; t < rw.tr_begin[(size_t)st + 1]; ++t) {
-                    const int dst = rw.tr_dst[t]; if (dst < 0) continue;
-                    const int sum2 = sum + rw.tr_ow[t];
-                    double sub = dfs(dst, sum2);
-                    if (rw.is_final[(size_t)dst] && sum2 >= 0 && (size_t)sum2 < m.i2info_id.size() && m.i2info_valid[(size_t)sum2]) {
-                        float f; const uint32_t b = m.i2info_score[(size_t)sum2]; memcpy(&f, &b, 4);
-                        const double pm = std::exp((double)f);
-                        sub += pm;
-                        const uint32_t k = (uint32_t)sum2, slot = k & (uint32_t)(SG_HOT_I - 1);
-                        if (pm > mass_i[slot] && m.i2info_id[(size_t)sum2] >= -1 && m.i2info_id[(size_t)sum2] < (1 << 20)) { mass_i[slot] = pm; m.uni_hot_i[slot] = sg_hot_i_word(k, m.i2info_id[(size_t)sum2], m.i2info_score[(size_t)sum2]); }
-                    }
-                    const int sy = rw.tr_sym[t];
-                    const int c = sy >= 0 && (size_t)sy < cls_of_sym.size() ? cls_of_sym[(size_t)sy] : -1;
-                    if (c >= 0) {
-                        const uint32_t idx = m.dict.state_base[(size_t)st] + (uint32_t)c, slot = idx & (uint32_t)(SG_HOT_T - 1);
-                        if (sub > mass_t[slot] && idx < m.dict.t64.size()) { mass_t[slot] = sub; m.uni_hot_tag[slot] = (uint16_t)(idx >> SG_HOT_T_LOG); m.uni_hot_t[slot] = m.dict.t64[idx]; }
-                    }
-                    mass += sub;
-                }
-                return mass;
-            };
-            dfs(rw.initial, 0);
-        }
         if (m.kind == KIND_BPE || m.kind == KIND_BPE_OPT || m.kind == KIND_BPE_MERGES) {
             bool ids_ok = true;
             for (size_t k = 0; k < m.i2info_id.size(); ++k) if (m.i2info_valid[k] && (m.i2info_id[k] < 0 || m.i2info_id[k] >= (1 << 20))) ids_ok = false;

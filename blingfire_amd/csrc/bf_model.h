@@ -159,8 +159,6 @@ struct Model {
     // of a call (bpe_unk_prio).  bpe_seg_ok: ids and depth fit the arc keys (ids in [0, 2^20), entries of <= 256 symbols).
     std::vector<uint32_t> bpe_prio; std::vector<int32_t> bpe_place_id; std::vector<uint32_t> bpe_place_rank;   // bpe_place_rank: rank bits of the entry at a place
     int bpe_prio_bits = 0; bool bpe_seg_ok = false;
-    // Unigram: the hottest transitions / I2Info rows for the lane program's LDS tables (bf_seg.h SG_HOT_*); empty: none
-    std::vector<uint16_t> uni_hot_tag; std::vector<uint64_t> uni_hot_t, uni_hot_i;
     // fused "code point (or byte) -> charmap -> element code" map of the _sp prologue.  Element codes (u16):
     //   class of the dictionary alphabet | SP_NONE (not in alphabet) | SP_WS (whitespace, tokdll.h:17-21) |
     //   SP_DELIM_ABSENT (U+2581 when the alphabet lacks it).  Value = code, or FUSED_MULTI | pool offset

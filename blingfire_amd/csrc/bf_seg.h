@@ -36,39 +36,7 @@ struct SegTables {
     uint32_t initial;
     uint32_t cls_delim;         // class-stream value of U+2581
     int kind, id_offset;
-    // optional (Unigram lane program): the model's hottest transitions and I2Info rows, direct-mapped by the low bits of the table index /
-    // MPH index (bf_model.cpp uni_hot_*; in LDS on the device).  nullptr: none
-    const uint16_t *hot_tag; const uint64_t *hot_t, *hot_i;
 };
-
-// The lane program's gathers are bound by the number of L2 requests (measured on MI355X, profiles/r04_*: three different kernels with the
-// same gathers take the same 33.6 ms per 2.5 M documents), and the vector L1 holds a few hundred 128-byte lines for 8-byte entries.  A table
-// of a few thousand eight-byte words in LDS, filled at load with the edges / rows that carry the most probability mass (exp(score) summed
-// over the entries below an edge), answers about half of the transition gathers and three quarters of the I2Info gathers of multilingual
-// text (tests/hosttest bft_uni_static_cache_sim).
-//   transitions: slot = index & (SG_HOT_T - 1), hot_tag[slot] = index >> SG_HOT_T_LOG (0xFFFF: empty), hot_t[slot] = the table entry itself
-//   (so the class check of a lookup is the one the table gets);  rows: slot = MPH index & (SG_HOT_I - 1), hot_i[slot] = sg_hot_i_word();
-//   an empty slot is all ones (no MPH index reaches the tag 0x7FF: checked when the table is made)
-constexpr int SG_HOT_T_LOG = 12, SG_HOT_T = 1 << SG_HOT_T_LOG, SG_HOT_I_LOG = 11, SG_HOT_I = 1 << SG_HOT_I_LOG;
-// rows: [63:53] MPH index >> SG_HOT_I_LOG (MPH indices are < 2^22), [52:32] id + 1, [31:0] score bits
-BF_HD uint64_t sg_hot_i_word(uint32_t mph, int32_t id, uint32_t score_bits) { return ((uint64_t)(mph >> SG_HOT_I_LOG) << 53) | ((uint64_t)((uint32_t)(id + 1) & 0x1FFFFFu) << 32) | (uint64_t)score_bits; }
-// the entry at table index idx (the caller checks its class)
-BF_HD uint64_t sg_entry(const SegTables &S, uint32_t idx)
-{
-    if (S.hot_t) {
-        const uint32_t slot = idx & (uint32_t)(SG_HOT_T - 1);
-        if ((uint32_t)S.hot_tag[slot] == (idx >> SG_HOT_T_LOG)) return S.hot_t[slot];
-    }
-    return S.T[idx];
-}
-BF_HD SegInfo sg_info(const SegTables &S, int mph)
-{
-    if (S.hot_i) {
-        const uint64_t w = S.hot_i[(uint32_t)mph & (uint32_t)(SG_HOT_I - 1)];
-        if ((w >> 53) == (uint64_t)((uint32_t)mph >> SG_HOT_I_LOG)) { SegInfo r; r.id = (int32_t)((w >> 32) & 0x1FFFFFu) - 1; r.score_bits = (uint32_t)w; return r; }
-    }
-    return S.info[mph];
-}
 
 struct SegArc { int32_t start, end, id; uint32_t rank_bits; };   // BPE arc (…_bpe_t.h:66-88, …_with_merges_t.h)
 
@@ -161,13 +129,36 @@ constexpr uint32_t UNI_REC_NONE = 0xFFFFFFFFu, UNI_LEN_MAX = 4095u;
 constexpr int UNI_MAX_ID = (1 << 20) - 3;
 BF_HD uint32_t uni_rec(int id, int len) { const uint32_t l = (uint32_t)(len - 1); return ((uint32_t)(id + 1) & 0xFFFFFu) | ((l < UNI_LEN_MAX ? l : UNI_LEN_MAX) << 20); }
 
-// what the two forward programs (UniLane below: trie walks; UniArcLane: arc records) share: the final records of the positions, stored
-// in aligned groups of four, and the backward pass over them
-struct UniRecOut {
-    uint32_t *recs; int L; int id_off;
+template <class ClsAt, class Ring>
+struct UniLane {
+    const SegTables &S; ClsAt &cls_at; Ring &ring; uint32_t *recs;
+    int L, depth, start, i, sum; uint32_t state; bool unknown, pend; double prev; SegInfo pend_r; int pend_i;
+    int unk_run;                                       // length of the unknown run that ends at start - 1 (0: that position is not unknown)
     uint32_t q0, q1, q2, q3; int qn;                   // final records of the last positions, not yet stored (qn of them, q3 newest)
     int64_t abs0;                                      // absolute element index of position 0 (16-byte store groups are aligned on it)
     int end, cnt;                                      // backward pass
+
+    BF_HD UniLane(const SegTables &S_, ClsAt &c, Ring &r) : S(S_), cls_at(c), ring(r), recs(nullptr) {}
+
+    static BF_HD double neg_flt_max() { return -3.40282346638528859811704183484516925e+38; }   // (double)-FLT_MAX
+
+    // Start a document of L >= 1 stream elements; recs_ has room for L records and is element abs0_ of a 16-byte aligned array.
+    BF_HD void init(int L_, int depth_, uint32_t *recs_, int64_t abs0_)
+    {
+        L = L_; depth = depth_; recs = recs_; abs0 = abs0_;
+        ring.fill(neg_flt_max());
+        start = 0; i = 0; state = S.initial; sum = 0; unknown = true; prev = 0; pend = false; pend_i = 0; pend_r.id = 0; pend_r.score_bits = 0;
+        unk_run = 0; q0 = q1 = q2 = q3 = 0; qn = 0;
+        end = 0; cnt = 0;
+        cls_at.seek(0);
+    }
+
+    BF_HD void relax()                                 // AddArc (..._1best_t.h:118-142) of the pending final transition
+    {
+        const double cand = sg_bits_to_float(pend_r.score_bits) + prev;
+        if (ring.score(pend_i) < cand) ring.set(pend_i, cand, uni_rec(pend_r.id, pend_i - start + 1));
+        pend = false;
+    }
 
     // the record of position p (= start) is final: queue it, store whole aligned groups of four
     BF_HD void finalize(int p, uint32_t r)
@@ -191,71 +182,19 @@ struct UniRecOut {
         }
     }
 
-    BF_HD void begin_back() { end = L - 1; cnt = 0; }
-    // One hop of the backward pass (..._1best_t.h:237-265) given r = recs[end] (read by the caller, so that a GPU driver can
-    // request it early): id k-from-the-end goes to put(k, ...).  Returns false after the last hop.
-    template <class IdPut>
-    BF_HD bool bstep(uint32_t r, IdPut &put, int unk)
-    {
-        int id = -1, begin = -1;
-        if (r != UNI_REC_NONE) {
-            id = (int)(r & 0xFFFFFu) - 1;
-            int64_t len = (int64_t)(r >> 20) + 1;
-            if ((r >> 20) == UNI_LEN_MAX) {                             // a long unknown run: add up 4095-position hops
-                int e = end; uint32_t rr = r; len = 0;
-                while ((rr >> 20) == UNI_LEN_MAX && e - (int)UNI_LEN_MAX >= 0) { len += UNI_LEN_MAX; e -= (int)UNI_LEN_MAX; rr = recs[e]; }
-                len += (int64_t)(rr >> 20) + 1;
-            }
-            begin = (int)((int64_t)end - len + 1);
-        }
-        put(cnt, (id != -1 ? id : unk) + id_off, begin, end);
-        ++cnt;
-        end = begin - 1;
-        return end >= 0;
-    }
-};
-
-template <class ClsAt, class Ring>
-struct UniLane : UniRecOut {
-    const SegTables &S; ClsAt &cls_at; Ring &ring;
-    int depth, start, i, sum; uint32_t state; bool unknown, pend; double prev; SegInfo pend_r; int pend_i;
-    int unk_run;                                       // length of the unknown run that ends at start - 1 (0: that position is not unknown)
-
-    BF_HD UniLane(const SegTables &S_, ClsAt &c, Ring &r) : S(S_), cls_at(c), ring(r) { recs = nullptr; id_off = S_.id_offset; }
-
-    static BF_HD double neg_flt_max() { return -3.40282346638528859811704183484516925e+38; }   // (double)-FLT_MAX
-
-    // Start a document of L >= 1 stream elements; recs_ has room for L records and is element abs0_ of a 16-byte aligned array.
-    BF_HD void init(int L_, int depth_, uint32_t *recs_, int64_t abs0_)
-    {
-        L = L_; depth = depth_; recs = recs_; abs0 = abs0_;
-        ring.fill(neg_flt_max());
-        start = 0; i = 0; state = S.initial; sum = 0; unknown = true; prev = 0; pend = false; pend_i = 0; pend_r.id = 0; pend_r.score_bits = 0;
-        unk_run = 0; q0 = q1 = q2 = q3 = 0; qn = 0;
-        end = 0; cnt = 0;
-        cls_at.seek(0);
-    }
-
-    BF_HD void relax()                                 // AddArc (..._1best_t.h:118-142) of the pending final transition
-    {
-        const double cand = sg_bits_to_float(pend_r.score_bits) + prev;
-        if (ring.score(pend_i) < cand) ring.set(pend_i, cand, uni_rec(pend_r.id, pend_i - start + 1));
-        pend = false;
-    }
-
     // One trie transition.  Returns false once the forward pass is complete (follow with begin_back / bstep).
     BF_HD bool wstep()
     {
         const uint32_t c = cls_at(i);
         const bool valid = c < SG_CLS_DELIM_ABSENT;                     // sg_lookup: symbols outside the alphabet never match
-        const uint64_t e = sg_entry(S, state + (valid ? c : 0u));       // the gather is issued (unless the hot table has the edge) ...
+        const uint64_t e = S.T[state + (valid ? c : 0u)];               // the gather is issued ...
         if (pend) relax();                                              // ... and the previous arc is relaxed while it travels
         const bool hit = valid && (e & SG_CLS_MASK) == c;
         bool ends = !hit;
         if (hit) {
             state = (uint32_t)((e >> SG_NEXT_SHIFT) & SG_NEXT_MASK);
             sum += (int)(e >> SG_OW_SHIFT);
-            if (e & SG_FINAL) { pend_r = sg_info(S, sum); pend_i = i; pend = true; unknown = false; }   // requested now, used next step
+            if (e & SG_FINAL) { pend_r = S.info[sum]; pend_i = i; pend = true; unknown = false; }   // requested now, used next step
             ++i;
             ends = i >= L;
         }
@@ -284,60 +223,28 @@ struct UniLane : UniRecOut {
         }
         return true;
     }
-};
 
-// ---------------------------------------------------------------------------------------------------
-// Unigram-LM, the forward pass from ARC RECORDS (bf_uni_walk_body.h writes them: the trie walks of all start positions do not depend
-// on the scores, so a wave makes them 64 starts at a time; what is sequential -- the relaxations in arc order, ..._1best_t.h:195-235
-// -- runs here, one document per lane, without a single table gather).  Records of a document come in the order the reference adds
-// its arcs: by start, then by end.  Record = two words:
-//   w0 = [id + 1 : 20 | length - 1 : 5 | UA_LAST: the start's last record | UA_UNK: the start has no arc (AddUnknownArc)], w1 = score bits
-// The relaxations and the end of a start are UniLane's, value for value.
-// ---------------------------------------------------------------------------------------------------
-constexpr uint32_t UA_LAST = 1u << 25, UA_UNK = 1u << 26, UA_REC_MASK = (1u << 25) - 1u;
-constexpr int UA_MAX_DEPTH = 32;
-BF_HD uint32_t ua_w0(int id, int len, bool last) { return ((uint32_t)(id + 1) & 0xFFFFFu) | ((uint32_t)(len - 1) << 20) | (last ? UA_LAST : 0u); }
-
-template <class Ring>
-struct UniArcLane : UniRecOut {
-    Ring &ring; int depth, start; double prev; int unk_run;
-
-    BF_HD UniArcLane(Ring &r, int id_offset) : ring(r) { recs = nullptr; id_off = id_offset; }
-    static BF_HD double neg_flt_max() { return -3.40282346638528859811704183484516925e+38; }
-
-    BF_HD void init(int L_, int depth_, uint32_t *recs_, int64_t abs0_)
+    BF_HD void begin_back() { end = L - 1; cnt = 0; }
+    // One hop of the backward pass (..._1best_t.h:237-265) given r = recs[end] (read by the caller, so that a GPU driver can
+    // request it early): id k-from-the-end goes to put(k, ...).  Returns false after the last hop.
+    template <class IdPut>
+    BF_HD bool bstep(uint32_t r, IdPut &put, int unk)
     {
-        L = L_; depth = depth_; recs = recs_; abs0 = abs0_;
-        ring.fill(neg_flt_max());
-        start = 0; prev = 0; unk_run = 0; q0 = q1 = q2 = q3 = 0; qn = 0; end = 0; cnt = 0;
-    }
-    // One record of the current start.  Returns false once the forward pass is complete (follow with begin_back / bstep).
-    BF_HD bool astep(uint32_t w0, uint32_t w1)
-    {
-        const bool unknown = (w0 & UA_UNK) != 0;
-        if (!unknown) {                                                 // AddArc (..._1best_t.h:118-142)
-            const int i = start + (int)((w0 >> 20) & 31u);
-            const double cand = sg_bits_to_float(w1) + prev;
-            if (ring.score(i) < cand) ring.set(i, cand, w0 & UA_REC_MASK);       // the low 25 bits are uni_rec(id, length)
-        }
-        if (w0 & (UA_LAST | UA_UNK)) {
-            double fin = ring.score(start);
-            uint32_t r = ring.rec(start);
-            int run = 0;
-            if (unknown) {                                              // AddUnknownArc (..._1best_t.h:145-171)
-                const float unk_score = -100000.0f;
-                const double cand = unk_score + prev;
-                if (fin < cand) { run = unk_run + 1; r = uni_rec(-1, run); fin = cand; }
+        int id = -1, begin = -1;
+        if (r != UNI_REC_NONE) {
+            id = (int)(r & 0xFFFFFu) - 1;
+            int64_t len = (int64_t)(r >> 20) + 1;
+            if ((r >> 20) == UNI_LEN_MAX) {                             // a long unknown run: add up 4095-position hops
+                int e = end; uint32_t rr = r; len = 0;
+                while ((rr >> 20) == UNI_LEN_MAX && e - (int)UNI_LEN_MAX >= 0) { len += UNI_LEN_MAX; e -= (int)UNI_LEN_MAX; rr = recs[e]; }
+                len += (int64_t)(rr >> 20) + 1;
             }
-            if (!(neg_flt_max() < fin)) r = UNI_REC_NONE;
-            unk_run = run;
-            finalize(start, r);
-            ++start;
-            if (!(start < L)) return false;
-            prev = fin;
-            ring.set(start + depth - 1, neg_flt_max(), UNI_REC_NONE);
+            begin = (int)((int64_t)end - len + 1);
         }
-        return true;
+        put(cnt, (id != -1 ? id : unk) + S.id_offset, begin, end);
+        ++cnt;
+        end = begin - 1;
+        return end >= 0;
     }
 };
 

@@ -25,7 +25,6 @@ using namespace bfa;
 #include "hosttest.h"
 
 static long g_big_pool = 64l << 20;   // bft_set_big_pool: bytes of the pool behind seg_bpe_doc_big (the device's is 64 MiB per batch)
-static int g_no_hot = 0;      // bft_set_no_hot(1): without the hot tables
 static int g_uni_seq = 0;     // bft_set_uni_seq(1): Unigram through the plain sequential restatement (seg_unigram_doc) instead of UniLane
 static int g_general = 0;     // bft_set_general(1): the general lexer machine even for two-level models (A/B in tests)
 static int g_no_ff = 0;       // bft_set_no_ff(1): run the lexer emulation without the loop-state fast-forward (A/B in tests)
@@ -58,7 +57,6 @@ void bft_set_general(int v) { g_general = v; }
 int bft_two_level(void *hv) { return ((Handle *)hv)->m.two_level ? 1 : 0; }
 int bft_fn_no_ra(void *hv) { return ((Handle *)hv)->m.fn_no_ra ? 1 : 0; }
 void bft_set_uni_seq(int v) { g_uni_seq = v; }
-void bft_set_no_hot(int v) { g_no_hot = v; }
 void bft_set_big_pool(long v) { g_big_pool = v; }
 // loop state facts: out[0] = base (-1: none), [1] = number of flagged classes, [2] = final, [3] = info
 void bft_loop_state(void *hv, long *out) { Model &m = ((Handle *)hv)->m; out[0] = m.loop_base == 0xFFFFFFFFu ? -1 : (long)m.loop_base; long n = 0; for (uint8_t b : m.loop_cls) n += b; out[1] = n; out[2] = m.loop_final; out[3] = m.loop_info; }
@@ -275,8 +273,6 @@ static int emu_sp(const Model &m, const char *s, int n, int32_t *ids, int32_t *s
     SegTables S;
     S.T = m.dict.t64.data(); S.info = (const SegInfo *)m.seg_info.data(); S.initial = m.dict.initial_base; S.cls_delim = D;
     S.kind = m.kind; S.id_offset = m.id_offset;
-    // the lane program's hot tables (in LDS on the device): the host runs the same lookups
-    S.hot_tag = m.uni_hot_t.empty() || g_no_hot ? nullptr : m.uni_hot_tag.data(); S.hot_t = S.hot_tag ? m.uni_hot_t.data() : nullptr; S.hot_i = S.hot_tag ? m.uni_hot_i.data() : nullptr;
     const uint16_t *cp = st.data();
     auto cls_at = [cp](int i) -> uint32_t { return cp[i]; };
     IdOutDirect out{ids, spans};
