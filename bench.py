@@ -63,6 +63,7 @@ def parse_args():
     ap.add_argument("--cpu-sample-docs", type=int, default=0)
     ap.add_argument("--verify", default="full", help="'full' (default): every document of the shard against the CPU checker; N: the first N; 0: none")
     ap.add_argument("--no-extra-timings", action="store_true", help="skip the PCIe-inclusive / host-API timings and the lexer transition count")
+    ap.add_argument("--offsets", action="store_true", help="time TextToIdsWithOffsetsBatchDevice (ids + byte offsets of every id) instead of TextToIdsBatchDevice; single-process form only")
     ap.add_argument("--inproc", action="store_true", help="N GPUs from ONE process through the library (BfSetDevices + the per-range handles, a thread per device) instead of N ranks")
     return ap.parse_args()
 
@@ -390,10 +391,19 @@ def main():
         cap = max(1, min(2 * (nb + nd), nd * max_ids))
         batches.append(dict(d0=d0, d1=d1, text=d_text_all[b0:b1], off=(d_off_all[d0:d1 + 1] - b0).contiguous(),
                             ids=torch.empty(cap, dtype=torch.int32, device=dev), id_off=torch.empty(nd + 1, dtype=torch.int64, device=dev)))
+        if args.offsets:
+            batches[-1]["starts"] = torch.empty(cap, dtype=torch.int32, device=dev); batches[-1]["ends"] = torch.empty(cap, dtype=torch.int32, device=dev)
 
     def step(collect_ms=None):
         for b in batches:
-            bf.text_to_ids_batch_device(h, b["text"], b["off"], max_ids, unk, out_ids=b["ids"], out_off=b["id_off"])
+            if args.offsets:
+                r = bf.lib().TextToIdsWithOffsetsBatchDevice(ctypes.c_void_p(h), b["text"].data_ptr(), b["off"].data_ptr(), b["d1"] - b["d0"], b["text"].numel(), b["ids"].data_ptr(),
+                                                             b["starts"].data_ptr(), b["ends"].data_ptr(), b["ids"].numel(), b["id_off"].data_ptr(), max_ids, unk,
+                                                             ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+                if r != 0:
+                    raise SystemExit("bench: TextToIdsWithOffsetsBatchDevice failed (%d)" % r)
+            else:
+                bf.text_to_ids_batch_device(h, b["text"], b["off"], max_ids, unk, out_ids=b["ids"], out_off=b["id_off"])
             if collect_ms is not None:
                 collect_ms += np.array(bf.last_kernel_ms(h), dtype=np.float64)   # HIP events recorded on the launch stream
 
@@ -441,6 +451,25 @@ def main():
                 verified += p1 - p0
                 del c_ids
 
+    offsets_verified = 0
+    if args.offsets and nv > 0:
+        # the byte offsets of every id of a sample of documents against the checker's TextToIdsWithOffsets (one call per document)
+        ck = bfutil.reference() if bfutil.have_ref() else bfutil.oracle()
+        hck = ck.load(bfutil.model_path(model_name))
+        name = "TextToIdsWithOffsets" if bfutil.have_ref() else "bfo_text_to_ids_with_offsets"
+        b = batches[0]
+        k = min(2000, b["d1"] - b["d0"], nv)
+        g_off = b["id_off"][:k + 1].cpu().numpy(); hi = int(g_off[k])
+        g_ids, g_st, g_en = b["ids"][:hi].cpu().numpy(), b["starts"][:hi].cpu().numpy(), b["ends"][:hi].cpu().numpy()
+        for d in range(k):
+            doc = bytes(text[off[d]:off[d + 1]])
+            c, gi, gs, ge = ck.with_offsets(hck, doc, max_ids, unk, name)
+            a, z = int(g_off[d]), int(g_off[d + 1])
+            if (z - a, g_ids[a:z].tolist(), g_st[a:z].tolist(), g_en[a:z].tolist()) != (c, gi[:c], gs[:c], ge[:c]):
+                raise SystemExit("bench: offsets of document %d differ from the CPU checker -- refusing to time" % d)
+        ck.free(hck)
+        offsets_verified = k
+
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize(dev)
@@ -486,7 +515,7 @@ def main():
         ids_all = sum(r["ids"] for r in ranks)
         value = docs_all * args.steps / elapsed
         # algorithmic bytes of one step's launches of the dominant kernel on THIS rank: n_in + 4*n_ids + 16 per document
-        alg_bytes = total_bytes + 4 * n_ids + 16 * ndocs
+        alg_bytes = total_bytes + (12 if args.offsets else 4) * n_ids + 16 * ndocs      # with offsets: id + first byte + last byte per id
         tok_ms = float(kms[1])
         achieved = alg_bytes / (tok_ms * 1e-3) / 1e9 if tok_ms > 0 else 0.0
         traffic, traffic_stale, l2_hit = None, None, None
@@ -511,6 +540,7 @@ def main():
                 args.workload, model_name, docs_all, ndocs, bytes_all / max(docs_all, 1), max_ids, unk),
                 "model_file": model_name, "total_docs": docs_all, "total_bytes": bytes_all, "total_ids": ids_all,
                 "docs_per_gpu": ndocs, "sub_batches_per_step": len(batches),
+                "api": "TextToIdsWithOffsetsBatchDevice (ids + first / last byte of every id)" if args.offsets else "TextToIdsBatchDevice",
                 "sharding": "static contiguous document ranges, no collective"},
             "gb_input_per_sec": bytes_all * args.steps / elapsed / 1e9,
             "ids_per_sec": ids_all * args.steps / elapsed,
@@ -528,6 +558,8 @@ def main():
             "status": max(r["status"] for r in ranks), "ranks": ranks,
             "backend": (dist.get_backend() if dist else None),
         }
+        if args.offsets:
+            res["verify"]["offsets"] = "start / end byte offsets of every id of the first %d documents against the checker's TextToIdsWithOffsets" % offsets_verified
 
     # ---- the other two timings of SURVEY.md section 8(d) and the work-rate roofline (rank 0, N=1 only; bounded sample)
     if rank == 0 and world == 1 and not args.no_extra_timings:

@@ -147,6 +147,7 @@ struct Handle {
     DevBuf t_kind;                                               // unit-form lexers: what a walk that starts on each class does (bf_wave.h)
     bool lex_stats = false;                                      // BF_LEX_STATS=1 at LoadModel: instrumented kernel instances (experiments)
     DevBuf t_wcp_l1, t_wcp_pages;                                // TextToWords: code point -> class without the charmap
+    DevBuf t_segscore;                                           // _sp Unigram: the rows' scores alone
     DevBuf t_dict, t_seginfo;                                    // _sp: Mealy table, I2Info rows (code-point maps reuse t_cp_*/t_multi)
     DevBuf t_dk_l1, t_dk_pages, t_dn_l1, t_dn_pages, t_dn_pool, t_k2i, t_rows;   // key -> info lookup (uploaded on first use)
     bool dict_ready = false;
@@ -182,7 +183,7 @@ struct Handle {
         for (Handle *c : shards) if (c && c != this) { DeviceGuard dg(c->device); (void)hipDeviceSynchronize(); delete c; }
         shards.clear();
         pipe.release(); m_small.release();
-        for (DevBuf *b : {&t_bpe_prio, &t_bpe_place, &t_dk_l1, &t_dk_pages, &t_dn_l1, &t_dn_pages, &t_dn_pool, &t_k2i, &t_rows, &w_keys, &w_keyoff, &w_dids, &w_dret, &w_vals, &t_i2w_off, &t_i2w_data, &t_kind, &t_wbd, &t_info, &t_acts, &t_cp_l1, &t_cp_pages, &t_multi, &t_wcp_l1, &t_wcp_pages, &t_dict, &t_seginfo, &w_s1, &w_s2, &w_s3, &w_s4, &w_big, &w_perm, &w_hist, &w_narcs, &w_bwflags, &w_cls, &w_nchars, &w_tmp, &w_counts, &w_flags, &w_out, &w_outoff,
+        for (DevBuf *b : {&t_segscore, &t_bpe_prio, &t_bpe_place, &t_dk_l1, &t_dk_pages, &t_dn_l1, &t_dn_pages, &t_dn_pool, &t_k2i, &t_rows, &w_keys, &w_keyoff, &w_dids, &w_dret, &w_vals, &t_i2w_off, &t_i2w_data, &t_kind, &t_wbd, &t_info, &t_acts, &t_cp_l1, &t_cp_pages, &t_multi, &t_wcp_l1, &t_wcp_pages, &t_dict, &t_seginfo, &w_s1, &w_s2, &w_s3, &w_s4, &w_big, &w_perm, &w_hist, &w_narcs, &w_bwflags, &w_cls, &w_nchars, &w_tmp, &w_counts, &w_flags, &w_out, &w_outoff,
                           &w_bsums, &w_misc, &w_text, &w_docoff, &w_ids, &w_idoff, &w_starts, &w_ends, &w_srcoff, &w_span}) b->release();
         for (auto &e : ev) if (e) (void)hipEventDestroy(e);
         if (stream) (void)hipStreamDestroy(stream);
@@ -278,6 +279,7 @@ Handle *make_handle(const uint8_t *img, size_t size)
         ok = ok && upload(h->t_dict, m.dict.t64, 16) && upload(h->t_seginfo, m.seg_info, 16) &&
              upload(h->t_cp_l1, m.sp_cpmap.l1) && upload(h->t_cp_pages, m.sp_cpmap.pages) && upload(h->t_multi, m.sp_multi_pool, 16);
         if (m.kind == KIND_BPE_MERGES) ok = ok && upload(h->t_bpe_prio, m.bpe_prio, 16) && upload(h->t_bpe_place, m.bpe_place_id, 16);
+        if (m.kind == KIND_UNIGRAM) ok = ok && upload(h->t_segscore, m.seg_score, 16);
     }
     if (m.has_i2w) ok = ok && upload(h->t_i2w_off, m.i2w_off, 4) && upload(h->t_i2w_data, m.i2w_data, 16);
     ok = ok && hip_ok(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking), "hipStreamCreate");
@@ -288,7 +290,7 @@ Handle *make_handle(const uint8_t *img, size_t size)
 }
 
 // the Unigram lane program (bf_seg.h UniLane) keeps `depth` window entries in LDS and packs id + 1 into 20 bits
-bool uni_lane_ok(const Model &m) { return m.trie_max_depth > 0 && m.trie_max_depth <= 32 && m.max_info_id <= UNI_MAX_ID; }
+bool uni_lane_ok(const Model &m) { return m.trie_max_depth > 0 && m.trie_max_depth <= 32 && m.seg_info.size() <= (size_t)UNI_MAX_ID && m.max_info_id < 0x7fffffff; }      // the records carry the row's key
 
 // Workspaces of the TextToIds pipeline for a batch of ndocs documents / total_bytes bytes (grow-only; see DevBuf::reserve).
 
@@ -297,7 +299,8 @@ bool uni_lane_ok(const Model &m) { return m.trie_max_depth > 0 && m.trie_max_dep
 // the lane-per-document kernels for every model.
 bool use_wave(const Handle *h, bool want_off, int words)
 {
-    return h->m.kind == KIND_WP && h->m.wave_ok && !want_off && !words && (h->variant & 0xff) != 2;
+    (void)want_off;                      // the offsets API has an instance of the wave program of its own (bf_wave_body.h OFFS)
+    return h->m.kind == KIND_WP && h->m.wave_ok && !words && (h->variant & 0xff) != 2;
 }
 
 // the BPE wave program (bf_bpe_wave_body.h) in front of the lane-per-document kernels, for the models its load-time analysis admits
@@ -311,7 +314,8 @@ bool reserve_ids_workspaces(Handle *h, int64_t ndocs, int64_t total_bytes, bool 
     if (!h->w_nchars.reserve((size_t)(ndocs + 1) * 4) || !h->w_counts.reserve((size_t)(ndocs + 1) * 4) ||
         !h->w_bsums.reserve((size_t)(nblocks + 1) * 8) || !h->w_tmp.reserve((size_t)(total_bytes + 8 * ndocs + 64) * 4)) return false;
     if (m.kind == KIND_WP) {
-        if (use_wave(h, want_off, words)) return true;                 // no class stream, no dirty flags
+        if (use_wave(h, want_off, words))                              // no class stream, no dirty flags
+            return !want_off || (h->w_srcoff.reserve((size_t)(total_bytes + 64) * 4) && h->w_span.reserve((size_t)(total_bytes + 8 * ndocs + 64) * 8));
         if (!h->w_cls.reserve((size_t)(total_bytes + 64) * 2) || !h->w_flags.reserve((size_t)((total_bytes >> 10) + 2) * 8)) return false;
         if (want_off && (!h->w_srcoff.reserve((size_t)(total_bytes + 64) * 4) || !h->w_span.reserve((size_t)(total_bytes + 8 * ndocs + 64) * 8))) return false;
         return true;
@@ -359,6 +363,7 @@ int run_device(Handle *h, const char *d_text, const int64_t *d_doc_off, int64_t 
         wp.initial = m.wbd.initial_base; wp.loop_info = m.loop_info; wp.solo_info = m.wave_solo_info; wp.max_token_length = m.max_token_length;
         wp.text = b.text; wp.doc_off = b.doc_off; wp.ndocs = b.ndocs; wp.total_bytes = b.total_bytes;
         wp.ids_tmp = h->w_tmp.as<int32_t>(); wp.counts = h->w_counts.as<int32_t>(); wp.max_ids = max_ids; wp.unk = unk;
+        wp.span_tmp = want_off ? h->w_span.as<int32_t>() : nullptr; wp.src_off = want_off ? h->w_srcoff.as<int32_t>() : nullptr;
         wp.next_doc = next_doc;
         wp.cold.cpmap = DevCpMap{h->t_cp_l1.as<uint16_t>(), h->t_cp_pages.as<uint32_t>()};
         wp.cold.kind = h->t_kind.as<uint8_t>(); wp.cold.nclasses = m.wbd.nclasses; wp.cold.status = status; wp.cold.no_fast = 0;
@@ -401,7 +406,7 @@ int run_device(Handle *h, const char *d_text, const int64_t *d_doc_off, int64_t 
         (void)hipEventRecord(h->ev[EV_PREP], s);
         SpSegParams sg;
         sg.S.T = h->t_dict.as<uint64_t>(); sg.S.info = h->t_seginfo.as<SegInfo>(); sg.S.initial = m.dict.initial_base;
-        sg.S.cls_delim = m.sp_delim_code; sg.S.kind = m.kind; sg.S.id_offset = m.id_offset;
+        sg.S.cls_delim = m.sp_delim_code; sg.S.kind = m.kind; sg.S.id_offset = m.id_offset; sg.S.score = m.kind == KIND_UNIGRAM ? h->t_segscore.as<uint32_t>() : nullptr;
         sg.b = b; sg.stream = h->w_cls.as<uint16_t>(); sg.lens = h->w_nchars.as<int32_t>(); sg.slot_mul = mul;
         sg.ids_tmp = h->w_tmp.as<int32_t>(); sg.counts = h->w_counts.as<int32_t>(); sg.span_tmp = want_off ? h->w_span.as<int32_t>() : nullptr; sg.max_ids = max_ids; sg.unk = unk; sg.status = status;
         sg.best = nullptr; sg.arcs = nullptr; sg.tos = nullptr; sg.idsv = nullptr; sg.inter = nullptr; sg.bm_words = 0; sg.fb_list = nullptr; sg.fb_count = nullptr;
@@ -652,6 +657,7 @@ int64_t run_host_mapped(Handle *h, const char *text, const int64_t *doc_off, int
     wp.initial = m.wbd.initial_base; wp.loop_info = m.loop_info; wp.solo_info = m.wave_solo_info; wp.max_token_length = m.max_token_length;
     wp.text = (const uint8_t *)(dp + SmallLayout::text); wp.doc_off = (const int64_t *)(dp + SmallLayout::off); wp.ndocs = ndocs; wp.total_bytes = total;
     wp.ids_tmp = (int32_t *)(dp + SmallLayout::ids); wp.counts = (int32_t *)(dp + SmallLayout::counts); wp.max_ids = max_ids < 0 ? 0 : max_ids; wp.unk = unk;
+    wp.span_tmp = nullptr; wp.src_off = nullptr;
     wp.next_doc = nullptr;              // no work counter: an atomic on host memory costs every wave a trip over the bus
     wp.cold.cpmap = DevCpMap{h->t_cp_l1.as<uint16_t>(), h->t_cp_pages.as<uint32_t>()};
     wp.cold.kind = h->t_kind.as<uint8_t>(); wp.cold.nclasses = m.wbd.nclasses; wp.cold.status = (int *)(dp + SmallLayout::ctrl + 16); wp.cold.no_fast = 0; wp.cold.stats = nullptr;
@@ -712,7 +718,7 @@ int64_t run_host_locked(Handle *h, const char *text, const int64_t *doc_off, int
     const int64_t base = doc_off[0];
     const int64_t total = ndocs > 0 ? doc_off[ndocs] - base : 0;
     hipStream_t s = h->stream;
-    if (!defer_ids && ndocs >= 1 && ndocs <= SMALL_MAX_DOCS && total <= SMALL_MAX_BYTES && use_wave(h, want_off, words) && small_ready(h))
+    if (!defer_ids && ndocs >= 1 && ndocs <= SMALL_MAX_DOCS && total <= SMALL_MAX_BYTES && !want_off && use_wave(h, want_off, words) && small_ready(h))
         return run_host_mapped(h, text, doc_off, ndocs, ids_out, ids_cap, id_off_out, max_ids, unk);
     if (!defer_ids && !want_off && !words && h->m.kind != KIND_I2W && h->host_chunk_bytes > 0 && total >= h->host_chunk_bytes && ndocs >= 2) {
         const int64_t r = run_host_chunked(h, text, doc_off, ndocs, ids_out, ids_cap, id_off_out, max_ids, unk);

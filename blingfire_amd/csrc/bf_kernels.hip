@@ -698,7 +698,7 @@ __device__ __forceinline__ uint32_t mbcnt(unsigned long long m) { return __built
 namespace bfa {
 
 // WPE: waves per SIMD the register allocation is asked to allow (a workgroup is four waves, one per SIMD: WPE workgroups per CU)
-template <class LDS, int NU, int STEPS, int WPE, bool STATS, int DBG = 0, int UMIN = 4, int CROOM = 0>
+template <class LDS, int NU, int STEPS, int WPE, bool STATS, int DBG = 0, int UMIN = 4, int CROOM = 0, bool OFFS = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_wp_wave(WpWaveParams p, int grab)
 {
     __shared__ LDS lds[4];
@@ -710,7 +710,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
     for (int i = (int)threadIdx.x; i < p.acts_n; i += 256) acts[i] = p.acts[i];
     __syncthreads();
     // the wave number as a scalar: what a wave reads of its own LDS block at a wave-uniform index is then wave-uniform for the compiler too
-    WpWave<LDS, NU, STATS, DBG, STEPS, UMIN, CROOM> w(p, cold, lds[wave_in_block()], ascii, acts);
+    WpWave<LDS, NU, STATS, DBG, STEPS, UMIN, CROOM, OFFS> w(p, cold, lds[wave_in_block()], ascii, acts);
     w.run(grab, (int)(blockIdx.x * 4) + wave_in_block(), (int)(gridDim.x * 4));
 }
 
@@ -753,6 +753,21 @@ void launch_wp_wave(const WpWaveParams &p, int variant, hipStream_t s)
     // 33.0 / 33.6 / 36.6; two units per lane 39.4; leaving the units phase with fewer than 12 / 24 / 32 / 48 busy units 27.7 / 28.1 /
     // 28.2 / 28.8 (at seven workgroups), 4 / 12 / 24: 25.7 / 26.0 / 26.3 (at eight).
     typedef WvLds<1024, 256, 8> L;
+    if (p.span_tmp) {                   // the offsets API: the instance that carries a span with every id (seven waves per SIMD: it needs a few registers more)
+        static int per_cu_off = 0;
+        if (per_cu_off <= 0) {
+            int q = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&q, k_wp_wave<L, 1, 3, 7, false, 0, 4, 0, true>, 256, 0) != hipSuccess || q <= 0) q = 2;
+            (void)hipGetLastError();
+            per_cu_off = q;
+        }
+        int64_t blocks = (int64_t)device_cus() * per_cu_off;
+        const int64_t need = (p.ndocs + (int64_t)grab * 4 - 1) / ((int64_t)grab * 4);
+        if (blocks > need) blocks = need;
+        if (blocks < 1) blocks = 1;
+        hipLaunchKernelGGL((k_wp_wave<L, 1, 3, 7, false, 0, 4, 0, true>), dim3((unsigned)blocks), dim3(256), 0, s, p, grab);
+        return;
+    }
     if (cfg == 14 || cfg == 15) {       // experiments: phase costs by difference (results are wrong by design)
         const int64_t nb = (int64_t)device_cus() * 8;
         if (cfg == 14) hipLaunchKernelGGL((k_wp_wave<L, 1, 3, 8, false, 1>), dim3((unsigned)nb), dim3(256), 0, s, p, grab);
@@ -1685,7 +1700,7 @@ __global__ __launch_bounds__(64) void k_seg_unigram_lane(SpSegParams p, int ring
     ClsWin2 cls_at; cls_at.init(p.stream, 0);
     UniLane<ClsWin2, RingLds> ul(p.S, cls_at, ring);
     ul.L = 0; ul.depth = p.trie_depth; ul.start = ul.i = ul.sum = 0; ul.state = 0; ul.unknown = true; ul.pend = false; ul.prev = 0; ul.pend_i = 0;
-    ul.pend_r.id = 0; ul.pend_r.score_bits = 0; ul.end = 0; ul.cnt = 0; ul.unk_run = 0; ul.q0 = ul.q1 = ul.q2 = ul.q3 = 0; ul.qn = 0; ul.abs0 = 0;
+    ul.pend_score = 0; ul.pend_key = 0; ul.end = 0; ul.cnt = 0; ul.unk_run = 0; ul.q0 = ul.q1 = ul.q2 = ul.q3 = 0; ul.qn = 0; ul.abs0 = 0;
     int mode = M_NEED;
     int64_t doc = 0; int32_t *ids = nullptr; int32_t *spans = nullptr; int cap = 0;
     int32_t g0 = 0, g1 = 0, g2 = 0, g3 = 0; int gn = 0;     // ids of the backward pass waiting for their 16-byte group

@@ -995,6 +995,7 @@ bool build_model(Model &m, const uint8_t *img, size_t size)
         }
         m.seg_info.resize(m.i2info_id.size());
         for (size_t k = 0; k < m.i2info_id.size(); ++k) m.seg_info[k] = (uint64_t)(uint32_t)m.i2info_id[k] | ((uint64_t)m.i2info_score[k] << 32);
+        m.seg_score = m.i2info_score;
         if (m.kind == KIND_BPE || m.kind == KIND_BPE_OPT || m.kind == KIND_BPE_MERGES) {
             bool ids_ok = true;
             for (size_t k = 0; k < m.i2info_id.size(); ++k) if (m.i2info_valid[k] && (m.i2info_id[k] < 0 || m.i2info_id[k] >= (1 << 20))) ids_ok = false;

@@ -153,6 +153,7 @@ struct Model {
     int info_stride = 0, info_min_key = 0;
     // device forms
     std::vector<uint64_t> seg_info;    // I2Info rows as (id | score_bits << 32), key = MPH index
+    std::vector<uint32_t> seg_score;   // their score bits alone (Unigram lane program, bf_seg.h SegTables::score)
     // bf_bpe_seg_body.h: the arc order of the BPE flavours as one integer per entry.  Plain BPE / bpe-opt sort by id (..._bpe_t.h:238-255):
     // priority = 2 * id + 1, no table.  With merges (..._with_merges_t.h:242-262: rank descending, then id ascending): bpe_prio[MPH index]
     // = 2 * place + 1, place = the entry's position in that order; bpe_place_id[place] = its id.  Even priorities are for the unknown arc

@@ -36,6 +36,7 @@ struct SegTables {
     uint32_t initial;
     uint32_t cls_delim;         // class-stream value of U+2581
     int kind, id_offset;
+    const uint32_t *score;      // Unigram lane program: the score bits of the I2Info rows alone (same key); the forward pass reads nothing else of a row
 };
 
 struct SegArc { int32_t start, end, id; uint32_t rank_bits; };   // BPE arc (…_bpe_t.h:66-88, …_with_merges_t.h)
@@ -123,7 +124,10 @@ BF_HD int seg_unigram_doc(const SegTables &S, ClsAt &cls_at, int L, SegBest *bes
 // Packed record of a position: [len - 1 : 12 | id + 1 : 20], len = position - begin + 1; id + 1 == 0 is the unknown arc (id -1);
 // a length field of 4095 means "4096 or more" -- only possible for a merged run of unknown positions, every position of which
 // carries the run's begin, so the backward pass hops 4095 positions back and adds up (bstep_len); 0xFFFFFFFF = no incoming arc
-// (the reference's {-1, -1} sentinel).  Needs ids below 2^20 - 2 (checked at load; other models use the sequential form).
+// (the reference's {-1, -1} sentinel).  The "id" of a record is the entry's MPH index (the key of its I2Info row): the forward pass then
+// needs only the row's score -- a 4-byte array half the size of the rows, so that transitions + scores of xlm_roberta_base.bin fit the
+// 4 MB of L2 of an XCD together -- and the id is looked up once per TOKEN in the backward pass instead of once per arc.  Needs fewer
+// than 2^20 - 2 rows (checked at load; other models use the sequential form).
 // ---------------------------------------------------------------------------------------------------
 constexpr uint32_t UNI_REC_NONE = 0xFFFFFFFFu, UNI_LEN_MAX = 4095u;
 constexpr int UNI_MAX_ID = (1 << 20) - 3;
@@ -132,7 +136,7 @@ BF_HD uint32_t uni_rec(int id, int len) { const uint32_t l = (uint32_t)(len - 1)
 template <class ClsAt, class Ring>
 struct UniLane {
     const SegTables &S; ClsAt &cls_at; Ring &ring; uint32_t *recs;
-    int L, depth, start, i, sum; uint32_t state; bool unknown, pend; double prev; SegInfo pend_r; int pend_i;
+    int L, depth, start, i, sum; uint32_t state; bool unknown, pend; double prev; uint32_t pend_score; int pend_key; int pend_i;
     int unk_run;                                       // length of the unknown run that ends at start - 1 (0: that position is not unknown)
     uint32_t q0, q1, q2, q3; int qn;                   // final records of the last positions, not yet stored (qn of them, q3 newest)
     int64_t abs0;                                      // absolute element index of position 0 (16-byte store groups are aligned on it)
@@ -147,7 +151,7 @@ struct UniLane {
     {
         L = L_; depth = depth_; recs = recs_; abs0 = abs0_;
         ring.fill(neg_flt_max());
-        start = 0; i = 0; state = S.initial; sum = 0; unknown = true; prev = 0; pend = false; pend_i = 0; pend_r.id = 0; pend_r.score_bits = 0;
+        start = 0; i = 0; state = S.initial; sum = 0; unknown = true; prev = 0; pend = false; pend_i = 0; pend_score = 0; pend_key = 0;
         unk_run = 0; q0 = q1 = q2 = q3 = 0; qn = 0;
         end = 0; cnt = 0;
         cls_at.seek(0);
@@ -155,8 +159,8 @@ struct UniLane {
 
     BF_HD void relax()                                 // AddArc (..._1best_t.h:118-142) of the pending final transition
     {
-        const double cand = sg_bits_to_float(pend_r.score_bits) + prev;
-        if (ring.score(pend_i) < cand) ring.set(pend_i, cand, uni_rec(pend_r.id, pend_i - start + 1));
+        const double cand = sg_bits_to_float(pend_score) + prev;
+        if (ring.score(pend_i) < cand) ring.set(pend_i, cand, uni_rec(pend_key, pend_i - start + 1));
         pend = false;
     }
 
@@ -194,7 +198,7 @@ struct UniLane {
         if (hit) {
             state = (uint32_t)((e >> SG_NEXT_SHIFT) & SG_NEXT_MASK);
             sum += (int)(e >> SG_OW_SHIFT);
-            if (e & SG_FINAL) { pend_r = S.info[sum]; pend_i = i; pend = true; unknown = false; }   // requested now, used next step
+            if (e & SG_FINAL) { pend_score = S.score[sum]; pend_key = sum; pend_i = i; pend = true; unknown = false; }   // requested now, used next step
             ++i;
             ends = i >= L;
         }
@@ -232,7 +236,8 @@ struct UniLane {
     {
         int id = -1, begin = -1;
         if (r != UNI_REC_NONE) {
-            id = (int)(r & 0xFFFFFu) - 1;
+            const int key = (int)(r & 0xFFFFFu) - 1;                    // the entry's MPH index, -1: the unknown arc
+            if (key != -1) id = S.info[key].id;
             int64_t len = (int64_t)(r >> 20) + 1;
             if ((r >> 20) == UNI_LEN_MAX) {                             // a long unknown run: add up 4095-position hops
                 int e = end; uint32_t rr = r; len = 0;

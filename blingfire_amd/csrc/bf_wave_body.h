@@ -43,7 +43,9 @@ struct WvLds {
 
 // DBG (experiments, wrong results by design): 1 = units finish at once without walking, 2 = also nothing is moved at retire:
 // instruction counts of the phases by difference (profiles/r03_phase_costs.txt)
-template <class LDS, int NU = 2, bool STATS = false, int DBG = 0, int STEPS = 3, int UMIN = 4, int CROOM = 0>
+// OFFS: the offsets API -- every id carries the first / last character of its sub-token (of its word, for UnkId: tokdll:1263-1297) through the
+// provisional homes to its place, and the decoder records the byte every character starts at
+template <class LDS, int NU = 2, bool STATS = false, int DBG = 0, int STEPS = 3, int UMIN = 4, int CROOM = 0, bool OFFS = false>
 struct WpWave {
     static constexpr int RING = LDS::RING, QCAP = LDS::QCAP, DTN = LDS::DTN;
     static constexpr uint32_t RMASK = RING - 1, QMASK = QCAP - 1, DMASK = DTN - 1;
@@ -233,6 +235,11 @@ struct WpWave {
 #pragma unroll
                 for (int k = 0; k < 8; ++k) if (k < nb) S.ring[(r + (uint32_t)k) & RMASK] = (uint16_t)e[k];
             }
+            if (OFFS) {                                              // character dec + 8 * lane + k starts at byte q0 + k
+                int32_t *so = p.src_off + (s - p.text) + dec + lane * 8;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) if (k < nb) so[k] = q0 + k;
+            }
             const int total = n - pos < WV_CHUNK ? n - pos : WV_CHUNK;
             dec += total; dec_bytes = pos + WV_CHUNK; rhi = rbase + (uint32_t)dec;
 #pragma unroll
@@ -268,6 +275,7 @@ struct WpWave {
             const bool on = ((em & ~leadm) >> k) & 1u;
             uint16_t *dst = on ? &S.ring[(base + (uint32_t)__builtin_popcount(em & ((1u << k) - 1u))) & RMASK] : &S.spare;
             *dst = (uint16_t)e[k];
+            if (OFFS && ((em >> k) & 1u)) p.src_off[(s - p.text) + (int64_t)(base - rbase) + __builtin_popcount(em & ((1u << k) - 1u))] = q0 + k;     // lead bytes too: every element of the lane
         }
         uint32_t cov = 0;                                                 // bytes behind a lead that belong to its character (bits 8..10: in the next lane)
         bool e_any = false;
@@ -430,12 +438,21 @@ struct WpWave {
         uint32_t rs; int Lk; uint32_t ini;       // Lk: length of the word | its document's table entry << 16
         int j, lim; uint32_t state; int fp; uint32_t ftag;
         int ca;                          // pieces so far | 1 << 16 while the anchored walk runs
+        int from;                        // OFFS: where the walk under way started (a piece is [from, fp])
         // a walk is under way while j < lim; j >= lim with tok >= 0: its end waits for unit_event (a miss sets j = lim)
     };
 
     // What follows runs for all lanes of the wave at once and is written with selects: a lane that has nothing to do (pred false)
     // executes the same instructions, keeps what it has and writes to the spare words.  (Measured, profiles/r03_*: as nested
     // conditionals the code of a round cost 127 scalar instructions, most of them execution-mask bookkeeping.)
+    // OFFS: id k of the unit's word and the characters [from, to] of the word it covers, to the provisional home
+    BF_WVD void home_put(const Unit &u, int k, int32_t id, int from, int to)
+    {
+        const uint32_t ke = (uint32_t)u.Lk >> 16;
+        const int f = (int)(u.rs - S.dt_rbase[ke]);
+        const int64_t at = S.dt_slot[ke] + (int64_t)f + k;
+        ids_tmp[at] = id; p.span_tmp[2 * at] = f + from; p.span_tmp[2 * at + 1] = f + to;
+    }
     BF_WVD void unit_finish(Unit &u, int cnt)
     {
         S.qc[(uint32_t)u.tok & QMASK] = (uint16_t)(cnt + 1);
@@ -449,6 +466,7 @@ struct WpWave {
         const int L = u.Lk & 0xFFFF;
         u.ini = pred ? ini : u.ini; u.state = pred ? (anchored ? ini_l : ini) : u.state; u.ca = pred ? (anchored ? 0x10000 : 0) : u.ca;
         u.j = pred ? 0 : u.j; u.lim = pred ? (cap < L ? cap : L) : u.lim; u.fp = pred ? -1 : u.fp;
+        if (OFFS) u.from = pred ? 0 : u.from;
     }
     // starts the unit of token t (take: this lane takes one)
     BF_WVD void unit_begin(Unit &u, uint32_t t, bool take)
@@ -472,7 +490,10 @@ struct WpWave {
                 if (info & LX_INFO_SIMPLE) tag = (int)(info & 0x7FFFFFFFu);
                 else { const int32_t *a = acts + info; tag = a[2]; ini = (uint32_t)a[5]; ini_l = (uint32_t)a[6]; call = true; }
                 if (tag != WBD_WORD_TAG) unit_finish(u, 0);                            // tags 2..4: neither a word nor a sub-token
-                else if (!call) { S.q[sl].pos = (uint32_t)unk; unit_finish(u, 1); }  // a word without sub-tokens (tokdll:1282-1301)
+                else if (!call) {                                                      // a word without sub-tokens (tokdll:1282-1301)
+                    if (OFFS) home_put(u, 0, unk, 0, (u.Lk & 0xFFFF) - 1); else S.q[sl].pos = (uint32_t)unk;
+                    unit_finish(u, 1);
+                }
                 else unit_call(u, ini, ini_l, true);
             }
         }
@@ -505,6 +526,10 @@ struct WpWave {
         const int32_t id = (int32_t)(u.ftag & 0x7FFFFFFFu);
         // The id of a word's only piece stays in LDS (in the queue entry's pos: the unit holds the word's ring position itself); with
         // the second piece the first one moves to its provisional home and the entry gets the position back (retire finds the home by it)
+        if (OFFS) {
+            // every id goes to its provisional home with its span (the word's own span for UnkId: tokdll:1282-1297); the entry keeps the word's position
+            if (wv::any(matched || gap)) { if (matched) home_put(u, cnt0, id, u.from, u.fp); else if (gap) home_put(u, 0, unk, 0, L - 1); }
+        } else {
         const bool more = matched && cnt0 >= 1;
         if (wv::any(more)) {
             if (more) {
@@ -516,6 +541,7 @@ struct WpWave {
         }
         uint32_t *wp = (gap || (matched && cnt0 == 0)) ? &S.q[sl].pos : &S.spare32;
         *wp = gap ? (uint32_t)unk : (uint32_t)id;
+        }
         const int cnt = cnt0 + (matched ? 1 : 0);
         const int nf = matched ? u.fp + 1 : 0;
         const bool fin = gap || (ev && nf >= L), go = ev && !fin;
@@ -523,6 +549,7 @@ struct WpWave {
         *cq = (uint16_t)((gap ? 1 : cnt) + 1);
         const int b = nf + maxtok;
         u.state = go ? u.ini : u.state; u.j = go ? nf : u.j; u.lim = go ? (b < L ? b : L) : u.lim; u.fp = go ? -1 : u.fp;
+        if (OFFS) u.from = go ? nf : u.from;
         u.ca = go ? cnt : u.ca; u.tok = fin ? -1 : u.tok;
     }
     // Runs the units until the queue is handed out and fewer than UNIT_MIN of them are still busy (`drain`: until all are done).
@@ -609,11 +636,19 @@ struct WpWave {
         int64_t slot = 0; int cap = 0, dcnt = 0; uint32_t f = 0;
         uint32_t w0 = 0;
         if (act) { slot = S.dt_slot[ke]; cap = S.dt_cap[ke]; dcnt = S.dt_cnt[ke]; w0 = te.pos; f = w0 - S.dt_rbase[ke]; }
-        const int32_t *src = ids_tmp + slot + (int64_t)f;          // used by words of two and more pieces only (unit_event)
+        const int32_t *src = ids_tmp + slot + (int64_t)f;          // used by words of two and more pieces only (unit_event); OFFS: by every word
         int32_t v0 = (int32_t)w0, v1 = 0, v2 = 0, v3 = 0;            // a single piece is in q0 itself
-        if (cnt > 1) { v0 = src[0]; v1 = src[1]; }
+        if (cnt > (OFFS ? 0 : 1)) { v0 = src[0]; if (cnt > 1) v1 = src[1]; }
         if (cnt > 2) v2 = src[2];
         if (cnt > 3) v3 = src[3];
+        int sa0 = 0, sb0 = 0, sa1 = 0, sb1 = 0, sa2 = 0, sb2 = 0, sa3 = 0, sb3 = 0;
+        if (OFFS) {
+            const int32_t *sp = p.span_tmp + 2 * (slot + (int64_t)f);
+            if (cnt > 0) { sa0 = sp[0]; sb0 = sp[1]; }
+            if (cnt > 1) { sa1 = sp[2]; sb1 = sp[3]; }
+            if (cnt > 2) { sa2 = sp[4]; sb2 = sp[5]; }
+            if (cnt > 3) { sa3 = sp[6]; sb3 = sp[7]; }
+        }
         const int inc = wv::incl_scan(cnt), exc = inc - cnt;
         const int kp = wv::shfl_up(k, 1), kn = wv::shfl_down(k, 1);
         const unsigned long long hm = wv::ballot(lane == 0 || k != kp);
@@ -633,10 +668,12 @@ struct WpWave {
             if (STATS && lane == 0) ++st_rewalk;
             for (int o = 4; o < bc; o += 64) {
                 const int i = o + lane;
-                int32_t v = 0;
+                int32_t v = 0, va = 0, vb = 0;
                 if (i < bc) v = ids_tmp[bs + i];
+                if (OFFS && i < bc) { va = p.span_tmp[2 * (bs + i)]; vb = p.span_tmp[2 * (bs + i) + 1]; }
                 wv::sync();
                 if (i < bc && i < br) ids_tmp[bd + i] = v;
+                if (OFFS && i < bc && i < br) { p.span_tmp[2 * (bd + i)] = va; p.span_tmp[2 * (bd + i) + 1] = vb; }
                 wv::sync();
             }
         }
@@ -645,6 +682,13 @@ struct WpWave {
         if (cnt > 1 && room > 1) dst[1] = v1;
         if (cnt > 2 && room > 2) dst[2] = v2;
         if (cnt > 3 && room > 3) dst[3] = v3;
+        if (OFFS) {
+            int32_t *sd = p.span_tmp + 2 * (slot + pos);
+            if (cnt > 0 && room > 0) { sd[0] = sa0; sd[1] = sb0; }
+            if (cnt > 1 && room > 1) { sd[2] = sa1; sd[3] = sb1; }
+            if (cnt > 2 && room > 2) { sd[4] = sa2; sd[5] = sb2; }
+            if (cnt > 3 && room > 3) { sd[6] = sa3; sd[7] = sb3; }
+        }
         q_retire += (uint32_t)nret;
         wv::sync();
         return nret;
@@ -751,7 +795,7 @@ struct WpWave {
         st_wave = wave_id; st_waves = n_waves; st_round = 0;
         Unit u[NU];
 #pragma unroll
-        for (int i = 0; i < NU; ++i) { u[i].tok = -1; u[i].rs = 0; u[i].j = 0; u[i].state = 0; u[i].lim = 0; u[i].fp = -1; u[i].ftag = 0; u[i].Lk = 0; u[i].ca = 0; u[i].ini = 0; }
+        for (int i = 0; i < NU; ++i) { u[i].tok = -1; u[i].rs = 0; u[i].j = 0; u[i].state = 0; u[i].lim = 0; u[i].fp = -1; u[i].ftag = 0; u[i].Lk = 0; u[i].ca = 0; u[i].ini = 0; u[i].from = 0; }
         for (;;) {
             bool moved = settle();
             bool filled = false;

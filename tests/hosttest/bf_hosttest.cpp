@@ -272,7 +272,7 @@ static int emu_sp(const Model &m, const char *s, int n, int32_t *ids, int32_t *s
     const int L = (int)st.size();
     SegTables S;
     S.T = m.dict.t64.data(); S.info = (const SegInfo *)m.seg_info.data(); S.initial = m.dict.initial_base; S.cls_delim = D;
-    S.kind = m.kind; S.id_offset = m.id_offset;
+    S.kind = m.kind; S.id_offset = m.id_offset; S.score = m.seg_score.data();
     const uint16_t *cp = st.data();
     auto cls_at = [cp](int i) -> uint32_t { return cp[i]; };
     IdOutDirect out{ids, spans};

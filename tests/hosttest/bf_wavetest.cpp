@@ -13,7 +13,7 @@
 
 using namespace bfa;
 
-template <class LDS, int NU>
+template <class LDS, int NU, bool OFFS = false>
 static void run_cfg(const WpWaveParams &p, int nwaves, int grab)
 {
     std::vector<LDS *> lds;
@@ -29,7 +29,7 @@ static void run_cfg(const WpWaveParams &p, int nwaves, int grab)
         size_t k = 0;
         for (; k < wave_ids.size(); ++k) if (wave_ids[k] == wid) break;
         if (k == wave_ids.size()) { wave_ids.push_back(wid); (void)next_wave; }
-        WpWave<LDS, NU, true> w(p, p.cold, *of_wave[k], ascii.data(), p.acts);
+        WpWave<LDS, NU, true, 0, 3, 4, 0, OFFS> w(p, p.cold, *of_wave[k], ascii.data(), p.acts);
         w.run(grab, (int)k, nwaves);
     };
     wvemu::run_waves(nwaves, body);
@@ -58,7 +58,7 @@ long bft_emu_wave_batch(void *hv, const uint8_t *text, long text_bytes, const in
     p.T = m.wbd_t2.data(); p.acts = m.acts_pool.data(); p.acts_n = (int)m.acts_pool.size();
     p.initial = m.wbd.initial_base; p.loop_info = m.loop_info; p.solo_info = m.wave_solo_info; p.max_token_length = m.max_token_length;
     p.text = text; p.doc_off = doc_off; p.ndocs = ndocs; p.total_bytes = total;
-    p.ids_tmp = tmp.data(); p.counts = counts.data(); p.max_ids = max_ids; p.unk = unk; p.next_doc = &next_doc;
+    p.ids_tmp = tmp.data(); p.counts = counts.data(); p.max_ids = max_ids; p.unk = unk; p.next_doc = &next_doc; p.span_tmp = nullptr; p.src_off = nullptr;
     if (cfg >= 16) { p.next_doc = nullptr; cfg -= 16; }            // cfg + 16: no work counter, the waves take their ranges round-robin
     p.cold.cpmap = DevCpMap{m.wbd_cpmap.l1.data(), m.wbd_cpmap.pages.data()};
     p.cold.kind = m.wave_kind.data(); p.cold.nclasses = m.wbd.nclasses; p.cold.status = &status; p.cold.stats = stats; p.cold.no_fast = cfg == 1 ? 1 : 0;
@@ -77,6 +77,52 @@ long bft_emu_wave_batch(void *hv, const uint8_t *text, long text_bytes, const in
         if (c == 0) continue;
         const int64_t slot = wv_ids_slot(doc_off[d], d);
         for (int i = 0; i < c; ++i) { if (o + i < ids_cap) ids_out[o + i] = tmp[(size_t)(slot + i)]; }
+        o += c;
+    }
+    id_off[ndocs] = o;
+    return o;
+}
+
+// TextToIdsWithOffsetsBatch through the OFFS instance of the wave program: ids + byte offsets of every id (first byte, last byte), the
+// span -> byte-offset step of k_compact restated (tokdll:1263-1273).  cfg as above (0, 1, 2).
+long bft_emu_wave_batch_offsets(void *hv, const uint8_t *text, long text_bytes, const int64_t *doc_off, long ndocs, int max_ids, int unk, int nwaves, int grab, int cfg,
+                                int32_t *ids_out, int32_t *starts_out, int32_t *ends_out, long ids_cap, int64_t *id_off)
+{
+    Model &m = ((Handle *)hv)->m;
+    if (!m.error.empty() || m.kind != KIND_WP || !m.wave_ok) return -1;
+    if (max_ids < 0) max_ids = 0;
+    const int64_t total = text_bytes;
+    std::vector<int32_t> tmp((size_t)(total + 8 * ndocs + 64 + 8), -77), counts((size_t)ndocs + 1, -55), span(2 * (size_t)(total + 8 * ndocs + 64 + 8), -77), srcoff((size_t)total + 64, -77);
+    unsigned long long next_doc = 0, stats[16] = {0}; int status = 0;
+    WpWaveParams p;
+    p.T = m.wbd_t2.data(); p.acts = m.acts_pool.data(); p.acts_n = (int)m.acts_pool.size();
+    p.initial = m.wbd.initial_base; p.loop_info = m.loop_info; p.solo_info = m.wave_solo_info; p.max_token_length = m.max_token_length;
+    p.text = text; p.doc_off = doc_off; p.ndocs = ndocs; p.total_bytes = total;
+    p.ids_tmp = tmp.data(); p.counts = counts.data(); p.max_ids = max_ids; p.unk = unk; p.next_doc = &next_doc;
+    p.span_tmp = span.data(); p.src_off = srcoff.data();
+    p.cold.cpmap = DevCpMap{m.wbd_cpmap.l1.data(), m.wbd_cpmap.pages.data()};
+    p.cold.kind = m.wave_kind.data(); p.cold.nclasses = m.wbd.nclasses; p.cold.status = &status; p.cold.stats = stats; p.cold.no_fast = cfg == 1 ? 1 : 0;
+    if (ndocs > 0) {
+        if (cfg == 1) run_cfg<WvLds<1024, 128, 2>, 2, true>(p, nwaves, grab);
+        else if (cfg == 2) run_cfg<WvLds<4096, 512, 64>, 3, true>(p, nwaves, grab);
+        else run_cfg<WvLds<1024, 256, 8>, 1, true>(p, nwaves, grab);
+    }
+    if (status) return -5;
+    long o = 0;
+    for (long d = 0; d < ndocs; ++d) {
+        id_off[d] = o;
+        const int c = counts[(size_t)d];
+        if (c < 0) return -6;
+        const int64_t b = doc_off[d], slot = wv_ids_slot(b, d);
+        for (int i = 0; i < c; ++i) {
+            if (o + i >= ids_cap) return -9;
+            ids_out[o + i] = tmp[(size_t)(slot + i)];
+            const int from = span[2 * (size_t)(slot + i)], to = span[2 * (size_t)(slot + i) + 1];
+            const int so = from >= 0 ? srcoff[(size_t)(b + from)] : -1, eo = to >= 0 ? srcoff[(size_t)(b + to)] : -1;
+            int sz = 0;
+            if (eo >= 0) { const uint32_t ch = text[b + eo]; sz = (ch & 0x80) == 0 ? 1 : (ch & 0xE0) == 0xC0 ? 2 : (ch & 0xF0) == 0xE0 ? 3 : (ch & 0xF8) == 0xF0 ? 4 : 0; }
+            starts_out[o + i] = so; ends_out[o + i] = eo + (sz > 0 ? sz - 1 : 0);
+        }
         o += c;
     }
     id_off[ndocs] = o;

@@ -156,3 +156,34 @@ def test_wave_program_any_batch(ht):
     run()
     ora.free(ho)
     L.bft_free(h)
+
+
+@pytest.mark.parametrize("model", WP_MODELS)
+def test_offsets_instance_of_the_wave_program(ht, model):
+    """TextToIdsWithOffsets through the OFFS instance (every id carries the span of its sub-token, of its word for UnkId; the decoder records
+    the byte of every character): ids, start and end byte offsets of every document against the oracle's TextToIdsWithOffsets (pinned to the
+    reference in tests/test_offsets.py), on adversarial input (BOM, multi-byte characters, invalid UTF-8), fuzz and long words"""
+    if not bfutil.have_model(model):
+        pytest.skip(model)
+    ht.bft_emu_wave_batch_offsets.restype = ctypes.c_long
+    ht.bft_emu_wave_batch_offsets.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_long, ctypes.c_void_p, ctypes.c_long, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                              ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_long, ctypes.c_void_p]
+    mp = bfutil.model_path(model)
+    h = ht.bft_load(mp.encode())
+    ora = bfutil.oracle()
+    ho = ora.load(mp)
+    docs = list(bfutil.ADVERSARIAL) + bfutil.fuzz_docs(250, seed=31) + [("x" * k + " " + "unaffable" * 3 + " é" * (k % 7)).encode() for k in (1, 63, 64, 65, 300, 511, 512, 513, 1100)]
+    text, off = bf.pack_docs(docs)
+    nd = len(docs)
+    for (mx, unk, nw, grab, cfg) in [(512, 100, 1, 8, 0), (512, 100, 3, 2, 1), (5, 7, 2, 8, 2), (512, 100, 4, 1, 16)]:
+        cap = len(text) + 16
+        ids = np.full(cap, -9, dtype=np.int32); st = np.full(cap, -9, dtype=np.int32); en = np.full(cap, -9, dtype=np.int32)
+        ido = np.zeros(nd + 1, dtype=np.int64)
+        r = ht.bft_emu_wave_batch_offsets(h, text.ctypes.data, len(text), off.ctypes.data, nd, mx, unk, nw, grab, cfg, ids.ctypes.data, st.ctypes.data, en.ctypes.data, cap, ido.ctypes.data)
+        assert r >= 0, (model, r)
+        for d, b in enumerate(docs):
+            c, gi, gs, ge = ora.with_offsets(ho, b, mx, unk, "bfo_text_to_ids_with_offsets")
+            a, z = int(ido[d]), int(ido[d + 1])
+            assert (z - a, ids[a:z].tolist(), st[a:z].tolist(), en[a:z].tolist()) == (c, gi[:c], gs[:c], ge[:c]), (model, (mx, unk, nw, grab, cfg), d, b[:60])
+    ora.free(ho)
+    ht.bft_free(h)

@@ -24,3 +24,22 @@ for chunk in (128 << 20, 256 << 20):
         r = L.TextToIdsBatch(ctypes.c_void_p(h), text.ctypes.data, off.ctypes.data, n, ids.ctypes.data, cap, ioff.ctypes.data, 512, 100)
         dt = time.perf_counter() - t
         print("chunk %d MiB, call %d: %.1f ms, %.1f M docs/s, %d ids" % (chunk >> 20, it, dt * 1e3, n / dt / 1e6, r), flush=True)
+
+# ---- the same batch range-sharded over two logical shards of the one device (BfSetDevices): throughput against the one-handle call above,
+# and what the call adds to the resident set (the caller's input and output arrays are touched already)
+import resource
+def rss_mb():
+    return resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1024.0
+L.BfSetHostChunkBytes(ctypes.c_void_p(h), 128 << 20)
+one = ids[:max(r, 0)].copy() if r > 0 else None
+base_rss = rss_mb()
+for G in (2, 4):
+    bf.set_devices(h, [0] * G)
+    for it in range(3):
+        t = time.perf_counter()
+        r2 = L.TextToIdsBatch(ctypes.c_void_p(h), text.ctypes.data, off.ctypes.data, n, ids.ctypes.data, cap, ioff.ctypes.data, 512, 100)
+        dt = time.perf_counter() - t
+        same = one is not None and r2 == len(one) and np.array_equal(ids[:r2], one)
+        print("BfSetDevices G = %d on one device, call %d: %.1f ms, %.1f M docs/s, %d ids, equal to G = 1: %s, peak RSS %.0f MB (before the sharded calls %.0f MB; input %.0f MB, output arrays %.0f MB)"
+              % (G, it, dt * 1e3, n / dt / 1e6, r2, same, rss_mb(), base_rss, len(text) / 1e6, (ids.nbytes + ioff.nbytes) / 1e6), flush=True)
+bf.set_devices(h, [0])
