@@ -315,7 +315,7 @@ bool reserve_ids_workspaces(Handle *h, int64_t ndocs, int64_t total_bytes, bool 
         !h->w_bsums.reserve((size_t)(nblocks + 1) * 8) || !h->w_tmp.reserve((size_t)(total_bytes + 8 * ndocs + 64) * 4)) return false;
     if (m.kind == KIND_WP) {
         if (use_wave(h, want_off, words))                              // no class stream, no dirty flags
-            return !want_off || (h->w_srcoff.reserve((size_t)(total_bytes + 64) * 4) && h->w_span.reserve((size_t)(total_bytes + 8 * ndocs + 64) * 8));
+            return !want_off || h->w_span.reserve((size_t)(total_bytes + 8 * ndocs + 64) * 8);
         if (!h->w_cls.reserve((size_t)(total_bytes + 64) * 2) || !h->w_flags.reserve((size_t)((total_bytes >> 10) + 2) * 8)) return false;
         if (want_off && (!h->w_srcoff.reserve((size_t)(total_bytes + 64) * 4) || !h->w_span.reserve((size_t)(total_bytes + 8 * ndocs + 64) * 8))) return false;
         return true;
@@ -363,7 +363,7 @@ int run_device(Handle *h, const char *d_text, const int64_t *d_doc_off, int64_t 
         wp.initial = m.wbd.initial_base; wp.loop_info = m.loop_info; wp.solo_info = m.wave_solo_info; wp.max_token_length = m.max_token_length;
         wp.text = b.text; wp.doc_off = b.doc_off; wp.ndocs = b.ndocs; wp.total_bytes = b.total_bytes;
         wp.ids_tmp = h->w_tmp.as<int32_t>(); wp.counts = h->w_counts.as<int32_t>(); wp.max_ids = max_ids; wp.unk = unk;
-        wp.span_tmp = want_off ? h->w_span.as<int32_t>() : nullptr; wp.src_off = want_off ? h->w_srcoff.as<int32_t>() : nullptr;
+        wp.span_tmp = want_off ? h->w_span.as<int32_t>() : nullptr;
         wp.next_doc = next_doc;
         wp.cold.cpmap = DevCpMap{h->t_cp_l1.as<uint16_t>(), h->t_cp_pages.as<uint32_t>()};
         wp.cold.kind = h->t_kind.as<uint8_t>(); wp.cold.nclasses = m.wbd.nclasses; wp.cold.status = status; wp.cold.no_fast = 0;
@@ -444,7 +444,7 @@ int run_device(Handle *h, const char *d_text, const int64_t *d_doc_off, int64_t 
     launch_scan(sp, s);
     (void)hipEventRecord(h->ev[EV_SCAN], s);
     CompactParams cp{b, h->w_tmp.as<int32_t>(), h->w_counts.as<int32_t>(), d_id_off, d_ids_out, ids_cap, status, slot_mul, first,
-                     want_off ? h->w_span.as<int32_t>() : nullptr, want_off ? h->w_srcoff.as<int32_t>() : nullptr, want_off ? d_starts : nullptr, want_off ? d_ends : nullptr};
+                     want_off ? h->w_span.as<int32_t>() : nullptr, want_off && !use_wave(h, want_off, words) ? h->w_srcoff.as<int32_t>() : nullptr, want_off ? d_starts : nullptr, want_off ? d_ends : nullptr};
     if (ndocs > 0) launch_compact(cp, s);
     (void)hipEventRecord(h->ev[EV_COMPACT], s);
     h->ev_valid = true;
@@ -657,7 +657,7 @@ int64_t run_host_mapped(Handle *h, const char *text, const int64_t *doc_off, int
     wp.initial = m.wbd.initial_base; wp.loop_info = m.loop_info; wp.solo_info = m.wave_solo_info; wp.max_token_length = m.max_token_length;
     wp.text = (const uint8_t *)(dp + SmallLayout::text); wp.doc_off = (const int64_t *)(dp + SmallLayout::off); wp.ndocs = ndocs; wp.total_bytes = total;
     wp.ids_tmp = (int32_t *)(dp + SmallLayout::ids); wp.counts = (int32_t *)(dp + SmallLayout::counts); wp.max_ids = max_ids < 0 ? 0 : max_ids; wp.unk = unk;
-    wp.span_tmp = nullptr; wp.src_off = nullptr;
+    wp.span_tmp = nullptr;
     wp.next_doc = nullptr;              // no work counter: an atomic on host memory costs every wave a trip over the bus
     wp.cold.cpmap = DevCpMap{h->t_cp_l1.as<uint16_t>(), h->t_cp_pages.as<uint32_t>()};
     wp.cold.kind = h->t_kind.as<uint8_t>(); wp.cold.nclasses = m.wbd.nclasses; wp.cold.status = (int *)(dp + SmallLayout::ctrl + 16); wp.cold.no_fast = 0; wp.cold.stats = nullptr;
@@ -1111,12 +1111,13 @@ void shard_bounds(const int64_t *doc_off, int64_t ndocs, int G, int64_t *bounds)
     }
 }
 
-// TextToIdsBatch of a handle with several devices: one host thread per range, each through its own handle, in two phases around one
-// barrier.  Phase 1: text in, kernels, id offsets out -- the ids stay in the range's device buffer; once every range knows its id count
-// the ranges' places in the caller's array are known.  Phase 2: every range copies its ids straight into its place and rebases its
-// offsets in place.  The host holds the caller's input and output and nothing else (a worst-case id array per range -- 4 bytes per
-// input byte for WordPiece -- lives on the device, where it costs nothing but HBM); the caller sees exactly what one device would
-// have returned.
+// TextToIdsBatch of a handle with several devices: one host thread per range, each through its own handle, in two steps.  Step 1: text
+// in, kernels, id offsets out -- the ids stay in the range's device buffer.  As soon as the ranges before it have published their id
+// counts a range knows its place in the caller's array, and step 2 copies its ids straight there and rebases its offsets in place (no
+// barrier: range 0 is on its way out while later ranges are still on their way in).  Ranges that share a DEVICE take turns for step 1
+// (a link moves one direction at full speed: serialising the ways in is what lets the way out of one range overlap the way in of the
+// next).  The host holds the caller's input and output and nothing else: the worst-case id array of a range -- 4 bytes per input byte
+// for WordPiece -- lives on the device.  The caller sees exactly what one device would have returned.
 int64_t run_host_sharded(Handle *h, const std::vector<Handle *> &shards, const char *text, const int64_t *doc_off, int64_t ndocs, int32_t *ids_out, int64_t ids_cap,
                          int64_t *id_off_out, int max_ids, int unk, int32_t *starts_out, int32_t *ends_out)
 {
@@ -1130,53 +1131,50 @@ int64_t run_host_sharded(Handle *h, const std::vector<Handle *> &shards, const c
     int64_t *offs = id_off_out;
     if (!offs) { try { tmp_off.resize((size_t)ndocs + 1); } catch (const std::bad_alloc &) { g_last_error = "out of host memory"; return BF_E_DEVICE; } offs = tmp_off.data(); }
     std::vector<std::string> errs((size_t)G);
-    int32_t flag = 0;                                             // non-NULL marker for "with spans" in phase 1
-    {
-        std::vector<std::thread> th;
-        for (int g = 0; g < G; ++g)
-            th.emplace_back([&, g]() {
-                const int64_t lo = bounds[(size_t)g], nd = bounds[(size_t)g + 1] - lo;
-                // the range's offsets land in the caller's array at once, relative to the range (rebased in phase 2).  Entry lo + nd is also
-                // the first entry of the next range (which writes its 0 there): it is set after the join
-                if (nd == 0) { nids[(size_t)g] = 0; return; }
-                const int64_t r = run_host(shards[(size_t)g], text, doc_off + lo, nd, nullptr, 0, offs + lo, max_ids, unk, want_off ? &flag : nullptr, want_off ? &flag : nullptr, 0, nullptr, true);
-                if (r < 0) errs[(size_t)g] = g_last_error;
-                nids[(size_t)g] = r;
-            });
-        for (auto &t : th) t.join();
-    }
-    for (int g = 0; g < G; ++g) offs[bounds[(size_t)g]] = 0;
-    int64_t total = 0;
-    for (int g = 0; g < G; ++g) {
-        if (nids[(size_t)g] < 0) { g_last_error = errs[(size_t)g]; return nids[(size_t)g]; }      // the failing thread's message reaches the caller
-        base[(size_t)g] = total; total += nids[(size_t)g];
-    }
-    base[(size_t)G] = total;
-    if (id_off_out) id_off_out[ndocs] = total;
-    if (total > ids_cap) {                                        // the offsets are complete (rebased) even so
-        if (id_off_out) for (int g = 0; g < G; ++g) { const int64_t lo = bounds[(size_t)g], nd = bounds[(size_t)g + 1] - lo; for (int64_t i = 0; i < nd; ++i) id_off_out[lo + i] += base[(size_t)g]; }
-        return BF_E_CAPACITY;
-    }
-    if (total > 0 && !ids_out) return BF_E_ARG;
-    std::vector<int> rc((size_t)G, 0);
+    std::vector<int64_t> rc((size_t)G, 0);
+    int32_t flag = 0;                                             // non-NULL marker for "with spans" in step 1
+    static std::mutex turn[64];                                   // step 1 of the ranges of one device, one at a time
+    std::mutex pm; std::condition_variable pcv; int published = 0; bool failed = false;     // counts of ranges 0 .. published - 1 are known
     {
         std::vector<std::thread> th;
         for (int g = 0; g < G; ++g)
             th.emplace_back([&, g]() {
                 Handle *c = shards[(size_t)g];
-                const int64_t n = nids[(size_t)g], at = base[(size_t)g];
-                if (n > 0) {
+                const int64_t lo = bounds[(size_t)g], nd = bounds[(size_t)g + 1] - lo;
+                int64_t r = 0;
+                if (nd > 0) {
+                    // the range's offsets land in the caller's array at once, relative to the range.  Entry lo + nd is also the first entry of the
+                    // next range: the boundary entries are set after the join
+                    std::lock_guard<std::mutex> t(turn[c->device & 63]);
+                    r = run_host(c, text, doc_off + lo, nd, nullptr, 0, offs + lo, max_ids, unk, want_off ? &flag : nullptr, want_off ? &flag : nullptr, 0, nullptr, true);
+                    if (r < 0) errs[(size_t)g] = g_last_error;
+                }
+                int64_t at = 0;
+                {
+                    std::unique_lock<std::mutex> lk(pm);
+                    pcv.wait(lk, [&] { return published == g || failed; });          // the ranges before this one have published
+                    nids[(size_t)g] = r;
+                    if (r < 0 || failed) { failed = true; rc[(size_t)g] = r < 0 ? r : 0; published = g + 1; pcv.notify_all(); return; }
+                    at = base[(size_t)g]; base[(size_t)g + 1] = at + r; published = g + 1;
+                    pcv.notify_all();
+                }
+                if (r > 0 && at + r <= ids_cap && ids_out) {
                     std::lock_guard<std::mutex> lock(c->mu);
                     DeviceGuard dg(c->device);
-                    if (!dg.ok || !hip_ok(hipMemcpy(ids_out + at, c->w_ids.p, (size_t)n * 4, hipMemcpyDeviceToHost), "D2H ids") ||
-                        (want_off && (!hip_ok(hipMemcpy(starts_out + at, c->w_starts.p, (size_t)n * 4, hipMemcpyDeviceToHost), "D2H starts") ||
-                                      !hip_ok(hipMemcpy(ends_out + at, c->w_ends.p, (size_t)n * 4, hipMemcpyDeviceToHost), "D2H ends")))) { rc[(size_t)g] = BF_E_DEVICE; errs[(size_t)g] = g_last_error; }
+                    if (!dg.ok || !hip_ok(hipMemcpy(ids_out + at, c->w_ids.p, (size_t)r * 4, hipMemcpyDeviceToHost), "D2H ids") ||
+                        (want_off && (!hip_ok(hipMemcpy(starts_out + at, c->w_starts.p, (size_t)r * 4, hipMemcpyDeviceToHost), "D2H starts") ||
+                                      !hip_ok(hipMemcpy(ends_out + at, c->w_ends.p, (size_t)r * 4, hipMemcpyDeviceToHost), "D2H ends")))) { rc[(size_t)g] = BF_E_DEVICE; errs[(size_t)g] = g_last_error; }
                 }
-                if (id_off_out && at != 0) { const int64_t lo = bounds[(size_t)g], nd = bounds[(size_t)g + 1] - lo; for (int64_t i = 0; i < nd; ++i) id_off_out[lo + i] += at; }
+                if (id_off_out && at != 0) for (int64_t i = 1; i < nd; ++i) id_off_out[lo + i] += at;      // entry lo itself: after the join
             });
         for (auto &t : th) t.join();
     }
-    for (int g = 0; g < G; ++g) if (rc[(size_t)g] != 0) { g_last_error = errs[(size_t)g]; return rc[(size_t)g]; }
+    for (int g = 0; g < G; ++g) if (nids[(size_t)g] < 0 || rc[(size_t)g] != 0) { g_last_error = errs[(size_t)g]; return nids[(size_t)g] < 0 ? nids[(size_t)g] : rc[(size_t)g]; }      // the failing thread's message reaches the caller
+    const int64_t total = base[(size_t)G];
+    for (int g = 0; g < G; ++g) offs[bounds[(size_t)g]] = base[(size_t)g];
+    offs[ndocs] = total;
+    if (total > ids_cap) return BF_E_CAPACITY;                    // the offsets are complete even so
+    if (total > 0 && !ids_out) return BF_E_ARG;
     return total;
 }
 

@@ -753,11 +753,12 @@ void launch_wp_wave(const WpWaveParams &p, int variant, hipStream_t s)
     // 33.0 / 33.6 / 36.6; two units per lane 39.4; leaving the units phase with fewer than 12 / 24 / 32 / 48 busy units 27.7 / 28.1 /
     // 28.2 / 28.8 (at seven workgroups), 4 / 12 / 24: 25.7 / 26.0 / 26.3 (at eight).
     typedef WvLds<1024, 256, 8> L;
-    if (p.span_tmp) {                   // the offsets API: the instance that carries a span with every id (seven waves per SIMD: it needs a few registers more)
+    if (p.span_tmp) {                   // the offsets API: the instance that carries a span with every id (six waves per SIMD: 24 KB of LDS per workgroup)
+        typedef WvLds<1024, 256, 8, true> LO;
         static int per_cu_off = 0;
         if (per_cu_off <= 0) {
             int q = 0;
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&q, k_wp_wave<L, 1, 3, 7, false, 0, 4, 0, true>, 256, 0) != hipSuccess || q <= 0) q = 2;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&q, k_wp_wave<LO, 1, 3, 6, false, 0, 4, 0, true>, 256, 0) != hipSuccess || q <= 0) q = 2;
             (void)hipGetLastError();
             per_cu_off = q;
         }
@@ -765,7 +766,7 @@ void launch_wp_wave(const WpWaveParams &p, int variant, hipStream_t s)
         const int64_t need = (p.ndocs + (int64_t)grab * 4 - 1) / ((int64_t)grab * 4);
         if (blocks > need) blocks = need;
         if (blocks < 1) blocks = 1;
-        hipLaunchKernelGGL((k_wp_wave<L, 1, 3, 7, false, 0, 4, 0, true>), dim3((unsigned)blocks), dim3(256), 0, s, p, grab);
+        hipLaunchKernelGGL((k_wp_wave<LO, 1, 3, 6, false, 0, 4, 0, true>), dim3((unsigned)blocks), dim3(256), 0, s, p, grab);
         return;
     }
     if (cfg == 14 || cfg == 15) {       // experiments: phase costs by difference (results are wrong by design)
@@ -2485,6 +2486,70 @@ __global__ __launch_bounds__(256) void k_compact(CompactParams p)
     }
 }
 
+// k_compact_text: the copy of k_compact for the offsets instance of the wave program, which stages [first, last] CHARACTER of every id and
+// no character -> byte stream: the byte offsets come from the text itself.  A character starts at every byte that is not a continuation byte
+// (a leading BOM is none, FAUtf8Utils.cpp:247-252; documents with invalid UTF-8 have no ids), so a 64-byte block's start bytes are one ballot;
+// the ids of a document are in text order, so the ones whose first (last) character lies in the block are the next few of the list:
+// one per lane, the k-th start byte of the block by a six-step search over population counts.  End offset = the last character's first
+// byte + its UTF-8 size - 1 (tokdll:1270-1272).  Wave per document.
+__device__ __forceinline__ int select_bit64(unsigned long long m, int k)       // position of the k-th (0-based) set bit of m; k < popcount(m)
+{
+    int pos = 0;
+#pragma unroll
+    for (int step = 32; step >= 1; step >>= 1) {
+        const int c = __popcll((m >> pos) & ((1ull << step) - 1ull));
+        if (k >= c) { pos += step; k -= c; }
+    }
+    return pos;
+}
+
+__global__ __launch_bounds__(256) void k_compact_text(CompactParams p)
+{
+    const int lane = lane_id();
+    const int64_t wave0 = (int64_t)blockIdx.x * 4 + wave_in_block();
+    const int64_t nwaves = (int64_t)gridDim.x * 4;
+    for (int64_t d = wave0; d < p.b.ndocs; d += nwaves) {
+        const int c = p.counts[d];
+        if (c <= 0) continue;
+        const int64_t b = p.b.doc_off[d];
+        const int n = (int)(p.b.doc_off[d + 1] - b);
+        const int64_t id_slot = ids_slot(b, d);
+        const int32_t *src = p.ids_tmp + id_slot;
+        const int32_t *span = p.span_tmp + 2 * id_slot;
+        const int64_t o = p.id_off[d];
+        if (o + c > p.ids_cap) { if (lane == 0) atomicOr(p.status, 1); continue; }
+        for (int i = lane; i < c; i += 64) p.ids_out[o + i] = src[i];
+        const uint8_t *t = p.b.text + b;
+        const int bom = (n >= 3 && t[0] == 0xEF && t[1] == 0xBB && t[2] == 0xBF) ? 3 : 0;
+        int pf = 0, pt = 0, cbase = 0;                              // next id whose first / last character is unresolved; characters before the block
+        for (int blk = 0; blk < n && (pf < c || pt < c); blk += 64) {
+            const int q = blk + lane;
+            const uint32_t v = q < n ? (uint32_t)t[q] : 0x80u;
+            const unsigned long long M = __ballot(q < n && q >= bom && (v & 0xC0u) != 0x80u);
+            const int nchar = __popcll(M);
+            const bool dense = M == (n - blk >= 64 ? ~0ull : ((1ull << (n - blk)) - 1ull));       // a block of plain ASCII: character k is byte k
+            {
+                const int i = pf + lane;
+                const int cf = i < c ? span[2 * i] : 0x7fffffff;
+                const bool in = cf < cbase + nchar;
+                if (in) p.starts_out[o + i] = blk + (dense ? cf - cbase : select_bit64(M, cf - cbase));
+                pf += __popcll(__ballot(in));
+            }
+            {
+                const int i = pt + lane;
+                const int ct = i < c ? span[2 * i + 1] : 0x7fffffff;
+                const bool in = ct < cbase + nchar;
+                const int pos = in ? (dense ? ct - cbase : select_bit64(M, ct - cbase)) : 0;
+                const uint32_t ch = __shfl(v, pos, 64);
+                const int sz = (ch & 0x80) == 0 ? 1 : (ch & 0xE0) == 0xC0 ? 2 : (ch & 0xF0) == 0xE0 ? 3 : (ch & 0xF8) == 0xF0 ? 4 : 0;
+                if (in) p.ends_out[o + i] = blk + pos + (sz > 0 ? sz - 1 : 0);
+                pt += __popcll(__ballot(in));
+            }
+            cbase += nchar;
+        }
+    }
+}
+
 // k_compact_ids: the same copy when only ids are asked for (no offsets).  A wave takes 64 consecutive documents: their count, slot and
 // place in the output are read once, one document per lane (three coalesced loads instead of three dependent loads per document),
 // then handed round with readlane; the copies of two documents are in flight together.  Measured on the 10 M x 512 B workload
@@ -2540,7 +2605,8 @@ void launch_compact(const CompactParams &p, hipStream_t s)
     int64_t blocks = (p.b.ndocs + 3) / 4;
     if (blocks > device_cus() * 16) blocks = device_cus() * 16;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(k_compact, dim3((unsigned)blocks), dim3(256), 0, s, p);
+    if (!p.src_off) hipLaunchKernelGGL(k_compact_text, dim3((unsigned)blocks), dim3(256), 0, s, p);      // the wave program's offsets instance: spans in characters, no character -> byte stream
+    else hipLaunchKernelGGL(k_compact, dim3((unsigned)blocks), dim3(256), 0, s, p);
 }
 
 } // namespace bfa

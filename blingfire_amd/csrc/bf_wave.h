@@ -71,8 +71,8 @@ struct WpWaveParams {
     const uint8_t *text; const int64_t *doc_off; int64_t ndocs, total_bytes;       // the batch (bf_batch.h Batch)
     int32_t *ids_tmp;                // staging: document d writes ids_tmp[ids_slot(doc_off[d], d) ..)
     // offsets API (the OFFS instance of the program, else unused): [2k], [2k + 1] = first / last character of staged id k (indexed like ids_tmp);
-    // src_off[doc_off[d] + c] = byte of document d its character c starts at (what k_compact turns the spans into byte offsets with, tokdll:1263-1273)
-    int32_t *span_tmp; int32_t *src_off;
+    // k_compact_text turns them into byte offsets from the text itself (tokdll:1263-1273)
+    int32_t *span_tmp;
     int32_t *counts;                 // [ndocs]
     int max_ids, unk;
     unsigned long long *next_doc;    // work counter

@@ -28,9 +28,10 @@ BF_WVD uint32_t wv_unpack_info(uint32_t v) { return (v & 0x8000u) ? (LX_INFO_SIM
 // WV_TK_INFO token (wv_pack_info: tags and action indices are small).
 struct WvTok { uint32_t pos, w; };
 constexpr int WV_GRAB_MAX = 8;         // documents a wave takes from the work counter at once, at most
-template <int RING_, int QCAP_, int DTN_>
+template <int RING_, int QCAP_, int DTN_, bool OFFS_ = false>
 struct WvLds {
     static constexpr int RING = RING_, QCAP = QCAP_, DTN = DTN_;
+    uint32_t qid[OFFS_ ? QCAP_ : 1];  // offsets API: the id of a word of one piece (its queue entry keeps the word's position: the span is derived from it at retire)
     alignas(16) uint16_t ring[RING];
     int64_t dt_slot[DTN], dt_doc[DTN];
     alignas(8) WvTok q[QCAP];
@@ -235,11 +236,6 @@ struct WpWave {
 #pragma unroll
                 for (int k = 0; k < 8; ++k) if (k < nb) S.ring[(r + (uint32_t)k) & RMASK] = (uint16_t)e[k];
             }
-            if (OFFS) {                                              // character dec + 8 * lane + k starts at byte q0 + k
-                int32_t *so = p.src_off + (s - p.text) + dec + lane * 8;
-#pragma unroll
-                for (int k = 0; k < 8; ++k) if (k < nb) so[k] = q0 + k;
-            }
             const int total = n - pos < WV_CHUNK ? n - pos : WV_CHUNK;
             dec += total; dec_bytes = pos + WV_CHUNK; rhi = rbase + (uint32_t)dec;
 #pragma unroll
@@ -275,7 +271,6 @@ struct WpWave {
             const bool on = ((em & ~leadm) >> k) & 1u;
             uint16_t *dst = on ? &S.ring[(base + (uint32_t)__builtin_popcount(em & ((1u << k) - 1u))) & RMASK] : &S.spare;
             *dst = (uint16_t)e[k];
-            if (OFFS && ((em >> k) & 1u)) p.src_off[(s - p.text) + (int64_t)(base - rbase) + __builtin_popcount(em & ((1u << k) - 1u))] = q0 + k;     // lead bytes too: every element of the lane
         }
         uint32_t cov = 0;                                                 // bytes behind a lead that belong to its character (bits 8..10: in the next lane)
         bool e_any = false;
@@ -491,7 +486,7 @@ struct WpWave {
                 else { const int32_t *a = acts + info; tag = a[2]; ini = (uint32_t)a[5]; ini_l = (uint32_t)a[6]; call = true; }
                 if (tag != WBD_WORD_TAG) unit_finish(u, 0);                            // tags 2..4: neither a word nor a sub-token
                 else if (!call) {                                                      // a word without sub-tokens (tokdll:1282-1301)
-                    if (OFFS) home_put(u, 0, unk, 0, (u.Lk & 0xFFFF) - 1); else S.q[sl].pos = (uint32_t)unk;
+                    if (OFFS) S.qid[sl] = (uint32_t)unk; else S.q[sl].pos = (uint32_t)unk;
                     unit_finish(u, 1);
                 }
                 else unit_call(u, ini, ini_l, true);
@@ -527,8 +522,13 @@ struct WpWave {
         // The id of a word's only piece stays in LDS (in the queue entry's pos: the unit holds the word's ring position itself); with
         // the second piece the first one moves to its provisional home and the entry gets the position back (retire finds the home by it)
         if (OFFS) {
-            // every id goes to its provisional home with its span (the word's own span for UnkId: tokdll:1282-1297); the entry keeps the word's position
-            if (wv::any(matched || gap)) { if (matched) home_put(u, cnt0, id, u.from, u.fp); else if (gap) home_put(u, 0, unk, 0, L - 1); }
+            // the entry keeps the word's position.  A word's only id stays in LDS (qid) and takes the word's own span at retire (also UnkId:
+            // tokdll:1282-1297); with the second piece the first one moves to its provisional home, its span is [0, the second one's begin - 1]
+            // (the pieces tile the word), and every further piece goes there with its span
+            const bool more = matched && cnt0 >= 1;
+            if (wv::any(more)) { if (more) { if (cnt0 == 1) home_put(u, 0, (int32_t)S.qid[sl], 0, u.from - 1); home_put(u, cnt0, id, u.from, u.fp); } }
+            uint32_t *wq = (gap || (matched && cnt0 == 0)) ? &S.qid[OFFS ? sl : 0] : &S.spare32;
+            *wq = gap ? (uint32_t)unk : (uint32_t)id;
         } else {
         const bool more = matched && cnt0 >= 1;
         if (wv::any(more)) {
@@ -638,14 +638,15 @@ struct WpWave {
         if (act) { slot = S.dt_slot[ke]; cap = S.dt_cap[ke]; dcnt = S.dt_cnt[ke]; w0 = te.pos; f = w0 - S.dt_rbase[ke]; }
         const int32_t *src = ids_tmp + slot + (int64_t)f;          // used by words of two and more pieces only (unit_event); OFFS: by every word
         int32_t v0 = (int32_t)w0, v1 = 0, v2 = 0, v3 = 0;            // a single piece is in q0 itself
-        if (cnt > (OFFS ? 0 : 1)) { v0 = src[0]; if (cnt > 1) v1 = src[1]; }
+        if (cnt > 1) { v0 = src[0]; v1 = src[1]; }
+        if (OFFS && cnt == 1) v0 = (int32_t)S.qid[OFFS ? sl : 0];
         if (cnt > 2) v2 = src[2];
         if (cnt > 3) v3 = src[3];
         int sa0 = 0, sb0 = 0, sa1 = 0, sb1 = 0, sa2 = 0, sb2 = 0, sa3 = 0, sb3 = 0;
         if (OFFS) {
             const int32_t *sp = p.span_tmp + 2 * (slot + (int64_t)f);
-            if (cnt > 0) { sa0 = sp[0]; sb0 = sp[1]; }
-            if (cnt > 1) { sa1 = sp[2]; sb1 = sp[3]; }
+            if (cnt == 1) { sa0 = (int)f; sb0 = (int)f + (int)(te.w & WV_TK_LEN_MASK) - 1; }      // the word's own span
+            if (cnt > 1) { sa0 = sp[0]; sb0 = sp[1]; sa1 = sp[2]; sb1 = sp[3]; }
             if (cnt > 2) { sa2 = sp[4]; sb2 = sp[5]; }
             if (cnt > 3) { sa3 = sp[6]; sb3 = sp[7]; }
         }

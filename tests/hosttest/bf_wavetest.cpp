@@ -58,7 +58,7 @@ long bft_emu_wave_batch(void *hv, const uint8_t *text, long text_bytes, const in
     p.T = m.wbd_t2.data(); p.acts = m.acts_pool.data(); p.acts_n = (int)m.acts_pool.size();
     p.initial = m.wbd.initial_base; p.loop_info = m.loop_info; p.solo_info = m.wave_solo_info; p.max_token_length = m.max_token_length;
     p.text = text; p.doc_off = doc_off; p.ndocs = ndocs; p.total_bytes = total;
-    p.ids_tmp = tmp.data(); p.counts = counts.data(); p.max_ids = max_ids; p.unk = unk; p.next_doc = &next_doc; p.span_tmp = nullptr; p.src_off = nullptr;
+    p.ids_tmp = tmp.data(); p.counts = counts.data(); p.max_ids = max_ids; p.unk = unk; p.next_doc = &next_doc; p.span_tmp = nullptr;
     if (cfg >= 16) { p.next_doc = nullptr; cfg -= 16; }            // cfg + 16: no work counter, the waves take their ranges round-robin
     p.cold.cpmap = DevCpMap{m.wbd_cpmap.l1.data(), m.wbd_cpmap.pages.data()};
     p.cold.kind = m.wave_kind.data(); p.cold.nclasses = m.wbd.nclasses; p.cold.status = &status; p.cold.stats = stats; p.cold.no_fast = cfg == 1 ? 1 : 0;
@@ -92,20 +92,20 @@ long bft_emu_wave_batch_offsets(void *hv, const uint8_t *text, long text_bytes, 
     if (!m.error.empty() || m.kind != KIND_WP || !m.wave_ok) return -1;
     if (max_ids < 0) max_ids = 0;
     const int64_t total = text_bytes;
-    std::vector<int32_t> tmp((size_t)(total + 8 * ndocs + 64 + 8), -77), counts((size_t)ndocs + 1, -55), span(2 * (size_t)(total + 8 * ndocs + 64 + 8), -77), srcoff((size_t)total + 64, -77);
+    std::vector<int32_t> tmp((size_t)(total + 8 * ndocs + 64 + 8), -77), counts((size_t)ndocs + 1, -55), span(2 * (size_t)(total + 8 * ndocs + 64 + 8), -77);
     unsigned long long next_doc = 0, stats[16] = {0}; int status = 0;
     WpWaveParams p;
     p.T = m.wbd_t2.data(); p.acts = m.acts_pool.data(); p.acts_n = (int)m.acts_pool.size();
     p.initial = m.wbd.initial_base; p.loop_info = m.loop_info; p.solo_info = m.wave_solo_info; p.max_token_length = m.max_token_length;
     p.text = text; p.doc_off = doc_off; p.ndocs = ndocs; p.total_bytes = total;
     p.ids_tmp = tmp.data(); p.counts = counts.data(); p.max_ids = max_ids; p.unk = unk; p.next_doc = &next_doc;
-    p.span_tmp = span.data(); p.src_off = srcoff.data();
+    p.span_tmp = span.data();
     p.cold.cpmap = DevCpMap{m.wbd_cpmap.l1.data(), m.wbd_cpmap.pages.data()};
     p.cold.kind = m.wave_kind.data(); p.cold.nclasses = m.wbd.nclasses; p.cold.status = &status; p.cold.stats = stats; p.cold.no_fast = cfg == 1 ? 1 : 0;
     if (ndocs > 0) {
-        if (cfg == 1) run_cfg<WvLds<1024, 128, 2>, 2, true>(p, nwaves, grab);
-        else if (cfg == 2) run_cfg<WvLds<4096, 512, 64>, 3, true>(p, nwaves, grab);
-        else run_cfg<WvLds<1024, 256, 8>, 1, true>(p, nwaves, grab);
+        if (cfg == 1) run_cfg<WvLds<1024, 128, 2, true>, 2, true>(p, nwaves, grab);
+        else if (cfg == 2) run_cfg<WvLds<4096, 512, 64, true>, 3, true>(p, nwaves, grab);
+        else run_cfg<WvLds<1024, 256, 8, true>, 1, true>(p, nwaves, grab);
     }
     if (status) return -5;
     long o = 0;
@@ -114,13 +114,20 @@ long bft_emu_wave_batch_offsets(void *hv, const uint8_t *text, long text_bytes, 
         const int c = counts[(size_t)d];
         if (c < 0) return -6;
         const int64_t b = doc_off[d], slot = wv_ids_slot(b, d);
+        // characters -> bytes from the text itself (what k_compact_text does by ballots): a character starts at every byte that is not a
+        // continuation byte, a leading BOM is none
+        const int n = (int)(doc_off[d + 1] - b);
+        std::vector<int> byte_of;
+        const int bom = (n >= 3 && text[b] == 0xEF && text[b + 1] == 0xBB && text[b + 2] == 0xBF) ? 3 : 0;
+        for (int q = bom; q < n; ++q) if ((text[b + q] & 0xC0) != 0x80) byte_of.push_back(q);
         for (int i = 0; i < c; ++i) {
             if (o + i >= ids_cap) return -9;
             ids_out[o + i] = tmp[(size_t)(slot + i)];
             const int from = span[2 * (size_t)(slot + i)], to = span[2 * (size_t)(slot + i) + 1];
-            const int so = from >= 0 ? srcoff[(size_t)(b + from)] : -1, eo = to >= 0 ? srcoff[(size_t)(b + to)] : -1;
-            int sz = 0;
-            if (eo >= 0) { const uint32_t ch = text[b + eo]; sz = (ch & 0x80) == 0 ? 1 : (ch & 0xE0) == 0xC0 ? 2 : (ch & 0xF0) == 0xE0 ? 3 : (ch & 0xF8) == 0xF0 ? 4 : 0; }
+            if (from < 0 || to < from || (size_t)to >= byte_of.size()) return -12;
+            const int so = byte_of[(size_t)from], eo = byte_of[(size_t)to];
+            const uint32_t ch = text[b + eo];
+            const int sz = (ch & 0x80) == 0 ? 1 : (ch & 0xE0) == 0xC0 ? 2 : (ch & 0xF0) == 0xE0 ? 3 : (ch & 0xF8) == 0xF0 ? 4 : 0;
             starts_out[o + i] = so; ends_out[o + i] = eo + (sz > 0 ? sz - 1 : 0);
         }
         o += c;
