@@ -2515,37 +2515,39 @@ __global__ __launch_bounds__(256) void k_compact_text(CompactParams p)
         const int n = (int)(p.b.doc_off[d + 1] - b);
         const int64_t id_slot = ids_slot(b, d);
         const int32_t *src = p.ids_tmp + id_slot;
-        const int32_t *span = p.span_tmp + 2 * id_slot;
+        const int2 *span = (const int2 *)(p.span_tmp + 2 * id_slot);
         const int64_t o = p.id_off[d];
         if (o + c > p.ids_cap) { if (lane == 0) atomicOr(p.status, 1); continue; }
-        for (int i = lane; i < c; i += 64) p.ids_out[o + i] = src[i];
         const uint8_t *t = p.b.text + b;
+        uint32_t v = lane < n ? (uint32_t)t[lane] : 0x80u;           // the first block travels with the spans
         const int bom = (n >= 3 && t[0] == 0xEF && t[1] == 0xBB && t[2] == 0xBF) ? 3 : 0;
-        int pf = 0, pt = 0, cbase = 0;                              // next id whose first / last character is unresolved; characters before the block
-        for (int blk = 0; blk < n && (pf < c || pt < c); blk += 64) {
-            const int q = blk + lane;
-            const uint32_t v = q < n ? (uint32_t)t[q] : 0x80u;
-            const unsigned long long M = __ballot(q < n && q >= bom && (v & 0xC0u) != 0x80u);
-            const int nchar = __popcll(M);
-            const bool dense = M == (n - blk >= 64 ? ~0ull : ((1ull << (n - blk)) - 1ull));       // a block of plain ASCII: character k is byte k
-            {
-                const int i = pf + lane;
-                const int cf = i < c ? span[2 * i] : 0x7fffffff;
-                const bool in = cf < cbase + nchar;
-                if (in) p.starts_out[o + i] = blk + (dense ? cf - cbase : select_bit64(M, cf - cbase));
-                pf += __popcll(__ballot(in));
+        int blk = 0, cbase = 0;                                        // the block under the lanes, characters before it
+        // the ids in groups of 128, two per lane: their spans are read once, before the blocks they fall into are looked at (what depends on
+        // what: nothing but the running character count -- the block loads are issued one block ahead)
+        for (int g0 = 0; g0 < c; g0 += 128) {
+            const int i0 = g0 + lane, i1 = g0 + 64 + lane;
+            const int2 s0 = i0 < c ? span[i0] : make_int2(0x7fffffff, 0x7fffffff), s1 = i1 < c ? span[i1] : make_int2(0x7fffffff, 0x7fffffff);
+            if (i0 < c) p.ids_out[o + i0] = src[i0];
+            if (i1 < c) p.ids_out[o + i1] = src[i1];
+            int gmax = max(i0 < c ? s0.y : -1, i1 < c ? s1.y : -1);           // the group's last character
+            for (int sh = 32; sh >= 1; sh >>= 1) gmax = max(gmax, __shfl_xor(gmax, sh, 64));
+            while (blk < n) {
+                const int qn = blk + 64 + lane;
+                const uint32_t vn = qn < n ? (uint32_t)t[qn] : 0x80u;        // the next block
+                const int q = blk + lane;
+                const unsigned long long M = __ballot(q < n && q >= bom && (v & 0xC0u) != 0x80u);
+                const int nchar = __popcll(M);
+                const bool dense = M == (n - blk >= 64 ? ~0ull : ((1ull << (n - blk)) - 1ull));
+                const int lo = cbase, hi = cbase + nchar;
+#define BF_CT_START(cf, idx) if ((cf) >= lo && (cf) < hi) p.starts_out[o + (idx)] = blk + (dense ? (cf) - lo : select_bit64(M, (cf) - lo));
+#define BF_CT_END(ct, idx) { const bool in = (ct) >= lo && (ct) < hi; const int pos = in ? (dense ? (ct) - lo : select_bit64(M, (ct) - lo)) : 0; const uint32_t ch = __shfl(v, pos, 64); \
+                             const int sz = (ch & 0x80) == 0 ? 1 : (ch & 0xE0) == 0xC0 ? 2 : (ch & 0xF0) == 0xE0 ? 3 : (ch & 0xF8) == 0xF0 ? 4 : 0; if (in) p.ends_out[o + (idx)] = blk + pos + (sz > 0 ? sz - 1 : 0); }
+                BF_CT_START(s0.x, i0) BF_CT_START(s1.x, i1) BF_CT_END(s0.y, i0) BF_CT_END(s1.y, i1)
+#undef BF_CT_START
+#undef BF_CT_END
+                if (gmax < hi) break;                                   // every id of the group is placed: the next group goes on in this block
+                cbase = hi; blk += 64; v = vn;
             }
-            {
-                const int i = pt + lane;
-                const int ct = i < c ? span[2 * i + 1] : 0x7fffffff;
-                const bool in = ct < cbase + nchar;
-                const int pos = in ? (dense ? ct - cbase : select_bit64(M, ct - cbase)) : 0;
-                const uint32_t ch = __shfl(v, pos, 64);
-                const int sz = (ch & 0x80) == 0 ? 1 : (ch & 0xE0) == 0xC0 ? 2 : (ch & 0xF0) == 0xE0 ? 3 : (ch & 0xF8) == 0xF0 ? 4 : 0;
-                if (in) p.ends_out[o + i] = blk + pos + (sz > 0 ? sz - 1 : 0);
-                pt += __popcll(__ballot(in));
-            }
-            cbase += nchar;
         }
     }
 }
