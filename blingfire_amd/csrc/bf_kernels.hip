@@ -2508,16 +2508,23 @@ __global__ __launch_bounds__(256) void k_compact_text(CompactParams p)
     const int lane = lane_id();
     const int64_t wave0 = (int64_t)blockIdx.x * 4 + wave_in_block();
     const int64_t nwaves = (int64_t)gridDim.x * 4;
-    for (int64_t d = wave0; d < p.b.ndocs; d += nwaves) {
-        const int c = p.counts[d];
+    bool over = false;
+    // a wave takes 64 consecutive documents: count, text range and place in the output are read once, one document per lane (as k_compact_ids does)
+    for (int64_t dbase = wave0 * 64; dbase < p.b.ndocs; dbase += nwaves * 64) {
+      int c_l = 0, n_l = 0; int64_t b_l = 0, o_l = 0;
+      if (dbase + lane < p.b.ndocs) {
+          c_l = p.counts[dbase + lane]; b_l = p.b.doc_off[dbase + lane]; n_l = (int)(p.b.doc_off[dbase + lane + 1] - b_l); o_l = p.id_off[dbase + lane];
+          if (o_l + c_l > p.ids_cap) { over = true; c_l = 0; }
+      }
+      const int nd = p.b.ndocs - dbase < 64 ? (int)(p.b.ndocs - dbase) : 64;
+      for (int dk = 0; dk < nd; ++dk) {
+        const int c = __builtin_amdgcn_readlane(c_l, dk);
         if (c <= 0) continue;
-        const int64_t b = p.b.doc_off[d];
-        const int n = (int)(p.b.doc_off[d + 1] - b);
+        const int64_t d = dbase + dk, b = wv::bcast(b_l, dk), o = wv::bcast(o_l, dk);
+        const int n = __builtin_amdgcn_readlane(n_l, dk);
         const int64_t id_slot = ids_slot(b, d);
         const int32_t *src = p.ids_tmp + id_slot;
         const int2 *span = (const int2 *)(p.span_tmp + 2 * id_slot);
-        const int64_t o = p.id_off[d];
-        if (o + c > p.ids_cap) { if (lane == 0) atomicOr(p.status, 1); continue; }
         const uint8_t *t = p.b.text + b;
         uint32_t v = lane < n ? (uint32_t)t[lane] : 0x80u;           // the first block travels with the spans
         const int bom = (n >= 3 && t[0] == 0xEF && t[1] == 0xBB && t[2] == 0xBF) ? 3 : 0;
@@ -2531,25 +2538,38 @@ __global__ __launch_bounds__(256) void k_compact_text(CompactParams p)
             if (i1 < c) p.ids_out[o + i1] = src[i1];
             int gmax = max(i0 < c ? s0.y : -1, i1 < c ? s1.y : -1);           // the group's last character
             for (int sh = 32; sh >= 1; sh >>= 1) gmax = max(gmax, __shfl_xor(gmax, sh, 64));
+            int so0 = -1, so1 = -1, eo0 = -1, eo1 = -1;                        // the byte offsets of the lane's two ids: stored once, whole rows
             while (blk < n) {
                 const int qn = blk + 64 + lane;
                 const uint32_t vn = qn < n ? (uint32_t)t[qn] : 0x80u;        // the next block
                 const int q = blk + lane;
                 const unsigned long long M = __ballot(q < n && q >= bom && (v & 0xC0u) != 0x80u);
                 const int nchar = __popcll(M);
-                const bool dense = M == (n - blk >= 64 ? ~0ull : ((1ull << (n - blk)) - 1ull));
+                const bool dense = __ballot(q < n && q >= bom && v < 0x80u) == (n - blk >= 64 ? ~0ull : ((1ull << (n - blk)) - 1ull));     // plain ASCII: character k of the block is byte k, one byte long
                 const int lo = cbase, hi = cbase + nchar;
-#define BF_CT_START(cf, idx) if ((cf) >= lo && (cf) < hi) p.starts_out[o + (idx)] = blk + (dense ? (cf) - lo : select_bit64(M, (cf) - lo));
-#define BF_CT_END(ct, idx) { const bool in = (ct) >= lo && (ct) < hi; const int pos = in ? (dense ? (ct) - lo : select_bit64(M, (ct) - lo)) : 0; const uint32_t ch = __shfl(v, pos, 64); \
-                             const int sz = (ch & 0x80) == 0 ? 1 : (ch & 0xE0) == 0xC0 ? 2 : (ch & 0xF0) == 0xE0 ? 3 : (ch & 0xF8) == 0xF0 ? 4 : 0; if (in) p.ends_out[o + (idx)] = blk + pos + (sz > 0 ? sz - 1 : 0); }
-                BF_CT_START(s0.x, i0) BF_CT_START(s1.x, i1) BF_CT_END(s0.y, i0) BF_CT_END(s1.y, i1)
-#undef BF_CT_START
+                // (dense is wave-uniform: the six-step search runs only for blocks that hold a multi-byte character or the BOM)
+#define BF_CT_END(ct, EO, POS) { const bool in = (ct) >= lo && (ct) < hi; const int pos = in ? (POS) : 0; const uint32_t ch = __shfl(v, pos, 64); \
+                                 const int sz = (ch & 0x80) == 0 ? 1 : (ch & 0xE0) == 0xC0 ? 2 : (ch & 0xF0) == 0xE0 ? 3 : (ch & 0xF8) == 0xF0 ? 4 : 0; if (in) EO = blk + pos + (sz > 0 ? sz - 1 : 0); }
+                if (dense) {
+                    if (s0.x >= lo && s0.x < hi) so0 = blk + s0.x - lo;
+                    if (s1.x >= lo && s1.x < hi) so1 = blk + s1.x - lo;
+                    if (s0.y >= lo && s0.y < hi) eo0 = blk + s0.y - lo;        // an ASCII character is one byte
+                    if (s1.y >= lo && s1.y < hi) eo1 = blk + s1.y - lo;
+                } else {
+                    if (s0.x >= lo && s0.x < hi) so0 = blk + select_bit64(M, s0.x - lo);
+                    if (s1.x >= lo && s1.x < hi) so1 = blk + select_bit64(M, s1.x - lo);
+                    BF_CT_END(s0.y, eo0, select_bit64(M, s0.y - lo)) BF_CT_END(s1.y, eo1, select_bit64(M, s1.y - lo))
+                }
 #undef BF_CT_END
                 if (gmax < hi) break;                                   // every id of the group is placed: the next group goes on in this block
                 cbase = hi; blk += 64; v = vn;
             }
+            if (i0 < c) { p.starts_out[o + i0] = so0; p.ends_out[o + i0] = eo0; }
+            if (i1 < c) { p.starts_out[o + i1] = so1; p.ends_out[o + i1] = eo1; }
         }
+      }
     }
+    if (over) atomicOr(p.status, 1);
 }
 
 // k_compact_ids: the same copy when only ids are asked for (no offsets).  A wave takes 64 consecutive documents: their count, slot and

@@ -223,9 +223,13 @@ BF_API int DictGetInfoBatchDevice(void *ModelPtr, const int32_t *d_keys, const i
  * Returns the number of values written, or a negative error. */
 BF_API int BfLastKernelMs(void *ModelPtr, float *ms, int n);
 
-/* Status word of the last batch call (synchronises): 0 = ok; bit 0 = ids_cap overflow; bit 1 = an internal
- * per-document capacity was exceeded (results are not trustworthy; never expected for shipped models); bit 3 = a document's
- * byte range was outside [0, total_bytes] (Device calls: see the precondition above) and was treated as empty. */
+/* Status word of the last batch call (synchronises): 0 = ok; bit 0 (1) = ids_cap overflow; bit 1 (2) and bit 4 (16) = an internal
+ * limit the load-time checks exclude was met (the results of the batch are not to be trusted; the host-buffer calls return
+ * BF_E_INTERNAL); bit 3 (8) = a document's byte range was outside [0, total_bytes] (Device calls: see the precondition above) and was
+ * treated as empty.  Per-document, the rest of the batch is valid: bit 5 (32) = a BPE document on which the reference itself does not
+ * terminate (a skipped start position left without an arc, FATokenSegmentationTools_1best_bpe_t.h:299-313) got 0 ids; bit 6 (64) = a
+ * BPE document's arcs did not fit the pool and it got 0 ids (only the ...BatchDevice forms: the host-buffer calls grow the pool and
+ * run again; BfSetBpePoolBytes). */
 BF_API int BfLastStatus(void *ModelPtr);
 
 /* Last load error message of the calling thread ("" if none). */
