@@ -232,7 +232,7 @@ struct BpeWave {
     // ------------------------------------------------------------------------------------------------------------------
     struct Unit {
         int tok; uint32_t rs; int L; uint32_t ke;
-        int mode, s0, j; uint32_t state; int sum; bool seen, last_final, ovf; int narc, narc0, pw;   // narc0: arcs before the walk of s0; pw: overflow window (-1: none)
+        int mode, s0, j; uint32_t state; int sum; uint32_t seen, last_final, ovf; int narc, narc0, pw;      // seen / last_final / ovf: 0 or 1 (bf_wave.h wv_b)   // narc0: arcs before the walk of s0; pw: overflow window (-1: none)
         unsigned long long single;       // bit s: the element at position s is an entry by itself (its one-element arc is not stored)
     };
     BF_WVD uint32_t *arc_at(const Unit &u, int a) { return a < BW_PRIV ? &S.win[a * 64 + lane] : &S.pool[(a - BW_PRIV) * BW_POOL_N + u.pw]; }
@@ -251,7 +251,7 @@ struct BpeWave {
         const WvTok e = S.q[t & QMASK];
         u.rs = e.pos; u.L = (int)(e.w & WV_TK_LEN_MASK); u.ke = (e.w >> 16) & DMASK;
         S.qc[t & QMASK] = 0;
-        u.state = p.initial; u.sum = 0; u.j = 0; u.s0 = 0; u.seen = false; u.last_final = false; u.ovf = false; u.narc = 0; u.narc0 = 0; u.pw = -1; u.single = 0;
+        u.state = p.initial; u.sum = 0; u.j = 0; u.s0 = 0; u.seen = 0; u.last_final = 0; u.ovf = 0; u.narc = 0; u.narc0 = 0; u.pw = -1; u.single = 0;
         u.mode = (e.w & BW_TK_TS) ? 1 : 2;                              // only a word that starts with U+2581 can be taken whole (:176,189)
         if (p.stats) wv::atomic_add(&p.stats[0], 1ull);
     }
@@ -260,24 +260,27 @@ struct BpeWave {
     // An arc of collection mode is stored as [MPH index : 20 | start : 6 | end : 6]; the solve pass turns the index into the id.
     BF_WVD void unit_step(Unit &u)
     {
-        const bool act = u.tok >= 0 && u.mode != 3 && u.j < u.L;
+        // (truth values as integers, combined in the vector unit: bf_wave.h wv_b)
+        const uint32_t act = wv_b(u.tok >= 0) & wv_b(u.mode != 3) & wv_b(u.j < u.L);
         const uint32_t c = (uint32_t)S.ring[(u.rs + (uint32_t)u.j) & RMASK];
-        const bool valid = act && c < SG_CLS_DELIM_ABSENT;
+        const uint32_t valid = act & wv_b(c < SG_CLS_DELIM_ABSENT);
         const uint64_t e = p.T[valid ? u.state + c : 0u];
-        const bool hit = valid && (e & SG_CLS_MASK) == c;
-        const bool fin = hit && (e & SG_FINAL) != 0;
+        const uint32_t hit = valid & wv_b((uint32_t)(e & SG_CLS_MASK) == c);
+        const uint32_t fin = hit & (uint32_t)((e >> 20) & 1ull);               // SG_FINAL
         u.state = hit ? (uint32_t)((e >> SG_NEXT_SHIFT) & SG_NEXT_MASK) : u.state;
-        u.sum += hit ? (int)(e >> SG_OW_SHIFT) : 0;
-        u.last_final = (u.mode == 1 && act) ? (fin && u.j == u.L - 1 && u.seen) : u.last_final;   // :189: final on the word's last element, after an earlier arc
-        const bool arc = fin && u.mode == 2 && u.j > u.s0;
-        const bool room = (u.narc < BW_PRIV || (u.pw >= 0 && u.narc < BW_WIN)) && (uint32_t)u.sum < (1u << 20);
-        uint32_t *dst = (arc && room) ? arc_at(u, u.narc) : &S.spare32;
+        u.sum += (int)((uint32_t)(e >> SG_OW_SHIFT) & (0u - hit));
+        const uint32_t m1 = wv_b(u.mode == 1), m2 = wv_b(u.mode == 2);
+        u.last_final = (m1 & act) ? (fin & wv_b(u.j == u.L - 1) & u.seen) : u.last_final;   // :189: final on the word's last element, after an earlier arc
+        const uint32_t arc = fin & m2 & wv_b(u.j > u.s0);
+        const uint32_t room = (wv_b(u.narc < BW_PRIV) | (wv_b(u.pw >= 0) & wv_b(u.narc < BW_WIN))) & wv_b((uint32_t)u.sum < (1u << 20));
+        const uint32_t put = arc & room, stop = arc & (room ^ 1u);
+        uint32_t *dst = put ? arc_at(u, u.narc) : &S.spare32;
         *dst = ((uint32_t)u.sum << 12) | ((uint32_t)u.s0 << 6) | (uint32_t)u.j;
-        u.narc += (arc && room) ? 1 : 0;
-        u.ovf = u.ovf || (arc && !room);
-        u.single |= (fin && u.mode == 2 && u.j == u.s0) ? (1ull << u.s0) : 0ull;
-        u.seen = u.seen || fin;
-        u.j = act ? ((hit && !(arc && !room)) ? u.j + 1 : u.L) : u.j;     // an arc that found no room ends the walk: unit_event gets a window or gives up
+        u.narc += (int)put;
+        u.ovf |= stop;
+        u.single |= (unsigned long long)(fin & m2 & wv_b(u.j == u.s0)) << u.s0;
+        u.seen |= fin;
+        u.j = act ? ((hit & (stop ^ 1u)) ? u.j + 1 : u.L) : u.j;     // an arc that found no room ends the walk: unit_event gets a window or gives up
     }
     // A word with more than BW_WIN arcs (a run of one letter whose run lengths are all entries: one word in a million of the config-3
     // corpus): its lane does the whole word alone, the plain sequential program of :151-313 restricted to the word, with the arcs in global
@@ -378,7 +381,7 @@ struct BpeWave {
             if (lane == 0) S.pool_free = freem & ~taken;
             wv::sync();
         }
-        if (retry) { u.narc = u.narc0; u.ovf = false; u.j = u.s0; u.state = p.initial; u.sum = 0; u.seen = false; u.single &= ~(1ull << u.s0); }
+        if (retry) { u.narc = u.narc0; u.ovf = 0; u.j = u.s0; u.state = p.initial; u.sum = 0; u.seen = 0; u.single &= ~(1ull << u.s0); }
         const bool huge = ev && !whole && !retry && !wait && u.mode == 2 && u.ovf && u.pw >= 0 && (uint32_t)u.sum < (1u << 20);   // more than BW_WIN arcs
         if (wv::any(huge)) { if (huge) unit_huge(u); }
         const bool bad = ev && !whole && !retry && !wait && !huge && u.mode == 2 && (!u.seen || u.ovf);      // a start without an arc (an unknown arc, :212-225)
@@ -387,9 +390,9 @@ struct BpeWave {
         const bool first = go && u.mode == 1;                           // not one entry: collect, from the word's first position
         const int ns0 = first ? 0 : u.s0 + 1;
         const bool more = go && ns0 < u.L;
-        u.single = first ? 0ull : u.single; u.narc = first ? 0 : u.narc; u.ovf = first ? false : u.ovf;
+        u.single = first ? 0ull : u.single; u.narc = first ? 0 : u.narc; u.ovf = first ? 0u : u.ovf;
         u.narc0 = go ? u.narc : u.narc0;
-        u.s0 = go ? ns0 : u.s0; u.j = more ? ns0 : u.j; u.state = more ? p.initial : u.state; u.sum = more ? 0 : u.sum; u.seen = more ? false : u.seen;
+        u.s0 = go ? ns0 : u.s0; u.j = more ? ns0 : u.j; u.state = more ? p.initial : u.state; u.sum = more ? 0 : u.sum; u.seen = more ? 0u : u.seen;
         u.mode = go ? (more ? 2 : 3) : u.mode;
     }
     // the solve pass of the lanes in mode 3: ids of the collected arcs, sort by key (:238-255), apply against the interior mask
@@ -646,7 +649,7 @@ struct BpeWave {
         st_wave = wave_id; st_waves = n_waves; st_round = 0;
         if (lane == 0) S.pool_free = (1u << BW_POOL_N) - 1u;
         wv::sync();
-        Unit u; u.narc0 = 0; u.pw = -1; u.tok = -1; u.mode = 0; u.rs = 0; u.L = 0; u.ke = 0; u.s0 = u.j = 0; u.state = 0; u.sum = 0; u.seen = u.last_final = u.ovf = false; u.narc = 0; u.single = 0;
+        Unit u; u.narc0 = 0; u.pw = -1; u.tok = -1; u.mode = 0; u.rs = 0; u.L = 0; u.ke = 0; u.s0 = u.j = 0; u.state = 0; u.sum = 0; u.seen = u.last_final = u.ovf = 0; u.narc = 0; u.single = 0;
         for (;;) {
             bool moved = settle();
             bool filled = false;

@@ -435,7 +435,7 @@ int run_device(Handle *h, const char *d_text, const int64_t *d_doc_off, int64_t 
             bw.prio = sg.bpe_prio; bw.place_id = sg.bpe_place_id;
             bw.stream = sg.stream; bw.lens = sg.lens; bw.doc_off = b.doc_off; bw.slot_mul = mul; bw.ndocs = ndocs;
             bw.ids_tmp = sg.ids_tmp; bw.counts = sg.counts; bw.flags = h->w_bwflags.as<int32_t>(); bw.max_ids = max_ids; bw.next_doc = next_doc; bw.status = status; bw.scratch = (uint32_t *)sg.arcs; bw.stats = h->lex_stats ? (unsigned long long *)(h->w_misc.as<char>() + 64) : nullptr;
-            launch_bpe_wave(bw, s);
+            launch_bpe_wave(bw, (h->variant >> 8) & 0xf, s);
             launch_bpe_seg_flags(sg, bw.flags, h->w_perm.as<int32_t>(), h->w_hist.as<unsigned int>(), s);
         } else if (ndocs > 0) launch_seg_sp(sg, s);
         (void)hipEventRecord(h->ev[EV_TOK], s);

@@ -111,7 +111,7 @@ struct CompactParams {
 void launch_prep_wp(const WpPrepParams &p, int64_t total_bytes, unsigned long long *flags, hipStream_t s);
 void launch_lex_wp(const WpLexParams &p, int variant, hipStream_t s);
 void launch_wp_wave(const WpWaveParams &p, int variant, hipStream_t s);     // unit-form lexers (bf_wave.h): replaces prep + lexer
-void launch_bpe_wave(const BpeWaveParams &p, hipStream_t s);                  // bpe-opt models (bf_bpe_wave_body.h)
+void launch_bpe_wave(const BpeWaveParams &p, int tune, hipStream_t s);                  // bpe-opt models (bf_bpe_wave_body.h)
 void launch_bpe_seg_flags(const SpSegParams &p, const int32_t *flags, int32_t *list, unsigned int *count, hipStream_t s);   // the documents it hands back: bf_bpe_seg_body.h
 void launch_prep_sp(const SpPrepParams &p, hipStream_t s);
 void launch_seg_sp(const SpSegParams &p, hipStream_t s);

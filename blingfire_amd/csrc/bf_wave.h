@@ -42,6 +42,24 @@
 
 namespace bfa {
 
+// A per-lane truth value as an INTEGER (0 / 1) in a vector register.  The compiler keeps a per-lane `bool` as a 64-bit lane mask in scalar
+// registers, and every `&&` / `||` / `!` on it is a scalar instruction: measured on MI355X (tools/microbench/valu_issue.hip), a CU issues
+// ~1 scalar but ~1.8 vector wave-instructions per cycle, and the wave programs are bound by the scalar stream (k_bpe_wave: 9.2 k scalar
+// against 7.8 k vector instructions per document).  Truth values that are combined a lot are therefore made integers once (wv_b) and
+// combined with & | ^ in the vector unit; the empty asm keeps the compiler from turning the integer logic back into mask logic.
+#if defined(__HIPCC__)
+__host__ __device__ __forceinline__ uint32_t wv_b(bool b)
+{
+    uint32_t x = b ? 1u : 0u;
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+v"(x));
+#endif
+    return x;
+}
+#else
+inline uint32_t wv_b(bool b) { return b ? 1u : 0u; }
+#endif
+
 // what a top-level walk that STARTS on an element of this class does (bf_model.cpp, "unit form")
 constexpr uint32_t WK_GENERAL = 0;   // walk the automaton
 constexpr uint32_t WK_LOOP = 1;      // enters the closed, final loop state: the token is the run of WK_LOOP elements (capped by max-length)

@@ -9,6 +9,7 @@
 //   and_ilp8   the same with v_and_b32
 //   mix        v_add_u32 and s_add_u32 alternating (does the scalar unit issue next to the vector unit?)
 //   salu_dep   s_add_u32 chain
+//   mix_3v1s / mix_1v3s   three vector instructions per scalar one, and the reverse: is the limit per kind, or one limit for all instructions?
 // Cycles are s_memtime differences (shader clock) taken by every wave around its loop; the kernel's duration comes from HIP events.
 // Output: per kind and W, wave-instructions per cycle per SIMD by the slowest wave's own cycle count, and the clock = cycles / time.
 // usage: valu_issue [iter]      (run alone; under `rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES` for the counters)
@@ -24,7 +25,7 @@ template <int KIND>
 __global__ __launch_bounds__(256) void k_issue(int iter, unsigned long long *cyc, unsigned *sink)
 {
     unsigned a0 = threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7;
-    unsigned s0 = blockIdx.x;
+    unsigned s0 = blockIdx.x, s1 = blockIdx.x + 1;
     __syncthreads();
     const unsigned long long t0 = __builtin_readcyclecounter();
     for (int it = 0; it < iter; ++it) {
@@ -39,13 +40,19 @@ __global__ __launch_bounds__(256) void k_issue(int iter, unsigned long long *cyc
         } else if (KIND == 3) {
             REP8(asm volatile("v_add_u32 %0, %0, 1\n s_add_u32 %4, %4, 1\n v_add_u32 %1, %1, 1\n s_add_u32 %4, %4, 1\n v_add_u32 %2, %2, 1\n s_add_u32 %4, %4, 1\n v_add_u32 %3, %3, 1\n s_add_u32 %4, %4, 1"
                               : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+s"(s0) : : "scc");)
-        } else {
+        } else if (KIND == 4) {
             REP8(REP8(asm volatile("s_add_u32 %0, %0, 1" : "+s"(s0) : : "scc");))
+        } else if (KIND == 5) {        // three vector : one scalar
+            REP8(asm volatile("v_add_u32 %0, %0, 1\n v_add_u32 %1, %1, 1\n v_add_u32 %2, %2, 1\n s_add_u32 %4, %4, 1\n v_add_u32 %3, %3, 1\n v_add_u32 %0, %0, 1\n v_add_u32 %1, %1, 1\n s_add_u32 %4, %4, 1"
+                              : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+s"(s0) : : "scc");)
+        } else {                       // one vector : three scalar (two scalar chains)
+            REP8(asm volatile("v_add_u32 %0, %0, 1\n s_add_u32 %2, %2, 1\n s_add_u32 %3, %3, 1\n s_add_u32 %2, %2, 1\n v_add_u32 %1, %1, 1\n s_add_u32 %3, %3, 1\n s_add_u32 %2, %2, 1\n s_add_u32 %3, %3, 1"
+                              : "+v"(a0), "+v"(a1), "+s"(s0), "+s"(s1) : : "scc");)
         }
     }
     const unsigned long long t1 = __builtin_readcyclecounter();
     if ((threadIdx.x & 63) == 0) cyc[blockIdx.x * 4 + (threadIdx.x >> 6)] = t1 - t0;
-    if ((a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7 ^ s0) == 0x12345u) sink[0] = a0;
+    if ((a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7 ^ s0 ^ s1) == 0x12345u) sink[0] = a0;
 }
 
 template <int KIND>
@@ -88,6 +95,8 @@ int main(int argc, char **argv)
     run<2>("and_ilp8", 64, 0, iter, cus, d_cyc, d_sink);
     run<3>("mix", 32, 32, iter, cus, d_cyc, d_sink);
     run<4>("salu_dep", 0, 64, iter, cus, d_cyc, d_sink);
+    run<5>("mix_3v1s", 48, 16, iter, cus, d_cyc, d_sink);
+    run<6>("mix_1v3s", 16, 48, iter, cus, d_cyc, d_sink);
     hipFree(d_cyc); hipFree(d_sink);
     return 0;
 }
