@@ -790,22 +790,22 @@ namespace bfa {
 // k_bpe_wave: the BPE wave program (bf_bpe_wave_body.h) on the class streams k_prep_sp wrote.  The program is validated in the test
 // simulator (tests/test_bpe_wave_emu.py); the device path (bf_capi.cpp, behind BfSetVariant bit 0x40 until it has had its GPU parity
 // and timing runs) redoes the documents it hands back (flags[d] = 1) with the lane-per-document kernels.
-template <class LDS, int WPE, int STEPS>
+template <class LDS, int WPE, int STEPS, int UMIN>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_bpe_wave(BpeWaveParams p, int grab)
 {
     __shared__ LDS lds[4];
-    BpeWave<LDS, STEPS> w(p, lds[wave_in_block()]);
+    BpeWave<LDS, STEPS, UMIN> w(p, lds[wave_in_block()]);
     w.run(grab, (int)(blockIdx.x * 4) + wave_in_block(), (int)(gridDim.x * 4));
 }
 
-template <int STEPS>
-static void launch_bpe_wave_steps(const BpeWaveParams &p, hipStream_t s)
+template <int STEPS, int UMIN, int QCAP = 256>
+static void launch_bpe_wave_cfg(const BpeWaveParams &p, hipStream_t s)
 {
-    typedef BwLds<1024, 256, 8> L;
+    typedef BwLds<1024, QCAP, 8> L;
     static int per_cu = 0;
     if (per_cu <= 0) {
         int q = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&q, k_bpe_wave<L, 4, STEPS>, 256, 0) != hipSuccess || q <= 0) q = 2;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&q, k_bpe_wave<L, 4, STEPS, UMIN>, 256, 0) != hipSuccess || q <= 0) q = 2;
         (void)hipGetLastError();
         per_cu = q;
     }
@@ -815,17 +815,20 @@ static void launch_bpe_wave_steps(const BpeWaveParams &p, hipStream_t s)
     const int64_t need = (p.ndocs + (int64_t)grab * 4 - 1) / ((int64_t)grab * 4);
     if (blocks > need) blocks = need;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL((k_bpe_wave<L, 4, STEPS>), dim3((unsigned)blocks), dim3(256), 0, s, p, grab);
+    hipLaunchKernelGGL((k_bpe_wave<L, 4, STEPS, UMIN>), dim3((unsigned)blocks), dim3(256), 0, s, p, grab);
 }
 
-// tune (experiments, BfSetVariant bits 8..11): transitions per round of the units phase
+// tune (experiments, BfSetVariant bits 8..11): 0 = shipped (four transitions per round, the units phase ends with fewer than 32 busy units, a queue
+// of 256 words); 1 .. 3: it ends with fewer than 16 / 4 / 48; 4 / 5: a queue of 512 / 128 words; 6: six transitions per round
 void launch_bpe_wave(const BpeWaveParams &p, int tune, hipStream_t s)
 {
-    if (tune == 3) launch_bpe_wave_steps<3>(p, s);
-    else if (tune == 4) launch_bpe_wave_steps<4>(p, s);
-    else if (tune == 8) launch_bpe_wave_steps<8>(p, s);
-    else if (tune == 12) launch_bpe_wave_steps<12>(p, s);
-    else launch_bpe_wave_steps<6>(p, s);
+    if (tune == 1) launch_bpe_wave_cfg<4, 16>(p, s);
+    else if (tune == 2) launch_bpe_wave_cfg<4, 4>(p, s);
+    else if (tune == 3) launch_bpe_wave_cfg<4, 48>(p, s);
+    else if (tune == 4) launch_bpe_wave_cfg<4, 32, 512>(p, s);
+    else if (tune == 5) launch_bpe_wave_cfg<4, 32, 128>(p, s);
+    else if (tune == 6) launch_bpe_wave_cfg<6, 32>(p, s);
+    else launch_bpe_wave_cfg<4, 32>(p, s);
 }
 
 // ------------------------------------------------------------------------------------------
