@@ -52,6 +52,7 @@ struct SpPrepParams {
     uint16_t *stream;           // element codes after prefix / charmap / whitespace collapse
     int32_t *src_off;           // optional (offsets API): byte offset of the source character of every kept element (-1: dummy prefix)
     int32_t *lens;              // [ndocs] stream length, 0 = "TextToIds returns 0"
+    int old_form;               // experiments: the byte-per-lane kernel
 };
 
 struct SpSegParams {

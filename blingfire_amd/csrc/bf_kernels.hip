@@ -1014,12 +1014,225 @@ __global__ __launch_bounds__(256) void k_prep_sp(SpPrepParams p)
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// k_prep_sp8: the same prologue with EIGHT bytes per lane (512 bytes per wave step), the decoder of the WordPiece wave program
+// (bf_wave_body.h decode_chunk) in front of the _sp rules.  Measured on the multilingual corpus of config 4 (round 4): the byte-per-lane
+// form issues 1,211 scalar + 1,220 vector instructions per 512-byte document -- as many as the whole WordPiece kernel -- because every
+// 64-byte window pays the full set of ballots, shuffles and execution-mask bookkeeping.  Here a chunk costs: one 8-byte load per lane,
+// one LDS look-up per ASCII byte, one trip per lead byte of the fullest lane (a lane of Cyrillic text holds four, of CJK three) with the
+// two-level map gather, a lane-local pass over the lane's (at most eight) characters for the keep rule of the whitespace collapse, one
+// prefix sum, and the stores.  Characters that expand 1 : n (or vanish) take a general form of the two lane-local passes.
+// Per character the rules are those of k_prep_sp above (tokdll:1367-1496, FAUtf8Utils.cpp:121-196,233-270,316-345).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_prep_sp8(SpPrepParams p)
+{
+    __shared__ uint32_t ascii_v[128];
+    __shared__ uint32_t stage_all[4][8 * 64];                  // per wave: map value of the character that starts at byte k of lane l at [k * 64 + l], SP8_NOCHAR: none
+    constexpr uint32_t SP8_NOCHAR = 0xFFFFFFFEu;
+    if (threadIdx.x < 128) ascii_v[threadIdx.x] = cpmap_get(p.cpmap, (int)threadIdx.x);
+    __syncthreads();
+    const int lane = lane_id();
+    uint32_t *stage = stage_all[wave_in_block()];
+    const int64_t wave0 = (int64_t)blockIdx.x * 4 + wave_in_block();
+    const int64_t nwaves = (int64_t)gridDim.x * 4;
+    const uint32_t D = p.delim_code;
+    for (int64_t d = wave0; d < p.b.ndocs; d += nwaves) {
+        const int64_t b = p.b.doc_off[d];
+        const int64_t n64 = p.b.doc_off[d + 1] - b;
+        if (n64 <= 0 || n64 > 1000000000) { if (lane == 0) p.lens[d] = 0; continue; }     // tokdll:1361-1363
+        if (b < 0 || b + n64 > p.b.total_bytes) { if (lane == 0) { p.lens[d] = 0; atomicOr(p.b.status, BF_STATUS_BAD_OFFSETS); } continue; }
+        const int n = (int)n64;
+        const uint8_t *s = p.b.text + b;
+        const int64_t slot = sp_slot(b, d, p.slot_mul);
+        uint16_t *out = p.stream + slot;
+        const int cap = p.slot_mul * (n + 1);
+        const int bom = (n >= 3 && s[0] == 0xEF && s[1] == 0xBB && s[2] == 0xBF) ? 3 : 0;   // also in bytes mode (FAUtf8Utils.cpp:330-335)
+        int outc = 0, normc = 0, decoded = 0;
+        uint32_t prev = 0; bool have_prev = false;
+        for (int k = 0; k < p.prefix_n; ++k) {                                            // the (normalised) dummy prefix: uniform
+            const uint32_t e = p.prefix[k];
+            const bool ws = e == 0xFFFDu;
+            const bool keep = !ws || !have_prev || !sp_delimish(prev, D);
+            if (keep) { if (lane == 0 && outc < cap) { out[outc] = (uint16_t)(ws ? D : e); if (p.src_off) p.src_off[slot + outc] = -1; } ++outc; }
+            prev = e; have_prev = true; ++normc;
+        }
+        bool bad = false;
+        for (int pos = 0; pos < n; pos += 512) {
+            const int q0 = pos + lane * 8;
+            int nb = n - q0; nb = nb < 0 ? 0 : (nb > 8 ? 8 : nb);
+            uint64_t own = 0;
+            if (nb == 8) __builtin_memcpy(&own, s + q0, 8);
+            else for (int k = 0; k < nb; ++k) own |= (uint64_t)s[q0 + k] << (8 * k);
+            uint32_t vmask = nb >= 8 ? 0xFFu : ((1u << nb) - 1u);
+            if (pos == 0 && lane == 0 && bom) vmask &= ~7u;
+            // ---- which bytes start a character, and its map value into the stage
+            uint32_t em;                                                                   // bytes of this lane that start a character
+            const bool plain = p.use_bytes || !__any((own & 0x8080808080808080ull) != 0);
+            if (plain && !p.use_bytes) {
+                em = vmask;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) stage[k * 64 + lane] = ((em >> k) & 1u) ? ascii_v[(uint32_t)(own >> (8 * k)) & 0x7f] : SP8_NOCHAR;
+            } else if (p.use_bytes) {                                                      // every byte is a symbol (FAUtf8Utils.cpp:316-345)
+                em = vmask;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const uint32_t by = (uint32_t)(own >> (8 * k)) & 0xFFu;
+                    uint32_t v = SP8_NOCHAR;
+                    if ((em >> k) & 1u) v = by < 0x80u ? ascii_v[by] : cpmap_get(p.cpmap, (int)by);
+                    stage[k * 64 + lane] = v;
+                }
+            } else {
+                uint32_t nxt = __shfl_down((uint32_t)own, 1, 64);
+                if (lane == 63) { nxt = 0; for (int k = 0; k < 3; ++k) if (q0 + 8 + k < n) nxt |= (uint32_t)s[q0 + 8 + k] << (8 * k); }
+                const uint64_t h80 = own & 0x8080808080808080ull, h40 = (own << 1) & 0x8080808080808080ull;
+                uint32_t m80 = 0, m40 = 0;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) { m80 |= (uint32_t)((h80 >> (8 * k + 7)) & 1ull) << k; m40 |= (uint32_t)((h40 >> (8 * k + 7)) & 1ull) << k; }
+                const uint32_t contm = m80 & ~m40 & vmask, leadm = m80 & m40 & vmask;
+                em = vmask & ~contm;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) stage[k * 64 + lane] = (((em & ~leadm) >> k) & 1u) ? ascii_v[(uint32_t)(own >> (8 * k)) & 0x7f] : SP8_NOCHAR;
+                uint32_t cov = 0; bool e_any = false; uint32_t errm = 0;
+                for (uint32_t lm = leadm; __any(lm != 0);) {                              // one lead byte per lane and trip
+                    if (lm) {
+                        const int k = __builtin_ctz(lm); lm &= lm - 1u;
+                        const int q = q0 + k;
+                        uint64_t w = own >> (8 * k);
+                        if (k) w |= (uint64_t)nxt << (64 - 8 * k);
+                        const uint32_t b0 = (uint32_t)w & 0xFF, b1 = (uint32_t)(w >> 8) & 0xFF, b2 = (uint32_t)(w >> 16) & 0xFF, b3 = (uint32_t)(w >> 24) & 0xFF;
+                        int len, cp; bool er = false;
+                        if ((b0 & 0xE0) == 0xC0) { len = 2; cp = (int)(b0 & 0x1F); }
+                        else if ((b0 & 0xF0) == 0xE0) { len = 3; cp = (int)(b0 & 0x0F); }
+                        else if ((b0 & 0xF8) == 0xF0) { len = 4; cp = (int)(b0 & 0x07); }
+                        else { len = 1; cp = 0; er = true; }
+                        if (q + len > n) er = true;
+                        if (len >= 2) { if ((b1 & 0xC0) != 0x80) er = true; cp = (cp << 6) | (int)(b1 & 0x3F); }
+                        if (len >= 3) { if ((b2 & 0xC0) != 0x80) er = true; cp = (cp << 6) | (int)(b2 & 0x3F); }
+                        if (len >= 4) { if ((b3 & 0xC0) != 0x80) er = true; cp = (cp << 6) | (int)(b3 & 0x3F); }
+                        const int need = cp <= 0x7F ? 1 : cp <= 0x7FF ? 2 : cp <= 0xFFFF ? 3 : cp <= 0x10FFFF ? 4 : 0;
+                        if (need != len) er = true;
+                        if ((cp & 0xFFFFF800) == 0xD800) er = true;
+                        e_any |= er; if (er) errm |= 1u << k;
+                        cov |= (((1u << len) - 1u) & ~1u) << k;
+                        stage[k * 64 + lane] = er ? SP8_NOCHAR : (0x40000000u | (uint32_t)cp);     // the map gathers of all the lane's characters go out together below
+                    }
+                }
+                uint32_t spill = __shfl_up(cov >> 8, 1, 64);
+                if (lane == 0) {
+                    spill = 0;
+                    for (int back = 1; back <= 3 && pos - back >= bom; ++back) {
+                        const uint32_t c0 = s[pos - back];
+                        if ((c0 & 0xC0) == 0x80) continue;
+                        const int len = (c0 & 0xE0) == 0xC0 ? 2 : (c0 & 0xF0) == 0xE0 ? 3 : (c0 & 0xF8) == 0xF0 ? 4 : 1;
+                        if (c0 >= 0xC0 && len > back) spill = (1u << (len - back)) - 1u;
+                        break;
+                    }
+                }
+                if (contm & ~(cov | spill)) e_any = true;
+                if (__any(e_any)) bad = true;
+                em &= ~errm;                                                               // (the document yields nothing anyway)
+            }
+            wave_handoff();
+            // ---- the lane's characters in order: elements, keep rule of the whitespace collapse (ws kept iff the element before it is
+            //      neither ws nor the delimiter), counts
+            uint32_t v[8]; int cnt_el = 0; uint32_t last = 0; bool any_multi = false;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = stage[k * 64 + lane];
+            if (!plain) {                                                                  // decoded code points -> map values: up to eight two-level gathers in flight
+                uint32_t pg[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) { const bool pend = (v[k] >> 30) == 1u; pg[k] = pend ? (uint32_t)p.cpmap.l1[(v[k] & 0x1FFFFFu) >> 8] : 0u; }
+#pragma unroll
+                for (int k = 0; k < 8; ++k) { const bool pend = (v[k] >> 30) == 1u; if (pend) v[k] = p.cpmap.pages[pg[k] * 256u + (v[k] & 255u)]; }
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                if (v[k] != SP8_NOCHAR) {
+                    if (v[k] & 0x80000000u) { any_multi = true; const uint16_t *rec = p.multi_pool + (v[k] & 0x7FFFFFFFu); const int c = (int)rec[0]; cnt_el += c; if (c > 0) last = rec[c]; }
+                    else { ++cnt_el; last = v[k]; }
+                }
+            }
+            const int nchars = __popc(em);
+            const unsigned long long m_has = __ballot(cnt_el > 0);
+            const unsigned long long below = m_has & lanemask_lt();
+            const int pl = below ? 63 - __clzll((long long)below) : 0;
+            const uint32_t pl_last = __shfl(last, pl, 64);
+            uint32_t pe = below ? pl_last : prev; bool hp = below ? true : have_prev;
+            uint32_t keepm = 0; int kept = 0;                                              // common form: bit k = the (single) element of byte k is kept
+            // (per lane: a lane that holds a character with 0 or several elements takes the general form of the two passes, the others --
+            // nearly all -- the straight-line one; with NFKC charmaps about one chunk in two holds such a character somewhere)
+            const bool multi = any_multi;
+            if (!multi) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const bool has = v[k] != SP8_NOCHAR;
+                    const bool ws = v[k] == 0xFFFDu;
+                    const bool keep = has && (!ws || !hp || !sp_delimish(pe, D));
+                    keepm |= keep ? (1u << k) : 0u;
+                    pe = has ? v[k] : pe; hp = hp || has;
+                }
+                kept = __popc(keepm);
+            } else {
+                for (int k = 0; k < 8; ++k) {
+                    if (v[k] == SP8_NOCHAR) continue;
+                    const bool mv = (v[k] & 0x80000000u) != 0;
+                    const uint16_t *rec = p.multi_pool + (v[k] & 0x7FFFFFFFu);
+                    const int c = mv ? (int)rec[0] : 1;
+                    for (int j = 0; j < c; ++j) {
+                        const uint32_t e = mv ? (uint32_t)rec[1 + j] : v[k];
+                        const bool ws = e == 0xFFFDu;
+                        if (!ws || !hp || !sp_delimish(pe, D)) ++kept;
+                        pe = e; hp = true;
+                    }
+                }
+            }
+            const int inc = wave_incl_scan(kept);
+            int idx = outc + inc - kept;
+            if (!multi) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    if ((keepm >> k) & 1u) {
+                        if (idx < cap) { out[idx] = (uint16_t)(v[k] == 0xFFFDu ? D : v[k]); if (p.src_off) p.src_off[slot + idx] = q0 + k; }
+                        ++idx;
+                    }
+                }
+            } else {
+                uint32_t pe2 = below ? pl_last : prev; bool hp2 = below ? true : have_prev;
+                for (int k = 0; k < 8; ++k) {
+                    if (v[k] == SP8_NOCHAR) continue;
+                    const bool mv = (v[k] & 0x80000000u) != 0;
+                    const uint16_t *rec = p.multi_pool + (v[k] & 0x7FFFFFFFu);
+                    const int c = mv ? (int)rec[0] : 1;
+                    for (int j = 0; j < c; ++j) {
+                        const uint32_t e = mv ? (uint32_t)rec[1 + j] : v[k];
+                        const bool ws = e == 0xFFFDu;
+                        if (!ws || !hp2 || !sp_delimish(pe2, D)) { if (idx < cap) { out[idx] = (uint16_t)(ws ? D : e); if (p.src_off) p.src_off[slot + idx] = q0 + k; } ++idx; }
+                        pe2 = e; hp2 = true;
+                    }
+                }
+            }
+            outc += __shfl(inc, 63, 64);
+            normc += __shfl(wave_incl_scan(cnt_el), 63, 64);
+            decoded += __shfl(wave_incl_scan(nchars), 63, 64);
+            if (m_has) { const int hl = 63 - __clzll((long long)m_has); prev = __shfl(last, hl, 64); have_prev = true; }
+            wave_handoff();                                                                // the stage is reused by the next chunk
+        }
+        int len = outc;
+        if (len > 1 && have_prev && sp_delimish(prev, D)) --len;                          // tokdll:1491-1493
+        if (bad || decoded <= 0) len = 0;                                                   // tokdll:1409-1411
+        if (p.has_charmap && (normc <= 0 || normc > 2 * (n + 1))) len = 0;                // tokdll:1440-1444
+        if (len > cap) len = 0;
+        if (lane == 0) p.lens[d] = len;
+    }
+}
+
 void launch_prep_sp(const SpPrepParams &p, hipStream_t s)
 {
     int64_t blocks = (p.b.ndocs + 3) / 4;
     if (blocks > device_cus() * 16) blocks = device_cus() * 16;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(k_prep_sp, dim3((unsigned)blocks), dim3(256), 0, s, p);
+    if (p.old_form) hipLaunchKernelGGL(k_prep_sp, dim3((unsigned)blocks), dim3(256), 0, s, p);      // the byte-per-lane form (A/B runs: BfSetVariant bit 0x80)
+    else hipLaunchKernelGGL(k_prep_sp8, dim3((unsigned)blocks), dim3(256), 0, s, p);
 }
 
 // ------------------------------------------------------------------------------------------
