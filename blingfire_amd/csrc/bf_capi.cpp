@@ -321,12 +321,12 @@ bool reserve_ids_workspaces(Handle *h, int64_t ndocs, int64_t total_bytes, bool 
         return true;
     }
     const size_t cap = (size_t)(m.dict_has_charmap ? 2 : 1) * (size_t)(total_bytes + ndocs) + 64;      // stream elements over all documents
-    if (!h->w_cls.reserve(cap * 2) || !h->w_tmp.reserve(cap * 4)) return false;
+    if (!h->w_cls.reserve(cap * 2 + 512) || !h->w_tmp.reserve(cap * 4)) return false;      // + the sector buffers of the Unigram lane program read up to two sectors past a document
     if (want_off && (!h->w_srcoff.reserve(cap * 4) || !h->w_span.reserve(cap * 8))) return false;
     if (m.kind == KIND_UNIGRAM) {
         // one packed 4-byte record per stream element (bf_seg.h uni_rec; 8 bytes reserved); the sequential / flat variants keep 16-byte records
         const bool lane_form = uni_lane_ok(m);
-        if (!h->w_s1.reserve(cap * (lane_form ? 4 : 16) + 64)) return false;
+        if (!h->w_s1.reserve(cap * (lane_form ? 4 : 16) + 256)) return false;
     } else {
         const size_t bm_words = (cap >> 5) + (size_t)ndocs + 4;
         if (!h->w_s1.reserve((6 * cap + 32 * (size_t)ndocs + 64) * 16) || !h->w_s2.reserve(std::max(cap * 4, 2 * bm_words * 4) + ((size_t)ndocs + 16) * 4) ||

@@ -819,14 +819,13 @@ static void launch_bpe_wave_cfg(const BpeWaveParams &p, hipStream_t s)
 }
 
 // tune (experiments, BfSetVariant bits 8..11): 0 = shipped (four transitions per round, the units phase ends with fewer than 32 busy units, a queue
-// of 256 words); 1 .. 3: it ends with fewer than 16 / 4 / 48; 4 / 5: a queue of 512 / 128 words; 6: six transitions per round
+// of 256 words); 1 .. 3: it ends with fewer than 16 / 4 / 48; 6: six transitions per round (queues of 512 / 128 words measured 22.6 / 22.7 ms
+// against 21.9 and are gone)
 void launch_bpe_wave(const BpeWaveParams &p, int tune, hipStream_t s)
 {
     if (tune == 1) launch_bpe_wave_cfg<4, 16>(p, s);
     else if (tune == 2) launch_bpe_wave_cfg<4, 4>(p, s);
     else if (tune == 3) launch_bpe_wave_cfg<4, 48>(p, s);
-    else if (tune == 4) launch_bpe_wave_cfg<4, 32, 512>(p, s);
-    else if (tune == 5) launch_bpe_wave_cfg<4, 32, 128>(p, s);
     else if (tune == 6) launch_bpe_wave_cfg<6, 32>(p, s);
     else launch_bpe_wave_cfg<4, 32>(p, s);
 }
@@ -1906,6 +1905,64 @@ struct ClsWin2 {
     }
 };
 
+// The same window fed from registers instead of memory: two 64-byte sector buffers follow it (sb0 = the sector of the window's second
+// block, sb1 = the sector after it), so a lane touches every sector of its stream ONCE, and the loads of sb1 are issued for the whole wave at
+// one time (refill(), called where the wave is converged): vector memory loads return in order, so a stream load that misses L2 holds up
+// every table gather issued behind it -- with one 16-byte load per lane and eight positions, some lane of the wave had one in flight on
+// 93 % of the steps.
+struct ClsWinS {
+    static __device__ __forceinline__ uint4 sel4(bool c, const uint4 &x, const uint4 &y) { return make_uint4(c ? x.x : y.x, c ? x.y : y.y, c ? x.z : y.z, c ? x.w : y.w); }
+    const uint4 *cls16; int64_t blk0; int shift; uint4 w0, w1; int t0;
+    uint4 a0, a1, a2, a3, b0, b1, b2, b3; bool have_b;
+    __device__ __forceinline__ void init(const uint16_t *cls_buf, int64_t elem_off)
+    {
+        cls16 = (const uint4 *)cls_buf; blk0 = elem_off >> 3; shift = (int)(elem_off & 7); t0 = -4; w0 = w1 = make_uint4(0, 0, 0, 0);
+        a0 = a1 = a2 = a3 = b0 = b1 = b2 = b3 = w0; have_b = true;
+    }
+    __device__ __forceinline__ void seek(int start)
+    {
+        const int t = (start + shift) >> 3;
+        if (t == t0) return;
+        const int64_t ab = blk0 + t + 1;                    // the block that enters the window
+        if (t == t0 + 1) {
+            w0 = w1;
+            if ((ab & 3) == 0) { a0 = b0; a1 = b1; a2 = b2; a3 = b3; have_b = false; }      // refill() keeps have_b true one block ahead of this
+            const int k = (int)(ab & 3);
+            const bool k1 = (k & 1) != 0, k2 = (k & 2) != 0;
+            const uint4 lo = sel4(k1, a1, a0), hi = sel4(k1, a3, a2);        // component-wise: a select between whole structs goes through memory
+            w1 = sel4(k2, hi, lo);
+        } else {
+            const int64_t sec = ab >> 2;
+            w0 = cls16[blk0 + t]; w1 = cls16[ab];
+            a0 = cls16[sec * 4]; a1 = cls16[sec * 4 + 1]; a2 = cls16[sec * 4 + 2]; a3 = cls16[sec * 4 + 3];
+            b0 = cls16[sec * 4 + 4]; b1 = cls16[sec * 4 + 5]; b2 = cls16[sec * 4 + 6]; b3 = cls16[sec * 4 + 7];
+            have_b = true;
+        }
+        t0 = t;
+    }
+    // wave-converged: when some walking lane comes within a block of needing sb1, every lane that lacks it loads it
+    __device__ __forceinline__ void refill(bool walking)
+    {
+        const int64_t ab = blk0 + t0 + 1;
+        const bool lacks = walking && !have_b;
+        if (__ballot(lacks && (ab & 3) >= 2) == 0) return;
+        if (lacks) {
+            const int64_t sec = (ab >> 2) + 1;
+            b0 = cls16[sec * 4]; b1 = cls16[sec * 4 + 1]; b2 = cls16[sec * 4 + 2]; b3 = cls16[sec * 4 + 3];
+            have_b = true;
+        }
+    }
+    __device__ __forceinline__ uint32_t operator()(int i) const
+    {
+        const int a = i + shift, r = a - (t0 << 3);
+        if ((unsigned)r >= 16u) return ((const uint16_t *)cls16)[(blk0 << 3) + a];
+        const bool hi = (r & 8) != 0, up = (r & 4) != 0;
+        const uint32_t x = hi ? w1.x : w0.x, y = hi ? w1.y : w0.y, z = hi ? w1.z : w0.z, w = hi ? w1.w : w0.w;
+        const uint32_t d0 = up ? z : x, d1 = up ? w : y;
+        return __builtin_amdgcn_perm(d1, d0, 0x0c0c0100u + 0x0202u * (uint32_t)(r & 3));
+    }
+};
+
 // End2BestArc entries of the live window: per-lane rings in LDS, structure-of-arrays (scores: bank pair = lane; records: bank = lane)
 struct RingLds {
     double *sc; uint32_t *rc; int mask, n;
@@ -1918,17 +1975,20 @@ struct RingLds {
 // Unigram-LM, default form: bf_seg.h UniLane per lane, persistent lanes pulling documents (longest first).  Every trip of
 // the loop a walking lane makes UNROLL trie transitions and a lane in its backward pass makes one hop whose record was
 // requested BEFORE the walk steps (its latency hides behind them); finished lanes fetch new documents by vote.
-template <int UNROLL>
-__global__ __launch_bounds__(64) void k_seg_unigram_lane(SpSegParams p, int ring_n)
+template <int UNROLL, bool SPLIT = false, int QN = 4>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void k_seg_unigram_lane(SpSegParams p, int ring_n)
 {
     extern __shared__ double seg_ring[];            // [ring_n][64] scores, then [ring_n][64] packed records
     enum { M_NEED = 0, M_WALK = 1, M_BACK = 2, M_EXIT = 3 };
     const int lane = lane_id();
     RingLds ring{seg_ring + lane, (uint32_t *)(seg_ring + (size_t)ring_n * 64) + lane, ring_n - 1, ring_n};
-    ClsWin2 cls_at; cls_at.init(p.stream, 0);
-    UniLane<ClsWin2, RingLds> ul(p.S, cls_at, ring);
+    typedef typename std::conditional<SPLIT, ClsWinS, ClsWin2>::type Win;
+    Win cls_at; cls_at.init(p.stream, 0);
+    UniLane<Win, RingLds, QN> ul(p.S, cls_at, ring);
     ul.L = 0; ul.depth = p.trie_depth; ul.start = ul.i = ul.sum = 0; ul.state = 0; ul.unknown = true; ul.pend = false; ul.prev = 0; ul.pend_i = 0;
-    ul.pend_score = 0; ul.pend_key = 0; ul.end = 0; ul.cnt = 0; ul.unk_run = 0; ul.q0 = ul.q1 = ul.q2 = ul.q3 = 0; ul.qn = 0; ul.abs0 = 0;
+    ul.pend_score = 0; ul.pend_key = 0; ul.end = 0; ul.cnt = 0; ul.unk_run = 0; ul.qn = 0; ul.abs0 = 0;
+#pragma unroll
+    for (int k = 0; k < QN; ++k) ul.q[k] = 0;
     int mode = M_NEED;
     int64_t doc = 0; int32_t *ids = nullptr; int32_t *spans = nullptr; int cap = 0;
     int32_t g0 = 0, g1 = 0, g2 = 0, g3 = 0; int gn = 0;     // ids of the backward pass waiting for their 16-byte group
@@ -1962,14 +2022,18 @@ __global__ __launch_bounds__(64) void k_seg_unigram_lane(SpSegParams p, int ring
         }
         // ---- backward pass: request this trip's record now, use it after the walk steps
         uint32_t br = 0;
-        const bool back = mode == M_BACK;
+        const bool back = !SPLIT && mode == M_BACK;
         if (back) br = ul.recs[ul.end];
+        if constexpr (SPLIT) cls_at.refill(mode == M_WALK);
         // ---- forward pass: UNROLL trie transitions
         if (mode == M_WALK) {
             bool walk = true;
 #pragma unroll
             for (int u = 0; u < UNROLL; ++u) { if (walk) walk = ul.wstep(); }
-            if (!walk) { ul.begin_back(); mode = M_BACK; }
+            if (!walk) {
+                if (SPLIT) mode = M_NEED;            // the records are complete; k_uni_back reads them
+                else { ul.begin_back(); mode = M_BACK; }
+            }
         }
         if (back) {
             // ids leave in descending address order (right-aligned in the slot): they are queued and stored as whole aligned
@@ -1994,6 +2058,56 @@ __global__ __launch_bounds__(64) void k_seg_unigram_lane(SpSegParams p, int ring
         }
     }
     if (mode != M_EXIT) atomicOr(p.status, 2);      // trip limit hit: never expected
+}
+
+// The backward pass of the lane program as its own kernel (SPLIT instance of k_seg_unigram_lane): a lane per document hops from record to
+// record (…_1best_t.h:237-265).  Every hop is a load that misses L2 (the records were written once, long ago); inside the forward kernel such
+// a load holds up the table gathers issued behind it (vector memory loads return in order), here nothing else waits.
+__global__ __launch_bounds__(256) void k_uni_back(SpSegParams p)
+{
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= p.b.ndocs) return;
+    const int64_t doc = idx;
+    const int L = p.lens[doc];
+    if (L <= 0) return;                               // counts / narcs were written by the forward kernel
+    const int64_t b = p.b.doc_off[doc];
+    const int64_t slot = sp_slot(b, doc, p.slot_mul);
+    const int cap = p.slot_mul * (int)(p.b.doc_off[doc + 1] - b + 1);
+    int32_t *ids = p.ids_tmp + slot; int32_t *spans = p.span_tmp ? p.span_tmp + 2 * slot : nullptr;
+    struct NoCls { __device__ void seek(int) {} __device__ uint32_t operator()(int) const { return 0; } } nocls;
+    struct NoRing { __device__ double score(int) const { return 0; } __device__ uint32_t rec(int) const { return 0; } __device__ void set(int, double, uint32_t) {} __device__ void fill(double) {} } noring;
+    UniLane<NoCls, NoRing> ul(p.S, nocls, noring);
+    ul.L = L; ul.recs = (uint32_t *)p.best + slot;
+    ul.begin_back();
+    int32_t g0 = 0, g1 = 0, g2 = 0, g3 = 0; int gn = 0;
+    // the records are read a 64-byte sector at a time (16 positions, ~4 hops) and kept in registers: with half a million documents in flight
+    // nothing survives in L2 between two hops of one lane, so a 4-byte load per hop fetched every sector four times over
+    const uint4 *rec16 = (const uint4 *)p.best;
+    uint4 r0 = make_uint4(0, 0, 0, 0), r1 = r0, r2 = r0, r3 = r0; int64_t cur = -1;
+    for (;;) {
+        const int64_t a = slot + ul.end, sec = a >> 4;
+        if (sec != cur) { r0 = rec16[sec * 4]; r1 = rec16[sec * 4 + 1]; r2 = rec16[sec * 4 + 2]; r3 = rec16[sec * 4 + 3]; cur = sec; }
+        const int k = (int)(a & 15);
+        const bool k4 = (k & 4) != 0, k8 = (k & 8) != 0;
+        const uint32_t x = k8 ? (k4 ? r3.x : r2.x) : (k4 ? r1.x : r0.x), y = k8 ? (k4 ? r3.y : r2.y) : (k4 ? r1.y : r0.y);
+        const uint32_t z = k8 ? (k4 ? r3.z : r2.z) : (k4 ? r1.z : r0.z), w = k8 ? (k4 ? r3.w : r2.w) : (k4 ? r1.w : r0.w);
+        const uint32_t br = (k & 2) ? ((k & 1) ? w : z) : ((k & 1) ? y : x);
+        int32_t *dst = nullptr;
+        auto put = [&](int kk, int id, int from, int to) {
+            g3 = g2; g2 = g1; g1 = g0; g0 = id; ++gn;
+            dst = ids + (cap - 1 - kk);
+            if (spans) { spans[2 * (cap - 1 - kk)] = from; spans[2 * (cap - 1 - kk) + 1] = to; }
+        };
+        const bool more = ul.bstep(br, put, p.unk);
+        if (!more || (((uintptr_t)dst >> 2) & 3) == 0) {
+            if (gn == 4 && (((uintptr_t)dst >> 2) & 3) == 0) *(int4 *)dst = make_int4(g0, g1, g2, g3);
+            else { dst[0] = g0; if (gn > 1) dst[1] = g1; if (gn > 2) dst[2] = g2; if (gn > 3) dst[3] = g3; }
+            gn = 0;
+        }
+        if (!more) break;
+    }
+    p.counts[doc] = ul.cnt < p.max_ids ? ul.cnt : p.max_ids;
+    p.narcs[doc] = cap - ul.cnt;
 }
 
 // BPE, documents whose arcs exceed the per-document reserve (narcs == -1 on the fallback list; a long run of one character whose
@@ -2061,18 +2175,21 @@ void launch_seg_sp(const SpSegParams &p_in, hipStream_t s)
             int ring = 1; while (ring < p.trie_depth) ring <<= 1;
             const size_t lds = (size_t)ring * 64 * (sizeof(double) + sizeof(uint32_t));
             int per_cu = 0;
+            const bool one_kernel = (p.variant & 0x20) != 0;     // A/B runs: forward and backward pass in one kernel (the form of rounds 2..3)
             const int unroll = p.tune ? p.tune : 3;
-            auto kern = unroll == 1 ? (const void *)k_seg_unigram_lane<1> : unroll == 2 ? (const void *)k_seg_unigram_lane<2> :
-                        unroll == 4 ? (const void *)k_seg_unigram_lane<4> : (const void *)k_seg_unigram_lane<3>;
+            auto kern = one_kernel ? (const void *)k_seg_unigram_lane<3> : unroll == 4 ? (const void *)k_seg_unigram_lane<4, true, 8> : (const void *)k_seg_unigram_lane<3, true, 8>;
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 64, lds) != hipSuccess || per_cu <= 0) per_cu = 8;
             (void)hipGetLastError();
             if (p.tune2 > 0 && p.tune2 < per_cu) per_cu = p.tune2;
             unsigned blocks = (unsigned)device_cus() * (unsigned)per_cu;
             if ((int64_t)blocks > (int64_t)b64) blocks = b64;
-            if (unroll == 1) hipLaunchKernelGGL(k_seg_unigram_lane<1>, dim3(blocks), dim3(64), lds, s, p, ring);
-            else if (unroll == 2) hipLaunchKernelGGL(k_seg_unigram_lane<2>, dim3(blocks), dim3(64), lds, s, p, ring);
-            else if (unroll == 4) hipLaunchKernelGGL(k_seg_unigram_lane<4>, dim3(blocks), dim3(64), lds, s, p, ring);
-            else hipLaunchKernelGGL(k_seg_unigram_lane<3>, dim3(blocks), dim3(64), lds, s, p, ring);
+            if (one_kernel) hipLaunchKernelGGL(k_seg_unigram_lane<3>, dim3(blocks), dim3(64), lds, s, p, ring);
+            else {
+                // forward pass (persistent lanes, records out), then the backward pass over every document
+                if (unroll == 4) hipLaunchKernelGGL((k_seg_unigram_lane<4, true, 8>), dim3(blocks), dim3(64), lds, s, p, ring);
+                else hipLaunchKernelGGL((k_seg_unigram_lane<3, true, 8>), dim3(blocks), dim3(64), lds, s, p, ring);
+                hipLaunchKernelGGL(k_uni_back, dim3((unsigned)((p.b.ndocs + 255) / 256)), dim3(256), 0, s, p);
+            }
         }
     } else {
         SpSegParams p = p_in;

@@ -115,7 +115,7 @@ BF_HD int seg_unigram_doc(const SegTables &S, ClsAt &cls_at, int L, SegBest *bes
 // with changes of *mechanism* that keep every value identical:
 //  * only `depth` End2BestArc entries are live at a time (an arc from `start` ends before start + depth, depth = longest
 //    dictionary entry): score AND {begin, id} sit in a ring (LDS on the device).  An entry is final when `start` moves past its
-//    position -- it is then written to memory ONCE, packed into 32 bits, four positions per 16-byte store (measured on MI355X:
+//    position -- it is then written to memory ONCE, packed into 32 bits, QN positions per aligned group (16 bytes, or a whole 64-byte sector in the split form) (measured on MI355X:
 //    8-byte records stored on every improvement cost 12.5 GB of write traffic per 0.3 GB of text and evicted the tables from L2);
 //  * the relaxation of a final transition is DEFERRED by one step: the I2Info row is requested when the transition is taken
 //    and consumed at the beginning of the next step, behind the issue of that step's trie gather -- the two dependent
@@ -133,12 +133,12 @@ constexpr uint32_t UNI_REC_NONE = 0xFFFFFFFFu, UNI_LEN_MAX = 4095u;
 constexpr int UNI_MAX_ID = (1 << 20) - 3;
 BF_HD uint32_t uni_rec(int id, int len) { const uint32_t l = (uint32_t)(len - 1); return ((uint32_t)(id + 1) & 0xFFFFFu) | ((l < UNI_LEN_MAX ? l : UNI_LEN_MAX) << 20); }
 
-template <class ClsAt, class Ring>
+template <class ClsAt, class Ring, int QN = 4>
 struct UniLane {
     const SegTables &S; ClsAt &cls_at; Ring &ring; uint32_t *recs;
     int L, depth, start, i, sum; uint32_t state; bool unknown, pend; double prev; uint32_t pend_score; int pend_key; int pend_i;
     int unk_run;                                       // length of the unknown run that ends at start - 1 (0: that position is not unknown)
-    uint32_t q0, q1, q2, q3; int qn;                   // final records of the last positions, not yet stored (qn of them, q3 newest)
+    uint32_t q[QN]; int qn;                            // final records of the last positions, not yet stored (qn of them, q[QN - 1] newest; static indices only: registers)
     int64_t abs0;                                      // absolute element index of position 0 (16-byte store groups are aligned on it)
     int end, cnt;                                      // backward pass
 
@@ -152,7 +152,7 @@ struct UniLane {
         L = L_; depth = depth_; recs = recs_; abs0 = abs0_;
         ring.fill(neg_flt_max());
         start = 0; i = 0; state = S.initial; sum = 0; unknown = true; prev = 0; pend = false; pend_i = 0; pend_score = 0; pend_key = 0;
-        unk_run = 0; q0 = q1 = q2 = q3 = 0; qn = 0;
+        unk_run = 0; for (int k = 0; k < QN; ++k) q[k] = 0; qn = 0;
         end = 0; cnt = 0;
         cls_at.seek(0);
     }
@@ -167,20 +167,25 @@ struct UniLane {
     // the record of position p (= start) is final: queue it, store whole aligned groups of four
     BF_HD void finalize(int p, uint32_t r)
     {
-        q0 = q1; q1 = q2; q2 = q3; q3 = r; ++qn;
-        const int64_t a = abs0 + p;
-        if ((a & 3) == 3 || p == L - 1) {
-            if (qn == 4 && (a & 3) == 3) {
 #if defined(__HIP_DEVICE_COMPILE__)
-                *(uint4 *)(recs + (p - 3)) = make_uint4(q0, q1, q2, q3);
+#pragma unroll
+#endif
+        for (int k = 0; k + 1 < QN; ++k) q[k] = q[k + 1];
+        q[QN - 1] = r; ++qn;
+        const int64_t a = abs0 + p;
+        if ((a & (QN - 1)) == QN - 1 || p == L - 1) {
+            if (qn == QN && (a & (QN - 1)) == QN - 1) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+                for (int k = 0; k < QN; k += 4) *(uint4 *)(recs + (p - (QN - 1) + k)) = make_uint4(q[k], q[k + 1], q[k + 2], q[k + 3]);
 #else
-                recs[p - 3] = q0; recs[p - 2] = q1; recs[p - 1] = q2; recs[p] = q3;
+                for (int k = 0; k < QN; ++k) recs[p - (QN - 1) + k] = q[k];
 #endif
             } else {                                   // a group that the document only partly owns (its first / last positions)
-                if (qn > 3) recs[p - 3] = q0;
-                if (qn > 2) recs[p - 2] = q1;
-                if (qn > 1) recs[p - 1] = q2;
-                recs[p] = q3;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+                for (int j = 0; j < QN; ++j) if (qn > j) recs[p - j] = q[QN - 1 - j];
             }
             qn = 0;
         }

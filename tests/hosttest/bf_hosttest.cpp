@@ -294,14 +294,22 @@ static int emu_sp(const Model &m, const char *s, int n, int32_t *ids, int32_t *s
         int ring_n = 1; while (ring_n < m.trie_max_depth) ring_n <<= 1;
         HostRing ring{std::vector<double>((size_t)ring_n), std::vector<uint32_t>((size_t)ring_n), ring_n - 1};
         HostSeek hs{cp};
-        // the record array starts at an arbitrary element of a 16-byte aligned array, like a document slot on the device
-        const int64_t abs0 = (int64_t)(n % 7);
-        std::vector<uint32_t> recs_all((size_t)L + 16, 0xDEADBEEFu);
-        uint32_t *recs = recs_all.data() + 8;
+        // the record array starts at an arbitrary element of a 64-byte aligned array, like a document slot on the device; the forward pass
+        // runs in both forms of the record queue (groups of 4: one kernel; groups of 16: the split form) and must leave the same records
+        const int64_t abs0 = (int64_t)(n % 23);
+        std::vector<uint32_t> recs_all((size_t)L + 64, 0xDEADBEEFu), recs_all16((size_t)L + 64, 0xDEADBEEFu);
+        uint32_t *recs = recs_all.data() + 32;
         UniLane<HostSeek, HostRing> ul(S, hs, ring);
         ul.init(L, m.trie_max_depth, recs, abs0);
         while (ul.wstep()) {}
-        if (recs_all[7] != 0xDEADBEEFu || recs_all[(size_t)L + 8] != 0xDEADBEEFu) return -3;     // a group store left the document's own range
+        {
+            HostRing ring16{std::vector<double>((size_t)ring_n), std::vector<uint32_t>((size_t)ring_n), ring_n - 1};
+            UniLane<HostSeek, HostRing, 16> ul16(S, hs, ring16);
+            ul16.init(L, m.trie_max_depth, recs_all16.data() + 32, abs0);
+            while (ul16.wstep()) {}
+            if (recs_all16 != recs_all) return -3;
+        }
+        if (recs_all[31] != 0xDEADBEEFu || recs_all[(size_t)L + 32] != 0xDEADBEEFu) return -3;     // a group store left the document's own range
         ul.begin_back();
         std::vector<int32_t> rid, rfrom, rto;              // ids in backward order, like the device's right-aligned slot
         auto put = [&](int, int id, int from, int to) { rid.push_back(id); rfrom.push_back(from); rto.push_back(to); };

@@ -1,8 +1,8 @@
 #!/bin/bash
-# round 4, session L: k_seg_unigram_lane with its streams (class stream, position records, ids) marked non-temporal (variant bit 0x20)
+# round 4, session M: the Unigram backward pass as its own kernel (variant bit 0x20: k_seg_unigram_lane<3, true> + k_uni_back)
 set -u
 export TMPDIR=/tmp
-O=$PWD/gpurun_out/r4l; mkdir -p $O
+O=$PWD/gpurun_out/r4m; mkdir -p $O
 root=${GRAFT_REPO_ROOT:-$PWD}
 Q="--no-cpu-baseline --no-extra-timings --steps 3 --warmup 1"
 for spec in "config4 3" "config4 35" "config5 3" "config5 35"; do
@@ -25,8 +25,10 @@ try:
     db = sqlite3.connect(glob.glob(os.path.join(sys.argv[1], "**", "*.db"), recursive=True)[0])
     tabs = [r[0] for r in db.execute("select name from sqlite_master where type in ('table','view')")]
     v = [t for t in tabs if t.startswith("counters_collection")][0]
-    for k, c, a in db.execute("select kernel_name, counter_name, avg(value) from %s where kernel_name like '%%unigram%%' group by kernel_name, counter_name" % v):
+    for k, c, a in db.execute("select kernel_name, counter_name, avg(value) from %s where kernel_name like '%%uni%%' group by kernel_name, counter_name" % v):
         print("variant", sys.argv[2], k[:50], c, "%.4g" % a)
 except Exception as e: print("pmc failed", e); print(open("/tmp/pmc%s.err" % sys.argv[2]).read()[-800:])
 PY
 done
+rm -rf /tmp/q_st; timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/q_st/stats -o stats -- python $root/bench.py --workload config4 --variant 35 --no-cpu-baseline --no-extra-timings --verify 0 --steps 2 --warmup 1 --docs 10000000 > /dev/null 2> /tmp/st.err
+python $root/tools/prof_summary.py /tmp/q_st $O/config4_v35_kernels.txt > /dev/null 2> $O/summary.err; head -8 $O/config4_v35_kernels.txt | cut -c1-110
