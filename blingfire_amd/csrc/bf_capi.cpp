@@ -31,6 +31,14 @@ namespace {
 
 thread_local std::string g_last_error;
 
+// a spin-wait hint (x86: pause; elsewhere nothing -- the loops it sits in are bounded and fall back to a futex wait)
+static inline void cpu_relax()
+{
+#if defined(__x86_64__) || defined(__i386__)
+    __builtin_ia32_pause();
+#endif
+}
+
 bool hip_ok(hipError_t e, const char *what)
 {
     if (e == hipSuccess) return true;
@@ -668,18 +676,17 @@ int64_t run_host_mapped(Handle *h, const char *text, const int64_t *doc_off, int
     h->small_status = *(const int *)(hp + SmallLayout::ctrl + 16);
     if (h->small_status & (2 | BF_STATUS_INTERNAL)) return BF_E_INTERNAL;
     const int32_t *counts = (const int32_t *)(hp + SmallLayout::counts), *ids = (const int32_t *)(hp + SmallLayout::ids);
+    // the offsets are complete whatever ids_cap is (like the other host paths); ids are copied only when all of them fit
     int64_t n = 0;
-    for (int64_t d = 0; d < ndocs; ++d) {
-        if (id_off_out) id_off_out[d] = n;
-        const int c = counts[d];
-        if (c > 0) {
-            if (n + c > ids_cap) return BF_E_CAPACITY;
-            if (!ids_out) return BF_E_ARG;
-            memcpy(ids_out + n, ids + wv_ids_slot(off[d], d), (size_t)c * 4);
-        }
-        n += c;
-    }
+    for (int64_t d = 0; d < ndocs; ++d) { if (id_off_out) id_off_out[d] = n; n += counts[d] > 0 ? counts[d] : 0; }
     if (id_off_out) id_off_out[ndocs] = n;
+    if (n > ids_cap) return BF_E_CAPACITY;
+    if (n > 0 && !ids_out) return BF_E_ARG;
+    int64_t at = 0;
+    for (int64_t d = 0; d < ndocs; ++d) {
+        const int c = counts[d];
+        if (c > 0) { memcpy(ids_out + at, ids + wv_ids_slot(off[d], d), (size_t)c * 4); at += c; }
+    }
     return n;
 }
 
@@ -1039,7 +1046,7 @@ int text_to_ids_one(void *hp, const char *s, int n, int32_t *ids, int max_ids, i
         lk.unlock();
         for (;;) {
             if (h->q_spinners.fetch_add(1) < g_max_spinners) {
-                for (int spin = 0; spin < 3000 && me.state.load(std::memory_order_acquire) == ONE_WAITING; ++spin) __builtin_ia32_pause();
+                for (int spin = 0; spin < 3000 && me.state.load(std::memory_order_acquire) == ONE_WAITING; ++spin) cpu_relax();
             }
             h->q_spinners.fetch_sub(1);
             if (me.state.load(std::memory_order_acquire) != ONE_WAITING) break;
@@ -1063,6 +1070,20 @@ int text_to_ids_one(void *hp, const char *s, int n, int32_t *ids, int max_ids, i
         lk.unlock();
         while (!all.empty()) {                                // groups of requests with the same call parameters
             std::vector<Handle::OneReq *> g, rest; int64_t bytes = 0, idcap = 0;
+            // the grouping allocates: out of memory here must not leave the taken requests waiting for ever -- they are answered 0
+            // (the reference's "no ids" result) and the lead goes on
+            try { g.reserve(all.size()); rest.reserve(all.size()); }
+            catch (const std::bad_alloc &) {
+                for (Handle::OneReq *q : all) {
+                    q->result = 0;
+                    if (q == &me) continue;
+                    std::atomic<int> *w = &q->state;
+                    w->store(ONE_DONE);
+                    if (h->q_sleepers.load() > 0) one_wake_word(w);
+                }
+                all.clear();
+                break;
+            }
             for (Handle::OneReq *q : all) {
                 const bool same = q->max_ids == all[0]->max_ids && q->unk == all[0]->unk && ((q->starts && q->ends) == (all[0]->starts && all[0]->ends));
                 const int64_t c = one_doc_cap(q->n, q->max_ids);
@@ -1605,7 +1626,12 @@ int BfReserve(void *p, int64_t max_docs, int64_t max_bytes, int want_offsets)
     if (h->m.kind == KIND_I2W) return BF_E_UNSUPPORTED;
     std::lock_guard<std::mutex> lock(h->mu);
     DeviceGuard dg(h->device); if (!dg.ok) return BF_E_DEVICE;
-    return reserve_ids_workspaces(h, max_docs, max_bytes, want_offsets != 0) ? 0 : BF_E_DEVICE;
+    // both forms of the WordPiece path: the wave program's workspaces and (words = 1 skips use_wave()'s early return) the class stream and flags of
+    // the lane-per-document kernels, which TextToWords / TextToSentences, lexers outside the unit form and BfSetVariant(2) run -- no hipMalloc
+    // (= device synchronisation) inside a later call of either kind
+    if (!reserve_ids_workspaces(h, max_docs, max_bytes, want_offsets != 0)) return BF_E_DEVICE;
+    if (h->m.kind == KIND_WP && !reserve_ids_workspaces(h, max_docs, max_bytes, true, 1)) return BF_E_DEVICE;
+    return 0;
 }
 
 int SetNoDummyPrefix(void *p, bool flag)          /* reference signature: blingfiretokdll.h:103 */
@@ -1625,7 +1651,7 @@ int64_t TextToIdsBatch(void *p, const char *text, const int64_t *doc_offsets, in
     if (!h) return BF_E_ARG;
     std::vector<Handle *> shards;
     { std::lock_guard<std::mutex> lock(h->mu); shards = h->shards; }      // a snapshot: BfSetDevices may replace the list (not while a batch call runs: documented)
-    if (shards.size() > 1) return run_host_sharded(h, shards, text, doc_offsets, ndocs, ids_out, ids_cap, id_offsets_out, max_ids_per_doc, unk, nullptr, nullptr);
+    if (shards.size() > 1 || (shards.size() == 1 && shards[0] != h)) return run_host_sharded(h, shards, text, doc_offsets, ndocs, ids_out, ids_cap, id_offsets_out, max_ids_per_doc, unk, nullptr, nullptr);
     return run_host(h, text, doc_offsets, ndocs, ids_out, ids_cap, id_offsets_out, max_ids_per_doc, unk);
 }
 
@@ -1683,7 +1709,7 @@ int64_t TextToIdsWithOffsetsBatch(void *p, const char *text, const int64_t *doc_
     if (!h) return BF_E_ARG;
     std::vector<Handle *> shards;
     { std::lock_guard<std::mutex> lock(h->mu); shards = h->shards; }
-    if (shards.size() > 1 && starts_out && ends_out) return run_host_sharded(h, shards, text, doc_offsets, ndocs, ids_out, cap, id_offsets_out, max_ids_per_doc, unk, starts_out, ends_out);
+    if ((shards.size() > 1 || (shards.size() == 1 && shards[0] != h)) && starts_out && ends_out) return run_host_sharded(h, shards, text, doc_offsets, ndocs, ids_out, cap, id_offsets_out, max_ids_per_doc, unk, starts_out, ends_out);
     return run_host(h, text, doc_offsets, ndocs, ids_out, cap, id_offsets_out, max_ids_per_doc, unk, starts_out, ends_out);
 }
 
