@@ -55,7 +55,7 @@ def build_product(force=False):
 def build_test_infra(force=False):
     odir = os.path.join(ROOT, "oracle")
     lib = os.path.join(odir, "liboracle.so")
-    if force or _newer(lib, [os.path.join(odir, "bf_oracle.c"), os.path.join(odir, "bf_oracle.h")]):
+    if force or _newer(lib, [os.path.join(odir, "bf_oracle.c"), os.path.join(odir, "bf_oracle.h"), os.path.join(odir, "bf_tolower_tab.h")]):
         _run(["gcc", "-O2", "-Wall", "-Wextra", "-std=c99", "-fPIC", "-shared", "bf_oracle.c", "-o", "liboracle.so"], cwd=odir)
     drv = os.path.join(odir, "libcpubaseline.so")
     if force or _newer(drv, [os.path.join(odir, "cpu_baseline.c")]):

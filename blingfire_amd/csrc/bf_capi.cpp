@@ -781,6 +781,7 @@ int run_words_device(Handle *h, const char *d_text, const int64_t *d_doc_off, in
                      char *d_out, int64_t out_cap, int64_t *d_out_off, hipStream_t s, bool tokenise, int mode = 1 /* 1 words, 2 sentences */)
 {
     if (h->m.kind != KIND_WP) return BF_E_UNSUPPORTED;
+    if (h->m.lexer_void) { g_last_error = "TextToWords / TextToSentences: a moore-multi-dfa lexer answers -1 to every input (the single-document calls return that)"; return BF_E_UNSUPPORTED; }
     if (ndocs < 0 || total_bytes < 0 || !d_doc_off || !d_out_off) return BF_E_ARG;
     if (tokenise) {
         if (!h->w_ids.reserve((size_t)(total_bytes + 1) * 4) || !h->w_starts.reserve((size_t)(total_bytes + 1) * 4) ||
@@ -931,7 +932,9 @@ bool ensure_dict_tables(Handle *h)
     if (h->dict_ready) return true;
     const Model &m = h->m;
     bool ok = upload(h->t_dk_l1, m.dict_clsmap.l1) && upload(h->t_dk_pages, m.dict_clsmap.pages) && upload(h->t_k2i, m.k2i, 4) && upload(h->t_rows, m.info_rows, 4);
-    if (m.dict_direction != 0 && m.dict_has_charmap)
+    if (m.dict_ignore_case)             // fold + charmap as one map (bf_model.cpp); the pool may be empty (no 1:n entry)
+        ok = ok && upload(h->t_dn_l1, m.dict_lookup_map.l1) && upload(h->t_dn_pages, m.dict_lookup_map.pages) && (m.dict_norm_pool.empty() || upload(h->t_dn_pool, m.dict_norm_pool, 4));
+    else if (m.dict_direction != 0 && m.dict_has_charmap)
         ok = ok && upload(h->t_dn_l1, m.dict_charmap.l1) && upload(h->t_dn_pages, m.dict_charmap.pages) && upload(h->t_dn_pool, m.dict_norm_pool, 4);
     h->dict_ready = ok;
     return ok;
@@ -945,7 +948,7 @@ int run_dict_device(Handle *h, const int32_t *d_keys, const int64_t *d_key_off, 
     // the reference looks a key up as it is only for (no ignore-case, left-to-right) dictionaries, lower-cases for ignore-case ones and
     // reverses only right-to-left ones (FADictInterpreter_t.h:203-205, FAFsmConst.h DIR_L2R = 0, DIR_R2L = 1): the other combinations are
     // refused here instead of being looked up wrongly
-    if (m.ignore_case || (m.dict_direction != 0 && m.dict_direction != 1)) { g_last_error = "dictionary lookup: ignore-case / direction other than l2r, r2l is not supported"; return BF_E_UNSUPPORTED; }
+    if (m.dict_direction != 0 && m.dict_direction != 1) { g_last_error = "dictionary lookup: direction other than l2r, r2l is not supported"; return BF_E_UNSUPPORTED; }
     if (nkeys < 0 || !d_key_off || !d_val_off) return BF_E_ARG;
     const int nblocks = scan_nblocks(nkeys);
     if (!ensure_dict_tables(h) || !h->w_counts.reserve((size_t)(nkeys + 1) * 4) || !h->w_bsums.reserve((size_t)(nblocks + 1) * 8) ||
@@ -953,7 +956,8 @@ int run_dict_device(Handle *h, const int32_t *d_keys, const int64_t *d_key_off, 
     DictParams p;
     p.D.T = h->t_dict.as<uint64_t>(); p.D.initial = m.dict.initial_base; p.D.initial_final = m.dict_raw.is_final[(size_t)m.dict_raw.initial] ? 1 : 0;
     p.D.cls_l1 = h->t_dk_l1.as<uint16_t>(); p.D.cls_pages = h->t_dk_pages.as<uint32_t>();
-    const bool nrm = m.dict_direction != 0 && m.dict_has_charmap;
+    // keys are normalised unless (no ignore-case, left-to-right): m_NoNorm, FADictInterpreter_t.h:203-205.  Ignore-case: fold + charmap in one map
+    const bool nrm = m.dict_ignore_case || (m.dict_direction != 0 && m.dict_has_charmap);
     p.D.nrm_l1 = nrm ? h->t_dn_l1.as<uint16_t>() : nullptr; p.D.nrm_pages = nrm ? h->t_dn_pages.as<uint32_t>() : nullptr; p.D.nrm_pool = nrm ? h->t_dn_pool.as<int32_t>() : nullptr;
     p.D.k2i = h->t_k2i.as<int32_t>(); p.D.k2i_n = (int)m.k2i.size(); p.D.r2l = m.dict_direction != 0 ? 1 : 0;
     p.rows = h->t_rows.as<int32_t>(); p.stride = m.info_stride; p.min_key = m.info_min_key; p.nrows = m.info_stride > 0 ? (int)(m.info_rows.size() / (size_t)m.info_stride) : 0;
@@ -1294,6 +1298,7 @@ int TextToWordsWithOffsetsWithModel(const char *s, int n, char *out, int *starts
     if (!h || h->m.kind != KIND_WP) return -1;
     if (n == 0) return 0;                                                      // tokdll:447-449
     if (n < 0 || n > 1000000000 || !s) return -1;                              // tokdll:450-455
+    if (h->m.lexer_void) return -1;                                            // moore-multi-dfa [wbd]: the reference's lexer answers -1 (tokdll:499-502, bf_model.cpp)
     if (starts && max_out > 0) memset(starts, 0, sizeof(int) * (size_t)max_out);   // tokdll:469-474
     if (ends && max_out > 0) memset(ends, 0, sizeof(int) * (size_t)max_out);
     std::vector<int32_t> tags((size_t)n + 1), ws((size_t)n + 1), we((size_t)n + 1);
@@ -1337,6 +1342,7 @@ int TextToSentencesWithOffsetsWithModel(const char *s, int n, char *out, int *st
     if (!h || h->m.kind != KIND_WP) return -1;
     if (n == 0) return 0;                                                      // tokdll:198-200
     if (n < 0 || n > 1000000000 || !s) return -1;
+    if (h->m.lexer_void) return -1;                                            // tokdll:247-250
     if (starts && max_out > 0) memset(starts, 0, sizeof(int) * (size_t)max_out);   // tokdll:220-225
     if (ends && max_out > 0) memset(ends, 0, sizeof(int) * (size_t)max_out);
     std::vector<int32_t> tags((size_t)n + 1), ws((size_t)n + 1), we((size_t)n + 1);

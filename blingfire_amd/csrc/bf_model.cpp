@@ -2,6 +2,7 @@
 // build the displacement-packed tables and code-point maps the kernels consume.
 #include "bf_model.h"
 #include "bf_layout.h"
+#include "bf_tolower.h"
 
 #include <algorithm>
 #include <cstdio>
@@ -501,11 +502,19 @@ bool build_model(Model &m, const uint8_t *img, size_t size)
             }
         }
         if (fsm_dump >= 0) {
-            if (fsm_type != TYPE_MOORE_DFA) return fail(m, "moore-multi-dfa lexers are not on the TextToIds path (unsupported)");
-            if (m.ignore_case) return fail(m, "ignore-case lexers are not supported");
+            if (fsm_type != TYPE_MOORE_DFA && fsm_type != TYPE_MOORE_MULTI_DFA) return fail(m, "[wbd] fsm-type must be moore-dfa or moore-multi-dfa");      // FAWbdConfKeeper.cpp:224-227
             if (acts_dump < 0) return fail(m, "[wbd] without an action map");
             if (m.max_depth < 0 || m.max_token_length < 0) return fail(m, "bad [wbd] limits");
-            if (!decode_dfa(dump(fsm_dump), false, m.wbd_raw, m.error)) return false;
+            if (fsm_type == TYPE_MOORE_MULTI_DFA) {
+                // FAWbdConfKeeper.cpp:219-224 gives such a model a State2Ows map and NO State2Ow one, and FALexTools_t has only the latter
+                // (FALexTools_t.h:134): Process() returns -1 for every input (:412-414), so TextToIds answers 0 ids (tokdll:1202-1205:
+                // -1 % 3 != 0) and TextToWords / TextToSentences -1 (tokdll:247-250, 499-502).  Reproduced by an automaton that has an
+                // initial state and nothing else (no walk finds a token: 0 ids from every kernel) and lexer_void for the words forms.
+                m.lexer_void = true;
+                RawDfa &v = m.wbd_raw;
+                v.initial = 0; v.remap = false; v.state_off.assign(1, 0); v.is_final.assign(1, 0); v.ow.assign(1, -1); v.tr_begin.assign(2, 0);
+                v.off_index.assign(1, std::make_pair(0, 0));
+            } else if (!decode_dfa(dump(fsm_dump), false, m.wbd_raw, m.error)) return false;
             if (!pack_dfa(m.wbd_raw, false, {IW_ANY, IW_L_ANCHOR, IW_R_ANCHOR, IW_EPSILON}, m.wbd, m.error)) return false;
             auto cls_sym = [&](int iw) -> uint32_t {   // symbol -> class of the packed table
                 int c = m.wbd_raw.class_of(iw);
@@ -533,6 +542,7 @@ bool build_model(Model &m, const uint8_t *img, size_t size)
                 for (; i < a.size(); ++i) if (a[i] == 0 && i + 1 < a.size()) { ++i; break; }
                 for (; i < a.size(); ++i) { if (a[i] < 0) return fail(m, "bad function id"); max_fn = std::max(max_fn, a[i]); }
             }
+            if (m.lexer_void) { actions.clear(); max_fn = -1; }      // no state of the empty automaton is final: no action is ever looked up
             // Fn2Ini[f] = GetDest(GetDest(Initial, IW_R_ANCHOR), f)
             std::vector<long> fn2ini((size_t)std::max(max_fn + 1, 1), -1);
             fn2ini[0] = m.wbd.initial_base;
@@ -736,10 +746,12 @@ bool build_model(Model &m, const uint8_t *img, size_t size)
             m.wbd_cpmap.init(CLS_NONE);
             m.words_cpmap.init(CLS_NONE);
             for (int cp = 0; cp <= 0x10FFFF; ++cp) {
-                { const int wcp = cp == 0 ? 0x20 : cp;                          // tokdll:482, then FALexTools_t.h:258-261
-                  const uint32_t k = cls_sym(wcp < IW_EPSILON ? IW_EPSILON : wcp); if (k != CLS_NONE) m.words_cpmap.set(cp, flagged(k)); }
+                // a letter on its way into GetDest (FALexTools_t.h:256-264): "Iw < IW_EPSILON -> DefSubIw", then -- ignore-case lexers -- the fold
+                // (only letters take this way: anchors and function ids are fed as they are)
+                auto cls_text = [&](int o) -> uint32_t { o = o < IW_EPSILON ? IW_EPSILON : o; return cls_sym(m.ignore_case ? bf_tolower(o) : o); };
+                { const int wcp = cp == 0 ? 0x20 : cp;                          // tokdll:482
+                  const uint32_t k = cls_text(wcp); if (k != CLS_NONE) m.words_cpmap.set(cp, flagged(k)); }
                 int norm[10]; int c = cm.set_ ? cm.get(cp, norm, 10) : -1;
-                auto cls_text = [&](int o) -> uint32_t { return cls_sym(o < IW_EPSILON ? IW_EPSILON : o); };
                 if (c == -1) { uint32_t k = cls_text(cp); if (k != CLS_NONE) m.wbd_cpmap.set(cp, flagged(k)); }
                 else if (c == 1) { uint32_t k = cls_text(norm[0]); if (k != CLS_NONE) m.wbd_cpmap.set(cp, flagged(k)); }
                 else {
@@ -857,7 +869,7 @@ bool build_model(Model &m, const uint8_t *img, size_t size)
         for (size_t i = 0; i < vals.size(); ++i) {
             const int p = vals[i];
             if (p == PARAM_NO_TR) continue;
-            if (p == PARAM_IGNORE_CASE) { m.ignore_case = true; continue; }
+            if (p == PARAM_IGNORE_CASE) { m.dict_ignore_case = true; continue; }
             if (p == PARAM_USE_BYTE_ENCODING) { m.use_bytes = true; continue; }
             if (p == PARAM_NO_DUMMY_PREFIX) { m.no_dummy_prefix = true; continue; }
             if (i + 1 >= vals.size()) return fail(m, "truncated [pos-dict] parameters");
@@ -972,6 +984,17 @@ bool build_model(Model &m, const uint8_t *img, size_t size)
                 for (int k = 0; k < c; ++k) m.dict_norm_pool.push_back(norm[k]);
             }
             if (cm.max_key > 0x10FFFF) return fail(m, "charmap keys beyond the code point range");
+        }
+        if (m.dict_ignore_case) {
+            // key normalisation of an ignore-case dictionary (FADictInterpreter_t.h:203-205, 231-247): every symbol is folded, THEN the
+            // charmap (if any) is applied -- in either direction.  One map does both: symbol -> charmap entry of its fold, or the fold itself
+            m.dict_lookup_map.init(NORM_NONE);
+            for (int cp = 0; cp <= 0x10FFFF; ++cp) {
+                const int l = bf_tolower(cp);
+                const uint32_t e = m.dict_has_charmap ? m.dict_charmap.get(l) : NORM_NONE;
+                if (e != NORM_NONE) m.dict_lookup_map.set(cp, e);
+                else if (l != cp) m.dict_lookup_map.set(cp, (1u << 24) | (uint32_t)l);
+            }
         }
     }
     if (m.has_seg) {

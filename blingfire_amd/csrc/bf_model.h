@@ -25,7 +25,7 @@ enum : int {
     PARAM_ARRAY = 24, PARAM_MULTI_MAP = 25, PARAM_FSM_TYPE = 26, PARAM_DEPTH = 38, PARAM_CHARMAP = 47,
     PARAM_MAX_LENGTH = 69, PARAM_VERIFY_LDB_BIN = 70, PARAM_TOKENIZATION_TYPE = 71, PARAM_ID_OFFSET = 72,
     PARAM_USE_BYTE_ENCODING = 73, PARAM_NO_DUMMY_PREFIX = 74,
-    MODE_PACK_TRIV = 1, MODE_PACK_FIXED = 3, TYPE_MOORE_DFA = 3, TYPE_MEALY_DFA = 7,
+    MODE_PACK_TRIV = 1, MODE_PACK_FIXED = 3, TYPE_MOORE_DFA = 3, TYPE_MOORE_MULTI_DFA = 4, TYPE_MEALY_DFA = 7,
     TOKENIZE_BPE = 3, TOKENIZE_BPE_OPT = 4, TOKENIZE_BPE_OPT_WITH_MERGES = 5,
 };
 
@@ -104,6 +104,7 @@ struct Model {
     // ---- [wbd] lexer (reference FAWbdConfKeeper.cpp:56-232, FALexTools_t.h:129-202)
     bool has_wbd = false;
     int max_depth = 2, max_token_length = 300; bool ignore_case = false;
+    bool lexer_void = false;           // a moore-multi-dfa [wbd]: the reference's lexer answers -1 to every input (bf_model.cpp)
     int lex_frames = 0;                // saved frames the call graph can need: min(max_depth, call depth) - 1
     RawDfa wbd_raw; PackedDfa wbd;
     std::vector<uint32_t> wbd_info;    // indexed by base: action info for final states
@@ -143,6 +144,7 @@ struct Model {
     int i2info_min_key = 0;
     // "code point -> charmap" map for the _sp prologue: value = NORM_NONE (copy), or count<<24 | (value | pool offset)
     TwoLevelMap dict_charmap; std::vector<int32_t> dict_norm_pool; bool dict_has_charmap = false;
+    bool dict_ignore_case = false; TwoLevelMap dict_lookup_map;      // ignore-case [pos-dict]: key symbol -> charmap entry of its fold (entries as in dict_charmap), key lookup only
     TwoLevelMap dict_clsmap;           // code point (or byte) -> class of the dictionary alphabet, CLS_NONE_W if absent
     int trie_max_depth = 0;            // longest path from the initial state (bounds every arc length)
     int max_info_id = 0;               // largest token id in I2Info (the Unigram lane program packs id + 1 into 20 bits)

@@ -477,8 +477,9 @@ BF_HD int dict_info_id(const DictTables &D, const int32_t *key, int n)
 {
     if (n <= 0 || n > DICT_MAX_WORD) return -1;
     DictWalk w; w.start(D);
-    if (!D.r2l) { for (int i = 0; i < n; ++i) w.feed(D, key[i]); return w.id(D); }
-    // r2l: length of the normalised word first (FANormalizeWord gives up beyond the buffer), then its symbols last to first
+    if (!D.r2l && !D.nrm_l1) { for (int i = 0; i < n; ++i) w.feed(D, key[i]); return w.id(D); }      // m_NoNorm (FADictInterpreter_t.h:203-205): the key as it is
+    // normalised keys (r2l dictionaries, ignore-case ones in either direction; the map holds fold + charmap): length of the normalised word
+    // first (FANormalizeWord gives up beyond the buffer), then its symbols -- first to last, or last to first for r2l
     int len = n;
     if (D.nrm_l1) {
         len = 0;
@@ -489,13 +490,14 @@ BF_HD int dict_info_id(const DictTables &D, const int32_t *key, int n)
         }
         if (len > DICT_NORM_BUF) return w.id(D);              // counts as the empty word
     }
-    for (int i = n - 1; i >= 0; --i) {
+    for (int t = 0; t < n; ++t) {
+        const int i = D.r2l ? n - 1 - t : t;
         const uint32_t v = D.nrm_l1 ? dict_map_get(D.nrm_l1, D.nrm_pages, key[i], DICT_NORM_NONE) : DICT_NORM_NONE;
         if (v == DICT_NORM_NONE) { w.feed(D, key[i]); continue; }
         const int c = (int)(v >> 24); const uint32_t pay = v & 0xFFFFFFu;
         if (c == 1) w.feed(D, (int)pay);
         else if (c == 11) w.feed(D, D.nrm_pool[pay]);
-        else for (int q = c - 1; q >= 0; --q) w.feed(D, D.nrm_pool[pay + (uint32_t)q]);
+        else for (int q = 0; q < c; ++q) w.feed(D, D.nrm_pool[pay + (uint32_t)(D.r2l ? c - 1 - q : q)]);
     }
     return w.id(D);
 }

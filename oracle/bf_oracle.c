@@ -383,7 +383,7 @@ struct bfo_model {
     mmap_t conf;                 /* cl/src/FALDB.cpp:24-64, dump 0 */
     /* [wbd] cl/src/FAWbdConfKeeper.cpp:56-232 */
     int has_wbd; dfa_t wbd_dfa; mmap_t acts; mmapf_t wbd_charmap;
-    int max_depth, max_token_length, ignore_case;
+    int max_depth, max_token_length, ignore_case /* [wbd] */, dict_ignore_case /* [pos-dict] */, lexer_void /* moore-multi-dfa [wbd] */;
     int *fn2ini; int fn2ini_size;
     /* [pos-dict] cl/src/FADictConfKeeper.cpp:57-228 */
     int has_seg; dfa_t dict_dfa; mmapf_t i2info; mmapf_t dict_charmap;
@@ -483,7 +483,13 @@ static int set_model_data(bfo_model *m)
             case PARAM_DEPTH: m->max_depth = vals[++i]; break;
             case PARAM_MAX_LENGTH: m->max_token_length = vals[++i]; break;
             case PARAM_IGNORE_CASE: m->ignore_case = 1; break;
-            case PARAM_FSM_TYPE: if (vals[++i] != TYPE_MOORE_DFA) return 0; break; /* multi-dfa not on the path */
+            case PARAM_FSM_TYPE:
+                /* FAWbdConfKeeper.cpp:212-227: moore-multi-dfa gets a State2Ows map and no State2Ow one -> FALexTools_t::Process
+                 * returns -1 for every input (FALexTools_t.h:134, 412-414); any other type is a LogAssert */
+                ++i;
+                if (vals[i] == 4 /* TYPE_MOORE_MULTI_DFA */) m->lexer_void = 1;
+                else if (vals[i] != TYPE_MOORE_DFA) return 0;
+                break;
             case PARAM_FSM: dfa_set(&m->wbd_dfa, m->dumps[vals[++i]]); have_fsm = 1; break;
             case PARAM_MULTI_MAP: mmap_set(&m->acts, m->dumps[vals[++i]]); break;
             case PARAM_CHARMAP: mmapf_set(&m->wbd_charmap, m->dumps[vals[++i]]); break;
@@ -500,7 +506,7 @@ static int set_model_data(bfo_model *m)
         m->has_seg = 1; m->fsm_type = TYPE_MOORE_DFA;
         for (i = 0; i < n; ++i) {
             switch (vals[i]) {
-            case PARAM_IGNORE_CASE: m->ignore_case = 1; break;
+            case PARAM_IGNORE_CASE: m->dict_ignore_case = 1; break;
             case 18 /* PARAM_NO_TR */: break;
             case 11 /* PARAM_DIRECTION */: m->direction = vals[++i]; break;
             case PARAM_USE_BYTE_ENCODING: m->use_bytes = 1; break;
@@ -683,9 +689,11 @@ static int normalize(const int *in, int n, int *out, int *offs, int max_out, con
 
 /* ---------------- lexer: cl/inc/FALexTools_t.h:205-421 ---------------- */
 
-/* cl/src/FAUtf32Utils.cpp:45-81 is only reached with ignore-case models; none of the
- * tokenizer models sets it, the oracle refuses such a model at call time instead of
- * restating the 1,283-line table. */
+/* cl/src/FAUtf32Utils.cpp:45-81 FAUtf32ToLower, reached with ignore-case models only: its three-level table is DATA, taken here as
+ * runs observed from the compiled reference (tools/make_tolower.py -> bf_tolower_tab.h; tests/test_ignore_case.py compares
+ * bfo_tolower with the reference's function on every code point). */
+#include "bf_tolower_tab.h"
+int bfo_tolower_sym(int cp) { return bfo_tolower(cp); }
 
 static int lex_process_int(const bfo_model *m, int initial, int offset, const int *in, int n,
                            int *out, int max_out, int depth, int once)
@@ -705,6 +713,7 @@ static int lex_process_int(const bfo_model *m, int initial, int offset, const in
         for (; j < bound; ++j) {
             int iw = in[j];
             if (iw < IW_EPSILON) iw = IW_EPSILON;
+            if (m->ignore_case) iw = bfo_tolower(iw);                 /* FALexTools_t.h:262-264 */
             dst = dfa_dest(d, state, iw);
             if (dst == -1) { dst = dfa_dest(d, state, IW_ANY); if (dst == -1) break; }
             if (dfa_is_final(d, dst)) { final_state = dst; final_pos = j; }
@@ -751,7 +760,7 @@ static int lex_process_int(const bfo_model *m, int initial, int offset, const in
 
 int bfo_lex_process(const bfo_model *m, const int *in, int n, int *out, int max_out)
 {
-    if (!m || !m->has_wbd || !m->wbd_dfa.set || !m->acts.set || m->ignore_case) return -1;
+    if (!m || !m->has_wbd || !m->wbd_dfa.set || !m->acts.set || m->lexer_void) return -1;      /* FALexTools_t.h:412-414 (no State2Ow: lexer_void) */
     return lex_process_int(m, m->wbd_dfa.initial, 0, in, n, out, max_out, 1, 0);
 }
 
@@ -1298,11 +1307,11 @@ int bfo_dict_get_info_id(const bfo_model *m, const int *in, int n)
     const int *w = in;
     int len = n, i, state, ow, id = 0;
     if (!m || !m->has_seg || !m->k2i || n <= 0 || n > 300 || !in) return -1;
-    if (m->ignore_case) return -1;                 /* FAUtf32ToLower tables are not restated: such models are refused by the product too */
-    if (m->direction != 0) {
-        if (m->dict_charmap.set) { len = normalize(in, n, tmp, NULL, 600, &m->dict_charmap); if (len < 0 || len > 600) len = 0; w = tmp; }
-        for (i = 0; i < len; ++i) buf[i] = w[len - 1 - i];
-        w = buf;
+    if (m->dict_ignore_case || m->direction != 0) {           /* !m_NoNorm: Normalize (:211-279) */
+        int low[300];
+        if (m->dict_ignore_case) { for (i = 0; i < n; ++i) low[i] = bfo_tolower(in[i]); w = low; }      /* :231-238 */
+        if (m->dict_charmap.set) { len = normalize(w, n, tmp, NULL, 600, &m->dict_charmap); if (len < 0 || len > 600) len = 0; w = tmp; }
+        if (m->direction != 0) { for (i = 0; i < len; ++i) buf[i] = w[len - 1 - i]; w = buf; }
     }
     state = m->dict_dfa.initial;
     for (i = 0; i < len; ++i) {

@@ -102,6 +102,8 @@ int bfo_utf8_to_utf32(const char *s, int len, int *out, int max_out);
 /* cl/inc/FALexTools_t.h:403-421 Process on an UTF-32 array (after normalisation);
  * writes <tag,from,to> triples, returns number of ints written or -1 */
 int bfo_lex_process(const bfo_model *m, const int *in, int n, int *out, int max_out);
+/* cl/src/FAUtf32Utils.cpp:45-81 FAUtf32ToLower (the fold of ignore-case lexers and dictionaries) */
+int bfo_tolower_sym(int cp);
 
 #ifdef __cplusplus
 }

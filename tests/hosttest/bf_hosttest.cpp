@@ -39,6 +39,7 @@ struct HostCls {
     int run(int i) const { int k = 0; while (i + k < n && ((i + k) >> 3) == (i >> 3) && (cp[i + k] & LX_C_LOOP)) ++k; return k; }
 };
 
+#include "../../blingfire_amd/csrc/bf_tolower.h"
 extern "C" {
 
 void *bft_load(const char *path)
@@ -51,6 +52,9 @@ void *bft_load(const char *path)
     return h;
 }
 const char *bft_error(void *hv) { return ((Handle *)hv)->m.error.c_str(); }
+// the fold of ignore-case models as the product has it (bf_tolower.h)
+int bft_tolower(int cp) { return bfa::bf_tolower(cp); }
+int bft_lexer_void(void *hv) { return ((Handle *)hv)->m.lexer_void ? 1 : 0; }
 void bft_free(void *hv) { delete (Handle *)hv; }
 void bft_set_no_ff(int v) { g_no_ff = v; }
 void bft_set_general(int v) { g_general = v; }
@@ -378,8 +382,10 @@ int bft_emu_dict_get_info(void *hv, const int32_t *key, int n, int32_t *info_id,
     DictTables D;
     D.T = m.dict.t64.data(); D.initial = m.dict.initial_base; D.initial_final = m.dict_raw.is_final[(size_t)m.dict_raw.initial] ? 1 : 0;
     D.cls_l1 = m.dict_clsmap.l1.data(); D.cls_pages = m.dict_clsmap.pages.data();
-    const bool nrm = m.dict_direction != 0 && m.dict_has_charmap;
-    D.nrm_l1 = nrm ? m.dict_charmap.l1.data() : nullptr; D.nrm_pages = nrm ? m.dict_charmap.pages.data() : nullptr; D.nrm_pool = nrm ? m.dict_norm_pool.data() : nullptr;
+    // as bf_capi.cpp run_dict_device / ensure_dict_tables: an ignore-case dictionary normalises through fold + charmap in one map
+    const bool nrm = m.dict_ignore_case || (m.dict_direction != 0 && m.dict_has_charmap);
+    const TwoLevelMap &nm = m.dict_ignore_case ? m.dict_lookup_map : m.dict_charmap;
+    D.nrm_l1 = nrm ? nm.l1.data() : nullptr; D.nrm_pages = nrm ? nm.pages.data() : nullptr; D.nrm_pool = nrm ? m.dict_norm_pool.data() : nullptr;
     D.k2i = m.k2i.data(); D.k2i_n = (int)m.k2i.size(); D.r2l = m.dict_direction != 0;
     const int id = dict_info_id(D, key, n);
     *info_id = id;

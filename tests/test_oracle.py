@@ -73,7 +73,7 @@ def test_known_answer_vectors(ora, i):
     assert all(v == -7 for v in buf[c:]), "ids beyond the count must stay untouched"
 
 
-GOLDEN_FILES = sorted(f for f in os.listdir(GOLDEN) if f.endswith(".json"))
+GOLDEN_FILES = sorted(f for f in os.listdir(GOLDEN) if f.endswith(".json") and f != "tolower_pairs.json")      # (that one is the fold table: tests/test_ignore_case.py)
 
 
 @pytest.mark.parametrize("fname", GOLDEN_FILES)
