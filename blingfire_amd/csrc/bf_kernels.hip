@@ -698,7 +698,7 @@ __device__ __forceinline__ uint32_t mbcnt(unsigned long long m) { return __built
 namespace bfa {
 
 // WPE: waves per SIMD the register allocation is asked to allow (a workgroup is four waves, one per SIMD: WPE workgroups per CU)
-template <class LDS, int NU, int STEPS, int WPE, bool STATS, int DBG = 0, int UMIN = 4, int CROOM = 0, bool OFFS = false>
+template <class LDS, int NU, int STEPS, int WPE, bool STATS, int DBG = 0, int UMIN = 4, int CROOM = 0, bool OFFS = false, int TRIM = 0>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_wp_wave(WpWaveParams p, int grab)
 {
     __shared__ LDS lds[4];
@@ -710,17 +710,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
     for (int i = (int)threadIdx.x; i < p.acts_n; i += 256) acts[i] = p.acts[i];
     __syncthreads();
     // the wave number as a scalar: what a wave reads of its own LDS block at a wave-uniform index is then wave-uniform for the compiler too
-    WpWave<LDS, NU, STATS, DBG, STEPS, UMIN, CROOM, OFFS> w(p, cold, lds[wave_in_block()], ascii, acts);
+    WpWave<LDS, NU, STATS, DBG, STEPS, UMIN, CROOM, OFFS, TRIM> w(p, cold, lds[wave_in_block()], ascii, acts);
     w.run(grab, (int)(blockIdx.x * 4) + wave_in_block(), (int)(gridDim.x * 4));
 }
 
-template <class LDS, int NU, int STEPS, int WPE, int UMIN = 4>
+template <class LDS, int NU, int STEPS, int WPE, int UMIN = 4, int TRIM = 0>
 static void launch_wp_wave_cfg(const WpWaveParams &p, int grab, int per_cu_override, hipStream_t s)
 {
     static int per_cu_cached = 0;                 // per instance; a property of the kernel and the device kind
     if (per_cu_cached <= 0) {
         int q = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&q, k_wp_wave<LDS, NU, STEPS, WPE, false, 0, UMIN>, 256, 0) != hipSuccess || q <= 0) q = 2;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&q, k_wp_wave<LDS, NU, STEPS, WPE, false, 0, UMIN, 0, false, TRIM>, 256, 0) != hipSuccess || q <= 0) q = 2;
         (void)hipGetLastError();
         per_cu_cached = q;
     }
@@ -730,8 +730,8 @@ static void launch_wp_wave_cfg(const WpWaveParams &p, int grab, int per_cu_overr
     const int64_t need = (p.ndocs + (int64_t)grab * 4 - 1) / ((int64_t)grab * 4);
     if (blocks > need) blocks = need;
     if (blocks < 1) blocks = 1;
-    if (p.cold.stats) hipLaunchKernelGGL((k_wp_wave<LDS, NU, STEPS, WPE, true, 0, UMIN>), dim3((unsigned)blocks), dim3(256), 0, s, p, grab);
-    else hipLaunchKernelGGL((k_wp_wave<LDS, NU, STEPS, WPE, false, 0, UMIN>), dim3((unsigned)blocks), dim3(256), 0, s, p, grab);
+    if (p.cold.stats) hipLaunchKernelGGL((k_wp_wave<LDS, NU, STEPS, WPE, true, 0, UMIN, 0, false, TRIM>), dim3((unsigned)blocks), dim3(256), 0, s, p, grab);
+    else hipLaunchKernelGGL((k_wp_wave<LDS, NU, STEPS, WPE, false, 0, UMIN, 0, false, TRIM>), dim3((unsigned)blocks), dim3(256), 0, s, p, grab);
 }
 
 // variant (experiments): bits 8..11 = configuration, bits 12..15 = documents per grab (0 = 8), bits 24..29 = workgroups per CU
@@ -780,6 +780,11 @@ void launch_wp_wave(const WpWaveParams &p, int variant, hipStream_t s)
     else if (cfg == 4) launch_wp_wave_cfg<WvLds<2048, 256, 16>, 1, 3, 5>(p, grab, per_cu, s);
     else if (cfg == 5) launch_wp_wave_cfg<L, 1, 3, 8, 1>(p, grab, per_cu, s);                                 // experiments: when the units phase ends
     else if (cfg == 6) launch_wp_wave_cfg<L, 1, 3, 8, 12>(p, grab, per_cu, s);
+    else if (cfg == 7) launch_wp_wave_cfg<L, 1, 3, 8, 4, 1>(p, grab, per_cu, s);                              // experiments: TRIM bits (bf_wave_body.h)
+    else if (cfg == 8) launch_wp_wave_cfg<L, 1, 3, 8, 4, 2>(p, grab, per_cu, s);
+    else if (cfg == 9) launch_wp_wave_cfg<L, 1, 3, 8, 4, 3>(p, grab, per_cu, s);
+    else if (cfg == 10) launch_wp_wave_cfg<L, 1, 3, 8, 4, 4>(p, grab, per_cu, s);
+    else if (cfg == 11) launch_wp_wave_cfg<L, 1, 3, 8, 4, 7>(p, grab, per_cu, s);
     else launch_wp_wave_cfg<L, 1, 3, 8>(p, grab, per_cu, s);
 }
 

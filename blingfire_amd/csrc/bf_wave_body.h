@@ -38,15 +38,19 @@ struct WvLds {
     int32_t dt_cap[DTN], dt_cnt[DTN]; uint32_t dt_flags[DTN], dt_rbase[DTN];      // dt_rbase: ring position of the document's first character
     uint16_t qc[QCAP];
     int64_t doff[WV_GRAB_MAX + 1];   // text offsets of the documents taken from the work counter
+    alignas(8) WvTok spare_tok;
     uint32_t spare32;
-    uint16_t spare;                  // spare, spare32: where a lane writes when it has nothing to write
+    uint16_t spare;                  // spare, spare32, spare_tok: where a lane writes when it has nothing to write
 };
 
 // DBG (experiments, wrong results by design): 1 = units finish at once without walking, 2 = also nothing is moved at retire:
 // instruction counts of the phases by difference (profiles/r03_phase_costs.txt)
 // OFFS: the offsets API -- every id carries the first / last character of its sub-token (of its word, for UnkId: tokdll:1263-1297) through the
 // provisional homes to its place, and the decoder records the byte every character starts at
-template <class LDS, int NU = 2, bool STATS = false, int DBG = 0, int STEPS = 3, int UMIN = 4, int CROOM = 0, bool OFFS = false>
+// TRIM (bits; each measured on its own before it became part of the shipped instance): 1 = no settle at the top of a trip (the one at the bottom of
+// the trip before has just run), 2 = the chunk-wide pass writes its tokens with selects (a lane without a token left writes to a spare entry)
+// instead of an execution-mask branch per token, 4 = fill as nested loops (fill_nested) instead of the re-entered fill_step
+template <class LDS, int NU = 2, bool STATS = false, int DBG = 0, int STEPS = 3, int UMIN = 4, int CROOM = 0, bool OFFS = false, int TRIM = 0>
 struct WpWave {
     static constexpr int RING = LDS::RING, QCAP = LDS::QCAP, DTN = LDS::DTN;
     static constexpr uint32_t RMASK = RING - 1, QMASK = QCAP - 1, DMASK = DTN - 1;
@@ -176,6 +180,28 @@ struct WpWave {
         const uint32_t w_hi = ((curk & 0xFFu) << 16) | (fast_ok ? 0u : WV_TK_INFO);
         const uint16_t li = wv_pack_info(p.loop_info), si = wv_pack_info(p.solo_info);
         const int lane0 = cb + lane * 8;
+        if (TRIM & 2) {
+            int mlen = 0;                                                  // the longest token written (an integer: a per-lane bool carried through the loop is a lane mask, its updates scalar instructions)
+            while (wv::any(tk != 0)) {
+                const bool on = tk != 0;
+                const int bit = __builtin_ctz(tk | 0x10000u); tk &= tk - 1u;           // (tk == 0: bit 16, nothing of it is kept)
+                const int bpos = lane0 + (bit >> 1);
+                const bool is_end = (en >> bit) & 1u;
+                const uint32_t hm = h & ((2u << bit) - 1u);
+                const int hs = hm ? lane0 + ((31 - __builtin_clz(hm | 1u)) >> 1) : hprev;
+                const int start = is_end ? hs : bpos;
+                const int len = bpos - start + 1;
+                const int lenon = on ? len : 0;
+                mlen = lenon > mlen ? lenon : mlen;
+                const uint32_t sl = t & QMASK;
+                WvTok e; e.pos = rbase + (uint32_t)start; e.w = (uint32_t)len | w_hi;
+                WvTok *dst = on ? &S.q[sl] : &S.spare_tok;
+                *dst = e;
+                if (!fast_ok) { uint16_t *dq = on ? &S.qc[sl] : &S.spare; *dq = is_end ? li : si; }
+                t += on ? 1u : 0u;
+            }
+            toolong = mlen > maxtok;
+        } else
         while (wv::any(tk != 0)) {
             if (tk) {
                 const int bit = __builtin_ctz(tk); tk &= tk - 1u;
@@ -789,6 +815,65 @@ struct WpWave {
         return false;
     }
 
+    // The same producing actions in the same order as `while (fill_step(grab))`, written as nested loops (TRIM bit 4): documents outside, the
+    // chunks of a document inside, the usual chunk -- decoded, resolved by the chunk-wide pass, the document closed behind it -- in one
+    // run of straight-line code.  (fill_step() is re-entered through one dispatching head per action, and every way into that head
+    // carries the wave-uniform state in another set of scalar registers: ~28 scalar copies per action, five actions per document.)
+    // Returns whether anything was produced.
+    BF_WVD bool fill_nested(int grab)
+    {
+        bool filled = false;
+        for (;;) {
+            if (!have_doc) {
+                if (exiting || dt_tail - dt_head >= (uint32_t)DTN) return filled;
+                if (di >= dn) {
+                    wv::sync();                                             // every lane has read the offsets of the range before
+                    unsigned long long base = 0;
+                    if (p.next_doc) {
+                        if (lane == 0) base = wv::atomic_add(p.next_doc, (unsigned long long)grab);
+                        base = wv::bcast(base, 0);
+                    } else { base = ((unsigned long long)st_wave + (unsigned long long)st_round * (unsigned long long)st_waves) * (unsigned long long)grab; ++st_round; }
+                    if ((int64_t)base >= p.ndocs) { exiting = true; return filled; }
+                    dbase = (int64_t)base; di = 0; dn = dbase + grab < p.ndocs ? grab : (int)(p.ndocs - dbase);
+                    if (lane <= dn) S.doff[lane] = p.doc_off[dbase + lane];
+                    wv::sync();
+                    filled = true;
+                }
+                const int64_t b = S.doff[di], e = S.doff[di + 1];
+                have_doc = open_document(dbase + di, b, e);
+                ++di;
+                filled = true;
+                if (!have_doc) continue;
+            }
+            // ---- the open document: resolve what is decoded, decode the next chunk, close
+            for (;;) {
+                const bool room_q = (q_tail - q_retire) + 66u <= (uint32_t)QCAP;
+                if (done < dec) {
+                    const bool fully = dec_bytes >= n;
+                    if (phase_a_wide(fully)) { filled = true; continue; }
+                    if (!room_q) return filled;
+                    if (open_start >= 0) { done = open_start; open_start = -1; }     // the general form starts at a certain start position
+                    if (phase_a_general(fully)) { filled = true; continue; }
+                }
+                if (dec_bytes < n) {
+                    if (ring_free() < WV_CHUNK || (q_tail - q_retire) + (uint32_t)CHUNK_ROOM > (uint32_t)QCAP) return filled;
+                    const bool fresh = done == dec;
+                    uint32_t kk = 0;
+                    const bool ascii_chunk = decode_chunk(kk);
+                    if (fresh && ascii_chunk) (void)phase_a_wide(dec_bytes >= n, true, kk);
+                    filled = true;
+                    continue;
+                }
+                if (done >= dec) {
+                    if (open_start >= 0 && !room_q) return filled;
+                    close_document(); have_doc = false; filled = true;
+                    break;
+                }
+                return filled;                                             // the token at `done` waits for room (cannot happen once the document is fully decoded: see run())
+            }
+        }
+    }
+
     // wave_id / n_waves: this wave's number and the number of waves of the launch (used when the batch has no work counter)
     BF_WVD void run(int grab, int wave_id, int n_waves)
     {
@@ -798,8 +883,9 @@ struct WpWave {
 #pragma unroll
         for (int i = 0; i < NU; ++i) { u[i].tok = -1; u[i].rs = 0; u[i].j = 0; u[i].state = 0; u[i].lim = 0; u[i].fp = -1; u[i].ftag = 0; u[i].Lk = 0; u[i].ca = 0; u[i].ini = 0; u[i].from = 0; }
         for (;;) {
-            bool moved = settle();
+            bool moved = (TRIM & 1) ? false : settle();       // (the settle at the bottom of the trip before has just run; the first trip has nothing to settle)
             bool filled = false;
+            if (TRIM & 4) filled = fill_nested(grab); else
             while (fill_step(grab)) filled = true;
             const bool drain = !filled;          // nothing could be produced: what blocks is freed only by finishing and retiring tokens
             if (units_phase(u, drain)) moved = true;

@@ -13,7 +13,7 @@
 
 using namespace bfa;
 
-template <class LDS, int NU, bool OFFS = false>
+template <class LDS, int NU, bool OFFS = false, int TRIM = 0>
 static void run_cfg(const WpWaveParams &p, int nwaves, int grab)
 {
     std::vector<LDS *> lds;
@@ -29,7 +29,7 @@ static void run_cfg(const WpWaveParams &p, int nwaves, int grab)
         size_t k = 0;
         for (; k < wave_ids.size(); ++k) if (wave_ids[k] == wid) break;
         if (k == wave_ids.size()) { wave_ids.push_back(wid); (void)next_wave; }
-        WpWave<LDS, NU, true, 0, 3, 4, 0, OFFS> w(p, p.cold, *of_wave[k], ascii.data(), p.acts);
+        WpWave<LDS, NU, true, 0, 3, 4, 0, OFFS, TRIM> w(p, p.cold, *of_wave[k], ascii.data(), p.acts);
         w.run(grab, (int)k, nwaves);
     };
     wvemu::run_waves(nwaves, body);
@@ -42,7 +42,7 @@ int bft_wave_ok(void *hv) { return ((Handle *)hv)->m.wave_ok ? 1 : 0; }
 const char *bft_wave_why(void *hv) { return ((Handle *)hv)->m.wave_why.c_str(); }
 int bft_bpe_wave_ok(void *hv) { return ((Handle *)hv)->m.bpe_wave_ok ? 1 : 0; }
 
-// TextToIdsBatch through the wave kernel on the host.  cfg: 0 = the shipped configuration, 1 = two units per lane, the smallest ring and queue, a two-entry
+// TextToIdsBatch through the wave kernel on the host.  cfg: 3 / 4 = configurations 0 / 1 with the TRIM bits; 0 = the shipped configuration, 1 = two units per lane, the smallest ring and queue, a two-entry
 // document table, every token with an explicit action, 2 = three units per lane, a large ring and queue.  Returns the total id count, or < 0 (-1: model not in unit form, -5: the kernel raised a status bit).
 // stats (optional, 16 counters): see bf_wave.h WpWaveParams::stats.
 long bft_emu_wave_batch(void *hv, const uint8_t *text, long text_bytes, const int64_t *doc_off, long ndocs, int max_ids, int unk, int nwaves, int grab, int cfg,
@@ -61,10 +61,13 @@ long bft_emu_wave_batch(void *hv, const uint8_t *text, long text_bytes, const in
     p.ids_tmp = tmp.data(); p.counts = counts.data(); p.max_ids = max_ids; p.unk = unk; p.next_doc = &next_doc; p.span_tmp = nullptr;
     if (cfg >= 16) { p.next_doc = nullptr; cfg -= 16; }            // cfg + 16: no work counter, the waves take their ranges round-robin
     p.cold.cpmap = DevCpMap{m.wbd_cpmap.l1.data(), m.wbd_cpmap.pages.data()};
-    p.cold.kind = m.wave_kind.data(); p.cold.nclasses = m.wbd.nclasses; p.cold.status = &status; p.cold.stats = stats; p.cold.no_fast = cfg == 1 ? 1 : 0;
+    p.cold.kind = m.wave_kind.data(); p.cold.nclasses = m.wbd.nclasses; p.cold.status = &status; p.cold.stats = stats; p.cold.no_fast = (cfg == 1 || cfg == 4) ? 1 : 0;
     if (ndocs > 0) {
         if (cfg == 1) run_cfg<WvLds<1024, 128, 2>, 2>(p, nwaves, grab);
         else if (cfg == 2) run_cfg<WvLds<4096, 512, 64>, 3>(p, nwaves, grab);
+        else if (cfg == 3) run_cfg<WvLds<1024, 256, 8>, 1, false, 7>(p, nwaves, grab);          // the TRIM bits (bf_wave_body.h) on the shipped configuration ...
+        else if (cfg == 4) run_cfg<WvLds<1024, 128, 2>, 2, false, 7>(p, nwaves, grab);          // ... and on the smallest one, every token with an explicit action
+        else if (cfg == 5) run_cfg<WvLds<1024, 256, 8>, 1, false, 3>(p, nwaves, grab);          // ... bits 1 + 2 alone
         else run_cfg<WvLds<1024, 256, 8>, 1>(p, nwaves, grab);
     }
     if (status) return -5;

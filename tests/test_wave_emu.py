@@ -16,7 +16,8 @@ WP_MODELS = ["bert_base_tok.bin", "bert_base_cased_tok.bin", "bert_chinese.bin"]
 # (max_ids, unk, waves, documents per grab, configuration: 0 = shipped, 1 = two units per lane / smallest ring and queue / two-entry
 #  document table, 2 = three units per lane / large ring and queue; + 16 = no work counter, the waves take their ranges round-robin
 #  -- the form small host batches run in)
-CONFS = [(512, 100, 1, 8, 0), (512, 100, 4, 2, 1), (64, 5, 2, 8, 2), (1, 100, 1, 3, 1), (0, 100, 2, 8, 0), (512, 100, 5, 1, 16)]
+CONFS = [(512, 100, 1, 8, 0), (512, 100, 4, 2, 1), (64, 5, 2, 8, 2), (1, 100, 1, 3, 1), (0, 100, 2, 8, 0), (512, 100, 5, 1, 16),
+         (512, 100, 2, 8, 3), (512, 100, 3, 2, 4), (7, 100, 1, 1, 4), (512, 100, 4, 8, 19), (512, 100, 2, 4, 5)]      # cfg 3 / 4 / 5: the TRIM bits of bf_wave_body.h
 
 
 @pytest.fixture(scope="module")
@@ -146,7 +147,7 @@ def test_wave_program_any_batch(ht):
 
     @settings(max_examples=120, deadline=None, suppress_health_check=list(HealthCheck))
     @given(docs=docs_st, mx=st.sampled_from([0, 1, 3, 64, 512]), unk=st.sampled_from([0, 100, 7]), nw=st.integers(1, 4), grab=st.integers(1, 8),
-           cfg=st.sampled_from([0, 1, 2, 16, 17]))
+           cfg=st.sampled_from([0, 1, 2, 3, 4, 5, 16, 17, 19, 20]))
     def run(docs, mx, unk, nw, grab, cfg):
         text, off = bf.pack_docs(docs)
         r, ids, ido, _ = wave_batch(L, h, text, off, mx, unk, nw, grab, cfg)
