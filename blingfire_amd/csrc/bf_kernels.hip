@@ -785,7 +785,8 @@ void launch_wp_wave(const WpWaveParams &p, int variant, hipStream_t s)
     else if (cfg == 9) launch_wp_wave_cfg<L, 1, 3, 8, 4, 3>(p, grab, per_cu, s);
     else if (cfg == 10) launch_wp_wave_cfg<L, 1, 3, 8, 4, 4>(p, grab, per_cu, s);
     else if (cfg == 11) launch_wp_wave_cfg<L, 1, 3, 8, 4, 7>(p, grab, per_cu, s);
-    else launch_wp_wave_cfg<L, 1, 3, 8>(p, grab, per_cu, s);
+    else if (cfg == 12) launch_wp_wave_cfg<L, 1, 3, 8>(p, grab, per_cu, s);                                   // the instance shipped until round 4 (TRIM 0)
+    else launch_wp_wave_cfg<L, 1, 3, 8, 4, 7>(p, grab, per_cu, s);                                          // shipped: TRIM 7 (10 M documents: 25.23 -> 24.28 ms, profiles/r04_p_wp_trim.txt)
 }
 
 } // namespace bfa
