@@ -692,6 +692,10 @@ __device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 // a wave-uniform value the compiler may not trace back to where it came from (it then lives in a scalar register of its own)
 __device__ __forceinline__ int own(int v) { asm volatile("" : "+s"(v)); return v; }
+// The four values are in their registers from here on: ONE s_waitcnt for the loads that fetch them, in straight-line code.  Without it the compiler
+// places a wait in front of the first use of each -- and when those uses are stores in conditional blocks of their own (k_wp_wave's retire pass),
+// every wait also waits for the store before it to be acknowledged (vmcnt counts stores on gfx9): four round trips to L2 instead of one.
+__device__ __forceinline__ void arrived(int32_t &a, int32_t &b, int32_t &c, int32_t &d) { asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d)); }
 __device__ __forceinline__ uint32_t mbcnt(unsigned long long m) { return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)); }
 } // namespace wv
 #include "bf_wave_body.h"
@@ -770,7 +774,7 @@ void launch_wp_wave(const WpWaveParams &p, int variant, hipStream_t s)
         return;
     }
     if (cfg == 14 || cfg == 15) {       // experiments: phase costs by difference (results are wrong by design)
-        const int64_t nb = (int64_t)device_cus() * 8;
+        const int64_t nb = (int64_t)device_cus() * (per_cu > 0 ? per_cu : 8);
         if (cfg == 14) hipLaunchKernelGGL((k_wp_wave<L, 1, 3, 8, false, 1>), dim3((unsigned)nb), dim3(256), 0, s, p, grab);
         else hipLaunchKernelGGL((k_wp_wave<L, 1, 3, 8, false, 2>), dim3((unsigned)nb), dim3(256), 0, s, p, grab);
         return;
@@ -785,8 +789,10 @@ void launch_wp_wave(const WpWaveParams &p, int variant, hipStream_t s)
     else if (cfg == 9) launch_wp_wave_cfg<L, 1, 3, 8, 4, 3>(p, grab, per_cu, s);
     else if (cfg == 10) launch_wp_wave_cfg<L, 1, 3, 8, 4, 4>(p, grab, per_cu, s);
     else if (cfg == 11) launch_wp_wave_cfg<L, 1, 3, 8, 4, 7>(p, grab, per_cu, s);
+    else if (cfg == 13) launch_wp_wave_cfg<L, 1, 3, 8, 4, 15>(p, grab, per_cu, s);                            // experiments: + TRIM 8 (one wait in the retire pass)
+    else if (cfg == 3) launch_wp_wave_cfg<L, 1, 3, 8, 4, 31>(p, grab, per_cu, s);                             // experiments: + no stores to the provisional homes (wrong results by design)
     else if (cfg == 12) launch_wp_wave_cfg<L, 1, 3, 8>(p, grab, per_cu, s);                                   // the instance shipped until round 4 (TRIM 0)
-    else launch_wp_wave_cfg<L, 1, 3, 8, 4, 7>(p, grab, per_cu, s);                                          // shipped: TRIM 7 (10 M documents: 25.23 -> 24.28 ms, profiles/r04_p_wp_trim.txt)
+    else launch_wp_wave_cfg<L, 1, 3, 8, 4, 15>(p, grab, per_cu, s);                                         // shipped: TRIM 15 (10 M documents: 25.23 -> 24.28 ms with TRIM 7, 2.5 M: 6.23 -> 6.11 with the one wait of the retire pass; profiles/r04_p_wp_trim.txt)
 }
 
 } // namespace bfa

@@ -49,7 +49,8 @@ struct WvLds {
 // provisional homes to its place, and the decoder records the byte every character starts at
 // TRIM (bits; each measured on its own before it became part of the shipped instance): 1 = no settle at the top of a trip (the one at the bottom of
 // the trip before has just run), 2 = the chunk-wide pass writes its tokens with selects (a lane without a token left writes to a spare entry)
-// instead of an execution-mask branch per token, 4 = fill as nested loops (fill_nested) instead of the re-entered fill_step
+// instead of an execution-mask branch per token, 4 = fill as nested loops (fill_nested) instead of the re-entered fill_step,
+// 8 = the retire pass waits once for the ids it loaded (wv::arrived) so that its stores leave back to back
 template <class LDS, int NU = 2, bool STATS = false, int DBG = 0, int STEPS = 3, int UMIN = 4, int CROOM = 0, bool OFFS = false, int TRIM = 0>
 struct WpWave {
     static constexpr int RING = LDS::RING, QCAP = LDS::QCAP, DTN = LDS::DTN;
@@ -561,8 +562,8 @@ struct WpWave {
             if (more) {
                 const uint32_t ke = (uint32_t)u.Lk >> 16;
                 int32_t *home = ids_tmp + S.dt_slot[ke] + (int64_t)(u.rs - S.dt_rbase[ke]);
-                if (cnt0 == 1) { home[0] = (int32_t)S.q[sl].pos; S.q[sl].pos = u.rs; }
-                home[cnt0] = id;
+                if (cnt0 == 1) { if (!(TRIM & 16)) home[0] = (int32_t)S.q[sl].pos; S.q[sl].pos = u.rs; }
+                if (!(TRIM & 16)) home[cnt0] = id;                    // (TRIM 16: an experiment, wrong results by design: what the stores to the provisional homes cost)
             }
         }
         uint32_t *wp = (gap || (matched && cnt0 == 0)) ? &S.q[sl].pos : &S.spare32;
@@ -682,6 +683,7 @@ struct WpWave {
         const int head = 63 - __builtin_clzll(hm & ((2ull << lane) - 1ull));
         const int segbase = wv::shfl(exc, head);
         const int pos = dcnt + (exc - segbase);
+        if (TRIM & 8) wv::arrived(v0, v1, v2, v3);                    // one wait for the loads above; the stores below then leave back to back
         wv::sync();                                                   // every lane has read its document's count and its first four ids
         if (act && (lane == 63 || k != kn)) S.dt_cnt[ke] = pos + cnt;
         const int room = cap - pos;

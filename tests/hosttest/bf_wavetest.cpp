@@ -65,8 +65,8 @@ long bft_emu_wave_batch(void *hv, const uint8_t *text, long text_bytes, const in
     if (ndocs > 0) {
         if (cfg == 1) run_cfg<WvLds<1024, 128, 2>, 2>(p, nwaves, grab);
         else if (cfg == 2) run_cfg<WvLds<4096, 512, 64>, 3>(p, nwaves, grab);
-        else if (cfg == 3) run_cfg<WvLds<1024, 256, 8>, 1, false, 7>(p, nwaves, grab);          // the TRIM bits (bf_wave_body.h) on the shipped configuration ...
-        else if (cfg == 4) run_cfg<WvLds<1024, 128, 2>, 2, false, 7>(p, nwaves, grab);          // ... and on the smallest one, every token with an explicit action
+        else if (cfg == 3) run_cfg<WvLds<1024, 256, 8>, 1, false, 15>(p, nwaves, grab);          // the TRIM bits (bf_wave_body.h) on the shipped configuration ...
+        else if (cfg == 4) run_cfg<WvLds<1024, 128, 2>, 2, false, 15>(p, nwaves, grab);          // ... and on the smallest one, every token with an explicit action
         else if (cfg == 5) run_cfg<WvLds<1024, 256, 8>, 1, false, 3>(p, nwaves, grab);          // ... bits 1 + 2 alone
         else run_cfg<WvLds<1024, 256, 8>, 1>(p, nwaves, grab);
     }

@@ -185,6 +185,7 @@ template <class T> __attribute__((noinline)) static T uni(T v WV_SITE_ARG)
     return v;
 }
 static inline int own(int v) { return v; }
+static inline void arrived(int32_t &, int32_t &, int32_t &, int32_t &) {}      // device: the four loaded values are in their registers from here on
 static inline uint32_t mbcnt(unsigned long long m) { return (uint32_t)__builtin_popcountll(m & ((1ull << wvemu::g_cur->lane) - 1ull)); }
 static inline unsigned long long atomic_add(unsigned long long *p, unsigned long long v) { unsigned long long o = *p; *p = o + v; return o; }
 static inline void atomic_or(int *p, int v) { *p |= v; }
