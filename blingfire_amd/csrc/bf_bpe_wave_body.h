@@ -593,6 +593,7 @@ struct BpeWave {
         const int head = 63 - __builtin_clzll(hm & ((2ull << lane) - 1ull));
         const int segbase = wv::shfl(exc, head);
         const int pos = dcnt + (exc - segbase);
+        wv::arrived(v0, v1, v2, v3);                                  // one wait for the loads above: the four stores below leave back to back (see k_wp_wave's retire pass)
         wv::sync();
         if (act && (lane == 63 || k != kn)) S.dt_cnt[ke] = pos + cnt;
         const int room = cap - pos;

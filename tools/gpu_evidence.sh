@@ -59,7 +59,7 @@ rm -f $O/stats.err
 timeout 600 python bench.py > $O/bench_default.json 2> $O/bench_default.err; tail -c 300 $O/bench_default.json; echo
 if [ -z "$quick" ]; then
   # traffic of the SentencePiece-style kernels (one sub-batch launch each): before their bench lines, which quote it
-  for spec in "config3 gpt2.bin 1000000 k_bpe_fused 1" "config4 xlm_roberta_base.bin 10000000 k_seg_unigram_lane 4" "config5 laser500k.bin 10000000 k_seg_unigram_lane 4"; do
+  for spec in "config3 gpt2.bin 1000000 k_bpe_wave 1" "config4 xlm_roberta_base.bin 10000000 k_seg_unigram_lane 4" "config5 laser500k.bin 10000000 k_seg_unigram_lane 4"; do
     set -- $spec
     Q=/tmp/prof_${tag}_$1; rm -rf $Q
     cd /tmp
