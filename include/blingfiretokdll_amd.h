@@ -206,7 +206,8 @@ BF_API int TextToIdsWithOffsetsBatchDevice(void *ModelPtr, const char *d_text, c
  * Key k = keys[key_offsets[k] .. key_offsets[k+1]) as int code points (the reference's Ty = int; byte-encoded models such as gpt2.bin
  * store bytes and U+2581 as their symbols), configured like blingfiretokdll would configure it (SetConf without a transformation):
  * an l2r dictionary is looked up as is (the [pos-dict] charmap is not applied, FADictInterpreter_t.h:203-205), an r2l one after
- * charmap normalisation and reversal.  ret_out[k] = GetInfo's return value (value count, -1 = no such key: not in the dictionary,
+ * charmap normalisation and reversal, an ignore-case one (either direction) after folding every symbol (FAUtf32ToLower, :231-238) and
+ * then the charmap.  ret_out[k] = GetInfo's return value (value count, -1 = no such key: not in the dictionary,
  * empty or longer than 300 symbols); info_ids_out[k] = GetInfoId (-1 = none); the values of key k (for the tokenizer dictionaries:
  * [token id, float score bits]) = values_out[value_offsets_out[k] .. value_offsets_out[k+1]).  ret_out / info_ids_out may be NULL.
  * Returns the total value count or BF_E_* (BF_E_CAPACITY: the offsets are valid and tell the size).  The Device form takes device
