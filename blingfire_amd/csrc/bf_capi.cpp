@@ -410,6 +410,7 @@ int run_device(Handle *h, const char *d_text, const int64_t *d_doc_off, int64_t 
         pp.prefix_n = m.no_dummy_prefix ? 0 : (int)m.sp_prefix.size();
         for (int k = 0; k < 10; ++k) pp.prefix[k] = k < pp.prefix_n ? m.sp_prefix[(size_t)k] : 0;
         pp.old_form = (h->variant & 0x80) ? 1 : 0;
+        pp.waves = (h->variant >> 24) & 0xf;
         pp.slot_mul = mul; pp.stream = h->w_cls.as<uint16_t>(); pp.lens = h->w_nchars.as<int32_t>(); pp.src_off = want_off ? h->w_srcoff.as<int32_t>() : nullptr;
         if (ndocs > 0) launch_prep_sp(pp, s);
         (void)hipEventRecord(h->ev[EV_PREP], s);

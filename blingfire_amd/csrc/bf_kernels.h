@@ -53,6 +53,7 @@ struct SpPrepParams {
     int32_t *src_off;           // optional (offsets API): byte offset of the source character of every kept element (-1: dummy prefix)
     int32_t *lens;              // [ndocs] stream length, 0 = "TextToIds returns 0"
     int old_form;               // experiments: the byte-per-lane kernel
+    int waves;                  // experiments: waves per SIMD the eight-bytes-per-lane kernel is compiled for (0 = the compiler's choice)
 };
 
 struct SpSegParams {

@@ -762,7 +762,7 @@ void launch_wp_wave(const WpWaveParams &p, int variant, hipStream_t s)
         static int per_cu_off = 0;
         if (per_cu_off <= 0) {
             int q = 0;
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&q, k_wp_wave<LO, 1, 3, 6, false, 0, 4, 0, true>, 256, 0) != hipSuccess || q <= 0) q = 2;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&q, k_wp_wave<LO, 1, 3, 6, false, 0, 4, 0, true, 15>, 256, 0) != hipSuccess || q <= 0) q = 2;
             (void)hipGetLastError();
             per_cu_off = q;
         }
@@ -770,7 +770,8 @@ void launch_wp_wave(const WpWaveParams &p, int variant, hipStream_t s)
         const int64_t need = (p.ndocs + (int64_t)grab * 4 - 1) / ((int64_t)grab * 4);
         if (blocks > need) blocks = need;
         if (blocks < 1) blocks = 1;
-        hipLaunchKernelGGL((k_wp_wave<LO, 1, 3, 6, false, 0, 4, 0, true>), dim3((unsigned)blocks), dim3(256), 0, s, p, grab);
+        if (cfg == 12) hipLaunchKernelGGL((k_wp_wave<LO, 1, 3, 6, false, 0, 4, 0, true>), dim3((unsigned)blocks), dim3(256), 0, s, p, grab);        // A/B runs: the instance of the first half of round 4 (TRIM 0)
+        else hipLaunchKernelGGL((k_wp_wave<LO, 1, 3, 6, false, 0, 4, 0, true, 15>), dim3((unsigned)blocks), dim3(256), 0, s, p, grab);
         return;
     }
     if (cfg == 14 || cfg == 15) {       // experiments: phase costs by difference (results are wrong by design)
@@ -1035,7 +1036,9 @@ __global__ __launch_bounds__(256) void k_prep_sp(SpPrepParams p)
 // prefix sum, and the stores.  Characters that expand 1 : n (or vanish) take a general form of the two lane-local passes.
 // Per character the rules are those of k_prep_sp above (tokdll:1367-1496, FAUtf8Utils.cpp:121-196,233-270,316-345).
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_prep_sp8(SpPrepParams p)
+// WPE: waves per SIMD the register allocation is asked to allow (0: the compiler's own choice, 73 VGPRs = six waves)
+template <int WPE>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE == 0 ? 1 : WPE, WPE == 0 ? 8 : WPE))) void k_prep_sp8(SpPrepParams p)
 {
     __shared__ uint32_t ascii_v[128];
     __shared__ uint32_t stage_all[4][8 * 64];                  // per wave: map value of the character that starts at byte k of lane l at [k * 64 + l], SP8_NOCHAR: none
@@ -1243,7 +1246,11 @@ void launch_prep_sp(const SpPrepParams &p, hipStream_t s)
     if (blocks > device_cus() * 16) blocks = device_cus() * 16;
     if (blocks < 1) blocks = 1;
     if (p.old_form) hipLaunchKernelGGL(k_prep_sp, dim3((unsigned)blocks), dim3(256), 0, s, p);      // the byte-per-lane form (A/B runs: BfSetVariant bit 0x80)
-    else hipLaunchKernelGGL(k_prep_sp8, dim3((unsigned)blocks), dim3(256), 0, s, p);
+    // shipped: compiled for eight waves per SIMD (64 VGPRs, 8 bytes of scratch).  Config 4, 10 M documents (profiles/r04_u_prep_waves.txt): six waves
+    // (the compiler's own choice, 73 VGPRs) 31.7 ms, seven (72 VGPRs) 30.5, eight 27.3.  BfSetVariant bits 24..27 = 6 / 7: the other instances
+    else if (p.waves == 6) hipLaunchKernelGGL(k_prep_sp8<0>, dim3((unsigned)blocks), dim3(256), 0, s, p);
+    else if (p.waves == 7) hipLaunchKernelGGL(k_prep_sp8<7>, dim3((unsigned)blocks), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL(k_prep_sp8<8>, dim3((unsigned)blocks), dim3(256), 0, s, p);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -683,7 +683,10 @@ struct WpWave {
         const int head = 63 - __builtin_clzll(hm & ((2ull << lane) - 1ull));
         const int segbase = wv::shfl(exc, head);
         const int pos = dcnt + (exc - segbase);
-        if (TRIM & 8) wv::arrived(v0, v1, v2, v3);                    // one wait for the loads above; the stores below then leave back to back
+        if (TRIM & 8) {                                               // one wait for the loads above; the stores below then leave back to back
+            wv::arrived(v0, v1, v2, v3);
+            if (OFFS) { wv::arrived(sa0, sb0, sa1, sb1); wv::arrived(sa2, sb2, sa3, sb3); }
+        }
         wv::sync();                                                   // every lane has read its document's count and its first four ids
         if (act && (lane == 63 || k != kn)) S.dt_cnt[ke] = pos + cnt;
         const int room = cap - pos;

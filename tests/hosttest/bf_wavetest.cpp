@@ -107,8 +107,9 @@ long bft_emu_wave_batch_offsets(void *hv, const uint8_t *text, long text_bytes, 
     p.cold.kind = m.wave_kind.data(); p.cold.nclasses = m.wbd.nclasses; p.cold.status = &status; p.cold.stats = stats; p.cold.no_fast = cfg == 1 ? 1 : 0;
     if (ndocs > 0) {
         if (cfg == 1) run_cfg<WvLds<1024, 128, 2, true>, 2, true>(p, nwaves, grab);
-        else if (cfg == 2) run_cfg<WvLds<4096, 512, 64, true>, 3, true>(p, nwaves, grab);
-        else run_cfg<WvLds<1024, 256, 8, true>, 1, true>(p, nwaves, grab);
+        else if (cfg == 2) run_cfg<WvLds<4096, 512, 64, true>, 3, true, 15>(p, nwaves, grab);
+        else if (cfg == 3) run_cfg<WvLds<1024, 256, 8, true>, 1, true>(p, nwaves, grab);           // the instance without the TRIM bits
+        else run_cfg<WvLds<1024, 256, 8, true>, 1, true, 15>(p, nwaves, grab);                     // shipped
     }
     if (status) return -5;
     long o = 0;

@@ -53,6 +53,26 @@ def test_set_model_from_memory_and_capacity_error():
     assert L.LoadModel(b"/nonexistent/model.bin") in (None, 0)
 
 
+def test_small_wordpiece_batch_capacity_error_writes_no_ids():
+    """the mapped path of small WordPiece batches (<= 256 documents, 64 KB): ids_cap too small -> BF_E_CAPACITY with the offsets complete (they
+    tell the size) and not one id written -- like the regular path (advisor finding of round 3)"""
+    L = bf.lib()
+    h = bf.load_model(bfutil.model_path(bfutil.bert_model_name()))
+    try:
+        docs = [b"Hello, world! This is a test."] * 40
+        want, want_off = bf.text_to_ids_batch(h, docs, 64, 100)
+        text, doff = bf.pack_docs(docs)
+        small = np.full(len(want) - 1, -7, dtype=np.int32)
+        id_off = np.full(41, -1, dtype=np.int64)
+        r = L.TextToIdsBatch(ctypes.c_void_p(h), text.ctypes.data, doff.ctypes.data, 40, small.ctypes.data, len(small), id_off.ctypes.data, 64, 100)
+        assert r == -3 and np.array_equal(id_off, want_off) and (small == -7).all()
+        exact = np.full(len(want), -7, dtype=np.int32)
+        r = L.TextToIdsBatch(ctypes.c_void_p(h), text.ctypes.data, doff.ctypes.data, 40, exact.ctypes.data, len(exact), id_off.ctypes.data, 64, 100)
+        assert r == len(want) and np.array_equal(exact, want)
+    finally:
+        bf.free_model(h)
+
+
 def test_concurrent_callers():
     """The reference is re-entrant on a loaded handle (README.md:105,215); calls on one handle serialise here,
     different handles run independently -- results must be the same as a serial run."""

@@ -176,7 +176,7 @@ def test_offsets_instance_of_the_wave_program(ht, model):
     docs = list(bfutil.ADVERSARIAL) + bfutil.fuzz_docs(250, seed=31) + [("x" * k + " " + "unaffable" * 3 + " é" * (k % 7)).encode() for k in (1, 63, 64, 65, 300, 511, 512, 513, 1100)]
     text, off = bf.pack_docs(docs)
     nd = len(docs)
-    for (mx, unk, nw, grab, cfg) in [(512, 100, 1, 8, 0), (512, 100, 3, 2, 1), (5, 7, 2, 8, 2), (512, 100, 4, 1, 16)]:
+    for (mx, unk, nw, grab, cfg) in [(512, 100, 1, 8, 0), (512, 100, 3, 2, 1), (5, 7, 2, 8, 2), (512, 100, 4, 1, 16), (512, 100, 2, 8, 3), (3, 100, 3, 4, 0)]:      # cfg 0 / 2: with the TRIM bits, 1 / 3: without
         cap = len(text) + 16
         ids = np.full(cap, -9, dtype=np.int32); st = np.full(cap, -9, dtype=np.int32); en = np.full(cap, -9, dtype=np.int32)
         ido = np.zeros(nd + 1, dtype=np.int64)

@@ -57,6 +57,8 @@ python tools/prof_traffic.py $P "headline512/$model/10000000" $kern 1 > $O/traff
 rm -f $O/stats.err
 # ---- the lines
 timeout 600 python bench.py > $O/bench_default.json 2> $O/bench_default.err; tail -c 300 $O/bench_default.json; echo
+# the offsets API of the metric's corpus (TextToIdsWithOffsetsBatchDevice: the wave program's instance that carries a span with every id + k_compact_text)
+timeout 400 python bench.py --offsets --no-cpu-baseline --no-extra-timings --verify 2000000 --steps 5 --warmup 2 > $O/bench_default_offsets.json 2> $O/bench_default_offsets.err; tail -c 200 $O/bench_default_offsets.json; echo
 if [ -z "$quick" ]; then
   # traffic of the SentencePiece-style kernels (one sub-batch launch each): before their bench lines, which quote it
   for spec in "config3 gpt2.bin 1000000 k_bpe_wave 1" "config4 xlm_roberta_base.bin 10000000 k_seg_unigram_lane 4" "config5 laser500k.bin 10000000 k_seg_unigram_lane 4"; do
