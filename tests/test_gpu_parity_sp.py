@@ -129,3 +129,19 @@ def test_bpe_wave_program_variant(model, checker):
     finally:
         bf.free_model(h)
         checker.free(hck)
+
+
+@pytest.mark.parametrize("model", [m for m in ("xlm_roberta_base.bin", "gpt2.bin", "laser100k.bin") if bfutil.have_model(m)])
+def test_prologue_instances_agree(model, checker):
+    """the _sp prologue as shipped (eight bytes per lane, compiled for eight waves per SIMD), compiled for six / seven waves (BfSetVariant
+    bits 24..27) and in its byte-per-lane form (bit 0x80): the same ids"""
+    h = bf.load_model(bfutil.model_path(model))
+    hck = checker.load(bfutil.model_path(model))
+    try:
+        docs = list(bfutil.ADVERSARIAL) + bfutil.fuzz_docs(1200, seed=23)
+        for variant in (3, 3 | (6 << 24), 3 | (7 << 24), 3 | 0x80):
+            bf.lib().BfSetVariant(h, variant)
+            _compare(h, checker, hck, docs, 512, 3)
+    finally:
+        bf.free_model(h)
+        checker.free(hck)

@@ -140,6 +140,26 @@ def test_wave_program_long_words_and_documents(checker):
             checker.free(hck)
 
 
+def test_wave_program_instances_agree(checker):
+    """every instance of k_wp_wave a BfSetVariant configuration selects and that computes the right answer -- the shipped one (TRIM 15), the one
+    of round 3 (12), the single TRIM steps (7, 9, 10, 11, 13) and the occupancy / units-phase experiments (1, 2, 4, 5, 6) -- gives the checker's ids"""
+    model = bfutil.bert_model_name()
+    h = bf.load_model(bfutil.model_path(model))
+    hck = checker.load(bfutil.model_path(model))
+    try:
+        docs = list(bfutil.ADVERSARIAL) + bfutil.fuzz_docs(1500, seed=19) + [("a" * 700 + " b").encode(), ("x " * 600).encode()]
+        text, off = bfutil.gen_workload("headline512", 3000)
+        raw = text.tobytes()
+        docs += [raw[off[d]:off[d + 1]] for d in range(3000)]
+        for cfg in (0, 12, 7, 9, 10, 11, 13, 1, 2, 4, 5, 6):
+            bf.lib().BfSetVariant(h, 3 | (cfg << 8))              # 3 = the low byte of a fresh handle's variant
+            for max_ids, unk in ((512, 100), (5, 7)):
+                _compare(h, checker, hck, docs, max_ids, unk)
+    finally:
+        bf.free_model(h)
+        checker.free(hck)
+
+
 @pytest.mark.parametrize("workload", ["headline512", "config3"])
 def test_bench_generators_pinned_to_the_reference(workload):
     """50 k documents of the generators bench.py times -- the metric's 512-byte corpus and config 3's 32-2048-byte mix -- through the
