@@ -97,6 +97,19 @@ def test_fixture_is_the_reference_fold():
         assert f(cp) == m.get(cp, cp), hex(cp)
 
 
+@pytest.mark.skipif(not bfutil.have_ref(), reason="oracle/_ref not built (needs /root/reference)")
+def test_committed_fold_tables_are_what_the_generator_writes():
+    """blingfire_amd/csrc/bf_tolower.h and oracle/bf_tolower_tab.h hold exactly the runs tools/make_tolower.py derives from the compiled reference"""
+    import re
+    import sys
+    sys.path.insert(0, os.path.join(bfutil.ROOT, "tools"))
+    import make_tolower
+    want = make_tolower.runs_of(make_tolower.observe())
+    for path in (os.path.join(bfutil.ROOT, "blingfire_amd", "csrc", "bf_tolower.h"), os.path.join(bfutil.ROOT, "oracle", "bf_tolower_tab.h")):
+        got = [(int(a, 16), int(b), int(c), int(d)) for a, b, c, d in re.findall(r"\{0x([0-9A-F]+), (\d+), (\d+), (-?\d+)\}", open(path).read())]
+        assert got == want, path
+
+
 # ------------------------------------------------------------------------------------------------------------------------------
 # ignore-case lexers
 # ------------------------------------------------------------------------------------------------------------------------------
