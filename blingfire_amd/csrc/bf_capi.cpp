@@ -169,6 +169,8 @@ struct Handle {
     DevBuf w_cls, w_nchars, w_tmp, w_counts, w_bsums, w_misc, w_flags, w_out, w_outoff;   // w_misc: [0] next_doc (u64), [2] status (int)
     DevBuf w_text, w_docoff, w_ids, w_idoff, w_starts, w_ends;  // host-API staging
     DevBuf w_srcoff, w_span;                                    // offsets API: source-offset stream, staged id spans
+    DevBuf w_ent, w_home, w_entoff, w_entcnt, w_dstat, w_ranges, w_list, t_flat;   // the flat program (bf_flat.h): entries, homes, per-document records, ranges, the documents handed back; its word table
+    bool last_flat = false;                                      // the last batch took the flat program (BfLastKernelMs names the kernels by it)
     // single-document calls that arrive while a batch is in flight are combined into the next launch (text_to_ids_one)
     struct OneReq { const char *s; int n; int32_t *ids; int max_ids, unk; int32_t *starts, *ends; int result; std::atomic<int> state; };
     std::mutex q_mu; std::vector<OneReq *> q; bool q_leader = false; std::atomic<int> q_spinners{0}, q_sleepers{0};
@@ -192,7 +194,7 @@ struct Handle {
         shards.clear();
         pipe.release(); m_small.release();
         for (DevBuf *b : {&t_segscore, &t_bpe_prio, &t_bpe_place, &t_dk_l1, &t_dk_pages, &t_dn_l1, &t_dn_pages, &t_dn_pool, &t_k2i, &t_rows, &w_keys, &w_keyoff, &w_dids, &w_dret, &w_vals, &t_i2w_off, &t_i2w_data, &t_kind, &t_wbd, &t_info, &t_acts, &t_cp_l1, &t_cp_pages, &t_multi, &t_wcp_l1, &t_wcp_pages, &t_dict, &t_seginfo, &w_s1, &w_s2, &w_s3, &w_s4, &w_big, &w_perm, &w_hist, &w_narcs, &w_bwflags, &w_cls, &w_nchars, &w_tmp, &w_counts, &w_flags, &w_out, &w_outoff,
-                          &w_bsums, &w_misc, &w_text, &w_docoff, &w_ids, &w_idoff, &w_starts, &w_ends, &w_srcoff, &w_span}) b->release();
+                          &w_bsums, &w_misc, &w_text, &w_docoff, &w_ids, &w_idoff, &w_starts, &w_ends, &w_srcoff, &w_span, &w_ent, &w_home, &w_entoff, &w_entcnt, &w_dstat, &w_ranges, &w_list, &t_flat}) b->release();
         for (auto &e : ev) if (e) (void)hipEventDestroy(e);
         if (stream) (void)hipStreamDestroy(stream);
         magic = 0;
@@ -283,6 +285,7 @@ Handle *make_handle(const uint8_t *img, size_t size)
         ok = ok && upload(h->t_wbd, m.wbd_t2, 16) && upload(h->t_acts, m.acts_pool, 16) &&
              upload(h->t_cp_l1, m.wbd_cpmap.l1) && upload(h->t_cp_pages, m.wbd_cpmap.pages) && upload(h->t_multi, m.wbd_multi_pool, 16) &&
              upload(h->t_wcp_l1, m.words_cpmap.l1) && upload(h->t_wcp_pages, m.words_cpmap.pages) && upload(h->t_kind, m.wave_kind, 16);
+        if (m.flat_ok) ok = ok && upload(h->t_flat, m.flat_tab, 16);
     } else if (m.kind != KIND_I2W) {
         ok = ok && upload(h->t_dict, m.dict.t64, 16) && upload(h->t_seginfo, m.seg_info, 16) &&
              upload(h->t_cp_l1, m.sp_cpmap.l1) && upload(h->t_cp_pages, m.sp_cpmap.pages) && upload(h->t_multi, m.sp_multi_pool, 16);
@@ -311,6 +314,16 @@ bool use_wave(const Handle *h, bool want_off, int words)
     return h->m.kind == KIND_WP && h->m.wave_ok && !words && (h->variant & 0xff) != 2;
 }
 
+// Batches of a flat-form model (bf_flat.h; every BERT model) that are large enough to fill the device take the flat program: ids only.
+// Variant 4 (tests): every batch; variant 5 (A/B): never.
+bool use_flat(const Handle *h, bool want_off, int words, int64_t ndocs, int64_t total_bytes)
+{
+    if (!use_wave(h, want_off, words) || want_off || !h->m.flat_ok || ndocs <= 0) return false;
+    const int v = h->variant & 0xff;
+    if (v == 4) return true;
+    return v == 3 && ndocs >= 1024 && total_bytes >= (1 << 20);
+}
+
 // the BPE wave program (bf_bpe_wave_body.h) in front of the lane-per-document kernels, for the models its load-time analysis admits
 // (Model::bpe_wave_ok); BfSetVariant bit 0x40 switches it off (A/B runs against the lane-per-document kernels alone)
 bool use_bpe_wave(const Handle *h, bool want_off) { return h->m.bpe_wave_ok && !want_off && (h->variant & 0x40) == 0; }
@@ -322,6 +335,10 @@ bool reserve_ids_workspaces(Handle *h, int64_t ndocs, int64_t total_bytes, bool 
     if (!h->w_nchars.reserve((size_t)(ndocs + 1) * 4) || !h->w_counts.reserve((size_t)(ndocs + 1) * 4) ||
         !h->w_bsums.reserve((size_t)(nblocks + 1) * 8) || !h->w_tmp.reserve((size_t)(total_bytes + 8 * ndocs + 64) * 4)) return false;
     if (m.kind == KIND_WP) {
+        if (use_flat(h, want_off, words, ndocs, total_bytes) &&
+            (!h->w_ent.reserve((size_t)(total_bytes + 64) * 4) || !h->w_home.reserve((size_t)(total_bytes + 64) * 4) || !h->w_entoff.reserve((size_t)(ndocs + 1) * 8) ||
+             !h->w_entcnt.reserve((size_t)(ndocs + 1) * 4) || !h->w_dstat.reserve((size_t)(ndocs + 1) * 4) || !h->w_list.reserve((size_t)(ndocs + 1) * 4) ||
+             !h->w_ranges.reserve((size_t)(wp_flat_ranges(ndocs, total_bytes) + 2) * 8))) return false;
         if (use_wave(h, want_off, words))                              // no class stream, no dirty flags
             return !want_off || h->w_span.reserve((size_t)(total_bytes + 8 * ndocs + 64) * 8);
         if (!h->w_cls.reserve((size_t)(total_bytes + 64) * 2) || !h->w_flags.reserve((size_t)((total_bytes >> 10) + 2) * 8)) return false;
@@ -364,6 +381,51 @@ int run_device(Handle *h, const char *d_text, const int64_t *d_doc_off, int64_t 
     if (!hip_ok(hipMemsetAsync(h->w_misc.p, 0, 64, s), "hipMemsetAsync")) return BF_E_DEVICE;
     h->small_status = -1;
     (void)hipEventRecord(h->ev[EV_BEGIN], s);
+    h->last_flat = use_flat(h, want_off, words, ndocs, total_bytes);
+    if (h->last_flat) {
+        // w_misc: [192] work counter of the ranges, [200] "the batch is not fit for the flat program", [204] documents handed back
+        char *misc = h->w_misc.as<char>();
+        if (!hip_ok(hipMemsetAsync(misc + 192, 0, 16, s), "hipMemsetAsync") || !hip_ok(hipMemsetAsync(h->w_dstat.p, 0, (size_t)ndocs * 4, s), "hipMemsetAsync")) return BF_E_DEVICE;
+        int *unsafe = (int *)(misc + 200); unsigned int *list_n = (unsigned int *)(misc + 204);
+        const int nranges = wp_flat_ranges(ndocs, total_bytes);
+        launch_wp_pre(d_doc_off, ndocs, total_bytes, nranges, h->w_ranges.as<int64_t>(), unsafe, s);
+        (void)hipEventRecord(h->ev[EV_PREP], s);
+        WpWaveCold cold;
+        cold.cpmap = DevCpMap{h->t_cp_l1.as<uint16_t>(), h->t_cp_pages.as<uint32_t>()};
+        cold.kind = h->t_kind.as<uint8_t>(); cold.nclasses = m.wbd.nclasses; cold.status = status; cold.no_fast = 0;
+        cold.stats = h->lex_stats ? (unsigned long long *)(misc + 64) : nullptr;
+        WfParams fp;
+        fp.T = h->t_wbd.as<uint64_t>(); fp.W = h->t_flat.as<uint64_t>(); fp.wbits = m.flat_bits; fp.m0 = m.flat_m0; fp.m1 = m.flat_m1; fp.m2 = m.flat_m2;
+        fp.ini = m.flat_ini; fp.ini_l = m.flat_ini_l; fp.max_token_length = m.max_token_length; fp.unk = unk;
+        fp.text = b.text; fp.doc_off = b.doc_off; fp.ndocs = ndocs; fp.total_bytes = total_bytes;
+        fp.range_doc = h->w_ranges.as<int64_t>(); fp.nranges = nranges; fp.next_range = (unsigned long long *)(misc + 192); fp.unsafe = unsafe;
+        fp.ent = h->w_ent.as<uint32_t>(); fp.home = h->w_home.as<int32_t>(); fp.ent_off = h->w_entoff.as<int64_t>(); fp.ent_cnt = h->w_entcnt.as<int32_t>();
+        fp.dstat = h->w_dstat.as<int32_t>(); fp.cold = cold;
+        launch_wp_flat(fp, h->variant, s);
+        (void)hipEventRecord(h->ev[EV_TOK], s);
+        // the documents it hands back: the wave program, one document at a time
+        launch_wp_hardlist(fp.dstat, unsafe, ndocs, h->w_list.as<int32_t>(), list_n, s);
+        WpWaveParams wp;
+        wp.T = fp.T; wp.acts = h->t_acts.as<int32_t>(); wp.acts_n = (int)m.acts_pool.size();
+        wp.initial = m.wbd.initial_base; wp.loop_info = m.loop_info; wp.solo_info = m.wave_solo_info; wp.max_token_length = m.max_token_length;
+        wp.text = b.text; wp.doc_off = b.doc_off; wp.ndocs = ndocs; wp.total_bytes = total_bytes;
+        wp.ids_tmp = h->w_tmp.as<int32_t>(); wp.counts = h->w_counts.as<int32_t>(); wp.max_ids = max_ids; wp.unk = unk; wp.span_tmp = nullptr;
+        wp.next_doc = next_doc; wp.doc_list = h->w_list.as<int32_t>(); wp.list_n = list_n;
+        wp.cold = cold; wp.cold.stats = nullptr;
+        launch_wp_wave(wp, h->variant & ~0x3f000000, s);
+        WfMergeParams mp;
+        mp.doc_off = b.doc_off; mp.ndocs = ndocs; mp.ent = fp.ent; mp.home = fp.home; mp.ent_off = fp.ent_off; mp.ent_cnt = fp.ent_cnt; mp.dstat = fp.dstat; mp.unsafe = unsafe;
+        mp.ids_tmp = wp.ids_tmp; mp.counts = wp.counts; mp.id_off = d_id_off; mp.ids_out = d_ids_out; mp.ids_cap = ids_cap; mp.status = status; mp.max_ids = max_ids; mp.unk = unk;
+        launch_wp_count(mp, s);
+        ScanParams sp{h->w_counts.as<int32_t>(), ndocs, d_id_off, h->w_bsums.as<int64_t>(), nblocks};
+        launch_scan(sp, s);
+        (void)hipEventRecord(h->ev[EV_SCAN], s);
+        launch_wp_merge(mp, s);
+        (void)hipEventRecord(h->ev[EV_COMPACT], s);
+        h->ev_valid = true;
+        if (!hip_ok(hipGetLastError(), "kernel launch")) return BF_E_DEVICE;
+        return 0;
+    }
     if (use_wave(h, want_off, words)) {
         (void)hipEventRecord(h->ev[EV_PREP], s);                       // decoding is part of the wave program
         WpWaveParams wp;
@@ -1851,7 +1913,7 @@ const char *BfTokeniseKernel(void *p)
     Handle *h = as_handle(p);
     if (!h) return "";
     switch (h->m.kind) {
-    case KIND_WP: return use_wave(h, false, 0) ? "k_wp_wave" : (h->m.two_level ? "k_lex_wp_plain" : "k_lex_wp_flat");
+    case KIND_WP: return h->last_flat ? "k_wp_flat" : use_wave(h, false, 0) ? "k_wp_wave" : (h->m.two_level ? "k_lex_wp_plain" : "k_lex_wp_flat");
     case KIND_UNIGRAM: return "k_seg_unigram_lane";
     case KIND_I2W: return "";
     default: return use_bpe_wave(h, false) ? "k_bpe_wave" : "k_bpe_fused";

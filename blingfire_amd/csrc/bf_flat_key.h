@@ -1,0 +1,36 @@
+// bf_flat_key.h -- the word table of the flat program (bf_flat.h): constants and hash functions shared by the loader (bf_model.cpp, host
+// only) and the kernels.
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define BF_FK __host__ __device__ inline
+#else
+#define BF_FK inline
+#endif
+
+namespace bfa {
+
+constexpr int WF_CHUNK = 512;            // bytes per step (8 per lane)
+constexpr int WF_RING = 1024;            // byte positions whose class is kept (two chunks: a run may begin in the chunk before)
+constexpr int WF_ARENA = 768;            // characters of the words that wait for a unit
+constexpr int WF_REC = 64;               // words that wait for a unit, at most (one per lane)
+constexpr int WF_NOTES = 64;
+constexpr int WF_RUN_MAX = 48;           // bytes of the longest run the program resolves itself
+constexpr int WF_KEY_CHARS = 9;          // 7 bits per character
+constexpr uint32_t WF_CONT = 0xFFFFu;    // ring: a byte that starts no character
+constexpr uint32_t WF_ENT_FLAG = 0x80000000u;   // entry with bit 31: [30:25] number of ids (0: one id, UnkId), [24:0] home index - entry index
+constexpr int WF_ENT_CNT_SHIFT = 25;
+constexpr uint32_t WF_ENT_DELTA_MASK = (1u << WF_ENT_CNT_SHIFT) - 1u;
+constexpr int32_t WF_D_BAD = 1, WF_D_HARD = 2;  // dstat[] bits: invalid UTF-8 (0 ids); handed to the wave program
+constexpr int64_t WF_DOC_MAX = 1 << 22;  // a batch with a longer document (or with offsets out of order) is not taken (k_wp_pre sets *unsafe)
+constexpr int64_t WF_RANGE_MAX = 1 << 22; // bytes a range aims at, at most (a range ends with a whole document: < WF_RANGE_MAX + WF_DOC_MAX bytes)
+constexpr uint64_t WF_KEY_SOLO = 1ull << 63, WF_KEY_SOLO_CLS = 1ull << 32;   // key of a one-element token: SOLO | byte (ASCII), SOLO | SOLO_CLS | class
+
+// ---- the word table.  Entry e = {key, id}; two candidate entries per key.
+BF_FK uint32_t wf_mix(uint64_t key, uint32_t m0) { return (uint32_t)key ^ ((uint32_t)(key >> 32) * m0); }
+BF_FK uint32_t wf_h(uint32_t x, uint32_t m, int bits) { return (x * m) >> (32 - bits); }
+// code of a class inside a key (0: the class has none)
+BF_FK uint32_t wf_code(uint32_t cls, uint32_t kind) { return (kind == 1u /* WK_LOOP */ && cls < 127u) ? cls + 1u : 0u; }
+
+} // namespace bfa

@@ -7,6 +7,7 @@
 #include "bf_batch.h"
 #include "bf_wave.h"
 #include "bf_bpe_wave.h"
+#include "bf_flat.h"
 
 namespace bfa {
 
@@ -113,6 +114,13 @@ struct CompactParams {
 void launch_prep_wp(const WpPrepParams &p, int64_t total_bytes, unsigned long long *flags, hipStream_t s);
 void launch_lex_wp(const WpLexParams &p, int variant, hipStream_t s);
 void launch_wp_wave(const WpWaveParams &p, int variant, hipStream_t s);     // unit-form lexers (bf_wave.h): replaces prep + lexer
+// the flat program (bf_flat.h): ranges + fitness of the batch, the program, the documents it hands back, counts, merge
+int wp_flat_ranges(int64_t ndocs, int64_t total_bytes);
+void launch_wp_pre(const int64_t *doc_off, int64_t ndocs, int64_t total_bytes, int nranges, int64_t *range_doc, int *unsafe, hipStream_t s);
+void launch_wp_flat(const WfParams &p, int variant, hipStream_t s);
+void launch_wp_hardlist(const int32_t *dstat, const int *unsafe, int64_t ndocs, int32_t *list, unsigned int *list_n, hipStream_t s);
+void launch_wp_count(const WfMergeParams &p, hipStream_t s);
+void launch_wp_merge(const WfMergeParams &p, hipStream_t s);
 void launch_bpe_wave(const BpeWaveParams &p, int tune, hipStream_t s);                  // bpe-opt models (bf_bpe_wave_body.h)
 void launch_bpe_seg_flags(const SpSegParams &p, const int32_t *flags, int32_t *list, unsigned int *count, hipStream_t s);   // the documents it hands back: bf_bpe_seg_body.h
 void launch_prep_sp(const SpPrepParams &p, hipStream_t s);

@@ -702,7 +702,7 @@ __device__ __forceinline__ uint32_t mbcnt(unsigned long long m) { return __built
 namespace bfa {
 
 // WPE: waves per SIMD the register allocation is asked to allow (a workgroup is four waves, one per SIMD: WPE workgroups per CU)
-template <class LDS, int NU, int STEPS, int WPE, bool STATS, int DBG = 0, int UMIN = 4, int CROOM = 0, bool OFFS = false, int TRIM = 0>
+template <class LDS, int NU, int STEPS, int WPE, bool STATS, int UMIN = 4, bool OFFS = false, int TRIM = 0, bool LIST = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_wp_wave(WpWaveParams p, int grab)
 {
     __shared__ LDS lds[4];
@@ -714,34 +714,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
     for (int i = (int)threadIdx.x; i < p.acts_n; i += 256) acts[i] = p.acts[i];
     __syncthreads();
     // the wave number as a scalar: what a wave reads of its own LDS block at a wave-uniform index is then wave-uniform for the compiler too
-    WpWave<LDS, NU, STATS, DBG, STEPS, UMIN, CROOM, OFFS, TRIM> w(p, cold, lds[wave_in_block()], ascii, acts);
+    WpWave<LDS, NU, STATS, 0, STEPS, UMIN, 0, OFFS, TRIM, LIST> w(p, cold, lds[wave_in_block()], ascii, acts);
     w.run(grab, (int)(blockIdx.x * 4) + wave_in_block(), (int)(gridDim.x * 4));
 }
 
-template <class LDS, int NU, int STEPS, int WPE, int UMIN = 4, int TRIM = 0>
-static void launch_wp_wave_cfg(const WpWaveParams &p, int grab, int per_cu_override, hipStream_t s)
+template <class K>
+static int wp_blocks_per_cu(K kernel, int &cached)
 {
-    static int per_cu_cached = 0;                 // per instance; a property of the kernel and the device kind
-    if (per_cu_cached <= 0) {
+    if (cached <= 0) {
         int q = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&q, k_wp_wave<LDS, NU, STEPS, WPE, false, 0, UMIN, 0, false, TRIM>, 256, 0) != hipSuccess || q <= 0) q = 2;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&q, kernel, 256, 0) != hipSuccess || q <= 0) q = 2;
         (void)hipGetLastError();
-        per_cu_cached = q;
+        cached = q;
     }
-    int per_cu = per_cu_cached;
-    if (per_cu_override > 0) per_cu = per_cu_override;
-    int64_t blocks = (int64_t)device_cus() * per_cu;
-    const int64_t need = (p.ndocs + (int64_t)grab * 4 - 1) / ((int64_t)grab * 4);
-    if (blocks > need) blocks = need;
-    if (blocks < 1) blocks = 1;
-    if (p.cold.stats) hipLaunchKernelGGL((k_wp_wave<LDS, NU, STEPS, WPE, true, 0, UMIN, 0, false, TRIM>), dim3((unsigned)blocks), dim3(256), 0, s, p, grab);
-    else hipLaunchKernelGGL((k_wp_wave<LDS, NU, STEPS, WPE, false, 0, UMIN, 0, false, TRIM>), dim3((unsigned)blocks), dim3(256), 0, s, p, grab);
+    return cached;
 }
 
-// variant (experiments): bits 8..11 = configuration, bits 12..15 = documents per grab (0 = 8), bits 24..29 = workgroups per CU
+// The instances the library carries: ids (ring of 1,024 elements -- the longest word + one chunk fit: bf_model.cpp "unit form" --, a queue
+// of 256 tokens, a table of 8 open documents, eight workgroups per CU: 64 VGPRs, 20 KB of LDS per workgroup; every parameter swept on
+// MI355X, profiles/r03_ab_runs.txt, r04_p_wp_trim.txt), its twin with counters (BfSetLexStats), the offsets instance (a span with every id:
+// six workgroups per CU) and the LIST instance (the documents the flat program hands back).  variant bits 12..15 = documents per grab
+// (0 = by batch size), bits 24..29 = workgroups per CU (measurements: fewer resident waves).
 void launch_wp_wave(const WpWaveParams &p, int variant, hipStream_t s)
 {
-    const int cfg = (variant >> 8) & 0xf;
     int grab = (variant >> 12) & 0xf;
     if (grab == 0 || grab > WV_GRAB_MAX) {
         // documents a wave takes from the work counter at once: eight in a large batch (one atomic per 4 KB of text); a batch with fewer
@@ -749,51 +744,156 @@ void launch_wp_wave(const WpWaveParams &p, int variant, hipStream_t s)
         const int64_t per_wave = p.ndocs / ((int64_t)device_cus() * 32);
         grab = per_wave >= WV_GRAB_MAX ? WV_GRAB_MAX : per_wave < 1 ? 1 : (int)per_wave;
     }
-    const int per_cu = (variant >> 24) & 0x3f;
-    // Shipped: a ring of 1,024 elements (the longest word + one chunk fit: bf_model.cpp "unit form"), a queue of 256 tokens, a table of 8
-    // open documents, eight workgroups per CU (eight waves per SIMD: 64 VGPRs, 20 KB of LDS per workgroup).  Measured on 10 M documents
-    // of 512 bytes (profiles/r03_*): 25.9 ms; seven workgroups (72 VGPRs) 27.7; six 29.9; a ring of 2,048 and five workgroups 32.3; a
-    // queue of 128 tokens and seven / eight workgroups 35.1 / 33.1; transitions per round 2 / 3 / 4 / 6 (at five workgroups): 33.9 /
-    // 33.0 / 33.6 / 36.6; two units per lane 39.4; leaving the units phase with fewer than 12 / 24 / 32 / 48 busy units 27.7 / 28.1 /
-    // 28.2 / 28.8 (at seven workgroups), 4 / 12 / 24: 25.7 / 26.0 / 26.3 (at eight).
+    const int per_cu_override = (variant >> 24) & 0x3f;
     typedef WvLds<1024, 256, 8> L;
-    if (p.span_tmp) {                   // the offsets API: the instance that carries a span with every id (six waves per SIMD: 24 KB of LDS per workgroup)
-        typedef WvLds<1024, 256, 8, true> LO;
-        static int per_cu_off = 0;
-        if (per_cu_off <= 0) {
-            int q = 0;
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&q, k_wp_wave<LO, 1, 3, 6, false, 0, 4, 0, true, 15>, 256, 0) != hipSuccess || q <= 0) q = 2;
-            (void)hipGetLastError();
-            per_cu_off = q;
-        }
-        int64_t blocks = (int64_t)device_cus() * per_cu_off;
+    typedef WvLds<1024, 256, 8, true> LO;
+    static int pc_ids = 0, pc_off = 0, pc_list = 0;
+    int per_cu;
+    if (p.doc_list) { per_cu = wp_blocks_per_cu(k_wp_wave<L, 1, 3, 8, false, 4, false, 15, true>, pc_list); grab = 1; }
+    else if (p.span_tmp) per_cu = wp_blocks_per_cu(k_wp_wave<LO, 1, 3, 6, false, 4, true, 15>, pc_off);
+    else per_cu = wp_blocks_per_cu(k_wp_wave<L, 1, 3, 8, false, 4, false, 15>, pc_ids);
+    if (per_cu_override > 0) per_cu = per_cu_override;
+    int64_t blocks = (int64_t)device_cus() * per_cu;
+    if (!p.doc_list) {                      // (the number of listed documents is known to the device only)
         const int64_t need = (p.ndocs + (int64_t)grab * 4 - 1) / ((int64_t)grab * 4);
         if (blocks > need) blocks = need;
-        if (blocks < 1) blocks = 1;
-        if (cfg == 12) hipLaunchKernelGGL((k_wp_wave<LO, 1, 3, 6, false, 0, 4, 0, true>), dim3((unsigned)blocks), dim3(256), 0, s, p, grab);        // A/B runs: the instance of the first half of round 4 (TRIM 0)
-        else hipLaunchKernelGGL((k_wp_wave<LO, 1, 3, 6, false, 0, 4, 0, true, 15>), dim3((unsigned)blocks), dim3(256), 0, s, p, grab);
-        return;
     }
-    if (cfg == 14 || cfg == 15) {       // experiments: phase costs by difference (results are wrong by design)
-        const int64_t nb = (int64_t)device_cus() * (per_cu > 0 ? per_cu : 8);
-        if (cfg == 14) hipLaunchKernelGGL((k_wp_wave<L, 1, 3, 8, false, 1>), dim3((unsigned)nb), dim3(256), 0, s, p, grab);
-        else hipLaunchKernelGGL((k_wp_wave<L, 1, 3, 8, false, 2>), dim3((unsigned)nb), dim3(256), 0, s, p, grab);
-        return;
+    if (blocks < 1) blocks = 1;
+    const dim3 g((unsigned)blocks), t(256);
+    if (p.doc_list) hipLaunchKernelGGL((k_wp_wave<L, 1, 3, 8, false, 4, false, 15, true>), g, t, 0, s, p, grab);
+    else if (p.span_tmp) hipLaunchKernelGGL((k_wp_wave<LO, 1, 3, 6, false, 4, true, 15>), g, t, 0, s, p, grab);
+    else if (p.cold.stats) hipLaunchKernelGGL((k_wp_wave<L, 1, 3, 8, true, 4, false, 15>), g, t, 0, s, p, grab);
+    else hipLaunchKernelGGL((k_wp_wave<L, 1, 3, 8, false, 4, false, 15>), g, t, 0, s, p, grab);
+}
+
+} // namespace bfa
+#include "bf_flat_body.h"
+namespace bfa {
+
+// ------------------------------------------------------------------------------------------
+// The flat program (bf_flat.h): k_wp_pre -> k_wp_flat -> k_wp_hardlist -> k_wp_wave<LIST> -> k_wp_count -> scan -> k_wp_merge
+// ------------------------------------------------------------------------------------------
+// ranges of documents of about equal bytes (range r begins with the first document at or behind r / nranges of the text), and whether the
+// batch is fit for the flat program at all: offsets in order and inside the buffer, no document of more than WF_DOC_MAX bytes
+__global__ __launch_bounds__(256) void k_wp_pre(const int64_t *doc_off, int64_t ndocs, int64_t total_bytes, int nranges, int64_t *range_doc, int *unsafe)
+{
+    const int64_t tid = (int64_t)blockIdx.x * 256 + threadIdx.x, nth = (int64_t)gridDim.x * 256;
+    bool bad = false;
+    for (int64_t d = tid; d < ndocs; d += nth) {
+        const int64_t a = doc_off[d], b = doc_off[d + 1];
+        bad |= a < 0 || b < a || b > total_bytes || b - a > WF_DOC_MAX;
     }
-    if (cfg == 1) launch_wp_wave_cfg<WvLds<1024, 256, 16>, 1, 3, 7>(p, grab, per_cu, s);                    // experiments: occupancy
-    else if (cfg == 2) launch_wp_wave_cfg<WvLds<1024, 256, 16>, 1, 3, 6>(p, grab, per_cu, s);
-    else if (cfg == 4) launch_wp_wave_cfg<WvLds<2048, 256, 16>, 1, 3, 5>(p, grab, per_cu, s);
-    else if (cfg == 5) launch_wp_wave_cfg<L, 1, 3, 8, 1>(p, grab, per_cu, s);                                 // experiments: when the units phase ends
-    else if (cfg == 6) launch_wp_wave_cfg<L, 1, 3, 8, 12>(p, grab, per_cu, s);
-    else if (cfg == 7) launch_wp_wave_cfg<L, 1, 3, 8, 4, 1>(p, grab, per_cu, s);                              // experiments: TRIM bits (bf_wave_body.h)
-    else if (cfg == 8) launch_wp_wave_cfg<L, 1, 3, 8, 4, 2>(p, grab, per_cu, s);
-    else if (cfg == 9) launch_wp_wave_cfg<L, 1, 3, 8, 4, 3>(p, grab, per_cu, s);
-    else if (cfg == 10) launch_wp_wave_cfg<L, 1, 3, 8, 4, 4>(p, grab, per_cu, s);
-    else if (cfg == 11) launch_wp_wave_cfg<L, 1, 3, 8, 4, 7>(p, grab, per_cu, s);
-    else if (cfg == 13) launch_wp_wave_cfg<L, 1, 3, 8, 4, 15>(p, grab, per_cu, s);                            // experiments: + TRIM 8 (one wait in the retire pass)
-    else if (cfg == 3) launch_wp_wave_cfg<L, 1, 3, 8, 4, 31>(p, grab, per_cu, s);                             // experiments: + no stores to the provisional homes (wrong results by design)
-    else if (cfg == 12) launch_wp_wave_cfg<L, 1, 3, 8>(p, grab, per_cu, s);                                   // the instance shipped until round 4 (TRIM 0)
-    else launch_wp_wave_cfg<L, 1, 3, 8, 4, 15>(p, grab, per_cu, s);                                         // shipped: TRIM 15 (10 M documents: 25.23 -> 24.28 ms with TRIM 7, 2.5 M: 6.23 -> 6.11 with the one wait of the retire pass; profiles/r04_p_wp_trim.txt)
+    if (bad) atomicOr(unsafe, 1);
+    const int64_t first = doc_off[0], span = doc_off[ndocs] - first;
+    for (int64_t r = tid; r <= nranges; r += nth) {
+        int64_t lo = 0, hi = ndocs;                              // the first document whose first byte is >= target
+        if (r == 0) hi = 0; else if (r == nranges) lo = ndocs;
+        else {
+            const int64_t target = first + (int64_t)((__int128)span * r / nranges);
+            while (lo < hi) { const int64_t mid = lo + (hi - lo) / 2; if (doc_off[mid] >= target) hi = mid; else lo = mid + 1; }
+        }
+        range_doc[r] = lo;
+    }
+}
+
+template <int WPE, bool STATS>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_wp_flat(WfParams p)
+{
+    __shared__ WfLds lds[4];
+    __shared__ uint32_t lut[128];
+    __shared__ WpWaveCold cold;
+    if (threadIdx.x == 0) cold = p.cold;
+    if (threadIdx.x < 128) lut[threadIdx.x] = wf_lut_value(p.cold, (int)threadIdx.x);
+    __syncthreads();
+    WfWave<STATS> w(p, lds[wave_in_block()], lut, cold);
+    w.run((int)(blockIdx.x * 4) + wave_in_block(), (int)(gridDim.x * 4));
+}
+
+// the documents the flat program hands back (all of them when the batch is not fit for it), in any order
+__global__ __launch_bounds__(256) void k_wp_hardlist(const int32_t *dstat, const int *unsafe, int64_t ndocs, int32_t *list, unsigned int *list_n)
+{
+    const bool all = *unsafe != 0;
+    for (int64_t d0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) & ~(int64_t)63; d0 < ndocs; d0 += (int64_t)gridDim.x * 256) {
+        const int64_t d = d0 + lane_id();
+        const bool take = d < ndocs && (all || (dstat[d] & WF_D_HARD));
+        const unsigned long long m = __ballot(take);
+        if (!m) continue;
+        unsigned int base = 0;
+        if (lane_id() == 0) base = atomicAdd(list_n, (unsigned int)__popcll(m));
+        base = (unsigned int)__builtin_amdgcn_readfirstlane((int)base);
+        if (take) list[base + (unsigned int)__popcll(m & lanemask_lt())] = (int32_t)d;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_wp_count(WfMergeParams p)
+{
+    const int64_t wave0 = (int64_t)blockIdx.x * 4 + wave_in_block(), nwaves = (int64_t)gridDim.x * 4;
+    for (int64_t base = wave0 * 64; base < p.ndocs; base += nwaves * 64) wf_count_docs(p, base);
+}
+
+__global__ __launch_bounds__(256) void k_wp_merge(WfMergeParams p)
+{
+    const int64_t wave0 = (int64_t)blockIdx.x * 4 + wave_in_block(), nwaves = (int64_t)gridDim.x * 4;
+    bool over = false;
+    for (int64_t base = wave0 * 64; base < p.ndocs; base += nwaves * 64) wf_merge_docs(p, base, over);
+    if (over) atomicOr(p.status, 1);
+}
+
+int wp_flat_ranges(int64_t ndocs, int64_t total_bytes)
+{
+    // four ranges per resident wave, of at least 16 KB and at most WF_RANGE_MAX bytes
+    int64_t r = (int64_t)device_cus() * 32 * 4;
+    const int64_t most = total_bytes / 16384 + 1, least = total_bytes / WF_RANGE_MAX + 1;
+    if (r > most) r = most;
+    if (r < least) r = least;
+    if (r > ndocs) r = ndocs;
+    return (int)(r < 1 ? 1 : r);
+}
+
+void launch_wp_pre(const int64_t *doc_off, int64_t ndocs, int64_t total_bytes, int nranges, int64_t *range_doc, int *unsafe, hipStream_t s)
+{
+    int64_t blocks = (ndocs + 255) / 256;
+    if (blocks > device_cus() * 8) blocks = device_cus() * 8;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(k_wp_pre, dim3((unsigned)blocks), dim3(256), 0, s, doc_off, ndocs, total_bytes, nranges, range_doc, unsafe);
+}
+
+void launch_wp_flat(const WfParams &p, int variant, hipStream_t s)
+{
+    static int pc = 0;
+    int per_cu = wp_blocks_per_cu(k_wp_flat<8, false>, pc);
+    const int per_cu_override = (variant >> 24) & 0x3f;
+    if (per_cu_override > 0) per_cu = per_cu_override;
+    int64_t blocks = (int64_t)device_cus() * per_cu;
+    const int64_t need = ((int64_t)p.nranges + 3) / 4;
+    if (blocks > need) blocks = need;
+    if (blocks < 1) blocks = 1;
+    if (p.cold.stats) hipLaunchKernelGGL((k_wp_flat<8, true>), dim3((unsigned)blocks), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((k_wp_flat<8, false>), dim3((unsigned)blocks), dim3(256), 0, s, p);
+}
+
+void launch_wp_hardlist(const int32_t *dstat, const int *unsafe, int64_t ndocs, int32_t *list, unsigned int *list_n, hipStream_t s)
+{
+    int64_t blocks = (ndocs + 255) / 256;
+    if (blocks > device_cus() * 8) blocks = device_cus() * 8;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(k_wp_hardlist, dim3((unsigned)blocks), dim3(256), 0, s, dstat, unsafe, ndocs, list, list_n);
+}
+
+void launch_wp_count(const WfMergeParams &p, hipStream_t s)
+{
+    int64_t blocks = (p.ndocs + 255) / 256;
+    if (blocks > device_cus() * 8) blocks = device_cus() * 8;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(k_wp_count, dim3((unsigned)blocks), dim3(256), 0, s, p);
+}
+
+void launch_wp_merge(const WfMergeParams &p, hipStream_t s)
+{
+    int64_t blocks = (p.ndocs + 255) / 256;
+    if (blocks > device_cus() * 8) blocks = device_cus() * 8;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(k_wp_merge, dim3((unsigned)blocks), dim3(256), 0, s, p);
 }
 
 } // namespace bfa

@@ -3,6 +3,7 @@
 #include "bf_model.h"
 #include "bf_layout.h"
 #include "bf_tolower.h"
+#include "bf_flat_key.h"
 
 #include <algorithm>
 #include <cstdio>
@@ -438,6 +439,95 @@ bool load_file(const char *path, std::vector<uint8_t> &out)
 
 static bool fail(Model &m, const std::string &e) { m.error = e; return false; }
 
+// Flat form (bf_flat.h, bf_model.h Model::flat_tab): the one-piece words of the vocabulary function as a hash table keyed by the word.
+// What a hit must mean, restated from bf_wave_body.h unit_call / unit_step / unit_event (themselves FALexTools_t.h:229-393 at depth 1 and
+// tokdll:1239-1301): the FIRST walk of the frame -- from the state behind the left anchor when the function has one, else from its plain
+// initial state -- reads the word's L characters (L <= max-token-length - 1: the walk's limit is the word's end), never misses, and its
+// last transition enters a final state: fp = L - 1, one sub-token that tiles the word, its tag is the id.  The walk is the device's own
+// (the entries of wbd_t2), so table and kernel cannot disagree about a transition.
+static void build_flat_table(Model &m)
+{
+    m.flat_ok = false; m.flat_tab.clear(); m.flat_words = 0;
+    if (!m.wave_ok || (m.loop_info & INFO_SIMPLE_BIT) || (m.wave_solo_info & INFO_SIMPLE_BIT)) return;
+    if ((size_t)m.loop_info + 7 > m.acts_pool.size() || (size_t)m.wave_solo_info + 7 > m.acts_pool.size()) return;
+    const int32_t *a = m.acts_pool.data() + m.loop_info, *c = m.acts_pool.data() + m.wave_solo_info;
+    if (a[2] != 1 /* WBD_WORD_TAG */ || c[2] != 1 || a[5] != c[5] || a[6] != c[6]) return;      // bf_wave_body.h WpWave::fast_ok
+    if (m.max_token_length < WF_RUN_MAX + 2) return;                  // every run the program resolves lies inside one walk limit
+    m.flat_ini = (uint32_t)a[5]; m.flat_ini_l = (uint32_t)a[6];
+    const bool anchored = m.flat_ini_l != 0xFFFFFFFFu && m.max_token_length > 1;
+    const uint32_t start = anchored ? m.flat_ini_l : m.flat_ini;
+    const std::vector<uint64_t> &T = m.wbd_t2;
+    std::vector<std::pair<uint64_t, uint32_t>> words;
+    auto step = [&](uint32_t state, uint32_t cls, uint32_t &next, bool &fin, uint32_t &tag) -> bool {
+        const size_t at = (size_t)state + cls;
+        if (at >= T.size()) return false;
+        const uint64_t e64 = T[at]; const uint32_t e = (uint32_t)e64;
+        if ((e & LX_T_CLS_MASK) != cls) return false;
+        fin = (int32_t)e < 0; tag = (uint32_t)(e64 >> 32); next = (e >> LX_T_NEXT_SHIFT) & LX_T_NEXT_MASK;
+        return true;
+    };
+    // runs: every word over the classes that have a code (a WK_LOOP class below 127), depth first
+    std::vector<uint32_t> codable;
+    for (int k = 0; k < m.wbd.nclasses && k < 127; ++k) if (m.wave_kind[(size_t)k] == 1 /* WK_LOOP */) codable.push_back((uint32_t)k);
+    struct Fr { uint32_t state; uint64_t key; int depth; };
+    std::vector<Fr> stack; stack.push_back({start, 0, 0});
+    while (!stack.empty()) {
+        const Fr f = stack.back(); stack.pop_back();
+        for (uint32_t k : codable) {
+            uint32_t nx = 0, tag = 0; bool fin = false;
+            if (!step(f.state, k, nx, fin, tag)) continue;
+            const uint64_t key = f.key | ((uint64_t)wf_code(k, 1u) << (7 * f.depth));
+            if (fin) {
+                if (!(tag & INFO_SIMPLE_BIT)) return;                 // cannot be (unit form: vocabulary tags are SIMPLE); no table then
+                words.push_back({key, tag & 0x7FFFFFFFu});
+            }
+            if (f.depth + 1 < WF_KEY_CHARS) stack.push_back({nx, key, f.depth + 1});
+            if (words.size() > (1u << 22)) return;
+        }
+    }
+    // one-element tokens: by class, and -- the ASCII ones -- by byte
+    for (int k = 0; k < m.wbd.nclasses; ++k) {
+        if (m.wave_kind[(size_t)k] != 3 /* WK_SOLO */) continue;
+        uint32_t nx = 0, tag = 0; bool fin = false;
+        if (step(start, (uint32_t)k, nx, fin, tag) && fin && (tag & INFO_SIMPLE_BIT)) words.push_back({WF_KEY_SOLO | WF_KEY_SOLO_CLS | (uint64_t)k, tag & 0x7FFFFFFFu});
+    }
+    for (int b = 0; b < 128; ++b) {
+        const uint32_t v = m.wbd_cpmap.get(b);
+        if (v & FUSED_MULTI) continue;
+        const uint32_t k = v & LX_T_CLS_MASK;
+        if (k >= (uint32_t)m.wbd.nclasses || m.wave_kind[k] != 3) continue;
+        uint32_t nx = 0, tag = 0; bool fin = false;
+        if (step(start, k, nx, fin, tag) && fin && (tag & INFO_SIMPLE_BIT)) words.push_back({WF_KEY_SOLO | (uint64_t)b, tag & 0x7FFFFFFFu});
+    }
+    // two-choice (cuckoo) placement at a load of at most 40 %; new multipliers when an insertion does not settle
+    int bits = 10; while ((size_t)1 << bits < words.size() * 5 / 2 + 16) ++bits;
+    uint64_t seed = 0x9E3779B97F4A7C15ull;
+    auto next_odd = [&]() { seed ^= seed << 13; seed ^= seed >> 7; seed ^= seed << 17; return (uint32_t)(seed >> 16) | 1u; };
+    for (int attempt = 0; attempt < 64; ++attempt) {
+        if (attempt == 32) ++bits;
+        const uint32_t m0 = next_odd(), m1 = next_odd(), m2 = next_odd();
+        std::vector<uint64_t> tab((size_t)2 << bits, 0);
+        bool ok = true;
+        for (size_t w = 0; w < words.size() && ok; ++w) {
+            uint64_t key = words[w].first; uint32_t id = words[w].second;
+            uint32_t x = wf_mix(key, m0), at = wf_h(x, m1, bits);
+            ok = false;
+            for (int kick = 0; kick < 512; ++kick) {
+                if (tab[2 * (size_t)at] == 0) { tab[2 * (size_t)at] = key; tab[2 * (size_t)at + 1] = id; ok = true; break; }
+                if (tab[2 * (size_t)at] == key) { ok = tab[2 * (size_t)at + 1] == id; break; }       // the same word twice (one-element tokens by class and by byte never share a key)
+                std::swap(key, tab[2 * (size_t)at]); uint64_t t = tab[2 * (size_t)at + 1]; tab[2 * (size_t)at + 1] = id; id = (uint32_t)t;
+                x = wf_mix(key, m0);
+                const uint32_t h1 = wf_h(x, m1, bits), h2 = wf_h(x, m2, bits);
+                at = at == h1 ? h2 : h1;
+            }
+        }
+        if (!ok) continue;
+        m.flat_tab.swap(tab); m.flat_bits = bits; m.flat_m0 = m0; m.flat_m1 = m1; m.flat_m2 = m2; m.flat_words = (int)words.size();
+        m.flat_ok = true;
+        return;
+    }
+}
+
 bool build_model(Model &m, const uint8_t *img, size_t size)
 {
     if (!img || size < 8) return fail(m, "empty model image");
@@ -858,6 +948,7 @@ bool build_model(Model &m, const uint8_t *img, size_t size)
                     m.wave_solo_info = best >= 0 ? freq[(size_t)best].first : 0;
                     for (int c = 0; c < m.wbd.nclasses; ++c) if (m.wave_kind[(size_t)c] == 3 && solo_inf(c) != m.wave_solo_info) m.wave_kind[(size_t)c] = 0;
                 }
+                if (m.wave_ok) build_flat_table(m);
             }
         }
     }

@@ -94,6 +94,7 @@ struct WpWaveParams {
     int32_t *counts;                 // [ndocs]
     int max_ids, unk;
     unsigned long long *next_doc;    // work counter
+    const int32_t *doc_list = nullptr; const unsigned int *list_n = nullptr;   // the LIST instance (the documents the flat program hands back, bf_flat.h): their numbers; else unused
     const int32_t *acts; int acts_n; // action records [left, right, tag, nfn, (fn, ini, ini_l)*] (<= WV_ACTS_MAX ints: staged in LDS)
     WpWaveCold cold;
 };

@@ -51,7 +51,8 @@ struct WvLds {
 // the trip before has just run), 2 = the chunk-wide pass writes its tokens with selects (a lane without a token left writes to a spare entry)
 // instead of an execution-mask branch per token, 4 = fill as nested loops (fill_nested) instead of the re-entered fill_step,
 // 8 = the retire pass waits once for the ids it loaded (wv::arrived) so that its stores leave back to back
-template <class LDS, int NU = 2, bool STATS = false, int DBG = 0, int STEPS = 3, int UMIN = 4, int CROOM = 0, bool OFFS = false, int TRIM = 0>
+// LIST: the documents are those of p.doc_list[0 .. *p.list_n) (the ones the flat program, bf_flat.h, hands back), taken one at a time
+template <class LDS, int NU = 2, bool STATS = false, int DBG = 0, int STEPS = 3, int UMIN = 4, int CROOM = 0, bool OFFS = false, int TRIM = 0, bool LIST = false>
 struct WpWave {
     static constexpr int RING = LDS::RING, QCAP = LDS::QCAP, DTN = LDS::DTN;
     static constexpr uint32_t RMASK = RING - 1, QMASK = QCAP - 1, DMASK = DTN - 1;
@@ -69,6 +70,7 @@ struct WpWave {
     uint32_t q_tail, q_issue, q_retire;   // tokens: queued / handed to a unit / retired (absolute counters; slot = counter & QMASK)
     uint32_t dt_head, dt_tail;       // document table entries in use (absolute counters)
     int64_t dbase; int di, dn;       // the range of documents this wave took from the work counter: [dbase, dbase + dn), di of them opened (offsets: S.doff[])
+    int64_t nd_all, list_doc;        // documents of the launch (LIST: *p.list_n); LIST: the document of list entry dbase
     int st_round, st_wave, st_waves; // without a work counter: range number st_wave + st_round * st_waves is this wave's next one
     bool have_doc, exiting;
     // current document
@@ -84,6 +86,7 @@ struct WpWave {
         unk = wv::own(p.unk); maxtok = wv::own(p.max_token_length);
         lane = wv::lane(); rhi = rlo = 0; u_need = 0xFFFFFFFFu; q_tail = q_issue = q_retire = 0; dt_head = dt_tail = 0;
         dbase = 0; di = dn = 0; st_round = st_wave = 0; st_waves = 1; have_doc = exiting = false;
+        nd_all = LIST ? (int64_t)*p.list_n : p.ndocs; list_doc = 0;
         s = nullptr; n = 0; rbase = 0; dec_bytes = dec = done = bom = 0; open_start = -1; curk = 0; err = false;
         st_trips = st_win = st_slow = st_tok = st_steps = st_ret = st_rewalk = st_idle = st_dec = st_gath = st_trans = 0;
         // the action of a run token and of a solo token (bf_model.cpp): the usual case is one calling WORD action for both
@@ -789,13 +792,14 @@ struct WpWave {
                     if (lane == 0) base = wv::atomic_add(p.next_doc, (unsigned long long)grab);
                     base = wv::bcast(base, 0);
                 } else { base = ((unsigned long long)st_wave + (unsigned long long)st_round * (unsigned long long)st_waves) * (unsigned long long)grab; ++st_round; }   // no work counter: ranges dealt out round-robin (small batches)
-                if ((int64_t)base >= p.ndocs) { exiting = true; return false; }
-                dbase = (int64_t)base; di = 0; dn = dbase + grab < p.ndocs ? grab : (int)(p.ndocs - dbase);
-                if (lane <= dn) S.doff[lane] = p.doc_off[dbase + lane];
+                if ((int64_t)base >= nd_all) { exiting = true; return false; }
+                dbase = (int64_t)base; di = 0; dn = dbase + grab < nd_all ? grab : (int)(nd_all - dbase);
+                if (LIST) { list_doc = (int64_t)p.doc_list[dbase]; if (lane <= 1) S.doff[lane] = p.doc_off[list_doc + lane]; }
+                else if (lane <= dn) S.doff[lane] = p.doc_off[dbase + lane];
                 wv::sync();
             }
             const int64_t b = S.doff[di], e = S.doff[di + 1];
-            have_doc = open_document(dbase + di, b, e);
+            have_doc = open_document(LIST ? list_doc : dbase + di, b, e);
             ++di;
             return true;
         }
@@ -838,14 +842,15 @@ struct WpWave {
                         if (lane == 0) base = wv::atomic_add(p.next_doc, (unsigned long long)grab);
                         base = wv::bcast(base, 0);
                     } else { base = ((unsigned long long)st_wave + (unsigned long long)st_round * (unsigned long long)st_waves) * (unsigned long long)grab; ++st_round; }
-                    if ((int64_t)base >= p.ndocs) { exiting = true; return filled; }
-                    dbase = (int64_t)base; di = 0; dn = dbase + grab < p.ndocs ? grab : (int)(p.ndocs - dbase);
-                    if (lane <= dn) S.doff[lane] = p.doc_off[dbase + lane];
+                    if ((int64_t)base >= nd_all) { exiting = true; return filled; }
+                    dbase = (int64_t)base; di = 0; dn = dbase + grab < nd_all ? grab : (int)(nd_all - dbase);
+                    if (LIST) { list_doc = (int64_t)p.doc_list[dbase]; if (lane <= 1) S.doff[lane] = p.doc_off[list_doc + lane]; }
+                    else if (lane <= dn) S.doff[lane] = p.doc_off[dbase + lane];
                     wv::sync();
                     filled = true;
                 }
                 const int64_t b = S.doff[di], e = S.doff[di + 1];
-                have_doc = open_document(dbase + di, b, e);
+                have_doc = open_document(LIST ? list_doc : dbase + di, b, e);
                 ++di;
                 filled = true;
                 if (!have_doc) continue;
@@ -882,7 +887,7 @@ struct WpWave {
     // wave_id / n_waves: this wave's number and the number of waves of the launch (used when the batch has no work counter)
     BF_WVD void run(int grab, int wave_id, int n_waves)
     {
-        grab = grab < 1 ? 1 : (grab > WV_GRAB_MAX ? WV_GRAB_MAX : grab);
+        grab = LIST ? 1 : grab < 1 ? 1 : (grab > WV_GRAB_MAX ? WV_GRAB_MAX : grab);
         st_wave = wave_id; st_waves = n_waves; st_round = 0;
         Unit u[NU];
 #pragma unroll

@@ -6,6 +6,7 @@
 #include "wave_emu.h"
 #include "../../blingfire_amd/csrc/bf_wave_body.h"
 #include "../../blingfire_amd/csrc/bf_bpe_wave_body.h"
+#include "../../blingfire_amd/csrc/bf_flat_body.h"
 #include "../../blingfire_amd/csrc/bf_bpe_seg_body.h"
 #include "hosttest.h"
 
@@ -281,5 +282,113 @@ long bft_emu_bpe_seg_batch(void *hv, const uint8_t *text, const int64_t *doc_off
     id_off[ndocs] = o;
     return o;
 }
+
+// TextToIdsBatch through the FLAT program (bf_flat.h) on the host: k_wp_pre restated (ranges, fitness of the batch), the flat wave program,
+// the list of documents it hands back, the wave program's LIST instance on those, k_wp_count / k_wp_merge (the device sources, in the
+// simulator) and the scan restated.  nranges <= 0: as many ranges as documents allow up to 4 per wave.  Returns the total id count or < 0;
+// stats (optional, 16 counters): [0] chunks [1] plain-ASCII chunks [2] tokens [3] table hits [4] words noted for a unit [5] drains
+// [6] unit rounds [7] documents handed back; [8] = documents on the list, [9] = 1 when the batch was not fit.
+long bft_emu_flat_batch(void *hv, const uint8_t *text, long text_bytes, const int64_t *doc_off, long ndocs, int max_ids, int unk, int nwaves, int nranges,
+                        int32_t *ids_out, long ids_cap, int64_t *id_off, unsigned long long *stats)
+{
+    Model &m = ((Handle *)hv)->m;
+    if (!m.error.empty() || m.kind != KIND_WP || !m.wave_ok || !m.flat_ok) return -1;
+    if (max_ids < 0) max_ids = 0;
+    const int64_t total = text_bytes;
+    // ---- k_wp_pre
+    int unsafe = 0;
+    for (long d = 0; d < ndocs; ++d) { const int64_t a = doc_off[d], b = doc_off[d + 1]; if (a < 0 || b < a || b > total || b - a > WF_DOC_MAX) unsafe = 1; }
+    if (nranges <= 0) nranges = nwaves * 4;
+    if (nranges > ndocs) nranges = (int)ndocs;
+    if (nranges < 1) nranges = 1;
+    std::vector<int64_t> range_doc((size_t)nranges + 1, 0);
+    if (!unsafe) {
+        const int64_t first = doc_off[0], span = doc_off[ndocs] - first;
+        for (int r = 0; r <= nranges; ++r) {
+            int64_t lo = 0, hi = ndocs;
+            if (r == 0) hi = 0; else if (r == nranges) lo = ndocs;
+            else { const int64_t target = first + (int64_t)((__int128)span * r / nranges); while (lo < hi) { const int64_t mid = lo + (hi - lo) / 2; if (doc_off[mid] >= target) hi = mid; else lo = mid + 1; } }
+            range_doc[(size_t)r] = lo;
+        }
+    }
+    std::vector<uint32_t> ent((size_t)total + 64, 0xDEADBEEFu);
+    std::vector<int32_t> home((size_t)total + 64, -77), entcnt((size_t)ndocs + 1, -55), dstat((size_t)ndocs + 1, 0), list((size_t)ndocs + 1, -1);
+    std::vector<int64_t> entoff((size_t)ndocs + 1, -1);
+    std::vector<int32_t> tmp((size_t)(total + 8 * ndocs + 64 + 8), -77), counts((size_t)ndocs + 1, -55);
+    unsigned long long next_range = 0, next_doc = 0; int status = 0;
+    WpWaveCold cold;
+    cold.cpmap = DevCpMap{m.wbd_cpmap.l1.data(), m.wbd_cpmap.pages.data()};
+    cold.kind = m.wave_kind.data(); cold.nclasses = m.wbd.nclasses; cold.status = &status; cold.stats = stats; cold.no_fast = 0;
+    WfParams fp;
+    fp.T = m.wbd_t2.data(); fp.W = m.flat_tab.data(); fp.wbits = m.flat_bits; fp.m0 = m.flat_m0; fp.m1 = m.flat_m1; fp.m2 = m.flat_m2;
+    fp.ini = m.flat_ini; fp.ini_l = m.flat_ini_l; fp.max_token_length = m.max_token_length; fp.unk = unk;
+    fp.text = text; fp.doc_off = doc_off; fp.ndocs = ndocs; fp.total_bytes = total;
+    fp.range_doc = range_doc.data(); fp.nranges = nranges; fp.next_range = &next_range; fp.unsafe = &unsafe;
+    fp.ent = ent.data(); fp.home = home.data(); fp.ent_off = entoff.data(); fp.ent_cnt = entcnt.data(); fp.dstat = dstat.data(); fp.cold = cold;
+    if (ndocs > 0) {
+        std::vector<uint32_t> lut(128);
+        for (int i = 0; i < 128; ++i) lut[(size_t)i] = wf_lut_value(cold, i);
+        std::vector<WfLds *> of_wave((size_t)nwaves);
+        for (int i = 0; i < nwaves; ++i) { of_wave[(size_t)i] = new WfLds(); memset((void *)of_wave[(size_t)i], 0xA5, sizeof(WfLds)); }
+        std::vector<const void *> wave_ids;
+        auto body = [&]() {
+            const void *wid = (const void *)wvemu::g_cur->wave;
+            size_t k = 0;
+            for (; k < wave_ids.size(); ++k) if (wave_ids[k] == wid) break;
+            if (k == wave_ids.size()) wave_ids.push_back(wid);
+            WfWave<true> w(fp, *of_wave[k], lut.data(), fp.cold);
+            w.run((int)k, nwaves);
+        };
+        wvemu::run_waves(nwaves, body);
+        for (auto *q : of_wave) delete q;
+    }
+    if (status) return -5;
+    // ---- k_wp_hardlist
+    unsigned int list_n = 0;
+    for (long d = 0; d < ndocs; ++d) if (unsafe || (dstat[(size_t)d] & WF_D_HARD)) list[list_n++] = (int32_t)d;
+    if (stats) { stats[8] = list_n; stats[9] = (unsigned long long)unsafe; }
+    // ---- the wave program on the listed documents
+    if (list_n > 0) {
+        WpWaveParams p;
+        p.T = m.wbd_t2.data(); p.acts = m.acts_pool.data(); p.acts_n = (int)m.acts_pool.size();
+        p.initial = m.wbd.initial_base; p.loop_info = m.loop_info; p.solo_info = m.wave_solo_info; p.max_token_length = m.max_token_length;
+        p.text = text; p.doc_off = doc_off; p.ndocs = ndocs; p.total_bytes = total;
+        p.ids_tmp = tmp.data(); p.counts = counts.data(); p.max_ids = max_ids; p.unk = unk; p.next_doc = &next_doc; p.span_tmp = nullptr;
+        p.doc_list = list.data(); p.list_n = &list_n;
+        p.cold = cold; p.cold.stats = nullptr;
+        typedef WvLds<1024, 256, 8> L;
+        std::vector<uint16_t> ascii(128);
+        for (int i = 0; i < 128; ++i) ascii[(size_t)i] = (uint16_t)wv_element(p.cold, i);
+        std::vector<L *> of_wave((size_t)nwaves);
+        for (int i = 0; i < nwaves; ++i) { of_wave[(size_t)i] = new L(); memset((void *)of_wave[(size_t)i], 0xA5, sizeof(L)); }
+        std::vector<const void *> wave_ids;
+        auto body = [&]() {
+            const void *wid = (const void *)wvemu::g_cur->wave;
+            size_t k = 0;
+            for (; k < wave_ids.size(); ++k) if (wave_ids[k] == wid) break;
+            if (k == wave_ids.size()) wave_ids.push_back(wid);
+            WpWave<L, 1, false, 0, 3, 4, 0, false, 15, true> w(p, p.cold, *of_wave[k], ascii.data(), p.acts);
+            w.run(1, (int)k, nwaves);
+        };
+        wvemu::run_waves(nwaves, body);
+        for (auto *q : of_wave) delete q;
+        if (status) return -5;
+    }
+    // ---- k_wp_count, scan, k_wp_merge
+    WfMergeParams mp;
+    mp.doc_off = doc_off; mp.ndocs = ndocs; mp.ent = ent.data(); mp.home = home.data(); mp.ent_off = entoff.data(); mp.ent_cnt = entcnt.data(); mp.dstat = dstat.data(); mp.unsafe = &unsafe;
+    mp.ids_tmp = tmp.data(); mp.counts = counts.data(); mp.id_off = id_off; mp.ids_out = ids_out; mp.ids_cap = ids_cap; mp.status = &status; mp.max_ids = max_ids; mp.unk = unk;
+    wvemu::run_waves(1, [&]() { for (int64_t base = 0; base < ndocs; base += 64) wf_count_docs(mp, base); });
+    long o = 0;
+    for (long d = 0; d < ndocs; ++d) { id_off[d] = o; if (counts[(size_t)d] < 0) return -6; o += counts[(size_t)d]; }
+    id_off[ndocs] = o;
+    bool over_any = false;
+    wvemu::run_waves(1, [&]() { bool over = false; for (int64_t base = 0; base < ndocs; base += 64) wf_merge_docs(mp, base, over); if (over) over_any = true; });
+    if (over_any) return -9;
+    return o;
+}
+
+int bft_flat_ok(void *hv) { return ((Handle *)hv)->m.flat_ok ? 1 : 0; }
+int bft_flat_words(void *hv) { return ((Handle *)hv)->m.flat_words; }
 
 } // extern "C"
