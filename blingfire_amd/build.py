@@ -48,7 +48,7 @@ def build_product(force=False):
         wbd = os.path.join(ROOT, "models", "wbd.bin")
         sbd = os.path.join(ROOT, "models", "sbd.bin")
         _run([hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
-              "-Wall", "-Wno-unused-result", "-fvisibility=hidden", "-Wl,--version-script=" + os.path.join(CSRC, "exports.map"), '-DBF_DEFAULT_WBD_PATH="%s"' % wbd, '-DBF_DEFAULT_SBD_PATH="%s"' % sbd, "-x", "hip"] + srcs + ["-o", PRODUCT])
+              "-Wall", "-Wno-unused-result", "-fvisibility=hidden"] + (["-DBF_EXPERIMENTS"] if os.environ.get("BF_EXPERIMENTS") else []) + [ "-Wl,--version-script=" + os.path.join(CSRC, "exports.map"), '-DBF_DEFAULT_WBD_PATH="%s"' % wbd, '-DBF_DEFAULT_SBD_PATH="%s"' % sbd, "-x", "hip"] + srcs + ["-o", PRODUCT])
     return PRODUCT
 
 

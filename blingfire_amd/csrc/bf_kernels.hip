@@ -858,18 +858,31 @@ void launch_wp_pre(const int64_t *doc_off, int64_t ndocs, int64_t total_bytes, i
     hipLaunchKernelGGL(k_wp_pre, dim3((unsigned)blocks), dim3(256), 0, s, doc_off, ndocs, total_bytes, nranges, range_doc, unsafe);
 }
 
-void launch_wp_flat(const WfParams &p, int variant, hipStream_t s)
+template <int WPE>
+static void launch_wp_flat_wpe(const WfParams &p, int per_cu_override, hipStream_t s)
 {
     static int pc = 0;
-    int per_cu = wp_blocks_per_cu(k_wp_flat<8, false>, pc);
-    const int per_cu_override = (variant >> 24) & 0x3f;
+    int per_cu = wp_blocks_per_cu(k_wp_flat<WPE, false>, pc);
     if (per_cu_override > 0) per_cu = per_cu_override;
     int64_t blocks = (int64_t)device_cus() * per_cu;
     const int64_t need = ((int64_t)p.nranges + 3) / 4;
     if (blocks > need) blocks = need;
     if (blocks < 1) blocks = 1;
-    if (p.cold.stats) hipLaunchKernelGGL((k_wp_flat<8, true>), dim3((unsigned)blocks), dim3(256), 0, s, p);
-    else hipLaunchKernelGGL((k_wp_flat<8, false>), dim3((unsigned)blocks), dim3(256), 0, s, p);
+    if (p.cold.stats) hipLaunchKernelGGL((k_wp_flat<WPE, true>), dim3((unsigned)blocks), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((k_wp_flat<WPE, false>), dim3((unsigned)blocks), dim3(256), 0, s, p);
+}
+
+// variant bits 16..19 (measurements): waves per SIMD the kernel is compiled for (0 = shipped), bits 24..29: workgroups per CU
+void launch_wp_flat(const WfParams &p, int variant, hipStream_t s)
+{
+    const int per_cu_override = (variant >> 24) & 0x3f, wpe = (variant >> 16) & 0xf;
+#ifdef BF_EXPERIMENTS
+    if (wpe == 7) { launch_wp_flat_wpe<7>(p, per_cu_override, s); return; }
+    if (wpe == 6) { launch_wp_flat_wpe<6>(p, per_cu_override, s); return; }
+    if (wpe == 5) { launch_wp_flat_wpe<5>(p, per_cu_override, s); return; }
+#endif
+    (void)wpe;
+    launch_wp_flat_wpe<8>(p, per_cu_override, s);
 }
 
 void launch_wp_hardlist(const int32_t *dstat, const int *unsafe, int64_t ndocs, int32_t *list, unsigned int *list_n, hipStream_t s)

@@ -485,19 +485,11 @@ static void build_flat_table(Model &m)
             if (words.size() > (1u << 22)) return;
         }
     }
-    // one-element tokens: by class, and -- the ASCII ones -- by byte
+    // one-element tokens: by class
     for (int k = 0; k < m.wbd.nclasses; ++k) {
         if (m.wave_kind[(size_t)k] != 3 /* WK_SOLO */) continue;
         uint32_t nx = 0, tag = 0; bool fin = false;
         if (step(start, (uint32_t)k, nx, fin, tag) && fin && (tag & INFO_SIMPLE_BIT)) words.push_back({WF_KEY_SOLO | WF_KEY_SOLO_CLS | (uint64_t)k, tag & 0x7FFFFFFFu});
-    }
-    for (int b = 0; b < 128; ++b) {
-        const uint32_t v = m.wbd_cpmap.get(b);
-        if (v & FUSED_MULTI) continue;
-        const uint32_t k = v & LX_T_CLS_MASK;
-        if (k >= (uint32_t)m.wbd.nclasses || m.wave_kind[k] != 3) continue;
-        uint32_t nx = 0, tag = 0; bool fin = false;
-        if (step(start, k, nx, fin, tag) && fin && (tag & INFO_SIMPLE_BIT)) words.push_back({WF_KEY_SOLO | (uint64_t)b, tag & 0x7FFFFFFFu});
     }
     // two-choice (cuckoo) placement at a load of at most 40 %; new multipliers when an insertion does not settle
     int bits = 10; while ((size_t)1 << bits < words.size() * 5 / 2 + 16) ++bits;

@@ -2,7 +2,7 @@
 (-Rpass-analysis=kernel-resource-usage, device side only, nothing is linked).  usage: python tools/kernel_resources.py [name filter]"""
 import os, re, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-src = os.path.join(ROOT, "blingfire_amd", "csrc", "bf_kernels.hip")
+src = os.path.join(ROOT, "blingfire_amd", "csrc", os.environ.get("BF_KSRC", "bf_kernels.hip"))
 r = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "--cuda-device-only", "-c",
                     "-Rpass-analysis=kernel-resource-usage", src, "-o", "/dev/null"], capture_output=True, text=True)
 flt = sys.argv[1] if len(sys.argv) > 1 else ""
