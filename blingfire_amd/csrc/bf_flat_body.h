@@ -9,9 +9,9 @@
 //   tokens    kinds as one bit per byte in 4-bit fields: run starts / ends from shifts, a document boundary is one more bit that cuts
 //             runs (FALexTools_t.h:229-393 on a unit-form lexer is a function of the kinds alone, bf_wave.h); every lane owns the tokens
 //             that END in its eight bytes; a prefix sum gives each its entry;
-//   keys      every lane cuts the keys of its tokens out of the packed codes of its bytes and the eight before them (a run of <= 9 plain
-//             characters: the key IS the word) and writes them, in token order, to a list in LDS;
-//   look-up   the list two tokens per lane: four 12-byte gathers in flight per lane, ids to the entries as whole rows;
+//   list      every lane writes where its tokens are, in token order, to a list in LDS;
+//   look-up   the list one token per lane and trip: the key of a run of <= 9 plain characters is made of its classes in the ring (the key IS
+//             the word), two 12-byte gathers per lane, ids to the entries as whole rows;
 //   units     the tokens the table did not answer wait as records (a plain-ASCII word: where its bytes are in the text; any other: its
 //             characters copied to an arena); 64 of them are walked at once (wf_drain: the frame of one call of the vocabulary function,
 //             bf_wave_body.h Unit restated without a queue), pieces to the word's home, the entry says how many.
@@ -21,29 +21,31 @@
 
 namespace bfa {
 
-constexpr int WF_TQ = 192;                // tokens of a chunk the list holds (three per lane); a chunk with more hands its documents on
+constexpr int WF_TQ = 512;                // tokens of a chunk, at most (every byte one)
+constexpr int WF_RING_DUP = 16;           // the first positions of the ring once more behind its end: a word of <= 16 bytes is read without a wrap
 constexpr uint64_t WF_KEY_NONE = 1ull << 62;     // "no key": matches no entry of the table (an entry's lowest field is never 0)
 constexpr uint32_t WF_REC_TEXT = 0x80000000u;    // record word 2: the word's characters are its bytes in the text (plain ASCII, <= 16 bytes); else arena base | characters << 16
+constexpr uint32_t WF_TQ_SOLO = 63;       // list entry: bytes == 63: a one-element token
 
 struct WfLds {
-    alignas(16) uint16_t ring[WF_RING];  // class of every byte position of this chunk and the one before (WF_CONT: no character starts there)
-    uint32_t tq_lo[WF_TQ], tq_hi[WF_TQ]; uint16_t tq_pos[WF_TQ];      // the chunk's tokens in order: key, (first byte - (chunk - 64)) | bytes << 10 (0 bytes: a run of more than WF_RUN_MAX; then its last byte)
+    alignas(16) uint16_t ring[WF_RING + WF_RING_DUP];   // class of every byte position of this chunk and the one before (WF_CONT: no character starts there)
+    uint16_t tq_pos[WF_TQ];              // the chunk's tokens in order: (first byte - (chunk - 64)) | bytes << 10; bytes == 0: a run of more than WF_RUN_MAX bytes, its LAST byte
     uint32_t rec[WF_REC * 3];            // a word that waits for a unit: entry (range-relative), first byte (range-relative), where its characters are
     uint16_t arena[WF_ARENA];            // characters of the waiting words that are not plain text
     int arena_n;                         // characters in the arena
     uint32_t spare32; uint16_t spare;
 };
 
-// the 128-entry table of the ASCII bytes: [12:0] class, [18:16] kind bits (loop, solo, general), [26:20] key code
+// the 128-entry table of the ASCII bytes: [12:0] class, [18:16] kind bits (loop, solo, general)
 BF_WV uint32_t wf_lut_value(const WpWaveCold &p, int b)
 {
     const uint32_t el = wv_element(p, b), c = el & LX_T_CLS_MASK, k = el >> WK_SHIFT;
     const uint32_t nib = k == WK_LOOP ? 1u : k == WK_SOLO ? 2u : k == WK_GENERAL ? 4u : 0u;
-    return c | (nib << 16) | (wf_code(c, k) << 20);
+    return c | (nib << 16);
 }
 
 #if defined(__HIPCC__)
-#define BF_WF_NOINLINE __device__ __noinline__
+#define BF_WF_NOINLINE __device__ __forceinline__
 #else
 #define BF_WF_NOINLINE static __attribute__((noinline))
 #endif
@@ -72,21 +74,28 @@ BF_WF_NOINLINE void wf_drain(const uint64_t *T, uint32_t ini, uint32_t ini_l, in
     uint32_t state = anchored0 ? ini_l : ini; int j = 0, fp = -1, cnt = 0; uint32_t ftag = 0; int32_t id0 = 0;
     bool anch = anchored0, act = have, missed = false;
     int32_t *hm = home + p_rel;
+    // class of character i of the word (i < L).  The class of the NEXT character is fetched while the transition on this one is in flight: it
+    // does not depend on it (a miss or the end of a walk re-reads at the walk's new start)
+    auto cls_at = [&](int i) -> uint32_t {
+        const uint32_t tb = (uint32_t)((i < 8 ? t_lo : t_hi) >> (8 * (i & 7))) & 0x7Fu;
+        const uint16_t *src = is_text ? (const uint16_t *)(lut + tb) : &S.arena[(act && i < L) ? abase + (uint32_t)i : 0u];
+        return (uint32_t)*src & LX_T_CLS_MASK;
+    };
+    uint32_t c_cur = cls_at(0);
     while (wv::any(act)) {
         if (STATS) ++*rounds;
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             const bool walking = act && !missed && j < L;
-            const uint32_t tb = (uint32_t)((j < 8 ? t_lo : t_hi) >> (8 * (j & 7))) & 0x7Fu;
-            const uint16_t *src = is_text ? (const uint16_t *)(lut + tb) : &S.arena[walking ? abase + (uint32_t)j : 0u];
-            const uint32_t c = (uint32_t)*src & LX_T_CLS_MASK;
-            const uint64_t e64 = T[walking ? state + c : 0u];
+            const uint64_t e64 = T[walking ? state + c_cur : 0u];
+            const uint32_t c_nxt = cls_at(j + 1);
             const uint32_t e = (uint32_t)e64;
-            const bool hit = walking && (e & LX_T_CLS_MASK) == c;
+            const bool hit = walking && (e & LX_T_CLS_MASK) == c_cur;
             const bool fin = hit && (int32_t)e < 0;
             fp = fin ? j : fp; ftag = fin ? (uint32_t)(e64 >> 32) : ftag;
             state = hit ? ((e >> LX_T_NEXT_SHIFT) & LX_T_NEXT_MASK) : state;
             j = hit ? j + 1 : j;
+            c_cur = hit ? c_nxt : c_cur;
             missed = missed || (walking && !hit);
         }
         const bool ev = act && (missed || j >= L);
@@ -106,6 +115,7 @@ BF_WF_NOINLINE void wf_drain(const uint64_t *T, uint32_t ini, uint32_t ini_l, in
                 } else if (anch) { state = ini; j = 0; fp = -1; anch = false; missed = false; }
                 else { ent[e_rel] = WF_ENT_FLAG; act = false; }            // a gap: UnkId
             }
+            c_cur = cls_at(j);
         }
     }
     wv::sync();
@@ -218,7 +228,7 @@ BF_WVD WfMb wf_decode_multibyte(uint64_t own, uint32_t S8, uint32_t peek, int c,
                 const uint32_t e2 = wv_element(cold, cp), kd = e2 >> WK_SHIFT;
                 el = e2 & LX_T_CLS_MASK; nib = kd == WK_LOOP ? 1u : kd == WK_SOLO ? 2u : kd == WK_GENERAL ? 4u : 0u;
             }
-            ring[((uint32_t)lane0 + (uint32_t)i) & RMASK] = (uint16_t)el;
+            { const uint32_t rp = ((uint32_t)lane0 + (uint32_t)i) & RMASK; ring[rp] = (uint16_t)el; if (rp < (uint32_t)WF_RING_DUP) ring[rp + WF_RING] = (uint16_t)el; }
             acc |= nib << (4 * i);
             if (nib & 1u) lsp |= cb;                                                       // the continuation bytes of a run member are run members
             if (er) errm |= 1u << i;
@@ -261,7 +271,7 @@ struct WfWave {
     int k, kdoc;                         // tokens so far; tokens before the open document
     int open_start;                      // first byte of the run that reaches the end of the chunk before (-1: none)
     unsigned long long na_prev;          // the lanes of the chunk before that hold a byte >= 0x80
-    uint64_t pcc63; uint32_t cov_carry, loop_carry;      // of lane 63 of the chunk before: packed codes; bytes of the next chunk that belong to its last character
+    uint32_t cov_carry, loop_carry;      // of lane 63 of the chunk before: bytes of the next chunk that belong to its last character
     int nrec;                            // words that wait for a unit
     int bad_lo, bad_hi, hard_lo, hard_hi; // [lo, hi): bytes of the document that got the flag last (one look-up per document, mostly)
     unsigned long long st_chunks, st_ascii, st_tok, st_hit, st_notes, st_drains, st_rounds, st_hard;
@@ -270,7 +280,7 @@ struct WfWave {
     {
         lane = wv::lane(); nrec = 0; if (lane == 0) S.arena_n = 0; wv::sync(); bad_lo = bad_hi = hard_lo = hard_hi = 0;
         st_chunks = st_ascii = st_tok = st_hit = st_notes = st_drains = st_rounds = st_hard = 0;
-        dlo = 0; dn = dnext = wlo = 0; b0 = 0; len = 0; win = 0; txt = nullptr; ent = nullptr; home = nullptr; k = kdoc = 0; open_start = -1; pcc63 = 0; cov_carry = loop_carry = 0; na_prev = 0;
+        dlo = 0; dn = dnext = wlo = 0; b0 = 0; len = 0; win = 0; txt = nullptr; ent = nullptr; home = nullptr; k = kdoc = 0; open_start = -1; cov_carry = loop_carry = 0; na_prev = 0;
     }
 
     // first byte of document dlo + d (0 <= d <= dn), range-relative; d is wave-uniform
@@ -349,7 +359,7 @@ struct WfWave {
             ++dnext;
         }
         // ---- decode
-        uint32_t acc = 0, cclo = 0, cchi = 0;
+        uint32_t acc = 0;
         unsigned long long na = 0;
         const bool ascii_chunk = !wv::any((own & 0x8080808080808080ull) != 0);
         {
@@ -360,12 +370,13 @@ struct WfWave {
                 v[i] = lut[b & 0x7Fu];
                 if (!ascii_chunk) v[i] = b < 0x80u ? v[i] : WF_CONT;
             }
-            uint32_t *row = (uint32_t *)(S.ring + ((uint32_t)lane0 & RMASK));        // 8 positions = one 16-byte row, never wraps
-            row[0] = (v[0] & 0xFFFFu) | (v[1] << 16); row[1] = (v[2] & 0xFFFFu) | (v[3] << 16); row[2] = (v[4] & 0xFFFFu) | (v[5] << 16); row[3] = (v[6] & 0xFFFFu) | (v[7] << 16);
+            const uint32_t rp = (uint32_t)lane0 & RMASK;
+            uint32_t *row = (uint32_t *)(S.ring + rp);                          // 8 positions = one 16-byte row, never wraps
+            const uint32_t r0 = (v[0] & 0xFFFFu) | (v[1] << 16), r1 = (v[2] & 0xFFFFu) | (v[3] << 16), r2 = (v[4] & 0xFFFFu) | (v[5] << 16), r3 = (v[6] & 0xFFFFu) | (v[7] << 16);
+            row[0] = r0; row[1] = r1; row[2] = r2; row[3] = r3;
+            if (rp < (uint32_t)WF_RING_DUP) { uint32_t *dup = (uint32_t *)(S.ring + rp + WF_RING); dup[0] = r0; dup[1] = r1; dup[2] = r2; dup[3] = r3; }
 #pragma unroll
             for (int i = 0; i < 8; ++i) acc |= ((v[i] >> 16) & 7u) << (4 * i);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) { cclo |= ((v[i] >> 20) & 0x7Fu) << (7 * i); cchi |= ((v[i + 4] >> 20) & 0x7Fu) << (7 * i); }
         }
         if (ascii_chunk) { if (STATS) ++st_ascii; cov_carry = 0; loop_carry = 0; }
         else {
@@ -377,11 +388,6 @@ struct WfWave {
             if (wv::any(r.errm != 0)) mark_bytes(c, r.errm, WF_D_BAD);          // invalid UTF-8: the document has no ids (tokdll:1151-1153)
         }
         wv::sync();                                                             // the ring is written
-        const uint64_t cc = (uint64_t)cclo | ((uint64_t)cchi << 28);
-        uint64_t pcc = (uint64_t)wv::shfl_up((unsigned long long)cc, 1);
-        if (lane == 0) pcc = pcc63;
-        pcc63 = (uint64_t)wv::bcast((unsigned long long)cc, 63);
-
         // ---- tokens: every lane owns the runs that END in its bytes and its one-element tokens
         const uint32_t Lm = acc & 0x11111111u & vm4, SO = (acc >> 1) & 0x11111111u & vm4;
         {
@@ -409,8 +415,7 @@ struct WfWave {
         const int ntok = wv::bcast(inc, 63) + coff;
         const int excl = inc - cnt;
         if (STATS) st_tok += (unsigned long long)ntok;
-        const bool over = ntok > WF_TQ;                                          // more tokens than the list holds: every document of the chunk is handed on
-        // (1) every lane writes the keys of ITS tokens to the list, in order (no memory but LDS)
+        // (1) every lane writes where ITS tokens are to the list, in order
         {
             // this lane's tokens as bits 4 i + 1 (the token that ends at byte i); bit 0 of lane 0: the run that ended with the chunk before
             uint32_t tk = (tk0 << 1) | ((carry_end && lane == 0) ? 1u : 0u);
@@ -427,39 +432,10 @@ struct WfWave {
                 const int hs = hm4 ? lane0 + ((31 - __builtin_clz(hm4 | 1u)) >> 2) : hprev;
                 const int start = cr ? open_start : (is_end ? hs : bpos);
                 const int blen = bpos - start + 1;
-                // the key: a run of <= 9 bytes that starts in this lane's bytes or the eight before them (a byte that is not an ASCII run
-                // member has code 0: a key with a zero field matches no entry, only a zero at the TOP would look like a shorter word)
-                const int rel = start - (lane0 - 8);
-                const bool inown = rel >= 8;
-                const uint64_t src = inown ? cc : pcc;
-                const int sha = 7 * (inown ? rel - 8 : (rel < 0 ? 0 : rel));
-                uint64_t key = src >> sha;
-                if (!inown) key |= cc << (56 - sha);
-                const int kl = blen > WF_KEY_CHARS ? WF_KEY_CHARS : (blen < 1 ? 1 : blen);
-                key &= (1ull << (7 * kl)) - 1ull;
-                // (a field of the key is 0 where the byte is no plain run member: the classic zero-field test, 7-bit fields; it may also flag the
-                // field above a zero one -- no harm: such a run takes the way of the runs without a key)
-                const uint64_t km = (1ull << (7 * kl)) - 1ull;
-                const bool haszero = (((key | ~km) - 0x0102040810204081ull) & ~key & 0x4081020408102040ull & km) != 0ull;
-                const bool fast = blen <= WF_KEY_CHARS && rel >= 0 && !haszero;
-                if (!fast) {
-                    // no key.  Is the run plain ASCII all the same (then a unit can read it from the text)?  No lane it touches holds a byte >= 0x80
-                    bool plain = true;
-                    if (na | na_prev) {
-                        const int ls = (start - (c - WF_CHUNK)) >> 3, le = (bpos - (c - WF_CHUNK)) >> 3;       // lanes counted from the chunk before (a run is <= 48 bytes)
-                        const unsigned long long wlo_ = ls < 64 ? ((na_prev >> (ls & 63)) | ((ls & 63) ? na << (64 - (ls & 63)) : 0ull)) : (na >> ((ls - 64) & 63));
-                        plain = ls >= 0 && (wlo_ & ((2ull << ((le - ls) & 63)) - 1ull)) == 0ull;
-                    }
-                    key = WF_KEY_NONE | (plain ? 1ull : 0ull);
-                }
-                if (!is_end) key = WF_KEY_SOLO | WF_KEY_SOLO_CLS | (uint64_t)(S.ring[(uint32_t)bpos & RMASK] & LX_T_CLS_MASK);     // a one-element token: by class
-                const bool put = on && (uint32_t)slot < (uint32_t)WF_TQ;
-                uint32_t *d0 = put ? &S.tq_lo[slot] : &S.spare32;
-                *d0 = (uint32_t)key;
-                uint32_t *d1 = put ? &S.tq_hi[slot] : &S.spare32;
-                *d1 = (uint32_t)(key >> 32);
-                uint16_t *d2 = put ? &S.tq_pos[slot] : &S.spare;
-                *d2 = (uint16_t)(blen > WF_RUN_MAX ? (uint32_t)(bpos - (c - 64)) : ((uint32_t)(start - (c - 64)) | ((uint32_t)blen << 10)));      // (a run that long may begin anywhere: its LAST byte is kept)
+                const uint32_t pw = !is_end ? ((uint32_t)(bpos - (c - 64)) | (WF_TQ_SOLO << 10))
+                                  : blen > WF_RUN_MAX ? (uint32_t)(bpos - (c - 64)) : ((uint32_t)(start - (c - 64)) | ((uint32_t)blen << 10));
+                uint16_t *d2 = on ? &S.tq_pos[slot] : &S.spare;
+                *d2 = (uint16_t)pw;
                 slot += on ? (cr ? coff : 1) : 0;
             }
         }
@@ -470,16 +446,45 @@ struct WfWave {
             const int kd = k + coff + wv::bcast(excl, sl) + __builtin_popcount(t_sl & ((1u << (4 * (r & 7))) - 1u));
             emit_boundary(d, kd);
         }
-        if (over) { mark(c > 0 ? c - 1 : 0, WF_D_HARD); for (int d = dfirst; d < dnext; ++d) { const int o = off_rel(d); if (o < len) mark(o, WF_D_HARD); } }
         wv::sync();
-        // (2) the list is looked up, one token per lane and trip: two 12-byte gathers per lane in flight, the ids go to their entries as whole rows
-        const int nlist = over ? 0 : ntok;
+        // (2) the list, one token per lane and trip.  The key of a run of <= 9 characters is made of its classes in the ring (class + 1 in 7 bits; a
+        // class without a code -- >= 127, or no character: a continuation byte -- and the run has no key): the key IS the word.  Two 12-byte
+        // gathers per lane in flight; the ids go to their entries as whole rows.
         uint32_t *eout = ent + k;
-        const bool last = at_end;
-        for (int t0 = 0; t0 < nlist || (t0 == 0 && last); t0 += 64) {
-            const bool have = t0 + lane < nlist;
-            const uint64_t key = have ? ((uint64_t)S.tq_lo[t0 + lane] | ((uint64_t)S.tq_hi[t0 + lane] << 32)) : WF_KEY_NONE;
+        for (int t0 = 0; t0 < ntok || (t0 == 0 && at_end); t0 += 64) {
+            const bool have = t0 + lane < ntok;
             const uint32_t ps = have ? (uint32_t)S.tq_pos[t0 + lane] : 0u;
+            const uint32_t b6 = ps >> 10;
+            const bool solo = b6 == WF_TQ_SOLO;
+            const int blen = solo ? 1 : (int)b6;                                 // (0: a run of more than WF_RUN_MAX bytes; its document is handed on)
+            const int s0 = c - 64 + (int)(ps & 0x3FFu);
+            const uint16_t *rw = S.ring + ((uint32_t)s0 & RMASK);                // (the duplicate rows: no wrap within 16 positions)
+            uint32_t klo = 0, khi = 0, k8 = 0, minc = 127;
+            const int kn = (have && !solo && blen <= WF_KEY_CHARS) ? blen : 0;
+#pragma unroll
+            for (int i = 0; i < WF_KEY_CHARS; ++i) {
+                const uint32_t cl = (uint32_t)rw[i] & LX_T_CLS_MASK;
+                uint32_t code = cl < 127u ? cl + 1u : 0u;
+                const bool in = i < kn;
+                minc = in ? (code < minc ? code : minc) : minc;
+                code = in ? code : 0u;
+                if (i < 4) klo |= code << (7 * i); else if (i < 8) khi |= code << (7 * (i - 4)); else k8 = code;
+            }
+            uint64_t key = (uint64_t)klo | ((uint64_t)khi << 28) | ((uint64_t)k8 << 56);
+            bool plain = kn > 0 && minc != 0;                                    // a run with a key is plain ASCII (a unit can read it from the text)
+            if (kn == 0 || minc == 0) {
+                key = WF_KEY_NONE;
+                if (solo) key = WF_KEY_SOLO | WF_KEY_SOLO_CLS | (uint64_t)(rw[0] & LX_T_CLS_MASK);      // a one-element token: by class
+                else if (kn == 0 && blen > 0) {
+                    // a longer run: plain when no lane it touches holds a byte >= 0x80 (lanes counted from the chunk before; a run is <= 48 bytes)
+                    plain = true;
+                    if (na | na_prev) {
+                        const int ls = (s0 - (c - WF_CHUNK)) >> 3, le = (s0 + blen - 1 - (c - WF_CHUNK)) >> 3;
+                        const unsigned long long wlo_ = ls < 64 ? ((na_prev >> (ls & 63)) | ((ls & 63) ? na << (64 - (ls & 63)) : 0ull)) : (na >> ((ls - 64) & 63));
+                        plain = ls >= 0 && (wlo_ & ((2ull << ((le - ls) & 63)) - 1ull)) == 0ull;
+                    }
+                }
+            }
             const uint32_t x = wf_mix(key, p.m0);
             const uint32_t *ea = (const uint32_t *)p.W + 4u * wf_h(x, p.m1, p.wbits), *eb = (const uint32_t *)p.W + 4u * wf_h(x, p.m2, p.wbits);
             const uint32_t al = ea[0], ah = ea[1], ai = ea[2], bl_ = eb[0], bh = eb[1], bi = eb[2];
@@ -488,15 +493,12 @@ struct WfWave {
             if (hit) eout[t0 + lane] = hita ? ai : bi;
             if (STATS) st_hit += (unsigned long long)__builtin_popcountll(wv::ballot(hit));
             const bool rest = have && !hit;
-            const int blen = (int)(ps >> 10);
             const unsigned long long RB = wv::ballot(rest), TL = wv::ballot(rest && blen == 0);
-            const bool fin = last && t0 + 64 >= nlist;
+            const bool fin = at_end && t0 + 64 >= ntok;
             if (RB) {
                 // a run of more than WF_RUN_MAX bytes: its document is handed on
                 for (unsigned long long tl = TL; tl;) { const int l = __builtin_ctzll(tl); tl &= tl - 1ull; mark(c - 64 + (int)(wv::bcast(ps, l) & 0x3FFu), WF_D_HARD); }
-                const int s0 = c - 64 + (int)(ps & 0x3FFu);
-                // a run with a key is plain ASCII; one without says so (bit 0); a one-element token the table does not hold takes the general way
-                const bool text_ok = !(key >> 63) && key != WF_KEY_NONE && blen <= 16 && s0 + 16 <= len;
+                const bool text_ok = plain && blen <= 16 && s0 + 16 <= len;
                 const bool word = rest && blen != 0;
                 const unsigned long long WB = wv::ballot(word), XB = wv::ballot(word && !text_ok);
                 const int nw = __builtin_popcountll(WB);
@@ -520,7 +522,7 @@ struct WfWave {
         dn = (int)(dhi - dlo);
         b0 = p.doc_off[dlo]; len = (int)(p.doc_off[dhi] - b0);
         txt = p.text + b0; ent = p.ent + b0; home = p.home + b0;
-        k = kdoc = 0; dnext = 0; open_start = -1; pcc63 = 0; cov_carry = loop_carry = 0; na_prev = 0; bad_lo = bad_hi = hard_lo = hard_hi = 0;
+        k = kdoc = 0; dnext = 0; open_start = -1; cov_carry = loop_carry = 0; na_prev = 0; bad_lo = bad_hi = hard_lo = hard_hi = 0;
         load_window(0);
         uint64_t own = load_chunk(0);
         for (int c = 0; c < len; c += WF_CHUNK) {
@@ -557,27 +559,59 @@ struct WfWave {
 BF_WVD int wf_entry_ids(uint32_t e) { const int n = (int)((e & ~WF_ENT_FLAG) >> WF_ENT_CNT_SHIFT); return (e & WF_ENT_FLAG) ? (n ? n : 1) : 1; }
 
 // counts[d] = ids of document d (tokdll:1308-1310: at most max_ids; 0 for invalid UTF-8: :1151-1153)
+// The usual block -- 64 documents of one range, none flagged: their entries are ONE contiguous run -- is streamed 256 entries per trip; an entry
+// of more than one id (2 % of them) adds to the document that holds it (which one: a count over the lanes' first entries).
 BF_WVD void wf_count_docs(const WfMergeParams &p, int64_t base)
 {
     const int lane = wv::lane();
     const int64_t d = base + lane;
     const bool unsafe = *p.unsafe != 0;
+    const int nd = p.ndocs - base < 64 ? (int)(p.ndocs - base) : 64;
     int ec = 0, st = 0, old = 0; int64_t eo = 0;
     if (d < p.ndocs) { st = unsafe ? WF_D_HARD : p.dstat[d]; old = p.counts[d]; if (!(st & WF_D_HARD)) { eo = p.ent_off[d]; ec = p.ent_cnt[d]; } }
-    if (st & (WF_D_BAD | WF_D_HARD)) ec = 0;
     int extra = 0;
-    const int nd = p.ndocs - base < 64 ? (int)(p.ndocs - base) : 64;
-    for (int i = 0; i < nd; ++i) {
-        const int n = wv::bcast(ec, i);
-        if (n == 0) continue;
-        const int64_t o = wv::bcast(eo, i);
-        int sum = 0;
-        for (int t = 0; t < n; t += 64) {
-            const uint32_t e = t + lane < n ? p.ent[o + t + lane] : 0u;
-            const int x = wf_entry_ids(e) - 1;
-            if (wv::any(x != 0)) sum += wv::bcast(wv::incl_scan(x), 63);
+    const int64_t eo_n = wv::shfl_down(eo, 1);
+    if (!wv::any(lane < nd && st != 0)) {
+      // (what limits a streaming kernel here is the number of vector-memory instructions a CU can issue: four consecutive entries per lane and load)
+      // the block's entries are contiguous but where a range of the flat program ends: one run per piece
+      unsigned long long brk = wv::ballot(lane < nd && (lane + 1 == nd || eo_n != eo + ec));      // the lanes that end a piece
+      for (int first = 0; brk;) {
+        const int lastl = __builtin_ctzll(brk); brk &= brk - 1ull;
+        const int64_t E0 = wv::bcast(eo, first), E1 = wv::bcast(eo + (int64_t)ec, lastl);
+        first = lastl + 1;
+        for (int64_t t = E0; t < E1; t += 256) {
+            const int64_t a = t + 4 * lane;
+            uint32_t e[4] = {0u, 0u, 0u, 0u};
+            if (a + 4 <= E1) __builtin_memcpy(e, p.ent + a, 16);
+            else for (int u = 0; u < 4; ++u) if (a + u < E1) e[u] = p.ent[a + u];
+            if (!wv::any(((e[0] | e[1] | e[2] | e[3]) & WF_ENT_FLAG) != 0u)) continue;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int x = wf_entry_ids(e[u]) - 1;
+                for (unsigned long long fb = wv::ballot(x != 0); fb;) {
+                    const int l = __builtin_ctzll(fb); fb &= fb - 1ull;
+                    const int64_t at = t + 4 * l + u;
+                    const int doc = __builtin_popcountll(wv::ballot(lane < nd && eo <= at)) - 1;      // the last document whose first entry is <= at
+                    const int xv = wv::bcast(x, l);
+                    if (lane == doc) extra += xv;
+                }
+            }
         }
-        if (lane == i) extra = sum;
+      }
+    } else {
+        if (st & (WF_D_BAD | WF_D_HARD)) ec = 0;
+        for (int i = 0; i < nd; ++i) {
+            const int n = wv::bcast(ec, i);
+            if (n == 0) continue;
+            const int64_t o = wv::bcast(eo, i);
+            int sum = 0;
+            for (int t = 0; t < n; t += 64) {
+                const uint32_t e = t + lane < n ? p.ent[o + t + lane] : 0u;
+                const int x = wf_entry_ids(e) - 1;
+                if (wv::any(x != 0)) sum += wv::bcast(wv::incl_scan(x), 63);
+            }
+            if (lane == i) extra = sum;
+        }
     }
     if (d < p.ndocs) {
         int cnt = (st & WF_D_HARD) ? old : (st & WF_D_BAD) ? 0 : ec + extra;
@@ -586,19 +620,116 @@ BF_WVD void wf_count_docs(const WfMergeParams &p, int64_t base)
     }
 }
 
+// One entry vector of a document (or of a block of documents whose ids follow one another): ids to out[run ...); returns the ids it held
+BF_WVD int wf_merge_vec(const WfMergeParams &p, uint32_t e, bool have, int64_t eidx, int32_t *out, int run, int cap)
+{
+    const int x = have ? wf_entry_ids(e) : 0;
+    const int inc = wv::incl_scan(x), pos = run + inc - x;
+    const bool flag = have && (e & WF_ENT_FLAG) != 0u;
+    const int nn = flag ? (int)((e & ~WF_ENT_FLAG) >> WF_ENT_CNT_SHIFT) : 0;
+    // the ids of a word of several pieces come from its home: the first four in one go (one trip to memory for the whole vector)
+    const int32_t *hm = p.home + eidx + (int64_t)(e & WF_ENT_DELTA_MASK);
+    int32_t v0 = flag ? p.unk : (int32_t)e, v1 = 0, v2 = 0, v3 = 0;
+    if (nn > 0) v0 = hm[0];
+    if (nn > 1) v1 = hm[1];
+    if (nn > 2) v2 = hm[2];
+    if (nn > 3) v3 = hm[3];
+    if (have && pos < cap) out[pos] = v0;
+    if (nn > 1 && pos + 1 < cap) out[pos + 1] = v1;
+    if (nn > 2 && pos + 2 < cap) out[pos + 2] = v2;
+    if (nn > 3 && pos + 3 < cap) out[pos + 3] = v3;
+    if (wv::any(nn > 4)) for (int j = 4; j < nn && pos + j < cap; ++j) out[pos + j] = hm[j];
+    return wv::bcast(inc, 63);
+}
+
 BF_WVD void wf_merge_docs(const WfMergeParams &p, int64_t base, bool &over)
 {
     const int lane = wv::lane();
     const int64_t d = base + lane;
     const bool unsafe = *p.unsafe != 0;
+    const int nd = p.ndocs - base < 64 ? (int)(p.ndocs - base) : 64;
     int ec = 0, st = 0, cnt = 0; int64_t eo = 0, o = 0;
+    bool capped = false;
     if (d < p.ndocs) {
         st = unsafe ? WF_D_HARD : p.dstat[d]; cnt = p.counts[d]; o = p.id_off[d];
         if (st & WF_D_HARD) { eo = wv_ids_slot(p.doc_off[d], d); ec = cnt; } else { eo = p.ent_off[d]; ec = p.ent_cnt[d]; }
+        capped = cnt >= p.max_ids || o + cnt > p.ids_cap;
         if (o + cnt > p.ids_cap) { over = true; cnt = o < p.ids_cap ? (int)(p.ids_cap - o) : 0; }
-        if (cnt == 0) ec = 0;
     }
-    const int nd = p.ndocs - base < 64 ? (int)(p.ndocs - base) : 64;
+    // the usual block: no document flagged or cut, the entries of all 64 one contiguous run -- then so are their ids (id_off is the running sum
+    // of the counts): the run is streamed 256 entries per trip without a look at the documents
+    const int64_t eo_n = wv::shfl_down(eo, 1);
+    if (!wv::any(lane < nd && (st != 0 || capped))) {
+      unsigned long long brk = wv::ballot(lane < nd && (lane + 1 == nd || eo_n != eo + ec));      // the lanes that end a contiguous piece (a range of the flat program ends there)
+      for (int first = 0; brk;) {
+        const int lastl = __builtin_ctzll(brk); brk &= brk - 1ull;
+        const int64_t E0 = wv::bcast(eo, first), E1 = wv::bcast(eo + (int64_t)ec, lastl);
+        int32_t *out = p.ids_out + wv::bcast(o, first);
+        first = lastl + 1;
+        int run = 0;
+        for (int64_t t = E0; t < E1; t += 256) {
+            // four consecutive entries per lane: one load; a lane whose four are plain ids stores them in one go (the usual lane); a lane
+            // that holds a word of several pieces (or UnkId) writes its ids one after the other
+            const int64_t a = t + 4 * lane;
+            uint32_t e[4] = {0u, 0u, 0u, 0u};
+            const int nin = a + 4 <= E1 ? 4 : (a < E1 ? (int)(E1 - a) : 0);
+            if (nin == 4) __builtin_memcpy(e, p.ent + a, 16);
+            else for (int u = 0; u < 4; ++u) if (u < nin) e[u] = p.ent[a + u];
+            bool flagged = ((e[0] | e[1] | e[2] | e[3]) & WF_ENT_FLAG) != 0u;
+            if (p.dbg == 3) flagged = false;
+            int xs = 0;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) xs += u < nin ? wf_entry_ids(e[u]) : 0;
+            int base_pos = run + 4 * lane;
+            if (wv::any(flagged)) { const int inc = wv::incl_scan(xs); base_pos = run + inc - xs; run += wv::bcast(inc, 63); }
+            else run += E1 - t < 256 ? (int)(E1 - t) : 256;
+            if (p.dbg == 2) continue;
+            if (!flagged) {
+                if (nin == 4) __builtin_memcpy(out + base_pos, e, 16);
+                else for (int u = 0; u < 4; ++u) if (u < nin) out[base_pos + u] = (int32_t)e[u];
+            } else {
+                // this lane's ids that are in its entries themselves (plain ids, UnkId), each at its place
+                int pos = base_pos;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const uint32_t eu = e[u];
+                    const int nn = (eu & WF_ENT_FLAG) ? (int)((eu & ~WF_ENT_FLAG) >> WF_ENT_CNT_SHIFT) : -1;       // -1: a plain id, 0: UnkId
+                    if (u < nin && nn <= 0) out[pos] = nn < 0 ? (int32_t)eu : p.unk;
+                    pos += u < nin ? (nn > 0 ? nn : 1) : 0;
+                }
+            }
+            // the words of several pieces: the whole wave copies each from its home (<= 48 ids: one load, one store), four words' loads in flight
+            if (wv::any(flagged) && p.dbg != 1) {
+                int qn = 0; int qp[4], qc[4]; const int32_t *qh[4];
+                int pos = base_pos;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const uint32_t eu = e[u];
+                    const int nn = (u < nin && (eu & WF_ENT_FLAG)) ? (int)((eu & ~WF_ENT_FLAG) >> WF_ENT_CNT_SHIFT) : 0;
+                    for (unsigned long long mb = wv::ballot(nn > 0); mb || (u == 3 && qn);) {
+                        if (mb) {
+                            const int l = __builtin_ctzll(mb); mb &= mb - 1ull;
+                            qp[qn] = wv::bcast(pos, l); qc[qn] = wv::bcast(nn, l);
+                            qh[qn] = p.home + (t + 4 * l + u) + (int64_t)(wv::bcast(eu, l) & WF_ENT_DELTA_MASK);
+                            ++qn;
+                        }
+                        if (qn == 4 || (!mb && u == 3 && qn)) {
+                            int32_t v[4];
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) v[q] = q < qn ? qh[q][lane < qc[q] ? lane : qc[q] - 1] : 0;
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) if (q < qn && lane < qc[q]) out[qp[q] + lane] = v[q];
+                            qn = 0;
+                        }
+                    }
+                    pos += u < nin ? ((eu & WF_ENT_FLAG) ? (nn > 0 ? nn : 1) : 1) : 0;
+                }
+            }
+        }
+      }
+      return;
+    }
+    if (cnt == 0) ec = 0;
     for (int i = 0; i < nd; ++i) {
         const int n = wv::bcast(ec, i);
         if (n == 0) continue;
@@ -609,28 +740,7 @@ BF_WVD void wf_merge_docs(const WfMergeParams &p, int64_t base, bool &over)
             continue;
         }
         int run = 0;
-        for (int t = 0; t < n && run < cap; t += 64) {
-            const bool have = t + lane < n;
-            const uint32_t e = have ? p.ent[src + t + lane] : 0u;
-            const int x = have ? wf_entry_ids(e) : 0;
-            if (!wv::any(have && (e & WF_ENT_FLAG) != 0u)) {
-                const int pos = run + lane;
-                if (have && pos < cap) p.ids_out[dst + pos] = (int32_t)e;
-                run += n - t < 64 ? n - t : 64;
-                continue;
-            }
-            const int inc = wv::incl_scan(x), pos = run + inc - x;
-            if (have && !(e & WF_ENT_FLAG)) { if (pos < cap) p.ids_out[dst + pos] = (int32_t)e; }
-            else if (have) {
-                const int nn = (int)((e & ~WF_ENT_FLAG) >> WF_ENT_CNT_SHIFT);
-                if (nn == 0) { if (pos < cap) p.ids_out[dst + pos] = p.unk; }
-                else {
-                    const int32_t *hm = p.home + (src + t + lane) + (int64_t)(e & WF_ENT_DELTA_MASK);
-                    for (int j = 0; j < nn && pos + j < cap; ++j) p.ids_out[dst + pos + j] = hm[j];
-                }
-            }
-            run += wv::bcast(inc, 63);
-        }
+        for (int t = 0; t < n && run < cap; t += 64) run += wf_merge_vec(p, t + lane < n ? p.ent[src + t + lane] : 0u, t + lane < n, src + t + lane, p.ids_out + dst, run, cap);
     }
 }
 

@@ -709,6 +709,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
     __shared__ uint16_t ascii[128];
     __shared__ int32_t acts[WV_ACTS_MAX];
     __shared__ WpWaveCold cold;
+    if (LIST && *p.list_n == 0) return;                 // (the usual case of the LIST instance: the flat program handed nothing back)
     if (threadIdx.x == 0) cold = p.cold;
     wv_init_ascii(p.cold, ascii, (int)threadIdx.x, 256);
     for (int i = (int)threadIdx.x; i < p.acts_n; i += 256) acts[i] = p.acts[i];

@@ -4,7 +4,7 @@ set -u
 export TMPDIR=/tmp
 O=$PWD/gpurun_out/flat_occ; mkdir -p $O
 run() { # name variant [extra args]
-  timeout 300 python bench.py --no-cpu-baseline --no-extra-timings --verify 200000 --steps 4 --warmup 2 --docs ${3:-2500000} --variant $2 > $O/$1.json 2> $O/$1.err
+  timeout 300 python bench.py --no-cpu-baseline --no-extra-timings --verify ${VERIFY:-200000} --steps 4 --warmup 2 --docs ${3:-2500000} --variant $2 > $O/$1.json 2> $O/$1.err
   python - $O/$1.json $1 <<'PY'
 import json, sys
 try:
