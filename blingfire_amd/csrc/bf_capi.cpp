@@ -169,7 +169,7 @@ struct Handle {
     DevBuf w_cls, w_nchars, w_tmp, w_counts, w_bsums, w_misc, w_flags, w_out, w_outoff;   // w_misc: [0] next_doc (u64), [2] status (int)
     DevBuf w_text, w_docoff, w_ids, w_idoff, w_starts, w_ends;  // host-API staging
     DevBuf w_srcoff, w_span;                                    // offsets API: source-offset stream, staged id spans
-    DevBuf w_ent, w_home, w_entoff, w_entcnt, w_dstat, w_ranges, w_list, t_flat;   // the flat program (bf_flat.h): entries, homes, per-document records, ranges, the documents handed back; its word table
+    DevBuf w_ent, w_home, w_entoff, w_entcnt, w_dstat, w_ranges, w_list, w_wrec, t_flat;   // the flat program (bf_flat.h): entries, homes, per-document records, ranges, the documents handed back; its word table
     bool last_flat = false;                                      // the last batch took the flat program (BfLastKernelMs names the kernels by it)
     // single-document calls that arrive while a batch is in flight are combined into the next launch (text_to_ids_one)
     struct OneReq { const char *s; int n; int32_t *ids; int max_ids, unk; int32_t *starts, *ends; int result; std::atomic<int> state; };
@@ -194,7 +194,7 @@ struct Handle {
         shards.clear();
         pipe.release(); m_small.release();
         for (DevBuf *b : {&t_segscore, &t_bpe_prio, &t_bpe_place, &t_dk_l1, &t_dk_pages, &t_dn_l1, &t_dn_pages, &t_dn_pool, &t_k2i, &t_rows, &w_keys, &w_keyoff, &w_dids, &w_dret, &w_vals, &t_i2w_off, &t_i2w_data, &t_kind, &t_wbd, &t_info, &t_acts, &t_cp_l1, &t_cp_pages, &t_multi, &t_wcp_l1, &t_wcp_pages, &t_dict, &t_seginfo, &w_s1, &w_s2, &w_s3, &w_s4, &w_big, &w_perm, &w_hist, &w_narcs, &w_bwflags, &w_cls, &w_nchars, &w_tmp, &w_counts, &w_flags, &w_out, &w_outoff,
-                          &w_bsums, &w_misc, &w_text, &w_docoff, &w_ids, &w_idoff, &w_starts, &w_ends, &w_srcoff, &w_span, &w_ent, &w_home, &w_entoff, &w_entcnt, &w_dstat, &w_ranges, &w_list, &t_flat}) b->release();
+                          &w_bsums, &w_misc, &w_text, &w_docoff, &w_ids, &w_idoff, &w_starts, &w_ends, &w_srcoff, &w_span, &w_ent, &w_home, &w_entoff, &w_entcnt, &w_dstat, &w_ranges, &w_list, &w_wrec, &t_flat}) b->release();
         for (auto &e : ev) if (e) (void)hipEventDestroy(e);
         if (stream) (void)hipStreamDestroy(stream);
         magic = 0;
@@ -338,7 +338,7 @@ bool reserve_ids_workspaces(Handle *h, int64_t ndocs, int64_t total_bytes, bool 
         if (use_flat(h, want_off, words, ndocs, total_bytes) &&
             (!h->w_ent.reserve((size_t)(total_bytes + 64) * 4) || !h->w_home.reserve((size_t)(total_bytes + 64) * 4) || !h->w_entoff.reserve((size_t)(ndocs + 1) * 8) ||
              !h->w_entcnt.reserve((size_t)(ndocs + 1) * 4) || !h->w_dstat.reserve((size_t)(ndocs + 1) * 4) || !h->w_list.reserve((size_t)(ndocs + 1) * 4) ||
-             !h->w_ranges.reserve((size_t)(wp_flat_ranges(ndocs, total_bytes) + 2) * 8))) return false;
+             !h->w_ranges.reserve((size_t)(wp_flat_ranges(ndocs, total_bytes) + 2) * 8) || !h->w_wrec.reserve((size_t)(total_bytes / 4 + 64) * 16 + (size_t)(wp_flat_ranges(ndocs, total_bytes) + 2) * 8))) return false;
         if (use_wave(h, want_off, words))                              // no class stream, no dirty flags
             return !want_off || h->w_span.reserve((size_t)(total_bytes + 8 * ndocs + 64) * 8);
         if (!h->w_cls.reserve((size_t)(total_bytes + 64) * 2) || !h->w_flags.reserve((size_t)((total_bytes >> 10) + 2) * 8)) return false;
@@ -383,9 +383,9 @@ int run_device(Handle *h, const char *d_text, const int64_t *d_doc_off, int64_t 
     (void)hipEventRecord(h->ev[EV_BEGIN], s);
     h->last_flat = use_flat(h, want_off, words, ndocs, total_bytes);
     if (h->last_flat) {
-        // w_misc: [192] work counter of the ranges, [200] "the batch is not fit for the flat program", [204] documents handed back
+        // w_misc: [192] work counter of the ranges, [200] "the batch is not fit for the flat program", [204] documents handed back, [208], [216] words on the two lists
         char *misc = h->w_misc.as<char>();
-        if (!hip_ok(hipMemsetAsync(misc + 192, 0, 16, s), "hipMemsetAsync") || !hip_ok(hipMemsetAsync(h->w_dstat.p, 0, (size_t)ndocs * 4, s), "hipMemsetAsync")) return BF_E_DEVICE;
+        if (!hip_ok(hipMemsetAsync(misc + 192, 0, 32, s), "hipMemsetAsync") || !hip_ok(hipMemsetAsync(h->w_dstat.p, 0, (size_t)ndocs * 4, s), "hipMemsetAsync")) return BF_E_DEVICE;
         int *unsafe = (int *)(misc + 200); unsigned int *list_n = (unsigned int *)(misc + 204);
         const int nranges = wp_flat_ranges(ndocs, total_bytes);
         launch_wp_pre(d_doc_off, ndocs, total_bytes, nranges, h->w_ranges.as<int64_t>(), unsafe, s);
@@ -401,7 +401,14 @@ int run_device(Handle *h, const char *d_text, const int64_t *d_doc_off, int64_t 
         fp.range_doc = h->w_ranges.as<int64_t>(); fp.nranges = nranges; fp.next_range = (unsigned long long *)(misc + 192); fp.unsafe = unsafe;
         fp.ent = h->w_ent.as<uint32_t>(); fp.home = h->w_home.as<int32_t>(); fp.ent_off = h->w_entoff.as<int64_t>(); fp.ent_cnt = h->w_entcnt.as<int32_t>();
         fp.dstat = h->w_dstat.as<int32_t>(); fp.cold = cold;
+        fp.wrec = h->w_wrec.as<uint32_t>(); fp.wrec_cnt = (int32_t *)(h->w_wrec.as<char>() + (size_t)(total_bytes / 4 + 64) * 16);
+        if (!hip_ok(hipMemsetAsync(fp.wrec_cnt, 0, (size_t)nranges * 8, s), "hipMemsetAsync")) return BF_E_DEVICE;      // (a range without documents writes nothing)
         launch_wp_flat(fp, h->variant, s);
+        // the words the table did not answer: walked by a kernel of their own
+        WfUnitParams up;
+        up.T = fp.T; up.ini = fp.ini; up.ini_l = fp.ini_l; up.max_token_length = fp.max_token_length; up.text = b.text; up.total_bytes = total_bytes;
+        up.wrec = fp.wrec; up.wrec_cnt = fp.wrec_cnt; up.range_doc = fp.range_doc; up.doc_off = b.doc_off; up.nranges = nranges; up.ent = fp.ent; up.home = fp.home; up.cpmap = cold.cpmap; up.kind = cold.kind; up.nclasses = cold.nclasses; up.stats = cold.stats;
+        launch_wp_units(up, h->variant, s);
         (void)hipEventRecord(h->ev[EV_TOK], s);
         // the documents it hands back: the wave program, one document at a time
         launch_wp_hardlist(fp.dstat, unsafe, ndocs, h->w_list.as<int32_t>(), list_n, s);
@@ -1913,7 +1920,7 @@ const char *BfTokeniseKernel(void *p)
     Handle *h = as_handle(p);
     if (!h) return "";
     switch (h->m.kind) {
-    case KIND_WP: return h->last_flat ? "k_wp_flat" : use_wave(h, false, 0) ? "k_wp_wave" : (h->m.two_level ? "k_lex_wp_plain" : "k_lex_wp_flat");
+    case KIND_WP: return h->last_flat ? "k_wp_flat + k_wp_units" : use_wave(h, false, 0) ? "k_wp_wave" : (h->m.two_level ? "k_lex_wp_plain" : "k_lex_wp_flat");
     case KIND_UNIGRAM: return "k_seg_unigram_lane";
     case KIND_I2W: return "";
     default: return use_bpe_wave(h, false) ? "k_bpe_wave" : "k_bpe_fused";

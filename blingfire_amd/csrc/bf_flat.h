@@ -39,7 +39,20 @@ struct WfParams {
     int32_t *home;                   // [total_bytes + 64] ids of the words of two and more pieces: piece j of the word that starts at byte p -> home[p + j]
     int64_t *ent_off; int32_t *ent_cnt;                    // per document: its first entry, its number of entries
     int32_t *dstat;                  // per document, zero before the launch: WF_D_* bits
+    // the words the table did not answer (16-byte records, bf_flat_body.h).  A range owns the records [first byte / 4, last byte / 4): the words a unit
+    // holds in registers from the front, the others from the back; wrec_cnt[2 r], [2 r + 1] = how many of each (written by the range's wave)
+    uint32_t *wrec; int32_t *wrec_cnt;
     WpWaveCold cold;                 // code-point map, class kinds, status word, optional counters
+};
+
+// the words of the list, walked (k_wp_units)
+struct WfUnitParams {
+    const uint64_t *T; uint32_t ini, ini_l; int max_token_length;
+    const uint8_t *text; int64_t total_bytes;
+    const uint32_t *wrec; const int32_t *wrec_cnt; const int64_t *range_doc; const int64_t *doc_off; int nranges;      // the ranges' lists (WfParams)
+    uint32_t *ent; int32_t *home;
+    DevCpMap cpmap; const uint8_t *kind; int nclasses;      // fused code point -> charmap -> class map, kinds of the classes (the table of the ASCII bytes is made of them)
+    unsigned long long *stats;       // optional: [8] rounds [9] batches
 };
 
 // the kernels behind the program (count -> scan -> merge)

@@ -12,9 +12,8 @@
 //   list      every lane writes where its tokens are, in token order, to a list in LDS;
 //   look-up   the list one token per lane and trip: the key of a run of <= 9 plain characters is made of its classes in the ring (the key IS
 //             the word), two 12-byte gathers per lane, ids to the entries as whole rows;
-//   units     the tokens the table did not answer wait as records (a plain-ASCII word: where its bytes are in the text; any other: its
-//             characters copied to an arena); 64 of them are walked at once (wf_drain: the frame of one call of the vocabulary function,
-//             bf_wave_body.h Unit restated without a queue), pieces to the word's home, the entry says how many.
+//   records   the tokens the table did not answer become records (entry, first byte, bytes) in a list in global memory, 64 at a time (one
+//             atomic per 64): the words are walked by a kernel of their own (k_wp_units, wf_units below), where nothing waits for them.
 // What couples documents is left to the kernels behind (k_wp_count, k_wp_merge): a document's entries are dense, its ids are not yet.
 #pragma once
 #include "bf_flat.h"
@@ -24,15 +23,15 @@ namespace bfa {
 constexpr int WF_TQ = 512;                // tokens of a chunk, at most (every byte one)
 constexpr int WF_RING_DUP = 16;           // the first positions of the ring once more behind its end: a word of <= 16 bytes is read without a wrap
 constexpr uint64_t WF_KEY_NONE = 1ull << 62;     // "no key": matches no entry of the table (an entry's lowest field is never 0)
-constexpr uint32_t WF_REC_TEXT = 0x80000000u;    // record word 2: the word's characters are its bytes in the text (plain ASCII, <= 16 bytes); else arena base | characters << 16
 constexpr uint32_t WF_TQ_SOLO = 63;       // list entry: bytes == 63: a one-element token
+// a record of the word list (16 bytes): [0] entry index (low 32 bits) [1] first byte in the text (low 32 bits) [2] entry index bits 32.. | first byte bits 32.. << 8 | bytes << 16 |
+// WF_REC_PLAIN [3] home index - entry index
+constexpr uint32_t WF_REC_PLAIN = 1u << 24;      // the word's bytes are plain ASCII (its characters are its bytes)
 
 struct WfLds {
     alignas(16) uint16_t ring[WF_RING + WF_RING_DUP];   // class of every byte position of this chunk and the one before (WF_CONT: no character starts there)
     uint16_t tq_pos[WF_TQ];              // the chunk's tokens in order: (first byte - (chunk - 64)) | bytes << 10; bytes == 0: a run of more than WF_RUN_MAX bytes, its LAST byte
-    uint32_t rec[WF_REC * 3];            // a word that waits for a unit: entry (range-relative), first byte (range-relative), where its characters are
-    uint16_t arena[WF_ARENA];            // characters of the waiting words that are not plain text
-    int arena_n;                         // characters in the arena
+    alignas(16) uint32_t rec[WF_REC * 4]; // words on their way to the list
     uint32_t spare32; uint16_t spare;
 };
 
@@ -49,126 +48,6 @@ BF_WV uint32_t wf_lut_value(const WpWaveCold &p, int b)
 #else
 #define BF_WF_NOINLINE static __attribute__((noinline))
 #endif
-
-// ------------------------------------------------------------------------------------------------------------------
-// units: the words that wait (records 0 .. n), all at once.  The frame of ONE call of the vocabulary function on a word of L characters
-// (FALexTools_t.h:229-393 at depth 1; L < max-token-length, so every walk's limit is the word's end): first the walk from the state behind
-// the left anchor at character 0, if the function has one; a walk that ends with a match is a piece and the next walk starts behind it
-// (:390-393); the anchored walk without a match is followed by the plain walk at 0 (:293); any other walk without a match leaves a gap:
-// the pieces cannot tile the word, its id is UnkId (tokdll:1252-1301).  Restated from bf_wave_body.h Unit / unit_step / unit_event.
-// A function of its own (not inlined): it runs once per ~10 chunks, and what it keeps in registers must not press on the chunk code.
-// ------------------------------------------------------------------------------------------------------------------
-template <bool STATS>
-BF_WF_NOINLINE void wf_drain(const uint64_t *T, uint32_t ini, uint32_t ini_l, int max_token_length, WfLds &S, const uint32_t *lut, const uint8_t *txt, uint32_t *ent, int32_t *home,
-                             int n, unsigned long long *rounds)
-{
-    const int lane = wv::lane();
-    const bool have = lane < n;
-    const uint32_t e_rel = have ? S.rec[3 * lane] : 0u, p_rel = have ? S.rec[3 * lane + 1] : 0u, w2 = have ? S.rec[3 * lane + 2] : 0u;
-    const bool is_text = (w2 & WF_REC_TEXT) != 0u;
-    const uint32_t abase = w2 & 0xFFFFu; const int L = is_text ? (int)(w2 & 0xFFu) : (int)(w2 >> 16);
-    // a plain-text word: its (at most 16) bytes in two registers, every byte's class through the table of the ASCII bytes
-    uint64_t t_lo = 0, t_hi = 0;
-    if (is_text) { __builtin_memcpy(&t_lo, txt + p_rel, 8); __builtin_memcpy(&t_hi, txt + p_rel + 8, 8); }
-    const bool anchored0 = ini_l != LX_NO_STATE && max_token_length > 1;
-    uint32_t state = anchored0 ? ini_l : ini; int j = 0, fp = -1, cnt = 0; uint32_t ftag = 0; int32_t id0 = 0;
-    bool anch = anchored0, act = have, missed = false;
-    int32_t *hm = home + p_rel;
-    // class of character i of the word (i < L).  The class of the NEXT character is fetched while the transition on this one is in flight: it
-    // does not depend on it (a miss or the end of a walk re-reads at the walk's new start)
-    auto cls_at = [&](int i) -> uint32_t {
-        const uint32_t tb = (uint32_t)((i < 8 ? t_lo : t_hi) >> (8 * (i & 7))) & 0x7Fu;
-        const uint16_t *src = is_text ? (const uint16_t *)(lut + tb) : &S.arena[(act && i < L) ? abase + (uint32_t)i : 0u];
-        return (uint32_t)*src & LX_T_CLS_MASK;
-    };
-    uint32_t c_cur = cls_at(0);
-    while (wv::any(act)) {
-        if (STATS) ++*rounds;
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const bool walking = act && !missed && j < L;
-            const uint64_t e64 = T[walking ? state + c_cur : 0u];
-            const uint32_t c_nxt = cls_at(j + 1);
-            const uint32_t e = (uint32_t)e64;
-            const bool hit = walking && (e & LX_T_CLS_MASK) == c_cur;
-            const bool fin = hit && (int32_t)e < 0;
-            fp = fin ? j : fp; ftag = fin ? (uint32_t)(e64 >> 32) : ftag;
-            state = hit ? ((e >> LX_T_NEXT_SHIFT) & LX_T_NEXT_MASK) : state;
-            j = hit ? j + 1 : j;
-            c_cur = hit ? c_nxt : c_cur;
-            missed = missed || (walking && !hit);
-        }
-        const bool ev = act && (missed || j >= L);
-        if (wv::any(ev)) {
-            if (ev) {
-                const bool matched = fp >= 0;
-                if (matched) {
-                    const int32_t id = (int32_t)(ftag & 0x7FFFFFFFu);
-                    if (cnt == 0) id0 = id;
-                    else { if (cnt == 1) hm[0] = id0; hm[cnt] = id; }
-                    ++cnt;
-                    const int nf = fp + 1;
-                    if (nf >= L) {
-                        ent[e_rel] = cnt == 1 ? (uint32_t)id0 : (WF_ENT_FLAG | ((uint32_t)cnt << WF_ENT_CNT_SHIFT) | (p_rel - e_rel));
-                        act = false;
-                    } else { state = ini; j = nf; fp = -1; anch = false; missed = false; }
-                } else if (anch) { state = ini; j = 0; fp = -1; anch = false; missed = false; }
-                else { ent[e_rel] = WF_ENT_FLAG; act = false; }            // a gap: UnkId
-            }
-            c_cur = cls_at(j);
-        }
-    }
-    wv::sync();
-}
-
-// The tokens the table did not answer (`miss`: this lane holds one; MB = the lanes that do) become waiting words.  A word of plain
-// ASCII that lies inside this chunk is walked from the text itself (`text_ok`); of any other the characters (not the continuation
-// bytes) are copied from the ring to the arena.  A full record table or arena is drained first; `flush`: and at the end.  nrec_in: words that
-// wait already; returns how many do now | drains << 8.
-template <bool STATS>
-BF_WF_NOINLINE int wf_words(unsigned long long MB, bool miss, uint32_t start, int blen, uint32_t rank, bool text_ok, bool flush, int nrec_in,
-                            const uint64_t *T, uint32_t ini, uint32_t ini_l, int max_token_length, WfLds &S, const uint32_t *lut, const uint8_t *txt, uint32_t *ent, int32_t *home, unsigned long long *rounds)
-{
-    constexpr uint32_t RMASK = WF_RING - 1;
-    const int lane = wv::lane();
-    wv::sync();                                                  // (records may have been added in line)
-    int nrec = wv::uni(nrec_in), arena_n = wv::uni(S.arena_n), drains = 0;
-    unsigned long long todo = MB;
-    bool full = false;
-    while (todo || flush) {
-        if (full || !todo) {                                     // no room for the next word -- or, at the end of a range, nothing left to add: the units run
-            if (nrec) { wf_drain<STATS>(T, ini, ini_l, max_token_length, S, lut, txt, ent, home, nrec, rounds); ++drains; }
-            nrec = 0; arena_n = 0; full = false;
-            if (!todo) break;
-            continue;
-        }
-        const bool mine_todo = miss && ((todo >> lane) & 1ull) != 0ull;
-        const int need = (mine_todo && !text_ok) ? blen : 0;
-        const int inc = wv::incl_scan(need);
-        const int ridx = (int)wv::mbcnt(todo);
-        const unsigned long long fit = wv::ballot(mine_todo && inc <= WF_ARENA - arena_n && ridx < WF_REC - nrec);     // a prefix of `todo`: both grow with the lane
-        if (!fit) { full = true; continue; }
-        const bool mine = mine_todo && ((fit >> lane) & 1ull) != 0ull;
-        const uint32_t ab = (uint32_t)(arena_n + inc - need);
-        int w = 0;
-        if (wv::any(mine && !text_ok)) {
-            for (int t = 0; wv::any(mine && !text_ok && t < blen); ++t) {
-                const bool on = mine && !text_ok && t < blen;
-                const uint32_t el = S.ring[(start + (uint32_t)t) & RMASK];
-                const bool ch = on && el != WF_CONT;
-                uint16_t *dst = ch ? &S.arena[ab + (uint32_t)w] : &S.spare;
-                *dst = (uint16_t)el;
-                w += ch ? 1 : 0;
-            }
-        }
-        if (mine) { uint32_t *r = S.rec + 3 * (nrec + ridx); r[0] = rank; r[1] = start; r[2] = text_ok ? (WF_REC_TEXT | (uint32_t)blen) : (ab | ((uint32_t)w << 16)); }
-        arena_n += wv::bcast(inc, 63 - __builtin_clzll(fit)); nrec += __builtin_popcountll(fit); todo &= ~fit;
-        wv::sync();
-    }
-    if (lane == 0) S.arena_n = arena_n;
-    wv::sync();
-    return nrec | (drains << 8);
-}
 
 // A chunk with bytes >= 0x80 (the caller has put the ASCII bytes' classes and WF_CONT for all others into the ring).  Every lead byte is decoded
 // by its lane, one per trip; a continuation byte is legal exactly when it is one of the (length - 1) bytes behind a lead byte OF ITS DOCUMENT (a
@@ -272,13 +151,13 @@ struct WfWave {
     int open_start;                      // first byte of the run that reaches the end of the chunk before (-1: none)
     unsigned long long na_prev;          // the lanes of the chunk before that hold a byte >= 0x80
     uint32_t cov_carry, loop_carry;      // of lane 63 of the chunk before: bytes of the next chunk that belong to its last character
-    int nrec;                            // words that wait for a unit
+    int nrec, wf_n, ws_n;                // words in S.rec; words of this range on its two lists
     int bad_lo, bad_hi, hard_lo, hard_hi; // [lo, hi): bytes of the document that got the flag last (one look-up per document, mostly)
     unsigned long long st_chunks, st_ascii, st_tok, st_hit, st_notes, st_drains, st_rounds, st_hard;
 
     BF_WVD WfWave(const WfParams &p_, WfLds &S_, const uint32_t *lut_, const WpWaveCold &cold_) : p(p_), S(S_), lut(lut_), cold(cold_)
     {
-        lane = wv::lane(); nrec = 0; if (lane == 0) S.arena_n = 0; wv::sync(); bad_lo = bad_hi = hard_lo = hard_hi = 0;
+        lane = wv::lane(); nrec = 0; wf_n = ws_n = 0; bad_lo = bad_hi = hard_lo = hard_hi = 0;
         st_chunks = st_ascii = st_tok = st_hit = st_notes = st_drains = st_rounds = st_hard = 0;
         dlo = 0; dn = dnext = wlo = 0; b0 = 0; len = 0; win = 0; txt = nullptr; ent = nullptr; home = nullptr; k = kdoc = 0; open_start = -1; cov_carry = loop_carry = 0; na_prev = 0;
     }
@@ -323,12 +202,38 @@ struct WfWave {
             while (m) { const int bit = __builtin_ctz(m); m &= m - 1u; mark(c + l * 8 + (bit == 8 ? -1 : bit), flag); }
         }
     }
-    // (see wf_words)
-    BF_WVD void add_words(unsigned long long MB, bool miss, uint32_t start, int blen, uint32_t rank, bool text_ok, bool flush)
+    // the words in S.rec go to the list (one atomic for all of them; a list that is full hands their documents on: cannot be but for text
+    // that is all words the table does not hold)
+    // The words in S.rec go to the lists of the range.  A range owns the records [b0 / 4, (b0 + len) / 4) (no counter is shared between waves: a
+    // counter that 8,000 waves add to costs more than the walks): the words a unit holds in registers (plain ASCII, <= 16 bytes, 16 readable bytes
+    // behind their first) from the front, the others from the back.  A range whose words do not fit hands their documents on (cannot be but
+    // for text that is all words the table does not hold).
+    BF_WVD void flush_records()
     {
-        const int r = wf_words<STATS>(MB, miss, start, blen, rank, text_ok, flush, nrec, p.T, p.ini, p.ini_l, p.max_token_length, S, lut, txt, ent, home, STATS ? &st_rounds : nullptr);
-        nrec = r & 0xFF;
-        if (STATS) st_drains += (unsigned long long)(r >> 8);
+        wv::sync();
+        if (nrec > 0) {
+            uint32_t r0 = 0, r1 = 0, r2 = 0, r3 = 0;
+            if (lane < nrec) { const uint32_t *r = S.rec + 4 * lane; r0 = r[0]; r1 = r[1]; r2 = r[2]; r3 = r[3]; }
+            const int64_t pa = (int64_t)r1 | ((int64_t)((r2 >> 8) & 0xFFu) << 32);
+            const bool fastw = lane < nrec && (r2 & WF_REC_PLAIN) != 0u && ((r2 >> 16) & 0xFFu) <= 16u && pa + 16 <= p.total_bytes;
+            const unsigned long long FB = wv::ballot(fastw), SB = wv::ballot(lane < nrec && !fastw);
+            const int nf = __builtin_popcountll(FB), ns = __builtin_popcountll(SB);
+            const int64_t lo = (b0 + 3) >> 2, hi = (b0 + (int64_t)len) >> 2;           // the range's records
+            if ((int64_t)(wf_n + nf + ws_n + ns) <= hi - lo) {
+                if (lane < nrec) {
+                    uint32_t *d = p.wrec + 4 * (fastw ? lo + wf_n + (int64_t)wv::mbcnt(FB) : hi - 1 - ws_n - (int64_t)wv::mbcnt(SB));
+                    d[0] = r0; d[1] = r1; d[2] = r2; d[3] = r3;
+                }
+                wf_n += nf; ws_n += ns;
+            } else {
+                for (unsigned long long lb = FB | SB; lb;) {
+                    const int l = __builtin_ctzll(lb); lb &= lb - 1ull;
+                    hard_lo = hard_hi = 0; mark((int)(wv::bcast(pa, l) - b0), WF_D_HARD);
+                }
+            }
+        }
+        nrec = 0;
+        wv::sync();
     }
 
     BF_WVD void emit_boundary(int d, int kd)
@@ -451,7 +356,7 @@ struct WfWave {
         // class without a code -- >= 127, or no character: a continuation byte -- and the run has no key): the key IS the word.  Two 12-byte
         // gathers per lane in flight; the ids go to their entries as whole rows.
         uint32_t *eout = ent + k;
-        for (int t0 = 0; t0 < ntok || (t0 == 0 && at_end); t0 += 64) {
+        for (int t0 = 0; t0 < ntok; t0 += 64) {
             const bool have = t0 + lane < ntok;
             const uint32_t ps = have ? (uint32_t)S.tq_pos[t0 + lane] : 0u;
             const uint32_t b6 = ps >> 10;
@@ -494,22 +399,22 @@ struct WfWave {
             if (STATS) st_hit += (unsigned long long)__builtin_popcountll(wv::ballot(hit));
             const bool rest = have && !hit;
             const unsigned long long RB = wv::ballot(rest), TL = wv::ballot(rest && blen == 0);
-            const bool fin = at_end && t0 + 64 >= ntok;
             if (RB) {
                 // a run of more than WF_RUN_MAX bytes: its document is handed on
                 for (unsigned long long tl = TL; tl;) { const int l = __builtin_ctzll(tl); tl &= tl - 1ull; mark(c - 64 + (int)(wv::bcast(ps, l) & 0x3FFu), WF_D_HARD); }
-                const bool text_ok = plain && blen <= 16 && s0 + 16 <= len;
                 const bool word = rest && blen != 0;
-                const unsigned long long WB = wv::ballot(word), XB = wv::ballot(word && !text_ok);
+                const unsigned long long WB = wv::ballot(word);
                 const int nw = __builtin_popcountll(WB);
                 if (STATS) st_notes += (unsigned long long)nw;
-                if (!XB && nrec + nw <= WF_REC) {
-                    // the usual case, in line: plain words that fit the record table
-                    if (word) { uint32_t *r = S.rec + 3 * (nrec + (int)wv::mbcnt(WB)); r[0] = (uint32_t)(k + t0 + lane); r[1] = (uint32_t)s0; r[2] = WF_REC_TEXT | (uint32_t)blen; }
-                    nrec += nw;
-                } else if (WB) add_words(WB, word, (uint32_t)s0, blen, (uint32_t)(k + t0 + lane), text_ok, false);
+                if (nrec + nw > WF_REC) flush_records();
+                if (word) {
+                    const int64_t ea = b0 + (int64_t)(k + t0 + lane), pa = b0 + (int64_t)s0;
+                    uint32_t *r = S.rec + 4 * (nrec + (int)wv::mbcnt(WB));
+                    r[0] = (uint32_t)ea; r[1] = (uint32_t)pa; r[2] = (uint32_t)((ea >> 32) & 0xFF) | ((uint32_t)((pa >> 32) & 0xFF) << 8) | ((uint32_t)blen << 16) | (plain ? WF_REC_PLAIN : 0u);
+                    r[3] = (uint32_t)(s0 - (k + t0 + lane));
+                }
+                nrec += nw;
             }
-            if (fin) { wv::sync(); add_words(0ull, false, 0u, 0, 0u, false, true); }
         }
         k += ntok; open_start = new_open; na_prev = na;
     }
@@ -522,7 +427,7 @@ struct WfWave {
         dn = (int)(dhi - dlo);
         b0 = p.doc_off[dlo]; len = (int)(p.doc_off[dhi] - b0);
         txt = p.text + b0; ent = p.ent + b0; home = p.home + b0;
-        k = kdoc = 0; dnext = 0; open_start = -1; cov_carry = loop_carry = 0; na_prev = 0; bad_lo = bad_hi = hard_lo = hard_hi = 0;
+        k = kdoc = 0; dnext = 0; open_start = -1; cov_carry = loop_carry = 0; na_prev = 0; bad_lo = bad_hi = hard_lo = hard_hi = 0; wf_n = ws_n = 0;
         load_window(0);
         uint64_t own = load_chunk(0);
         for (int c = 0; c < len; c += WF_CHUNK) {
@@ -533,6 +438,8 @@ struct WfWave {
         // documents that begin where the range ends (empty ones), then the last document's count
         for (; dnext < dn; ++dnext) emit_boundary(dnext, k);
         if (lane == 0) p.ent_cnt[dhi - 1] = k - kdoc;
+        flush_records();
+        if (lane == 0) { p.wrec_cnt[2 * r] = wf_n; p.wrec_cnt[2 * r + 1] = ws_n; }
     }
 
     BF_WVD void run(int wave_id, int n_waves)
@@ -551,6 +458,165 @@ struct WfWave {
         }
     }
 };
+
+// ----------------------------------------------------------------------------------------------------------------------
+// k_wp_units: the words of the list, NU per lane and 64 * NU per wave at a time.  The frame of ONE call of the vocabulary function on a word
+// (FALexTools_t.h:229-393 at depth 1; the word is shorter than max-token-length, so every walk's limit is the word's end): first the walk from
+// the state behind the left anchor at character 0, if the function has one; a walk that ends with a match is a piece and the next walk starts
+// behind it (:390-393); the anchored walk without a match is followed by the plain walk at 0 (:293); any other walk without a match leaves a
+// gap: the pieces cannot tile the word, its id is UnkId (tokdll:1252-1301).  Restated from bf_wave_body.h Unit / unit_step / unit_event.
+// Positions are BYTES of the word.  A plain-ASCII word of <= 16 bytes is held in two registers (its characters' classes through the table of
+// the ASCII bytes, the class of the next character fetched while the transition on this one is in flight); any other word is read from the text
+// character by character (UTF-8 as the flat program has validated it, fused code-point map).  What a wave waits for is the longest chain of
+// dependent gathers among its words: nothing else runs in this kernel, and all resident waves wait alike.  FAST: the list of the words in
+// registers (no other code in the loop); else the list of the others.
+// ----------------------------------------------------------------------------------------------------------------------
+// MODE 0: the list of the plain-ASCII words of <= 16 bytes: the word in two registers, classes through the table of the ASCII bytes.
+// MODE 1: the other list, its words of <= 16 bytes: the word in two registers, its characters' classes made up front (`cbuf`: 16 classes per
+//         lane in LDS; a character outside ASCII: fused code-point map) -- positions are then CHARACTERS.
+// MODE 2: the other list, what is left (longer words, words at the very end of the text): read from the text character by character.
+template <int NU, bool STATS, int MODE>
+BF_WVD void wf_units(const WfUnitParams &p, const uint32_t *lut, uint16_t *cbuf, const uint32_t *wrec, unsigned long long first, unsigned long long total, unsigned long long *rounds)
+{
+    static_assert(MODE == 0 || NU == 1, "one word per lane but on the first list");
+    const int lane = wv::lane();
+    const bool anchored0 = p.ini_l != LX_NO_STATE && p.max_token_length > 1;
+    const uint64_t *T = p.T;
+    uint32_t state[NU], ftag[NU], c_cur[NU], w3[NU]; int L[NU], j[NU], fp[NU], cnt[NU], clen[NU]; int32_t id0[NU];
+    int64_t ea[NU], pa[NU];
+    uint64_t t_lo[NU], t_hi[NU];
+    bool anch[NU], act[NU], missed[NU], stale[NU];
+    // MODE 2: the character at byte j of word u, read from the text: its class and its length
+    auto fetch_mem = [&](int u) {
+        const uint8_t *q = p.text + pa[u] + j[u];
+        const int left = L[u] - j[u];
+        const uint32_t b0 = q[0];
+        int cl = b0 < 0x80u ? 1 : (b0 & 0xE0u) == 0xC0u ? 2 : (b0 & 0xF0u) == 0xE0u ? 3 : (b0 & 0xF8u) == 0xF0u ? 4 : 1;
+        if (cl > left) cl = left;                                  // (cannot be in a document that has ids)
+        uint32_t cls;
+        if (b0 < 0x80u) cls = lut[b0] & LX_T_CLS_MASK;
+        else {
+            int cp = cl == 2 ? (int)(b0 & 0x1Fu) : cl == 3 ? (int)(b0 & 0x0Fu) : (int)(b0 & 0x07u);
+            for (int t = 1; t < cl; ++t) cp = (cp << 6) | (int)(q[t] & 0x3Fu);
+            if (cp > 0x10FFFF) cp = 0;
+            cls = wv_cpmap_get(p.cpmap, cp) & LX_T_CLS_MASK;
+        }
+        c_cur[u] = cls; clen[u] = cl;
+    };
+    auto byte_at = [&](int u, int i) -> uint32_t { return (uint32_t)((i < 8 ? t_lo[u] : t_hi[u]) >> (8 * (i & 7))) & 0xFFu; };
+    // class of character i (MODE 0: byte i through the table; MODE 1: from the classes made up front)
+    auto cls_at = [&](int u, int i) -> uint32_t {
+        if (MODE == 0) return lut[byte_at(u, i) & 0x7Fu] & LX_T_CLS_MASK;
+        return (uint32_t)cbuf[lane * 16 + (i & 15)];
+    };
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+        const unsigned long long ri = first + (unsigned long long)(64 * u + lane);
+        bool have = ri < total;
+        const uint32_t *r = wrec + 4 * (have ? ri : first);
+        const uint32_t r0 = r[0], r1 = r[1], r2 = r[2]; w3[u] = r[3];
+        ea[u] = (int64_t)r0 | ((int64_t)(r2 & 0xFFu) << 32); pa[u] = (int64_t)r1 | ((int64_t)((r2 >> 8) & 0xFFu) << 32);
+        L[u] = (int)((r2 >> 16) & 0xFFu);
+        const bool b16 = L[u] <= 16 && pa[u] + 16 <= p.total_bytes;
+        if (MODE == 1) have = have && b16;
+        if (MODE == 2) have = have && !b16;
+        t_lo[u] = 0; t_hi[u] = 0;
+        if (MODE != 2 && have) { __builtin_memcpy(&t_lo[u], p.text + pa[u], 8); __builtin_memcpy(&t_hi[u], p.text + pa[u] + 8, 8); }
+        state[u] = anchored0 ? p.ini_l : p.ini; j[u] = 0; fp[u] = -1; cnt[u] = 0; ftag[u] = 0; id0[u] = 0; clen[u] = 1;
+        anch[u] = anchored0; act[u] = have; missed[u] = false; stale[u] = MODE == 2 && have;
+        c_cur[u] = 0;
+    }
+    { bool a = false;
+#pragma unroll
+      for (int u = 0; u < NU; ++u) a = a || act[u];
+      if (!wv::any(a)) return; }
+    if (MODE == 1) {
+        // the classes of the word's characters, up front: the ASCII ones through the table, the others one per lane and trip through the code-point map
+        uint32_t startm = 0, leadm = 0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const uint32_t b = byte_at(0, i);
+            const bool in = act[0] && i < L[0];
+            if (in && (b & 0xC0u) != 0x80u) startm |= 1u << i;
+            if (in && b >= 0xC0u) leadm |= 1u << i;
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const bool on = ((startm & ~leadm) >> i) & 1u;
+            uint16_t *d = on ? &cbuf[lane * 16 + __builtin_popcount(startm & ((1u << i) - 1u))] : &cbuf[64 * 16];
+            *d = (uint16_t)(lut[byte_at(0, i) & 0x7Fu] & LX_T_CLS_MASK);
+        }
+        for (uint32_t lm = leadm; wv::any(lm != 0);) {
+            if (lm) {
+                const int i = __builtin_ctz(lm); lm &= lm - 1u;
+                uint32_t w = i < 8 ? (uint32_t)(t_lo[0] >> (8 * i)) : (uint32_t)(t_hi[0] >> (8 * (i - 8)));
+                if (i > 4 && i < 8) w |= (uint32_t)(t_hi[0] << (64 - 8 * i));
+                const uint32_t b0 = w & 0xFFu;
+                const int cl = (b0 & 0xE0u) == 0xC0u ? 2 : (b0 & 0xF0u) == 0xE0u ? 3 : 4;
+                int cp = cl == 2 ? (int)(b0 & 0x1Fu) : cl == 3 ? (int)(b0 & 0x0Fu) : (int)(b0 & 0x07u);
+                for (int t = 1; t < cl; ++t) cp = (cp << 6) | (int)((w >> (8 * t)) & 0x3Fu);
+                if (cp > 0x10FFFF) cp = 0;
+                cbuf[lane * 16 + __builtin_popcount(startm & ((1u << i) - 1u))] = (uint16_t)(wv_cpmap_get(p.cpmap, cp) & LX_T_CLS_MASK);
+            }
+        }
+        L[0] = __builtin_popcount(startm);                                     // characters from here on
+        wv::sync();
+    }
+#pragma unroll
+    for (int u = 0; u < NU; ++u) if (MODE != 2) c_cur[u] = cls_at(u, 0);
+    bool any_act = true;
+    while (any_act) {
+        if (STATS) ++*rounds;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            uint64_t e64[NU]; uint32_t c_nxt[NU]; bool walking[NU];
+#pragma unroll
+            for (int u = 0; u < NU; ++u) { if (MODE == 2 && wv::any(stale[u])) { if (stale[u]) fetch_mem(u); stale[u] = false; } }
+#pragma unroll
+            for (int u = 0; u < NU; ++u) { walking[u] = act[u] && !missed[u] && j[u] < L[u]; e64[u] = 0; if (walking[u]) e64[u] = T[state[u] + c_cur[u]]; }      // (only the lanes that walk: a gather costs by the lane)
+#pragma unroll
+            for (int u = 0; u < NU; ++u) c_nxt[u] = MODE != 2 ? cls_at(u, j[u] + 1) : 0u;       // (the class of the next character while the transition on this one is in flight)
+#pragma unroll
+            for (int u = 0; u < NU; ++u) {
+                const uint32_t e = (uint32_t)e64[u];
+                const bool hit = walking[u] && (e & LX_T_CLS_MASK) == c_cur[u];
+                const bool fin = hit && (int32_t)e < 0;
+                const int jn = j[u] + clen[u];
+                fp[u] = fin ? jn : fp[u]; ftag[u] = fin ? (uint32_t)(e64[u] >> 32) : ftag[u];
+                state[u] = hit ? ((e >> LX_T_NEXT_SHIFT) & LX_T_NEXT_MASK) : state[u];
+                j[u] = hit ? jn : j[u];
+                c_cur[u] = (hit && MODE != 2) ? c_nxt[u] : c_cur[u];
+                stale[u] = MODE == 2 && hit && jn < L[u];
+                missed[u] = missed[u] || (walking[u] && !hit);
+            }
+        }
+        any_act = false;
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            const bool ev = act[u] && (missed[u] || j[u] >= L[u]);
+            if (wv::any(ev)) {
+                if (ev) {
+                    int32_t *hm = p.home + ea[u] + (int64_t)w3[u];
+                    if (fp[u] >= 0) {                                        // fp: the position behind the last character of the match
+                        const int32_t id = (int32_t)(ftag[u] & 0x7FFFFFFFu);
+                        if (cnt[u] == 0) id0[u] = id;
+                        else { if (cnt[u] == 1) hm[0] = id0[u]; hm[cnt[u]] = id; }
+                        ++cnt[u];
+                        const int nf = fp[u];
+                        if (nf >= L[u]) {
+                            p.ent[ea[u]] = cnt[u] == 1 ? (uint32_t)id0[u] : (WF_ENT_FLAG | ((uint32_t)cnt[u] << WF_ENT_CNT_SHIFT) | w3[u]);
+                            act[u] = false;
+                        } else { state[u] = p.ini; j[u] = nf; fp[u] = -1; anch[u] = false; missed[u] = false; }
+                    } else if (anch[u]) { state[u] = p.ini; j[u] = 0; fp[u] = -1; anch[u] = false; missed[u] = false; }
+                    else { p.ent[ea[u]] = WF_ENT_FLAG; act[u] = false; }        // a gap: UnkId
+                    if (act[u]) { if (MODE != 2) c_cur[u] = cls_at(u, j[u]); else stale[u] = true; }
+                }
+            }
+            any_act = any_act || wv::any(act[u]);
+        }
+    }
+    if (MODE == 1) wv::sync();                                               // (the next batch writes the classes anew)
+}
 
 // ----------------------------------------------------------------------------------------------------------------------
 // k_wp_count / k_wp_merge: a wave takes 64 consecutive documents, one per lane for what is read once (first entry, number of entries, flags,
@@ -667,14 +733,21 @@ BF_WVD void wf_merge_docs(const WfMergeParams &p, int64_t base, bool &over)
         int32_t *out = p.ids_out + wv::bcast(o, first);
         first = lastl + 1;
         int run = 0;
-        for (int64_t t = E0; t < E1; t += 256) {
-            // four consecutive entries per lane: one load; a lane whose four are plain ids stores them in one go (the usual lane); a lane
-            // that holds a word of several pieces (or UnkId) writes its ids one after the other
+        // four consecutive entries per lane: one load (the next trip's is on its way while this trip works); a lane whose four are plain ids stores
+        // them in one go (the usual lane); a lane that holds a word of several pieces (or UnkId) writes its ids one after the other
+        auto load4 = [&](int64_t t, uint32_t (&e)[4]) {
             const int64_t a = t + 4 * lane;
-            uint32_t e[4] = {0u, 0u, 0u, 0u};
+            e[0] = e[1] = e[2] = e[3] = 0u;
+            if (a + 4 <= E1) __builtin_memcpy(e, p.ent + a, 16);
+            else for (int u = 0; u < 4; ++u) if (a + u < E1) e[u] = p.ent[a + u];
+        };
+        uint32_t en[4];
+        load4(E0, en);
+        for (int64_t t = E0; t < E1; t += 256) {
+            const int64_t a = t + 4 * lane;
+            uint32_t e[4] = {en[0], en[1], en[2], en[3]};
             const int nin = a + 4 <= E1 ? 4 : (a < E1 ? (int)(E1 - a) : 0);
-            if (nin == 4) __builtin_memcpy(e, p.ent + a, 16);
-            else for (int u = 0; u < 4; ++u) if (u < nin) e[u] = p.ent[a + u];
+            if (t + 256 < E1) load4(t + 256, en);
             bool flagged = ((e[0] | e[1] | e[2] | e[3]) & WF_ENT_FLAG) != 0u;
             if (p.dbg == 3) flagged = false;
             int xs = 0;

@@ -118,6 +118,7 @@ void launch_wp_wave(const WpWaveParams &p, int variant, hipStream_t s);     // u
 int wp_flat_ranges(int64_t ndocs, int64_t total_bytes);
 void launch_wp_pre(const int64_t *doc_off, int64_t ndocs, int64_t total_bytes, int nranges, int64_t *range_doc, int *unsafe, hipStream_t s);
 void launch_wp_flat(const WfParams &p, int variant, hipStream_t s);
+void launch_wp_units(const WfUnitParams &p, int variant, hipStream_t s);
 void launch_wp_hardlist(const int32_t *dstat, const int *unsafe, int64_t ndocs, int32_t *list, unsigned int *list_n, hipStream_t s);
 void launch_wp_count(const WfMergeParams &p, hipStream_t s);
 void launch_wp_merge(const WfMergeParams &p, hipStream_t s);

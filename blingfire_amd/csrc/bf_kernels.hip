@@ -810,6 +810,32 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
     w.run((int)(blockIdx.x * 4) + wave_in_block(), (int)(gridDim.x * 4));
 }
 
+// the words of the list (bf_flat_body.h wf_units): a wave takes batches of 64 * NU records, batch number = wave number + k * waves
+template <int WPE, int NU, bool STATS>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_wp_units(WfUnitParams p)
+{
+    __shared__ uint32_t lut[128];
+    __shared__ uint16_t cbuf[4][64 * 16 + 8];             // the classes of a word's characters, made up front (the second list)
+    if (threadIdx.x < 128) {
+        WpWaveCold cold; cold.cpmap = p.cpmap; cold.kind = p.kind; cold.nclasses = p.nclasses; cold.status = nullptr; cold.stats = nullptr; cold.no_fast = 0;
+        lut[threadIdx.x] = wf_lut_value(cold, (int)threadIdx.x);
+    }
+    __syncthreads();
+    const int wave = (int)(blockIdx.x * 4) + wave_in_block(), nwaves = (int)(gridDim.x * 4);
+    unsigned long long rounds = 0, batches = 0;
+    for (int r = wave; r < p.nranges; r += nwaves) {
+        const int64_t dlo = p.range_doc[r], dhi = p.range_doc[r + 1];
+        if (dlo >= dhi) continue;
+        const int64_t b0 = p.doc_off[dlo], b1 = p.doc_off[dhi];
+        const unsigned long long nfast = (unsigned long long)p.wrec_cnt[2 * r], nslow = (unsigned long long)p.wrec_cnt[2 * r + 1];
+        const uint32_t *fl = p.wrec + 4 * ((b0 + 3) >> 2), *sl = p.wrec + 4 * ((b1 >> 2) - (int64_t)nslow);       // (the second list grows down from the end: its order does not matter)
+        uint16_t *cb = cbuf[wave_in_block()];
+        for (unsigned long long first = 0; first < nfast; first += 64 * NU) { wf_units<NU, STATS, 0>(p, lut, cb, fl, first, nfast, &rounds); ++batches; }
+        for (unsigned long long first = 0; first < nslow; first += 64) { wf_units<1, STATS, 1>(p, lut, cb, sl, first, nslow, &rounds); wf_units<1, STATS, 2>(p, lut, cb, sl, first, nslow, &rounds); ++batches; }
+    }
+    if (STATS && p.stats && lane_id() == 0) { atomicAdd(&p.stats[8], rounds); atomicAdd(&p.stats[9], batches); }
+}
+
 // the documents the flat program hands back (all of them when the batch is not fit for it), in any order
 __global__ __launch_bounds__(256) void k_wp_hardlist(const int32_t *dstat, const int *unsafe, int64_t ndocs, int32_t *list, unsigned int *list_n)
 {
@@ -884,6 +910,30 @@ void launch_wp_flat(const WfParams &p, int variant, hipStream_t s)
 #endif
     (void)wpe;
     launch_wp_flat_wpe<8>(p, per_cu_override, s);
+}
+
+template <int WPE, int NU>
+static void launch_wp_units_cfg(const WfUnitParams &p, int per_cu_override, hipStream_t s)
+{
+    static int pc = 0;
+    int per_cu = wp_blocks_per_cu(k_wp_units<WPE, NU, false>, pc);
+    if (per_cu_override > 0) per_cu = per_cu_override;
+    const int64_t blocks = (int64_t)device_cus() * per_cu;
+    if (p.stats) hipLaunchKernelGGL((k_wp_units<WPE, NU, true>), dim3((unsigned)blocks), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((k_wp_units<WPE, NU, false>), dim3((unsigned)blocks), dim3(256), 0, s, p);
+}
+
+// variant bits 8..11 (measurements, BF_EXPERIMENTS builds): 1 = eight waves per SIMD, 2 = one word per lane
+void launch_wp_units(const WfUnitParams &p, int variant, hipStream_t s)
+{
+    const int per_cu_override = (variant >> 24) & 0x3f, cfg = (variant >> 8) & 0xf;
+#ifdef BF_EXPERIMENTS
+    if (cfg == 1) { launch_wp_units_cfg<8, 2>(p, per_cu_override, s); return; }
+    if (cfg == 2) { launch_wp_units_cfg<8, 1>(p, per_cu_override, s); return; }
+    if (cfg == 3) { launch_wp_units_cfg<4, 4>(p, per_cu_override, s); return; }
+#endif
+    (void)cfg;
+    launch_wp_units_cfg<6, 2>(p, per_cu_override, s);
 }
 
 void launch_wp_hardlist(const int32_t *dstat, const int *unsafe, int64_t ndocs, int32_t *list, unsigned int *list_n, hipStream_t s)

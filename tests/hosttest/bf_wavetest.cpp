@@ -286,10 +286,11 @@ long bft_emu_bpe_seg_batch(void *hv, const uint8_t *text, const int64_t *doc_off
 // TextToIdsBatch through the FLAT program (bf_flat.h) on the host: k_wp_pre restated (ranges, fitness of the batch), the flat wave program,
 // the list of documents it hands back, the wave program's LIST instance on those, k_wp_count / k_wp_merge (the device sources, in the
 // simulator) and the scan restated.  nranges <= 0: as many ranges as documents allow up to 4 per wave.  Returns the total id count or < 0;
-// stats (optional, 16 counters): [0] chunks [1] plain-ASCII chunks [2] tokens [3] table hits [4] words noted for a unit [5] drains
-// [6] unit rounds [7] documents handed back; [8] = documents on the list, [9] = 1 when the batch was not fit.
+// stats (optional, 16 counters): [0] chunks [1] plain-ASCII chunks [2] tokens [3] table hits [4] words for the list [7] documents handed back;
+// [8] = documents on the list of the wave program, [9] = 1 when the batch was not fit, [10] unit rounds, [11] words on the list.
+// wrec_cap_in > 0: capacity of the word list (tests: a list that is too small).
 long bft_emu_flat_batch(void *hv, const uint8_t *text, long text_bytes, const int64_t *doc_off, long ndocs, int max_ids, int unk, int nwaves, int nranges,
-                        int32_t *ids_out, long ids_cap, int64_t *id_off, unsigned long long *stats)
+                        int32_t *ids_out, long ids_cap, int64_t *id_off, unsigned long long *stats, long wrec_cap_in)
 {
     Model &m = ((Handle *)hv)->m;
     if (!m.error.empty() || m.kind != KIND_WP || !m.wave_ok || !m.flat_ok) return -1;
@@ -325,6 +326,9 @@ long bft_emu_flat_batch(void *hv, const uint8_t *text, long text_bytes, const in
     fp.text = text; fp.doc_off = doc_off; fp.ndocs = ndocs; fp.total_bytes = total;
     fp.range_doc = range_doc.data(); fp.nranges = nranges; fp.next_range = &next_range; fp.unsafe = &unsafe;
     fp.ent = ent.data(); fp.home = home.data(); fp.ent_off = entoff.data(); fp.ent_cnt = entcnt.data(); fp.dstat = dstat.data(); fp.cold = cold;
+    (void)wrec_cap_in;
+    std::vector<uint32_t> wrec((size_t)(total / 4 + 64) * 4, 0xDEADBEEFu); std::vector<int32_t> wrec_cnt((size_t)nranges * 2 + 2, 0);
+    fp.wrec = wrec.data(); fp.wrec_cnt = wrec_cnt.data();
     if (ndocs > 0) {
         std::vector<uint32_t> lut(128);
         for (int i = 0; i < 128; ++i) lut[(size_t)i] = wf_lut_value(cold, i);
@@ -343,6 +347,30 @@ long bft_emu_flat_batch(void *hv, const uint8_t *text, long text_bytes, const in
         for (auto *q : of_wave) delete q;
     }
     if (status) return -5;
+    // ---- k_wp_units
+    if (!unsafe && ndocs > 0) {
+        WfUnitParams up;
+        up.T = fp.T; up.ini = fp.ini; up.ini_l = fp.ini_l; up.max_token_length = fp.max_token_length; up.text = text; up.total_bytes = total;
+        up.wrec = wrec.data(); up.wrec_cnt = wrec_cnt.data(); up.range_doc = range_doc.data(); up.doc_off = doc_off; up.nranges = nranges;
+        up.ent = ent.data(); up.home = home.data(); up.cpmap = cold.cpmap; up.kind = cold.kind; up.nclasses = cold.nclasses; up.stats = stats;
+        std::vector<uint32_t> lut(128);
+        for (int i = 0; i < 128; ++i) lut[(size_t)i] = wf_lut_value(cold, i);
+        unsigned long long rounds = 0, nf_all = 0, ns_all = 0;
+        std::vector<uint16_t> cbuf(64 * 16 + 8);
+        wvemu::run_waves(1, [&]() {
+            for (int r = 0; r < nranges; ++r) {
+                const int64_t dlo = range_doc[(size_t)r], dhi = range_doc[(size_t)r + 1];
+                if (dlo >= dhi) continue;
+                const int64_t b0 = doc_off[dlo], b1 = doc_off[dhi];
+                const unsigned long long nfast = (unsigned long long)wrec_cnt[2 * (size_t)r], nslow = (unsigned long long)wrec_cnt[2 * (size_t)r + 1];
+                const uint32_t *fl = up.wrec + 4 * ((b0 + 3) >> 2), *sl = up.wrec + 4 * ((b1 >> 2) - (int64_t)nslow);
+                for (unsigned long long first = 0; first < nfast; first += 128) wf_units<2, true, 0>(up, lut.data(), cbuf.data(), fl, first, nfast, &rounds);
+                for (unsigned long long first = 0; first < nslow; first += 64) { wf_units<1, true, 1>(up, lut.data(), cbuf.data(), sl, first, nslow, &rounds); wf_units<1, true, 2>(up, lut.data(), cbuf.data(), sl, first, nslow, &rounds); }
+                if (wvemu::g_cur->lane == 0) { nf_all += nfast; ns_all += nslow; }
+            }
+        });
+        if (stats) { stats[10] = rounds; stats[11] = nf_all; stats[12] = ns_all; }
+    }
     // ---- k_wp_hardlist
     unsigned int list_n = 0;
     for (long d = 0; d < ndocs; ++d) if (unsafe || (dstat[(size_t)d] & WF_D_HARD)) list[list_n++] = (int32_t)d;

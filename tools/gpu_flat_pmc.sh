@@ -6,7 +6,7 @@ O=$PWD/gpurun_out/flat_pmc; mkdir -p $O
 root=${GRAFT_REPO_ROOT:-$PWD}
 V=${1:-3}
 cd /tmp
-for set in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_ANY" "FETCH_SIZE WRITE_SIZE" "SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_SMEM SQ_INSTS_FLAT SQ_WAVES SQ_INST_CYCLES_VMEM_WR SQ_INST_CYCLES_VMEM_RD"; do
+for set in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_ANY"; do
   rm -rf /tmp/fl_pmc
   timeout 300 rocprofv3 --pmc $set --kernel-trace -d /tmp/fl_pmc -o pmc -- python $root/bench.py --no-cpu-baseline --no-extra-timings --verify 0 --steps 2 --warmup 1 --docs 2500000 --variant $V > /dev/null 2>> $O/pmc.err
   python - /tmp/fl_pmc >> $O/pmc_v$V.txt 2>&1 <<'PY'
