@@ -1,0 +1,182 @@
+"""CPU: the flat program of the WordPiece path (blingfire_amd/csrc/bf_flat_body.h -- the sources the GPU kernels k_wp_flat, k_wp_units,
+k_wp_count and k_wp_merge run) executed inside the 64-fibre wave simulator of tests/hosttest/wave_emu.h, with k_wp_pre, the list of
+the documents it hands back, the wave program's LIST instance on those and the scan restated around it (tests/hosttest/bf_wavetest.cpp
+bft_emu_flat_batch), against the oracle.  What a per-lane emulation cannot cover: ranges that ignore document boundaries, the token list
+and its look-up trips, the word lists of a range, the streaming count / merge over contiguous pieces, and every way a document is handed
+back (a run of more than 48 bytes, an element the automaton itself decides, a batch that is not fit)."""
+import ctypes
+import random
+
+import numpy as np
+import pytest
+
+import bfutil
+import blingfire_amd as bf
+
+WP_MODELS = ["bert_base_tok.bin", "bert_base_cased_tok.bin", "bert_chinese.bin"]
+# (max_ids, unk, waves, ranges): ranges 0 = four per wave (as many as documents allow)
+CONFS = [(512, 100, 1, 0), (512, 100, 2, 3), (16, 7, 1, 1), (64, 5, 3, 7), (0, 100, 2, 1), (512, 100, 2, 1)]
+
+
+@pytest.fixture(scope="module")
+def ht():
+    L = ctypes.CDLL(bfutil.HOSTTEST_LIB)
+    L.bft_load.restype = ctypes.c_void_p
+    L.bft_load.argtypes = [ctypes.c_char_p]
+    L.bft_free.argtypes = [ctypes.c_void_p]
+    L.bft_flat_ok.argtypes = [ctypes.c_void_p]
+    L.bft_flat_words.argtypes = [ctypes.c_void_p]
+    L.bft_emu_flat_batch.restype = ctypes.c_long
+    L.bft_emu_flat_batch.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_long, ctypes.c_void_p, ctypes.c_long, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                     ctypes.c_int, ctypes.c_void_p, ctypes.c_long, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_long]
+    return L
+
+
+def flat_batch(ht, h, text, off, max_ids, unk, nwaves, nranges):
+    nd = len(off) - 1
+    cap = len(text) + 16
+    ids = np.full(cap, -9, dtype=np.int32)
+    ido = np.zeros(nd + 1, dtype=np.int64)
+    st = np.zeros(16, dtype=np.uint64)
+    text = np.ascontiguousarray(text)
+    r = ht.bft_emu_flat_batch(h, text.ctypes.data, len(text), off.ctypes.data, nd, max_ids, unk, nwaves, nranges, ids.ctypes.data, cap, ido.ctypes.data, st.ctypes.data, 0)
+    return r, ids[:max(r, 0)], ido, st
+
+
+def check(ht, model, docs, confs, want=None):
+    mp = bfutil.model_path(model)
+    h = ht.bft_load(mp.encode())
+    assert ht.bft_flat_ok(h) == 1
+    ora = bfutil.oracle()
+    ho = ora.load(mp)
+    text, off = docs if isinstance(docs, tuple) else bf.pack_docs(docs)
+    last = None
+    for (mx, unk, nw, nr) in confs:
+        r, ids, ido, st = flat_batch(ht, h, text, off, mx, unk, nw, nr)
+        gids, goff = ora.batch(ho, text, off, mx, unk)
+        assert r >= 0, (model, r)
+        if not (np.array_equal(ido, goff) and np.array_equal(ids, gids)):
+            for d in range(len(off) - 1):
+                a, b = ids[ido[d]:ido[d + 1]], gids[goff[d]:goff[d + 1]]
+                assert np.array_equal(a, b), (model, (mx, unk, nw, nr), d, bytes(text[off[d]:off[d + 1]])[:80], a.tolist()[:20], b.tolist()[:20])
+        if want is not None:
+            want(st)
+        last = st
+    ora.free(ho)
+    ht.bft_free(h)
+    return last
+
+
+def test_flat_form_is_proven_for_the_bert_lexers_only(ht):
+    for model, want in [(m, 1) for m in WP_MODELS] + [("wbd.bin", 0), ("sbd.bin", 0), ("wbd_chuni.bin", 0), ("xlnet.bin", 0)]:
+        if not bfutil.have_model(model):
+            continue
+        h = ht.bft_load(bfutil.model_path(model).encode())
+        assert ht.bft_flat_ok(h) == want, model
+        if want:
+            assert ht.bft_flat_words(h) > 5000        # the one-piece words of <= 9 characters of the vocabulary
+        ht.bft_free(h)
+
+
+@pytest.mark.parametrize("model", WP_MODELS)
+def test_adversarial_and_fuzz(ht, model):
+    if not bfutil.have_model(model):
+        pytest.skip("model not present")
+    check(ht, model, list(bfutil.ADVERSARIAL), CONFS)
+    check(ht, model, bfutil.fuzz_docs(300, seed=3), CONFS[:4])
+    check(ht, model, bfutil.fuzz_docs(200, seed=17, maxwords=200), [(512, 100, 2, 0), (512, 100, 1, 1)])
+
+
+@pytest.mark.parametrize("model", WP_MODELS)
+def test_corpora(ht, model):
+    if not bfutil.have_model(model):
+        pytest.skip("model not present")
+    # the metric's documents (most blocks of 64 documents stream; several ranges per wave and one range for all)
+    st = check(ht, model, bfutil.gen_workload("headline512", 300), [(512, 100, 2, 0), (512, 100, 2, 1), (40, 100, 1, 2)])
+    assert st[3] > 0.6 * st[2]                        # most tokens are answered by the table
+    check(ht, model, bfutil.gen_workload("config2", 600), [(512, 100, 3, 0), (512, 100, 2, 1), (30, 100, 2, 1)])
+
+
+def test_document_shapes(ht):
+    model = bfutil.bert_model_name()
+    rnd = random.Random(5)
+    words = [b"the", b"of", b"unaffable", b"qzxjkvw", "café".encode(), "naïve".encode(), b"e-mail", b"3,000.50", "日本語".encode(), b"internationalization", b"x"]
+    # thousands of one- and two-byte documents, empty documents in runs, documents that end inside a chunk, at its end, one byte behind it
+    tiny = [rnd.choice([b"a", b"", b"", b"to", b".", b" ", b"\xc3\xa9", b"\xff", b"ab"]) for _ in range(3000)]
+    check(ht, model, tiny, [(512, 100, 2, 0), (512, 100, 1, 1), (1, 100, 3, 5)])
+    edges = []
+    for n in (1, 7, 8, 9, 63, 64, 65, 511, 512, 513, 1023, 1024, 1025, 1536):
+        for fill in (b"a ", b"ab, ", "é ".encode(), b"word "):
+            edges.append((fill * (n // len(fill) + 1))[:n])
+    check(ht, model, edges, [(512, 100, 1, 1), (2000, 100, 2, 0)])
+    mixed = [b" ".join(rnd.choice(words) for _ in range(rnd.randint(0, 120))) for _ in range(200)]
+    check(ht, model, mixed, [(512, 100, 2, 0), (512, 100, 3, 1), (5, 100, 1, 2)])
+
+
+def test_handed_back(ht):
+    model = bfutil.bert_model_name()
+    # runs of more than 48 bytes (one that crosses a chunk, one that fills several chunks), an element the automaton itself decides ('['),
+    # next to documents the flat program keeps: only the former go to the wave program
+    docs = [b"plain words only", b"a" * 49, b"fine again", b"b" * 700 + b" tail", b"with [UNK] inside", b"x" * 48, b"ok " * 100, (b"q" * 300 + b" ") * 5, b"[", b"end"]
+
+    def want(st):
+        assert st[8] == 5 and st[9] == 0, st.tolist()          # five documents on the list; the batch was fit
+
+    check(ht, model, docs, [(512, 100, 1, 1), (512, 100, 2, 0), (3, 100, 2, 3)], want)
+    # words of 17 .. 48 bytes and words with characters outside ASCII: the second list of a range
+    longw = [("über" + "x" * k).encode() + b" " + b"y" * (17 + k) + b" fin" for k in range(0, 31)]
+    check(ht, model, longw, [(512, 100, 1, 1), (512, 100, 2, 0)])
+
+
+def test_batch_not_fit(ht):
+    model = bfutil.bert_model_name()
+    # a document of more than 4 MiB: the whole batch is handed to the wave program
+    big = (b"word " * 900000)[:(1 << 22) + 5]
+    text, off = bf.pack_docs([b"small one", big, b"small two"])
+
+    def want(st):
+        assert st[9] == 1 and st[8] == 3, st.tolist()
+
+    check(ht, model, (text, off), [(64, 100, 2, 0)], want)
+
+
+def test_invalid_utf8_everywhere(ht):
+    model = bfutil.bert_model_name()
+    rnd = random.Random(9)
+    bad = [b"\xff", b"\xc3", b"\xe2\x82", b"\xf0\x9f\x98", b"\x80", b"\xed\xa0\x80", b"\xc0\xaf", b"\xf4\x90\x80\x80"]
+    docs = []
+    for i in range(400):
+        n = rnd.randint(0, 1100)
+        body = bytearray((b"some words, and more " * 60)[:n])
+        if i % 3 == 0 and n > 0:
+            at = rnd.randint(0, n)
+            body[at:at] = rnd.choice(bad)              # at any place: inside a chunk, across a chunk boundary, at the very end
+        if i % 7 == 0:
+            body = bytearray(b"\xef\xbb\xbf") + body   # a BOM at the start is skipped, elsewhere it is a character
+        docs.append(bytes(body))
+    check(ht, model, docs, [(512, 100, 2, 0), (512, 100, 1, 1), (512, 100, 3, 9)])
+
+
+def test_any_batch_hypothesis(ht):
+    hyp = pytest.importorskip("hypothesis")
+    st = hyp.strategies
+    model = bfutil.bert_model_name()
+    mp = bfutil.model_path(model)
+    h = ht.bft_load(mp.encode())
+    ora = bfutil.oracle()
+    ho = ora.load(mp)
+    alphabet = ["a", "b", "the", " ", " ", ",", ".", "é", "日", "[", " ", "ß", "İ", "x" * 50, "﻿", "un", "##ing", "1", "-"]
+    doc = st.lists(st.sampled_from(alphabet), min_size=0, max_size=150).map(lambda xs: "".join(xs).encode())
+    raw = st.binary(min_size=0, max_size=40)
+
+    @hyp.settings(max_examples=60, deadline=None)
+    @hyp.given(st.lists(st.one_of(doc, doc, raw), min_size=1, max_size=90), st.integers(0, 40), st.integers(1, 3), st.integers(0, 6))
+    def run(docs, mx, nw, nr):
+        text, off = bf.pack_docs(docs)
+        r, ids, ido, _ = flat_batch(ht, h, text, off, mx, 100, nw, nr)
+        gids, goff = ora.batch(ho, text, off, mx, 100)
+        assert r >= 0 and np.array_equal(ido, goff) and np.array_equal(ids, gids)
+
+    run()
+    ora.free(ho)
+    ht.bft_free(h)

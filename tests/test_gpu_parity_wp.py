@@ -140,21 +140,50 @@ def test_wave_program_long_words_and_documents(checker):
             checker.free(hck)
 
 
-def test_wave_program_instances_agree(checker):
-    """every instance of k_wp_wave a BfSetVariant configuration selects and that computes the right answer -- the shipped one (TRIM 15), the one
-    of round 3 (12), the single TRIM steps (7, 9, 10, 11, 13) and the occupancy / units-phase experiments (1, 2, 4, 5, 6) -- gives the checker's ids"""
+def test_flat_wave_and_lane_programs_agree(checker):
+    """the three ways a WordPiece batch can take -- the flat program (bf_flat.h: what large batches take; BfSetVariant 4 = every batch), the wave
+    program (5 = never the flat one: what small batches and the documents the flat program hands back take) and the lane-per-document kernels
+    (2) -- give the checker's ids on the same inputs; 3 = the default choice by batch size"""
+    import random
+    rnd = random.Random(23)
+    for model in [m for m in ("bert_base_tok.bin", "bert_base_cased_tok.bin", "bert_chinese.bin") if bfutil.have_model(m)]:
+        h = bf.load_model(bfutil.model_path(model))
+        hck = checker.load(bfutil.model_path(model))
+        try:
+            docs = list(bfutil.ADVERSARIAL) + bfutil.fuzz_docs(1500, seed=19) + [("a" * 700 + " b").encode(), ("x " * 600).encode()]
+            text, off = bfutil.gen_workload("headline512", 3000)
+            raw = text.tobytes()
+            docs += [raw[off[d]:off[d + 1]] for d in range(3000)]
+            # what the flat program hands back or treats apart: runs of more than 48 bytes, '[', words of 17 .. 48 bytes, words with characters outside
+            # ASCII, thousands of tiny and empty documents, invalid UTF-8 at any place
+            docs += [b"a" * 49, b"b" * 700 + b" tail", b"with [UNK] inside", b"x" * 48, (b"q" * 300 + b" ") * 5, b"["]
+            docs += [("über" + "x" * k).encode() + b" " + b"y" * (17 + k) + b" fin" for k in range(0, 31)]
+            docs += [rnd.choice([b"a", b"", b"", b"to", b".", b" ", b"\xc3\xa9", b"\xff", b"ab"]) for _ in range(4000)]
+            for i in range(300):
+                body = bytearray((b"some words, and more " * 60)[:rnd.randint(0, 1100)])
+                if i % 2 == 0 and body:
+                    at = rnd.randint(0, len(body))
+                    body[at:at] = rnd.choice([b"\xff", b"\xc3", b"\xe2\x82", b"\xf0\x9f\x98", b"\x80", b"\xed\xa0\x80"])
+                docs.append(bytes(body))
+            for variant in (4, 5, 3, 2):
+                bf.lib().BfSetVariant(h, variant)
+                for max_ids, unk in ((512, 100), (5, 7)):
+                    _compare(h, checker, hck, docs, max_ids, unk)
+        finally:
+            bf.free_model(h)
+            checker.free(hck)
+
+
+def test_flat_program_batch_not_fit(checker):
+    """a batch with a document of more than 4 MiB is not taken by the flat program (k_wp_pre): every document goes to the wave program, the answer is the same"""
     model = bfutil.bert_model_name()
     h = bf.load_model(bfutil.model_path(model))
     hck = checker.load(bfutil.model_path(model))
     try:
-        docs = list(bfutil.ADVERSARIAL) + bfutil.fuzz_docs(1500, seed=19) + [("a" * 700 + " b").encode(), ("x " * 600).encode()]
-        text, off = bfutil.gen_workload("headline512", 3000)
-        raw = text.tobytes()
-        docs += [raw[off[d]:off[d + 1]] for d in range(3000)]
-        for cfg in (0, 12, 7, 9, 10, 11, 13, 1, 2, 4, 5, 6):
-            bf.lib().BfSetVariant(h, 3 | (cfg << 8))              # 3 = the low byte of a fresh handle's variant
-            for max_ids, unk in ((512, 100), (5, 7)):
-                _compare(h, checker, hck, docs, max_ids, unk)
+        big = (b"word " * 900000)[:(1 << 22) + 5]
+        docs = [b"small one", big, b"small two"] + bfutil.fuzz_docs(100, seed=2)
+        bf.lib().BfSetVariant(h, 4)
+        _compare(h, checker, hck, docs, 1 << 22, 100)
     finally:
         bf.free_model(h)
         checker.free(hck)

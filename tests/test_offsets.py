@@ -83,8 +83,8 @@ def test_gpu_offsets_match_checker(model):
     hck = ck.load(bfutil.model_path(model))
     try:
         docs = _docs(1200, 53)
-        # WordPiece models in unit form: the wave program's offsets instance as shipped, and the one without the TRIM bits (configuration 12)
-        for mx, unk, variant in ((256, 100, 3), (3, 0, 3), (256, 100, 3 | (12 << 8))):
+        # WordPiece models in unit form: the wave program's offsets instance; variant 2: the lane-per-document kernels
+        for mx, unk, variant in ((256, 100, 3), (3, 0, 3), (256, 100, 2)):
             if variant != 3 and bf.lib().BfModelKind(h) != 0:
                 continue
             bf.lib().BfSetVariant(h, variant)                     # 3 = the default of a fresh handle
