@@ -2,16 +2,17 @@
 //
 // Reproduces FATokenSegmentationTools_1best_bpe_t<int>::Process (cl/inc/FATokenSegmentationTools_1best_bpe_t.h:126-316) and the id
 // loop of TextToIdsWithOffsets_sp (tokdll:1509-1532) on the class stream the prologue kernel produced (k_prep_sp), for models whose
-// load-time analysis (bf_model.cpp, Model::bpe_wave_ok) proves (gpt2.bin, bpe_example*.bin; the flavour with merge ranks needs a
-// rank-ordered key and is not covered yet):
+// load-time analysis (bf_model.cpp, Model::bpe_wave_ok) proves (gpt2.bin, bpe_example*.bin, and -- the flavour with merge ranks, whose arcs are
+// ordered by the entry's place in "rank descending, id ascending": prio / place_id, 20 bits of place in the keys here, a larger place hands the
+// document back -- roberta.bin):
 //   (a) m_fFastBpe (bpe-opt): the collection loop takes a whole word as ONE arc and jumps behind it (:189-206,228-230);
 //   (b) no vocabulary entry has U+2581 behind its first position: an arc never leaves the stretch from one U+2581 to the next
 //       ("word"), so every word is a segment of the merge procedure of its own (:234-313: an arc is applied depending on the
 //       interior marks of the positions it covers only);
 // What can still couple two words is the unknown arc of a start position without any arc, which merges with an unknown arc right before
 // it (:212-225): a unit that meets such a start -- or a symbol outside the alphabet -- hands its document back.  So does a word of more
-// than BW_WORD_MAX positions or with more arcs than the lane's window holds (flags[d] = 1, no ids): the lane-per-document kernels
-// redo those documents from scratch.  Measured with the oracle on the config-3 corpus (gpt2.bin): 80 % of the words are one entry,
+// than BW_WORD_MAX positions or with more arcs than the lane's window holds (flags[d] = 1, no ids): k_bpe_seg (bf_bpe_seg_body.h, one wave per
+// document, keys with 22 bits of priority; launch_bpe_seg_flags) redoes those documents from scratch.  Measured with the oracle on the config-3 corpus (gpt2.bin): 80 % of the words are one entry,
 // 5.7 % of the documents are handed back (a word with more than 32 arcs of more than one element).
 //
 //   fill    a chunk of 512 stream elements goes into the LDS ring, eight per lane; words = [a U+2581 (or the document's first

@@ -150,6 +150,10 @@ struct Handle {
     int device = 0;
     int variant = 3;
     std::mutex mu;
+    // held while the ids of a batch wait in this handle's buffers (w_ids / w_starts / w_ends) for their place in the caller's array: a range of a
+    // sharded call from its kernels to its copy out (run_host_sharded), any other host-buffer call for its whole duration -- the second call
+    // on a sharded handle (or a call on the handle of range 0 itself) cannot overwrite what the first has not fetched yet
+    std::mutex defer_mu;
     // device tables
     DevBuf t_wbd, t_info, t_acts, t_cp_l1, t_cp_pages, t_multi, t_i2w_off, t_i2w_data;
     DevBuf t_kind;                                               // unit-form lexers: what a walk that starts on each class does (bf_wave.h)
@@ -291,6 +295,11 @@ Handle *make_handle(const uint8_t *img, size_t size)
              upload(h->t_cp_l1, m.sp_cpmap.l1) && upload(h->t_cp_pages, m.sp_cpmap.pages) && upload(h->t_multi, m.sp_multi_pool, 16);
         if (m.kind == KIND_BPE_MERGES) ok = ok && upload(h->t_bpe_prio, m.bpe_prio, 16) && upload(h->t_bpe_place, m.bpe_place_id, 16);
         if (m.kind == KIND_UNIGRAM) ok = ok && upload(h->t_segscore, m.seg_score, 16);
+    }
+    if ((m.kind == KIND_BPE || m.kind == KIND_BPE_OPT || m.kind == KIND_BPE_MERGES) && !m.bpe_seg_ok) {
+        // k_bpe_seg (the kernel every BPE document can end up in) packs an arc's id into 20 bits, its length - 1 into 8 and a place into 21
+        g_last_error = "BPE model outside the limits of the segmenter (ids in [0, 2^20), entries of at most 256 symbols, ranks that order)";
+        fprintf(stderr, "[blingfire_amd] %s\n", g_last_error.c_str()); delete h; return nullptr;
     }
     if (m.has_i2w) ok = ok && upload(h->t_i2w_off, m.i2w_off, 4) && upload(h->t_i2w_data, m.i2w_data, 16);
     ok = ok && hip_ok(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking), "hipStreamCreate");
@@ -490,7 +499,7 @@ int run_device(Handle *h, const char *d_text, const int64_t *d_doc_off, int64_t 
         sg.ids_tmp = h->w_tmp.as<int32_t>(); sg.counts = h->w_counts.as<int32_t>(); sg.span_tmp = want_off ? h->w_span.as<int32_t>() : nullptr; sg.max_ids = max_ids; sg.unk = unk; sg.status = status;
         sg.best = nullptr; sg.arcs = nullptr; sg.tos = nullptr; sg.idsv = nullptr; sg.inter = nullptr; sg.bm_words = 0; sg.fb_list = nullptr; sg.fb_count = nullptr;
         sg.big_pool = nullptr; sg.big_cap = 0; sg.big_used = (unsigned long long *)(h->w_misc.as<char>() + 32);     // zeroed with the status word above
-        sg.big_need = (unsigned long long *)(h->w_misc.as<char>() + 40);
+        sg.big_need = (unsigned long long *)(h->w_misc.as<char>() + 224);      // (not among the words a launch clears: the chunks of a pipelined host call add up in it, run_host clears it)
         sg.bpe_prio = nullptr; sg.bpe_place_id = nullptr; sg.bpe_unk_prio = 0; sg.bpe_prio_bits = m.bpe_prio_bits; sg.seg_stats = nullptr;
         if (m.kind == KIND_UNIGRAM) sg.best = h->w_s1.as<SegBest>();
         else {
@@ -771,17 +780,21 @@ int64_t run_host(Handle *h, const char *text, const int64_t *doc_off, int64_t nd
 {
     if (ndocs < 0 || !doc_off || (ndocs > 0 && !text && doc_off[ndocs] > doc_off[0])) return BF_E_ARG;
     if (ndocs > 0 && doc_off[ndocs] - doc_off[0] < 0) return BF_E_ARG;
+    std::unique_lock<std::mutex> dl(h->defer_mu, std::defer_lock);
+    if (!defer_ids) dl.lock();                                    // (a range of a sharded call holds it already, until its ids are out)
     std::lock_guard<std::mutex> lock(h->mu);
     DeviceGuard dg(h->device); if (!dg.ok) return BF_E_DEVICE;
     // A BPE document whose arcs do not fit the pool costs that document only (count 0, BF_STATUS_POOL) -- a caller of the host-buffer
     // API never sees it: the pool grows by what did not fit and the batch runs again (the reference collects into an unbounded
     // std::vector, ..._bpe_t.h:143-144)
     for (int attempt = 0; attempt < 8; ++attempt) {
+        const bool is_bpe = h->m.kind == KIND_BPE || h->m.kind == KIND_BPE_OPT || h->m.kind == KIND_BPE_MERGES;
+        if (is_bpe && !hip_ok(hipMemset(h->w_misc.as<char>() + 224, 0, 8), "hipMemset")) return BF_E_DEVICE;      // bytes the pool lacked, over all launches of this attempt
         const int64_t r = run_host_locked(h, text, doc_off, ndocs, ids_out, ids_cap, id_off_out, max_ids, unk, starts_out, ends_out, words, first_doc_nonempty, defer_ids);
         if (r != BF_RETRY_POOL) return r;
         (void)hipDeviceSynchronize();
         unsigned long long need = 0;
-        if (!hip_ok(hipMemcpy(&need, h->w_misc.as<char>() + 40, 8, hipMemcpyDeviceToHost), "D2H pool need")) return BF_E_DEVICE;
+        if (!hip_ok(hipMemcpy(&need, h->w_misc.as<char>() + 224, 8, hipMemcpyDeviceToHost), "D2H pool need")) return BF_E_DEVICE;
         const size_t want = std::max(h->w_big.cap * 2, h->w_big.cap + (size_t)need + (size_t)(need >> 2) + ((size_t)1 << 20));
         h->bpe_pool_bytes = want;
         if (!h->w_big.reserve(want)) { g_last_error = "the arc pool of a BPE document does not fit the device memory"; return BF_E_DEVICE; }
@@ -1029,7 +1042,7 @@ int run_dict_device(Handle *h, const int32_t *d_keys, const int64_t *d_key_off, 
     // keys are normalised unless (no ignore-case, left-to-right): m_NoNorm, FADictInterpreter_t.h:203-205.  Ignore-case: fold + charmap in one map
     const bool nrm = m.dict_ignore_case || (m.dict_direction != 0 && m.dict_has_charmap);
     p.D.nrm_l1 = nrm ? h->t_dn_l1.as<uint16_t>() : nullptr; p.D.nrm_pages = nrm ? h->t_dn_pages.as<uint32_t>() : nullptr; p.D.nrm_pool = nrm ? h->t_dn_pool.as<int32_t>() : nullptr;
-    p.D.k2i = h->t_k2i.as<int32_t>(); p.D.k2i_n = (int)m.k2i.size(); p.D.r2l = m.dict_direction != 0 ? 1 : 0;
+    p.D.k2i = h->t_k2i.as<int32_t>(); p.D.k2i_n = (int)m.k2i.size(); p.D.r2l = m.dict_direction != 0 ? 1 : 0; p.D.ignore_case = m.dict_ignore_case ? 1 : 0;
     p.rows = h->t_rows.as<int32_t>(); p.stride = m.info_stride; p.min_key = m.info_min_key; p.nrows = m.info_stride > 0 ? (int)(m.info_rows.size() / (size_t)m.info_stride) : 0;
     p.keys = d_keys; p.key_off = d_key_off; p.nkeys = nkeys;
     p.info_ids = d_info_ids ? d_info_ids : h->w_dids.as<int32_t>(); p.ret = d_ret ? d_ret : h->w_dret.as<int32_t>(); p.counts = h->w_counts.as<int32_t>();
@@ -1238,6 +1251,7 @@ int64_t run_host_sharded(Handle *h, const std::vector<Handle *> &shards, const c
                 Handle *c = shards[(size_t)g];
                 const int64_t lo = bounds[(size_t)g], nd = bounds[(size_t)g + 1] - lo;
                 int64_t r = 0;
+                std::unique_lock<std::mutex> dl(c->defer_mu);           // from the range's kernels to the copy of its ids: nobody else uses this handle's id buffers
                 if (nd > 0) {
                     // the range's offsets land in the caller's array at once, relative to the range.  Entry lo + nd is also the first entry of the
                     // next range: the boundary entries are set after the join

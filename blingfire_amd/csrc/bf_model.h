@@ -129,7 +129,7 @@ struct Model {
     // no IW_ANY), so top-level tokens can be found for many start positions at once and every word can be looked up by a lane
     // of its own.  wave_kind[class]: what a walk that STARTS on this class does (bf_wave.h WK_*), proven from the automaton.
     bool wave_ok = false; std::string wave_why;        // wave_why: the first condition that failed (diagnostics, tests)
-    bool bpe_wave_ok = false;          // bpe-opt model whose entries never contain U+2581 behind their first symbol: bf_bpe_wave_body.h applies
+    bool bpe_wave_ok = false;          // bpe-opt or merge-rank model whose entries never contain U+2581 behind their first symbol: bf_bpe_wave_body.h applies
     std::vector<uint8_t> wave_kind;
     uint32_t wave_solo_info = 0;                       // action info of every WK_SOLO token
     // "Flat form" (bf_flat.h): a unit-form lexer whose run and solo tokens both call ONE vocabulary function.  The whole-word answers of that

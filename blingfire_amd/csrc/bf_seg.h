@@ -446,6 +446,7 @@ struct DictTables {
     const uint16_t *nrm_l1; const uint32_t *nrm_pages; const int32_t *nrm_pool;   // [pos-dict] charmap (bf_model.h dict_charmap), nullptr = none
     const int32_t *k2i; int k2i_n;
     int r2l;                                                    // PARAM_DIRECTION != l2r
+    int ignore_case;                                            // the dictionary folds its keys (then the charmap is applied in place: a buffer of 300)
 };
 constexpr int DICT_MAX_WORD = 300, DICT_NORM_BUF = 600;
 constexpr uint32_t DICT_CLS_NONE = 0xFFFFFu, DICT_NORM_NONE = 0xFFFFFFFFu;
@@ -488,7 +489,9 @@ BF_HD int dict_info_id(const DictTables &D, const int32_t *key, int n)
             const int c = v == DICT_NORM_NONE ? 1 : (int)(v >> 24) == 11 ? 1 : (int)(v >> 24);
             len += c;
         }
-        if (len > DICT_NORM_BUF) return w.id(D);              // counts as the empty word
+        // (an ignore-case dictionary normalises IN PLACE, through a buffer of MaxWordLen = 300: FADictInterpreter_t.h:231-247, FANormalizeWord with
+        // pIn == pOut; the r2l-only way has the 600 of its own buffer)
+        if (len > (D.ignore_case ? DICT_MAX_WORD : DICT_NORM_BUF)) return w.id(D);              // counts as the empty word
     }
     for (int t = 0; t < n; ++t) {
         const int i = D.r2l ? n - 1 - t : t;

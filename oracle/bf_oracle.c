@@ -1298,7 +1298,7 @@ static int k2i_get_at(const uint8_t *img, int idx)
  *   :203-205  m_NoNorm = no transformation && !ignore-case && direction == l2r: then the word is looked up AS IS -- the
  *             [pos-dict] charmap is NOT applied (it only is inside Normalize(), i.e. for r2l / ignore-case dictionaries)
  *   :211-279  Normalize: lower-casing (ignore-case), FANormalizeWord with the charmap (FAUtils_cl.h:441-487: a result longer
- *             than the 600-element buffer counts as length 0), reversal for r2l
+ *             than the buffer -- 600 elements, 300 when the word was lower-cased first: then it is normalised in place -- counts as length 0), reversal for r2l
  *   :283-301  GetInfoId_mph: FAMphInterpretTools_t::GetId (FAMphInterpretTools_t.h:97-122: walk every symbol, add the output
  *             weights, the last state must be final) then K2I */
 int bfo_dict_get_info_id(const bfo_model *m, const int *in, int n)
@@ -1310,7 +1310,8 @@ int bfo_dict_get_info_id(const bfo_model *m, const int *in, int n)
     if (m->dict_ignore_case || m->direction != 0) {           /* !m_NoNorm: Normalize (:211-279) */
         int low[300];
         if (m->dict_ignore_case) { for (i = 0; i < n; ++i) low[i] = bfo_tolower(in[i]); w = low; }      /* :231-238 */
-        if (m->dict_charmap.set) { len = normalize(w, n, tmp, NULL, 600, &m->dict_charmap); if (len < 0 || len > 600) len = 0; w = tmp; }
+        /* FAUtils_cl.h:441-487: in place (the ignore-case way: pSrc == pOut) the result goes through Tmp[MaxWordLen = 300], else into the 600 of pOut */
+        if (m->dict_charmap.set) { const int lim = m->dict_ignore_case ? 300 : 600; len = normalize(w, n, tmp, NULL, 600, &m->dict_charmap); if (len < 0 || len > lim) len = 0; w = tmp; }
         if (m->direction != 0) { for (i = 0; i < len; ++i) buf[i] = w[len - 1 - i]; w = buf; }
     }
     state = m->dict_dfa.initial;

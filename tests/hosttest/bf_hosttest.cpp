@@ -386,7 +386,7 @@ int bft_emu_dict_get_info(void *hv, const int32_t *key, int n, int32_t *info_id,
     const bool nrm = m.dict_ignore_case || (m.dict_direction != 0 && m.dict_has_charmap);
     const TwoLevelMap &nm = m.dict_ignore_case ? m.dict_lookup_map : m.dict_charmap;
     D.nrm_l1 = nrm ? nm.l1.data() : nullptr; D.nrm_pages = nrm ? nm.pages.data() : nullptr; D.nrm_pool = nrm ? m.dict_norm_pool.data() : nullptr;
-    D.k2i = m.k2i.data(); D.k2i_n = (int)m.k2i.size(); D.r2l = m.dict_direction != 0;
+    D.k2i = m.k2i.data(); D.k2i_n = (int)m.k2i.size(); D.r2l = m.dict_direction != 0; D.ignore_case = m.dict_ignore_case ? 1 : 0;
     const int id = dict_info_id(D, key, n);
     *info_id = id;
     const int nrows = m.info_stride > 0 ? (int)(m.info_rows.size() / (size_t)m.info_stride) : 0;
