@@ -291,7 +291,7 @@ def run_inproc(args):
         except Exception:
             pci = None
         n_ids = sum(int(b["id_off"][-1].item()) for b in pt["batches"])
-        ranks.append({"rank": pt["g"], "device": pt["dev"].index, "name": props.name, "pci": pci, "cus": props.multi_processor_count, "docs": pt["hi"] - pt["lo"],
+        ranks.append({"rank": pt["g"], "device": pt["dev"].index, "name": props.name, "pci": pci, "cus": props.multi_processor_count, "first_doc": int(pt["lo"]), "docs": int(pt["hi"] - pt["lo"]),
                       "bytes": int(off[pt["hi"]] - off[pt["lo"]]), "ids": n_ids, "seconds": pt["secs"], "status": bf.lib().BfLastStatus(pt["h"]),
                       "kernel_ms": [float(x) / max(args.steps, 1) for x in pt["kms"]]})
     bytes_all, ids_all = int(off[-1]), sum(r["ids"] for r in ranks)
@@ -312,7 +312,7 @@ def run_inproc(args):
                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None, "algorithmic_bytes_per_launch": alg},
            "cpu_baseline": None,
            "verified_docs": verified, "verify": {"checker": ck_kind, "seconds": verify_secs, "method": "exact: id offsets and every id of every document against the CPU checker (array equality)"},
-           "status": max(r["status"] for r in ranks), "ranks": ranks, "backend": None}
+           "status": max(r["status"] for r in ranks), "ranks": ranks, "backend": "inproc"}
     bf.free_model(h)
     print(json.dumps(res))
     return 0
@@ -501,7 +501,7 @@ def main():
         pci = "%04x:%02x:%02x" % (props.pci_domain_id, props.pci_bus_id, props.pci_device_id)
     except Exception:
         pci = None
-    me = {"rank": rank, "device": dev_index, "name": props.name, "pci": pci, "cus": props.multi_processor_count,
+    me = {"rank": rank, "device": dev_index, "name": props.name, "pci": pci, "cus": props.multi_processor_count, "first_doc": first,
           "docs": ndocs, "bytes": total_bytes, "ids": n_ids, "verified_docs": verified, "seconds": my_elapsed, "status": status}
     ranks = [me]
     if dist:

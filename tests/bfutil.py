@@ -357,17 +357,35 @@ def gen_corpus_multi(ndocs, pieces="xlmr", seed=4, mean=512, sd=64, minlen=128, 
     return text, off
 
 
+CONFIG1_LINES = os.path.join(ROOT, "tests", "data", "config1_lines.txt.gz")
+
+
+def config1_lines(ndocs, first_doc=0):
+    """BASELINE.json configs[0] / SURVEY.md section 8(d): the first 10,000 non-empty lines of the reference's own
+    ldbsrc/bert_multi_cased/test.legacy.txt.zip:test.txt (a reference-held fixture, staged under tests/data/ by the snippet in
+    tests/data/README.md: 427,735 bytes, 42.8 per line, real English, no RNG); more than 10,000 documents: the lines again from the top"""
+    import gzip
+    with gzip.open(CONFIG1_LINES, "rb") as f:
+        lines = f.read().split(b"\n")[:-1]
+    docs = [lines[(first_doc + i) % len(lines)] for i in range(ndocs)]
+    off = np.zeros(ndocs + 1, dtype=np.int64)
+    np.cumsum([len(d) for d in docs], out=off[1:])
+    return np.frombuffer(b"".join(docs), dtype=np.uint8).copy(), off
+
+
 def gen_workload(name, ndocs, first_doc=0):
     """the corpus of a named workload (WORKLOADS below): documents [first_doc, first_doc + ndocs)"""
     wl = WORKLOADS[name]
+    if name == "config1" and os.path.exists(CONFIG1_LINES):
+        return config1_lines(ndocs, first_doc)
     if wl.get("multi"):
         return gen_corpus_multi(ndocs, first_doc=first_doc, **wl["multi"])
     return gen_corpus(ndocs, first_doc=first_doc, **wl["gen"])
 
 
 WORKLOADS = {
-    # BASELINE.json configs[0]: the default pattern tokenizer (built-in wbd.bin), TextToWords on short English lines (SURVEY.md section 8d
-    # names 10,000 lines of a reference corpus that does not travel; same shape from the generator: ~43 bytes per line)
+    # BASELINE.json configs[0]: the default pattern tokenizer (built-in wbd.bin), TextToWords on short English lines: the 10,000 lines SURVEY.md
+    # section 8(d) names (tests/data/config1_lines.txt.gz, config1_lines() above); the generator only when that fixture is absent
     "config1": dict(model="wbd.bin", gen=dict(seed=1, mean=43, sd=12, minlen=8, maxlen=120), max_ids=0, unk=0),
     # name: generator kwargs + tokenizer call parameters (SURVEY.md §8d)
     "headline512": dict(model=None, gen=dict(seed=20240201, mean=512, sd=64, minlen=128, maxlen=1024), max_ids=512, unk=100),

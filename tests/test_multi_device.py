@@ -140,3 +140,68 @@ def test_in_process_shards_of_the_bench():
     j = _bench(["--gpus", "2", "--inproc"], {"BF_BENCH_SHARE_GPU": "1"})
     assert j["n_gpus"] == 2 and len(j["ranks"]) == 2 and j["verified_docs"] == 40000 and j["status"] == 0
     assert j["config"]["launcher"] == "inproc"
+
+
+@pytest.mark.gpu
+def test_concurrent_calls_on_a_sharded_handle():
+    """two threads call TextToIdsBatch on ONE sharded handle at the same time (documented as safe: host-buffer calls serialise): each gets its own
+    batch's ids -- a range's ids stay in its handle's buffers from its kernels to its copy out, and nobody else may use them meanwhile"""
+    import threading
+    model = bfutil.bert_model_name()
+    ta, oa = _batch(model, 4000, 11)
+    tb, ob = _batch(model, 3500, 12)
+    h = bf.load_model(bfutil.model_path(model))
+    try:
+        wa = bf.text_to_ids_batch(h, (ta, oa), 128, 100)
+        wb = bf.text_to_ids_batch(h, (tb, ob), 128, 100)
+        bf.set_devices(h, [0, 0, 0])
+        bad = []
+
+        def work(text, off, want, n):
+            for _ in range(n):
+                ids, ido = bf.text_to_ids_batch(h, (text, off), 128, 100)
+                if not (np.array_equal(ido, want[1]) and np.array_equal(ids, want[0])):
+                    bad.append(1)
+
+        ts = [threading.Thread(target=work, args=(ta, oa, wa, 6)), threading.Thread(target=work, args=(tb, ob, wb, 6)),
+              threading.Thread(target=work, args=(ta[:oa[50]], oa[:51], (wa[0][:wa[1][50]], wa[1][:51]), 20))]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+        assert not bad
+    finally:
+        bf.free_model(h)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("extra", [[], ["--inproc"]])
+def test_eight_ranks_of_the_bench_on_one_device(extra):
+    """the N = 8 forms of the bench (ranks over torch.distributed; one process with BfSetDevices) before hardware with 8 devices shows up: eight
+    disjoint ranges that cover the corpus, every document verified, status 0 (BF_BENCH_SHARE_GPU=1: all on device 0, over gloo)"""
+    env = dict(os.environ)
+    env["BF_BENCH_SHARE_GPU"] = "1"
+    cmd = [sys.executable, os.path.join(bfutil.ROOT, "bench.py"), "--docs", "200000", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-extra-timings", "--gpus", "8"] + extra
+    out = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=1500)
+    assert out.returncode == 0, out.stderr[-2000:]
+    j = json.loads(out.stdout.strip().splitlines()[-1])
+    assert j["n_gpus"] == 8 and len(j["ranks"]) == 8 and j["verified_docs"] == 200000 and j["status"] == 0
+    docs = sorted((r.get("first_doc", None), r["docs"]) for r in j["ranks"])
+    assert sum(d for _, d in docs) == 200000
+    if all(f is not None for f, _ in docs):                      # the ranges are disjoint and cover the corpus
+        at = 0
+        for f, d in docs:
+            assert f == at
+            at += d
+    assert j.get("backend") in ("gloo", "nccl", "inproc")
+
+
+def test_more_gpus_than_devices_is_refused():
+    """`bench.py --gpus 8` on a box with fewer devices exits non-zero with the stated message instead of reporting an 8-GPU number from fewer (CPU test:
+    this container has none)"""
+    env = dict(os.environ)
+    env.pop("BF_BENCH_SHARE_GPU", None)
+    for extra in ([], ["--inproc"]):
+        out = subprocess.run([sys.executable, os.path.join(bfutil.ROOT, "bench.py"), "--gpus", "8"] + extra, capture_output=True, text=True, env=env, timeout=600)
+        assert out.returncode != 0
+        assert "GPU(s)" in out.stderr

@@ -76,10 +76,12 @@ def test_words_lane_program_on_host_matches_oracle(model):
 
 def test_config1_reference_cpu_case():
     """BASELINE.json configs[0]: default pattern tokenizer on 10k short English lines, CPU reference path only -- the oracle
-    (and the compiled reference when present) agree on a deterministic 10k-line corpus (~43 bytes per line)."""
+    (and the compiled reference when present) agree on the 10,000 lines SURVEY.md section 8(d) names: the first non-empty lines of the
+    reference's own ldbsrc/bert_multi_cased/test.legacy.txt.zip (tests/data/config1_lines.txt.gz, 427,735 bytes)."""
     ora, f = _oracle_fn()
     ho = ora.load(bfutil.model_path("wbd.bin"))
-    text, off = bfutil.gen_corpus(10000, seed=1, mean=43, sd=12, minlen=8, maxlen=120)
+    text, off = bfutil.gen_workload("config1", 10000)
+    assert len(text) == 427735 and len(off) == 10001
     raw = text.tobytes()
     ref = bfutil.reference() if bfutil.have_ref() else None
     if ref:
