@@ -625,8 +625,10 @@ void launch_lex_wp(const WpLexParams &p, int variant, hipStream_t s)
         if (nb < 1) nb = 1;
         const dim3 g2((unsigned)nb), t2(64);
         if (has_any) hipLaunchKernelGGL((k_lex_wp_flat<64, ClsWin, true, 1, false, false, true>), g2, t2, lds2, s, q2);
+#ifdef BF_EXPERIMENTS
         else if (plain && un == 5) hipLaunchKernelGGL(k_lex_wp_plain<5>, g2, t2, lds2, s, q2);
         else if (plain && un == 3) hipLaunchKernelGGL(k_lex_wp_plain<3>, g2, t2, lds2, s, q2);
+#endif
         else if (plain) hipLaunchKernelGGL(k_lex_wp_plain<4>, g2, t2, lds2, s, q2);
         else hipLaunchKernelGGL((k_lex_wp_flat<64, ClsWin, false, 4, false, false, true>), g2, t2, lds2, s, q2);
         return;
@@ -1000,11 +1002,14 @@ static void launch_bpe_wave_cfg(const BpeWaveParams &p, hipStream_t s)
 // against 21.9 and are gone)
 void launch_bpe_wave(const BpeWaveParams &p, int tune, hipStream_t s)
 {
-    if (tune == 1) launch_bpe_wave_cfg<4, 16>(p, s);
-    else if (tune == 2) launch_bpe_wave_cfg<4, 4>(p, s);
-    else if (tune == 3) launch_bpe_wave_cfg<4, 48>(p, s);
-    else if (tune == 6) launch_bpe_wave_cfg<6, 32>(p, s);
-    else launch_bpe_wave_cfg<4, 32>(p, s);
+#ifdef BF_EXPERIMENTS
+    if (tune == 1) { launch_bpe_wave_cfg<4, 16>(p, s); return; }
+    if (tune == 2) { launch_bpe_wave_cfg<4, 4>(p, s); return; }
+    if (tune == 3) { launch_bpe_wave_cfg<4, 48>(p, s); return; }
+    if (tune == 6) { launch_bpe_wave_cfg<6, 32>(p, s); return; }
+#endif
+    (void)tune;
+    launch_bpe_wave_cfg<4, 32>(p, s);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1412,8 +1417,10 @@ void launch_prep_sp(const SpPrepParams &p, hipStream_t s)
     if (p.old_form) hipLaunchKernelGGL(k_prep_sp, dim3((unsigned)blocks), dim3(256), 0, s, p);      // the byte-per-lane form (A/B runs: BfSetVariant bit 0x80)
     // shipped: compiled for eight waves per SIMD (64 VGPRs, 8 bytes of scratch).  Config 4, 10 M documents (profiles/r04_u_prep_waves.txt): six waves
     // (the compiler's own choice, 73 VGPRs) 31.7 ms, seven (72 VGPRs) 30.5, eight 27.3.  BfSetVariant bits 24..27 = 6 / 7: the other instances
+#ifdef BF_EXPERIMENTS
     else if (p.waves == 6) hipLaunchKernelGGL(k_prep_sp8<0>, dim3((unsigned)blocks), dim3(256), 0, s, p);
     else if (p.waves == 7) hipLaunchKernelGGL(k_prep_sp8<7>, dim3((unsigned)blocks), dim3(256), 0, s, p);
+#endif
     else hipLaunchKernelGGL(k_prep_sp8<8>, dim3((unsigned)blocks), dim3(256), 0, s, p);
 }
 
@@ -2358,19 +2365,28 @@ void launch_seg_sp(const SpSegParams &p_in, hipStream_t s)
             int ring = 1; while (ring < p.trie_depth) ring <<= 1;
             const size_t lds = (size_t)ring * 64 * (sizeof(double) + sizeof(uint32_t));
             int per_cu = 0;
+#ifdef BF_EXPERIMENTS
             const bool one_kernel = (p.variant & 0x20) != 0;     // A/B runs: forward and backward pass in one kernel (the form of rounds 2..3)
             const int unroll = p.tune ? p.tune : 3;
             auto kern = one_kernel ? (const void *)k_seg_unigram_lane<3> : unroll == 4 ? (const void *)k_seg_unigram_lane<4, true, 8> : (const void *)k_seg_unigram_lane<3, true, 8>;
+#else
+            const bool one_kernel = false; const int unroll = 3;
+            auto kern = (const void *)k_seg_unigram_lane<3, true, 8>;
+#endif
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 64, lds) != hipSuccess || per_cu <= 0) per_cu = 8;
             (void)hipGetLastError();
             if (p.tune2 > 0 && p.tune2 < per_cu) per_cu = p.tune2;
             unsigned blocks = (unsigned)device_cus() * (unsigned)per_cu;
             if ((int64_t)blocks > (int64_t)b64) blocks = b64;
+#ifdef BF_EXPERIMENTS
             if (one_kernel) hipLaunchKernelGGL(k_seg_unigram_lane<3>, dim3(blocks), dim3(64), lds, s, p, ring);
-            else {
+            else if (unroll == 4) { hipLaunchKernelGGL((k_seg_unigram_lane<4, true, 8>), dim3(blocks), dim3(64), lds, s, p, ring); hipLaunchKernelGGL(k_uni_back, dim3((unsigned)((p.b.ndocs + 255) / 256)), dim3(256), 0, s, p); }
+            else
+#endif
+            {
                 // forward pass (persistent lanes, records out), then the backward pass over every document
-                if (unroll == 4) hipLaunchKernelGGL((k_seg_unigram_lane<4, true, 8>), dim3(blocks), dim3(64), lds, s, p, ring);
-                else hipLaunchKernelGGL((k_seg_unigram_lane<3, true, 8>), dim3(blocks), dim3(64), lds, s, p, ring);
+                (void)one_kernel; (void)unroll;
+                hipLaunchKernelGGL((k_seg_unigram_lane<3, true, 8>), dim3(blocks), dim3(64), lds, s, p, ring);
                 hipLaunchKernelGGL(k_uni_back, dim3((unsigned)((p.b.ndocs + 255) / 256)), dim3(256), 0, s, p);
             }
         }
