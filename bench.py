@@ -233,7 +233,7 @@ def run_inproc(args):
             cap = max(1, min(2 * (b1 - b0 + d1 - d0), (d1 - d0) * max_ids))
             batches.append(dict(d0=d0, d1=d1, text=torch.from_numpy(text[b0:b1]).to(dev), off=torch.from_numpy(off[d0:d1 + 1] - b0).to(dev),
                                 ids=torch.empty(cap, dtype=torch.int32, device=dev), id_off=torch.empty(d1 - d0 + 1, dtype=torch.int64, device=dev)))
-        parts.append(dict(g=g, dev=dev, h=bf.shard_handle(h, g), lo=lo, hi=hi, batches=batches, secs=0.0, kms=np.zeros(5)))
+        parts.append(dict(g=g, dev=dev, h=bf.shard_handle(h, g), lo=lo, hi=hi, batches=batches, secs=0.0, kms=np.zeros(6)))
 
     def run_part(pt, steps, barrier=None, collect=False):
         torch.cuda.set_device(pt["dev"])
@@ -296,7 +296,7 @@ def run_inproc(args):
                       "kernel_ms": [float(x) / max(args.steps, 1) for x in pt["kms"]]})
     bytes_all, ids_all = int(off[-1]), sum(r["ids"] for r in ranks)
     slow = max(parts, key=lambda q: q["secs"])
-    tok_ms = float(slow["kms"][1]) / max(args.steps, 1)
+    tok_ms = float(slow["kms"][5]) / max(args.steps, 1)           # the dominant kernel alone (BfLastKernelMs [5])
     alg = int(off[slow["hi"]] - off[slow["lo"]]) + 4 * ranks[slow["g"]]["ids"] + 16 * (slow["hi"] - slow["lo"])
     bf.lib().BfTokeniseKernel.restype = ctypes.c_char_p
     bf.lib().BfTokeniseKernel.argtypes = [ctypes.c_void_p]
@@ -308,7 +308,7 @@ def run_inproc(args):
                       "model_file": model_name, "total_docs": total_docs, "total_bytes": bytes_all, "total_ids": ids_all, "launcher": "inproc",
                       "sharding": "BfSetDevices: contiguous byte-balanced document ranges (BfShardRanges), a host thread per device, no collective"},
            "gb_input_per_sec": bytes_all * args.steps / elapsed / 1e9, "ids_per_sec": ids_all * args.steps / elapsed,
-           "roofline": {"bound": "hbm", "kernel": "tokenise (%s), slowest range" % kernel_name, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+           "roofline": {"bound": "hbm", "kernel": "%s, slowest range" % kernel_name, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None, "algorithmic_bytes_per_launch": alg},
            "cpu_baseline": None,
            "verified_docs": verified, "verify": {"checker": ck_kind, "seconds": verify_secs, "method": "exact: id offsets and every id of every document against the CPU checker (array equality)"},
@@ -475,11 +475,11 @@ def main():
     torch.cuda.synchronize(dev)
     if dist:
         dist.barrier()
-    kms = np.zeros(5, dtype=np.float64)
+    kms = np.zeros(6, dtype=np.float64)
     per_step = []                       # HIP-event time of every timed step (all its launches), for the median / min of SURVEY.md section 8(d)
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        one = np.zeros(5, dtype=np.float64)
+        one = np.zeros(6, dtype=np.float64)
         step(one)
         kms += one
         per_step.append(float(one[4]))
@@ -517,16 +517,23 @@ def main():
         # algorithmic bytes of one step's launches of the dominant kernel on THIS rank: n_in + 4*n_ids + 16 per document
         alg_bytes = total_bytes + (12 if args.offsets else 4) * n_ids + 16 * ndocs      # with offsets: id + first byte + last byte per id
         tok_ms = float(kms[1])
-        achieved = alg_bytes / (tok_ms * 1e-3) / 1e9 if tok_ms > 0 else 0.0
-        traffic, traffic_stale, l2_hit = None, None, None
+        dom_ms = float(kms[5]) if kms[5] > 0 else tok_ms                # the dominant kernel alone (HIP events around it on the launch stream)
+        step_ms = float(kms[4])
+        achieved = alg_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+        traffic, traffic_stale, l2_hit, traffic_dom, traffic_kernels = None, None, None, None, None
         bf.lib().BfTokeniseKernel.restype = ctypes.c_char_p
         bf.lib().BfTokeniseKernel.argtypes = [ctypes.c_void_p]
         kernel_name = (bf.lib().BfTokeniseKernel(ctypes.c_void_p(h)) or b"").decode()
-        try:   # HBM bytes per step of the dominant kernel from the committed rocprofv3 PMC passes of this same command
+        bf.lib().BfStepKernels.restype = ctypes.c_char_p
+        bf.lib().BfStepKernels.argtypes = [ctypes.c_void_p]
+        step_kernels = (bf.lib().BfStepKernels(ctypes.c_void_p(h)) or b"").decode()
+        try:   # HBM bytes per step -- of ALL kernels of the step, and of the dominant one -- from the committed rocprofv3 PMC passes of this same command
             tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
-            ent = tj.get("%s/%s/%d" % (args.workload, model_name, ndocs))
+            ent = tj.get("%s/%s/%d%s" % (args.workload, model_name, ndocs, "/offsets" if args.offsets else ""))
             if ent:
-                traffic = ent.get("hbm_bytes_per_step", ent["hbm_bytes_per_launch"])
+                traffic = ent.get("hbm_bytes_per_step", ent.get("hbm_bytes_per_launch"))
+                traffic_dom = ent.get("dominant_hbm_bytes_per_step")
+                traffic_kernels = ent.get("kernels")
                 l2_hit = ent.get("l2_hit_rate")
                 # the counters belong to the kernels they were taken of: a profile of another build of csrc/ is flagged
                 traffic_stale = ent.get("csrc_sha") != csrc_sha() or ent.get("kernel") != kernel_name
@@ -544,15 +551,20 @@ def main():
                 "sharding": "static contiguous document ranges, no collective"},
             "gb_input_per_sec": bytes_all * args.steps / elapsed / 1e9,
             "ids_per_sec": ids_all * args.steps / elapsed,
-            "kernel_ms": {"prep": float(kms[0]), "tokenise": tok_ms, "scan": float(kms[2]), "compact": float(kms[3]), "total": float(kms[4])},
+            "kernel_ms": {"prep": float(kms[0]), "tokenise": tok_ms, "scan": float(kms[2]), "compact": float(kms[3]), "total": float(kms[4]), "dominant": dom_ms, "kernels": step_kernels},
             "kernel_ms_per_step": {"median": float(np.median(per_step)) if per_step else None, "min": float(np.min(per_step)) if per_step else None,
                                    "max": float(np.max(per_step)) if per_step else None, "n": len(per_step),
                                    "what": "HIP-event time of one step's launches (prep .. compact), every timed step"},
-            "roofline": {"bound": "hbm", "kernel": "tokenise (%s)" % kernel_name, "achieved": achieved, "peak": HBM_PEAK_GBPS,
+            "roofline": {"bound": "hbm", "kernel": kernel_name, "achieved": achieved, "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_stale": traffic_stale, "l2_hit_rate": l2_hit,
-                         "algorithmic_bytes_per_launch": alg_bytes, "launches_per_step": len(batches),
-                         "note": "achieved = algorithmic bytes of one step (all its launches) / tokenise-kernel time of one step; traffic = FETCH_SIZE + WRITE_SIZE "
-                                 "of the same command (separate rocprofv3 --pmc passes, profiles/traffic.json; traffic_stale: the profile is of another build of csrc/)"},
+                         "kernel_ms": dom_ms, "algorithmic_bytes_per_launch": alg_bytes, "launches_per_step": len(batches),
+                         "traffic_dominant_kernel": traffic_dom, "traffic_by_kernel": traffic_kernels,
+                         "step": {"kernels": step_kernels, "ms": step_ms, "achieved": alg_bytes / (step_ms * 1e-3) / 1e9 if step_ms > 0 else 0.0,
+                                  "frac": (alg_bytes / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if step_ms > 0 else 0.0,
+                                  "what": "the same algorithmic bytes over ALL kernels of the step (prep .. compact)"},
+                         "note": "achieved = algorithmic bytes of one step (all its launches) / time of the dominant kernel (`kernel`) in one step, HIP events around it on the launch "
+                                 "stream; traffic = FETCH_SIZE + WRITE_SIZE of EVERY kernel of the step of the same command (separate rocprofv3 --pmc passes, "
+                                 "profiles/traffic.json: traffic_by_kernel; traffic_dominant_kernel: the dominant kernel's share; traffic_stale: the profile is of another build of csrc/)"},
             "verified_docs": sum(r["verified_docs"] for r in ranks), "verify": {"checker": ck_kind, "threads": cpu_threads, "seconds": verify_secs,
                                                                                "method": "exact: id offsets and every id of every document against the CPU checker (array equality)"},
             "status": max(r["status"] for r in ranks), "ranks": ranks,

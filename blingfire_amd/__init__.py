@@ -463,7 +463,7 @@ def reserve(h, max_docs, max_bytes, want_offsets=False):
 
 
 def last_kernel_ms(h):
-    """[prep, tokenise, scan, compact, total] GPU milliseconds of the last batch call (HIP events on its stream)."""
-    buf = (c_float * 5)()
-    n = lib().BfLastKernelMs(c_void_p(h), buf, 5)
+    """[prep, tokenise, scan, compact, total, dominant kernel] GPU milliseconds of the last batch call (HIP events on its stream)."""
+    buf = (c_float * 6)()
+    n = lib().BfLastKernelMs(c_void_p(h), buf, 6)
     return [buf[i] for i in range(max(n, 0))]

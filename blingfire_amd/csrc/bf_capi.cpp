@@ -93,7 +93,7 @@ struct PinBuf {
     template <class T> T *as() const { return (T *)p; }
 };
 
-enum { EV_BEGIN = 0, EV_PREP, EV_TOK, EV_SCAN, EV_COMPACT, EV_COUNT };
+enum { EV_BEGIN = 0, EV_PREP, EV_TOK, EV_SCAN, EV_COMPACT, EV_DOM0, EV_DOM1, EV_COUNT };      // EV_DOM0 / 1: around the dominant kernel of the step (the one a roofline is about)
 
 // TextToIdsBatch on host buffers, large batches: the batch is cut into chunks that flow through NS slots of page-locked staging
 // and device buffers -- while chunk k is tokenised, chunk k+1 is copied in (CPU threads -> pinned -> DMA) and the ids of the chunks
@@ -412,7 +412,9 @@ int run_device(Handle *h, const char *d_text, const int64_t *d_doc_off, int64_t 
         fp.dstat = h->w_dstat.as<int32_t>(); fp.cold = cold;
         fp.wrec = h->w_wrec.as<uint32_t>(); fp.wrec_cnt = (int32_t *)(h->w_wrec.as<char>() + (size_t)(total_bytes / 4 + 64) * 16);
         if (!hip_ok(hipMemsetAsync(fp.wrec_cnt, 0, (size_t)nranges * 8, s), "hipMemsetAsync")) return BF_E_DEVICE;      // (a range without documents writes nothing)
+        (void)hipEventRecord(h->ev[EV_DOM0], s);
         launch_wp_flat(fp, h->variant, s);
+        (void)hipEventRecord(h->ev[EV_DOM1], s);
         // the words the table did not answer: walked by a kernel of their own
         WfUnitParams up;
         up.T = fp.T; up.ini = fp.ini; up.ini_l = fp.ini_l; up.max_token_length = fp.max_token_length; up.text = b.text; up.total_bytes = total_bytes;
@@ -454,7 +456,9 @@ int run_device(Handle *h, const char *d_text, const int64_t *d_doc_off, int64_t 
         wp.cold.cpmap = DevCpMap{h->t_cp_l1.as<uint16_t>(), h->t_cp_pages.as<uint32_t>()};
         wp.cold.kind = h->t_kind.as<uint8_t>(); wp.cold.nclasses = m.wbd.nclasses; wp.cold.status = status; wp.cold.no_fast = 0;
         wp.cold.stats = h->lex_stats ? (unsigned long long *)(h->w_misc.as<char>() + 64) : nullptr;
+        (void)hipEventRecord(h->ev[EV_DOM0], s);
         if (ndocs > 0) launch_wp_wave(wp, h->variant, s);
+        (void)hipEventRecord(h->ev[EV_DOM1], s);
         (void)hipEventRecord(h->ev[EV_TOK], s);
     } else if (m.kind == KIND_WP) {
         WpPrepParams pp{b, DevCpMap{h->t_cp_l1.as<uint16_t>(), h->t_cp_pages.as<uint32_t>()}, h->t_multi.as<uint16_t>(),
@@ -475,7 +479,9 @@ int run_device(Handle *h, const char *d_text, const int64_t *d_doc_off, int64_t 
         lp.max_ids = max_ids; lp.unk = unk; lp.next_doc = next_doc; lp.status = status; lp.ev_thresh = 0; lp.fetch_thresh = 0; lp.acts_n = (int)m.acts_pool.size(); lp.words = words;
         lp.table_n = (int)(m.wbd_t2.size() > (size_t)LX_T_CLS_MASK + 1 ? m.wbd_t2.size() - ((size_t)LX_T_CLS_MASK + 1) : 0);
         lp.stats = h->lex_stats ? (unsigned long long *)(h->w_misc.as<char>() + 64) : nullptr;
+        (void)hipEventRecord(h->ev[EV_DOM0], s);
         if (ndocs > 0) launch_lex_wp(lp, h->variant, s);
+        (void)hipEventRecord(h->ev[EV_DOM1], s);
         (void)hipEventRecord(h->ev[EV_TOK], s);
     } else {
         const int mul = m.dict_has_charmap ? 2 : 1;
@@ -523,9 +529,17 @@ int run_device(Handle *h, const char *d_text, const int64_t *d_doc_off, int64_t 
             bw.prio = sg.bpe_prio; bw.place_id = sg.bpe_place_id;
             bw.stream = sg.stream; bw.lens = sg.lens; bw.doc_off = b.doc_off; bw.slot_mul = mul; bw.ndocs = ndocs;
             bw.ids_tmp = sg.ids_tmp; bw.counts = sg.counts; bw.flags = h->w_bwflags.as<int32_t>(); bw.max_ids = max_ids; bw.next_doc = next_doc; bw.status = status; bw.scratch = (uint32_t *)sg.arcs; bw.stats = h->lex_stats ? (unsigned long long *)(h->w_misc.as<char>() + 64) : nullptr;
+            (void)hipEventRecord(h->ev[EV_DOM0], s);
             launch_bpe_wave(bw, (h->variant >> 8) & 0xf, s);
+            (void)hipEventRecord(h->ev[EV_DOM1], s);
             launch_bpe_seg_flags(sg, bw.flags, h->w_perm.as<int32_t>(), h->w_hist.as<unsigned int>(), s);
-        } else if (ndocs > 0) launch_seg_sp(sg, s);
+        } else {
+            // (the Unigram lane program records the two events around its forward kernel itself: the sort of the documents comes before it)
+            sg.ev_dom0 = h->ev[EV_DOM0]; sg.ev_dom1 = h->ev[EV_DOM1];
+            if (m.kind != KIND_UNIGRAM || !sg.lane_ok || ndocs <= 0) (void)hipEventRecord(h->ev[EV_DOM0], s);
+            if (ndocs > 0) launch_seg_sp(sg, s);
+            if (m.kind != KIND_UNIGRAM || !sg.lane_ok || ndocs <= 0) (void)hipEventRecord(h->ev[EV_DOM1], s);
+        }
         (void)hipEventRecord(h->ev[EV_TOK], s);
     }
     ScanParams sp{h->w_counts.as<int32_t>(), ndocs, d_id_off, h->w_bsums.as<int64_t>(), nblocks};
@@ -1832,13 +1846,14 @@ int BfLastKernelMs(void *p, float *ms, int n)
     std::lock_guard<std::mutex> lock(h->mu);
     if (!h->ev_valid) return 0;
     if (!hip_ok(hipEventSynchronize(h->ev[EV_COMPACT]), "hipEventSynchronize")) return BF_E_DEVICE;
-    float v[5] = {0, 0, 0, 0, 0};
+    float v[6] = {0, 0, 0, 0, 0, 0};
     (void)hipEventElapsedTime(&v[0], h->ev[EV_BEGIN], h->ev[EV_PREP]);
     (void)hipEventElapsedTime(&v[1], h->ev[EV_PREP], h->ev[EV_TOK]);
     (void)hipEventElapsedTime(&v[2], h->ev[EV_TOK], h->ev[EV_SCAN]);
     (void)hipEventElapsedTime(&v[3], h->ev[EV_SCAN], h->ev[EV_COMPACT]);
     (void)hipEventElapsedTime(&v[4], h->ev[EV_BEGIN], h->ev[EV_COMPACT]);
-    int k = n < 5 ? n : 5;
+    (void)hipEventElapsedTime(&v[5], h->ev[EV_DOM0], h->ev[EV_DOM1]);
+    int k = n < 6 ? n : 6;
     for (int i = 0; i < k; ++i) ms[i] = v[i];
     return k;
 }
@@ -1928,16 +1943,34 @@ int BfSetLexStats(void *p, int on)
     return old;
 }
 
-/* the kernel that tokenises a plain TextToIds batch of this model (the one a bench line's roofline is about) */
+/* the dominant kernel of a plain TextToIds batch of this model, as the last batch ran it (the one a bench line's roofline is about) */
 const char *BfTokeniseKernel(void *p)
 {
     Handle *h = as_handle(p);
     if (!h) return "";
     switch (h->m.kind) {
-    case KIND_WP: return h->last_flat ? "k_wp_flat + k_wp_units" : use_wave(h, false, 0) ? "k_wp_wave" : (h->m.two_level ? "k_lex_wp_plain" : "k_lex_wp_flat");
+    case KIND_WP: return h->last_flat ? "k_wp_flat" : use_wave(h, false, 0) ? "k_wp_wave" : (h->m.two_level ? "k_lex_wp_plain" : "k_lex_wp_flat");
     case KIND_UNIGRAM: return "k_seg_unigram_lane";
     case KIND_I2W: return "";
     default: return use_bpe_wave(h, false) ? "k_bpe_wave" : "k_bpe_fused";
+    }
+}
+
+/* every kernel of a plain TextToIds step of this model, by the segment of BfLastKernelMs it is timed in */
+const char *BfStepKernels(void *p)
+{
+    Handle *h = as_handle(p);
+    if (!h) return "";
+    switch (h->m.kind) {
+    case KIND_WP:
+        if (h->last_flat) return "prep: k_wp_pre | tokenise: k_wp_flat, k_wp_units | scan: k_wp_hardlist, k_wp_wave (the documents handed back), k_wp_count, k_scan_block_sums, k_scan_top, k_scan_apply | compact: k_wp_merge";
+        if (use_wave(h, false, 0)) return "prep: - | tokenise: k_wp_wave | scan: k_scan_block_sums, k_scan_top, k_scan_apply | compact: k_compact_ids (offsets: k_compact_text)";
+        return "prep: k_prep_wp_flat, k_prep_wp_docs | tokenise: k_lex_wp_plain / k_lex_wp_flat | scan: k_scan_block_sums, k_scan_top, k_scan_apply | compact: k_compact_ids (offsets: k_compact)";
+    case KIND_UNIGRAM: return "prep: k_prep_sp8 | tokenise: k_sp_hist, k_sp_hist_scan, k_sp_scatter, k_seg_unigram_lane, k_uni_back | scan: k_scan_block_sums, k_scan_top, k_scan_apply | compact: k_compact_ids";
+    case KIND_I2W: return "";
+    default:
+        if (use_bpe_wave(h, false)) return "prep: k_prep_sp8 | tokenise: k_bpe_wave, k_bpe_flag_list, k_bpe_seg | scan: k_scan_block_sums, k_scan_top, k_scan_apply | compact: k_compact_ids";
+        return "prep: k_prep_sp8 | tokenise: k_sp_hist, k_sp_hist_scan, k_sp_scatter, k_bpe_fused, k_bpe_collect_list, k_bpe_sort, k_bpe_apply_flat, k_bpe_seg | scan: k_scan_block_sums, k_scan_top, k_scan_apply | compact: k_compact_ids";
     }
 }
 

@@ -16,8 +16,10 @@ BF_API int BfLexStats(void *ModelPtr, unsigned long long *out, int n);
 BF_API int BfSetVariant(void *ModelPtr, int variant);
 /* switches the instrumented kernel instances on / off for this handle and clears the counters; returns the previous setting */
 BF_API int BfSetLexStats(void *ModelPtr, int on);
-/* name of the kernel that tokenises a plain TextToIds batch of this model */
+/* name of the dominant kernel of a plain TextToIds batch of this model (as the last batch ran it); BfLastKernelMs value [5] is its time */
 BF_API const char *BfTokeniseKernel(void *ModelPtr);
+/* every kernel of a step, by the segment of BfLastKernelMs it is timed in: "prep: ... | tokenise: ... | scan: ... | compact: ..." */
+BF_API const char *BfStepKernels(void *ModelPtr);
 /* largest chunk of the pipelined host-buffer path of TextToIdsBatch (default 128 MiB; batches of at least that size take it, cut into
  * chunks of half to all of it; 0 = never).
  * Tests use small values to put chunk boundaries everywhere.  Returns the previous value. */

@@ -84,6 +84,7 @@ struct SpSegParams {
     int tune;                   // experiments: vote threshold of the lane-local BPE solve / Unigram transitions per trip (0 = default)
     int tune2;                  // experiments: resident waves per CU of the persistent segmenter kernels (0 = what fits)
     unsigned long long *next_doc;
+    void *ev_dom0 = nullptr, *ev_dom1 = nullptr;   // optional (hipEvent_t): recorded around the dominant kernel of the step (the Unigram forward pass)
 };
 
 // key -> info lookup (reference FADictInterpreter_t<int>::GetInfo) for a batch of keys: key k = keys[key_off[k] .. key_off[k+1])

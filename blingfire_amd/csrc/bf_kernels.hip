@@ -2386,7 +2386,9 @@ void launch_seg_sp(const SpSegParams &p_in, hipStream_t s)
             {
                 // forward pass (persistent lanes, records out), then the backward pass over every document
                 (void)one_kernel; (void)unroll;
+                if (p.ev_dom0) (void)hipEventRecord((hipEvent_t)p.ev_dom0, s);
                 hipLaunchKernelGGL((k_seg_unigram_lane<3, true, 8>), dim3(blocks), dim3(64), lds, s, p, ring);
+                if (p.ev_dom1) (void)hipEventRecord((hipEvent_t)p.ev_dom1, s);
                 hipLaunchKernelGGL(k_uni_back, dim3((unsigned)((p.b.ndocs + 255) / 256)), dim3(256), 0, s, p);
             }
         }

@@ -220,7 +220,8 @@ BF_API int DictGetInfoBatchDevice(void *ModelPtr, const int32_t *d_keys, const i
 
 /* Per-kernel GPU time of the last batch call on this handle, measured with HIP events recorded on the
  * call's own stream.  Synchronises with those events.  Fills up to n floats (milliseconds):
- * [0] prep (decode+normalise+classify)  [1] tokenise (lexer / segmenter)  [2] scan  [3] compact  [4] total.
+ * [0] prep (decode+normalise+classify)  [1] tokenise (lexer / segmenter)  [2] scan  [3] compact  [4] total  [5] the dominant kernel of the
+ * tokenise segment alone.
  * Returns the number of values written, or a negative error. */
 BF_API int BfLastKernelMs(void *ModelPtr, float *ms, int n);
 

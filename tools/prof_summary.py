@@ -15,7 +15,7 @@ def rows(db, q):
 def main():
     src, dst = sys.argv[1], sys.argv[2]
     out = []
-    st = glob.glob(os.path.join(src, "stats", "*.db"))
+    st = glob.glob(os.path.join(src, "stats", "**", "*.db"), recursive=True)
     if st:
         db = sqlite3.connect(st[0])
         out.append("== rocprofv3 --kernel-trace --stats (durations in ns) ==")
@@ -41,7 +41,7 @@ def main():
     for d in sorted(glob.glob(os.path.join(src, "pmc_*"))):
         if not os.path.isdir(d):
             continue
-        dbs = glob.glob(os.path.join(d, "*.db"))
+        dbs = glob.glob(os.path.join(d, "**", "*.db"), recursive=True)
         if not dbs:
             continue
         db = sqlite3.connect(dbs[0])
