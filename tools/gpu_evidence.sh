@@ -71,7 +71,7 @@ prof() { # name, traffic key, dominant kernel, launches of it per step, more cou
   python tools/prof_traffic.py $P "$key" $kern $per > $O/traffic_$name.txt 2>&1; head -1 $O/traffic_$name.txt | cut -c1-300
   rm -rf $P
 }
-model=$(python -c "import sys; sys.path.insert(0,'tests'); import bfutil; print(bfutil.bert_model_name())")
+model=$(python -c "import sys; sys.path.insert(0,'$root/tests'); import bfutil; print(bfutil.bert_model_name())")
 prof default "headline512/$model/10000000" k_wp_flat 1 1
 line default
 if [ -z "$quick" ]; then
