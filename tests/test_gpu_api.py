@@ -120,7 +120,7 @@ def test_device_api_on_torch_tensors():
         assert np.array_equal(ids[:n].cpu().numpy(), want[0]) and np.array_equal(id_off.cpu().numpy(), want[1])
         assert bf.lib().BfLastStatus(h) == 0
         ms = bf.last_kernel_ms(h)
-        assert len(ms) == 5 and ms[4] > 0
+        assert len(ms) == 6 and ms[4] > 0
     finally:
         bf.free_model(h)
 
