@@ -433,7 +433,7 @@ int run_device(Handle *h, const char *d_text, const int64_t *d_doc_off, int64_t 
         launch_wp_wave(wp, h->variant & ~0x3f000000, s);
         WfMergeParams mp;
         mp.doc_off = b.doc_off; mp.ndocs = ndocs; mp.ent = fp.ent; mp.home = fp.home; mp.ent_off = fp.ent_off; mp.ent_cnt = fp.ent_cnt; mp.dstat = fp.dstat; mp.unsafe = unsafe;
-        mp.ids_tmp = wp.ids_tmp; mp.counts = wp.counts; mp.id_off = d_id_off; mp.ids_out = d_ids_out; mp.ids_cap = ids_cap; mp.status = status; mp.max_ids = max_ids; mp.unk = unk; mp.dbg = (h->variant >> 20) & 0xf;
+        mp.ids_tmp = wp.ids_tmp; mp.counts = wp.counts; mp.id_off = d_id_off; mp.ids_out = d_ids_out; mp.ids_cap = ids_cap; mp.status = status; mp.max_ids = max_ids; mp.unk = unk;
         launch_wp_count(mp, s);
         ScanParams sp{h->w_counts.as<int32_t>(), ndocs, d_id_off, h->w_bsums.as<int64_t>(), nblocks};
         launch_scan(sp, s);

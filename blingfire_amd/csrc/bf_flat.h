@@ -63,7 +63,6 @@ struct WfMergeParams {
     int32_t *counts;                 // [ndocs] in: the wave program's counts of those documents; out (k_wp_count): every document's
     const int64_t *id_off; int32_t *ids_out; int64_t ids_cap; int *status;
     int max_ids, unk;
-    int dbg;                         // measurements (BF_EXPERIMENTS builds): parts of the merge switched off
 };
 
 } // namespace bfa

@@ -10,7 +10,7 @@
 //             runs (FALexTools_t.h:229-393 on a unit-form lexer is a function of the kinds alone, bf_wave.h); every lane owns the tokens
 //             that END in its eight bytes; a prefix sum gives each its entry;
 //   list      every lane writes where its tokens are, in token order, to a list in LDS;
-//   look-up   the list one token per lane and trip: the key of a run of <= 9 plain characters is made of its classes in the ring (the key IS
+//   look-up   the list one token per lane and trip: the key of a run of <= 12 plain characters is its bytes of the code ring (the key IS
 //             the word), two 12-byte gathers per lane, ids to the entries as whole rows;
 //   records   the tokens the table did not answer become records (entry, first byte, bytes) in a list in global memory, 64 at a time (one
 //             atomic per 64): the words are walked by a kernel of their own (k_wp_units, wf_units below), where nothing waits for them.
@@ -21,32 +21,36 @@
 namespace bfa {
 
 constexpr int WF_TQ = 512;                // tokens of a chunk, at most (every byte one)
-constexpr int WF_RING_DUP = 16;           // the first positions of the ring once more behind its end: a word of <= 16 bytes is read without a wrap
-constexpr uint64_t WF_KEY_NONE = 1ull << 62;     // "no key": matches no entry of the table (an entry's lowest field is never 0)
+constexpr int WF_RING_DUP = 16;           // the first positions of the code ring once more behind its end: the 12 bytes of a key are read without a wrap
 constexpr uint32_t WF_TQ_SOLO = 63;       // list entry: bytes == 63: a one-element token
 // a record of the word list (16 bytes): [0] entry index (low 32 bits) [1] first byte in the text (low 32 bits) [2] entry index bits 32.. | first byte bits 32.. << 8 | bytes << 16 |
 // WF_REC_PLAIN [3] home index - entry index
 constexpr uint32_t WF_REC_PLAIN = 1u << 24;      // the word's bytes are plain ASCII (its characters are its bytes)
 
+struct alignas(16) WfRow { uint32_t k0lo, k0hi, k1, id; };      // an entry of the word table (bf_flat_key.h)
 struct WfLds {
-    alignas(16) uint16_t ring[WF_RING + WF_RING_DUP];   // class of every byte position of this chunk and the one before (WF_CONT: no character starts there)
+    alignas(16) uint16_t ring[WF_RING];  // class of every byte position of this chunk and the one before (WF_CONT: no character starts there)
+    alignas(16) uint8_t cring[WF_RING + WF_RING_DUP];   // the same positions: the class's code inside a key (bf_flat_key.h; 0: it has none, or no character starts there)
     uint16_t tq_pos[WF_TQ];              // the chunk's tokens in order: (first byte - (chunk - 64)) | bytes << 10; bytes == 0: a run of more than WF_RUN_MAX bytes, its LAST byte
     alignas(16) uint32_t rec[WF_REC * 4]; // words on their way to the list
     uint32_t spare32; uint16_t spare;
 };
 
-// the 128-entry table of the ASCII bytes: [12:0] class, [18:16] kind bits (loop, solo, general)
+// the 128-entry table of the ASCII bytes: [12:0] class, [18:16] kind bits (loop, solo, general), [30:24] the class's code inside a key
 BF_WV uint32_t wf_lut_value(const WpWaveCold &p, int b)
 {
     const uint32_t el = wv_element(p, b), c = el & LX_T_CLS_MASK, k = el >> WK_SHIFT;
     const uint32_t nib = k == WK_LOOP ? 1u : k == WK_SOLO ? 2u : k == WK_GENERAL ? 4u : 0u;
-    return c | (nib << 16);
+    return c | (nib << 16) | ((c < 127u ? c + 1u : 0u) << 24);
 }
 
 #if defined(__HIPCC__)
 #define BF_WF_NOINLINE __device__ __forceinline__
+// (the compiler would fetch the second row's key only after the first row has come back and did not match)
+#define BF_WF_BOTH_ROWS(A, B) asm volatile("" : "+v"(A.k0lo), "+v"(A.k0hi), "+v"(A.k1), "+v"(A.id), "+v"(B.k0lo), "+v"(B.k0hi), "+v"(B.k1), "+v"(B.id))
 #else
 #define BF_WF_NOINLINE static __attribute__((noinline))
+#define BF_WF_BOTH_ROWS(A, B) ((void)0)
 #endif
 
 // A chunk with bytes >= 0x80 (the caller has put the ASCII bytes' classes and WF_CONT for all others into the ring).  Every lead byte is decoded
@@ -55,7 +59,7 @@ BF_WV uint32_t wf_lut_value(const WpWaveCold &p, int b)
 // three bytes behind the chunk.  Returns what the characters add to the kind bits, the bytes that are invalid, and what the last character of
 // the chunk covers of the next one.
 struct WfMb { uint32_t acc, errm, cov_carry, loop_carry; unsigned long long na; };      // na: the lanes that hold a byte >= 0x80
-BF_WVD WfMb wf_decode_multibyte(uint64_t own, uint32_t S8, uint32_t peek, int c, int len, const uint8_t *txt, uint16_t *ring, const uint16_t *cp_l1, const uint32_t *cp_pages,
+BF_WVD WfMb wf_decode_multibyte(uint64_t own, uint32_t S8, uint32_t peek, int c, int len, const uint8_t *txt, uint16_t *ring, uint8_t *cring, const uint16_t *cp_l1, const uint32_t *cp_pages,
                                         const uint8_t *kind, int nclasses, uint32_t cov_carry, uint32_t loop_carry)
 {
     const int lane = wv::lane(), lane0 = c + lane * 8;
@@ -107,7 +111,10 @@ BF_WVD WfMb wf_decode_multibyte(uint64_t own, uint32_t S8, uint32_t peek, int c,
                 const uint32_t e2 = wv_element(cold, cp), kd = e2 >> WK_SHIFT;
                 el = e2 & LX_T_CLS_MASK; nib = kd == WK_LOOP ? 1u : kd == WK_SOLO ? 2u : kd == WK_GENERAL ? 4u : 0u;
             }
-            { const uint32_t rp = ((uint32_t)lane0 + (uint32_t)i) & RMASK; ring[rp] = (uint16_t)el; if (rp < (uint32_t)WF_RING_DUP) ring[rp + WF_RING] = (uint16_t)el; }
+            {
+                const uint32_t rp = ((uint32_t)lane0 + (uint32_t)i) & RMASK; const uint8_t code = (uint8_t)(el < 127u ? el + 1u : 0u);
+                ring[rp] = (uint16_t)el; cring[rp] = code; if (rp < (uint32_t)WF_RING_DUP) cring[rp + WF_RING] = code;
+            }
             acc |= nib << (4 * i);
             if (nib & 1u) lsp |= cb;                                                       // the continuation bytes of a run member are run members
             if (er) errm |= 1u << i;
@@ -279,7 +286,11 @@ struct WfWave {
             uint32_t *row = (uint32_t *)(S.ring + rp);                          // 8 positions = one 16-byte row, never wraps
             const uint32_t r0 = (v[0] & 0xFFFFu) | (v[1] << 16), r1 = (v[2] & 0xFFFFu) | (v[3] << 16), r2 = (v[4] & 0xFFFFu) | (v[5] << 16), r3 = (v[6] & 0xFFFFu) | (v[7] << 16);
             row[0] = r0; row[1] = r1; row[2] = r2; row[3] = r3;
-            if (rp < (uint32_t)WF_RING_DUP) { uint32_t *dup = (uint32_t *)(S.ring + rp + WF_RING); dup[0] = r0; dup[1] = r1; dup[2] = r2; dup[3] = r3; }
+            const uint32_t c0 = (v[0] >> 24) | ((v[1] >> 16) & 0xFF00u) | ((v[2] >> 8) & 0xFF0000u) | (v[3] & 0xFF000000u);
+            const uint32_t c1 = (v[4] >> 24) | ((v[5] >> 16) & 0xFF00u) | ((v[6] >> 8) & 0xFF0000u) | (v[7] & 0xFF000000u);
+            uint32_t *crow = (uint32_t *)(S.cring + rp);
+            crow[0] = c0; crow[1] = c1;
+            if (rp < (uint32_t)WF_RING_DUP) { uint32_t *dup = (uint32_t *)(S.cring + rp + WF_RING); dup[0] = c0; dup[1] = c1; }
 #pragma unroll
             for (int i = 0; i < 8; ++i) acc |= ((v[i] >> 16) & 7u) << (4 * i);
         }
@@ -288,7 +299,7 @@ struct WfWave {
             // lane 63: the documents that begin in the first three bytes of the next chunk (not consumed here)
             uint32_t peek = 0;
             for (int d = dnext; d < dn; ++d) { const int o = off_rel(d); if (o >= c + WF_CHUNK + 3) break; peek |= 1u << (o - (c + WF_CHUNK)); }
-            const WfMb r = wf_decode_multibyte(own, S8, peek, c, len, txt, S.ring, cold.cpmap.l1, cold.cpmap.pages, cold.kind, cold.nclasses, cov_carry, loop_carry);
+            const WfMb r = wf_decode_multibyte(own, S8, peek, c, len, txt, S.ring, S.cring, cold.cpmap.l1, cold.cpmap.pages, cold.kind, cold.nclasses, cov_carry, loop_carry);
             acc |= r.acc; cov_carry = r.cov_carry; loop_carry = r.loop_carry; na = r.na;
             if (wv::any(r.errm != 0)) mark_bytes(c, r.errm, WF_D_BAD);          // invalid UTF-8: the document has no ids (tokdll:1151-1153)
         }
@@ -352,9 +363,8 @@ struct WfWave {
             emit_boundary(d, kd);
         }
         wv::sync();
-        // (2) the list, one token per lane and trip.  The key of a run of <= 9 characters is made of its classes in the ring (class + 1 in 7 bits; a
-        // class without a code -- >= 127, or no character: a continuation byte -- and the run has no key): the key IS the word.  Two 12-byte
-        // gathers per lane in flight; the ids go to their entries as whole rows.
+        // (2) the list, one token per lane and trip.  The key of a run of <= 12 bytes is its bytes of the code ring (bf_flat_key.h): the key IS the
+        // word.  Two 16-byte gathers per lane in flight; the ids go to their entries as whole rows.
         uint32_t *eout = ent + k;
         for (int t0 = 0; t0 < ntok; t0 += 64) {
             const bool have = t0 + lane < ntok;
@@ -363,23 +373,22 @@ struct WfWave {
             const bool solo = b6 == WF_TQ_SOLO;
             const int blen = solo ? 1 : (int)b6;                                 // (0: a run of more than WF_RUN_MAX bytes; its document is handed on)
             const int s0 = c - 64 + (int)(ps & 0x3FFu);
-            const uint16_t *rw = S.ring + ((uint32_t)s0 & RMASK);                // (the duplicate rows: no wrap within 16 positions)
-            uint32_t klo = 0, khi = 0, k8 = 0, minc = 127;
+            // the 12 codes behind the token's first byte, those behind the word cleared; a code 0 inside the word (a class without a code, or no
+            // character: a continuation byte) and the word has no key
+            uint32_t w[3];
+            __builtin_memcpy(w, S.cring + ((uint32_t)s0 & RMASK), 12);                 // (the duplicate bytes: no wrap)
             const int kn = (have && !solo && blen <= WF_KEY_CHARS) ? blen : 0;
-#pragma unroll
-            for (int i = 0; i < WF_KEY_CHARS; ++i) {
-                const uint32_t cl = (uint32_t)rw[i] & LX_T_CLS_MASK;
-                uint32_t code = cl < 127u ? cl + 1u : 0u;
-                const bool in = i < kn;
-                minc = in ? (code < minc ? code : minc) : minc;
-                code = in ? code : 0u;
-                if (i < 4) klo |= code << (7 * i); else if (i < 8) khi |= code << (7 * (i - 4)); else k8 = code;
-            }
-            uint64_t key = (uint64_t)klo | ((uint64_t)khi << 28) | ((uint64_t)k8 << 56);
-            bool plain = kn > 0 && minc != 0;                                    // a run with a key is plain ASCII (a unit can read it from the text)
-            if (kn == 0 || minc == 0) {
-                key = WF_KEY_NONE;
-                if (solo) key = WF_KEY_SOLO | WF_KEY_SOLO_CLS | (uint64_t)(rw[0] & LX_T_CLS_MASK);      // a one-element token: by class
+            const uint64_t m01 = kn >= 8 ? ~0ull : ((1ull << (8 * kn)) - 1ull);
+            const uint32_t m2 = kn >= 12 ? ~0u : kn > 8 ? ((1u << (8 * (kn - 8))) - 1u) : 0u;
+            uint64_t k0 = ((uint64_t)w[0] | ((uint64_t)w[1] << 32)) & m01;
+            uint32_t k1 = w[2] & m2;
+            const uint64_t z0 = ((k0 | ~m01) - 0x0101010101010101ull) & ~(k0 | ~m01) & 0x8080808080808080ull;
+            const uint32_t z2 = ((k1 | ~m2) - 0x01010101u) & ~(k1 | ~m2) & 0x80808080u;
+            const bool nozero = z0 == 0ull && z2 == 0u;
+            bool plain = kn > 0 && nozero;                                       // a run with a key is plain ASCII (a unit can read it from the text)
+            if (!plain) {
+                k0 = WF_KEY_NONE; k1 = 0u;
+                if (solo) k0 = WF_KEY_SOLO | ((uint64_t)(S.ring[(uint32_t)s0 & RMASK] & LX_T_CLS_MASK) << WF_KEY_SOLO_SHIFT);      // a one-element token: by class
                 else if (kn == 0 && blen > 0) {
                     // a longer run: plain when no lane it touches holds a byte >= 0x80 (lanes counted from the chunk before; a run is <= 48 bytes)
                     plain = true;
@@ -390,10 +399,12 @@ struct WfWave {
                     }
                 }
             }
-            const uint32_t x = wf_mix(key, p.m0);
-            const uint32_t *ea = (const uint32_t *)p.W + 4u * wf_h(x, p.m1, p.wbits), *eb = (const uint32_t *)p.W + 4u * wf_h(x, p.m2, p.wbits);
-            const uint32_t al = ea[0], ah = ea[1], ai = ea[2], bl_ = eb[0], bh = eb[1], bi = eb[2];
-            const bool hita = al == (uint32_t)key && ah == (uint32_t)(key >> 32), hitb = bl_ == (uint32_t)key && bh == (uint32_t)(key >> 32);
+            const uint32_t x = wf_mix(k0, k1, p.m0);
+            WfRow A = *((const WfRow *)p.W + wf_h(x, p.m1, p.wbits)), B = *((const WfRow *)p.W + wf_h(x, p.m2, p.wbits));
+            BF_WF_BOTH_ROWS(A, B);                                               // both rows whole and in flight together: one trip to the table
+            const bool hita = ((A.k0lo ^ (uint32_t)k0) | (A.k0hi ^ (uint32_t)(k0 >> 32)) | (A.k1 ^ k1)) == 0u;
+            const bool hitb = ((B.k0lo ^ (uint32_t)k0) | (B.k0hi ^ (uint32_t)(k0 >> 32)) | (B.k1 ^ k1)) == 0u;
+            const uint32_t ai = A.id, bi = B.id;
             const bool hit = have && (hita || hitb);
             if (hit) eout[t0 + lane] = hita ? ai : bi;
             if (STATS) st_hit += (unsigned long long)__builtin_popcountll(wv::ballot(hit));
@@ -708,7 +719,12 @@ BF_WVD int wf_merge_vec(const WfMergeParams &p, uint32_t e, bool have, int64_t e
     return wv::bcast(inc, 63);
 }
 
-BF_WVD void wf_merge_docs(const WfMergeParams &p, int64_t base, bool &over)
+// ids a trip of the merge stages in LDS: 256 entries, their extra ids and the <= 3 ids carried from the trip before
+constexpr int WF_MBUF = 1024;
+struct alignas(16) WfQuad { int32_t v[4]; };
+struct WfMergeLds { alignas(16) int32_t buf[WF_MBUF]; };
+
+BF_WVD void wf_merge_docs(const WfMergeParams &p, int64_t base, bool &over, WfMergeLds &M)
 {
     const int lane = wv::lane();
     const int64_t d = base + lane;
@@ -722,19 +738,23 @@ BF_WVD void wf_merge_docs(const WfMergeParams &p, int64_t base, bool &over)
         capped = cnt >= p.max_ids || o + cnt > p.ids_cap;
         if (o + cnt > p.ids_cap) { over = true; cnt = o < p.ids_cap ? (int)(p.ids_cap - o) : 0; }
     }
-    // the usual block: no document flagged or cut, the entries of all 64 one contiguous run -- then so are their ids (id_off is the running sum
-    // of the counts): the run is streamed 256 entries per trip without a look at the documents
+    // The usual block: no document flagged or cut, the entries of all 64 one contiguous run -- then so are their ids (id_off is the running sum
+    // of the counts).  The run is streamed 256 entries per trip without a look at the documents: four consecutive entries per lane and load (the
+    // next trip's on its way); the trip's ids are put together in LDS -- a plain id at its place, the pieces of a word of several from its home
+    // by the lane that holds its entry -- and leave as whole aligned 16-byte rows (what bounds a streaming kernel here is the number of
+    // vector-memory instructions a CU can issue: a store per word of several pieces was most of them); the <= 3 ids behind the last whole row
+    // wait for the next trip.
     const int64_t eo_n = wv::shfl_down(eo, 1);
     if (!wv::any(lane < nd && (st != 0 || capped))) {
       unsigned long long brk = wv::ballot(lane < nd && (lane + 1 == nd || eo_n != eo + ec));      // the lanes that end a contiguous piece (a range of the flat program ends there)
       for (int first = 0; brk;) {
         const int lastl = __builtin_ctzll(brk); brk &= brk - 1ull;
         const int64_t E0 = wv::bcast(eo, first), E1 = wv::bcast(eo + (int64_t)ec, lastl);
-        int32_t *out = p.ids_out + wv::bcast(o, first);
+        int32_t *const op = p.ids_out + wv::bcast(o, first);
         first = lastl + 1;
-        int run = 0;
-        // four consecutive entries per lane: one load (the next trip's is on its way while this trip works); a lane whose four are plain ids stores
-        // them in one go (the usual lane); a lane that holds a word of several pieces (or UnkId) writes its ids one after the other
+        const int head = (int)(((uintptr_t)op >> 2) & 3u);
+        int32_t *outq = op - head;                      // M.buf[i] is outq[i]; outq is 16-byte aligned
+        int lo = head, carry = head;                    // the first slot that is this piece's; the slots filled so far
         auto load4 = [&](int64_t t, uint32_t (&e)[4]) {
             const int64_t a = t + 4 * lane;
             e[0] = e[1] = e[2] = e[3] = 0u;
@@ -748,56 +768,83 @@ BF_WVD void wf_merge_docs(const WfMergeParams &p, int64_t base, bool &over)
             uint32_t e[4] = {en[0], en[1], en[2], en[3]};
             const int nin = a + 4 <= E1 ? 4 : (a < E1 ? (int)(E1 - a) : 0);
             if (t + 256 < E1) load4(t + 256, en);
-            bool flagged = ((e[0] | e[1] | e[2] | e[3]) & WF_ENT_FLAG) != 0u;
-            if (p.dbg == 3) flagged = false;
-            int xs = 0;
+            const bool flagged = ((e[0] | e[1] | e[2] | e[3]) & WF_ENT_FLAG) != 0u;
+            const bool any_f = wv::any(flagged);
+            int n[4], xs = 0;
 #pragma unroll
-            for (int u = 0; u < 4; ++u) xs += u < nin ? wf_entry_ids(e[u]) : 0;
-            int base_pos = run + 4 * lane;
-            if (wv::any(flagged)) { const int inc = wv::incl_scan(xs); base_pos = run + inc - xs; run += wv::bcast(inc, 63); }
-            else run += E1 - t < 256 ? (int)(E1 - t) : 256;
-            if (p.dbg == 2) continue;
-            if (!flagged) {
-                if (nin == 4) __builtin_memcpy(out + base_pos, e, 16);
-                else for (int u = 0; u < 4; ++u) if (u < nin) out[base_pos + u] = (int32_t)e[u];
-            } else {
-                // this lane's ids that are in its entries themselves (plain ids, UnkId), each at its place
-                int pos = base_pos;
-#pragma unroll
+            for (int u = 0; u < 4; ++u) { n[u] = u < nin ? wf_entry_ids(e[u]) : 0; xs += n[u]; }
+            int pos0 = carry + 4 * lane, sum = E1 - t < 256 ? (int)(E1 - t) : 256;
+            if (any_f) { const int inc = wv::incl_scan(xs); pos0 = carry + inc - xs; sum = wv::bcast(inc, 63); }
+            if (carry + sum > WF_MBUF) {
+                // more ids than the buffer holds (entries of four ids and more on average): what waits leaves, the trip's ids go out one by one
+                if (lane >= lo && lane < carry) outq[lane] = M.buf[lane];
+                int pos = pos0;
                 for (int u = 0; u < 4; ++u) {
+                    if (u >= nin) break;
                     const uint32_t eu = e[u];
                     const int nn = (eu & WF_ENT_FLAG) ? (int)((eu & ~WF_ENT_FLAG) >> WF_ENT_CNT_SHIFT) : -1;       // -1: a plain id, 0: UnkId
-                    if (u < nin && nn <= 0) out[pos] = nn < 0 ? (int32_t)eu : p.unk;
-                    pos += u < nin ? (nn > 0 ? nn : 1) : 0;
+                    if (nn <= 0) outq[pos] = nn < 0 ? (int32_t)eu : p.unk;
+                    else { const int32_t *hm = p.home + (a + u) + (int64_t)(eu & WF_ENT_DELTA_MASK); for (int j = 0; j < nn; ++j) outq[pos + j] = hm[j]; }
+                    pos += n[u];
                 }
+                int32_t *const np = outq + carry + sum;
+                const int h2 = (int)(((uintptr_t)np >> 2) & 3u);
+                outq = np - h2; lo = carry = h2;
+                wv::sync();
+                continue;
             }
-            // the words of several pieces: the whole wave copies each from its home (<= 48 ids: one load, one store), four words' loads in flight
-            if (wv::any(flagged) && p.dbg != 1) {
-                int qn = 0; int qp[4], qc[4]; const int32_t *qh[4];
-                int pos = base_pos;
+            // ---- the trip's ids to their slots
+            if (!flagged) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) if (u < nin) M.buf[pos0 + u] = (int32_t)e[u];
+            } else {
+                int pos = pos0;
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const uint32_t eu = e[u];
-                    const int nn = (u < nin && (eu & WF_ENT_FLAG)) ? (int)((eu & ~WF_ENT_FLAG) >> WF_ENT_CNT_SHIFT) : 0;
-                    for (unsigned long long mb = wv::ballot(nn > 0); mb || (u == 3 && qn);) {
-                        if (mb) {
-                            const int l = __builtin_ctzll(mb); mb &= mb - 1ull;
-                            qp[qn] = wv::bcast(pos, l); qc[qn] = wv::bcast(nn, l);
-                            qh[qn] = p.home + (t + 4 * l + u) + (int64_t)(wv::bcast(eu, l) & WF_ENT_DELTA_MASK);
-                            ++qn;
-                        }
-                        if (qn == 4 || (!mb && u == 3 && qn)) {
-                            int32_t v[4];
-#pragma unroll
-                            for (int q = 0; q < 4; ++q) v[q] = q < qn ? qh[q][lane < qc[q] ? lane : qc[q] - 1] : 0;
-#pragma unroll
-                            for (int q = 0; q < 4; ++q) if (q < qn && lane < qc[q]) out[qp[q] + lane] = v[q];
-                            qn = 0;
-                        }
-                    }
-                    pos += u < nin ? ((eu & WF_ENT_FLAG) ? (nn > 0 ? nn : 1) : 1) : 0;
+                    const int nn = (eu & WF_ENT_FLAG) ? (int)((eu & ~WF_ENT_FLAG) >> WF_ENT_CNT_SHIFT) : -1;
+                    if (u < nin && nn <= 0) M.buf[pos] = nn < 0 ? (int32_t)eu : p.unk;
+                    pos += n[u];
                 }
             }
+            if (any_f) {
+                // the words of several pieces, one per lane and turn: four pieces in one load (the homes have 64 entries of slack behind them)
+                uint32_t fm = 0;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) if (u < nin && (e[u] & WF_ENT_FLAG) && (e[u] & ~WF_ENT_FLAG) >> WF_ENT_CNT_SHIFT) fm |= 1u << u;
+                const int p1 = pos0 + n[0], p2 = p1 + n[1], p3 = p2 + n[2];
+                while (wv::any(fm != 0u)) {
+                    if (fm) {
+                        const int u = __builtin_ctz(fm); fm &= fm - 1u;
+                        const uint32_t eu = u == 0 ? e[0] : u == 1 ? e[1] : u == 2 ? e[2] : e[3];
+                        const int pu = u == 0 ? pos0 : u == 1 ? p1 : u == 2 ? p2 : p3;
+                        const int nn = (int)((eu & ~WF_ENT_FLAG) >> WF_ENT_CNT_SHIFT);
+                        const int32_t *hm = p.home + (a + u) + (int64_t)(eu & WF_ENT_DELTA_MASK);
+                        int32_t v[4];
+                        __builtin_memcpy(v, hm, 16);
+                        M.buf[pu] = v[0];
+                        if (nn > 1) M.buf[pu + 1] = v[1];
+                        if (nn > 2) M.buf[pu + 2] = v[2];
+                        if (nn > 3) M.buf[pu + 3] = v[3];
+                        for (int j = 4; j < nn; ++j) M.buf[pu + j] = hm[j];
+                    }
+                }
+            }
+            wv::sync();
+            // ---- whole rows out
+            const int total = carry + sum;
+            const bool last = t + 256 >= E1;
+            const int nfull = last ? total : (total & ~3);
+            for (int q = 4 * lane; q < nfull; q += 256) {
+                const WfQuad v = *(const WfQuad *)(M.buf + q);
+                if (q >= lo && q + 4 <= nfull) *(WfQuad *)(outq + q) = v;
+                else for (int j = 0; j < 4; ++j) if (q + j >= lo && q + j < nfull) outq[q + j] = v.v[j];
+            }
+            const int rest = total - nfull;
+            const int32_t keep = lane < rest ? M.buf[nfull + lane] : 0;
+            wv::sync();
+            if (lane < rest) M.buf[lane] = keep;
+            outq += nfull; lo = 0; carry = rest;
         }
       }
       return;

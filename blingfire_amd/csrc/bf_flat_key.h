@@ -16,7 +16,7 @@ constexpr int WF_RING = 1024;            // byte positions whose class is kept (
 constexpr int WF_ARENA = 256;            // characters of the waiting words that are not plain text (bf_flat_body.h)
 constexpr int WF_REC = 64;               // words that wait for a unit, at most (one per lane)
 constexpr int WF_RUN_MAX = 48;           // bytes of the longest run the program resolves itself
-constexpr int WF_KEY_CHARS = 9;          // 7 bits per character
+constexpr int WF_KEY_CHARS = 12;         // one byte per character (its code: class + 1, 1 .. 127)
 constexpr uint32_t WF_CONT = 0xFFFFu;    // ring: a byte that starts no character
 constexpr uint32_t WF_ENT_FLAG = 0x80000000u;   // entry with bit 31: [30:25] number of ids (0: one id, UnkId), [24:0] home index - entry index
 constexpr int WF_ENT_CNT_SHIFT = 25;
@@ -24,10 +24,13 @@ constexpr uint32_t WF_ENT_DELTA_MASK = (1u << WF_ENT_CNT_SHIFT) - 1u;
 constexpr int32_t WF_D_BAD = 1, WF_D_HARD = 2;  // dstat[] bits: invalid UTF-8 (0 ids); handed to the wave program
 constexpr int64_t WF_DOC_MAX = 1 << 22;  // a batch with a longer document (or with offsets out of order) is not taken (k_wp_pre sets *unsafe)
 constexpr int64_t WF_RANGE_MAX = 1 << 22; // bytes a range aims at, at most (a range ends with a whole document: < WF_RANGE_MAX + WF_DOC_MAX bytes)
-constexpr uint64_t WF_KEY_SOLO = 1ull << 63, WF_KEY_SOLO_CLS = 1ull << 32;   // key of a one-element token: SOLO | byte (ASCII), SOLO | SOLO_CLS | class
+// A key is 12 bytes: the codes of the word's characters, first character in the lowest byte, 0 behind the word (k0: characters 0..7, k1: 8..11).
+// A code is never 0 and never has bit 7: byte 0 == 0x80 marks the key of a one-element token (class in bits 8..), byte 0 == 0xFF is no key at all.
+constexpr uint64_t WF_KEY_SOLO = 0x80ull, WF_KEY_NONE = 0xFFull;
+constexpr int WF_KEY_SOLO_SHIFT = 8;
 
-// ---- the word table.  Entry e = {key, id}; two candidate entries per key.
-BF_FK uint32_t wf_mix(uint64_t key, uint32_t m0) { return (uint32_t)key ^ ((uint32_t)(key >> 32) * m0); }
+// ---- the word table.  Entry e = 16 bytes {k0 (8), k1 (4), id (4)}; k0 == 0: empty; two candidate entries per key.
+BF_FK uint32_t wf_mix(uint64_t k0, uint32_t k1, uint32_t m0) { return (uint32_t)k0 ^ ((uint32_t)(k0 >> 32) * m0) ^ (k1 * 0x85EBCA6Bu); }
 BF_FK uint32_t wf_h(uint32_t x, uint32_t m, int bits) { return (x * m) >> (32 - bits); }
 // code of a class inside a key (0: the class has none)
 BF_FK uint32_t wf_code(uint32_t cls, uint32_t kind) { return (kind == 1u /* WK_LOOP */ && cls < 127u) ? cls + 1u : 0u; }

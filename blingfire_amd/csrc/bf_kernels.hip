@@ -863,8 +863,9 @@ __global__ __launch_bounds__(256) void k_wp_count(WfMergeParams p)
 __global__ __launch_bounds__(256) void k_wp_merge(WfMergeParams p)
 {
     const int64_t wave0 = (int64_t)blockIdx.x * 4 + wave_in_block(), nwaves = (int64_t)gridDim.x * 4;
+    __shared__ WfMergeLds lds[4];
     bool over = false;
-    for (int64_t base = wave0 * 64; base < p.ndocs; base += nwaves * 64) wf_merge_docs(p, base, over);
+    for (int64_t base = wave0 * 64; base < p.ndocs; base += nwaves * 64) wf_merge_docs(p, base, over, lds[wave_in_block()]);
     if (over) atomicOr(p.status, 1);
 }
 
@@ -906,12 +907,12 @@ void launch_wp_flat(const WfParams &p, int variant, hipStream_t s)
 {
     const int per_cu_override = (variant >> 24) & 0x3f, wpe = (variant >> 16) & 0xf;
 #ifdef BF_EXPERIMENTS
-    if (wpe == 7) { launch_wp_flat_wpe<7>(p, per_cu_override, s); return; }
+    if (wpe == 8) { launch_wp_flat_wpe<8>(p, per_cu_override, s); return; }
     if (wpe == 6) { launch_wp_flat_wpe<6>(p, per_cu_override, s); return; }
     if (wpe == 5) { launch_wp_flat_wpe<5>(p, per_cu_override, s); return; }
 #endif
     (void)wpe;
-    launch_wp_flat_wpe<8>(p, per_cu_override, s);
+    launch_wp_flat_wpe<7>(p, per_cu_override, s);          // seven waves per SIMD: 72 registers (swept on MI355X: 5 / 6 / 7 waves 3.09 / 2.92 / 2.83 ms per 2.5 M documents)
 }
 
 template <int WPE, int NU>

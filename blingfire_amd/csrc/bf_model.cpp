@@ -457,7 +457,8 @@ static void build_flat_table(Model &m)
     const bool anchored = m.flat_ini_l != 0xFFFFFFFFu && m.max_token_length > 1;
     const uint32_t start = anchored ? m.flat_ini_l : m.flat_ini;
     const std::vector<uint64_t> &T = m.wbd_t2;
-    std::vector<std::pair<uint64_t, uint32_t>> words;
+    struct Word { uint64_t k0; uint32_t k1, id; };
+    std::vector<Word> words;
     auto step = [&](uint32_t state, uint32_t cls, uint32_t &next, bool &fin, uint32_t &tag) -> bool {
         const size_t at = (size_t)state + cls;
         if (at >= T.size()) return false;
@@ -469,19 +470,20 @@ static void build_flat_table(Model &m)
     // runs: every word over the classes that have a code (a WK_LOOP class below 127), depth first
     std::vector<uint32_t> codable;
     for (int k = 0; k < m.wbd.nclasses && k < 127; ++k) if (m.wave_kind[(size_t)k] == 1 /* WK_LOOP */) codable.push_back((uint32_t)k);
-    struct Fr { uint32_t state; uint64_t key; int depth; };
-    std::vector<Fr> stack; stack.push_back({start, 0, 0});
+    struct Fr { uint32_t state; uint64_t k0; uint32_t k1; int depth; };
+    std::vector<Fr> stack; stack.push_back({start, 0, 0, 0});
     while (!stack.empty()) {
         const Fr f = stack.back(); stack.pop_back();
         for (uint32_t k : codable) {
             uint32_t nx = 0, tag = 0; bool fin = false;
             if (!step(f.state, k, nx, fin, tag)) continue;
-            const uint64_t key = f.key | ((uint64_t)wf_code(k, 1u) << (7 * f.depth));
+            const uint64_t k0 = f.depth < 8 ? f.k0 | ((uint64_t)wf_code(k, 1u) << (8 * f.depth)) : f.k0;
+            const uint32_t k1 = f.depth < 8 ? 0u : f.k1 | (wf_code(k, 1u) << (8 * (f.depth - 8)));
             if (fin) {
                 if (!(tag & INFO_SIMPLE_BIT)) return;                 // cannot be (unit form: vocabulary tags are SIMPLE); no table then
-                words.push_back({key, tag & 0x7FFFFFFFu});
+                words.push_back({k0, k1, tag & 0x7FFFFFFFu});
             }
-            if (f.depth + 1 < WF_KEY_CHARS) stack.push_back({nx, key, f.depth + 1});
+            if (f.depth + 1 < WF_KEY_CHARS) stack.push_back({nx, k0, k1, f.depth + 1});
             if (words.size() > (1u << 22)) return;
         }
     }
@@ -489,7 +491,7 @@ static void build_flat_table(Model &m)
     for (int k = 0; k < m.wbd.nclasses; ++k) {
         if (m.wave_kind[(size_t)k] != 3 /* WK_SOLO */) continue;
         uint32_t nx = 0, tag = 0; bool fin = false;
-        if (step(start, (uint32_t)k, nx, fin, tag) && fin && (tag & INFO_SIMPLE_BIT)) words.push_back({WF_KEY_SOLO | WF_KEY_SOLO_CLS | (uint64_t)k, tag & 0x7FFFFFFFu});
+        if (step(start, (uint32_t)k, nx, fin, tag) && fin && (tag & INFO_SIMPLE_BIT)) words.push_back({WF_KEY_SOLO | ((uint64_t)k << WF_KEY_SOLO_SHIFT), 0u, tag & 0x7FFFFFFFu});
     }
     // two-choice (cuckoo) placement at a load of at most 40 %; new multipliers when an insertion does not settle
     int bits = 10; while ((size_t)1 << bits < words.size() * 5 / 2 + 16) ++bits;
@@ -498,17 +500,18 @@ static void build_flat_table(Model &m)
     for (int attempt = 0; attempt < 64; ++attempt) {
         if (attempt == 32) ++bits;
         const uint32_t m0 = next_odd(), m1 = next_odd(), m2 = next_odd();
-        std::vector<uint64_t> tab((size_t)2 << bits, 0);
+        std::vector<uint64_t> tab((size_t)2 << bits, 0);              // [2e] k0, [2e + 1] k1 | id << 32
         bool ok = true;
         for (size_t w = 0; w < words.size() && ok; ++w) {
-            uint64_t key = words[w].first; uint32_t id = words[w].second;
-            uint32_t x = wf_mix(key, m0), at = wf_h(x, m1, bits);
+            uint64_t k0 = words[w].k0, ki = (uint64_t)words[w].k1 | ((uint64_t)words[w].id << 32);
+            uint32_t x = wf_mix(k0, (uint32_t)ki, m0), at = wf_h(x, m1, bits);
             ok = false;
             for (int kick = 0; kick < 512; ++kick) {
-                if (tab[2 * (size_t)at] == 0) { tab[2 * (size_t)at] = key; tab[2 * (size_t)at + 1] = id; ok = true; break; }
-                if (tab[2 * (size_t)at] == key) { ok = tab[2 * (size_t)at + 1] == id; break; }       // the same word twice (one-element tokens by class and by byte never share a key)
-                std::swap(key, tab[2 * (size_t)at]); uint64_t t = tab[2 * (size_t)at + 1]; tab[2 * (size_t)at + 1] = id; id = (uint32_t)t;
-                x = wf_mix(key, m0);
+                uint64_t &t0 = tab[2 * (size_t)at], &t1 = tab[2 * (size_t)at + 1];
+                if (t0 == 0) { t0 = k0; t1 = ki; ok = true; break; }
+                if (t0 == k0 && (uint32_t)t1 == (uint32_t)ki) { ok = t1 == ki; break; }              // the same word twice
+                std::swap(k0, t0); std::swap(ki, t1);
+                x = wf_mix(k0, (uint32_t)ki, m0);
                 const uint32_t h1 = wf_h(x, m1, bits), h2 = wf_h(x, m2, bits);
                 at = at == h1 ? h2 : h1;
             }

@@ -133,10 +133,10 @@ struct Model {
     std::vector<uint8_t> wave_kind;
     uint32_t wave_solo_info = 0;                       // action info of every WK_SOLO token
     // "Flat form" (bf_flat.h): a unit-form lexer whose run and solo tokens both call ONE vocabulary function.  The whole-word answers of that
-    // function -- every word of <= FLAT_KEY_CHARS characters over the classes 0 .. 126 that the walk from the function's first state consumes
+    // function -- every word of <= WF_KEY_CHARS characters over the classes 0 .. 126 that the walk from the function's first state consumes
     // entirely and ends on a final state (= the word is ONE piece: FALexTools_t.h:255-277 keeps the LAST final position, tokdll:1239-1301
     // then has a single sub-token that tiles the word) -- are enumerated at load into a two-choice hash table keyed by the word itself
-    // (7 bits per character: the key IS the word, a hit needs no second check).  flat_tab: entry e = [2e] key, [2e + 1] id; key 0 = empty.
+    // (one byte per character, bf_flat_key.h: the key IS the word, a hit needs no second check).  flat_tab: entry e = [2e] k0, [2e + 1] k1 | id << 32; k0 0 = empty.
     bool flat_ok = false; uint32_t flat_ini = 0, flat_ini_l = 0xFFFFFFFFu;
     std::vector<uint64_t> flat_tab; int flat_bits = 0; uint32_t flat_m0 = 0, flat_m1 = 0, flat_m2 = 0; int flat_words = 0;
     // TextToWords view of the same lexer (tokdll:415-566): NO charmap, U+0000 is fed as U+0020 -> plain code point -> class map

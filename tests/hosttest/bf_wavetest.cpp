@@ -405,13 +405,14 @@ long bft_emu_flat_batch(void *hv, const uint8_t *text, long text_bytes, const in
     // ---- k_wp_count, scan, k_wp_merge
     WfMergeParams mp;
     mp.doc_off = doc_off; mp.ndocs = ndocs; mp.ent = ent.data(); mp.home = home.data(); mp.ent_off = entoff.data(); mp.ent_cnt = entcnt.data(); mp.dstat = dstat.data(); mp.unsafe = &unsafe;
-    mp.ids_tmp = tmp.data(); mp.counts = counts.data(); mp.id_off = id_off; mp.ids_out = ids_out; mp.ids_cap = ids_cap; mp.status = &status; mp.max_ids = max_ids; mp.unk = unk; mp.dbg = 0;
+    mp.ids_tmp = tmp.data(); mp.counts = counts.data(); mp.id_off = id_off; mp.ids_out = ids_out; mp.ids_cap = ids_cap; mp.status = &status; mp.max_ids = max_ids; mp.unk = unk;
     wvemu::run_waves(1, [&]() { for (int64_t base = 0; base < ndocs; base += 64) wf_count_docs(mp, base); });
     long o = 0;
     for (long d = 0; d < ndocs; ++d) { id_off[d] = o; if (counts[(size_t)d] < 0) return -6; o += counts[(size_t)d]; }
     id_off[ndocs] = o;
     bool over_any = false;
-    wvemu::run_waves(1, [&]() { bool over = false; for (int64_t base = 0; base < ndocs; base += 64) wf_merge_docs(mp, base, over); if (over) over_any = true; });
+    WfMergeLds mlds;
+    wvemu::run_waves(1, [&]() { bool over = false; for (int64_t base = 0; base < ndocs; base += 64) wf_merge_docs(mp, base, over, mlds); if (over) over_any = true; });
     if (over_any) return -9;
     return o;
 }

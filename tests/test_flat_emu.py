@@ -74,7 +74,7 @@ def test_flat_form_is_proven_for_the_bert_lexers_only(ht):
         h = ht.bft_load(bfutil.model_path(model).encode())
         assert ht.bft_flat_ok(h) == want, model
         if want:
-            assert ht.bft_flat_words(h) > 5000        # the one-piece words of <= 9 characters of the vocabulary
+            assert ht.bft_flat_words(h) > 5000        # the one-piece words of <= 12 characters of the vocabulary
         ht.bft_free(h)
 
 
@@ -111,6 +111,10 @@ def test_document_shapes(ht):
     check(ht, model, edges, [(512, 100, 1, 1), (2000, 100, 2, 0)])
     mixed = [b" ".join(rnd.choice(words) for _ in range(rnd.randint(0, 120))) for _ in range(200)]
     check(ht, model, mixed, [(512, 100, 2, 0), (512, 100, 3, 1), (5, 100, 1, 2)])
+    # words of many pieces one after the other (more ids per trip of the merge than its buffer holds), among documents of plain words
+    many = [b" ".join(bytes(rnd.choice(b"qzxjkvw") for _ in range(rnd.randint(6, 14))) for _ in range(rnd.randint(1, 400))) if i % 3 else b"plain words only , here"
+            for i in range(150)]
+    check(ht, model, many, [(4096, 100, 2, 0), (4096, 100, 1, 1), (100, 100, 2, 1)])
 
 
 def test_handed_back(ht):
