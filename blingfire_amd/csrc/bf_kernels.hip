@@ -860,7 +860,7 @@ __global__ __launch_bounds__(256) void k_wp_count(WfMergeParams p)
     for (int64_t base = wave0 * 64; base < p.ndocs; base += nwaves * 64) wf_count_docs(p, base);
 }
 
-__global__ __launch_bounds__(256) void k_wp_merge(WfMergeParams p)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_wp_merge(WfMergeParams p)
 {
     const int64_t wave0 = (int64_t)blockIdx.x * 4 + wave_in_block(), nwaves = (int64_t)gridDim.x * 4;
     __shared__ WfMergeLds lds[4];
@@ -950,15 +950,19 @@ void launch_wp_hardlist(const int32_t *dstat, const int *unsafe, int64_t ndocs, 
 void launch_wp_count(const WfMergeParams &p, hipStream_t s)
 {
     int64_t blocks = (p.ndocs + 255) / 256;
-    if (blocks > device_cus() * 8) blocks = device_cus() * 8;
+    static int pc = 0;
+    const int64_t resident = (int64_t)device_cus() * wp_blocks_per_cu(k_wp_count, pc);
+    if (blocks > resident) blocks = resident;
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(k_wp_count, dim3((unsigned)blocks), dim3(256), 0, s, p);
 }
 
 void launch_wp_merge(const WfMergeParams &p, hipStream_t s)
 {
+    static int pc = 0;
     int64_t blocks = (p.ndocs + 255) / 256;
-    if (blocks > device_cus() * 8) blocks = device_cus() * 8;
+    const int64_t resident = (int64_t)device_cus() * wp_blocks_per_cu(k_wp_merge, pc);      // one round of workgroups: every wave has the same share
+    if (blocks > resident) blocks = resident;
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(k_wp_merge, dim3((unsigned)blocks), dim3(256), 0, s, p);
 }
