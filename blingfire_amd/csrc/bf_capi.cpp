@@ -173,6 +173,7 @@ struct Handle {
     DevBuf w_cls, w_nchars, w_tmp, w_counts, w_bsums, w_misc, w_flags, w_out, w_outoff;   // w_misc: [0] next_doc (u64), [2] status (int)
     DevBuf w_text, w_docoff, w_ids, w_idoff, w_starts, w_ends;  // host-API staging
     DevBuf w_srcoff, w_span;                                    // offsets API: source-offset stream, staged id spans
+    DevBuf w_espan, w_hspan, w_chard;                           // the flat program, offsets API: spans of the entries, of the pieces at the homes; counts of the documents handed back
     DevBuf w_ent, w_home, w_entoff, w_entcnt, w_dstat, w_ranges, w_list, w_wrec, t_flat;   // the flat program (bf_flat.h): entries, homes, per-document records, ranges, the documents handed back; its word table
     bool last_flat = false;                                      // the last batch took the flat program (BfLastKernelMs names the kernels by it)
     // single-document calls that arrive while a batch is in flight are combined into the next launch (text_to_ids_one)
@@ -198,7 +199,7 @@ struct Handle {
         shards.clear();
         pipe.release(); m_small.release();
         for (DevBuf *b : {&t_segscore, &t_bpe_prio, &t_bpe_place, &t_dk_l1, &t_dk_pages, &t_dn_l1, &t_dn_pages, &t_dn_pool, &t_k2i, &t_rows, &w_keys, &w_keyoff, &w_dids, &w_dret, &w_vals, &t_i2w_off, &t_i2w_data, &t_kind, &t_wbd, &t_info, &t_acts, &t_cp_l1, &t_cp_pages, &t_multi, &t_wcp_l1, &t_wcp_pages, &t_dict, &t_seginfo, &w_s1, &w_s2, &w_s3, &w_s4, &w_big, &w_perm, &w_hist, &w_narcs, &w_bwflags, &w_cls, &w_nchars, &w_tmp, &w_counts, &w_flags, &w_out, &w_outoff,
-                          &w_bsums, &w_misc, &w_text, &w_docoff, &w_ids, &w_idoff, &w_starts, &w_ends, &w_srcoff, &w_span, &w_ent, &w_home, &w_entoff, &w_entcnt, &w_dstat, &w_ranges, &w_list, &w_wrec, &t_flat}) b->release();
+                          &w_bsums, &w_misc, &w_text, &w_docoff, &w_ids, &w_idoff, &w_starts, &w_ends, &w_srcoff, &w_span, &w_ent, &w_home, &w_entoff, &w_entcnt, &w_dstat, &w_ranges, &w_list, &w_wrec, &t_flat, &w_espan, &w_hspan, &w_chard}) b->release();
         for (auto &e : ev) if (e) (void)hipEventDestroy(e);
         if (stream) (void)hipStreamDestroy(stream);
         magic = 0;
@@ -323,11 +324,11 @@ bool use_wave(const Handle *h, bool want_off, int words)
     return h->m.kind == KIND_WP && h->m.wave_ok && !words && (h->variant & 0xff) != 2;
 }
 
-// Batches of a flat-form model (bf_flat.h; every BERT model) that are large enough to fill the device take the flat program: ids only.
-// Variant 4 (tests): every batch; variant 5 (A/B): never.
+// Batches of a flat-form model (bf_flat.h; every BERT model) that are large enough to fill the device take the flat program: ids, and ids
+// with their byte offsets.  Variant 4 (tests): every batch; variant 5 (A/B): never.
 bool use_flat(const Handle *h, bool want_off, int words, int64_t ndocs, int64_t total_bytes)
 {
-    if (!use_wave(h, want_off, words) || want_off || !h->m.flat_ok || ndocs <= 0) return false;
+    if (!use_wave(h, want_off, words) || !h->m.flat_ok || ndocs <= 0) return false;
     const int v = h->variant & 0xff;
     if (v == 4) return true;
     return v == 3 && ndocs >= 1024 && total_bytes >= (1 << 20);
@@ -347,7 +348,8 @@ bool reserve_ids_workspaces(Handle *h, int64_t ndocs, int64_t total_bytes, bool 
         if (use_flat(h, want_off, words, ndocs, total_bytes) &&
             (!h->w_ent.reserve((size_t)(total_bytes + 64) * 4) || !h->w_home.reserve((size_t)(total_bytes + 64) * 4) || !h->w_entoff.reserve((size_t)(ndocs + 1) * 8) ||
              !h->w_entcnt.reserve((size_t)(ndocs + 1) * 4) || !h->w_dstat.reserve((size_t)(ndocs + 1) * 4) || !h->w_list.reserve((size_t)(ndocs + 1) * 4) ||
-             !h->w_ranges.reserve((size_t)(wp_flat_ranges(ndocs, total_bytes) + 2) * 8) || !h->w_wrec.reserve((size_t)(total_bytes / 4 + 64) * 16 + (size_t)(wp_flat_ranges(ndocs, total_bytes) + 2) * 8))) return false;
+             !h->w_ranges.reserve((size_t)(wp_flat_ranges(ndocs, total_bytes) + 2) * 8) || !h->w_wrec.reserve((size_t)(total_bytes / 4 + 64) * 16 + (size_t)(wp_flat_ranges(ndocs, total_bytes) + 2) * 8) ||
+             (want_off && (!h->w_espan.reserve((size_t)(total_bytes + 64) * 4) || !h->w_hspan.reserve((size_t)(total_bytes + 64) * 8) || !h->w_chard.reserve((size_t)(ndocs + 1) * 4))))) return false;
         if (use_wave(h, want_off, words))                              // no class stream, no dirty flags
             return !want_off || h->w_span.reserve((size_t)(total_bytes + 8 * ndocs + 64) * 8);
         if (!h->w_cls.reserve((size_t)(total_bytes + 64) * 2) || !h->w_flags.reserve((size_t)((total_bytes >> 10) + 2) * 8)) return false;
@@ -409,7 +411,7 @@ int run_device(Handle *h, const char *d_text, const int64_t *d_doc_off, int64_t 
         fp.text = b.text; fp.doc_off = b.doc_off; fp.ndocs = ndocs; fp.total_bytes = total_bytes;
         fp.range_doc = h->w_ranges.as<int64_t>(); fp.nranges = nranges; fp.next_range = (unsigned long long *)(misc + 192); fp.unsafe = unsafe;
         fp.ent = h->w_ent.as<uint32_t>(); fp.home = h->w_home.as<int32_t>(); fp.ent_off = h->w_entoff.as<int64_t>(); fp.ent_cnt = h->w_entcnt.as<int32_t>();
-        fp.dstat = h->w_dstat.as<int32_t>(); fp.cold = cold;
+        fp.dstat = h->w_dstat.as<int32_t>(); fp.cold = cold; fp.espan = want_off ? h->w_espan.as<uint32_t>() : nullptr;
         fp.wrec = h->w_wrec.as<uint32_t>(); fp.wrec_cnt = (int32_t *)(h->w_wrec.as<char>() + (size_t)(total_bytes / 4 + 64) * 16);
         if (!hip_ok(hipMemsetAsync(fp.wrec_cnt, 0, (size_t)nranges * 8, s), "hipMemsetAsync")) return BF_E_DEVICE;      // (a range without documents writes nothing)
         (void)hipEventRecord(h->ev[EV_DOM0], s);
@@ -418,7 +420,7 @@ int run_device(Handle *h, const char *d_text, const int64_t *d_doc_off, int64_t 
         // the words the table did not answer: walked by a kernel of their own
         WfUnitParams up;
         up.T = fp.T; up.ini = fp.ini; up.ini_l = fp.ini_l; up.max_token_length = fp.max_token_length; up.text = b.text; up.total_bytes = total_bytes;
-        up.wrec = fp.wrec; up.wrec_cnt = fp.wrec_cnt; up.range_doc = fp.range_doc; up.doc_off = b.doc_off; up.nranges = nranges; up.ent = fp.ent; up.home = fp.home; up.cpmap = cold.cpmap; up.kind = cold.kind; up.nclasses = cold.nclasses; up.stats = cold.stats;
+        up.wrec = fp.wrec; up.wrec_cnt = fp.wrec_cnt; up.range_doc = fp.range_doc; up.doc_off = b.doc_off; up.nranges = nranges; up.ent = fp.ent; up.home = fp.home; up.espan = fp.espan; up.hspan = want_off ? h->w_hspan.as<uint32_t>() : nullptr; up.cpmap = cold.cpmap; up.kind = cold.kind; up.nclasses = cold.nclasses; up.stats = cold.stats;
         launch_wp_units(up, h->variant, s);
         (void)hipEventRecord(h->ev[EV_TOK], s);
         // the documents it hands back: the wave program, one document at a time
@@ -427,18 +429,24 @@ int run_device(Handle *h, const char *d_text, const int64_t *d_doc_off, int64_t 
         wp.T = fp.T; wp.acts = h->t_acts.as<int32_t>(); wp.acts_n = (int)m.acts_pool.size();
         wp.initial = m.wbd.initial_base; wp.loop_info = m.loop_info; wp.solo_info = m.wave_solo_info; wp.max_token_length = m.max_token_length;
         wp.text = b.text; wp.doc_off = b.doc_off; wp.ndocs = ndocs; wp.total_bytes = total_bytes;
-        wp.ids_tmp = h->w_tmp.as<int32_t>(); wp.counts = h->w_counts.as<int32_t>(); wp.max_ids = max_ids; wp.unk = unk; wp.span_tmp = nullptr;
+        wp.ids_tmp = h->w_tmp.as<int32_t>(); wp.counts = h->w_counts.as<int32_t>(); wp.max_ids = max_ids; wp.unk = unk; wp.span_tmp = want_off ? h->w_span.as<int32_t>() : nullptr;
         wp.next_doc = next_doc; wp.doc_list = h->w_list.as<int32_t>(); wp.list_n = list_n;
         wp.cold = cold; wp.cold.stats = nullptr;
         launch_wp_wave(wp, h->variant & ~0x3f000000, s);
         WfMergeParams mp;
         mp.doc_off = b.doc_off; mp.ndocs = ndocs; mp.ent = fp.ent; mp.home = fp.home; mp.ent_off = fp.ent_off; mp.ent_cnt = fp.ent_cnt; mp.dstat = fp.dstat; mp.unsafe = unsafe;
         mp.ids_tmp = wp.ids_tmp; mp.counts = wp.counts; mp.id_off = d_id_off; mp.ids_out = d_ids_out; mp.ids_cap = ids_cap; mp.status = status; mp.max_ids = max_ids; mp.unk = unk;
+        mp.espan = fp.espan; mp.hspan = up.hspan; mp.starts_out = d_starts; mp.ends_out = d_ends; mp.counts_hard = want_off ? h->w_chard.as<int32_t>() : nullptr;
         launch_wp_count(mp, s);
         ScanParams sp{h->w_counts.as<int32_t>(), ndocs, d_id_off, h->w_bsums.as<int64_t>(), nblocks};
         launch_scan(sp, s);
         (void)hipEventRecord(h->ev[EV_SCAN], s);
         launch_wp_merge(mp, s);
+        if (want_off) {
+            // the documents the wave program tokenised: their ids, and the byte offsets from the characters it staged (usually there are none)
+            CompactParams cp{b, wp.ids_tmp, mp.counts_hard, d_id_off, d_ids_out, ids_cap, status, 0, nullptr, wp.span_tmp, nullptr, d_starts, d_ends, list_n};
+            launch_compact(cp, s);
+        }
         (void)hipEventRecord(h->ev[EV_COMPACT], s);
         h->ev_valid = true;
         if (!hip_ok(hipGetLastError(), "kernel launch")) return BF_E_DEVICE;

@@ -39,6 +39,7 @@ struct WfParams {
     int32_t *home;                   // [total_bytes + 64] ids of the words of two and more pieces: piece j of the word that starts at byte p -> home[p + j]
     int64_t *ent_off; int32_t *ent_cnt;                    // per document: its first entry, its number of entries
     int32_t *dstat;                  // per document, zero before the launch: WF_D_* bits
+    uint32_t *espan;                 // offsets API (else nullptr), parallel to ent: where the token is in its document (WF_SPAN_*: first byte | bytes - 1 << 24)
     // the words the table did not answer (16-byte records, bf_flat_body.h).  A range owns the records [first byte / 4, last byte / 4): the words a unit
     // holds in registers from the front, the others from the back; wrec_cnt[2 r], [2 r + 1] = how many of each (written by the range's wave)
     uint32_t *wrec; int32_t *wrec_cnt;
@@ -51,6 +52,7 @@ struct WfUnitParams {
     const uint8_t *text; int64_t total_bytes;
     const uint32_t *wrec; const int32_t *wrec_cnt; const int64_t *range_doc; const int64_t *doc_off; int nranges;      // the ranges' lists (WfParams)
     uint32_t *ent; int32_t *home;
+    const uint32_t *espan; uint32_t *hspan;                 // offsets API (else nullptr): the words' spans (WfParams); INSTEAD of home: (id, span) of piece j of the word at byte p -> hspan[2 (p + j)], [2 (p + j) + 1]
     DevCpMap cpmap; const uint8_t *kind; int nclasses;      // fused code point -> charmap -> class map, kinds of the classes (the table of the ASCII bytes is made of them)
     unsigned long long *stats;       // optional: [8] rounds [9] batches
 };
@@ -63,6 +65,9 @@ struct WfMergeParams {
     int32_t *counts;                 // [ndocs] in: the wave program's counts of those documents; out (k_wp_count): every document's
     const int64_t *id_off; int32_t *ids_out; int64_t ids_cap; int *status;
     int max_ids, unk;
+    // offsets API (else nullptr): the spans of the entries and of the pieces at the homes; the byte offsets of every id (tokdll:1263-1297).  The documents
+    // the wave program tokenised are not copied here then: counts_hard[d] = their count (0 for all others) for the kernel that does (k_compact_text)
+    const uint32_t *espan, *hspan; int32_t *starts_out, *ends_out; int32_t *counts_hard;
 };
 
 } // namespace bfa

@@ -153,9 +153,10 @@ struct WfWave {
     int dn, dnext, wlo;                  // its documents; the next one whose first byte has not been met; the first one of the window (all relative to dlo)
     int len;                             // its bytes
     int32_t win;                         // per lane: first byte (range-relative) of document dlo + wlo + lane
-    const uint8_t *txt; uint32_t *ent; int32_t *home;
+    const uint8_t *txt; uint32_t *ent, *esp; int32_t *home;
     int k, kdoc;                         // tokens so far; tokens before the open document
     int open_start;                      // first byte of the run that reaches the end of the chunk before (-1: none)
+    int doc0;                            // first byte of the document that is open where the chunk begins (offsets API)
     unsigned long long na_prev;          // the lanes of the chunk before that hold a byte >= 0x80
     uint32_t cov_carry, loop_carry;      // of lane 63 of the chunk before: bytes of the next chunk that belong to its last character
     int nrec, wf_n, ws_n;                // words in S.rec; words of this range on its two lists
@@ -166,7 +167,7 @@ struct WfWave {
     {
         lane = wv::lane(); nrec = 0; wf_n = ws_n = 0; bad_lo = bad_hi = hard_lo = hard_hi = 0;
         st_chunks = st_ascii = st_tok = st_hit = st_notes = st_drains = st_rounds = st_hard = 0;
-        dlo = 0; dn = dnext = wlo = 0; b0 = 0; len = 0; win = 0; txt = nullptr; ent = nullptr; home = nullptr; k = kdoc = 0; open_start = -1; cov_carry = loop_carry = 0; na_prev = 0;
+        dlo = 0; dn = dnext = wlo = 0; b0 = 0; len = 0; win = 0; txt = nullptr; ent = esp = nullptr; home = nullptr; k = kdoc = 0; open_start = -1; doc0 = 0; cov_carry = loop_carry = 0; na_prev = 0;
     }
 
     // first byte of document dlo + d (0 <= d <= dn), range-relative; d is wave-uniform
@@ -407,6 +408,15 @@ struct WfWave {
             const uint32_t ai = A.id, bi = B.id;
             const bool hit = have && (hita || hitb);
             if (hit) eout[t0 + lane] = hita ? ai : bi;
+            if (p.espan) {
+                // offsets API: where the token is in its document (the first byte of the last document that begins at or before it; a one-element
+                // token is one character: its bytes from its first one)
+                int ds = doc0;
+                for (int d = dfirst; d < dnext; ++d) { const int o = off_rel(d); ds = s0 >= o ? o : ds; }
+                int bl = blen > 0 ? blen : 1;
+                if (!ascii_chunk && have && solo) { const uint32_t b = txt[s0]; bl = b < 0x80u ? 1 : b < 0xE0u ? 2 : b < 0xF0u ? 3 : 4; }      // (a one-element token lies in this chunk)
+                if (have) esp[k + t0 + lane] = (uint32_t)(s0 - ds) | ((uint32_t)(bl - 1) << WF_SPAN_LEN_SHIFT);
+            }
             if (STATS) st_hit += (unsigned long long)__builtin_popcountll(wv::ballot(hit));
             const bool rest = have && !hit;
             const unsigned long long RB = wv::ballot(rest), TL = wv::ballot(rest && blen == 0);
@@ -428,6 +438,7 @@ struct WfWave {
             }
         }
         k += ntok; open_start = new_open; na_prev = na;
+        if (p.espan && dnext > dfirst) doc0 = off_rel(dnext - 1);
     }
 
     BF_WVD void range(int64_t r)
@@ -437,8 +448,8 @@ struct WfWave {
         if (dlo >= dhi) return;
         dn = (int)(dhi - dlo);
         b0 = p.doc_off[dlo]; len = (int)(p.doc_off[dhi] - b0);
-        txt = p.text + b0; ent = p.ent + b0; home = p.home + b0;
-        k = kdoc = 0; dnext = 0; open_start = -1; cov_carry = loop_carry = 0; na_prev = 0; bad_lo = bad_hi = hard_lo = hard_hi = 0; wf_n = ws_n = 0;
+        txt = p.text + b0; ent = p.ent + b0; home = p.home + b0; esp = p.espan ? p.espan + b0 : nullptr;
+        k = kdoc = 0; dnext = 0; open_start = -1; doc0 = 0; cov_carry = loop_carry = 0; na_prev = 0; bad_lo = bad_hi = hard_lo = hard_hi = 0; wf_n = ws_n = 0;
         load_window(0);
         uint64_t own = load_chunk(0);
         for (int c = 0; c < len; c += WF_CHUNK) {
@@ -494,6 +505,10 @@ BF_WVD void wf_units(const WfUnitParams &p, const uint32_t *lut, uint16_t *cbuf,
     const bool anchored0 = p.ini_l != LX_NO_STATE && p.max_token_length > 1;
     const uint64_t *T = p.T;
     uint32_t state[NU], ftag[NU], c_cur[NU], w3[NU]; int L[NU], j[NU], fp[NU], cnt[NU], clen[NU]; int32_t id0[NU];
+    // offsets API: where the walk under way started (a piece is [from, fp)); the span of the first piece; the word's first byte in its document;
+    // MODE 1: the bytes at which the word's characters start, its bytes
+    int from[NU]; uint32_t sp0[NU], wstart[NU]; uint32_t startm_keep = 0; int Lb = 0;
+    const bool offs = p.hspan != nullptr;
     int64_t ea[NU], pa[NU];
     uint64_t t_lo[NU], t_hi[NU];
     bool anch[NU], act[NU], missed[NU], stale[NU];
@@ -536,6 +551,8 @@ BF_WVD void wf_units(const WfUnitParams &p, const uint32_t *lut, uint16_t *cbuf,
         state[u] = anchored0 ? p.ini_l : p.ini; j[u] = 0; fp[u] = -1; cnt[u] = 0; ftag[u] = 0; id0[u] = 0; clen[u] = 1;
         anch[u] = anchored0; act[u] = have; missed[u] = false; stale[u] = MODE == 2 && have;
         c_cur[u] = 0;
+        from[u] = 0; sp0[u] = 0; wstart[u] = 0;
+        if (offs && have) wstart[u] = p.espan[ea[u]] & WF_SPAN_POS_MASK;
     }
     { bool a = false;
 #pragma unroll
@@ -570,6 +587,7 @@ BF_WVD void wf_units(const WfUnitParams &p, const uint32_t *lut, uint16_t *cbuf,
                 cbuf[lane * 16 + __builtin_popcount(startm & ((1u << i) - 1u))] = (uint16_t)(wv_cpmap_get(p.cpmap, cp) & LX_T_CLS_MASK);
             }
         }
+        startm_keep = startm; Lb = L[0];
         L[0] = __builtin_popcount(startm);                                     // characters from here on
         wv::sync();
     }
@@ -611,13 +629,28 @@ BF_WVD void wf_units(const WfUnitParams &p, const uint32_t *lut, uint16_t *cbuf,
                     if (fp[u] >= 0) {                                        // fp: the position behind the last character of the match
                         const int32_t id = (int32_t)(ftag[u] & 0x7FFFFFFFu);
                         if (cnt[u] == 0) id0[u] = id;
-                        else { if (cnt[u] == 1) hm[0] = id0[u]; hm[cnt[u]] = id; }
+                        else if (!offs) { if (cnt[u] == 1) hm[0] = id0[u]; hm[cnt[u]] = id; }
+                        if (offs) {
+                            // the piece's bytes [fb, tb) of the word (MODE 1 counts characters: the byte a character starts at is a bit of startm_keep)
+                            int fb = from[u], tb = fp[u];
+                            if (MODE == 1) {
+                                uint32_t mf = startm_keep, mt = startm_keep;
+                                for (int i = 0; i < fb; ++i) mf &= mf - 1u;
+                                for (int i = 0; i < tb; ++i) mt &= mt - 1u;
+                                fb = mf ? __builtin_ctz(mf) : Lb; tb = mt ? __builtin_ctz(mt) : Lb;
+                            }
+                            const uint32_t sp = (wstart[u] + (uint32_t)fb) | ((uint32_t)(tb - fb - 1) << WF_SPAN_LEN_SHIFT);
+                            // (id, span) of a piece side by side: one scattered store of eight bytes, and one gather in the merge
+                            uint32_t *hs = p.hspan + 2 * (ea[u] + (int64_t)w3[u]);
+                            if (cnt[u] == 0) sp0[u] = sp;
+                            else { if (cnt[u] == 1) { hs[0] = (uint32_t)id0[u]; hs[1] = sp0[u]; } hs[2 * cnt[u]] = (uint32_t)id; hs[2 * cnt[u] + 1] = sp; }
+                        }
                         ++cnt[u];
                         const int nf = fp[u];
                         if (nf >= L[u]) {
                             p.ent[ea[u]] = cnt[u] == 1 ? (uint32_t)id0[u] : (WF_ENT_FLAG | ((uint32_t)cnt[u] << WF_ENT_CNT_SHIFT) | w3[u]);
                             act[u] = false;
-                        } else { state[u] = p.ini; j[u] = nf; fp[u] = -1; anch[u] = false; missed[u] = false; }
+                        } else { state[u] = p.ini; j[u] = nf; from[u] = nf; fp[u] = -1; anch[u] = false; missed[u] = false; }
                     } else if (anch[u]) { state[u] = p.ini; j[u] = 0; fp[u] = -1; anch[u] = false; missed[u] = false; }
                     else { p.ent[ea[u]] = WF_ENT_FLAG; act[u] = false; }        // a gap: UnkId
                     if (act[u]) { if (MODE != 2) c_cur[u] = cls_at(u, j[u]); else stale[u] = true; }
@@ -694,37 +727,41 @@ BF_WVD void wf_count_docs(const WfMergeParams &p, int64_t base)
         int cnt = (st & WF_D_HARD) ? old : (st & WF_D_BAD) ? 0 : ec + extra;
         if (!(st & WF_D_HARD) && cnt > p.max_ids) cnt = p.max_ids;
         p.counts[d] = cnt;
+        if (p.counts_hard) p.counts_hard[d] = (st & WF_D_HARD) ? cnt : 0;
     }
 }
 
-// One entry vector of a document (or of a block of documents whose ids follow one another): ids to out[run ...); returns the ids it held
-BF_WVD int wf_merge_vec(const WfMergeParams &p, uint32_t e, bool have, int64_t eidx, int32_t *out, int run, int cap)
+// a span (WF_SPAN_*) as the byte offsets of the id's first and last byte in its document (tokdll:1263-1297)
+BF_WVD void wf_span_out(const WfMergeParams &p, int64_t at, uint32_t sp)
+{
+    const int32_t st = (int32_t)(sp & WF_SPAN_POS_MASK);
+    p.starts_out[at] = st; p.ends_out[at] = st + (int32_t)(sp >> WF_SPAN_LEN_SHIFT);
+}
+
+// One entry vector of a document: ids to out[run ...); returns the ids it held.  OFFS: their spans to the same places of starts_out / ends_out.
+template <bool OFFS>
+BF_WVD int wf_merge_vec(const WfMergeParams &p, uint32_t e, bool have, int64_t eidx, int64_t dst, int run, int cap)
 {
     const int x = have ? wf_entry_ids(e) : 0;
     const int inc = wv::incl_scan(x), pos = run + inc - x;
     const bool flag = have && (e & WF_ENT_FLAG) != 0u;
     const int nn = flag ? (int)((e & ~WF_ENT_FLAG) >> WF_ENT_CNT_SHIFT) : 0;
-    // the ids of a word of several pieces come from its home: the first four in one go (one trip to memory for the whole vector)
-    const int32_t *hm = p.home + eidx + (int64_t)(e & WF_ENT_DELTA_MASK);
-    int32_t v0 = flag ? p.unk : (int32_t)e, v1 = 0, v2 = 0, v3 = 0;
-    if (nn > 0) v0 = hm[0];
-    if (nn > 1) v1 = hm[1];
-    if (nn > 2) v2 = hm[2];
-    if (nn > 3) v3 = hm[3];
-    if (have && pos < cap) out[pos] = v0;
-    if (nn > 1 && pos + 1 < cap) out[pos + 1] = v1;
-    if (nn > 2 && pos + 2 < cap) out[pos + 2] = v2;
-    if (nn > 3 && pos + 3 < cap) out[pos + 3] = v3;
-    if (wv::any(nn > 4)) for (int j = 4; j < nn && pos + j < cap; ++j) out[pos + j] = hm[j];
+    const int64_t hi = eidx + (int64_t)(e & WF_ENT_DELTA_MASK);
+    int32_t *out = p.ids_out + dst;
+    if (have && nn == 0 && pos < cap) { out[pos] = flag ? p.unk : (int32_t)e; if (OFFS) wf_span_out(p, dst + pos, p.espan[eidx]); }
+    for (int j = 0; j < nn && pos + j < cap; ++j) {
+        if (OFFS) { out[pos + j] = (int32_t)p.hspan[2 * (hi + j)]; wf_span_out(p, dst + pos + j, p.hspan[2 * (hi + j) + 1]); }
+        else out[pos + j] = p.home[hi + j];
+    }
     return wv::bcast(inc, 63);
 }
 
 // ids a trip of the merge stages in LDS: 256 entries, their extra ids and the <= 3 ids carried from the trip before
-constexpr int WF_MBUF = 1024;
+template <bool OFFS> struct WfMergeLds { static constexpr int N = OFFS ? 512 : 1024; alignas(16) int32_t buf[N]; alignas(16) uint32_t sbuf[OFFS ? N : 4]; };
 struct alignas(16) WfQuad { int32_t v[4]; };
-struct WfMergeLds { alignas(16) int32_t buf[WF_MBUF]; };
 
-BF_WVD void wf_merge_docs(const WfMergeParams &p, int64_t base, bool &over, WfMergeLds &M)
+template <bool OFFS>
+BF_WVD void wf_merge_docs(const WfMergeParams &p, int64_t base, bool &over, WfMergeLds<OFFS> &M)
 {
     const int lane = wv::lane();
     const int64_t d = base + lane;
@@ -743,31 +780,33 @@ BF_WVD void wf_merge_docs(const WfMergeParams &p, int64_t base, bool &over, WfMe
     // next trip's on its way); the trip's ids are put together in LDS -- a plain id at its place, the pieces of a word of several from its home
     // by the lane that holds its entry -- and leave as whole aligned 16-byte rows (what bounds a streaming kernel here is the number of
     // vector-memory instructions a CU can issue: a store per word of several pieces was most of them); the <= 3 ids behind the last whole row
-    // wait for the next trip.
+    // wait for the next trip.  OFFS: the spans travel the same way (a second buffer) and leave as two rows, first and last byte.
     const int64_t eo_n = wv::shfl_down(eo, 1);
     if (!wv::any(lane < nd && (st != 0 || capped))) {
       unsigned long long brk = wv::ballot(lane < nd && (lane + 1 == nd || eo_n != eo + ec));      // the lanes that end a contiguous piece (a range of the flat program ends there)
       for (int first = 0; brk;) {
         const int lastl = __builtin_ctzll(brk); brk &= brk - 1ull;
         const int64_t E0 = wv::bcast(eo, first), E1 = wv::bcast(eo + (int64_t)ec, lastl);
-        int32_t *const op = p.ids_out + wv::bcast(o, first);
+        const int64_t O0 = wv::bcast(o, first);
         first = lastl + 1;
-        const int head = (int)(((uintptr_t)op >> 2) & 3u);
-        int32_t *outq = op - head;                      // M.buf[i] is outq[i]; outq is 16-byte aligned
+        const int head = (int)(((uintptr_t)(p.ids_out + O0) >> 2) & 3u);
+        int64_t oq = O0 - head;                         // M.buf[i] is ids_out[oq + i]; that address is 16-byte aligned
+        const bool rows_ok = !OFFS || ((((uintptr_t)(p.starts_out + oq)) | ((uintptr_t)(p.ends_out + oq))) & 15u) == 0u;     // (the three outputs are aligned alike but for a caller's odd pointers)
         int lo = head, carry = head;                    // the first slot that is this piece's; the slots filled so far
-        auto load4 = [&](int64_t t, uint32_t (&e)[4]) {
+        auto load4 = [&](const uint32_t *src, int64_t t, uint32_t (&e)[4]) {
             const int64_t a = t + 4 * lane;
             e[0] = e[1] = e[2] = e[3] = 0u;
-            if (a + 4 <= E1) __builtin_memcpy(e, p.ent + a, 16);
-            else for (int u = 0; u < 4; ++u) if (a + u < E1) e[u] = p.ent[a + u];
+            if (a + 4 <= E1) __builtin_memcpy(e, src + a, 16);
+            else for (int u = 0; u < 4; ++u) if (a + u < E1) e[u] = src[a + u];
         };
-        uint32_t en[4];
-        load4(E0, en);
+        uint32_t en[4], sn[4] = {0u, 0u, 0u, 0u};
+        load4(p.ent, E0, en);
+        if (OFFS) load4(p.espan, E0, sn);
         for (int64_t t = E0; t < E1; t += 256) {
             const int64_t a = t + 4 * lane;
-            uint32_t e[4] = {en[0], en[1], en[2], en[3]};
+            uint32_t e[4] = {en[0], en[1], en[2], en[3]}, sp[4] = {sn[0], sn[1], sn[2], sn[3]};
             const int nin = a + 4 <= E1 ? 4 : (a < E1 ? (int)(E1 - a) : 0);
-            if (t + 256 < E1) load4(t + 256, en);
+            if (t + 256 < E1) { load4(p.ent, t + 256, en); if (OFFS) load4(p.espan, t + 256, sn); }
             const bool flagged = ((e[0] | e[1] | e[2] | e[3]) & WF_ENT_FLAG) != 0u;
             const bool any_f = wv::any(flagged);
             int n[4], xs = 0;
@@ -775,35 +814,41 @@ BF_WVD void wf_merge_docs(const WfMergeParams &p, int64_t base, bool &over, WfMe
             for (int u = 0; u < 4; ++u) { n[u] = u < nin ? wf_entry_ids(e[u]) : 0; xs += n[u]; }
             int pos0 = carry + 4 * lane, sum = E1 - t < 256 ? (int)(E1 - t) : 256;
             if (any_f) { const int inc = wv::incl_scan(xs); pos0 = carry + inc - xs; sum = wv::bcast(inc, 63); }
-            if (carry + sum > WF_MBUF) {
+            if (carry + sum > WfMergeLds<OFFS>::N) {
                 // more ids than the buffer holds (entries of four ids and more on average): what waits leaves, the trip's ids go out one by one
-                if (lane >= lo && lane < carry) outq[lane] = M.buf[lane];
+                if (lane >= lo && lane < carry) { p.ids_out[oq + lane] = M.buf[lane]; if (OFFS) wf_span_out(p, oq + lane, M.sbuf[lane]); }
                 int pos = pos0;
                 for (int u = 0; u < 4; ++u) {
                     if (u >= nin) break;
                     const uint32_t eu = e[u];
                     const int nn = (eu & WF_ENT_FLAG) ? (int)((eu & ~WF_ENT_FLAG) >> WF_ENT_CNT_SHIFT) : -1;       // -1: a plain id, 0: UnkId
-                    if (nn <= 0) outq[pos] = nn < 0 ? (int32_t)eu : p.unk;
-                    else { const int32_t *hm = p.home + (a + u) + (int64_t)(eu & WF_ENT_DELTA_MASK); for (int j = 0; j < nn; ++j) outq[pos + j] = hm[j]; }
+                    if (nn <= 0) { p.ids_out[oq + pos] = nn < 0 ? (int32_t)eu : p.unk; if (OFFS) wf_span_out(p, oq + pos, sp[u]); }
+                    else {
+                        const int64_t hi = (a + u) + (int64_t)(eu & WF_ENT_DELTA_MASK);
+                        for (int j = 0; j < nn; ++j) {
+                            if (OFFS) { p.ids_out[oq + pos + j] = (int32_t)p.hspan[2 * (hi + j)]; wf_span_out(p, oq + pos + j, p.hspan[2 * (hi + j) + 1]); }
+                            else p.ids_out[oq + pos + j] = p.home[hi + j];
+                        }
+                    }
                     pos += n[u];
                 }
-                int32_t *const np = outq + carry + sum;
-                const int h2 = (int)(((uintptr_t)np >> 2) & 3u);
-                outq = np - h2; lo = carry = h2;
+                const int64_t np = oq + carry + sum;
+                const int h2 = (int)(((uintptr_t)(p.ids_out + np) >> 2) & 3u);
+                oq = np - h2; lo = carry = h2;
                 wv::sync();
                 continue;
             }
             // ---- the trip's ids to their slots
             if (!flagged) {
 #pragma unroll
-                for (int u = 0; u < 4; ++u) if (u < nin) M.buf[pos0 + u] = (int32_t)e[u];
+                for (int u = 0; u < 4; ++u) if (u < nin) { M.buf[pos0 + u] = (int32_t)e[u]; if (OFFS) M.sbuf[pos0 + u] = sp[u]; }
             } else {
                 int pos = pos0;
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const uint32_t eu = e[u];
                     const int nn = (eu & WF_ENT_FLAG) ? (int)((eu & ~WF_ENT_FLAG) >> WF_ENT_CNT_SHIFT) : -1;
-                    if (u < nin && nn <= 0) M.buf[pos] = nn < 0 ? (int32_t)eu : p.unk;
+                    if (u < nin && nn <= 0) { M.buf[pos] = nn < 0 ? (int32_t)eu : p.unk; if (OFFS) M.sbuf[pos] = sp[u]; }
                     pos += n[u];
                 }
             }
@@ -819,14 +864,26 @@ BF_WVD void wf_merge_docs(const WfMergeParams &p, int64_t base, bool &over, WfMe
                         const uint32_t eu = u == 0 ? e[0] : u == 1 ? e[1] : u == 2 ? e[2] : e[3];
                         const int pu = u == 0 ? pos0 : u == 1 ? p1 : u == 2 ? p2 : p3;
                         const int nn = (int)((eu & ~WF_ENT_FLAG) >> WF_ENT_CNT_SHIFT);
-                        const int32_t *hm = p.home + (a + u) + (int64_t)(eu & WF_ENT_DELTA_MASK);
-                        int32_t v[4];
-                        __builtin_memcpy(v, hm, 16);
-                        M.buf[pu] = v[0];
-                        if (nn > 1) M.buf[pu + 1] = v[1];
-                        if (nn > 2) M.buf[pu + 2] = v[2];
-                        if (nn > 3) M.buf[pu + 3] = v[3];
-                        for (int j = 4; j < nn; ++j) M.buf[pu + j] = hm[j];
+                        const int64_t hi = (a + u) + (int64_t)(eu & WF_ENT_DELTA_MASK);
+                        if (OFFS) {
+                            const uint32_t *hp = p.hspan + 2 * hi;            // (id, span) pairs
+                            uint32_t v[8];
+                            __builtin_memcpy(v, hp, 32);
+                            M.buf[pu] = (int32_t)v[0]; M.sbuf[pu] = v[1];
+                            if (nn > 1) { M.buf[pu + 1] = (int32_t)v[2]; M.sbuf[pu + 1] = v[3]; }
+                            if (nn > 2) { M.buf[pu + 2] = (int32_t)v[4]; M.sbuf[pu + 2] = v[5]; }
+                            if (nn > 3) { M.buf[pu + 3] = (int32_t)v[6]; M.sbuf[pu + 3] = v[7]; }
+                            for (int j = 4; j < nn; ++j) { M.buf[pu + j] = (int32_t)hp[2 * j]; M.sbuf[pu + j] = hp[2 * j + 1]; }
+                        } else {
+                            const int32_t *hm = p.home + hi;
+                            int32_t v[4];
+                            __builtin_memcpy(v, hm, 16);
+                            M.buf[pu] = v[0];
+                            if (nn > 1) M.buf[pu + 1] = v[1];
+                            if (nn > 2) M.buf[pu + 2] = v[2];
+                            if (nn > 3) M.buf[pu + 3] = v[3];
+                            for (int j = 4; j < nn; ++j) M.buf[pu + j] = hm[j];
+                        }
                     }
                 }
             }
@@ -837,14 +894,24 @@ BF_WVD void wf_merge_docs(const WfMergeParams &p, int64_t base, bool &over, WfMe
             const int nfull = last ? total : (total & ~3);
             for (int q = 4 * lane; q < nfull; q += 256) {
                 const WfQuad v = *(const WfQuad *)(M.buf + q);
-                if (q >= lo && q + 4 <= nfull) *(WfQuad *)(outq + q) = v;
-                else for (int j = 0; j < 4; ++j) if (q + j >= lo && q + j < nfull) outq[q + j] = v.v[j];
+                const bool whole = q >= lo && q + 4 <= nfull;
+                if (whole) *(WfQuad *)(p.ids_out + oq + q) = v;
+                else for (int j = 0; j < 4; ++j) if (q + j >= lo && q + j < nfull) p.ids_out[oq + q + j] = v.v[j];
+                if (OFFS) {
+                    const WfQuad w = *(const WfQuad *)(M.sbuf + q);
+                    WfQuad sa, sb;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { sa.v[j] = (int32_t)((uint32_t)w.v[j] & WF_SPAN_POS_MASK); sb.v[j] = sa.v[j] + (int32_t)((uint32_t)w.v[j] >> WF_SPAN_LEN_SHIFT); }
+                    if (whole && rows_ok) { *(WfQuad *)(p.starts_out + oq + q) = sa; *(WfQuad *)(p.ends_out + oq + q) = sb; }
+                    else for (int j = 0; j < 4; ++j) if (q + j >= lo && q + j < nfull) { p.starts_out[oq + q + j] = sa.v[j]; p.ends_out[oq + q + j] = sb.v[j]; }
+                }
             }
             const int rest = total - nfull;
             const int32_t keep = lane < rest ? M.buf[nfull + lane] : 0;
+            const uint32_t skeep = (OFFS && lane < rest) ? M.sbuf[nfull + lane] : 0u;
             wv::sync();
-            if (lane < rest) M.buf[lane] = keep;
-            outq += nfull; lo = 0; carry = rest;
+            if (lane < rest) { M.buf[lane] = keep; if (OFFS) M.sbuf[lane] = skeep; }
+            oq += nfull; lo = 0; carry = rest;
         }
       }
       return;
@@ -856,11 +923,11 @@ BF_WVD void wf_merge_docs(const WfMergeParams &p, int64_t base, bool &over, WfMe
         const int64_t src = wv::bcast(eo, i), dst = wv::bcast(o, i);
         const int cap = wv::bcast(cnt, i);
         if (wv::bcast(st, i) & WF_D_HARD) {                                   // tokenised by the wave program: its ids are in place
-            for (int t = lane; t < cap; t += 64) p.ids_out[dst + t] = p.ids_tmp[src + t];
+            if (!OFFS) for (int t = lane; t < cap; t += 64) p.ids_out[dst + t] = p.ids_tmp[src + t];      // (OFFS: k_compact_text copies them, and makes their byte offsets)
             continue;
         }
         int run = 0;
-        for (int t = 0; t < n && run < cap; t += 64) run += wf_merge_vec(p, t + lane < n ? p.ent[src + t + lane] : 0u, t + lane < n, src + t + lane, p.ids_out + dst, run, cap);
+        for (int t = 0; t < n && run < cap; t += 64) run += wf_merge_vec<OFFS>(p, t + lane < n ? p.ent[src + t + lane] : 0u, t + lane < n, src + t + lane, dst, run, cap);
     }
 }
 

@@ -22,6 +22,8 @@ constexpr uint32_t WF_ENT_FLAG = 0x80000000u;   // entry with bit 31: [30:25] nu
 constexpr int WF_ENT_CNT_SHIFT = 25;
 constexpr uint32_t WF_ENT_DELTA_MASK = (1u << WF_ENT_CNT_SHIFT) - 1u;
 constexpr int32_t WF_D_BAD = 1, WF_D_HARD = 2;  // dstat[] bits: invalid UTF-8 (0 ids); handed to the wave program
+constexpr int WF_SPAN_LEN_SHIFT = 24;    // a span (offsets API): [21:0] first byte in the document, [29:24] bytes - 1
+constexpr uint32_t WF_SPAN_POS_MASK = (1u << 22) - 1u;
 constexpr int64_t WF_DOC_MAX = 1 << 22;  // a batch with a longer document (or with offsets out of order) is not taken (k_wp_pre sets *unsafe)
 constexpr int64_t WF_RANGE_MAX = 1 << 22; // bytes a range aims at, at most (a range ends with a whole document: < WF_RANGE_MAX + WF_DOC_MAX bytes)
 // A key is 12 bytes: the codes of the word's characters, first character in the lowest byte, 0 behind the word (k0: characters 0..7, k1: 8..11).

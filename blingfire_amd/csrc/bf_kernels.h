@@ -109,6 +109,7 @@ struct CompactParams {
     const int32_t *first;       // optional: index of the first id inside the slot (Unigram flat kernel writes ids right-aligned)
     // offsets API (all optional): stream positions of the staged ids -> byte offsets in the original text (tokdll:1263-1273,1519-1529)
     const int32_t *span_tmp; const int32_t *src_off; int32_t *starts_out; int32_t *ends_out;
+    const unsigned int *only_if = nullptr;      // optional: nothing to do when *only_if == 0 (the documents the flat program hands back: usually none)
 };
 
 // flags: one bit per 16-byte chunk of the text (u64 per KiB, + 1), or nullptr for the one-pass wave-per-document form

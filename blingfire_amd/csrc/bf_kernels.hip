@@ -750,9 +750,10 @@ void launch_wp_wave(const WpWaveParams &p, int variant, hipStream_t s)
     const int per_cu_override = (variant >> 24) & 0x3f;
     typedef WvLds<1024, 256, 8> L;
     typedef WvLds<1024, 256, 8, true> LO;
-    static int pc_ids = 0, pc_off = 0, pc_list = 0;
+    static int pc_ids = 0, pc_off = 0, pc_list = 0, pc_list_off = 0;
     int per_cu;
-    if (p.doc_list) { per_cu = wp_blocks_per_cu(k_wp_wave<L, 1, 3, 8, false, 4, false, 15, true>, pc_list); grab = 1; }
+    if (p.doc_list && p.span_tmp) { per_cu = wp_blocks_per_cu(k_wp_wave<LO, 1, 3, 6, false, 4, true, 15, true>, pc_list_off); grab = 1; }
+    else if (p.doc_list) { per_cu = wp_blocks_per_cu(k_wp_wave<L, 1, 3, 8, false, 4, false, 15, true>, pc_list); grab = 1; }
     else if (p.span_tmp) per_cu = wp_blocks_per_cu(k_wp_wave<LO, 1, 3, 6, false, 4, true, 15>, pc_off);
     else per_cu = wp_blocks_per_cu(k_wp_wave<L, 1, 3, 8, false, 4, false, 15>, pc_ids);
     if (per_cu_override > 0) per_cu = per_cu_override;
@@ -763,7 +764,8 @@ void launch_wp_wave(const WpWaveParams &p, int variant, hipStream_t s)
     }
     if (blocks < 1) blocks = 1;
     const dim3 g((unsigned)blocks), t(256);
-    if (p.doc_list) hipLaunchKernelGGL((k_wp_wave<L, 1, 3, 8, false, 4, false, 15, true>), g, t, 0, s, p, grab);
+    if (p.doc_list && p.span_tmp) hipLaunchKernelGGL((k_wp_wave<LO, 1, 3, 6, false, 4, true, 15, true>), g, t, 0, s, p, grab);
+    else if (p.doc_list) hipLaunchKernelGGL((k_wp_wave<L, 1, 3, 8, false, 4, false, 15, true>), g, t, 0, s, p, grab);
     else if (p.span_tmp) hipLaunchKernelGGL((k_wp_wave<LO, 1, 3, 6, false, 4, true, 15>), g, t, 0, s, p, grab);
     else if (p.cold.stats) hipLaunchKernelGGL((k_wp_wave<L, 1, 3, 8, true, 4, false, 15>), g, t, 0, s, p, grab);
     else hipLaunchKernelGGL((k_wp_wave<L, 1, 3, 8, false, 4, false, 15>), g, t, 0, s, p, grab);
@@ -860,12 +862,13 @@ __global__ __launch_bounds__(256) void k_wp_count(WfMergeParams p)
     for (int64_t base = wave0 * 64; base < p.ndocs; base += nwaves * 64) wf_count_docs(p, base);
 }
 
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_wp_merge(WfMergeParams p)
+template <bool OFFS>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OFFS ? 6 : 8, OFFS ? 6 : 8))) void k_wp_merge(WfMergeParams p)
 {
     const int64_t wave0 = (int64_t)blockIdx.x * 4 + wave_in_block(), nwaves = (int64_t)gridDim.x * 4;
-    __shared__ WfMergeLds lds[4];
+    __shared__ WfMergeLds<OFFS> lds[4];
     bool over = false;
-    for (int64_t base = wave0 * 64; base < p.ndocs; base += nwaves * 64) wf_merge_docs(p, base, over, lds[wave_in_block()]);
+    for (int64_t base = wave0 * 64; base < p.ndocs; base += nwaves * 64) wf_merge_docs<OFFS>(p, base, over, lds[wave_in_block()]);
     if (over) atomicOr(p.status, 1);
 }
 
@@ -961,10 +964,12 @@ void launch_wp_merge(const WfMergeParams &p, hipStream_t s)
 {
     static int pc = 0;
     int64_t blocks = (p.ndocs + 255) / 256;
-    const int64_t resident = (int64_t)device_cus() * wp_blocks_per_cu(k_wp_merge, pc);      // one round of workgroups: every wave has the same share
+    static int pc_off = 0;
+    const int64_t resident = (int64_t)device_cus() * (p.espan ? wp_blocks_per_cu(k_wp_merge<true>, pc_off) : wp_blocks_per_cu(k_wp_merge<false>, pc));      // one round of workgroups: every wave has the same share
     if (blocks > resident) blocks = resident;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(k_wp_merge, dim3((unsigned)blocks), dim3(256), 0, s, p);
+    if (p.espan) hipLaunchKernelGGL(k_wp_merge<true>, dim3((unsigned)blocks), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL(k_wp_merge<false>, dim3((unsigned)blocks), dim3(256), 0, s, p);
 }
 
 } // namespace bfa
@@ -3055,6 +3060,7 @@ __device__ __forceinline__ int select_bit64(unsigned long long m, int k)       /
 
 __global__ __launch_bounds__(256) void k_compact_text(CompactParams p)
 {
+    if (p.only_if && *p.only_if == 0u) return;
     const int lane = lane_id();
     const int64_t wave0 = (int64_t)blockIdx.x * 4 + wave_in_block();
     const int64_t nwaves = (int64_t)gridDim.x * 4;

@@ -289,9 +289,12 @@ long bft_emu_bpe_seg_batch(void *hv, const uint8_t *text, const int64_t *doc_off
 // stats (optional, 16 counters): [0] chunks [1] plain-ASCII chunks [2] tokens [3] table hits [4] words for the list [7] documents handed back;
 // [8] = documents on the list of the wave program, [9] = 1 when the batch was not fit, [10] unit rounds, [11] words on the list.
 // wrec_cap_in > 0: capacity of the word list (tests: a list that is too small).
-long bft_emu_flat_batch(void *hv, const uint8_t *text, long text_bytes, const int64_t *doc_off, long ndocs, int max_ids, int unk, int nwaves, int nranges,
-                        int32_t *ids_out, long ids_cap, int64_t *id_off, unsigned long long *stats, long wrec_cap_in)
+// starts_out / ends_out (optional): the offsets API -- the byte offsets of every id (the listed documents': the OFFS + LIST instance of the wave
+// program and the characters -> bytes step of k_compact_text restated).
+static long emu_flat_batch(void *hv, const uint8_t *text, long text_bytes, const int64_t *doc_off, long ndocs, int max_ids, int unk, int nwaves, int nranges,
+                           int32_t *ids_out, long ids_cap, int64_t *id_off, unsigned long long *stats, long wrec_cap_in, int32_t *starts_out, int32_t *ends_out)
 {
+    const bool offs = starts_out && ends_out;
     Model &m = ((Handle *)hv)->m;
     if (!m.error.empty() || m.kind != KIND_WP || !m.wave_ok || !m.flat_ok) return -1;
     if (max_ids < 0) max_ids = 0;
@@ -315,7 +318,9 @@ long bft_emu_flat_batch(void *hv, const uint8_t *text, long text_bytes, const in
     std::vector<uint32_t> ent((size_t)total + 64, 0xDEADBEEFu);
     std::vector<int32_t> home((size_t)total + 64, -77), entcnt((size_t)ndocs + 1, -55), dstat((size_t)ndocs + 1, 0), list((size_t)ndocs + 1, -1);
     std::vector<int64_t> entoff((size_t)ndocs + 1, -1);
-    std::vector<int32_t> tmp((size_t)(total + 8 * ndocs + 64 + 8), -77), counts((size_t)ndocs + 1, -55);
+    std::vector<int32_t> tmp((size_t)(total + 8 * ndocs + 64 + 8), -77), counts((size_t)ndocs + 1, -55), counts_hard((size_t)ndocs + 1, -55);
+    std::vector<int32_t> span(offs ? 2 * (size_t)(total + 8 * ndocs + 64 + 8) : 2, -77);
+    std::vector<uint32_t> espan(offs ? (size_t)total + 64 : 1, 0xDEADBEEFu), hspan(offs ? 2 * ((size_t)total + 64) : 1, 0xDEADBEEFu);
     unsigned long long next_range = 0, next_doc = 0; int status = 0;
     WpWaveCold cold;
     cold.cpmap = DevCpMap{m.wbd_cpmap.l1.data(), m.wbd_cpmap.pages.data()};
@@ -326,6 +331,7 @@ long bft_emu_flat_batch(void *hv, const uint8_t *text, long text_bytes, const in
     fp.text = text; fp.doc_off = doc_off; fp.ndocs = ndocs; fp.total_bytes = total;
     fp.range_doc = range_doc.data(); fp.nranges = nranges; fp.next_range = &next_range; fp.unsafe = &unsafe;
     fp.ent = ent.data(); fp.home = home.data(); fp.ent_off = entoff.data(); fp.ent_cnt = entcnt.data(); fp.dstat = dstat.data(); fp.cold = cold;
+    fp.espan = offs ? espan.data() : nullptr;
     (void)wrec_cap_in;
     std::vector<uint32_t> wrec((size_t)(total / 4 + 64) * 4, 0xDEADBEEFu); std::vector<int32_t> wrec_cnt((size_t)nranges * 2 + 2, 0);
     fp.wrec = wrec.data(); fp.wrec_cnt = wrec_cnt.data();
@@ -352,7 +358,7 @@ long bft_emu_flat_batch(void *hv, const uint8_t *text, long text_bytes, const in
         WfUnitParams up;
         up.T = fp.T; up.ini = fp.ini; up.ini_l = fp.ini_l; up.max_token_length = fp.max_token_length; up.text = text; up.total_bytes = total;
         up.wrec = wrec.data(); up.wrec_cnt = wrec_cnt.data(); up.range_doc = range_doc.data(); up.doc_off = doc_off; up.nranges = nranges;
-        up.ent = ent.data(); up.home = home.data(); up.cpmap = cold.cpmap; up.kind = cold.kind; up.nclasses = cold.nclasses; up.stats = stats;
+        up.ent = ent.data(); up.home = home.data(); up.espan = fp.espan; up.hspan = offs ? hspan.data() : nullptr; up.cpmap = cold.cpmap; up.kind = cold.kind; up.nclasses = cold.nclasses; up.stats = stats;
         std::vector<uint32_t> lut(128);
         for (int i = 0; i < 128; ++i) lut[(size_t)i] = wf_lut_value(cold, i);
         unsigned long long rounds = 0, nf_all = 0, ns_all = 0;
@@ -381,40 +387,83 @@ long bft_emu_flat_batch(void *hv, const uint8_t *text, long text_bytes, const in
         p.T = m.wbd_t2.data(); p.acts = m.acts_pool.data(); p.acts_n = (int)m.acts_pool.size();
         p.initial = m.wbd.initial_base; p.loop_info = m.loop_info; p.solo_info = m.wave_solo_info; p.max_token_length = m.max_token_length;
         p.text = text; p.doc_off = doc_off; p.ndocs = ndocs; p.total_bytes = total;
-        p.ids_tmp = tmp.data(); p.counts = counts.data(); p.max_ids = max_ids; p.unk = unk; p.next_doc = &next_doc; p.span_tmp = nullptr;
+        p.ids_tmp = tmp.data(); p.counts = counts.data(); p.max_ids = max_ids; p.unk = unk; p.next_doc = &next_doc; p.span_tmp = offs ? span.data() : nullptr;
         p.doc_list = list.data(); p.list_n = &list_n;
         p.cold = cold; p.cold.stats = nullptr;
         typedef WvLds<1024, 256, 8> L;
+        typedef WvLds<1024, 256, 8, true> LO;
         std::vector<uint16_t> ascii(128);
         for (int i = 0; i < 128; ++i) ascii[(size_t)i] = (uint16_t)wv_element(p.cold, i);
-        std::vector<L *> of_wave((size_t)nwaves);
-        for (int i = 0; i < nwaves; ++i) { of_wave[(size_t)i] = new L(); memset((void *)of_wave[(size_t)i], 0xA5, sizeof(L)); }
+        std::vector<L *> of_wave((size_t)nwaves); std::vector<LO *> of_wave_o((size_t)nwaves);
+        for (int i = 0; i < nwaves; ++i) { of_wave[(size_t)i] = new L(); memset((void *)of_wave[(size_t)i], 0xA5, sizeof(L)); of_wave_o[(size_t)i] = new LO(); memset((void *)of_wave_o[(size_t)i], 0xA5, sizeof(LO)); }
         std::vector<const void *> wave_ids;
         auto body = [&]() {
             const void *wid = (const void *)wvemu::g_cur->wave;
             size_t k = 0;
             for (; k < wave_ids.size(); ++k) if (wave_ids[k] == wid) break;
             if (k == wave_ids.size()) wave_ids.push_back(wid);
-            WpWave<L, 1, false, 0, 3, 4, 0, false, 15, true> w(p, p.cold, *of_wave[k], ascii.data(), p.acts);
-            w.run(1, (int)k, nwaves);
+            if (offs) { WpWave<LO, 1, false, 0, 3, 4, 0, true, 15, true> w(p, p.cold, *of_wave_o[k], ascii.data(), p.acts); w.run(1, (int)k, nwaves); }
+            else { WpWave<L, 1, false, 0, 3, 4, 0, false, 15, true> w(p, p.cold, *of_wave[k], ascii.data(), p.acts); w.run(1, (int)k, nwaves); }
         };
         wvemu::run_waves(nwaves, body);
         for (auto *q : of_wave) delete q;
+        for (auto *q : of_wave_o) delete q;
         if (status) return -5;
     }
     // ---- k_wp_count, scan, k_wp_merge
     WfMergeParams mp;
     mp.doc_off = doc_off; mp.ndocs = ndocs; mp.ent = ent.data(); mp.home = home.data(); mp.ent_off = entoff.data(); mp.ent_cnt = entcnt.data(); mp.dstat = dstat.data(); mp.unsafe = &unsafe;
     mp.ids_tmp = tmp.data(); mp.counts = counts.data(); mp.id_off = id_off; mp.ids_out = ids_out; mp.ids_cap = ids_cap; mp.status = &status; mp.max_ids = max_ids; mp.unk = unk;
+    mp.espan = offs ? espan.data() : nullptr; mp.hspan = offs ? hspan.data() : nullptr; mp.starts_out = starts_out; mp.ends_out = ends_out; mp.counts_hard = offs ? counts_hard.data() : nullptr;
     wvemu::run_waves(1, [&]() { for (int64_t base = 0; base < ndocs; base += 64) wf_count_docs(mp, base); });
     long o = 0;
     for (long d = 0; d < ndocs; ++d) { id_off[d] = o; if (counts[(size_t)d] < 0) return -6; o += counts[(size_t)d]; }
     id_off[ndocs] = o;
     bool over_any = false;
-    WfMergeLds mlds;
-    wvemu::run_waves(1, [&]() { bool over = false; for (int64_t base = 0; base < ndocs; base += 64) wf_merge_docs(mp, base, over, mlds); if (over) over_any = true; });
+    if (offs) {
+        WfMergeLds<true> *mlds = new WfMergeLds<true>();
+        wvemu::run_waves(1, [&]() { bool over = false; for (int64_t base = 0; base < ndocs; base += 64) wf_merge_docs<true>(mp, base, over, *mlds); if (over) over_any = true; });
+        delete mlds;
+        // k_compact_text restated for the documents the wave program tokenised (counts_hard): characters -> bytes from the text itself
+        for (long d = 0; d < ndocs && list_n > 0; ++d) {
+            const int c = counts_hard[(size_t)d];
+            if (c < 0) return -6;
+            if (c == 0) continue;
+            const int64_t b = doc_off[d], slot = wv_ids_slot(b, d), od = id_off[d];
+            const int n = (int)(doc_off[d + 1] - b);
+            std::vector<int> byte_of;
+            const int bom = (n >= 3 && text[b] == 0xEF && text[b + 1] == 0xBB && text[b + 2] == 0xBF) ? 3 : 0;
+            for (int q = bom; q < n; ++q) if ((text[b + q] & 0xC0) != 0x80) byte_of.push_back(q);
+            for (int i = 0; i < c; ++i) {
+                if (od + i >= ids_cap) return -9;
+                ids_out[od + i] = tmp[(size_t)(slot + i)];
+                const int from = span[2 * (size_t)(slot + i)], to = span[2 * (size_t)(slot + i) + 1];
+                if (from < 0 || to < from || (size_t)to >= byte_of.size()) return -12;
+                const int so = byte_of[(size_t)from], eo = byte_of[(size_t)to];
+                const uint32_t ch = text[b + eo];
+                const int sz = (ch & 0x80) == 0 ? 1 : (ch & 0xE0) == 0xC0 ? 2 : (ch & 0xF0) == 0xE0 ? 3 : (ch & 0xF8) == 0xF0 ? 4 : 0;
+                starts_out[od + i] = so; ends_out[od + i] = eo + (sz > 0 ? sz - 1 : 0);
+            }
+        }
+    } else {
+        WfMergeLds<false> *mlds = new WfMergeLds<false>();
+        wvemu::run_waves(1, [&]() { bool over = false; for (int64_t base = 0; base < ndocs; base += 64) wf_merge_docs<false>(mp, base, over, *mlds); if (over) over_any = true; });
+        delete mlds;
+    }
     if (over_any) return -9;
     return o;
+}
+
+long bft_emu_flat_batch(void *hv, const uint8_t *text, long text_bytes, const int64_t *doc_off, long ndocs, int max_ids, int unk, int nwaves, int nranges,
+                        int32_t *ids_out, long ids_cap, int64_t *id_off, unsigned long long *stats, long wrec_cap_in)
+{
+    return emu_flat_batch(hv, text, text_bytes, doc_off, ndocs, max_ids, unk, nwaves, nranges, ids_out, ids_cap, id_off, stats, wrec_cap_in, nullptr, nullptr);
+}
+
+long bft_emu_flat_batch_offsets(void *hv, const uint8_t *text, long text_bytes, const int64_t *doc_off, long ndocs, int max_ids, int unk, int nwaves, int nranges,
+                                int32_t *ids_out, int32_t *starts_out, int32_t *ends_out, long ids_cap, int64_t *id_off, unsigned long long *stats)
+{
+    return emu_flat_batch(hv, text, text_bytes, doc_off, ndocs, max_ids, unk, nwaves, nranges, ids_out, ids_cap, id_off, stats, 0, starts_out, ends_out);
 }
 
 int bft_flat_ok(void *hv) { return ((Handle *)hv)->m.flat_ok ? 1 : 0; }

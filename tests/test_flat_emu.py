@@ -29,7 +29,23 @@ def ht():
     L.bft_emu_flat_batch.restype = ctypes.c_long
     L.bft_emu_flat_batch.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_long, ctypes.c_void_p, ctypes.c_long, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                      ctypes.c_int, ctypes.c_void_p, ctypes.c_long, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_long]
+    L.bft_emu_flat_batch_offsets.restype = ctypes.c_long
+    L.bft_emu_flat_batch_offsets.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_long, ctypes.c_void_p, ctypes.c_long, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                             ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_long, ctypes.c_void_p, ctypes.c_void_p]
     return L
+
+
+def flat_batch_offsets(ht, h, text, off, max_ids, unk, nwaves, nranges):
+    nd = len(off) - 1
+    cap = len(text) + 16
+    ids, sts, ens = (np.full(cap, -9, dtype=np.int32) for _ in range(3))
+    ido = np.zeros(nd + 1, dtype=np.int64)
+    st = np.zeros(16, dtype=np.uint64)
+    text = np.ascontiguousarray(text)
+    r = ht.bft_emu_flat_batch_offsets(h, text.ctypes.data, len(text), off.ctypes.data, nd, max_ids, unk, nwaves, nranges, ids.ctypes.data, sts.ctypes.data, ens.ctypes.data,
+                                      cap, ido.ctypes.data, st.ctypes.data)
+    n = max(r, 0)
+    return r, ids[:n], sts[:n], ens[:n], ido, st
 
 
 def flat_batch(ht, h, text, off, max_ids, unk, nwaves, nranges):
@@ -43,7 +59,11 @@ def flat_batch(ht, h, text, off, max_ids, unk, nwaves, nranges):
     return r, ids[:max(r, 0)], ido, st
 
 
+offsets_oracle = {}
+
+
 def check(ht, model, docs, confs, want=None):
+    offsets_oracle.clear()
     mp = bfutil.model_path(model)
     h = ht.bft_load(mp.encode())
     assert ht.bft_flat_ok(h) == 1
@@ -62,6 +82,24 @@ def check(ht, model, docs, confs, want=None):
         if want is not None:
             want(st)
         last = st
+        # the offsets API through the same program: the same ids, and the byte offsets of every id (oracle: per document)
+        r2, ids2, sts, ens, ido2, st2 = flat_batch_offsets(ht, h, text, off, mx, unk, nw, nr)
+        assert r2 == r and np.array_equal(ids2, ids) and np.array_equal(ido2, ido), (model, r2, r)
+        if offsets_oracle.get((model, id(docs), mx, unk)) is None:
+            raw = text.tobytes()
+            ws, we = [], []
+            for d in range(len(off) - 1):
+                c, _, s_, e_ = ora.with_offsets(ho, raw[off[d]:off[d + 1]], mx, unk, "bfo_text_to_ids_with_offsets")
+                ws += s_[:min(c, mx)]; we += e_[:min(c, mx)]
+            offsets_oracle[(model, id(docs), mx, unk)] = (np.array(ws, dtype=np.int32), np.array(we, dtype=np.int32))
+        ws, we = offsets_oracle[(model, id(docs), mx, unk)]
+        if not (np.array_equal(sts, ws) and np.array_equal(ens, we)):
+            for d in range(len(off) - 1):
+                a, b = slice(ido[d], ido[d + 1]), slice(goff[d], goff[d + 1])
+                assert np.array_equal(sts[a], ws[b]) and np.array_equal(ens[a], we[b]), (model, (mx, unk, nw, nr), d, bytes(text[off[d]:off[d + 1]])[:80],
+                                                                                        sts[a].tolist()[:24], ws[b].tolist()[:24], ens[a].tolist()[:24], we[b].tolist()[:24])
+        if want is not None:
+            want(st2)
     ora.free(ho)
     ht.bft_free(h)
     return last

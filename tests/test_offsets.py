@@ -83,8 +83,9 @@ def test_gpu_offsets_match_checker(model):
     hck = ck.load(bfutil.model_path(model))
     try:
         docs = _docs(1200, 53)
-        # WordPiece models in unit form: the wave program's offsets instance; variant 2: the lane-per-document kernels
-        for mx, unk, variant in ((256, 100, 3), (3, 0, 3), (256, 100, 2)):
+        # WordPiece models in unit form: the wave program's offsets instance (what a batch this small takes by default: 5); 4: the flat program
+        # (every larger batch); variant 2: the lane-per-document kernels
+        for mx, unk, variant in ((256, 100, 3), (3, 0, 3), (256, 100, 4), (3, 0, 4), (256, 100, 2)):
             if variant != 3 and bf.lib().BfModelKind(h) != 0:
                 continue
             bf.lib().BfSetVariant(h, variant)                     # 3 = the default of a fresh handle
