@@ -40,15 +40,29 @@ def hipcc():
 
 
 def build_product(force=False):
-    srcs = [os.path.join(CSRC, f) for f in ("bf_kernels.hip", "bf_capi.cpp", "bf_model.cpp")]
+    """the product: four translation units compiled side by side (the two kernel files are most of the time), then linked"""
+    names = ("bf_kernels.hip", "bf_kernels_sp.hip", "bf_capi.cpp", "bf_model.cpp")
+    srcs = [os.path.join(CSRC, f) for f in names]
     deps = srcs + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + [
         os.path.join(ROOT, "include", "blingfiretokdll_amd.h"), os.path.join(CSRC, "exports.map"), os.path.join(ROOT, "models", "wbd.bin"), os.path.join(ROOT, "models", "sbd.bin")]
     if force or _newer(PRODUCT, deps):
         # the reference compiles its default word- and sentence-breaking models (wbd.bin, sbd.bin) into the library; same here (data, via .incbin)
         wbd = os.path.join(ROOT, "models", "wbd.bin")
         sbd = os.path.join(ROOT, "models", "sbd.bin")
-        _run([hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
-              "-Wall", "-Wno-unused-result", "-fvisibility=hidden"] + (["-DBF_EXPERIMENTS"] if os.environ.get("BF_EXPERIMENTS") else []) + [ "-Wl,--version-script=" + os.path.join(CSRC, "exports.map"), '-DBF_DEFAULT_WBD_PATH="%s"' % wbd, '-DBF_DEFAULT_SBD_PATH="%s"' % sbd, "-x", "hip"] + srcs + ["-o", PRODUCT])
+        odir = os.path.join(CSRC, "obj")
+        os.makedirs(odir, exist_ok=True)
+        flags = ["--offload-arch=gfx950", "--offload-compress", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-result", "-fvisibility=hidden"] + (
+            ["-DBF_EXPERIMENTS"] if os.environ.get("BF_EXPERIMENTS") else []) + ['-DBF_DEFAULT_WBD_PATH="%s"' % wbd, '-DBF_DEFAULT_SBD_PATH="%s"' % sbd]
+        objs, procs = [], []
+        for src in srcs:
+            obj = os.path.join(odir, os.path.basename(src) + ".o")
+            cmd = [hipcc()] + flags + ["-c", "-x", "hip", src, "-o", obj]
+            print("+", " ".join(cmd), flush=True)
+            objs.append(obj); procs.append((cmd, subprocess.Popen(cmd)))
+        for cmd, pr in procs:
+            if pr.wait() != 0:
+                raise subprocess.CalledProcessError(pr.returncode, cmd)
+        _run([hipcc(), "--offload-arch=gfx950", "--offload-compress", "-shared", "-fPIC", "-Wl,-s", "-Wl,--version-script=" + os.path.join(CSRC, "exports.map")] + objs + ["-o", PRODUCT])
     return PRODUCT
 
 

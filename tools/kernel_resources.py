@@ -1,13 +1,15 @@
-"""Registers, scratch, LDS and occupancy of every kernel of bf_kernels.hip as the compiler reports them
+"""Registers, scratch, LDS and occupancy of every kernel of bf_kernels.hip / bf_kernels_sp.hip as the compiler reports them
 (-Rpass-analysis=kernel-resource-usage, device side only, nothing is linked).  usage: python tools/kernel_resources.py [name filter]"""
 import os, re, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-src = os.path.join(ROOT, "blingfire_amd", "csrc", os.environ.get("BF_KSRC", "bf_kernels.hip"))
-r = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "--cuda-device-only", "-c",
-                    "-Rpass-analysis=kernel-resource-usage", src, "-o", "/dev/null"], capture_output=True, text=True)
+srcs = [os.path.join(ROOT, "blingfire_amd", "csrc", f) for f in os.environ.get("BF_KSRC", "bf_kernels.hip,bf_kernels_sp.hip").split(",")]
+procs = [subprocess.Popen(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "--cuda-device-only", "-c"] +
+                          (["-DBF_EXPERIMENTS"] if os.environ.get("BF_EXPERIMENTS") else []) +
+                          ["-Rpass-analysis=kernel-resource-usage", src, "-o", "/dev/null"], stderr=subprocess.PIPE, text=True) for src in srcs]
+err = "".join(p.communicate()[1] for p in procs)
 flt = sys.argv[1] if len(sys.argv) > 1 else ""
 cur, rows = None, []
-for line in r.stderr.splitlines():
+for line in err.splitlines():
     m = re.search(r"remark: +(.*?) \[-Rpass", line)
     if not m:
         continue
