@@ -215,8 +215,8 @@ def run_inproc(args):
     torch.cuda.set_device(dev_ids[0])
     h = bf.load_model(bfutil.model_path(model_name))
     kind = bf.lib().BfModelKind(h)
-    if args.variant >= 0:
-        bf.lib().BfSetVariant(h, args.variant)
+    if args.variant >= 0 and bf.lib().BfSetVariant(h, args.variant) == -5:
+        raise SystemExit("bench.py: --variant %d selects a measurement instance: build with BF_EXPERIMENTS=1" % args.variant)
     bf.set_devices(h, dev_ids)
     bounds = bf.shard_ranges(off, G)
     per_doc_ws = (int(off[-1]) / max(total_docs, 1) + 1) * (6 if kind == 0 else 44)
@@ -373,8 +373,8 @@ def main():
     total_bytes = int(off[-1])
     h = bf.load_model(bfutil.model_path(model_name))
     kind = bf.lib().BfModelKind(h)
-    if args.variant >= 0:
-        bf.lib().BfSetVariant(h, args.variant)
+    if args.variant >= 0 and bf.lib().BfSetVariant(h, args.variant) == -5:
+        raise SystemExit("bench.py: --variant %d selects a measurement instance: build with BF_EXPERIMENTS=1" % args.variant)
     # sub-batches: one TextToIdsBatchDevice call each.  The _sp segmenters keep up to 16 bytes of workspace per stream element
     # (2 elements per byte with a charmap), so a 5 GB shard is issued in pieces that keep the workspace under ~64 GB.
     sub = args.sub_batch_docs

@@ -1933,6 +1933,11 @@ int BfSetVariant(void *p, int variant)
     Handle *h = as_handle(p);
     if (!h) return BF_E_ARG;
     std::lock_guard<std::mutex> lock(h->mu);
+#ifndef BF_EXPERIMENTS
+    // the bits that select a measurement instance (compiled with BF_EXPERIMENTS only): WordPiece -- units configuration (8..11), waves per SIMD of
+    // the flat program (16..19), transitions per vote of the lane kernel (20..23); _sp -- waves per SIMD of the prologue (24..27)
+    if (variant & (h->m.kind == KIND_WP ? 0x00FF0F00 : 0x0F000000)) return BF_E_UNSUPPORTED;
+#endif
     int old = h->variant; h->variant = variant;
     for (Handle *c : h->shards) if (c && c != h) { std::lock_guard<std::mutex> lc(c->mu); c->variant = variant; }
     return old;

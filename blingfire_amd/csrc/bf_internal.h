@@ -10,9 +10,11 @@ extern "C" {
  * Lane-per-document kernels: [0] walk trips [1] lane-steps [2] event rounds [3] event lanes [4] fetch rounds [5] idle lane-steps
  * [6..8] cycles in walk / event / fetch */
 BF_API int BfLexStats(void *ModelPtr, unsigned long long *out, int n);
-/* experiments / A-B runs.  Low byte: 3 = default; 2 = the lane-per-document WordPiece kernels (bf_lex.h) also for unit-form lexers, whose
- * default is the wave program (bf_wave.h).  The higher bits carry tuning values (bf_kernels.hip launch_wp_wave / launch_lex_wp / launch_seg_sp).
- * Returns the previous value. */
+/* experiments / A-B runs.  Low byte: 3 = default (flat-form WordPiece models: the flat program, bf_flat.h, for batches of >= 1,024 documents and
+ * >= 1 MiB, else the wave program, bf_wave.h); 4 = the flat program for every batch; 5 = never; 2 = the lane-per-document WordPiece kernels
+ * (bf_lex.h) also for unit-form lexers; bit 0x40 = BPE without its wave program.  The higher bits carry tuning values (bf_kernels.hip
+ * launch_wp_wave / launch_wp_flat / launch_lex_wp, bf_kernels_sp.hip launch_seg_sp); the ones that select a measurement instance need a build
+ * with BF_EXPERIMENTS, else BF_E_UNSUPPORTED (-5) comes back and the setting stays.  Returns the previous value. */
 BF_API int BfSetVariant(void *ModelPtr, int variant);
 /* switches the instrumented kernel instances on / off for this handle and clears the counters; returns the previous setting */
 BF_API int BfSetLexStats(void *ModelPtr, int on);

@@ -140,7 +140,9 @@ def test_prologue_instances_agree(model, checker):
     try:
         docs = list(bfutil.ADVERSARIAL) + bfutil.fuzz_docs(1200, seed=23)
         for variant in (3, 3 | (6 << 24), 3 | (7 << 24), 3 | 0x80):
-            bf.lib().BfSetVariant(h, variant)
+            if bf.lib().BfSetVariant(h, variant) == -5:           # BF_E_UNSUPPORTED: a measurement instance, compiled with BF_EXPERIMENTS only
+                assert variant >> 24
+                continue
             _compare(h, checker, hck, docs, 512, 3)
     finally:
         bf.free_model(h)
