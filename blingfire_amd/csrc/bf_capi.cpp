@@ -414,6 +414,9 @@ int run_device(Handle *h, const char *d_text, const int64_t *d_doc_off, int64_t 
         fp.dstat = h->w_dstat.as<int32_t>(); fp.cold = cold; fp.espan = want_off ? h->w_espan.as<uint32_t>() : nullptr;
         fp.wrec = h->w_wrec.as<uint32_t>(); fp.wrec_cnt = (int32_t *)(h->w_wrec.as<char>() + (size_t)(total_bytes / 4 + 64) * 16);
         if (!hip_ok(hipMemsetAsync(fp.wrec_cnt, 0, (size_t)nranges * 8, s), "hipMemsetAsync")) return BF_E_DEVICE;      // (a range without documents writes nothing)
+#ifdef BF_EXPERIMENTS
+        fp.dbg = (h->variant >> 20) & 0xf;
+#endif
         (void)hipEventRecord(h->ev[EV_DOM0], s);
         launch_wp_flat(fp, h->variant, s);
         (void)hipEventRecord(h->ev[EV_DOM1], s);

@@ -44,6 +44,7 @@ struct WfParams {
     // holds in registers from the front, the others from the back; wrec_cnt[2 r], [2 r + 1] = how many of each (written by the range's wave)
     uint32_t *wrec; int32_t *wrec_cnt;
     WpWaveCold cold;                 // code-point map, class kinds, status word, optional counters
+    int dbg = 0;                     // measurements (BF_EXPERIMENTS builds; wrong results by design): 1 = no look-up pass, 2 = no token list either, 4 = look-up without the table gathers
 };
 
 // the words of the list, walked (k_wp_units)

@@ -23,9 +23,8 @@ namespace bfa {
 constexpr int WF_TQ = 512;                // tokens of a chunk, at most (every byte one)
 constexpr int WF_RING_DUP = 16;           // the first positions of the code ring once more behind its end: the 12 bytes of a key are read without a wrap
 constexpr uint32_t WF_TQ_SOLO = 63;       // list entry: bytes == 63: a one-element token
-// a record of the word list (16 bytes): [0] entry index (low 32 bits) [1] first byte in the text (low 32 bits) [2] entry index bits 32.. | first byte bits 32.. << 8 | bytes << 16 |
-// WF_REC_PLAIN [3] home index - entry index
-constexpr uint32_t WF_REC_PLAIN = 1u << 24;      // the word's bytes are plain ASCII (its characters are its bytes)
+// a record of the word list (16 bytes): [0] the word's entry, [1] its first byte -- both counted from the first entry / byte of the range -- [2] bytes | WF_REC_PLAIN
+constexpr uint32_t WF_REC_PLAIN = 1u << 8;       // the word's bytes are plain ASCII (its characters are its bytes)
 
 struct alignas(16) WfRow { uint32_t k0lo, k0hi, k1, id; };      // an entry of the word table (bf_flat_key.h)
 struct WfLds {
@@ -42,6 +41,13 @@ BF_WV uint32_t wf_lut_value(const WpWaveCold &p, int b)
     const uint32_t el = wv_element(p, b), c = el & LX_T_CLS_MASK, k = el >> WK_SHIFT;
     const uint32_t nib = k == WK_LOOP ? 1u : k == WK_SOLO ? 2u : k == WK_GENERAL ? 4u : 0u;
     return c | (nib << 16) | ((c < 127u ? c + 1u : 0u) << 24);
+}
+// behind it (entries 128 + 4 n .. + 2): the bytes of a key a word of n characters has (bf_flat_key.h), as three masks
+constexpr int WF_LUT = 128 + 4 * 16;
+BF_WV uint32_t wf_kmask_value(int i)
+{
+    const int n = (i >> 2) - (i & 3) * 4;                 // bytes of dword i & 3 that belong to a word of i >> 2 characters
+    return (i & 3) == 3 || n <= 0 ? 0u : n >= 4 ? 0xFFFFFFFFu : (1u << (8 * n)) - 1u;
 }
 
 #if defined(__HIPCC__)
@@ -222,8 +228,7 @@ struct WfWave {
         if (nrec > 0) {
             uint32_t r0 = 0, r1 = 0, r2 = 0, r3 = 0;
             if (lane < nrec) { const uint32_t *r = S.rec + 4 * lane; r0 = r[0]; r1 = r[1]; r2 = r[2]; r3 = r[3]; }
-            const int64_t pa = (int64_t)r1 | ((int64_t)((r2 >> 8) & 0xFFu) << 32);
-            const bool fastw = lane < nrec && (r2 & WF_REC_PLAIN) != 0u && ((r2 >> 16) & 0xFFu) <= 16u && pa + 16 <= p.total_bytes;
+            const bool fastw = lane < nrec && (r2 & WF_REC_PLAIN) != 0u && (r2 & 0xFFu) <= 16u && b0 + (int64_t)r1 + 16 <= p.total_bytes;
             const unsigned long long FB = wv::ballot(fastw), SB = wv::ballot(lane < nrec && !fastw);
             const int nf = __builtin_popcountll(FB), ns = __builtin_popcountll(SB);
             const int64_t lo = (b0 + 3) >> 2, hi = (b0 + (int64_t)len) >> 2;           // the range's records
@@ -236,7 +241,7 @@ struct WfWave {
             } else {
                 for (unsigned long long lb = FB | SB; lb;) {
                     const int l = __builtin_ctzll(lb); lb &= lb - 1ull;
-                    hard_lo = hard_hi = 0; mark((int)(wv::bcast(pa, l) - b0), WF_D_HARD);
+                    hard_lo = hard_hi = 0; mark((int)wv::bcast(r1, l), WF_D_HARD);
                 }
             }
         }
@@ -333,6 +338,9 @@ struct WfWave {
         const int excl = inc - cnt;
         if (STATS) st_tok += (unsigned long long)ntok;
         // (1) every lane writes where ITS tokens are to the list, in order
+#ifdef BF_EXPERIMENTS
+        if (!(p.dbg & 2))
+#endif
         {
             // this lane's tokens as bits 4 i + 1 (the token that ends at byte i); bit 0 of lane 0: the run that ended with the chunk before
             uint32_t tk = (tk0 << 1) | ((carry_end && lane == 0) ? 1u : 0u);
@@ -367,6 +375,9 @@ struct WfWave {
         // (2) the list, one token per lane and trip.  The key of a run of <= 12 bytes is its bytes of the code ring (bf_flat_key.h): the key IS the
         // word.  Two 16-byte gathers per lane in flight; the ids go to their entries as whole rows.
         uint32_t *eout = ent + k;
+#ifdef BF_EXPERIMENTS
+        if (!(p.dbg & 3))
+#endif
         for (int t0 = 0; t0 < ntok; t0 += 64) {
             const bool have = t0 + lane < ntok;
             const uint32_t ps = have ? (uint32_t)S.tq_pos[t0 + lane] : 0u;
@@ -374,38 +385,28 @@ struct WfWave {
             const bool solo = b6 == WF_TQ_SOLO;
             const int blen = solo ? 1 : (int)b6;                                 // (0: a run of more than WF_RUN_MAX bytes; its document is handed on)
             const int s0 = c - 64 + (int)(ps & 0x3FFu);
-            // the 12 codes behind the token's first byte, those behind the word cleared; a code 0 inside the word (a class without a code, or no
-            // character: a continuation byte) and the word has no key
+            // the 12 codes behind the token's first byte, those behind the word cleared (the masks of a length: behind the table of the ASCII bytes).
+            // A word with a code 0 inside (a class without a code, or no character: a continuation byte) matches no entry: an entry's bytes are codes up
+            // to its length, which is part of the match.
             uint32_t w[3];
             __builtin_memcpy(w, S.cring + ((uint32_t)s0 & RMASK), 12);                 // (the duplicate bytes: no wrap)
             const int kn = (have && !solo && blen <= WF_KEY_CHARS) ? blen : 0;
-            const uint64_t m01 = kn >= 8 ? ~0ull : ((1ull << (8 * kn)) - 1ull);
-            const uint32_t m2 = kn >= 12 ? ~0u : kn > 8 ? ((1u << (8 * (kn - 8))) - 1u) : 0u;
-            uint64_t k0 = ((uint64_t)w[0] | ((uint64_t)w[1] << 32)) & m01;
-            uint32_t k1 = w[2] & m2;
-            const uint64_t z0 = ((k0 | ~m01) - 0x0101010101010101ull) & ~(k0 | ~m01) & 0x8080808080808080ull;
-            const uint32_t z2 = ((k1 | ~m2) - 0x01010101u) & ~(k1 | ~m2) & 0x80808080u;
-            const bool nozero = z0 == 0ull && z2 == 0u;
-            bool plain = kn > 0 && nozero;                                       // a run with a key is plain ASCII (a unit can read it from the text)
-            if (!plain) {
-                k0 = WF_KEY_NONE; k1 = 0u;
-                if (solo) k0 = WF_KEY_SOLO | ((uint64_t)(S.ring[(uint32_t)s0 & RMASK] & LX_T_CLS_MASK) << WF_KEY_SOLO_SHIFT);      // a one-element token: by class
-                else if (kn == 0 && blen > 0) {
-                    // a longer run: plain when no lane it touches holds a byte >= 0x80 (lanes counted from the chunk before; a run is <= 48 bytes)
-                    plain = true;
-                    if (na | na_prev) {
-                        const int ls = (s0 - (c - WF_CHUNK)) >> 3, le = (s0 + blen - 1 - (c - WF_CHUNK)) >> 3;
-                        const unsigned long long wlo_ = ls < 64 ? ((na_prev >> (ls & 63)) | ((ls & 63) ? na << (64 - (ls & 63)) : 0ull)) : (na >> ((ls - 64) & 63));
-                        plain = ls >= 0 && (wlo_ & ((2ull << ((le - ls) & 63)) - 1ull)) == 0ull;
-                    }
-                }
-            }
+            const uint32_t *km = lut + 128 + 4 * kn;
+            uint64_t k0 = ((uint64_t)(w[0] & km[0])) | ((uint64_t)(w[1] & km[1]) << 32);
+            uint32_t k1 = w[2] & km[2];
+            if (kn == 0) { k0 = solo ? (WF_KEY_SOLO | ((uint64_t)(S.ring[(uint32_t)s0 & RMASK] & LX_T_CLS_MASK) << WF_KEY_SOLO_SHIFT)) : WF_KEY_NONE; k1 = 0u; }       // a one-element token: by class
             const uint32_t x = wf_mix(k0, k1, p.m0);
+#ifdef BF_EXPERIMENTS
+            const uint32_t gmask = (p.dbg & 4) ? 0u : 0xFFFFFFFFu;
+            WfRow A = *((const WfRow *)p.W + (wf_h(x, p.m1, p.wbits) & gmask)), B = *((const WfRow *)p.W + (wf_h(x, p.m2, p.wbits) & gmask));
+#else
             WfRow A = *((const WfRow *)p.W + wf_h(x, p.m1, p.wbits)), B = *((const WfRow *)p.W + wf_h(x, p.m2, p.wbits));
+#endif
             BF_WF_BOTH_ROWS(A, B);                                               // both rows whole and in flight together: one trip to the table
-            const bool hita = ((A.k0lo ^ (uint32_t)k0) | (A.k0hi ^ (uint32_t)(k0 >> 32)) | (A.k1 ^ k1)) == 0u;
-            const bool hitb = ((B.k0lo ^ (uint32_t)k0) | (B.k0hi ^ (uint32_t)(k0 >> 32)) | (B.k1 ^ k1)) == 0u;
-            const uint32_t ai = A.id, bi = B.id;
+            const uint32_t klen = (uint32_t)kn << WF_ROW_LEN_SHIFT;
+            const bool hita = ((A.k0lo ^ (uint32_t)k0) | (A.k0hi ^ (uint32_t)(k0 >> 32)) | (A.k1 ^ k1) | ((A.id ^ klen) & ~WF_ROW_ID_MASK)) == 0u;
+            const bool hitb = ((B.k0lo ^ (uint32_t)k0) | (B.k0hi ^ (uint32_t)(k0 >> 32)) | (B.k1 ^ k1) | ((B.id ^ klen) & ~WF_ROW_ID_MASK)) == 0u;
+            const uint32_t ai = A.id & WF_ROW_ID_MASK, bi = B.id & WF_ROW_ID_MASK;
             const bool hit = have && (hita || hitb);
             if (hit) eout[t0 + lane] = hita ? ai : bi;
             if (p.espan) {
@@ -428,11 +429,18 @@ struct WfWave {
                 const int nw = __builtin_popcountll(WB);
                 if (STATS) st_notes += (unsigned long long)nw;
                 if (nrec + nw > WF_REC) flush_records();
+                // a unit can read the word from the text when no lane it touches holds a byte >= 0x80 (lanes counted from the chunk before; a run is <= 48 bytes)
+                bool plain = true;
+                int rl = blen;                                                       // (a one-element token is one character: its bytes)
+                if (na | na_prev) {
+                    if (word && solo) { const uint32_t b = txt[s0]; rl = b < 0x80u ? 1 : b < 0xE0u ? 2 : b < 0xF0u ? 3 : 4; }
+                    const int ls = (s0 - (c - WF_CHUNK)) >> 3, le = (s0 + rl - 1 - (c - WF_CHUNK)) >> 3;
+                    const unsigned long long wlo_ = ls < 64 ? ((na_prev >> (ls & 63)) | ((ls & 63) ? na << (64 - (ls & 63)) : 0ull)) : (na >> ((ls - 64) & 63));
+                    plain = ls >= 0 && (wlo_ & ((2ull << ((le - ls) & 63)) - 1ull)) == 0ull;
+                }
                 if (word) {
-                    const int64_t ea = b0 + (int64_t)(k + t0 + lane), pa = b0 + (int64_t)s0;
-                    uint32_t *r = S.rec + 4 * (nrec + (int)wv::mbcnt(WB));
-                    r[0] = (uint32_t)ea; r[1] = (uint32_t)pa; r[2] = (uint32_t)((ea >> 32) & 0xFF) | ((uint32_t)((pa >> 32) & 0xFF) << 8) | ((uint32_t)blen << 16) | (plain ? WF_REC_PLAIN : 0u);
-                    r[3] = (uint32_t)(s0 - (k + t0 + lane));
+                    uint32_t *r = S.rec + 4 * (nrec + (int)wv::mbcnt(WB));          // (entry and first byte count from the range's first)
+                    r[0] = (uint32_t)(k + t0 + lane); r[1] = (uint32_t)s0; r[2] = (uint32_t)rl | (plain ? WF_REC_PLAIN : 0u); r[3] = 0u;
                 }
                 nrec += nw;
             }
@@ -498,7 +506,7 @@ struct WfWave {
 //         lane in LDS; a character outside ASCII: fused code-point map) -- positions are then CHARACTERS.
 // MODE 2: the other list, what is left (longer words, words at the very end of the text): read from the text character by character.
 template <int NU, bool STATS, int MODE>
-BF_WVD void wf_units(const WfUnitParams &p, const uint32_t *lut, uint16_t *cbuf, const uint32_t *wrec, unsigned long long first, unsigned long long total, unsigned long long *rounds)
+BF_WVD void wf_units(const WfUnitParams &p, const uint32_t *lut, uint16_t *cbuf, const uint32_t *wrec, int64_t b0, unsigned long long first, unsigned long long total, unsigned long long *rounds)
 {
     static_assert(MODE == 0 || NU == 1, "one word per lane but on the first list");
     const int lane = wv::lane();
@@ -540,9 +548,9 @@ BF_WVD void wf_units(const WfUnitParams &p, const uint32_t *lut, uint16_t *cbuf,
         const unsigned long long ri = first + (unsigned long long)(64 * u + lane);
         bool have = ri < total;
         const uint32_t *r = wrec + 4 * (have ? ri : first);
-        const uint32_t r0 = r[0], r1 = r[1], r2 = r[2]; w3[u] = r[3];
-        ea[u] = (int64_t)r0 | ((int64_t)(r2 & 0xFFu) << 32); pa[u] = (int64_t)r1 | ((int64_t)((r2 >> 8) & 0xFFu) << 32);
-        L[u] = (int)((r2 >> 16) & 0xFFu);
+        const uint32_t r0 = r[0], r1 = r[1], r2 = r[2]; w3[u] = r1 - r0;               // (home - entry: a word has no more pieces than bytes)
+        ea[u] = b0 + (int64_t)r0; pa[u] = b0 + (int64_t)r1;
+        L[u] = (int)(r2 & 0xFFu);
         const bool b16 = L[u] <= 16 && pa[u] + 16 <= p.total_bytes;
         if (MODE == 1) have = have && b16;
         if (MODE == 2) have = have && !b16;

@@ -31,7 +31,9 @@ constexpr int64_t WF_RANGE_MAX = 1 << 22; // bytes a range aims at, at most (a r
 constexpr uint64_t WF_KEY_SOLO = 0x80ull, WF_KEY_NONE = 0xFFull;
 constexpr int WF_KEY_SOLO_SHIFT = 8;
 
-// ---- the word table.  Entry e = 16 bytes {k0 (8), k1 (4), id (4)}; k0 == 0: empty; two candidate entries per key.
+// ---- the word table.  Entry e = 16 bytes {k0 (8), k1 (4), id | characters << 24 (4)}; k0 == 0: empty; two candidate entries per key.
+constexpr int WF_ROW_LEN_SHIFT = 24;
+constexpr uint32_t WF_ROW_ID_MASK = (1u << WF_ROW_LEN_SHIFT) - 1u;
 BF_FK uint32_t wf_mix(uint64_t k0, uint32_t k1, uint32_t m0) { return (uint32_t)k0 ^ ((uint32_t)(k0 >> 32) * m0) ^ (k1 * 0x85EBCA6Bu); }
 BF_FK uint32_t wf_h(uint32_t x, uint32_t m, int bits) { return (x * m) >> (32 - bits); }
 // code of a class inside a key (0: the class has none)

@@ -643,10 +643,11 @@ template <int WPE, bool STATS>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_wp_flat(WfParams p)
 {
     __shared__ WfLds lds[4];
-    __shared__ uint32_t lut[128];
+    __shared__ alignas(16) uint32_t lut[WF_LUT];
     __shared__ WpWaveCold cold;
     if (threadIdx.x == 0) cold = p.cold;
     if (threadIdx.x < 128) lut[threadIdx.x] = wf_lut_value(p.cold, (int)threadIdx.x);
+    else if (threadIdx.x < WF_LUT) lut[threadIdx.x] = wf_kmask_value((int)threadIdx.x - 128);
     __syncthreads();
     WfWave<STATS> w(p, lds[wave_in_block()], lut, cold);
     w.run((int)(blockIdx.x * 4) + wave_in_block(), (int)(gridDim.x * 4));
@@ -672,8 +673,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
         const unsigned long long nfast = (unsigned long long)p.wrec_cnt[2 * r], nslow = (unsigned long long)p.wrec_cnt[2 * r + 1];
         const uint32_t *fl = p.wrec + 4 * ((b0 + 3) >> 2), *sl = p.wrec + 4 * ((b1 >> 2) - (int64_t)nslow);       // (the second list grows down from the end: its order does not matter)
         uint16_t *cb = cbuf[wave_in_block()];
-        for (unsigned long long first = 0; first < nfast; first += 64 * NU) { wf_units<NU, STATS, 0>(p, lut, cb, fl, first, nfast, &rounds); ++batches; }
-        for (unsigned long long first = 0; first < nslow; first += 64) { wf_units<1, STATS, 1>(p, lut, cb, sl, first, nslow, &rounds); wf_units<1, STATS, 2>(p, lut, cb, sl, first, nslow, &rounds); ++batches; }
+        for (unsigned long long first = 0; first < nfast; first += 64 * NU) { wf_units<NU, STATS, 0>(p, lut, cb, fl, b0, first, nfast, &rounds); ++batches; }
+        for (unsigned long long first = 0; first < nslow; first += 64) { wf_units<1, STATS, 1>(p, lut, cb, sl, b0, first, nslow, &rounds); wf_units<1, STATS, 2>(p, lut, cb, sl, b0, first, nslow, &rounds); ++batches; }
     }
     if (STATS && p.stats && lane_id() == 0) { atomicAdd(&p.stats[8], rounds); atomicAdd(&p.stats[9], batches); }
 }

@@ -481,7 +481,8 @@ static void build_flat_table(Model &m)
             const uint32_t k1 = f.depth < 8 ? 0u : f.k1 | (wf_code(k, 1u) << (8 * (f.depth - 8)));
             if (fin) {
                 if (!(tag & INFO_SIMPLE_BIT)) return;                 // cannot be (unit form: vocabulary tags are SIMPLE); no table then
-                words.push_back({k0, k1, tag & 0x7FFFFFFFu});
+                if ((tag & 0x7FFFFFFFu) > WF_ROW_ID_MASK) return;        // (an id of more than 24 bits: no table)
+                words.push_back({k0, k1, (tag & 0x7FFFFFFFu) | ((uint32_t)(f.depth + 1) << WF_ROW_LEN_SHIFT)});
             }
             if (f.depth + 1 < WF_KEY_CHARS) stack.push_back({nx, k0, k1, f.depth + 1});
             if (words.size() > (1u << 22)) return;
@@ -491,7 +492,10 @@ static void build_flat_table(Model &m)
     for (int k = 0; k < m.wbd.nclasses; ++k) {
         if (m.wave_kind[(size_t)k] != 3 /* WK_SOLO */) continue;
         uint32_t nx = 0, tag = 0; bool fin = false;
-        if (step(start, (uint32_t)k, nx, fin, tag) && fin && (tag & INFO_SIMPLE_BIT)) words.push_back({WF_KEY_SOLO | ((uint64_t)k << WF_KEY_SOLO_SHIFT), 0u, tag & 0x7FFFFFFFu});
+        if (step(start, (uint32_t)k, nx, fin, tag) && fin && (tag & INFO_SIMPLE_BIT)) {
+            if ((tag & 0x7FFFFFFFu) > WF_ROW_ID_MASK) return;
+            words.push_back({WF_KEY_SOLO | ((uint64_t)k << WF_KEY_SOLO_SHIFT), 0u, tag & 0x7FFFFFFFu});        // (characters: 0)
+        }
     }
     // two-choice (cuckoo) placement at a load of at most 40 %; new multipliers when an insertion does not settle
     int bits = 10; while ((size_t)1 << bits < words.size() * 5 / 2 + 16) ++bits;

@@ -336,8 +336,9 @@ static long emu_flat_batch(void *hv, const uint8_t *text, long text_bytes, const
     std::vector<uint32_t> wrec((size_t)(total / 4 + 64) * 4, 0xDEADBEEFu); std::vector<int32_t> wrec_cnt((size_t)nranges * 2 + 2, 0);
     fp.wrec = wrec.data(); fp.wrec_cnt = wrec_cnt.data();
     if (ndocs > 0) {
-        std::vector<uint32_t> lut(128);
+        std::vector<uint32_t> lut(WF_LUT);
         for (int i = 0; i < 128; ++i) lut[(size_t)i] = wf_lut_value(cold, i);
+        for (int i = 128; i < WF_LUT; ++i) lut[(size_t)i] = wf_kmask_value(i - 128);
         std::vector<WfLds *> of_wave((size_t)nwaves);
         for (int i = 0; i < nwaves; ++i) { of_wave[(size_t)i] = new WfLds(); memset((void *)of_wave[(size_t)i], 0xA5, sizeof(WfLds)); }
         std::vector<const void *> wave_ids;
@@ -370,8 +371,8 @@ static long emu_flat_batch(void *hv, const uint8_t *text, long text_bytes, const
                 const int64_t b0 = doc_off[dlo], b1 = doc_off[dhi];
                 const unsigned long long nfast = (unsigned long long)wrec_cnt[2 * (size_t)r], nslow = (unsigned long long)wrec_cnt[2 * (size_t)r + 1];
                 const uint32_t *fl = up.wrec + 4 * ((b0 + 3) >> 2), *sl = up.wrec + 4 * ((b1 >> 2) - (int64_t)nslow);
-                for (unsigned long long first = 0; first < nfast; first += 128) wf_units<2, true, 0>(up, lut.data(), cbuf.data(), fl, first, nfast, &rounds);
-                for (unsigned long long first = 0; first < nslow; first += 64) { wf_units<1, true, 1>(up, lut.data(), cbuf.data(), sl, first, nslow, &rounds); wf_units<1, true, 2>(up, lut.data(), cbuf.data(), sl, first, nslow, &rounds); }
+                for (unsigned long long first = 0; first < nfast; first += 128) wf_units<2, true, 0>(up, lut.data(), cbuf.data(), fl, b0, first, nfast, &rounds);
+                for (unsigned long long first = 0; first < nslow; first += 64) { wf_units<1, true, 1>(up, lut.data(), cbuf.data(), sl, b0, first, nslow, &rounds); wf_units<1, true, 2>(up, lut.data(), cbuf.data(), sl, b0, first, nslow, &rounds); }
                 if (wvemu::g_cur->lane == 0) { nf_all += nfast; ns_all += nslow; }
             }
         });

@@ -149,6 +149,9 @@ def test_document_shapes(ht):
     check(ht, model, edges, [(512, 100, 1, 1), (2000, 100, 2, 0)])
     mixed = [b" ".join(rnd.choice(words) for _ in range(rnd.randint(0, 120))) for _ in range(200)]
     check(ht, model, mixed, [(512, 100, 2, 0), (512, 100, 3, 1), (5, 100, 1, 2)])
+    # a character the vocabulary does not hold as the last bytes of the batch (its word is read from the text, character by character)
+    for tail in ("tail \U00020000", "tail \u0e5b", "x\u4e00"):
+        check(ht, model, [b"plain words", tail.encode()], [(512, 100, 1, 1)])
     # words of many pieces one after the other (more ids per trip of the merge than its buffer holds), among documents of plain words
     many = [b" ".join(bytes(rnd.choice(b"qzxjkvw") for _ in range(rnd.randint(6, 14))) for _ in range(rnd.randint(1, 400))) if i % 3 else b"plain words only , here"
             for i in range(150)]
