@@ -52,11 +52,15 @@ BF_WV uint32_t wf_kmask_value(int i)
 
 #if defined(__HIPCC__)
 #define BF_WF_NOINLINE __device__ __forceinline__
-// (the compiler would fetch the second row's key only after the first row has come back and did not match)
-#define BF_WF_BOTH_ROWS(A, B) asm volatile("" : "+v"(A.k0lo), "+v"(A.k0hi), "+v"(A.k1), "+v"(A.id), "+v"(B.k0lo), "+v"(B.k0hi), "+v"(B.k1), "+v"(B.id))
+// (left to itself the compiler fetches the second row's key only after the first row has come back and did not match, or waits for the first row
+// before it sends for the second: two trips to the table for one)
+typedef uint32_t wf_u32x4 __attribute__((ext_vector_type(4)));
+#define BF_WF_LOAD_ROWS(A, B, PA, PB) { wf_u32x4 ra_, rb_; const WfRow *pa_ = (PA), *pb_ = (PB); \
+    asm volatile("global_load_dwordx4 %0, %2, off\n\tglobal_load_dwordx4 %1, %3, off\n\ts_waitcnt vmcnt(0)" : "=&v"(ra_), "=&v"(rb_) : "v"(pa_), "v"(pb_) : "memory"); \
+    A.k0lo = ra_.x; A.k0hi = ra_.y; A.k1 = ra_.z; A.id = ra_.w; B.k0lo = rb_.x; B.k0hi = rb_.y; B.k1 = rb_.z; B.id = rb_.w; }
 #else
 #define BF_WF_NOINLINE static __attribute__((noinline))
-#define BF_WF_BOTH_ROWS(A, B) ((void)0)
+#define BF_WF_LOAD_ROWS(A, B, PA, PB) { A = *(PA); B = *(PB); }
 #endif
 
 // A chunk with bytes >= 0x80 (the caller has put the ASCII bytes' classes and WF_CONT for all others into the ring).  Every lead byte is decoded
@@ -396,13 +400,8 @@ struct WfWave {
             uint32_t k1 = w[2] & km[2];
             if (kn == 0) { k0 = solo ? (WF_KEY_SOLO | ((uint64_t)(S.ring[(uint32_t)s0 & RMASK] & LX_T_CLS_MASK) << WF_KEY_SOLO_SHIFT)) : WF_KEY_NONE; k1 = 0u; }       // a one-element token: by class
             const uint32_t x = wf_mix(k0, k1, p.m0);
-#ifdef BF_EXPERIMENTS
-            const uint32_t gmask = (p.dbg & 4) ? 0u : 0xFFFFFFFFu;
-            WfRow A = *((const WfRow *)p.W + (wf_h(x, p.m1, p.wbits) & gmask)), B = *((const WfRow *)p.W + (wf_h(x, p.m2, p.wbits) & gmask));
-#else
-            WfRow A = *((const WfRow *)p.W + wf_h(x, p.m1, p.wbits)), B = *((const WfRow *)p.W + wf_h(x, p.m2, p.wbits));
-#endif
-            BF_WF_BOTH_ROWS(A, B);                                               // both rows whole and in flight together: one trip to the table
+            WfRow A, B;
+            BF_WF_LOAD_ROWS(A, B, (const WfRow *)p.W + wf_h(x, p.m1, p.wbits), (const WfRow *)p.W + wf_h(x, p.m2, p.wbits));     // both rows whole and in flight together: one trip to the table
             const uint32_t klen = (uint32_t)kn << WF_ROW_LEN_SHIFT;
             const bool hita = ((A.k0lo ^ (uint32_t)k0) | (A.k0hi ^ (uint32_t)(k0 >> 32)) | (A.k1 ^ k1) | ((A.id ^ klen) & ~WF_ROW_ID_MASK)) == 0u;
             const bool hitb = ((B.k0lo ^ (uint32_t)k0) | (B.k0hi ^ (uint32_t)(k0 >> 32)) | (B.k1 ^ k1) | ((B.id ^ klen) & ~WF_ROW_ID_MASK)) == 0u;
