@@ -396,7 +396,8 @@ int run_device(Handle *h, const char *d_text, const int64_t *d_doc_off, int64_t 
     if (h->last_flat) {
         // w_misc: [192] work counter of the ranges, [200] "the batch is not fit for the flat program", [204] documents handed back, [208], [216] words on the two lists
         char *misc = h->w_misc.as<char>();
-        if (!hip_ok(hipMemsetAsync(misc + 192, 0, 32, s), "hipMemsetAsync") || !hip_ok(hipMemsetAsync(h->w_dstat.p, 0, (size_t)ndocs * 4, s), "hipMemsetAsync")) return BF_E_DEVICE;
+        if (!hip_ok(hipMemsetAsync(misc + 192, 0, 32, s), "hipMemsetAsync") || !hip_ok(hipMemsetAsync(h->w_dstat.p, 0, (size_t)ndocs * 4, s), "hipMemsetAsync") ||
+            !hip_ok(hipMemsetAsync(h->w_counts.p, 0, (size_t)ndocs * 4, s), "hipMemsetAsync")) return BF_E_DEVICE;
         int *unsafe = (int *)(misc + 200); unsigned int *list_n = (unsigned int *)(misc + 204);
         const int nranges = wp_flat_ranges(ndocs, total_bytes);
         launch_wp_pre(d_doc_off, ndocs, total_bytes, nranges, h->w_ranges.as<int64_t>(), unsafe, s);
@@ -423,7 +424,7 @@ int run_device(Handle *h, const char *d_text, const int64_t *d_doc_off, int64_t 
         // the words the table did not answer: walked by a kernel of their own
         WfUnitParams up;
         up.T = fp.T; up.ini = fp.ini; up.ini_l = fp.ini_l; up.max_token_length = fp.max_token_length; up.text = b.text; up.total_bytes = total_bytes;
-        up.wrec = fp.wrec; up.wrec_cnt = fp.wrec_cnt; up.range_doc = fp.range_doc; up.doc_off = b.doc_off; up.nranges = nranges; up.ent = fp.ent; up.home = fp.home; up.espan = fp.espan; up.hspan = want_off ? h->w_hspan.as<uint32_t>() : nullptr; up.cpmap = cold.cpmap; up.kind = cold.kind; up.nclasses = cold.nclasses; up.stats = cold.stats;
+        up.wrec = fp.wrec; up.wrec_cnt = fp.wrec_cnt; up.range_doc = fp.range_doc; up.doc_off = b.doc_off; up.nranges = nranges; up.ent = fp.ent; up.home = fp.home; up.extra = h->w_counts.as<int32_t>(); up.espan = fp.espan; up.hspan = want_off ? h->w_hspan.as<uint32_t>() : nullptr; up.cpmap = cold.cpmap; up.kind = cold.kind; up.nclasses = cold.nclasses; up.stats = cold.stats;
         launch_wp_units(up, h->variant, s);
         (void)hipEventRecord(h->ev[EV_TOK], s);
         // the documents it hands back: the wave program, one document at a time

@@ -53,6 +53,7 @@ struct WfUnitParams {
     const uint8_t *text; int64_t total_bytes;
     const uint32_t *wrec; const int32_t *wrec_cnt; const int64_t *range_doc; const int64_t *doc_off; int nranges;      // the ranges' lists (WfParams)
     uint32_t *ent; int32_t *home;
+    int32_t *extra;                  // per document, zero before the launch: the ids its words of several pieces have beyond one each (what k_wp_count adds to the entries)
     const uint32_t *espan; uint32_t *hspan;                 // offsets API (else nullptr): the words' spans (WfParams); INSTEAD of home: (id, span) of piece j of the word at byte p -> hspan[2 (p + j)], [2 (p + j) + 1]
     DevCpMap cpmap; const uint8_t *kind; int nclasses;      // fused code point -> charmap -> class map, kinds of the classes (the table of the ASCII bytes is made of them)
     unsigned long long *stats;       // optional: [8] rounds [9] batches
@@ -63,7 +64,7 @@ struct WfMergeParams {
     const int64_t *doc_off; int64_t ndocs;
     const uint32_t *ent; const int32_t *home; const int64_t *ent_off; const int32_t *ent_cnt; const int32_t *dstat; const int *unsafe;
     const int32_t *ids_tmp;          // staging of the documents the wave program tokenised (bf_wave.h wv_ids_slot)
-    int32_t *counts;                 // [ndocs] in: the wave program's counts of those documents; out (k_wp_count): every document's
+    int32_t *counts;                 // [ndocs] in: the wave program's counts of the documents it tokenised, of all others the ids beyond one per entry (k_wp_units); out (k_wp_count): every document's ids
     const int64_t *id_off; int32_t *ids_out; int64_t ids_cap; int *status;
     int max_ids, unk;
     // offsets API (else nullptr): the spans of the entries and of the pieces at the homes; the byte offsets of every id (tokdll:1263-1297).  The documents

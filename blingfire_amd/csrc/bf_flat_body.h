@@ -23,7 +23,7 @@ namespace bfa {
 constexpr int WF_TQ = 512;                // tokens of a chunk, at most (every byte one)
 constexpr int WF_RING_DUP = 16;           // the first positions of the code ring once more behind its end: the 12 bytes of a key are read without a wrap
 constexpr uint32_t WF_TQ_SOLO = 63;       // list entry: bytes == 63: a one-element token
-// a record of the word list (16 bytes): [0] the word's entry, [1] its first byte -- both counted from the first entry / byte of the range -- [2] bytes | WF_REC_PLAIN
+// a record of the word list (16 bytes): [0] the word's entry, [1] its first byte, [3] its document -- counted from the first entry / byte / document of the range -- [2] bytes | WF_REC_PLAIN
 constexpr uint32_t WF_REC_PLAIN = 1u << 8;       // the word's bytes are plain ASCII (its characters are its bytes)
 
 struct alignas(16) WfRow { uint32_t k0lo, k0hi, k1, id; };      // an entry of the word table (bf_flat_key.h)
@@ -437,9 +437,12 @@ struct WfWave {
                     const unsigned long long wlo_ = ls < 64 ? ((na_prev >> (ls & 63)) | ((ls & 63) ? na << (64 - (ls & 63)) : 0ull)) : (na >> ((ls - 64) & 63));
                     plain = ls >= 0 && (wlo_ & ((2ull << ((le - ls) & 63)) - 1ull)) == 0ull;
                 }
+                // the word's document: the last one that begins at or before it (the one open where the chunk begins: the one before the first that begins here)
+                int dd = dfirst - 1;
+                for (int d = dfirst; d < dnext; ++d) dd += s0 >= off_rel(d) ? 1 : 0;
                 if (word) {
-                    uint32_t *r = S.rec + 4 * (nrec + (int)wv::mbcnt(WB));          // (entry and first byte count from the range's first)
-                    r[0] = (uint32_t)(k + t0 + lane); r[1] = (uint32_t)s0; r[2] = (uint32_t)rl | (plain ? WF_REC_PLAIN : 0u); r[3] = 0u;
+                    uint32_t *r = S.rec + 4 * (nrec + (int)wv::mbcnt(WB));          // (entry, first byte and document count from the range's first)
+                    r[0] = (uint32_t)(k + t0 + lane); r[1] = (uint32_t)s0; r[2] = (uint32_t)rl | (plain ? WF_REC_PLAIN : 0u); r[3] = (uint32_t)dd;
                 }
                 nrec += nw;
             }
@@ -504,8 +507,8 @@ struct WfWave {
 // MODE 1: the other list, its words of <= 16 bytes: the word in two registers, its characters' classes made up front (`cbuf`: 16 classes per
 //         lane in LDS; a character outside ASCII: fused code-point map) -- positions are then CHARACTERS.
 // MODE 2: the other list, what is left (longer words, words at the very end of the text): read from the text character by character.
-template <int NU, bool STATS, int MODE>
-BF_WVD void wf_units(const WfUnitParams &p, const uint32_t *lut, uint16_t *cbuf, const uint32_t *wrec, int64_t b0, unsigned long long first, unsigned long long total, unsigned long long *rounds)
+template <int NU, bool STATS, int MODE, bool OFFS>
+BF_WVD void wf_units(const WfUnitParams &p, const uint32_t *lut, uint16_t *cbuf, const uint32_t *wrec, int64_t b0, int64_t dlo, unsigned long long first, unsigned long long total, unsigned long long *rounds)
 {
     static_assert(MODE == 0 || NU == 1, "one word per lane but on the first list");
     const int lane = wv::lane();
@@ -514,9 +517,9 @@ BF_WVD void wf_units(const WfUnitParams &p, const uint32_t *lut, uint16_t *cbuf,
     uint32_t state[NU], ftag[NU], c_cur[NU], w3[NU]; int L[NU], j[NU], fp[NU], cnt[NU], clen[NU]; int32_t id0[NU];
     // offsets API: where the walk under way started (a piece is [from, fp)); the span of the first piece; the word's first byte in its document;
     // MODE 1: the bytes at which the word's characters start, its bytes
-    int from[NU]; uint32_t sp0[NU], wstart[NU]; uint32_t startm_keep = 0; int Lb = 0;
-    const bool offs = p.hspan != nullptr;
-    int64_t ea[NU], pa[NU];
+    int from[NU]; uint32_t sp0[NU]; uint32_t startm_keep = 0; int Lb = 0;
+    constexpr bool offs = OFFS;
+    int64_t ea[NU], pa[NU]; int xtra[NU];
     uint64_t t_lo[NU], t_hi[NU];
     bool anch[NU], act[NU], missed[NU], stale[NU];
     // MODE 2: the character at byte j of word u, read from the text: its class and its length
@@ -558,8 +561,7 @@ BF_WVD void wf_units(const WfUnitParams &p, const uint32_t *lut, uint16_t *cbuf,
         state[u] = anchored0 ? p.ini_l : p.ini; j[u] = 0; fp[u] = -1; cnt[u] = 0; ftag[u] = 0; id0[u] = 0; clen[u] = 1;
         anch[u] = anchored0; act[u] = have; missed[u] = false; stale[u] = MODE == 2 && have;
         c_cur[u] = 0;
-        from[u] = 0; sp0[u] = 0; wstart[u] = 0;
-        if (offs && have) wstart[u] = p.espan[ea[u]] & WF_SPAN_POS_MASK;
+        from[u] = 0; sp0[u] = 0; xtra[u] = 0;
     }
     { bool a = false;
 #pragma unroll
@@ -646,7 +648,7 @@ BF_WVD void wf_units(const WfUnitParams &p, const uint32_t *lut, uint16_t *cbuf,
                                 for (int i = 0; i < tb; ++i) mt &= mt - 1u;
                                 fb = mf ? __builtin_ctz(mf) : Lb; tb = mt ? __builtin_ctz(mt) : Lb;
                             }
-                            const uint32_t sp = (wstart[u] + (uint32_t)fb) | ((uint32_t)(tb - fb - 1) << WF_SPAN_LEN_SHIFT);
+                            const uint32_t sp = ((p.espan[ea[u]] & WF_SPAN_POS_MASK) + (uint32_t)fb) | ((uint32_t)(tb - fb - 1) << WF_SPAN_LEN_SHIFT);
                             // (id, span) of a piece side by side: one scattered store of eight bytes, and one gather in the merge
                             uint32_t *hs = p.hspan + 2 * (ea[u] + (int64_t)w3[u]);
                             if (cnt[u] == 0) sp0[u] = sp;
@@ -656,6 +658,7 @@ BF_WVD void wf_units(const WfUnitParams &p, const uint32_t *lut, uint16_t *cbuf,
                         const int nf = fp[u];
                         if (nf >= L[u]) {
                             p.ent[ea[u]] = cnt[u] == 1 ? (uint32_t)id0[u] : (WF_ENT_FLAG | ((uint32_t)cnt[u] << WF_ENT_CNT_SHIFT) | w3[u]);
+                            xtra[u] = cnt[u] - 1;                              // (its document has that many ids more than entries)
                             act[u] = false;
                         } else { state[u] = p.ini; j[u] = nf; from[u] = nf; fp[u] = -1; anch[u] = false; missed[u] = false; }
                     } else if (anch[u]) { state[u] = p.ini; j[u] = 0; fp[u] = -1; anch[u] = false; missed[u] = false; }
@@ -666,6 +669,22 @@ BF_WVD void wf_units(const WfUnitParams &p, const uint32_t *lut, uint16_t *cbuf,
             any_act = any_act || wv::any(act[u]);
         }
     }
+    // What the documents of these words have in ids beyond their entries: the records of a list are in the order of their documents, so the lanes
+    // of one document are neighbours -- their sum by a segmented scan, one atomic per document (a third of one per word).
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+        if (!wv::any(xtra[u] != 0)) continue;
+        const unsigned long long ri = first + (unsigned long long)(64 * u + lane);
+        const int doc = ri < total ? (int)wrec[4 * ri + 3] : -1 - lane;
+        int x = xtra[u];
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int t = wv::shfl_up(x, o), dp = wv::shfl_up(doc, o);
+            if (lane >= o && dp == doc) x += t;
+        }
+        const int dn = wv::shfl_down(doc, 1);
+        if ((lane == 63 || dn != doc) && x != 0) wv::atomic_add_i32(&p.extra[dlo + (int64_t)doc], x);
+    }
     if (MODE == 1) wv::sync();                                               // (the next batch writes the classes anew)
 }
 
@@ -675,67 +694,18 @@ BF_WVD void wf_units(const WfUnitParams &p, const uint32_t *lut, uint16_t *cbuf,
 // ----------------------------------------------------------------------------------------------------------------------
 BF_WVD int wf_entry_ids(uint32_t e) { const int n = (int)((e & ~WF_ENT_FLAG) >> WF_ENT_CNT_SHIFT); return (e & WF_ENT_FLAG) ? (n ? n : 1) : 1; }
 
-// counts[d] = ids of document d (tokdll:1308-1310: at most max_ids; 0 for invalid UTF-8: :1151-1153)
-// The usual block -- 64 documents of one range, none flagged: their entries are ONE contiguous run -- is streamed 256 entries per trip; an entry
-// of more than one id (2 % of them) adds to the document that holds it (which one: a count over the lanes' first entries).
+// counts[d] = ids of document d (tokdll:1308-1310: at most max_ids; 0 for invalid UTF-8: :1151-1153): its entries and what its words of several
+// pieces have beyond one id each (k_wp_units has added that up in counts[d]); a document the wave program tokenised keeps the count that wrote
 BF_WVD void wf_count_docs(const WfMergeParams &p, int64_t base)
 {
-    const int lane = wv::lane();
-    const int64_t d = base + lane;
-    const bool unsafe = *p.unsafe != 0;
-    const int nd = p.ndocs - base < 64 ? (int)(p.ndocs - base) : 64;
-    int ec = 0, st = 0, old = 0; int64_t eo = 0;
-    if (d < p.ndocs) { st = unsafe ? WF_D_HARD : p.dstat[d]; old = p.counts[d]; if (!(st & WF_D_HARD)) { eo = p.ent_off[d]; ec = p.ent_cnt[d]; } }
-    int extra = 0;
-    const int64_t eo_n = wv::shfl_down(eo, 1);
-    if (!wv::any(lane < nd && st != 0)) {
-      // (what limits a streaming kernel here is the number of vector-memory instructions a CU can issue: four consecutive entries per lane and load)
-      // the block's entries are contiguous but where a range of the flat program ends: one run per piece
-      unsigned long long brk = wv::ballot(lane < nd && (lane + 1 == nd || eo_n != eo + ec));      // the lanes that end a piece
-      for (int first = 0; brk;) {
-        const int lastl = __builtin_ctzll(brk); brk &= brk - 1ull;
-        const int64_t E0 = wv::bcast(eo, first), E1 = wv::bcast(eo + (int64_t)ec, lastl);
-        first = lastl + 1;
-        for (int64_t t = E0; t < E1; t += 256) {
-            const int64_t a = t + 4 * lane;
-            uint32_t e[4] = {0u, 0u, 0u, 0u};
-            if (a + 4 <= E1) __builtin_memcpy(e, p.ent + a, 16);
-            else for (int u = 0; u < 4; ++u) if (a + u < E1) e[u] = p.ent[a + u];
-            if (!wv::any(((e[0] | e[1] | e[2] | e[3]) & WF_ENT_FLAG) != 0u)) continue;
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int x = wf_entry_ids(e[u]) - 1;
-                for (unsigned long long fb = wv::ballot(x != 0); fb;) {
-                    const int l = __builtin_ctzll(fb); fb &= fb - 1ull;
-                    const int64_t at = t + 4 * l + u;
-                    const int doc = __builtin_popcountll(wv::ballot(lane < nd && eo <= at)) - 1;      // the last document whose first entry is <= at
-                    const int xv = wv::bcast(x, l);
-                    if (lane == doc) extra += xv;
-                }
-            }
-        }
-      }
-    } else {
-        if (st & (WF_D_BAD | WF_D_HARD)) ec = 0;
-        for (int i = 0; i < nd; ++i) {
-            const int n = wv::bcast(ec, i);
-            if (n == 0) continue;
-            const int64_t o = wv::bcast(eo, i);
-            int sum = 0;
-            for (int t = 0; t < n; t += 64) {
-                const uint32_t e = t + lane < n ? p.ent[o + t + lane] : 0u;
-                const int x = wf_entry_ids(e) - 1;
-                if (wv::any(x != 0)) sum += wv::bcast(wv::incl_scan(x), 63);
-            }
-            if (lane == i) extra = sum;
-        }
-    }
-    if (d < p.ndocs) {
-        int cnt = (st & WF_D_HARD) ? old : (st & WF_D_BAD) ? 0 : ec + extra;
-        if (!(st & WF_D_HARD) && cnt > p.max_ids) cnt = p.max_ids;
-        p.counts[d] = cnt;
-        if (p.counts_hard) p.counts_hard[d] = (st & WF_D_HARD) ? cnt : 0;
-    }
+    const int64_t d = base + wv::lane();
+    if (d >= p.ndocs) return;
+    const int st = *p.unsafe != 0 ? WF_D_HARD : p.dstat[d];
+    const int old = p.counts[d];
+    int cnt = (st & WF_D_HARD) ? old : (st & WF_D_BAD) ? 0 : p.ent_cnt[d] + old;
+    if (!(st & WF_D_HARD) && cnt > p.max_ids) cnt = p.max_ids;
+    p.counts[d] = cnt;
+    if (p.counts_hard) p.counts_hard[d] = (st & WF_D_HARD) ? cnt : 0;
 }
 
 // a span (WF_SPAN_*) as the byte offsets of the id's first and last byte in its document (tokdll:1263-1297)

@@ -654,7 +654,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
 }
 
 // the words of the list (bf_flat_body.h wf_units): a wave takes batches of 64 * NU records, batch number = wave number + k * waves
-template <int WPE, int NU, bool STATS>
+template <int WPE, int NU, bool STATS, bool OFFS = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_wp_units(WfUnitParams p)
 {
     __shared__ uint32_t lut[128];
@@ -673,8 +673,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
         const unsigned long long nfast = (unsigned long long)p.wrec_cnt[2 * r], nslow = (unsigned long long)p.wrec_cnt[2 * r + 1];
         const uint32_t *fl = p.wrec + 4 * ((b0 + 3) >> 2), *sl = p.wrec + 4 * ((b1 >> 2) - (int64_t)nslow);       // (the second list grows down from the end: its order does not matter)
         uint16_t *cb = cbuf[wave_in_block()];
-        for (unsigned long long first = 0; first < nfast; first += 64 * NU) { wf_units<NU, STATS, 0>(p, lut, cb, fl, b0, first, nfast, &rounds); ++batches; }
-        for (unsigned long long first = 0; first < nslow; first += 64) { wf_units<1, STATS, 1>(p, lut, cb, sl, b0, first, nslow, &rounds); wf_units<1, STATS, 2>(p, lut, cb, sl, b0, first, nslow, &rounds); ++batches; }
+        for (unsigned long long first = 0; first < nfast; first += 64 * NU) { wf_units<NU, STATS, 0, OFFS>(p, lut, cb, fl, b0, dlo, first, nfast, &rounds); ++batches; }
+        for (unsigned long long first = 0; first < nslow; first += 64) { wf_units<1, STATS, 1, OFFS>(p, lut, cb, sl, b0, dlo, first, nslow, &rounds); wf_units<1, STATS, 2, OFFS>(p, lut, cb, sl, b0, dlo, first, nslow, &rounds); ++batches; }
     }
     if (STATS && p.stats && lane_id() == 0) { atomicAdd(&p.stats[8], rounds); atomicAdd(&p.stats[9], batches); }
 }
@@ -764,7 +764,8 @@ static void launch_wp_units_cfg(const WfUnitParams &p, int per_cu_override, hipS
     int per_cu = wp_blocks_per_cu(k_wp_units<WPE, NU, false>, pc);
     if (per_cu_override > 0) per_cu = per_cu_override;
     const int64_t blocks = (int64_t)device_cus() * per_cu;
-    if (p.stats) hipLaunchKernelGGL((k_wp_units<WPE, NU, true>), dim3((unsigned)blocks), dim3(256), 0, s, p);
+    if (p.hspan) hipLaunchKernelGGL((k_wp_units<WPE, NU, false, true>), dim3((unsigned)blocks), dim3(256), 0, s, p);      // the offsets API: the pieces carry their spans
+    else if (p.stats) hipLaunchKernelGGL((k_wp_units<WPE, NU, true>), dim3((unsigned)blocks), dim3(256), 0, s, p);
     else hipLaunchKernelGGL((k_wp_units<WPE, NU, false>), dim3((unsigned)blocks), dim3(256), 0, s, p);
 }
 

@@ -318,7 +318,7 @@ static long emu_flat_batch(void *hv, const uint8_t *text, long text_bytes, const
     std::vector<uint32_t> ent((size_t)total + 64, 0xDEADBEEFu);
     std::vector<int32_t> home((size_t)total + 64, -77), entcnt((size_t)ndocs + 1, -55), dstat((size_t)ndocs + 1, 0), list((size_t)ndocs + 1, -1);
     std::vector<int64_t> entoff((size_t)ndocs + 1, -1);
-    std::vector<int32_t> tmp((size_t)(total + 8 * ndocs + 64 + 8), -77), counts((size_t)ndocs + 1, -55), counts_hard((size_t)ndocs + 1, -55);
+    std::vector<int32_t> tmp((size_t)(total + 8 * ndocs + 64 + 8), -77), counts((size_t)ndocs + 1, 0), counts_hard((size_t)ndocs + 1, -55);
     std::vector<int32_t> span(offs ? 2 * (size_t)(total + 8 * ndocs + 64 + 8) : 2, -77);
     std::vector<uint32_t> espan(offs ? (size_t)total + 64 : 1, 0xDEADBEEFu), hspan(offs ? 2 * ((size_t)total + 64) : 1, 0xDEADBEEFu);
     unsigned long long next_range = 0, next_doc = 0; int status = 0;
@@ -359,7 +359,7 @@ static long emu_flat_batch(void *hv, const uint8_t *text, long text_bytes, const
         WfUnitParams up;
         up.T = fp.T; up.ini = fp.ini; up.ini_l = fp.ini_l; up.max_token_length = fp.max_token_length; up.text = text; up.total_bytes = total;
         up.wrec = wrec.data(); up.wrec_cnt = wrec_cnt.data(); up.range_doc = range_doc.data(); up.doc_off = doc_off; up.nranges = nranges;
-        up.ent = ent.data(); up.home = home.data(); up.espan = fp.espan; up.hspan = offs ? hspan.data() : nullptr; up.cpmap = cold.cpmap; up.kind = cold.kind; up.nclasses = cold.nclasses; up.stats = stats;
+        up.ent = ent.data(); up.home = home.data(); up.extra = counts.data(); up.espan = fp.espan; up.hspan = offs ? hspan.data() : nullptr; up.cpmap = cold.cpmap; up.kind = cold.kind; up.nclasses = cold.nclasses; up.stats = stats;
         std::vector<uint32_t> lut(128);
         for (int i = 0; i < 128; ++i) lut[(size_t)i] = wf_lut_value(cold, i);
         unsigned long long rounds = 0, nf_all = 0, ns_all = 0;
@@ -371,8 +371,13 @@ static long emu_flat_batch(void *hv, const uint8_t *text, long text_bytes, const
                 const int64_t b0 = doc_off[dlo], b1 = doc_off[dhi];
                 const unsigned long long nfast = (unsigned long long)wrec_cnt[2 * (size_t)r], nslow = (unsigned long long)wrec_cnt[2 * (size_t)r + 1];
                 const uint32_t *fl = up.wrec + 4 * ((b0 + 3) >> 2), *sl = up.wrec + 4 * ((b1 >> 2) - (int64_t)nslow);
-                for (unsigned long long first = 0; first < nfast; first += 128) wf_units<2, true, 0>(up, lut.data(), cbuf.data(), fl, b0, first, nfast, &rounds);
-                for (unsigned long long first = 0; first < nslow; first += 64) { wf_units<1, true, 1>(up, lut.data(), cbuf.data(), sl, b0, first, nslow, &rounds); wf_units<1, true, 2>(up, lut.data(), cbuf.data(), sl, b0, first, nslow, &rounds); }
+                if (offs) {
+                    for (unsigned long long first = 0; first < nfast; first += 128) wf_units<2, true, 0, true>(up, lut.data(), cbuf.data(), fl, b0, dlo, first, nfast, &rounds);
+                    for (unsigned long long first = 0; first < nslow; first += 64) { wf_units<1, true, 1, true>(up, lut.data(), cbuf.data(), sl, b0, dlo, first, nslow, &rounds); wf_units<1, true, 2, true>(up, lut.data(), cbuf.data(), sl, b0, dlo, first, nslow, &rounds); }
+                } else {
+                    for (unsigned long long first = 0; first < nfast; first += 128) wf_units<2, true, 0, false>(up, lut.data(), cbuf.data(), fl, b0, dlo, first, nfast, &rounds);
+                    for (unsigned long long first = 0; first < nslow; first += 64) { wf_units<1, true, 1, false>(up, lut.data(), cbuf.data(), sl, b0, dlo, first, nslow, &rounds); wf_units<1, true, 2, false>(up, lut.data(), cbuf.data(), sl, b0, dlo, first, nslow, &rounds); }
+                }
                 if (wvemu::g_cur->lane == 0) { nf_all += nfast; ns_all += nslow; }
             }
         });

@@ -189,6 +189,7 @@ static inline void arrived(int32_t &, int32_t &, int32_t &, int32_t &) {}      /
 static inline uint32_t mbcnt(unsigned long long m) { return (uint32_t)__builtin_popcountll(m & ((1ull << wvemu::g_cur->lane) - 1ull)); }
 static inline unsigned long long atomic_add(unsigned long long *p, unsigned long long v) { unsigned long long o = *p; *p = o + v; return o; }
 static inline void atomic_or(int *p, int v) { *p |= v; }
+static inline void atomic_add_i32(int32_t *p, int32_t v) { *p += v; }
 static inline void lds_or(uint32_t *p, uint32_t v) { *p |= v; }
 static inline unsigned long long clock() { return 0; }
 static inline uint32_t load_l2(const uint32_t *p) { return *p; }
