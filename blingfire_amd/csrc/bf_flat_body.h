@@ -35,13 +35,15 @@ struct WfLds {
     uint32_t spare32; uint16_t spare;
 };
 
-// the 128-entry table of the ASCII bytes: [12:0] class, [18:16] kind bits (loop, solo, general), [30:24] the class's code inside a key
+// the 128-entry table of the ASCII bytes: [2:0] kind bits (loop, solo, general), [14:8] the class's code inside a key, [28:16] class -- where one
+// v_perm_b32 / v_alignbit_b32 picks them up for the rows of the two rings and the kind mask of a lane's eight bytes
 BF_WV uint32_t wf_lut_value(const WpWaveCold &p, int b)
 {
     const uint32_t el = wv_element(p, b), c = el & LX_T_CLS_MASK, k = el >> WK_SHIFT;
     const uint32_t nib = k == WK_LOOP ? 1u : k == WK_SOLO ? 2u : k == WK_GENERAL ? 4u : 0u;
-    return c | (nib << 16) | ((c < 127u ? c + 1u : 0u) << 24);
+    return nib | ((c < 127u ? c + 1u : 0u) << 8) | (c << 16);
 }
+BF_WV uint32_t wf_lut_class(uint32_t v) { return v >> 16; }
 // behind it (entries 128 + 4 n .. + 2): the bytes of a key a word of n characters has (bf_flat_key.h), as three masks
 constexpr int WF_LUT = 128 + 4 * 16;
 BF_WV uint32_t wf_kmask_value(int i)
@@ -63,12 +65,12 @@ typedef uint32_t wf_u32x4 __attribute__((ext_vector_type(4)));
 #define BF_WF_LOAD_ROWS(A, B, PA, PB) { A = *(PA); B = *(PB); }
 #endif
 
-// A chunk with bytes >= 0x80 (the caller has put the ASCII bytes' classes and WF_CONT for all others into the ring).  Every lead byte is decoded
+// A chunk with bytes >= 0x80 (the caller has put every byte through the table of the ASCII bytes).  Every lead byte is decoded
 // by its lane, one per trip; a continuation byte is legal exactly when it is one of the (length - 1) bytes behind a lead byte OF ITS DOCUMENT (a
 // document boundary inside a character truncates it, FAUtf8Utils.cpp:167-171).  S8: the documents that begin in this lane's bytes; peek: in the
 // three bytes behind the chunk.  Returns what the characters add to the kind bits, the bytes that are invalid, and what the last character of
 // the chunk covers of the next one.
-struct WfMb { uint32_t acc, errm, cov_carry, loop_carry; unsigned long long na; };      // na: the lanes that hold a byte >= 0x80
+struct WfMb { uint32_t acc, clr, errm, cov_carry, loop_carry; unsigned long long na; };      // na: the lanes that hold a byte >= 0x80; clr: the kind bits of those bytes
 BF_WVD WfMb wf_decode_multibyte(uint64_t own, uint32_t S8, uint32_t peek, int c, int len, const uint8_t *txt, uint16_t *ring, uint8_t *cring, const uint16_t *cp_l1, const uint32_t *cp_pages,
                                         const uint8_t *kind, int nclasses, uint32_t cov_carry, uint32_t loop_carry)
 {
@@ -83,6 +85,15 @@ BF_WVD WfMb wf_decode_multibyte(uint64_t own, uint32_t S8, uint32_t peek, int c,
 #pragma unroll
     for (int i = 0; i < 8; ++i) { m80 |= (uint32_t)((h80 >> (8 * i + 7)) & 1ull) << i; m40 |= (uint32_t)((h40 >> (8 * i + 7)) & 1ull) << i; }
     const uint32_t contm = m80 & ~m40 & vm8, leadm = m80 & m40 & vm8;
+    // what the caller made of the bytes >= 0x80 (their low seven bits through the table of the ASCII bytes) is taken back: no character starts
+    // there until a lead byte below says so
+    uint32_t clr = 0;
+    for (uint32_t m = m80; m;) {
+        const int i = __builtin_ctz(m); m &= m - 1u;
+        const uint32_t rp = ((uint32_t)lane0 + (uint32_t)i) & RMASK;
+        ring[rp] = (uint16_t)WF_CONT; cring[rp] = 0; if (rp < (uint32_t)WF_RING_DUP) cring[rp + WF_RING] = 0;
+        clr |= 0xFu << (4 * i);
+    }
     uint32_t nxt = wv::shfl_down((uint32_t)own, 1);
     uint32_t s_nx = wv::shfl_down(S8, 1) & 7u;                         // boundaries at the three bytes behind this lane's
     if (lane == 63) {
@@ -137,7 +148,7 @@ BF_WVD WfMb wf_decode_multibyte(uint64_t own, uint32_t S8, uint32_t peek, int c,
     const uint32_t lb = (lsp | sp_loop) & 0xFFu & contm;
 #pragma unroll
     for (int i = 0; i < 8; ++i) acc |= ((lb >> i) & 1u) << (4 * i);
-    WfMb r; r.acc = acc; r.errm = errm; r.cov_carry = cov_out; r.loop_carry = loop_out; r.na = wv::ballot(m80 != 0);
+    WfMb r; r.acc = acc; r.clr = clr; r.errm = errm; r.cov_carry = cov_out; r.loop_carry = loop_out; r.na = wv::ballot(m80 != 0);
     return r;
 }
 
@@ -285,24 +296,22 @@ struct WfWave {
         unsigned long long na = 0;
         const bool ascii_chunk = !wv::any((own & 0x8080808080808080ull) != 0);
         {
+            // every byte through the table of the ASCII bytes (a byte >= 0x80 gets what its low seven bits say: a chunk that holds one puts that
+            // right below, wf_decode_multibyte): class rows, code rows, kind bits -- one instruction per pair, per pair and per byte
             uint32_t v[8];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const uint32_t b = (uint32_t)(own >> (8 * i)) & 0xFFu;
-                v[i] = lut[b & 0x7Fu];
-                if (!ascii_chunk) v[i] = b < 0x80u ? v[i] : WF_CONT;
-            }
+            for (int i = 0; i < 8; ++i) v[i] = lut[(uint32_t)(own >> (8 * i)) & 0x7Fu];
             const uint32_t rp = (uint32_t)lane0 & RMASK;
             uint32_t *row = (uint32_t *)(S.ring + rp);                          // 8 positions = one 16-byte row, never wraps
-            const uint32_t r0 = (v[0] & 0xFFFFu) | (v[1] << 16), r1 = (v[2] & 0xFFFFu) | (v[3] << 16), r2 = (v[4] & 0xFFFFu) | (v[5] << 16), r3 = (v[6] & 0xFFFFu) | (v[7] << 16);
-            row[0] = r0; row[1] = r1; row[2] = r2; row[3] = r3;
-            const uint32_t c0 = (v[0] >> 24) | ((v[1] >> 16) & 0xFF00u) | ((v[2] >> 8) & 0xFF0000u) | (v[3] & 0xFF000000u);
-            const uint32_t c1 = (v[4] >> 24) | ((v[5] >> 16) & 0xFF00u) | ((v[6] >> 8) & 0xFF0000u) | (v[7] & 0xFF000000u);
+            row[0] = wv::perm(v[1], v[0], 0x07060302u); row[1] = wv::perm(v[3], v[2], 0x07060302u);
+            row[2] = wv::perm(v[5], v[4], 0x07060302u); row[3] = wv::perm(v[7], v[6], 0x07060302u);
+            const uint32_t c0 = wv::perm(wv::perm(v[3], v[2], 0x05010c0cu), wv::perm(v[1], v[0], 0x0c0c0501u), 0x07060100u);
+            const uint32_t c1 = wv::perm(wv::perm(v[7], v[6], 0x05010c0cu), wv::perm(v[5], v[4], 0x0c0c0501u), 0x07060100u);
             uint32_t *crow = (uint32_t *)(S.cring + rp);
             crow[0] = c0; crow[1] = c1;
             if (rp < (uint32_t)WF_RING_DUP) { uint32_t *dup = (uint32_t *)(S.cring + rp + WF_RING); dup[0] = c0; dup[1] = c1; }
 #pragma unroll
-            for (int i = 0; i < 8; ++i) acc |= ((v[i] >> 16) & 7u) << (4 * i);
+            for (int i = 0; i < 8; ++i) acc = wv::alignbit(v[i], acc, 4);         // (the kind bits of byte i end up in bits 4 i ..)
         }
         if (ascii_chunk) { if (STATS) ++st_ascii; cov_carry = 0; loop_carry = 0; }
         else {
@@ -310,7 +319,7 @@ struct WfWave {
             uint32_t peek = 0;
             for (int d = dnext; d < dn; ++d) { const int o = off_rel(d); if (o >= c + WF_CHUNK + 3) break; peek |= 1u << (o - (c + WF_CHUNK)); }
             const WfMb r = wf_decode_multibyte(own, S8, peek, c, len, txt, S.ring, S.cring, cold.cpmap.l1, cold.cpmap.pages, cold.kind, cold.nclasses, cov_carry, loop_carry);
-            acc |= r.acc; cov_carry = r.cov_carry; loop_carry = r.loop_carry; na = r.na;
+            acc = (acc & ~r.clr) | r.acc; cov_carry = r.cov_carry; loop_carry = r.loop_carry; na = r.na;
             if (wv::any(r.errm != 0)) mark_bytes(c, r.errm, WF_D_BAD);          // invalid UTF-8: the document has no ids (tokdll:1151-1153)
         }
         wv::sync();                                                             // the ring is written
@@ -530,7 +539,7 @@ BF_WVD void wf_units(const WfUnitParams &p, const uint32_t *lut, uint16_t *cbuf,
         int cl = b0 < 0x80u ? 1 : (b0 & 0xE0u) == 0xC0u ? 2 : (b0 & 0xF0u) == 0xE0u ? 3 : (b0 & 0xF8u) == 0xF0u ? 4 : 1;
         if (cl > left) cl = left;                                  // (cannot be in a document that has ids)
         uint32_t cls;
-        if (b0 < 0x80u) cls = lut[b0] & LX_T_CLS_MASK;
+        if (b0 < 0x80u) cls = wf_lut_class(lut[b0]);
         else {
             int cp = cl == 2 ? (int)(b0 & 0x1Fu) : cl == 3 ? (int)(b0 & 0x0Fu) : (int)(b0 & 0x07u);
             for (int t = 1; t < cl; ++t) cp = (cp << 6) | (int)(q[t] & 0x3Fu);
@@ -542,7 +551,7 @@ BF_WVD void wf_units(const WfUnitParams &p, const uint32_t *lut, uint16_t *cbuf,
     auto byte_at = [&](int u, int i) -> uint32_t { return (uint32_t)((i < 8 ? t_lo[u] : t_hi[u]) >> (8 * (i & 7))) & 0xFFu; };
     // class of character i (MODE 0: byte i through the table; MODE 1: from the classes made up front)
     auto cls_at = [&](int u, int i) -> uint32_t {
-        if (MODE == 0) return lut[byte_at(u, i) & 0x7Fu] & LX_T_CLS_MASK;
+        if (MODE == 0) return wf_lut_class(lut[byte_at(u, i) & 0x7Fu]);
         return (uint32_t)cbuf[lane * 16 + (i & 15)];
     };
 #pragma unroll
@@ -581,7 +590,7 @@ BF_WVD void wf_units(const WfUnitParams &p, const uint32_t *lut, uint16_t *cbuf,
         for (int i = 0; i < 16; ++i) {
             const bool on = ((startm & ~leadm) >> i) & 1u;
             uint16_t *d = on ? &cbuf[lane * 16 + __builtin_popcount(startm & ((1u << i) - 1u))] : &cbuf[64 * 16];
-            *d = (uint16_t)(lut[byte_at(0, i) & 0x7Fu] & LX_T_CLS_MASK);
+            *d = (uint16_t)wf_lut_class(lut[byte_at(0, i) & 0x7Fu]);
         }
         for (uint32_t lm = leadm; wv::any(lm != 0);) {
             if (lm) {

@@ -143,6 +143,9 @@ __device__ __forceinline__ uint32_t min_all(uint32_t v)
 __device__ __forceinline__ unsigned long long atomic_add(unsigned long long *p, unsigned long long v) { return atomicAdd(p, v); }
 __device__ __forceinline__ void atomic_or(int *p, int v) { atomicOr(p, v); }
 __device__ __forceinline__ void atomic_add_i32(int32_t *p, int32_t v) { atomicAdd(p, v); }
+// v_perm_b32: byte k of the result = byte sel[k] of {hi, lo} (0..3 = lo, 4..7 = hi); v_alignbit_b32: ({hi, lo} >> sh) [31:0]
+__device__ __forceinline__ uint32_t perm(uint32_t hi, uint32_t lo, uint32_t sel) { return __builtin_amdgcn_perm(hi, lo, sel); }
+__device__ __forceinline__ uint32_t alignbit(uint32_t hi, uint32_t lo, uint32_t sh) { return __builtin_amdgcn_alignbit(hi, lo, sh); }
 __device__ __forceinline__ void lds_or(uint32_t *p, uint32_t v) { atomicOr(p, v); }      // a word in LDS, from divergent lanes
 __device__ __forceinline__ unsigned long long clock() { return __builtin_readcyclecounter(); }
 // a word that other lanes of the wave update with atomics (executed in the L2): read past the CU's vector cache

@@ -190,6 +190,13 @@ static inline uint32_t mbcnt(unsigned long long m) { return (uint32_t)__builtin_
 static inline unsigned long long atomic_add(unsigned long long *p, unsigned long long v) { unsigned long long o = *p; *p = o + v; return o; }
 static inline void atomic_or(int *p, int v) { *p |= v; }
 static inline void atomic_add_i32(int32_t *p, int32_t v) { *p += v; }
+static inline uint32_t perm(uint32_t hi, uint32_t lo, uint32_t sel)
+{
+    const unsigned long long w = ((unsigned long long)hi << 32) | lo; uint32_t r = 0;
+    for (int k = 0; k < 4; ++k) { const uint32_t s = (sel >> (8 * k)) & 0xFFu; r |= (s < 8u ? (uint32_t)((w >> (8 * s)) & 0xFFu) : 0u) << (8 * k); }
+    return r;
+}
+static inline uint32_t alignbit(uint32_t hi, uint32_t lo, uint32_t sh) { return (uint32_t)(((((unsigned long long)hi) << 32) | lo) >> (sh & 31u)); }
 static inline void lds_or(uint32_t *p, uint32_t v) { *p |= v; }
 static inline unsigned long long clock() { return 0; }
 static inline uint32_t load_l2(const uint32_t *p) { return *p; }
