@@ -61,8 +61,8 @@ prof() { # name, traffic key, dominant kernel, launches of it per step, more cou
   timeout 900 rocprofv3 --kernel-trace --stats -d $P/stats -o stats -- $B > $O/${name}_traced.json 2> /dev/null
   timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $P/pmc_fetch -o pmc -- $B --steps 3 --warmup 1 > /dev/null 2>&1
   timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $P/pmc_write -o pmc -- $B --steps 3 --warmup 1 > /dev/null 2>&1
-  timeout 600 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --kernel-trace -d $P/pmc_tcc -o pmc -- $B --steps 3 --warmup 1 > /dev/null 2>&1
   if [ "$more" = 1 ]; then
+    timeout 600 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --kernel-trace -d $P/pmc_tcc -o pmc -- $B --steps 3 --warmup 1 > /dev/null 2>&1
     timeout 600 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR --kernel-trace -d $P/pmc_sq1 -o pmc -- $B --steps 3 --warmup 1 > /dev/null 2>&1
     timeout 600 rocprofv3 --pmc SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT --kernel-trace -d $P/pmc_sq2 -o pmc -- $B --steps 3 --warmup 1 > /dev/null 2>&1
   fi
@@ -75,7 +75,7 @@ model=$(python -c "import sys; sys.path.insert(0,'$root/tests'); import bfutil; 
 prof default "headline512/$model/10000000" k_wp_flat 1 1
 line default
 if [ -z "$quick" ]; then
-  prof default_offsets "headline512/$model/10000000/offsets" k_wp_wave 1 0 --offsets
+  prof default_offsets "headline512/$model/10000000/offsets" k_wp_flat 1 0 --offsets
   line default_offsets --offsets --verify 2000000
   prof config2 "config2/$model/1000000" k_wp_flat 1 0 --workload config2
   prof config3 "config3/gpt2.bin/1000000" k_bpe_wave 1 0 --workload config3
