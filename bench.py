@@ -645,6 +645,13 @@ def main():
                 torch.cuda.synchronize(dev)
                 bf.lib().BfLexStats(ctypes.c_void_p(h), buf, 16)
                 bf.lib().BfSetLexStats(ctypes.c_void_p(h), 0)
+                if kernel_name == "k_wp_flat":
+                    # the flat program is bound by vector instructions, not by gathers: what its instrumented twin counts
+                    res["roofline"]["lookups"] = {"chunks_per_step": int(buf[0]), "plain_ascii_chunks": int(buf[1]), "tokens_per_step": int(buf[2]), "table_hits": int(buf[3]),
+                                                  "hit_rate": int(buf[3]) / max(int(buf[2]), 1), "words_walked_by_k_wp_units": int(buf[4]), "row_gathers_per_step": 2 * int(buf[2]),
+                                                  "documents_handed_to_the_wave_program": int(buf[7]),
+                                                  "counted_by": "the STATS instances of k_wp_flat / k_wp_units in one extra untimed step (BfSetLexStats)"}
+                    raise StopIteration
                 wave = kernel_name == "k_wp_wave"
                 issued = int(buf[9]) if wave else int(buf[1])          # gathers issued (the wave program's transition step loads on all 64 lanes)
                 transitions = int(buf[10]) if wave else int(buf[1])    # transitions made
@@ -660,6 +667,8 @@ def main():
                                              "transitions_per_input_byte": transitions / max(total_bytes, 1),
                                              "counted_by": "the STATS instance of %s (every gather the kernel issues; idle lanes of a transition step included)" % kernel_name,
                                              "ceiling_source": "tools/microbench/gather.hip on this GPU, table of the model's size (profiles/gather_ceiling.json)"}
+            except StopIteration:
+                pass
             except Exception as e:   # instrumentation is optional
                 res["roofline"]["gather"] = {"error": str(e)}
 

@@ -1,5 +1,6 @@
 """GPU parity, WordPiece path: the HIP pipeline (through the C-ABI) vs the CPU checker on the same inputs.
 Bar: bit-exact ids and counts (integer work)."""
+import ctypes
 import numpy as np
 import pytest
 
@@ -208,3 +209,39 @@ def test_bench_generators_pinned_to_the_reference(workload):
         assert np.array_equal(ids, gids)
     finally:
         bf.free_model(h)
+
+
+@pytest.mark.gpu
+def test_flat_program_output_smaller_than_the_ids():
+    """ids_cap too small on the device call through the flat program: BfLastStatus bit 0, the id offsets are complete (they say what was needed), the
+    documents that lie wholly inside the buffer have their ids, nothing is written behind it; the host call answers BF_E_CAPACITY"""
+    import torch
+    model = bfutil.bert_model_name()
+    h = bf.load_model(bfutil.model_path(model))
+    ck = bfutil.reference() if bfutil.have_ref() else bfutil.oracle()
+    hck = ck.load(bfutil.model_path(model))
+    try:
+        text, off = bfutil.gen_workload("config2", 3000)
+        want_ids, want_off = ck.batch(hck, text, off, 512, 100)
+        bf.lib().BfSetVariant(h, 4)
+        dev = torch.device("cuda", 0)
+        dt, do = torch.from_numpy(text).to(dev), torch.from_numpy(off).to(dev)
+        for cap in (int(want_off[-1]) - 1, int(want_off[-1]) // 2, 7):
+            out = torch.full((cap + 64,), -7, dtype=torch.int32, device=dev)
+            ido = torch.empty(len(off), dtype=torch.int64, device=dev)
+            r = bf.lib().TextToIdsBatchDevice(ctypes.c_void_p(h), dt.data_ptr(), do.data_ptr(), len(off) - 1, len(text), out.data_ptr(), cap, ido.data_ptr(), 512, 100,
+                                              ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+            assert r == 0
+            torch.cuda.synchronize(dev)
+            assert bf.lib().BfLastStatus(ctypes.c_void_p(h)) & 1
+            g_off, g = ido.cpu().numpy(), out.cpu().numpy()
+            assert np.array_equal(g_off, want_off)
+            nfit = int(np.searchsorted(want_off, cap, side="right")) - 1          # documents [0, nfit) end at or before cap
+            assert np.array_equal(g[:want_off[nfit]], want_ids[:want_off[nfit]])
+            assert (g[cap:] == -7).all()
+        ids = np.zeros(7, dtype=np.int32); id_off = np.zeros(len(off), dtype=np.int64)
+        r = bf.lib().TextToIdsBatch(ctypes.c_void_p(h), text.ctypes.data, off.ctypes.data, len(off) - 1, ids.ctypes.data, 7, id_off.ctypes.data, 512, 100)
+        assert r == -3
+    finally:
+        bf.free_model(h)
+        ck.free(hck)
