@@ -111,3 +111,45 @@ def test_pool_exhaustion_is_per_document(ht):
     r, ids, ido, status, used2, _ = run(ht, h, text, off, 1 << 20, 0, nw=1, pool=used)
     assert status == 0 and np.array_equal(ido, goff) and np.array_equal(ids, gids)
     ora.free(ho); ht.bft_free(h)
+
+
+def _bpe_model_with_a_large_id(tmp_path):
+    """a copy of bpe_example.bin whose first I2Info row holds the id 2^20 (the multi-map dump of [pos-dict] patched in place, the CRC dump written anew)"""
+    import struct
+    import ldbedit
+    src = bfutil.model_path("bpe_example.bin")
+    dumps = ldbedit.read_ldb(src)
+    conf = ldbedit.decode_conf(dumps[0])
+    mm = dict((p, v) for p, v in ldbedit.params(conf[ldbedit.FUNC_POS_DICT]) if v is not None)[25]       # PARAM_MULTI_MAP: the dump of the I2Info rows
+    d = bytearray(dumps[mm])
+    size_of_value, max_count = struct.unpack_from("<Ii", d, 0)
+    assert size_of_value == 4 and max_count >= 1
+    struct.pack_into("<i", d, 16 + 4, 1 << 20)                         # row 0: [count][id][score]
+    dumps[mm] = bytes(d)
+    return ldbedit.write_ldb(str(tmp_path / "bpe_large_id.bin"), dumps, conf)
+
+
+def test_model_outside_the_key_format_is_marked(ht, tmp_path):
+    """k_bpe_seg keeps an id in 20 bits of its keys: a model with a larger id is not `bpe_seg_ok` (bf_model.cpp), and the library refuses to load it (GPU test below)"""
+    if not bfutil.have_model("bpe_example.bin"):
+        pytest.skip("model not present")
+    p = _bpe_model_with_a_large_id(tmp_path)
+    h = ht.bft_load(p.encode())
+    assert h and ht.bft_bpe_seg_ok(h) == 0
+    ht.bft_free(h)
+    ho = bfutil.oracle().load(p)                                          # (the oracle, which has no such limit, loads it)
+    assert ho
+    bfutil.oracle().free(ho)
+
+
+@pytest.mark.gpu
+def test_model_outside_the_key_format_is_refused_at_load(tmp_path):
+    import blingfire_amd as bf
+    if not bfutil.have_model("bpe_example.bin"):
+        pytest.skip("model not present")
+    p = _bpe_model_with_a_large_id(tmp_path)
+    bf.lib().LoadModel.restype = ctypes.c_void_p
+    h = bf.lib().LoadModel(p.encode())
+    assert not h
+    bf.lib().BfLastError.restype = ctypes.c_char_p
+    assert b"BPE" in (bf.lib().BfLastError() or b"") or b"bpe" in (bf.lib().BfLastError() or b"")
