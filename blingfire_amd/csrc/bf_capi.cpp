@@ -394,7 +394,7 @@ int run_device(Handle *h, const char *d_text, const int64_t *d_doc_off, int64_t 
     (void)hipEventRecord(h->ev[EV_BEGIN], s);
     h->last_flat = use_flat(h, want_off, words, ndocs, total_bytes);
     if (h->last_flat) {
-        // w_misc: [192] work counter of the ranges, [200] "the batch is not fit for the flat program", [204] documents handed back, [208], [216] words on the two lists
+        // w_misc: [192] work counter of the ranges, [200] "the batch is not fit for the flat program", [204] documents handed back
         char *misc = h->w_misc.as<char>();
         if (!hip_ok(hipMemsetAsync(misc + 192, 0, 32, s), "hipMemsetAsync") || !hip_ok(hipMemsetAsync(h->w_dstat.p, 0, (size_t)ndocs * 4, s), "hipMemsetAsync") ||
             !hip_ok(hipMemsetAsync(h->w_counts.p, 0, (size_t)ndocs * 4, s), "hipMemsetAsync")) return BF_E_DEVICE;

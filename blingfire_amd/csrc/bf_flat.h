@@ -5,15 +5,15 @@
 //   -> FALexTools_t<int>::Process_int (cl/inc/FALexTools_t.h:205-400) -> the _wp post-pass (tokdll:1207-1313)
 // -- organised around two more facts (bf_model.cpp "flat form"):
 //
-//   * 98 % of the words of running text are ONE vocabulary entry, and whether a word is one is a function of the word alone: the walk of
-//     the vocabulary function from its first state consumes the whole word and ends on a final state.  All such words of <= 9 characters are
-//     enumerated at load into a two-choice hash table keyed BY THE WORD (7 bits per character): a word is resolved by two independent
-//     16-byte gathers instead of a chain of dependent transitions, and a hit needs no verification (the key is the word);
+//   * 97 % of the words of running text are ONE vocabulary entry, and whether a word is one is a function of the word alone: the walk of
+//     the vocabulary function from its first state consumes the whole word and ends on a final state.  All such words of <= 12 characters are
+//     enumerated at load into a two-choice hash table keyed BY THE WORD (a byte per character, bf_flat_key.h): a word is resolved by two
+//     independent 16-byte gathers instead of a chain of dependent transitions, and a hit needs no verification (the key is the word);
 //   * nothing but the position of a word in its document's id list couples the words of a batch.  So a wave takes a contiguous RANGE of
 //     documents as one stream of 512-byte chunks that ignore document boundaries (a boundary is a bit in a mask that cuts runs), gives every
 //     token an ENTRY (range-dense: entry k of the range = its k-th token) and lets the merge kernel (k_wp_merge) put the entries of a
-//     document in their final place; the words the table does not hold (2-5 %: long words, words of several pieces, words with
-//     characters outside ASCII) are copied to a small arena in LDS and walked by 64 units at once when 64 of them have come together.
+//     document in their final place; the words the table does not hold (3 %: long words, words of several pieces, words with
+//     characters outside ASCII) become records of the range's own list and are walked by a kernel of their own (k_wp_units).
 //
 // What the program does not resolve it hands back PER DOCUMENT (a flag in dstat[]): a run of more than WF_RUN_MAX bytes, an element whose
 // top-level token the automaton itself must decide (WK_GENERAL).  Those documents are tokenised by the wave program (bf_wave.h) afterwards.

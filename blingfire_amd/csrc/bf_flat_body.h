@@ -3,17 +3,17 @@
 //
 // One wave takes ranges of documents from a work counter.  A range is a stream of 512-byte chunks, eight bytes per lane, positions counted
 // in BYTES from the range's first byte:
-//   decode    plain ASCII (one vote): eight look-ups per lane in a 128-entry table give class, kind and key code of every byte; else every lead
-//             byte is decoded by its lane (strict UTF-8, the rules of FAUtf8Utils.cpp:121-196 per byte position), its continuation bytes
-//             belong to its character.  The class of every byte goes to a ring in LDS (what a unit reads, should the word need one);
+//   classes   eight look-ups per lane in a 128-entry table give class, kind and key code of every byte; a chunk with a byte >= 0x80 (one vote)
+//             then has every lead byte decoded by its lane (strict UTF-8, the rules of FAUtf8Utils.cpp:121-196 per byte position), its
+//             continuation bytes belong to its character.  Class and key code of every byte position go to two rings in LDS;
 //   tokens    kinds as one bit per byte in 4-bit fields: run starts / ends from shifts, a document boundary is one more bit that cuts
 //             runs (FALexTools_t.h:229-393 on a unit-form lexer is a function of the kinds alone, bf_wave.h); every lane owns the tokens
 //             that END in its eight bytes; a prefix sum gives each its entry;
 //   list      every lane writes where its tokens are, in token order, to a list in LDS;
 //   look-up   the list one token per lane and trip: the key of a run of <= 12 plain characters is its bytes of the code ring (the key IS
-//             the word), two 12-byte gathers per lane, ids to the entries as whole rows;
-//   records   the tokens the table did not answer become records (entry, first byte, bytes) in a list in global memory, 64 at a time (one
-//             atomic per 64): the words are walked by a kernel of their own (k_wp_units, wf_units below), where nothing waits for them.
+//             the word), two 16-byte gathers per lane, ids to the entries as whole rows;
+//   records   the tokens the table did not answer become records (entry, first byte, bytes, document) in the range's own list in global
+//             memory, 64 at a time: the words are walked by a kernel of their own (k_wp_units, wf_units below), where nothing waits for them.
 // What couples documents is left to the kernels behind (k_wp_count, k_wp_merge): a document's entries are dense, its ids are not yet.
 #pragma once
 #include "bf_flat.h"

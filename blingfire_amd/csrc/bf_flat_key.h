@@ -13,7 +13,6 @@ namespace bfa {
 
 constexpr int WF_CHUNK = 512;            // bytes per step (8 per lane)
 constexpr int WF_RING = 1024;            // byte positions whose class is kept (two chunks: a run may begin in the chunk before)
-constexpr int WF_ARENA = 256;            // characters of the waiting words that are not plain text (bf_flat_body.h)
 constexpr int WF_REC = 64;               // words that wait for a unit, at most (one per lane)
 constexpr int WF_RUN_MAX = 48;           // bytes of the longest run the program resolves itself
 constexpr int WF_KEY_CHARS = 12;         // one byte per character (its code: class + 1, 1 .. 127)

@@ -1,18 +1,18 @@
-// bf_kernels.hip -- HIP kernels for gfx950 (MI355X, wave64).  Integer / indexing work: no MFMA.
+// bf_kernels.hip -- HIP kernels for gfx950 (MI355X, wave64), WordPiece branch.  Integer / indexing work: no MFMA.  (The _sp branch, the dictionary
+// look-ups, scan, compaction and the string-assembly kernels: bf_kernels_sp.hip.)
 //
-//  k_prep_wp_flat / _docs   WordPiece branch prep in two passes: byte -> class translation of the whole text buffer (HBM
+//  k_wp_pre, k_wp_flat, k_wp_units, k_wp_hardlist, k_wp_count, k_wp_merge   the flat program (bf_flat.h, bf_flat_body.h): the batch as one byte
+//              stream, whole words answered by a hash table keyed by the word, the others walked by a kernel of their own, ids (and byte
+//              offsets) merged into place through LDS.  The path of flat-form lexers (every BERT model) for batches that fill the device.
+//  k_wp_wave   the wave program (bf_wave.h, bf_wave_body.h): decode + lexer + post-pass of a unit-form lexer in one kernel, document by document:
+//              small batches, the documents the flat program hands back (LIST instances), the offsets instance.
+//  k_prep_wp_flat / _docs   prologue of the lane kernels in two passes: byte -> class translation of the whole text buffer (HBM
 //              streaming) + per-document check; documents with multi-byte characters are redone by a wave (strict UTF-8
 //              decode, BOM skip, fused charmap+class lookup, wave scan).  k_prep_wp: the one-pass form (offsets API).
 //              (reference: FAStrUtf8ToArray cl/src/FAUtf8Utils.cpp:233-270, FAUtf8ToInt :121-196, FANormalize
 //              cl/inc/FAUtils_cl.h:311-369, FAIwMap_pack::GetNewIw cl/inc/FAIwMap_pack.h:55-110)
-//  k_lex_wp_*  one document per lane: DFA lexer + WordPiece post-pass (bf_lex.h).  Bound by the divergent-gather path:
-//              one 8-byte gather per DFA transition into the displacement-packed table.
-//  k_prep_sp, k_sp_hist/_scan/_scatter, k_seg_unigram_*, k_bpe_*   SentencePiece-style branch: prologue, document order,
-//              Unigram-LM (scores in an LDS ring) and BPE (one-pass segment solver + full path) segmenters (bf_seg.h).
-//  k_scan_*    exclusive scan of per-document counts -> offsets.
-//  k_compact   wave-cooperative gather of the per-document staging slots into one contiguous id array.
-//  k_i2t_*, k_w2t_*, k_s2t_*, k_normsp, k_hash_*   IdsToText / TextToWords / TextToSentences string assembly,
-//              NormalizeSpaces, TextToHashes: variable-length byte gathers and streaming kernels.
+//  k_lex_wp_*  one document per lane: DFA lexer + WordPiece post-pass (bf_lex.h): TextToWords / TextToSentences and lexers outside the unit
+//              form.  One 8-byte gather per DFA transition into the displacement-packed table.
 #include "bf_kernels_common.h"
 
 namespace bfa {

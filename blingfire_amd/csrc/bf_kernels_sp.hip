@@ -1,5 +1,15 @@
-// bf_kernels_sp.hip -- the kernels of the SentencePiece-style branch (prologue, document order, Unigram, BPE), the dictionary look-ups, scan,
-// compaction and the string-assembly kernels (see bf_kernels.hip for the list).
+// bf_kernels_sp.hip -- HIP kernels for gfx950 (MI355X, wave64): the SentencePiece-style branch and what every branch shares.
+//
+//  k_prep_sp8 / k_prep_sp, k_sp_hist/_scan/_scatter   prologue (decode, dummy prefix, 1:n charmap, white-space collapse, symbol -> class) and the
+//              order of the documents (longest first).
+//  k_seg_unigram_lane, k_uni_back   Unigram-LM: forward pass (scores and the live window in LDS rings) and backward pass (bf_seg.h).
+//  k_bpe_wave, k_bpe_seg, k_bpe_*   BPE: the wave program with a word unit (bf_bpe_wave_body.h), one wave per document for any input
+//              (bf_bpe_seg_body.h), the lane kernels of plain BPE and the offsets API.
+//  k_dict_*    FADictInterpreter_t::GetInfo for many keys.
+//  k_scan_*    exclusive scan of per-document counts -> offsets.
+//  k_compact*  gather of the per-document staging slots into one contiguous id array (+ byte offsets).
+//  k_i2t_*, k_w2t_*, k_s2t_*, k_normsp, k_hash_*   IdsToText / TextToWords / TextToSentences string assembly,
+//              NormalizeSpaces, TextToHashes: variable-length byte gathers and streaming kernels.
 #include "bf_kernels_common.h"
 #include "bf_bpe_wave_body.h"
 namespace bfa {
