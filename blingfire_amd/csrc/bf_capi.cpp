@@ -762,6 +762,7 @@ int64_t run_host_mapped(Handle *h, const char *text, const int64_t *doc_off, int
     const Model &m = h->m;
     char *hp = h->m_small.as<char>(), *dp = (char *)h->m_small_dev;
     const int64_t base = doc_off[0], total = doc_off[ndocs] - base;
+    h->last_flat = false;                                          // (the wave program: what BfTokeniseKernel / BfStepKernels report)
     memset(hp + SmallLayout::ctrl, 0, 64);
     int64_t *off = (int64_t *)(hp + SmallLayout::off);
     for (int64_t i = 0; i <= ndocs; ++i) off[i] = doc_off[i] - base;

@@ -275,3 +275,25 @@ def test_single_document_calls_from_64_native_threads(tmp_path):
     r = subprocess.run([exe, lib, bfutil.model_path(bfutil.bert_model_name()), str(docs), "0.4"], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "64 threads" in r.stdout and " 0 results that differ" in r.stdout.splitlines()[-1], r.stdout
+
+
+def test_step_diagnostics_name_the_kernels_that_ran():
+    """BfTokeniseKernel / BfStepKernels / BfLastKernelMs after a batch: the flat program for a large WordPiece batch, the wave program for a small one"""
+    L = bf.lib()
+    L.BfTokeniseKernel.restype = ctypes.c_char_p; L.BfTokeniseKernel.argtypes = [ctypes.c_void_p]
+    L.BfStepKernels.restype = ctypes.c_char_p; L.BfStepKernels.argtypes = [ctypes.c_void_p]
+    h = bf.load_model(bfutil.model_path(bfutil.bert_model_name()))
+    try:
+        text, off = bfutil.gen_workload("config2", 20000)                     # 2.5 MB: the flat program
+        bf.text_to_ids_batch(h, (text, off), 128, 100)
+        assert L.BfTokeniseKernel(ctypes.c_void_p(h)) == b"k_wp_flat"
+        names = L.BfStepKernels(ctypes.c_void_p(h)).decode()
+        for k in ("k_wp_pre", "k_wp_flat", "k_wp_units", "k_wp_count", "k_wp_merge"):
+            assert k in names, names
+        ms = bf.last_kernel_ms(h)
+        assert len(ms) == 6 and 0 < ms[5] <= ms[1] <= ms[4]
+        bf.text_to_ids_batch(h, [b"a small batch", b"of two documents"], 128, 100)   # the wave program
+        assert L.BfTokeniseKernel(ctypes.c_void_p(h)) == b"k_wp_wave"
+        assert "k_wp_flat" not in L.BfStepKernels(ctypes.c_void_p(h)).decode()
+    finally:
+        bf.free_model(h)
