@@ -152,6 +152,10 @@ def test_document_shapes(ht):
     # a character the vocabulary does not hold as the last bytes of the batch (its word is read from the text, character by character)
     for tail in ("tail \U00020000", "tail \u0e5b", "x\u4e00"):
         check(ht, model, [b"plain words", tail.encode()], [(512, 100, 1, 1)])
+    # more words the table does not answer than a range's list holds (a record per four bytes of the range): the documents of the words that do not
+    # fit are handed back; characters the vocabulary lacks, with and without blanks between them, in one range and in several
+    for body in ("͸ " * 2000, "͸" * 3000, "\U00020000" * 1500, "͸a͹b " * 1200):
+        check(ht, model, [b"plain first", body.encode(), b"plain last"], [(4096, 100, 2, 0), (4096, 100, 2, 1)])
     # words of many pieces one after the other (more ids per trip of the merge than its buffer holds), among documents of plain words
     many = [b" ".join(bytes(rnd.choice(b"qzxjkvw") for _ in range(rnd.randint(6, 14))) for _ in range(rnd.randint(1, 400))) if i % 3 else b"plain words only , here"
             for i in range(150)]
