@@ -20,7 +20,7 @@
 
 namespace bfa {
 
-constexpr int WF_TQ = 512;                // tokens of a chunk, at most (every byte one)
+constexpr int WF_TQ = 512 + 8;            // tokens of a chunk, at most: every byte one, and the run that ended with the chunk before (513; the rest keeps the alignment)
 constexpr int WF_RING_DUP = 16;           // the first positions of the code ring once more behind its end: the 12 bytes of a key are read without a wrap
 constexpr uint32_t WF_TQ_SOLO = 63;       // list entry: bytes == 63: a one-element token
 // a record of the word list (16 bytes): [0] the word's entry, [1] its first byte, [3] its document -- counted from the first entry / byte / document of the range -- [2] bytes | WF_REC_PLAIN

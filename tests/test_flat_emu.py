@@ -152,6 +152,14 @@ def test_document_shapes(ht):
     # a character the vocabulary does not hold as the last bytes of the batch (its word is read from the text, character by character)
     for tail in ("tail \U00020000", "tail \u0e5b", "x\u4e00"):
         check(ht, model, [b"plain words", tail.encode()], [(512, 100, 1, 1)])
+    # a chunk of 512 one-byte tokens behind a run that ends with the chunk before it: 513 tokens on the list of one chunk (the list once had 512
+    # places, the 513th token went to the first record that waited: found by tools/stress_flat_emu.py).  The document before ends at a chunk boundary
+    # with a word the table does not hold, so that a record waits while the next chunk is listed
+    for tail in (b"zqxjkvw", b"caf\xc3\xa9s", b"word"):
+        first = (b"zqxjkvw " + b"some words and " * 40)[:512 - len(tail) - 1] + b" " + tail          # (its first word leaves a record that waits)
+        assert len(first) == 512
+        check(ht, model, [first, b"." * 600, b"after"], [(4096, 100, 1, 1), (4096, 100, 2, 0)])
+        check(ht, model, [first + b"." * 1100 + b" " + tail], [(4096, 100, 1, 1)])
     # more words the table does not answer than a range's list holds (a record per four bytes of the range): the documents of the words that do not
     # fit are handed back; characters the vocabulary lacks, with and without blanks between them, in one range and in several
     for body in ("͸ " * 2000, "͸" * 3000, "\U00020000" * 1500, "͸a͹b " * 1200):

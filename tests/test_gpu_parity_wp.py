@@ -245,3 +245,28 @@ def test_flat_program_output_smaller_than_the_ids():
     finally:
         bf.free_model(h)
         ck.free(hck)
+
+
+@pytest.mark.gpu
+def test_flat_program_chunk_of_513_tokens():
+    """a chunk of 512 one-byte tokens behind a run that ends with the chunk before it (513 tokens on one chunk's list) while a record of an earlier
+    word waits: the case tools/stress_flat_emu.py found (tests/test_flat_emu.py has it for the simulator)"""
+    model = bfutil.bert_model_name()
+    h = bf.load_model(bfutil.model_path(model))
+    ck = bfutil.reference() if bfutil.have_ref() else bfutil.oracle()
+    hck = ck.load(bfutil.model_path(model))
+    try:
+        docs = []
+        for tail in (b"zqxjkvw", b"caf\xc3\xa9s", b"word"):
+            first = (b"zqxjkvw " + b"some words and " * 40)[:512 - len(tail) - 1] + b" " + tail
+            docs += [first, b"." * 600, b"after", first + b"." * 1100 + b" " + tail]
+        docs = docs * 40                                   # (several ranges, every alignment of the pattern to a range)
+        text, off = bf.pack_docs(docs)
+        want_ids, want_off = ck.batch(hck, text, off, 4096, 100)
+        for variant in (4, 5):
+            bf.lib().BfSetVariant(h, variant)
+            ids, id_off = bf.text_to_ids_batch(h, (text, off), 4096, 100)
+            assert np.array_equal(id_off, want_off) and np.array_equal(ids, want_ids), variant
+    finally:
+        bf.free_model(h)
+        ck.free(hck)
