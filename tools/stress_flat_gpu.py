@@ -1,6 +1,6 @@
 """TEST INFRASTRUCTURE: random batches through the FLAT program on the GPU (C-ABI, BfSetVariant 4) against the CPU checker -- the generator of
 tools/stress_flat_emu.py at batch sizes the device is meant for (hundreds to thousands of documents, so that ranges, chunk alignments and document
-boundaries fall everywhere), ids of every batch, byte offsets of every id of every fourth.  usage: python tools/stress_flat_gpu.py <first seed> <seconds>   (round 5: 300 s on an MI355X, 476 batches / 683,240 documents / 94 batches with offsets, all equal)"""
+boundaries fall everywhere), ids of every batch, byte offsets of every id of every fourth.  usage: python tools/stress_flat_gpu.py <first seed> <seconds>   (round 5: two runs of 5 minutes on an MI355X, 1,052 batches / 1,461,600 documents / 197 batches with offsets, all equal)"""
 import sys, random, time
 import os; ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import numpy as np, bfutil, blingfire_amd as bf
