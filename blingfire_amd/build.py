@@ -83,7 +83,7 @@ def build_test_infra(force=False):
         _run(["gcc", "-O2", "-Wall", "-o", "single_calls", "single_calls.c", "-ldl", "-lpthread"], cwd=os.path.join(ROOT, "tools"))
     # microbenchmarks the evidence scripts run on the GPU box (counter calibration, gather ceiling, issue rate): binaries, not tracked
     mb = os.path.join(ROOT, "tools", "microbench")
-    for name in ("stream", "gather", "valu_issue"):
+    for name in ("stream", "gather", "valu_issue", "gather_sweep"):
         src, out = os.path.join(mb, name + ".hip"), os.path.join(mb, name)
         if os.path.exists(src) and (force or _newer(out, [src])):
             _run([hipcc(), "--offload-arch=gfx950", "-O2", "-w", "-o", out, src])
