@@ -149,6 +149,7 @@ struct Handle {
     Model m;
     int device = 0;
     int variant = 3;
+    bool last_uni_cut = false;          // the last Unigram batch took the cut form (BfTokeniseKernel / BfStepKernels)
     std::mutex mu;
     // held while the ids of a batch wait in this handle's buffers (w_ids / w_starts / w_ends) for their place in the caller's array: a range of a
     // sharded call from its kernels to its copy out (run_host_sharded), any other host-buffer call for its whole duration -- the second call
@@ -159,7 +160,7 @@ struct Handle {
     DevBuf t_kind;                                               // unit-form lexers: what a walk that starts on each class does (bf_wave.h)
     bool lex_stats = false;                                      // BF_LEX_STATS=1 at LoadModel: instrumented kernel instances (experiments)
     DevBuf t_wcp_l1, t_wcp_pages;                                // TextToWords: code point -> class without the charmap
-    DevBuf t_segscore;                                           // _sp Unigram: the rows' scores alone
+    DevBuf t_segscore, t_segid;                                  // _sp Unigram: the rows' scores alone; their ids alone (the cut form's compaction)
     DevBuf t_dict, t_seginfo;                                    // _sp: Mealy table, I2Info rows (code-point maps reuse t_cp_*/t_multi)
     DevBuf t_dk_l1, t_dk_pages, t_dn_l1, t_dn_pages, t_dn_pool, t_k2i, t_rows;   // key -> info lookup (uploaded on first use)
     bool dict_ready = false;
@@ -198,7 +199,7 @@ struct Handle {
         for (Handle *c : shards) if (c && c != this) { DeviceGuard dg(c->device); (void)hipDeviceSynchronize(); delete c; }
         shards.clear();
         pipe.release(); m_small.release();
-        for (DevBuf *b : {&t_segscore, &t_bpe_prio, &t_bpe_place, &t_dk_l1, &t_dk_pages, &t_dn_l1, &t_dn_pages, &t_dn_pool, &t_k2i, &t_rows, &w_keys, &w_keyoff, &w_dids, &w_dret, &w_vals, &t_i2w_off, &t_i2w_data, &t_kind, &t_wbd, &t_info, &t_acts, &t_cp_l1, &t_cp_pages, &t_multi, &t_wcp_l1, &t_wcp_pages, &t_dict, &t_seginfo, &w_s1, &w_s2, &w_s3, &w_s4, &w_big, &w_perm, &w_hist, &w_narcs, &w_bwflags, &w_cls, &w_nchars, &w_tmp, &w_counts, &w_flags, &w_out, &w_outoff,
+        for (DevBuf *b : {&t_segscore, &t_segid, &t_bpe_prio, &t_bpe_place, &t_dk_l1, &t_dk_pages, &t_dn_l1, &t_dn_pages, &t_dn_pool, &t_k2i, &t_rows, &w_keys, &w_keyoff, &w_dids, &w_dret, &w_vals, &t_i2w_off, &t_i2w_data, &t_kind, &t_wbd, &t_info, &t_acts, &t_cp_l1, &t_cp_pages, &t_multi, &t_wcp_l1, &t_wcp_pages, &t_dict, &t_seginfo, &w_s1, &w_s2, &w_s3, &w_s4, &w_big, &w_perm, &w_hist, &w_narcs, &w_bwflags, &w_cls, &w_nchars, &w_tmp, &w_counts, &w_flags, &w_out, &w_outoff,
                           &w_bsums, &w_misc, &w_text, &w_docoff, &w_ids, &w_idoff, &w_starts, &w_ends, &w_srcoff, &w_span, &w_ent, &w_home, &w_entoff, &w_entcnt, &w_dstat, &w_ranges, &w_list, &w_wrec, &t_flat, &w_espan, &w_hspan, &w_chard}) b->release();
         for (auto &e : ev) if (e) (void)hipEventDestroy(e);
         if (stream) (void)hipStreamDestroy(stream);
@@ -295,7 +296,7 @@ Handle *make_handle(const uint8_t *img, size_t size)
         ok = ok && upload(h->t_dict, m.dict.t64, 16) && upload(h->t_seginfo, m.seg_info, 16) &&
              upload(h->t_cp_l1, m.sp_cpmap.l1) && upload(h->t_cp_pages, m.sp_cpmap.pages) && upload(h->t_multi, m.sp_multi_pool, 16);
         if (m.kind == KIND_BPE_MERGES) ok = ok && upload(h->t_bpe_prio, m.bpe_prio, 16) && upload(h->t_bpe_place, m.bpe_place_id, 16);
-        if (m.kind == KIND_UNIGRAM) ok = ok && upload(h->t_segscore, m.seg_score, 16);
+        if (m.kind == KIND_UNIGRAM) ok = ok && upload(h->t_segscore, m.seg_score, 16) && upload(h->t_segid, m.i2info_id, 16);
     }
     if ((m.kind == KIND_BPE || m.kind == KIND_BPE_OPT || m.kind == KIND_BPE_MERGES) && !m.bpe_seg_ok) {
         // k_bpe_seg (the kernel every BPE document can end up in) packs an arc's id into 20 bits, its length - 1 into 8 and a place into 21
@@ -385,7 +386,7 @@ int run_device(Handle *h, const char *d_text, const int64_t *d_doc_off, int64_t 
     Model &m = h->m;
     const int nblocks = scan_nblocks(ndocs);
     if (!reserve_ids_workspaces(h, ndocs, total_bytes, want_off, words)) return BF_E_DEVICE;
-    int slot_mul = 0; const int32_t *first = nullptr;
+    int slot_mul = 0; const int32_t *first = nullptr; bool uni_cut_keys = false;
     unsigned long long *next_doc = h->w_misc.as<unsigned long long>();
     int *status = (int *)(h->w_misc.as<char>() + 16);
     Batch b{(const uint8_t *)d_text, d_doc_off, ndocs, total_bytes, status};
@@ -530,7 +531,11 @@ int run_device(Handle *h, const char *d_text, const int64_t *d_doc_off, int64_t 
         }
         sg.narcs = h->w_narcs.as<int32_t>(); sg.next_doc = next_doc; sg.trie_depth = m.trie_max_depth; sg.variant = h->variant & 0xff; sg.tune = (h->variant >> 8) & 0xff; sg.tune2 = (h->variant >> 16) & 0xff;
         sg.lane_ok = uni_lane_ok(m) ? 1 : 0;
-        if (m.kind == KIND_UNIGRAM && sg.lane_ok) first = h->w_narcs.as<int32_t>();
+        // ids only: the cut form (bf_seg.h UniCut; BfSetVariant 6: the forward / backward kernels of round 4, which the offsets API still takes)
+        sg.uni_cut = (m.kind == KIND_UNIGRAM && sg.lane_ok && !want_off && (h->variant & 0xff) != 6) ? 1 : 0;
+        if (m.kind == KIND_UNIGRAM && sg.lane_ok && !sg.uni_cut) first = h->w_narcs.as<int32_t>();
+        uni_cut_keys = sg.uni_cut != 0;
+        h->last_uni_cut = uni_cut_keys;
         sg.perm = h->w_perm.as<int32_t>(); sg.hist = h->w_hist.as<unsigned int>();
         const bool bwave = use_bpe_wave(h, want_off);
         if (bwave && ndocs > 0) {
@@ -559,6 +564,7 @@ int run_device(Handle *h, const char *d_text, const int64_t *d_doc_off, int64_t 
     (void)hipEventRecord(h->ev[EV_SCAN], s);
     CompactParams cp{b, h->w_tmp.as<int32_t>(), h->w_counts.as<int32_t>(), d_id_off, d_ids_out, ids_cap, status, slot_mul, first,
                      want_off ? h->w_span.as<int32_t>() : nullptr, want_off && !use_wave(h, want_off, words) ? h->w_srcoff.as<int32_t>() : nullptr, want_off ? d_starts : nullptr, want_off ? d_ends : nullptr};
+    if (uni_cut_keys) { cp.key_ids = h->t_segid.as<int32_t>(); cp.key_unk = unk; cp.key_id_offset = m.id_offset; }
     if (ndocs > 0) launch_compact(cp, s);
     (void)hipEventRecord(h->ev[EV_COMPACT], s);
     h->ev_valid = true;
@@ -1968,7 +1974,7 @@ const char *BfTokeniseKernel(void *p)
     if (!h) return "";
     switch (h->m.kind) {
     case KIND_WP: return h->last_flat ? "k_wp_flat" : use_wave(h, false, 0) ? "k_wp_wave" : (h->m.two_level ? "k_lex_wp_plain" : "k_lex_wp_flat");
-    case KIND_UNIGRAM: return "k_seg_unigram_lane";
+    case KIND_UNIGRAM: return h->last_uni_cut ? "k_uni_cut" : "k_seg_unigram_lane";
     case KIND_I2W: return "";
     default: return use_bpe_wave(h, false) ? "k_bpe_wave" : "k_bpe_fused";
     }
@@ -1984,7 +1990,9 @@ const char *BfStepKernels(void *p)
         if (h->last_flat) return "prep: k_wp_pre | tokenise: k_wp_flat, k_wp_units | scan: k_wp_hardlist, k_wp_wave (the documents handed back), k_wp_count, k_scan_block_sums, k_scan_top, k_scan_apply | compact: k_wp_merge";
         if (use_wave(h, false, 0)) return "prep: - | tokenise: k_wp_wave | scan: k_scan_block_sums, k_scan_top, k_scan_apply | compact: k_compact_ids (offsets: k_compact_text)";
         return "prep: k_prep_wp_flat, k_prep_wp_docs | tokenise: k_lex_wp_plain / k_lex_wp_flat | scan: k_scan_block_sums, k_scan_top, k_scan_apply | compact: k_compact_ids (offsets: k_compact)";
-    case KIND_UNIGRAM: return "prep: k_prep_sp8 | tokenise: k_sp_hist, k_sp_hist_scan, k_sp_scatter, k_seg_unigram_lane, k_uni_back | scan: k_scan_block_sums, k_scan_top, k_scan_apply | compact: k_compact_ids";
+    case KIND_UNIGRAM:
+        if (h->last_uni_cut) return "prep: k_prep_sp8 | tokenise: k_sp_hist, k_sp_hist_scan, k_sp_scatter, k_uni_cut | scan: k_scan_block_sums, k_scan_top, k_scan_apply | compact: k_compact_ids<keys>";
+        return "prep: k_prep_sp8 | tokenise: k_sp_hist, k_sp_hist_scan, k_sp_scatter, k_seg_unigram_lane, k_uni_back | scan: k_scan_block_sums, k_scan_top, k_scan_apply | compact: k_compact_ids";
     case KIND_I2W: return "";
     default:
         if (use_bpe_wave(h, false)) return "prep: k_prep_sp8 | tokenise: k_bpe_wave, k_bpe_flag_list, k_bpe_seg | scan: k_scan_block_sums, k_scan_top, k_scan_apply | compact: k_compact_ids";

@@ -75,6 +75,7 @@ struct SpSegParams {
     int32_t *narcs;             // [ndocs] BPE arc count per document (-1 = capacity exceeded); Unigram: first id index within the slot
     int trie_depth;             // longest dictionary entry (bounds every arc length)
     int lane_ok;                // Unigram: the model fits the lane program (bf_seg.h UniLane: entries <= 32 symbols, ids < 2^20 - 2)
+    int uni_cut = 0;            // Unigram: the cut form (bf_seg.h UniCut; ids only): tokens leave as key + 1, left-aligned in the slot -> CompactParams::key_ids
     int64_t bm_words;           // BPE apply: words per bitmap (the two bitmaps live in the `tos` buffer)
     int32_t *fb_list; unsigned int *fb_count;   // BPE: documents k_bpe_fused hands to the full path (set by launch_seg_sp)
     uint8_t *big_pool; unsigned long long big_cap; unsigned long long *big_used, *big_need;   // BPE: pool of the documents whose arcs exceed the per-document reserve (k_bpe_seg); *big_need: bytes that did not fit
@@ -110,6 +111,8 @@ struct CompactParams {
     // offsets API (all optional): stream positions of the staged ids -> byte offsets in the original text (tokdll:1263-1273,1519-1529)
     const int32_t *span_tmp; const int32_t *src_off; int32_t *starts_out; int32_t *ends_out;
     const unsigned int *only_if = nullptr;      // optional: nothing to do when *only_if == 0 (the documents the flat program hands back: usually none)
+    // Unigram cut form: the staged words are key + 1 of the tokens' entries (0: unknown) -> id = key_ids[key] (or key_unk) + key_id_offset (tokdll:1512-1516)
+    const int32_t *key_ids = nullptr; int key_unk = 0, key_id_offset = 0;
 };
 
 // flags: one bit per 16-byte chunk of the text (u64 per KiB, + 1), or nullptr for the one-pass wave-per-document form

@@ -1348,6 +1348,90 @@ __global__ __launch_bounds__(256) void k_uni_back(SpSegParams p)
     p.narcs[doc] = cap - ul.cnt;
 }
 
+// Unigram-LM, cut form (round 6): bf_seg.h UniCut per lane -- the forward pass of the lane program above, the records in an LDS ring of W
+// positions instead of memory, the tokens read off the ring at the cuts (positions the reference's backward pass is certain to land on)
+// and written in forward order, left-aligned in the document's slot, as key + 1 of their entry (0: unknown) -- k_compact_keys looks the ids
+// up.  No record array traffic, no backward kernel.  LDS per lane: ring_n scores (8 B) + W records (4 B): 16 KB per wave, ten waves per CU.
+// Emission is a phase the whole wave enters together -- when a lane has finished its document or filled its ring, and every `period` trips --
+// so that its loops run with most lanes active instead of a few lanes every trip.
+struct RingCut {
+    double *sc; uint32_t *rc; int smask, rmask, sn;
+    __device__ __forceinline__ double score(int pos) const { return sc[(pos & smask) * 64]; }
+    __device__ __forceinline__ uint32_t rec(int pos) const { return rc[(pos & rmask) * 64]; }
+    __device__ __forceinline__ void set(int pos, double v, uint32_t r) { sc[(pos & smask) * 64] = v; rc[(pos & rmask) * 64] = r; }
+    __device__ __forceinline__ void setrec(int pos, uint32_t r) { rc[(pos & rmask) * 64] = r; }
+    __device__ __forceinline__ void setscore(int pos, double v) { sc[(pos & smask) * 64] = v; }
+    __device__ __forceinline__ void fill(double v) { for (int k = 0; k < sn; ++k) sc[k * 64] = v; }      // (a record slot is written before it is read: bf_seg.h)
+};
+
+template <int UNROLL>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4))) void k_uni_cut(SpSegParams p, int ring_n, int W, unsigned period_mask)
+{
+    extern __shared__ double seg_ring[];            // [ring_n][64] scores, then [W][64] packed records
+    enum { M_NEED = 0, M_WALK = 1, M_FLUSH = 2, M_EXIT = 3 };
+    const int lane = lane_id();
+    RingCut ring{seg_ring + lane, (uint32_t *)(seg_ring + (size_t)ring_n * 64) + lane, ring_n - 1, W - 1, ring_n};
+    ClsWinS cls_at; cls_at.init(p.stream, 0);
+    UniCut<ClsWinS, RingCut> uc(p.S, cls_at, ring);
+    uc.L = 0; uc.depth = p.trie_depth; uc.W = W; uc.start = uc.i = uc.sum = 0; uc.state = 0; uc.unknown = true; uc.pend = false; uc.prev = 0; uc.pend_i = 0;
+    uc.pend_score = 0; uc.pend_key = 0; uc.unk_run = 0; uc.reach = -1; uc.cut0 = 0; uc.lastcut = -1; uc.ring_lo = 0; uc.nout = 0;
+    int mode = M_NEED;
+    int64_t doc = 0; int32_t *ids = nullptr;
+    for (unsigned long long trip = 0; trip < (1ull << 34); ++trip) {
+        // ---- documents for idle lanes
+        const unsigned long long m_need = __ballot(mode == M_NEED);
+        if (m_need) {
+            const unsigned long long m_busy = __ballot(mode == M_WALK || mode == M_FLUSH);
+            if (__popcll(m_need) >= 8 || m_busy == 0) {
+                if (mode == M_NEED) {
+                    const int c = __popcll(m_need);
+                    const int leader = __ffsll((long long)m_need) - 1;
+                    unsigned long long base = 0;
+                    if (lane == leader) base = atomicAdd(p.next_doc, (unsigned long long)c);
+                    base = __shfl(base, leader, 64);
+                    const int64_t idx = (int64_t)base + __popcll(m_need & lanemask_lt());
+                    if (idx >= p.b.ndocs) mode = M_EXIT;
+                    else {
+                        doc = p.perm[idx];
+                        const int64_t b = p.b.doc_off[doc];
+                        const int64_t slot = sp_slot(b, doc, p.slot_mul);
+                        const int L = p.lens[doc];
+                        ids = p.ids_tmp + slot;
+                        if (L <= 0) { p.counts[doc] = 0; p.narcs[doc] = 0; }
+                        else { cls_at.init(p.stream, slot); uc.init(L, p.trie_depth, W, (uint32_t *)p.best + slot); mode = M_WALK; }
+                    }
+                }
+                if (__ballot(mode != M_EXIT) == 0) break;
+            }
+        }
+        cls_at.refill(mode == M_WALK);
+        // ---- forward pass: UNROLL trie transitions
+        bool stall = false;
+        if (mode == M_WALK) {
+            int st = UC_MORE;
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) { if (st == UC_MORE) st = uc.wstep(); }
+            if (st == UC_DONE) mode = M_FLUSH;
+            stall = st == UC_STALL;
+        }
+        // ---- emission phase: the tokens in front of every lane's latest cut
+        if (__ballot(mode == M_FLUSH || stall) != 0 || ((unsigned)trip & period_mask) == period_mask) {
+            if (mode == M_WALK || mode == M_FLUSH) {
+                if (uc.pending()) {
+                    auto put = [&](int k, uint32_t v) { if (k < p.max_ids) ids[k] = (int32_t)v; };
+                    uc.emit(put);
+                } else if (stall) uc.spill();
+            }
+            if (mode == M_FLUSH) {
+                p.counts[doc] = uc.nout < p.max_ids ? uc.nout : p.max_ids;
+                p.narcs[doc] = 0;
+                mode = M_NEED;
+            }
+        }
+    }
+    if (mode != M_EXIT) atomicOr(p.status, 2);      // trip limit hit: never expected
+}
+
 // BPE, documents whose arcs exceed the per-document reserve (narcs == -1 on the fallback list; a long run of one character whose
 // run-length tokens are all in the vocabulary): one wave per document, every step wave-cooperative, arcs in a block claimed from the
 // batch's pool at its exact size (bf_bpe_seg_body.h; the same source runs in the test simulator against the oracle).  A pool that
@@ -1421,6 +1505,23 @@ void launch_seg_sp(const SpSegParams &p_in, hipStream_t s)
             const bool one_kernel = false; const int unroll = 3;
             auto kern = (const void *)k_seg_unigram_lane<3, true, 8>;
 #endif
+            if (p.uni_cut) {
+                // the cut form (ids only): records in LDS, tokens out at the cuts, no backward kernel
+                int W = 32; while (W < p.trie_depth + UC_SPILL) W <<= 1;
+                const size_t lds_c = (size_t)ring * 64 * sizeof(double) + (size_t)W * 64 * sizeof(uint32_t);
+                int pc = 0;
+                if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&pc, (const void *)k_uni_cut<3>, 64, lds_c) != hipSuccess || pc <= 0) pc = 8;
+                (void)hipGetLastError();
+                if (p.tune2 > 0 && p.tune2 < pc) pc = p.tune2;
+                unsigned blocks = (unsigned)device_cus() * (unsigned)pc;
+                if ((int64_t)blocks > (int64_t)b64) blocks = b64;
+                unsigned period_mask = 7u;
+                if (p.tune > 0) { period_mask = 1u; while (period_mask + 1u < (unsigned)p.tune) period_mask = period_mask * 2u + 1u; if (p.tune == 1) period_mask = 0u; }
+                if (p.ev_dom0) (void)hipEventRecord((hipEvent_t)p.ev_dom0, s);
+                hipLaunchKernelGGL(k_uni_cut<3>, dim3(blocks), dim3(64), lds_c, s, p, ring, W, period_mask);
+                if (p.ev_dom1) (void)hipEventRecord((hipEvent_t)p.ev_dom1, s);
+                return;
+            }
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 64, lds) != hipSuccess || per_cu <= 0) per_cu = 8;
             (void)hipGetLastError();
             if (p.tune2 > 0 && p.tune2 < per_cu) per_cu = p.tune2;
@@ -2170,8 +2271,12 @@ __global__ __launch_bounds__(256) void k_compact_text(CompactParams p)
 // place in the output are read once, one document per lane (three coalesced loads instead of three dependent loads per document),
 // then handed round with readlane; the copies of two documents are in flight together.  Measured on the 10 M x 512 B workload
 // (profiles/r03_*): 3.56 ms with the wave-per-document form, whose waves spend most of their time waiting for those three loads.
+// KEYS (the Unigram cut form): the staged words are key + 1 of the tokens' dictionary entries, 0 for the unknown arc; the id comes from the
+// id column of I2Info here, where 64 independent look-ups per instruction cost next to nothing (tokdll:1512-1516: UnkId and IdOffset as there)
+template <bool KEYS>
 __global__ __launch_bounds__(256) void k_compact_ids(CompactParams p)
 {
+    auto tr = [&](int32_t v) -> int32_t { if constexpr (KEYS) { const int32_t id = v ? p.key_ids[v - 1] : -1; return (id != -1 ? id : p.key_unk) + p.key_id_offset; } else return v; };
     const int lane = lane_id();
     const int64_t wave0 = (int64_t)blockIdx.x * 4 + wave_in_block();
     const int64_t nwaves = (int64_t)gridDim.x * 4;
@@ -2198,12 +2303,12 @@ __global__ __launch_bounds__(256) void k_compact_ids(CompactParams p)
             if (lane + 64 < c0) a1 = tmp[s0 + lane + 64];
             if (lane < c1) b0 = tmp[s1 + lane];
             if (lane + 64 < c1) b1 = tmp[s1 + lane + 64];
-            if (lane < c0) out[o0 + lane] = a0;
-            if (lane + 64 < c0) out[o0 + lane + 64] = a1;
-            if (lane < c1) out[o1 + lane] = b0;
-            if (lane + 64 < c1) out[o1 + lane + 64] = b1;
-            for (int i = lane + 128; i < c0; i += 64) out[o0 + i] = tmp[s0 + i];
-            for (int i = lane + 128; i < c1; i += 64) out[o1 + i] = tmp[s1 + i];
+            if (lane < c0) out[o0 + lane] = tr(a0);
+            if (lane + 64 < c0) out[o0 + lane + 64] = tr(a1);
+            if (lane < c1) out[o1 + lane] = tr(b0);
+            if (lane + 64 < c1) out[o1 + lane + 64] = tr(b1);
+            for (int i = lane + 128; i < c0; i += 64) out[o0 + i] = tr(tmp[s0 + i]);
+            for (int i = lane + 128; i < c1; i += 64) out[o1 + i] = tr(tmp[s1 + i]);
         }
     }
     if (over) atomicOr(p.status, 1);
@@ -2215,7 +2320,8 @@ void launch_compact(const CompactParams &p, hipStream_t s)
         int64_t blocks = (p.b.ndocs + 255) / 256;
         if (blocks > device_cus() * 8) blocks = device_cus() * 8;
         if (blocks < 1) blocks = 1;
-        hipLaunchKernelGGL(k_compact_ids, dim3((unsigned)blocks), dim3(256), 0, s, p);
+        if (p.key_ids) hipLaunchKernelGGL(k_compact_ids<true>, dim3((unsigned)blocks), dim3(256), 0, s, p);
+        else hipLaunchKernelGGL(k_compact_ids<false>, dim3((unsigned)blocks), dim3(256), 0, s, p);
         return;
     }
     int64_t blocks = (p.b.ndocs + 3) / 4;

@@ -259,6 +259,146 @@ struct UniLane {
 };
 
 // ---------------------------------------------------------------------------------------------------
+// Unigram-LM, cut form (round 6; bf_kernels_sp.hip k_uni_cut drives it, tests/hosttest runs the same code on the host): the lane program
+// above WITHOUT the lattice in memory.  The forward pass is UniLane's (same walks, same deferred relaxation, same doubles in the same
+// order); what changes is where the End2BestArc records go.  A position p is a CUT when
+//   (a) its final record is a dictionary entry (not the unknown arc, not "no incoming arc"), and
+//   (b) no dictionary arc found from any start <= p ends behind p   (reach <= p: every walk from a start <= p is complete when p is final).
+// Then the backward pass of the reference (..._1best_t.h:237-265) is certain to land on p: a hop over p would need an arc that spans
+// p | p + 1 -- a dictionary arc contradicts (b), a merged unknown run (begin <= p < end) makes every position of the run an unknown record and
+// contradicts (a).  So the tokens of [previous cut + 1, p] are final as soon as p is: they are read off the record ring (LDS) by the
+// reference's own hops and leave the lane in forward order; the last position of a document always ends a chunk.  Nothing is proved about
+// the model -- the criterion is evaluated on the lattice of the document itself (for the shipped SentencePiece models every position in front
+// of a U+2581 qualifies, because no entry holds U+2581 behind its first symbol; text without blanks is cut wherever its arcs allow).
+// A hop that lands on a position without incoming arc makes the reference emit <UnkId, -1, end> and STOP (..._1best_t.h:250-262): everything
+// in front of it is dropped -- here the output restarts at index 0 with that token.
+// The ring holds the records of [ring_lo, i]: a record slot is written by the relaxation that sets its score (a position no arc reached is
+// "no incoming arc" by its score alone), so nothing is reserved ahead of the walk.  A lane whose pending region fills the ring with no cut to
+// emit (a word of more than ~24 symbols, a long unknown run) SPILLS its oldest final records to the document's record array in memory
+// (the array the lane program above writes every record to); the hops read them back from there.  Rare: 0.1 % of the documents of running text.
+// Output: one word per token, key + 1 of its entry (0: the unknown id) -- the id is looked up where the ids are copied to their place
+// (k_compact_ids), off this kernel's dependent-gather path.
+// ---------------------------------------------------------------------------------------------------
+enum { UC_DONE = 0, UC_MORE = 1, UC_STALL = 2 };
+constexpr int UC_SPILL = 8;                           // records per spill
+template <class ClsAt, class Ring>
+struct UniCut {
+    const SegTables &S; ClsAt &cls_at; Ring &ring; uint32_t *recs;
+    int L, depth, W, start, i, sum; uint32_t state; bool unknown, pend; double prev; uint32_t pend_score; int pend_key; int pend_i;
+    int unk_run;
+    int reach;                                         // last position a dictionary arc found so far ends at
+    int cut0, lastcut;                                 // first position not emitted yet; latest cut (cut0 - 1: nothing to emit)
+    int ring_lo;                                       // first position whose record is in the ring (cut0 <= older ones: in recs[])
+    int nout;                                          // tokens emitted so far (not limited by max_ids)
+
+    BF_HD UniCut(const SegTables &S_, ClsAt &c, Ring &r) : S(S_), cls_at(c), ring(r), recs(nullptr) {}
+    static BF_HD double neg_flt_max() { return -3.40282346638528859811704183484516925e+38; }
+
+    // Start a document of L >= 1 stream elements; recs_ has room for L records (touched by spills only)
+    BF_HD void init(int L_, int depth_, int W_, uint32_t *recs_)
+    {
+        L = L_; depth = depth_; W = W_; recs = recs_;
+        ring.fill(neg_flt_max());
+        start = 0; i = 0; state = S.initial; sum = 0; unknown = true; prev = 0; pend = false; pend_i = 0; pend_score = 0; pend_key = 0;
+        unk_run = 0; reach = -1; cut0 = 0; lastcut = -1; ring_lo = 0; nout = 0;
+        cls_at.seek(0);
+    }
+    BF_HD void relax()
+    {
+        const double cand = sg_bits_to_float(pend_score) + prev;
+        if (ring.score(pend_i) < cand) ring.set(pend_i, cand, uni_rec(pend_key, pend_i - start + 1));
+        pend = false;
+    }
+    BF_HD bool pending() const { return lastcut >= cut0; }
+    BF_HD bool stalled() const { return i - ring_lo >= W; }
+    BF_HD uint32_t rec_at(int e) const { return e >= ring_lo ? ring.rec(e) : recs[e]; }
+    // a stalled lane with nothing to emit: its oldest final records go to memory (the walk is at most depth - 1 positions ahead of `start`,
+    // so W >= depth + UC_SPILL leaves at least UC_SPILL final ones in the ring)
+    BF_HD void spill()
+    {
+        for (int k = 0; k < UC_SPILL; ++k) recs[ring_lo + k] = ring.rec(ring_lo + k);
+        ring_lo += UC_SPILL;
+    }
+
+    // One trie transition (UniLane::wstep); UC_STALL: the ring is full -- emit() or spill() first (nothing was done)
+    BF_HD int wstep()
+    {
+        if (stalled()) return UC_STALL;
+        const uint32_t c = cls_at(i);
+        const bool valid = c < SG_CLS_DELIM_ABSENT;
+        const uint64_t e = S.T[state + (valid ? c : 0u)];
+        if (pend) relax();
+        const bool hit = valid && (e & SG_CLS_MASK) == c;
+        bool ends = !hit;
+        if (hit) {
+            state = (uint32_t)((e >> SG_NEXT_SHIFT) & SG_NEXT_MASK);
+            sum += (int)(e >> SG_OW_SHIFT);
+            if (e & SG_FINAL) { pend_score = S.score[sum]; pend_key = sum; pend_i = i; pend = true; unknown = false; reach = reach > i ? reach : i; }
+            ++i;
+            ends = i >= L;
+        }
+        if (ends) {
+            if (pend) relax();
+            double fin = ring.score(start);
+            uint32_t r = ring.rec(start);
+            int run = 0;
+            if (unknown) {                                              // AddUnknownArc (..._1best_t.h:145-171)
+                const float unk_score = -100000.0f;
+                const double cand = unk_score + prev;
+                if (fin < cand) { run = unk_run + 1; r = uni_rec(-1, run); fin = cand; }
+            }
+            const bool none = !(neg_flt_max() < fin);                   // no incoming arc at all (..._1best_t.h:61-77); its record slot was never written
+            if (none) r = UNI_REC_NONE;
+            unk_run = run;
+            if (run != 0 || none) ring.setrec(start, r);
+            const bool piece = !none && (r & 0xFFFFFu) != 0u;
+            if ((piece && reach <= start) || start == L - 1) lastcut = start;
+            ++start;
+            if (!(start < L)) return UC_DONE;
+            prev = fin;
+            ring.setscore(start + depth - 1, neg_flt_max());            // the position that enters the reach of this start
+            i = start; state = S.initial; sum = 0; unknown = true;
+            cls_at.seek(start);
+        }
+        return UC_MORE;
+    }
+
+    // length of the token whose last position is e, r = its record (a 4095 in the length field: "4096 or more", UniLane::bstep)
+    BF_HD int tok_len(int e, uint32_t r) const
+    {
+        if ((r >> 20) != UNI_LEN_MAX) return (int)(r >> 20) + 1;
+        int len = 0;
+        while ((r >> 20) == UNI_LEN_MAX && e - (int)UNI_LEN_MAX >= 0) { len += (int)UNI_LEN_MAX; e -= (int)UNI_LEN_MAX; r = rec_at(e); }
+        return len + (int)(r >> 20) + 1;
+    }
+
+    // The tokens of [cut0, lastcut], first to last: put(index in the document's id sequence, key + 1 or 0).  Two passes over the records: the
+    // hops of the backward pass count the tokens, the same hops place them.
+    template <class Put>
+    BF_HD void emit(Put &put)
+    {
+        if (!pending()) return;
+        int n = 0; bool restart = false;
+        for (int e = lastcut; e >= cut0;) {
+            const uint32_t r = rec_at(e);
+            ++n;
+            if (r == UNI_REC_NONE) { restart = true; break; }          // <UnkId, -1, end>, and the reference stops
+            e -= tok_len(e, r);
+        }
+        const int base = restart ? 0 : nout;
+        int k = n - 1;
+        for (int e = lastcut; k >= 0; --k) {
+            const uint32_t r = rec_at(e);
+            put(base + k, r == UNI_REC_NONE ? 0u : (r & 0xFFFFFu));
+            if (r != UNI_REC_NONE) e -= tok_len(e, r);
+        }
+        nout = base + n;
+        cut0 = lastcut + 1;
+        if (ring_lo < cut0) ring_lo = cut0;
+    }
+};
+
+// ---------------------------------------------------------------------------------------------------
 // BPE (both flavours).  arcs[] has room for arc_cap entries; tos/idsv/inter are the three work arrays of
 // …_bpe_t.h:258-296.  Returns -1 if arc_cap is exceeded (the host turns that into a loud error).
 // ---------------------------------------------------------------------------------------------------

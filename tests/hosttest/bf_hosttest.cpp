@@ -25,6 +25,9 @@ using namespace bfa;
 #include "hosttest.h"
 
 static long g_big_pool = 64l << 20;   // bft_set_big_pool: bytes of the pool behind seg_bpe_doc_big (the device's is 64 MiB per batch)
+static int g_uni_cut_w = 0;   // bft_set_uni_cut(W, period): Unigram through the cut form (bf_seg.h UniCut) with a record ring of W positions; emission every `period` steps
+static int g_uni_cut_period = 1;
+static unsigned long long g_uni_cut_stats[8 + 260];   // [0] documents, [1] given up (hard), [2] chunks, [3] tokens, [4] restarts; [8 + k] documents whose widest pending span (start + depth - cut0, emitted as soon as possible) was k
 static int g_uni_seq = 0;     // bft_set_uni_seq(1): Unigram through the plain sequential restatement (seg_unigram_doc) instead of UniLane
 static int g_general = 0;     // bft_set_general(1): the general lexer machine even for two-level models (A/B in tests)
 static int g_no_ff = 0;       // bft_set_no_ff(1): run the lexer emulation without the loop-state fast-forward (A/B in tests)
@@ -57,6 +60,8 @@ int bft_tolower(int cp) { return bfa::bf_tolower(cp); }
 int bft_lexer_void(void *hv) { return ((Handle *)hv)->m.lexer_void ? 1 : 0; }
 void bft_free(void *hv) { delete (Handle *)hv; }
 void bft_set_no_ff(int v) { g_no_ff = v; }
+void bft_set_uni_cut(int w, int period) { g_uni_cut_w = w; g_uni_cut_period = period > 0 ? period : 1; }
+void bft_uni_cut_stats(unsigned long long *out, int reset) { memcpy(out, g_uni_cut_stats, sizeof(g_uni_cut_stats)); if (reset) memset(g_uni_cut_stats, 0, sizeof(g_uni_cut_stats)); }
 void bft_set_general(int v) { g_general = v; }
 int bft_two_level(void *hv) { return ((Handle *)hv)->m.two_level ? 1 : 0; }
 int bft_fn_no_ra(void *hv) { return ((Handle *)hv)->m.fn_no_ra ? 1 : 0; }
@@ -284,6 +289,55 @@ static int emu_sp(const Model &m, const char *s, int n, int32_t *ids, int32_t *s
         std::vector<SegBest> best((size_t)L + 1);
         return seg_unigram_doc(S, cls_at, L, best.data(), out, max_ids, unk);
     }
+    if (m.kind == KIND_UNIGRAM && g_uni_cut_w > 0 && !spans && L > 0) {
+        // the cut form (bf_seg.h UniCut): records in a ring of W positions, tokens leave at the cuts; a document that outgrows the ring falls
+        // through to the lane program below, like on the device
+        struct CutRing {
+            std::vector<double> v; std::vector<uint32_t> r; int smask, rmask;
+            double score(int pos) const { return v[(size_t)(pos & smask)]; }
+            uint32_t rec(int pos) const { return r[(size_t)(pos & rmask)]; }
+            void set(int pos, double x, uint32_t rr) { v[(size_t)(pos & smask)] = x; r[(size_t)(pos & rmask)] = rr; }
+            void setrec(int pos, uint32_t rr) { r[(size_t)(pos & rmask)] = rr; }
+            void setscore(int pos, double x) { v[(size_t)(pos & smask)] = x; }
+            void fill(double x) { for (auto &e : v) e = x; for (auto &e : r) e = 0x12345678u; }      // (record slots are not initialised on the device either)
+        };
+        struct HostSeek { const uint16_t *cp; uint32_t operator()(int i) const { return cp[i]; } void seek(int) const {} };
+        int ring_n = 1; while (ring_n < m.trie_max_depth) ring_n <<= 1;
+        CutRing ring{std::vector<double>((size_t)ring_n), std::vector<uint32_t>((size_t)g_uni_cut_w), ring_n - 1, g_uni_cut_w - 1};
+        HostSeek hs{cp};
+        UniCut<HostSeek, CutRing> uc(S, hs, ring);
+        std::vector<uint32_t> spill_all((size_t)L + 64, 0xDEADBEEFu);
+        uc.init(L, m.trie_max_depth, g_uni_cut_w, spill_all.data() + 32);
+        std::vector<uint32_t> toks((size_t)L + 1, 0xDEADBEEFu);
+        auto put = [&](int k, uint32_t v) { toks[(size_t)k] = v; };
+        int widest = 0; unsigned long long chunks = 0, restarts = 0, spills = 0;
+        for (unsigned long long step = 1;; ++step) {
+            const int span = uc.i - uc.cut0 + 1;
+            if (g_uni_cut_period == 1 && span > widest) widest = span;
+            const int st = uc.wstep();
+            if (st == UC_STALL || st == UC_DONE || step % (unsigned long long)g_uni_cut_period == 0) {
+                if (uc.pending()) { const int before = uc.nout; uc.emit(put); ++chunks; if (uc.nout <= before) ++restarts; }
+                else if (st == UC_STALL) { uc.spill(); ++spills; }
+            }
+            if (st == UC_DONE) break;
+        }
+        if (spill_all[31] != 0xDEADBEEFu || spill_all[(size_t)L + 32] != 0xDEADBEEFu) return -3;     // a spill left the document's own range
+        ++g_uni_cut_stats[0];
+        if (spills) ++g_uni_cut_stats[1];
+        g_uni_cut_stats[5] += spills;
+        {
+            g_uni_cut_stats[2] += chunks; g_uni_cut_stats[3] += (unsigned long long)uc.nout; g_uni_cut_stats[4] += restarts;
+            if (g_uni_cut_period == 1) ++g_uni_cut_stats[8 + (widest < 259 ? widest : 259)];
+            const int nout = uc.nout < max_ids ? uc.nout : max_ids;
+            for (int k = 0; k < nout; ++k) {
+                const uint32_t v = toks[(size_t)k];
+                if (v == 0xDEADBEEFu) return -3;                           // a place no chunk wrote
+                { const int32_t id = v ? ((const SegInfo *)m.seg_info.data())[v - 1].id : -1; out.put(k, (id != -1 ? id : unk) + S.id_offset); }      // what k_compact_ids<keys> does
+            }
+            out.finish(nout);
+            return nout;
+        }
+    }
     if (m.kind == KIND_UNIGRAM) {
         // the default GPU form (bf_seg.h UniLane: score ring + deferred relaxation), driven sequentially
         if (L <= 0) return 0;
@@ -364,6 +418,105 @@ int bft_emu_bpe_arcs(void *hv, const char *s, int n, int32_t *ids, int max_ids, 
     g_arc_dump = nullptr;
     if ((int)dump.size() <= out_cap) { memcpy(out, dump.data(), dump.size() * sizeof(int32_t)); *out_ints = (int)dump.size(); }
     return r;
+}
+
+// Structural fuzz of the cut form (bf_seg.h UniCut) against the sequential restatement (seg_unigram_doc, itself pinned to the oracle on the real
+// models): small random dictionaries over 2..4 symbols with entries of 1..7 symbols, scores with ties and -- rarely -- a huge POSITIVE value, so
+// that the paths no shipped model reaches are walked too: positions without incoming arc that the backward pass LANDS on (the reference emits
+// <UnkId, -1, end> and stops: the output restarts), dictionaries without single-symbol entries, spills out of rings as small as depth + 8,
+// emission at random times.  Returns the number of (dictionary, text) pairs whose ids differ; *restarts / *spills: how often those paths ran.
+int bft_uni_cut_fuzz(unsigned seed, int ndicts, int ntexts, unsigned long long *restarts, unsigned long long *spills)
+{
+    auto rnd = [&seed]() { seed = seed * 1664525u + 1013904223u; return seed >> 8; };
+    int bad = 0; unsigned long long nrestart = 0, nspill = 0;
+    for (int dct = 0; dct < ndicts; ++dct) {
+        const int ncls = 2 + (int)(rnd() % 3u), npieces = 1 + (int)(rnd() % 12u), maxlen = 1 + (int)(rnd() % 7u);
+        // trie: node 0 = root; child[node * ncls + c]
+        std::vector<int> child((size_t)ncls, -1); std::vector<char> fin(1, 0);
+        for (int k = 0; k < npieces; ++k) {
+            int node = 0; const int len = 1 + (int)(rnd() % (unsigned)maxlen);
+            for (int j = 0; j < len; ++j) {
+                const int c = (int)(rnd() % (unsigned)ncls);
+                if (child[(size_t)node * ncls + c] < 0) { child[(size_t)node * ncls + c] = (int)fin.size(); fin.push_back(0); child.resize(fin.size() * (size_t)ncls, -1); }
+                node = child[(size_t)node * ncls + c];
+            }
+            fin[(size_t)node] = 1;
+        }
+        const int nn = (int)fin.size();
+        // keys in preorder (growing along every path), the output weight of a transition = key difference to the nearest final ancestor
+        std::vector<int> key((size_t)nn, -1), base((size_t)nn, 0); int nkeys = 0, depth = 0;
+        std::vector<uint64_t> T((size_t)nn * ncls + 8, (uint64_t)0xFFFFFull);
+        std::vector<int> order; std::vector<int> dep((size_t)nn, 0); { std::vector<int> s2(1, 0); while (!s2.empty()) { const int n = s2.back(); s2.pop_back(); order.push_back(n); for (int c = ncls - 1; c >= 0; --c) { const int ch = child[(size_t)n * ncls + c]; if (ch >= 0) { dep[(size_t)ch] = dep[(size_t)n] + 1; if (dep[(size_t)ch] > depth) depth = dep[(size_t)ch]; s2.push_back(ch); } } } }
+        for (int n : order) if (fin[(size_t)n]) key[(size_t)n] = nkeys++;
+        std::vector<int> accv((size_t)nn, 0);
+        for (int n : order) {
+            for (int c = 0; c < ncls; ++c) {
+                const int ch = child[(size_t)n * ncls + c];
+                if (ch < 0) continue;
+                const int ow = fin[(size_t)ch] ? key[(size_t)ch] - accv[(size_t)n] : 0;
+                accv[(size_t)ch] = accv[(size_t)n] + ow;
+                T[(size_t)n * ncls + c] = (uint64_t)c | (fin[(size_t)ch] ? SG_FINAL : 0ull) | ((uint64_t)((size_t)ch * ncls) << SG_NEXT_SHIFT) | ((uint64_t)ow << SG_OW_SHIFT);
+            }
+        }
+        if (depth < 1) depth = 1;
+        std::vector<SegInfo> info((size_t)nkeys + 1); std::vector<uint32_t> score((size_t)nkeys + 1);
+        for (int k = 0; k < nkeys; ++k) {
+            float sc = -(float)(1 + rnd() % 6u) * 0.5f;                   // few distinct values: ties
+            const unsigned r = rnd() % 40u;
+            if (r == 0) sc = 3.0e38f; else if (r == 1) sc = -3.0e38f; else if (r == 2) sc = 0.0f;
+            union { float f; uint32_t u; } x; x.f = sc;
+            info[(size_t)k].id = (int32_t)(rnd() % 1000u); info[(size_t)k].score_bits = x.u; score[(size_t)k] = x.u;
+        }
+        SegTables S; S.T = T.data(); S.info = info.data(); S.initial = 0; S.cls_delim = 0xFFFDu; S.kind = SG_KIND_UNIGRAM; S.id_offset = (int)(rnd() % 3u) - 1; S.score = score.data();
+        for (int t = 0; t < ntexts; ++t) {
+            const int L = 1 + (int)(rnd() % 90u);
+            std::vector<uint16_t> cls((size_t)L + 1);
+            for (int j = 0; j < L; ++j) { const unsigned r = rnd() % 16u; cls[(size_t)j] = r == 0 ? (uint16_t)SG_CLS_NONE : (uint16_t)(rnd() % (unsigned)ncls); }
+            const uint16_t *cp = cls.data();
+            auto cls_at = [cp](int i) -> uint32_t { return cp[i]; };
+            const int max_ids = 1 + (int)(rnd() % 100u), unk = (int)(rnd() % 1000u);
+            std::vector<int32_t> want((size_t)max_ids + 1, -7), got((size_t)max_ids + 1, -7);
+            std::vector<SegBest> best((size_t)L + 1);
+            IdOutDirect ow{want.data(), nullptr};
+            const int nw = seg_unigram_doc(S, cls_at, L, best.data(), ow, max_ids, unk);
+            struct CutRing {
+                std::vector<double> v; std::vector<uint32_t> r; int smask, rmask;
+                double score(int pos) const { return v[(size_t)(pos & smask)]; }
+                uint32_t rec(int pos) const { return r[(size_t)(pos & rmask)]; }
+                void set(int pos, double x, uint32_t rr) { v[(size_t)(pos & smask)] = x; r[(size_t)(pos & rmask)] = rr; }
+                void setrec(int pos, uint32_t rr) { r[(size_t)(pos & rmask)] = rr; }
+                void setscore(int pos, double x) { v[(size_t)(pos & smask)] = x; }
+                void fill(double x) { for (auto &e : v) e = x; for (auto &e : r) e = 0x12345678u; }
+            };
+            struct HostSeek { const uint16_t *cp; uint32_t operator()(int i) const { return cp[i]; } void seek(int) const {} };
+            int ring_n = 1; while (ring_n < depth) ring_n <<= 1;
+            int W = 16; while (W < depth + UC_SPILL) W <<= 1;
+            if (rnd() % 4u == 0) W <<= 1;
+            CutRing ring{std::vector<double>((size_t)ring_n), std::vector<uint32_t>((size_t)W), ring_n - 1, W - 1};
+            HostSeek hs{cp};
+            UniCut<HostSeek, CutRing> uc(S, hs, ring);
+            std::vector<uint32_t> sp((size_t)L + 2, 0xDEADBEEFu);
+            uc.init(L, depth, W, sp.data());
+            std::vector<uint32_t> toks((size_t)L + 1, 0xDEADBEEFu);
+            auto put = [&](int k, uint32_t v) { toks[(size_t)k] = v; };
+            const unsigned period = 1 + rnd() % 40u;
+            for (unsigned step = 1;; ++step) {
+                const int stt = uc.wstep();
+                if (stt == UC_STALL || stt == UC_DONE || step % period == 0) {
+                    if (uc.pending()) { const int before = uc.nout; uc.emit(put); if (uc.nout <= before) ++nrestart; }
+                    else if (stt == UC_STALL) { uc.spill(); ++nspill; }
+                }
+                if (stt == UC_DONE) break;
+            }
+            const int ng = uc.nout < max_ids ? uc.nout : max_ids;
+            bool ok = ng == nw;
+            for (int k = 0; ok && k < ng; ++k) { const uint32_t v = toks[(size_t)k]; { const int32_t id = (v && v != 0xDEADBEEFu) ? info[(size_t)v - 1].id : -1; got[(size_t)k] = (id != -1 ? id : unk) + S.id_offset; } ok = v != 0xDEADBEEFu && got[(size_t)k] == want[(size_t)k]; }
+            if (!ok) ++bad;
+        }
+    }
+    if (restarts) *restarts = nrestart;
+    if (spills) *spills = nspill;
+    return bad;
 }
 
 int bft_emu_text_to_ids(void *hv, const char *s, int n, int32_t *ids, int max_ids, int unk)

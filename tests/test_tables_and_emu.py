@@ -105,6 +105,126 @@ def test_unigram_long_unknown_runs(ht, model):
     ht.bft_free(h)
 
 
+UNIGRAM_MODELS = ["xlnet.bin", "xlnet_nonorm.bin", "laser50k.bin", "laser100k.bin", "xlm_roberta_base.bin", "laser500k.bin", "uri100k.bin", "uri100kint.bin"]
+
+
+def _cut_api(ht):
+    ht.bft_set_uni_cut.argtypes = [ctypes.c_int, ctypes.c_int]
+    ht.bft_uni_cut_stats.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    ht.bft_uni_cut_fuzz.restype = ctypes.c_int
+    ht.bft_uni_cut_fuzz.argtypes = [ctypes.c_uint, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+    return (ctypes.c_ulonglong * 268)()
+
+
+@pytest.mark.parametrize("model", UNIGRAM_MODELS)
+def test_unigram_cut_form_on_host(ht, model):
+    """round 6: the cut form of the Unigram lane program (bf_seg.h UniCut -- the code k_uni_cut runs per lane: records in a ring, tokens read off
+    it at the positions the reference's backward pass must land on, spills when a word outgrows the ring) against the oracle: adversarial +
+    fuzz documents, the reference's own English lines, rings of 32 and 64 positions, emission after every step / every 7 / every 24 / only
+    when the ring is full"""
+    if not bfutil.have_model(model):
+        pytest.skip("%s not present" % model)
+    st = _cut_api(ht)
+    ora = bfutil.oracle()
+    h = ht.bft_load(bfutil.model_path(model).encode())
+    assert ht.bft_error(h) == b""
+    if ht.bft_emu_text_to_ids(h, b"a", 1, (ctypes.c_int32 * 4)(), 4, 0) == -1:
+        pytest.skip("not a Unigram model")
+    ho = ora.load(bfutil.model_path(model))
+    text, off = bfutil.gen_workload("config1", 1500)
+    raw = text.tobytes()
+    docs = list(bfutil.ADVERSARIAL) + bfutil.fuzz_docs(1200, seed=61) + [raw[off[d]:off[d + 1]] for d in range(len(off) - 1)]
+    docs += [("x" * n + " " + "\u0e01\u0e32\u0e23" * n).encode("utf-8") for n in (20, 40, 90)] + [("\U000F0000" * 70 + " a").encode("utf-8")]
+    want = []
+    for k, b in enumerate(docs):
+        want.append(ora.text_to_ids(ho, b, (1024, 3, 64, 1)[k % 4], (3, 0, 257)[k % 3]))
+    try:
+        seen = [0, 0, 0]
+        for W, period in ((32, 1), (32, 7), (32, 24), (64, 1 << 30)):
+            ht.bft_set_uni_cut(W, period)
+            ht.bft_uni_cut_stats(st, 1)
+            for k, b in enumerate(docs):
+                mx, unk = (1024, 3, 64, 1)[k % 4], (3, 0, 257)[k % 3]
+                arr = (ctypes.c_int32 * max(mx, 1))()
+                c = ht.bft_emu_text_to_ids(h, b, len(b), arr, mx, unk)
+                gc, gbuf = want[k]
+                assert c == gc and list(arr)[:c] == gbuf[:gc], (model, W, period, b[:60])
+            ht.bft_uni_cut_stats(st, 1)
+            seen = [seen[0] + st[0], seen[1] + st[1], seen[2] + st[2]]
+        assert seen[0] > 0 and seen[2] > seen[0]          # the cut form did run: documents, chunks
+        if model in ("xlm_roberta_base.bin", "laser500k.bin", "xlnet.bin"):
+            assert seen[1] > 0                            # ... and some document spilled
+    finally:
+        ht.bft_set_uni_cut(0, 1)
+    ora.free(ho)
+    ht.bft_free(h)
+
+
+@pytest.mark.parametrize("model,workload", [("xlm_roberta_base.bin", "config4"), ("laser500k.bin", "config5")])
+def test_unigram_cut_form_on_multilingual_corpus(ht, model, workload):
+    """the cut form on the corpora of configs 4 / 5 (all script buckets, charmap keys), ring of 32 positions, emission every 24 steps"""
+    if not bfutil.have_model(model):
+        pytest.skip("%s not present" % model)
+    _cut_api(ht)
+    wl = bfutil.WORKLOADS[workload]
+    text, off = bfutil.gen_workload(workload, 800)
+    raw = text.tobytes()
+    ora = bfutil.oracle()
+    h = ht.bft_load(bfutil.model_path(model).encode())
+    ho = ora.load(bfutil.model_path(model))
+    mx, unk = wl["max_ids"], wl["unk"]
+    arr = (ctypes.c_int32 * mx)()
+    try:
+        ht.bft_set_uni_cut(32, 24)
+        for d in range(len(off) - 1):
+            b = raw[off[d]:off[d + 1]]
+            c = ht.bft_emu_text_to_ids(h, b, len(b), arr, mx, unk)
+            gc, gbuf = ora.text_to_ids(ho, b, mx, unk)
+            assert c == gc and list(arr)[:c] == gbuf[:gc], (model, d, b[:80])
+    finally:
+        ht.bft_set_uni_cut(0, 1)
+    ora.free(ho)
+    ht.bft_free(h)
+
+
+def test_unigram_cut_form_long_unknown_runs(ht):
+    """unknown runs beyond the ring and beyond the 12-bit length field in the cut form: the run is spilled to the record array eight positions
+    at a time and the hop over it adds up 4095-position pieces (bf_seg.h UniCut::tok_len)"""
+    model = "xlnet.bin"
+    if not bfutil.have_model(model):
+        pytest.skip("%s not present" % model)
+    _cut_api(ht)
+    ora = bfutil.oracle()
+    h = ht.bft_load(bfutil.model_path(model).encode())
+    ho = ora.load(bfutil.model_path(model))
+    arr = (ctypes.c_int32 * 4096)()
+    try:
+        ht.bft_set_uni_cut(32, 24)
+        for n in (30, 100, 4094, 4095, 4096, 4097, 8191, 12290):
+            b = ("hello " + "\U000F0000" * n + " world " + "\U000F0000" * 3 + "x").encode("utf-8")
+            c = ht.bft_emu_text_to_ids(h, b, len(b), arr, 4096, 7)
+            gc, gbuf = ora.text_to_ids(ho, b, 4096, 7)
+            assert c == gc and list(arr)[:c] == gbuf[:gc], n
+    finally:
+        ht.bft_set_uni_cut(0, 1)
+    ora.free(ho)
+    ht.bft_free(h)
+
+
+def test_unigram_cut_form_structural_fuzz(ht):
+    """random small dictionaries (no single-symbol entries, ties, huge positive scores) x random texts: the cut form against the sequential
+    restatement of the reference's algorithm, including what no shipped model reaches -- a backward pass that LANDS on a position without
+    incoming arc (the reference emits <UnkId, -1, end> and stops, ..._1best_t.h:250-262: the output restarts) -- and spills from the smallest rings"""
+    _cut_api(ht)
+    restarts, spills = ctypes.c_ulonglong(), ctypes.c_ulonglong()
+    total_r = total_s = 0
+    for seed in (1, 2, 3, 4):
+        assert ht.bft_uni_cut_fuzz(seed, 1500, 40, ctypes.byref(restarts), ctypes.byref(spills)) == 0
+        total_r += restarts.value
+        total_s += spills.value
+    assert total_r > 1000 and total_s > 10000
+
+
 @pytest.mark.parametrize("model", ["bert_base_tok.bin", "bert_base_cased_tok.bin", "bert_chinese.bin", "wbd.bin"])
 def test_lexer_shortcuts_are_equivalent(ht, model):
     """the load-time shortcuts of the lexer lane program (bf_lex.h: loop-state fast-forward, two-level form, no right-anchor step
