@@ -513,7 +513,7 @@ int run_device(Handle *h, const char *d_text, const int64_t *d_doc_off, int64_t 
         (void)hipEventRecord(h->ev[EV_PREP], s);
         SpSegParams sg;
         sg.S.T = h->t_dict.as<uint64_t>(); sg.S.info = h->t_seginfo.as<SegInfo>(); sg.S.initial = m.dict.initial_base;
-        sg.S.cls_delim = m.sp_delim_code; sg.S.kind = m.kind; sg.S.id_offset = m.id_offset; sg.S.score = m.kind == KIND_UNIGRAM ? h->t_segscore.as<uint32_t>() : nullptr;
+        sg.S.cls_delim = m.sp_delim_code; sg.S.kind = m.kind; sg.S.id_offset = m.id_offset; sg.S.score = m.kind == KIND_UNIGRAM ? h->t_segscore.as<uint32_t>() : nullptr; sg.S.leaf_lo = m.dict.leaf_lo; sg.S.leaf_n = m.dict.leaf_n;
         sg.b = b; sg.stream = h->w_cls.as<uint16_t>(); sg.lens = h->w_nchars.as<int32_t>(); sg.slot_mul = mul;
         sg.ids_tmp = h->w_tmp.as<int32_t>(); sg.counts = h->w_counts.as<int32_t>(); sg.span_tmp = want_off ? h->w_span.as<int32_t>() : nullptr; sg.max_ids = max_ids; sg.unk = unk; sg.status = status;
         sg.best = nullptr; sg.arcs = nullptr; sg.tos = nullptr; sg.idsv = nullptr; sg.inter = nullptr; sg.bm_words = 0; sg.fb_list = nullptr; sg.fb_count = nullptr;
@@ -564,8 +564,12 @@ int run_device(Handle *h, const char *d_text, const int64_t *d_doc_off, int64_t 
     (void)hipEventRecord(h->ev[EV_SCAN], s);
     CompactParams cp{b, h->w_tmp.as<int32_t>(), h->w_counts.as<int32_t>(), d_id_off, d_ids_out, ids_cap, status, slot_mul, first,
                      want_off ? h->w_span.as<int32_t>() : nullptr, want_off && !use_wave(h, want_off, words) ? h->w_srcoff.as<int32_t>() : nullptr, want_off ? d_starts : nullptr, want_off ? d_ends : nullptr};
-    if (uni_cut_keys) { cp.key_ids = h->t_segid.as<int32_t>(); cp.key_unk = unk; cp.key_id_offset = m.id_offset; }
-    if (ndocs > 0) launch_compact(cp, s);
+    if (uni_cut_keys) {
+        // the cut form left tokens, not ids: their ids go straight to the caller's array (k_uni_ids is the compaction of this path)
+        UniIdsParams up{b, h->t_dict.as<uint64_t>(), m.dict.initial_base, h->t_segid.as<int32_t>(), h->w_cls.as<uint16_t>(), h->w_nchars.as<int32_t>(), slot_mul,
+                        h->w_tmp.as<int32_t>(), h->w_counts.as<int32_t>(), d_id_off, d_ids_out, ids_cap, unk, m.id_offset, status};
+        if (ndocs > 0) launch_uni_ids(up, s);
+    } else if (ndocs > 0) launch_compact(cp, s);
     (void)hipEventRecord(h->ev[EV_COMPACT], s);
     h->ev_valid = true;
     if (!hip_ok(hipGetLastError(), "kernel launch")) return BF_E_DEVICE;
@@ -1991,7 +1995,7 @@ const char *BfStepKernels(void *p)
         if (use_wave(h, false, 0)) return "prep: - | tokenise: k_wp_wave | scan: k_scan_block_sums, k_scan_top, k_scan_apply | compact: k_compact_ids (offsets: k_compact_text)";
         return "prep: k_prep_wp_flat, k_prep_wp_docs | tokenise: k_lex_wp_plain / k_lex_wp_flat | scan: k_scan_block_sums, k_scan_top, k_scan_apply | compact: k_compact_ids (offsets: k_compact)";
     case KIND_UNIGRAM:
-        if (h->last_uni_cut) return "prep: k_prep_sp8 | tokenise: k_sp_hist, k_sp_hist_scan, k_sp_scatter, k_uni_cut | scan: k_scan_block_sums, k_scan_top, k_scan_apply | compact: k_compact_ids<keys>";
+        if (h->last_uni_cut) return "prep: k_prep_sp8 | tokenise: k_sp_hist, k_sp_hist_scan, k_sp_scatter, k_uni_cut | scan: k_scan_block_sums, k_scan_top, k_scan_apply | compact: k_uni_ids";
         return "prep: k_prep_sp8 | tokenise: k_sp_hist, k_sp_hist_scan, k_sp_scatter, k_seg_unigram_lane, k_uni_back | scan: k_scan_block_sums, k_scan_top, k_scan_apply | compact: k_compact_ids";
     case KIND_I2W: return "";
     default:

@@ -75,7 +75,7 @@ struct SpSegParams {
     int32_t *narcs;             // [ndocs] BPE arc count per document (-1 = capacity exceeded); Unigram: first id index within the slot
     int trie_depth;             // longest dictionary entry (bounds every arc length)
     int lane_ok;                // Unigram: the model fits the lane program (bf_seg.h UniLane: entries <= 32 symbols, ids < 2^20 - 2)
-    int uni_cut = 0;            // Unigram: the cut form (bf_seg.h UniCut; ids only): tokens leave as key + 1, left-aligned in the slot -> CompactParams::key_ids
+    int uni_cut = 0;            // Unigram: the cut form (bf_seg.h UniCut; ids only): tokens leave as words (bf_seg.h: key / symbols to walk / unknown), left-aligned in the slot -> k_uni_ids
     int64_t bm_words;           // BPE apply: words per bitmap (the two bitmaps live in the `tos` buffer)
     int32_t *fb_list; unsigned int *fb_count;   // BPE: documents k_bpe_fused hands to the full path (set by launch_seg_sp)
     uint8_t *big_pool; unsigned long long big_cap; unsigned long long *big_used, *big_need;   // BPE: pool of the documents whose arcs exceed the per-document reserve (k_bpe_seg); *big_need: bytes that did not fit
@@ -101,6 +101,15 @@ struct DictParams {
 void launch_dict_ids(const DictParams &p, hipStream_t s);
 void launch_dict_fill(const DictParams &p, hipStream_t s);
 
+// the ids of the tokens of the Unigram cut form, written to their place in the caller's array (bf_kernels_sp.hip k_uni_ids)
+struct UniIdsParams {
+    Batch b; const uint64_t *T; uint32_t initial; const int32_t *ids;     // dictionary transitions; the id column of I2Info
+    const uint16_t *stream; const int32_t *lens; int slot_mul;
+    const int32_t *toks; const int32_t *counts; const int64_t *id_off;
+    int32_t *ids_out; int64_t ids_cap; int unk, id_offset; int *status;
+};
+void launch_uni_ids(const UniIdsParams &p, hipStream_t s);
+
 struct ScanParams { const int32_t *counts; int64_t ndocs; int64_t *id_off; int64_t *block_sums; int nblocks; };
 
 struct CompactParams {
@@ -111,8 +120,6 @@ struct CompactParams {
     // offsets API (all optional): stream positions of the staged ids -> byte offsets in the original text (tokdll:1263-1273,1519-1529)
     const int32_t *span_tmp; const int32_t *src_off; int32_t *starts_out; int32_t *ends_out;
     const unsigned int *only_if = nullptr;      // optional: nothing to do when *only_if == 0 (the documents the flat program hands back: usually none)
-    // Unigram cut form: the staged words are key + 1 of the tokens' entries (0: unknown) -> id = key_ids[key] (or key_unk) + key_id_offset (tokdll:1512-1516)
-    const int32_t *key_ids = nullptr; int key_unk = 0, key_id_offset = 0;
 };
 
 // flags: one bit per 16-byte chunk of the text (u64 per KiB, + 1), or nullptr for the one-pass wave-per-document form

@@ -1149,7 +1149,7 @@ struct ClsWin2 {
 // every table gather issued behind it -- with one 16-byte load per lane and eight positions, some lane of the wave had one in flight on
 // 93 % of the steps.
 struct ClsWinS {
-    static __device__ __forceinline__ uint4 sel4(bool c, const uint4 &x, const uint4 &y) { return make_uint4(c ? x.x : y.x, c ? x.y : y.y, c ? x.z : y.z, c ? x.w : y.w); }
+    static __device__ __forceinline__ uint4 sel4(bool c, const uint4 x, const uint4 y) { return make_uint4(c ? x.x : y.x, c ? x.y : y.y, c ? x.z : y.z, c ? x.w : y.w); }
     const uint4 *cls16; int64_t blk0; int shift; uint4 w0, w1; int t0;
     uint4 a0, a1, a2, a3, b0, b1, b2, b3; bool have_b;
     __device__ __forceinline__ void init(const uint16_t *cls_buf, int64_t elem_off)
@@ -1176,6 +1176,20 @@ struct ClsWinS {
             b0 = cls16[sec * 4 + 4]; b1 = cls16[sec * 4 + 5]; b2 = cls16[sec * 4 + 6]; b3 = cls16[sec * 4 + 7];
             have_b = true;
         }
+        t0 = t;
+    }
+    // seek(start) for a start that is the one before, or the one after it (the cut form's walks: no loads here, refill() brings the sectors)
+    __device__ __forceinline__ void advance(int start)
+    {
+        const int t = (start + shift) >> 3;
+        if (t == t0) return;
+        const int64_t ab = blk0 + t + 1;
+        w0 = w1;
+        if ((ab & 3) == 0) { a0 = b0; a1 = b1; a2 = b2; a3 = b3; have_b = false; }
+        const int k = (int)(ab & 3);
+        const bool k1 = (k & 1) != 0, k2 = (k & 2) != 0;
+        const uint4 lo = sel4(k1, a1, a0), hi = sel4(k1, a3, a2);
+        w1 = sel4(k2, hi, lo);
         t0 = t;
     }
     // wave-converged: when some walking lane comes within a block of needing sb1, every lane that lacks it loads it
@@ -1348,35 +1362,36 @@ __global__ __launch_bounds__(256) void k_uni_back(SpSegParams p)
     p.narcs[doc] = cap - ul.cnt;
 }
 
-// Unigram-LM, cut form (round 6): bf_seg.h UniCut per lane -- the forward pass of the lane program above, the records in an LDS ring of W
-// positions instead of memory, the tokens read off the ring at the cuts (positions the reference's backward pass is certain to land on)
-// and written in forward order, left-aligned in the document's slot, as key + 1 of their entry (0: unknown) -- k_compact_keys looks the ids
-// up.  No record array traffic, no backward kernel.  LDS per lane: ring_n scores (8 B) + W records (4 B): 16 KB per wave, ten waves per CU.
+// Unigram-LM, cut form (round 6): bf_seg.h UniCut per lane -- the forward pass of the lane program above, one BYTE of record per position in
+// an LDS ring of W positions instead of four in memory, the tokens read off the ring at the cuts (positions the reference's backward pass
+// is certain to land on) and written in forward order, left-aligned in the document's slot, one word per token (key / symbols to walk / unknown);
+// k_uni_ids turns them into ids.  No record array traffic, no backward kernel.  LDS per lane: ring_n scores (8 B) + W record bytes: 10 KB
+// per wave, sixteen waves per CU (the lane program above: 12 KB, thirteen) -- and the kernel's time is latency x waves (bf_seg.h).
 // Emission is a phase the whole wave enters together -- when a lane has finished its document or filled its ring, and every `period` trips --
 // so that its loops run with most lanes active instead of a few lanes every trip.
 struct RingCut {
-    double *sc; uint32_t *rc; int smask, rmask, sn;
+    double *sc; uint8_t *rc; int smask, rmask, sn;
     __device__ __forceinline__ double score(int pos) const { return sc[(pos & smask) * 64]; }
     __device__ __forceinline__ uint32_t rec(int pos) const { return rc[(pos & rmask) * 64]; }
-    __device__ __forceinline__ void set(int pos, double v, uint32_t r) { sc[(pos & smask) * 64] = v; rc[(pos & rmask) * 64] = r; }
-    __device__ __forceinline__ void setrec(int pos, uint32_t r) { rc[(pos & rmask) * 64] = r; }
+    __device__ __forceinline__ void set(int pos, double v, uint32_t r) { sc[(pos & smask) * 64] = v; rc[(pos & rmask) * 64] = (uint8_t)r; }
+    __device__ __forceinline__ void setrec(int pos, uint32_t r) { rc[(pos & rmask) * 64] = (uint8_t)r; }
     __device__ __forceinline__ void setscore(int pos, double v) { sc[(pos & smask) * 64] = v; }
     __device__ __forceinline__ void fill(double v) { for (int k = 0; k < sn; ++k) sc[k * 64] = v; }      // (a record slot is written before it is read: bf_seg.h)
 };
 
 template <int UNROLL>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4))) void k_uni_cut(SpSegParams p, int ring_n, int W, unsigned period_mask)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_uni_cut(SpSegParams p, int ring_n, int W, unsigned period_mask, int quick)
 {
-    extern __shared__ double seg_ring[];            // [ring_n][64] scores, then [W][64] packed records
+    extern __shared__ double seg_ring[];            // [ring_n][64] scores, then [W][64] record bytes
     enum { M_NEED = 0, M_WALK = 1, M_FLUSH = 2, M_EXIT = 3 };
     const int lane = lane_id();
-    RingCut ring{seg_ring + lane, (uint32_t *)(seg_ring + (size_t)ring_n * 64) + lane, ring_n - 1, W - 1, ring_n};
+    RingCut ring{seg_ring + lane, (uint8_t *)(seg_ring + (size_t)ring_n * 64) + lane, ring_n - 1, W - 1, ring_n};
     ClsWinS cls_at; cls_at.init(p.stream, 0);
     UniCut<ClsWinS, RingCut> uc(p.S, cls_at, ring);
     uc.L = 0; uc.depth = p.trie_depth; uc.W = W; uc.start = uc.i = uc.sum = 0; uc.state = 0; uc.unknown = true; uc.pend = false; uc.prev = 0; uc.pend_i = 0;
-    uc.pend_score = 0; uc.pend_key = 0; uc.unk_run = 0; uc.reach = -1; uc.cut0 = 0; uc.lastcut = -1; uc.ring_lo = 0; uc.nout = 0;
+    uc.pend_score = 0; uc.unk_run = 0; uc.reach = -1; uc.rk = 0; uc.rs = 0; uc.ck = 0; uc.cs = -1; uc.cut0 = 0; uc.lastcut = -1; uc.ring_lo = 0; uc.nout = 0;
     int mode = M_NEED;
-    int64_t doc = 0; int32_t *ids = nullptr;
+    int64_t doc = 0; int32_t *toks = nullptr;
     for (unsigned long long trip = 0; trip < (1ull << 34); ++trip) {
         // ---- documents for idle lanes
         const unsigned long long m_need = __ballot(mode == M_NEED);
@@ -1396,9 +1411,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4))) void
                         const int64_t b = p.b.doc_off[doc];
                         const int64_t slot = sp_slot(b, doc, p.slot_mul);
                         const int L = p.lens[doc];
-                        ids = p.ids_tmp + slot;
+                        toks = p.ids_tmp + slot;
                         if (L <= 0) { p.counts[doc] = 0; p.narcs[doc] = 0; }
-                        else { cls_at.init(p.stream, slot); uc.init(L, p.trie_depth, W, (uint32_t *)p.best + slot); mode = M_WALK; }
+                        else { cls_at.init(p.stream, slot); uc.init(L, p.trie_depth, W, (uint8_t *)p.best + slot); mode = M_WALK; }
                     }
                 }
                 if (__ballot(mode != M_EXIT) == 0) break;
@@ -1407,29 +1422,116 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4))) void
         cls_at.refill(mode == M_WALK);
         // ---- forward pass: UNROLL trie transitions
         bool stall = false;
+        auto put = [&](int k, uint32_t v) { if (k < p.max_ids) toks[k] = (int32_t)v; };
         if (mode == M_WALK) {
             int st = UC_MORE;
 #pragma unroll
             for (int u = 0; u < UNROLL; ++u) { if (st == UC_MORE) st = uc.wstep(); }
             if (st == UC_DONE) mode = M_FLUSH;
             stall = st == UC_STALL;
+            if (quick) uc.quick(put);                // nine chunks in ten leave here (bf_seg.h)
         }
-        // ---- emission phase: the tokens in front of every lane's latest cut
+        // ---- emission phase: the chunks of several tokens in front of every lane's latest cut
         if (__ballot(mode == M_FLUSH || stall) != 0 || ((unsigned)trip & period_mask) == period_mask) {
             if (mode == M_WALK || mode == M_FLUSH) {
-                if (uc.pending()) {
-                    auto put = [&](int k, uint32_t v) { if (k < p.max_ids) ids[k] = (int32_t)v; };
-                    uc.emit(put);
-                } else if (stall) uc.spill();
+                if (uc.pending()) uc.emit(put);
+                else if (stall) uc.spill();
             }
             if (mode == M_FLUSH) {
                 p.counts[doc] = uc.nout < p.max_ids ? uc.nout : p.max_ids;
-                p.narcs[doc] = 0;
+                p.narcs[doc] = uc.nout;
                 mode = M_NEED;
             }
         }
     }
     if (mode != M_EXIT) atomicOr(p.status, 2);      // trip limit hit: never expected
+}
+
+// The ids of the token words the cut form left behind (tokdll:1512-1516 on the Unigram path; bf_seg.h uni_token_id): the id column of I2Info
+// at the word's key; UnkId for a word flagged unknown; for a word that names its symbols (one token in eight) the walk over them first -- one
+// transition per symbol, the output weights add up to the key; + IdOffset in every case.  The ids go straight to their place in the caller's
+// array: this kernel is the compaction of the path too.
+// A wave takes 64 consecutive documents (count, slot, place: one document per lane, handed round with readlane as in k_compact_ids) and their
+// tokens 64 per trip: keys and unknowns are answered at once (64 independent look-ups); the words to walk go to a list in LDS and are walked
+// 64 at a time, whatever documents they come from -- every lane of a walk has a token, and a walk's symbols are read eight per load.
+constexpr int UNI_WL = 128;                       // the wave's list of words to walk (a ring: up to 63 wait while 64 more arrive)
+__global__ __launch_bounds__(256) void k_uni_ids(UniIdsParams p)
+{
+    __shared__ int64_t wl_src[4][UNI_WL], wl_out[4][UNI_WL];
+    __shared__ int32_t wl_len[4][UNI_WL];
+    const int lane = lane_id(), wv_i = wave_in_block();
+    int64_t *l_src = wl_src[wv_i], *l_out = wl_out[wv_i]; int32_t *l_len = wl_len[wv_i];
+    const int64_t wave0 = (int64_t)blockIdx.x * 4 + wv_i;
+    const int64_t nwaves = (int64_t)gridDim.x * 4;
+    bool over = false;
+    uint32_t head = 0, tail = 0;                    // wave-uniform
+    auto walk64 = [&](int n) {                      // the first n (<= 64) words of the list
+        const bool act = lane < n;
+        int64_t src = 0, out = 0; int len = 0;
+        if (act) { const uint32_t e = (head + (uint32_t)lane) & (UNI_WL - 1); src = l_src[e]; out = l_out[e]; len = l_len[e]; }
+        uint32_t state = p.initial; int sum = 0;
+        uint4 blk = make_uint4(0, 0, 0, 0);
+        for (int j = 0; __any(j < len); ++j) {      // j is the same for every lane: the symbol's place in the block is a scalar
+            if ((j & 7) == 0 && j < len) __builtin_memcpy(&blk, p.stream + src + j, 16);     // (the element slot is 2-byte aligned only; the stream buffer is padded)
+            const int q = (j >> 1) & 3;
+            const uint32_t dw = q == 0 ? blk.x : q == 1 ? blk.y : q == 2 ? blk.z : blk.w;
+            const uint32_t c = (j & 1) ? dw >> 16 : dw & 0xFFFFu;
+            if (j < len) {
+                const uint64_t e = p.T[state + c];
+                state = (uint32_t)((e >> SG_NEXT_SHIFT) & SG_NEXT_MASK);
+                sum += (int)(e >> SG_OW_SHIFT);
+            }
+        }
+        if (act) { const int id = p.ids[sum]; p.ids_out[out] = (id != -1 ? id : p.unk) + p.id_offset; }
+        head += (uint32_t)n;
+    };
+    for (int64_t base = wave0 * 64; base < p.b.ndocs; base += nwaves * 64) {
+        const int64_t d = base + lane;
+        int c = 0; int64_t slot = 0, o = 0;
+        if (d < p.b.ndocs) {
+            c = p.counts[d];
+            slot = sp_slot(p.b.doc_off[d], d, p.slot_mul);
+            o = p.id_off[d];
+            if (o + c > p.ids_cap) { over = true; c = o < p.ids_cap ? (int)(p.ids_cap - o) : 0; }
+        }
+        const int nd = p.b.ndocs - base < 64 ? (int)(p.b.ndocs - base) : 64;
+        for (int k = 0; k < nd; ++k) {
+            const int ck = __builtin_amdgcn_readlane(c, k);
+            if (ck <= 0) continue;
+            const int64_t sk = wv::bcast(slot, k), ok = wv::bcast(o, k);
+            const uint32_t *tok = (const uint32_t *)p.toks + sk;
+            for (int t0 = 0; t0 < ck; t0 += 64) {
+                const int t = t0 + lane;
+                const bool act = t < ck;
+                const uint32_t v = act ? tok[t] : UC_TOK_UNK;
+                const bool walk = act && (v & (UC_TOK_UNK | UC_TOK_KEY)) == 0u;
+                if (act && !walk) {
+                    const int id = (v & UC_TOK_KEY) ? p.ids[v & 0xFFFFFu] : -1;
+                    p.ids_out[ok + t] = (id != -1 ? id : p.unk) + p.id_offset;
+                }
+                const unsigned long long wm = __ballot(walk);
+                if (wm) {
+                    if (walk) {
+                        const uint32_t e = (tail + (uint32_t)__popcll(wm & lanemask_lt())) & (UNI_WL - 1);
+                        l_src[e] = sk + (int64_t)(v & ((1u << UC_BEGIN_BITS) - 1u)); l_out[e] = ok + t; l_len[e] = (int)(v >> UC_BEGIN_BITS) + 1;
+                    }
+                    tail += (uint32_t)__popcll(wm);
+                    wave_handoff();
+                    if (tail - head >= 64u) { walk64(64); wave_handoff(); }
+                }
+            }
+        }
+    }
+    if (tail != head) walk64((int)(tail - head));
+    if (over) atomicOr(p.status, 1);
+}
+
+void launch_uni_ids(const UniIdsParams &p, hipStream_t s)
+{
+    int64_t blocks = (p.b.ndocs + 255) / 256;
+    if (blocks > device_cus() * 8) blocks = device_cus() * 8;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(k_uni_ids, dim3((unsigned)blocks), dim3(256), 0, s, p);
 }
 
 // BPE, documents whose arcs exceed the per-document reserve (narcs == -1 on the fallback list; a long run of one character whose
@@ -1508,7 +1610,7 @@ void launch_seg_sp(const SpSegParams &p_in, hipStream_t s)
             if (p.uni_cut) {
                 // the cut form (ids only): records in LDS, tokens out at the cuts, no backward kernel
                 int W = 32; while (W < p.trie_depth + UC_SPILL) W <<= 1;
-                const size_t lds_c = (size_t)ring * 64 * sizeof(double) + (size_t)W * 64 * sizeof(uint32_t);
+                const size_t lds_c = (size_t)ring * 64 * sizeof(double) + (size_t)W * 64;
                 int pc = 0;
                 if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&pc, (const void *)k_uni_cut<3>, 64, lds_c) != hipSuccess || pc <= 0) pc = 8;
                 (void)hipGetLastError();
@@ -1518,7 +1620,8 @@ void launch_seg_sp(const SpSegParams &p_in, hipStream_t s)
                 unsigned period_mask = 7u;
                 if (p.tune > 0) { period_mask = 1u; while (period_mask + 1u < (unsigned)p.tune) period_mask = period_mask * 2u + 1u; if (p.tune == 1) period_mask = 0u; }
                 if (p.ev_dom0) (void)hipEventRecord((hipEvent_t)p.ev_dom0, s);
-                hipLaunchKernelGGL(k_uni_cut<3>, dim3(blocks), dim3(64), lds_c, s, p, ring, W, period_mask);
+                if (p.variant & 0x10) hipLaunchKernelGGL(k_uni_cut<2>, dim3(blocks), dim3(64), lds_c, s, p, ring, W, period_mask, (p.variant & 0x20) ? 0 : 1);
+                else hipLaunchKernelGGL(k_uni_cut<3>, dim3(blocks), dim3(64), lds_c, s, p, ring, W, period_mask, (p.variant & 0x20) ? 0 : 1);
                 if (p.ev_dom1) (void)hipEventRecord((hipEvent_t)p.ev_dom1, s);
                 return;
             }
@@ -2271,12 +2374,8 @@ __global__ __launch_bounds__(256) void k_compact_text(CompactParams p)
 // place in the output are read once, one document per lane (three coalesced loads instead of three dependent loads per document),
 // then handed round with readlane; the copies of two documents are in flight together.  Measured on the 10 M x 512 B workload
 // (profiles/r03_*): 3.56 ms with the wave-per-document form, whose waves spend most of their time waiting for those three loads.
-// KEYS (the Unigram cut form): the staged words are key + 1 of the tokens' dictionary entries, 0 for the unknown arc; the id comes from the
-// id column of I2Info here, where 64 independent look-ups per instruction cost next to nothing (tokdll:1512-1516: UnkId and IdOffset as there)
-template <bool KEYS>
 __global__ __launch_bounds__(256) void k_compact_ids(CompactParams p)
 {
-    auto tr = [&](int32_t v) -> int32_t { if constexpr (KEYS) { const int32_t id = v ? p.key_ids[v - 1] : -1; return (id != -1 ? id : p.key_unk) + p.key_id_offset; } else return v; };
     const int lane = lane_id();
     const int64_t wave0 = (int64_t)blockIdx.x * 4 + wave_in_block();
     const int64_t nwaves = (int64_t)gridDim.x * 4;
@@ -2303,12 +2402,12 @@ __global__ __launch_bounds__(256) void k_compact_ids(CompactParams p)
             if (lane + 64 < c0) a1 = tmp[s0 + lane + 64];
             if (lane < c1) b0 = tmp[s1 + lane];
             if (lane + 64 < c1) b1 = tmp[s1 + lane + 64];
-            if (lane < c0) out[o0 + lane] = tr(a0);
-            if (lane + 64 < c0) out[o0 + lane + 64] = tr(a1);
-            if (lane < c1) out[o1 + lane] = tr(b0);
-            if (lane + 64 < c1) out[o1 + lane + 64] = tr(b1);
-            for (int i = lane + 128; i < c0; i += 64) out[o0 + i] = tr(tmp[s0 + i]);
-            for (int i = lane + 128; i < c1; i += 64) out[o1 + i] = tr(tmp[s1 + i]);
+            if (lane < c0) out[o0 + lane] = a0;
+            if (lane + 64 < c0) out[o0 + lane + 64] = a1;
+            if (lane < c1) out[o1 + lane] = b0;
+            if (lane + 64 < c1) out[o1 + lane + 64] = b1;
+            for (int i = lane + 128; i < c0; i += 64) out[o0 + i] = tmp[s0 + i];
+            for (int i = lane + 128; i < c1; i += 64) out[o1 + i] = tmp[s1 + i];
         }
     }
     if (over) atomicOr(p.status, 1);
@@ -2320,8 +2419,7 @@ void launch_compact(const CompactParams &p, hipStream_t s)
         int64_t blocks = (p.b.ndocs + 255) / 256;
         if (blocks > device_cus() * 8) blocks = device_cus() * 8;
         if (blocks < 1) blocks = 1;
-        if (p.key_ids) hipLaunchKernelGGL(k_compact_ids<true>, dim3((unsigned)blocks), dim3(256), 0, s, p);
-        else hipLaunchKernelGGL(k_compact_ids<false>, dim3((unsigned)blocks), dim3(256), 0, s, p);
+        hipLaunchKernelGGL(k_compact_ids, dim3((unsigned)blocks), dim3(256), 0, s, p);
         return;
     }
     int64_t blocks = (p.b.ndocs + 3) / 4;

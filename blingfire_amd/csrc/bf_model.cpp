@@ -339,7 +339,22 @@ bool pack_dfa(const RawDfa &raw, bool wide, const std::vector<int> &extra_syms, 
     auto next_free_base = [&]() -> uint32_t {
         for (;; ++bcur) { grow(bcur + 1); if (!base_used[bcur]) { base_used[bcur] = 1; return (uint32_t)bcur++; } }
     };
-    for (uint32_t s : order) if (fan(s) == 0) base[s] = next_free_base();
+    if (wide) {
+        // a dictionary has a handful of leaves (a minimised Mealy automaton merges equivalent ones): they take CONSECUTIVE unused base values, so
+        // that a walk knows by its state alone that it is over (base - leaf_lo < leaf_n: bf_seg.h, one gather less per walk that ends on a leaf)
+        size_t nleaf = 0;
+        for (uint32_t s : order) if (fan(s) == 0) ++nleaf;
+        size_t b = 0;
+        for (;; ++b) {
+            grow(b + nleaf + 2);
+            bool ok = true;
+            for (size_t k = 0; ok && k < nleaf; ++k) if (base_used[b + k]) ok = false;
+            if (ok) break;
+        }
+        out.leaf_lo = (uint32_t)b; out.leaf_n = (uint32_t)nleaf;
+        for (uint32_t s : order) if (fan(s) == 0) { base[s] = (uint32_t)b; base_used[b] = 1; ++b; }
+    } else
+        for (uint32_t s : order) if (fan(s) == 0) base[s] = next_free_base();
     base[ns] = next_free_base();
     uint32_t max_base = 0;
     for (uint32_t v : base) max_base = std::max(max_base, v);

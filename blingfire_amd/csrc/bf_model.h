@@ -72,6 +72,7 @@ struct PackedDfa {
     std::vector<uint64_t> t64;
     std::vector<uint32_t> state_base;  // state index -> base (unique)
     uint32_t dead_base = 0;            // base of the synthetic dead state
+    uint32_t leaf_lo = 0, leaf_n = 0;  // wide tables: the states without transitions have the bases [leaf_lo, leaf_lo + leaf_n)
     uint32_t initial_base = 0;
     int nclasses = 0;                  // classes are 0 .. nclasses-1
     std::vector<int> sym_of_class;     // non-remap: class -> raw symbol

@@ -37,6 +37,7 @@ struct SegTables {
     uint32_t cls_delim;         // class-stream value of U+2581
     int kind, id_offset;
     const uint32_t *score;      // Unigram lane program: the score bits of the I2Info rows alone (same key); the forward pass reads nothing else of a row
+    uint32_t leaf_lo = 0, leaf_n = 0;   // states [leaf_lo, leaf_lo + leaf_n) have no transitions (bf_model.h PackedDfa): a walk that reaches one is over
 };
 
 struct SegArc { int32_t start, end, id; uint32_t rank_bits; };   // BPE arc (…_bpe_t.h:66-88, …_with_merges_t.h)
@@ -261,7 +262,7 @@ struct UniLane {
 // ---------------------------------------------------------------------------------------------------
 // Unigram-LM, cut form (round 6; bf_kernels_sp.hip k_uni_cut drives it, tests/hosttest runs the same code on the host): the lane program
 // above WITHOUT the lattice in memory.  The forward pass is UniLane's (same walks, same deferred relaxation, same doubles in the same
-// order); what changes is where the End2BestArc records go.  A position p is a CUT when
+// order); what changes is what is kept of the End2BestArc records and where.  A position p is a CUT when
 //   (a) its final record is a dictionary entry (not the unknown arc, not "no incoming arc"), and
 //   (b) no dictionary arc found from any start <= p ends behind p   (reach <= p: every walk from a start <= p is complete when p is final).
 // Then the backward pass of the reference (..._1best_t.h:237-265) is certain to land on p: a hop over p would need an arc that spans
@@ -272,21 +273,43 @@ struct UniLane {
 // of a U+2581 qualifies, because no entry holds U+2581 behind its first symbol; text without blanks is cut wherever its arcs allow).
 // A hop that lands on a position without incoming arc makes the reference emit <UnkId, -1, end> and STOP (..._1best_t.h:250-262): everything
 // in front of it is dropped -- here the output restarts at index 0 with that token.
+// What bounds the lane program is the latency of its dependent gathers times the waves a CU holds, and the waves are bounded by the LDS of
+// the rings (measured on MI355X, configs 4 / 5: T = 22 ms + 756 ms / waves per CU).  So a record is ONE BYTE -- the length of the arc,
+// which is all the hops need:
+//     0           no incoming arc                      1 .. 32      a dictionary entry of that many symbols
+//     0x80 | f    the unknown arc, f = min(run - 1, 127), run = length of the merged unknown run that ends here (f == 127: "128 or more" --
+//                 every position of a run carries its length so far, so the hop goes 127 back and adds up, like UniLane's 4095)
+// and WHICH entry a token is -- 20 bits of MPH index per position in the lane program above -- is not carried along at all.  A token leaves as
+// one word:   0x80000000               the unknown id
+//             0x40000000 | key         the entry's MPH index, when the lane still knows it (below)
+//             (len - 1) << 25 | begin  otherwise: k_uni_ids walks the token's symbols once more (independent walks at full occupancy;
+//                                      uni_token_id below).  A document of 2^25 elements or more walks them here instead.
+// Nine chunks in ten are one token, or two, and leave by the short way (quick(), once per trip of the driver): the lane remembers the arc
+// that last extended `reach` -- its start and MPH index, two registers -- and at a cut p that is the longest entry from the leftmost start that
+// ends at p: if the best arc into p begins where it does, it is that arc (the arc from a start to an end is unique) and its key goes out.
+// The other chunks (more tokens, an unknown run in front of the cut) wait for the wave's emission phase and are read off the ring by the
+// reference's hops.
 // The ring holds the records of [ring_lo, i]: a record slot is written by the relaxation that sets its score (a position no arc reached is
 // "no incoming arc" by its score alone), so nothing is reserved ahead of the walk.  A lane whose pending region fills the ring with no cut to
-// emit (a word of more than ~24 symbols, a long unknown run) SPILLS its oldest final records to the document's record array in memory
-// (the array the lane program above writes every record to); the hops read them back from there.  Rare: 0.1 % of the documents of running text.
-// Output: one word per token, key + 1 of its entry (0: the unknown id) -- the id is looked up where the ids are copied to their place
-// (k_compact_ids), off this kernel's dependent-gather path.
+// emit (a word of more than ~24 symbols, a long unknown run) SPILLS its oldest final records to the document's record bytes in memory;
+// the hops read them back from there.  Rare: 0.1 % of the documents of running text.
 // ---------------------------------------------------------------------------------------------------
 enum { UC_DONE = 0, UC_MORE = 1, UC_STALL = 2 };
 constexpr int UC_SPILL = 8;                           // records per spill
+constexpr uint32_t UC_NONE = 0u, UC_UNK = 0x80u, UC_RUN_MAX = 127u, UC_TOK_UNK = 0x80000000u, UC_TOK_KEY = 0x40000000u;
+constexpr int UC_BEGIN_BITS = 25;
+#ifndef BF_UC_STAT
+#define BF_UC_STAT(k)
+#endif
+BF_HD uint32_t uc_unk_rec(int run) { const uint32_t f = (uint32_t)(run - 1); return UC_UNK | (f < UC_RUN_MAX ? f : UC_RUN_MAX); }
+
 template <class ClsAt, class Ring>
 struct UniCut {
-    const SegTables &S; ClsAt &cls_at; Ring &ring; uint32_t *recs;
-    int L, depth, W, start, i, sum; uint32_t state; bool unknown, pend; double prev; uint32_t pend_score; int pend_key; int pend_i;
+    const SegTables &S; ClsAt &cls_at; Ring &ring; uint8_t *recs;
+    int L, depth, W, start, i, sum; uint32_t state; bool unknown, pend; double prev; uint32_t pend_score; int pend_i;
     int unk_run;
-    int reach;                                         // last position a dictionary arc found so far ends at
+    int reach, rk, rs;                                 // last position a dictionary arc found so far ends at; MPH index and start of the arc that moved it there
+    int ck, cs;                                        // the same two of the arc that moved `reach` to the latest cut (cs == -1: none)
     int cut0, lastcut;                                 // first position not emitted yet; latest cut (cut0 - 1: nothing to emit)
     int ring_lo;                                       // first position whose record is in the ring (cut0 <= older ones: in recs[])
     int nout;                                          // tokens emitted so far (not limited by max_ids)
@@ -294,49 +317,70 @@ struct UniCut {
     BF_HD UniCut(const SegTables &S_, ClsAt &c, Ring &r) : S(S_), cls_at(c), ring(r), recs(nullptr) {}
     static BF_HD double neg_flt_max() { return -3.40282346638528859811704183484516925e+38; }
 
-    // Start a document of L >= 1 stream elements; recs_ has room for L records (touched by spills only)
-    BF_HD void init(int L_, int depth_, int W_, uint32_t *recs_)
+    // Start a document of L >= 1 stream elements; recs_ has room for L record bytes (touched by spills only)
+    BF_HD void init(int L_, int depth_, int W_, uint8_t *recs_)
     {
         L = L_; depth = depth_; W = W_; recs = recs_;
         ring.fill(neg_flt_max());
-        start = 0; i = 0; state = S.initial; sum = 0; unknown = true; prev = 0; pend = false; pend_i = 0; pend_score = 0; pend_key = 0;
-        unk_run = 0; reach = -1; cut0 = 0; lastcut = -1; ring_lo = 0; nout = 0;
+        start = 0; prev = 0; pend = false; pend_i = 0; pend_score = 0;
+        unk_run = 0; reach = -1; rk = 0; rs = 0; ck = 0; cs = -1; cut0 = 0; lastcut = -1; ring_lo = 0; nout = 0;
+        i = 0; state = S.initial; sum = 0; unknown = true;
         cls_at.seek(0);
     }
     BF_HD void relax()
     {
         const double cand = sg_bits_to_float(pend_score) + prev;
-        if (ring.score(pend_i) < cand) ring.set(pend_i, cand, uni_rec(pend_key, pend_i - start + 1));
+        if (ring.score(pend_i) < cand) ring.set(pend_i, cand, (uint32_t)(pend_i - start + 1));
         pend = false;
     }
     BF_HD bool pending() const { return lastcut >= cut0; }
     BF_HD bool stalled() const { return i - ring_lo >= W; }
-    BF_HD uint32_t rec_at(int e) const { return e >= ring_lo ? ring.rec(e) : recs[e]; }
+    BF_HD uint32_t rec_at(int e) const { return e >= ring_lo ? ring.rec(e) : (uint32_t)recs[e]; }
     // a stalled lane with nothing to emit: its oldest final records go to memory (the walk is at most depth - 1 positions ahead of `start`,
     // so W >= depth + UC_SPILL leaves at least UC_SPILL final ones in the ring)
     BF_HD void spill()
     {
-        for (int k = 0; k < UC_SPILL; ++k) recs[ring_lo + k] = ring.rec(ring_lo + k);
+        if (!stalled()) return;                                         // (the short way out may have made room since the walk stalled)
+        for (int k = 0; k < UC_SPILL; ++k) recs[ring_lo + k] = (uint8_t)ring.rec(ring_lo + k);
         ring_lo += UC_SPILL;
     }
 
-    // One trie transition (UniLane::wstep); UC_STALL: the ring is full -- emit() or spill() first (nothing was done)
+    // the word of a token that is a dictionary entry of `len` symbols from `begin`, key unknown
+    BF_HD uint32_t walk_word(int begin, int len)
+    {
+        if (begin < (1 << UC_BEGIN_BITS)) return ((uint32_t)(len - 1) << UC_BEGIN_BITS) | (uint32_t)begin;
+        uint32_t st = S.initial; int sm = 0;                            // (a document this long: the walk k_uni_ids would do)
+        for (int j = 0; j < len; ++j) { const uint64_t e = S.T[st + cls_at(begin + j)]; st = (uint32_t)((e >> SG_NEXT_SHIFT) & SG_NEXT_MASK); sm += (int)(e >> SG_OW_SHIFT); }
+        return UC_TOK_KEY | (uint32_t)sm;
+    }
+
+    // the walk from `start` has reached position i in `state`: take the transition entry e that was gathered for the symbol class c there
+    // (AddArc's part of ..._1best_t.h:203-226 for a final destination).  Returns whether the walk is over.
+    BF_HD bool consume(uint64_t e, uint32_t c)
+    {
+        if (!(c < SG_CLS_DELIM_ABSENT && (e & SG_CLS_MASK) == c)) return true;          // no such transition (sg_lookup)
+        state = (uint32_t)((e >> SG_NEXT_SHIFT) & SG_NEXT_MASK);
+        sum += (int)(e >> SG_OW_SHIFT);
+        if (e & SG_FINAL) {
+            pend_score = S.score[sum]; pend_i = i; pend = true; unknown = false;           // requested now, relaxed at the next step
+            const bool ext = i > reach;
+            reach = ext ? i : reach; rk = ext ? sum : rk; rs = ext ? start : rs;
+        }
+        ++i;
+        return i >= L || state - S.leaf_lo < S.leaf_n;                  // (a state without transitions: the next GetDestOw would fail, ..._1best_t.h:209-212)
+    }
+    // One trie transition of the walk from `start` (UniLane::wstep) and, when that walk is over, the end of its start position.
+    // UC_STALL: the ring is full -- emit() or spill() first (nothing was done).
+    // (Measured and removed again, round 6: the first transition of the NEXT walk gathered one walk ahead -- it depends on nothing but the symbol
+    //  there -- takes a third of the steps out and made the kernel 4 ms SLOWER: its time is the gathers' -- 22 G of them per 10 M documents into
+    //  3.6 MB of tables, at the rate tools/microbench/gather_sweep.hip finds for that footprint --, not the length of a lane's chain.)
     BF_HD int wstep()
     {
         if (stalled()) return UC_STALL;
         const uint32_t c = cls_at(i);
-        const bool valid = c < SG_CLS_DELIM_ABSENT;
-        const uint64_t e = S.T[state + (valid ? c : 0u)];
-        if (pend) relax();
-        const bool hit = valid && (e & SG_CLS_MASK) == c;
-        bool ends = !hit;
-        if (hit) {
-            state = (uint32_t)((e >> SG_NEXT_SHIFT) & SG_NEXT_MASK);
-            sum += (int)(e >> SG_OW_SHIFT);
-            if (e & SG_FINAL) { pend_score = S.score[sum]; pend_key = sum; pend_i = i; pend = true; unknown = false; reach = reach > i ? reach : i; }
-            ++i;
-            ends = i >= L;
-        }
+        const uint64_t e = S.T[state + (c < SG_CLS_DELIM_ABSENT ? c : 0u)];           // the gather is issued ...
+        if (pend) relax();                                                              // ... and the previous arc is relaxed while it travels
+        const bool ends = consume(e, c);
         if (ends) {
             if (pend) relax();
             double fin = ring.score(start);
@@ -345,34 +389,61 @@ struct UniCut {
             if (unknown) {                                              // AddUnknownArc (..._1best_t.h:145-171)
                 const float unk_score = -100000.0f;
                 const double cand = unk_score + prev;
-                if (fin < cand) { run = unk_run + 1; r = uni_rec(-1, run); fin = cand; }
+                if (fin < cand) { run = unk_run + 1; r = uc_unk_rec(run); fin = cand; }
             }
             const bool none = !(neg_flt_max() < fin);                   // no incoming arc at all (..._1best_t.h:61-77); its record slot was never written
-            if (none) r = UNI_REC_NONE;
+            if (none) r = UC_NONE;
             unk_run = run;
             if (run != 0 || none) ring.setrec(start, r);
-            const bool piece = !none && (r & 0xFFFFFu) != 0u;
-            if ((piece && reach <= start) || start == L - 1) lastcut = start;
+            const bool piece = !none && run == 0;
+            if ((piece && reach <= start) || start == L - 1) {          // a cut: remember what is known about the arc that ends here (quick())
+                lastcut = start; ck = rk; cs = (piece && reach == start) ? rs : -1;
+            }
             ++start;
             if (!(start < L)) return UC_DONE;
             prev = fin;
             ring.setscore(start + depth - 1, neg_flt_max());            // the position that enters the reach of this start
             i = start; state = S.initial; sum = 0; unknown = true;
-            cls_at.seek(start);
+            cls_at.advance(start);
         }
         return UC_MORE;
     }
 
-    // length of the token whose last position is e, r = its record (a 4095 in the length field: "4096 or more", UniLane::bstep)
-    BF_HD int tok_len(int e, uint32_t r) const
+    // The short way out, once per trip of the driver: the chunk [cut0, lastcut] when it is ONE token, or two, both dictionary entries -- nine
+    // chunks in ten of running text.  The last token's key is at hand when the arc that moved `reach` to the cut begins where the token does (it
+    // is the longest entry from the leftmost start that ends there; the arc from a start to an end is unique): its word carries the key, every
+    // other word names its symbols.  put(index in the document's token sequence, word).  Anything else stays for emit().
+    template <class Put>
+    BF_HD void quick(Put &put)
     {
-        if ((r >> 20) != UNI_LEN_MAX) return (int)(r >> 20) + 1;
-        int len = 0;
-        while ((r >> 20) == UNI_LEN_MAX && e - (int)UNI_LEN_MAX >= 0) { len += (int)UNI_LEN_MAX; e -= (int)UNI_LEN_MAX; r = rec_at(e); }
-        return len + (int)(r >> 20) + 1;
+        if (!pending() || lastcut < ring_lo || L > (1 << UC_BEGIN_BITS)) return;
+        const uint32_t r = ring.rec(lastcut);
+        if (r == UC_NONE || (r & UC_UNK)) return;
+        const int b1 = lastcut - (int)r + 1;                            // the last token begins here
+        const uint32_t w1 = cs == b1 ? (UC_TOK_KEY | (uint32_t)ck) : (((r - 1u) << UC_BEGIN_BITS) | (uint32_t)b1);
+        int n = 0; uint32_t w0 = w1;
+        if (b1 == cut0) n = 1;
+        else if (b1 > cut0 && b1 - 1 >= ring_lo) {
+            const uint32_t r0 = ring.rec(b1 - 1);
+            if (r0 != UC_NONE && !(r0 & UC_UNK) && b1 - (int)r0 == cut0) { n = 2; w0 = ((r0 - 1u) << UC_BEGIN_BITS) | (uint32_t)cut0; }
+        }
+        if (n == 0) return;
+        put(nout, w0);
+        if (n == 2) put(nout + 1, w1);
+        BF_UC_STAT(cs == b1 ? 0 : 1); if (n == 2) BF_UC_STAT(1);
+        nout += n; cut0 = lastcut + 1; ring_lo = ring_lo < cut0 ? cut0 : ring_lo;
     }
 
-    // The tokens of [cut0, lastcut], first to last: put(index in the document's id sequence, key + 1 or 0).  Two passes over the records: the
+    // length of the token whose last position is e, r = its record
+    BF_HD int tok_len(int e, uint32_t r) const
+    {
+        if (!(r & UC_UNK)) return (int)r;
+        int len = 0;
+        while ((r & 0x7Fu) == UC_RUN_MAX && e - (int)UC_RUN_MAX >= 0 && (r & UC_UNK)) { len += (int)UC_RUN_MAX; e -= (int)UC_RUN_MAX; r = rec_at(e); }
+        return len + (int)(r & 0x7Fu) + 1;
+    }
+
+    // The tokens of [cut0, lastcut], first to last: put(index in the document's token sequence, word).  Two passes over the records: the
     // hops of the backward pass count the tokens, the same hops place them.
     template <class Put>
     BF_HD void emit(Put &put)
@@ -382,21 +453,45 @@ struct UniCut {
         for (int e = lastcut; e >= cut0;) {
             const uint32_t r = rec_at(e);
             ++n;
-            if (r == UNI_REC_NONE) { restart = true; break; }          // <UnkId, -1, end>, and the reference stops
+            if (r == UC_NONE) { restart = true; break; }               // <UnkId, -1, end>, and the reference stops
             e -= tok_len(e, r);
         }
         const int base = restart ? 0 : nout;
         int k = n - 1;
         for (int e = lastcut; k >= 0; --k) {
             const uint32_t r = rec_at(e);
-            put(base + k, r == UNI_REC_NONE ? 0u : (r & 0xFFFFFu));
-            if (r != UNI_REC_NONE) e -= tok_len(e, r);
+            if (r == UC_NONE) { put(base + k, UC_TOK_UNK); break; }
+            const int len = tok_len(e, r);
+            put(base + k, (r & UC_UNK) ? UC_TOK_UNK : walk_word(e - len + 1, len));
+            BF_UC_STAT(2);
+            e -= len;
         }
         nout = base + n;
         cut0 = lastcut + 1;
         if (ring_lo < cut0) ring_lo = cut0;
     }
 };
+
+// The id of a token word (what k_uni_ids does per lane): the key, or the walk of the token's symbols, gives the entry's MPH index, the id
+// column of I2Info the id (..._1best_t.h:118-142 stored it with the arc; -1 and the unknown arc: UnkId, tokdll:1512-1516 adds IdOffset to
+// either).  A walked token is an arc the forward pass found, so every transition exists; ids[] = Model::i2info_id.
+template <class ClsAt>
+BF_HD int uni_token_id(const SegTables &S, const int32_t *ids, ClsAt &cls_at, uint32_t word, int unk)
+{
+    int id = -1;
+    if (word & UC_TOK_KEY) id = ids[word & 0xFFFFFu];
+    else if (!(word & UC_TOK_UNK)) {
+        const int begin = (int)(word & ((1u << UC_BEGIN_BITS) - 1u)), len = (int)(word >> UC_BEGIN_BITS) + 1;
+        uint32_t state = S.initial; int sum = 0;
+        for (int j = 0; j < len; ++j) {
+            const uint64_t e = S.T[state + cls_at(begin + j)];
+            state = (uint32_t)((e >> SG_NEXT_SHIFT) & SG_NEXT_MASK);
+            sum += (int)(e >> SG_OW_SHIFT);
+        }
+        id = ids[sum];
+    }
+    return (id != -1 ? id : unk) + S.id_offset;
+}
 
 // ---------------------------------------------------------------------------------------------------
 // BPE (both flavours).  arcs[] has room for arc_cap entries; tos/idsv/inter are the three work arrays of

@@ -10,6 +10,8 @@
 // lookup-index histogram of the lexer table (design evidence for the LDS-resident prefix, tools/lookup_profile.py)
 static unsigned long long g_lookup_hist[4096];
 #define BF_LEX_PROFILE_HOOK(idx) (g_lookup_hist[((idx) >> 8) & 4095]++)
+static unsigned long long g_uc_stat[8];       // tokens of the Unigram cut form: [0] inline with their key, [1] inline to be walked, [2] through the emission phase
+#define BF_UC_STAT(k) (g_uc_stat[(k)]++)
 #include "../../blingfire_amd/csrc/bf_model.h"
 #include "../../blingfire_amd/csrc/bf_lex.h"
 #include "../../blingfire_amd/csrc/bf_seg.h"
@@ -27,6 +29,7 @@ using namespace bfa;
 static long g_big_pool = 64l << 20;   // bft_set_big_pool: bytes of the pool behind seg_bpe_doc_big (the device's is 64 MiB per batch)
 static int g_uni_cut_w = 0;   // bft_set_uni_cut(W, period): Unigram through the cut form (bf_seg.h UniCut) with a record ring of W positions; emission every `period` steps
 static int g_uni_cut_period = 1;
+static int g_uni_cut_quick = 1;     // bft_set_uni_cut_quick(0): every chunk through the emission phase
 static unsigned long long g_uni_cut_stats[8 + 260];   // [0] documents, [1] given up (hard), [2] chunks, [3] tokens, [4] restarts; [8 + k] documents whose widest pending span (start + depth - cut0, emitted as soon as possible) was k
 static int g_uni_seq = 0;     // bft_set_uni_seq(1): Unigram through the plain sequential restatement (seg_unigram_doc) instead of UniLane
 static int g_general = 0;     // bft_set_general(1): the general lexer machine even for two-level models (A/B in tests)
@@ -60,8 +63,14 @@ int bft_tolower(int cp) { return bfa::bf_tolower(cp); }
 int bft_lexer_void(void *hv) { return ((Handle *)hv)->m.lexer_void ? 1 : 0; }
 void bft_free(void *hv) { delete (Handle *)hv; }
 void bft_set_no_ff(int v) { g_no_ff = v; }
+void bft_set_uni_cut_quick(int v) { g_uni_cut_quick = v; }
 void bft_set_uni_cut(int w, int period) { g_uni_cut_w = w; g_uni_cut_period = period > 0 ? period : 1; }
-void bft_uni_cut_stats(unsigned long long *out, int reset) { memcpy(out, g_uni_cut_stats, sizeof(g_uni_cut_stats)); if (reset) memset(g_uni_cut_stats, 0, sizeof(g_uni_cut_stats)); }
+void bft_uni_cut_stats(unsigned long long *out, int reset)
+{
+    g_uni_cut_stats[6] = g_uc_stat[0]; g_uni_cut_stats[7] = g_uc_stat[1]; g_uni_cut_stats[3] = g_uc_stat[2]; g_uni_cut_stats[0 + 268 - 2] = g_uc_stat[3]; g_uni_cut_stats[268 - 1] = g_uc_stat[4];      // [6] inline with key, [7] inline walked, [3] through the emission phase
+    memcpy(out, g_uni_cut_stats, sizeof(g_uni_cut_stats));
+    if (reset) { memset(g_uni_cut_stats, 0, sizeof(g_uni_cut_stats)); memset(g_uc_stat, 0, sizeof(g_uc_stat)); }
+}
 void bft_set_general(int v) { g_general = v; }
 int bft_two_level(void *hv) { return ((Handle *)hv)->m.two_level ? 1 : 0; }
 int bft_fn_no_ra(void *hv) { return ((Handle *)hv)->m.fn_no_ra ? 1 : 0; }
@@ -281,7 +290,7 @@ static int emu_sp(const Model &m, const char *s, int n, int32_t *ids, int32_t *s
     const int L = (int)st.size();
     SegTables S;
     S.T = m.dict.t64.data(); S.info = (const SegInfo *)m.seg_info.data(); S.initial = m.dict.initial_base; S.cls_delim = D;
-    S.kind = m.kind; S.id_offset = m.id_offset; S.score = m.seg_score.data();
+    S.kind = m.kind; S.id_offset = m.id_offset; S.score = m.seg_score.data(); S.leaf_lo = m.dict.leaf_lo; S.leaf_n = m.dict.leaf_n;
     const uint16_t *cp = st.data();
     auto cls_at = [cp](int i) -> uint32_t { return cp[i]; };
     IdOutDirect out{ids, spans};
@@ -293,20 +302,20 @@ static int emu_sp(const Model &m, const char *s, int n, int32_t *ids, int32_t *s
         // the cut form (bf_seg.h UniCut): records in a ring of W positions, tokens leave at the cuts; a document that outgrows the ring falls
         // through to the lane program below, like on the device
         struct CutRing {
-            std::vector<double> v; std::vector<uint32_t> r; int smask, rmask;
+            std::vector<double> v; std::vector<uint8_t> r; int smask, rmask;
             double score(int pos) const { return v[(size_t)(pos & smask)]; }
             uint32_t rec(int pos) const { return r[(size_t)(pos & rmask)]; }
-            void set(int pos, double x, uint32_t rr) { v[(size_t)(pos & smask)] = x; r[(size_t)(pos & rmask)] = rr; }
-            void setrec(int pos, uint32_t rr) { r[(size_t)(pos & rmask)] = rr; }
+            void set(int pos, double x, uint32_t rr) { v[(size_t)(pos & smask)] = x; r[(size_t)(pos & rmask)] = (uint8_t)rr; }
+            void setrec(int pos, uint32_t rr) { r[(size_t)(pos & rmask)] = (uint8_t)rr; }
             void setscore(int pos, double x) { v[(size_t)(pos & smask)] = x; }
-            void fill(double x) { for (auto &e : v) e = x; for (auto &e : r) e = 0x12345678u; }      // (record slots are not initialised on the device either)
+            void fill(double x) { for (auto &e : v) e = x; for (auto &e : r) e = 0x5A; }      // (record slots are not initialised on the device either)
         };
-        struct HostSeek { const uint16_t *cp; uint32_t operator()(int i) const { return cp[i]; } void seek(int) const {} };
+        struct HostSeek { const uint16_t *cp; uint32_t operator()(int i) const { return cp[i]; } void seek(int) const {} void advance(int) const {} };
         int ring_n = 1; while (ring_n < m.trie_max_depth) ring_n <<= 1;
-        CutRing ring{std::vector<double>((size_t)ring_n), std::vector<uint32_t>((size_t)g_uni_cut_w), ring_n - 1, g_uni_cut_w - 1};
+        CutRing ring{std::vector<double>((size_t)ring_n), std::vector<uint8_t>((size_t)g_uni_cut_w), ring_n - 1, g_uni_cut_w - 1};
         HostSeek hs{cp};
         UniCut<HostSeek, CutRing> uc(S, hs, ring);
-        std::vector<uint32_t> spill_all((size_t)L + 64, 0xDEADBEEFu);
+        std::vector<uint8_t> spill_all((size_t)L + 64, (uint8_t)0xEE);
         uc.init(L, m.trie_max_depth, g_uni_cut_w, spill_all.data() + 32);
         std::vector<uint32_t> toks((size_t)L + 1, 0xDEADBEEFu);
         auto put = [&](int k, uint32_t v) { toks[(size_t)k] = v; };
@@ -315,24 +324,25 @@ static int emu_sp(const Model &m, const char *s, int n, int32_t *ids, int32_t *s
             const int span = uc.i - uc.cut0 + 1;
             if (g_uni_cut_period == 1 && span > widest) widest = span;
             const int st = uc.wstep();
+            if (g_uni_cut_quick && step % 3 == 0) uc.quick(put);
             if (st == UC_STALL || st == UC_DONE || step % (unsigned long long)g_uni_cut_period == 0) {
                 if (uc.pending()) { const int before = uc.nout; uc.emit(put); ++chunks; if (uc.nout <= before) ++restarts; }
                 else if (st == UC_STALL) { uc.spill(); ++spills; }
             }
             if (st == UC_DONE) break;
         }
-        if (spill_all[31] != 0xDEADBEEFu || spill_all[(size_t)L + 32] != 0xDEADBEEFu) return -3;     // a spill left the document's own range
+        if (spill_all[31] != 0xEE || spill_all[(size_t)L + 32] != 0xEE) return -3;     // a spill left the document's own range
         ++g_uni_cut_stats[0];
         if (spills) ++g_uni_cut_stats[1];
         g_uni_cut_stats[5] += spills;
         {
-            g_uni_cut_stats[2] += chunks; g_uni_cut_stats[3] += (unsigned long long)uc.nout; g_uni_cut_stats[4] += restarts;
+            g_uni_cut_stats[2] += chunks; g_uni_cut_stats[4] += restarts;
             if (g_uni_cut_period == 1) ++g_uni_cut_stats[8 + (widest < 259 ? widest : 259)];
             const int nout = uc.nout < max_ids ? uc.nout : max_ids;
-            for (int k = 0; k < nout; ++k) {
+            for (int k = 0; k < nout; ++k) {                                // what k_uni_ids does
                 const uint32_t v = toks[(size_t)k];
-                if (v == 0xDEADBEEFu) return -3;                           // a place no chunk wrote
-                { const int32_t id = v ? ((const SegInfo *)m.seg_info.data())[v - 1].id : -1; out.put(k, (id != -1 ? id : unk) + S.id_offset); }      // what k_compact_ids<keys> does
+                if (v == 0xDEADBEEFu) return -3;                            // a place no chunk wrote
+                out.put(k, uni_token_id(S, m.i2info_id.data(), hs, v, unk));
             }
             out.finish(nout);
             return nout;
@@ -348,7 +358,7 @@ static int emu_sp(const Model &m, const char *s, int n, int32_t *ids, int32_t *s
             void set(int pos, double x, uint32_t rr) { v[(size_t)(pos & mask)] = x; r[(size_t)(pos & mask)] = rr; }
             void fill(double x) { for (auto &e : v) e = x; for (auto &e : r) e = UNI_REC_NONE; }
         };
-        struct HostSeek { const uint16_t *cp; uint32_t operator()(int i) const { return cp[i]; } void seek(int) const {} };
+        struct HostSeek { const uint16_t *cp; uint32_t operator()(int i) const { return cp[i]; } void seek(int) const {} void advance(int) const {} };
         int ring_n = 1; while (ring_n < m.trie_max_depth) ring_n <<= 1;
         HostRing ring{std::vector<double>((size_t)ring_n), std::vector<uint32_t>((size_t)ring_n), ring_n - 1};
         HostSeek hs{cp};
@@ -480,28 +490,29 @@ int bft_uni_cut_fuzz(unsigned seed, int ndicts, int ntexts, unsigned long long *
             IdOutDirect ow{want.data(), nullptr};
             const int nw = seg_unigram_doc(S, cls_at, L, best.data(), ow, max_ids, unk);
             struct CutRing {
-                std::vector<double> v; std::vector<uint32_t> r; int smask, rmask;
+                std::vector<double> v; std::vector<uint8_t> r; int smask, rmask;
                 double score(int pos) const { return v[(size_t)(pos & smask)]; }
                 uint32_t rec(int pos) const { return r[(size_t)(pos & rmask)]; }
-                void set(int pos, double x, uint32_t rr) { v[(size_t)(pos & smask)] = x; r[(size_t)(pos & rmask)] = rr; }
-                void setrec(int pos, uint32_t rr) { r[(size_t)(pos & rmask)] = rr; }
+                void set(int pos, double x, uint32_t rr) { v[(size_t)(pos & smask)] = x; r[(size_t)(pos & rmask)] = (uint8_t)rr; }
+                void setrec(int pos, uint32_t rr) { r[(size_t)(pos & rmask)] = (uint8_t)rr; }
                 void setscore(int pos, double x) { v[(size_t)(pos & smask)] = x; }
-                void fill(double x) { for (auto &e : v) e = x; for (auto &e : r) e = 0x12345678u; }
+                void fill(double x) { for (auto &e : v) e = x; for (auto &e : r) e = 0x5A; }
             };
-            struct HostSeek { const uint16_t *cp; uint32_t operator()(int i) const { return cp[i]; } void seek(int) const {} };
+            struct HostSeek { const uint16_t *cp; uint32_t operator()(int i) const { return cp[i]; } void seek(int) const {} void advance(int) const {} };
             int ring_n = 1; while (ring_n < depth) ring_n <<= 1;
             int W = 16; while (W < depth + UC_SPILL) W <<= 1;
             if (rnd() % 4u == 0) W <<= 1;
-            CutRing ring{std::vector<double>((size_t)ring_n), std::vector<uint32_t>((size_t)W), ring_n - 1, W - 1};
+            CutRing ring{std::vector<double>((size_t)ring_n), std::vector<uint8_t>((size_t)W), ring_n - 1, W - 1};
             HostSeek hs{cp};
             UniCut<HostSeek, CutRing> uc(S, hs, ring);
-            std::vector<uint32_t> sp((size_t)L + 2, 0xDEADBEEFu);
+            std::vector<uint8_t> sp((size_t)L + 2, (uint8_t)0xEE);
             uc.init(L, depth, W, sp.data());
             std::vector<uint32_t> toks((size_t)L + 1, 0xDEADBEEFu);
             auto put = [&](int k, uint32_t v) { toks[(size_t)k] = v; };
-            const unsigned period = 1 + rnd() % 40u;
+            const unsigned period = 1 + rnd() % 40u, qper = 1 + rnd() % 5u;
             for (unsigned step = 1;; ++step) {
                 const int stt = uc.wstep();
+                if (step % qper == 0) uc.quick(put);
                 if (stt == UC_STALL || stt == UC_DONE || step % period == 0) {
                     if (uc.pending()) { const int before = uc.nout; uc.emit(put); if (uc.nout <= before) ++nrestart; }
                     else if (stt == UC_STALL) { uc.spill(); ++nspill; }
@@ -510,7 +521,14 @@ int bft_uni_cut_fuzz(unsigned seed, int ndicts, int ntexts, unsigned long long *
             }
             const int ng = uc.nout < max_ids ? uc.nout : max_ids;
             bool ok = ng == nw;
-            for (int k = 0; ok && k < ng; ++k) { const uint32_t v = toks[(size_t)k]; { const int32_t id = (v && v != 0xDEADBEEFu) ? info[(size_t)v - 1].id : -1; got[(size_t)k] = (id != -1 ? id : unk) + S.id_offset; } ok = v != 0xDEADBEEFu && got[(size_t)k] == want[(size_t)k]; }
+            std::vector<int32_t> idcol((size_t)nkeys + 1);
+            for (int k = 0; k < nkeys; ++k) idcol[(size_t)k] = info[(size_t)k].id;
+            for (int k = 0; ok && k < ng; ++k) {
+                const uint32_t v = toks[(size_t)k];
+                if (v == 0xDEADBEEFu) { ok = false; break; }
+                got[(size_t)k] = uni_token_id(S, idcol.data(), hs, v, unk);
+                ok = got[(size_t)k] == want[(size_t)k];
+            }
             if (!ok) ++bad;
         }
     }

@@ -110,6 +110,7 @@ UNIGRAM_MODELS = ["xlnet.bin", "xlnet_nonorm.bin", "laser50k.bin", "laser100k.bi
 
 def _cut_api(ht):
     ht.bft_set_uni_cut.argtypes = [ctypes.c_int, ctypes.c_int]
+    ht.bft_set_uni_cut_quick.argtypes = [ctypes.c_int]
     ht.bft_uni_cut_stats.argtypes = [ctypes.c_void_p, ctypes.c_int]
     ht.bft_uni_cut_fuzz.restype = ctypes.c_int
     ht.bft_uni_cut_fuzz.argtypes = [ctypes.c_uint, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
@@ -140,8 +141,9 @@ def test_unigram_cut_form_on_host(ht, model):
         want.append(ora.text_to_ids(ho, b, (1024, 3, 64, 1)[k % 4], (3, 0, 257)[k % 3]))
     try:
         seen = [0, 0, 0]
-        for W, period in ((32, 1), (32, 7), (32, 24), (64, 1 << 30)):
+        for W, period in ((32, 1), (32, 7), (32, 24), (64, 1 << 30), (32, 24)):
             ht.bft_set_uni_cut(W, period)
+            ht.bft_set_uni_cut_quick(0 if (W, period) == (32, 7) else 1)        # (once without the short way out: every chunk through the emission phase)
             ht.bft_uni_cut_stats(st, 1)
             for k, b in enumerate(docs):
                 mx, unk = (1024, 3, 64, 1)[k % 4], (3, 0, 257)[k % 3]
@@ -150,12 +152,13 @@ def test_unigram_cut_form_on_host(ht, model):
                 gc, gbuf = want[k]
                 assert c == gc and list(arr)[:c] == gbuf[:gc], (model, W, period, b[:60])
             ht.bft_uni_cut_stats(st, 1)
-            seen = [seen[0] + st[0], seen[1] + st[1], seen[2] + st[2]]
-        assert seen[0] > 0 and seen[2] > seen[0]          # the cut form did run: documents, chunks
+            seen = [seen[0] + st[0], seen[1] + st[1], seen[2] + st[2] + st[6]]
+        assert seen[0] > 0 and seen[2] > seen[0]          # the cut form did run: documents, chunks (emission phase + the short way)
         if model in ("xlm_roberta_base.bin", "laser500k.bin", "xlnet.bin"):
             assert seen[1] > 0                            # ... and some document spilled
     finally:
         ht.bft_set_uni_cut(0, 1)
+        ht.bft_set_uni_cut_quick(1)
     ora.free(ho)
     ht.bft_free(h)
 
@@ -174,13 +177,18 @@ def test_unigram_cut_form_on_multilingual_corpus(ht, model, workload):
     ho = ora.load(bfutil.model_path(model))
     mx, unk = wl["max_ids"], wl["unk"]
     arr = (ctypes.c_int32 * mx)()
+    # (+ a document of config 5 the first GPU run of the short way out got wrong: two entries of 15 and 16 symbols fill the ring, the walk
+    #  stalls, the short way out empties the ring in the same step -- and the spill that the stall had asked for moved records that were not final)
+    text2, off2 = bfutil.gen_workload(workload, 4, first_doc=3467790)
+    raw2 = text2.tobytes()
+    docs = [raw[off[d]:off[d + 1]] for d in range(len(off) - 1)] + [raw2[off2[d]:off2[d + 1]] for d in range(len(off2) - 1)]
     try:
-        ht.bft_set_uni_cut(32, 24)
-        for d in range(len(off) - 1):
-            b = raw[off[d]:off[d + 1]]
-            c = ht.bft_emu_text_to_ids(h, b, len(b), arr, mx, unk)
-            gc, gbuf = ora.text_to_ids(ho, b, mx, unk)
-            assert c == gc and list(arr)[:c] == gbuf[:gc], (model, d, b[:80])
+        for period in (24, 3, 96):
+            ht.bft_set_uni_cut(32, period)
+            for d, b in enumerate(docs if period == 24 else docs[-4:]):
+                c = ht.bft_emu_text_to_ids(h, b, len(b), arr, mx, unk)
+                gc, gbuf = ora.text_to_ids(ho, b, mx, unk)
+                assert c == gc and list(arr)[:c] == gbuf[:gc], (model, d, b[:80])
     finally:
         ht.bft_set_uni_cut(0, 1)
     ora.free(ho)

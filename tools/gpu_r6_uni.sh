@@ -1,8 +1,9 @@
 #!/bin/bash
 # round 6, Unigram cut form: GPU parity tests of the _sp branch, then config 4 / 5 lines (every document verified) for the cut form, the
-# round-4 kernels (variant 6) and a few emission periods / occupancies.   usage: tools/gpu_r6_uni.sh <tag>
+# round-4 kernels (variant 6) and a few emission periods / occupancies.   usage: tools/gpu_r6_uni.sh <tag> [variants...]
 set -u
-tag=${1:-r06_uni}; O=$PWD/gpurun_out/$tag; mkdir -p $O
+tag=${1:-r06_uni}; shift
+O=$PWD/gpurun_out/$tag; mkdir -p $O
 timeout 900 python -m pytest tests/test_gpu_parity_sp.py tests/test_gpu_api.py -m gpu -x -q > $O/pytest_sp.txt 2>&1; tail -3 $O/pytest_sp.txt
 show() { python - "$1" "$2" <<'PY'
 import json, sys
@@ -15,8 +16,7 @@ PY
 }
 for w in config4 config5; do
   timeout 600 python bench.py --workload $w --no-cpu-baseline --no-extra-timings > $O/bench_$w.json 2> $O/bench_$w.err; show $O/bench_$w.json "$w cut"
-  timeout 600 python bench.py --workload $w --no-cpu-baseline --no-extra-timings --verify 0 --variant 6 > $O/bench_${w}_v6.json 2> $O/bench_${w}_v6.err; show $O/bench_${w}_v6.json "$w round-4 kernels"
 done
-for v in $((3 + (4<<8))) $((3 + (16<<8))) $((3 + (32<<8))) $((3 + (8<<16))) $((3 + (6<<16))); do
+for v in "$@"; do
   timeout 600 python bench.py --workload config4 --no-cpu-baseline --no-extra-timings --verify 0 --variant $v > $O/bench_config4_var$v.json 2> $O/bench_config4_var$v.err; show $O/bench_config4_var$v.json "config4 variant $v"
 done
