@@ -1388,7 +1388,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     RingCut ring{seg_ring + lane, (uint8_t *)(seg_ring + (size_t)ring_n * 64) + lane, ring_n - 1, W - 1, ring_n};
     ClsWinS cls_at; cls_at.init(p.stream, 0);
     UniCut<ClsWinS, RingCut> uc(p.S, cls_at, ring);
-    uc.L = 0; uc.depth = p.trie_depth; uc.W = W; uc.start = uc.i = uc.sum = 0; uc.state = 0; uc.unknown = true; uc.pend = false; uc.prev = 0; uc.pend_i = 0;
+    uc.L = 0; uc.depth = p.trie_depth; uc.W = W; uc.start = uc.i = uc.sum = 0; uc.state = 0; uc.unknown = true; uc.pend = false; uc.walking = false; uc.prev = 0; uc.pend_i = 0;
     uc.pend_score = 0; uc.unk_run = 0; uc.reach = -1; uc.rk = 0; uc.rs = 0; uc.ck = 0; uc.cs = -1; uc.cut0 = 0; uc.lastcut = -1; uc.ring_lo = 0; uc.nout = 0;
     int mode = M_NEED;
     int64_t doc = 0; int32_t *toks = nullptr;
@@ -1421,21 +1421,22 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         }
         cls_at.refill(mode == M_WALK);
         // ---- forward pass: UNROLL trie transitions
-        bool stall = false;
         auto put = [&](int k, uint32_t v) { if (k < p.max_ids) toks[k] = (int32_t)v; };
-        if (mode == M_WALK) {
-            int st = UC_MORE;
+        // a trip: UNROLL transitions of the lane's walk (a walk that is over waits), then -- once, for all the lanes whose walk is over -- the
+        // end of the start position; the short way out for the chunks that are complete
+        const bool can = mode == M_WALK && uc.room(UNROLL);
+        const bool stall = mode == M_WALK && !can;
+        if (can) {
 #pragma unroll
-            for (int u = 0; u < UNROLL; ++u) { if (st == UC_MORE) st = uc.wstep(); }
-            if (st == UC_DONE) mode = M_FLUSH;
-            stall = st == UC_STALL;
-            if (quick) uc.quick(put);                // nine chunks in ten leave here (bf_seg.h)
+            for (int u = 0; u < UNROLL; ++u) { if (uc.walking) uc.step(); }
+            if (!uc.walking) { if (uc.finish_start() == UC_DONE) mode = M_FLUSH; }
+            if (quick) uc.quick(put);                // (A/B runs, BfSetVariant bit 0x20: chunks of one or two tokens leave here with their key, bf_seg.h)
         }
         // ---- emission phase: the chunks of several tokens in front of every lane's latest cut
         if (__ballot(mode == M_FLUSH || stall) != 0 || ((unsigned)trip & period_mask) == period_mask) {
             if (mode == M_WALK || mode == M_FLUSH) {
                 if (uc.pending()) uc.emit(put);
-                else if (stall) uc.spill();
+                else if (stall) uc.spill(UNROLL);
             }
             if (mode == M_FLUSH) {
                 p.counts[doc] = uc.nout < p.max_ids ? uc.nout : p.max_ids;
@@ -1453,8 +1454,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
 // array: this kernel is the compaction of the path too.
 // A wave takes 64 consecutive documents (count, slot, place: one document per lane, handed round with readlane as in k_compact_ids) and their
 // tokens 64 per trip: keys and unknowns are answered at once (64 independent look-ups); the words to walk go to a list in LDS and are walked
-// 64 at a time, whatever documents they come from -- every lane of a walk has a token, and a walk's symbols are read eight per load.
-constexpr int UNI_WL = 128;                       // the wave's list of words to walk (a ring: up to 63 wait while 64 more arrive)
+// 128 at a time, two per lane, whatever documents they come from -- every lane of a walk has tokens, and a walk's symbols are read eight per load.
+struct __attribute__((packed, aligned(2))) Sym8 { uint32_t x, y, z, w; };      // eight stream elements at a 2-byte aligned address: one 16-byte load
+constexpr int UNI_WM = 2;                         // words a lane walks at a time (independent chains: the dependent gathers of one hide behind the other's)
+constexpr int UNI_WL = 64 * UNI_WM * 2;           // the wave's list of words to walk (a ring: a batch waits while up to 64 more arrive)
 __global__ __launch_bounds__(256) void k_uni_ids(UniIdsParams p)
 {
     __shared__ int64_t wl_src[4][UNI_WL], wl_out[4][UNI_WL];
@@ -1465,24 +1468,36 @@ __global__ __launch_bounds__(256) void k_uni_ids(UniIdsParams p)
     const int64_t nwaves = (int64_t)gridDim.x * 4;
     bool over = false;
     uint32_t head = 0, tail = 0;                    // wave-uniform
-    auto walk64 = [&](int n) {                      // the first n (<= 64) words of the list
-        const bool act = lane < n;
-        int64_t src = 0, out = 0; int len = 0;
-        if (act) { const uint32_t e = (head + (uint32_t)lane) & (UNI_WL - 1); src = l_src[e]; out = l_out[e]; len = l_len[e]; }
-        uint32_t state = p.initial; int sum = 0;
-        uint4 blk = make_uint4(0, 0, 0, 0);
-        for (int j = 0; __any(j < len); ++j) {      // j is the same for every lane: the symbol's place in the block is a scalar
-            if ((j & 7) == 0 && j < len) __builtin_memcpy(&blk, p.stream + src + j, 16);     // (the element slot is 2-byte aligned only; the stream buffer is padded)
-            const int q = (j >> 1) & 3;
-            const uint32_t dw = q == 0 ? blk.x : q == 1 ? blk.y : q == 2 ? blk.z : blk.w;
-            const uint32_t c = (j & 1) ? dw >> 16 : dw & 0xFFFFu;
-            if (j < len) {
-                const uint64_t e = p.T[state + c];
-                state = (uint32_t)((e >> SG_NEXT_SHIFT) & SG_NEXT_MASK);
-                sum += (int)(e >> SG_OW_SHIFT);
+    auto walk_batch = [&](int n) {                  // the first n (<= 64 * UNI_WM) words of the list: lane l takes the words l, l + 64, ...
+        int64_t src[UNI_WM], out[UNI_WM]; int len[UNI_WM], sum[UNI_WM]; uint32_t state[UNI_WM]; uint64_t blo[UNI_WM], bhi[UNI_WM];      // (the eight symbols at hand: two 64-bit halves)
+        int maxlen = 0;
+#pragma unroll
+        for (int m = 0; m < UNI_WM; ++m) {
+            src[m] = 0; out[m] = 0; len[m] = 0; sum[m] = 0; state[m] = p.initial; blo[m] = bhi[m] = 0;
+            if (lane + 64 * m < n) { const uint32_t e = (head + (uint32_t)(lane + 64 * m)) & (UNI_WL - 1); src[m] = l_src[e]; out[m] = l_out[e]; len[m] = l_len[e]; }
+            maxlen = len[m] > maxlen ? len[m] : maxlen;
+        }
+        for (int j = 0; __any(j < maxlen); ++j) {   // j is the same for every lane: the symbol's place in the block is a scalar
+            uint64_t e[UNI_WM];
+#pragma unroll
+            for (int m = 0; m < UNI_WM; ++m) {
+                if ((j & 7) == 0 && j < len[m]) { const Sym8 v = *(const Sym8 *)(p.stream + src[m] + j); blo[m] = (uint64_t)v.x | ((uint64_t)v.y << 32); bhi[m] = (uint64_t)v.z | ((uint64_t)v.w << 32); }     // (the element slot is 2-byte aligned only; the stream buffer is padded)
+            }
+#pragma unroll
+            for (int m = 0; m < UNI_WM; ++m) {
+                const uint32_t c = (uint32_t)(((j & 4) ? bhi[m] : blo[m]) >> (16 * (j & 3))) & 0xFFFFu;
+                e[m] = j < len[m] ? p.T[state[m] + c] : 0ull;
+            }
+#pragma unroll
+            for (int m = 0; m < UNI_WM; ++m) {
+                if (j < len[m]) { state[m] = (uint32_t)((e[m] >> SG_NEXT_SHIFT) & SG_NEXT_MASK); sum[m] += (int)(e[m] >> SG_OW_SHIFT); }
             }
         }
-        if (act) { const int id = p.ids[sum]; p.ids_out[out] = (id != -1 ? id : p.unk) + p.id_offset; }
+        int id[UNI_WM];
+#pragma unroll
+        for (int m = 0; m < UNI_WM; ++m) id[m] = lane + 64 * m < n ? p.ids[sum[m]] : -1;
+#pragma unroll
+        for (int m = 0; m < UNI_WM; ++m) if (lane + 64 * m < n) p.ids_out[out[m]] = (id[m] != -1 ? id[m] : p.unk) + p.id_offset;
         head += (uint32_t)n;
     };
     for (int64_t base = wave0 * 64; base < p.b.ndocs; base += nwaves * 64) {
@@ -1517,12 +1532,12 @@ __global__ __launch_bounds__(256) void k_uni_ids(UniIdsParams p)
                     }
                     tail += (uint32_t)__popcll(wm);
                     wave_handoff();
-                    if (tail - head >= 64u) { walk64(64); wave_handoff(); }
+                    if (tail - head >= 64u * UNI_WM) { walk_batch(64 * UNI_WM); wave_handoff(); }
                 }
             }
         }
     }
-    if (tail != head) walk64((int)(tail - head));
+    if (tail != head) walk_batch((int)(tail - head));
     if (over) atomicOr(p.status, 1);
 }
 
@@ -1609,7 +1624,7 @@ void launch_seg_sp(const SpSegParams &p_in, hipStream_t s)
 #endif
             if (p.uni_cut) {
                 // the cut form (ids only): records in LDS, tokens out at the cuts, no backward kernel
-                int W = 32; while (W < p.trie_depth + UC_SPILL) W <<= 1;
+                int W = 32; while (W < p.trie_depth + UC_SPILL + 4) W <<= 1;
                 const size_t lds_c = (size_t)ring * 64 * sizeof(double) + (size_t)W * 64;
                 int pc = 0;
                 if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&pc, (const void *)k_uni_cut<3>, 64, lds_c) != hipSuccess || pc <= 0) pc = 8;
@@ -1617,11 +1632,11 @@ void launch_seg_sp(const SpSegParams &p_in, hipStream_t s)
                 if (p.tune2 > 0 && p.tune2 < pc) pc = p.tune2;
                 unsigned blocks = (unsigned)device_cus() * (unsigned)pc;
                 if ((int64_t)blocks > (int64_t)b64) blocks = b64;
-                unsigned period_mask = 7u;
+                unsigned period_mask = 31u;
                 if (p.tune > 0) { period_mask = 1u; while (period_mask + 1u < (unsigned)p.tune) period_mask = period_mask * 2u + 1u; if (p.tune == 1) period_mask = 0u; }
                 if (p.ev_dom0) (void)hipEventRecord((hipEvent_t)p.ev_dom0, s);
-                if (p.variant & 0x10) hipLaunchKernelGGL(k_uni_cut<2>, dim3(blocks), dim3(64), lds_c, s, p, ring, W, period_mask, (p.variant & 0x20) ? 0 : 1);
-                else hipLaunchKernelGGL(k_uni_cut<3>, dim3(blocks), dim3(64), lds_c, s, p, ring, W, period_mask, (p.variant & 0x20) ? 0 : 1);
+                if (p.variant & 0x10) hipLaunchKernelGGL(k_uni_cut<2>, dim3(blocks), dim3(64), lds_c, s, p, ring, W, period_mask, (p.variant & 0x20) ? 1 : 0);
+                else hipLaunchKernelGGL(k_uni_cut<3>, dim3(blocks), dim3(64), lds_c, s, p, ring, W, period_mask, (p.variant & 0x20) ? 1 : 0);
                 if (p.ev_dom1) (void)hipEventRecord((hipEvent_t)p.ev_dom1, s);
                 return;
             }

@@ -306,7 +306,7 @@ BF_HD uint32_t uc_unk_rec(int run) { const uint32_t f = (uint32_t)(run - 1); ret
 template <class ClsAt, class Ring>
 struct UniCut {
     const SegTables &S; ClsAt &cls_at; Ring &ring; uint8_t *recs;
-    int L, depth, W, start, i, sum; uint32_t state; bool unknown, pend; double prev; uint32_t pend_score; int pend_i;
+    int L, depth, W, start, i, sum; uint32_t state; bool unknown, pend, walking; double prev; uint32_t pend_score; int pend_i;
     int unk_run;
     int reach, rk, rs;                                 // last position a dictionary arc found so far ends at; MPH index and start of the arc that moved it there
     int ck, cs;                                        // the same two of the arc that moved `reach` to the latest cut (cs == -1: none)
@@ -324,7 +324,7 @@ struct UniCut {
         ring.fill(neg_flt_max());
         start = 0; prev = 0; pend = false; pend_i = 0; pend_score = 0;
         unk_run = 0; reach = -1; rk = 0; rs = 0; ck = 0; cs = -1; cut0 = 0; lastcut = -1; ring_lo = 0; nout = 0;
-        i = 0; state = S.initial; sum = 0; unknown = true;
+        i = 0; state = S.initial; sum = 0; unknown = true; walking = true;
         cls_at.seek(0);
     }
     BF_HD void relax()
@@ -334,14 +334,15 @@ struct UniCut {
         pend = false;
     }
     BF_HD bool pending() const { return lastcut >= cut0; }
-    BF_HD bool stalled() const { return i - ring_lo >= W; }
+    BF_HD bool room(int k) const { return i + k - 1 - ring_lo < W; }     // room in the ring for k more steps (a step may write the record of position i)
+    BF_HD bool stalled() const { return !room(1); }
     BF_HD uint32_t rec_at(int e) const { return e >= ring_lo ? ring.rec(e) : (uint32_t)recs[e]; }
-    // a stalled lane with nothing to emit: its oldest final records go to memory (the walk is at most depth - 1 positions ahead of `start`,
-    // so W >= depth + UC_SPILL leaves at least UC_SPILL final ones in the ring)
-    BF_HD void spill()
+    // a lane without room for k more steps and with nothing to emit: its oldest final records go to memory (the walk is at most depth - 1
+    // positions ahead of `start`, so W >= depth + UC_SPILL + k leaves at least UC_SPILL final ones in the ring)
+    BF_HD void spill(int k = 1)
     {
-        if (!stalled()) return;                                         // (the short way out may have made room since the walk stalled)
-        for (int k = 0; k < UC_SPILL; ++k) recs[ring_lo + k] = (uint8_t)ring.rec(ring_lo + k);
+        if (room(k)) return;                                            // (the short way out may have made room since the walk stalled)
+        for (int q = 0; q < UC_SPILL; ++q) recs[ring_lo + q] = (uint8_t)ring.rec(ring_lo + q);
         ring_lo += UC_SPILL;
     }
 
@@ -354,59 +355,70 @@ struct UniCut {
         return UC_TOK_KEY | (uint32_t)sm;
     }
 
-    // the walk from `start` has reached position i in `state`: take the transition entry e that was gathered for the symbol class c there
-    // (AddArc's part of ..._1best_t.h:203-226 for a final destination).  Returns whether the walk is over.
-    BF_HD bool consume(uint64_t e, uint32_t c)
-    {
-        if (!(c < SG_CLS_DELIM_ABSENT && (e & SG_CLS_MASK) == c)) return true;          // no such transition (sg_lookup)
-        state = (uint32_t)((e >> SG_NEXT_SHIFT) & SG_NEXT_MASK);
-        sum += (int)(e >> SG_OW_SHIFT);
-        if (e & SG_FINAL) {
-            pend_score = S.score[sum]; pend_i = i; pend = true; unknown = false;           // requested now, relaxed at the next step
-            const bool ext = i > reach;
-            reach = ext ? i : reach; rk = ext ? sum : rk; rs = ext ? start : rs;
-        }
-        ++i;
-        return i >= L || state - S.leaf_lo < S.leaf_n;                  // (a state without transitions: the next GetDestOw would fail, ..._1best_t.h:209-212)
-    }
-    // One trie transition of the walk from `start` (UniLane::wstep) and, when that walk is over, the end of its start position.
-    // UC_STALL: the ring is full -- emit() or spill() first (nothing was done).
+    // One trie transition of the walk from `start` (the walk must be on: `walking`): the gather for the symbol at position i, the
+    // relaxation of the arc the step before found while it travels (AddArc, ..._1best_t.h:118-142), the transition.  The walk is over
+    // (`walking` false) behind a symbol without transition, at the end of the document, and in a state without transitions (the next
+    // GetDestOw would fail, ..._1best_t.h:209-212); finish_start() then ends the start position.
     // (Measured and removed again, round 6: the first transition of the NEXT walk gathered one walk ahead -- it depends on nothing but the symbol
-    //  there -- takes a third of the steps out and made the kernel 4 ms SLOWER: its time is the gathers' -- 22 G of them per 10 M documents into
-    //  3.6 MB of tables, at the rate tools/microbench/gather_sweep.hip finds for that footprint --, not the length of a lane's chain.)
+    //  there -- takes a third of the steps out and made the kernel 4 ms slower: its time is instruction issue and the gathers' rate, not the
+    //  length of a lane's chain.)
+    BF_HD void step()
+    {
+        const uint32_t c = cls_at(i);
+        const bool valid = c < SG_CLS_DELIM_ABSENT;
+        const uint64_t e = S.T[state + (valid ? c : 0u)];               // the gather is issued ...
+        if (pend) relax();                                              // ... and the previous arc is relaxed while it travels
+        const bool hit = valid && (uint32_t)(e & SG_CLS_MASK) == c;
+        if (hit) {
+            state = (uint32_t)((e >> SG_NEXT_SHIFT) & SG_NEXT_MASK);
+            sum += (int)(e >> SG_OW_SHIFT);
+            if (e & SG_FINAL) {
+                pend_score = S.score[sum]; pend_i = i; pend = true; unknown = false;       // requested now, relaxed at the next step
+                const bool ext = i > reach;
+                reach = ext ? i : reach; rk = ext ? sum : rk; rs = ext ? start : rs;
+            }
+            ++i;
+        }
+        walking = hit && i < L && !(state - S.leaf_lo < S.leaf_n);
+    }
+
+    // The walk from `start` is over: the position is final (AddUnknownArc ..._1best_t.h:145-171 if no arc began here), a cut is noted, the
+    // next walk is set up.  UC_DONE behind the document's last position.
+    BF_HD int finish_start()
+    {
+        if (pend) relax();
+        double fin = ring.score(start);
+        uint32_t r = ring.rec(start);
+        int run = 0;
+        if (unknown) {
+            const float unk_score = -100000.0f;
+            const double cand = unk_score + prev;
+            if (fin < cand) { run = unk_run + 1; r = uc_unk_rec(run); fin = cand; }
+        }
+        const bool none = !(neg_flt_max() < fin);                       // no incoming arc at all (..._1best_t.h:61-77); its record slot was never written
+        if (none) r = UC_NONE;
+        unk_run = run;
+        if (run != 0 || none) ring.setrec(start, r);
+        const bool piece = !none && run == 0;
+        if ((piece && reach <= start) || start == L - 1) {              // a cut: remember what is known about the arc that ends here (quick())
+            lastcut = start; ck = rk; cs = (piece && reach == start) ? rs : -1;
+        }
+        ++start;
+        if (!(start < L)) return UC_DONE;
+        prev = fin;
+        ring.setscore(start + depth - 1, neg_flt_max());                // the position that enters the reach of this start
+        i = start; state = S.initial; sum = 0; unknown = true; walking = true;
+        cls_at.advance(start);
+        return UC_MORE;
+    }
+
+    // step() and finish_start() as one call (the host drivers; the device runs a few steps, then the finish, once per trip).
+    // UC_STALL: the ring is full -- emit() or spill() first (nothing was done).
     BF_HD int wstep()
     {
         if (stalled()) return UC_STALL;
-        const uint32_t c = cls_at(i);
-        const uint64_t e = S.T[state + (c < SG_CLS_DELIM_ABSENT ? c : 0u)];           // the gather is issued ...
-        if (pend) relax();                                                              // ... and the previous arc is relaxed while it travels
-        const bool ends = consume(e, c);
-        if (ends) {
-            if (pend) relax();
-            double fin = ring.score(start);
-            uint32_t r = ring.rec(start);
-            int run = 0;
-            if (unknown) {                                              // AddUnknownArc (..._1best_t.h:145-171)
-                const float unk_score = -100000.0f;
-                const double cand = unk_score + prev;
-                if (fin < cand) { run = unk_run + 1; r = uc_unk_rec(run); fin = cand; }
-            }
-            const bool none = !(neg_flt_max() < fin);                   // no incoming arc at all (..._1best_t.h:61-77); its record slot was never written
-            if (none) r = UC_NONE;
-            unk_run = run;
-            if (run != 0 || none) ring.setrec(start, r);
-            const bool piece = !none && run == 0;
-            if ((piece && reach <= start) || start == L - 1) {          // a cut: remember what is known about the arc that ends here (quick())
-                lastcut = start; ck = rk; cs = (piece && reach == start) ? rs : -1;
-            }
-            ++start;
-            if (!(start < L)) return UC_DONE;
-            prev = fin;
-            ring.setscore(start + depth - 1, neg_flt_max());            // the position that enters the reach of this start
-            i = start; state = S.initial; sum = 0; unknown = true;
-            cls_at.advance(start);
-        }
-        return UC_MORE;
+        step();
+        return walking ? (int)UC_MORE : finish_start();
     }
 
     // The short way out, once per trip of the driver: the chunk [cut0, lastcut] when it is ONE token, or two, both dictionary entries -- nine

@@ -29,6 +29,7 @@ using namespace bfa;
 static long g_big_pool = 64l << 20;   // bft_set_big_pool: bytes of the pool behind seg_bpe_doc_big (the device's is 64 MiB per batch)
 static int g_uni_cut_w = 0;   // bft_set_uni_cut(W, period): Unigram through the cut form (bf_seg.h UniCut) with a record ring of W positions; emission every `period` steps
 static int g_uni_cut_period = 1;
+static int g_uni_cut_k = 3;         // bft_set_uni_cut_k: transitions per trip of the driver (the device: 3)
 static int g_uni_cut_quick = 1;     // bft_set_uni_cut_quick(0): every chunk through the emission phase
 static unsigned long long g_uni_cut_stats[8 + 260];   // [0] documents, [1] given up (hard), [2] chunks, [3] tokens, [4] restarts; [8 + k] documents whose widest pending span (start + depth - cut0, emitted as soon as possible) was k
 static int g_uni_seq = 0;     // bft_set_uni_seq(1): Unigram through the plain sequential restatement (seg_unigram_doc) instead of UniLane
@@ -64,6 +65,7 @@ int bft_lexer_void(void *hv) { return ((Handle *)hv)->m.lexer_void ? 1 : 0; }
 void bft_free(void *hv) { delete (Handle *)hv; }
 void bft_set_no_ff(int v) { g_no_ff = v; }
 void bft_set_uni_cut_quick(int v) { g_uni_cut_quick = v; }
+void bft_set_uni_cut_k(int k) { g_uni_cut_k = k < 1 ? 1 : (k > 4 ? 4 : k); }
 void bft_set_uni_cut(int w, int period) { g_uni_cut_w = w; g_uni_cut_period = period > 0 ? period : 1; }
 void bft_uni_cut_stats(unsigned long long *out, int reset)
 {
@@ -320,16 +322,25 @@ static int emu_sp(const Model &m, const char *s, int n, int32_t *ids, int32_t *s
         std::vector<uint32_t> toks((size_t)L + 1, 0xDEADBEEFu);
         auto put = [&](int k, uint32_t v) { toks[(size_t)k] = v; };
         int widest = 0; unsigned long long chunks = 0, restarts = 0, spills = 0;
-        for (unsigned long long step = 1;; ++step) {
+        // the trip of k_uni_cut: K transitions of the walk (a walk that is over waits), the end of the start position once, the short way out; the
+        // emission phase when the document is done, the ring has no room, or every `period` trips
+        const int K = g_uni_cut_k;
+        for (unsigned long long trip = 1;; ++trip) {
             const int span = uc.i - uc.cut0 + 1;
             if (g_uni_cut_period == 1 && span > widest) widest = span;
-            const int st = uc.wstep();
-            if (g_uni_cut_quick && step % 3 == 0) uc.quick(put);
-            if (st == UC_STALL || st == UC_DONE || step % (unsigned long long)g_uni_cut_period == 0) {
-                if (uc.pending()) { const int before = uc.nout; uc.emit(put); ++chunks; if (uc.nout <= before) ++restarts; }
-                else if (st == UC_STALL) { uc.spill(); ++spills; }
+            const bool can = uc.room(K);
+            bool done = false;
+            if (can) {
+                for (int u = 0; u < K; ++u) if (uc.walking) uc.step();
+                if (!uc.walking) done = uc.finish_start() == UC_DONE;
+                if (g_uni_cut_quick) uc.quick(put);
             }
-            if (st == UC_DONE) break;
+            if (done || !can || trip % (unsigned long long)g_uni_cut_period == 0) {
+                if (uc.pending()) { const int before = uc.nout; uc.emit(put); ++chunks; if (uc.nout <= before) ++restarts; }
+                else if (!can) { uc.spill(K); ++spills; }
+            }
+            if (done) break;
+            if (trip > 64ull * (unsigned long long)L + 1024ull) return -5;      // the driver does not make progress
         }
         if (spill_all[31] != 0xEE || spill_all[(size_t)L + 32] != 0xEE) return -3;     // a spill left the document's own range
         ++g_uni_cut_stats[0];
@@ -500,7 +511,7 @@ int bft_uni_cut_fuzz(unsigned seed, int ndicts, int ntexts, unsigned long long *
             };
             struct HostSeek { const uint16_t *cp; uint32_t operator()(int i) const { return cp[i]; } void seek(int) const {} void advance(int) const {} };
             int ring_n = 1; while (ring_n < depth) ring_n <<= 1;
-            int W = 16; while (W < depth + UC_SPILL) W <<= 1;
+            int W = 16; while (W < depth + UC_SPILL + 4) W <<= 1;
             if (rnd() % 4u == 0) W <<= 1;
             CutRing ring{std::vector<double>((size_t)ring_n), std::vector<uint8_t>((size_t)W), ring_n - 1, W - 1};
             HostSeek hs{cp};
@@ -509,16 +520,24 @@ int bft_uni_cut_fuzz(unsigned seed, int ndicts, int ntexts, unsigned long long *
             uc.init(L, depth, W, sp.data());
             std::vector<uint32_t> toks((size_t)L + 1, 0xDEADBEEFu);
             auto put = [&](int k, uint32_t v) { toks[(size_t)k] = v; };
-            const unsigned period = 1 + rnd() % 40u, qper = 1 + rnd() % 5u;
-            for (unsigned step = 1;; ++step) {
-                const int stt = uc.wstep();
-                if (step % qper == 0) uc.quick(put);
-                if (stt == UC_STALL || stt == UC_DONE || step % period == 0) {
-                    if (uc.pending()) { const int before = uc.nout; uc.emit(put); if (uc.nout <= before) ++nrestart; }
-                    else if (stt == UC_STALL) { uc.spill(); ++nspill; }
+            const unsigned period = 1 + rnd() % 40u; const int K = 1 + (int)(rnd() % 4u); const bool use_quick = rnd() % 4u != 0;
+            bool hang = false;
+            for (unsigned trip = 1;; ++trip) {                            // the trip of k_uni_cut (emu_sp above)
+                const bool can = uc.room(K);
+                bool done = false;
+                if (can) {
+                    for (int u = 0; u < K; ++u) if (uc.walking) uc.step();
+                    if (!uc.walking) done = uc.finish_start() == UC_DONE;
+                    if (use_quick) uc.quick(put);
                 }
-                if (stt == UC_DONE) break;
+                if (done || !can || trip % period == 0) {
+                    if (uc.pending()) { const int before = uc.nout; uc.emit(put); if (uc.nout <= before) ++nrestart; }
+                    else if (!can) { uc.spill(K); ++nspill; }
+                }
+                if (done) break;
+                if (trip > 64u * (unsigned)L + 1024u) { hang = true; break; }
             }
+            if (hang) { ++bad; continue; }
             const int ng = uc.nout < max_ids ? uc.nout : max_ids;
             bool ok = ng == nw;
             std::vector<int32_t> idcol((size_t)nkeys + 1);

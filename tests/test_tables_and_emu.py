@@ -111,6 +111,7 @@ UNIGRAM_MODELS = ["xlnet.bin", "xlnet_nonorm.bin", "laser50k.bin", "laser100k.bi
 def _cut_api(ht):
     ht.bft_set_uni_cut.argtypes = [ctypes.c_int, ctypes.c_int]
     ht.bft_set_uni_cut_quick.argtypes = [ctypes.c_int]
+    ht.bft_set_uni_cut_k.argtypes = [ctypes.c_int]
     ht.bft_uni_cut_stats.argtypes = [ctypes.c_void_p, ctypes.c_int]
     ht.bft_uni_cut_fuzz.restype = ctypes.c_int
     ht.bft_uni_cut_fuzz.argtypes = [ctypes.c_uint, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
@@ -141,9 +142,10 @@ def test_unigram_cut_form_on_host(ht, model):
         want.append(ora.text_to_ids(ho, b, (1024, 3, 64, 1)[k % 4], (3, 0, 257)[k % 3]))
     try:
         seen = [0, 0, 0]
-        for W, period in ((32, 1), (32, 7), (32, 24), (64, 1 << 30), (32, 24)):
+        for W, period, K in ((32, 1, 3), (32, 3, 3), (32, 8, 1), (64, 1 << 30, 3), (32, 8, 3), (32, 32, 2), (32, 32, 4)):     # (period: trips of the driver, K transitions each)
             ht.bft_set_uni_cut(W, period)
-            ht.bft_set_uni_cut_quick(0 if (W, period) == (32, 7) else 1)        # (once without the short way out: every chunk through the emission phase)
+            ht.bft_set_uni_cut_k(K)
+            ht.bft_set_uni_cut_quick(0 if (W, period) == (32, 3) else 1)        # (once without the short way out: every chunk through the emission phase)
             ht.bft_uni_cut_stats(st, 1)
             for k, b in enumerate(docs):
                 mx, unk = (1024, 3, 64, 1)[k % 4], (3, 0, 257)[k % 3]
@@ -159,6 +161,7 @@ def test_unigram_cut_form_on_host(ht, model):
     finally:
         ht.bft_set_uni_cut(0, 1)
         ht.bft_set_uni_cut_quick(1)
+        ht.bft_set_uni_cut_k(3)
     ora.free(ho)
     ht.bft_free(h)
 
@@ -183,9 +186,9 @@ def test_unigram_cut_form_on_multilingual_corpus(ht, model, workload):
     raw2 = text2.tobytes()
     docs = [raw[off[d]:off[d + 1]] for d in range(len(off) - 1)] + [raw2[off2[d]:off2[d + 1]] for d in range(len(off2) - 1)]
     try:
-        for period in (24, 3, 96):
+        for period in (8, 1, 32):
             ht.bft_set_uni_cut(32, period)
-            for d, b in enumerate(docs if period == 24 else docs[-4:]):
+            for d, b in enumerate(docs if period == 8 else docs[-4:]):
                 c = ht.bft_emu_text_to_ids(h, b, len(b), arr, mx, unk)
                 gc, gbuf = ora.text_to_ids(ho, b, mx, unk)
                 assert c == gc and list(arr)[:c] == gbuf[:gc], (model, d, b[:80])
@@ -207,7 +210,7 @@ def test_unigram_cut_form_long_unknown_runs(ht):
     ho = ora.load(bfutil.model_path(model))
     arr = (ctypes.c_int32 * 4096)()
     try:
-        ht.bft_set_uni_cut(32, 24)
+        ht.bft_set_uni_cut(32, 8)
         for n in (30, 100, 4094, 4095, 4096, 4097, 8191, 12290):
             b = ("hello " + "\U000F0000" * n + " world " + "\U000F0000" * 3 + "x").encode("utf-8")
             c = ht.bft_emu_text_to_ids(h, b, len(b), arr, 4096, 7)

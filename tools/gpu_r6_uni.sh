@@ -4,7 +4,7 @@
 set -u
 tag=${1:-r06_uni}; shift
 O=$PWD/gpurun_out/$tag; mkdir -p $O
-timeout 900 python -m pytest tests/test_gpu_parity_sp.py tests/test_gpu_api.py -m gpu -x -q > $O/pytest_sp.txt 2>&1; tail -3 $O/pytest_sp.txt
+timeout 400 python -m pytest tests/test_gpu_parity_sp.py tests/test_gpu_api.py -m gpu -x -q > $O/pytest_sp.txt 2>&1; tail -3 $O/pytest_sp.txt
 show() { python - "$1" "$2" <<'PY'
 import json, sys
 try:
@@ -15,8 +15,8 @@ except Exception as e: print(sys.argv[2], "failed", e)
 PY
 }
 for w in config4 config5; do
-  timeout 600 python bench.py --workload $w --no-cpu-baseline --no-extra-timings > $O/bench_$w.json 2> $O/bench_$w.err; show $O/bench_$w.json "$w cut"
+  timeout 240 python bench.py --workload $w --no-cpu-baseline --no-extra-timings > $O/bench_$w.json 2> $O/bench_$w.err; show $O/bench_$w.json "$w cut"
 done
 for v in "$@"; do
-  timeout 600 python bench.py --workload config4 --no-cpu-baseline --no-extra-timings --verify 0 --variant $v > $O/bench_config4_var$v.json 2> $O/bench_config4_var$v.err; show $O/bench_config4_var$v.json "config4 variant $v"
+  timeout 240 python bench.py --workload config4 --no-cpu-baseline --no-extra-timings --verify 0 --variant $v > $O/bench_config4_var$v.json 2> $O/bench_config4_var$v.err; show $O/bench_config4_var$v.json "config4 variant $v"
 done
