@@ -562,6 +562,11 @@ def main():
             "roofline": {"bound": "hbm", "kernel": kernel_name, "achieved": achieved, "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_stale": traffic_stale, "l2_hit_rate": l2_hit,
                          "kernel_ms": dom_ms, "algorithmic_bytes_per_launch": alg_bytes, "launches_per_step": len(batches),
+                         # the step's ids are WRITTEN by the kernels behind the dominant one (k_wp_merge, k_uni_ids ...), so `achieved` credits the
+                         # dominant kernel with bytes it does not move; `step` below is the honest whole-path figure, and this is the dominant kernel on the
+                         # bytes of the step's INPUT alone (what every form of the path has to read once in that kernel)
+                         "input_only": {"bytes": total_bytes + 8 * ndocs, "achieved": (total_bytes + 8 * ndocs) / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0,
+                                        "frac": ((total_bytes + 8 * ndocs) / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if dom_ms > 0 else 0.0},
                          "traffic_dominant_kernel": traffic_dom, "traffic_by_kernel": traffic_kernels,
                          "step": {"kernels": step_kernels, "ms": step_ms, "achieved": alg_bytes / (step_ms * 1e-3) / 1e9 if step_ms > 0 else 0.0,
                                   "frac": (alg_bytes / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if step_ms > 0 else 0.0,

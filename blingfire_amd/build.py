@@ -45,6 +45,14 @@ def build_product(force=False):
     srcs = [os.path.join(CSRC, f) for f in names]
     deps = srcs + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + [
         os.path.join(ROOT, "include", "blingfiretokdll_amd.h"), os.path.join(CSRC, "exports.map"), os.path.join(ROOT, "models", "wbd.bin"), os.path.join(ROOT, "models", "sbd.bin")]
+    odir0 = os.path.join(CSRC, "obj")
+    os.makedirs(odir0, exist_ok=True)
+    # the flag set is part of what the library is built from: toggling BF_EXPERIMENTS must not keep the old objects
+    stamp = os.path.join(odir0, "flags.stamp")
+    want = "experiments" if os.environ.get("BF_EXPERIMENTS") else "product"
+    have = open(stamp).read().strip() if os.path.exists(stamp) else ""
+    if have != want:
+        force = True
     if force or _newer(PRODUCT, deps):
         # the reference compiles its default word- and sentence-breaking models (wbd.bin, sbd.bin) into the library; same here (data, via .incbin)
         wbd = os.path.join(ROOT, "models", "wbd.bin")
@@ -63,6 +71,8 @@ def build_product(force=False):
             if pr.wait() != 0:
                 raise subprocess.CalledProcessError(pr.returncode, cmd)
         _run([hipcc(), "--offload-arch=gfx950", "--offload-compress", "-shared", "-fPIC", "-Wl,-s", "-Wl,--version-script=" + os.path.join(CSRC, "exports.map")] + objs + ["-o", PRODUCT])
+        with open(stamp, "w") as f:
+            f.write(want + "\n")
     return PRODUCT
 
 

@@ -952,6 +952,7 @@ int64_t run_i2t_host(Handle *h, const int32_t *ids, const int64_t *id_off, int64
     if (nseq < 0 || !id_off || (nseq > 0 && id_off[nseq] > id_off[0] && !ids)) return BF_E_ARG;
     const int64_t base = id_off[0], total_ids = nseq > 0 ? id_off[nseq] - base : 0;
     if (total_ids < 0) return BF_E_ARG;
+    std::lock_guard<std::mutex> dlock(h->defer_mu);      // (the id buffers this call uses may hold a sharded range's ids that wait for their copy out)
     std::lock_guard<std::mutex> lock(h->mu);
     DeviceGuard dg(h->device); if (!dg.ok) return BF_E_DEVICE;
     hipStream_t s = h->stream;
@@ -1332,6 +1333,7 @@ int64_t text_batch_host(void *p, const char *text, const int64_t *doc_off, int64
     if (ndocs < 0 || !doc_off || (ndocs > 0 && !text && doc_off[ndocs] > doc_off[0])) return BF_E_ARG;
     const int64_t base = doc_off[0], total = ndocs > 0 ? doc_off[ndocs] - base : 0;
     if (total < 0) return BF_E_ARG;
+    std::lock_guard<std::mutex> dlock(h->defer_mu);      // (the id buffers this call uses may hold a sharded range's ids that wait for their copy out)
     std::lock_guard<std::mutex> lock(h->mu);
     DeviceGuard dg(h->device); if (!dg.ok) return BF_E_DEVICE;
     hipStream_t s = h->stream;
@@ -1523,6 +1525,7 @@ int TextToWordsBatchDevice(void *p, const char *d_text, const int64_t *d_doc_off
 {
     Handle *h = p ? as_handle(p) : default_wbd();
     if (!h) return BF_E_ARG;
+    std::lock_guard<std::mutex> dlock(h->defer_mu);      // (the id buffers this call uses may hold a sharded range's ids that wait for their copy out)
     std::lock_guard<std::mutex> lock(h->mu);
     DeviceGuard dg(h->device); if (!dg.ok) return BF_E_DEVICE;
     return run_words_device(h, d_text, d_doc_off, ndocs, total_bytes, d_text_out, text_cap, d_text_off_out, (hipStream_t)stream, true);
@@ -1533,6 +1536,7 @@ int TextToSentencesBatchDevice(void *p, const char *d_text, const int64_t *d_doc
 {
     Handle *h = p ? as_handle(p) : default_sbd();
     if (!h) return BF_E_ARG;
+    std::lock_guard<std::mutex> dlock(h->defer_mu);      // (the id buffers this call uses may hold a sharded range's ids that wait for their copy out)
     std::lock_guard<std::mutex> lock(h->mu);
     DeviceGuard dg(h->device); if (!dg.ok) return BF_E_DEVICE;
     return run_words_device(h, d_text, d_doc_off, ndocs, total_bytes, d_text_out, text_cap, d_text_off_out, (hipStream_t)stream, true, 2);
@@ -1602,6 +1606,7 @@ int TextToHashes(const char *s, int n, int32_t *hashes, const int max_hashes, in
     int tokens = 0;
     Handle *h = util_handle();
     if (!h) return -1;
+    std::lock_guard<std::mutex> dlock(h->defer_mu);      // (the id buffers this call uses may hold a sharded range's ids that wait for their copy out)
     std::lock_guard<std::mutex> lock(h->mu);
     DeviceGuard dg(h->device); if (!dg.ok) return -1;
     hipStream_t st = h->stream;
@@ -1625,6 +1630,7 @@ int64_t TextToHashesBatch(const char *text, const int64_t *doc_off, int64_t ndoc
     if (ngrams <= 0 || bucket == 0) return BF_E_ARG;
     Handle *h = util_handle();
     if (!h) return BF_E_DEVICE;
+    std::lock_guard<std::mutex> dlock(h->defer_mu);      // (the id buffers this call uses may hold a sharded range's ids that wait for their copy out)
     std::lock_guard<std::mutex> lock(h->mu);
     DeviceGuard dg(h->device); if (!dg.ok) return BF_E_DEVICE;
     hipStream_t s = h->stream;
@@ -1976,6 +1982,7 @@ const char *BfTokeniseKernel(void *p)
 {
     Handle *h = as_handle(p);
     if (!h) return "";
+    std::lock_guard<std::mutex> lock(h->mu);          // (last_flat / last_uni_cut / variant are written under it by the batch calls)
     switch (h->m.kind) {
     case KIND_WP: return h->last_flat ? "k_wp_flat" : use_wave(h, false, 0) ? "k_wp_wave" : (h->m.two_level ? "k_lex_wp_plain" : "k_lex_wp_flat");
     case KIND_UNIGRAM: return h->last_uni_cut ? "k_uni_cut" : "k_seg_unigram_lane";
@@ -1989,6 +1996,7 @@ const char *BfStepKernels(void *p)
 {
     Handle *h = as_handle(p);
     if (!h) return "";
+    std::lock_guard<std::mutex> lock(h->mu);
     switch (h->m.kind) {
     case KIND_WP:
         if (h->last_flat) return "prep: k_wp_pre | tokenise: k_wp_flat, k_wp_units | scan: k_wp_hardlist, k_wp_wave (the documents handed back), k_wp_count, k_scan_block_sums, k_scan_top, k_scan_apply | compact: k_wp_merge";

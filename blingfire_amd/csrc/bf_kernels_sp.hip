@@ -1646,9 +1646,16 @@ void launch_seg_sp(const SpSegParams &p_in, hipStream_t s)
             unsigned blocks = (unsigned)device_cus() * (unsigned)per_cu;
             if ((int64_t)blocks > (int64_t)b64) blocks = b64;
 #ifdef BF_EXPERIMENTS
-            if (one_kernel) hipLaunchKernelGGL(k_seg_unigram_lane<3>, dim3(blocks), dim3(64), lds, s, p, ring);
-            else if (unroll == 4) { hipLaunchKernelGGL((k_seg_unigram_lane<4, true, 8>), dim3(blocks), dim3(64), lds, s, p, ring); hipLaunchKernelGGL(k_uni_back, dim3((unsigned)((p.b.ndocs + 255) / 256)), dim3(256), 0, s, p); }
-            else
+            if (one_kernel) {
+                if (p.ev_dom0) (void)hipEventRecord((hipEvent_t)p.ev_dom0, s);
+                hipLaunchKernelGGL(k_seg_unigram_lane<3>, dim3(blocks), dim3(64), lds, s, p, ring);
+                if (p.ev_dom1) (void)hipEventRecord((hipEvent_t)p.ev_dom1, s);
+            } else if (unroll == 4) {
+                if (p.ev_dom0) (void)hipEventRecord((hipEvent_t)p.ev_dom0, s);
+                hipLaunchKernelGGL((k_seg_unigram_lane<4, true, 8>), dim3(blocks), dim3(64), lds, s, p, ring);
+                if (p.ev_dom1) (void)hipEventRecord((hipEvent_t)p.ev_dom1, s);
+                hipLaunchKernelGGL(k_uni_back, dim3((unsigned)((p.b.ndocs + 255) / 256)), dim3(256), 0, s, p);
+            } else
 #endif
             {
                 // forward pass (persistent lanes, records out), then the backward pass over every document

@@ -50,7 +50,51 @@ def test_adversarial_and_fuzz(model, checker):
                                                   ("laser500k.bin", "config5", 100000)])
 def test_corpus_bit_exact(model, workload, ndocs, checker):
     """the configuration's own corpus (configs 4 / 5: the multilingual generator of SURVEY.md section 8d, 100 k documents of all
-    seven script buckets): id counts exactly, ids through the per-document 64-bit hash, against the CPU checker"""
+    seven script buckets): id counts and EVERY id as arrays against the CPU checker (round 6: no longer through the per-document hash)"""
+    if not bfutil.have_model(model):
+        pytest.skip("%s not present" % model)
+    wl = bfutil.WORKLOADS[workload]
+    text, off = bfutil.gen_workload(workload, ndocs)
+    max_ids, unk = wl["max_ids"], wl["unk"]
+    lib_path, _ = bfutil.checker_lib_path()
+    _, want_ids, want_off = bfutil.cpu_ids_compact(lib_path, bfutil.model_path(model), text, off, max_ids, unk)
+    h = bf.load_model(bfutil.model_path(model))
+    try:
+        for variant in ((3, 6, 3 | 0x20) if workload != "config3" else (3,)):      # Unigram: the cut form, the round-4 kernels, the cut form with the short way out
+            bf.lib().BfSetVariant(h, variant)
+            ids, id_off = bf.text_to_ids_batch(h, (text, off), max_ids, unk)
+            assert np.array_equal(id_off, want_off), (model, variant)
+            bad = np.nonzero(ids != want_ids)[0]
+            assert len(bad) == 0, "variant %d: first differing id at %d (document %d)" % (variant, bad[0], int(np.searchsorted(want_off, bad[0], side="right") - 1))
+    finally:
+        bf.free_model(h)
+
+
+@pytest.mark.parametrize("model", [m for m in ("xlm_roberta_base.bin", "laser500k.bin", "xlnet.bin", "laser100k.bin") if bfutil.have_model(m)])
+def test_unigram_cut_form_rings_and_periods(model, checker):
+    """round 6, the Unigram cut form (k_uni_cut + k_uni_ids): words longer than the record ring (entries of 15 and 16 symbols back to back, Thai
+    and CJK runs without a blank, unknown runs of 20 .. 200 symbols: the spill path), documents of one symbol, every emission period from 1 to
+    64 trips, the short way out on and off, 10 and 13 waves per CU -- all against the CPU checker; and the offsets API, which still takes the
+    forward / backward kernels of round 4"""
+    docs = list(bfutil.ADVERSARIAL) + bfutil.fuzz_docs(1500, seed=71)
+    docs += [("x" * n + " " + "\u0e01\u0e32\u0e23" * n + " internationalization" * (n % 7)).encode("utf-8") for n in range(1, 120, 7)]
+    docs += [("\U000F0000" * n + " a " + "\u4e2d\u6587" * n).encode("utf-8") for n in (1, 20, 33, 70, 200)]
+    docs += [b"a", b" ", "\u2581".encode("utf-8"), ("pneumonoultramicroscopicsilicovolcanoconiosis " * 12).encode("utf-8")]
+    h = bf.load_model(bfutil.model_path(model))
+    hck = checker.load(bfutil.model_path(model))
+    try:
+        for variant in (3, 3 | (1 << 8), 3 | (2 << 8), 3 | (64 << 8), 3 | 0x20, 3 | 0x20 | (1 << 8), 3 | 0x10, 3 | (10 << 16), 3 | (13 << 16) | 0x20, 6):
+            bf.lib().BfSetVariant(h, variant)
+            _compare(h, checker, hck, docs, 1024, 3)
+            _compare(h, checker, hck, docs, 4, 0)
+    finally:
+        bf.free_model(h)
+        checker.free(hck)
+
+
+@pytest.mark.parametrize("model,workload,ndocs", [("gpt2.bin", "config3", 6000)])
+def test_corpus_hash_bit_exact(model, workload, ndocs, checker):
+    """the per-document 64-bit hash bench.py used before round 3 stays pinned on one corpus"""
     if not bfutil.have_model(model):
         pytest.skip("%s not present" % model)
     wl = bfutil.WORKLOADS[workload]

@@ -102,3 +102,34 @@ def test_gpu_offsets_match_checker(model):
     finally:
         bf.free_model(h)
         ck.free(hck)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("workload,ndocs", [("headline512", 50000), ("config2", 20000)])
+def test_gpu_flat_offsets_on_the_metric_corpus(workload, ndocs):
+    """The flat program's OFFS instance on the corpora it is timed on: TextToIdsWithOffsetsBatch with the default variant
+    -- batches of this size take the flat program, several ranges -- against the compiled reference's TextToIdsWithOffsets per document: ids,
+    first bytes and last bytes, at max_ids 512 and 16 (truncation, tokdll:1263-1297,1308-1310)"""
+    if not bfutil.have_ref():
+        pytest.skip("oracle/_ref not built")
+    import blingfire_amd as bf
+    model = bfutil.bert_model_name()
+    text, off = bfutil.gen_workload(workload, ndocs)
+    raw = text.tobytes()
+    ref = bfutil.reference()
+    h = bf.load_model(bfutil.model_path(model))
+    hr = ref.load(bfutil.model_path(model))
+    try:
+        for mx in (512, 16):
+            ids, st, en, id_off = bf.text_to_ids_with_offsets_batch(h, (text, off), mx, 100)
+            bf.lib().BfTokeniseKernel.restype = ctypes.c_char_p
+            assert bf.lib().BfTokeniseKernel(ctypes.c_void_p(h)) == b"k_wp_flat"
+            step = 1 if mx == 512 else 7                      # every document at 512; every seventh at 16 (the reference call is the slow part)
+            for d in range(0, ndocs, step):
+                b = raw[off[d]:off[d + 1]]
+                c, wi, ws, we = ref.with_offsets(hr, b, mx, 100, "TextToIdsWithOffsets")
+                a, z = int(id_off[d]), int(id_off[d + 1])
+                assert z - a == c and ids[a:z].tolist() == wi[:c] and st[a:z].tolist() == ws[:c] and en[a:z].tolist() == we[:c], (workload, d, mx, b[:60])
+    finally:
+        bf.free_model(h)
+        ref.free(hr)
