@@ -18,6 +18,10 @@
 //   fill    a chunk of 512 stream elements goes into the LDS ring, eight per lane; words = [a U+2581 (or the document's first
 //           element) .. the element before the next U+2581]: starts and ends from one 8-bit mask per lane, two shuffles, one ballot,
 //           one prefix sum -- the chunk-wide pass of bf_wave_body.h with one element kind;
+//   table   (round 6) the words just queued, one per lane and 64 per trip: a word of U+2581 + at most 12 symbols (classes below 256) is looked up
+//           in the word table by its symbols (lookup_words; bf_model.cpp build_bpe_word_table: every word the collection loop takes WHOLE,
+//           :189-206 -- a function of the word alone): two 16-byte gathers per lane, a hit IS the word's id.  80 % of the words of running text
+//           never reach a unit;
 //   units   one word per lane.  First the walk of the whole word from its first element, output weights summed: if it ends on the
 //           word's last element in a final state and an earlier prefix was an entry too (:189 count_at_start < narcs), the word is
 //           that entry.  Otherwise the lane collects the arcs of every start position of the word into its LDS window
@@ -32,6 +36,17 @@
 #include "bf_bpe_wave.h"
 
 namespace bfa {
+
+struct alignas(16) BwRow { uint32_t k0lo, k0hi, k1, id; };      // a row of the word table (bf_flat_key.h: the flat program's layout)
+#if defined(__HIPCC__)
+// both candidate rows whole and in flight together (left alone the compiler fetches the second only after the first has come back: bf_flat_body.h)
+typedef uint32_t bw_u32x4 __attribute__((ext_vector_type(4)));
+#define BF_BW_LOAD_ROWS(A, B, PA, PB) { bw_u32x4 ra_, rb_; const BwRow *pa_ = (PA), *pb_ = (PB); \
+    asm volatile("global_load_dwordx4 %0, %2, off\n\tglobal_load_dwordx4 %1, %3, off\n\ts_waitcnt vmcnt(0)" : "=&v"(ra_), "=&v"(rb_) : "v"(pa_), "v"(pb_) : "memory"); \
+    A.k0lo = ra_.x; A.k0hi = ra_.y; A.k1 = ra_.z; A.id = ra_.w; B.k0lo = rb_.x; B.k0hi = rb_.y; B.k1 = rb_.z; B.id = rb_.w; }
+#else
+#define BF_BW_LOAD_ROWS(A, B, PA, PB) { A = *(PA); B = *(PB); }
+#endif
 
 constexpr int BW_WORD_MAX = 62;          // positions of a word (the interior mask has 64 bits: position + 1 must fit)
 constexpr int BW_PRIV = 16;              // arcs of more than one element in a lane's own window: 85 % of the words of the config-3 corpus that are not one entry
@@ -169,10 +184,47 @@ struct BpeWave {
         if (stays_open && cb + total - new_open > BW_WORD_MAX) toolong = true;       // (its head may leave the ring before its end is seen)
         if (wv::any(toolong)) { fall = true; if (p.stats && lane == 0) wv::atomic_add(&p.stats[3], 1ull); }
         wv::sync();
+        lookup_words(q_tail, ntok);
         q_tail += ntok; done = cb + total;
         open_start = stays_open ? new_open : -1;
         if (fall) { n = dec; done = dec; open_start = -1; }             // the rest of a document that is handed back is not looked at
         return true;
+    }
+
+    // The words [first, first + n) of the queue, just put there by resolve_chunk: every one gets its count slot (0: a unit will take it), and a
+    // word the table holds its id at once (count slot 2 = one id, in the token's `pos` -- what unit_event writes for a word taken whole).
+    // The key of a word is the classes of the (at most 12) symbols behind its U+2581, one byte each; a class of 256 or more has no byte.
+    BF_WVD void lookup_words(uint32_t first, uint32_t n)
+    {
+        for (uint32_t t0 = 0; t0 < n; t0 += 64u) {
+            const bool have = t0 + (uint32_t)lane < n;
+            const uint32_t sl = (first + t0 + (uint32_t)lane) & QMASK;
+            WvTok e; e.pos = 0; e.w = 0;
+            if (have) e = S.q[sl];
+            const int len = (int)(e.w & WV_TK_LEN_MASK);
+            const int kn = (have && p.W && (e.w & BW_TK_TS) && len >= 2 && len <= WF_KEY_CHARS + 1) ? len - 1 : 0;
+            const uint32_t r0 = (e.pos + 1u) & RMASK;
+            uint32_t c[6];
+            if (r0 + 12u <= (uint32_t)RING) __builtin_memcpy(c, S.ring + r0, 24);
+            else for (int k = 0; k < 6; ++k) c[k] = (uint32_t)S.ring[(r0 + 2u * (uint32_t)k) & RMASK] | ((uint32_t)S.ring[(r0 + 2u * (uint32_t)k + 1u) & RMASK] << 16);
+            const uint32_t km0 = kn >= 4 ? 0xFFFFFFFFu : ((1u << (8 * kn)) - 1u);
+            const uint32_t km1 = kn >= 8 ? 0xFFFFFFFFu : kn > 4 ? ((1u << (8 * (kn - 4))) - 1u) : 0u;
+            const uint32_t km2 = kn >= 12 ? 0xFFFFFFFFu : kn > 8 ? ((1u << (8 * (kn - 8))) - 1u) : 0u;
+            const uint32_t w0 = wv::perm(c[1], c[0], 0x06040200u) & km0, w1 = wv::perm(c[3], c[2], 0x06040200u) & km1, w2 = wv::perm(c[5], c[4], 0x06040200u) & km2;
+            const uint32_t hb = (wv::perm(c[1], c[0], 0x07050301u) & km0) | (wv::perm(c[3], c[2], 0x07050301u) & km1) | (wv::perm(c[5], c[4], 0x07050301u) & km2);
+            const uint64_t k0 = (uint64_t)w0 | ((uint64_t)w1 << 32);
+            const uint32_t x = wf_mix(k0, w2, p.m0);
+            BwRow A, B; A.k0lo = A.k0hi = A.k1 = A.id = 0; B = A;
+            if (wv::any(kn != 0)) BF_BW_LOAD_ROWS(A, B, (const BwRow *)p.W + (kn ? wf_h(x, p.m1, p.wbits) : 0u), (const BwRow *)p.W + (kn ? wf_h(x, p.m2, p.wbits) : 0u));
+            const uint32_t klen = (uint32_t)kn << WF_ROW_LEN_SHIFT;
+            const bool hita = ((A.k0lo ^ w0) | (A.k0hi ^ w1) | (A.k1 ^ w2) | ((A.id ^ klen) & ~WF_ROW_ID_MASK)) == 0u;
+            const bool hitb = ((B.k0lo ^ w0) | (B.k0hi ^ w1) | (B.k1 ^ w2) | ((B.id ^ klen) & ~WF_ROW_ID_MASK)) == 0u;
+            const bool hit = kn != 0 && hb == 0u && (hita || hitb);
+            if (hit) S.q[sl].pos = (hita ? A.id : B.id) & WF_ROW_ID_MASK;
+            if (have) S.qc[sl] = hit ? (uint16_t)2 : (uint16_t)0;
+            if (p.stats && hit) wv::atomic_add(&p.stats[12], 1ull);
+        }
+        wv::sync();
     }
 
     BF_WVD bool open_document(int64_t d, int64_t sl, int len)
@@ -248,10 +300,10 @@ struct BpeWave {
     }
     BF_WVD void unit_begin(Unit &u, uint32_t t)
     {
+        if (S.qc[t & QMASK] != 0) return;                                // the word table had it (lookup_words): the lane stays idle and asks again
         u.tok = (int)t;
         const WvTok e = S.q[t & QMASK];
         u.rs = e.pos; u.L = (int)(e.w & WV_TK_LEN_MASK); u.ke = (e.w >> 16) & DMASK;
-        S.qc[t & QMASK] = 0;
         u.state = p.initial; u.sum = 0; u.j = 0; u.s0 = 0; u.seen = 0; u.last_final = 0; u.ovf = 0; u.narc = 0; u.narc0 = 0; u.pw = -1; u.single = 0;
         u.mode = (e.w & BW_TK_TS) ? 1 : 2;                              // only a word that starts with U+2581 can be taken whole (:176,189)
         if (p.stats) wv::atomic_add(&p.stats[0], 1ull);
@@ -525,15 +577,18 @@ struct BpeWave {
         for (;;) {
             const bool ev = u.tok >= 0 && u.mode != 3 && u.j >= u.L;
             if (wv::any(ev)) unit_event(u, ev);
-            const uint32_t avail = tail - issue;
+            // words for idle lanes -- several times over: four words in five have their id from the table and leave their lane idle
             unsigned long long idle = wv::ballot(u.tok < 0);
-            if (avail != 0 && idle != 0) {
+            for (int rep = 0; rep < 8; ++rep) {
+                const uint32_t avail = tail - issue;
+                if (avail == 0 || idle == 0) break;
                 const uint32_t r = wv::mbcnt(idle);
                 const bool take = u.tok < 0 && r < avail;
                 if (take) unit_begin(u, issue + r);
                 const uint32_t k = (uint32_t)__builtin_popcountll(idle);
                 issue += k < avail ? k : avail;
                 idle = wv::ballot(u.tok < 0);
+                if (__builtin_popcountll(idle) < 16) break;
             }
             const int nb = 64 - __builtin_popcountll(idle);
             const unsigned long long ready = wv::ballot(u.tok >= 0 && u.mode == 3);

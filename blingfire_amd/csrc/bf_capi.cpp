@@ -160,6 +160,7 @@ struct Handle {
     DevBuf t_kind;                                               // unit-form lexers: what a walk that starts on each class does (bf_wave.h)
     bool lex_stats = false;                                      // BF_LEX_STATS=1 at LoadModel: instrumented kernel instances (experiments)
     DevBuf t_wcp_l1, t_wcp_pages;                                // TextToWords: code point -> class without the charmap
+    DevBuf t_bpetab;                                             // _sp BPE: the word table of the wave program
     DevBuf t_segscore, t_segid;                                  // _sp Unigram: the rows' scores alone; their ids alone (the cut form's compaction)
     DevBuf t_dict, t_seginfo;                                    // _sp: Mealy table, I2Info rows (code-point maps reuse t_cp_*/t_multi)
     DevBuf t_dk_l1, t_dk_pages, t_dn_l1, t_dn_pages, t_dn_pool, t_k2i, t_rows;   // key -> info lookup (uploaded on first use)
@@ -199,7 +200,7 @@ struct Handle {
         for (Handle *c : shards) if (c && c != this) { DeviceGuard dg(c->device); (void)hipDeviceSynchronize(); delete c; }
         shards.clear();
         pipe.release(); m_small.release();
-        for (DevBuf *b : {&t_segscore, &t_segid, &t_bpe_prio, &t_bpe_place, &t_dk_l1, &t_dk_pages, &t_dn_l1, &t_dn_pages, &t_dn_pool, &t_k2i, &t_rows, &w_keys, &w_keyoff, &w_dids, &w_dret, &w_vals, &t_i2w_off, &t_i2w_data, &t_kind, &t_wbd, &t_info, &t_acts, &t_cp_l1, &t_cp_pages, &t_multi, &t_wcp_l1, &t_wcp_pages, &t_dict, &t_seginfo, &w_s1, &w_s2, &w_s3, &w_s4, &w_big, &w_perm, &w_hist, &w_narcs, &w_bwflags, &w_cls, &w_nchars, &w_tmp, &w_counts, &w_flags, &w_out, &w_outoff,
+        for (DevBuf *b : {&t_segscore, &t_segid, &t_bpetab, &t_bpe_prio, &t_bpe_place, &t_dk_l1, &t_dk_pages, &t_dn_l1, &t_dn_pages, &t_dn_pool, &t_k2i, &t_rows, &w_keys, &w_keyoff, &w_dids, &w_dret, &w_vals, &t_i2w_off, &t_i2w_data, &t_kind, &t_wbd, &t_info, &t_acts, &t_cp_l1, &t_cp_pages, &t_multi, &t_wcp_l1, &t_wcp_pages, &t_dict, &t_seginfo, &w_s1, &w_s2, &w_s3, &w_s4, &w_big, &w_perm, &w_hist, &w_narcs, &w_bwflags, &w_cls, &w_nchars, &w_tmp, &w_counts, &w_flags, &w_out, &w_outoff,
                           &w_bsums, &w_misc, &w_text, &w_docoff, &w_ids, &w_idoff, &w_starts, &w_ends, &w_srcoff, &w_span, &w_ent, &w_home, &w_entoff, &w_entcnt, &w_dstat, &w_ranges, &w_list, &w_wrec, &t_flat, &w_espan, &w_hspan, &w_chard}) b->release();
         for (auto &e : ev) if (e) (void)hipEventDestroy(e);
         if (stream) (void)hipStreamDestroy(stream);
@@ -296,6 +297,7 @@ Handle *make_handle(const uint8_t *img, size_t size)
         ok = ok && upload(h->t_dict, m.dict.t64, 16) && upload(h->t_seginfo, m.seg_info, 16) &&
              upload(h->t_cp_l1, m.sp_cpmap.l1) && upload(h->t_cp_pages, m.sp_cpmap.pages) && upload(h->t_multi, m.sp_multi_pool, 16);
         if (m.kind == KIND_BPE_MERGES) ok = ok && upload(h->t_bpe_prio, m.bpe_prio, 16) && upload(h->t_bpe_place, m.bpe_place_id, 16);
+        if (!m.bpe_tab.empty()) ok = ok && upload(h->t_bpetab, m.bpe_tab, 16);
         if (m.kind == KIND_UNIGRAM) ok = ok && upload(h->t_segscore, m.seg_score, 16) && upload(h->t_segid, m.i2info_id, 16);
     }
     if ((m.kind == KIND_BPE || m.kind == KIND_BPE_OPT || m.kind == KIND_BPE_MERGES) && !m.bpe_seg_ok) {
@@ -544,6 +546,7 @@ int run_device(Handle *h, const char *d_text, const int64_t *d_doc_off, int64_t 
             BpeWaveParams bw;
             bw.T = sg.S.T; bw.info = sg.S.info; bw.initial = sg.S.initial; bw.cls_delim = sg.S.cls_delim; bw.id_offset = sg.S.id_offset;
             bw.prio = sg.bpe_prio; bw.place_id = sg.bpe_place_id;
+            if (!m.bpe_tab.empty() && (h->variant & 0x100000) == 0) { bw.W = h->t_bpetab.as<uint64_t>(); bw.wbits = m.bpe_tab_bits; bw.m0 = m.bpe_tab_m0; bw.m1 = m.bpe_tab_m1; bw.m2 = m.bpe_tab_m2; }      // (BfSetVariant bit 20: A/B runs without the word table)
             bw.stream = sg.stream; bw.lens = sg.lens; bw.doc_off = b.doc_off; bw.slot_mul = mul; bw.ndocs = ndocs;
             bw.ids_tmp = sg.ids_tmp; bw.counts = sg.counts; bw.flags = h->w_bwflags.as<int32_t>(); bw.max_ids = max_ids; bw.next_doc = next_doc; bw.status = status; bw.scratch = (uint32_t *)sg.arcs; bw.stats = h->lex_stats ? (unsigned long long *)(h->w_misc.as<char>() + 64) : nullptr;
             (void)hipEventRecord(h->ev[EV_DOM0], s);

@@ -56,7 +56,9 @@ void launch_bpe_wave(const BpeWaveParams &p, int tune, hipStream_t s)
     if (tune == 3) { launch_bpe_wave_cfg<4, 48>(p, s); return; }
     if (tune == 6) { launch_bpe_wave_cfg<6, 32>(p, s); return; }
 #endif
-    (void)tune;
+    if (tune == 4) { launch_bpe_wave_cfg<4, 32, 512>(p, s); return; }      // (round 6 A/B: with the word table four words in five sit in the queue answered, waiting for their turn to retire)
+    if (tune == 5) { launch_bpe_wave_cfg<4, 32, 1024>(p, s); return; }
+    if (tune == 7) { launch_bpe_wave_cfg<4, 8, 512>(p, s); return; }
     launch_bpe_wave_cfg<4, 32>(p, s);
 }
 

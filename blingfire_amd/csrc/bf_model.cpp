@@ -460,6 +460,39 @@ static bool fail(Model &m, const std::string &e) { m.error = e; return false; }
 // initial state -- reads the word's L characters (L <= max-token-length - 1: the walk's limit is the word's end), never misses, and its
 // last transition enters a final state: fp = L - 1, one sub-token that tiles the word, its tag is the id.  The walk is the device's own
 // (the entries of wbd_t2), so table and kernel cannot disagree about a transition.
+struct FlatWord { uint64_t k0; uint32_t k1, id; };
+// two-choice (cuckoo) placement at a load of at most 40 %; new multipliers when an insertion does not settle.  tab: entry e = [2e] k0, [2e + 1] k1 | id << 32
+static bool place_words(const std::vector<FlatWord> &words, std::vector<uint64_t> &out, int &out_bits, uint32_t &out_m0, uint32_t &out_m1, uint32_t &out_m2)
+{
+    int bits = 10; while ((size_t)1 << bits < words.size() * 5 / 2 + 16) ++bits;
+    uint64_t seed = 0x9E3779B97F4A7C15ull;
+    auto next_odd = [&]() { seed ^= seed << 13; seed ^= seed >> 7; seed ^= seed << 17; return (uint32_t)(seed >> 16) | 1u; };
+    for (int attempt = 0; attempt < 64; ++attempt) {
+        if (attempt == 32) ++bits;
+        const uint32_t m0 = next_odd(), m1 = next_odd(), m2 = next_odd();
+        std::vector<uint64_t> tab((size_t)2 << bits, 0);
+        bool ok = true;
+        for (size_t w = 0; w < words.size() && ok; ++w) {
+            uint64_t k0 = words[w].k0, ki = (uint64_t)words[w].k1 | ((uint64_t)words[w].id << 32);
+            uint32_t x = wf_mix(k0, (uint32_t)ki, m0), at = wf_h(x, m1, bits);
+            ok = false;
+            for (int kick = 0; kick < 512; ++kick) {
+                uint64_t &t0 = tab[2 * (size_t)at], &t1 = tab[2 * (size_t)at + 1];
+                if (t0 == 0) { t0 = k0; t1 = ki; ok = true; break; }
+                if (t0 == k0 && (uint32_t)t1 == (uint32_t)ki) { ok = t1 == ki; break; }              // the same word twice
+                std::swap(k0, t0); std::swap(ki, t1);
+                x = wf_mix(k0, (uint32_t)ki, m0);
+                const uint32_t h1 = wf_h(x, m1, bits), h2 = wf_h(x, m2, bits);
+                at = at == h1 ? h2 : h1;
+            }
+        }
+        if (!ok) continue;
+        out.swap(tab); out_bits = bits; out_m0 = m0; out_m1 = m1; out_m2 = m2;
+        return true;
+    }
+    return false;
+}
+
 static void build_flat_table(Model &m)
 {
     m.flat_ok = false; m.flat_tab.clear(); m.flat_words = 0;
@@ -472,8 +505,7 @@ static void build_flat_table(Model &m)
     const bool anchored = m.flat_ini_l != 0xFFFFFFFFu && m.max_token_length > 1;
     const uint32_t start = anchored ? m.flat_ini_l : m.flat_ini;
     const std::vector<uint64_t> &T = m.wbd_t2;
-    struct Word { uint64_t k0; uint32_t k1, id; };
-    std::vector<Word> words;
+    std::vector<FlatWord> words;
     auto step = [&](uint32_t state, uint32_t cls, uint32_t &next, bool &fin, uint32_t &tag) -> bool {
         const size_t at = (size_t)state + cls;
         if (at >= T.size()) return false;
@@ -512,34 +544,58 @@ static void build_flat_table(Model &m)
             words.push_back({WF_KEY_SOLO | ((uint64_t)k << WF_KEY_SOLO_SHIFT), 0u, tag & 0x7FFFFFFFu});        // (characters: 0)
         }
     }
-    // two-choice (cuckoo) placement at a load of at most 40 %; new multipliers when an insertion does not settle
-    int bits = 10; while ((size_t)1 << bits < words.size() * 5 / 2 + 16) ++bits;
-    uint64_t seed = 0x9E3779B97F4A7C15ull;
-    auto next_odd = [&]() { seed ^= seed << 13; seed ^= seed >> 7; seed ^= seed << 17; return (uint32_t)(seed >> 16) | 1u; };
-    for (int attempt = 0; attempt < 64; ++attempt) {
-        if (attempt == 32) ++bits;
-        const uint32_t m0 = next_odd(), m1 = next_odd(), m2 = next_odd();
-        std::vector<uint64_t> tab((size_t)2 << bits, 0);              // [2e] k0, [2e + 1] k1 | id << 32
-        bool ok = true;
-        for (size_t w = 0; w < words.size() && ok; ++w) {
-            uint64_t k0 = words[w].k0, ki = (uint64_t)words[w].k1 | ((uint64_t)words[w].id << 32);
-            uint32_t x = wf_mix(k0, (uint32_t)ki, m0), at = wf_h(x, m1, bits);
-            ok = false;
-            for (int kick = 0; kick < 512; ++kick) {
-                uint64_t &t0 = tab[2 * (size_t)at], &t1 = tab[2 * (size_t)at + 1];
-                if (t0 == 0) { t0 = k0; t1 = ki; ok = true; break; }
-                if (t0 == k0 && (uint32_t)t1 == (uint32_t)ki) { ok = t1 == ki; break; }              // the same word twice
-                std::swap(k0, t0); std::swap(ki, t1);
-                x = wf_mix(k0, (uint32_t)ki, m0);
-                const uint32_t h1 = wf_h(x, m1, bits), h2 = wf_h(x, m2, bits);
-                at = at == h1 ? h2 : h1;
+    if (place_words(words, m.flat_tab, m.flat_bits, m.flat_m0, m.flat_m1, m.flat_m2)) { m.flat_words = (int)words.size(); m.flat_ok = true; }
+}
+
+// ---- the word table of the BPE wave program (bf_bpe_wave_body.h, round 6).  A word of the text -- U+2581 and the symbols up to the next U+2581 --
+// that IS a dictionary entry, with a shorter entry in front of it (the U+2581 alone, usually), is taken whole by the collection loop of both
+// BPE flavours with m_fFastBpe: the whole-token arc replaces the arcs collected from that start and the walk jumps behind the word
+// (..._1best_bpe_t.h:176,189-206,228-230: `token_start && next is U+2581 or the end && count_at_start < narcs`).  Whether that happens is a
+// function of the word alone -- no rank is compared --, so every such word of <= 12 symbols behind the U+2581 is found here, by a walk of the
+// device's own transition table from the state behind U+2581, and keyed by its symbols: one byte per symbol, its class (classes below 256; a
+// word with another symbol has no key and takes the walk; the row's length field tells a class 0 from the padding), the U+2581 itself is not part of the key.  Rows and hash as the flat program's
+// (bf_flat_key.h): {12 code bytes | id + IdOffset | symbols << 24}, two candidate rows per key.  gpt2.bin: 31 k words in 2^17 rows (2 MB).
+static void build_bpe_word_table(Model &m)
+{
+    m.bpe_tab.clear(); m.bpe_tab_words = 0; m.bpe_tab_bits = 0;
+    if (!m.bpe_wave_ok || m.sp_delim_code >= 0xFFFEu) return;
+    const std::vector<uint64_t> &T = m.dict.t64;
+    auto step = [&](uint32_t state, uint32_t cls, uint32_t &next, bool &fin, uint32_t &ow) -> bool {
+        const size_t at = (size_t)state + cls;
+        if (at >= T.size()) return false;
+        const uint64_t e = T[at];
+        if ((e & T64_CLS_MASK) != cls) return false;
+        fin = (e & T64_FINAL_BIT) != 0; next = (uint32_t)((e >> T64_NEXT_SHIFT) & T64_NEXT_MASK); ow = (uint32_t)(e >> T64_OW_SHIFT);
+        return true;
+    };
+    uint32_t s1 = 0, ow0 = 0; bool fin0 = false;
+    if (!step(m.dict.initial_base, m.sp_delim_code, s1, fin0, ow0)) return;
+    std::vector<FlatWord> words;
+    const uint32_t ncode = (uint32_t)std::min(m.dict.nclasses, 256);
+    struct Fr { uint32_t state, sum; uint64_t k0; uint32_t k1; int depth; bool seen; };
+    std::vector<Fr> stack; stack.push_back({s1, ow0, 0, 0, 0, fin0});
+    while (!stack.empty()) {
+        const Fr f = stack.back(); stack.pop_back();
+        for (uint32_t k = 0; k < ncode; ++k) {
+            if (k == m.sp_delim_code) continue;
+            uint32_t nx = 0, ow = 0; bool fin = false;
+            if (!step(f.state, k, nx, fin, ow)) continue;
+            const uint32_t sum = f.sum + ow;
+            const uint64_t k0 = f.depth < 8 ? f.k0 | ((uint64_t)k << (8 * f.depth)) : f.k0;
+            const uint32_t k1 = f.depth < 8 ? 0u : f.k1 | (k << (8 * (f.depth - 8)));
+            if (fin && f.seen && k0 != 0) {                                                      // (k0 == 0 marks an empty row: a word of class-0 symbols alone takes the walk)
+                if (sum >= m.i2info_id.size() || !m.i2info_valid[sum]) return;
+                const int64_t id = (int64_t)m.i2info_id[sum] + m.id_offset;
+                if (id < 0 || id > (int64_t)WF_ROW_ID_MASK) return;                            // (an id of more than 24 bits: no table)
+                words.push_back({k0, k1, (uint32_t)id | ((uint32_t)(f.depth + 1) << WF_ROW_LEN_SHIFT)});
             }
+            if (f.depth + 1 < WF_KEY_CHARS) stack.push_back({nx, sum, k0, k1, f.depth + 1, f.seen || fin});
+            if (words.size() > (1u << 22)) return;
         }
-        if (!ok) continue;
-        m.flat_tab.swap(tab); m.flat_bits = bits; m.flat_m0 = m0; m.flat_m1 = m1; m.flat_m2 = m2; m.flat_words = (int)words.size();
-        m.flat_ok = true;
-        return;
     }
+    if (words.empty()) return;
+    if (place_words(words, m.bpe_tab, m.bpe_tab_bits, m.bpe_tab_m0, m.bpe_tab_m1, m.bpe_tab_m2)) m.bpe_tab_words = (int)words.size();
+    else m.bpe_tab.clear();
 }
 
 bool build_model(Model &m, const uint8_t *img, size_t size)
@@ -1182,6 +1238,7 @@ bool build_model(Model &m, const uint8_t *img, size_t size)
             for (uint16_t c : codes) m.sp_multi_pool.push_back(c);
         }
         fused(0x2581, m.sp_prefix);
+        build_bpe_word_table(m);
     }
     // ---- [i2w] (reference tokdll:998-1045): string array dump + the range of regular token ids
     if (conf.get(35 /* FUNC_I2W */, vals)) {

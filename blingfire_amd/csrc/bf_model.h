@@ -140,6 +140,8 @@ struct Model {
     // (one byte per character, bf_flat_key.h: the key IS the word, a hit needs no second check).  flat_tab: entry e = [2e] k0, [2e + 1] k1 | id << 32; k0 0 = empty.
     bool flat_ok = false; uint32_t flat_ini = 0, flat_ini_l = 0xFFFFFFFFu;
     std::vector<uint64_t> flat_tab; int flat_bits = 0; uint32_t flat_m0 = 0, flat_m1 = 0, flat_m2 = 0; int flat_words = 0;
+    // the word table of the BPE wave program (bf_model.cpp build_bpe_word_table): words that the bpe-opt collection takes whole, keyed by their symbols
+    std::vector<uint64_t> bpe_tab; int bpe_tab_bits = 0; uint32_t bpe_tab_m0 = 0, bpe_tab_m1 = 0, bpe_tab_m2 = 0; int bpe_tab_words = 0;
     // TextToWords view of the same lexer (tokdll:415-566): NO charmap, U+0000 is fed as U+0020 -> plain code point -> class map
     TwoLevelMap words_cpmap;
 

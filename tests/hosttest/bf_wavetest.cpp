@@ -173,6 +173,9 @@ long bft_emu_bpe_wave_batch(void *hv, const uint8_t *text, long text_bytes, cons
     p.stream = stream.data(); p.lens = lens.data(); p.doc_off = doc_off; p.slot_mul = mul; p.ndocs = ndocs;
     p.ids_tmp = tmp.data(); p.counts = counts.data(); p.flags = flags.data(); p.max_ids = max_ids; p.next_doc = &next_doc; p.status = &status; p.stats = stats; p.scratch = scratch.data();
     if (cfg >= 16) { p.next_doc = nullptr; cfg -= 16; }
+    // the word table (cfg bit 3: without it -- the program must give the same ids either way)
+    if (!(cfg & 8) && !m.bpe_tab.empty()) { p.W = m.bpe_tab.data(); p.wbits = m.bpe_tab_bits; p.m0 = m.bpe_tab_m0; p.m1 = m.bpe_tab_m1; p.m2 = m.bpe_tab_m2; }
+    cfg &= ~8;
     if (ndocs > 0) {
         auto run = [&](auto *lds_tag) {
             typedef typename std::remove_pointer<decltype(lds_tag)>::type LDS;

@@ -12,8 +12,9 @@ import bfutil
 import blingfire_amd as bf
 
 MODELS = ["gpt2.bin", "roberta.bin", "bpe_example.bin", "bpe_example2.bin"]
-# (max_ids, unk, waves, documents per range, configuration: 0 = queue 256 / 8 open documents, 1 = queue 128 / 2 open documents; + 16 = no work counter)
-CONFS = [(512, 0, 1, 8, 0), (512, 3, 3, 2, 1), (7, 5, 2, 3, 16), (0, 0, 1, 8, 0), (2048, 0, 4, 8, 17), (1, 1, 2, 1, 1)]
+# (max_ids, unk, waves, documents per range, configuration: 0 = queue 256 / 8 open documents, 1 = queue 128 / 2 open documents; + 16 = no work counter;
+#  + 8 = without the word table of round 6 -- the program gives the same ids either way)
+CONFS = [(512, 0, 1, 8, 0), (512, 3, 3, 2, 1), (7, 5, 2, 3, 16), (0, 0, 1, 8, 0), (2048, 0, 4, 8, 17), (1, 1, 2, 1, 1), (512, 0, 2, 8, 8), (64, 3, 3, 2, 9)]
 
 
 @pytest.fixture(scope="module")
@@ -102,3 +103,23 @@ def test_multilingual_and_charmap_model(ht):
         pytest.skip("bpe_example2.bin not present")
     check(ht, "bpe_example2.bin", bfutil.gen_corpus_multi(300), CONFS[:3])
     check(ht, "bpe_example.bin", bfutil.gen_corpus_multi(300), CONFS[:3])
+
+
+def test_word_table_answers_most_words(ht):
+    """round 6: the word table (bf_model.cpp build_bpe_word_table) answers the words the bpe-opt collection takes whole -- four in five on the
+    config-3 corpus -- before a unit is spent on them; the ids are the oracle's with and without it (check), and the table does answer them (stats[12])"""
+    model = "gpt2.bin"
+    if not bfutil.have_model(model):
+        pytest.skip("%s not present" % model)
+    text, off = bfutil.gen_workload("config3", 300)
+    h = ht.bft_load(bfutil.model_path(model).encode())
+    r, ids, ido, fl, st = run(ht, h, text, off, 2048, 0, 2, 8, 0)
+    r2, ids2, ido2, fl2, st2 = run(ht, h, text, off, 2048, 0, 2, 8, 8)
+    ht.bft_free(h)
+    assert r >= 0 and r == r2 and np.array_equal(ids, ids2) and np.array_equal(ido, ido2)
+    words_unit, whole_unit, table = int(st[0]), int(st[1]), int(st[12])
+    words2, whole2 = int(st2[0]), int(st2[1])
+    assert int(st2[12]) == 0 and table > 0
+    assert table + words_unit == words2                       # every word is answered by the table or begun by a unit
+    assert table >= 0.9 * whole2                              # what the units took whole without the table, the table now answers (words of > 12 symbols stay)
+    assert table >= 0.6 * words2
