@@ -30,6 +30,11 @@
 //           token of its own), sorts and applies them against a 64-bit interior mask (:274-296) and emits the pieces in position
 //           order (:299-313);
 //   retire  as in bf_wave_body.h: ids move from LDS / their provisional homes down to their place in the document.
+// HOME form (round 6, the shipped one): nothing is retired in order.  Every word's ids stay at its HOME -- the cells of the document's staging slot
+// under the word's own elements (a word has no more ids than elements; the fill writes BW_HOME_NONE into every cell first) -- and two streaming
+// kernels behind (k_bpe_home_count / k_bpe_home_gather) count and squeeze the cells that hold an id.  A word the table answers never enters the
+// queue: the queue holds only the words a unit must walk, sixteen documents' worth instead of three, so the lanes of a round are busy -- with
+// the in-order queue the table's hits sat in it waiting for their turn and the kernel's time did not move (18.8 vs 19.1 ms per 1 M documents).
 // Include AFTER a definition of namespace wv (bf_kernels.hip on the device, tests/hosttest/wave_emu.h in the test simulator).
 #pragma once
 #include "bf_wave_body.h"
@@ -71,7 +76,9 @@ struct BwLds {
     uint32_t spare32; uint16_t spare;
 };
 
-template <class LDS, int STEPS = 3, int UMIN = 4>
+constexpr int32_t BW_HOME_NONE = (int32_t)0x80000000;      // HOME form: a cell of the staging slot that holds no id (an id is a dictionary id + IdOffset: never this)
+
+template <class LDS, int STEPS = 3, int UMIN = 4, bool HOME = false>
 struct BpeWave {
     static constexpr int RING = LDS::RING, QCAP = LDS::QCAP, DTN = LDS::DTN;
     static constexpr uint32_t RMASK = RING - 1, QMASK = QCAP - 1, DMASK = DTN - 1;
@@ -118,6 +125,7 @@ struct BpeWave {
             uint32_t *dst = (uint32_t *)(S.ring + (r & RMASK));
             dst[0] = d[0]; dst[1] = d[1]; dst[2] = d[2]; dst[3] = d[3];
         } else for (int k = 0; k < nb; ++k) S.ring[(r + (uint32_t)k) & RMASK] = src[k];
+        if (HOME) { int32_t *cell = p.ids_tmp + slot + pos + lane * 8; for (int k = 0; k < nb; ++k) cell[k] = BW_HOME_NONE; }      // no id here (yet)
         dec += total; rhi = rbase + (uint32_t)dec;
         wv::sync();
     }
@@ -184,8 +192,7 @@ struct BpeWave {
         if (stays_open && cb + total - new_open > BW_WORD_MAX) toolong = true;       // (its head may leave the ring before its end is seen)
         if (wv::any(toolong)) { fall = true; if (p.stats && lane == 0) wv::atomic_add(&p.stats[3], 1ull); }
         wv::sync();
-        lookup_words(q_tail, ntok);
-        q_tail += ntok; done = cb + total;
+        q_tail += lookup_words(q_tail, ntok); done = cb + total;
         open_start = stays_open ? new_open : -1;
         if (fall) { n = dec; done = dec; open_start = -1; }             // the rest of a document that is handed back is not looked at
         return true;
@@ -194,8 +201,11 @@ struct BpeWave {
     // The words [first, first + n) of the queue, just put there by resolve_chunk: every one gets its count slot (0: a unit will take it), and a
     // word the table holds its id at once (count slot 2 = one id, in the token's `pos` -- what unit_event writes for a word taken whole).
     // The key of a word is the classes of the (at most 12) symbols behind its U+2581, one byte each; a class of 256 or more has no byte.
-    BF_WVD void lookup_words(uint32_t first, uint32_t n)
+    // HOME form: the id of a word the table holds goes to the word's home at once and the word leaves the queue -- the words that stay move up;
+    // returns how many stay.
+    BF_WVD uint32_t lookup_words(uint32_t first, uint32_t n)
     {
+        uint32_t kept = 0;
         for (uint32_t t0 = 0; t0 < n; t0 += 64u) {
             const bool have = t0 + (uint32_t)lane < n;
             const uint32_t sl = (first + t0 + (uint32_t)lane) & QMASK;
@@ -220,11 +230,21 @@ struct BpeWave {
             const bool hita = ((A.k0lo ^ w0) | (A.k0hi ^ w1) | (A.k1 ^ w2) | ((A.id ^ klen) & ~WF_ROW_ID_MASK)) == 0u;
             const bool hitb = ((B.k0lo ^ w0) | (B.k0hi ^ w1) | (B.k1 ^ w2) | ((B.id ^ klen) & ~WF_ROW_ID_MASK)) == 0u;
             const bool hit = kn != 0 && hb == 0u && (hita || hitb);
-            if (hit) S.q[sl].pos = (hita ? A.id : B.id) & WF_ROW_ID_MASK;
-            if (have) S.qc[sl] = hit ? (uint16_t)2 : (uint16_t)0;
             if (p.stats && hit) wv::atomic_add(&p.stats[12], 1ull);
+            if (HOME) {
+                if (hit) p.ids_tmp[slot + (int64_t)(e.pos - rbase)] = (int32_t)((hita ? A.id : B.id) & WF_ROW_ID_MASK);      // (the words of a chunk are the current document's)
+                const unsigned long long keep = wv::ballot(have && !hit);
+                wv::sync();                                              // every lane has read its token: the ones that stay move up
+                if (have && !hit) { const uint32_t dl = (first + kept + wv::mbcnt(keep)) & QMASK; S.q[dl] = e; S.qc[dl] = 0; }
+                kept += (uint32_t)__builtin_popcountll(keep);
+            } else {
+                if (hit) S.q[sl].pos = (hita ? A.id : B.id) & WF_ROW_ID_MASK;
+                if (have) S.qc[sl] = hit ? (uint16_t)2 : (uint16_t)0;
+                kept = n;
+            }
         }
         wv::sync();
+        return kept;
     }
 
     BF_WVD bool open_document(int64_t d, int64_t sl, int len)
@@ -285,9 +305,12 @@ struct BpeWave {
     // ------------------------------------------------------------------------------------------------------------------
     struct Unit {
         int tok; uint32_t rs; int L; uint32_t ke;
+        int64_t g;                       // HOME form: the word's first element in the class stream (the units read their symbols there, not in the ring)
         int mode, s0, j; uint32_t state; int sum; uint32_t seen, last_final, ovf; int narc, narc0, pw;      // seen / last_final / ovf: 0 or 1 (bf_wave.h wv_b)   // narc0: arcs before the walk of s0; pw: overflow window (-1: none)
         unsigned long long single;       // bit s: the element at position s is an entry by itself (its one-element arc is not stored)
     };
+    // element `pos` of the unit's word
+    BF_WVD uint32_t sym_at(const Unit &u, int pos) const { return HOME ? (uint32_t)p.stream[u.g + pos] : (uint32_t)S.ring[(u.rs + (uint32_t)pos) & RMASK]; }
     BF_WVD uint32_t *arc_at(const Unit &u, int a) { return a < BW_PRIV ? &S.win[a * 64 + lane] : &S.pool[(a - BW_PRIV) * BW_POOL_N + u.pw]; }
     BF_WVD void unit_finish(Unit &u, int cnt) {
         if (u.pw >= 0) { wv::lds_or(&S.pool_free, 1u << u.pw); u.pw = -1; }          // (lanes that finish in the same instruction return different windows)
@@ -304,6 +327,7 @@ struct BpeWave {
         u.tok = (int)t;
         const WvTok e = S.q[t & QMASK];
         u.rs = e.pos; u.L = (int)(e.w & WV_TK_LEN_MASK); u.ke = (e.w >> 16) & DMASK;
+        if (HOME) u.g = S.dt_slot[u.ke] + (int64_t)(u.rs - S.dt_rbase[u.ke]);
         u.state = p.initial; u.sum = 0; u.j = 0; u.s0 = 0; u.seen = 0; u.last_final = 0; u.ovf = 0; u.narc = 0; u.narc0 = 0; u.pw = -1; u.single = 0;
         u.mode = (e.w & BW_TK_TS) ? 1 : 2;                              // only a word that starts with U+2581 can be taken whole (:176,189)
         if (p.stats) wv::atomic_add(&p.stats[0], 1ull);
@@ -311,11 +335,11 @@ struct BpeWave {
     // One transition for every lane at once, straight-line: a lane that is not walking (idle, waiting for the solve pass, walk over)
     // gathers entry 0 and keeps what it has.  j >= L afterwards: the walk is over (a miss sets j = L) and waits for unit_event().
     // An arc of collection mode is stored as [MPH index : 20 | start : 6 | end : 6]; the solve pass turns the index into the id.
-    BF_WVD void unit_step(Unit &u)
+    BF_WVD void unit_step(Unit &u, uint32_t c_home = 0)
     {
         // (truth values as integers, combined in the vector unit: bf_wave.h wv_b)
         const uint32_t act = wv_b(u.tok >= 0) & wv_b(u.mode != 3) & wv_b(u.j < u.L);
-        const uint32_t c = (uint32_t)S.ring[(u.rs + (uint32_t)u.j) & RMASK];
+        const uint32_t c = HOME ? c_home : (uint32_t)S.ring[(u.rs + (uint32_t)u.j) & RMASK];
         const uint32_t valid = act & wv_b(c < SG_CLS_DELIM_ABSENT);
         const uint64_t e = p.T[valid ? u.state + c : 0u];
         const uint32_t hit = valid & wv_b((uint32_t)(e & SG_CLS_MASK) == c);
@@ -350,7 +374,7 @@ struct BpeWave {
         for (int s0 = 0; s0 < u.L && !give_up; ++s0) {                   // :151-232 on the word (no unknown arc: a start without an arc gives up)
             uint32_t state = p.initial; int sum = 0; bool seen = false;
             for (int j = s0; j < u.L; ++j) {
-                const uint32_t c = (uint32_t)S.ring[(u.rs + (uint32_t)j) & RMASK];
+                const uint32_t c = sym_at(u, j);
                 if (c >= SG_CLS_DELIM_ABSENT) break;
                 const uint64_t e = p.T[state + c];
                 if ((e & SG_CLS_MASK) != c) break;
@@ -393,7 +417,7 @@ struct BpeWave {
             if (v != 0xFFFFFFFFu) { id = id_of_order((int)(v >> 6)); end = (int)(v & 63u); }
             else {
                 if (!((single >> pos) & 1ull)) { bad = true; break; }
-                const uint32_t c = (uint32_t)S.ring[(u.rs + (uint32_t)pos) & RMASK];
+                const uint32_t c = sym_at(u, pos);
                 id = p.info[(int)(p.T[p.initial + c] >> SG_OW_SHIFT)].id;
             }
             if (cnt == 0) first = id + p.id_offset; else { if (cnt == 1) home[0] = first; home[cnt] = id + p.id_offset; }
@@ -401,7 +425,7 @@ struct BpeWave {
             pos = end + 1;
         }
         if (bad || cnt == 0) { unit_fallback(u, 6); return; }
-        if (cnt == 1) S.q[(uint32_t)u.tok & QMASK].pos = (uint32_t)first;
+        if (cnt == 1) { if (HOME) home[0] = first; else S.q[(uint32_t)u.tok & QMASK].pos = (uint32_t)first; }
         unit_finish(u, cnt);
     }
     // the walk of the unit is over (ev): the whole word matched / go on collecting / all arcs collected
@@ -411,7 +435,8 @@ struct BpeWave {
         if (wv::any(whole)) {
             if (whole) {                                                // the word is one entry
                 const SegInfo r = p.info[u.sum];
-                S.q[(uint32_t)u.tok & QMASK].pos = (uint32_t)(r.id + p.id_offset);
+                if (HOME) p.ids_tmp[S.dt_slot[u.ke] + (int64_t)(u.rs - S.dt_rbase[u.ke])] = r.id + p.id_offset;
+                else S.q[(uint32_t)u.tok & QMASK].pos = (uint32_t)(r.id + p.id_offset);
                 if (p.stats) wv::atomic_add(&p.stats[1], 1ull);
                 unit_finish(u, 1);
             }
@@ -506,7 +531,7 @@ struct BpeWave {
             }
             if (id < 0) {                                                // no applied arc of more than one element starts here: the one-element arc
                 if (!((u.single >> pos) & 1ull)) { bad = true; break; }  // none: pTos[start] == 0 < start, the reference does not come back from here
-                const uint32_t c = (uint32_t)S.ring[(u.rs + (uint32_t)pos) & RMASK];
+                const uint32_t c = sym_at(u, pos);
                 const uint64_t e1 = p.T[p.initial + c];
                 id = p.info[(int)(e1 >> SG_OW_SHIFT)].id;
             } else id = id_of_order(id);
@@ -515,7 +540,7 @@ struct BpeWave {
             pos = end + 1;
         }
         if (bad || cnt == 0) { unit_fallback(u, 6); return; }
-        if (cnt == 1) S.q[(uint32_t)u.tok & QMASK].pos = (uint32_t)first;
+        if (cnt == 1) { if (HOME) home[0] = first; else S.q[(uint32_t)u.tok & QMASK].pos = (uint32_t)first; }
         unit_finish(u, cnt);
     }
     // Words with more arcs, one after the other by the whole wave: lane j takes arc j (BW_WIN <= 64), its rank among the keys from an
@@ -527,6 +552,7 @@ struct BpeWave {
             const int o = __builtin_ctzll(bigm); bigm &= bigm - 1ull;
             const int na = wv::bcast(u.narc, o), pw = wv::bcast(u.pw, o), L = wv::bcast(u.L, o), tok = wv::bcast(u.tok, o);
             const uint32_t rs = wv::bcast(u.rs, o), ke = wv::bcast(u.ke, o);
+            const int64_t gg = HOME ? wv::bcast(u.g, o) : 0;
             const unsigned long long single = wv::bcast(u.single, o);
             uint32_t *slot = lane < BW_PRIV ? &S.win[lane * 64 + o] : &S.pool[(lane - BW_PRIV) * BW_POOL_N + pw];
             uint32_t key = 0xFFFFFFFFu;
@@ -555,13 +581,13 @@ struct BpeWave {
             bool bad = false; int idv = my_id;
             if (is_tok && my_id < 0) {                                   // no applied arc of more than one element starts here: the one-element arc
                 if (!((single >> lane) & 1ull)) bad = true;
-                else { const uint32_t c = (uint32_t)S.ring[(rs + (uint32_t)lane) & RMASK]; const uint64_t e1 = p.T[p.initial + c]; idv = p.info[(int)(e1 >> SG_OW_SHIFT)].id; }
+                else { const uint32_t c = HOME ? (uint32_t)p.stream[gg + lane] : (uint32_t)S.ring[(rs + (uint32_t)lane) & RMASK]; const uint64_t e1 = p.T[p.initial + c]; idv = p.info[(int)(e1 >> SG_OW_SHIFT)].id; }
             }
             const unsigned long long mt = wv::ballot(is_tok);
             const int cnt = __builtin_popcountll(mt), k = __builtin_popcountll(mt & ((1ull << lane) - 1ull));
             if (wv::any(bad) || cnt == 0) { if (lane == o) unit_fallback(u, 6); wv::sync(); continue; }
             int32_t *home = p.ids_tmp + S.dt_slot[ke] + (int64_t)(rs - S.dt_rbase[ke]);
-            if (is_tok) { if (cnt == 1) S.q[(uint32_t)tok & QMASK].pos = (uint32_t)(idv + p.id_offset); else home[k] = idv + p.id_offset; }
+            if (is_tok) { if (cnt == 1 && !HOME) S.q[(uint32_t)tok & QMASK].pos = (uint32_t)(idv + p.id_offset); else home[k] = idv + p.id_offset; }
             wv::sync();
             if (lane == o) unit_finish(u, cnt);
             wv::sync();
@@ -605,14 +631,20 @@ struct BpeWave {
             }
             if (nb == 0) break;
             if (!drain && issue == tail && nb < UMIN) break;
-            for (int st = 0; st < STEPS; ++st) unit_step(u);
+            if (HOME) {
+                // the symbols of this round's transitions: one load (a lane that walks at all walks consecutive elements within a round)
+                static_assert(!HOME || STEPS <= 4, "four symbols per load");
+                uint64_t s4 = 0;
+                if (u.tok >= 0 && u.mode != 3 && u.j < u.L) __builtin_memcpy(&s4, p.stream + u.g + u.j, 8);      // (the stream buffer is padded)
+                for (int st = 0; st < STEPS; ++st) unit_step(u, (uint32_t)(s4 >> (16 * st)) & 0xFFFFu);
+            } else for (int st = 0; st < STEPS; ++st) unit_step(u);
             ran = true;
         }
         q_issue = issue;
         u_need = 0xFFFFFFFFu;
         {
             uint32_t need = 0xFFFFFFFFu;
-            if (u.tok >= 0) need = u.rs - rlo;
+            if (!HOME && u.tok >= 0) need = u.rs - rlo;
             if (wv::any(need != 0xFFFFFFFFu)) u_need = wv::min_all(need);
         }
         wv::sync();
@@ -624,6 +656,14 @@ struct BpeWave {
     // ------------------------------------------------------------------------------------------------------------------
     BF_WVD int retire(bool all)
     {
+        if (HOME) {                                                     // nothing moves: the finished words at the head of the queue give their places back
+            const uint32_t nav = q_issue - q_retire < 64u ? q_issue - q_retire : 64u;
+            if (nav == 0) return 0;
+            const unsigned long long fin = wv::ballot((uint32_t)lane < nav && S.qc[(q_retire + (uint32_t)lane) & QMASK] != 0);
+            const int nret = fin == ~0ull ? 64 : __builtin_ctzll(~fin);
+            q_retire += (uint32_t)nret;
+            return nret;
+        }
         const uint32_t navail = q_issue - q_retire < 64u ? q_issue - q_retire : 64u;
         if (navail == 0 || (!all && navail < 64u)) return 0;
         const uint32_t t = q_retire + (uint32_t)lane, sl = t & QMASK;
@@ -688,13 +728,14 @@ struct BpeWave {
                 const uint32_t e = kk & DMASK, f = S.dt_flags[e];
                 const int c = S.dt_cnt[e], cap = S.dt_cap[e];
                 const bool fb = (f & BW_DT_FALLBACK) != 0;
-                p.counts[S.dt_doc[e]] = fb ? 0 : (c < cap ? c : cap);
+                if (!HOME) p.counts[S.dt_doc[e]] = fb ? 0 : (c < cap ? c : cap);       // (HOME form: k_bpe_home_count counts the cells that hold an id)
                 p.flags[S.dt_doc[e]] = fb ? 1 : 0;
             }
             dt_head = limit; moved = true;
         }
         const uint32_t old_lo = rlo;
-        uint32_t keep = q_issue != q_tail ? S.q[q_issue & QMASK].pos - old_lo : (have_doc ? rbase + (uint32_t)(open_start >= 0 ? open_start : done) : rhi) - old_lo;
+        // (HOME form: a word is looked up when it is queued and a unit reads the class stream: the ring holds only what the fill has not resolved yet)
+        uint32_t keep = (!HOME && q_issue != q_tail) ? S.q[q_issue & QMASK].pos - old_lo : (have_doc ? rbase + (uint32_t)(open_start >= 0 ? open_start : done) : rhi) - old_lo;
         if (u_need < keep) keep = u_need;
         rlo = old_lo + keep; u_need -= u_need == 0xFFFFFFFFu ? 0u : keep;
         return moved || keep != 0;

@@ -388,7 +388,7 @@ int run_device(Handle *h, const char *d_text, const int64_t *d_doc_off, int64_t 
     Model &m = h->m;
     const int nblocks = scan_nblocks(ndocs);
     if (!reserve_ids_workspaces(h, ndocs, total_bytes, want_off, words)) return BF_E_DEVICE;
-    int slot_mul = 0; const int32_t *first = nullptr; bool uni_cut_keys = false;
+    int slot_mul = 0; const int32_t *first = nullptr; bool uni_cut_keys = false, bpe_home = false;
     unsigned long long *next_doc = h->w_misc.as<unsigned long long>();
     int *status = (int *)(h->w_misc.as<char>() + 16);
     Batch b{(const uint8_t *)d_text, d_doc_off, ndocs, total_bytes, status};
@@ -553,6 +553,11 @@ int run_device(Handle *h, const char *d_text, const int64_t *d_doc_off, int64_t 
             launch_bpe_wave(bw, (h->variant >> 8) & 0xf, s);
             (void)hipEventRecord(h->ev[EV_DOM1], s);
             launch_bpe_seg_flags(sg, bw.flags, h->w_perm.as<int32_t>(), h->w_hist.as<unsigned int>(), s);
+            bpe_home = bpe_wave_home((h->variant >> 8) & 0xf);
+            if (bpe_home) {          // the ids sit at their words' homes: count them (the documents k_bpe_seg redid keep its count)
+                BpeHomeParams hp{b, sg.ids_tmp, sg.lens, bw.flags, mul, sg.counts, d_id_off, d_ids_out, ids_cap, max_ids, status};
+                launch_bpe_home_count(hp, s);
+            }
         } else {
             // (the Unigram lane program records the two events around its forward kernel itself: the sort of the documents comes before it)
             sg.ev_dom0 = h->ev[EV_DOM0]; sg.ev_dom1 = h->ev[EV_DOM1];
@@ -572,6 +577,9 @@ int run_device(Handle *h, const char *d_text, const int64_t *d_doc_off, int64_t 
         UniIdsParams up{b, h->t_dict.as<uint64_t>(), m.dict.initial_base, h->t_segid.as<int32_t>(), h->w_cls.as<uint16_t>(), h->w_nchars.as<int32_t>(), slot_mul,
                         h->w_tmp.as<int32_t>(), h->w_counts.as<int32_t>(), d_id_off, d_ids_out, ids_cap, unk, m.id_offset, status};
         if (ndocs > 0) launch_uni_ids(up, s);
+    } else if (bpe_home) {
+        BpeHomeParams hp{b, h->w_tmp.as<int32_t>(), h->w_nchars.as<int32_t>(), h->w_bwflags.as<int32_t>(), slot_mul, h->w_counts.as<int32_t>(), d_id_off, d_ids_out, ids_cap, max_ids, status};
+        if (ndocs > 0) launch_bpe_home_gather(hp, s);
     } else if (ndocs > 0) launch_compact(cp, s);
     (void)hipEventRecord(h->ev[EV_COMPACT], s);
     h->ev_valid = true;
@@ -2010,7 +2018,8 @@ const char *BfStepKernels(void *p)
         return "prep: k_prep_sp8 | tokenise: k_sp_hist, k_sp_hist_scan, k_sp_scatter, k_seg_unigram_lane, k_uni_back | scan: k_scan_block_sums, k_scan_top, k_scan_apply | compact: k_compact_ids";
     case KIND_I2W: return "";
     default:
-        if (use_bpe_wave(h, false)) return "prep: k_prep_sp8 | tokenise: k_bpe_wave, k_bpe_flag_list, k_bpe_seg | scan: k_scan_block_sums, k_scan_top, k_scan_apply | compact: k_compact_ids";
+        if (use_bpe_wave(h, false)) return bpe_wave_home((h->variant >> 8) & 0xf) ? "prep: k_prep_sp8 | tokenise: k_bpe_wave, k_bpe_flag_list, k_bpe_seg, k_bpe_home_count | scan: k_scan_block_sums, k_scan_top, k_scan_apply | compact: k_bpe_home_gather"
+                                                                              : "prep: k_prep_sp8 | tokenise: k_bpe_wave, k_bpe_flag_list, k_bpe_seg | scan: k_scan_block_sums, k_scan_top, k_scan_apply | compact: k_compact_ids";
         return "prep: k_prep_sp8 | tokenise: k_sp_hist, k_sp_hist_scan, k_sp_scatter, k_bpe_fused, k_bpe_collect_list, k_bpe_sort, k_bpe_apply_flat, k_bpe_seg | scan: k_scan_block_sums, k_scan_top, k_scan_apply | compact: k_compact_ids";
     }
 }

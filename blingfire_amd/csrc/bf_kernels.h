@@ -110,6 +110,15 @@ struct UniIdsParams {
 };
 void launch_uni_ids(const UniIdsParams &p, hipStream_t s);
 
+// the HOME form of the BPE wave program (bf_bpe_wave_body.h): ids at their words' homes -> counts -> (scan) -> the caller's array (bf_kernels_sp.hip)
+struct BpeHomeParams {
+    Batch b; const int32_t *ids_tmp; const int32_t *lens; const int32_t *flags; int slot_mul;
+    int32_t *counts; const int64_t *id_off; int32_t *ids_out; int64_t ids_cap; int max_ids; int *status;
+};
+bool bpe_wave_home(int tune);
+void launch_bpe_home_count(const BpeHomeParams &p, hipStream_t s);
+void launch_bpe_home_gather(const BpeHomeParams &p, hipStream_t s);
+
 struct ScanParams { const int32_t *counts; int64_t ndocs; int64_t *id_off; int64_t *block_sums; int nblocks; };
 
 struct CompactParams {

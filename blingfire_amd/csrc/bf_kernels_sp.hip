@@ -17,22 +17,24 @@ namespace bfa {
 // k_bpe_wave: the BPE wave program (bf_bpe_wave_body.h) on the class streams k_prep_sp wrote.  The program is validated in the test
 // simulator (tests/test_bpe_wave_emu.py); the device path (bf_capi.cpp, behind BfSetVariant bit 0x40 until it has had its GPU parity
 // and timing runs) redoes the documents it hands back (flags[d] = 1) with the lane-per-document kernels.
-template <class LDS, int WPE, int STEPS, int UMIN>
+__host__ __device__ __forceinline__ int64_t sp_slot(int64_t doc_off_d, int64_t d, int mul) { return (int64_t)mul * (doc_off_d + d); }
+
+template <class LDS, int WPE, int STEPS, int UMIN, bool HOME>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_bpe_wave(BpeWaveParams p, int grab)
 {
     __shared__ LDS lds[4];
-    BpeWave<LDS, STEPS, UMIN> w(p, lds[wave_in_block()]);
+    BpeWave<LDS, STEPS, UMIN, HOME> w(p, lds[wave_in_block()]);
     w.run(grab, (int)(blockIdx.x * 4) + wave_in_block(), (int)(gridDim.x * 4));
 }
 
-template <int STEPS, int UMIN, int QCAP = 256>
+template <int STEPS, int UMIN, int QCAP = 256, bool HOME = true>
 static void launch_bpe_wave_cfg(const BpeWaveParams &p, hipStream_t s)
 {
     typedef BwLds<1024, QCAP, 8> L;
     static int per_cu = 0;
     if (per_cu <= 0) {
         int q = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&q, k_bpe_wave<L, 4, STEPS, UMIN>, 256, 0) != hipSuccess || q <= 0) q = 2;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&q, k_bpe_wave<L, 4, STEPS, UMIN, HOME>, 256, 0) != hipSuccess || q <= 0) q = 2;
         (void)hipGetLastError();
         per_cu = q;
     }
@@ -42,31 +44,101 @@ static void launch_bpe_wave_cfg(const BpeWaveParams &p, hipStream_t s)
     const int64_t need = (p.ndocs + (int64_t)grab * 4 - 1) / ((int64_t)grab * 4);
     if (blocks > need) blocks = need;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL((k_bpe_wave<L, 4, STEPS, UMIN>), dim3((unsigned)blocks), dim3(256), 0, s, p, grab);
+    hipLaunchKernelGGL((k_bpe_wave<L, 4, STEPS, UMIN, HOME>), dim3((unsigned)blocks), dim3(256), 0, s, p, grab);
 }
 
-// tune (experiments, BfSetVariant bits 8..11): 0 = shipped (four transitions per round, the units phase ends with fewer than 32 busy units, a queue
-// of 256 words); 1 .. 3: it ends with fewer than 16 / 4 / 48; 6: six transitions per round (queues of 512 / 128 words measured 22.6 / 22.7 ms
-// against 21.9 and are gone)
+// tune (BfSetVariant bits 8..11): 0 = shipped (the HOME form, four transitions per round, the units phase ends with fewer than 32 busy units, a queue
+// of 256 words); 8: the in-order form of rounds 4..5 (ids retired through the queue; A/B runs and tests); experiments builds: 1 .. 3: the phase ends
+// with fewer than 16 / 4 / 48; 6: six transitions per round (in-order form).  Queues of 512 / 1024 words cost a block per CU each: 22.9 / 31.5 ms against 18.8.
+bool bpe_wave_home(int tune) { return tune != 8 && tune != 1 && tune != 2 && tune != 3 && tune != 6 && tune != 4 && tune != 5 && tune != 7; }
 void launch_bpe_wave(const BpeWaveParams &p, int tune, hipStream_t s)
 {
 #ifdef BF_EXPERIMENTS
-    if (tune == 1) { launch_bpe_wave_cfg<4, 16>(p, s); return; }
-    if (tune == 2) { launch_bpe_wave_cfg<4, 4>(p, s); return; }
-    if (tune == 3) { launch_bpe_wave_cfg<4, 48>(p, s); return; }
-    if (tune == 6) { launch_bpe_wave_cfg<6, 32>(p, s); return; }
+    if (tune == 1) { launch_bpe_wave_cfg<4, 16, 256, false>(p, s); return; }
+    if (tune == 2) { launch_bpe_wave_cfg<4, 4, 256, false>(p, s); return; }
+    if (tune == 3) { launch_bpe_wave_cfg<4, 48, 256, false>(p, s); return; }
+    if (tune == 6) { launch_bpe_wave_cfg<6, 32, 256, false>(p, s); return; }
 #endif
-    if (tune == 4) { launch_bpe_wave_cfg<4, 32, 512>(p, s); return; }      // (round 6 A/B: with the word table four words in five sit in the queue answered, waiting for their turn to retire)
-    if (tune == 5) { launch_bpe_wave_cfg<4, 32, 1024>(p, s); return; }
-    if (tune == 7) { launch_bpe_wave_cfg<4, 8, 512>(p, s); return; }
-    launch_bpe_wave_cfg<4, 32>(p, s);
+    if (tune == 8) { launch_bpe_wave_cfg<4, 32, 256, false>(p, s); return; }
+    if (tune == 9) { launch_bpe_wave_cfg<4, 48, 256, true>(p, s); return; }
+    if (tune == 10) { launch_bpe_wave_cfg<3, 32, 256, true>(p, s); return; }
+    if (tune == 11) { launch_bpe_wave_cfg<4, 60, 256, true>(p, s); return; }
+    launch_bpe_wave_cfg<4, 32, 256, true>(p, s);
+}
+
+// The HOME form of the BPE wave program leaves every id at its word's home -- a cell of the document's staging slot under the word's own elements,
+// BW_HOME_NONE in the cells between -- and these two put them where the API wants them (tokdll:1512: the first max_ids of them, front to back):
+//   k_bpe_home_count   counts[d] = min(cells of the document that hold an id, max_ids); a document the program handed back (flags[d]) keeps the
+//                      count k_bpe_seg gave it
+//   k_bpe_home_gather  the cells that hold an id, in order, to ids_out + id_off[d]; a handed-back document's ids are dense at the slot's start
+// A wave per document, 64 cells per trip, one ballot and one population count each: streaming, 4 bytes per stream element read twice.
+__global__ __launch_bounds__(256) void k_bpe_home_count(BpeHomeParams p)
+{
+    const int lane = lane_id();
+    const int64_t wave0 = (int64_t)blockIdx.x * 4 + wave_in_block();
+    const int64_t nwaves = (int64_t)gridDim.x * 4;
+    for (int64_t d = wave0; d < p.b.ndocs; d += nwaves) {
+        if (p.flags[d]) continue;
+        const int L = p.lens[d];
+        const int32_t *cell = p.ids_tmp + sp_slot(p.b.doc_off[d], d, p.slot_mul);
+        int c = 0;
+        for (int i0 = 0; i0 < L && c < p.max_ids; i0 += 256) {      // four loads in flight
+            int32_t v[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { const int i = i0 + 64 * k + lane; v[k] = i < L ? cell[i] : BW_HOME_NONE; }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) c += __popcll(__ballot(v[k] != BW_HOME_NONE));
+        }
+        if (lane == 0) p.counts[d] = c < p.max_ids ? c : p.max_ids;
+    }
+}
+__global__ __launch_bounds__(256) void k_bpe_home_gather(BpeHomeParams p)
+{
+    const int lane = lane_id();
+    const int64_t wave0 = (int64_t)blockIdx.x * 4 + wave_in_block();
+    const int64_t nwaves = (int64_t)gridDim.x * 4;
+    bool over = false;
+    for (int64_t d = wave0; d < p.b.ndocs; d += nwaves) {
+        int c = p.counts[d];
+        if (c <= 0) continue;
+        const int64_t o = p.id_off[d];
+        if (o + c > p.ids_cap) { over = true; c = o < p.ids_cap ? (int)(p.ids_cap - o) : 0; }
+        const int32_t *cell = p.ids_tmp + sp_slot(p.b.doc_off[d], d, p.slot_mul);
+        int32_t *out = p.ids_out + o;
+        if (p.flags[d]) { for (int i = lane; i < c; i += 64) out[i] = cell[i]; continue; }
+        const int L = p.lens[d];
+        int k = 0;
+        for (int i0 = 0; i0 < L && k < c; i0 += 128) {
+            const int ia = i0 + lane, ib = i0 + 64 + lane;
+            const int32_t va = ia < L ? cell[ia] : BW_HOME_NONE, vb = ib < L ? cell[ib] : BW_HOME_NONE;
+            const unsigned long long ma = __ballot(va != BW_HOME_NONE), mb = __ballot(vb != BW_HOME_NONE);
+            const int ka = k + __popcll(ma & lanemask_lt()), kb = k + __popcll(ma) + __popcll(mb & lanemask_lt());
+            if (va != BW_HOME_NONE && ka < c) out[ka] = va;
+            if (vb != BW_HOME_NONE && kb < c) out[kb] = vb;
+            k += __popcll(ma) + __popcll(mb);
+        }
+    }
+    if (over) atomicOr(p.status, 1);
+}
+void launch_bpe_home_count(const BpeHomeParams &p, hipStream_t s)
+{
+    int64_t blocks = (p.b.ndocs + 3) / 4;
+    if (blocks > device_cus() * 16) blocks = device_cus() * 16;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(k_bpe_home_count, dim3((unsigned)blocks), dim3(256), 0, s, p);
+}
+void launch_bpe_home_gather(const BpeHomeParams &p, hipStream_t s)
+{
+    int64_t blocks = (p.b.ndocs + 3) / 4;
+    if (blocks > device_cus() * 16) blocks = device_cus() * 16;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(k_bpe_home_gather, dim3((unsigned)blocks), dim3(256), 0, s, p);
 }
 
 // ------------------------------------------------------------------------------------------
 // k_prep_sp: wave per document.  bytes / strict UTF-8 -> fused charmap+element-code map -> dummy prefix ->
 // whitespace collapse (local keep-predicate) -> trailing trim  (tokdll:1367-1496).
 // ------------------------------------------------------------------------------------------
-__host__ __device__ __forceinline__ int64_t sp_slot(int64_t doc_off_d, int64_t d, int mul) { return (int64_t)mul * (doc_off_d + d); }
 
 __device__ __forceinline__ bool sp_delimish(uint32_t code, uint32_t delim) { return code == 0xFFFDu || code == delim; }
 

@@ -176,6 +176,8 @@ long bft_emu_bpe_wave_batch(void *hv, const uint8_t *text, long text_bytes, cons
     // the word table (cfg bit 3: without it -- the program must give the same ids either way)
     if (!(cfg & 8) && !m.bpe_tab.empty()) { p.W = m.bpe_tab.data(); p.wbits = m.bpe_tab_bits; p.m0 = m.bpe_tab_m0; p.m1 = m.bpe_tab_m1; p.m2 = m.bpe_tab_m2; }
     cfg &= ~8;
+    const bool home = (cfg & 32) != 0;                                   // the HOME form (ids at their words' homes; count + gather restated below)
+    cfg &= ~32;
     if (ndocs > 0) {
         auto run = [&](auto *lds_tag) {
             typedef typename std::remove_pointer<decltype(lds_tag)>::type LDS;
@@ -187,8 +189,8 @@ long bft_emu_bpe_wave_batch(void *hv, const uint8_t *text, long text_bytes, cons
                 size_t k = 0;
                 for (; k < wave_ids.size(); ++k) if (wave_ids[k] == wid) break;
                 if (k == wave_ids.size()) wave_ids.push_back(wid);
-                BpeWave<LDS> w(p, *of_wave[k]);
-                w.run(grab, (int)k, nwaves);
+                if (home) { BpeWave<LDS, 3, 4, true> w(p, *of_wave[k]); w.run(grab, (int)k, nwaves); }
+                else { BpeWave<LDS> w(p, *of_wave[k]); w.run(grab, (int)k, nwaves); }
             };
             wvemu::run_waves(nwaves, body);
             for (auto *q : of_wave) delete q;
@@ -200,10 +202,15 @@ long bft_emu_bpe_wave_batch(void *hv, const uint8_t *text, long text_bytes, cons
     std::vector<int32_t> one((size_t)(max_ids > 0 ? max_ids : 1));
     for (long d = 0; d < ndocs; ++d) {
         id_off[d] = o;
-        if (counts[(size_t)d] < 0 || flags[(size_t)d] < 0) return -7;                 // a document the kernel never settled
+        if ((!home && counts[(size_t)d] < 0) || flags[(size_t)d] < 0) return -7;      // a document the kernel never settled
         if (flags_out) flags_out[d] = flags[(size_t)d];
         int c = counts[(size_t)d];
         const int32_t *src = tmp.data() + (size_t)mul * (size_t)(doc_off[d] + d);
+        std::vector<int32_t> squeezed;
+        if (home && !flags[(size_t)d]) {                                               // k_bpe_home_count / k_bpe_home_gather: the cells that hold an id, front to back
+            for (int i = 0; i < lens[(size_t)d] && (int)squeezed.size() < max_ids; ++i) if (src[i] != BW_HOME_NONE) squeezed.push_back(src[i]);
+            c = (int)squeezed.size(); src = squeezed.data();
+        }
         if (flags[(size_t)d]) {                                                        // handed back: the lane-per-document path
             c = bft_emu_sp_doc(m, (const char *)text + doc_off[d], (int)(doc_off[d + 1] - doc_off[d]), one.data(), max_ids, unk);
             if (c < 0) return -8;

@@ -13,8 +13,8 @@ import blingfire_amd as bf
 
 MODELS = ["gpt2.bin", "roberta.bin", "bpe_example.bin", "bpe_example2.bin"]
 # (max_ids, unk, waves, documents per range, configuration: 0 = queue 256 / 8 open documents, 1 = queue 128 / 2 open documents; + 16 = no work counter;
-#  + 8 = without the word table of round 6 -- the program gives the same ids either way)
-CONFS = [(512, 0, 1, 8, 0), (512, 3, 3, 2, 1), (7, 5, 2, 3, 16), (0, 0, 1, 8, 0), (2048, 0, 4, 8, 17), (1, 1, 2, 1, 1), (512, 0, 2, 8, 8), (64, 3, 3, 2, 9)]
+#  + 8 = without the word table of round 6 -- the program gives the same ids either way; + 32 = the HOME form (what ships: ids at their words' homes))
+CONFS = [(512, 0, 1, 8, 32), (512, 3, 3, 2, 33), (7, 5, 2, 3, 48), (0, 0, 1, 8, 32), (2048, 0, 4, 8, 49), (1, 1, 2, 1, 33), (512, 0, 2, 8, 40), (64, 3, 3, 2, 9), (512, 0, 1, 8, 0), (7, 5, 2, 3, 17)]
 
 
 @pytest.fixture(scope="module")
@@ -95,7 +95,7 @@ def test_long_words_runs_and_tiny_documents(ht, model):
                  (" " * L).encode(), ("a " * L).encode(), ("the quick brown fox " * (L // 8 + 1)).encode(), ("▁" * (L % 40 + 1)).encode()]
     docs += [bytes([rnd.randrange(32, 127)]) for _ in range(300)] + [b"", b" ", b"\xff", b"\xef\xbb\xbf", b"\xef\xbb\xbfhello world"]
     docs.append(" ".join("".join(rnd.choice(alpha) for _ in range(rnd.randint(1, 12))) for _ in range(6000)).encode())       # ~40 KB
-    check(ht, model, docs, CONFS[:4])
+    check(ht, model, docs, CONFS[:4] + CONFS[8:9])
 
 
 def test_multilingual_and_charmap_model(ht):
@@ -113,8 +113,8 @@ def test_word_table_answers_most_words(ht):
         pytest.skip("%s not present" % model)
     text, off = bfutil.gen_workload("config3", 300)
     h = ht.bft_load(bfutil.model_path(model).encode())
-    r, ids, ido, fl, st = run(ht, h, text, off, 2048, 0, 2, 8, 0)
-    r2, ids2, ido2, fl2, st2 = run(ht, h, text, off, 2048, 0, 2, 8, 8)
+    r, ids, ido, fl, st = run(ht, h, text, off, 2048, 0, 2, 8, 32)
+    r2, ids2, ido2, fl2, st2 = run(ht, h, text, off, 2048, 0, 2, 8, 40)
     ht.bft_free(h)
     assert r >= 0 and r == r2 and np.array_equal(ids, ids2) and np.array_equal(ido, ido2)
     words_unit, whole_unit, table = int(st[0]), int(st[1]), int(st[12])

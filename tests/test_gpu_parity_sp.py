@@ -164,7 +164,8 @@ def test_bpe_wave_program_variant(model, checker):
         docs = list(bfutil.ADVERSARIAL) + bfutil.fuzz_docs(2500, seed=17)
         text, off = bfutil.gen_workload("config3", 20000)
         gids, goff = checker.batch(hck, text, off, 2048, 0)
-        for variant in (3, 3 | 0x40, 3 | 0x100000):               # the wave program with its word table (round 6), the lane kernels alone, the wave program without the table
+        # the wave program as shipped (HOME form + word table, round 6), the lane kernels alone, without the table, the in-order form of rounds 4..5 with and without it
+        for variant in (3, 3 | 0x40, 3 | 0x100000, 3 | (8 << 8), 3 | (8 << 8) | 0x100000, 3 | (9 << 8)):
             bf.lib().BfSetVariant(h, variant)
             for max_ids, unk in ((2048, 0), (3, 0), (64, 3), (1, 1), (2048, 262)):
                 _compare(h, checker, hck, docs, max_ids, unk)
