@@ -631,12 +631,49 @@ def main():
         if r != n_ids or int(a_off[-1]) != n_ids:
             raise RuntimeError("TextToIdsBatch on host buffers returned %d ids, the device-resident run %d" % (r, n_ids))
         del a_ids, a_off
+        # what the link does on this box, each direction alone and both together (pinned memory, 1 GiB each way): the yardstick for the host API's figure
+        pcie = None
+        try:
+            nbytes = 1 << 30
+            hp_in = torch.empty(nbytes, dtype=torch.uint8).pin_memory(); hp_out = torch.empty(nbytes, dtype=torch.uint8).pin_memory()
+            d_in = torch.empty(nbytes, dtype=torch.uint8, device=dev); d_out = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            s_in, s_out = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+            def timed(do_in, do_out):
+                best = 1e9
+                for _ in range(3):
+                    torch.cuda.synchronize(dev)
+                    t1 = time.perf_counter()
+                    if do_in:
+                        with torch.cuda.stream(s_in): d_in.copy_(hp_in, non_blocking=True)
+                    if do_out:
+                        with torch.cuda.stream(s_out): hp_out.copy_(d_out, non_blocking=True)
+                    torch.cuda.synchronize(dev)
+                    best = min(best, time.perf_counter() - t1)
+                return best
+            t_in, t_out, t_both = timed(True, False), timed(False, True), timed(True, True)
+            pcie = {"h2d_GBps": nbytes / t_in / 1e9, "d2h_GBps": nbytes / t_out / 1e9, "both_directions_GBps_sum": 2 * nbytes / t_both / 1e9,
+                    "what": "1 GiB of pinned memory each way, best of 3, the two directions on two streams"}
+            del hp_in, hp_out, d_in, d_out
+        except Exception as e:
+            pcie = {"error": str(e)}
+        b_in, b_out = int(total_bytes) + 8 * (n_api + 1), 4 * int(n_ids) + 8 * (n_api + 1)
+        api_t = min(api)
+        link = None
+        if pcie and "h2d_GBps" in pcie:
+            serial = b_in / (pcie["h2d_GBps"] * 1e9) + b_out / (pcie["d2h_GBps"] * 1e9)
+            ideal = max(b_in / (pcie["h2d_GBps"] * 1e9), b_out / (pcie["d2h_GBps"] * 1e9))
+            link = {"bytes_in": b_in, "bytes_out": b_out, "GBps_in": b_in / api_t / 1e9, "GBps_out": b_out / api_t / 1e9,
+                    "ms_if_the_copies_ran_one_after_the_other": serial * 1e3, "ms_if_they_overlapped_fully": ideal * 1e3,
+                    "overlap_fraction": max(0.0, min(1.0, (serial - api_t) / (serial - ideal))) if serial > ideal else None,
+                    "what": "the call's wall clock against this box's pinned copy rates: 1 = as fast as the slower direction alone, 0 = as slow as both in a row (pageable buffers: the staging copies are on top)"}
         res["timings"] = {
             "kernel_only": {"docs_per_s": value, "ms_per_step": res["ms_per_step"], "what": "device-resident input and output, the whole shard (= value)"},
             "device_e2e_pinned": {"docs_per_s": ns / min(e2e), "ms": min(e2e) * 1e3, "median_ms": float(np.median(e2e)) * 1e3, "sample_docs": ns,
                                   "what": "pinned host text -> H2D -> kernels -> D2H ids+offsets, one batch, best of 3"},
             "host_api_wall": {"docs_per_s": n_api / min(api), "ms": min(api) * 1e3, "median_ms": float(np.median(api)) * 1e3, "sample_docs": n_api,
-                              "what": "wall clock of TextToIdsBatch on pageable host arrays (chunked through pinned staging, bf_capi.cpp run_host_chunked), output arrays reused, best of 3"},
+                              "what": "wall clock of TextToIdsBatch on pageable host arrays (chunked through pinned staging, bf_capi.cpp run_host_chunked), output arrays reused, best of 3",
+                              "link": link},
+            "pcie": pcie,
         }
         # work-rate roofline of the lexer: table gathers per second against the measured gather ceiling.
         # Counted by the instrumented instance of the SAME kernel in one extra untimed step (BfSetLexStats).

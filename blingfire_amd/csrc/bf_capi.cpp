@@ -351,7 +351,7 @@ bool reserve_ids_workspaces(Handle *h, int64_t ndocs, int64_t total_bytes, bool 
         if (use_flat(h, want_off, words, ndocs, total_bytes) &&
             (!h->w_ent.reserve((size_t)(total_bytes + 64) * 4) || !h->w_home.reserve((size_t)(total_bytes + 64) * 4) || !h->w_entoff.reserve((size_t)(ndocs + 1) * 8) ||
              !h->w_entcnt.reserve((size_t)(ndocs + 1) * 4) || !h->w_dstat.reserve((size_t)(ndocs + 1) * 4) || !h->w_list.reserve((size_t)(ndocs + 1) * 4) ||
-             !h->w_ranges.reserve((size_t)(wp_flat_ranges(ndocs, total_bytes) + 2) * 8) || !h->w_wrec.reserve((size_t)(total_bytes / 4 + 64) * 16 + (size_t)(wp_flat_ranges(ndocs, total_bytes) + 2) * 8) ||
+             !h->w_ranges.reserve((size_t)(wp_flat_ranges(ndocs, total_bytes) + 2) * 8) || !h->w_wrec.reserve((size_t)((total_bytes >> WF_REC_SHIFT) + 64) * 16 + (size_t)(wp_flat_ranges(ndocs, total_bytes) + 2) * 8) ||
              (want_off && (!h->w_espan.reserve((size_t)(total_bytes + 64) * 4) || !h->w_hspan.reserve((size_t)(total_bytes + 64) * 8) || !h->w_chard.reserve((size_t)(ndocs + 1) * 4))))) return false;
         if (use_wave(h, want_off, words))                              // no class stream, no dirty flags
             return !want_off || h->w_span.reserve((size_t)(total_bytes + 8 * ndocs + 64) * 8);
@@ -416,7 +416,7 @@ int run_device(Handle *h, const char *d_text, const int64_t *d_doc_off, int64_t 
         fp.range_doc = h->w_ranges.as<int64_t>(); fp.nranges = nranges; fp.next_range = (unsigned long long *)(misc + 192); fp.unsafe = unsafe;
         fp.ent = h->w_ent.as<uint32_t>(); fp.home = h->w_home.as<int32_t>(); fp.ent_off = h->w_entoff.as<int64_t>(); fp.ent_cnt = h->w_entcnt.as<int32_t>();
         fp.dstat = h->w_dstat.as<int32_t>(); fp.cold = cold; fp.espan = want_off ? h->w_espan.as<uint32_t>() : nullptr;
-        fp.wrec = h->w_wrec.as<uint32_t>(); fp.wrec_cnt = (int32_t *)(h->w_wrec.as<char>() + (size_t)(total_bytes / 4 + 64) * 16);
+        fp.wrec = h->w_wrec.as<uint32_t>(); fp.wrec_cnt = (int32_t *)(h->w_wrec.as<char>() + (size_t)((total_bytes >> WF_REC_SHIFT) + 64) * 16);
         if (!hip_ok(hipMemsetAsync(fp.wrec_cnt, 0, (size_t)nranges * 8, s), "hipMemsetAsync")) return BF_E_DEVICE;      // (a range without documents writes nothing)
 #ifdef BF_EXPERIMENTS
         fp.dbg = (h->variant >> 20) & 0xf;

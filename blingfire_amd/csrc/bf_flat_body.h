@@ -233,7 +233,7 @@ struct WfWave {
     }
     // the words in S.rec go to the list (one atomic for all of them; a list that is full hands their documents on: cannot be but for text
     // that is all words the table does not hold)
-    // The words in S.rec go to the lists of the range.  A range owns the records [b0 / 4, (b0 + len) / 4) (no counter is shared between waves: a
+    // The words in S.rec go to the lists of the range.  A range owns the records [b0 / 16, (b0 + len) / 16) (WF_REC_SHIFT) (no counter is shared between waves: a
     // counter that 8,000 waves add to costs more than the walks): the words a unit holds in registers (plain ASCII, <= 16 bytes, 16 readable bytes
     // behind their first) from the front, the others from the back.  A range whose words do not fit hands their documents on (cannot be but
     // for text that is all words the table does not hold).
@@ -246,7 +246,7 @@ struct WfWave {
             const bool fastw = lane < nrec && (r2 & WF_REC_PLAIN) != 0u && (r2 & 0xFFu) <= 16u && b0 + (int64_t)r1 + 16 <= p.total_bytes;
             const unsigned long long FB = wv::ballot(fastw), SB = wv::ballot(lane < nrec && !fastw);
             const int nf = __builtin_popcountll(FB), ns = __builtin_popcountll(SB);
-            const int64_t lo = (b0 + 3) >> 2, hi = (b0 + (int64_t)len) >> 2;           // the range's records
+            const int64_t lo = (b0 + (1 << WF_REC_SHIFT) - 1) >> WF_REC_SHIFT, hi = (b0 + (int64_t)len) >> WF_REC_SHIFT;           // the range's records
             if ((int64_t)(wf_n + nf + ws_n + ns) <= hi - lo) {
                 if (lane < nrec) {
                     uint32_t *d = p.wrec + 4 * (fastw ? lo + wf_n + (int64_t)wv::mbcnt(FB) : hi - 1 - ws_n - (int64_t)wv::mbcnt(SB));

@@ -13,6 +13,8 @@ namespace bfa {
 
 constexpr int WF_CHUNK = 512;            // bytes per step (8 per lane)
 constexpr int WF_RING = 1024;            // byte positions whose class is kept (two chunks: a run may begin in the chunk before)
+constexpr int WF_REC_SHIFT = 4;           // a range of b bytes owns b >> WF_REC_SHIFT records of the word list (round 6: one per 16 bytes instead of one per 4 -- 1.3 instead of 4 bytes of
+                                         // workspace per byte of text; the metric's corpus needs one per 167 bytes, a range whose words do not fit hands their documents on)
 constexpr int WF_REC = 64;               // words that wait for a unit, at most (one per lane)
 constexpr int WF_RUN_MAX = 48;           // bytes of the longest run the program resolves itself
 constexpr int WF_KEY_CHARS = 12;         // one byte per character (its code: class + 1, 1 .. 127)

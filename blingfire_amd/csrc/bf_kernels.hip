@@ -671,7 +671,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
         if (dlo >= dhi) continue;
         const int64_t b0 = p.doc_off[dlo], b1 = p.doc_off[dhi];
         const unsigned long long nfast = (unsigned long long)p.wrec_cnt[2 * r], nslow = (unsigned long long)p.wrec_cnt[2 * r + 1];
-        const uint32_t *fl = p.wrec + 4 * ((b0 + 3) >> 2), *sl = p.wrec + 4 * ((b1 >> 2) - (int64_t)nslow);       // (the second list grows down from the end: its order does not matter)
+        const uint32_t *fl = p.wrec + 4 * ((b0 + (1 << WF_REC_SHIFT) - 1) >> WF_REC_SHIFT), *sl = p.wrec + 4 * ((b1 >> WF_REC_SHIFT) - (int64_t)nslow);       // (the second list grows down from the end: its order does not matter)
         uint16_t *cb = cbuf[wave_in_block()];
         for (unsigned long long first = 0; first < nfast; first += 64 * NU) { wf_units<NU, STATS, 0, OFFS>(p, lut, cb, fl, b0, dlo, first, nfast, &rounds); ++batches; }
         for (unsigned long long first = 0; first < nslow; first += 64) { wf_units<1, STATS, 1, OFFS>(p, lut, cb, sl, b0, dlo, first, nslow, &rounds); wf_units<1, STATS, 2, OFFS>(p, lut, cb, sl, b0, dlo, first, nslow, &rounds); ++batches; }

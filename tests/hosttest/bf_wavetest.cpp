@@ -343,7 +343,7 @@ static long emu_flat_batch(void *hv, const uint8_t *text, long text_bytes, const
     fp.ent = ent.data(); fp.home = home.data(); fp.ent_off = entoff.data(); fp.ent_cnt = entcnt.data(); fp.dstat = dstat.data(); fp.cold = cold;
     fp.espan = offs ? espan.data() : nullptr;
     (void)wrec_cap_in;
-    std::vector<uint32_t> wrec((size_t)(total / 4 + 64) * 4, 0xDEADBEEFu); std::vector<int32_t> wrec_cnt((size_t)nranges * 2 + 2, 0);
+    std::vector<uint32_t> wrec((size_t)((total >> WF_REC_SHIFT) + 64) * 4, 0xDEADBEEFu); std::vector<int32_t> wrec_cnt((size_t)nranges * 2 + 2, 0);
     fp.wrec = wrec.data(); fp.wrec_cnt = wrec_cnt.data();
     if (ndocs > 0) {
         std::vector<uint32_t> lut(WF_LUT);
@@ -380,7 +380,7 @@ static long emu_flat_batch(void *hv, const uint8_t *text, long text_bytes, const
                 if (dlo >= dhi) continue;
                 const int64_t b0 = doc_off[dlo], b1 = doc_off[dhi];
                 const unsigned long long nfast = (unsigned long long)wrec_cnt[2 * (size_t)r], nslow = (unsigned long long)wrec_cnt[2 * (size_t)r + 1];
-                const uint32_t *fl = up.wrec + 4 * ((b0 + 3) >> 2), *sl = up.wrec + 4 * ((b1 >> 2) - (int64_t)nslow);
+                const uint32_t *fl = up.wrec + 4 * ((b0 + (1 << WF_REC_SHIFT) - 1) >> WF_REC_SHIFT), *sl = up.wrec + 4 * ((b1 >> WF_REC_SHIFT) - (int64_t)nslow);
                 if (offs) {
                     for (unsigned long long first = 0; first < nfast; first += 128) wf_units<2, true, 0, true>(up, lut.data(), cbuf.data(), fl, b0, dlo, first, nfast, &rounds);
                     for (unsigned long long first = 0; first < nslow; first += 64) { wf_units<1, true, 1, true>(up, lut.data(), cbuf.data(), sl, b0, dlo, first, nslow, &rounds); wf_units<1, true, 2, true>(up, lut.data(), cbuf.data(), sl, b0, dlo, first, nslow, &rounds); }

@@ -79,8 +79,8 @@ if [ -z "$quick" ]; then
   line default_offsets --offsets --verify 2000000
   prof config2 "config2/$model/1000000" k_wp_flat 1 0 --workload config2
   prof config3 "config3/gpt2.bin/1000000" k_bpe_wave 1 0 --workload config3
-  prof config4 "config4/xlm_roberta_base.bin/10000000" k_seg_unigram_lane 4 0 --workload config4
-  prof config5 "config5/laser500k.bin/10000000" k_seg_unigram_lane 4 0 --workload config5
+  prof config4 "config4/xlm_roberta_base.bin/10000000" k_uni_cut 4 0 --workload config4
+  prof config5 "config5/laser500k.bin/10000000" k_uni_cut 4 0 --workload config5
   for w in config2 config1 config3 config4 config5; do line $w --workload $w; done
 fi
 cp profiles/traffic.json profiles/fetch_calibration.json $O/ 2>/dev/null
