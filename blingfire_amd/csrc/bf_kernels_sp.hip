@@ -1463,7 +1463,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     ClsWinS cls_at; cls_at.init(p.stream, 0);
     UniCut<ClsWinS, RingCut> uc(p.S, cls_at, ring);
     uc.L = 0; uc.depth = p.trie_depth; uc.W = W; uc.start = uc.i = uc.sum = 0; uc.state = 0; uc.unknown = true; uc.pend = false; uc.walking = false; uc.prev = 0; uc.pend_i = 0;
-    uc.pend_score = 0; uc.unk_run = 0; uc.reach = -1; uc.rk = 0; uc.rs = 0; uc.ck = 0; uc.cs = -1; uc.cut0 = 0; uc.lastcut = -1; uc.ring_lo = 0; uc.nout = 0;
+    uc.pend_score = 0; uc.unk_run = 0; uc.reach = -1; uc.rk = 0; uc.rs = 0; uc.ck = 0; uc.cs = -1; uc.cut0 = 0; uc.lastcut = -1; uc.ring_lo = 0; uc.nout = 0; uc.tok_align = 0;
     int mode = M_NEED;
     int64_t doc = 0; int32_t *toks = nullptr;
     for (unsigned long long trip = 0; trip < (1ull << 34); ++trip) {
@@ -1487,7 +1487,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
                         const int L = p.lens[doc];
                         toks = p.ids_tmp + slot;
                         if (L <= 0) { p.counts[doc] = 0; p.narcs[doc] = 0; }
-                        else { cls_at.init(p.stream, slot); uc.init(L, p.trie_depth, W, (uint8_t *)p.best + slot); mode = M_WALK; }
+                        else { cls_at.init(p.stream, slot); uc.init(L, p.trie_depth, W, (uint8_t *)p.best + slot); uc.tok_align = (int)(slot & 3); mode = M_WALK; }
                     }
                 }
                 if (__ballot(mode != M_EXIT) == 0) break;
@@ -1495,7 +1495,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         }
         cls_at.refill(mode == M_WALK);
         // ---- forward pass: UNROLL trie transitions
-        auto put = [&](int k, uint32_t v) { if (k < p.max_ids) toks[k] = (int32_t)v; };
+        struct TokPut {
+            int32_t *toks; int max_ids;
+            __device__ __forceinline__ void operator()(int k, uint32_t v) const { if (k < max_ids) toks[k] = (int32_t)v; }
+            __device__ __forceinline__ void quad(int k, uint32_t a, uint32_t b, uint32_t c, uint32_t d) const
+            {
+                if (k + 3 < max_ids) *(uint4 *)(toks + k) = make_uint4(a, b, c, d);
+                else { (*this)(k, a); (*this)(k + 1, b); (*this)(k + 2, c); (*this)(k + 3, d); }
+            }
+        } put{toks, p.max_ids};
         // a trip: UNROLL transitions of the lane's walk (a walk that is over waits), then -- once, for all the lanes whose walk is over -- the
         // end of the start position; the short way out for the chunks that are complete
         const bool can = mode == M_WALK && uc.room(UNROLL);

@@ -320,7 +320,12 @@ static int emu_sp(const Model &m, const char *s, int n, int32_t *ids, int32_t *s
         std::vector<uint8_t> spill_all((size_t)L + 64, (uint8_t)0xEE);
         uc.init(L, m.trie_max_depth, g_uni_cut_w, spill_all.data() + 32);
         std::vector<uint32_t> toks((size_t)L + 1, 0xDEADBEEFu);
-        auto put = [&](int k, uint32_t v) { toks[(size_t)k] = v; };
+        struct HostPut {
+            std::vector<uint32_t> &toks; int align;
+            void operator()(int k, uint32_t v) const { toks[(size_t)k] = v; }
+            void quad(int k, uint32_t a, uint32_t b, uint32_t c, uint32_t d) const { if (((k + align) & 3) != 0) abort(); toks[(size_t)k] = a; toks[(size_t)k + 1] = b; toks[(size_t)k + 2] = c; toks[(size_t)k + 3] = d; }
+        } put{toks, n % 4};
+        uc.tok_align = n % 4;                                           // (the document's token array starts at any alignment, like a slot on the device)
         int widest = 0; unsigned long long chunks = 0, restarts = 0, spills = 0;
         // the trip of k_uni_cut: K transitions of the walk (a walk that is over waits), the end of the start position once, the short way out; the
         // emission phase when the document is done, the ring has no room, or every `period` trips
@@ -519,7 +524,12 @@ int bft_uni_cut_fuzz(unsigned seed, int ndicts, int ntexts, unsigned long long *
             std::vector<uint8_t> sp((size_t)L + 2, (uint8_t)0xEE);
             uc.init(L, depth, W, sp.data());
             std::vector<uint32_t> toks((size_t)L + 1, 0xDEADBEEFu);
-            auto put = [&](int k, uint32_t v) { toks[(size_t)k] = v; };
+            struct HostPut {
+                std::vector<uint32_t> &toks; int align;
+                void operator()(int k, uint32_t v) const { toks[(size_t)k] = v; }
+                void quad(int k, uint32_t a, uint32_t b, uint32_t c, uint32_t d) const { if (((k + align) & 3) != 0) abort(); toks[(size_t)k] = a; toks[(size_t)k + 1] = b; toks[(size_t)k + 2] = c; toks[(size_t)k + 3] = d; }
+            } put{toks, (int)(rnd() % 4u)};
+            uc.tok_align = put.align;
             const unsigned period = 1 + rnd() % 40u; const int K = 1 + (int)(rnd() % 4u); const bool use_quick = rnd() % 4u != 0;
             bool hang = false;
             for (unsigned trip = 1;; ++trip) {                            // the trip of k_uni_cut (emu_sp above)

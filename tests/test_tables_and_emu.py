@@ -133,16 +133,16 @@ def test_unigram_cut_form_on_host(ht, model):
     if ht.bft_emu_text_to_ids(h, b"a", 1, (ctypes.c_int32 * 4)(), 4, 0) == -1:
         pytest.skip("not a Unigram model")
     ho = ora.load(bfutil.model_path(model))
-    text, off = bfutil.gen_workload("config1", 1500)
+    text, off = bfutil.gen_workload("config1", 600)
     raw = text.tobytes()
-    docs = list(bfutil.ADVERSARIAL) + bfutil.fuzz_docs(1200, seed=61) + [raw[off[d]:off[d + 1]] for d in range(len(off) - 1)]
+    docs = list(bfutil.ADVERSARIAL) + bfutil.fuzz_docs(500, seed=61) + [raw[off[d]:off[d + 1]] for d in range(len(off) - 1)]
     docs += [("x" * n + " " + "\u0e01\u0e32\u0e23" * n).encode("utf-8") for n in (20, 40, 90)] + [("\U000F0000" * 70 + " a").encode("utf-8")]
     want = []
     for k, b in enumerate(docs):
         want.append(ora.text_to_ids(ho, b, (1024, 3, 64, 1)[k % 4], (3, 0, 257)[k % 3]))
     try:
         seen = [0, 0, 0]
-        for W, period, K in ((32, 1, 3), (32, 3, 3), (32, 8, 1), (64, 1 << 30, 3), (32, 8, 3), (32, 32, 2), (32, 32, 4)):     # (period: trips of the driver, K transitions each)
+        for W, period, K in ((32, 1, 3), (32, 3, 3), (64, 1 << 30, 1), (32, 32, 3), (32, 8, 4)):     # (period: trips of the driver, K transitions each)
             ht.bft_set_uni_cut(W, period)
             ht.bft_set_uni_cut_k(K)
             ht.bft_set_uni_cut_quick(0 if (W, period) == (32, 3) else 1)        # (once without the short way out: every chunk through the emission phase)
@@ -229,8 +229,8 @@ def test_unigram_cut_form_structural_fuzz(ht):
     _cut_api(ht)
     restarts, spills = ctypes.c_ulonglong(), ctypes.c_ulonglong()
     total_r = total_s = 0
-    for seed in (1, 2, 3, 4):
-        assert ht.bft_uni_cut_fuzz(seed, 1500, 40, ctypes.byref(restarts), ctypes.byref(spills)) == 0
+    for seed in (1, 2, 3):
+        assert ht.bft_uni_cut_fuzz(seed, 1200, 40, ctypes.byref(restarts), ctypes.byref(spills)) == 0
         total_r += restarts.value
         total_s += spills.value
     assert total_r > 1000 and total_s > 10000
