@@ -14,7 +14,7 @@ import blingfire_amd as bf
 MODELS = ["gpt2.bin", "roberta.bin", "bpe_example.bin", "bpe_example2.bin"]
 # (max_ids, unk, waves, documents per range, configuration: 0 = queue 256 / 8 open documents, 1 = queue 128 / 2 open documents; + 16 = no work counter;
 #  + 8 = without the word table of round 6 -- the program gives the same ids either way; + 32 = the HOME form (what ships: ids at their words' homes))
-CONFS = [(512, 0, 1, 8, 32), (512, 3, 3, 2, 33), (7, 5, 2, 3, 48), (0, 0, 1, 8, 32), (2048, 0, 4, 8, 49), (1, 1, 2, 1, 33), (512, 0, 2, 8, 40), (64, 3, 3, 2, 9), (512, 0, 1, 8, 0), (7, 5, 2, 3, 17)]
+CONFS = [(512, 0, 1, 8, 32), (512, 3, 3, 2, 33), (7, 5, 2, 3, 48), (0, 0, 1, 8, 32), (2048, 0, 4, 8, 49), (512, 0, 2, 8, 40), (64, 3, 3, 2, 9), (7, 5, 2, 3, 16)]
 
 
 @pytest.fixture(scope="module")
@@ -95,7 +95,7 @@ def test_long_words_runs_and_tiny_documents(ht, model):
                  (" " * L).encode(), ("a " * L).encode(), ("the quick brown fox " * (L // 8 + 1)).encode(), ("▁" * (L % 40 + 1)).encode()]
     docs += [bytes([rnd.randrange(32, 127)]) for _ in range(300)] + [b"", b" ", b"\xff", b"\xef\xbb\xbf", b"\xef\xbb\xbfhello world"]
     docs.append(" ".join("".join(rnd.choice(alpha) for _ in range(rnd.randint(1, 12))) for _ in range(6000)).encode())       # ~40 KB
-    check(ht, model, docs, CONFS[:4] + CONFS[8:9])
+    check(ht, model, docs, CONFS[:4] + CONFS[7:8])
 
 
 def test_multilingual_and_charmap_model(ht):
