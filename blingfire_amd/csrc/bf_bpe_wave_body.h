@@ -31,8 +31,9 @@
 //           order (:299-313);
 //   retire  as in bf_wave_body.h: ids move from LDS / their provisional homes down to their place in the document.
 // HOME form (round 6, the shipped one): nothing is retired in order.  Every word's ids stay at its HOME -- the cells of the document's staging slot
-// under the word's own elements (a word has no more ids than elements; the fill writes BW_HOME_NONE into every cell first) -- and two streaming
-// kernels behind (k_bpe_home_count / k_bpe_home_gather) count and squeeze the cells that hold an id.  A word the table answers never enters the
+// under the word's own elements (a word has no more ids than elements; the fill writes BW_HOME_NONE into every cell first) -- the document's count
+// is added up as its words report (table hits per trip, units by an LDS atomic) and a streaming kernel behind (k_bpe_home_gather) squeezes the cells
+// that hold an id.  A word the table answers never enters the
 // queue: the queue holds only the words a unit must walk, sixteen documents' worth instead of three, so the lanes of a round are busy -- with
 // the in-order queue the table's hits sat in it waiting for their turn and the kernel's time did not move (18.8 vs 19.1 ms per 1 M documents).
 // Include AFTER a definition of namespace wv (bf_kernels.hip on the device, tests/hosttest/wave_emu.h in the test simulator).
@@ -232,6 +233,7 @@ struct BpeWave {
             const bool hit = kn != 0 && hb == 0u && (hita || hitb);
             if (p.stats && hit) wv::atomic_add(&p.stats[12], 1ull);
             if (HOME) {
+                { const int nh = __builtin_popcountll(wv::ballot(hit)); if (lane == 0 && nh) S.dt_cnt[curk & DMASK] += nh; }      // the document's ids so far (settle() writes its count)
                 if (hit) p.ids_tmp[slot + (int64_t)(e.pos - rbase)] = (int32_t)((hita ? A.id : B.id) & WF_ROW_ID_MASK);      // (the words of a chunk are the current document's)
                 const unsigned long long keep = wv::ballot(have && !hit);
                 wv::sync();                                              // every lane has read its token: the ones that stay move up
@@ -314,6 +316,7 @@ struct BpeWave {
     BF_WVD uint32_t *arc_at(const Unit &u, int a) { return a < BW_PRIV ? &S.win[a * 64 + lane] : &S.pool[(a - BW_PRIV) * BW_POOL_N + u.pw]; }
     BF_WVD void unit_finish(Unit &u, int cnt) {
         if (u.pw >= 0) { wv::lds_or(&S.pool_free, 1u << u.pw); u.pw = -1; }          // (lanes that finish in the same instruction return different windows)
+        if (HOME && cnt > 0) wv::lds_add((uint32_t *)&S.dt_cnt[u.ke], (uint32_t)cnt);      // (several lanes may finish words of one document in the same instruction)
         S.qc[(uint32_t)u.tok & QMASK] = (uint16_t)(cnt + 1); u.tok = -1; u.mode = 0; u.j = u.L; }
     BF_WVD void unit_fallback(Unit &u, int why)
     {
@@ -728,7 +731,7 @@ struct BpeWave {
                 const uint32_t e = kk & DMASK, f = S.dt_flags[e];
                 const int c = S.dt_cnt[e], cap = S.dt_cap[e];
                 const bool fb = (f & BW_DT_FALLBACK) != 0;
-                if (!HOME) p.counts[S.dt_doc[e]] = fb ? 0 : (c < cap ? c : cap);       // (HOME form: k_bpe_home_count counts the cells that hold an id)
+                p.counts[S.dt_doc[e]] = fb ? 0 : (c < cap ? c : cap);                  // (HOME form: dt_cnt = the table's hits + what the units reported)
                 p.flags[S.dt_doc[e]] = fb ? 1 : 0;
             }
             dt_head = limit; moved = true;

@@ -368,7 +368,11 @@ bool reserve_ids_workspaces(Handle *h, int64_t ndocs, int64_t total_bytes, bool 
         if (!h->w_s1.reserve(cap * (lane_form ? 4 : 16) + 256)) return false;
     } else {
         const size_t bm_words = (cap >> 5) + (size_t)ndocs + 4;
-        if (!h->w_s1.reserve((6 * cap + 32 * (size_t)ndocs + 64) * 16) || !h->w_s2.reserve(std::max(cap * 4, 2 * bm_words * 4) + ((size_t)ndocs + 16) * 4) ||
+        if (use_bpe_wave(h, want_off)) {
+            // the wave program + k_bpe_seg: six words per stream cell for a word of more than 64 arcs (unit_huge), the arc pool of k_bpe_seg -- not the
+            // 96 + 9 bytes per cell of the lane kernels' arc lists and work arrays (round 6: 111 -> 30 bytes of workspace per stream element)
+            if (!h->w_s1.reserve(cap * 24 + 256) || !h->w_big.reserve(h->bpe_pool_bytes)) return false;
+        } else if (!h->w_s1.reserve((6 * cap + 32 * (size_t)ndocs + 64) * 16) || !h->w_s2.reserve(std::max(cap * 4, 2 * bm_words * 4) + ((size_t)ndocs + 16) * 4) ||
             !h->w_s3.reserve(cap * 4) || !h->w_s4.reserve(cap) || !h->w_big.reserve(h->bpe_pool_bytes)) return false;
     }
     if (use_bpe_wave(h, want_off) && !h->w_bwflags.reserve((size_t)(ndocs + 1) * 4)) return false;
@@ -554,10 +558,6 @@ int run_device(Handle *h, const char *d_text, const int64_t *d_doc_off, int64_t 
             (void)hipEventRecord(h->ev[EV_DOM1], s);
             launch_bpe_seg_flags(sg, bw.flags, h->w_perm.as<int32_t>(), h->w_hist.as<unsigned int>(), s);
             bpe_home = bpe_wave_home((h->variant >> 8) & 0xf);
-            if (bpe_home) {          // the ids sit at their words' homes: count them (the documents k_bpe_seg redid keep its count)
-                BpeHomeParams hp{b, sg.ids_tmp, sg.lens, bw.flags, mul, sg.counts, d_id_off, d_ids_out, ids_cap, max_ids, status};
-                launch_bpe_home_count(hp, s);
-            }
         } else {
             // (the Unigram lane program records the two events around its forward kernel itself: the sort of the documents comes before it)
             sg.ev_dom0 = h->ev[EV_DOM0]; sg.ev_dom1 = h->ev[EV_DOM1];
@@ -2018,7 +2018,7 @@ const char *BfStepKernels(void *p)
         return "prep: k_prep_sp8 | tokenise: k_sp_hist, k_sp_hist_scan, k_sp_scatter, k_seg_unigram_lane, k_uni_back | scan: k_scan_block_sums, k_scan_top, k_scan_apply | compact: k_compact_ids";
     case KIND_I2W: return "";
     default:
-        if (use_bpe_wave(h, false)) return bpe_wave_home((h->variant >> 8) & 0xf) ? "prep: k_prep_sp8 | tokenise: k_bpe_wave, k_bpe_flag_list, k_bpe_seg, k_bpe_home_count | scan: k_scan_block_sums, k_scan_top, k_scan_apply | compact: k_bpe_home_gather"
+        if (use_bpe_wave(h, false)) return bpe_wave_home((h->variant >> 8) & 0xf) ? "prep: k_prep_sp8 | tokenise: k_bpe_wave, k_bpe_flag_list, k_bpe_seg | scan: k_scan_block_sums, k_scan_top, k_scan_apply | compact: k_bpe_home_gather"
                                                                               : "prep: k_prep_sp8 | tokenise: k_bpe_wave, k_bpe_flag_list, k_bpe_seg | scan: k_scan_block_sums, k_scan_top, k_scan_apply | compact: k_compact_ids";
         return "prep: k_prep_sp8 | tokenise: k_sp_hist, k_sp_hist_scan, k_sp_scatter, k_bpe_fused, k_bpe_collect_list, k_bpe_sort, k_bpe_apply_flat, k_bpe_seg | scan: k_scan_block_sums, k_scan_top, k_scan_apply | compact: k_compact_ids";
     }

@@ -116,7 +116,6 @@ struct BpeHomeParams {
     int32_t *counts; const int64_t *id_off; int32_t *ids_out; int64_t ids_cap; int max_ids; int *status;
 };
 bool bpe_wave_home(int tune);
-void launch_bpe_home_count(const BpeHomeParams &p, hipStream_t s);
 void launch_bpe_home_gather(const BpeHomeParams &p, hipStream_t s);
 
 struct ScanParams { const int32_t *counts; int64_t ndocs; int64_t *id_off; int64_t *block_sums; int nblocks; };

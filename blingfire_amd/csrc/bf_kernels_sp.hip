@@ -67,31 +67,10 @@ void launch_bpe_wave(const BpeWaveParams &p, int tune, hipStream_t s)
 }
 
 // The HOME form of the BPE wave program leaves every id at its word's home -- a cell of the document's staging slot under the word's own elements,
-// BW_HOME_NONE in the cells between -- and these two put them where the API wants them (tokdll:1512: the first max_ids of them, front to back):
-//   k_bpe_home_count   counts[d] = min(cells of the document that hold an id, max_ids); a document the program handed back (flags[d]) keeps the
-//                      count k_bpe_seg gave it
-//   k_bpe_home_gather  the cells that hold an id, in order, to ids_out + id_off[d]; a handed-back document's ids are dense at the slot's start
-// A wave per document, 64 cells per trip, one ballot and one population count each: streaming, 4 bytes per stream element read twice.
-__global__ __launch_bounds__(256) void k_bpe_home_count(BpeHomeParams p)
-{
-    const int lane = lane_id();
-    const int64_t wave0 = (int64_t)blockIdx.x * 4 + wave_in_block();
-    const int64_t nwaves = (int64_t)gridDim.x * 4;
-    for (int64_t d = wave0; d < p.b.ndocs; d += nwaves) {
-        if (p.flags[d]) continue;
-        const int L = p.lens[d];
-        const int32_t *cell = p.ids_tmp + sp_slot(p.b.doc_off[d], d, p.slot_mul);
-        int c = 0;
-        for (int i0 = 0; i0 < L && c < p.max_ids; i0 += 256) {      // four loads in flight
-            int32_t v[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) { const int i = i0 + 64 * k + lane; v[k] = i < L ? cell[i] : BW_HOME_NONE; }
-#pragma unroll
-            for (int k = 0; k < 4; ++k) c += __popcll(__ballot(v[k] != BW_HOME_NONE));
-        }
-        if (lane == 0) p.counts[d] = c < p.max_ids ? c : p.max_ids;
-    }
-}
+// BW_HOME_NONE in the cells between -- with the document's count (the program adds it up as the words report); this puts them where the API wants
+// them (tokdll:1512: the first max_ids of them, front to back):
+//   k_bpe_home_gather  the cells that hold an id, in order, to ids_out + id_off[d]; a handed-back document's ids (k_bpe_seg) are dense at the slot's start
+// A wave per document, 128 cells per trip, a ballot and a population count each: streaming, 4 bytes per stream element.
 __global__ __launch_bounds__(256) void k_bpe_home_gather(BpeHomeParams p)
 {
     const int lane = lane_id();
@@ -119,13 +98,6 @@ __global__ __launch_bounds__(256) void k_bpe_home_gather(BpeHomeParams p)
         }
     }
     if (over) atomicOr(p.status, 1);
-}
-void launch_bpe_home_count(const BpeHomeParams &p, hipStream_t s)
-{
-    int64_t blocks = (p.b.ndocs + 3) / 4;
-    if (blocks > device_cus() * 16) blocks = device_cus() * 16;
-    if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(k_bpe_home_count, dim3((unsigned)blocks), dim3(256), 0, s, p);
 }
 void launch_bpe_home_gather(const BpeHomeParams &p, hipStream_t s)
 {

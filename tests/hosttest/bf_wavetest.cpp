@@ -202,14 +202,15 @@ long bft_emu_bpe_wave_batch(void *hv, const uint8_t *text, long text_bytes, cons
     std::vector<int32_t> one((size_t)(max_ids > 0 ? max_ids : 1));
     for (long d = 0; d < ndocs; ++d) {
         id_off[d] = o;
-        if ((!home && counts[(size_t)d] < 0) || flags[(size_t)d] < 0) return -7;      // a document the kernel never settled
+        if (counts[(size_t)d] < 0 || flags[(size_t)d] < 0) return -7;                 // a document the kernel never settled
         if (flags_out) flags_out[d] = flags[(size_t)d];
         int c = counts[(size_t)d];
         const int32_t *src = tmp.data() + (size_t)mul * (size_t)(doc_off[d] + d);
         std::vector<int32_t> squeezed;
-        if (home && !flags[(size_t)d]) {                                               // k_bpe_home_count / k_bpe_home_gather: the cells that hold an id, front to back
+        if (home && !flags[(size_t)d]) {                                               // k_bpe_home_gather: the cells that hold an id, front to back
             for (int i = 0; i < lens[(size_t)d] && (int)squeezed.size() < max_ids; ++i) if (src[i] != BW_HOME_NONE) squeezed.push_back(src[i]);
-            c = (int)squeezed.size(); src = squeezed.data();
+            if ((int)squeezed.size() != c) return -10;                                // the count the program added up is not the number of cells that hold an id
+            src = squeezed.data();
         }
         if (flags[(size_t)d]) {                                                        // handed back: the lane-per-document path
             c = bft_emu_sp_doc(m, (const char *)text + doc_off[d], (int)(doc_off[d + 1] - doc_off[d]), one.data(), max_ids, unk);
