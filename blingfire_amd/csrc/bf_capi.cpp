@@ -175,6 +175,7 @@ struct Handle {
     DevBuf w_cls, w_nchars, w_tmp, w_counts, w_bsums, w_misc, w_flags, w_out, w_outoff;   // w_misc: [0] next_doc (u64), [2] status (int)
     DevBuf w_text, w_docoff, w_ids, w_idoff, w_starts, w_ends;  // host-API staging
     DevBuf w_srcoff, w_span;                                    // offsets API: source-offset stream, staged id spans
+    DevBuf w_long;                                              // words modes: the long-document path (bf_kernels.h LexLongParams: list, spec, vis)
     DevBuf w_espan, w_hspan, w_chard;                           // the flat program, offsets API: spans of the entries, of the pieces at the homes; counts of the documents handed back
     DevBuf w_ent, w_home, w_entoff, w_entcnt, w_dstat, w_ranges, w_list, w_wrec, t_flat;   // the flat program (bf_flat.h): entries, homes, per-document records, ranges, the documents handed back; its word table
     bool last_flat = false;                                      // the last batch took the flat program (BfLastKernelMs names the kernels by it)
@@ -201,7 +202,7 @@ struct Handle {
         shards.clear();
         pipe.release(); m_small.release();
         for (DevBuf *b : {&t_segscore, &t_segid, &t_bpetab, &t_bpe_prio, &t_bpe_place, &t_dk_l1, &t_dk_pages, &t_dn_l1, &t_dn_pages, &t_dn_pool, &t_k2i, &t_rows, &w_keys, &w_keyoff, &w_dids, &w_dret, &w_vals, &t_i2w_off, &t_i2w_data, &t_kind, &t_wbd, &t_info, &t_acts, &t_cp_l1, &t_cp_pages, &t_multi, &t_wcp_l1, &t_wcp_pages, &t_dict, &t_seginfo, &w_s1, &w_s2, &w_s3, &w_s4, &w_big, &w_perm, &w_hist, &w_narcs, &w_bwflags, &w_cls, &w_nchars, &w_tmp, &w_counts, &w_flags, &w_out, &w_outoff,
-                          &w_bsums, &w_misc, &w_text, &w_docoff, &w_ids, &w_idoff, &w_starts, &w_ends, &w_srcoff, &w_span, &w_ent, &w_home, &w_entoff, &w_entcnt, &w_dstat, &w_ranges, &w_list, &w_wrec, &t_flat, &w_espan, &w_hspan, &w_chard}) b->release();
+                          &w_bsums, &w_misc, &w_text, &w_docoff, &w_ids, &w_idoff, &w_starts, &w_ends, &w_srcoff, &w_span, &w_long, &w_ent, &w_home, &w_entoff, &w_entcnt, &w_dstat, &w_ranges, &w_list, &w_wrec, &t_flat, &w_espan, &w_hspan, &w_chard}) b->release();
         for (auto &e : ev) if (e) (void)hipEventDestroy(e);
         if (stream) (void)hipStreamDestroy(stream);
         magic = 0;
@@ -341,8 +342,37 @@ bool use_flat(const Handle *h, bool want_off, int words, int64_t ndocs, int64_t 
 // (Model::bpe_wave_ok); BfSetVariant bit 0x40 switches it off (A/B runs against the lane-per-document kernels alone)
 bool use_bpe_wave(const Handle *h, bool want_off) { return h->m.bpe_wave_ok && !want_off && (h->variant & 0x40) == 0; }
 
-bool reserve_ids_workspaces(Handle *h, int64_t ndocs, int64_t total_bytes, bool want_off, int words = 0)
+// Words modes (TextToWords / TextToSentences): documents of more than `thresh` characters go through the long-document path
+// (bf_lex.h lex_one_start), which spends about three times the transitions of the lane kernel on a document of short words but spreads
+// them over as many lanes as the document has characters.  It pays where the batch has too few documents to fill the chip or one
+// that is much longer than the rest: a lane walks 1.8 us per character when it is the last one running (config 1's 8,396-byte line:
+// 4.9 ms), the chip as a whole 75 ps per character (1 M lines: 3.25 ms), so a document of more than total_bytes / 24,000 characters
+// would hold the batch up (measured on MI355X, profiles/r06_words_*: 10,000 lines 4.6 -> 0.55 ms at 16, 1 M lines 3.25 ms at 128 and
+// 10.2 ms at 16).  BfSetVariant: bit 0x40000000 = off (every document on one lane), bits 12..15 = k > 0: thresh = 8 << k.
+// The capacities are bounds that hold for any batch of these sizes (a listed document has more than thresh bytes and owns
+// (n + 1 + 63) / 64 chunks) unless that is more than LONG_MAX_CHUNKS: then the documents that do not fit stay on lanes.
+constexpr int LONG_THRESH_MIN = 16;
+constexpr int64_t LONG_BYTES_PER_THRESH = 24000;
+constexpr int64_t LONG_MAX_CHUNKS = (int64_t)2 << 20;           // 128 M cells: 2.5 GB of workspace
+struct LongCaps { int thresh; int64_t docs, chunks; size_t list_off, spec_off, vis_off, bytes; };
+LongCaps long_caps(const Handle *h, int64_t ndocs, int64_t total_bytes, int words)
 {
+    LongCaps c{0, 0, 0, 0, 0, 0, 0};
+    if (!words || h->m.kind != KIND_WP || h->m.max_depth < 1 || h->m.lexer_void || (h->variant & 0x40000000) || ndocs <= 0) return c;
+    const int k = (h->variant >> 12) & 0xf;
+    c.thresh = k ? (8 << k) : (int)std::min<int64_t>(std::max<int64_t>(LONG_THRESH_MIN, total_bytes / LONG_BYTES_PER_THRESH), 1 << 30);
+    c.docs = std::min<int64_t>(ndocs, total_bytes / ((int64_t)c.thresh + 1)) + 1;
+    c.chunks = std::min<int64_t>(total_bytes / 64 + 2 * c.docs + 1, LONG_MAX_CHUNKS);
+    c.list_off = 0;
+    c.spec_off = ((size_t)c.docs * sizeof(LexLongDoc) + 255) & ~(size_t)255;
+    c.vis_off = c.spec_off + (size_t)c.chunks * 64 * 16;
+    c.bytes = c.vis_off + (size_t)c.chunks * 64 * 4;
+    return c;
+}
+
+bool reserve_ids_workspaces(Handle *h, int64_t ndocs, int64_t total_bytes, bool want_off, int words = 0, bool with_long = true)
+{
+    if (const LongCaps lc = long_caps(h, ndocs, total_bytes, words); with_long && lc.thresh > 0 && !h->w_long.reserve(lc.bytes)) return false;
     const Model &m = h->m;
     const int nblocks = scan_nblocks(ndocs);
     if (!h->w_nchars.reserve((size_t)(ndocs + 1) * 4) || !h->w_counts.reserve((size_t)(ndocs + 1) * 4) ||
@@ -498,8 +528,15 @@ int run_device(Handle *h, const char *d_text, const int64_t *d_doc_off, int64_t 
         lp.max_ids = max_ids; lp.unk = unk; lp.next_doc = next_doc; lp.status = status; lp.ev_thresh = 0; lp.fetch_thresh = 0; lp.acts_n = (int)m.acts_pool.size(); lp.words = words;
         lp.table_n = (int)(m.wbd_t2.size() > (size_t)LX_T_CLS_MASK + 1 ? m.wbd_t2.size() - ((size_t)LX_T_CLS_MASK + 1) : 0);
         lp.stats = h->lex_stats ? (unsigned long long *)(h->w_misc.as<char>() + 64) : nullptr;
+        const LongCaps lc = long_caps(h, ndocs, total_bytes, words);
+        lp.lg = LexLongParams{lc.thresh, lc.docs, lc.chunks, (unsigned long long *)(h->w_misc.as<char>() + 40) /* zeroed with the status word above */,
+                              (LexLongDoc *)(h->w_long.as<char>() + lc.list_off), (int32_t *)(h->w_long.as<char>() + lc.spec_off), (int32_t *)(h->w_long.as<char>() + lc.vis_off)};
         (void)hipEventRecord(h->ev[EV_DOM0], s);
-        if (ndocs > 0) launch_lex_wp(lp, h->variant, s);
+        if (ndocs > 0) {
+            launch_lex_long_list(lp, s);
+            launch_lex_wp(lp, words ? (h->variant & ~0x4000F000) : h->variant, s);
+            launch_lex_long(lp, s);
+        }
         (void)hipEventRecord(h->ev[EV_DOM1], s);
         (void)hipEventRecord(h->ev[EV_TOK], s);
     } else {
@@ -1774,7 +1811,8 @@ int BfReserve(void *p, int64_t max_docs, int64_t max_bytes, int want_offsets)
     // the lane-per-document kernels, which TextToWords / TextToSentences, lexers outside the unit form and BfSetVariant(2) run -- no hipMalloc
     // (= device synchronisation) inside a later call of either kind
     if (!reserve_ids_workspaces(h, max_docs, max_bytes, want_offsets != 0)) return BF_E_DEVICE;
-    if (h->m.kind == KIND_WP && !reserve_ids_workspaces(h, max_docs, max_bytes, true, 1)) return BF_E_DEVICE;
+    // (not the long-document workspace of the words modes, w_long: 20 bytes per cell, allocated by the first words call that is that large)
+    if (h->m.kind == KIND_WP && !reserve_ids_workspaces(h, max_docs, max_bytes, true, 1, false)) return BF_E_DEVICE;
     return 0;
 }
 

@@ -21,6 +21,22 @@ struct WpPrepParams {
     int32_t *nchars;            // [ndocs] normalised length, 0 = "TextToIds returns 0"
 };
 
+// Long documents of the words modes (bf_lex.h: lex_one_start / lex_chain_visit).  A document of more than `thresh` characters is
+// listed (k_lex_long_list) and leaves the lane kernel alone; its n + 1 start positions are cells of a dense "chunk space" (64 cells
+// per chunk, a document owns whole chunks: cell = 64 * chunk0 + position + 1) that three kernels go over: k_lex_long<false> (every
+// cell: next position + counts), k_lex_long_chain (one wave per document: the visited cells and their output bases),
+// k_lex_long<true> (the visited cells write their tokens into the document's staging slot).
+struct LexLongDoc { int64_t doc, chunk0; };       // doc < 0: a listed document that did not fit the workspace (the lane kernel keeps it)
+struct LexLongParams {
+    int thresh;                       // 0: off
+    int64_t cap_docs, cap_chunks;     // capacity of `list` / of the cell arrays in chunks
+    unsigned long long *hdr;          // documents listed << 40 | chunks handed out (zeroed per launch)
+    LexLongDoc *list;
+    int32_t *spec;                    // [4 * cell]: next position, tokens output, triples produced, room + 1 of the position that fills the buffer (else 0)
+    int32_t *vis;                     // [cell]: -1 = not visited, else the output index of the position's first token
+};
+constexpr unsigned long long LEX_LONG_CHUNK_MASK = (1ull << 40) - 1;
+
 struct WpLexParams {
     LexTables L;
     Batch b;
@@ -38,6 +54,7 @@ struct WpLexParams {
     unsigned long long *stats;    // optional instrumentation counters (experiments), else nullptr
     int table_n;                  // entries of L.T that can hold a transition (the branch-free probe tail behind them is all empty):
                                   // when they fit, the kernel stages them in LDS (bf_kernels.hip TabLds)
+    LexLongParams lg;             // words modes: the long-document path (thresh 0 = every document on a lane)
 };
 
 // _sp branch: element slot of document d (stream, DP arrays and the id staging slot share it):
@@ -133,6 +150,8 @@ struct CompactParams {
 // flags: one bit per 16-byte chunk of the text (u64 per KiB, + 1), or nullptr for the one-pass wave-per-document form
 void launch_prep_wp(const WpPrepParams &p, int64_t total_bytes, unsigned long long *flags, hipStream_t s);
 void launch_lex_wp(const WpLexParams &p, int variant, hipStream_t s);
+void launch_lex_long_list(const WpLexParams &p, hipStream_t s);      // before launch_lex_wp: lists the long documents (counts[doc] = -1)
+void launch_lex_long(const WpLexParams &p, hipStream_t s);           // after it: the three kernels of the long-document path
 void launch_wp_wave(const WpWaveParams &p, int variant, hipStream_t s);     // unit-form lexers (bf_wave.h): replaces prep + lexer
 // the flat program (bf_flat.h): ranges + fitness of the batch, the program, the documents it hands back, counts, merge
 int wp_flat_ranges(int64_t ndocs, int64_t total_bytes);

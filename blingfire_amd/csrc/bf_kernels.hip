@@ -429,16 +429,20 @@ __device__ __forceinline__ void lex_wp_flat_body(const WpLexParams &p)
                     else {
                         const int64_t b = p.b.doc_off[doc];
                         const int64_t nbytes = p.b.doc_off[doc + 1] - b;
-                        const int n = p.nchars[doc];
+                        int n = p.nchars[doc];
                         int cap = p.max_ids; if ((int64_t)cap > nbytes) cap = (int)nbytes;
                         if (cap < 0) cap = 0;
+                        // words modes: a long document that k_lex_long_list took (its count is the mark) belongs to the long path; the lane
+                        // sees an empty document, writes nothing and asks for the next one
+                        bool taken = false;
+                        if constexpr (!PLAIN) { taken = p.lg.thresh > 0 && n > p.lg.thresh && p.counts[doc] == -1; n = taken ? 0 : n; }
                         cls_at.init(p.cls, b);
                         if constexpr (PLAIN) { out.init(p.ids_tmp + ids_slot(b, doc), nullptr); lane.init(n, cap, p.unk, 0); }
                         else { out.init(p.ids_tmp + ids_slot(b, doc), p.span_tmp ? p.span_tmp + 2 * ids_slot(b, doc) : nullptr); lane.init(n, cap, p.unk, p.words); }
                         bool more;
                         if constexpr (TWO) more = lane.prepare2(); else more = lane.prepare();
                         if (more) mode = M_WALK;
-                        else p.counts[doc] = lane.finish();          // empty / invalid document: 0 ids, stay idle
+                        else if (!taken) p.counts[doc] = lane.finish();          // empty / invalid document: 0 ids, stay idle
                     }
                 }
                 if (__ballot(mode != M_EXIT) == 0) break;
@@ -495,19 +499,25 @@ void launch_lex_wp(const WpLexParams &p, int variant, hipStream_t s)
     if (blocks > need) blocks = need;
     if (blocks < 1) blocks = 1;
     const bool has_any = p.L.cls_any != LX_CLS_NONE;
-    // small models (wbd.bin: TextToWords): the whole table lives in LDS
-    if (!p.stats && p.table_n > 0 && lex_lds_bytes(q, LEX_TLDS_THREADS, true) <= LEX_TLDS_MAX_BYTES) {
-        constexpr int TH = LEX_TLDS_THREADS;
-        const size_t lds = lex_lds_bytes(q, TH, true);
-        int per_cu = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_lex_wp_flat<TH, ClsWin, false, 3, false, true>, TH, lds) != hipSuccess || per_cu <= 0) per_cu = 2;
-        (void)hipGetLastError();
-        int64_t nb = (int64_t)device_cus() * per_cu;
-        const int64_t need_b = (p.b.ndocs + TH - 1) / TH;
-        if (nb > need_b) nb = need_b;
-        if (nb < 1) nb = 1;
-        if (has_any) hipLaunchKernelGGL((k_lex_wp_flat<TH, ClsWin, true, 1, false, true>), dim3((unsigned)nb), dim3(TH), lds, s, q);
-        else hipLaunchKernelGGL((k_lex_wp_flat<TH, ClsWin, false, 3, false, true>), dim3((unsigned)nb), dim3(TH), lds, s, q);
+    // small models (wbd.bin: TextToWords): the whole table lives in LDS, one copy per workgroup of 512 threads -- or of 256 when the
+    // lanes' frames and id buffers leave no room for it beside 512 (wbd.bin: 41 + 27 KB; a table gather from L2 is 250+ ns, the lane
+    // kernel of config 1 took 225 us with it)
+    if (!p.stats && p.table_n > 0 && lex_lds_bytes(q, LEX_TLDS_THREADS / 2, true) <= LEX_TLDS_MAX_BYTES) {
+        auto go = [&](auto th) {
+            constexpr int TH = decltype(th)::value;
+            const size_t lds = lex_lds_bytes(q, TH, true);
+            int per_cu = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_lex_wp_flat<TH, ClsWin, false, 3, false, true>, TH, lds) != hipSuccess || per_cu <= 0) per_cu = 2;
+            (void)hipGetLastError();
+            int64_t nb = (int64_t)device_cus() * per_cu;
+            const int64_t need_b = (p.b.ndocs + TH - 1) / TH;
+            if (nb > need_b) nb = need_b;
+            if (nb < 1) nb = 1;
+            if (has_any) hipLaunchKernelGGL((k_lex_wp_flat<TH, ClsWin, true, 1, false, true>), dim3((unsigned)nb), dim3(TH), lds, s, q);
+            else hipLaunchKernelGGL((k_lex_wp_flat<TH, ClsWin, false, 3, false, true>), dim3((unsigned)nb), dim3(TH), lds, s, q);
+        };
+        if (lex_lds_bytes(q, LEX_TLDS_THREADS, true) <= LEX_TLDS_MAX_BYTES) go(std::integral_constant<int, LEX_TLDS_THREADS>{});
+        else go(std::integral_constant<int, LEX_TLDS_THREADS / 2>{});
         return;
     }
     if (p.L.two_level && !p.stats) {
@@ -541,6 +551,185 @@ void launch_lex_wp(const WpLexParams &p, int variant, hipStream_t s)
     if (has_any) hipLaunchKernelGGL((k_lex_wp_flat<64, ClsWin, true, 1, false>), g, t, lds, s, q);
     else if (p.stats) hipLaunchKernelGGL((k_lex_wp_flat<64, ClsWin, false, 3, true>), g, t, lds, s, q);
     else hipLaunchKernelGGL((k_lex_wp_flat<64, ClsWin, false, 3, false>), g, t, lds, s, q);     // three transitions per vote: swept on MI355X
+}
+
+// ------------------------------------------------------------------------------------------
+// The long documents of the words modes (bf_kernels.h LexLongParams, bf_lex.h lex_one_start / lex_chain_visit).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_lex_long_list(WpLexParams p)
+{
+    for (int64_t doc = (int64_t)blockIdx.x * 256 + threadIdx.x; doc < p.b.ndocs; doc += (int64_t)gridDim.x * 256) {
+        const int n = p.nchars[doc];
+        if (n <= p.lg.thresh) continue;
+        const unsigned long long nch = ((unsigned long long)n + 1 + 63) >> 6;              // positions -1 .. n-1
+        const unsigned long long old = atomicAdd(p.lg.hdr, (1ull << 40) | nch);
+        const int64_t slot = (int64_t)(old >> 40), c0 = (int64_t)(old & LEX_LONG_CHUNK_MASK);
+        const bool fits = slot < p.lg.cap_docs && c0 + (int64_t)nch <= p.lg.cap_chunks;
+        if (slot < p.lg.cap_docs) p.lg.list[slot] = LexLongDoc{fits ? doc : -1, c0};
+        p.counts[doc] = fits ? -1 : 0;               // -1: the lane kernel leaves the document to the long path
+    }
+}
+
+constexpr int LEX_LONG_THREADS = 256;
+static size_t lex_long_lds_bytes(const WpLexParams &p, bool tlds)
+{
+    return (((size_t)p.L.max_frames * LEX_FRAME_WORDS) * LEX_LONG_THREADS + (size_t)((p.acts_n + 1) & ~1)) * 4 + (tlds ? (size_t)p.table_n * 8 : 0);
+}
+
+// EMIT false: every cell of the chunk space runs its start position without output (spec, vis = -1).
+// EMIT true:  the cells the chain visited run again and write their tokens.
+template <bool HAS_ANY, bool TLDS, bool EMIT>
+__global__ __launch_bounds__(LEX_LONG_THREADS) void k_lex_long(WpLexParams p)
+{
+    extern __shared__ int32_t lex_lds[];
+    constexpr int THREADS = LEX_LONG_THREADS, WAVES = THREADS / 64;
+    typedef typename std::conditional<TLDS, TabLds, TabDirect>::type TAB;
+    const unsigned long long hdr = *p.lg.hdr;
+    int64_t nlist = (int64_t)(hdr >> 40), nchunks = (int64_t)(hdr & LEX_LONG_CHUNK_MASK);
+    if (nlist > p.lg.cap_docs) nlist = p.lg.cap_docs;
+    if (nchunks > p.lg.cap_chunks) nchunks = p.lg.cap_chunks;
+    if ((int64_t)blockIdx.x * WAVES >= nchunks) return;                   // no chunk for this workgroup: before anything is staged
+    LexTables L = p.L;
+    TAB tab;
+    {
+        int32_t *acts_lds = lex_lds + (size_t)p.L.max_frames * LEX_FRAME_WORDS * THREADS;
+        for (int i = threadIdx.x; i < p.acts_n; i += THREADS) acts_lds[i] = p.L.acts[i];
+        if constexpr (TLDS) {
+            uint64_t *tab_lds = (uint64_t *)(acts_lds + ((p.acts_n + 1) & ~1));
+            for (int i = threadIdx.x; i < p.table_n; i += THREADS) tab_lds[i] = p.L.T[i];
+            tab.lds = tab_lds; tab.n = (uint32_t)p.table_n;
+        } else tab.T = p.L.T;
+        __syncthreads();
+        L.acts = acts_lds;
+    }
+    FramesLds frames{lex_lds, THREADS};
+    const int lane = lane_id();
+    for (int64_t c = (int64_t)blockIdx.x * WAVES + wave_in_block(); c < nchunks; c += (int64_t)gridDim.x * WAVES) {
+        int64_t lo = 0, hi = nlist;                                       // the listed document whose chunks hold chunk c
+        while (hi - lo > 1) { const int64_t mid = (lo + hi) >> 1; if (p.lg.list[mid].chunk0 <= c) lo = mid; else hi = mid; }
+        const LexLongDoc ld = p.lg.list[lo];
+        if (ld.doc < 0) continue;
+        const int n = p.nchars[ld.doc];
+        const int64_t b = p.b.doc_off[ld.doc];
+        const int pos = (int)(c - ld.chunk0) * 64 + lane - 1;
+        const int64_t cell = c * 64 + lane;
+        bool act = pos < n;
+        int base = 0, room1 = 0;
+        if constexpr (EMIT) {
+            base = act ? p.lg.vis[cell] : -1;
+            act = base >= 0;
+            if (act) room1 = p.lg.spec[4 * cell + 3];
+        } else p.lg.vis[cell] = -1;
+        if (!act) continue;
+        ClsWin cls_at; cls_at.init(p.cls, b);
+        if constexpr (EMIT) {
+            const int64_t slot = ids_slot(b, ld.doc) + base;
+            IdOutDirect out{p.ids_tmp + slot, p.span_tmp + 2 * slot};
+            const LexStart r = lex_one_start<HAS_ANY>(L, cls_at, n, pos, out, frames, tab, p.words, room1 ? room1 - 1 : n);
+            if (room1) p.counts[ld.doc] = base + r.n_out;                 // the position at which the triple buffer fills ends the document
+        } else {
+            IdOutNull out;
+            const LexStart r = lex_one_start<HAS_ANY>(L, cls_at, n, pos, out, frames, tab, p.words, n);
+            ((int4 *)p.lg.spec)[cell] = make_int4(r.next, r.n_out, r.n_emit, 0);
+        }
+    }
+}
+
+// One wave per listed document follows the chain (bf_lex.h lex_chain_visit), a window of 64 cells at a time: the cells' results sit
+// in the lanes' registers, the chain inside the window is followed on the scalar unit (v_readlane of the next position, no memory
+// access per hop -- a hop through LDS measured 380 cycles, the 8,396-byte line of config 1 took 474 us), the visited cells' output
+// bases are one wave scan over the window.  The results come in through LDS, 2048 cells per load (a register prefetch of the next window
+// only moved the wait: the hop loop's s_waitcnt covers every load in flight).
+constexpr int LEX_CHAIN_BLK = 2048, LEX_CHAIN_END = 0x40000000;
+__global__ __launch_bounds__(64) void k_lex_long_chain(WpLexParams p)
+{
+    __shared__ int4 blk[LEX_CHAIN_BLK];
+    const unsigned long long hdr = *p.lg.hdr;
+    int64_t nlist = (int64_t)(hdr >> 40);
+    if (nlist > p.lg.cap_docs) nlist = p.lg.cap_docs;
+    const int lane = lane_id();
+    for (int64_t j = blockIdx.x; j < nlist; j += gridDim.x) {
+        const LexLongDoc ld = p.lg.list[j];
+        if (ld.doc < 0) continue;
+        const int n = __builtin_amdgcn_readfirstlane(p.nchars[ld.doc]);
+        const int64_t cell0 = ld.chunk0 * 64;
+        const int4 *spec = (const int4 *)p.lg.spec + cell0;
+        // cells 0 .. n (cell = position + 1); the document owns whole chunks, so a window never leaves its cells
+        const int end_cells = (n & ~63) + 64;
+        int w0 = 0, q = 0, ob = 0, eb = 0, blk0 = -1;
+        for (;;) {
+            if (blk0 < 0 || w0 >= blk0 + LEX_CHAIN_BLK) {                           // the next block of windows: one exposed load latency per 2048 cells
+                blk0 = w0;
+                int cnt = end_cells - blk0; if (cnt > LEX_CHAIN_BLK) cnt = LEX_CHAIN_BLK;
+                wave_handoff();
+                for (int i0 = 0; i0 < cnt; i0 += 64 * 8) {                          // eight loads in flight per lane (cnt is a multiple of 64)
+                    int4 t[8];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) { const int i = i0 + 64 * k; t[k] = i < cnt ? spec[blk0 + i + lane] : make_int4(0, 0, 0, 0); }
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) { const int i = i0 + 64 * k; if (i < cnt) blk[i + lane] = t[k]; }
+                }
+                wave_handoff();
+            }
+            const int4 cur = blk[w0 - blk0 + lane];
+            // the chain inside [w0, w0 + 64): scalar, five instructions per hop.  to = the next cell relative to the window; a chain that
+            // leaves the document (next position >= n) goes to LEX_CHAIN_END
+            const int to = cur.x + 1 > n ? LEX_CHAIN_END : cur.x + 1 - w0;
+            unsigned long long V = 0;
+            int rel = q - w0;
+            do { V |= 1ull << rel; rel = __builtin_amdgcn_readlane(to, rel); } while (rel < 64);
+            const int qq = rel == LEX_CHAIN_END ? n + 1 : w0 + rel;
+            const bool in = (V >> lane) & 1ull;
+            const int no = in ? cur.y : 0, ne = in ? cur.z : 0;
+            const int so = wv::incl_scan(no), se = wv::incl_scan(ne);
+            const bool over = in && eb + se > n;                                   // the triple buffer fills at this cell (or did at an earlier one)
+            const unsigned long long m_over = __ballot(over);
+            if (m_over) {
+                const int first = __ffsll((long long)m_over) - 1;
+                if (in && lane <= first) p.lg.vis[cell0 + w0 + lane] = ob + so - no;
+                if (lane == first) p.lg.spec[4 * (cell0 + w0 + lane) + 3] = n - (eb + se - ne) + 1;      // room + 1: k_lex_long<EMIT> ends the document there
+                break;
+            }
+            if (in) p.lg.vis[cell0 + w0 + lane] = ob + so - no;
+            ob += __builtin_amdgcn_readlane(so, 63); eb += __builtin_amdgcn_readlane(se, 63);
+            if (qq > n) { if (lane == 0) p.counts[ld.doc] = ob; break; }          // the chain left the document
+            q = qq; w0 = qq & ~63;
+        }
+    }
+}
+
+void launch_lex_long_list(const WpLexParams &p, hipStream_t s)
+{
+    if (p.lg.thresh <= 0 || p.b.ndocs <= 0) return;
+    int64_t nb = (p.b.ndocs + 255) / 256;
+    const int64_t cap = (int64_t)device_cus() * 8;
+    if (nb > cap) nb = cap;
+    hipLaunchKernelGGL(k_lex_long_list, dim3((unsigned)nb), dim3(256), 0, s, p);
+}
+
+void launch_lex_long(const WpLexParams &p, hipStream_t s)
+{
+    if (p.lg.thresh <= 0 || p.b.ndocs <= 0) return;
+    const bool has_any = p.L.cls_any != LX_CLS_NONE;
+    const bool tlds = p.table_n > 0 && lex_long_lds_bytes(p, true) <= LEX_TLDS_MAX_BYTES;
+    const size_t lds = lex_long_lds_bytes(p, tlds);
+    // the number of chunks is on the device: a grid that fills the chip, workgroups without a chunk leave at once
+    int64_t nb = (int64_t)device_cus() * 4;
+    const int64_t most = (p.lg.cap_chunks + 3) / 4;
+    if (nb > most) nb = most;
+    if (nb < 1) nb = 1;
+    int64_t nc = p.lg.cap_docs < (int64_t)device_cus() * 4 ? p.lg.cap_docs : (int64_t)device_cus() * 4;
+    if (nc < 1) nc = 1;
+    const dim3 g((unsigned)nb), t(LEX_LONG_THREADS);
+#define BF_LONG(EMIT) \
+    do { \
+        if (has_any) { if (tlds) hipLaunchKernelGGL((k_lex_long<true, true, EMIT>), g, t, lds, s, p); else hipLaunchKernelGGL((k_lex_long<true, false, EMIT>), g, t, lds, s, p); } \
+        else { if (tlds) hipLaunchKernelGGL((k_lex_long<false, true, EMIT>), g, t, lds, s, p); else hipLaunchKernelGGL((k_lex_long<false, false, EMIT>), g, t, lds, s, p); } \
+    } while (0)
+    BF_LONG(false);
+    hipLaunchKernelGGL(k_lex_long_chain, dim3((unsigned)nc), dim3(64), 0, s, p);
+    BF_LONG(true);
+#undef BF_LONG
 }
 
 // ------------------------------------------------------------------------------------------

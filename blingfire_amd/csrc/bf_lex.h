@@ -120,9 +120,14 @@ struct FramesArray {   // host emulation only (a dynamically indexed private str
     BF_HD void load(int d, LexFrame &f) const { f = st[d]; }
 };
 
-template <class ClsAt, class IdOut, class Frames, bool HAS_ANY, class Tab = TabDirect>
+// SINGLE: the lane runs ONE top-level start position `p0` (set after init(): from = p0 = the position) and everything that position
+// causes (its walk, its action, the functions the action calls), then prepare() returns false with `from` = the next top-level
+// start position (FALexTools_t.h:229-252, 385-393).  What a top-level start position does depends on nothing before it -- the
+// loop of Process_int carries only FromPos -- which is what the long-document path of the words modes (lex_long_* below) builds on.
+template <class ClsAt, class IdOut, class Frames, bool HAS_ANY, class Tab = TabDirect, bool SINGLE = false>
 struct LexLane {
     const LexTables &L; ClsAt &cls_at; IdOut &ids; Frames &frames; Tab tab;
+    int p0 = 0;                                                   // SINGLE: the start position this lane runs
     // ---- streaming _wp post-pass (tokdll:1210-1311)
     int max_ids, unk;
     int out_count, scanning, tok_from, tok_to, expected, nsub, word_out;
@@ -186,6 +191,7 @@ struct LexLane {
     {
         if (stop) return false;
         for (;;) {
+            if (SINGLE) { if (d == 0 && from != p0) return false; }
             if (from >= fn_) {
                 // ---- Process_int returns (FALexTools_t.h:399); resume the caller's function loop
                 if (d == 0) return false;
@@ -280,7 +286,7 @@ struct LexLane {
     {
         bool cont = step();
         const int nf = from + 1;
-        if (!cont && fp == -1 && nf < fn_ && L.max_token_length > 0) {
+        if (!cont && fp == -1 && nf < fn_ && L.max_token_length > 0 && !(SINGLE && d == 0)) {
             from = nf; state = ini; finfo = 0; j = nf;
             set_lim(nf);
             cont = true;
@@ -446,6 +452,52 @@ BF_HD int lex_doc(const LexTables &L, ClsAt &cls_at, int n, IdOut &out, int max_
 {
     return L.cls_any != LX_CLS_NONE ? lex_doc_t<true>(L, cls_at, n, out, max_ids, unk, frames, words)
                                     : lex_doc_t<false>(L, cls_at, n, out, max_ids, unk, frames, words);
+}
+
+// ------------------------------------------------------------------------------------------
+// Long documents in the words modes (TextToWords / TextToSentences, tokdll:415-614): a document does not have to walk on one lane.
+// The top-level loop of Process_int (FALexTools_t.h:229-393) carries nothing from one start position to the next but the
+// position itself, and the words modes copy every triple out as it comes (no post-pass state), so
+//   1. every position p of the document (-1 = the left anchor, 0 .. n-1) is run on its own as if the loop had arrived there
+//      (lex_one_start with IdOutNull): where the loop goes next, how many triples it produces, how many of them are output;
+//   2. the chain -1 -> next(-1) -> ... is followed once, adding the counts up: the positions the reference really visits and
+//      the output index of each one's first token;
+//   3. the visited positions are run again, writing their tokens at those indices.
+// The triple buffer of the reference holds MaxTriples = n triples in these modes (tokdll:494-499, FALexTools_t.h:337-340): step 2
+// finds the position at which it would fill, step 3 runs that position with the room that is left (LexLong::room) and nothing
+// after it.  Step 1 reports a position that fills the buffer alone as n + 1 triples.
+// ------------------------------------------------------------------------------------------
+struct IdOutNull {
+    BF_HD void put(int, int32_t) {}
+    BF_HD void span(int, int, int) {}
+    BF_HD void finish(int) {}
+};
+
+struct LexStart { int next, n_out, n_emit; };       // of one start position: the next one, tokens output, triples produced
+
+template <bool HAS_ANY, class ClsAt, class IdOut, class Frames, class Tab>
+BF_HD LexStart lex_one_start(const LexTables &L, ClsAt &cls_at, int n, int p0, IdOut &out, Frames &frames, const Tab &tab, int words, int max_triples)
+{
+    LexLane<ClsAt, IdOut, Frames, HAS_ANY, Tab, true> lane(L, cls_at, out, frames, tab);
+    lane.init(n, 0x7fffffff, 0, words);
+    lane.from = p0; lane.p0 = p0; lane.max_triples = max_triples;
+    while (lane.prepare()) {
+        while (lane.step_r()) {}
+        lane.after_walk();
+    }
+    LexStart r;
+    r.next = lane.stop ? n : lane.from; r.n_out = lane.out_count; r.n_emit = lane.stop ? max_triples + 1 : lane.emitted;
+    return r;
+}
+
+// One visit of step 2: position `pos` with the result `r` of step 1; `ob` / `eb` = tokens output / triples produced before it.
+// Returns true while the chain goes on (pos = the next visited position).  room >= 0: the triple buffer fills at this
+// position -- it is the last one visited and step 3 runs it with that much room.
+BF_HD bool lex_chain_visit(int n, int max_triples, const LexStart &r, int &pos, int &ob, int &eb, int &room)
+{
+    if (eb + r.n_emit > max_triples) { room = max_triples - eb; return false; }
+    room = -1; ob += r.n_out; eb += r.n_emit; pos = r.next;
+    return pos < n;
 }
 
 } // namespace bfa

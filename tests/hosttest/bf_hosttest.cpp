@@ -638,6 +638,66 @@ int bft_emu_text_to_words(void *hv, const char *s, int n, char *out, int32_t *st
     return (int)os.size();
 }
 
+// The raw tokens of the words modes (mode 1: TextToWords, 2: TextToSentences) as <tag, first, last> over characters, two ways:
+// long_form 0 = the sequential lane program (lex_doc), 1 = the long-document form (bf_lex.h lex_one_start / lex_chain_visit: every
+// start position on its own, the chain, the visited positions again).  cap > 0 pretends the reference's triple buffer holds `cap`
+// triples instead of n (both forms), to exercise the position at which it fills.  visited (optional) = positions the chain visits.
+int bft_emu_lex_tokens(void *hv, const char *s, int n, int mode, int long_form, int cap, int32_t *tags, int32_t *spans, int max_out, int *visited)
+{
+    Model &m = ((Handle *)hv)->m;
+    if (!m.error.empty() || m.kind != KIND_WP || n <= 0 || !s) return -1;
+    std::vector<int> cps((size_t)n);
+    const int len = bfo_utf8_to_utf32(s, n, cps.data(), n);
+    if (len <= 0) return -1;
+    std::vector<uint16_t> cls;
+    for (int i = 0; i < len; ++i) cls.push_back((uint16_t)m.words_cpmap.get(cps[(size_t)i]));
+    LexTables L;
+    L.T = m.wbd_t2.data(); L.acts = m.acts_pool.data(); L.initial = m.wbd.initial_base; L.initial_l = m.initial_l; L.cls_any = m.cls_any; L.cls_l = m.cls_l; L.cls_r = m.cls_r;
+    L.max_depth = m.max_depth; L.max_token_length = m.max_token_length; L.max_frames = m.lex_frames;
+    L.loop_state = g_no_ff ? LX_NO_STATE : m.loop_base; L.loop_info = m.loop_info; L.loop_final = m.loop_final ? 1 : 0; L.two_level = 0; L.fn_no_ra = (m.fn_no_ra && !g_general) ? 1 : 0;
+    cls.push_back((uint16_t)CLS_NONE);
+    HostCls cls_at{cls.data(), len + 1};
+    const int room_all = cap > 0 ? cap : len;
+    std::vector<int32_t> tg((size_t)len + 1), sp(2 * (size_t)len + 2);
+    FramesArray frames;
+    const bool any = L.cls_any != LX_CLS_NONE;
+    TabDirect tab{L.T};
+    int w = 0;
+    if (!long_form) {
+        IdOutDirect o{tg.data(), sp.data()};
+        auto run = [&](auto has_any) {
+            LexLane<HostCls, IdOutDirect, FramesArray, decltype(has_any)::value> lane(L, cls_at, o, frames);
+            lane.init(len, 0x7fffffff, 0, mode); lane.max_triples = room_all;
+            while (lane.prepare()) { while (lane.step_r()) {} lane.after_walk(); }
+            return lane.finish();
+        };
+        w = any ? run(std::true_type{}) : run(std::false_type{});
+    } else {
+        auto one = [&](int p0, auto &out, int room) {
+            return any ? lex_one_start<true>(L, cls_at, len, p0, out, frames, tab, mode, room) : lex_one_start<false>(L, cls_at, len, p0, out, frames, tab, mode, room);
+        };
+        std::vector<LexStart> st((size_t)len + 1);
+        IdOutNull none;
+        for (int p = -1; p < len; ++p) st[(size_t)p + 1] = one(p, none, room_all);
+        int pos = -1, ob = 0, eb = 0, nv = 0;
+        for (;;) {
+            int room; const int here = pos, base = ob;
+            const bool more = lex_chain_visit(len, room_all, st[(size_t)pos + 1], pos, ob, eb, room);
+            if (visited) visited[nv] = here;
+            ++nv;
+            IdOutDirect o{tg.data() + base, sp.data() + 2 * (size_t)base};
+            const LexStart r = one(here, o, room >= 0 ? room : room_all);
+            if (room >= 0) { ob = base + r.n_out; break; }
+            if (r.next != st[(size_t)here + 1].next || r.n_out != st[(size_t)here + 1].n_out) return -3;      // the two runs of a position differ
+            if (!more) break;
+        }
+        w = ob;
+        if (visited) visited[nv] = -2;
+    }
+    for (int k = 0; k < w && k < max_out; ++k) { tags[k] = tg[(size_t)k]; spans[2 * k] = sp[2 * (size_t)k]; spans[2 * k + 1] = sp[2 * (size_t)k + 1]; }
+    return w;
+}
+
 // offsets form: the lane programs report stream positions, the source-offset stream maps them to bytes and the end
 // offset adds the UTF-8 size of the last character (tokdll:1263-1273,1519-1529) -- what k_compact does on the GPU
 int bft_emu_text_to_ids_with_offsets(void *hv, const char *s, int n, int32_t *ids, int32_t *starts, int32_t *ends, int max_ids, int unk)

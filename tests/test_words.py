@@ -254,3 +254,83 @@ def test_gpu_text_to_sentences_batch(model):
         if h:
             bf.free_model(h)
         ora.free(ho)
+
+
+# ---- long documents of the words modes (bf_lex.h lex_one_start / lex_chain_visit, bf_kernels.hip k_lex_long*): every start position of
+#      a document on its own, the chain of the positions the reference's loop visits (FALexTools_t.h:229-393), those again with output
+
+def _long_docs(seed):
+    import random
+    rnd = random.Random(seed)
+    text, off = bfutil.gen_workload("config1", 10000)
+    raw = text.tobytes()
+    lines = [raw[off[d]:off[d + 1]] for d in range(10000)]
+    docs = sorted(lines, key=len)[-25:] + rnd.sample(lines, 200)
+    docs += [b" ".join(rnd.sample(lines, 40)), b". ".join(rnd.sample(lines, 25)), b"x" * 700, b" " * 400, ("д" * 301 + " 好的。" * 50).encode()]
+    docs += [b for b in bfutil.fuzz_docs(150, seed=seed) if len(b) > 40]
+    return docs
+
+
+@pytest.mark.parametrize("model,mode", [("wbd.bin", 1), ("sbd.bin", 2), ("wbd_chuni.bin", 1), ("bert_base_cased_tok.bin", 1), ("wbd.bin", 2), ("sbd.bin", 1)])
+def test_long_form_on_host_equals_the_sequential_program(model, mode):
+    """the three steps of the long-document form, run on the host over the same tables, give the tokens of the sequential lane program
+    (which test_words_lane_program_on_host_matches_oracle pins to the oracle) -- also when the triple buffer fills in the middle"""
+    import numpy as np
+    L = ctypes.CDLL(bfutil.HOSTTEST_LIB)
+    L.bft_load.restype = ctypes.c_void_p
+    L.bft_load.argtypes = [ctypes.c_char_p]
+    g = L.bft_emu_lex_tokens
+    g.restype = ctypes.c_int
+    g.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+    h = L.bft_load(bfutil.model_path(model).encode())
+
+    def toks(b, long_form, cap):
+        n = len(b)
+        tags, sp, vis = np.zeros(n + 2, np.int32), np.zeros(2 * n + 4, np.int32), np.zeros(n + 4, np.int32)
+        w = g(h, b, n, mode, long_form, cap, tags.ctypes.data, sp.ctypes.data, n + 1, vis.ctypes.data)
+        return w, tags[:max(w, 0)].tolist(), sp[:2 * max(w, 0)].tolist()
+    ntok = 0
+    for b in _long_docs(3):
+        for cap in (0, 3, max(1, len(b) // 9)):
+            a = toks(b, 0, cap)
+            assert a == toks(b, 1, cap), (model, mode, cap, b[:60])
+            ntok += max(a[0], 0)
+    assert ntok > 200
+    L.bft_free(ctypes.c_void_p(h))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("model,mode", [("wbd.bin", 1), (None, 1), ("sbd.bin", 2), (None, 2), ("bert_base_cased_tok.bin", 1), ("wbd.bin", 2)])
+def test_gpu_long_documents(model, mode):
+    """batches that mix short lines with long ones (up to 1 MB in one document): per document the string of the single-document reference call,
+    with the long-document path at its default threshold, at 16 characters, and switched off"""
+    import random
+    import blingfire_amd as bf
+    ora, f = _oracle_fn() if mode == 1 else _oracle_sent_fn()
+    default = "wbd.bin" if mode == 1 else "sbd.bin"
+    ho = ora.load(bfutil.model_path(model or default))
+    h = bf.load_model(bfutil.model_path(model)) if model else None
+    fn = bf.text_to_words_batch if mode == 1 else bf.text_to_sentences_batch
+    try:
+        docs = _long_docs(5)
+        rnd = random.Random(9)
+        text, off = bfutil.gen_workload("config1", 10000)
+        raw = text.tobytes()
+        lines = [raw[off[d]:off[d + 1]] for d in range(10000)]
+        big = (b" " if mode == 1 else b". ").join(rnd.choices(lines, k=24000))[:1 << 20]
+        docs += [big, b"", lines[0], big[:200000]]
+        want = []
+        for b in docs:
+            r, o, _, _ = _call(f, (ctypes.c_void_p(ho),), b, 4 * len(b) + 8)
+            want.append(o[:r - 1] if r > 0 else b"")
+        variants = [0] if h is None else [0, 1 << 12, 0x40000000]
+        for v in variants:
+            if h is not None:
+                assert bf.lib().BfSetVariant(ctypes.c_void_p(h), v) >= 0
+            out, t_off = fn(docs, h)
+            for d, b in enumerate(docs):
+                assert out[t_off[d]:t_off[d + 1]].tobytes() == want[d], (model, mode, hex(v), d, len(b), b[:60])
+    finally:
+        if h:
+            bf.free_model(h)
+        ora.free(ho)
