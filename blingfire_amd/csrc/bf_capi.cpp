@@ -175,6 +175,7 @@ struct Handle {
     DevBuf w_cls, w_nchars, w_tmp, w_counts, w_bsums, w_misc, w_flags, w_out, w_outoff;   // w_misc: [0] next_doc (u64), [2] status (int)
     DevBuf w_text, w_docoff, w_ids, w_idoff, w_starts, w_ends;  // host-API staging
     DevBuf w_srcoff, w_span;                                    // offsets API: source-offset stream, staged id spans
+    DevBuf w_preplong, w_w2tlong;                               // k_prep_wp_long / k_w2t_copy_long: the documents of more than 2048 bytes / 1024 tokens
     DevBuf w_long;                                              // words modes: the long-document path (bf_kernels.h LexLongParams: list, spec, vis)
     DevBuf w_espan, w_hspan, w_chard;                           // the flat program, offsets API: spans of the entries, of the pieces at the homes; counts of the documents handed back
     DevBuf w_ent, w_home, w_entoff, w_entcnt, w_dstat, w_ranges, w_list, w_wrec, t_flat;   // the flat program (bf_flat.h): entries, homes, per-document records, ranges, the documents handed back; its word table
@@ -202,7 +203,7 @@ struct Handle {
         shards.clear();
         pipe.release(); m_small.release();
         for (DevBuf *b : {&t_segscore, &t_segid, &t_bpetab, &t_bpe_prio, &t_bpe_place, &t_dk_l1, &t_dk_pages, &t_dn_l1, &t_dn_pages, &t_dn_pool, &t_k2i, &t_rows, &w_keys, &w_keyoff, &w_dids, &w_dret, &w_vals, &t_i2w_off, &t_i2w_data, &t_kind, &t_wbd, &t_info, &t_acts, &t_cp_l1, &t_cp_pages, &t_multi, &t_wcp_l1, &t_wcp_pages, &t_dict, &t_seginfo, &w_s1, &w_s2, &w_s3, &w_s4, &w_big, &w_perm, &w_hist, &w_narcs, &w_bwflags, &w_cls, &w_nchars, &w_tmp, &w_counts, &w_flags, &w_out, &w_outoff,
-                          &w_bsums, &w_misc, &w_text, &w_docoff, &w_ids, &w_idoff, &w_starts, &w_ends, &w_srcoff, &w_span, &w_long, &w_ent, &w_home, &w_entoff, &w_entcnt, &w_dstat, &w_ranges, &w_list, &w_wrec, &t_flat, &w_espan, &w_hspan, &w_chard}) b->release();
+                          &w_bsums, &w_misc, &w_text, &w_docoff, &w_ids, &w_idoff, &w_starts, &w_ends, &w_srcoff, &w_span, &w_long, &w_preplong, &w_w2tlong, &w_ent, &w_home, &w_entoff, &w_entcnt, &w_dstat, &w_ranges, &w_list, &w_wrec, &t_flat, &w_espan, &w_hspan, &w_chard}) b->release();
         for (auto &e : ev) if (e) (void)hipEventDestroy(e);
         if (stream) (void)hipStreamDestroy(stream);
         magic = 0;
@@ -348,25 +349,33 @@ bool use_bpe_wave(const Handle *h, bool want_off) { return h->m.bpe_wave_ok && !
 // that is much longer than the rest: a lane walks 1.8 us per character when it is the last one running (config 1's 8,396-byte line:
 // 4.9 ms), the chip as a whole 75 ps per character (1 M lines: 3.25 ms), so a document of more than total_bytes / 24,000 characters
 // would hold the batch up (measured on MI355X, profiles/r06_words_*: 10,000 lines 4.6 -> 0.55 ms at 16, 1 M lines 3.25 ms at 128 and
-// 10.2 ms at 16).  BfSetVariant: bit 0x40000000 = off (every document on one lane), bits 12..15 = k > 0: thresh = 8 << k.
+// 10.2 ms at 16).  BfSetVariant: bit 0x40000000 = off (every document on one lane), bits 12..15 = k > 0: thresh = 8 << k, bit 0x20000000 = a test
+// knob: the triple buffer of the words modes holds n / 8 triples instead of n (so that tests reach the position at which it fills).
 // The capacities are bounds that hold for any batch of these sizes (a listed document has more than thresh bytes and owns
 // (n + 1 + 63) / 64 chunks) unless that is more than LONG_MAX_CHUNKS: then the documents that do not fit stay on lanes.
+// A lexer whose table does not fit LDS (sbd.bin) and whose loop visits every position walks far slower per character on a lane but
+// also spends more on every start position here: the same bytes as 100-byte documents took 2.0 ms on lanes and 3.4 ms here, as
+// 1000-byte documents 8 ms either way, as one 1 MB document 1 s and 30 ms -> total_bytes / 4,000 for those.
 constexpr int LONG_THRESH_MIN = 16;
-constexpr int64_t LONG_BYTES_PER_THRESH = 24000;
-constexpr int64_t LONG_MAX_CHUNKS = (int64_t)2 << 20;           // 128 M cells: 2.5 GB of workspace
-struct LongCaps { int thresh; int64_t docs, chunks; size_t list_off, spec_off, vis_off, bytes; };
+constexpr int64_t LONG_BYTES_PER_THRESH = 24000, LONG_BYTES_PER_THRESH_BIG_TABLE = 4000;
+constexpr size_t LONG_TABLE_IN_LDS_ENTRIES = 5000;              // (bf_kernels.hip: LEX_TLDS_MAX_BYTES less the frames and the action pool, in 8-byte entries)
+constexpr int64_t LONG_MAX_CHUNKS = (int64_t)2 << 20;           // 128 M cells: 4 GB of workspace
+struct LongCaps { int thresh; int64_t docs, chunks; size_t list_off, spec_off, jump_off, entry_off, bytes; };
 LongCaps long_caps(const Handle *h, int64_t ndocs, int64_t total_bytes, int words)
 {
-    LongCaps c{0, 0, 0, 0, 0, 0, 0};
+    LongCaps c{0, 0, 0, 0, 0, 0, 0, 0};
     if (!words || h->m.kind != KIND_WP || h->m.max_depth < 1 || h->m.lexer_void || (h->variant & 0x40000000) || ndocs <= 0) return c;
     const int k = (h->variant >> 12) & 0xf;
-    c.thresh = k ? (8 << k) : (int)std::min<int64_t>(std::max<int64_t>(LONG_THRESH_MIN, total_bytes / LONG_BYTES_PER_THRESH), 1 << 30);
+    const size_t table_n = h->m.wbd_t2.size() > (size_t)LX_T_CLS_MASK + 1 ? h->m.wbd_t2.size() - ((size_t)LX_T_CLS_MASK + 1) : 0;
+    const int64_t per = table_n > 0 && table_n <= LONG_TABLE_IN_LDS_ENTRIES ? LONG_BYTES_PER_THRESH : LONG_BYTES_PER_THRESH_BIG_TABLE;
+    c.thresh = k ? (8 << k) : (int)std::min<int64_t>(std::max<int64_t>(LONG_THRESH_MIN, total_bytes / per), 1 << 30);
     c.docs = std::min<int64_t>(ndocs, total_bytes / ((int64_t)c.thresh + 1)) + 1;
     c.chunks = std::min<int64_t>(total_bytes / 64 + 2 * c.docs + 1, LONG_MAX_CHUNKS);
     c.list_off = 0;
     c.spec_off = ((size_t)c.docs * sizeof(LexLongDoc) + 255) & ~(size_t)255;
-    c.vis_off = c.spec_off + (size_t)c.chunks * 64 * 16;
-    c.bytes = c.vis_off + (size_t)c.chunks * 64 * 4;
+    c.jump_off = c.spec_off + (size_t)c.chunks * 64 * 16;
+    c.entry_off = c.jump_off + (size_t)c.chunks * 64 * 16;
+    c.bytes = c.entry_off + (size_t)c.chunks * 16;
     return c;
 }
 
@@ -513,6 +522,10 @@ int run_device(Handle *h, const char *d_text, const int64_t *d_doc_off, int64_t 
         WpPrepParams pp{b, DevCpMap{h->t_cp_l1.as<uint16_t>(), h->t_cp_pages.as<uint32_t>()}, h->t_multi.as<uint16_t>(),
                         m.wbd_charmap_multi ? 1 : 0, h->w_cls.as<uint16_t>(), want_off ? h->w_srcoff.as<int32_t>() : nullptr, h->w_nchars.as<int32_t>()};
         if (words) { pp.cpmap = DevCpMap{h->t_wcp_l1.as<uint16_t>(), h->t_wcp_pages.as<uint32_t>()}; pp.has_multi = 0; }   // no charmap (tokdll:476-499)
+        // long documents are decoded by sixteen waves each (k_prep_wp_long); w_misc + 48: their number, zeroed with the status word above
+        pp.long_cap = total_bytes / 2048 + 1;
+        pp.long_list = h->w_preplong.reserve((size_t)pp.long_cap * 8) ? h->w_preplong.as<int64_t>() : nullptr;
+        pp.long_count = (unsigned int *)(h->w_misc.as<char>() + 48);
         if (ndocs > 0) launch_prep_wp(pp, total_bytes, h->w_flags.as<unsigned long long>(), s);
         (void)hipEventRecord(h->ev[EV_PREP], s);
         WpLexParams lp;
@@ -529,12 +542,13 @@ int run_device(Handle *h, const char *d_text, const int64_t *d_doc_off, int64_t 
         lp.table_n = (int)(m.wbd_t2.size() > (size_t)LX_T_CLS_MASK + 1 ? m.wbd_t2.size() - ((size_t)LX_T_CLS_MASK + 1) : 0);
         lp.stats = h->lex_stats ? (unsigned long long *)(h->w_misc.as<char>() + 64) : nullptr;
         const LongCaps lc = long_caps(h, ndocs, total_bytes, words);
-        lp.lg = LexLongParams{lc.thresh, lc.docs, lc.chunks, (unsigned long long *)(h->w_misc.as<char>() + 40) /* zeroed with the status word above */,
-                              (LexLongDoc *)(h->w_long.as<char>() + lc.list_off), (int32_t *)(h->w_long.as<char>() + lc.spec_off), (int32_t *)(h->w_long.as<char>() + lc.vis_off)};
+        lp.lg = LexLongParams{lc.thresh, (words && (h->variant & 0x20000000)) ? 3 : 0, lc.docs, lc.chunks, (unsigned long long *)(h->w_misc.as<char>() + 40) /* zeroed with the status word above */,
+                              (LexLongDoc *)(h->w_long.as<char>() + lc.list_off), (int32_t *)(h->w_long.as<char>() + lc.spec_off), (int32_t *)(h->w_long.as<char>() + lc.jump_off),
+                              (int32_t *)(h->w_long.as<char>() + lc.entry_off)};
         (void)hipEventRecord(h->ev[EV_DOM0], s);
         if (ndocs > 0) {
             launch_lex_long_list(lp, s);
-            launch_lex_wp(lp, words ? (h->variant & ~0x4000F000) : h->variant, s);
+            launch_lex_wp(lp, words ? (h->variant & ~0x6000F000) : h->variant, s);
             launch_lex_long(lp, s);
         }
         (void)hipEventRecord(h->ev[EV_DOM1], s);
@@ -966,7 +980,13 @@ int run_words_device(Handle *h, const char *d_text, const int64_t *d_doc_off, in
         ScanParams sp{h->w_counts.as<int32_t>(), ndocs, d_out_off, h->w_bsums.as<int64_t>(), nblocks};
         launch_scan(sp, s);
     }
-    if (d_out && ndocs > 0) { if (mode == 2) launch_s2t_copy(p, s); else launch_w2t_copy(p, s); }
+    if (d_out && ndocs > 0) {
+        // documents of many tokens are assembled by sixteen waves each (k_w2t_copy_long); w_misc + 52: their number
+        p.long_cap = total_bytes / 1024 + 2;
+        p.long_count = (unsigned int *)(h->w_misc.as<char>() + 52);
+        p.long_list = (h->w_w2tlong.reserve((size_t)p.long_cap * 8) && hip_ok(hipMemsetAsync(p.long_count, 0, 4, s), "hipMemsetAsync")) ? h->w_w2tlong.as<int64_t>() : nullptr;
+        if (mode == 2) launch_s2t_copy(p, s); else launch_w2t_copy(p, s);
+    }
     return hip_ok(hipGetLastError(), "TextToWords kernels") ? 0 : BF_E_DEVICE;
 }
 
@@ -1811,7 +1831,7 @@ int BfReserve(void *p, int64_t max_docs, int64_t max_bytes, int want_offsets)
     // the lane-per-document kernels, which TextToWords / TextToSentences, lexers outside the unit form and BfSetVariant(2) run -- no hipMalloc
     // (= device synchronisation) inside a later call of either kind
     if (!reserve_ids_workspaces(h, max_docs, max_bytes, want_offsets != 0)) return BF_E_DEVICE;
-    // (not the long-document workspace of the words modes, w_long: 20 bytes per cell, allocated by the first words call that is that large)
+    // (not the long-document workspace of the words modes, w_long: 32 bytes per cell, allocated by the first words call that is that large)
     if (h->m.kind == KIND_WP && !reserve_ids_workspaces(h, max_docs, max_bytes, true, 1, false)) return BF_E_DEVICE;
     return 0;
 }

@@ -19,22 +19,32 @@ struct WpPrepParams {
     uint16_t *cls;              // [total_bytes] class stream: document d occupies cls[doc_off[d] ..)
     int32_t *src_off;           // optional (offsets API): byte offset in the document of the source character of every stream element
     int32_t *nchars;            // [ndocs] normalised length, 0 = "TextToIds returns 0"
+    // optional (k_prep_wp, the one-pass form): documents of more than PREP_LONG_BYTES bytes are listed here and decoded by sixteen waves
+    // each (k_prep_wp_long) instead of one; long_count is zeroed per launch
+    int64_t *long_list; unsigned int *long_count; int64_t long_cap;
 };
 
 // Long documents of the words modes (bf_lex.h: lex_one_start / lex_chain_visit).  A document of more than `thresh` characters is
 // listed (k_lex_long_list) and leaves the lane kernel alone; its n + 1 start positions are cells of a dense "chunk space" (64 cells
-// per chunk, a document owns whole chunks: cell = 64 * chunk0 + position + 1) that three kernels go over: k_lex_long<false> (every
-// cell: next position + counts), k_lex_long_chain (one wave per document: the visited cells and their output bases),
-// k_lex_long<true> (the visited cells write their tokens into the document's staging slot).
+// per chunk, a document owns whole chunks: cell = 64 * chunk0 + position + 1) that three kernels go over:
+//   k_lex_long<false>   every cell runs its start position without output (spec), then the wave resolves its own chunk: from every cell,
+//                       the first cell beyond the chunk the chain reaches and the counts summed on the way there (jump);
+//   k_lex_long_chain    one workgroup per document goes from chunk to chunk, one hop each: where the chain enters a chunk and the
+//                       output index / triples so far at that point (entry);
+//   k_lex_long<true>    every entered chunk follows the chain inside itself, the visited cells run again and write their tokens into
+//                       the document's staging slot.
 struct LexLongDoc { int64_t doc, chunk0; };       // doc < 0: a listed document that did not fit the workspace (the lane kernel keeps it)
 struct LexLongParams {
     int thresh;                       // 0: off
+    int cap_shift;                    // test knob (BfSetVariant 0x20000000): the triple buffer holds n >> cap_shift triples instead of n (lane kernel too)
     int64_t cap_docs, cap_chunks;     // capacity of `list` / of the cell arrays in chunks
     unsigned long long *hdr;          // documents listed << 40 | chunks handed out (zeroed per launch)
     LexLongDoc *list;
-    int32_t *spec;                    // [4 * cell]: next position, tokens output, triples produced, room + 1 of the position that fills the buffer (else 0)
-    int32_t *vis;                     // [cell]: -1 = not visited, else the output index of the position's first token
+    int32_t *spec;                    // [4 * cell]: next position, tokens output, triples produced, -
+    int32_t *jump;                    // [4 * cell]: first cell of the document beyond this chunk on the chain from here (LEX_CHAIN_END: none), tokens / triples summed up to there, -
+    int32_t *entry;                   // [4 * chunk]: cell of the chunk the chain enters at (-1: it does not), tokens output / triples produced before it, -
 };
+constexpr int LEX_CHAIN_END = 0x40000000, LEX_COUNT_SAT = 0x3fffffff;
 constexpr unsigned long long LEX_LONG_CHUNK_MASK = (1ull << 40) - 1;
 
 struct WpLexParams {
@@ -186,6 +196,9 @@ struct W2tParams {
     const int64_t *word_off; const int32_t *starts, *ends;
     int32_t *lens; const int64_t *text_off; uint8_t *out; int64_t out_cap;
     const int32_t *nvalid;       // sentences only: characters decoded per document (<= 0: the document is rejected)
+    // optional (the copy kernels): documents of more than W2T_LONG_TOKENS tokens are listed here and assembled by sixteen waves each
+    // (k_w2t_copy_long); long_count is zeroed by the caller
+    int64_t *long_list; unsigned int *long_count; int64_t long_cap;
 };
 void launch_w2t_len(const W2tParams &p, hipStream_t s);
 // TextToSentences output assembly (reference tokdll:257-339) on the same parameters: ends[] = last byte of every token of the

@@ -37,19 +37,17 @@ __device__ __forceinline__ void prep_ascii_table(const WpPrepParams &p, uint16_t
 //   lead byte          -> length from the lead, continuation bytes checked, truncated tail (:167-171), overlong and
 //                         > U+10FFFF (:185-188), surrogates (:190-193)
 // then the fused charmap+class map gives 0 / 1 / 2..10 stream elements per character, compacted with a wave scan.
-__device__ __forceinline__ void prep_wp_doc(const WpPrepParams &p, int64_t d, int64_t b, int64_t n64, int lane, const uint16_t *ascii_cls, uint16_t *stage /* 512 elements of LDS, this wave's */)
+// The pieces [pos0, pos1) of a document (pos0 a multiple of 512), stream position of the first one's first element = outc.  bom < 0:
+// the range starts the document and finds the byte order mark itself; COUNT: nothing is written, outc counts the elements.
+template <bool COUNT>
+__device__ __forceinline__ void prep_wp_pieces(const WpPrepParams &p, int64_t b, int n, int lane, const uint16_t *ascii_cls, uint16_t *stage /* 512 elements of LDS, this wave's */,
+                                               int pos0, int pos1, int bom, int &outc, bool &err_any)
 {
-    if (n64 <= 0 || n64 > 1000000000) { if (lane == 0) p.nchars[d] = 0; return; }   // tokdll:1121
-    if (b < 0 || b + n64 > p.b.total_bytes) {                                         // outside the caller's buffer: empty + status
-        if (lane == 0) { p.nchars[d] = 0; atomicOr(p.b.status, BF_STATUS_BAD_OFFSETS); }
-        return;
-    }
-    const int n = (int)n64;
     const uint8_t *s = p.b.text + b;
     uint16_t *out = p.cls + b;
-    int outc = 0, bom = 0; bool err_any = false;
     uint32_t carry = 0;
-    for (int pos = 0; pos < n; pos += 512) {
+    if (pos0 > 0) carry = (uint32_t)s[pos0 - 3] | ((uint32_t)s[pos0 - 2] << 8) | ((uint32_t)s[pos0 - 1] << 16);
+    for (int pos = pos0; pos < pos1; pos += 512) {
         const int q0 = pos + lane * 8;
         uint64_t own = 0;
         int nb = n - q0; nb = nb < 0 ? 0 : (nb > 8 ? 8 : nb);
@@ -61,7 +59,7 @@ __device__ __forceinline__ void prep_wp_doc(const WpPrepParams &p, int64_t d, in
         uint32_t prv = __shfl_up(tail3, 1, 64);
         if (lane == 0) prv = carry;
         carry = __shfl(tail3, 63, 64);
-        if (pos == 0) {                                                   // FAUtf8Utils.cpp:247-252
+        if (pos == 0 && bom < 0) {                                        // FAUtf8Utils.cpp:247-252
             const int has_bom = (n >= 3 && ((uint32_t)own & 0xFFFFFFu) == 0xBFBBEFu) ? 3 : 0;
             bom = __shfl(has_bom, 0, 64);
         }
@@ -118,6 +116,7 @@ __device__ __forceinline__ void prep_wp_doc(const WpPrepParams &p, int64_t d, in
         const int inc = wave_incl_scan(cnt);
         int idx = outc + inc - cnt;
         const int total = __shfl(inc, 63, 64);
+        if constexpr (COUNT) { outc += total; continue; }
         bool multi = false;
 #pragma unroll
         for (int k = 0; k < 8; ++k) multi |= w[k] > 0 && (v[k] & 0x80000000u) != 0;
@@ -144,6 +143,28 @@ __device__ __forceinline__ void prep_wp_doc(const WpPrepParams &p, int64_t d, in
         }
         outc += total;
     }
+}
+
+// documents of more than this many bytes are decoded by sixteen waves (k_prep_wp_long) when the caller gives a list to put them on
+constexpr int PREP_LONG_BYTES = 2048, PREP_LONG_WAVES = 16;
+
+__device__ __forceinline__ void prep_wp_doc(const WpPrepParams &p, int64_t d, int64_t b, int64_t n64, int lane, const uint16_t *ascii_cls, uint16_t *stage /* 512 elements of LDS, this wave's */)
+{
+    if (n64 <= 0 || n64 > 1000000000) { if (lane == 0) p.nchars[d] = 0; return; }   // tokdll:1121
+    if (b < 0 || b + n64 > p.b.total_bytes) {                                         // outside the caller's buffer: empty + status
+        if (lane == 0) { p.nchars[d] = 0; atomicOr(p.b.status, BF_STATUS_BAD_OFFSETS); }
+        return;
+    }
+    const int n = (int)n64;
+    if (p.long_list && n > PREP_LONG_BYTES) {                                         // a long document: listed for k_prep_wp_long
+        if (lane == 0) {
+            const unsigned slot = atomicAdd(p.long_count, 1u);
+            if ((int64_t)slot < p.long_cap) p.long_list[slot] = d;
+        }
+        return;
+    }
+    int outc = 0; bool err_any = false;
+    prep_wp_pieces<false>(p, b, n, lane, ascii_cls, stage, 0, n, -1, outc, err_any);
     const bool bad = __any(err_any);
     if (lane == 0) p.nchars[d] = (bad || outc > n) ? 0 : outc;     // tokdll:1151-1153,1185-1187
 }
@@ -158,6 +179,41 @@ __global__ __launch_bounds__(256) void k_prep_wp(WpPrepParams p)
     const int64_t wave0 = (int64_t)blockIdx.x * 4 + wave_in_block();
     const int64_t nwaves = (int64_t)gridDim.x * 4;
     for (int64_t d = wave0; d < p.b.ndocs; d += nwaves) { const int64_t b = p.b.doc_off[d]; prep_wp_doc(p, d, b, p.b.doc_off[d + 1] - b, lane, ascii_cls, stage_all + wave_in_block() * 512); }
+}
+
+// The listed documents, one workgroup of sixteen waves each: every wave owns a contiguous run of 512-byte pieces, counts its elements
+// (the decode without the stores), the counts are summed in front of each wave, and the wave decodes its pieces again at that
+// stream position.  (One wave took 7.6 ms for a 1 MB document: 3.7 us per piece, one after the other.)
+__global__ __launch_bounds__(PREP_LONG_WAVES * 64) void k_prep_wp_long(WpPrepParams p)
+{
+    __shared__ uint16_t ascii_cls[128];
+    __shared__ uint16_t stage_all[PREP_LONG_WAVES * 512];
+    __shared__ int s_cnt[PREP_LONG_WAVES], s_err[PREP_LONG_WAVES];
+    prep_ascii_table(p, ascii_cls);
+    const int lane = lane_id(), wave = wave_in_block();
+    int64_t nlist = (int64_t)*p.long_count; if (nlist > p.long_cap) nlist = p.long_cap;
+    for (int64_t j = blockIdx.x; j < nlist; j += gridDim.x) {
+        const int64_t d = p.long_list[j];
+        const int64_t b = p.b.doc_off[d];
+        const int n = (int)(p.b.doc_off[d + 1] - b);                                  // (checked by prep_wp_doc before the document was listed)
+        const uint8_t *s = p.b.text + b;
+        const int bom = (s[0] == 0xEF && s[1] == 0xBB && s[2] == 0xBF) ? 3 : 0;       // n > PREP_LONG_BYTES
+        const int pieces = (n + 511) >> 9, per = (pieces + PREP_LONG_WAVES - 1) / PREP_LONG_WAVES;
+        int pos0 = wave * per * 512, pos1 = pos0 + per * 512;
+        if (pos0 > n) pos0 = n;
+        if (pos1 > n) pos1 = n;
+        int cnt = 0; bool err = false;
+        prep_wp_pieces<true>(p, b, n, lane, ascii_cls, stage_all + wave * 512, pos0, pos1, bom, cnt, err);
+        const bool err_wave = __any(err);
+        if (lane == 0) { s_cnt[wave] = cnt; s_err[wave] = err_wave ? 1 : 0; }
+        __syncthreads();
+        int outc = 0, total = 0, bad = 0;
+        for (int w = 0; w < PREP_LONG_WAVES; ++w) { if (w < wave) outc += s_cnt[w]; total += s_cnt[w]; bad |= s_err[w]; }
+        bool err2 = false;
+        if (!bad && total <= n) prep_wp_pieces<false>(p, b, n, lane, ascii_cls, stage_all + wave * 512, pos0, pos1, bom, outc, err2);
+        if (wave == 0 && lane == 0) p.nchars[d] = (bad || total > n) ? 0 : total;     // tokdll:1151-1153,1185-1187
+        __syncthreads();                                                              // (s_cnt / s_err are rewritten by the next document)
+    }
 }
 
 // Two-pass form for the common case (no offsets wanted).  An all-ASCII document whose characters all map 1:1 has
@@ -239,6 +295,14 @@ __global__ __launch_bounds__(256) void k_prep_wp_docs(WpPrepParams p, const unsi
     }
 }
 
+static void launch_prep_wp_long(const WpPrepParams &p, hipStream_t s)
+{
+    if (!p.long_list) return;
+    int64_t nb = p.long_cap < device_cus() ? p.long_cap : device_cus();       // (the number of listed documents is on the device: workgroups without one leave at once)
+    if (nb < 1) nb = 1;
+    hipLaunchKernelGGL(k_prep_wp_long, dim3((unsigned)nb), dim3(PREP_LONG_WAVES * 64), 0, s, p);
+}
+
 void launch_prep_wp(const WpPrepParams &p, int64_t total_bytes, unsigned long long *flags, hipStream_t s)
 {
     if (flags && !p.src_off && ((uintptr_t)p.b.text & 15) == 0 && ((uintptr_t)p.cls & 31) == 0 && total_bytes > 0) {
@@ -247,12 +311,14 @@ void launch_prep_wp(const WpPrepParams &p, int64_t total_bytes, unsigned long lo
         hipLaunchKernelGGL(k_prep_wp_flat, dim3((unsigned)b1), dim3(256), 0, s, p, total_bytes, flags);
         int64_t b2 = (p.b.ndocs + 255) / 256; if (b2 > device_cus() * 16) b2 = device_cus() * 16; if (b2 < 1) b2 = 1;
         hipLaunchKernelGGL(k_prep_wp_docs, dim3((unsigned)b2), dim3(256), 0, s, p, (const unsigned long long *)flags);
+        launch_prep_wp_long(p, s);
         return;
     }
     int64_t blocks = (p.b.ndocs + 3) / 4;
     if (blocks > device_cus() * 16) blocks = device_cus() * 16;
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(k_prep_wp, dim3((unsigned)blocks), dim3(256), 0, s, p);
+    launch_prep_wp_long(p, s);
 }
 
 
@@ -438,7 +504,10 @@ __device__ __forceinline__ void lex_wp_flat_body(const WpLexParams &p)
                         if constexpr (!PLAIN) { taken = p.lg.thresh > 0 && n > p.lg.thresh && p.counts[doc] == -1; n = taken ? 0 : n; }
                         cls_at.init(p.cls, b);
                         if constexpr (PLAIN) { out.init(p.ids_tmp + ids_slot(b, doc), nullptr); lane.init(n, cap, p.unk, 0); }
-                        else { out.init(p.ids_tmp + ids_slot(b, doc), p.span_tmp ? p.span_tmp + 2 * ids_slot(b, doc) : nullptr); lane.init(n, cap, p.unk, p.words); }
+                        else {
+                            out.init(p.ids_tmp + ids_slot(b, doc), p.span_tmp ? p.span_tmp + 2 * ids_slot(b, doc) : nullptr); lane.init(n, cap, p.unk, p.words);
+                            if (p.lg.cap_shift) lane.max_triples = n >> p.lg.cap_shift;      // (test knob of the words modes: bf_kernels.h LexLongParams)
+                        }
                         bool more;
                         if constexpr (TWO) more = lane.prepare2(); else more = lane.prepare();
                         if (more) mode = M_WALK;
@@ -576,8 +645,17 @@ static size_t lex_long_lds_bytes(const WpLexParams &p, bool tlds)
     return (((size_t)p.L.max_frames * LEX_FRAME_WORDS) * LEX_LONG_THREADS + (size_t)((p.acts_n + 1) & ~1)) * 4 + (tlds ? (size_t)p.table_n * 8 : 0);
 }
 
-// EMIT false: every cell of the chunk space runs its start position without output (spec, vis = -1).
-// EMIT true:  the cells the chain visited run again and write their tokens.
+// The chain inside one chunk, from cell `rel`, for the wave that holds the chunk's results in its lanes (to = the next cell relative to
+// the chunk, >= 64: outside): the mask of the visited cells.  Scalar: v_readlane of the next cell, five instructions per hop.
+__device__ __forceinline__ unsigned long long lex_chunk_chain(int to, int rel)
+{
+    unsigned long long V = 0;
+    do { V |= 1ull << rel; rel = __builtin_amdgcn_readlane(to, rel); } while (rel < 64);
+    return V;
+}
+
+// EMIT false: every cell of the chunk space runs its start position without output (spec), the wave resolves its chunk (jump).
+// EMIT true:  the chunks the chain enters follow it inside themselves; the visited cells run again and write their tokens.
 template <bool HAS_ANY, bool TLDS, bool EMIT>
 __global__ __launch_bounds__(LEX_LONG_THREADS) void k_lex_long(WpLexParams p)
 {
@@ -610,90 +688,115 @@ __global__ __launch_bounds__(LEX_LONG_THREADS) void k_lex_long(WpLexParams p)
         const LexLongDoc ld = p.lg.list[lo];
         if (ld.doc < 0) continue;
         const int n = p.nchars[ld.doc];
+        const int cap = n >> p.lg.cap_shift;                              // triples the reference's buffer holds (tokdll:494-499)
         const int64_t b = p.b.doc_off[ld.doc];
-        const int pos = (int)(c - ld.chunk0) * 64 + lane - 1;
+        const int w0 = (int)(c - ld.chunk0) * 64;                         // the chunk's first cell in the document (cell = position + 1)
+        const int pos = w0 + lane - 1;
         const int64_t cell = c * 64 + lane;
-        bool act = pos < n;
-        int base = 0, room1 = 0;
-        if constexpr (EMIT) {
-            base = act ? p.lg.vis[cell] : -1;
-            act = base >= 0;
-            if (act) room1 = p.lg.spec[4 * cell + 3];
-        } else p.lg.vis[cell] = -1;
-        if (!act) continue;
+        const bool act = pos < n;
         ClsWin cls_at; cls_at.init(p.cls, b);
-        if constexpr (EMIT) {
-            const int64_t slot = ids_slot(b, ld.doc) + base;
-            IdOutDirect out{p.ids_tmp + slot, p.span_tmp + 2 * slot};
-            const LexStart r = lex_one_start<HAS_ANY>(L, cls_at, n, pos, out, frames, tab, p.words, room1 ? room1 - 1 : n);
-            if (room1) p.counts[ld.doc] = base + r.n_out;                 // the position at which the triple buffer fills ends the document
+        if constexpr (!EMIT) {
+            LexStart r; r.next = n; r.n_out = 0; r.n_emit = 0;
+            if (act) {
+                IdOutNull out;
+                r = lex_one_start<HAS_ANY>(L, cls_at, n, pos, out, frames, tab, p.words, cap);
+                ((int4 *)p.lg.spec)[cell] = make_int4(r.next, r.n_out, r.n_emit, 0);
+            }
+            // from every cell: the first cell beyond the chunk and the counts on the way, by pointer doubling over the lanes (a chain
+            // makes at most 63 hops inside a chunk).  J >= 0: the chain from here is at lane J after 2^k hops; J < 0: it has left, to E
+            const bool end = !act || r.next >= n;
+            const int to = r.next + 1;
+            int J = (!end && to < w0 + 64) ? to - w0 : -1;
+            int E = end ? LEX_CHAIN_END : to;
+            int so = r.n_out, se = r.n_emit;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+                const int j = J < 0 ? lane : J;
+                const int Jj = __shfl(J, j, 64), Ej = __shfl(E, j, 64), soj = __shfl(so, j, 64), sej = __shfl(se, j, 64);
+                if (J >= 0) {
+                    so = so + soj < LEX_COUNT_SAT ? so + soj : LEX_COUNT_SAT; se = se + sej < LEX_COUNT_SAT ? se + sej : LEX_COUNT_SAT;
+                    if (Jj < 0) { E = Ej; J = -1; } else J = Jj;
+                }
+            }
+            ((int4 *)p.lg.jump)[cell] = make_int4(E, so, se, 0);
+            if (lane == 0) ((int4 *)p.lg.entry)[c] = make_int4(-1, 0, 0, 0);
         } else {
-            IdOutNull out;
-            const LexStart r = lex_one_start<HAS_ANY>(L, cls_at, n, pos, out, frames, tab, p.words, n);
-            ((int4 *)p.lg.spec)[cell] = make_int4(r.next, r.n_out, r.n_emit, 0);
+            const int4 ent = ((const int4 *)p.lg.entry)[c];
+            const int rel0 = __builtin_amdgcn_readfirstlane(ent.x);
+            if (rel0 < 0) continue;                                       // the chain does not come through this chunk
+            const int ob = __builtin_amdgcn_readfirstlane(ent.y), eb = __builtin_amdgcn_readfirstlane(ent.z);
+            int4 sp = make_int4(n, 0, 0, 0);
+            if (act) sp = ((const int4 *)p.lg.spec)[cell];
+            const int to = sp.x + 1 > n ? LEX_CHAIN_END : sp.x + 1 - w0;
+            const unsigned long long V = lex_chunk_chain(to, rel0);
+            const bool in = (V >> lane) & 1ull;
+            const int no = in ? sp.y : 0, ne = in ? sp.z : 0;
+            const int so = wv::incl_scan(no), se = wv::incl_scan(ne);
+            // the visited cell at which the triple buffer fills (bf_lex.h lex_chain_visit) runs with the room that is left and ends the document
+            const unsigned long long m_over = __ballot(in && eb + se > cap);
+            const int first = m_over ? __ffsll((long long)m_over) - 1 : 64;
+            if (in && lane <= first) {
+                const int base = ob + so - no;
+                const int64_t slot = ids_slot(b, ld.doc) + base;
+                IdOutDirect out{p.ids_tmp + slot, p.span_tmp + 2 * slot};
+                const LexStart r = lex_one_start<HAS_ANY>(L, cls_at, n, pos, out, frames, tab, p.words, lane == first ? cap - (eb + se - ne) : cap);
+                if (lane == first) p.counts[ld.doc] = base + r.n_out;
+            }
         }
     }
 }
 
-// One wave per listed document follows the chain (bf_lex.h lex_chain_visit), a window of 64 cells at a time: the cells' results sit
-// in the lanes' registers, the chain inside the window is followed on the scalar unit (v_readlane of the next position, no memory
-// access per hop -- a hop through LDS measured 380 cycles, the 8,396-byte line of config 1 took 474 us), the visited cells' output
-// bases are one wave scan over the window.  The results come in through LDS, 2048 cells per load (a register prefetch of the next window
-// only moved the wait: the hop loop's s_waitcnt covers every load in flight).
-constexpr int LEX_CHAIN_BLK = 2048, LEX_CHAIN_END = 0x40000000;
-__global__ __launch_bounds__(64) void k_lex_long_chain(WpLexParams p)
+// One workgroup per listed document goes from chunk to chunk along the chain: one hop per chunk through the results of k_lex_long<false>
+// (jump), staged in LDS 1024 cells per round by all four waves; the first wave hops.  (Following the chain cell by cell here, with
+// the chunk's results in registers and v_readlane hops, cost 78 cycles per visited cell: 131 us for the 8,396-byte line of config 1 and
+// 34 ms for a 1 MB document under sbd.bin, whose loop visits every position.)
+constexpr int LEX_CHAIN_BLK = 1024, LEX_CHAIN_THREADS = 256;
+__global__ __launch_bounds__(LEX_CHAIN_THREADS) void k_lex_long_chain(WpLexParams p)
 {
     __shared__ int4 blk[LEX_CHAIN_BLK];
+    __shared__ int s_next;                             // wave 0 -> the workgroup: the cell the chain goes on at (-1: the document is done)
     const unsigned long long hdr = *p.lg.hdr;
     int64_t nlist = (int64_t)(hdr >> 40);
     if (nlist > p.lg.cap_docs) nlist = p.lg.cap_docs;
-    const int lane = lane_id();
+    const int lane = lane_id(), wave = wave_in_block();
     for (int64_t j = blockIdx.x; j < nlist; j += gridDim.x) {
         const LexLongDoc ld = p.lg.list[j];
         if (ld.doc < 0) continue;
         const int n = __builtin_amdgcn_readfirstlane(p.nchars[ld.doc]);
-        const int64_t cell0 = ld.chunk0 * 64;
-        const int4 *spec = (const int4 *)p.lg.spec + cell0;
-        // cells 0 .. n (cell = position + 1); the document owns whole chunks, so a window never leaves its cells
-        const int end_cells = (n & ~63) + 64;
-        int w0 = 0, q = 0, ob = 0, eb = 0, blk0 = -1;
+        const int cap = n >> p.lg.cap_shift;
+        const int4 *jump = (const int4 *)p.lg.jump + ld.chunk0 * 64;
+        int4 *entry = (int4 *)p.lg.entry + ld.chunk0;
+        const int end_cells = (n & ~63) + 64;          // cells 0 .. n (cell = position + 1); the document owns whole chunks
+        int q = 0, ob = 0, eb = 0;
         for (;;) {
-            if (blk0 < 0 || w0 >= blk0 + LEX_CHAIN_BLK) {                           // the next block of windows: one exposed load latency per 2048 cells
-                blk0 = w0;
-                int cnt = end_cells - blk0; if (cnt > LEX_CHAIN_BLK) cnt = LEX_CHAIN_BLK;
-                wave_handoff();
-                for (int i0 = 0; i0 < cnt; i0 += 64 * 8) {                          // eight loads in flight per lane (cnt is a multiple of 64)
-                    int4 t[8];
+            const int blk0 = q & ~63;
+            int cnt = end_cells - blk0; if (cnt > LEX_CHAIN_BLK) cnt = LEX_CHAIN_BLK;
+            {
+                int4 t[LEX_CHAIN_BLK / LEX_CHAIN_THREADS];
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) { const int i = i0 + 64 * k; t[k] = i < cnt ? spec[blk0 + i + lane] : make_int4(0, 0, 0, 0); }
+                for (int k = 0; k < LEX_CHAIN_BLK / LEX_CHAIN_THREADS; ++k) { const int i = k * LEX_CHAIN_THREADS + (int)threadIdx.x; t[k] = i < cnt ? jump[blk0 + i] : make_int4(0, 0, 0, 0); }
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) { const int i = i0 + 64 * k; if (i < cnt) blk[i + lane] = t[k]; }
+                for (int k = 0; k < LEX_CHAIN_BLK / LEX_CHAIN_THREADS; ++k) { const int i = k * LEX_CHAIN_THREADS + (int)threadIdx.x; if (i < cnt) blk[i] = t[k]; }
+            }
+            __syncthreads();
+            if (wave == 0) {
+                int next = -1;
+                for (;;) {
+                    const int4 rec = blk[q - blk0];
+                    const int E = __builtin_amdgcn_readfirstlane(rec.x), so = __builtin_amdgcn_readfirstlane(rec.y), se = __builtin_amdgcn_readfirstlane(rec.z);
+                    if (lane == 0) entry[q >> 6] = make_int4(q & 63, ob, eb, 0);
+                    if (eb + se > cap) break;                                       // the triple buffer fills inside this chunk: k_lex_long<true> ends the document there
+                    ob += so; eb += se;
+                    if (E == LEX_CHAIN_END) { if (lane == 0) p.counts[ld.doc] = ob; break; }
+                    q = E;
+                    if (q >= blk0 + LEX_CHAIN_BLK) { next = q; break; }
                 }
-                wave_handoff();
+                if (lane == 0) s_next = next;
             }
-            const int4 cur = blk[w0 - blk0 + lane];
-            // the chain inside [w0, w0 + 64): scalar, five instructions per hop.  to = the next cell relative to the window; a chain that
-            // leaves the document (next position >= n) goes to LEX_CHAIN_END
-            const int to = cur.x + 1 > n ? LEX_CHAIN_END : cur.x + 1 - w0;
-            unsigned long long V = 0;
-            int rel = q - w0;
-            do { V |= 1ull << rel; rel = __builtin_amdgcn_readlane(to, rel); } while (rel < 64);
-            const int qq = rel == LEX_CHAIN_END ? n + 1 : w0 + rel;
-            const bool in = (V >> lane) & 1ull;
-            const int no = in ? cur.y : 0, ne = in ? cur.z : 0;
-            const int so = wv::incl_scan(no), se = wv::incl_scan(ne);
-            const bool over = in && eb + se > n;                                   // the triple buffer fills at this cell (or did at an earlier one)
-            const unsigned long long m_over = __ballot(over);
-            if (m_over) {
-                const int first = __ffsll((long long)m_over) - 1;
-                if (in && lane <= first) p.lg.vis[cell0 + w0 + lane] = ob + so - no;
-                if (lane == first) p.lg.spec[4 * (cell0 + w0 + lane) + 3] = n - (eb + se - ne) + 1;      // room + 1: k_lex_long<EMIT> ends the document there
-                break;
-            }
-            if (in) p.lg.vis[cell0 + w0 + lane] = ob + so - no;
-            ob += __builtin_amdgcn_readlane(so, 63); eb += __builtin_amdgcn_readlane(se, 63);
-            if (qq > n) { if (lane == 0) p.counts[ld.doc] = ob; break; }          // the chain left the document
-            q = qq; w0 = qq & ~63;
+            __syncthreads();
+            q = s_next;
+            __syncthreads();                           // (s_next and blk are rewritten by the next round)
+            if (q < 0) break;
         }
     }
 }
@@ -718,7 +821,7 @@ void launch_lex_long(const WpLexParams &p, hipStream_t s)
     const int64_t most = (p.lg.cap_chunks + 3) / 4;
     if (nb > most) nb = most;
     if (nb < 1) nb = 1;
-    int64_t nc = p.lg.cap_docs < (int64_t)device_cus() * 4 ? p.lg.cap_docs : (int64_t)device_cus() * 4;
+    int64_t nc = p.lg.cap_docs < (int64_t)device_cus() * 8 ? p.lg.cap_docs : (int64_t)device_cus() * 8;
     if (nc < 1) nc = 1;
     const dim3 g((unsigned)nb), t(LEX_LONG_THREADS);
 #define BF_LONG(EMIT) \
@@ -727,7 +830,7 @@ void launch_lex_long(const WpLexParams &p, hipStream_t s)
         else { if (tlds) hipLaunchKernelGGL((k_lex_long<false, true, EMIT>), g, t, lds, s, p); else hipLaunchKernelGGL((k_lex_long<false, false, EMIT>), g, t, lds, s, p); } \
     } while (0)
     BF_LONG(false);
-    hipLaunchKernelGGL(k_lex_long_chain, dim3((unsigned)nc), dim3(64), 0, s, p);
+    hipLaunchKernelGGL(k_lex_long_chain, dim3((unsigned)nc), dim3(LEX_CHAIN_THREADS), 0, s, p);
     BF_LONG(true);
 #undef BF_LONG
 }

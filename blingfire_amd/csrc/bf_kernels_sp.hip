@@ -1858,7 +1858,21 @@ __global__ __launch_bounds__(256) void k_i2t_copy(I2tParams p)
     }
 }
 
-// TextToWords output assembly (reference tokdll:502-565) for a batch: the same byte-gather scheme as k_i2t_*; a word's bytes
+// Documents of more than W2T_LONG_TOKENS tokens leave the wave-per-document copy kernels (one wave assembles 64 tokens at a time, one
+// block after the other: 2.2 us per block, 96 us for the 2,800 words of config 1's longest line, 10.6 ms for a 1 MB document of
+// sentences) for k_w2t_copy_long: sixteen waves per document, each round 1024 tokens.
+constexpr int W2T_LONG_TOKENS = 1024, W2T_LONG_WAVES = 16;
+__device__ __forceinline__ bool w2t_list_long(const W2tParams &p, int64_t d, int64_t ntok, int lane)
+{
+    if (!p.long_list || ntok <= W2T_LONG_TOKENS) return false;
+    if (lane == 0) {
+        const unsigned slot = atomicAdd(p.long_count, 1u);
+        if ((int64_t)slot < p.long_cap) p.long_list[slot] = d;
+    }
+    return true;
+}
+
+
 // come from the caller's text, every word but the first of its document is preceded by one ' '.
 __global__ __launch_bounds__(256) void k_w2t_len(W2tParams p)
 {
@@ -1884,6 +1898,7 @@ __global__ __launch_bounds__(256) void k_w2t_copy(W2tParams p)
         const int64_t b = p.word_off[d], e = p.word_off[d + 1];
         int64_t out = p.text_off[d];
         if (p.text_off[d + 1] <= out) continue;
+        if (w2t_list_long(p, d, e - b, lane)) continue;
         const uint8_t *src = p.text + p.doc_off[d];
         for (int64_t i0 = b; i0 < e; i0 += 64) {
             const int64_t i = i0 + lane;
@@ -1920,7 +1935,7 @@ __device__ __forceinline__ bool dev_is_ws(int c)      // blingfiretokdll.h:17-21
 // tokdll:138-150, on the valid UTF-8 the lexer accepted) and drops the sentence if nothing is left.  Every emitted sentence
 // but the first is preceded by '\n' (counted with it, like the separator of k_w2t_*).
 struct S2tTok { int len; int src; };
-__device__ __forceinline__ S2tTok s2t_sentence(const W2tParams &p, const uint8_t *src, int n, int bom, int64_t b, int64_t e, int64_t i, bool &any_before)
+__device__ __forceinline__ S2tTok s2t_sentence(const W2tParams &p, const uint8_t *src, int n, int bom, int64_t b, int64_t e, int64_t i, bool &any_before, unsigned long long *emit_mask = nullptr)
 {
     S2tTok t; t.len = 0; t.src = 0;
     bool emit = false;
@@ -1941,6 +1956,7 @@ __device__ __forceinline__ S2tTok s2t_sentence(const W2tParams &p, const uint8_t
         }
     }
     const unsigned long long me = __ballot(emit);
+    if (emit_mask) *emit_mask = me;
     const bool sep = emit && (any_before || (me & lanemask_lt()) != 0);
     if (sep) { t.len += 1; t.src -= 1; }                                // the '\n' in front of it
     else if (emit) t.src = -t.src - 2;                                  // marks "no separator" (decoded in the copy loop)
@@ -1980,6 +1996,7 @@ __global__ __launch_bounds__(256) void k_s2t_copy(W2tParams p)
         const int64_t b = p.word_off[d], e = p.word_off[d + 1];
         int64_t out = p.text_off[d];
         if (p.text_off[d + 1] <= out) continue;
+        if (w2t_list_long(p, d, e - b, lane)) continue;
         const int n = (int)(p.doc_off[d + 1] - p.doc_off[d]);
         const uint8_t *src = p.text + p.doc_off[d];
         const int bom = (n >= 3 && src[0] == 0xEF && src[1] == 0xBB && src[2] == 0xBF) ? 3 : 0;
@@ -2012,10 +2029,81 @@ void launch_s2t_len(const W2tParams &p, hipStream_t s)
     int64_t blocks = (p.ndocs + 3) / 4; if (blocks > device_cus() * 16) blocks = device_cus() * 16; if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(k_s2t_len, dim3((unsigned)blocks), dim3(256), 0, s, p);
 }
+template <bool SENT>
+__global__ __launch_bounds__(W2T_LONG_WAVES * 64) void k_w2t_copy_long(W2tParams p)
+{
+    __shared__ int s_pre[W2T_LONG_WAVES][65];
+    __shared__ int s_src[W2T_LONG_WAVES][64];
+    __shared__ int s_tot[W2T_LONG_WAVES], s_emit[W2T_LONG_WAVES];
+    const int lane = lane_id(), wv = wave_in_block();
+    int64_t nlist = (int64_t)*p.long_count; if (nlist > p.long_cap) nlist = p.long_cap;
+    for (int64_t j = blockIdx.x; j < nlist; j += gridDim.x) {
+        const int64_t d = p.long_list[j];
+        const int64_t b = p.word_off[d], e = p.word_off[d + 1];
+        int64_t out0 = p.text_off[d];
+        const int n = (int)(p.doc_off[d + 1] - p.doc_off[d]);
+        const uint8_t *src = p.text + p.doc_off[d];
+        const int bom = (SENT && n >= 3 && src[0] == 0xEF && src[1] == 0xBB && src[2] == 0xBF) ? 3 : 0;
+        bool doc_any_before = false;                                       // SENT: a sentence was emitted in an earlier round
+        const int64_t last = SENT ? e : e - 1;                             // SENT: index e is the rest of the document (tokdll:307-311)
+        for (int64_t r0 = b; r0 <= last; r0 += 64 * W2T_LONG_WAVES) {
+            const int64_t i0 = r0 + 64 * wv, i = i0 + lane;
+            int len = 0, sv = 0;
+            if constexpr (SENT) {
+                // every emitted sentence with its '\n' in front; the document's first one gives it back below
+                bool all_before = true; unsigned long long me = 0;
+                S2tTok t = s2t_sentence(p, src, n, bom, b, e, i, all_before, &me);
+                if (lane == 0) s_emit[wv] = me != 0;
+                __syncthreads();
+                int first_wave = -1;
+                for (int w = W2T_LONG_WAVES - 1; w >= 0; --w) if (s_emit[w]) first_wave = w;
+                if (!doc_any_before && wv == first_wave && lane == __ffsll((long long)me) - 1) { t.len -= 1; t.src = -(t.src + 1) - 2; }
+                doc_any_before = doc_any_before || first_wave >= 0;
+                len = t.len; sv = t.src;
+            } else if (i < e) { const int st = p.starts[i]; len = p.ends[i] - st + 1 + (i > b ? 1 : 0); sv = st - (i > b ? 1 : 0); }
+            const int inc = wave_incl_scan(len);
+            const int total = __shfl(inc, 63, 64);
+            s_pre[wv][lane] = inc - len; s_src[wv][lane] = sv;
+            if (lane == 63) s_pre[wv][64] = total;
+            if (lane == 0) s_tot[wv] = total;
+            __syncthreads();
+            int64_t out = out0; int round_total = 0;
+            for (int w = 0; w < W2T_LONG_WAVES; ++w) { if (w < wv) out += s_tot[w]; round_total += s_tot[w]; }
+            for (int q = lane; q < total; q += 64) {
+                int lo = 0, hi = 63;
+                while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (s_pre[wv][mid] <= q) lo = mid; else hi = mid - 1; }
+                const int k = q - s_pre[wv][lo];
+                const int v = s_src[wv][lo];
+                uint8_t c;
+                if constexpr (SENT) {
+                    if (v >= -1) { if (k == 0) c = '\n'; else { c = src[v + k]; if (c == '\n' || c == 0) c = ' '; } }     // tokdll:291-296
+                    else { c = src[(-v - 2) + k]; if (c == '\n' || c == 0) c = ' '; }
+                } else {
+                    if (k == 0 && i0 + lo > b) c = ' ';                                         // tokdll:529-531
+                    else { c = src[v + k]; if (c == ' ' || c == 0) c = '_'; }                   // tokdll:482,543
+                }
+                if (out + q < p.out_cap) p.out[out + q] = c;
+            }
+            out0 += round_total;
+            __syncthreads();                                               // the next round overwrites s_pre / s_src / s_tot / s_emit
+        }
+    }
+}
+
+template <bool SENT>
+static void launch_w2t_copy_long(const W2tParams &p, hipStream_t s)
+{
+    if (!p.long_list) return;
+    int64_t nb = p.long_cap < device_cus() ? p.long_cap : device_cus();       // (the number of listed documents is on the device)
+    if (nb < 1) nb = 1;
+    hipLaunchKernelGGL(k_w2t_copy_long<SENT>, dim3((unsigned)nb), dim3(W2T_LONG_WAVES * 64), 0, s, p);
+}
+
 void launch_s2t_copy(const W2tParams &p, hipStream_t s)
 {
     int64_t blocks = (p.ndocs + 3) / 4; if (blocks > device_cus() * 16) blocks = device_cus() * 16; if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(k_s2t_copy, dim3((unsigned)blocks), dim3(256), 0, s, p);
+    launch_w2t_copy_long<true>(p, s);
 }
 
 void launch_w2t_len(const W2tParams &p, hipStream_t s)
@@ -2027,6 +2115,7 @@ void launch_w2t_copy(const W2tParams &p, hipStream_t s)
 {
     int64_t blocks = (p.ndocs + 3) / 4; if (blocks > device_cus() * 16) blocks = device_cus() * 16; if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(k_w2t_copy, dim3((unsigned)blocks), dim3(256), 0, s, p);
+    launch_w2t_copy_long<false>(p, s);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -268,6 +268,11 @@ def _long_docs(seed):
     docs = sorted(lines, key=len)[-25:] + rnd.sample(lines, 200)
     docs += [b" ".join(rnd.sample(lines, 40)), b". ".join(rnd.sample(lines, 25)), b"x" * 700, b" " * 400, ("д" * 301 + " 好的。" * 50).encode()]
     docs += [b for b in bfutil.fuzz_docs(150, seed=seed) if len(b) > 40]
+    # more than 2048 bytes / 1024 tokens: the sixteen-wave forms of the decode and of the string assembly (k_prep_wp_long, k_w2t_copy_long) --
+    # multi-byte characters across the 512-byte pieces, a byte order mark, invalid and truncated UTF-8 (the document yields nothing)
+    mixed = ("д好x. Ünï çødé\u3000text! " * 900).encode()
+    docs += [mixed, b"\xef\xbb\xbf" + mixed[:30011], b"abc d. " * 700 + b"\xff" + b"def g. " * 700, mixed[:8191], mixed[1:9000], b"a b. " * 5000,
+             (b"One sentence here. " * 40 + b"\n\n") * 60, b" \n" * 3000 + b"end."]
     return docs
 
 
@@ -330,6 +335,21 @@ def test_gpu_long_documents(model, mode):
             out, t_off = fn(docs, h)
             for d, b in enumerate(docs):
                 assert out[t_off[d]:t_off[d + 1]].tobytes() == want[d], (model, mode, hex(v), d, len(b), b[:60])
+        if h is not None:
+            # the position at which the reference's triple buffer fills (FALexTools_t.h:337-340; n triples in these modes, which no text
+            # reaches): with the test knob 0x20000000 the buffer holds n / 8, and the long-document path ends every document where the
+            # lane kernel does
+            res = []
+            for v in (0x20000000 | 0x40000000, 0x20000000 | (1 << 12), 0x20000000):
+                assert bf.lib().BfSetVariant(ctypes.c_void_p(h), v) >= 0
+                res.append(fn(docs, h))
+            cut = 0
+            for d, b in enumerate(docs):
+                a = res[0][0][res[0][1][d]:res[0][1][d + 1]].tobytes()
+                cut += a != want[d]
+                for k in (1, 2):
+                    assert res[k][0][res[k][1][d]:res[k][1][d + 1]].tobytes() == a, (model, mode, k, d, len(b), b[:60])
+            assert mode == 2 or cut > len(docs) // 4
     finally:
         if h:
             bf.free_model(h)
