@@ -359,11 +359,11 @@ bool use_bpe_wave(const Handle *h, bool want_off) { return h->m.bpe_wave_ok && !
 constexpr int LONG_THRESH_MIN = 16;
 constexpr int64_t LONG_BYTES_PER_THRESH = 24000, LONG_BYTES_PER_THRESH_BIG_TABLE = 4000;
 constexpr size_t LONG_TABLE_IN_LDS_ENTRIES = 5000;              // (bf_kernels.hip: LEX_TLDS_MAX_BYTES less the frames and the action pool, in 8-byte entries)
-constexpr int64_t LONG_MAX_CHUNKS = (int64_t)2 << 20;           // 128 M cells: 4 GB of workspace
-struct LongCaps { int thresh; int64_t docs, chunks; size_t list_off, spec_off, jump_off, entry_off, bytes; };
+constexpr int64_t LONG_MAX_CHUNKS = (int64_t)2 << 20;           // 128 M cells: 5 GB of workspace
+struct LongCaps { int thresh; int64_t docs, chunks; size_t list_off, spec_off, jump_off, tok2_off, entry_off, bytes; };
 LongCaps long_caps(const Handle *h, int64_t ndocs, int64_t total_bytes, int words)
 {
-    LongCaps c{0, 0, 0, 0, 0, 0, 0, 0};
+    LongCaps c{0, 0, 0, 0, 0, 0, 0, 0, 0};
     if (!words || h->m.kind != KIND_WP || h->m.max_depth < 1 || h->m.lexer_void || (h->variant & 0x40000000) || ndocs <= 0) return c;
     const int k = (h->variant >> 12) & 0xf;
     const size_t table_n = h->m.wbd_t2.size() > (size_t)LX_T_CLS_MASK + 1 ? h->m.wbd_t2.size() - ((size_t)LX_T_CLS_MASK + 1) : 0;
@@ -374,7 +374,8 @@ LongCaps long_caps(const Handle *h, int64_t ndocs, int64_t total_bytes, int word
     c.list_off = 0;
     c.spec_off = ((size_t)c.docs * sizeof(LexLongDoc) + 255) & ~(size_t)255;
     c.jump_off = c.spec_off + (size_t)c.chunks * 64 * 16;
-    c.entry_off = c.jump_off + (size_t)c.chunks * 64 * 16;
+    c.tok2_off = c.jump_off + (size_t)c.chunks * 64 * 16;
+    c.entry_off = c.tok2_off + (size_t)c.chunks * 64 * 8;
     c.bytes = c.entry_off + (size_t)c.chunks * 16;
     return c;
 }
@@ -544,7 +545,7 @@ int run_device(Handle *h, const char *d_text, const int64_t *d_doc_off, int64_t 
         const LongCaps lc = long_caps(h, ndocs, total_bytes, words);
         lp.lg = LexLongParams{lc.thresh, (words && (h->variant & 0x20000000)) ? 3 : 0, lc.docs, lc.chunks, (unsigned long long *)(h->w_misc.as<char>() + 40) /* zeroed with the status word above */,
                               (LexLongDoc *)(h->w_long.as<char>() + lc.list_off), (int32_t *)(h->w_long.as<char>() + lc.spec_off), (int32_t *)(h->w_long.as<char>() + lc.jump_off),
-                              (int32_t *)(h->w_long.as<char>() + lc.entry_off)};
+                              (int32_t *)(h->w_long.as<char>() + lc.tok2_off), (int32_t *)(h->w_long.as<char>() + lc.entry_off)};
         (void)hipEventRecord(h->ev[EV_DOM0], s);
         if (ndocs > 0) {
             launch_lex_long_list(lp, s);
@@ -1831,7 +1832,7 @@ int BfReserve(void *p, int64_t max_docs, int64_t max_bytes, int want_offsets)
     // the lane-per-document kernels, which TextToWords / TextToSentences, lexers outside the unit form and BfSetVariant(2) run -- no hipMalloc
     // (= device synchronisation) inside a later call of either kind
     if (!reserve_ids_workspaces(h, max_docs, max_bytes, want_offsets != 0)) return BF_E_DEVICE;
-    // (not the long-document workspace of the words modes, w_long: 32 bytes per cell, allocated by the first words call that is that large)
+    // (not the long-document workspace of the words modes, w_long: 40 bytes per cell, allocated by the first words call that is that large)
     if (h->m.kind == KIND_WP && !reserve_ids_workspaces(h, max_docs, max_bytes, true, 1, false)) return BF_E_DEVICE;
     return 0;
 }

@@ -40,8 +40,11 @@ struct LexLongParams {
     int64_t cap_docs, cap_chunks;     // capacity of `list` / of the cell arrays in chunks
     unsigned long long *hdr;          // documents listed << 40 | chunks handed out (zeroed per launch)
     LexLongDoc *list;
-    int32_t *spec;                    // [4 * cell]: next position, tokens output, triples produced, -
-    int32_t *jump;                    // [4 * cell]: first cell of the document beyond this chunk on the chain from here (LEX_CHAIN_END: none), tokens / triples summed up to there, -
+    int32_t *spec;                    // [4 * cell]: next position, tokens output, triples produced, tag of the first token
+    int32_t *jump;                    // [4 * cell]: first cell of the document beyond this chunk on the chain from here (LEX_CHAIN_END: none), tokens / triples summed up to there,
+                                      // the span of the position's first token when it writes one or two (0x80000000 | first - position << 16 | last - position; else 0):
+                                      // those are written without a second walk
+    int32_t *tok2;                    // [2 * cell]: tag and span of the second token of a position that writes two (the span of the first in `jump` is 0 unless both pack)
     int32_t *entry;                   // [4 * chunk]: cell of the chunk the chain enters at (-1: it does not), tokens output / triples produced before it, -
 };
 constexpr int LEX_CHAIN_END = 0x40000000, LEX_COUNT_SAT = 0x3fffffff;

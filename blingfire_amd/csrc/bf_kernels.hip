@@ -697,10 +697,17 @@ __global__ __launch_bounds__(LEX_LONG_THREADS) void k_lex_long(WpLexParams p)
         ClsWin cls_at; cls_at.init(p.cls, b);
         if constexpr (!EMIT) {
             LexStart r; r.next = n; r.n_out = 0; r.n_emit = 0;
+            int one = 0;                                                   // the span of the position's first token when it writes one or two and they pack (else 0)
             if (act) {
-                IdOutNull out;
+                IdOutFirst out;
                 r = lex_one_start<HAS_ANY>(L, cls_at, n, pos, out, frames, tab, p.words, cap);
-                ((int4 *)p.lg.spec)[cell] = make_int4(r.next, r.n_out, r.n_emit, 0);
+                if (r.n_out == 1) one = out.packed0(pos);
+                else if (r.n_out == 2) {
+                    const int two = out.packed1(pos);
+                    one = two ? out.packed0(pos) : 0;
+                    ((int2 *)p.lg.tok2)[cell] = make_int2(out.tag1, two);
+                }
+                ((int4 *)p.lg.spec)[cell] = make_int4(r.next, r.n_out, r.n_emit, out.tag0);
             }
             // from every cell: the first cell beyond the chunk and the counts on the way, by pointer doubling over the lanes (a chain
             // makes at most 63 hops inside a chunk).  J >= 0: the chain from here is at lane J after 2^k hops; J < 0: it has left, to E
@@ -718,7 +725,7 @@ __global__ __launch_bounds__(LEX_LONG_THREADS) void k_lex_long(WpLexParams p)
                     if (Jj < 0) { E = Ej; J = -1; } else J = Jj;
                 }
             }
-            ((int4 *)p.lg.jump)[cell] = make_int4(E, so, se, 0);
+            ((int4 *)p.lg.jump)[cell] = make_int4(E, so, se, one);
             if (lane == 0) ((int4 *)p.lg.entry)[c] = make_int4(-1, 0, 0, 0);
         } else {
             const int4 ent = ((const int4 *)p.lg.entry)[c];
@@ -735,9 +742,19 @@ __global__ __launch_bounds__(LEX_LONG_THREADS) void k_lex_long(WpLexParams p)
             // the visited cell at which the triple buffer fills (bf_lex.h lex_chain_visit) runs with the room that is left and ends the document
             const unsigned long long m_over = __ballot(in && eb + se > cap);
             const int first = m_over ? __ffsll((long long)m_over) - 1 : 64;
-            if (in && lane <= first) {
+            // (a visited cell without a token has nothing to write: under sbd.bin the loop visits every position and one in a hundred ends a sentence)
+            if (in && lane <= first && (no > 0 || lane == first)) {
                 const int base = ob + so - no;
                 const int64_t slot = ids_slot(b, ld.doc) + base;
+                const int one = (no <= 2 && lane != first) ? p.lg.jump[4 * cell + 3] : 0;
+                if (one < 0) {                                                 // the one or two tokens of this position are on record: no second walk
+                    p.ids_tmp[slot] = sp.w; p.span_tmp[2 * slot] = pos + ((one >> 16) & 0x7fff); p.span_tmp[2 * slot + 1] = pos + (one & 0xffff);
+                    if (no == 2) {
+                        const int2 t2 = ((const int2 *)p.lg.tok2)[cell];
+                        p.ids_tmp[slot + 1] = t2.x; p.span_tmp[2 * slot + 2] = pos + ((t2.y >> 16) & 0x7fff); p.span_tmp[2 * slot + 3] = pos + (t2.y & 0xffff);
+                    }
+                    continue;
+                }
                 IdOutDirect out{p.ids_tmp + slot, p.span_tmp + 2 * slot};
                 const LexStart r = lex_one_start<HAS_ANY>(L, cls_at, n, pos, out, frames, tab, p.words, lane == first ? cap - (eb + se - ne) : cap);
                 if (lane == first) p.counts[ld.doc] = base + r.n_out;
@@ -816,8 +833,12 @@ void launch_lex_long(const WpLexParams &p, hipStream_t s)
     const bool has_any = p.L.cls_any != LX_CLS_NONE;
     const bool tlds = p.table_n > 0 && lex_long_lds_bytes(p, true) <= LEX_TLDS_MAX_BYTES;
     const size_t lds = lex_long_lds_bytes(p, tlds);
-    // the number of chunks is on the device: a grid that fills the chip, workgroups without a chunk leave at once
-    int64_t nb = (int64_t)device_cus() * 4;
+    // the number of chunks is on the device: a grid that fills the chip (the resident workgroups: LDS -- frames and the table -- bounds them),
+    // workgroups without a chunk leave at once
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_lex_long<false, false, false>, LEX_LONG_THREADS, lds) != hipSuccess || per_cu <= 0) per_cu = 4;
+    (void)hipGetLastError();
+    int64_t nb = (int64_t)device_cus() * per_cu;
     const int64_t most = (p.lg.cap_chunks + 3) / 4;
     if (nb > most) nb = most;
     if (nb < 1) nb = 1;

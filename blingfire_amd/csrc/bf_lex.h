@@ -473,6 +473,23 @@ struct IdOutNull {
     BF_HD void finish(int) {}
 };
 
+// keeps the first two tokens a start position writes: most positions write one (a few two), and the pass that writes the output then
+// needs no second walk for them
+struct IdOutFirst {
+    int32_t tag0 = 0, tag1 = 0; int from0 = 0, to0 = 0, from1 = 0, to1 = 0;       // (scalars: a two-element array went to scratch on the device)
+    BF_HD void put(int k, int32_t v) { tag0 = k == 0 ? v : tag0; tag1 = k == 1 ? v : tag1; }
+    BF_HD void span(int k, int f, int t) { from0 = k == 0 ? f : from0; to0 = k == 0 ? t : to0; from1 = k == 1 ? f : from1; to1 = k == 1 ? t : to1; }
+    BF_HD void finish(int) {}
+    // a span relative to position p as one word (0x80000000 | first - p << 16 | last - p), 0 when it does not pack
+    static BF_HD int pack(int from, int to, int p)
+    {
+        const int df = from - p, dt = to - p;
+        return (df >= 0 && df < 0x8000 && dt >= 0 && dt < 0x10000) ? (int)(0x80000000u | ((unsigned)df << 16) | (unsigned)dt) : 0;
+    }
+    BF_HD int packed0(int p) const { return pack(from0, to0, p); }
+    BF_HD int packed1(int p) const { return pack(from1, to1, p); }
+};
+
 struct LexStart { int next, n_out, n_emit; };       // of one start position: the next one, tokens output, triples produced
 
 template <bool HAS_ANY, class ClsAt, class IdOut, class Frames, class Tab>

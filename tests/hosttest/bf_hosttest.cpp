@@ -698,6 +698,35 @@ int bft_emu_lex_tokens(void *hv, const char *s, int n, int mode, int long_form, 
     return w;
 }
 
+// what every start position of a document does on its own (bf_lex.h lex_one_start): out[4 * (p + 1) ..] = next position, tokens output,
+// triples produced, first - p << 16 | last - p of the first token (tools: the shape of a lexer's chain); returns the number of characters
+int bft_emu_lex_starts(void *hv, const char *s, int n, int mode, int32_t *out, int max_pos)
+{
+    Model &m = ((Handle *)hv)->m;
+    if (!m.error.empty() || m.kind != KIND_WP || n <= 0 || !s) return -1;
+    std::vector<int> cps((size_t)n);
+    const int len = bfo_utf8_to_utf32(s, n, cps.data(), n);
+    if (len <= 0) return -1;
+    std::vector<uint16_t> cls;
+    for (int i = 0; i < len; ++i) cls.push_back((uint16_t)m.words_cpmap.get(cps[(size_t)i]));
+    LexTables L;
+    L.T = m.wbd_t2.data(); L.acts = m.acts_pool.data(); L.initial = m.wbd.initial_base; L.initial_l = m.initial_l; L.cls_any = m.cls_any; L.cls_l = m.cls_l; L.cls_r = m.cls_r;
+    L.max_depth = m.max_depth; L.max_token_length = m.max_token_length; L.max_frames = m.lex_frames;
+    L.loop_state = m.loop_base; L.loop_info = m.loop_info; L.loop_final = m.loop_final ? 1 : 0; L.two_level = 0; L.fn_no_ra = m.fn_no_ra ? 1 : 0;
+    cls.push_back((uint16_t)CLS_NONE);
+    HostCls cls_at{cls.data(), len + 1};
+    FramesArray frames;
+    TabDirect tab{L.T};
+    const bool any = L.cls_any != LX_CLS_NONE;
+    for (int p = -1; p < len && p + 1 < max_pos; ++p) {
+        IdOutFirst o;
+        const LexStart r = any ? lex_one_start<true>(L, cls_at, len, p, o, frames, tab, mode, len) : lex_one_start<false>(L, cls_at, len, p, o, frames, tab, mode, len);
+        int32_t *q = out + 4 * (size_t)(p + 1);
+        q[0] = r.next; q[1] = r.n_out; q[2] = r.n_emit; q[3] = r.n_out > 0 ? (int32_t)(((unsigned)(o.from0 - p) << 16) | (unsigned)((o.to0 - p) & 0xffff)) : 0;
+    }
+    return len;
+}
+
 // offsets form: the lane programs report stream positions, the source-offset stream maps them to bytes and the end
 // offset adds the UTF-8 size of the last character (tokdll:1263-1273,1519-1529) -- what k_compact does on the GPU
 int bft_emu_text_to_ids_with_offsets(void *hv, const char *s, int n, int32_t *ids, int32_t *starts, int32_t *ends, int max_ids, int unk)
