@@ -114,8 +114,9 @@ def device_doc_hashes(torch, ids, id_off, ndocs):
 
 def run_config1(args):
     """BASELINE.json configs[0]: the default pattern tokenizer (TextToWords, built-in wbd.bin) on short English lines.  The config names
-    the reference's CPU path; the GPU batch entry point (TextToWordsBatchDevice: lexer with the table in LDS + string assembly) is timed
-    beside it.  One GPU only (10,000 lines are one launch)."""
+    the reference's CPU path; the GPU batch entry point (TextToWordsBatchDevice: class stream, lexer -- lanes for the short lines, the
+    long-document form of DESIGN.md section 5.3 for the others -- scan, string assembly) is timed beside it.  One GPU only (10,000 lines are
+    one launch of each kernel)."""
     import ctypes
     import numpy as np
     import torch
@@ -178,10 +179,10 @@ def run_config1(args):
            "data": "the reference's own lines (tests/data/config1_lines.txt.gz)" if os.path.exists(bfutil.CONFIG1_LINES) else "synthetic",
            "config": {"workload": "config1: built-in wbd.bin TextToWords (TextToWordsBatchDevice), %d lines, %.1f B/line" % (nl, len(text) / nl), "model_file": "wbd.bin (built in)",
                       "total_docs": nl, "total_bytes": int(len(text)), "output_bytes": out_bytes,
-                      "longest_line_bytes": int((off[1:] - off[:-1]).max()),       # (one lane walks a line: the longest one is the step's time)
+                      "longest_line_bytes": int((off[1:] - off[:-1]).max()),       # (until round 5 one lane walked it: the step's time)
                       "lines_over_1KiB": int(((off[1:] - off[:-1]) > 1024).sum())},
            "gb_input_per_sec": len(text) * args.steps / elapsed / 1e9, "gpu_ms_per_step": gpu_ms,
-           "roofline": {"bound": "hbm", "kernel": "whole step (lexer with the table in LDS + scan + string assembly)", "achieved": alg / (gpu_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+           "roofline": {"bound": "hbm", "kernel": "whole step (class stream + lexer: lanes and the long-document form + scan + string assembly; latency of 20 small launches, not bandwidth)", "achieved": alg / (gpu_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                         "frac": alg / (gpu_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "traffic": None, "algorithmic_bytes_per_launch": alg},
            "verified_docs": verified}
     if not args.no_cpu_baseline and ck_kind == "reference":

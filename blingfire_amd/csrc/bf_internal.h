@@ -14,7 +14,10 @@ BF_API int BfLexStats(void *ModelPtr, unsigned long long *out, int n);
  * >= 1 MiB, else the wave program, bf_wave.h); 4 = the flat program for every batch; 5 = never; 2 = the lane-per-document WordPiece kernels
  * (bf_lex.h) also for unit-form lexers; bit 0x40 = BPE without its wave program.  The higher bits carry tuning values (bf_kernels.hip
  * launch_wp_wave / launch_wp_flat / launch_lex_wp, bf_kernels_sp.hip launch_seg_sp); the ones that select a measurement instance need a build
- * with BF_EXPERIMENTS, else BF_E_UNSUPPORTED (-5) comes back and the setting stays.  Returns the previous value. */
+ * with BF_EXPERIMENTS, else BF_E_UNSUPPORTED (-5) comes back and the setting stays.  The words modes (TextToWords / TextToSentences): bit
+ * 0x40000000 = no long-document path (every document walks on one lane), bits 12..15 = k > 0: documents of more than 8 << k characters take it
+ * (default: total_bytes / 24,000, or / 4,000 for a lexer whose table does not fit LDS, at least 16), bit 0x20000000 = a test knob: the triple
+ * buffer holds n / 8 triples instead of n (FALexTools_t.h:337-340), so that tests reach the position at which it fills.  Returns the previous value. */
 BF_API int BfSetVariant(void *ModelPtr, int variant);
 /* switches the instrumented kernel instances on / off for this handle and clears the counters; returns the previous setting */
 BF_API int BfSetLexStats(void *ModelPtr, int on);

@@ -38,7 +38,7 @@ struct LexLongParams {
     int thresh;                       // 0: off
     int cap_shift;                    // test knob (BfSetVariant 0x20000000): the triple buffer holds n >> cap_shift triples instead of n (lane kernel too)
     int64_t cap_docs, cap_chunks;     // capacity of `list` / of the cell arrays in chunks
-    unsigned long long *hdr;          // documents listed << 40 | chunks handed out (zeroed per launch)
+    unsigned long long *hdr;          // documents listed << 32 | chunks handed out (zeroed per launch)
     LexLongDoc *list;
     int32_t *spec;                    // [4 * cell]: next position, tokens output, triples produced, tag of the first token
     int32_t *jump;                    // [4 * cell]: first cell of the document beyond this chunk on the chain from here (LEX_CHAIN_END: none), tokens / triples summed up to there,
@@ -48,7 +48,7 @@ struct LexLongParams {
     int32_t *entry;                   // [4 * chunk]: cell of the chunk the chain enters at (-1: it does not), tokens output / triples produced before it, -
 };
 constexpr int LEX_CHAIN_END = 0x40000000, LEX_COUNT_SAT = 0x3fffffff;
-constexpr unsigned long long LEX_LONG_CHUNK_MASK = (1ull << 40) - 1;
+constexpr unsigned long long LEX_LONG_CHUNK_MASK = (1ull << 32) - 1;
 
 struct WpLexParams {
     LexTables L;

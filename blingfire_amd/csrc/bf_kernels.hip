@@ -631,8 +631,8 @@ __global__ __launch_bounds__(256) void k_lex_long_list(WpLexParams p)
         const int n = p.nchars[doc];
         if (n <= p.lg.thresh) continue;
         const unsigned long long nch = ((unsigned long long)n + 1 + 63) >> 6;              // positions -1 .. n-1
-        const unsigned long long old = atomicAdd(p.lg.hdr, (1ull << 40) | nch);
-        const int64_t slot = (int64_t)(old >> 40), c0 = (int64_t)(old & LEX_LONG_CHUNK_MASK);
+        const unsigned long long old = atomicAdd(p.lg.hdr, (1ull << 32) | nch);
+        const int64_t slot = (int64_t)(old >> 32), c0 = (int64_t)(old & LEX_LONG_CHUNK_MASK);
         const bool fits = slot < p.lg.cap_docs && c0 + (int64_t)nch <= p.lg.cap_chunks;
         if (slot < p.lg.cap_docs) p.lg.list[slot] = LexLongDoc{fits ? doc : -1, c0};
         p.counts[doc] = fits ? -1 : 0;               // -1: the lane kernel leaves the document to the long path
@@ -663,7 +663,7 @@ __global__ __launch_bounds__(LEX_LONG_THREADS) void k_lex_long(WpLexParams p)
     constexpr int THREADS = LEX_LONG_THREADS, WAVES = THREADS / 64;
     typedef typename std::conditional<TLDS, TabLds, TabDirect>::type TAB;
     const unsigned long long hdr = *p.lg.hdr;
-    int64_t nlist = (int64_t)(hdr >> 40), nchunks = (int64_t)(hdr & LEX_LONG_CHUNK_MASK);
+    int64_t nlist = (int64_t)(hdr >> 32), nchunks = (int64_t)(hdr & LEX_LONG_CHUNK_MASK);
     if (nlist > p.lg.cap_docs) nlist = p.lg.cap_docs;
     if (nchunks > p.lg.cap_chunks) nchunks = p.lg.cap_chunks;
     if ((int64_t)blockIdx.x * WAVES >= nchunks) return;                   // no chunk for this workgroup: before anything is staged
@@ -764,16 +764,16 @@ __global__ __launch_bounds__(LEX_LONG_THREADS) void k_lex_long(WpLexParams p)
 }
 
 // One workgroup per listed document goes from chunk to chunk along the chain: one hop per chunk through the results of k_lex_long<false>
-// (jump), staged in LDS 1024 cells per round by all four waves; the first wave hops.  (Following the chain cell by cell here, with
+// (jump), staged in LDS 2048 cells per round by all four waves -- the next round's loads in flight while the first wave hops through this one's.  (Following the chain cell by cell here, with
 // the chunk's results in registers and v_readlane hops, cost 78 cycles per visited cell: 131 us for the 8,396-byte line of config 1 and
 // 34 ms for a 1 MB document under sbd.bin, whose loop visits every position.)
-constexpr int LEX_CHAIN_BLK = 1024, LEX_CHAIN_THREADS = 256;
+constexpr int LEX_CHAIN_BLK = 2048, LEX_CHAIN_THREADS = 256, LEX_CHAIN_PER = LEX_CHAIN_BLK / LEX_CHAIN_THREADS;
 __global__ __launch_bounds__(LEX_CHAIN_THREADS) void k_lex_long_chain(WpLexParams p)
 {
     __shared__ int4 blk[LEX_CHAIN_BLK];
     __shared__ int s_next;                             // wave 0 -> the workgroup: the cell the chain goes on at (-1: the document is done)
     const unsigned long long hdr = *p.lg.hdr;
-    int64_t nlist = (int64_t)(hdr >> 40);
+    int64_t nlist = (int64_t)(hdr >> 32);
     if (nlist > p.lg.cap_docs) nlist = p.lg.cap_docs;
     const int lane = lane_id(), wave = wave_in_block();
     for (int64_t j = blockIdx.x; j < nlist; j += gridDim.x) {
@@ -784,18 +784,22 @@ __global__ __launch_bounds__(LEX_CHAIN_THREADS) void k_lex_long_chain(WpLexParam
         const int4 *jump = (const int4 *)p.lg.jump + ld.chunk0 * 64;
         int4 *entry = (int4 *)p.lg.entry + ld.chunk0;
         const int end_cells = (n & ~63) + 64;          // cells 0 .. n (cell = position + 1); the document owns whole chunks
-        int q = 0, ob = 0, eb = 0;
+        int q = 0, ob = 0, eb = 0, blk0 = 0;
+        int4 t[LEX_CHAIN_PER];
+        auto load = [&](int from) {
+#pragma unroll
+            for (int k = 0; k < LEX_CHAIN_PER; ++k) { const int i = from + k * LEX_CHAIN_THREADS + (int)threadIdx.x; t[k] = i < end_cells ? jump[i] : make_int4(0, 0, 0, 0); }
+        };
+        auto store = [&]() {
+#pragma unroll
+            for (int k = 0; k < LEX_CHAIN_PER; ++k) blk[k * LEX_CHAIN_THREADS + (int)threadIdx.x] = t[k];
+        };
+        load(0); store();
+        __syncthreads();
         for (;;) {
-            const int blk0 = q & ~63;
-            int cnt = end_cells - blk0; if (cnt > LEX_CHAIN_BLK) cnt = LEX_CHAIN_BLK;
-            {
-                int4 t[LEX_CHAIN_BLK / LEX_CHAIN_THREADS];
-#pragma unroll
-                for (int k = 0; k < LEX_CHAIN_BLK / LEX_CHAIN_THREADS; ++k) { const int i = k * LEX_CHAIN_THREADS + (int)threadIdx.x; t[k] = i < cnt ? jump[blk0 + i] : make_int4(0, 0, 0, 0); }
-#pragma unroll
-                for (int k = 0; k < LEX_CHAIN_BLK / LEX_CHAIN_THREADS; ++k) { const int i = k * LEX_CHAIN_THREADS + (int)threadIdx.x; if (i < cnt) blk[i] = t[k]; }
-            }
-            __syncthreads();
+            // the next round's cells are on their way while the first wave hops through this round's (the chain seldom jumps over a round)
+            const bool more = blk0 + LEX_CHAIN_BLK < end_cells;
+            if (more) load(blk0 + LEX_CHAIN_BLK);
             if (wave == 0) {
                 int next = -1;
                 for (;;) {
@@ -810,11 +814,15 @@ __global__ __launch_bounds__(LEX_CHAIN_THREADS) void k_lex_long_chain(WpLexParam
                 }
                 if (lane == 0) s_next = next;
             }
-            __syncthreads();
+            __syncthreads();                           // the first wave is done with blk
             q = s_next;
-            __syncthreads();                           // (s_next and blk are rewritten by the next round)
             if (q < 0) break;
+            if (q >= blk0 + 2 * LEX_CHAIN_BLK) { blk0 = q & ~63; load(blk0); }      // (a jump over the whole next round)
+            else blk0 += LEX_CHAIN_BLK;
+            store();
+            __syncthreads();
         }
+        __syncthreads();                               // (s_next and blk are rewritten by the next document)
     }
 }
 
