@@ -350,7 +350,8 @@ bool use_bpe_wave(const Handle *h, bool want_off) { return h->m.bpe_wave_ok && !
 // 4.9 ms), the chip as a whole 75 ps per character (1 M lines: 3.25 ms), so a document of more than total_bytes / 24,000 characters
 // would hold the batch up (measured on MI355X, profiles/r06_words_*: 10,000 lines 4.6 -> 0.55 ms at 16, 1 M lines 3.25 ms at 128 and
 // 10.2 ms at 16).  BfSetVariant: bit 0x40000000 = off (every document on one lane), bits 12..15 = k > 0: thresh = 8 << k, bit 0x20000000 = a test
-// knob: the triple buffer of the words modes holds n / 8 triples instead of n (so that tests reach the position at which it fills).
+// knob: the triple buffer of the words modes holds n / 8 triples instead of n (so that tests reach the position at which it fills), bit 0x10000000 =
+// another: the workspace has room for 40 chunks only (so that tests reach the documents that do not fit and stay on lanes).
 // The capacities are bounds that hold for any batch of these sizes (a listed document has more than thresh bytes and owns
 // (n + 1 + 63) / 64 chunks) unless that is more than LONG_MAX_CHUNKS: then the documents that do not fit stay on lanes.
 // A lexer whose table does not fit LDS (sbd.bin) and whose loop visits every position walks far slower per character on a lane but
@@ -370,7 +371,7 @@ LongCaps long_caps(const Handle *h, int64_t ndocs, int64_t total_bytes, int word
     const int64_t per = table_n > 0 && table_n <= LONG_TABLE_IN_LDS_ENTRIES ? LONG_BYTES_PER_THRESH : LONG_BYTES_PER_THRESH_BIG_TABLE;
     c.thresh = k ? (8 << k) : (int)std::min<int64_t>(std::max<int64_t>(LONG_THRESH_MIN, total_bytes / per), 1 << 30);
     c.docs = std::min<int64_t>(ndocs, total_bytes / ((int64_t)c.thresh + 1)) + 1;
-    c.chunks = std::min<int64_t>(total_bytes / 64 + 2 * c.docs + 1, LONG_MAX_CHUNKS);
+    c.chunks = std::min<int64_t>(total_bytes / 64 + 2 * c.docs + 1, (h->variant & 0x10000000) ? 40 : LONG_MAX_CHUNKS);      // (0x10000000: a test knob -- room for 40 chunks only)
     c.list_off = 0;
     c.spec_off = ((size_t)c.docs * sizeof(LexLongDoc) + 255) & ~(size_t)255;
     c.jump_off = c.spec_off + (size_t)c.chunks * 64 * 16;
@@ -549,7 +550,7 @@ int run_device(Handle *h, const char *d_text, const int64_t *d_doc_off, int64_t 
         (void)hipEventRecord(h->ev[EV_DOM0], s);
         if (ndocs > 0) {
             launch_lex_long_list(lp, s);
-            launch_lex_wp(lp, words ? (h->variant & ~0x6000F000) : h->variant, s);
+            launch_lex_wp(lp, words ? (h->variant & ~0x7000F000) : h->variant, s);
             launch_lex_long(lp, s);
         }
         (void)hipEventRecord(h->ev[EV_DOM1], s);

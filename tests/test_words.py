@@ -328,7 +328,8 @@ def test_gpu_long_documents(model, mode):
         for b in docs:
             r, o, _, _ = _call(f, (ctypes.c_void_p(ho),), b, 4 * len(b) + 8)
             want.append(o[:r - 1] if r > 0 else b"")
-        variants = [0] if h is None else [0, 1 << 12, 0x40000000]
+        # (0x10000000: a workspace of 40 chunks -- most of the long documents do not fit and stay with the lane kernel)
+        variants = [0] if h is None else [0, 1 << 12, 0x40000000, 0x10000000 | (1 << 12), 0x10000000 | (3 << 12)]
         for v in variants:
             if h is not None:
                 assert bf.lib().BfSetVariant(ctypes.c_void_p(h), v) >= 0
