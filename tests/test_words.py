@@ -329,6 +329,14 @@ def test_gpu_long_documents(model, mode):
             r, o, _, _ = _call(f, (ctypes.c_void_p(ho),), b, 4 * len(b) + 8)
             want.append(o[:r - 1] if r > 0 else b"")
         # (0x10000000: a workspace of 40 chunks -- most of the long documents do not fit and stay with the lane kernel)
+        # the single-document calls (reference signatures, byte offsets of every token) on long documents: the same kernels behind run_host
+        L = bf.lib()
+        g1 = L.TextToWordsWithOffsetsWithModel if mode == 1 else L.TextToSentencesWithOffsetsWithModel
+        g1.restype = ctypes.c_int
+        g1.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+        for b in [docs[0], docs[24], big[:50000], docs[-12]]:
+            mx = 4 * len(b) + 8
+            assert _call(g1, (), b, mx, (ctypes.c_void_p(h) if h else None,)) == _call(f, (ctypes.c_void_p(ho),), b, mx), (model, mode, len(b), b[:60])
         variants = [0] if h is None else [0, 1 << 12, 0x40000000, 0x10000000 | (1 << 12), 0x10000000 | (3 << 12)]
         for v in variants:
             if h is not None:
