@@ -357,14 +357,14 @@ bool use_bpe_wave(const Handle *h, bool want_off) { return h->m.bpe_wave_ok && !
 // A lexer whose table does not fit LDS (sbd.bin) and whose loop visits every position walks far slower per character on a lane but
 // also spends more on every start position here: the same bytes as 100-byte documents took 2.0 ms on lanes and 3.4 ms here, as
 // 1000-byte documents 8 ms either way, as one 1 MB document 1 s and 30 ms -> total_bytes / 4,000 for those.
-constexpr int LONG_THRESH_MIN = 16;
+constexpr int LONG_THRESH_MIN = 16, LONG_BIG_CELLS = 1 << 19;
 constexpr int64_t LONG_BYTES_PER_THRESH = 24000, LONG_BYTES_PER_THRESH_BIG_TABLE = 4000;
 constexpr size_t LONG_TABLE_IN_LDS_ENTRIES = 5000;              // (bf_kernels.hip: LEX_TLDS_MAX_BYTES less the frames and the action pool, in 8-byte entries)
 constexpr int64_t LONG_MAX_CHUNKS = (int64_t)2 << 20;           // 128 M cells: 5 GB of workspace
-struct LongCaps { int thresh; int64_t docs, chunks; size_t list_off, spec_off, jump_off, tok2_off, entry_off, bytes; };
+struct LongCaps { int thresh; int64_t docs, chunks; size_t list_off, spec_off, jump_off, tok2_off, entry_off, jump2_off, entry2_off, bytes; int big_cells; };
 LongCaps long_caps(const Handle *h, int64_t ndocs, int64_t total_bytes, int words)
 {
-    LongCaps c{0, 0, 0, 0, 0, 0, 0, 0, 0};
+    LongCaps c{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     if (!words || h->m.kind != KIND_WP || h->m.max_depth < 1 || h->m.lexer_void || (h->variant & 0x40000000) || ndocs <= 0) return c;
     const int k = (h->variant >> 12) & 0xf;
     const size_t table_n = h->m.wbd_t2.size() > (size_t)LX_T_CLS_MASK + 1 ? h->m.wbd_t2.size() - ((size_t)LX_T_CLS_MASK + 1) : 0;
@@ -377,7 +377,13 @@ LongCaps long_caps(const Handle *h, int64_t ndocs, int64_t total_bytes, int word
     c.jump_off = c.spec_off + (size_t)c.chunks * 64 * 16;
     c.tok2_off = c.jump_off + (size_t)c.chunks * 64 * 16;
     c.entry_off = c.tok2_off + (size_t)c.chunks * 64 * 8;
-    c.bytes = c.entry_off + (size_t)c.chunks * 16;
+    // documents of more than LONG_BIG_CELLS cells take the chain in two levels (bf_kernels.hip k_lex_long_jump2 / _chain2 / _chain3): 16 more bytes
+    // per cell, reserved only for batches that can hold such a document.  BfSetVariant 0x08000000: a test knob -- from 256 cells on
+    c.big_cells = (h->variant & 0x08000000) ? 256 : LONG_BIG_CELLS;
+    const bool big = total_bytes + 1 > c.big_cells;
+    c.jump2_off = c.entry_off + (size_t)c.chunks * 16;
+    c.entry2_off = c.jump2_off + (big ? (size_t)c.chunks * 64 * 16 : 0);
+    c.bytes = c.entry2_off + (big ? (size_t)c.chunks * 16 : 0);
     return c;
 }
 
@@ -546,11 +552,12 @@ int run_device(Handle *h, const char *d_text, const int64_t *d_doc_off, int64_t 
         const LongCaps lc = long_caps(h, ndocs, total_bytes, words);
         lp.lg = LexLongParams{lc.thresh, (words && (h->variant & 0x20000000)) ? 3 : 0, lc.docs, lc.chunks, (unsigned long long *)(h->w_misc.as<char>() + 40) /* zeroed with the status word above */,
                               (LexLongDoc *)(h->w_long.as<char>() + lc.list_off), (int32_t *)(h->w_long.as<char>() + lc.spec_off), (int32_t *)(h->w_long.as<char>() + lc.jump_off),
-                              (int32_t *)(h->w_long.as<char>() + lc.tok2_off), (int32_t *)(h->w_long.as<char>() + lc.entry_off)};
+                              (int32_t *)(h->w_long.as<char>() + lc.tok2_off), lc.big_cells, (int32_t *)(h->w_long.as<char>() + lc.jump2_off),
+                              (int32_t *)(h->w_long.as<char>() + lc.entry2_off), (int32_t *)(h->w_long.as<char>() + lc.entry_off)};
         (void)hipEventRecord(h->ev[EV_DOM0], s);
         if (ndocs > 0) {
             launch_lex_long_list(lp, s);
-            launch_lex_wp(lp, words ? (h->variant & ~0x7000F000) : h->variant, s);
+            launch_lex_wp(lp, words ? (h->variant & ~0x7800F000) : h->variant, s);
             launch_lex_long(lp, s);
         }
         (void)hipEventRecord(h->ev[EV_DOM1], s);
@@ -977,16 +984,19 @@ int run_words_device(Handle *h, const char *d_text, const int64_t *d_doc_off, in
     const int nblocks = scan_nblocks(ndocs);
     W2tParams p{(const uint8_t *)d_text, d_doc_off, ndocs, h->w_idoff.as<int64_t>(), h->w_starts.as<int32_t>(), h->w_ends.as<int32_t>(),
                 h->w_counts.as<int32_t>(), d_out_off, (uint8_t *)d_out, out_cap, mode == 2 ? h->w_nchars.as<int32_t>() : nullptr};
+    // documents of many tokens are measured and assembled by sixteen waves each (k_w2t_len_long / k_w2t_copy_long); w_misc + 56 / + 52: their number
+    // (+ 56 zeroed with the status word by run_device above, + 52 below)
+    p.long_cap = total_bytes / 1024 + 2;
+    p.long_list = h->w_w2tlong.reserve((size_t)p.long_cap * 8) ? h->w_w2tlong.as<int64_t>() : nullptr;
+    p.long_count = (unsigned int *)(h->w_misc.as<char>() + 56);
     if (tokenise) {
         if (ndocs > 0) { if (mode == 2) launch_s2t_len(p, s); else launch_w2t_len(p, s); }
         ScanParams sp{h->w_counts.as<int32_t>(), ndocs, d_out_off, h->w_bsums.as<int64_t>(), nblocks};
         launch_scan(sp, s);
     }
     if (d_out && ndocs > 0) {
-        // documents of many tokens are assembled by sixteen waves each (k_w2t_copy_long); w_misc + 52: their number
-        p.long_cap = total_bytes / 1024 + 2;
         p.long_count = (unsigned int *)(h->w_misc.as<char>() + 52);
-        p.long_list = (h->w_w2tlong.reserve((size_t)p.long_cap * 8) && hip_ok(hipMemsetAsync(p.long_count, 0, 4, s), "hipMemsetAsync")) ? h->w_w2tlong.as<int64_t>() : nullptr;
+        if (!p.long_list || !hip_ok(hipMemsetAsync(p.long_count, 0, 4, s), "hipMemsetAsync")) p.long_list = nullptr;
         if (mode == 2) launch_s2t_copy(p, s); else launch_w2t_copy(p, s);
     }
     return hip_ok(hipGetLastError(), "TextToWords kernels") ? 0 : BF_E_DEVICE;

@@ -18,7 +18,8 @@ BF_API int BfLexStats(void *ModelPtr, unsigned long long *out, int n);
  * 0x40000000 = no long-document path (every document walks on one lane), bits 12..15 = k > 0: documents of more than 8 << k characters take it
  * (default: total_bytes / 24,000, or / 4,000 for a lexer whose table does not fit LDS, at least 16), bit 0x20000000 = a test knob: the triple
  * buffer holds n / 8 triples instead of n (FALexTools_t.h:337-340), so that tests reach the position at which it fills, bit 0x10000000 = another: room for 40 chunks of long documents only (the ones
- * that do not fit stay on lanes).  Returns the previous value. */
+ * that do not fit stay on lanes), bit 0x08000000 = a third: the two-level chain of very long documents from 256 characters on instead of 512 K.
+ * Returns the previous value. */
 BF_API int BfSetVariant(void *ModelPtr, int variant);
 /* switches the instrumented kernel instances on / off for this handle and clears the counters; returns the previous setting */
 BF_API int BfSetLexStats(void *ModelPtr, int on);

@@ -45,6 +45,12 @@ struct LexLongParams {
                                       // the span of the position's first token when it writes one or two (0x80000000 | first - position << 16 | last - position; else 0):
                                       // those are written without a second walk
     int32_t *tok2;                    // [2 * cell]: tag and span of the second token of a position that writes two (the span of the first in `jump` is 0 unless both pack)
+    // documents of more than `big_cells` cells (0: none) take the chain in two levels: jump2 = the same as jump for the document's
+    // 64-chunk super-chunks (k_lex_long_jump2), entry2[first chunk of a super-chunk] = the CELL OF THE DOCUMENT the chain enters it at
+    // (-1: it does not), tokens / triples before it (k_lex_long_chain2); k_lex_long_chain3 fills `entry` per super-chunk
+    int big_cells;
+    int32_t *jump2;                   // [4 * cell]
+    int32_t *entry2;                  // [4 * chunk] (used at the first chunk of every super-chunk)
     int32_t *entry;                   // [4 * chunk]: cell of the chunk the chain enters at (-1: it does not), tokens output / triples produced before it, -
 };
 constexpr int LEX_CHAIN_END = 0x40000000, LEX_COUNT_SAT = 0x3fffffff;

@@ -780,6 +780,7 @@ __global__ __launch_bounds__(LEX_CHAIN_THREADS) void k_lex_long_chain(WpLexParam
         const LexLongDoc ld = p.lg.list[j];
         if (ld.doc < 0) continue;
         const int n = __builtin_amdgcn_readfirstlane(p.nchars[ld.doc]);
+        if (p.lg.big_cells > 0 && n + 1 > p.lg.big_cells) continue;      // (the two-level kernels below)
         const int cap = n >> p.lg.cap_shift;
         const int4 *jump = (const int4 *)p.lg.jump + ld.chunk0 * 64;
         int4 *entry = (int4 *)p.lg.entry + ld.chunk0;
@@ -826,6 +827,108 @@ __global__ __launch_bounds__(LEX_CHAIN_THREADS) void k_lex_long_chain(WpLexParam
     }
 }
 
+// ---- the chain of a very long document in two levels.  One hop per chunk is 16 k dependent hops for a 1 MB document (2.3 ms at 140 ns);
+//      the hops of different super-chunks (64 chunks) do not depend on each other once every cell knows where the chain from it leaves its
+//      super-chunk, and that is the same walk from every cell at once.
+constexpr int LEX_SUPER_SHIFT = 12;             // cells per super-chunk: 4096
+
+// every cell of a big document: follow the chunk-level jumps to the first cell beyond the cell's super-chunk, summing the counts
+__global__ __launch_bounds__(256) void k_lex_long_jump2(WpLexParams p)
+{
+    const unsigned long long hdr = *p.lg.hdr;
+    int64_t nlist = (int64_t)(hdr >> 32), nchunks = (int64_t)(hdr & LEX_LONG_CHUNK_MASK);
+    if (nlist > p.lg.cap_docs) nlist = p.lg.cap_docs;
+    if (nchunks > p.lg.cap_chunks) nchunks = p.lg.cap_chunks;
+    const int lane = lane_id();
+    for (int64_t c = (int64_t)blockIdx.x * 4 + wave_in_block(); c < nchunks; c += (int64_t)gridDim.x * 4) {
+        int64_t lo = 0, hi = nlist;
+        while (hi - lo > 1) { const int64_t mid = (lo + hi) >> 1; if (p.lg.list[mid].chunk0 <= c) lo = mid; else hi = mid; }
+        const LexLongDoc ld = p.lg.list[lo];
+        if (ld.doc < 0) continue;
+        const int n = p.nchars[ld.doc];
+        if (n + 1 <= p.lg.big_cells) continue;
+        const int4 *jump = (const int4 *)p.lg.jump + ld.chunk0 * 64;
+        const int rel_chunk = (int)(c - ld.chunk0);
+        const int q = rel_chunk * 64 + lane;
+        const int sc_end = ((q >> LEX_SUPER_SHIFT) + 1) << LEX_SUPER_SHIFT;
+        int4 r = jump[q];
+        int E = r.x, so = r.y, se = r.z;
+        while (E != LEX_CHAIN_END && E < sc_end) {
+            r = jump[E];
+            so = so + r.y < LEX_COUNT_SAT ? so + r.y : LEX_COUNT_SAT; se = se + r.z < LEX_COUNT_SAT ? se + r.z : LEX_COUNT_SAT;
+            E = r.x;
+        }
+        ((int4 *)p.lg.jump2)[c * 64 + lane] = make_int4(E, so, se, 0);
+        if (lane == 0 && (rel_chunk & 63) == 0) ((int4 *)p.lg.entry2)[c] = make_int4(-1, 0, 0, 0);
+    }
+}
+
+// one wave per big document: from super-chunk to super-chunk
+__global__ __launch_bounds__(64) void k_lex_long_chain2(WpLexParams p)
+{
+    const unsigned long long hdr = *p.lg.hdr;
+    int64_t nlist = (int64_t)(hdr >> 32);
+    if (nlist > p.lg.cap_docs) nlist = p.lg.cap_docs;
+    const int lane = lane_id();
+    for (int64_t j = blockIdx.x; j < nlist; j += gridDim.x) {
+        const LexLongDoc ld = p.lg.list[j];
+        if (ld.doc < 0) continue;
+        const int n = __builtin_amdgcn_readfirstlane(p.nchars[ld.doc]);
+        if (n + 1 <= p.lg.big_cells) continue;
+        const int cap = n >> p.lg.cap_shift;
+        const int4 *jump2 = (const int4 *)p.lg.jump2 + ld.chunk0 * 64;
+        int4 *entry2 = (int4 *)p.lg.entry2 + ld.chunk0;
+        int q = 0, ob = 0, eb = 0;
+        for (;;) {
+            const int4 rec = jump2[q];
+            const int E = __builtin_amdgcn_readfirstlane(rec.x), so = __builtin_amdgcn_readfirstlane(rec.y), se = __builtin_amdgcn_readfirstlane(rec.z);
+            if (lane == 0) entry2[(q >> LEX_SUPER_SHIFT) << (LEX_SUPER_SHIFT - 6)] = make_int4(q, ob, eb, 0);
+            if (eb + se > cap) break;                   // the triple buffer fills inside this super-chunk: k_lex_long_chain3 stops at the chunk
+            ob += so; eb += se;
+            if (E == LEX_CHAIN_END) break;              // (k_lex_long_chain3 arrives there itself and writes the document's count)
+            q = E;
+        }
+    }
+}
+
+// one wave per entered super-chunk of a big document: from chunk to chunk inside it (what k_lex_long_chain does for a whole document)
+__global__ __launch_bounds__(256) void k_lex_long_chain3(WpLexParams p)
+{
+    const unsigned long long hdr = *p.lg.hdr;
+    int64_t nlist = (int64_t)(hdr >> 32), nchunks = (int64_t)(hdr & LEX_LONG_CHUNK_MASK);
+    if (nlist > p.lg.cap_docs) nlist = p.lg.cap_docs;
+    if (nchunks > p.lg.cap_chunks) nchunks = p.lg.cap_chunks;
+    const int lane = lane_id();
+    const int64_t nsuper = (nchunks + 63) >> 6;          // (an upper bound of the super-chunks: a document's are spaced 64 chunks from ITS first chunk)
+    for (int64_t c = (int64_t)blockIdx.x * 4 + wave_in_block(); c < nchunks; c += (int64_t)gridDim.x * 4) {
+        (void)nsuper;
+        int64_t lo = 0, hi = nlist;
+        while (hi - lo > 1) { const int64_t mid = (lo + hi) >> 1; if (p.lg.list[mid].chunk0 <= c) lo = mid; else hi = mid; }
+        const LexLongDoc ld = p.lg.list[lo];
+        if (ld.doc < 0 || ((c - ld.chunk0) & 63) != 0) continue;
+        const int n = __builtin_amdgcn_readfirstlane(p.nchars[ld.doc]);
+        if (n + 1 <= p.lg.big_cells) continue;
+        const int4 ent = ((const int4 *)p.lg.entry2)[c];
+        int q = __builtin_amdgcn_readfirstlane(ent.x);
+        if (q < 0) continue;                              // the chain does not come through this super-chunk
+        int ob = __builtin_amdgcn_readfirstlane(ent.y), eb = __builtin_amdgcn_readfirstlane(ent.z);
+        const int cap = n >> p.lg.cap_shift;
+        const int4 *jump = (const int4 *)p.lg.jump + ld.chunk0 * 64;
+        int4 *entry = (int4 *)p.lg.entry + ld.chunk0;
+        const int sc_end = ((q >> LEX_SUPER_SHIFT) + 1) << LEX_SUPER_SHIFT;
+        for (;;) {
+            const int4 rec = jump[q];
+            const int E = __builtin_amdgcn_readfirstlane(rec.x), so = __builtin_amdgcn_readfirstlane(rec.y), se = __builtin_amdgcn_readfirstlane(rec.z);
+            if (lane == 0) entry[q >> 6] = make_int4(q & 63, ob, eb, 0);
+            if (eb + se > cap) break;                     // the triple buffer fills inside this chunk: k_lex_long<true> ends the document there
+            ob += so; eb += se;
+            if (E == LEX_CHAIN_END) { if (lane == 0) p.counts[ld.doc] = ob; break; }
+            q = E;
+            if (q >= sc_end) break;
+        }
+    }
+}
+
 void launch_lex_long_list(const WpLexParams &p, hipStream_t s)
 {
     if (p.lg.thresh <= 0 || p.b.ndocs <= 0) return;
@@ -859,7 +962,17 @@ void launch_lex_long(const WpLexParams &p, hipStream_t s)
         else { if (tlds) hipLaunchKernelGGL((k_lex_long<false, true, EMIT>), g, t, lds, s, p); else hipLaunchKernelGGL((k_lex_long<false, false, EMIT>), g, t, lds, s, p); } \
     } while (0)
     BF_LONG(false);
+    // (a document of more than big_cells cells has more bytes than that: batches that cannot hold one skip the three launches)
+    const bool big = p.lg.big_cells > 0 && p.b.total_bytes + 1 > p.lg.big_cells;
+    int64_t nb2 = (p.lg.cap_chunks + 3) / 4;
+    if (nb2 > (int64_t)device_cus() * 8) nb2 = (int64_t)device_cus() * 8;
+    if (nb2 < 1) nb2 = 1;
+    if (big) hipLaunchKernelGGL(k_lex_long_jump2, dim3((unsigned)nb2), dim3(256), 0, s, p);
     hipLaunchKernelGGL(k_lex_long_chain, dim3((unsigned)nc), dim3(LEX_CHAIN_THREADS), 0, s, p);
+    if (big) {
+        hipLaunchKernelGGL(k_lex_long_chain2, dim3((unsigned)(nc < 256 ? nc : 256)), dim3(64), 0, s, p);
+        hipLaunchKernelGGL(k_lex_long_chain3, dim3((unsigned)nb2), dim3(256), 0, s, p);
+    }
     BF_LONG(true);
 #undef BF_LONG
 }

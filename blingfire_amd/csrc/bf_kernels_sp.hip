@@ -1880,6 +1880,7 @@ __global__ __launch_bounds__(256) void k_w2t_len(W2tParams p)
     const int64_t wave0 = (int64_t)blockIdx.x * 4 + wave_in_block(), nwaves = (int64_t)gridDim.x * 4;
     for (int64_t d = wave0; d < p.ndocs; d += nwaves) {
         const int64_t b = p.word_off[d], e = p.word_off[d + 1];
+        if (w2t_list_long(p, d, e - b, lane)) continue;
         long long total = 0;
         for (int64_t i = b + lane; i < e; i += 64) total += (long long)(p.ends[i] - p.starts[i] + 1) + (i > b ? 1 : 0);
 #pragma unroll
@@ -1971,6 +1972,7 @@ __global__ __launch_bounds__(256) void k_s2t_len(W2tParams p)
     for (int64_t d = wave0; d < p.ndocs; d += nwaves) {
         const int64_t b = p.word_off[d], e = p.word_off[d + 1];
         const int64_t n64 = p.doc_off[d + 1] - p.doc_off[d];
+        if (n64 > 0 && n64 <= 1000000000 && w2t_list_long(p, d, e - b, lane)) continue;
         const uint8_t *src = p.text + p.doc_off[d];
         long long total = 0;
         if (n64 > 0 && n64 <= 1000000000) {
@@ -2024,10 +2026,59 @@ __global__ __launch_bounds__(256) void k_s2t_copy(W2tParams p)
     }
 }
 
+// the output length of a listed document, sixteen waves: the sum does not depend on the order (a sentence's '\n' is counted with every emitted
+// one and taken back once for the document's first)
+template <bool SENT>
+__global__ __launch_bounds__(W2T_LONG_WAVES * 64) void k_w2t_len_long(W2tParams p)
+{
+    __shared__ long long s_sum[W2T_LONG_WAVES];
+    __shared__ int s_any[W2T_LONG_WAVES];
+    const int lane = lane_id(), wv = wave_in_block();
+    int64_t nlist = (int64_t)*p.long_count; if (nlist > p.long_cap) nlist = p.long_cap;
+    for (int64_t j = blockIdx.x; j < nlist; j += gridDim.x) {
+        const int64_t d = p.long_list[j];
+        const int64_t b = p.word_off[d], e = p.word_off[d + 1];
+        const int n = (int)(p.doc_off[d + 1] - p.doc_off[d]);
+        const uint8_t *src = p.text + p.doc_off[d];
+        const int bom = (SENT && n >= 3 && src[0] == 0xEF && src[1] == 0xBB && src[2] == 0xBF) ? 3 : 0;
+        const int64_t last = SENT ? e : e - 1;
+        long long total = 0; bool any = false;
+        for (int64_t i0 = b + 64 * wv; i0 <= last; i0 += 64 * W2T_LONG_WAVES) {
+            const int64_t i = i0 + lane;
+            if constexpr (SENT) {
+                bool all_before = true; unsigned long long me = 0;
+                const S2tTok t = s2t_sentence(p, src, n, bom, b, e, i, all_before, &me);
+                total += t.len; any = any || me != 0;
+            } else if (i < e) total += (long long)(p.ends[i] - p.starts[i] + 1) + (i > b ? 1 : 0);
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) total += __shfl_xor(total, o, 64);
+        if (lane == 0) { s_sum[wv] = total; s_any[wv] = any ? 1 : 0; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            long long t = 0; int a = 0;
+            for (int w = 0; w < W2T_LONG_WAVES; ++w) { t += s_sum[w]; a |= s_any[w]; }
+            if (SENT && a) t -= 1;
+            p.lens[d] = (t > 0x7ffffff0ll || (SENT && p.nvalid && p.nvalid[d] <= 0)) ? 0 : (int32_t)t;
+        }
+        __syncthreads();
+    }
+}
+
+template <bool SENT>
+static void launch_w2t_len_long(const W2tParams &p, hipStream_t s)
+{
+    if (!p.long_list) return;
+    int64_t nb = p.long_cap < device_cus() ? p.long_cap : device_cus();
+    if (nb < 1) nb = 1;
+    hipLaunchKernelGGL(k_w2t_len_long<SENT>, dim3((unsigned)nb), dim3(W2T_LONG_WAVES * 64), 0, s, p);
+}
+
 void launch_s2t_len(const W2tParams &p, hipStream_t s)
 {
     int64_t blocks = (p.ndocs + 3) / 4; if (blocks > device_cus() * 16) blocks = device_cus() * 16; if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(k_s2t_len, dim3((unsigned)blocks), dim3(256), 0, s, p);
+    launch_w2t_len_long<true>(p, s);
 }
 template <bool SENT>
 __global__ __launch_bounds__(W2T_LONG_WAVES * 64) void k_w2t_copy_long(W2tParams p)
@@ -2110,6 +2161,7 @@ void launch_w2t_len(const W2tParams &p, hipStream_t s)
 {
     int64_t blocks = (p.ndocs + 3) / 4; if (blocks > device_cus() * 16) blocks = device_cus() * 16; if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(k_w2t_len, dim3((unsigned)blocks), dim3(256), 0, s, p);
+    launch_w2t_len_long<false>(p, s);
 }
 void launch_w2t_copy(const W2tParams &p, hipStream_t s)
 {

@@ -337,7 +337,8 @@ def test_gpu_long_documents(model, mode):
         for b in [docs[0], docs[24], big[:50000], docs[-12]]:
             mx = 4 * len(b) + 8
             assert _call(g1, (), b, mx, (ctypes.c_void_p(h) if h else None,)) == _call(f, (ctypes.c_void_p(ho),), b, mx), (model, mode, len(b), b[:60])
-        variants = [0] if h is None else [0, 1 << 12, 0x40000000, 0x10000000 | (1 << 12), 0x10000000 | (3 << 12)]
+        # (0x08000000: the two-level chain of very long documents from 256 cells on instead of 512 K)
+        variants = [0] if h is None else [0, 1 << 12, 0x40000000, 0x10000000 | (1 << 12), 0x10000000 | (3 << 12), 0x08000000, 0x08000000 | (1 << 12)]
         for v in variants:
             if h is not None:
                 assert bf.lib().BfSetVariant(ctypes.c_void_p(h), v) >= 0
@@ -349,14 +350,14 @@ def test_gpu_long_documents(model, mode):
             # reaches): with the test knob 0x20000000 the buffer holds n / 8, and the long-document path ends every document where the
             # lane kernel does
             res = []
-            for v in (0x20000000 | 0x40000000, 0x20000000 | (1 << 12), 0x20000000):
+            for v in (0x20000000 | 0x40000000, 0x20000000 | (1 << 12), 0x20000000, 0x28000000 | (1 << 12)):
                 assert bf.lib().BfSetVariant(ctypes.c_void_p(h), v) >= 0
                 res.append(fn(docs, h))
             cut = 0
             for d, b in enumerate(docs):
                 a = res[0][0][res[0][1][d]:res[0][1][d + 1]].tobytes()
                 cut += a != want[d]
-                for k in (1, 2):
+                for k in (1, 2, 3):
                     assert res[k][0][res[k][1][d]:res[k][1][d + 1]].tobytes() == a, (model, mode, k, d, len(b), b[:60])
             assert mode == 2 or cut > len(docs) // 4
     finally:
