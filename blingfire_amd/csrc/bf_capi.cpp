@@ -360,7 +360,7 @@ bool use_bpe_wave(const Handle *h, bool want_off) { return h->m.bpe_wave_ok && !
 constexpr int LONG_THRESH_MIN = 16, LONG_BIG_CELLS = 1 << 19;
 constexpr int64_t LONG_BYTES_PER_THRESH = 24000, LONG_BYTES_PER_THRESH_BIG_TABLE = 4000;
 constexpr size_t LONG_TABLE_IN_LDS_ENTRIES = 5000;              // (bf_kernels.hip: LEX_TLDS_MAX_BYTES less the frames and the action pool, in 8-byte entries)
-constexpr int64_t LONG_MAX_CHUNKS = (int64_t)2 << 20;           // 128 M cells: 5 GB of workspace
+constexpr int64_t LONG_MAX_CHUNKS = (int64_t)2 << 20;           // 128 M cells: 5 .. 7 GB of workspace
 struct LongCaps { int thresh; int64_t docs, chunks; size_t list_off, spec_off, jump_off, tok2_off, entry_off, jump2_off, entry2_off, bytes; int big_cells; };
 LongCaps long_caps(const Handle *h, int64_t ndocs, int64_t total_bytes, int words)
 {
@@ -1843,7 +1843,7 @@ int BfReserve(void *p, int64_t max_docs, int64_t max_bytes, int want_offsets)
     // the lane-per-document kernels, which TextToWords / TextToSentences, lexers outside the unit form and BfSetVariant(2) run -- no hipMalloc
     // (= device synchronisation) inside a later call of either kind
     if (!reserve_ids_workspaces(h, max_docs, max_bytes, want_offsets != 0)) return BF_E_DEVICE;
-    // (not the long-document workspace of the words modes, w_long: 40 bytes per cell, allocated by the first words call that is that large)
+    // (not the long-document workspace of the words modes, w_long: 40 .. 56 bytes per cell, allocated by the first words call that is that large)
     if (h->m.kind == KIND_WP && !reserve_ids_workspaces(h, max_docs, max_bytes, true, 1, false)) return BF_E_DEVICE;
     return 0;
 }

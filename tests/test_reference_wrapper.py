@@ -66,8 +66,12 @@ def test_text_to_ids_through_the_reference_wrapper(wrappers, model, unk):
             for max_len, no_padding in ((128, False), (128, True), (5, False)):
                 assert np.array_equal(prod.text_to_ids(hp, t, max_len, unk, no_padding), ref.text_to_ids(hr, t, max_len, unk, no_padding))
             a, b = prod.utf8text_to_ids_with_offsets(hp, t.encode("utf-8"), 64, unk), ref.utf8text_to_ids_with_offsets(hr, t.encode("utf-8"), 64, unk)
-            for x, y in zip(a, b):
-                assert np.array_equal(x, y)
+            assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+            # documented deviation: for a token made of the dummy prefix alone the reference adds the UTF-8 size of the byte
+            # BEFORE the caller's string to -1 (tokdll:1527) -- here the last byte of the bytes object's header, its cached hash: -1 when it is
+            # 0xFF (not hashed yet), 0 .. 2 otherwise; the product reports -1
+            lone = (a[1] == -1) & (a[2] == -1)
+            assert np.array_equal(a[2][~lone], b[2][~lone]) and (b[2][lone] <= 2).all()
             assert prod.text_to_words_with_model(None, t) == ref.text_to_words_with_model(None, t)
     finally:
         prod.free_model(hp)
