@@ -659,6 +659,14 @@ def main():
             pcie = {"error": str(e)}
         b_in, b_out = int(total_bytes) + 8 * (n_api + 1), 4 * int(n_ids) + 8 * (n_api + 1)
         api_t = min(api)
+        # the call has two speeds that follow the process, not the build: how much of this process sits on huge pages is recorded beside it
+        host_memory = None
+        try:
+            roll = {l.split(":")[0]: int(l.split()[1]) for l in open("/proc/self/smaps_rollup").read().splitlines() if l.startswith(("Rss:", "AnonHugePages:"))}
+            host_memory = {"rss_kB": roll.get("Rss"), "anon_huge_pages_kB": roll.get("AnonHugePages"),
+                           "transparent_hugepage": open("/sys/kernel/mm/transparent_hugepage/enabled").read().strip()}
+        except Exception:
+            pass
         link = None
         if pcie and "h2d_GBps" in pcie:
             serial = b_in / (pcie["h2d_GBps"] * 1e9) + b_out / (pcie["d2h_GBps"] * 1e9)
@@ -673,7 +681,7 @@ def main():
                                   "what": "pinned host text -> H2D -> kernels -> D2H ids+offsets, one batch, best of 3"},
             "host_api_wall": {"docs_per_s": n_api / min(api), "ms": min(api) * 1e3, "median_ms": float(np.median(api)) * 1e3, "sample_docs": n_api,
                               "what": "wall clock of TextToIdsBatch on pageable host arrays (chunked through pinned staging, bf_capi.cpp run_host_chunked), output arrays reused, best of 3",
-                              "link": link},
+                              "link": link, "host_memory": host_memory},
             "pcie": pcie,
         }
         # work-rate roofline of the lexer: table gathers per second against the measured gather ceiling.

@@ -21,3 +21,8 @@ for it in range(4):
     dt = time.perf_counter() - t
     if it: best = max(best, n / dt / 1e6)
 print("cpus %s: TextToIdsBatch, %d documents: best of 3 %.1f M docs/s (%d ids)" % (os.sched_getaffinity(0) and ("%d..%d (%d)" % (min(os.sched_getaffinity(0)), max(os.sched_getaffinity(0)), len(os.sched_getaffinity(0)))), n, best, r), flush=True)
+try:
+    roll = open("/proc/self/smaps_rollup").read()
+    print("   " + " ".join(l.strip() for l in roll.splitlines() if l.startswith(("Rss", "AnonHugePages"))), "| THP:", open("/sys/kernel/mm/transparent_hugepage/enabled").read().strip(), flush=True)
+except Exception as e:
+    print("   (no smaps_rollup: %s)" % e)
