@@ -354,12 +354,13 @@ bool use_bpe_wave(const Handle *h, bool want_off) { return h->m.bpe_wave_ok && !
 // another: the workspace has room for 40 chunks only (so that tests reach the documents that do not fit and stay on lanes).
 // The capacities are bounds that hold for any batch of these sizes (a listed document has more than thresh bytes and owns
 // (n + 1 + 63) / 64 chunks) unless that is more than LONG_MAX_CHUNKS: then the documents that do not fit stay on lanes.
-// A lexer whose table does not fit LDS (sbd.bin) and whose loop visits every position walks far slower per character on a lane but
-// also spends more on every start position here: the same bytes as 100-byte documents took 2.0 ms on lanes and 3.4 ms here, as
-// 1000-byte documents 8 ms either way, as one 1 MB document 1 s and 30 ms -> total_bytes / 4,000 for those.
+// The same rule holds for a lexer whose table does not fit LDS (sbd.bin, 1 MB as 100-byte documents: 0.35 ms here, 1.23 ms on lanes; 16 MB as
+// 100-byte documents: 3.6 ms here, 2.7 ms on lanes -- the rule sends the first batch here and keeps the second on lanes).  (A first
+// measurement said otherwise because of ONE start position: the reference's test file has lines with a run of a hundred spaces, the
+// action of sbd.bin's rule at such a line calls a function that starts again at every space -- 6,440 sequential steps, 4 ms on one lane
+// whatever runs it; profiles/r06_words_sentences_*.)
 constexpr int LONG_THRESH_MIN = 16, LONG_BIG_CELLS = 1 << 19;
-constexpr int64_t LONG_BYTES_PER_THRESH = 24000, LONG_BYTES_PER_THRESH_BIG_TABLE = 4000;
-constexpr size_t LONG_TABLE_IN_LDS_ENTRIES = 5000;              // (bf_kernels.hip: LEX_TLDS_MAX_BYTES less the frames and the action pool, in 8-byte entries)
+constexpr int64_t LONG_BYTES_PER_THRESH = 24000;
 constexpr int64_t LONG_MAX_CHUNKS = (int64_t)2 << 20;           // 128 M cells: 5 .. 7 GB of workspace
 struct LongCaps { int thresh; int64_t docs, chunks; size_t list_off, spec_off, jump_off, tok2_off, entry_off, jump2_off, entry2_off, bytes; int big_cells; };
 LongCaps long_caps(const Handle *h, int64_t ndocs, int64_t total_bytes, int words)
@@ -367,9 +368,7 @@ LongCaps long_caps(const Handle *h, int64_t ndocs, int64_t total_bytes, int word
     LongCaps c{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     if (!words || h->m.kind != KIND_WP || h->m.max_depth < 1 || h->m.lexer_void || (h->variant & 0x40000000) || ndocs <= 0) return c;
     const int k = (h->variant >> 12) & 0xf;
-    const size_t table_n = h->m.wbd_t2.size() > (size_t)LX_T_CLS_MASK + 1 ? h->m.wbd_t2.size() - ((size_t)LX_T_CLS_MASK + 1) : 0;
-    const int64_t per = table_n > 0 && table_n <= LONG_TABLE_IN_LDS_ENTRIES ? LONG_BYTES_PER_THRESH : LONG_BYTES_PER_THRESH_BIG_TABLE;
-    c.thresh = k ? (8 << k) : (int)std::min<int64_t>(std::max<int64_t>(LONG_THRESH_MIN, total_bytes / per), 1 << 30);
+    c.thresh = k ? (8 << k) : (int)std::min<int64_t>(std::max<int64_t>(LONG_THRESH_MIN, total_bytes / LONG_BYTES_PER_THRESH), 1 << 30);
     c.docs = std::min<int64_t>(ndocs, total_bytes / ((int64_t)c.thresh + 1)) + 1;
     c.chunks = std::min<int64_t>(total_bytes / 64 + 2 * c.docs + 1, (h->variant & 0x10000000) ? 40 : LONG_MAX_CHUNKS);      // (0x10000000: a test knob -- room for 40 chunks only)
     c.list_off = 0;

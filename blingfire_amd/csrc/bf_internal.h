@@ -16,7 +16,7 @@ BF_API int BfLexStats(void *ModelPtr, unsigned long long *out, int n);
  * launch_wp_wave / launch_wp_flat / launch_lex_wp, bf_kernels_sp.hip launch_seg_sp); the ones that select a measurement instance need a build
  * with BF_EXPERIMENTS, else BF_E_UNSUPPORTED (-5) comes back and the setting stays.  The words modes (TextToWords / TextToSentences): bit
  * 0x40000000 = no long-document path (every document walks on one lane), bits 12..15 = k > 0: documents of more than 8 << k characters take it
- * (default: total_bytes / 24,000, or / 4,000 for a lexer whose table does not fit LDS, at least 16), bit 0x20000000 = a test knob: the triple
+ * (default: total_bytes / 24,000, at least 16), bit 0x20000000 = a test knob: the triple
  * buffer holds n / 8 triples instead of n (FALexTools_t.h:337-340), so that tests reach the position at which it fills, bit 0x10000000 = another: room for 40 chunks of long documents only (the ones
  * that do not fit stay on lanes), bit 0x08000000 = a third: the two-level chain of very long documents from 256 characters on instead of 512 K.
  * Returns the previous value. */

@@ -38,12 +38,13 @@ static int g_no_ff = 0;       // bft_set_no_ff(1): run the lexer emulation witho
 
 // class stream of the host emulation, seen through the same 8-element aligned windows as the device's ClsWin: run() never
 // looks past the window that holds position i (nor past the stream, which ends with one unflagged element of padding)
+static unsigned long long g_cls_reads = 0;      // class-stream accesses of the lexer emulation (tools: the work of one start position)
 struct HostCls {
     const uint16_t *cp; int n;
-    uint32_t operator()(int i) const { return cp[i]; }
+    uint32_t operator()(int i) const { ++g_cls_reads; return cp[i]; }
     void prefetch(int) const {}
     bool has(int) const { return true; }
-    int run(int i) const { int k = 0; while (i + k < n && ((i + k) >> 3) == (i >> 3) && (cp[i + k] & LX_C_LOOP)) ++k; return k; }
+    int run(int i) const { ++g_cls_reads; int k = 0; while (i + k < n && ((i + k) >> 3) == (i >> 3) && (cp[i + k] & LX_C_LOOP)) ++k; return k; }
 };
 
 #include "../../blingfire_amd/csrc/bf_tolower.h"
@@ -720,8 +721,11 @@ int bft_emu_lex_starts(void *hv, const char *s, int n, int mode, int32_t *out, i
     const bool any = L.cls_any != LX_CLS_NONE;
     for (int p = -1; p < len && p + 1 < max_pos; ++p) {
         IdOutFirst o;
-        const LexStart r = any ? lex_one_start<true>(L, cls_at, len, p, o, frames, tab, mode, len) : lex_one_start<false>(L, cls_at, len, p, o, frames, tab, mode, len);
+        const unsigned long long reads0 = g_cls_reads;
+        const int md = mode & 0xff;
+        const LexStart r = any ? lex_one_start<true>(L, cls_at, len, p, o, frames, tab, md, len) : lex_one_start<false>(L, cls_at, len, p, o, frames, tab, md, len);
         int32_t *q = out + 4 * (size_t)(p + 1);
+        if (mode & 0x100) { q[0] = r.next; q[1] = r.n_out; q[2] = r.n_emit; q[3] = (int32_t)(g_cls_reads - reads0); continue; }      // (the position's class-stream accesses instead of the span)
         q[0] = r.next; q[1] = r.n_out; q[2] = r.n_emit; q[3] = r.n_out > 0 ? (int32_t)(((unsigned)(o.from0 - p) << 16) | (unsigned)((o.to0 - p) & 0xffff)) : 0;
     }
     return len;

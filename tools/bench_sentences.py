@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """TextToSentencesBatchDevice (built-in sbd.bin) on text resident in HBM: one long document against the same bytes as short documents.
-usage: bench_sentences.py [bytes of the long document] [variant] [case 0..2]: a variant (BfSetVariant: 0x40000000 = no long-document path, k << 12 = documents of
+usage: bench_sentences.py [bytes of the long document] [variant] [case 0..2, -1 = all] [noruns]: a variant (BfSetVariant: 0x40000000 = no long-document path, k << 12 = documents of
 more than 8 << k characters take it) runs models/sbd.bin as a loaded model instead of the built-in one"""
 import ctypes, os, sys
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "tests"))
@@ -8,6 +8,8 @@ import numpy as np, torch, bfutil, blingfire_amd as bf
 nbytes = int(sys.argv[1]) if len(sys.argv) > 1 else 1 << 20
 text, off = bfutil.gen_workload("config1", 10000)
 raw = text.tobytes(); lines = [raw[off[d]:off[d + 1]] for d in range(10000)]
+if len(sys.argv) > 4 and sys.argv[4] == "noruns":      # without the lines that hold a run of ten spaces (one start position of such a line costs sbd.bin 6,440 sequential steps)
+    lines = [l for l in lines if b" " * 10 not in l]; print("(%d lines without a run of ten spaces)" % len(lines))
 big = (b". ".join(lines * (nbytes // len(raw) + 1)))[:nbytes]
 L = bf.lib(); s = torch.cuda.current_stream().cuda_stream
 variant = int(sys.argv[2], 0) if len(sys.argv) > 2 else None
